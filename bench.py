@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the block-encode hot path (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): BC7 UNORM,
+Texture::Quality::Normal ("quality"), one 4096x4096 RGBA8 synthetic photographic
+tile per GPU, resident in HBM when the timed region starts.  A "step" = one pass of
+the hot path (cfhip_encode_device) over that tile.  Multi-GPU: independent tiles,
+one process per GPU, no data-path collective (blocks/surfaces are independent:
+weak scaling); torch.distributed (RCCL) is used only for the barriers and the
+max-over-ranks of the elapsed time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM
+(8 TB/s, /opt/skills/guides/MI355X_MICROARCH.md): algorithmic bytes = 5 B/px
+(read RGBA8 once + write 1 B/px payload once) x 16 777 216 px per launch, divided by
+the kernel's average duration from hipEvents recorded on the launch stream.
+`cpu_baseline` times the CPU oracle ("port": our from-spec encoder at the same
+search settings, NOT bc7enc_rdo -- its sources are absent) on a bounded strip of
+the same tile on this box's host cores (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SIZE = 4096
+FORMAT_NAME = "BC7"
+QUALITY_NAME = "Normal"
+HBM_PEAK_GBPS = 8000.0
+ALGO_BYTES_PER_PIXEL = 5.0   # 4 B RGBA8 read + 16 B / 16 px payload write
+
+
+def cpu_baseline(img, gpu_payload, width, budget_s=15.0):
+    """Time the CPU oracle on a strip of the tile (about budget_s of host work) and check
+    the GPU payload of the same strip against it.  This is the only place bench.py touches
+    oracle/ (test infrastructure)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as O
+    from cuttlefish_amd import Format, synth
+
+    cores = os.cpu_count() or 1
+    fmt = int(Format.BC7)
+    # calibrate on 2 block rows, then size the sample
+    t0 = time.perf_counter()
+    O.encode(img[:8], fmt, quality=2, threads=cores)
+    dt = max(time.perf_counter() - t0, 1e-3)
+    rows = int(min(SIZE // 4, max(2, budget_s / (dt / 2))))
+    y0 = (SIZE // 2) - (rows * 4) // 2          # centred: includes the alpha band
+    y0 -= y0 % 4
+    strip = img[y0:y0 + rows * 4]
+    t0 = time.perf_counter()
+    ref = O.encode(strip, fmt, quality=2, threads=cores)
+    dt = time.perf_counter() - t0
+    mpix = strip.shape[0] * strip.shape[1] / 1e6
+    bw = width // 4
+    got = gpu_payload.reshape(-1, bw * 16)[y0 // 4:y0 // 4 + rows].reshape(-1)
+    dec_cpu = O.decode(ref, fmt, width, rows * 4)
+    dec_gpu = O.decode(got, fmt, width, rows * 4)
+    return {
+        "value": round(mpix / dt, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+        "sample": "rows %d..%d of the same 4096x4096 tile (%d blocks, %.1f s)" %
+                  (y0, y0 + rows * 4, rows * bw, dt),
+        "psnr_y_cpu": round(synth.psnr_y(strip, dec_cpu), 3),
+        "psnr_y_gpu": round(synth.psnr_y(strip, dec_gpu), 3),
+        "psnr_rgba_gpu": round(synth.psnr(strip, dec_gpu), 3),
+        "gpu_payload_equals_cpu": bool(np.array_equal(ref, got)),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--quality", type=int, default=2)
+    ap.add_argument("--size", type=int, default=SIZE)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from cuttlefish_amd import Context, Format, PixelType, Type, make_params, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    size = args.size
+    # every rank encodes its own tile (independent surfaces; weak scaling)
+    img = synth.photo(size, size, seed=1 + rank)
+    src = torch.from_numpy(img).cuda()
+    out = torch.empty((size // 4) * (size // 4) * 16, dtype=torch.uint8, device="cuda")
+    params = make_params(Format.BC7, Type.UNorm, args.quality)
+    surf = [{"pixels": src.data_ptr(), "pixel_type": PixelType.RGBA8, "width": size,
+             "height": size, "row_pitch_bytes": size * 4, "out": out.data_ptr(),
+             "out_capacity": out.numel()}]
+    ctx = Context(local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        ctx.encode_device(surf, params, stream)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ctx.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.encode_device(surf, params, stream)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = ctx.profile_end()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        pixels_per_step = float(size * size) * world
+        value = pixels_per_step * args.steps / elapsed / 1e6
+        avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
+        algo_bytes = ALGO_BYTES_PER_PIXEL * size * size
+        achieved = algo_bytes / avg_kernel_s / 1e9
+        line = {
+            "metric": "Mpixels/s encode, BC7 4096x4096 RGBA8",
+            "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "BC7 UNORM Texture::Quality::%s, one %dx%d RGBA8 synthetic "
+                                   "photo tile per GPU, resident in HBM" %
+                                   (["Lowest", "Low", "Normal", "High", "Highest"][args.quality],
+                                    size, size),
+                       "format": FORMAT_NAME, "quality": args.quality,
+                       "blocks_per_launch": (size // 4) ** 2, "parallelism": "surface-per-gpu x%d"
+                       % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 8),
+                         "traffic": None, "kernel": ctx.last_kernel_name(),
+                         "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
+                         "algorithmic_bytes_per_launch": int(algo_bytes),
+                         "note": "VALU-bound search; HBM fraction is expected to be tiny "
+                                 "(DESIGN.md roofline section)"},
+        }
+        if world == 1 and not args.no_cpu_baseline and size == SIZE:
+            payload = out.cpu().numpy()
+            line["cpu_baseline"] = cpu_baseline(img, payload, size)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,14 @@
+"""cuttlefish_amd -- MI355X-native block-texture encoder backend for Cuttlefish.
+
+The product is the HIP library (csrc/ -> libcuttlefish_hip.so) behind the C-ABI of
+include/cuttlefish_hip.h.  This package holds the host-side mirror of the
+reference interface for that one path (Texture.convert / Converter) used by the
+parity tests and bench.py; it never falls back to a CPU encoder.
+"""
+from .api import (Alpha, CfhipError, ColorSpace, Context, Format, PixelType, Quality, Type,  # noqa: F401
+                  device_count, load_library, make_params, payload_size, query, shard_rows)
+from .texture import Texture  # noqa: F401
+
+__all__ = ["Alpha", "CfhipError", "ColorSpace", "Context", "Format", "PixelType", "Quality",
+           "Type", "Texture", "device_count", "load_library", "make_params", "payload_size",
+           "query", "shard_rows"]

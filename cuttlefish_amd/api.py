@@ -1,0 +1,282 @@
+"""ctypes binding of the C-ABI in include/cuttlefish_hip.h (libcuttlefish_hip.so).
+
+This is plumbing: the product is the HIP library.  There is no CPU fallback --
+if the library or a HIP device is missing every call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import enum
+import os
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libcuttlefish_hip.so")
+
+
+class Format(enum.IntEnum):
+    """cuttlefish::Texture::Format values (lib/include/cuttlefish/Texture.h:59-130)."""
+    BC1_RGB = 29
+    BC1_RGBA = 30
+    BC2 = 31
+    BC3 = 32
+    BC4 = 33
+    BC5 = 34
+    BC6H = 35
+    BC7 = 36
+
+
+class Type(enum.IntEnum):
+    """cuttlefish::Texture::Type (Texture.h:135-143)."""
+    UNorm = 0
+    SNorm = 1
+    UInt = 2
+    Int = 3
+    UFloat = 4
+    Float = 5
+
+
+class Quality(enum.IntEnum):
+    """cuttlefish::Texture::Quality (Texture.h:181-188)."""
+    Lowest = 0
+    Low = 1
+    Normal = 2
+    High = 3
+    Highest = 4
+
+
+class Alpha(enum.IntEnum):
+    """cuttlefish::Texture::Alpha (Texture.h:161-167)."""
+    None_ = 0
+    Standard = 1
+    PreMultiplied = 2
+    Encoded = 3
+
+
+class ColorSpace(enum.IntEnum):
+    """cuttlefish::ColorSpace (Color.h:40-44)."""
+    Linear = 0
+    sRGB = 1
+
+
+class PixelType(enum.IntEnum):
+    RGBA8 = 0
+    RGBA32F = 1
+    RGBA16F = 2
+
+
+E_INVALID, E_UNSUPPORTED, E_CAPACITY, E_DEVICE, E_NO_DEVICE = -1, -2, -3, -4, -5
+
+EXPORTS = ["cfhip_abi_version", "cfhip_device_count", "cfhip_create", "cfhip_destroy",
+           "cfhip_query", "cfhip_encode", "cfhip_encode_device", "cfhip_shard_rows",
+           "cfhip_last_kernel_ms", "cfhip_last_kernel_name", "cfhip_last_error",
+           "cfhip_profile_begin", "cfhip_profile_end"]
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("format", ctypes.c_int32), ("type", ctypes.c_int32), ("quality", ctypes.c_int32),
+                ("alpha", ctypes.c_int32), ("mask_rgba", ctypes.c_uint8 * 4),
+                ("color_space", ctypes.c_int32)]
+
+
+class Surface(ctypes.Structure):
+    _fields_ = [("pixels", ctypes.c_void_p), ("pixel_type", ctypes.c_int32),
+                ("width", ctypes.c_uint32), ("height", ctypes.c_uint32),
+                ("row_pitch_bytes", ctypes.c_ssize_t), ("out", ctypes.c_void_p),
+                ("out_capacity", ctypes.c_size_t)]
+
+
+class CfhipError(RuntimeError):
+    def __init__(self, code: int, text: str):
+        super().__init__("cfhip error %d: %s" % (code, text))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen libcuttlefish_hip.so.  torch (if importable) is imported first so the
+    process holds ONE HIP runtime (torch bundles libamdhip64.so.7 with the same soname)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the product has no CPU fallback)" % path)
+    try:  # pragma: no cover - depends on environment
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    L.cfhip_abi_version.restype = ctypes.c_int
+    L.cfhip_device_count.restype = ctypes.c_int
+    L.cfhip_create.restype = ctypes.c_void_p
+    L.cfhip_create.argtypes = [ctypes.c_int, ctypes.c_uint, ctypes.POINTER(ctypes.c_int)]
+    L.cfhip_destroy.argtypes = [ctypes.c_void_p]
+    L.cfhip_destroy.restype = None
+    L.cfhip_query.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 3
+    L.cfhip_query.restype = ctypes.c_int
+    L.cfhip_encode.argtypes = [ctypes.c_void_p, ctypes.POINTER(Surface), ctypes.c_size_t,
+                               ctypes.POINTER(Params)]
+    L.cfhip_encode.restype = ctypes.c_int
+    L.cfhip_encode_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(Surface), ctypes.c_size_t,
+                                      ctypes.POINTER(Params), ctypes.c_void_p]
+    L.cfhip_encode_device.restype = ctypes.c_int
+    L.cfhip_shard_rows.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_int,
+                                   ctypes.POINTER(ctypes.c_uint32),
+                                   ctypes.POINTER(ctypes.c_uint32)]
+    L.cfhip_shard_rows.restype = ctypes.c_int
+    L.cfhip_last_kernel_ms.argtypes = [ctypes.c_void_p]
+    L.cfhip_last_kernel_ms.restype = ctypes.c_float
+    L.cfhip_last_kernel_name.argtypes = [ctypes.c_void_p]
+    L.cfhip_last_kernel_name.restype = ctypes.c_char_p
+    L.cfhip_profile_begin.argtypes = [ctypes.c_void_p]
+    L.cfhip_profile_begin.restype = ctypes.c_int
+    L.cfhip_profile_end.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
+                                    ctypes.POINTER(ctypes.c_uint32)]
+    L.cfhip_profile_end.restype = ctypes.c_int
+    L.cfhip_last_error.argtypes = [ctypes.c_void_p]
+    L.cfhip_last_error.restype = ctypes.c_char_p
+    _lib = L
+    return L
+
+
+def make_params(fmt, typ=Type.UNorm, quality=Quality.Normal, alpha=Alpha.Standard,
+                color_mask: Sequence[bool] = (True, True, True, True),
+                color_space=ColorSpace.Linear) -> Params:
+    p = Params()
+    p.format, p.type, p.quality = int(fmt), int(typ), int(quality)
+    p.alpha, p.color_space = int(alpha), int(color_space)
+    for i in range(4):
+        p.mask_rgba[i] = 1 if color_mask[i] else 0
+    return p
+
+
+def query(fmt, typ=Type.UNorm):
+    """(block_w, block_h, block_bytes) = Texture::blockWidth/Height/Size; raises on the
+    (format, type) pairs createConverter rejects (Converter.cpp:339-412)."""
+    bw, bh, bs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    rc = load_library().cfhip_query(int(fmt), int(typ), bw, bh, bs)
+    if rc != 0:
+        raise CfhipError(rc, "illegal (format, type) = (%r, %r)" % (fmt, typ))
+    return bw.value, bh.value, bs.value
+
+
+def payload_size(fmt, typ, width: int, height: int) -> int:
+    bw, bh, bs = query(fmt, typ)
+    return ((width + bw - 1) // bw) * ((height + bh - 1) // bh) * bs
+
+
+def shard_rows(block_rows: int, rank: int, world: int):
+    a, b = ctypes.c_uint32(), ctypes.c_uint32()
+    rc = load_library().cfhip_shard_rows(block_rows, rank, world, a, b)
+    if rc != 0:
+        raise CfhipError(rc, "bad shard arguments")
+    return a.value, b.value
+
+
+def pixel_type_of(arr: np.ndarray) -> PixelType:
+    if arr.dtype == np.uint8:
+        return PixelType.RGBA8
+    if arr.dtype == np.float32:
+        return PixelType.RGBA32F
+    if arr.dtype == np.float16:
+        return PixelType.RGBA16F
+    raise TypeError("pixel dtype %s not accepted at the boundary" % arr.dtype)
+
+
+class Context:
+    """One encoder context = one GPU (one process per GPU in multi-GPU jobs)."""
+
+    def __init__(self, device_id: int = 0):
+        self._lib = load_library()
+        err = ctypes.c_int(0)
+        self._h = self._lib.cfhip_create(device_id, 0, ctypes.byref(err))
+        if not self._h:
+            raise CfhipError(err.value, self._lib.cfhip_last_error(None).decode())
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cfhip_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise CfhipError(rc, self._lib.cfhip_last_error(self._h).decode())
+
+    def encode(self, images: Iterable[np.ndarray], params: Params):
+        """Host-buffer path (what HipConverter::process calls): list of (h, w, 4) arrays
+        -> list of payload byte arrays."""
+        images = [np.asarray(im) for im in images]
+        surf = (Surface * len(images))()
+        outs = []
+        keep = []
+        for i, im in enumerate(images):
+            if im.ndim != 3 or im.shape[2] != 4:
+                raise ValueError("surface %d: expected (h, w, 4)" % i)
+            if im.strides[2] != im.itemsize or im.strides[1] != 4 * im.itemsize:
+                im = np.ascontiguousarray(im)
+            keep.append(im)
+            h, w = im.shape[:2]
+            out = np.zeros(payload_size(params.format, params.type, w, h), np.uint8)
+            outs.append(out)
+            surf[i].pixels = im.ctypes.data
+            surf[i].pixel_type = int(pixel_type_of(im))
+            surf[i].width, surf[i].height = w, h
+            surf[i].row_pitch_bytes = im.strides[0]
+            surf[i].out = out.ctypes.data
+            surf[i].out_capacity = out.nbytes
+        self._check(self._lib.cfhip_encode(self._h, surf, len(images), ctypes.byref(params)))
+        return outs
+
+    def encode_device(self, surfaces: Sequence[dict], params: Params, stream: int = 0):
+        """Device-buffer path.  surfaces: dicts with pixels (device ptr int), pixel_type,
+        width, height, row_pitch_bytes, out (device ptr int), out_capacity."""
+        surf = (Surface * len(surfaces))()
+        for i, s in enumerate(surfaces):
+            surf[i].pixels = s["pixels"]
+            surf[i].pixel_type = int(s["pixel_type"])
+            surf[i].width, surf[i].height = s["width"], s["height"]
+            surf[i].row_pitch_bytes = s["row_pitch_bytes"]
+            surf[i].out = s["out"]
+            surf[i].out_capacity = s["out_capacity"]
+        self._check(self._lib.cfhip_encode_device(self._h, surf, len(surfaces),
+                                                   ctypes.byref(params),
+                                                   ctypes.c_void_p(stream) if stream else None))
+
+    def last_kernel_ms(self) -> float:
+        return float(self._lib.cfhip_last_kernel_ms(self._h))
+
+    def profile_begin(self):
+        self._check(self._lib.cfhip_profile_begin(self._h))
+
+    def profile_end(self):
+        """-> (summed kernel ms, launches) since profile_begin (hipEvents on the launch stream)."""
+        ms, n = ctypes.c_float(), ctypes.c_uint32()
+        self._check(self._lib.cfhip_profile_end(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def last_kernel_name(self) -> str:
+        return self._lib.cfhip_last_kernel_name(self._h).decode()
+
+
+def device_count() -> int:
+    return int(load_library().cfhip_device_count())

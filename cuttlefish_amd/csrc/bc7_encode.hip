@@ -1,0 +1,787 @@
+// bc7_encode.hip -- BC7 block encoder for gfx950 (MI355X), one wavefront per block.
+//
+// Replaces, behind cfhip_encode(), the per-block call the reference makes in
+// Bc7Converter::compressBlock (lib/src/S3tcConverter.cpp:632-646) into
+// bc7enc_compress_block / ispc::bc7e_compress_blocks(1, ...), with the per-quality
+// budgets of createBc7BlockParams (S3tcConverter.cpp:170-227).
+//
+// Mapping (DESIGN.md "BC7 kernel"):
+//   * workgroup = 4 wave64 = 16 adjacent blocks, tile staged in LDS by coalesced
+//     row loads (cf_device.h); the 16 texels of a block are then wave-uniform
+//     (SGPR operands), so per-lane work carries no texel registers.
+//   * lane = search candidate.  Pass 0: lane 0 = mode 6, lanes 1..4 = mode 5 x
+//     rotation, lanes 5..12 = mode 4 x rotation x index-selector.  Partitioned
+//     passes (modes 1,3,0,2 opaque / 7 alpha): lane = partition id, every lane
+//     runs the full fit (PCA axis -> extremes -> p-bit quantise -> exhaustive
+//     selectors via v_dot4_u32_u8 -> closed-form least-squares refit rounds).
+//   * all error arithmetic is integer; each lane keeps its best (error, id,
+//     endpoints, selectors); a 6-step wave argmin on (error,id) picks the block
+//     and only the winning lane bit-packs 16 B, written out coalesced via LDS.
+//   * no MFMA: branchy integer/float search, VALU-bound (roofline in DESIGN.md).
+//
+// Candidate ids and every float operation order are identical to the CPU oracle
+// (oracle/bc7_encode.c), so the payload is byte-identical to it.
+// Build with -ffp-contract=off: fused ops are written as explicit fmaf().
+#include "cf_device.h"
+
+namespace {
+
+__device__ const uint16_t k_part2[64] = {
+	0xcccc, 0x8888, 0xeeee, 0xecc8, 0xc880, 0xfeec, 0xfec8, 0xec80,
+	0xc800, 0xffec, 0xfe80, 0xe800, 0xffe8, 0xff00, 0xfff0, 0xf000,
+	0xf710, 0x008e, 0x7100, 0x08ce, 0x008c, 0x7310, 0x3100, 0x8cce,
+	0x088c, 0x3110, 0x6666, 0x366c, 0x17e8, 0x0ff0, 0x718e, 0x399c,
+	0xaaaa, 0xf0f0, 0x5a5a, 0x33cc, 0x3c3c, 0x55aa, 0x9696, 0xa55a,
+	0x73ce, 0x13c8, 0x324c, 0x3bdc, 0x6996, 0xc33c, 0x9966, 0x0660,
+	0x0272, 0x04e4, 0x4e40, 0x2720, 0xc936, 0x936c, 0x39c6, 0x639c,
+	0x9336, 0x9cc6, 0x817e, 0xe718, 0xccf0, 0x0fcc, 0x7744, 0xee22
+};
+
+__device__ const uint8_t k_anchor2[64] = {
+	15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,
+	15, 2, 8, 2, 2, 8, 8,15,  2, 8, 2, 2, 8, 8, 2, 2,
+	15,15, 6, 8, 2, 8,15,15,  2, 8, 2, 2, 2,15,15, 6,
+	 6, 2, 6, 8,15,15, 2, 2, 15,15,15,15,15, 2, 2,15
+};
+
+__device__ const uint32_t k_part3[64] = {
+	0xaa685050, 0x6a5a5040, 0x5a5a4200, 0x5450a0a8, 0xa5a50000, 0xa0a05050, 0x5555a0a0, 0x5a5a5050,
+	0xaa550000, 0xaa555500, 0xaaaa5500, 0x90909090, 0x94949494, 0xa4a4a4a4, 0xa9a59450, 0x2a0a4250,
+	0xa5945040, 0x0a425054, 0xa5a5a500, 0x55a0a0a0, 0xa8a85454, 0x6a6a4040, 0xa4a45000, 0x1a1a0500,
+	0x0050a4a4, 0xaaa59090, 0x14696914, 0x69691400, 0xa08585a0, 0xaa821414, 0x50a4a450, 0x6a5a0200,
+	0xa9a58000, 0x5090a0a8, 0xa8a09050, 0x24242424, 0x00aa5500, 0x24924924, 0x24499224, 0x50a50a50,
+	0x500aa550, 0xaaaa4444, 0x66660000, 0xa5a0a5a0, 0x50a050a0, 0x69286928, 0x44aaaa44, 0x66666600,
+	0xaa444444, 0x54a854a8, 0x95809580, 0x96969600, 0xa85454a8, 0x80959580, 0xaa141414, 0x96960000,
+	0xaaaa1414, 0xa05050a0, 0xa0a5a5a0, 0x96000000, 0x40804080, 0xa9a8a9a8, 0xaaaaaa44, 0x2a4a5254
+};
+
+__device__ const uint8_t k_anchor3a[64] = {
+	 3, 3,15,15, 8, 3,15,15,  8, 8, 6, 6, 6, 5, 3, 3,
+	 3, 3, 8,15, 3, 3, 6,10,  5, 8, 8, 6, 8, 5,15,15,
+	 8,15, 3, 5, 6,10, 8,15, 15, 3,15, 5,15,15,15,15,
+	 3,15, 5, 5, 5, 8, 5,10,  5,10, 8,13,15,12, 3, 3
+};
+
+__device__ const uint8_t k_anchor3b[64] = {
+	15, 8, 8, 3,15,15, 3, 8, 15,15,15,15,15,15,15, 8,
+	15, 8,15, 3,15, 8,15, 8,  3,15, 6,10,15,15,10, 8,
+	15, 3,15,10,10, 8, 9,10,  6,15, 8,15, 3, 6, 6, 8,
+	15, 3,15,15,15,15,15,15, 15,15,15,15, 3,15,15, 8
+};
+
+// (2^t - 1)/255, folded at compile time exactly like the oracle's expression
+__device__ const float k_sc[9] = {
+	0.0f/255.0f, 1.0f/255.0f, 3.0f/255.0f, 7.0f/255.0f, 15.0f/255.0f,
+	31.0f/255.0f, 63.0f/255.0f, 127.0f/255.0f, 255.0f/255.0f
+};
+
+struct SubFit {
+	uint32_t e0, e1;   // dequantised endpoints, bytes r,g,b,a
+	uint32_t q0, q1;   // quantised fields, bytes r,g,b,a
+	uint32_t pb;       // bit0: p-bit of endpoint 0, bit1: endpoint 1
+	uint32_t err;
+	uint32_t w[4];     // interpolation weight per pixel (bytes), 0 outside the subset
+};
+
+struct Cand {
+	uint32_t err, id;
+	uint32_t q[6];     // q[2s+e]
+	uint32_t pb;       // bit 2s+e
+	uint32_t w[4];     // vector-plane weights per pixel
+	uint32_t w2[4];    // scalar-plane weights per pixel (modes 4/5)
+};
+
+__device__ __forceinline__ uint32_t ub(uint32_t v, int c) { return (v >> (8*c)) & 255u; }
+__device__ __forceinline__ float fb(uint32_t v, int c) { return (float)((v >> (8*c)) & 255u); }
+
+__device__ __forceinline__ float clamp255(float x)
+{
+	return x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x);
+}
+
+__device__ __forceinline__ uint32_t dequant(uint32_t v, uint32_t t)
+{
+	return ((v << (8u - t)) | (v >> (2u*t - 8u))) & 255u;
+}
+
+// BC7 interpolation weight k of an ib-bit index: ((k*64 + d/2)/d), d = 2^ib - 1
+__device__ __forceinline__ uint32_t bc7_weight(uint32_t ib, uint32_t k)
+{
+	const uint32_t d = (1u << ib) - 1u;
+	const uint32_t mg = ib == 2u ? 21846u : (ib == 3u ? 9363u : 4370u);
+	return ((k*64u + (d >> 1))*mg) >> 16;
+}
+
+// C: quantise float endpoints.  cb: bits of channels 0..2, ab: bits of channel 3
+// (0 = channel not coded).  pbk: 0 none, 1 per endpoint, 2 shared.
+__device__ __forceinline__ void quantize(const float (&x0)[4], const float (&x1)[4], uint32_t cb,
+	uint32_t ab, uint32_t pbk, const float (&fwt)[4], SubFit& f)
+{
+	if (pbk == 0u) {
+		uint32_t q0 = 0, q1 = 0, e0 = 0, e1 = 0;
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			const uint32_t t = c < 3 ? cb : ab;
+			if (t) {
+				const float sc = k_sc[t];
+				const int qmax = (1 << t) - 1;
+				int a = (int)floorf(x0[c]*sc + 0.5f);
+				int b = (int)floorf(x1[c]*sc + 0.5f);
+				a = a < 0 ? 0 : (a > qmax ? qmax : a);
+				b = b < 0 ? 0 : (b > qmax ? qmax : b);
+				q0 |= (uint32_t)a << (8*c);
+				q1 |= (uint32_t)b << (8*c);
+				e0 |= dequant((uint32_t)a, t) << (8*c);
+				e1 |= dequant((uint32_t)b, t) << (8*c);
+			}
+		}
+		f.q0 = q0; f.q1 = q1; f.e0 = e0; f.e1 = e1; f.pb = 0;
+		return;
+	}
+	// [endpoint][p]
+	uint32_t q[2][2] = {{0, 0}, {0, 0}}, d[2][2] = {{0, 0}, {0, 0}};
+	float er[2][2];
+#pragma unroll
+	for (int e = 0; e < 2; ++e) {
+#pragma unroll
+		for (int p = 0; p < 2; ++p) {
+			float acc = 0.0f;
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const uint32_t bits = c < 3 ? cb : ab;
+				if (bits) {
+					const uint32_t t = bits + 1u;
+					const float xv = e ? x1[c] : x0[c];
+					const float sc = k_sc[t];
+					const float y = xv*sc;
+					const float u = (y - (float)p)*0.5f;
+					int qq = (int)floorf(u + 0.5f);
+					const int qmax = (1 << bits) - 1;
+					qq = qq < 0 ? 0 : (qq > qmax ? qmax : qq);
+					const uint32_t dd = dequant(((uint32_t)qq << 1) | (uint32_t)p, t);
+					const float dx = (float)dd - xv;
+					const float t2 = dx*dx;
+					acc = fmaf(fwt[c], t2, acc);
+					q[e][p] |= (uint32_t)qq << (8*c);
+					d[e][p] |= dd << (8*c);
+				}
+			}
+			er[e][p] = acc;
+		}
+	}
+	uint32_t p0, p1;
+	if (pbk == 1u) {
+		p0 = er[0][1] < er[0][0] ? 1u : 0u;
+		p1 = er[1][1] < er[1][0] ? 1u : 0u;
+	} else {
+		const float s0 = er[0][0] + er[1][0];
+		const float s1 = er[0][1] + er[1][1];
+		p0 = p1 = s1 < s0 ? 1u : 0u;
+	}
+	f.q0 = p0 ? q[0][1] : q[0][0];
+	f.e0 = p0 ? d[0][1] : d[0][0];
+	f.q1 = p1 ? q[1][1] : q[1][0];
+	f.e1 = p1 ? d[1][1] : d[1][0];
+	f.pb = p0 | (p1 << 1);
+}
+
+// D: exhaustive selector assignment over the 2^ib palette entries (integer error).
+// P: texels with non-coded channels zeroed.  keys hold (dist << 7) | weight.
+template <bool UNITW>
+__device__ __forceinline__ void assign(const uint32_t (&P)[16], uint32_t mask, uint32_t ib,
+	const uint32_t (&wt)[4], SubFit& f)
+{
+	uint32_t keys[16];
+#pragma unroll
+	for (int i = 0; i < 16; ++i)
+		keys[i] = 0xFFFFFFFFu;
+	const uint32_t nk = 1u << ib;
+	const uint32_t e00 = ub(f.e0, 0), e01 = ub(f.e0, 1), e02 = ub(f.e0, 2), e03 = ub(f.e0, 3);
+	const uint32_t e10 = ub(f.e1, 0), e11 = ub(f.e1, 1), e12 = ub(f.e1, 2), e13 = ub(f.e1, 3);
+	for (uint32_t k = 0; k < nk; ++k) {
+		const uint32_t w = bc7_weight(ib, k), iw = 64u - w;
+		const uint32_t c0 = (iw*e00 + w*e10 + 32u) >> 6;
+		const uint32_t c1 = (iw*e01 + w*e11 + 32u) >> 6;
+		const uint32_t c2 = (iw*e02 + w*e12 + 32u) >> 6;
+		const uint32_t c3 = (iw*e03 + w*e13 + 32u) >> 6;
+		if (UNITW) {
+			const uint32_t pal = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+			const uint32_t base = (__builtin_amdgcn_udot4(pal, pal, 0u, false) << 7) | w;
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				const uint32_t pp = __builtin_amdgcn_udot4(P[i], P[i], 0u, false);
+				const uint32_t dt = __builtin_amdgcn_udot4(P[i], pal, 0u, false);
+				const uint32_t key = ((pp << 7) + base) - (dt << 8);
+				keys[i] = key < keys[i] ? key : keys[i];
+			}
+		} else {
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				const int d0 = (int)ub(P[i], 0) - (int)c0;
+				const int d1 = (int)ub(P[i], 1) - (int)c1;
+				const int d2 = (int)ub(P[i], 2) - (int)c2;
+				const int d3 = (int)ub(P[i], 3) - (int)c3;
+				const uint32_t dist = wt[0]*(uint32_t)(d0*d0) + wt[1]*(uint32_t)(d1*d1) +
+					wt[2]*(uint32_t)(d2*d2) + wt[3]*(uint32_t)(d3*d3);
+				const uint32_t key = (dist << 7) | w;
+				keys[i] = key < keys[i] ? key : keys[i];
+			}
+		}
+	}
+	uint32_t err = 0;
+	uint32_t wp[4] = {0, 0, 0, 0};
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		const bool m = (mask >> i) & 1u;
+		err += m ? (keys[i] >> 7) : 0u;
+		wp[i >> 2] |= (m ? (keys[i] & 127u) : 0u) << (8*(i & 3));
+	}
+	f.err = err;
+	f.w[0] = wp[0]; f.w[1] = wp[1]; f.w[2] = wp[2]; f.w[3] = wp[3];
+}
+
+// E: closed-form least squares for the endpoints given the selectors of f.
+__device__ __forceinline__ bool lsq(const uint32_t (&P)[16], uint32_t mask, uint32_t ab,
+	const SubFit& f, float (&x0)[4], float (&x1)[4])
+{
+	uint32_t n = 0, S = 0, A = 0, B = 0, C = 0;
+	uint32_t U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		const uint32_t m = (mask >> i) & 1u;
+		const uint32_t wb = (f.w[i >> 2] >> (8*(i & 3))) & 255u;
+		const uint32_t w = m ? wb : 0u;
+		const uint32_t iw = m ? 64u - wb : 0u;
+		n += m;
+		S += w;
+		A += iw*iw;
+		B += iw*w;
+		C += w*w;
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			U[c] += iw*ub(P[i], c);
+			V[c] += w*ub(P[i], c);
+		}
+	}
+	const int det = (int)(n*C) - (int)(S*S);
+	const bool ok = det > 0;
+	const float inv = 1.0f/(64.0f*(float)(ok ? det : 1));
+	const float fA = (float)A, fB = (float)B, fC = (float)C;
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		if (c < 3 || ab) {
+			const float fU = (float)U[c], fV = (float)V[c];
+			const float t0 = fB*fV;
+			const float n0 = fmaf(fC, fU, -t0);
+			const float t1 = fB*fU;
+			const float n1 = fmaf(fA, fV, -t1);
+			x0[c] = clamp255(n0*inv);
+			x1[c] = clamp255(n1*inv);
+		} else {
+			x0[c] = 0.0f;
+			x1[c] = 0.0f;
+		}
+	}
+	return ok;
+}
+
+// Vector fit of the texels selected by mask.  P must have non-coded channels zero
+// (channel 3 when ab == 0).  Mirrors fit_subset() of oracle/bc7_encode.c.
+template <bool UNITW>
+__device__ __forceinline__ void fit_vec(const uint32_t (&P)[16], uint32_t mask, uint32_t cb,
+	uint32_t ab, uint32_t pbk, uint32_t ib, uint32_t iters, const uint32_t (&wt)[4],
+	SubFit& best)
+{
+	// A: integer statistics of the subset
+	uint32_t n = 0, s[4] = {0, 0, 0, 0};
+	uint32_t q00 = 0, q01 = 0, q02 = 0, q03 = 0, q11 = 0, q12 = 0, q13 = 0, q22 = 0, q23 = 0,
+		q33 = 0;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		const uint32_t m = (mask >> i) & 1u;
+		const uint32_t p0 = ub(P[i], 0), p1 = ub(P[i], 1), p2 = ub(P[i], 2), p3 = ub(P[i], 3);
+		n += m;
+		s[0] += m*p0; s[1] += m*p1; s[2] += m*p2; s[3] += m*p3;
+		q00 += m*(p0*p0); q01 += m*(p0*p1); q02 += m*(p0*p2); q03 += m*(p0*p3);
+		q11 += m*(p1*p1); q12 += m*(p1*p2); q13 += m*(p1*p3);
+		q22 += m*(p2*p2); q23 += m*(p2*p3);
+		q33 += m*(p3*p3);
+	}
+	const float C00 = (float)(int)(n*q00 - s[0]*s[0]), C01 = (float)(int)(n*q01 - s[0]*s[1]);
+	const float C02 = (float)(int)(n*q02 - s[0]*s[2]), C03 = (float)(int)(n*q03 - s[0]*s[3]);
+	const float C11 = (float)(int)(n*q11 - s[1]*s[1]), C12 = (float)(int)(n*q12 - s[1]*s[2]);
+	const float C13 = (float)(int)(n*q13 - s[1]*s[3]), C22 = (float)(int)(n*q22 - s[2]*s[2]);
+	const float C23 = (float)(int)(n*q23 - s[2]*s[3]), C33 = (float)(int)(n*q33 - s[3]*s[3]);
+
+	// principal axis: C^4 e_amax
+	float bestd = C00;
+	float v0 = C00, v1 = C01, v2 = C02, v3 = C03;
+	if (C11 > bestd) { bestd = C11; v0 = C01; v1 = C11; v2 = C12; v3 = C13; }
+	if (C22 > bestd) { bestd = C22; v0 = C02; v1 = C12; v2 = C22; v3 = C23; }
+	if (C33 > bestd) { bestd = C33; v0 = C03; v1 = C13; v2 = C23; v3 = C33; }
+#pragma unroll
+	for (int it = 0; it < 3; ++it) {
+		float r0 = C00*v0; r0 = fmaf(C01, v1, r0); r0 = fmaf(C02, v2, r0); r0 = fmaf(C03, v3, r0);
+		float r1 = C01*v0; r1 = fmaf(C11, v1, r1); r1 = fmaf(C12, v2, r1); r1 = fmaf(C13, v3, r1);
+		float r2 = C02*v0; r2 = fmaf(C12, v1, r2); r2 = fmaf(C22, v2, r2); r2 = fmaf(C23, v3, r2);
+		float r3 = C03*v0; r3 = fmaf(C13, v1, r3); r3 = fmaf(C23, v2, r3); r3 = fmaf(C33, v3, r3);
+		v0 = r0; v1 = r1; v2 = r2; v3 = r3;
+	}
+	const float mx = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
+	float axis[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+	if (mx > 0.0f) {
+		const float im = 1.0f/mx;
+		v0 = v0*im; v1 = v1*im; v2 = v2*im; v3 = v3*im;
+		float l2 = v0*v0;
+		l2 = fmaf(v1, v1, l2);
+		l2 = fmaf(v2, v2, l2);
+		l2 = fmaf(v3, v3, l2);
+		const float is = 1.0f/sqrtf(l2);
+		axis[0] = v0*is; axis[1] = v1*is; axis[2] = v2*is; axis[3] = v3*is;
+	}
+
+	// B: extremes of the projection on the axis
+	const float in = 1.0f/(float)n;
+	float mean[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c)
+		mean[c] = (float)s[c]*in;
+	float tmin = 3.0e38f, tmax = -3.0e38f;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		const bool m = (mask >> i) & 1u;
+		float t = axis[0]*(fb(P[i], 0) - mean[0]);
+		t = fmaf(axis[1], fb(P[i], 1) - mean[1], t);
+		t = fmaf(axis[2], fb(P[i], 2) - mean[2], t);
+		t = fmaf(axis[3], fb(P[i], 3) - mean[3], t);
+		tmin = m ? fminf(tmin, t) : tmin;
+		tmax = m ? fmaxf(tmax, t) : tmax;
+	}
+	float x0[4], x1[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		x0[c] = clamp255(fmaf(axis[c], tmin, mean[c]));
+		x1[c] = clamp255(fmaf(axis[c], tmax, mean[c]));
+	}
+
+	float fwt[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c)
+		fwt[c] = (float)wt[c];
+
+	// C/D then E rounds, always restarting from the best
+	quantize(x0, x1, cb, ab, pbk, fwt, best);
+	assign<UNITW>(P, mask, ib, wt, best);
+	for (uint32_t r = 0; r < iters; ++r) {
+		SubFit cur;
+		const bool ok = lsq(P, mask, ab, best, x0, x1);
+		quantize(x0, x1, cb, ab, pbk, fwt, cur);
+		assign<UNITW>(P, mask, ib, wt, cur);
+		if (ok && cur.err < best.err)
+			best = cur;
+	}
+}
+
+// Scalar fit of channel 3 of P over all 16 texels (alpha plane of modes 4/5).
+template <bool UNITW>
+__device__ __forceinline__ void fit_scalar(const uint32_t (&P)[16], uint32_t ab, uint32_t ib,
+	uint32_t iters, const uint32_t (&wt)[4], SubFit& best)
+{
+	uint32_t A3[16];
+	uint32_t lo = 255u, hi = 0u;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		A3[i] = P[i] & 0xFF000000u;
+		const uint32_t a = P[i] >> 24;
+		lo = a < lo ? a : lo;
+		hi = a > hi ? a : hi;
+	}
+	float x0[4] = {0.0f, 0.0f, 0.0f, (float)lo}, x1[4] = {0.0f, 0.0f, 0.0f, (float)hi};
+	float fwt[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c)
+		fwt[c] = (float)wt[c];
+	const uint32_t swt[4] = {0u, 0u, 0u, wt[3]};
+	quantize(x0, x1, 0u, ab, 0u, fwt, best);
+	assign<UNITW>(A3, 0xFFFFu, ib, swt, best);
+	for (uint32_t r = 0; r < iters; ++r) {
+		SubFit cur;
+		const bool ok = lsq(A3, 0xFFFFu, ab, best, x0, x1);
+		x0[0] = x0[1] = x0[2] = 0.0f;
+		x1[0] = x1[1] = x1[2] = 0.0f;
+		quantize(x0, x1, 0u, ab, 0u, fwt, cur);
+		assign<UNITW>(A3, 0xFFFFu, ib, swt, cur);
+		if (ok && cur.err < best.err)
+			best = cur;
+	}
+}
+
+__device__ __forceinline__ void cand_take(Cand& best, const Cand& c, bool take)
+{
+	if (take)
+		best = c;
+}
+
+struct BitWriter {
+	unsigned long long lo, hi;
+	uint32_t pos;
+	__device__ __forceinline__ void put(uint32_t v, uint32_t n)
+	{
+		if (n == 0u)
+			return;
+		const unsigned long long vv = (unsigned long long)(v & ((1u << n) - 1u));
+		if (pos < 64u) {
+			lo |= vv << pos;
+			if (pos + n > 64u)
+				hi |= vv >> (64u - pos);
+		} else
+			hi |= vv << (pos - 64u);
+		pos += n;
+	}
+};
+
+__device__ __forceinline__ uint32_t w2i(uint32_t w, uint32_t ib)
+{
+	return (w*((1u << ib) - 1u) + 32u) >> 6;
+}
+
+// Bit-pack the winning candidate (mirrors pack() of the oracle).
+__device__ __forceinline__ uint4 pack_block(const Cand& c)
+{
+	uint32_t mode, part = 0, rot = 0, isel = 0;
+	const uint32_t id = c.id;
+	if (id == 0u) mode = 6;
+	else if (id < 5u) { mode = 5; rot = id - 1u; }
+	else if (id < 13u) { mode = 4; rot = (id - 5u) & 3u; isel = (id - 5u) >> 2; }
+	else if (id < 128u) { mode = 1; part = id - 64u; }
+	else if (id < 192u) { mode = 3; part = id - 128u; }
+	else if (id < 256u) { mode = 0; part = id - 192u; }
+	else if (id < 320u) { mode = 2; part = id - 256u; }
+	else { mode = 7; part = id - 320u; }
+	// field widths: ns, pb, rb, isb, cb, ab, pbits, ib, ib2 packed as nibbles
+	//                       mode: 0          1          2          3          4          5          6          7
+	const uint32_t tab_ns[8]  = {3, 2, 3, 2, 1, 1, 1, 2};
+	const uint32_t tab_pb[8]  = {4, 6, 6, 6, 0, 0, 0, 6};
+	const uint32_t tab_cb[8]  = {4, 6, 5, 7, 5, 7, 7, 5};
+	const uint32_t tab_ab[8]  = {0, 0, 0, 0, 6, 8, 7, 5};
+	const uint32_t tab_pk[8]  = {1, 2, 0, 1, 0, 0, 1, 1};
+	const uint32_t tab_ib[8]  = {3, 3, 2, 2, 2, 2, 4, 2};
+	const uint32_t tab_ib2[8] = {0, 0, 0, 0, 3, 2, 0, 0};
+	uint32_t ns = 0, pbn = 0, cb = 0, ab = 0, pk = 0, ib = 0, ib2 = 0;
+#pragma unroll
+	for (int m = 0; m < 8; ++m) {
+		if (mode == (uint32_t)m) {
+			ns = tab_ns[m]; pbn = tab_pb[m]; cb = tab_cb[m]; ab = tab_ab[m];
+			pk = tab_pk[m]; ib = tab_ib[m]; ib2 = tab_ib2[m];
+		}
+	}
+	uint32_t ibc = ib, iba = ib2;
+	if (mode == 4u && isel) { ibc = 3u; iba = 2u; }
+
+	const uint32_t p2 = k_part2[part], p3 = k_part3[part];
+	uint32_t a1 = 0, a2 = 0;
+	if (ns == 2u) a1 = k_anchor2[part];
+	else if (ns == 3u) { a1 = k_anchor3a[part]; a2 = k_anchor3b[part]; }
+
+	uint32_t sub[16], idx[16], idx2[16];
+	uint32_t ia0 = 0, ia1 = 0, ia2 = 0;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		sub[i] = ns == 1u ? 0u : (ns == 2u ? ((p2 >> i) & 1u) : ((p3 >> (2*i)) & 3u));
+		const uint32_t wv = (c.w[i >> 2] >> (8*(i & 3))) & 255u;
+		const uint32_t ws = (c.w2[i >> 2] >> (8*(i & 3))) & 255u;
+		idx[i] = w2i(wv, ibc);
+		idx2[i] = iba ? w2i(ws, iba) : 0u;
+		if (i == 0) ia0 = idx[i];
+		if ((uint32_t)i == a1) ia1 = idx[i];
+		if ((uint32_t)i == a2) ia2 = idx[i];
+	}
+	const uint32_t sw0 = ia0 >> (ibc - 1u);
+	const uint32_t sw1 = ns > 1u ? ia1 >> (ibc - 1u) : 0u;
+	const uint32_t sw2 = ns > 2u ? ia2 >> (ibc - 1u) : 0u;
+	const uint32_t maxi = (1u << ibc) - 1u;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		const uint32_t sw = sub[i] == 0u ? sw0 : (sub[i] == 1u ? sw1 : sw2);
+		idx[i] = sw ? maxi - idx[i] : idx[i];
+	}
+	uint32_t q[6], pb[6];
+	q[0] = sw0 ? c.q[1] : c.q[0]; q[1] = sw0 ? c.q[0] : c.q[1];
+	q[2] = sw1 ? c.q[3] : c.q[2]; q[3] = sw1 ? c.q[2] : c.q[3];
+	q[4] = sw2 ? c.q[5] : c.q[4]; q[5] = sw2 ? c.q[4] : c.q[5];
+	pb[0] = (c.pb >> (sw0 ? 1 : 0)) & 1u; pb[1] = (c.pb >> (sw0 ? 0 : 1)) & 1u;
+	pb[2] = (c.pb >> (sw1 ? 3 : 2)) & 1u; pb[3] = (c.pb >> (sw1 ? 2 : 3)) & 1u;
+	pb[4] = (c.pb >> (sw2 ? 5 : 4)) & 1u; pb[5] = (c.pb >> (sw2 ? 4 : 5)) & 1u;
+	if (iba) {
+		// separate scalar plane: own anchor (pixel 0) and endpoint order; its
+		// endpoints travel in byte 3 of w2's fit, stored in q[0]/q[1] byte 3 by caller
+		const uint32_t sws = idx2[0] >> (iba - 1u);
+		const uint32_t s0 = c.q[4] >> 24, s1 = c.q[5] >> 24;   // scalar endpoints parked in q[4],q[5]
+		q[0] = (q[0] & 0x00FFFFFFu) | ((sws ? s1 : s0) << 24);
+		q[1] = (q[1] & 0x00FFFFFFu) | ((sws ? s0 : s1) << 24);
+		const uint32_t maxa = (1u << iba) - 1u;
+#pragma unroll
+		for (int i = 0; i < 16; ++i)
+			idx2[i] = sws ? maxa - idx2[i] : idx2[i];
+	}
+
+	BitWriter bw = {0ull, 0ull, 0u};
+	bw.put(1u << mode, mode + 1u);
+	bw.put(part, pbn);
+	bw.put(rot, (mode == 4u || mode == 5u) ? 2u : 0u);
+	bw.put(isel, mode == 4u ? 1u : 0u);
+	const uint32_t ne = 2u*ns;
+#pragma unroll
+	for (int ch = 0; ch < 3; ++ch) {
+#pragma unroll
+		for (int e = 0; e < 6; ++e)
+			if ((uint32_t)e < ne)
+				bw.put(ub(q[e], ch), cb);
+	}
+	if (ab) {
+#pragma unroll
+		for (int e = 0; e < 6; ++e)
+			if ((uint32_t)e < ne)
+				bw.put(q[e] >> 24, ab);
+	}
+	if (pk == 1u) {
+#pragma unroll
+		for (int e = 0; e < 6; ++e)
+			if ((uint32_t)e < ne)
+				bw.put(pb[e], 1u);
+	} else if (pk == 2u) {
+		bw.put(pb[0], 1u);
+		bw.put(pb[2], 1u);
+	}
+	const bool swapsets = mode == 4u && isel;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		const uint32_t anchor = sub[i] == 0u ? 0u : (sub[i] == 1u ? a1 : a2);
+		const uint32_t nb = ib - ((uint32_t)i == anchor ? 1u : 0u);
+		bw.put(swapsets ? idx2[i] : idx[i], nb);
+	}
+	if (ib2) {
+#pragma unroll
+		for (int i = 0; i < 16; ++i)
+			bw.put(swapsets ? idx[i] : idx2[i], ib2 - (i == 0 ? 1u : 0u));
+	}
+	return make_uint4((uint32_t)bw.lo, (uint32_t)(bw.lo >> 32), (uint32_t)bw.hi,
+		(uint32_t)(bw.hi >> 32));
+}
+
+// Encode one block with the whole wavefront.  P: the 16 texels, wave-uniform.
+template <bool UNITW>
+__device__ __forceinline__ uint4 encode_block(const uint32_t (&Pin)[16], const cf_kparams& kp,
+	uint32_t lane, bool& is_winner)
+{
+	uint32_t P[16];
+	bool has_alpha = false;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		P[i] = (Pin[i] & kp.keep_mask) | kp.set_mask;
+		has_alpha = has_alpha || (P[i] >> 24) != 255u;
+	}
+	const uint32_t quality = kp.quality;
+	const uint32_t iters = quality == 0u ? 0u : (quality == 1u ? 1u : (quality == 2u ? 2u :
+		(quality == 3u ? 3u : 4u)));
+	const uint32_t wt[4] = {kp.wt[0], kp.wt[1], kp.wt[2], kp.wt[3]};
+
+	Cand best;
+	best.err = 0xFFFFFFFFu;
+	best.id = 0x7FFFFFFFu;
+#pragma unroll
+	for (int k = 0; k < 6; ++k) best.q[k] = 0;
+	best.pb = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) { best.w[k] = 0; best.w2[k] = 0; }
+
+	// ---- pass 0: single-subset modes, lane = (mode, rotation, index selector) ----
+	{
+		uint32_t rot = 0, isel = 0, cb = 7, abv = 7, absc = 0, pbk = 1, ibc = 4, iba = 0;
+		bool active = lane == 0u;
+		if (lane >= 1u && lane <= 4u) {
+			rot = lane - 1u; cb = 7; abv = 0; absc = 8; pbk = 0; ibc = 2; iba = 2;
+			active = quality >= 2u || (quality == 1u ? lane == 1u : (lane == 1u && has_alpha));
+		} else if (lane >= 5u && lane <= 12u) {
+			rot = (lane - 5u) & 3u; isel = (lane - 5u) >> 2;
+			cb = 5; abv = 0; absc = 6; pbk = 0;
+			ibc = isel ? 3u : 2u; iba = isel ? 2u : 3u;
+			active = quality >= 2u;
+		}
+		const uint32_t sel = rot == 0u ? 0x03020100u : (rot == 1u ? 0x00020103u :
+			(rot == 2u ? 0x01020300u : 0x02030100u));
+		uint32_t Pl[16], Pv[16];
+		const uint32_t vmask = abv ? 0xFFFFFFFFu : 0x00FFFFFFu;
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			Pl[i] = __builtin_amdgcn_perm(P[i], P[i], sel);
+			Pv[i] = Pl[i] & vmask;
+		}
+		uint32_t wl[4] = {wt[0], wt[1], wt[2], wt[3]};
+		if (!UNITW && rot) {
+			const uint32_t t3 = wl[3];
+			if (rot == 1u) { wl[3] = wl[0]; wl[0] = t3; }
+			else if (rot == 2u) { wl[3] = wl[1]; wl[1] = t3; }
+			else { wl[3] = wl[2]; wl[2] = t3; }
+		}
+		// only the lanes that hold a candidate need to run (wave-level skip of idle work)
+		if (active) {
+			SubFit fv;
+			const uint32_t wv[4] = {wl[0], wl[1], wl[2], abv ? wl[3] : 0u};
+			fit_vec<UNITW>(Pv, 0xFFFFu, cb, abv, pbk, ibc, iters, wv, fv);
+			Cand c;
+			c.err = fv.err;
+			c.id = lane;
+			c.q[0] = fv.q0; c.q[1] = fv.q1; c.q[2] = 0; c.q[3] = 0; c.q[4] = 0; c.q[5] = 0;
+			c.pb = fv.pb;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { c.w[k] = fv.w[k]; c.w2[k] = 0; }
+			if (absc) {
+				SubFit fs;
+				fit_scalar<UNITW>(Pl, absc, iba, iters, wl, fs);
+				c.err += fs.err;
+				c.q[4] = fs.q0 & 0xFF000000u;   // parked for pack_block
+				c.q[5] = fs.q1 & 0xFF000000u;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) c.w2[k] = fs.w[k];
+			}
+			if (c.err < best.err)
+				best = c;
+		}
+	}
+
+	// ---- partitioned passes: lane = partition ----
+	if (quality >= 1u) {
+		uint32_t P3[16];   // opaque modes do not code alpha
+#pragma unroll
+		for (int i = 0; i < 16; ++i)
+			P3[i] = P[i] & 0x00FFFFFFu;
+		// list of modes for this block (uniform), one nibble each
+		uint32_t modes, nmodes;
+		if (has_alpha) {
+			modes = 7u; nmodes = 1u;
+		} else {
+			modes = 1u; nmodes = 1u;
+			if (quality >= 2u) { modes |= 3u << 4; nmodes = 2u; }
+			if (quality >= 3u) { modes |= (0u << 8) | (2u << 12); nmodes = 4u; }
+		}
+		const uint32_t p2 = k_part2[lane], p3 = k_part3[lane];
+		uint32_t m3[3] = {0, 0, 0};
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			const uint32_t sb = (p3 >> (2*i)) & 3u;
+			m3[0] |= (sb == 0u ? 1u : 0u) << i;
+			m3[1] |= (sb == 1u ? 1u : 0u) << i;
+			m3[2] |= (sb == 2u ? 1u : 0u) << i;
+		}
+		for (uint32_t mi = 0; mi < nmodes; ++mi) {
+			const uint32_t mode = (modes >> (4u*mi)) & 15u;
+			uint32_t ns, cb, ab, pbk, ib, npart, idbase;
+			switch (mode) {
+				case 1: ns = 2; cb = 6; ab = 0; pbk = 2; ib = 3; npart = 64; idbase = 64; break;
+				case 3: ns = 2; cb = 7; ab = 0; pbk = 1; ib = 2; npart = 64; idbase = 128; break;
+				case 0: ns = 3; cb = 4; ab = 0; pbk = 1; ib = 3; npart = 16; idbase = 192; break;
+				case 2: ns = 3; cb = 5; ab = 0; pbk = 0; ib = 2; npart = 64; idbase = 256; break;
+				default: ns = 2; cb = 5; ab = 5; pbk = 1; ib = 2; npart = 64; idbase = 320; break;
+			}
+			Cand c;
+			c.err = 0;
+			c.id = idbase + lane;
+#pragma unroll
+			for (int k = 0; k < 6; ++k) c.q[k] = 0;
+			c.pb = 0;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { c.w[k] = 0; c.w2[k] = 0; }
+			const uint32_t wv[4] = {wt[0], wt[1], wt[2], ab ? wt[3] : 0u};
+			for (uint32_t s = 0; s < ns; ++s) {
+				uint32_t mask;
+				if (ns == 2u)
+					mask = s ? p2 : (~p2 & 0xFFFFu);
+				else
+					mask = s == 0u ? m3[0] : (s == 1u ? m3[1] : m3[2]);
+				SubFit f;
+				if (ab)
+					fit_vec<UNITW>(P, mask, cb, ab, pbk, ib, iters, wv, f);
+				else
+					fit_vec<UNITW>(P3, mask, cb, ab, pbk, ib, iters, wv, f);
+				c.err += f.err;
+				if (s == 0u) { c.q[0] = f.q0; c.q[1] = f.q1; c.pb |= f.pb; }
+				else if (s == 1u) { c.q[2] = f.q0; c.q[3] = f.q1; c.pb |= f.pb << 2; }
+				else { c.q[4] = f.q0; c.q[5] = f.q1; c.pb |= f.pb << 4; }
+#pragma unroll
+				for (int k = 0; k < 4; ++k) c.w[k] |= f.w[k];
+			}
+			if (lane < npart && c.err < best.err)
+				best = c;
+		}
+	}
+
+	// ---- wave argmin on (error, id); winner packs ----
+	const unsigned long long key = ((unsigned long long)best.err << 32) | best.id;
+	const unsigned long long kmin = cf_wave_min_u64(key);
+	is_winner = key == kmin;
+	uint4 blk = make_uint4(0, 0, 0, 0);
+	if (is_winner)
+		blk = pack_block(best);
+	return blk;
+}
+
+} // namespace
+
+template <int PIX, bool UNITW>
+__global__ void __launch_bounds__(CF_WG_THREADS)
+cfhip_bc7_encode_kernel(cf_kparams kp)
+{
+	__shared__ uint32_t tile[CF_BLOCKS_PER_WG*16];
+	__shared__ uint4 outb[CF_BLOCKS_PER_WG];
+	const uint32_t bx0 = blockIdx.x*CF_BLOCKS_PER_WG;
+	const uint32_t byy = blockIdx.y;
+	cf_load_tile_rgba8<PIX>(kp, bx0, byy, tile);
+	__syncthreads();
+
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	for (uint32_t j = 0; j < 4u; ++j) {
+		const uint32_t b = wave*4u + j;
+		if (bx0 + b >= kp.bx)
+			break;
+		uint32_t P[16];
+#pragma unroll
+		for (int i = 0; i < 16; ++i)
+			P[i] = cf_rfl(tile[b*16u + i]);
+		bool win;
+		const uint4 blk = encode_block<UNITW>(P, kp, lane, win);
+		if (win)
+			outb[b] = blk;
+	}
+	__syncthreads();
+	// coalesced payload store: 16 blocks x 16 B = 256 B contiguous
+	const uint32_t t = threadIdx.x;
+	if (t < 64u) {
+		const uint32_t b = t >> 2;
+		if (bx0 + b < kp.bx) {
+			const uint32_t* o = reinterpret_cast<const uint32_t*>(outb);
+			uint32_t* dst = reinterpret_cast<uint32_t*>(kp.out +
+				((size_t)byy*kp.bx + bx0)*16u);
+			dst[t] = o[t];
+		}
+	}
+}
+
+extern "C" hipError_t cfhip_launch_bc7(const cf_kparams* kp, int pixel_type, int unit_weights,
+	hipStream_t stream)
+{
+	dim3 grid((kp->bx + CF_BLOCKS_PER_WG - 1)/CF_BLOCKS_PER_WG, kp->by, 1);
+	dim3 block(CF_WG_THREADS, 1, 1);
+	if (pixel_type == 0) {
+		if (unit_weights)
+			hipLaunchKernelGGL((cfhip_bc7_encode_kernel<0, true>), grid, block, 0, stream, *kp);
+		else
+			hipLaunchKernelGGL((cfhip_bc7_encode_kernel<0, false>), grid, block, 0, stream, *kp);
+	} else {
+		if (unit_weights)
+			hipLaunchKernelGGL((cfhip_bc7_encode_kernel<1, true>), grid, block, 0, stream, *kp);
+		else
+			hipLaunchKernelGGL((cfhip_bc7_encode_kernel<1, false>), grid, block, 0, stream, *kp);
+	}
+	return hipGetLastError();
+}

@@ -1,0 +1,122 @@
+"""Deterministic synthetic surfaces for the block-encode path.
+
+There is no dataset and no network: every test/bench input is generated here
+from integer seeds, identically on every machine.
+
+* ``gradient``   -- the reference's own test pattern, lib/test/TextureTest.cpp:53-61
+                    (r = x/(w-1), g = y/(h-1), b = (w-1-x)/(w-1), a = (h-1-y)/(h-1)).
+* ``photo``      -- "photographic" RGBA8 tile: 6 octaves of bilinear value noise on a
+                    shared luminance field + weaker independent chroma fields, hard
+                    edged rectangles/discs (these exercise the partitioned modes),
+                    +-2 LSB grain, alpha = 255 except a 12.5 % band with a smooth
+                    alpha ramp (exercises BC7 modes 4-7).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SEED_BASE = 0xC0FFEE
+
+
+def gradient(width: int, height: int, dtype=np.uint8) -> np.ndarray:
+    """Reference test colour (TextureTest.cpp:53-61) as RGBA8 or RGBA32F."""
+    x = np.arange(width, dtype=np.float64)[None, :]
+    y = np.arange(height, dtype=np.float64)[:, None]
+    wd = max(width - 1, 1)
+    hd = max(height - 1, 1)
+    img = np.empty((height, width, 4), np.float64)
+    img[..., 0] = x / wd
+    img[..., 1] = y / hd
+    img[..., 2] = (width - x - 1) / wd
+    img[..., 3] = (height - y - 1) / hd
+    if dtype == np.uint8:
+        # same quantisation as toColorBlock (S3tcConverter.cpp:97-111) from float32
+        f = img.astype(np.float32)
+        return np.floor(np.clip(f, 0, 1) * np.float32(255) + np.float32(0.5)).astype(np.uint8)
+    return img.astype(np.float32)
+
+
+def _value_noise(rng: np.random.Generator, width: int, height: int, cell: int) -> np.ndarray:
+    gx = width // cell + 2
+    gy = height // cell + 2
+    lat = rng.random((gy, gx))
+    xs = np.arange(width) / cell
+    ys = np.arange(height) / cell
+    x0 = xs.astype(np.int64)
+    y0 = ys.astype(np.int64)
+    fx = (xs - x0)[None, :]
+    fy = (ys - y0)[:, None]
+    a = lat[y0][:, x0]
+    b = lat[y0][:, x0 + 1]
+    c = lat[y0 + 1][:, x0]
+    d = lat[y0 + 1][:, x0 + 1]
+    return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+
+
+def _fbm(rng, width, height, base_cell=256, octaves=6, persistence=0.55):
+    out = np.zeros((height, width))
+    amp = 1.0
+    norm = 0.0
+    cell = base_cell
+    for _ in range(octaves):
+        out += amp * _value_noise(rng, width, height, max(cell, 1))
+        norm += amp
+        amp *= persistence
+        cell = max(cell // 2, 1)
+    return out / norm
+
+
+def photo(width: int, height: int, seed: int = 1, alpha: bool = True) -> np.ndarray:
+    """Photo-like RGBA8 tile, deterministic in (width, height, seed)."""
+    rng = np.random.default_rng(SEED_BASE + seed)
+    lum = _fbm(rng, width, height)
+    img = np.empty((height, width, 4), np.float64)
+    for c in range(3):
+        chroma = _fbm(rng, width, height, base_cell=128, octaves=4)
+        img[..., c] = lum * 0.75 + 0.35 * (chroma - 0.5) + 0.1
+    # hard-edged shapes: 64 per Mpixel
+    nshapes = max(4, (width * height * 64) // (1 << 20))
+    yy, xx = np.mgrid[0:height, 0:width]
+    for i in range(nshapes):
+        cx = int(rng.integers(0, width))
+        cy = int(rng.integers(0, height))
+        rx = int(rng.integers(3, max(4, width // 16)))
+        ry = int(rng.integers(3, max(4, height // 16)))
+        col = rng.random(3)
+        x0, x1 = max(cx - rx, 0), min(cx + rx, width)
+        y0, y1 = max(cy - ry, 0), min(cy + ry, height)
+        if i & 1:
+            img[y0:y1, x0:x1, :3] = col
+        else:
+            sub = ((xx[y0:y1, x0:x1] - cx) / rx) ** 2 + ((yy[y0:y1, x0:x1] - cy) / ry) ** 2 <= 1.0
+            img[y0:y1, x0:x1, :3][sub] = col
+    img[..., 3] = 1.0
+    if alpha:
+        # 12.5 % band with a smooth alpha ramp
+        y0 = height // 2
+        y1 = y0 + max(height // 8, 1)
+        ramp = np.linspace(0.0, 1.0, width)[None, :] * np.ones((y1 - y0, 1))
+        img[y0:y1, :, 3] = ramp * (0.5 + 0.5 * lum[y0:y1])
+    out = np.clip(img, 0, 1) * 255.0
+    grain = rng.integers(-2, 3, size=(height, width, 3))
+    out[..., :3] += grain
+    return np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)
+
+
+def psnr(a: np.ndarray, b: np.ndarray, channels=slice(0, 4)) -> float:
+    d = a[..., channels].astype(np.float64) - b[..., channels].astype(np.float64)
+    mse = float(np.mean(d * d))
+    if mse == 0.0:
+        return 99.0
+    return float(10.0 * np.log10(255.0 * 255.0 / mse))
+
+
+def psnr_y(a: np.ndarray, b: np.ndarray) -> float:
+    """PSNR of Rec.709 luma."""
+    wts = np.array([0.2126, 0.7152, 0.0722])
+    ya = a[..., :3].astype(np.float64) @ wts
+    yb = b[..., :3].astype(np.float64) @ wts
+    mse = float(np.mean((ya - yb) ** 2))
+    if mse == 0.0:
+        return 99.0
+    return float(10.0 * np.log10(255.0 * 255.0 / mse))

@@ -1,0 +1,177 @@
+/*
+ * cuttlefish_hip.h -- C ABI of the MI355X-native block-texture encoder backend.
+ *
+ * This is the drop-in boundary for the ONE hot path of Cuttlefish:
+ *
+ *   Texture::convert            lib/src/Texture.cpp:1536-1561
+ *     -> Converter::convert     lib/src/Converter.cpp:508-593   (per-surface job loop)
+ *       -> createConverter      lib/src/Converter.cpp:32-506    (BC: :339-412)
+ *         -> S3tcConverter::process / compressBlock
+ *                               lib/src/S3tcConverter.cpp:242-255, :263-646
+ *
+ * The reference has no FFI for this path (converters are compiled-in C++
+ * subclasses of cuttlefish::Converter, lib/src/Converter.h:31-76).  The binding a
+ * maintainer adds is a whole-surface Converter subclass (jobsX()==jobsY()==1, the
+ * PvrtcConverter pattern, lib/src/PvrtcConverter.h:37-38) that forwards to
+ * cfhip_encode(); see INTEGRATION.md and integration/cuttlefish/HipConverter.cpp.
+ *
+ * Plain C: pointers, sizes, ints.  No C++/torch types cross this boundary.  All
+ * entry points are thread-safe per context, never throw and never abort; errors
+ * are negative CFHIP_E_* codes with cfhip_last_error() text.  There is NO CPU
+ * fallback inside this library: with no HIP device cfhip_create() fails.
+ */
+#ifndef CUTTLEFISH_HIP_H
+#define CUTTLEFISH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFHIP_ABI_VERSION 1
+
+/* Values mirror cuttlefish::Texture::Format (lib/include/cuttlefish/Texture.h:59-130). */
+enum cfhip_format {
+	CFHIP_FORMAT_BC1_RGB = 29,
+	CFHIP_FORMAT_BC1_RGBA = 30,
+	CFHIP_FORMAT_BC2 = 31,
+	CFHIP_FORMAT_BC3 = 32,
+	CFHIP_FORMAT_BC4 = 33,
+	CFHIP_FORMAT_BC5 = 34,
+	CFHIP_FORMAT_BC6H = 35,
+	CFHIP_FORMAT_BC7 = 36
+};
+
+/* cuttlefish::Texture::Type (Texture.h:135-143) */
+enum cfhip_type {
+	CFHIP_TYPE_UNORM = 0,
+	CFHIP_TYPE_SNORM = 1,
+	CFHIP_TYPE_UINT = 2,
+	CFHIP_TYPE_INT = 3,
+	CFHIP_TYPE_UFLOAT = 4,
+	CFHIP_TYPE_FLOAT = 5
+};
+
+/* cuttlefish::Texture::Quality (Texture.h:181-188) */
+enum cfhip_quality {
+	CFHIP_QUALITY_LOWEST = 0,
+	CFHIP_QUALITY_LOW = 1,
+	CFHIP_QUALITY_NORMAL = 2,
+	CFHIP_QUALITY_HIGH = 3,
+	CFHIP_QUALITY_HIGHEST = 4
+};
+
+/* cuttlefish::Texture::Alpha (Texture.h:161-167) */
+enum cfhip_alpha {
+	CFHIP_ALPHA_NONE = 0,
+	CFHIP_ALPHA_STANDARD = 1,
+	CFHIP_ALPHA_PREMULTIPLIED = 2,
+	CFHIP_ALPHA_ENCODED = 3
+};
+
+/* cuttlefish::ColorSpace (lib/include/cuttlefish/Color.h:40-44) */
+enum cfhip_color_space {
+	CFHIP_COLOR_LINEAR = 0,
+	CFHIP_COLOR_SRGB = 1
+};
+
+/* Source pixel layouts.  RGBA32F is the reference's ColorRGBAf scanline
+ * (Converter.h:52-56 asserts Image::Format::RGBAF); RGBA8 is what toColorBlock
+ * (S3tcConverter.cpp:97-111) produces from it and costs a quarter of the upload. */
+enum cfhip_pixel_type {
+	CFHIP_PIXEL_RGBA8 = 0,
+	CFHIP_PIXEL_RGBA32F = 1,
+	CFHIP_PIXEL_RGBA16F = 2
+};
+
+enum cfhip_error {
+	CFHIP_OK = 0,
+	CFHIP_E_INVALID = -1,      /* bad argument */
+	CFHIP_E_UNSUPPORTED = -2,  /* (format, type) pair createConverter would reject / not built yet */
+	CFHIP_E_CAPACITY = -3,     /* out_capacity too small */
+	CFHIP_E_DEVICE = -4,       /* HIP runtime error (text in cfhip_last_error) */
+	CFHIP_E_NO_DEVICE = -5     /* no usable gfx950 device */
+};
+
+typedef struct cfhip_ctx cfhip_ctx;
+
+/* Conversion parameters = the arguments of Texture::convert (Texture.h:740-742)
+ * plus the image colour space the converters read (S3tcConverter.cpp:233). */
+typedef struct cfhip_params {
+	int32_t format;       /* enum cfhip_format */
+	int32_t type;         /* enum cfhip_type */
+	int32_t quality;      /* enum cfhip_quality */
+	int32_t alpha;        /* enum cfhip_alpha */
+	uint8_t mask_rgba[4]; /* Texture::ColorMask r,g,b,a; non-zero = channel participates */
+	int32_t color_space;  /* enum cfhip_color_space */
+} cfhip_params;
+
+/* One surface = one (mip, depth, face) image of Converter::convert's loop
+ * (Converter.cpp:521-527).  pixels: top-down rows (Image::scanline order,
+ * Image.cpp:340-343), row_pitch_bytes apart.  out receives
+ * ceil(w/bw)*ceil(h/bh)*block_bytes, blocks row-major (S3tcConverter.cpp:239,244).
+ * Partial edge blocks replicate the last row/column (S3tcConverter.cpp:246-252). */
+typedef struct cfhip_surface {
+	const void* pixels;
+	int32_t pixel_type;     /* enum cfhip_pixel_type */
+	uint32_t width, height;
+	ptrdiff_t row_pitch_bytes;
+	void* out;
+	size_t out_capacity;
+} cfhip_surface;
+
+int cfhip_abi_version(void);
+
+/* Number of visible HIP devices (0 if none / runtime unavailable). */
+int cfhip_device_count(void);
+
+/* One context per GPU (one process per GPU in multi-GPU jobs).  NULL on failure;
+ * *err (optional) receives the CFHIP_E_* code. */
+cfhip_ctx* cfhip_create(int device_id, unsigned flags, int* err);
+void cfhip_destroy(cfhip_ctx* ctx);
+
+/* Block geometry of a format = Texture::blockWidth/blockHeight/blockSize
+ * (Texture.cpp:529,611,693-773); CFHIP_E_UNSUPPORTED for illegal (format,type)
+ * pairs exactly where createConverter returns nullptr (Converter.cpp:339-412). */
+int cfhip_query(int format, int type, int* block_w, int* block_h, int* block_bytes);
+
+/* Host-buffer entry point (what HipConverter::process calls): uploads each
+ * surface, encodes on the GPU, downloads the payload.  Blocking. */
+int cfhip_encode(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n_surfaces,
+	const cfhip_params* params);
+
+/* Device-buffer entry point: pixels/out of every surface are device pointers on
+ * ctx's GPU (e.g. produced by a GPU mip generator).  Kernels are enqueued on
+ * `stream` (a hipStream_t, NULL = the context's own stream) and the call returns
+ * without synchronising when stream != NULL. */
+int cfhip_encode_device(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n_surfaces,
+	const cfhip_params* params, void* stream);
+
+/* Block-row sharding of one surface across `world` ranks:
+ * rank r owns block rows [*row_begin, *row_end).  Pure function, no communication. */
+int cfhip_shard_rows(uint32_t block_rows, int rank, int world, uint32_t* row_begin,
+	uint32_t* row_end);
+
+/* Kernel-only time of the most recent cfhip_encode or cfhip_encode_device call on
+ * this context, measured with hipEvents on the launch stream (ms; <0 if none).
+ * Synchronises the stream. */
+float cfhip_last_kernel_ms(cfhip_ctx* ctx);
+
+/* Accumulate kernel timings over several calls: between cfhip_profile_begin and
+ * cfhip_profile_end every launch made through this context is bracketed by
+ * hipEvents on its launch stream.  _end synchronises, returns the summed kernel
+ * time (ms) and the number of launches. */
+int cfhip_profile_begin(cfhip_ctx* ctx);
+int cfhip_profile_end(cfhip_ctx* ctx, float* total_ms, uint32_t* launches);
+
+/* Name of the kernel that dominated the last call (for rocprof cross-reference). */
+const char* cfhip_last_kernel_name(const cfhip_ctx* ctx);
+
+const char* cfhip_last_error(const cfhip_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUTTLEFISH_HIP_H */

@@ -1,0 +1,589 @@
+/*
+ * oracle/bc7_encode.c -- TEST INFRASTRUCTURE (see cf_oracle.h header).
+ *
+ * CPU restatement of the BC7 leg of the reference hot path:
+ *   Bc7Converter::compressBlock        lib/src/S3tcConverter.cpp:632-646
+ *   createBc7BlockParams (budgets)     lib/src/S3tcConverter.cpp:170-227
+ *   bc7e profile selection (ISPC)      lib/src/S3tcConverter.cpp:593-620
+ * The reference forwards each 4x4 RGBA8 block to bc7enc_rdo / bc7e.ispc
+ * (github.com/richgel999/bc7enc_rdo, pinned commit unknown, sources absent --
+ * "parity unpinned").  This file is therefore a from-specification encoder of
+ * the same class (per-subset PCA endpoint fit, p-bit selection, exhaustive
+ * selector assignment, closed-form least-squares endpoint refit, exhaustive
+ * partition / rotation / index-selector enumeration).
+ *
+ * The search is written candidate-by-candidate so that it is the scalar
+ * twin of the one-wavefront-per-block HIP kernel (lane = candidate):
+ *   id   0        mode 6
+ *   id   1..4     mode 5, rotation 0..3
+ *   id   5..12    mode 4, rotation (id-5)&3, index selector (id-5)>>2
+ *   id  64..127   mode 1, partition id-64
+ *   id 128..191   mode 3, partition id-128
+ *   id 192..207   mode 0, partition id-192
+ *   id 256..319   mode 2, partition id-256
+ *   id 320..383   mode 7, partition id-320
+ * The winner is the minimum of (error, id).  All error arithmetic is integer;
+ * the float parts (PCA, projection, quantisation, LSQ) use a fixed operation
+ * order with explicit fmaf() and must be compiled with -ffp-contract=off.
+ */
+#include "cf_oracle.h"
+#include "bc7_tables.h"
+#include <math.h>
+#include <string.h>
+
+typedef struct {
+	int e[2][4];     /* dequantised 8-bit endpoints */
+	int q[2][4];     /* quantised endpoint fields (without p-bit) */
+	int pb[2];
+	uint8_t w[16];   /* interpolation weight chosen per pixel (0..64) */
+	uint32_t err;
+} sfit;
+
+typedef struct {
+	uint32_t err;
+	int id, mode, part, rot, isel, ns;
+	sfit vec[3];     /* per-subset vector fits */
+	sfit sca;        /* scalar (rotated alpha) fit for modes 4/5 */
+} cand;
+
+static const uint8_t* weight_table(int ib)
+{
+	return ib == 2 ? cfo_w2 : ib == 3 ? cfo_w3 : cfo_w4;
+}
+
+static float clamp255(float x)
+{
+	return x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x);
+}
+
+static int dequant(int v, int t)
+{
+	return ((v << (8 - t)) | (v >> (2*t - 8))) & 255;
+}
+
+/* Quantise the float endpoints x[2][4] of the coded channels (bits[c] > 0).
+ * pbk: 0 none, 1 one p-bit per endpoint, 2 one p-bit shared by both. */
+static void quantize_endpoints(float x[2][4], const int bits[4], int pbk, const int wt[4],
+	sfit* f)
+{
+	if (!pbk) {
+		for (int e = 0; e < 2; ++e) {
+			f->pb[e] = 0;
+			for (int c = 0; c < 4; ++c) {
+				if (!bits[c]) {
+					f->q[e][c] = 0;
+					f->e[e][c] = 0;
+					continue;
+				}
+				int t = bits[c];
+				float sc = (float)((1 << t) - 1)/255.0f;
+				int q = (int)floorf(x[e][c]*sc + 0.5f);
+				int qmax = (1 << t) - 1;
+				q = q < 0 ? 0 : (q > qmax ? qmax : q);
+				f->q[e][c] = q;
+				f->e[e][c] = dequant(q, t);
+			}
+		}
+		return;
+	}
+
+	int q[2][2][4], d[2][2][4];  /* [endpoint][p][channel] */
+	float err[2][2];
+	for (int e = 0; e < 2; ++e) {
+		for (int p = 0; p < 2; ++p) {
+			float er = 0.0f;
+			for (int c = 0; c < 4; ++c) {
+				if (!bits[c]) {
+					q[e][p][c] = d[e][p][c] = 0;
+					continue;
+				}
+				int t = bits[c] + 1;
+				float sc = (float)((1 << t) - 1)/255.0f;
+				float y = x[e][c]*sc;
+				float u = (y - (float)p)*0.5f;
+				int qq = (int)floorf(u + 0.5f);
+				int qmax = (1 << bits[c]) - 1;
+				qq = qq < 0 ? 0 : (qq > qmax ? qmax : qq);
+				int dd = dequant((qq << 1) | p, t);
+				float dx = (float)dd - x[e][c];
+				float t2 = dx*dx;
+				er = fmaf((float)wt[c], t2, er);
+				q[e][p][c] = qq;
+				d[e][p][c] = dd;
+			}
+			err[e][p] = er;
+		}
+	}
+	int pe[2];
+	if (pbk == 1) {
+		pe[0] = err[0][1] < err[0][0];
+		pe[1] = err[1][1] < err[1][0];
+	} else {
+		float e0 = err[0][0] + err[1][0];
+		float e1 = err[0][1] + err[1][1];
+		pe[0] = pe[1] = e1 < e0;
+	}
+	for (int e = 0; e < 2; ++e) {
+		f->pb[e] = pe[e];
+		for (int c = 0; c < 4; ++c) {
+			f->q[e][c] = q[e][pe[e]][c];
+			f->e[e][c] = d[e][pe[e]][c];
+		}
+	}
+}
+
+/* exhaustive selector assignment; integer error */
+static void assign(const int px[16][4], const int wt[4], unsigned mask, const int bits[4],
+	int ib, sfit* f)
+{
+	const uint8_t* wtab = weight_table(ib);
+	int n = 1 << ib;
+	uint32_t total = 0;
+	for (int i = 0; i < 16; ++i) {
+		f->w[i] = 0;
+		if (!((mask >> i) & 1))
+			continue;
+		uint32_t best = 0xFFFFFFFFu;
+		for (int k = 0; k < n; ++k) {
+			int w = wtab[k];
+			uint32_t dist = 0;
+			for (int c = 0; c < 4; ++c) {
+				if (!bits[c])
+					continue;
+				int pal = ((64 - w)*f->e[0][c] + w*f->e[1][c] + 32) >> 6;
+				int dd = px[i][c] - pal;
+				dist += (uint32_t)(wt[c]*dd*dd);
+			}
+			uint32_t key = (dist << 7) | (uint32_t)w;
+			if (key < best)
+				best = key;
+		}
+		f->w[i] = (uint8_t)(best & 127);
+		total += best >> 7;
+	}
+	f->err = total;
+}
+
+/* closed-form least squares for the endpoints given the selectors */
+static int lsq(const int px[16][4], unsigned mask, const int bits[4], const sfit* f,
+	float x[2][4])
+{
+	int n = 0, S = 0, A = 0, B = 0, C = 0;
+	int U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
+	for (int i = 0; i < 16; ++i) {
+		if (!((mask >> i) & 1))
+			continue;
+		int w = f->w[i], iw = 64 - w;
+		++n;
+		S += w;
+		A += iw*iw;
+		B += iw*w;
+		C += w*w;
+		for (int c = 0; c < 4; ++c) {
+			U[c] += iw*px[i][c];
+			V[c] += w*px[i][c];
+		}
+	}
+	int det = n*C - S*S;   /* = (A*C - B*B)/4096, exact */
+	if (det <= 0)
+		return 0;
+	float inv = 1.0f/(64.0f*(float)det);
+	float fA = (float)A, fB = (float)B, fC = (float)C;
+	for (int c = 0; c < 4; ++c) {
+		if (!bits[c]) {
+			x[0][c] = x[1][c] = 0.0f;
+			continue;
+		}
+		float fU = (float)U[c], fV = (float)V[c];
+		float t0 = fB*fV;
+		float n0 = fmaf(fC, fU, -t0);
+		float t1 = fB*fU;
+		float n1 = fmaf(fA, fV, -t1);
+		x[0][c] = clamp255(n0*inv);
+		x[1][c] = clamp255(n1*inv);
+	}
+	return 1;
+}
+
+/* Vector fit of the pixels selected by mask over the channels with bits[c] > 0. */
+static void fit_subset(const int px[16][4], const int wt[4], unsigned mask, const int bits[4],
+	int pbk, int ib, int iters, sfit* best)
+{
+	/* A: integer statistics */
+	int n = 0, sum[4] = {0, 0, 0, 0}, sq[4][4];
+	memset(sq, 0, sizeof(sq));
+	for (int i = 0; i < 16; ++i) {
+		if (!((mask >> i) & 1))
+			continue;
+		++n;
+		for (int a = 0; a < 4; ++a) {
+			if (!bits[a])
+				continue;
+			sum[a] += px[i][a];
+			for (int b = a; b < 4; ++b)
+				if (bits[b])
+					sq[a][b] += px[i][a]*px[i][b];
+		}
+	}
+	float Cm[4][4];
+	for (int a = 0; a < 4; ++a)
+		for (int b = a; b < 4; ++b)
+			Cm[a][b] = Cm[b][a] = (float)(n*sq[a][b] - sum[a]*sum[b]);
+
+	/* principal axis: C^4 e_amax, amax = channel of largest variance */
+	int amax = 0;
+	for (int a = 1; a < 4; ++a)
+		if (Cm[a][a] > Cm[amax][amax])
+			amax = a;
+	float v[4];
+	for (int a = 0; a < 4; ++a)
+		v[a] = Cm[amax][a];
+	for (int it = 0; it < 3; ++it) {
+		float r[4];
+		for (int a = 0; a < 4; ++a) {
+			float t = Cm[a][0]*v[0];
+			t = fmaf(Cm[a][1], v[1], t);
+			t = fmaf(Cm[a][2], v[2], t);
+			t = fmaf(Cm[a][3], v[3], t);
+			r[a] = t;
+		}
+		memcpy(v, r, sizeof(v));
+	}
+	float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+	float axis[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+	if (m > 0.0f) {
+		float im = 1.0f/m;
+		for (int a = 0; a < 4; ++a)
+			v[a] = v[a]*im;
+		float l2 = v[0]*v[0];
+		l2 = fmaf(v[1], v[1], l2);
+		l2 = fmaf(v[2], v[2], l2);
+		l2 = fmaf(v[3], v[3], l2);
+		float is = 1.0f/sqrtf(l2);
+		for (int a = 0; a < 4; ++a)
+			axis[a] = v[a]*is;
+	}
+
+	/* B: project, take the extremes along the axis */
+	float mean[4], in = 1.0f/(float)n;
+	for (int a = 0; a < 4; ++a)
+		mean[a] = (float)sum[a]*in;
+	float tmin = 3.0e38f, tmax = -3.0e38f;
+	for (int i = 0; i < 16; ++i) {
+		if (!((mask >> i) & 1))
+			continue;
+		float t = axis[0]*((float)(bits[0] ? px[i][0] : 0) - mean[0]);
+		t = fmaf(axis[1], (float)(bits[1] ? px[i][1] : 0) - mean[1], t);
+		t = fmaf(axis[2], (float)(bits[2] ? px[i][2] : 0) - mean[2], t);
+		t = fmaf(axis[3], (float)(bits[3] ? px[i][3] : 0) - mean[3], t);
+		tmin = fminf(tmin, t);
+		tmax = fmaxf(tmax, t);
+	}
+	float x[2][4];
+	for (int a = 0; a < 4; ++a) {
+		x[0][a] = clamp255(fmaf(axis[a], tmin, mean[a]));
+		x[1][a] = clamp255(fmaf(axis[a], tmax, mean[a]));
+	}
+
+	/* C/D: quantise + assign; E: LSQ rounds, always restarting from the best */
+	quantize_endpoints(x, bits, pbk, wt, best);
+	assign(px, wt, mask, bits, ib, best);
+	for (int r = 0; r < iters; ++r) {
+		sfit cur;
+		if (!lsq(px, mask, bits, best, x))
+			break;
+		quantize_endpoints(x, bits, pbk, wt, &cur);
+		assign(px, wt, mask, bits, ib, &cur);
+		if (cur.err < best->err)
+			*best = cur;
+		else
+			break;   /* same input would give the same output again */
+	}
+}
+
+/* Scalar fit of channel 3 of px over all 16 pixels (modes 4/5 alpha plane). */
+static void fit_scalar(const int px[16][4], const int wt[4], int abits, int ib, int iters,
+	sfit* best)
+{
+	const int bits[4] = {0, 0, 0, abits};
+	int lo = 255, hi = 0;
+	for (int i = 0; i < 16; ++i) {
+		if (px[i][3] < lo) lo = px[i][3];
+		if (px[i][3] > hi) hi = px[i][3];
+	}
+	float x[2][4] = {{0, 0, 0, (float)lo}, {0, 0, 0, (float)hi}};
+	quantize_endpoints(x, bits, 0, wt, best);
+	assign(px, wt, 0xFFFF, bits, ib, best);
+	for (int r = 0; r < iters; ++r) {
+		sfit cur;
+		if (!lsq(px, 0xFFFF, bits, best, x))
+			break;
+		quantize_endpoints(x, bits, 0, wt, &cur);
+		assign(px, wt, 0xFFFF, bits, ib, &cur);
+		if (cur.err < best->err)
+			*best = cur;
+		else
+			break;
+	}
+}
+
+static void eval_candidate(const int px[16][4], const int wt[4], int id, int iters, cand* c)
+{
+	memset(c, 0, sizeof(*c));
+	c->id = id;
+	if (id < 13) {
+		if (id == 0) {
+			const int bits[4] = {7, 7, 7, 7};
+			c->mode = 6;
+			c->ns = 1;
+			fit_subset(px, wt, 0xFFFF, bits, 1, 4, iters, &c->vec[0]);
+			c->err = c->vec[0].err;
+			return;
+		}
+		int rot, isel = 0, cb, ab, ibc, iba;
+		if (id < 5) {
+			c->mode = 5;
+			rot = id - 1;
+			cb = 7; ab = 8; ibc = 2; iba = 2;
+		} else {
+			c->mode = 4;
+			rot = (id - 5) & 3;
+			isel = (id - 5) >> 2;
+			cb = 5; ab = 6;
+			ibc = isel ? 3 : 2;
+			iba = isel ? 2 : 3;
+		}
+		c->ns = 1;
+		c->rot = rot;
+		c->isel = isel;
+		int rp[16][4], rw[4];
+		memcpy(rp, px, sizeof(rp));
+		memcpy(rw, wt, sizeof(rw));
+		if (rot) {
+			for (int i = 0; i < 16; ++i) {
+				int t = rp[i][3];
+				rp[i][3] = rp[i][rot - 1];
+				rp[i][rot - 1] = t;
+			}
+			int t = rw[3];
+			rw[3] = rw[rot - 1];
+			rw[rot - 1] = t;
+		}
+		const int bits[4] = {cb, cb, cb, 0};
+		fit_subset(rp, rw, 0xFFFF, bits, 0, ibc, iters, &c->vec[0]);
+		fit_scalar(rp, rw, ab, iba, iters, &c->sca);
+		c->err = c->vec[0].err + c->sca.err;
+		return;
+	}
+	int mode, part;
+	if (id < 128) { mode = 1; part = id - 64; }
+	else if (id < 192) { mode = 3; part = id - 128; }
+	else if (id < 256) { mode = 0; part = id - 192; }
+	else if (id < 320) { mode = 2; part = id - 256; }
+	else { mode = 7; part = id - 320; }
+	const cfo_bc7_mode* m = &cfo_bc7_modes[mode];
+	c->mode = mode;
+	c->part = part;
+	c->ns = m->ns;
+	const int bits[4] = {m->cb, m->cb, m->cb, m->ab};
+	unsigned masks[3];
+	if (m->ns == 2) {
+		masks[1] = cfo_part2[part];
+		masks[0] = ~masks[1] & 0xFFFFu;
+	} else {
+		masks[0] = masks[1] = masks[2] = 0;
+		for (int i = 0; i < 16; ++i)
+			masks[(cfo_part3[part] >> (2*i)) & 3] |= 1u << i;
+	}
+	c->err = 0;
+	for (int s = 0; s < m->ns; ++s) {
+		fit_subset(px, wt, masks[s], bits, m->pbits, m->ib, iters, &c->vec[s]);
+		c->err += c->vec[s].err;
+	}
+}
+
+/* ---- bit packing ---- */
+typedef struct { uint8_t* p; unsigned pos; } bitwr;
+
+static void put(bitwr* b, unsigned v, unsigned n)
+{
+	for (unsigned i = 0; i < n; ++i, ++b->pos)
+		if ((v >> i) & 1)
+			b->p[b->pos >> 3] |= (uint8_t)(1u << (b->pos & 7));
+}
+
+static int weight_to_index(int w, int ib)
+{
+	return (w*((1 << ib) - 1) + 32) >> 6;
+}
+
+static void pack(const cand* c, uint8_t out[16])
+{
+	const cfo_bc7_mode* m = &cfo_bc7_modes[c->mode];
+	memset(out, 0, 16);
+	bitwr b = {out, 0};
+	put(&b, 1u << c->mode, (unsigned)c->mode + 1);
+	put(&b, (unsigned)c->part, m->pb);
+	put(&b, (unsigned)c->rot, m->rb);
+	put(&b, (unsigned)c->isel, m->isb);
+
+	int q[6][4], pb[6], idx[16], idx2[16];
+	int subset[16], anchor[3] = {0, 0, 0};
+	for (int i = 0; i < 16; ++i) {
+		subset[i] = m->ns == 1 ? 0 : m->ns == 2 ? (cfo_part2[c->part] >> i) & 1 :
+			(int)((cfo_part3[c->part] >> (2*i)) & 3);
+	}
+	if (m->ns == 2)
+		anchor[1] = cfo_anchor2[c->part];
+	else if (m->ns == 3) {
+		anchor[1] = cfo_anchor3a[c->part];
+		anchor[2] = cfo_anchor3b[c->part];
+	}
+
+	int ibc = m->ib, iba = m->ib2;
+	if (c->mode == 4 && c->isel) {
+		ibc = 3;
+		iba = 2;
+	}
+	for (int i = 0; i < 16; ++i) {
+		idx[i] = weight_to_index(c->vec[subset[i]].w[i], ibc);
+		idx2[i] = iba ? weight_to_index(c->sca.w[i], iba) : 0;
+	}
+	for (int s = 0; s < m->ns; ++s) {
+		int swap = idx[anchor[s]] >> (ibc - 1);
+		for (int e = 0; e < 2; ++e) {
+			int se = swap ? 1 - e : e;
+			for (int ch = 0; ch < 3; ++ch)
+				q[2*s + e][ch] = c->vec[s].q[se][ch];
+			q[2*s + e][3] = c->vec[s].q[se][3];
+			pb[2*s + e] = c->vec[s].pb[se];
+		}
+		if (swap)
+			for (int i = 0; i < 16; ++i)
+				if (subset[i] == s)
+					idx[i] = ((1 << ibc) - 1) - idx[i];
+	}
+	if (iba) {
+		/* separate scalar plane: its own anchor (pixel 0) and endpoint order */
+		int swap = idx2[0] >> (iba - 1);
+		q[0][3] = c->sca.q[swap ? 1 : 0][3];
+		q[1][3] = c->sca.q[swap ? 0 : 1][3];
+		if (swap)
+			for (int i = 0; i < 16; ++i)
+				idx2[i] = ((1 << iba) - 1) - idx2[i];
+	}
+
+	int ne = 2*m->ns;
+	for (int ch = 0; ch < 3; ++ch)
+		for (int e = 0; e < ne; ++e)
+			put(&b, (unsigned)q[e][ch], m->cb);
+	if (m->ab)
+		for (int e = 0; e < ne; ++e)
+			put(&b, (unsigned)q[e][3], m->ab);
+	if (m->pbits == 1)
+		for (int e = 0; e < ne; ++e)
+			put(&b, (unsigned)pb[e], 1);
+	else if (m->pbits == 2)
+		for (int s = 0; s < m->ns; ++s)
+			put(&b, (unsigned)pb[2*s], 1);
+
+	/* primary index field has m->ib bits per pixel, secondary m->ib2 */
+	const int* prim = idx;
+	const int* sec = idx2;
+	if (c->mode == 4 && c->isel) {
+		prim = idx2;   /* 2-bit alpha selectors go first */
+		sec = idx;     /* 3-bit colour selectors second */
+	}
+	for (int i = 0; i < 16; ++i) {
+		unsigned nb = m->ib;
+		if (i == anchor[subset[i]])
+			--nb;
+		put(&b, (unsigned)prim[i], nb);
+	}
+	if (m->ib2)
+		for (int i = 0; i < 16; ++i)
+			put(&b, (unsigned)sec[i], (unsigned)m->ib2 - (i == 0 ? 1u : 0u));
+}
+
+/* Search budget per Texture::Quality (S3tcConverter.cpp:170-227 / :600-620). */
+typedef struct { int iters; int m6only; int two; int mode3; int three; int rot; } budget;
+
+static budget quality_budget(int quality)
+{
+	budget b;
+	switch (quality) {
+		case 0: b = (budget){0, 1, 0, 0, 0, 0}; break;
+		case 1: b = (budget){1, 0, 1, 0, 0, 0}; break;
+		case 2: b = (budget){2, 0, 1, 1, 0, 1}; break;
+		case 3: b = (budget){3, 0, 1, 1, 1, 1}; break;
+		default: b = (budget){4, 0, 1, 1, 1, 1}; break;
+	}
+	return b;
+}
+
+void cfo_bc7_weights(const cfo_params* p, int wt[4])
+{
+	/* Linear: 1,1,1,1 (bc7enc_compress_block_params_init_linear_weights).  sRGB
+	 * images ask for perceptual weights (S3tcConverter.cpp:196-199); we use the
+	 * rounded diagonal of bc7enc's YCbCr form, 3:7:1 with alpha 2. */
+	static const int lin[4] = {1, 1, 1, 1}, perc[4] = {3, 7, 1, 2};
+	const int* w = (p->color_space == 1 && p->quality >= 2) ? perc : lin;
+	for (int c = 0; c < 4; ++c)
+		wt[c] = p->mask[c] ? w[c] : 0;   /* colour mask zeroes weights (:217-224) */
+}
+
+void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p)
+{
+	int px[16][4], wt[4];
+	cfo_bc7_weights(p, wt);
+	int has_alpha = 0;
+	for (int i = 0; i < 16; ++i) {
+		for (int c = 0; c < 4; ++c)
+			px[i][c] = wt[c] ? rgba[4*i + c] : (c == 3 ? 255 : 0);
+		if (px[i][3] != 255)
+			has_alpha = 1;
+	}
+	/* masked channels are constant, so any positive weight is harmless */
+	for (int c = 0; c < 4; ++c)
+		if (!wt[c])
+			wt[c] = 1;
+
+	budget b = quality_budget(p->quality);
+	cand best, cur;
+	memset(&best, 0, sizeof(best));
+	best.err = 0xFFFFFFFFu;
+	best.id = 0x7FFFFFFF;
+#define TRY(ID) do { eval_candidate(px, wt, (ID), b.iters, &cur); \
+	if (cur.err < best.err) best = cur; } while (0)
+	TRY(0);
+	if (b.m6only) {
+		if (has_alpha)
+			TRY(1);
+	} else {
+		int nrot = b.rot ? 4 : 1;
+		for (int r = 0; r < nrot; ++r)
+			TRY(1 + r);
+		if (b.rot)
+			for (int k = 0; k < 8; ++k)
+				TRY(5 + k);
+		if (!has_alpha) {
+			if (b.two)
+				for (int k = 0; k < 64; ++k)
+					TRY(64 + k);
+			if (b.mode3)
+				for (int k = 0; k < 64; ++k)
+					TRY(128 + k);
+			if (b.three) {
+				for (int k = 0; k < 16; ++k)
+					TRY(192 + k);
+				for (int k = 0; k < 64; ++k)
+					TRY(256 + k);
+			}
+		} else if (b.two) {
+			for (int k = 0; k < 64; ++k)
+				TRY(320 + k);
+		}
+	}
+#undef TRY
+	pack(&best, out);
+}

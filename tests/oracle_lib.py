@@ -1,0 +1,103 @@
+"""ctypes binding of oracle/libcf_oracle.so -- the CPU oracle (TEST INFRASTRUCTURE).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use this.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "libcf_oracle.so")
+
+PIX_RGBA8, PIX_RGBA32F, PIX_RGBA16F = 0, 1, 2
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("format", ctypes.c_int), ("type", ctypes.c_int), ("quality", ctypes.c_int),
+                ("alpha", ctypes.c_int), ("mask", ctypes.c_uint8 * 4),
+                ("color_space", ctypes.c_int)]
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR)
+            if f.endswith((".c", ".h")) or f == "Makefile"]
+    stale = (not os.path.exists(LIB_PATH) or
+             any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs))
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libcf_oracle.so"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(LIB_PATH)
+        L.cfo_encode.restype = ctypes.c_int
+        L.cfo_encode.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32,
+                                 ctypes.c_ssize_t, ctypes.c_void_p, ctypes.c_size_t,
+                                 ctypes.POINTER(Params), ctypes.c_uint]
+        L.cfo_decode.restype = ctypes.c_int
+        L.cfo_decode.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32,
+                                 ctypes.c_uint32, ctypes.c_void_p]
+        L.cfo_block_info.argtypes = [ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 3
+        _lib = L
+    return _lib
+
+
+def make_params(fmt, typ=0, quality=2, alpha=1, mask=(1, 1, 1, 1), color_space=0) -> Params:
+    p = Params()
+    p.format, p.type, p.quality, p.alpha, p.color_space = int(fmt), int(typ), int(quality), \
+        int(alpha), int(color_space)
+    for i in range(4):
+        p.mask[i] = 1 if mask[i] else 0
+    return p
+
+
+def block_bytes(fmt) -> int:
+    bw, bh, bs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    if lib().cfo_block_info(int(fmt), bw, bh, bs) != 0:
+        raise ValueError("unsupported format %r" % (fmt,))
+    return bs.value
+
+
+def _pixel_type(img: np.ndarray) -> int:
+    if img.dtype == np.uint8:
+        return PIX_RGBA8
+    if img.dtype == np.float32:
+        return PIX_RGBA32F
+    if img.dtype == np.float16:
+        return PIX_RGBA16F
+    raise TypeError(img.dtype)
+
+
+def encode(img: np.ndarray, fmt, typ=0, quality=2, threads=1, **kw) -> np.ndarray:
+    """img: (h, w, 4) uint8 / float32 / float16, C-contiguous rows."""
+    assert img.ndim == 3 and img.shape[2] == 4
+    img = np.ascontiguousarray(img)
+    h, w = img.shape[:2]
+    n = ((w + 3) // 4) * ((h + 3) // 4) * block_bytes(fmt)
+    out = np.zeros(n, np.uint8)
+    p = make_params(fmt, typ, quality, **kw)
+    rc = lib().cfo_encode(img.ctypes.data, _pixel_type(img), w, h, img.strides[0],
+                          out.ctypes.data, out.nbytes, ctypes.byref(p), threads)
+    if rc != 0:
+        raise RuntimeError("cfo_encode failed: %d" % rc)
+    return out
+
+
+def decode(blocks: np.ndarray, fmt, width: int, height: int, typ=0) -> np.ndarray:
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
+    out = np.zeros((height, width, 4), np.uint8)
+    rc = lib().cfo_decode(int(fmt), int(typ), blocks.ctypes.data, width, height, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("cfo_decode failed: %d" % rc)
+    return out

@@ -1,0 +1,76 @@
+"""The C-ABI library loads and exports every symbol include/cuttlefish_hip.h declares.
+No compute calls here (this file runs without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cuttlefish_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cfhip_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    from cuttlefish_amd import api
+    assert _declared_symbols() == sorted(api.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    for name in _declared_symbols():
+        assert hasattr(hip_lib, name), name
+
+
+def test_abi_version_and_query(hip_lib):
+    from cuttlefish_amd import api
+    assert hip_lib.cfhip_abi_version() == 1
+    # Texture::blockSize (Texture.cpp:693-773)
+    assert api.query(api.Format.BC7, api.Type.UNorm) == (4, 4, 16)
+    assert api.query(api.Format.BC1_RGB, api.Type.UNorm) == (4, 4, 8)
+    assert api.query(api.Format.BC4, api.Type.SNorm) == (4, 4, 8)
+    assert api.query(api.Format.BC6H, api.Type.UFloat) == (4, 4, 16)
+    # createConverter returns nullptr for these (Converter.cpp:339-412)
+    for fmt, typ in [(api.Format.BC7, api.Type.SNorm), (api.Format.BC1_RGB, api.Type.Float),
+                     (api.Format.BC6H, api.Type.UNorm), (api.Format.BC4, api.Type.UFloat)]:
+        with pytest.raises(api.CfhipError):
+            api.query(fmt, typ)
+
+
+def test_shard_rows_partition_is_exact(hip_lib):
+    from cuttlefish_amd import api
+    for rows in (1, 7, 1024, 1025):
+        for world in (1, 2, 3, 8):
+            spans = [api.shard_rows(rows, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == rows
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+    with pytest.raises(api.CfhipError):
+        api.shard_rows(8, 2, 2)
+
+
+def test_no_device_fails_loudly(hip_lib):
+    """No CPU fallback: without a HIP device context creation must fail."""
+    from cuttlefish_amd import api
+    if api.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.CfhipError):
+        api.Context(0)
+
+
+def test_texture_convert_rejects_illegal_combinations(hip_lib):
+    """Texture::convert returns false before touching the device for illegal input
+    (Texture.cpp:1539-1543)."""
+    import numpy as np
+    from cuttlefish_amd import ColorSpace, Format, Texture, Type
+    t = Texture(16, 16)
+    assert not t.convert(Format.BC7, Type.UNorm)          # images incomplete
+    assert t.set_image(np.zeros((16, 16, 4), np.float32))
+    assert not t.convert(Format.BC7, Type.SNorm)          # illegal type
+    assert not t.set_image(np.zeros((8, 16, 4), np.float32))
+    s = Texture(16, 16, color_space=ColorSpace.sRGB)
+    assert s.set_image(np.zeros((16, 16, 4), np.float32))
+    assert not s.convert(Format.BC4, Type.UNorm)          # no native sRGB (Texture.cpp:421-465)
