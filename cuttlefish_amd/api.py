@@ -103,7 +103,7 @@ def load_library(path: Optional[str] = None):
     global _lib
     if _lib is not None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("CFHIP_LIB") or LIB_PATH   # CFHIP_LIB: A/B kernel variants
     if not os.path.exists(path):
         raise FileNotFoundError(
             "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "

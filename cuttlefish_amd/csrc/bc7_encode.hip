@@ -81,6 +81,8 @@ struct SubFit {
 	uint32_t pb;       // bit0: p-bit of endpoint 0, bit1: endpoint 1
 	uint32_t err;
 	uint32_t w[4];     // interpolation weight per pixel (bytes), 0 outside the subset
+	float nx0[4], nx1[4];   // least-squares endpoints for these selectors (next round)
+	bool ok;                // least-squares system was solvable
 };
 
 struct Cand {
@@ -185,87 +187,136 @@ __device__ __forceinline__ void quantize(const float (&x0)[4], const float (&x1)
 	f.pb = p0 | (p1 << 1);
 }
 
-// D: exhaustive selector assignment over the 2^ib palette entries (integer error).
-// P: texels with non-coded channels zeroed.  keys hold (dist << 7) | weight.
-template <bool UNITW>
-__device__ __forceinline__ void assign(const uint32_t (&P)[16], uint32_t mask, uint32_t ib,
-	const uint32_t (&wt)[4], SubFit& f)
+// Fetch one texel row (4 texels of the block) from LDS; ROT applies the lane's
+// channel rotation (v_perm_b32), vmask zeroes channels the fit does not code.
+template <bool ROT>
+__device__ __forceinline__ uint32_t texel(uint32_t raw, uint32_t sel, uint32_t vmask)
 {
-	uint32_t keys[16];
-#pragma unroll
-	for (int i = 0; i < 16; ++i)
-		keys[i] = 0xFFFFFFFFu;
+	const uint32_t p = ROT ? __builtin_amdgcn_perm(raw, raw, sel) : raw;
+	return p & vmask;
+}
+
+// Rolled walk over the block's 16 texels in LDS, CF_UNR texels per trip (one
+// ds_read_b128 / b64 / b32 per trip).  Rolled on purpose: the texels are loop
+// invariant across refinement rounds, and a fully unrolled body gets hoisted by
+// LICM into >64 live registers.
+#ifndef CF_UNR
+#define CF_UNR 1
+#endif
+template <typename F>
+__device__ __forceinline__ void for_texels(const uint32_t* tp, F&& f)
+{
+#if CF_UNR == 4
+#pragma unroll 1
+	for (uint32_t r = 0; r < 4u; ++r) {
+		const uint4 row = *reinterpret_cast<const uint4*>(tp + 4u*r);
+		f(row.x, 4u*r); f(row.y, 4u*r + 1u); f(row.z, 4u*r + 2u); f(row.w, 4u*r + 3u);
+	}
+#elif CF_UNR == 2
+#pragma unroll 1
+	for (uint32_t r = 0; r < 8u; ++r) {
+		const uint2 row = *reinterpret_cast<const uint2*>(tp + 2u*r);
+		f(row.x, 2u*r); f(row.y, 2u*r + 1u);
+	}
+#else
+#pragma unroll 1
+	for (uint32_t i = 0; i < 16u; ++i)
+		f(tp[i], i);
+#endif
+}
+
+// D+E fused: exhaustive selector assignment over the 2^ib palette entries of
+// (f.e0, f.e1) with integer error, accumulating in the same texel loop the sums of
+// the closed-form least-squares refit, whose solution is left in f.nx0/nx1.
+// Texel-outer / palette-inner: the palette (<= 16 entries) lives in registers, the
+// texels are re-read from LDS (rolled row loop, one ds_read_b128 per 4 texels).
+template <bool UNITW, bool ROT>
+__device__ __forceinline__ void assign_lsq(const uint32_t* tp, uint32_t sel, uint32_t vmask,
+	uint32_t mask, uint32_t ab, uint32_t ib, const uint32_t (&wt)[4], bool want_lsq, SubFit& f)
+{
 	const uint32_t nk = 1u << ib;
 	const uint32_t e00 = ub(f.e0, 0), e01 = ub(f.e0, 1), e02 = ub(f.e0, 2), e03 = ub(f.e0, 3);
 	const uint32_t e10 = ub(f.e1, 0), e11 = ub(f.e1, 1), e12 = ub(f.e1, 2), e13 = ub(f.e1, 3);
-	for (uint32_t k = 0; k < nk; ++k) {
-		const uint32_t w = bc7_weight(ib, k), iw = 64u - w;
-		const uint32_t c0 = (iw*e00 + w*e10 + 32u) >> 6;
-		const uint32_t c1 = (iw*e01 + w*e11 + 32u) >> 6;
-		const uint32_t c2 = (iw*e02 + w*e12 + 32u) >> 6;
-		const uint32_t c3 = (iw*e03 + w*e13 + 32u) >> 6;
-		if (UNITW) {
-			const uint32_t pal = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-			const uint32_t base = (__builtin_amdgcn_udot4(pal, pal, 0u, false) << 7) | w;
+	uint32_t pal[16];
+	int base[16];
 #pragma unroll
-			for (int i = 0; i < 16; ++i) {
-				const uint32_t pp = __builtin_amdgcn_udot4(P[i], P[i], 0u, false);
-				const uint32_t dt = __builtin_amdgcn_udot4(P[i], pal, 0u, false);
-				const uint32_t key = ((pp << 7) + base) - (dt << 8);
-				keys[i] = key < keys[i] ? key : keys[i];
-			}
-		} else {
-#pragma unroll
-			for (int i = 0; i < 16; ++i) {
-				const int d0 = (int)ub(P[i], 0) - (int)c0;
-				const int d1 = (int)ub(P[i], 1) - (int)c1;
-				const int d2 = (int)ub(P[i], 2) - (int)c2;
-				const int d3 = (int)ub(P[i], 3) - (int)c3;
-				const uint32_t dist = wt[0]*(uint32_t)(d0*d0) + wt[1]*(uint32_t)(d1*d1) +
-					wt[2]*(uint32_t)(d2*d2) + wt[3]*(uint32_t)(d3*d3);
-				const uint32_t key = (dist << 7) | w;
-				keys[i] = key < keys[i] ? key : keys[i];
-			}
+	for (int k = 0; k < 16; ++k) {
+		pal[k] = 0;
+		base[k] = 0;
+		if ((uint32_t)k < nk) {
+			const uint32_t w = bc7_weight(ib, (uint32_t)k), iw = 64u - w;
+			const uint32_t c0 = (iw*e00 + w*e10 + 32u) >> 6;
+			const uint32_t c1 = (iw*e01 + w*e11 + 32u) >> 6;
+			const uint32_t c2 = (iw*e02 + w*e12 + 32u) >> 6;
+			const uint32_t c3 = (iw*e03 + w*e13 + 32u) >> 6;
+			pal[k] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+			base[k] = UNITW ? (int)((__builtin_amdgcn_udot4(pal[k], pal[k], 0u, false) << 7) | w)
+				: (int)w;
 		}
 	}
-	uint32_t err = 0;
-	uint32_t wp[4] = {0, 0, 0, 0};
-#pragma unroll
-	for (int i = 0; i < 16; ++i) {
-		const bool m = (mask >> i) & 1u;
-		err += m ? (keys[i] >> 7) : 0u;
-		wp[i >> 2] |= (m ? (keys[i] & 127u) : 0u) << (8*(i & 3));
-	}
-	f.err = err;
-	f.w[0] = wp[0]; f.w[1] = wp[1]; f.w[2] = wp[2]; f.w[3] = wp[3];
-}
-
-// E: closed-form least squares for the endpoints given the selectors of f.
-__device__ __forceinline__ bool lsq(const uint32_t (&P)[16], uint32_t mask, uint32_t ab,
-	const SubFit& f, float (&x0)[4], float (&x1)[4])
-{
-	uint32_t n = 0, S = 0, A = 0, B = 0, C = 0;
+	uint32_t err = 0, n = 0, S = 0, A = 0, B = 0, C = 0;
 	uint32_t U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
+	uint32_t wp0 = 0, wp1 = 0, wp2 = 0, wp3 = 0;
+	for_texels(tp, [&](uint32_t raw, uint32_t i) {
+		const uint32_t p = texel<ROT>(raw, sel, vmask);
+		const bool m = (mask >> i) & 1u;
+		uint32_t key;
+		if (UNITW) {
+			int bestk = 0x7FFFFFFF;
 #pragma unroll
-	for (int i = 0; i < 16; ++i) {
-		const uint32_t m = (mask >> i) & 1u;
-		const uint32_t wb = (f.w[i >> 2] >> (8*(i & 3))) & 255u;
+			for (int k = 0; k < 16; ++k) {
+				if ((uint32_t)k < nk) {
+					const int dt = (int)__builtin_amdgcn_udot4(p, pal[k], 0u, false);
+					const int v = base[k] - (dt << 8);
+					bestk = v < bestk ? v : bestk;
+				}
+			}
+			key = (uint32_t)bestk + (__builtin_amdgcn_udot4(p, p, 0u, false) << 7);
+		} else {
+			key = 0xFFFFFFFFu;
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+				if ((uint32_t)k < nk) {
+					const int d0 = (int)ub(p, 0) - (int)ub(pal[k], 0);
+					const int d1 = (int)ub(p, 1) - (int)ub(pal[k], 1);
+					const int d2 = (int)ub(p, 2) - (int)ub(pal[k], 2);
+					const int d3 = (int)ub(p, 3) - (int)ub(pal[k], 3);
+					const uint32_t dist = wt[0]*(uint32_t)(d0*d0) + wt[1]*(uint32_t)(d1*d1) +
+						wt[2]*(uint32_t)(d2*d2) + wt[3]*(uint32_t)(d3*d3);
+					const uint32_t v = (dist << 7) | (uint32_t)base[k];
+					key = v < key ? v : key;
+				}
+			}
+		}
+		const uint32_t wb = key & 127u;
+		err += m ? (key >> 7) : 0u;
 		const uint32_t w = m ? wb : 0u;
 		const uint32_t iw = m ? 64u - wb : 0u;
-		n += m;
-		S += w;
-		A += iw*iw;
-		B += iw*w;
-		C += w*w;
+		// 128-bit byte shift register: after 16 texels, texel i sits in byte i
+		wp0 = (wp0 >> 8) | (wp1 << 24);
+		wp1 = (wp1 >> 8) | (wp2 << 24);
+		wp2 = (wp2 >> 8) | (wp3 << 24);
+		wp3 = (wp3 >> 8) | (w << 24);
+		if (want_lsq) {   // uniform: the last round's refit would never be used
+			n += m ? 1u : 0u;
+			S += w;
+			A += iw*iw;
+			B += iw*w;
+			C += w*w;
 #pragma unroll
-		for (int c = 0; c < 4; ++c) {
-			U[c] += iw*ub(P[i], c);
-			V[c] += w*ub(P[i], c);
+			for (int c = 0; c < 4; ++c) {
+				U[c] += iw*ub(p, c);
+				V[c] += w*ub(p, c);
+			}
 		}
-	}
-	const int det = (int)(n*C) - (int)(S*S);
-	const bool ok = det > 0;
-	const float inv = 1.0f/(64.0f*(float)(ok ? det : 1));
+	});
+	f.err = err;
+	f.w[0] = wp0; f.w[1] = wp1; f.w[2] = wp2; f.w[3] = wp3;
+
+	// closed-form least squares given these selectors
+	const int det = (int)(n*C) - (int)(S*S);   // = (A*C - B*B)/4096, exact
+	f.ok = det > 0;
+	const float inv = 1.0f/(64.0f*(float)(det > 0 ? det : 1));
 	const float fA = (float)A, fB = (float)B, fC = (float)C;
 #pragma unroll
 	for (int c = 0; c < 4; ++c) {
@@ -275,38 +326,37 @@ __device__ __forceinline__ bool lsq(const uint32_t (&P)[16], uint32_t mask, uint
 			const float n0 = fmaf(fC, fU, -t0);
 			const float t1 = fB*fU;
 			const float n1 = fmaf(fA, fV, -t1);
-			x0[c] = clamp255(n0*inv);
-			x1[c] = clamp255(n1*inv);
+			f.nx0[c] = clamp255(n0*inv);
+			f.nx1[c] = clamp255(n1*inv);
 		} else {
-			x0[c] = 0.0f;
-			x1[c] = 0.0f;
+			f.nx0[c] = 0.0f;
+			f.nx1[c] = 0.0f;
 		}
 	}
-	return ok;
 }
 
-// Vector fit of the texels selected by mask.  P must have non-coded channels zero
-// (channel 3 when ab == 0).  Mirrors fit_subset() of oracle/bc7_encode.c.
-template <bool UNITW>
-__device__ __forceinline__ void fit_vec(const uint32_t (&P)[16], uint32_t mask, uint32_t cb,
-	uint32_t ab, uint32_t pbk, uint32_t ib, uint32_t iters, const uint32_t (&wt)[4],
-	SubFit& best)
+// Vector fit of the texels selected by mask (channels zeroed by vmask are not
+// coded; ab == 0 <=> channel 3 not coded).  Mirrors fit_subset() of the oracle.
+template <bool UNITW, bool ROT>
+__device__ __forceinline__ void fit_vec(const uint32_t* tp, uint32_t sel, uint32_t vmask,
+	uint32_t mask, uint32_t cb, uint32_t ab, uint32_t pbk, uint32_t ib, uint32_t iters,
+	const uint32_t (&wt)[4], SubFit& best)
 {
 	// A: integer statistics of the subset
 	uint32_t n = 0, s[4] = {0, 0, 0, 0};
 	uint32_t q00 = 0, q01 = 0, q02 = 0, q03 = 0, q11 = 0, q12 = 0, q13 = 0, q22 = 0, q23 = 0,
 		q33 = 0;
-#pragma unroll
-	for (int i = 0; i < 16; ++i) {
+	for_texels(tp, [&](uint32_t raw, uint32_t i) {
+		const uint32_t p = texel<ROT>(raw, sel, vmask);
 		const uint32_t m = (mask >> i) & 1u;
-		const uint32_t p0 = ub(P[i], 0), p1 = ub(P[i], 1), p2 = ub(P[i], 2), p3 = ub(P[i], 3);
+		const uint32_t p0 = m*ub(p, 0), p1 = m*ub(p, 1), p2 = m*ub(p, 2), p3 = m*ub(p, 3);
 		n += m;
-		s[0] += m*p0; s[1] += m*p1; s[2] += m*p2; s[3] += m*p3;
-		q00 += m*(p0*p0); q01 += m*(p0*p1); q02 += m*(p0*p2); q03 += m*(p0*p3);
-		q11 += m*(p1*p1); q12 += m*(p1*p2); q13 += m*(p1*p3);
-		q22 += m*(p2*p2); q23 += m*(p2*p3);
-		q33 += m*(p3*p3);
-	}
+		s[0] += p0; s[1] += p1; s[2] += p2; s[3] += p3;
+		q00 += p0*p0; q01 += p0*p1; q02 += p0*p2; q03 += p0*p3;
+		q11 += p1*p1; q12 += p1*p2; q13 += p1*p3;
+		q22 += p2*p2; q23 += p2*p3;
+		q33 += p3*p3;
+	});
 	const float C00 = (float)(int)(n*q00 - s[0]*s[0]), C01 = (float)(int)(n*q01 - s[0]*s[1]);
 	const float C02 = (float)(int)(n*q02 - s[0]*s[2]), C03 = (float)(int)(n*q03 - s[0]*s[3]);
 	const float C11 = (float)(int)(n*q11 - s[1]*s[1]), C12 = (float)(int)(n*q12 - s[1]*s[2]);
@@ -347,16 +397,16 @@ __device__ __forceinline__ void fit_vec(const uint32_t (&P)[16], uint32_t mask, 
 	for (int c = 0; c < 4; ++c)
 		mean[c] = (float)s[c]*in;
 	float tmin = 3.0e38f, tmax = -3.0e38f;
-#pragma unroll
-	for (int i = 0; i < 16; ++i) {
+	for_texels(tp, [&](uint32_t raw, uint32_t i) {
+		const uint32_t p = texel<ROT>(raw, sel, vmask);
 		const bool m = (mask >> i) & 1u;
-		float t = axis[0]*(fb(P[i], 0) - mean[0]);
-		t = fmaf(axis[1], fb(P[i], 1) - mean[1], t);
-		t = fmaf(axis[2], fb(P[i], 2) - mean[2], t);
-		t = fmaf(axis[3], fb(P[i], 3) - mean[3], t);
+		float t = axis[0]*(fb(p, 0) - mean[0]);
+		t = fmaf(axis[1], fb(p, 1) - mean[1], t);
+		t = fmaf(axis[2], fb(p, 2) - mean[2], t);
+		t = fmaf(axis[3], fb(p, 3) - mean[3], t);
 		tmin = m ? fminf(tmin, t) : tmin;
 		tmax = m ? fmaxf(tmax, t) : tmax;
-	}
+	});
 	float x0[4], x1[4];
 #pragma unroll
 	for (int c = 0; c < 4; ++c) {
@@ -371,31 +421,27 @@ __device__ __forceinline__ void fit_vec(const uint32_t (&P)[16], uint32_t mask, 
 
 	// C/D then E rounds, always restarting from the best
 	quantize(x0, x1, cb, ab, pbk, fwt, best);
-	assign<UNITW>(P, mask, ib, wt, best);
+	assign_lsq<UNITW, ROT>(tp, sel, vmask, mask, ab, ib, wt, iters > 0u, best);
 	for (uint32_t r = 0; r < iters; ++r) {
 		SubFit cur;
-		const bool ok = lsq(P, mask, ab, best, x0, x1);
-		quantize(x0, x1, cb, ab, pbk, fwt, cur);
-		assign<UNITW>(P, mask, ib, wt, cur);
-		if (ok && cur.err < best.err)
+		quantize(best.nx0, best.nx1, cb, ab, pbk, fwt, cur);
+		assign_lsq<UNITW, ROT>(tp, sel, vmask, mask, ab, ib, wt, r + 1u < iters, cur);
+		if (best.ok && cur.err < best.err)
 			best = cur;
 	}
 }
 
-// Scalar fit of channel 3 of P over all 16 texels (alpha plane of modes 4/5).
+// Scalar fit of channel 3 (after rotation) over all 16 texels: alpha plane of modes 4/5.
 template <bool UNITW>
-__device__ __forceinline__ void fit_scalar(const uint32_t (&P)[16], uint32_t ab, uint32_t ib,
-	uint32_t iters, const uint32_t (&wt)[4], SubFit& best)
+__device__ __forceinline__ void fit_scalar(const uint32_t* tp, uint32_t sel, uint32_t ab,
+	uint32_t ib, uint32_t iters, const uint32_t (&wt)[4], SubFit& best)
 {
-	uint32_t A3[16];
 	uint32_t lo = 255u, hi = 0u;
-#pragma unroll
-	for (int i = 0; i < 16; ++i) {
-		A3[i] = P[i] & 0xFF000000u;
-		const uint32_t a = P[i] >> 24;
+	for_texels(tp, [&](uint32_t raw, uint32_t) {
+		const uint32_t a = texel<true>(raw, sel, 0xFF000000u) >> 24;
 		lo = a < lo ? a : lo;
 		hi = a > hi ? a : hi;
-	}
+	});
 	float x0[4] = {0.0f, 0.0f, 0.0f, (float)lo}, x1[4] = {0.0f, 0.0f, 0.0f, (float)hi};
 	float fwt[4];
 #pragma unroll
@@ -403,15 +449,14 @@ __device__ __forceinline__ void fit_scalar(const uint32_t (&P)[16], uint32_t ab,
 		fwt[c] = (float)wt[c];
 	const uint32_t swt[4] = {0u, 0u, 0u, wt[3]};
 	quantize(x0, x1, 0u, ab, 0u, fwt, best);
-	assign<UNITW>(A3, 0xFFFFu, ib, swt, best);
+	assign_lsq<UNITW, true>(tp, sel, 0xFF000000u, 0xFFFFu, ab, ib, swt, iters > 0u, best);
 	for (uint32_t r = 0; r < iters; ++r) {
 		SubFit cur;
-		const bool ok = lsq(A3, 0xFFFFu, ab, best, x0, x1);
-		x0[0] = x0[1] = x0[2] = 0.0f;
-		x1[0] = x1[1] = x1[2] = 0.0f;
-		quantize(x0, x1, 0u, ab, 0u, fwt, cur);
-		assign<UNITW>(A3, 0xFFFFu, ib, swt, cur);
-		if (ok && cur.err < best.err)
+		best.nx0[0] = best.nx0[1] = best.nx0[2] = 0.0f;
+		best.nx1[0] = best.nx1[1] = best.nx1[2] = 0.0f;
+		quantize(best.nx0, best.nx1, 0u, ab, 0u, fwt, cur);
+		assign_lsq<UNITW, true>(tp, sel, 0xFF000000u, 0xFFFFu, ab, ib, swt, r + 1u < iters, cur);
+		if (best.ok && cur.err < best.err)
 			best = cur;
 	}
 }
@@ -569,21 +614,15 @@ __device__ __forceinline__ uint4 pack_block(const Cand& c)
 		(uint32_t)(bw.hi >> 32));
 }
 
-// Encode one block with the whole wavefront.  P: the 16 texels, wave-uniform.
+// Encode one block with the whole wavefront.  tp: the block's 16 texels in LDS
+// (colour mask already applied), identical for every lane.
 template <bool UNITW>
-__device__ __forceinline__ uint4 encode_block(const uint32_t (&Pin)[16], const cf_kparams& kp,
+__device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const cf_kparams& kp,
 	uint32_t lane, bool& is_winner)
 {
-	uint32_t P[16];
-	bool has_alpha = false;
-#pragma unroll
-	for (int i = 0; i < 16; ++i) {
-		P[i] = (Pin[i] & kp.keep_mask) | kp.set_mask;
-		has_alpha = has_alpha || (P[i] >> 24) != 255u;
-	}
+	const bool has_alpha = __ballot(lane < 16u && (tp[lane & 15u] >> 24) != 255u) != 0ull;
 	const uint32_t quality = kp.quality;
-	const uint32_t iters = quality == 0u ? 0u : (quality == 1u ? 1u : (quality == 2u ? 2u :
-		(quality == 3u ? 3u : 4u)));
+	const uint32_t iters = quality < 4u ? quality : 4u;
 	const uint32_t wt[4] = {kp.wt[0], kp.wt[1], kp.wt[2], kp.wt[3]};
 
 	Cand best;
@@ -610,13 +649,7 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t (&Pin)[16], const c
 		}
 		const uint32_t sel = rot == 0u ? 0x03020100u : (rot == 1u ? 0x00020103u :
 			(rot == 2u ? 0x01020300u : 0x02030100u));
-		uint32_t Pl[16], Pv[16];
 		const uint32_t vmask = abv ? 0xFFFFFFFFu : 0x00FFFFFFu;
-#pragma unroll
-		for (int i = 0; i < 16; ++i) {
-			Pl[i] = __builtin_amdgcn_perm(P[i], P[i], sel);
-			Pv[i] = Pl[i] & vmask;
-		}
 		uint32_t wl[4] = {wt[0], wt[1], wt[2], wt[3]};
 		if (!UNITW && rot) {
 			const uint32_t t3 = wl[3];
@@ -624,11 +657,11 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t (&Pin)[16], const c
 			else if (rot == 2u) { wl[3] = wl[1]; wl[1] = t3; }
 			else { wl[3] = wl[2]; wl[2] = t3; }
 		}
-		// only the lanes that hold a candidate need to run (wave-level skip of idle work)
+		// only the lanes that hold a candidate run
 		if (active) {
 			SubFit fv;
 			const uint32_t wv[4] = {wl[0], wl[1], wl[2], abv ? wl[3] : 0u};
-			fit_vec<UNITW>(Pv, 0xFFFFu, cb, abv, pbk, ibc, iters, wv, fv);
+			fit_vec<UNITW, true>(tp, sel, vmask, 0xFFFFu, cb, abv, pbk, ibc, iters, wv, fv);
 			Cand c;
 			c.err = fv.err;
 			c.id = lane;
@@ -638,7 +671,7 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t (&Pin)[16], const c
 			for (int k = 0; k < 4; ++k) { c.w[k] = fv.w[k]; c.w2[k] = 0; }
 			if (absc) {
 				SubFit fs;
-				fit_scalar<UNITW>(Pl, absc, iba, iters, wl, fs);
+				fit_scalar<UNITW>(tp, sel, absc, iba, iters, wl, fs);
 				c.err += fs.err;
 				c.q[4] = fs.q0 & 0xFF000000u;   // parked for pack_block
 				c.q[5] = fs.q1 & 0xFF000000u;
@@ -650,12 +683,12 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t (&Pin)[16], const c
 		}
 	}
 
+	// A zero-error candidate cannot be beaten (ties go to the lowest id), so the
+	// remaining passes may be skipped without changing the payload.
+	bool solved = __ballot(best.err == 0u) != 0ull;
+
 	// ---- partitioned passes: lane = partition ----
-	if (quality >= 1u) {
-		uint32_t P3[16];   // opaque modes do not code alpha
-#pragma unroll
-		for (int i = 0; i < 16; ++i)
-			P3[i] = P[i] & 0x00FFFFFFu;
+	if (quality >= 1u && !solved) {
 		// list of modes for this block (uniform), one nibble each
 		uint32_t modes, nmodes;
 		if (has_alpha) {
@@ -666,15 +699,15 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t (&Pin)[16], const c
 			if (quality >= 3u) { modes |= (0u << 8) | (2u << 12); nmodes = 4u; }
 		}
 		const uint32_t p2 = k_part2[lane], p3 = k_part3[lane];
-		uint32_t m3[3] = {0, 0, 0};
+		uint32_t m30 = 0, m31 = 0, m32 = 0;
 #pragma unroll
 		for (int i = 0; i < 16; ++i) {
 			const uint32_t sb = (p3 >> (2*i)) & 3u;
-			m3[0] |= (sb == 0u ? 1u : 0u) << i;
-			m3[1] |= (sb == 1u ? 1u : 0u) << i;
-			m3[2] |= (sb == 2u ? 1u : 0u) << i;
+			m30 |= (sb == 0u ? 1u : 0u) << i;
+			m31 |= (sb == 1u ? 1u : 0u) << i;
+			m32 |= (sb == 2u ? 1u : 0u) << i;
 		}
-		for (uint32_t mi = 0; mi < nmodes; ++mi) {
+		for (uint32_t mi = 0; mi < nmodes && !solved; ++mi) {
 			const uint32_t mode = (modes >> (4u*mi)) & 15u;
 			uint32_t ns, cb, ab, pbk, ib, npart, idbase;
 			switch (mode) {
@@ -684,6 +717,7 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t (&Pin)[16], const c
 				case 2: ns = 3; cb = 5; ab = 0; pbk = 0; ib = 2; npart = 64; idbase = 256; break;
 				default: ns = 2; cb = 5; ab = 5; pbk = 1; ib = 2; npart = 64; idbase = 320; break;
 			}
+			const uint32_t vmask = ab ? 0xFFFFFFFFu : 0x00FFFFFFu;   // opaque modes do not code alpha
 			Cand c;
 			c.err = 0;
 			c.id = idbase + lane;
@@ -698,12 +732,9 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t (&Pin)[16], const c
 				if (ns == 2u)
 					mask = s ? p2 : (~p2 & 0xFFFFu);
 				else
-					mask = s == 0u ? m3[0] : (s == 1u ? m3[1] : m3[2]);
+					mask = s == 0u ? m30 : (s == 1u ? m31 : m32);
 				SubFit f;
-				if (ab)
-					fit_vec<UNITW>(P, mask, cb, ab, pbk, ib, iters, wv, f);
-				else
-					fit_vec<UNITW>(P3, mask, cb, ab, pbk, ib, iters, wv, f);
+				fit_vec<UNITW, false>(tp, 0u, vmask, mask, cb, ab, pbk, ib, iters, wv, f);
 				c.err += f.err;
 				if (s == 0u) { c.q[0] = f.q0; c.q[1] = f.q1; c.pb |= f.pb; }
 				else if (s == 1u) { c.q[2] = f.q0; c.q[3] = f.q1; c.pb |= f.pb << 2; }
@@ -713,6 +744,7 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t (&Pin)[16], const c
 			}
 			if (lane < npart && c.err < best.err)
 				best = c;
+			solved = __ballot(best.err == 0u) != 0ull;
 		}
 	}
 
@@ -729,10 +761,13 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t (&Pin)[16], const c
 } // namespace
 
 template <int PIX, bool UNITW>
-__global__ void __launch_bounds__(CF_WG_THREADS)
+#ifndef CF_BC7_WAVES
+#define CF_BC7_WAVES 3
+#endif
+__global__ void __launch_bounds__(CF_WG_THREADS) __attribute__((amdgpu_waves_per_eu(CF_BC7_WAVES, CF_BC7_WAVES)))
 cfhip_bc7_encode_kernel(cf_kparams kp)
 {
-	__shared__ uint32_t tile[CF_BLOCKS_PER_WG*16];
+	__shared__ __attribute__((aligned(16))) uint32_t tile[CF_BLOCKS_PER_WG*16];
 	__shared__ uint4 outb[CF_BLOCKS_PER_WG];
 	const uint32_t bx0 = blockIdx.x*CF_BLOCKS_PER_WG;
 	const uint32_t byy = blockIdx.y;
@@ -744,12 +779,8 @@ cfhip_bc7_encode_kernel(cf_kparams kp)
 		const uint32_t b = wave*4u + j;
 		if (bx0 + b >= kp.bx)
 			break;
-		uint32_t P[16];
-#pragma unroll
-		for (int i = 0; i < 16; ++i)
-			P[i] = cf_rfl(tile[b*16u + i]);
 		bool win;
-		const uint4 blk = encode_block<UNITW>(P, kp, lane, win);
+		const uint4 blk = encode_block<UNITW>(tile + b*16u, kp, lane, win);
 		if (win)
 			outb[b] = blk;
 	}

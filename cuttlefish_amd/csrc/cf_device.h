@@ -61,7 +61,8 @@ __device__ __forceinline__ void cf_load_tile_rgba8(const cf_kparams& kp, uint32_
 		px = cf_unorm8(f.x) | (cf_unorm8(f.y) << 8) | (cf_unorm8(f.z) << 16) |
 			(cf_unorm8(f.w) << 24);
 	}
-	tile[(col >> 2)*16u + row*4u + (col & 3u)] = px;
+	// colour mask: masked channels become constant before any search sees them
+	tile[(col >> 2)*16u + row*4u + (col & 3u)] = (px & kp.keep_mask) | kp.set_mask;
 }
 
 // wave64 argmin of a 64-bit key; every lane gets the minimum.
