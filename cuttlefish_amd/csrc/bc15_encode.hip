@@ -1,0 +1,571 @@
+// bc15_encode.hip -- BC1 / BC1A / BC2 / BC3 / BC4 / BC5 block encoders for gfx950,
+// one wavefront per block, lanes = search candidates, all-integer arithmetic.
+//
+// Replaces the per-block calls of lib/src/S3tcConverter.cpp:263-490
+// (Bc1Converter .. Bc5Converter::compressBlock -> rgbcx::encode_bc1/3/4/5[_hq],
+// squish::Compress, Compressonator CompressBlockBC4S/BC5S).  The searches are the
+// ones restated in oracle/bc15_encode.c and produce byte-identical payloads:
+//
+//   colour (BC1 family): lane L = start candidate (bounding-box diagonal inset by
+//     (L&7)/16 and (L>>3)/16), then R rounds where lane m = endpoint move m (27 moves
+//     of endpoint a, 27 of b, 10 joint) around the current best; every candidate is
+//     scored in 4-colour and 3-colour order with exact SSE (v_dot4_u32_u8 against
+//     the decoder's palette); wave argmin on (error, id); uniform early exit when a
+//     round does not improve.
+//   alpha (BC4 family): lanes stride over the (2r+1)^2 x 2 endpoint pairs around
+//     (min, max) / interior (min, max); v_sad_u32 + v_min per palette entry.
+//
+// Texels are staged per workgroup (16 blocks) in LDS by coalesced row loads, the
+// payload leaves through LDS as contiguous 128/256 B rows.  No MFMA (integer search).
+#include "cf_device.h"
+
+namespace {
+
+enum { F_BC1 = 29, F_BC1A = 30, F_BC2 = 31, F_BC3 = 32, F_BC4 = 33, F_BC5 = 34 };
+
+__device__ __forceinline__ uint32_t ub(uint32_t v, int c) { return (v >> (8*c)) & 255u; }
+
+__device__ __forceinline__ int clampi(int x, int lo, int hi)
+{
+	return x < lo ? lo : (x > hi ? hi : x);
+}
+
+// x/3, x/5, x/7, x/255 for the small non-negative ranges used here (verified exhaustively
+// by tests/test_oracle_bc15.py::test_magic_divisions)
+__device__ __forceinline__ uint32_t div3(uint32_t x) { return (x*43691u) >> 17; }     // x < 98304
+__device__ __forceinline__ uint32_t div5(uint32_t x) { return (x*52429u) >> 18; }     // x < 81920
+__device__ __forceinline__ uint32_t div7(uint32_t x) { return (x*74899u) >> 19; }     // x < 43690
+__device__ __forceinline__ uint32_t div255(uint32_t x) { return (x*32897u) >> 23; }   // x < 65536
+
+// ------------------------------------------------------------------ BC4 family
+
+__device__ __forceinline__ void bc4_palette(int a0, int a1, bool mode6, int e0, int (&pal)[8])
+{
+	pal[0] = a0;
+	pal[1] = a1;
+	if (!mode6) {
+#pragma unroll
+		for (int k = 2; k < 8; ++k)
+			pal[k] = (int)div7((uint32_t)((8 - k)*a0 + (k - 1)*a1));
+	} else {
+#pragma unroll
+		for (int k = 2; k < 6; ++k)
+			pal[k] = (int)div5((uint32_t)((6 - k)*a0 + (k - 1)*a1));
+		pal[6] = e0;
+		pal[7] = 255;
+	}
+}
+
+// tp: the block's 16 texel words in LDS; ch: byte holding the value.
+// Returns the 8-byte block (lo, hi words) in every lane.
+__device__ __forceinline__ uint2 bc4_search(const uint32_t* tp, int ch, int vmin, int radius,
+	uint32_t lane)
+{
+	int lo = 255, hi = 0, lo6 = 255, hi6 = vmin;
+#pragma unroll 1
+	for (uint32_t i = 0; i < 16u; ++i) {
+		const int v = (int)ub(tp[i], ch);
+		lo = v < lo ? v : lo;
+		hi = v > hi ? v : hi;
+		lo6 = (v != vmin && v < lo6) ? v : lo6;
+		hi6 = (v != 255 && v > hi6) ? v : hi6;
+	}
+	if (lo6 > hi6)
+		lo6 = hi6 = vmin;
+	const uint32_t span = 2u*(uint32_t)radius + 1u, span2 = span*span, total = 2u*span2;
+	const float inv_span = 1.0f/(float)span;
+	uint32_t best_err = 0xFFFFFFFFu, best_id = 0xFFFFFFFFu;
+	int best_a0 = 0, best_a1 = 0;
+	for (uint32_t base = 0; base < total; base += 64u) {
+		const uint32_t id = base + lane;
+		if (id < total) {
+			const bool mode6 = id >= span2;
+			const uint32_t t = mode6 ? id - span2 : id;
+			uint32_t il = (uint32_t)(((float)t + 0.5f)*inv_span);
+			il = il*span > t ? il - 1u : il;
+			il = (il + 1u)*span <= t ? il + 1u : il;
+			const uint32_t ih = t - il*span;
+			const int dl = (int)il - radius, dh = (int)ih - radius;
+			int a0, a1;
+			bool valid;
+			if (!mode6) {
+				a1 = clampi(lo + dl, vmin, 255);
+				a0 = clampi(hi + dh, vmin, 255);
+				valid = a0 > a1;
+			} else {
+				a0 = clampi(lo6 + dl, vmin, 255);
+				a1 = clampi(hi6 + dh, vmin, 255);
+				valid = a0 <= a1;
+			}
+			if (valid) {
+				int pal[8];
+				bc4_palette(a0, a1, mode6, vmin, pal);
+				uint32_t err = 0;
+#pragma unroll 1
+				for (uint32_t i = 0; i < 16u; ++i) {
+					const uint32_t v = ub(tp[i], ch);
+					uint32_t d = 0xFFFFu;
+#pragma unroll
+					for (int k = 0; k < 8; ++k) {
+						const uint32_t ad = __builtin_amdgcn_sad_u8(v, (uint32_t)pal[k], 0u);
+						d = ad < d ? ad : d;
+					}
+					err += d*d;
+				}
+				if (err < best_err) {   // ids ascend per lane, so strict < keeps the lowest id
+					best_err = err;
+					best_id = id;
+					best_a0 = a0;
+					best_a1 = a1;
+				}
+			}
+		}
+	}
+	const unsigned long long key = ((unsigned long long)best_err << 32) | best_id;
+	const unsigned long long kmin = cf_wave_min_u64(key);
+	const uint32_t wl = (uint32_t)__builtin_ctzll(__ballot(key == kmin));
+	const int a0 = __shfl(best_a0, (int)wl, 64), a1 = __shfl(best_a1, (int)wl, 64);
+	int pal[8];
+	bc4_palette(a0, a1, a0 <= a1, vmin, pal);
+	unsigned long long sel = 0ull;
+#pragma unroll 1
+	for (uint32_t i = 0; i < 16u; ++i) {
+		const uint32_t v = ub(tp[i], ch);
+		uint32_t bestk = 0xFFFFFFFFu;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const uint32_t ad = __builtin_amdgcn_sad_u8(v, (uint32_t)pal[k], 0u);
+			const uint32_t kk = (ad << 3) | (uint32_t)k;   // |d| orders like d*d; ties -> lowest k
+			bestk = kk < bestk ? kk : bestk;
+		}
+		sel |= (unsigned long long)(bestk & 7u) << (3u*i);
+	}
+	uint2 out;
+	out.x = (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)(sel & 0xFFFFull) << 16);
+	out.y = (uint32_t)(sel >> 16);
+	return out;
+}
+
+// ------------------------------------------------------------------ BC1 family
+
+struct COpts {
+	uint32_t allow3;   // 0: 4-colour only, 1: both orders, 2: 3-colour only (punch-through)
+	bool black;        // index 3 usable as black
+	bool force4;       // BC2/BC3 colour block
+	uint32_t wt[3];
+	uint32_t active;   // bit i: texel i takes part
+	uint32_t rounds;
+};
+
+__device__ __forceinline__ uint32_t expand565(uint32_t c)
+{
+	const uint32_t r = (c >> 11) & 31u, g = (c >> 5) & 63u, b = c & 31u;
+	return ((r << 3) | (r >> 2)) | (((g << 2) | (g >> 4)) << 8) | (((b << 3) | (b >> 2)) << 16);
+}
+
+__device__ __forceinline__ uint32_t pack565(int r, int g, int b)
+{
+	return ((uint32_t)clampi(r, 0, 31) << 11) | ((uint32_t)clampi(g, 0, 63) << 5) |
+		(uint32_t)clampi(b, 0, 31);
+}
+
+// Palette of the pair in one order as packed RGB0 words; returns false when the order
+// cannot be expressed.
+__device__ __forceinline__ bool bc1_palette(uint32_t a, uint32_t b, bool mode3, bool force4,
+	uint32_t (&pal)[4])
+{
+	uint32_t c0, c1;
+	if (!mode3) {
+		c0 = a > b ? a : b;
+		c1 = a > b ? b : a;
+		if (c0 == c1 && !force4)
+			return false;
+	} else {
+		c0 = a < b ? a : b;
+		c1 = a < b ? b : a;
+	}
+	const uint32_t e0 = expand565(c0), e1 = expand565(c1);
+	uint32_t p2 = 0, p3 = 0;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		const uint32_t x = ub(e0, k), y = ub(e1, k);
+		if (!mode3) {
+			p2 |= div3(2u*x + y) << (8*k);
+			p3 |= div3(x + 2u*y) << (8*k);
+		} else
+			p2 |= ((x + y) >> 1) << (8*k);
+	}
+	pal[0] = e0; pal[1] = e1; pal[2] = p2; pal[3] = p3;
+	return true;
+}
+
+template <bool UNITW>
+__device__ __forceinline__ uint32_t bc1_dist(uint32_t p, uint32_t q, const uint32_t (&wt)[3])
+{
+	if (UNITW) {
+		// |p|^2 - 2 p.q + |q|^2 on the RGB bytes (byte 3 of both operands is zero)
+		return __builtin_amdgcn_udot4(p, p, 0u, false) + __builtin_amdgcn_udot4(q, q, 0u, false) -
+			2u*__builtin_amdgcn_udot4(p, q, 0u, false);
+	}
+	const int d0 = (int)ub(p, 0) - (int)ub(q, 0), d1 = (int)ub(p, 1) - (int)ub(q, 1),
+		d2 = (int)ub(p, 2) - (int)ub(q, 2);
+	return wt[0]*(uint32_t)(d0*d0) + wt[1]*(uint32_t)(d1*d1) + wt[2]*(uint32_t)(d2*d2);
+}
+
+template <bool UNITW>
+__device__ __forceinline__ uint32_t bc1_error(const uint32_t* tp, const COpts& o, uint32_t a,
+	uint32_t b, bool mode3)
+{
+	uint32_t pal[4];
+	if (!bc1_palette(a, b, mode3, o.force4, pal))
+		return 0xFFFFFFFFu;
+	const bool use3 = !mode3 || o.black;
+	uint32_t err = 0;
+#pragma unroll 1
+	for (uint32_t i = 0; i < 16u; ++i) {
+		const uint32_t p = tp[i] & 0x00FFFFFFu;
+		uint32_t d = bc1_dist<UNITW>(p, pal[0], o.wt);
+		const uint32_t d1 = bc1_dist<UNITW>(p, pal[1], o.wt);
+		const uint32_t d2 = bc1_dist<UNITW>(p, pal[2], o.wt);
+		const uint32_t d3 = bc1_dist<UNITW>(p, pal[3], o.wt);
+		d = d1 < d ? d1 : d;
+		d = d2 < d ? d2 : d;
+		d = (use3 && d3 < d) ? d3 : d;
+		err += ((o.active >> i) & 1u) ? d : 0u;
+	}
+	return err;
+}
+
+struct CBest { uint32_t err, id, a, b, mode3; };
+
+template <bool UNITW>
+__device__ __forceinline__ void consider(const uint32_t* tp, const COpts& o, uint32_t a, uint32_t b,
+	uint32_t idbase, CBest& best)
+{
+#pragma unroll
+	for (uint32_t mode3 = 0; mode3 < 2u; ++mode3) {
+		if (mode3 && !o.allow3)
+			continue;
+		if (!mode3 && o.allow3 == 2u)
+			continue;
+		const uint32_t err = bc1_error<UNITW>(tp, o, a, b, mode3 != 0u);
+		const uint32_t id = idbase + mode3;
+		if (err < best.err || (err == best.err && id < best.id)) {
+			best.err = err; best.id = id; best.a = a; best.b = b; best.mode3 = mode3;
+		}
+	}
+}
+
+__device__ __forceinline__ void move565(uint32_t m, uint32_t a, uint32_t b, uint32_t& na,
+	uint32_t& nb)
+{
+	int ar = (int)((a >> 11) & 31u), ag = (int)((a >> 5) & 63u), ab = (int)(a & 31u);
+	int br = (int)((b >> 11) & 31u), bg = (int)((b >> 5) & 63u), bb = (int)(b & 31u);
+	if (m < 54u) {
+		const uint32_t k = m < 27u ? m : m - 27u;
+		const uint32_t k3 = div3(k), k9 = div3(k3);
+		const int dr = (int)(k - 3u*k3) - 1, dg = (int)(k3 - 3u*k9) - 1, db = (int)k9 - 1;
+		if (m < 27u) { ar += dr; ag += dg; ab += db; }
+		else { br += dr; bg += dg; bb += db; }
+	} else {
+		const uint32_t j = m - 54u;
+		if (j < 2u) {
+			const int s = j ? -1 : 1;
+			ar += s; ag += s; ab += s; br += s; bg += s; bb += s;
+		} else if (j < 4u) {
+			const int s = j == 2u ? 1 : -1;
+			const int sr = (br > ar) - (br < ar), sg = (bg > ag) - (bg < ag),
+				sb = (bb > ab) - (bb < ab);
+			ar -= s*sr; br += s*sr;
+			ag -= s*sg; bg += s*sg;
+			ab -= s*sb; bb += s*sb;
+		} else {
+			const uint32_t c = (j - 4u) >> 1;
+			const int s = ((j - 4u) & 1u) ? -1 : 1;
+			if (c == 0u) { ar += s; br += s; }
+			else if (c == 1u) { ag += s; bg += s; }
+			else { ab += s; bb += s; }
+		}
+	}
+	na = pack565(ar, ag, ab);
+	nb = pack565(br, bg, bb);
+}
+
+// Returns the 8-byte colour block in every lane.
+template <bool UNITW>
+__device__ __forceinline__ uint2 bc1_search(const uint32_t* tp, const COpts& o, uint32_t lane)
+{
+	if (!o.active)
+		return make_uint2(0u, 0xFFFFFFFFu);
+	// bounding box + covariance signs against the channel of largest range
+	int n = 0, mn[3] = {255, 255, 255}, mx[3] = {0, 0, 0}, s[3] = {0, 0, 0};
+	int s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0;
+#pragma unroll 1
+	for (uint32_t i = 0; i < 16u; ++i) {
+		const uint32_t p = tp[i];
+		if ((o.active >> i) & 1u) {
+			const int r = (int)ub(p, 0), g = (int)ub(p, 1), b = (int)ub(p, 2);
+			++n;
+			mn[0] = r < mn[0] ? r : mn[0]; mx[0] = r > mx[0] ? r : mx[0];
+			mn[1] = g < mn[1] ? g : mn[1]; mx[1] = g > mx[1] ? g : mx[1];
+			mn[2] = b < mn[2] ? b : mn[2]; mx[2] = b > mx[2] ? b : mx[2];
+			s[0] += r; s[1] += g; s[2] += b;
+			s00 += r*r; s01 += r*g; s02 += r*b; s11 += g*g; s12 += g*b; s22 += b*b;
+		}
+	}
+	int ref = 0;
+	if (mx[1] - mn[1] > mx[0] - mn[0]) ref = 1;
+	if (mx[2] - mn[2] > mx[ref == 1 ? 1 : 0] - mn[ref == 1 ? 1 : 0]) ref = 2;
+	// sq[ref][c]
+	const int sr0 = ref == 0 ? s00 : (ref == 1 ? s01 : s02);
+	const int sr1 = ref == 0 ? s01 : (ref == 1 ? s11 : s12);
+	const int sr2 = ref == 0 ? s02 : (ref == 1 ? s12 : s22);
+	const int sref = ref == 0 ? s[0] : (ref == 1 ? s[1] : s[2]);
+	const int cov[3] = {n*sr0 - sref*s[0], n*sr1 - sref*s[1], n*sr2 - sref*s[2]};
+	int lo[3], hi[3];
+#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		const bool flip = c != ref && cov[c] < 0;
+		lo[c] = flip ? mx[c] : mn[c];
+		hi[c] = flip ? mn[c] : mx[c];
+	}
+
+	CBest best = {0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+	{
+		const int tl = (int)(lane & 7u), th = (int)(lane >> 3);
+		int ea[3], eb[3];
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			const int d = hi[c] - lo[c], sg = (d > 0) - (d < 0), ad = d < 0 ? -d : d;
+			ea[c] = lo[c] + sg*((ad*tl + 8) >> 4);
+			eb[c] = hi[c] - sg*((ad*th + 8) >> 4);
+		}
+		const uint32_t a = pack565((int)div255((uint32_t)(ea[0]*31 + 127)),
+			(int)div255((uint32_t)(ea[1]*63 + 127)), (int)div255((uint32_t)(ea[2]*31 + 127)));
+		const uint32_t b = pack565((int)div255((uint32_t)(eb[0]*31 + 127)),
+			(int)div255((uint32_t)(eb[1]*63 + 127)), (int)div255((uint32_t)(eb[2]*31 + 127)));
+		consider<UNITW>(tp, o, a, b, 2u*lane, best);
+	}
+	// wave winner of the start candidates
+	unsigned long long key = ((unsigned long long)best.err << 32) | best.id;
+	unsigned long long kmin = cf_wave_min_u64(key);
+	uint32_t wl = (uint32_t)__builtin_ctzll(__ballot(key == kmin));
+	CBest cur;
+	cur.err = (uint32_t)(kmin >> 32);
+	cur.id = (uint32_t)kmin;
+	cur.a = (uint32_t)__shfl((int)best.a, (int)wl, 64);
+	cur.b = (uint32_t)__shfl((int)best.b, (int)wl, 64);
+	cur.mode3 = (uint32_t)__shfl((int)best.mode3, (int)wl, 64);
+
+	for (uint32_t r = 1; r <= o.rounds; ++r) {
+		uint32_t na, nb;
+		move565(lane, cur.a, cur.b, na, nb);
+		CBest cand = {0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+		consider<UNITW>(tp, o, na, nb, r*128u + 2u*lane, cand);
+		key = ((unsigned long long)cand.err << 32) | cand.id;
+		kmin = cf_wave_min_u64(key);
+		if ((uint32_t)(kmin >> 32) >= cur.err)
+			break;                    // uniform: the round did not improve
+		wl = (uint32_t)__builtin_ctzll(__ballot(key == kmin));
+		cur.err = (uint32_t)(kmin >> 32);
+		cur.id = (uint32_t)kmin;
+		cur.a = (uint32_t)__shfl((int)cand.a, (int)wl, 64);
+		cur.b = (uint32_t)__shfl((int)cand.b, (int)wl, 64);
+		cur.mode3 = (uint32_t)__shfl((int)cand.mode3, (int)wl, 64);
+	}
+
+	// selectors of the winner (uniform work, every lane computes the same words)
+	uint32_t pal[4];
+	const bool mode3 = cur.mode3 != 0u;
+	bc1_palette(cur.a, cur.b, mode3, true, pal);
+	const uint32_t c0 = mode3 ? (cur.a < cur.b ? cur.a : cur.b) : (cur.a > cur.b ? cur.a : cur.b);
+	const uint32_t c1 = mode3 ? (cur.a < cur.b ? cur.b : cur.a) : (cur.a > cur.b ? cur.b : cur.a);
+	const uint32_t np = mode3 ? (o.black ? 4u : 3u) : 4u;
+	uint32_t sel = 0;
+#pragma unroll 1
+	for (uint32_t i = 0; i < 16u; ++i) {
+		const uint32_t p = tp[i] & 0x00FFFFFFu;
+		uint32_t bk = 3u;
+		if ((o.active >> i) & 1u) {
+			uint32_t bd = 0xFFFFFFFFu;
+#pragma unroll
+			for (uint32_t k = 0; k < 4u; ++k) {
+				if (k < np) {
+					const uint32_t d = bc1_dist<UNITW>(p, pal[k], o.wt);
+					if (d < bd) { bd = d; bk = k; }
+				}
+			}
+		}
+		sel |= bk << (2u*i);
+	}
+	return make_uint2(c0 | (c1 << 16), sel);
+}
+
+__device__ __forceinline__ uint32_t colour_rounds(uint32_t quality)
+{
+	return quality == 0u ? 0u : (quality == 1u ? 2u : (quality == 2u ? 4u : (quality == 3u ? 8u :
+		16u)));
+}
+
+__device__ __forceinline__ int alpha_radius(uint32_t quality)
+{
+	return quality <= 1u ? 0 : (quality == 2u ? 5 : (quality == 3u ? 16 : 32));
+}
+
+__device__ __forceinline__ uint32_t snorm8_biased(float f)
+{
+	// (int8)round(clamp(f,-1,1)*127) + 128  -- S3tcConverter.cpp:404-411
+	f = f < -1.0f ? -1.0f : (f > 1.0f ? 1.0f : f);
+	return (uint32_t)((int)roundf(f*127.0f) + 128);
+}
+
+// Stage the strip: like cf_load_tile_rgba8, but snorm formats store round(f*127)+128 in
+// bytes 0/1 (f = u8/255 for RGBA8 sources, as the reference's RGBAF view would hold).
+template <int PIX, bool SNORM>
+__device__ __forceinline__ void load_tile(const cf_kparams& kp, uint32_t bx0, uint32_t byy,
+	uint32_t* tile)
+{
+	const uint32_t t = threadIdx.x;
+	const uint32_t row = t >> 6, col = t & 63u;
+	uint32_t x = bx0*4u + col, y = byy*4u + row;
+	x = x < kp.width ? x : kp.width - 1u;
+	y = y < kp.height ? y : kp.height - 1u;
+	const uint8_t* rowp = kp.src + (long long)y*kp.pitch;
+	uint32_t px;
+	if (PIX == 0) {
+		px = *reinterpret_cast<const uint32_t*>(rowp + (size_t)x*4u);
+		if (SNORM)
+			px = (px & 0xFFFF0000u) | snorm8_biased((float)(px & 255u)/255.0f) |
+				(snorm8_biased((float)((px >> 8) & 255u)/255.0f) << 8);
+	} else {
+		const float4 f = *reinterpret_cast<const float4*>(rowp + (size_t)x*16u);
+		if (SNORM)
+			px = snorm8_biased(f.x) | (snorm8_biased(f.y) << 8) | (cf_unorm8(f.z) << 16) |
+				(cf_unorm8(f.w) << 24);
+		else
+			px = cf_unorm8(f.x) | (cf_unorm8(f.y) << 8) | (cf_unorm8(f.z) << 16) |
+				(cf_unorm8(f.w) << 24);
+	}
+	tile[(col >> 2)*16u + row*4u + (col & 3u)] = px;
+}
+
+} // namespace
+
+// FMT: Texture::Format value; SNORM only for BC4/BC5.
+template <int PIX, int FMT, bool SNORM>
+__global__ void __launch_bounds__(CF_WG_THREADS)
+cfhip_bc15_encode_kernel(cf_kparams kp)
+{
+	constexpr uint32_t BYTES = (FMT == F_BC1 || FMT == F_BC1A || FMT == F_BC4) ? 8u : 16u;
+	__shared__ __attribute__((aligned(16))) uint32_t tile[CF_BLOCKS_PER_WG*16];
+	__shared__ uint32_t outb[CF_BLOCKS_PER_WG*4];
+	const uint32_t bx0 = blockIdx.x*CF_BLOCKS_PER_WG;
+	const uint32_t byy = blockIdx.y;
+	load_tile<PIX, SNORM>(kp, bx0, byy, tile);
+	__syncthreads();
+
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	for (uint32_t j = 0; j < 4u; ++j) {
+		const uint32_t b = wave*4u + j;
+		if (bx0 + b >= kp.bx)
+			break;
+		const uint32_t* tp = tile + b*16u;
+		COpts o;
+		o.allow3 = 0; o.black = false; o.force4 = false;
+		o.wt[0] = o.wt[1] = o.wt[2] = 1u;
+		o.active = 0xFFFFu;
+		o.rounds = colour_rounds(kp.quality);
+		const int radius = alpha_radius(kp.quality);
+		uint2 w0 = make_uint2(0, 0), w1 = make_uint2(0, 0);
+		if (FMT == F_BC1) {
+			o.allow3 = 1; o.black = true;
+			w0 = bc1_search<true>(tp, o, lane);
+		} else if (FMT == F_BC1A) {
+			// alpha < 0.5 <=> quantised alpha < 128 (S3tcConverter.cpp:285-290)
+			const uint32_t opaque = (uint32_t)__ballot(lane < 16u && (tp[lane & 15u] >> 24) >= 128u);
+			if (opaque != 0xFFFFu) {
+				o.allow3 = 2; o.black = false; o.active = opaque;
+				o.wt[0] = kp.wt[0]; o.wt[1] = kp.wt[1]; o.wt[2] = kp.wt[2];
+				w0 = bc1_search<false>(tp, o, lane);
+			} else {
+				o.allow3 = 1; o.black = false;
+				w0 = bc1_search<true>(tp, o, lane);
+			}
+		} else if (FMT == F_BC2) {
+			uint32_t a0 = 0, a1 = 0;
+#pragma unroll 1
+			for (uint32_t i = 0; i < 8u; ++i) {
+				a0 |= div255((tp[i] >> 24)*15u + 127u) << (4u*i);
+				a1 |= div255((tp[8u + i] >> 24)*15u + 127u) << (4u*i);
+			}
+			w0 = make_uint2(a0, a1);
+			o.force4 = true;
+			w1 = bc1_search<true>(tp, o, lane);
+		} else if (FMT == F_BC3) {
+			w0 = bc4_search(tp, 3, 0, radius, lane);
+			o.force4 = true;
+			w1 = bc1_search<true>(tp, o, lane);
+		} else {
+			w0 = bc4_search(tp, 0, SNORM ? 1 : 0, radius, lane);
+			if (SNORM)
+				w0.x = (w0.x & 0xFFFF0000u) | (((w0.x & 0xFFu) - 128u) & 0xFFu) |
+					(((((w0.x >> 8) & 0xFFu) - 128u) & 0xFFu) << 8);
+			if (FMT == F_BC5) {
+				w1 = bc4_search(tp, 1, SNORM ? 1 : 0, radius, lane);
+				if (SNORM)
+					w1.x = (w1.x & 0xFFFF0000u) | (((w1.x & 0xFFu) - 128u) & 0xFFu) |
+						(((((w1.x >> 8) & 0xFFu) - 128u) & 0xFFu) << 8);
+			}
+		}
+		if (lane == 0u) {
+			if (BYTES == 8u) {
+				outb[b*2u] = w0.x; outb[b*2u + 1u] = w0.y;
+			} else {
+				outb[b*4u] = w0.x; outb[b*4u + 1u] = w0.y;
+				outb[b*4u + 2u] = w1.x; outb[b*4u + 3u] = w1.y;
+			}
+		}
+	}
+	__syncthreads();
+	const uint32_t t = threadIdx.x;
+	constexpr uint32_t WPB = BYTES/4u;   // words per block
+	if (t < CF_BLOCKS_PER_WG*WPB) {
+		const uint32_t b = t/WPB;
+		if (bx0 + b < kp.bx) {
+			uint32_t* dst = reinterpret_cast<uint32_t*>(kp.out + ((size_t)byy*kp.bx + bx0)*BYTES);
+			dst[t] = outb[t];
+		}
+	}
+}
+
+template <int PIX>
+static hipError_t launch_fmt(const cf_kparams* kp, int format, int snorm, dim3 grid, dim3 block,
+	hipStream_t stream)
+{
+	switch (format) {
+		case F_BC1: hipLaunchKernelGGL((cfhip_bc15_encode_kernel<PIX, F_BC1, false>), grid, block, 0, stream, *kp); break;
+		case F_BC1A: hipLaunchKernelGGL((cfhip_bc15_encode_kernel<PIX, F_BC1A, false>), grid, block, 0, stream, *kp); break;
+		case F_BC2: hipLaunchKernelGGL((cfhip_bc15_encode_kernel<PIX, F_BC2, false>), grid, block, 0, stream, *kp); break;
+		case F_BC3: hipLaunchKernelGGL((cfhip_bc15_encode_kernel<PIX, F_BC3, false>), grid, block, 0, stream, *kp); break;
+		case F_BC4:
+			if (snorm) hipLaunchKernelGGL((cfhip_bc15_encode_kernel<PIX, F_BC4, true>), grid, block, 0, stream, *kp);
+			else hipLaunchKernelGGL((cfhip_bc15_encode_kernel<PIX, F_BC4, false>), grid, block, 0, stream, *kp);
+			break;
+		case F_BC5:
+			if (snorm) hipLaunchKernelGGL((cfhip_bc15_encode_kernel<PIX, F_BC5, true>), grid, block, 0, stream, *kp);
+			else hipLaunchKernelGGL((cfhip_bc15_encode_kernel<PIX, F_BC5, false>), grid, block, 0, stream, *kp);
+			break;
+		default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+extern "C" hipError_t cfhip_launch_bc15(const cf_kparams* kp, int format, int pixel_type,
+	int snorm, hipStream_t stream)
+{
+	dim3 grid((kp->bx + CF_BLOCKS_PER_WG - 1)/CF_BLOCKS_PER_WG, kp->by, 1);
+	dim3 block(CF_WG_THREADS, 1, 1);
+	if (pixel_type == 0)
+		return launch_fmt<0>(kp, format, snorm, grid, block, stream);
+	return launch_fmt<1>(kp, format, snorm, grid, block, stream);
+}

@@ -18,6 +18,8 @@
 
 extern "C" hipError_t cfhip_launch_bc7(const cf_kparams* kp, int pixel_type, int unit_weights,
 	hipStream_t stream);
+extern "C" hipError_t cfhip_launch_bc15(const cf_kparams* kp, int format, int pixel_type,
+	int snorm, hipStream_t stream);
 
 struct cfhip_ctx {
 	int device = 0;
@@ -98,6 +100,12 @@ bool format_implemented(int format, int type)
 {
 	(void)type;
 	switch (format) {
+		case CFHIP_FORMAT_BC1_RGB:
+		case CFHIP_FORMAT_BC1_RGBA:
+		case CFHIP_FORMAT_BC2:
+		case CFHIP_FORMAT_BC3:
+		case CFHIP_FORMAT_BC4:
+		case CFHIP_FORMAT_BC5:
 		case CFHIP_FORMAT_BC7:
 			return true;
 		default:
@@ -158,6 +166,14 @@ void fill_kparams(cf_kparams& kp, const cfhip_params& p, const void* src, void* 
 	const uint32_t* wsel = (p.color_space == CFHIP_COLOR_SRGB && p.quality >= 2) ? perc : lin;
 	for (int c = 0; c < 4; ++c)
 		kp.wt[c] = p.mask_rgba[c] ? wsel[c] : 1u;
+	if (p.format == CFHIP_FORMAT_BC1_RGBA) {
+		// punch-through blocks (squish path, S3tcConverter.cpp:294-330): Rec.709-like
+		// integer weights for sRGB images, colour mask zeroes a channel's weight
+		static const uint32_t plin[3] = {1, 1, 1}, pperc[3] = {3, 10, 1};
+		const uint32_t* w = p.color_space == CFHIP_COLOR_SRGB ? pperc : plin;
+		for (int c = 0; c < 3; ++c)
+			kp.wt[c] = p.mask_rgba[c] ? w[c] : 0u;
+	}
 }
 
 int launch(cfhip_ctx* ctx, const cf_kparams& kp, const cfhip_params& p, int pixel_type,
@@ -173,6 +189,18 @@ int launch(cfhip_ctx* ctx, const cf_kparams& kp, const cfhip_params& p, int pixe
 			ctx->last_kernel = "cfhip_bc7_encode_kernel";
 			break;
 		}
+		case CFHIP_FORMAT_BC1_RGB:
+		case CFHIP_FORMAT_BC1_RGBA:
+		case CFHIP_FORMAT_BC2:
+		case CFHIP_FORMAT_BC3:
+		case CFHIP_FORMAT_BC4:
+		case CFHIP_FORMAT_BC5:
+			if (pixel_type != CFHIP_PIXEL_RGBA8 && pixel_type != CFHIP_PIXEL_RGBA32F)
+				return fail(ctx, CFHIP_E_UNSUPPORTED, "BC1-5 take RGBA8 or RGBA32F pixels");
+			e = cfhip_launch_bc15(&kp, p.format, pixel_type == CFHIP_PIXEL_RGBA32F ? 1 : 0,
+				p.type == CFHIP_TYPE_SNORM ? 1 : 0, stream);
+			ctx->last_kernel = "cfhip_bc15_encode_kernel";
+			break;
 		default:
 			return fail(ctx, CFHIP_E_UNSUPPORTED, "format %d has no gfx950 kernel yet", p.format);
 	}
