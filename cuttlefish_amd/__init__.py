@@ -7,8 +7,9 @@ parity tests and bench.py; it never falls back to a CPU encoder.
 """
 from .api import (Alpha, CfhipError, ColorSpace, Context, Format, PixelType, Quality, Type,  # noqa: F401
                   device_count, load_library, make_params, payload_size, query, shard_rows)
+from . import shard  # noqa: F401
 from .texture import Texture  # noqa: F401
 
 __all__ = ["Alpha", "CfhipError", "ColorSpace", "Context", "Format", "PixelType", "Quality",
            "Type", "Texture", "device_count", "load_library", "make_params", "payload_size",
-           "query", "shard_rows"]
+           "query", "shard", "shard_rows"]

@@ -1,0 +1,77 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard surfaces / block rows and gather the
+payload; the result must be byte-identical to the single-rank result.  The encoder injected
+here is the CPU oracle (tests may use it); on GPUs the same code runs with Context.encode."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as O
+from cuttlefish_amd import Format, Type, make_params, shard, synth
+
+
+def _oracle_encode(images, params):
+    return [O.encode(np.ascontiguousarray(im), int(params.format), typ=int(params.type),
+                     quality=int(params.quality)) for im in images]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        params = make_params(Format.BC3, Type.UNorm, 1)
+        chain = [synth.photo(32 >> i, 32 >> i, seed=60 + i) for i in range(6)]
+        chain += [synth.photo(20, 12, seed=70), synth.photo(8, 40, seed=71)]
+        got = shard.encode_surfaces_sharded(chain, params, _oracle_encode, rank, world)
+        img = synth.photo(40, 52, seed=80)
+        rows = shard.encode_rows_sharded(img, params, _oracle_encode, rank, world)
+        q.put((rank, [g.tobytes() for g in got], rows.tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_assign_surfaces_is_balanced_and_deterministic():
+    counts = [shard.block_count(2048 >> i, 2048 >> i) for i in range(12)] * 4
+    plan = shard.assign_surfaces(counts, 8)
+    assert sorted(i for p in plan for i in p) == list(range(len(counts)))
+    loads = [sum(counts[i] for i in p) for p in plan]
+    assert max(loads) - min(loads) <= max(counts)
+    assert plan == shard.assign_surfaces(counts, 8)
+    assert shard.assign_surfaces([5, 1], 4) == [[0], [1], [], []]
+
+
+@pytest.mark.timeout(300)
+def test_world2_gloo_matches_single_rank():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+
+    params = make_params(Format.BC3, Type.UNorm, 1)
+    chain = [synth.photo(32 >> i, 32 >> i, seed=60 + i) for i in range(6)]
+    chain += [synth.photo(20, 12, seed=70), synth.photo(8, 40, seed=71)]
+    want = [o.tobytes() for o in _oracle_encode(chain, params)]
+    img = synth.photo(40, 52, seed=80)
+    want_rows = _oracle_encode([img], params)[0].tobytes()
+    for rank, got, rows in results:
+        assert got == want, "rank %d surfaces differ" % rank
+        assert rows == want_rows, "rank %d row shards differ" % rank
