@@ -170,6 +170,13 @@ def main():
                          "note": "VALU-bound search; HBM fraction is expected to be tiny "
                                  "(DESIGN.md roofline section)"},
         }
+        # HBM traffic per launch from the committed PMC profile of this kernel (rocprofv3
+        # --pmc passes cannot run inside the timed benchmark); null when not applicable.
+        tpath = os.path.join(ROOT, "profiles", "bc7_traffic.json")
+        if size == SIZE and args.quality == 2 and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            line["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
+            line["roofline"]["traffic_source"] = tj["source"]
         if world == 1 and not args.no_cpu_baseline and size == SIZE:
             payload = out.cpu().numpy()
             line["cpu_baseline"] = cpu_baseline(img, payload, size)

@@ -187,60 +187,79 @@ __device__ __forceinline__ void quantize(const float (&x0)[4], const float (&x1)
 	f.pb = p0 | (p1 << 1);
 }
 
-// Fetch one texel row (4 texels of the block) from LDS; ROT applies the lane's
-// channel rotation (v_perm_b32), vmask zeroes channels the fit does not code.
-template <bool ROT>
-__device__ __forceinline__ uint32_t texel(uint32_t raw, uint32_t sel, uint32_t vmask)
+// View of one block's texels in LDS for one fit: packed RGBA words (tp) and the
+// channel-planar copy (pl: row r -> 4 words R,G,B,A, texel j of the row in byte j),
+// the lane's channel rotation and the set of (rotated) channels this fit codes.
+struct Tex {
+	const uint32_t* tp;
+	const uint32_t* pl;
+	uint32_t sel;      // v_perm_b32 selector of the rotation
+	uint32_t rot;      // 0..3
+	uint32_t chmask;   // bit c: rotated channel c is coded by this fit
+	uint32_t vmask;    // byte mask of chmask
+};
+
+__device__ __forceinline__ Tex make_tex(const uint32_t* tp, const uint32_t* pl, uint32_t rot,
+	uint32_t chmask)
 {
-	const uint32_t p = ROT ? __builtin_amdgcn_perm(raw, raw, sel) : raw;
-	return p & vmask;
+	Tex t;
+	t.tp = tp; t.pl = pl; t.rot = rot; t.chmask = chmask;
+	t.sel = rot == 0u ? 0x03020100u : (rot == 1u ? 0x00020103u :
+		(rot == 2u ? 0x01020300u : 0x02030100u));
+	t.vmask = ((chmask & 1u) ? 0xFFu : 0u) | ((chmask & 2u) ? 0xFF00u : 0u) |
+		((chmask & 4u) ? 0xFF0000u : 0u) | ((chmask & 8u) ? 0xFF000000u : 0u);
+	return t;
 }
 
-// Rolled walk over the block's 16 texels in LDS, CF_UNR texels per trip (one
-// ds_read_b128 / b64 / b32 per trip).  Rolled on purpose: the texels are loop
-// invariant across refinement rounds, and a fully unrolled body gets hoisted by
-// LICM into >64 live registers.
-#ifndef CF_UNR
-#define CF_UNR 1
-#endif
-template <typename F>
-__device__ __forceinline__ void for_texels(const uint32_t* tp, F&& f)
+template <bool ROT>
+__device__ __forceinline__ uint32_t texel(const Tex& t, uint32_t raw)
 {
-#if CF_UNR == 4
-#pragma unroll 1
-	for (uint32_t r = 0; r < 4u; ++r) {
-		const uint4 row = *reinterpret_cast<const uint4*>(tp + 4u*r);
-		f(row.x, 4u*r); f(row.y, 4u*r + 1u); f(row.z, 4u*r + 2u); f(row.w, 4u*r + 3u);
+	const uint32_t p = ROT ? __builtin_amdgcn_perm(raw, raw, t.sel) : raw;
+	return p & t.vmask;
+}
+
+// The four channel planes of one texel row after rotation, non-coded channels zeroed.
+template <bool ROT>
+__device__ __forceinline__ void planes(const Tex& t, const uint4 pr, uint32_t (&P)[4])
+{
+	if (ROT) {
+		P[0] = t.rot == 1u ? pr.w : pr.x;
+		P[1] = t.rot == 2u ? pr.w : pr.y;
+		P[2] = t.rot == 3u ? pr.w : pr.z;
+		P[3] = t.rot == 0u ? pr.w : (t.rot == 1u ? pr.x : (t.rot == 2u ? pr.y : pr.z));
+	} else {
+		P[0] = pr.x; P[1] = pr.y; P[2] = pr.z; P[3] = pr.w;
 	}
-#elif CF_UNR == 2
-#pragma unroll 1
-	for (uint32_t r = 0; r < 8u; ++r) {
-		const uint2 row = *reinterpret_cast<const uint2*>(tp + 2u*r);
-		f(row.x, 2u*r); f(row.y, 2u*r + 1u);
-	}
-#else
-#pragma unroll 1
-	for (uint32_t i = 0; i < 16u; ++i)
-		f(tp[i], i);
-#endif
+#pragma unroll
+	for (int c = 0; c < 4; ++c)
+		P[c] = ((t.chmask >> c) & 1u) ? P[c] : 0u;
+}
+
+// 4 mask bits -> 4 mask bytes (0x00 / 0xFF)
+__device__ __forceinline__ uint32_t bytemask4(uint32_t m)
+{
+	return ((m*0x00204081u) & 0x01010101u)*0xFFu;
 }
 
 // D+E fused: exhaustive selector assignment over the 2^ib palette entries of
-// (f.e0, f.e1) with integer error, accumulating in the same texel loop the sums of
-// the closed-form least-squares refit, whose solution is left in f.nx0/nx1.
+// (f.e0, f.e1) with integer error, plus (want_lsq) the sums of the closed-form
+// least-squares refit, whose solution is left in f.nx0/nx1.
 // Texel-outer / palette-inner: the palette (<= 16 entries) lives in registers, the
-// texels are re-read from LDS (rolled row loop, one ds_read_b128 per 4 texels).
-template <bool UNITW, bool ROT>
-__device__ __forceinline__ void assign_lsq(const uint32_t* tp, uint32_t sel, uint32_t vmask,
-	uint32_t mask, uint32_t ab, uint32_t ib, const uint32_t (&wt)[4], bool want_lsq, SubFit& f)
+// texels are re-read from LDS one row (4 texels) per trip of a ROLLED loop -- the
+// texels are invariant across refit rounds and a fully unrolled body would be
+// hoisted by LICM into >64 live registers.  The refit sums are row operations on
+// the channel-planar copy: 12 v_dot4 per row instead of ~20 MADs per texel.
+template <bool UNITW, bool ROT, int NKMAX>
+__device__ __forceinline__ void assign_lsq(const Tex& tx, uint32_t mask, uint32_t ib,
+	const uint32_t (&wt)[4], bool want_lsq, SubFit& f)
 {
 	const uint32_t nk = 1u << ib;
 	const uint32_t e00 = ub(f.e0, 0), e01 = ub(f.e0, 1), e02 = ub(f.e0, 2), e03 = ub(f.e0, 3);
 	const uint32_t e10 = ub(f.e1, 0), e11 = ub(f.e1, 1), e12 = ub(f.e1, 2), e13 = ub(f.e1, 3);
-	uint32_t pal[16];
-	int base[16];
+	uint32_t pal[NKMAX];
+	int base[NKMAX];
 #pragma unroll
-	for (int k = 0; k < 16; ++k) {
+	for (int k = 0; k < NKMAX; ++k) {
 		pal[k] = 0;
 		base[k] = 0;
 		if ((uint32_t)k < nk) {
@@ -254,73 +273,78 @@ __device__ __forceinline__ void assign_lsq(const uint32_t* tp, uint32_t sel, uin
 				: (int)w;
 		}
 	}
-	uint32_t err = 0, n = 0, S = 0, A = 0, B = 0, C = 0;
+	uint32_t err = 0, S = 0, A = 0, B = 0, C = 0;
 	uint32_t U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
 	uint32_t wp0 = 0, wp1 = 0, wp2 = 0, wp3 = 0;
-	for_texels(tp, [&](uint32_t raw, uint32_t i) {
-		const uint32_t p = texel<ROT>(raw, sel, vmask);
-		const bool m = (mask >> i) & 1u;
-		uint32_t key;
-		if (UNITW) {
-			int bestk = 0x7FFFFFFF;
+#pragma unroll 1
+	for (uint32_t r = 0; r < 4u; ++r) {
+		const uint32_t mrow = (mask >> (4u*r)) & 15u;
+		uint32_t wrow = 0;
+		const uint4 row = *reinterpret_cast<const uint4*>(tx.tp + 4u*r);
+		const uint32_t raw[4] = {row.x, row.y, row.z, row.w};
 #pragma unroll
-			for (int k = 0; k < 16; ++k) {
-				if ((uint32_t)k < nk) {
-					const int dt = (int)__builtin_amdgcn_udot4(p, pal[k], 0u, false);
-					const int v = base[k] - (dt << 8);
-					bestk = v < bestk ? v : bestk;
+		for (int j = 0; j < 4; ++j) {
+			const uint32_t p = texel<ROT>(tx, raw[j]);
+			uint32_t key;
+			if (UNITW) {
+				int bestk = 0x7FFFFFFF;
+#pragma unroll
+				for (int k = 0; k < NKMAX; ++k) {
+					if ((uint32_t)k < nk) {
+						const int dt = (int)__builtin_amdgcn_udot4(p, pal[k], 0u, false);
+						const int v = base[k] - (dt << 8);
+						bestk = v < bestk ? v : bestk;
+					}
+				}
+				key = (uint32_t)bestk + (__builtin_amdgcn_udot4(p, p, 0u, false) << 7);
+			} else {
+				key = 0xFFFFFFFFu;
+#pragma unroll
+				for (int k = 0; k < NKMAX; ++k) {
+					if ((uint32_t)k < nk) {
+						const int d0 = (int)ub(p, 0) - (int)ub(pal[k], 0);
+						const int d1 = (int)ub(p, 1) - (int)ub(pal[k], 1);
+						const int d2 = (int)ub(p, 2) - (int)ub(pal[k], 2);
+						const int d3 = (int)ub(p, 3) - (int)ub(pal[k], 3);
+						const uint32_t dist = wt[0]*(uint32_t)(d0*d0) + wt[1]*(uint32_t)(d1*d1) +
+							wt[2]*(uint32_t)(d2*d2) + wt[3]*(uint32_t)(d3*d3);
+						const uint32_t v = (dist << 7) | (uint32_t)base[k];
+						key = v < key ? v : key;
+					}
 				}
 			}
-			key = (uint32_t)bestk + (__builtin_amdgcn_udot4(p, p, 0u, false) << 7);
-		} else {
-			key = 0xFFFFFFFFu;
-#pragma unroll
-			for (int k = 0; k < 16; ++k) {
-				if ((uint32_t)k < nk) {
-					const int d0 = (int)ub(p, 0) - (int)ub(pal[k], 0);
-					const int d1 = (int)ub(p, 1) - (int)ub(pal[k], 1);
-					const int d2 = (int)ub(p, 2) - (int)ub(pal[k], 2);
-					const int d3 = (int)ub(p, 3) - (int)ub(pal[k], 3);
-					const uint32_t dist = wt[0]*(uint32_t)(d0*d0) + wt[1]*(uint32_t)(d1*d1) +
-						wt[2]*(uint32_t)(d2*d2) + wt[3]*(uint32_t)(d3*d3);
-					const uint32_t v = (dist << 7) | (uint32_t)base[k];
-					key = v < key ? v : key;
-				}
-			}
+			const bool m = (mrow >> j) & 1u;
+			err += m ? (key >> 7) : 0u;
+			wrow |= (m ? (key & 127u) : 0u) << (8*j);
 		}
-		const uint32_t wb = key & 127u;
-		err += m ? (key >> 7) : 0u;
-		const uint32_t w = m ? wb : 0u;
-		const uint32_t iw = m ? 64u - wb : 0u;
-		// 128-bit byte shift register: after 16 texels, texel i sits in byte i
-		wp0 = (wp0 >> 8) | (wp1 << 24);
-		wp1 = (wp1 >> 8) | (wp2 << 24);
-		wp2 = (wp2 >> 8) | (wp3 << 24);
-		wp3 = (wp3 >> 8) | (w << 24);
+		wp0 = wp1; wp1 = wp2; wp2 = wp3; wp3 = wrow;
 		if (want_lsq) {   // uniform: the last round's refit would never be used
-			n += m ? 1u : 0u;
-			S += w;
-			A += iw*iw;
-			B += iw*w;
-			C += w*w;
+			const uint32_t iwrow = (0x40404040u - wrow) & bytemask4(mrow);
+			uint32_t P[4];
+			planes<ROT>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
+			S = __builtin_amdgcn_udot4(wrow, 0x01010101u, S, false);
+			A = __builtin_amdgcn_udot4(iwrow, iwrow, A, false);
+			B = __builtin_amdgcn_udot4(iwrow, wrow, B, false);
+			C = __builtin_amdgcn_udot4(wrow, wrow, C, false);
 #pragma unroll
 			for (int c = 0; c < 4; ++c) {
-				U[c] += iw*ub(p, c);
-				V[c] += w*ub(p, c);
+				U[c] = __builtin_amdgcn_udot4(iwrow, P[c], U[c], false);
+				V[c] = __builtin_amdgcn_udot4(wrow, P[c], V[c], false);
 			}
 		}
-	});
+	}
 	f.err = err;
 	f.w[0] = wp0; f.w[1] = wp1; f.w[2] = wp2; f.w[3] = wp3;
 
 	// closed-form least squares given these selectors
+	const uint32_t n = (uint32_t)__builtin_popcount(mask);
 	const int det = (int)(n*C) - (int)(S*S);   // = (A*C - B*B)/4096, exact
 	f.ok = det > 0;
 	const float inv = 1.0f/(64.0f*(float)(det > 0 ? det : 1));
 	const float fA = (float)A, fB = (float)B, fC = (float)C;
 #pragma unroll
 	for (int c = 0; c < 4; ++c) {
-		if (c < 3 || ab) {
+		if ((tx.chmask >> c) & 1u) {
 			const float fU = (float)U[c], fV = (float)V[c];
 			const float t0 = fB*fV;
 			const float n0 = fmaf(fC, fU, -t0);
@@ -335,28 +359,38 @@ __device__ __forceinline__ void assign_lsq(const uint32_t* tp, uint32_t sel, uin
 	}
 }
 
-// Vector fit of the texels selected by mask (channels zeroed by vmask are not
-// coded; ab == 0 <=> channel 3 not coded).  Mirrors fit_subset() of the oracle.
-template <bool UNITW, bool ROT>
-__device__ __forceinline__ void fit_vec(const uint32_t* tp, uint32_t sel, uint32_t vmask,
-	uint32_t mask, uint32_t cb, uint32_t ab, uint32_t pbk, uint32_t ib, uint32_t iters,
-	const uint32_t (&wt)[4], SubFit& best)
+// Vector fit of the texels selected by mask over the channels of tx.chmask.
+// Mirrors fit_subset() of the oracle.
+template <bool UNITW, bool ROT, int NKMAX>
+__device__ __forceinline__ void fit_vec(const Tex& tx, uint32_t mask, uint32_t cb, uint32_t ab,
+	uint32_t pbk, uint32_t ib, uint32_t iters, const uint32_t (&wt)[4], SubFit& best)
 {
-	// A: integer statistics of the subset
-	uint32_t n = 0, s[4] = {0, 0, 0, 0};
+	// A: integer statistics of the subset, as row dot products on the planar copy
+	const uint32_t n = (uint32_t)__builtin_popcount(mask);
+	uint32_t s[4] = {0, 0, 0, 0};
 	uint32_t q00 = 0, q01 = 0, q02 = 0, q03 = 0, q11 = 0, q12 = 0, q13 = 0, q22 = 0, q23 = 0,
 		q33 = 0;
-	for_texels(tp, [&](uint32_t raw, uint32_t i) {
-		const uint32_t p = texel<ROT>(raw, sel, vmask);
-		const uint32_t m = (mask >> i) & 1u;
-		const uint32_t p0 = m*ub(p, 0), p1 = m*ub(p, 1), p2 = m*ub(p, 2), p3 = m*ub(p, 3);
-		n += m;
-		s[0] += p0; s[1] += p1; s[2] += p2; s[3] += p3;
-		q00 += p0*p0; q01 += p0*p1; q02 += p0*p2; q03 += p0*p3;
-		q11 += p1*p1; q12 += p1*p2; q13 += p1*p3;
-		q22 += p2*p2; q23 += p2*p3;
-		q33 += p3*p3;
-	});
+#pragma unroll 1
+	for (uint32_t r = 0; r < 4u; ++r) {
+		uint32_t P[4];
+		planes<ROT>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
+		const uint32_t m4 = bytemask4((mask >> (4u*r)) & 15u);
+		const uint32_t M0 = P[0] & m4, M1 = P[1] & m4, M2 = P[2] & m4, M3 = P[3] & m4;
+		s[0] = __builtin_amdgcn_udot4(M0, 0x01010101u, s[0], false);
+		s[1] = __builtin_amdgcn_udot4(M1, 0x01010101u, s[1], false);
+		s[2] = __builtin_amdgcn_udot4(M2, 0x01010101u, s[2], false);
+		s[3] = __builtin_amdgcn_udot4(M3, 0x01010101u, s[3], false);
+		q00 = __builtin_amdgcn_udot4(M0, P[0], q00, false);
+		q01 = __builtin_amdgcn_udot4(M0, P[1], q01, false);
+		q02 = __builtin_amdgcn_udot4(M0, P[2], q02, false);
+		q03 = __builtin_amdgcn_udot4(M0, P[3], q03, false);
+		q11 = __builtin_amdgcn_udot4(M1, P[1], q11, false);
+		q12 = __builtin_amdgcn_udot4(M1, P[2], q12, false);
+		q13 = __builtin_amdgcn_udot4(M1, P[3], q13, false);
+		q22 = __builtin_amdgcn_udot4(M2, P[2], q22, false);
+		q23 = __builtin_amdgcn_udot4(M2, P[3], q23, false);
+		q33 = __builtin_amdgcn_udot4(M3, P[3], q33, false);
+	}
 	const float C00 = (float)(int)(n*q00 - s[0]*s[0]), C01 = (float)(int)(n*q01 - s[0]*s[1]);
 	const float C02 = (float)(int)(n*q02 - s[0]*s[2]), C03 = (float)(int)(n*q03 - s[0]*s[3]);
 	const float C11 = (float)(int)(n*q11 - s[1]*s[1]), C12 = (float)(int)(n*q12 - s[1]*s[2]);
@@ -397,16 +431,23 @@ __device__ __forceinline__ void fit_vec(const uint32_t* tp, uint32_t sel, uint32
 	for (int c = 0; c < 4; ++c)
 		mean[c] = (float)s[c]*in;
 	float tmin = 3.0e38f, tmax = -3.0e38f;
-	for_texels(tp, [&](uint32_t raw, uint32_t i) {
-		const uint32_t p = texel<ROT>(raw, sel, vmask);
-		const bool m = (mask >> i) & 1u;
-		float t = axis[0]*(fb(p, 0) - mean[0]);
-		t = fmaf(axis[1], fb(p, 1) - mean[1], t);
-		t = fmaf(axis[2], fb(p, 2) - mean[2], t);
-		t = fmaf(axis[3], fb(p, 3) - mean[3], t);
-		tmin = m ? fminf(tmin, t) : tmin;
-		tmax = m ? fmaxf(tmax, t) : tmax;
-	});
+#pragma unroll 1
+	for (uint32_t r = 0; r < 4u; ++r) {
+		const uint4 row = *reinterpret_cast<const uint4*>(tx.tp + 4u*r);
+		const uint32_t raw[4] = {row.x, row.y, row.z, row.w};
+		const uint32_t mrow = (mask >> (4u*r)) & 15u;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const uint32_t p = texel<ROT>(tx, raw[j]);
+			const bool m = (mrow >> j) & 1u;
+			float t = axis[0]*(fb(p, 0) - mean[0]);
+			t = fmaf(axis[1], fb(p, 1) - mean[1], t);
+			t = fmaf(axis[2], fb(p, 2) - mean[2], t);
+			t = fmaf(axis[3], fb(p, 3) - mean[3], t);
+			tmin = m ? fminf(tmin, t) : tmin;
+			tmax = m ? fmaxf(tmax, t) : tmax;
+		}
+	}
 	float x0[4], x1[4];
 #pragma unroll
 	for (int c = 0; c < 4; ++c) {
@@ -421,27 +462,34 @@ __device__ __forceinline__ void fit_vec(const uint32_t* tp, uint32_t sel, uint32
 
 	// C/D then E rounds, always restarting from the best
 	quantize(x0, x1, cb, ab, pbk, fwt, best);
-	assign_lsq<UNITW, ROT>(tp, sel, vmask, mask, ab, ib, wt, iters > 0u, best);
+	assign_lsq<UNITW, ROT, NKMAX>(tx, mask, ib, wt, iters > 0u, best);
 	for (uint32_t r = 0; r < iters; ++r) {
 		SubFit cur;
 		quantize(best.nx0, best.nx1, cb, ab, pbk, fwt, cur);
-		assign_lsq<UNITW, ROT>(tp, sel, vmask, mask, ab, ib, wt, r + 1u < iters, cur);
+		assign_lsq<UNITW, ROT, NKMAX>(tx, mask, ib, wt, r + 1u < iters, cur);
 		if (best.ok && cur.err < best.err)
 			best = cur;
 	}
 }
 
 // Scalar fit of channel 3 (after rotation) over all 16 texels: alpha plane of modes 4/5.
+// tx.chmask must be 8 (only the rotated alpha channel).
 template <bool UNITW>
-__device__ __forceinline__ void fit_scalar(const uint32_t* tp, uint32_t sel, uint32_t ab,
-	uint32_t ib, uint32_t iters, const uint32_t (&wt)[4], SubFit& best)
+__device__ __forceinline__ void fit_scalar(const Tex& tx, uint32_t ab, uint32_t ib, uint32_t iters,
+	const uint32_t (&wt)[4], SubFit& best)
 {
 	uint32_t lo = 255u, hi = 0u;
-	for_texels(tp, [&](uint32_t raw, uint32_t) {
-		const uint32_t a = texel<true>(raw, sel, 0xFF000000u) >> 24;
-		lo = a < lo ? a : lo;
-		hi = a > hi ? a : hi;
-	});
+#pragma unroll 1
+	for (uint32_t r = 0; r < 4u; ++r) {
+		const uint4 row = *reinterpret_cast<const uint4*>(tx.tp + 4u*r);
+		const uint32_t raw[4] = {row.x, row.y, row.z, row.w};
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const uint32_t a = texel<true>(tx, raw[j]) >> 24;
+			lo = a < lo ? a : lo;
+			hi = a > hi ? a : hi;
+		}
+	}
 	float x0[4] = {0.0f, 0.0f, 0.0f, (float)lo}, x1[4] = {0.0f, 0.0f, 0.0f, (float)hi};
 	float fwt[4];
 #pragma unroll
@@ -449,13 +497,286 @@ __device__ __forceinline__ void fit_scalar(const uint32_t* tp, uint32_t sel, uin
 		fwt[c] = (float)wt[c];
 	const uint32_t swt[4] = {0u, 0u, 0u, wt[3]};
 	quantize(x0, x1, 0u, ab, 0u, fwt, best);
-	assign_lsq<UNITW, true>(tp, sel, 0xFF000000u, 0xFFFFu, ab, ib, swt, iters > 0u, best);
+	assign_lsq<UNITW, true, 8>(tx, 0xFFFFu, ib, swt, iters > 0u, best);
 	for (uint32_t r = 0; r < iters; ++r) {
 		SubFit cur;
-		best.nx0[0] = best.nx0[1] = best.nx0[2] = 0.0f;
-		best.nx1[0] = best.nx1[1] = best.nx1[2] = 0.0f;
 		quantize(best.nx0, best.nx1, 0u, ab, 0u, fwt, cur);
-		assign_lsq<UNITW, true>(tp, sel, 0xFF000000u, 0xFFFFu, ab, ib, swt, r + 1u < iters, cur);
+		assign_lsq<UNITW, true, 8>(tx, 0xFFFFu, ib, swt, r + 1u < iters, cur);
+		if (best.ok && cur.err < best.err)
+			best = cur;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// Row-split fits for the single-subset pass: one candidate is spread over 4 lanes
+// (lane = texel row), mode 6 additionally over 2 palette halves (lane ^ 4).  Sums
+// are integers, so the 4-lane reductions are exact and every lane of a group
+// continues with identical values; min/max of floats are exact as well.  This is
+// the same arithmetic as fit_vec/fit_scalar, only distributed differently.
+
+struct RowFit {
+	uint32_t e0, e1, q0, q1, pb, err;
+	uint32_t wrow;          // weights of this lane's row
+	float nx0[4], nx1[4];
+	bool ok;
+};
+
+__device__ __forceinline__ uint32_t quad_sum(uint32_t v)
+{
+	v += (uint32_t)__shfl_xor((int)v, 1, 64);
+	v += (uint32_t)__shfl_xor((int)v, 2, 64);
+	return v;
+}
+
+template <bool UNITW>
+__device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t row, bool m6,
+	uint32_t khalf, uint32_t ib, const uint32_t (&wt)[4], bool want_lsq, RowFit& f)
+{
+	const uint32_t nk = m6 ? 8u : (1u << ib), kbase = m6 ? 8u*khalf : 0u;
+	const uint32_t e00 = ub(f.e0, 0), e01 = ub(f.e0, 1), e02 = ub(f.e0, 2), e03 = ub(f.e0, 3);
+	const uint32_t e10 = ub(f.e1, 0), e11 = ub(f.e1, 1), e12 = ub(f.e1, 2), e13 = ub(f.e1, 3);
+	uint32_t pal[8];
+	int base[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		pal[k] = 0;
+		base[k] = 0;
+		if ((uint32_t)k < nk) {
+			const uint32_t w = bc7_weight(ib, kbase + (uint32_t)k), iw = 64u - w;
+			const uint32_t c0 = (iw*e00 + w*e10 + 32u) >> 6;
+			const uint32_t c1 = (iw*e01 + w*e11 + 32u) >> 6;
+			const uint32_t c2 = (iw*e02 + w*e12 + 32u) >> 6;
+			const uint32_t c3 = (iw*e03 + w*e13 + 32u) >> 6;
+			pal[k] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+			base[k] = UNITW ? (int)((__builtin_amdgcn_udot4(pal[k], pal[k], 0u, false) << 7) | w)
+				: (int)w;
+		}
+	}
+	const uint4 rw = *reinterpret_cast<const uint4*>(tx.tp + 4u*row);
+	const uint32_t raw[4] = {rw.x, rw.y, rw.z, rw.w};
+	uint32_t err = 0, wrow = 0;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const uint32_t p = texel<true>(tx, raw[j]);
+		uint32_t key;
+		if (UNITW) {
+			int bestk = 0x7FFFFFFF;
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				if ((uint32_t)k < nk) {
+					const int dt = (int)__builtin_amdgcn_udot4(p, pal[k], 0u, false);
+					const int v = base[k] - (dt << 8);
+					bestk = v < bestk ? v : bestk;
+				}
+			}
+			key = (uint32_t)bestk + (__builtin_amdgcn_udot4(p, p, 0u, false) << 7);
+		} else {
+			key = 0xFFFFFFFFu;
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				if ((uint32_t)k < nk) {
+					const int d0 = (int)ub(p, 0) - (int)ub(pal[k], 0);
+					const int d1 = (int)ub(p, 1) - (int)ub(pal[k], 1);
+					const int d2 = (int)ub(p, 2) - (int)ub(pal[k], 2);
+					const int d3 = (int)ub(p, 3) - (int)ub(pal[k], 3);
+					const uint32_t dist = wt[0]*(uint32_t)(d0*d0) + wt[1]*(uint32_t)(d1*d1) +
+						wt[2]*(uint32_t)(d2*d2) + wt[3]*(uint32_t)(d3*d3);
+					const uint32_t v = (dist << 7) | (uint32_t)base[k];
+					key = v < key ? v : key;
+				}
+			}
+		}
+		// mode 6: the other palette half lives in lane ^ 4
+		const uint32_t other = (uint32_t)__shfl_xor((int)key, 4, 64);
+		key = (m6 && other < key) ? other : key;
+		err += key >> 7;
+		wrow |= (key & 127u) << (8*j);
+	}
+	f.err = quad_sum(err);
+	f.wrow = wrow;
+
+	uint32_t S = 0, A = 0, B = 0, C = 0, U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
+	if (want_lsq) {
+		const uint32_t iwrow = 0x40404040u - wrow;
+		uint32_t P[4];
+		planes<true>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*row), P);
+		S = quad_sum(__builtin_amdgcn_udot4(wrow, 0x01010101u, 0u, false));
+		A = quad_sum(__builtin_amdgcn_udot4(iwrow, iwrow, 0u, false));
+		B = quad_sum(__builtin_amdgcn_udot4(iwrow, wrow, 0u, false));
+		C = quad_sum(__builtin_amdgcn_udot4(wrow, wrow, 0u, false));
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			U[c] = quad_sum(__builtin_amdgcn_udot4(iwrow, P[c], 0u, false));
+			V[c] = quad_sum(__builtin_amdgcn_udot4(wrow, P[c], 0u, false));
+		}
+	}
+	const int det = (int)(16u*C) - (int)(S*S);
+	f.ok = det > 0;
+	const float inv = 1.0f/(64.0f*(float)(det > 0 ? det : 1));
+	const float fA = (float)A, fB = (float)B, fC = (float)C;
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		if ((tx.chmask >> c) & 1u) {
+			const float fU = (float)U[c], fV = (float)V[c];
+			const float t0 = fB*fV;
+			const float n0 = fmaf(fC, fU, -t0);
+			const float t1 = fB*fU;
+			const float n1 = fmaf(fA, fV, -t1);
+			f.nx0[c] = clamp255(n0*inv);
+			f.nx1[c] = clamp255(n1*inv);
+		} else {
+			f.nx0[c] = 0.0f;
+			f.nx1[c] = 0.0f;
+		}
+	}
+}
+
+template <bool UNITW>
+__device__ __forceinline__ void fit_vec_rows(const Tex& tx, uint32_t row, bool m6, uint32_t khalf,
+	uint32_t cb, uint32_t ab, uint32_t pbk, uint32_t ib, uint32_t iters,
+	const uint32_t (&wt)[4], RowFit& best)
+{
+	// A: statistics of the whole block (every lane of the group computes them)
+	uint32_t s[4] = {0, 0, 0, 0};
+	uint32_t q00 = 0, q01 = 0, q02 = 0, q03 = 0, q11 = 0, q12 = 0, q13 = 0, q22 = 0, q23 = 0,
+		q33 = 0;
+#pragma unroll 1
+	for (uint32_t r = 0; r < 4u; ++r) {
+		uint32_t P[4];
+		planes<true>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
+		s[0] = __builtin_amdgcn_udot4(P[0], 0x01010101u, s[0], false);
+		s[1] = __builtin_amdgcn_udot4(P[1], 0x01010101u, s[1], false);
+		s[2] = __builtin_amdgcn_udot4(P[2], 0x01010101u, s[2], false);
+		s[3] = __builtin_amdgcn_udot4(P[3], 0x01010101u, s[3], false);
+		q00 = __builtin_amdgcn_udot4(P[0], P[0], q00, false);
+		q01 = __builtin_amdgcn_udot4(P[0], P[1], q01, false);
+		q02 = __builtin_amdgcn_udot4(P[0], P[2], q02, false);
+		q03 = __builtin_amdgcn_udot4(P[0], P[3], q03, false);
+		q11 = __builtin_amdgcn_udot4(P[1], P[1], q11, false);
+		q12 = __builtin_amdgcn_udot4(P[1], P[2], q12, false);
+		q13 = __builtin_amdgcn_udot4(P[1], P[3], q13, false);
+		q22 = __builtin_amdgcn_udot4(P[2], P[2], q22, false);
+		q23 = __builtin_amdgcn_udot4(P[2], P[3], q23, false);
+		q33 = __builtin_amdgcn_udot4(P[3], P[3], q33, false);
+	}
+	const uint32_t n = 16u;
+	const float C00 = (float)(int)(n*q00 - s[0]*s[0]), C01 = (float)(int)(n*q01 - s[0]*s[1]);
+	const float C02 = (float)(int)(n*q02 - s[0]*s[2]), C03 = (float)(int)(n*q03 - s[0]*s[3]);
+	const float C11 = (float)(int)(n*q11 - s[1]*s[1]), C12 = (float)(int)(n*q12 - s[1]*s[2]);
+	const float C13 = (float)(int)(n*q13 - s[1]*s[3]), C22 = (float)(int)(n*q22 - s[2]*s[2]);
+	const float C23 = (float)(int)(n*q23 - s[2]*s[3]), C33 = (float)(int)(n*q33 - s[3]*s[3]);
+
+	float bestd = C00;
+	float v0 = C00, v1 = C01, v2 = C02, v3 = C03;
+	if (C11 > bestd) { bestd = C11; v0 = C01; v1 = C11; v2 = C12; v3 = C13; }
+	if (C22 > bestd) { bestd = C22; v0 = C02; v1 = C12; v2 = C22; v3 = C23; }
+	if (C33 > bestd) { bestd = C33; v0 = C03; v1 = C13; v2 = C23; v3 = C33; }
+#pragma unroll
+	for (int it = 0; it < 3; ++it) {
+		float r0 = C00*v0; r0 = fmaf(C01, v1, r0); r0 = fmaf(C02, v2, r0); r0 = fmaf(C03, v3, r0);
+		float r1 = C01*v0; r1 = fmaf(C11, v1, r1); r1 = fmaf(C12, v2, r1); r1 = fmaf(C13, v3, r1);
+		float r2 = C02*v0; r2 = fmaf(C12, v1, r2); r2 = fmaf(C22, v2, r2); r2 = fmaf(C23, v3, r2);
+		float r3 = C03*v0; r3 = fmaf(C13, v1, r3); r3 = fmaf(C23, v2, r3); r3 = fmaf(C33, v3, r3);
+		v0 = r0; v1 = r1; v2 = r2; v3 = r3;
+	}
+	const float mx = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
+	float axis[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+	if (mx > 0.0f) {
+		const float im = 1.0f/mx;
+		v0 = v0*im; v1 = v1*im; v2 = v2*im; v3 = v3*im;
+		float l2 = v0*v0;
+		l2 = fmaf(v1, v1, l2);
+		l2 = fmaf(v2, v2, l2);
+		l2 = fmaf(v3, v3, l2);
+		const float is = 1.0f/sqrtf(l2);
+		axis[0] = v0*is; axis[1] = v1*is; axis[2] = v2*is; axis[3] = v3*is;
+	}
+
+	// B: projection extremes: own row, then exact min/max over the 4 lanes
+	const float in = 1.0f/(float)n;
+	float mean[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c)
+		mean[c] = (float)s[c]*in;
+	float tmin = 3.0e38f, tmax = -3.0e38f;
+	{
+		const uint4 rw = *reinterpret_cast<const uint4*>(tx.tp + 4u*row);
+		const uint32_t raw[4] = {rw.x, rw.y, rw.z, rw.w};
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const uint32_t p = texel<true>(tx, raw[j]);
+			float t = axis[0]*(fb(p, 0) - mean[0]);
+			t = fmaf(axis[1], fb(p, 1) - mean[1], t);
+			t = fmaf(axis[2], fb(p, 2) - mean[2], t);
+			t = fmaf(axis[3], fb(p, 3) - mean[3], t);
+			tmin = fminf(tmin, t);
+			tmax = fmaxf(tmax, t);
+		}
+		tmin = fminf(tmin, __shfl_xor(tmin, 1, 64));
+		tmin = fminf(tmin, __shfl_xor(tmin, 2, 64));
+		tmax = fmaxf(tmax, __shfl_xor(tmax, 1, 64));
+		tmax = fmaxf(tmax, __shfl_xor(tmax, 2, 64));
+	}
+	float x0[4], x1[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		x0[c] = clamp255(fmaf(axis[c], tmin, mean[c]));
+		x1[c] = clamp255(fmaf(axis[c], tmax, mean[c]));
+	}
+	float fwt[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c)
+		fwt[c] = (float)wt[c];
+
+	SubFit q;
+	quantize(x0, x1, cb, ab, pbk, fwt, q);
+	best.e0 = q.e0; best.e1 = q.e1; best.q0 = q.q0; best.q1 = q.q1; best.pb = q.pb;
+	assign_lsq_rows<UNITW>(tx, row, m6, khalf, ib, wt, iters > 0u, best);
+	for (uint32_t r = 0; r < iters; ++r) {
+		RowFit cur;
+		quantize(best.nx0, best.nx1, cb, ab, pbk, fwt, q);
+		cur.e0 = q.e0; cur.e1 = q.e1; cur.q0 = q.q0; cur.q1 = q.q1; cur.pb = q.pb;
+		assign_lsq_rows<UNITW>(tx, row, m6, khalf, ib, wt, r + 1u < iters, cur);
+		if (best.ok && cur.err < best.err)
+			best = cur;
+	}
+}
+
+template <bool UNITW>
+__device__ __forceinline__ void fit_scalar_rows(const Tex& tx, uint32_t row, uint32_t ab,
+	uint32_t ib, uint32_t iters, const uint32_t (&wt)[4], RowFit& best)
+{
+	uint32_t lo = 255u, hi = 0u;
+	{
+		const uint4 rw = *reinterpret_cast<const uint4*>(tx.tp + 4u*row);
+		const uint32_t raw[4] = {rw.x, rw.y, rw.z, rw.w};
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const uint32_t a = texel<true>(tx, raw[j]) >> 24;
+			lo = a < lo ? a : lo;
+			hi = a > hi ? a : hi;
+		}
+		uint32_t o;
+		o = (uint32_t)__shfl_xor((int)lo, 1, 64); lo = o < lo ? o : lo;
+		o = (uint32_t)__shfl_xor((int)lo, 2, 64); lo = o < lo ? o : lo;
+		o = (uint32_t)__shfl_xor((int)hi, 1, 64); hi = o > hi ? o : hi;
+		o = (uint32_t)__shfl_xor((int)hi, 2, 64); hi = o > hi ? o : hi;
+	}
+	float x0[4] = {0.0f, 0.0f, 0.0f, (float)lo}, x1[4] = {0.0f, 0.0f, 0.0f, (float)hi};
+	float fwt[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c)
+		fwt[c] = (float)wt[c];
+	const uint32_t swt[4] = {0u, 0u, 0u, wt[3]};
+	SubFit q;
+	quantize(x0, x1, 0u, ab, 0u, fwt, q);
+	best.e0 = q.e0; best.e1 = q.e1; best.q0 = q.q0; best.q1 = q.q1; best.pb = q.pb;
+	assign_lsq_rows<UNITW>(tx, row, false, 0u, ib, swt, iters > 0u, best);
+	for (uint32_t r = 0; r < iters; ++r) {
+		RowFit cur;
+		quantize(best.nx0, best.nx1, 0u, ab, 0u, fwt, q);
+		cur.e0 = q.e0; cur.e1 = q.e1; cur.q0 = q.q0; cur.q1 = q.q1; cur.pb = q.pb;
+		assign_lsq_rows<UNITW>(tx, row, false, 0u, ib, swt, r + 1u < iters, cur);
 		if (best.ok && cur.err < best.err)
 			best = cur;
 	}
@@ -617,8 +938,8 @@ __device__ __forceinline__ uint4 pack_block(const Cand& c)
 // Encode one block with the whole wavefront.  tp: the block's 16 texels in LDS
 // (colour mask already applied), identical for every lane.
 template <bool UNITW>
-__device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const cf_kparams& kp,
-	uint32_t lane, bool& is_winner)
+__device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t* pl,
+	const cf_kparams& kp, uint32_t lane, bool& is_winner)
 {
 	const bool has_alpha = __ballot(lane < 16u && (tp[lane & 15u] >> 24) != 255u) != 0ull;
 	const uint32_t quality = kp.quality;
@@ -634,22 +955,25 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const cf_kpara
 #pragma unroll
 	for (int k = 0; k < 4; ++k) { best.w[k] = 0; best.w2[k] = 0; }
 
-	// ---- pass 0: single-subset modes, lane = (mode, rotation, index selector) ----
+	// ---- pass 0: single-subset modes, 4 lanes per candidate (lane = texel row) ----
+	//   lanes 0..7  : mode 6, row = lane & 3, palette half = lane >> 2
+	//   lanes 8..55 : candidate 1 + (lane-8)/4 (mode 5 x rot, mode 4 x rot x isel), row = lane & 3
 	{
+		const uint32_t row = lane & 3u;
+		const bool m6 = lane < 8u;
+		const uint32_t cid = m6 ? 0u : 1u + ((lane - 8u) >> 2);      // candidate id 0..12 (13+: idle)
 		uint32_t rot = 0, isel = 0, cb = 7, abv = 7, absc = 0, pbk = 1, ibc = 4, iba = 0;
-		bool active = lane == 0u;
-		if (lane >= 1u && lane <= 4u) {
-			rot = lane - 1u; cb = 7; abv = 0; absc = 8; pbk = 0; ibc = 2; iba = 2;
-			active = quality >= 2u || (quality == 1u ? lane == 1u : (lane == 1u && has_alpha));
-		} else if (lane >= 5u && lane <= 12u) {
-			rot = (lane - 5u) & 3u; isel = (lane - 5u) >> 2;
+		bool active = m6;
+		if (cid >= 1u && cid <= 4u) {
+			rot = cid - 1u; cb = 7; abv = 0; absc = 8; pbk = 0; ibc = 2; iba = 2;
+			active = quality >= 2u || (quality == 1u ? cid == 1u : (cid == 1u && has_alpha));
+		} else if (cid >= 5u && cid <= 12u) {
+			rot = (cid - 5u) & 3u; isel = (cid - 5u) >> 2;
 			cb = 5; abv = 0; absc = 6; pbk = 0;
 			ibc = isel ? 3u : 2u; iba = isel ? 2u : 3u;
 			active = quality >= 2u;
-		}
-		const uint32_t sel = rot == 0u ? 0x03020100u : (rot == 1u ? 0x00020103u :
-			(rot == 2u ? 0x01020300u : 0x02030100u));
-		const uint32_t vmask = abv ? 0xFFFFFFFFu : 0x00FFFFFFu;
+		} else if (cid > 12u)
+			active = false;
 		uint32_t wl[4] = {wt[0], wt[1], wt[2], wt[3]};
 		if (!UNITW && rot) {
 			const uint32_t t3 = wl[3];
@@ -657,28 +981,34 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const cf_kpara
 			else if (rot == 2u) { wl[3] = wl[1]; wl[1] = t3; }
 			else { wl[3] = wl[2]; wl[2] = t3; }
 		}
-		// only the lanes that hold a candidate run
-		if (active) {
-			SubFit fv;
+		if (active) {   // groups of 4 (mode 6: 8) lanes are active together
+			RowFit fv;
 			const uint32_t wv[4] = {wl[0], wl[1], wl[2], abv ? wl[3] : 0u};
-			fit_vec<UNITW, true>(tp, sel, vmask, 0xFFFFu, cb, abv, pbk, ibc, iters, wv, fv);
+			fit_vec_rows<UNITW>(make_tex(tp, pl, rot, abv ? 15u : 7u), row, m6, lane >> 2, cb, abv,
+				pbk, ibc, iters, wv, fv);
 			Cand c;
 			c.err = fv.err;
-			c.id = lane;
+			c.id = cid;
 			c.q[0] = fv.q0; c.q[1] = fv.q1; c.q[2] = 0; c.q[3] = 0; c.q[4] = 0; c.q[5] = 0;
 			c.pb = fv.pb;
+			const int g0 = (int)(lane & ~3u);
 #pragma unroll
-			for (int k = 0; k < 4; ++k) { c.w[k] = fv.w[k]; c.w2[k] = 0; }
+			for (int k = 0; k < 4; ++k) {
+				c.w[k] = (uint32_t)__shfl((int)fv.wrow, g0 + k, 64);
+				c.w2[k] = 0;
+			}
 			if (absc) {
-				SubFit fs;
-				fit_scalar<UNITW>(tp, sel, absc, iba, iters, wl, fs);
+				RowFit fs;
+				fit_scalar_rows<UNITW>(make_tex(tp, pl, rot, 8u), row, absc, iba, iters, wl, fs);
 				c.err += fs.err;
 				c.q[4] = fs.q0 & 0xFF000000u;   // parked for pack_block
 				c.q[5] = fs.q1 & 0xFF000000u;
 #pragma unroll
-				for (int k = 0; k < 4; ++k) c.w2[k] = fs.w[k];
+				for (int k = 0; k < 4; ++k)
+					c.w2[k] = (uint32_t)__shfl((int)fs.wrow, g0 + k, 64);
 			}
-			if (c.err < best.err)
+			// one lane per candidate registers it
+			if ((m6 ? lane == 0u : row == 0u) && c.err < best.err)
 				best = c;
 		}
 	}
@@ -717,7 +1047,7 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const cf_kpara
 				case 2: ns = 3; cb = 5; ab = 0; pbk = 0; ib = 2; npart = 64; idbase = 256; break;
 				default: ns = 2; cb = 5; ab = 5; pbk = 1; ib = 2; npart = 64; idbase = 320; break;
 			}
-			const uint32_t vmask = ab ? 0xFFFFFFFFu : 0x00FFFFFFu;   // opaque modes do not code alpha
+			const Tex tx = make_tex(tp, pl, 0u, ab ? 15u : 7u);   // opaque modes do not code alpha
 			Cand c;
 			c.err = 0;
 			c.id = idbase + lane;
@@ -734,7 +1064,7 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const cf_kpara
 				else
 					mask = s == 0u ? m30 : (s == 1u ? m31 : m32);
 				SubFit f;
-				fit_vec<UNITW, false>(tp, 0u, vmask, mask, cb, ab, pbk, ib, iters, wv, f);
+				fit_vec<UNITW, false, 8>(tx, mask, cb, ab, pbk, ib, iters, wv, f);
 				c.err += f.err;
 				if (s == 0u) { c.q[0] = f.q0; c.q[1] = f.q1; c.pb |= f.pb; }
 				else if (s == 1u) { c.q[2] = f.q0; c.q[3] = f.q1; c.pb |= f.pb << 2; }
@@ -768,10 +1098,19 @@ __global__ void __launch_bounds__(CF_WG_THREADS) __attribute__((amdgpu_waves_per
 cfhip_bc7_encode_kernel(cf_kparams kp)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t tile[CF_BLOCKS_PER_WG*16];
+	__shared__ __attribute__((aligned(16))) uint32_t plan[CF_BLOCKS_PER_WG*16];
 	__shared__ uint4 outb[CF_BLOCKS_PER_WG];
 	const uint32_t bx0 = blockIdx.x*CF_BLOCKS_PER_WG;
 	const uint32_t byy = blockIdx.y;
 	cf_load_tile_rgba8<PIX>(kp, bx0, byy, tile);
+	__syncthreads();
+	{
+		// channel-planar copy: plan[b*16 + r*4 + c] = channel c of the 4 texels of row r
+		const uint32_t t = threadIdx.x, c = t & 3u;
+		const uint4 row = *reinterpret_cast<const uint4*>(tile + (t & ~3u));
+		plan[t] = ((row.x >> (8u*c)) & 255u) | (((row.y >> (8u*c)) & 255u) << 8) |
+			(((row.z >> (8u*c)) & 255u) << 16) | (((row.w >> (8u*c)) & 255u) << 24);
+	}
 	__syncthreads();
 
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -780,7 +1119,7 @@ cfhip_bc7_encode_kernel(cf_kparams kp)
 		if (bx0 + b >= kp.bx)
 			break;
 		bool win;
-		const uint4 blk = encode_block<UNITW>(tile + b*16u, kp, lane, win);
+		const uint4 blk = encode_block<UNITW>(tile + b*16u, plan + b*16u, kp, lane, win);
 		if (win)
 			outb[b] = blk;
 	}
