@@ -18,6 +18,8 @@
 
 extern "C" hipError_t cfhip_launch_bc7(const cf_kparams* kp, int pixel_type, int unit_weights,
 	hipStream_t stream);
+extern "C" hipError_t cfhip_launch_bc6h(const cf_kparams* kp, int pixel_type, int is_signed,
+	hipStream_t stream);
 extern "C" hipError_t cfhip_launch_bc15(const cf_kparams* kp, int format, int pixel_type,
 	int snorm, hipStream_t stream);
 
@@ -106,6 +108,7 @@ bool format_implemented(int format, int type)
 		case CFHIP_FORMAT_BC3:
 		case CFHIP_FORMAT_BC4:
 		case CFHIP_FORMAT_BC5:
+		case CFHIP_FORMAT_BC6H:
 		case CFHIP_FORMAT_BC7:
 			return true;
 		default:
@@ -189,6 +192,10 @@ int launch(cfhip_ctx* ctx, const cf_kparams& kp, const cfhip_params& p, int pixe
 			ctx->last_kernel = "cfhip_bc7_encode_kernel";
 			break;
 		}
+		case CFHIP_FORMAT_BC6H:
+			e = cfhip_launch_bc6h(&kp, pixel_type, p.type == CFHIP_TYPE_FLOAT ? 1 : 0, stream);
+			ctx->last_kernel = "cfhip_bc6h_encode_kernel";
+			break;
 		case CFHIP_FORMAT_BC1_RGB:
 		case CFHIP_FORMAT_BC1_RGBA:
 		case CFHIP_FORMAT_BC2:

@@ -103,6 +103,43 @@ def photo(width: int, height: int, seed: int = 1, alpha: bool = True) -> np.ndar
     return np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)
 
 
+def hdr_probe(width: int, height: int, seed: int = 4, signed: bool = False) -> np.ndarray:
+    """HDR RGBA16F probe: exp2(12*noise - 6) (2^-6..2^6) with weak
+    chroma variation plus four gaussian "suns" peaking near 6e4; alpha = 1.  signed=True
+    flips the sign of one quadrant-sized region (BC6H SF16 inputs)."""
+    rng = np.random.default_rng(SEED_BASE + 1000 + seed)
+    lum = _fbm(rng, width, height)
+    img = np.empty((height, width, 4), np.float64)
+    for c in range(3):
+        chroma = _fbm(rng, width, height, base_cell=128, octaves=4)
+        img[..., c] = np.exp2(12.0 * lum - 6.0) * (0.6 + 0.8 * chroma)
+    yy, xx = np.mgrid[0:height, 0:width]
+    for _ in range(4):
+        cx, cy = rng.integers(0, width), rng.integers(0, height)
+        sig = max(width, height) / float(rng.integers(24, 64))
+        g = np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * sig * sig))
+        col = 0.5 + 0.5 * rng.random(3)
+        img[..., :3] += 6.0e4 * g[..., None] * col
+    img[..., :3] = np.minimum(img[..., :3], 65000.0)
+    if signed:
+        img[: height // 2, : width // 2, :3] *= -1.0
+    img[..., 3] = 1.0
+    return img.astype(np.float16)
+
+
+def psnr_log(ref_half: np.ndarray, dec_half: np.ndarray) -> float:
+    """PSNR of log2(1+|x|)*sign(x) mapped RGB (SURVEY.md 8d HDR metric), peak = log2(1+65504)."""
+    def m(x):
+        x = x[..., :3].astype(np.float64)
+        return np.sign(x) * np.log2(1.0 + np.abs(x))
+    d = m(ref_half) - m(dec_half)
+    mse = float(np.mean(d * d))
+    if mse == 0.0:
+        return 99.0
+    peak = np.log2(1.0 + 65504.0)
+    return float(10.0 * np.log10(peak * peak / mse))
+
+
 def psnr(a: np.ndarray, b: np.ndarray, channels=slice(0, 4)) -> float:
     d = a[..., channels].astype(np.float64) - b[..., channels].astype(np.float64)
     mse = float(np.mean(d * d))

@@ -69,6 +69,12 @@ void cfo_decode_bc4u(const uint8_t* blk, uint8_t* out16);
 void cfo_decode_bc4s(const uint8_t* blk, int8_t* out16);
 void cfo_decode_bc7(const uint8_t* blk, uint8_t* rgba64);
 
+/* BC6H: flags bit0 signed, bit1 Pillow-compat (tests only); out = 16 x RGB half bits */
+int cfo_decode_bc6h(const uint8_t* blk, int flags, uint16_t* rgb48);
+int cfo_decode_bc6h_image(const void* blocks, int type, uint32_t width, uint32_t height,
+	uint16_t* rgb_out);
+uint16_t cfo_float_to_half(float f);
+
 /* single-block encoders (inputs already quantised as the reference does) */
 void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p);
 

@@ -19,6 +19,8 @@
 void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p);
 int cfo_encode_bc15_block(const float rgbaf[64], const uint8_t rgba[64], uint8_t* out,
 	const cfo_params* p);
+void cfo_encode_bc6h_block(const uint16_t rgba_half[64], uint8_t out[16], const cfo_params* p);
+int cfo_decode_bc6h(const uint8_t* blk, int flags, uint16_t* rgb48);
 
 typedef struct {
 	const uint8_t* pixels;
@@ -51,6 +53,29 @@ static float half_to_float(uint16_t h)
 	float f;
 	memcpy(&f, &bits, 4);
 	return f;
+}
+
+/* float -> half, round to nearest even (F16C imm 0; lib/src/HalfFloat.h:96-136) */
+uint16_t cfo_float_to_half(float f)
+{
+	uint32_t x;
+	memcpy(&x, &f, 4);
+	uint32_t sign = (x >> 16) & 0x8000u, em = x & 0x7FFFFFFFu;
+	if (em >= 0x7F800000u)                       /* Inf / NaN */
+		return (uint16_t)(sign | 0x7C00u | (em > 0x7F800000u ? 0x200u | ((em >> 13) & 0x3FFu) : 0u));
+	if (em >= 0x477FF000u)                       /* rounds to >= 65520 -> Inf */
+		return (uint16_t)(sign | 0x7C00u);
+	if (em < 0x33000001u)                        /* < 2^-25 (or exactly 2^-25: ties to even 0) */
+		return (uint16_t)sign;
+	int e = (int)(em >> 23) - 127;
+	uint32_t m = (em & 0x7FFFFFu) | 0x800000u;
+	int shift = e < -14 ? 13 + (-14 - e) : 13;   /* denormal halves shift further */
+	uint32_t hm = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+	if (rem > half || (rem == half && (hm & 1u)))
+		++hm;
+	uint32_t he = e < -14 ? 0u : (uint32_t)(e + 15) << 10;
+	/* hm carries its implicit bit for normals; adding handles mantissa overflow into the exponent */
+	return (uint16_t)(sign | (e < -14 ? hm : (he + hm - 0x400u)));
 }
 
 static uint8_t unorm8(float f)
@@ -104,7 +129,27 @@ static void* worker(void* arg)
 		uint8_t u[64];
 		gather(j, x, y, f, u);
 		uint8_t* dst = j->out + (size_t)job*(size_t)j->bytes;
-		if (j->p->format == CFO_FMT_BC7)
+		if (j->p->format == CFO_FMT_BC6H) {
+			/* packHalfFloatBlockHardware (S3tcConverter.cpp:113-129): fp32 -> fp16 RNE;
+			 * RGBA16F sources are passed through bit-exactly */
+			uint16_t hb[64];
+			for (uint32_t r = 0; r < 4; ++r) {
+				uint32_t sy = y*4 + r;
+				if (sy > j->height - 1) sy = j->height - 1;
+				const uint8_t* row = j->pixels + (ptrdiff_t)sy*j->pitch;
+				for (uint32_t c = 0; c < 4; ++c) {
+					uint32_t sx = x*4 + c;
+					if (sx > j->width - 1) sx = j->width - 1;
+					for (int k = 0; k < 4; ++k) {
+						if (j->pixel_type == CFO_PIX_RGBA16F)
+							hb[(r*4 + c)*4 + k] = ((const uint16_t*)(row + (size_t)sx*8))[k];
+						else
+							hb[(r*4 + c)*4 + k] = cfo_float_to_half(f[(r*4 + c)*4 + k]);
+					}
+				}
+			}
+			cfo_encode_bc6h_block(hb, dst, j->p);
+		} else if (j->p->format == CFO_FMT_BC7)
 			cfo_encode_bc7_block(u, dst, j->p);
 		else if (cfo_encode_bc15_block(f, u, dst, j->p) != 0)
 			j->status = -1;
@@ -152,4 +197,21 @@ int cfo_encode(const void* pixels, int pixel_type, uint32_t width, uint32_t heig
 	for (unsigned i = 0; i < started; ++i)
 		pthread_join(th[i], NULL);
 	return j.status;
+}
+
+/* Decode a BC6H payload to RGB half-float bit patterns (w*h*3 uint16). */
+int cfo_decode_bc6h_image(const void* blocks, int type, uint32_t width, uint32_t height,
+	uint16_t* rgb_out)
+{
+	uint32_t bx = (width + 3)/4, by = (height + 3)/4;
+	const uint8_t* src = (const uint8_t*)blocks;
+	for (uint32_t y = 0; y < by; ++y)
+		for (uint32_t x = 0; x < bx; ++x) {
+			uint16_t px[48];
+			cfo_decode_bc6h(src + ((size_t)y*bx + x)*16, type == CFO_TYPE_FLOAT ? 1 : 0, px);
+			for (uint32_t j = 0; j < 4 && y*4 + j < height; ++j)
+				for (uint32_t i = 0; i < 4 && x*4 + i < width; ++i)
+					memcpy(rgb_out + (((size_t)y*4 + j)*width + x*4 + i)*3, px + (j*4 + i)*3, 6);
+		}
+	return 0;
 }

@@ -94,6 +94,19 @@ def encode(img: np.ndarray, fmt, typ=0, quality=2, threads=1, **kw) -> np.ndarra
     return out
 
 
+def decode_bc6h(blocks: np.ndarray, width: int, height: int, typ=4) -> np.ndarray:
+    """-> (h, w, 3) float16 (typ 4 = UFloat, 5 = Float)."""
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
+    out = np.zeros((height, width, 3), np.uint16)
+    L = lib()
+    L.cfo_decode_bc6h_image.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32,
+                                        ctypes.c_uint32, ctypes.c_void_p]
+    rc = L.cfo_decode_bc6h_image(blocks.ctypes.data, int(typ), width, height, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("cfo_decode_bc6h_image failed: %d" % rc)
+    return out.view(np.float16)
+
+
 def decode(blocks: np.ndarray, fmt, width: int, height: int, typ=0) -> np.ndarray:
     blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
     out = np.zeros((height, width, 4), np.uint8)
