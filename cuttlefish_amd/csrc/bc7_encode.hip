@@ -528,8 +528,8 @@ __device__ __forceinline__ uint32_t quad_sum(uint32_t v)
 	return v;
 }
 
-template <bool UNITW>
-__device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t row, bool m6,
+template <bool UNITW, bool ROT>
+__device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t mask, uint32_t row, bool m6,
 	uint32_t khalf, uint32_t ib, const uint32_t (&wt)[4], bool want_lsq, RowFit& f)
 {
 	const uint32_t nk = m6 ? 8u : (1u << ib), kbase = m6 ? 8u*khalf : 0u;
@@ -554,10 +554,11 @@ __device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t row, boo
 	}
 	const uint4 rw = *reinterpret_cast<const uint4*>(tx.tp + 4u*row);
 	const uint32_t raw[4] = {rw.x, rw.y, rw.z, rw.w};
+	const uint32_t mrow = (mask >> (4u*row)) & 15u;
 	uint32_t err = 0, wrow = 0;
 #pragma unroll
 	for (int j = 0; j < 4; ++j) {
-		const uint32_t p = texel<true>(tx, raw[j]);
+		const uint32_t p = texel<ROT>(tx, raw[j]);
 		uint32_t key;
 		if (UNITW) {
 			int bestk = 0x7FFFFFFF;
@@ -589,17 +590,18 @@ __device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t row, boo
 		// mode 6: the other palette half lives in lane ^ 4
 		const uint32_t other = (uint32_t)__shfl_xor((int)key, 4, 64);
 		key = (m6 && other < key) ? other : key;
-		err += key >> 7;
-		wrow |= (key & 127u) << (8*j);
+		const bool m = (mrow >> j) & 1u;
+		err += m ? (key >> 7) : 0u;
+		wrow |= (m ? (key & 127u) : 0u) << (8*j);
 	}
 	f.err = quad_sum(err);
 	f.wrow = wrow;
 
 	uint32_t S = 0, A = 0, B = 0, C = 0, U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
 	if (want_lsq) {
-		const uint32_t iwrow = 0x40404040u - wrow;
+		const uint32_t iwrow = (0x40404040u - wrow) & bytemask4(mrow);
 		uint32_t P[4];
-		planes<true>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*row), P);
+		planes<ROT>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*row), P);
 		S = quad_sum(__builtin_amdgcn_udot4(wrow, 0x01010101u, 0u, false));
 		A = quad_sum(__builtin_amdgcn_udot4(iwrow, iwrow, 0u, false));
 		B = quad_sum(__builtin_amdgcn_udot4(iwrow, wrow, 0u, false));
@@ -610,7 +612,7 @@ __device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t row, boo
 			V[c] = quad_sum(__builtin_amdgcn_udot4(wrow, P[c], 0u, false));
 		}
 	}
-	const int det = (int)(16u*C) - (int)(S*S);
+	const int det = (int)((uint32_t)__builtin_popcount(mask)*C) - (int)(S*S);
 	f.ok = det > 0;
 	const float inv = 1.0f/(64.0f*(float)(det > 0 ? det : 1));
 	const float fA = (float)A, fB = (float)B, fC = (float)C;
@@ -631,35 +633,37 @@ __device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t row, boo
 	}
 }
 
-template <bool UNITW>
-__device__ __forceinline__ void fit_vec_rows(const Tex& tx, uint32_t row, bool m6, uint32_t khalf,
-	uint32_t cb, uint32_t ab, uint32_t pbk, uint32_t ib, uint32_t iters,
+template <bool UNITW, bool ROT>
+__device__ __forceinline__ void fit_vec_rows(const Tex& tx, uint32_t mask, uint32_t row, bool m6,
+	uint32_t khalf, uint32_t cb, uint32_t ab, uint32_t pbk, uint32_t ib, uint32_t iters,
 	const uint32_t (&wt)[4], RowFit& best)
 {
-	// A: statistics of the whole block (every lane of the group computes them)
+	// A: statistics of the subset (every lane of the group computes them)
 	uint32_t s[4] = {0, 0, 0, 0};
 	uint32_t q00 = 0, q01 = 0, q02 = 0, q03 = 0, q11 = 0, q12 = 0, q13 = 0, q22 = 0, q23 = 0,
 		q33 = 0;
 #pragma unroll 1
 	for (uint32_t r = 0; r < 4u; ++r) {
 		uint32_t P[4];
-		planes<true>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
-		s[0] = __builtin_amdgcn_udot4(P[0], 0x01010101u, s[0], false);
-		s[1] = __builtin_amdgcn_udot4(P[1], 0x01010101u, s[1], false);
-		s[2] = __builtin_amdgcn_udot4(P[2], 0x01010101u, s[2], false);
-		s[3] = __builtin_amdgcn_udot4(P[3], 0x01010101u, s[3], false);
-		q00 = __builtin_amdgcn_udot4(P[0], P[0], q00, false);
-		q01 = __builtin_amdgcn_udot4(P[0], P[1], q01, false);
-		q02 = __builtin_amdgcn_udot4(P[0], P[2], q02, false);
-		q03 = __builtin_amdgcn_udot4(P[0], P[3], q03, false);
-		q11 = __builtin_amdgcn_udot4(P[1], P[1], q11, false);
-		q12 = __builtin_amdgcn_udot4(P[1], P[2], q12, false);
-		q13 = __builtin_amdgcn_udot4(P[1], P[3], q13, false);
-		q22 = __builtin_amdgcn_udot4(P[2], P[2], q22, false);
-		q23 = __builtin_amdgcn_udot4(P[2], P[3], q23, false);
-		q33 = __builtin_amdgcn_udot4(P[3], P[3], q33, false);
+		planes<ROT>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
+		const uint32_t m4 = bytemask4((mask >> (4u*r)) & 15u);
+		const uint32_t M0 = P[0] & m4, M1 = P[1] & m4, M2 = P[2] & m4, M3 = P[3] & m4;
+		s[0] = __builtin_amdgcn_udot4(M0, 0x01010101u, s[0], false);
+		s[1] = __builtin_amdgcn_udot4(M1, 0x01010101u, s[1], false);
+		s[2] = __builtin_amdgcn_udot4(M2, 0x01010101u, s[2], false);
+		s[3] = __builtin_amdgcn_udot4(M3, 0x01010101u, s[3], false);
+		q00 = __builtin_amdgcn_udot4(M0, P[0], q00, false);
+		q01 = __builtin_amdgcn_udot4(M0, P[1], q01, false);
+		q02 = __builtin_amdgcn_udot4(M0, P[2], q02, false);
+		q03 = __builtin_amdgcn_udot4(M0, P[3], q03, false);
+		q11 = __builtin_amdgcn_udot4(M1, P[1], q11, false);
+		q12 = __builtin_amdgcn_udot4(M1, P[2], q12, false);
+		q13 = __builtin_amdgcn_udot4(M1, P[3], q13, false);
+		q22 = __builtin_amdgcn_udot4(M2, P[2], q22, false);
+		q23 = __builtin_amdgcn_udot4(M2, P[3], q23, false);
+		q33 = __builtin_amdgcn_udot4(M3, P[3], q33, false);
 	}
-	const uint32_t n = 16u;
+	const uint32_t n = (uint32_t)__builtin_popcount(mask);
 	const float C00 = (float)(int)(n*q00 - s[0]*s[0]), C01 = (float)(int)(n*q01 - s[0]*s[1]);
 	const float C02 = (float)(int)(n*q02 - s[0]*s[2]), C03 = (float)(int)(n*q03 - s[0]*s[3]);
 	const float C11 = (float)(int)(n*q11 - s[1]*s[1]), C12 = (float)(int)(n*q12 - s[1]*s[2]);
@@ -702,15 +706,17 @@ __device__ __forceinline__ void fit_vec_rows(const Tex& tx, uint32_t row, bool m
 	{
 		const uint4 rw = *reinterpret_cast<const uint4*>(tx.tp + 4u*row);
 		const uint32_t raw[4] = {rw.x, rw.y, rw.z, rw.w};
+		const uint32_t mrow = (mask >> (4u*row)) & 15u;
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
-			const uint32_t p = texel<true>(tx, raw[j]);
+			const uint32_t p = texel<ROT>(tx, raw[j]);
+			const bool m = (mrow >> j) & 1u;
 			float t = axis[0]*(fb(p, 0) - mean[0]);
 			t = fmaf(axis[1], fb(p, 1) - mean[1], t);
 			t = fmaf(axis[2], fb(p, 2) - mean[2], t);
 			t = fmaf(axis[3], fb(p, 3) - mean[3], t);
-			tmin = fminf(tmin, t);
-			tmax = fmaxf(tmax, t);
+			tmin = m ? fminf(tmin, t) : tmin;
+			tmax = m ? fmaxf(tmax, t) : tmax;
 		}
 		tmin = fminf(tmin, __shfl_xor(tmin, 1, 64));
 		tmin = fminf(tmin, __shfl_xor(tmin, 2, 64));
@@ -731,12 +737,12 @@ __device__ __forceinline__ void fit_vec_rows(const Tex& tx, uint32_t row, bool m
 	SubFit q;
 	quantize(x0, x1, cb, ab, pbk, fwt, q);
 	best.e0 = q.e0; best.e1 = q.e1; best.q0 = q.q0; best.q1 = q.q1; best.pb = q.pb;
-	assign_lsq_rows<UNITW>(tx, row, m6, khalf, ib, wt, iters > 0u, best);
+	assign_lsq_rows<UNITW, ROT>(tx, mask, row, m6, khalf, ib, wt, iters > 0u, best);
 	for (uint32_t r = 0; r < iters; ++r) {
 		RowFit cur;
 		quantize(best.nx0, best.nx1, cb, ab, pbk, fwt, q);
 		cur.e0 = q.e0; cur.e1 = q.e1; cur.q0 = q.q0; cur.q1 = q.q1; cur.pb = q.pb;
-		assign_lsq_rows<UNITW>(tx, row, m6, khalf, ib, wt, r + 1u < iters, cur);
+		assign_lsq_rows<UNITW, ROT>(tx, mask, row, m6, khalf, ib, wt, r + 1u < iters, cur);
 		if (best.ok && cur.err < best.err)
 			best = cur;
 	}
@@ -771,12 +777,12 @@ __device__ __forceinline__ void fit_scalar_rows(const Tex& tx, uint32_t row, uin
 	SubFit q;
 	quantize(x0, x1, 0u, ab, 0u, fwt, q);
 	best.e0 = q.e0; best.e1 = q.e1; best.q0 = q.q0; best.q1 = q.q1; best.pb = q.pb;
-	assign_lsq_rows<UNITW>(tx, row, false, 0u, ib, swt, iters > 0u, best);
+	assign_lsq_rows<UNITW, true>(tx, 0xFFFFu, row, false, 0u, ib, swt, iters > 0u, best);
 	for (uint32_t r = 0; r < iters; ++r) {
 		RowFit cur;
 		quantize(best.nx0, best.nx1, 0u, ab, 0u, fwt, q);
 		cur.e0 = q.e0; cur.e1 = q.e1; cur.q0 = q.q0; cur.q1 = q.q1; cur.pb = q.pb;
-		assign_lsq_rows<UNITW>(tx, row, false, 0u, ib, swt, r + 1u < iters, cur);
+		assign_lsq_rows<UNITW, true>(tx, 0xFFFFu, row, false, 0u, ib, swt, r + 1u < iters, cur);
 		if (best.ok && cur.err < best.err)
 			best = cur;
 	}
@@ -984,8 +990,8 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 		if (active) {   // groups of 4 (mode 6: 8) lanes are active together
 			RowFit fv;
 			const uint32_t wv[4] = {wl[0], wl[1], wl[2], abv ? wl[3] : 0u};
-			fit_vec_rows<UNITW>(make_tex(tp, pl, rot, abv ? 15u : 7u), row, m6, lane >> 2, cb, abv,
-				pbk, ibc, iters, wv, fv);
+			fit_vec_rows<UNITW, true>(make_tex(tp, pl, rot, abv ? 15u : 7u), 0xFFFFu, row, m6,
+				lane >> 2, cb, abv, pbk, ibc, iters, wv, fv);
 			Cand c;
 			c.err = fv.err;
 			c.id = cid;
@@ -1048,6 +1054,9 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 				default: ns = 2; cb = 5; ab = 5; pbk = 1; ib = 2; npart = 64; idbase = 320; break;
 			}
 			const Tex tx = make_tex(tp, pl, 0u, ab ? 15u : 7u);   // opaque modes do not code alpha
+			const uint32_t wv[4] = {wt[0], wt[1], wt[2], ab ? wt[3] : 0u};
+			const bool exhaustive = quality >= 4u;
+			// ---- stage 1: lane = partition; round-0 fit (all rounds when exhaustive) ----
 			Cand c;
 			c.err = 0;
 			c.id = idbase + lane;
@@ -1056,7 +1065,6 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 			c.pb = 0;
 #pragma unroll
 			for (int k = 0; k < 4; ++k) { c.w[k] = 0; c.w2[k] = 0; }
-			const uint32_t wv[4] = {wt[0], wt[1], wt[2], ab ? wt[3] : 0u};
 			for (uint32_t s = 0; s < ns; ++s) {
 				uint32_t mask;
 				if (ns == 2u)
@@ -1064,7 +1072,7 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 				else
 					mask = s == 0u ? m30 : (s == 1u ? m31 : m32);
 				SubFit f;
-				fit_vec<UNITW, false, 8>(tx, mask, cb, ab, pbk, ib, iters, wv, f);
+				fit_vec<UNITW, false, 8>(tx, mask, cb, ab, pbk, ib, exhaustive ? iters : 0u, wv, f);
 				c.err += f.err;
 				if (s == 0u) { c.q[0] = f.q0; c.q[1] = f.q1; c.pb |= f.pb; }
 				else if (s == 1u) { c.q[2] = f.q0; c.q[3] = f.q1; c.pb |= f.pb << 2; }
@@ -1072,8 +1080,78 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 #pragma unroll
 				for (int k = 0; k < 4; ++k) c.w[k] |= f.w[k];
 			}
+			const uint32_t err0 = c.err;
 			if (lane < npart && c.err < best.err)
 				best = c;
+			solved = __ballot(best.err == 0u) != 0ull;
+			if (!exhaustive && iters > 0u && !solved) {
+				// ---- select the T partitions with the smallest (round-0 error, id) ----
+				// ---- stage 2: lane = (rank, subset, texel row): all refit rounds ----
+				const uint32_t gl = 4u*ns;                       // lanes per partition
+				const uint32_t T = ns == 2u ? 8u : 5u;
+				const uint32_t rank = lane/gl, sub = (lane - rank*gl) >> 2, row = lane & 3u;
+				uint32_t key = lane < npart ? ((err0 << 6) | lane) : 0xFFFFFFFFu;
+				uint32_t mypart = 0;
+				for (uint32_t t = 0; t < T; ++t) {
+					uint32_t kmin = key;
+#pragma unroll
+					for (int off = 32; off >= 1; off >>= 1) {
+						const uint32_t o = (uint32_t)__shfl_xor((int)kmin, off, 64);
+						kmin = o < kmin ? o : kmin;
+					}
+					mypart = rank == t ? (kmin & 63u) : mypart;
+					key = key == kmin ? 0xFFFFFFFFu : key;
+				}
+				const bool act = rank < T;
+				const uint32_t sp2 = k_part2[mypart], sp3 = k_part3[mypart];
+				uint32_t smask;
+				if (ns == 2u)
+					smask = sub ? sp2 : (~sp2 & 0xFFFFu);
+				else {
+					smask = 0;
+#pragma unroll
+					for (int i = 0; i < 16; ++i)
+						smask |= (((sp3 >> (2*i)) & 3u) == sub ? 1u : 0u) << i;
+				}
+				RowFit rf;
+				rf.err = 0; rf.q0 = 0; rf.q1 = 0; rf.pb = 0; rf.wrow = 0;
+				if (act)
+					fit_vec_rows<UNITW, false>(tx, smask, row, false, 0u, cb, ab, pbk, ib, iters, wv,
+						rf);
+				// gather the partition's subsets into the leader lane (sub 0, row 0)
+				const int g0 = (int)(rank*gl);
+				Cand r2;
+				r2.id = idbase + mypart;
+				r2.err = 0;
+				r2.pb = 0;
+#pragma unroll
+				for (int k = 0; k < 6; ++k) r2.q[k] = 0;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) { r2.w[k] = 0; r2.w2[k] = 0; }
+#pragma unroll
+				for (int sb = 0; sb < 3; ++sb) {
+					const int src = g0 + 4*sb;
+					const uint32_t e = (uint32_t)__shfl((int)rf.err, src, 64);
+					const uint32_t a0 = (uint32_t)__shfl((int)rf.q0, src, 64);
+					const uint32_t a1 = (uint32_t)__shfl((int)rf.q1, src, 64);
+					const uint32_t pbs = (uint32_t)__shfl((int)rf.pb, src, 64);
+					uint32_t wr[4];
+#pragma unroll
+					for (int k = 0; k < 4; ++k)
+						wr[k] = (uint32_t)__shfl((int)rf.wrow, src + k, 64);
+					if ((uint32_t)sb < ns) {
+						r2.err += e;
+						r2.q[2*sb] = a0; r2.q[2*sb + 1] = a1;
+						r2.pb |= pbs << (2*sb);
+#pragma unroll
+						for (int k = 0; k < 4; ++k) r2.w[k] |= wr[k];
+					}
+				}
+				// (error, id) order: a refined partition may carry a lower id than this lane's best
+				if (act && sub == 0u && row == 0u &&
+					(r2.err < best.err || (r2.err == best.err && r2.id < best.id)))
+					best = r2;
+			}
 			solved = __ballot(best.err == 0u) != 0ull;
 		}
 	}

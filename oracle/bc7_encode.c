@@ -553,8 +553,11 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 	memset(&best, 0, sizeof(best));
 	best.err = 0xFFFFFFFFu;
 	best.id = 0x7FFFFFFF;
+	/* winner = min (error, id): evaluation order must not matter (phase 2 below visits
+	 * partitions in rank order, the kernel visits them lane-parallel) */
+#define BETTER(c, b) ((c).err < (b).err || ((c).err == (b).err && (c).id < (b).id))
 #define TRY(ID) do { eval_candidate(px, wt, (ID), b.iters, &cur); \
-	if (cur.err < best.err) best = cur; } while (0)
+	if (BETTER(cur, best)) best = cur; } while (0)
 	TRY(0);
 	if (b.m6only) {
 		if (has_alpha)
@@ -566,24 +569,50 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 		if (b.rot)
 			for (int k = 0; k < 8; ++k)
 				TRY(5 + k);
+		/* Partitioned modes.  Below Highest the refit rounds are spent only on the T
+		 * partitions with the smallest round-0 error (T = 8 for two-subset modes, 5 for
+		 * three-subset modes): phase 1 scores every partition with the round-0 fit
+		 * (ids as usual), phase 2 re-fits the T best with all rounds.  The HIP kernel
+		 * runs phase 1 with lane = partition and phase 2 with lane = (rank, subset,
+		 * texel row).  Highest refits every partition. */
+		int bases[4], counts[4], nm = 0;
 		if (!has_alpha) {
-			if (b.two)
-				for (int k = 0; k < 64; ++k)
-					TRY(64 + k);
-			if (b.mode3)
-				for (int k = 0; k < 64; ++k)
-					TRY(128 + k);
+			if (b.two) { bases[nm] = 64; counts[nm++] = 64; }
+			if (b.mode3) { bases[nm] = 128; counts[nm++] = 64; }
 			if (b.three) {
-				for (int k = 0; k < 16; ++k)
-					TRY(192 + k);
-				for (int k = 0; k < 64; ++k)
-					TRY(256 + k);
+				bases[nm] = 192; counts[nm++] = 16;
+				bases[nm] = 256; counts[nm++] = 64;
 			}
-		} else if (b.two) {
-			for (int k = 0; k < 64; ++k)
-				TRY(320 + k);
+		} else if (b.two) { bases[nm] = 320; counts[nm++] = 64; }
+		for (int mi = 0; mi < nm && best.err != 0; ++mi) {
+			if (p->quality >= 4) {
+				for (int k = 0; k < counts[mi]; ++k)
+					TRY(bases[mi] + k);
+				continue;
+			}
+			uint32_t e0[64];
+			for (int k = 0; k < counts[mi]; ++k) {
+				eval_candidate(px, wt, bases[mi] + k, 0, &cur);
+				e0[k] = cur.err;
+				if (BETTER(cur, best))
+					best = cur;
+			}
+			if (b.iters == 0 || best.err == 0)
+				continue;
+			int T = (bases[mi] == 192 || bases[mi] == 256) ? 5 : 8;
+			for (int r = 0; r < T; ++r) {
+				int bk = -1;
+				for (int k = 0; k < counts[mi]; ++k)
+					if (e0[k] != 0xFFFFFFFFu && (bk < 0 || e0[k] < e0[bk]))
+						bk = k;
+				if (bk < 0)
+					break;
+				e0[bk] = 0xFFFFFFFFu;
+				TRY(bases[mi] + bk);
+			}
 		}
 	}
 #undef TRY
+#undef BETTER
 	pack(&best, out);
 }

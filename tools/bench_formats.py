@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Kernel-only throughput of every block format (NOT the contract benchmark -- that is
+bench.py).  Device-resident synthetic surfaces, hipEvent timing via cfhip_profile_begin/end.
+usage (GPU box): python tools/bench_formats.py [--size 2048] [--steps 5]"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=5)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from cuttlefish_amd import Context, Format, PixelType, Type, make_params, payload_size, synth
+
+    n = args.size
+    ldr = torch.from_numpy(synth.photo(n, n, seed=1)).cuda()
+    hdr = torch.from_numpy(synth.hdr_probe(n, n, seed=4).view(np.uint16).astype(np.int32)
+                           .astype(np.uint16).view(np.int16)).cuda()
+    ctx = Context(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    rows = []
+    cases = [(Format.BC1_RGB, Type.UNorm), (Format.BC1_RGBA, Type.UNorm), (Format.BC2, Type.UNorm),
+             (Format.BC3, Type.UNorm), (Format.BC4, Type.UNorm), (Format.BC4, Type.SNorm),
+             (Format.BC5, Type.UNorm), (Format.BC5, Type.SNorm), (Format.BC6H, Type.UFloat),
+             (Format.BC6H, Type.Float), (Format.BC7, Type.UNorm)]
+    for fmt, typ in cases:
+        is_hdr = fmt == Format.BC6H
+        src = hdr if is_hdr else ldr
+        nbytes = payload_size(fmt, typ, n, n)
+        out = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        surf = [{"pixels": src.data_ptr(), "pixel_type": PixelType.RGBA16F if is_hdr else
+                 PixelType.RGBA8, "width": n, "height": n,
+                 "row_pitch_bytes": n * (8 if is_hdr else 4), "out": out.data_ptr(),
+                 "out_capacity": nbytes}]
+        for q in (0, 2, 4):
+            p = make_params(fmt, typ, q)
+            ctx.encode_device(surf, p, stream)
+            torch.cuda.synchronize()
+            ctx.profile_begin()
+            for _ in range(args.steps):
+                ctx.encode_device(surf, p, stream)
+            ms, launches = ctx.profile_end()
+            ms /= launches
+            algo = n * n * (8 if is_hdr else 4) + nbytes
+            rows.append({"format": fmt.name, "type": typ.name, "quality": q,
+                         "kernel_ms": round(ms, 3), "mpix_s": round(n * n / ms / 1e3, 1),
+                         "algo_gb_s": round(algo / ms / 1e6, 3)})
+            print(json.dumps(rows[-1]), flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
