@@ -26,6 +26,12 @@ class Format(enum.IntEnum):
     BC5 = 34
     BC6H = 35
     BC7 = 36
+    ETC1 = 37
+    ETC2_R8G8B8 = 38
+    ETC2_R8G8B8A1 = 39
+    ETC2_R8G8B8A8 = 40
+    EAC_R11 = 41
+    EAC_R11G11 = 42
 
 
 class Type(enum.IntEnum):

@@ -18,6 +18,8 @@
 
 extern "C" hipError_t cfhip_launch_bc7(const cf_kparams* kp, int pixel_type, int unit_weights,
 	hipStream_t stream);
+extern "C" hipError_t cfhip_launch_etc(const cf_kparams* kp, int format, int pixel_type, int snorm,
+	hipStream_t stream);
 extern "C" hipError_t cfhip_launch_bc6h(const cf_kparams* kp, int pixel_type, int is_signed,
 	hipStream_t stream);
 extern "C" hipError_t cfhip_launch_bc15(const cf_kparams* kp, int format, int pixel_type,
@@ -66,7 +68,14 @@ int block_bytes(int format)
 		case CFHIP_FORMAT_BC1_RGB:
 		case CFHIP_FORMAT_BC1_RGBA:
 		case CFHIP_FORMAT_BC4:
+		case CFHIP_FORMAT_ETC1:
+		case CFHIP_FORMAT_ETC2_R8G8B8:
+		case CFHIP_FORMAT_ETC2_R8G8B8A1:
+		case CFHIP_FORMAT_EAC_R11:
 			return 8;
+		case CFHIP_FORMAT_ETC2_R8G8B8A8:
+		case CFHIP_FORMAT_EAC_R11G11:
+			return 16;
 		case CFHIP_FORMAT_BC2:
 		case CFHIP_FORMAT_BC3:
 		case CFHIP_FORMAT_BC5:
@@ -90,7 +99,14 @@ bool type_valid(int format, int type)
 			return type == CFHIP_TYPE_UNORM;
 		case CFHIP_FORMAT_BC4:
 		case CFHIP_FORMAT_BC5:
+		case CFHIP_FORMAT_EAC_R11:       // Converter.cpp:424-430
+		case CFHIP_FORMAT_EAC_R11G11:
 			return type == CFHIP_TYPE_UNORM || type == CFHIP_TYPE_SNORM;
+		case CFHIP_FORMAT_ETC1:          // Converter.cpp:414-422
+		case CFHIP_FORMAT_ETC2_R8G8B8:
+		case CFHIP_FORMAT_ETC2_R8G8B8A1:
+		case CFHIP_FORMAT_ETC2_R8G8B8A8:
+			return type == CFHIP_TYPE_UNORM;
 		case CFHIP_FORMAT_BC6H:
 			return type == CFHIP_TYPE_UFLOAT || type == CFHIP_TYPE_FLOAT;
 		default:
@@ -110,6 +126,12 @@ bool format_implemented(int format, int type)
 		case CFHIP_FORMAT_BC5:
 		case CFHIP_FORMAT_BC6H:
 		case CFHIP_FORMAT_BC7:
+		case CFHIP_FORMAT_ETC1:
+		case CFHIP_FORMAT_ETC2_R8G8B8:
+		case CFHIP_FORMAT_ETC2_R8G8B8A1:
+		case CFHIP_FORMAT_ETC2_R8G8B8A8:
+		case CFHIP_FORMAT_EAC_R11:
+		case CFHIP_FORMAT_EAC_R11G11:
 			return true;
 		default:
 			return false;
@@ -169,6 +191,14 @@ void fill_kparams(cf_kparams& kp, const cfhip_params& p, const void* src, void* 
 	const uint32_t* wsel = (p.color_space == CFHIP_COLOR_SRGB && p.quality >= 2) ? perc : lin;
 	for (int c = 0; c < 4; ++c)
 		kp.wt[c] = p.mask_rgba[c] ? wsel[c] : 1u;
+	if (p.format >= CFHIP_FORMAT_ETC1 && p.format <= CFHIP_FORMAT_EAC_R11G11) {
+		// RGBX/RGBA metric for linear images, REC709 for sRGB (EtcConverter.cpp:60-88);
+		// EtcConverter ignores the colour mask
+		static const uint32_t elin[3] = {1, 1, 1}, erec[3] = {3, 10, 1};
+		const uint32_t* w = p.color_space == CFHIP_COLOR_SRGB ? erec : elin;
+		for (int c = 0; c < 3; ++c)
+			kp.wt[c] = w[c];
+	}
 	if (p.format == CFHIP_FORMAT_BC1_RGBA) {
 		// punch-through blocks (squish path, S3tcConverter.cpp:294-330): Rec.709-like
 		// integer weights for sRGB images, colour mask zeroes a channel's weight
@@ -192,6 +222,18 @@ int launch(cfhip_ctx* ctx, const cf_kparams& kp, const cfhip_params& p, int pixe
 			ctx->last_kernel = "cfhip_bc7_encode_kernel";
 			break;
 		}
+		case CFHIP_FORMAT_ETC1:
+		case CFHIP_FORMAT_ETC2_R8G8B8:
+		case CFHIP_FORMAT_ETC2_R8G8B8A1:
+		case CFHIP_FORMAT_ETC2_R8G8B8A8:
+		case CFHIP_FORMAT_EAC_R11:
+		case CFHIP_FORMAT_EAC_R11G11:
+			if (pixel_type != CFHIP_PIXEL_RGBA8 && pixel_type != CFHIP_PIXEL_RGBA32F)
+				return fail(ctx, CFHIP_E_UNSUPPORTED, "ETC/EAC take RGBA8 or RGBA32F pixels");
+			e = cfhip_launch_etc(&kp, p.format, pixel_type == CFHIP_PIXEL_RGBA32F ? 1 : 0,
+				p.type == CFHIP_TYPE_SNORM ? 1 : 0, stream);
+			ctx->last_kernel = "cfhip_etc_encode_kernel";
+			break;
 		case CFHIP_FORMAT_BC6H:
 			e = cfhip_launch_bc6h(&kp, pixel_type, p.type == CFHIP_TYPE_FLOAT ? 1 : 0, stream);
 			ctx->last_kernel = "cfhip_bc6h_encode_kernel";

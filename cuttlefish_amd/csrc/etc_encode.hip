@@ -1,0 +1,579 @@
+// etc_encode.hip -- ETC1 / ETC2 RGB / RGB+A1 / RGBA8 / EAC R11 / RG11 block encoders for
+// gfx950, one wavefront per block, all-integer arithmetic.
+//
+// Replaces the per-block Etc::Image construction + Encode() of EtcConverter::process
+// (lib/src/EtcConverter.cpp:120-152; etc2comp, absent).  Twin of oracle/etc_codec.c and
+// byte-identical to it.  Like the oracle it is only self-consistent with a from-
+// specification decoder: no independent ETC decoder exists in this environment.
+//
+// RGB block: 8 groups of 8 lanes = (precision family 5/4 bit) x (flip) x (half); lane in
+//   group = modifier table; every lane walks the (2r+1)^3 base colours around its half's
+//   mean, exact SSE with the per-texel best modifier; 3-step group argmin on (error, id);
+//   the differential pair is clamped into the [-4,3] window (re-scored on 16 lanes);
+//   ETC2 planar: closed-form integer least squares + 2 rounds where lanes 0..17 score the
+//   single-field +-1 moves.  T/H modes are never emitted.
+// EAC block: lanes 0..47 = 16 tables x 3 multipliers, each walks the 2R+1 base values.
+// Texels outside the image carry no error weight (EtcConverter.cpp:122-129).
+#include "cf_device.h"
+
+namespace {
+
+enum { E_ETC1 = 37, E_RGB = 38, E_A1 = 39, E_A8 = 40, E_R11 = 41, E_RG11 = 42 };
+
+__device__ const int k_etc_mod[8][2] = {{2, 8}, {5, 17}, {9, 29}, {13, 42}, {18, 60}, {24, 80},
+	{33, 106}, {47, 183}};
+__device__ const int k_eac_mod[16][8] = {
+	{-3, -6, -9, -15, 2, 5, 8, 14}, {-3, -7, -10, -13, 2, 6, 9, 12},
+	{-2, -5, -8, -13, 1, 4, 7, 12}, {-2, -4, -6, -13, 1, 3, 5, 12},
+	{-3, -6, -8, -12, 2, 5, 7, 11}, {-3, -7, -9, -11, 2, 6, 8, 10},
+	{-4, -7, -8, -11, 3, 6, 7, 10}, {-3, -5, -8, -11, 2, 4, 7, 10},
+	{-2, -6, -8, -10, 1, 5, 7, 9}, {-2, -5, -8, -10, 1, 4, 7, 9},
+	{-2, -4, -8, -10, 1, 3, 7, 9}, {-2, -5, -7, -10, 1, 4, 6, 9},
+	{-3, -4, -7, -10, 2, 3, 6, 9}, {-1, -2, -3, -10, 0, 1, 2, 9},
+	{-4, -6, -8, -9, 3, 5, 7, 8}, {-3, -5, -7, -9, 2, 4, 6, 8}};
+
+__device__ __forceinline__ int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int ex4(int v) { return (v << 4) | v; }
+__device__ __forceinline__ int ex5(int v) { return (v << 3) | (v >> 2); }
+__device__ __forceinline__ int ex6(int v) { return (v << 2) | (v >> 4); }
+__device__ __forceinline__ int ex7(int v) { return (v << 1) | (v >> 6); }
+__device__ __forceinline__ int sx3(int v) { return v >= 4 ? v - 8 : v; }
+__device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+struct RgbOpts {
+	bool allow_indiv, allow_planar, punch, a1;
+	uint32_t active, transparent;
+	int wt[3];
+	int radius;
+};
+
+__device__ __forceinline__ uint32_t half_mask(uint32_t flip, uint32_t sub)
+{
+	return flip ? (sub ? 0xFF00u : 0x00FFu) : (sub ? 0xCCCCu : 0x3333u);
+}
+
+__device__ __forceinline__ int etc_modifier(int t, int v, bool punch)
+{
+	const int a = punch ? 0 : k_etc_mod[t][0], b = k_etc_mod[t][1];
+	return v == 0 ? a : (v == 1 ? b : (v == 2 ? -a : -b));
+}
+
+// error of one half for base colour c and table t; sel (2 bits per texel) when WANT_SEL
+template <bool WANT_SEL>
+__device__ __forceinline__ uint32_t half_err(const uint32_t* tp, const RgbOpts& o, uint32_t hmask,
+	const int (&c)[3], int t, uint32_t& sel)
+{
+	uint32_t total = 0;
+	const int ma = o.punch ? 0 : k_etc_mod[t][0], mb = k_etc_mod[t][1];
+#pragma unroll 1
+	for (uint32_t i = 0; i < 16u; ++i) {
+		if (!((hmask >> i) & 1u))
+			continue;
+		if ((o.transparent >> i) & 1u) {
+			if (WANT_SEL) sel |= 2u << (2u*i);
+			continue;
+		}
+		const uint32_t p = tp[i];
+		const int p0 = (int)(p & 255u), p1 = (int)((p >> 8) & 255u), p2 = (int)((p >> 16) & 255u);
+		uint32_t best = 0xFFFFFFFFu;
+		uint32_t bv = 0;
+#pragma unroll
+		for (int v = 0; v < 4; ++v) {
+			if (v == 2 && o.punch)
+				continue;
+			const int m = v == 0 ? ma : (v == 1 ? mb : (v == 2 ? -ma : -mb));
+			const int d0 = clamp255(c[0] + m) - p0, d1 = clamp255(c[1] + m) - p1,
+				d2 = clamp255(c[2] + m) - p2;
+			const uint32_t e = (uint32_t)(o.wt[0]*d0*d0) + (uint32_t)(o.wt[1]*d1*d1) +
+				(uint32_t)(o.wt[2]*d2*d2);
+			if (e < best) { best = e; bv = (uint32_t)v; }
+		}
+		if (WANT_SEL) sel |= bv << (2u*i);
+		total += ((o.active >> i) & 1u) ? best : 0u;
+	}
+	return total;
+}
+
+struct PlanarQ { int O[3], H[3], V[3]; };
+
+__device__ __forceinline__ uint32_t planar_err(const uint32_t* tp, const RgbOpts& o, const PlanarQ& q)
+{
+	int O[3], H[3], V[3];
+#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		O[c] = c == 1 ? ex7(q.O[c]) : ex6(q.O[c]);
+		H[c] = c == 1 ? ex7(q.H[c]) : ex6(q.H[c]);
+		V[c] = c == 1 ? ex7(q.V[c]) : ex6(q.V[c]);
+	}
+	uint32_t e = 0;
+#pragma unroll 1
+	for (uint32_t i = 0; i < 16u; ++i) {
+		if (!((o.active >> i) & 1u))
+			continue;
+		const int x = (int)(i & 3u), y = (int)(i >> 2);
+		const uint32_t p = tp[i];
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			const int v = clamp255((x*(H[c] - O[c]) + y*(V[c] - O[c]) + 4*O[c] + 2) >> 2);
+			const int d = v - (int)((p >> (8*c)) & 255u);
+			e += (uint32_t)(o.wt[c]*d*d);
+		}
+	}
+	return e;
+}
+
+// add d to field f (0..8 = O.rgb, H.rgb, V.rgb) without dynamic register indexing;
+// returns false when the field would leave its range
+__device__ __forceinline__ bool planar_move(PlanarQ& q, int f, int d)
+{
+	bool ok = true;
+#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		const int mq = c == 1 ? 127 : 63;
+		if (f == c) { const int nv = q.O[c] + d; ok = nv >= 0 && nv <= mq; q.O[c] = ok ? nv : q.O[c]; }
+		if (f == 3 + c) { const int nv = q.H[c] + d; ok = nv >= 0 && nv <= mq; q.H[c] = ok ? nv : q.H[c]; }
+		if (f == 6 + c) { const int nv = q.V[c] + d; ok = nv >= 0 && nv <= mq; q.V[c] = ok ? nv : q.V[c]; }
+	}
+	return ok;
+}
+
+__device__ __forceinline__ uint2 pack_planar(const PlanarQ& p)
+{
+	const uint32_t RO = (uint32_t)p.O[0], GO = (uint32_t)p.O[1], BO = (uint32_t)p.O[2],
+		RH = (uint32_t)p.H[0];
+	uint32_t hi = 0;
+	for (uint32_t pad = 0; pad < 64u; ++pad) {
+		hi = ((pad & 1u) << 31) | (RO << 25) | ((GO >> 6) << 24) | (((pad >> 1) & 1u) << 23) |
+			((GO & 63u) << 17) | ((BO >> 5) << 16) | (((pad >> 2) & 7u) << 13) |
+			(((BO >> 3) & 3u) << 11) | (((pad >> 5) & 1u) << 10) | ((BO & 7u) << 7) |
+			((RH >> 1) << 2) | (1u << 1) | (RH & 1u);
+		const int r = (int)((hi >> 27) & 31u), dr = sx3((int)((hi >> 24) & 7u));
+		const int g = (int)((hi >> 19) & 31u), dg = sx3((int)((hi >> 16) & 7u));
+		const int b = (int)((hi >> 11) & 31u), db = sx3((int)((hi >> 8) & 7u));
+		const bool rg_ok = r + dr >= 0 && r + dr <= 31 && g + dg >= 0 && g + dg <= 31;
+		const bool b_over = b + db < 0 || b + db > 31;
+		if (rg_ok && b_over)
+			break;
+	}
+	const uint32_t lo = ((uint32_t)p.H[1] << 25) | ((uint32_t)p.H[2] << 19) |
+		((uint32_t)p.V[0] << 13) | ((uint32_t)p.V[1] << 6) | (uint32_t)p.V[2];
+	return make_uint2(bswap32(hi), bswap32(lo));
+}
+
+// (key, payload) argmin over the 8 lanes of a group
+__device__ __forceinline__ void group_min8(unsigned long long& key, uint32_t& pay)
+{
+#pragma unroll
+	for (int off = 1; off <= 4; off <<= 1) {
+		const uint32_t klo = (uint32_t)__shfl_xor((int)(uint32_t)key, off, 64);
+		const uint32_t khi = (uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), off, 64);
+		const uint32_t op = (uint32_t)__shfl_xor((int)pay, off, 64);
+		const unsigned long long ok = ((unsigned long long)khi << 32) | klo;
+		if (ok < key) { key = ok; pay = op; }
+	}
+}
+
+// Returns the 8-byte RGB block (memory order: x = bytes 0..3, y = bytes 4..7) in every lane.
+__device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o, uint32_t lane)
+{
+	const uint32_t g = lane >> 3, t = lane & 7u;
+	const uint32_t fam4 = g >> 2, flip = (g >> 1) & 1u, sub = g & 1u;
+	const int bits = fam4 ? 4 : 5, maxq = (1 << bits) - 1;
+	const uint32_t hmask = half_mask(flip, sub);
+	// mean of the half over the texels that carry weight
+	int n = 0, sum[3] = {0, 0, 0};
+#pragma unroll 1
+	for (uint32_t i = 0; i < 16u; ++i) {
+		if (((hmask & o.active) >> i) & 1u) {
+			const uint32_t p = tp[i];
+			++n;
+			sum[0] += (int)(p & 255u); sum[1] += (int)((p >> 8) & 255u); sum[2] += (int)((p >> 16) & 255u);
+		}
+	}
+	int q0[3];
+#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		const int mean = n ? (2*sum[c] + n)/(2*n) : 0;
+		q0[c] = (mean*maxq + 127)/255;
+	}
+	uint32_t berr = 0xFFFFFFFFu, bcand = 0, bq = 0, dummy = 0;
+	if (!fam4 || o.allow_indiv) {
+		const int r = o.radius;
+		uint32_t cand = 0;
+		for (int dr = -r; dr <= r; ++dr)
+			for (int dg = -r; dg <= r; ++dg)
+				for (int db = -r; db <= r; ++db, ++cand) {
+					const int q[3] = {clampi(q0[0] + dr, 0, maxq), clampi(q0[1] + dg, 0, maxq),
+						clampi(q0[2] + db, 0, maxq)};
+					const int c[3] = {fam4 ? ex4(q[0]) : ex5(q[0]), fam4 ? ex4(q[1]) : ex5(q[1]),
+						fam4 ? ex4(q[2]) : ex5(q[2])};
+					const uint32_t e = half_err<false>(tp, o, hmask, c, (int)t, dummy);
+					if (e < berr) {
+						berr = e; bcand = cand;
+						bq = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16);
+					}
+				}
+	}
+	unsigned long long key = ((unsigned long long)berr << 32) | (bcand*8u + t);
+	group_min8(key, bq);
+	// gather the eight group results
+	uint32_t herr[8], hq[8], ht[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		herr[k] = (uint32_t)__shfl((int)(uint32_t)(key >> 32), 8*k, 64);
+		hq[k] = (uint32_t)__shfl((int)bq, 8*k, 64);
+		ht[k] = (uint32_t)__shfl((int)(uint32_t)key, 8*k, 64) & 7u;
+	}
+	// group index = fam4*4 + flip*2 + sub
+	// differential: pull the second base colour into the delta window of the first
+	uint32_t q2p[2], e2[2], t2[2];
+#pragma unroll
+	for (int f = 0; f < 2; ++f) {
+		const uint32_t a = hq[2*f], b = hq[2*f + 1];
+		uint32_t qq = 0;
+		bool inside = true;
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			const int a_c = (int)((a >> (8*c)) & 255u), b_c = (int)((b >> (8*c)) & 255u);
+			int v = clampi(b_c, a_c - 4, a_c + 3);
+			v = clampi(v, 0, 31);
+			inside = inside && v == b_c;
+			qq |= (uint32_t)v << (8*c);
+		}
+		q2p[f] = qq;
+		e2[f] = herr[2*f + 1];
+		t2[f] = ht[2*f + 1];
+		const bool need = !inside;   // uniform across the wave
+		if (need) {
+			const int c[3] = {ex5((int)(qq & 255u)), ex5((int)((qq >> 8) & 255u)),
+				ex5((int)((qq >> 16) & 255u))};
+			const uint32_t e = half_err<false>(tp, o, half_mask((uint32_t)f, 1u), c, (int)t, dummy);
+			unsigned long long k2 = ((unsigned long long)e << 32) | t;
+			uint32_t pay = 0;
+			group_min8(k2, pay);
+			e2[f] = (uint32_t)__shfl((int)(uint32_t)(k2 >> 32), 0, 64);
+			t2[f] = (uint32_t)__shfl((int)(uint32_t)k2, 0, 64) & 7u;
+		}
+	}
+	// candidates in id order: 0,1 differential (flip 0,1); 2,3 individual
+	uint32_t best_err = 0xFFFFFFFFu, best_id = 0;
+#pragma unroll
+	for (int f = 0; f < 2; ++f) {
+		const uint32_t ed = herr[2*f] + e2[f];
+		if (ed < best_err) { best_err = ed; best_id = (uint32_t)f; }
+	}
+	if (o.allow_indiv) {
+#pragma unroll
+		for (int f = 0; f < 2; ++f) {
+			const uint32_t ei = herr[4 + 2*f] + herr[4 + 2*f + 1];
+			if (ei < best_err) { best_err = ei; best_id = 2u + (uint32_t)f; }
+		}
+	}
+	if (o.allow_planar && !o.punch) {
+		// closed-form least squares on the 4x4 grid (uniform), then 2 rounds of moves
+		PlanarQ pq;
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			int S = 0, Sx = 0, Sy = 0;
+#pragma unroll 1
+			for (uint32_t i = 0; i < 16u; ++i) {
+				const int x = (int)(i & 3u), y = (int)(i >> 2);
+				const int v = (int)((tp[i] >> (8*c)) & 255u);
+				S += v; Sx += (2*x - 3)*v; Sy += (2*y - 3)*v;
+			}
+			const int mq = c == 1 ? 127 : 63;
+			pq.O[c] = (clampi(5*S - 3*Sx - 3*Sy, 0, 255*80)*mq + 10200)/20400;
+			pq.H[c] = (clampi(5*S + 5*Sx - 3*Sy, 0, 255*80)*mq + 10200)/20400;
+			pq.V[c] = (clampi(5*S - 3*Sx + 5*Sy, 0, 255*80)*mq + 10200)/20400;
+		}
+		uint32_t ep = planar_err(tp, o, pq);
+		for (int round = 0; round < 2; ++round) {
+			unsigned long long mk = ~0ull;
+			if (lane < 18u) {
+				const int f = (int)(lane >> 1), d = (lane & 1u) ? 1 : -1;
+				PlanarQ tq = pq;
+				if (planar_move(tq, f, d))
+					mk = ((unsigned long long)planar_err(tp, o, tq) << 32) | lane;
+			}
+			const unsigned long long mm = cf_wave_min_u64(mk);
+			if ((uint32_t)(mm >> 32) >= ep)
+				break;
+			ep = (uint32_t)(mm >> 32);
+			const int id = (int)(uint32_t)mm;
+			planar_move(pq, id >> 1, (id & 1) ? 1 : -1);
+		}
+		if (ep < best_err)
+			return pack_planar(pq);
+	}
+	const bool differential = best_id < 2u;
+	const uint32_t bf = best_id & 1u;
+	uint32_t qa, qb, ta, tb;
+	if (differential) {
+		qa = bf ? hq[2] : hq[0]; qb = bf ? q2p[1] : q2p[0];
+		ta = bf ? ht[2] : ht[0]; tb = bf ? t2[1] : t2[0];
+	} else {
+		qa = bf ? hq[6] : hq[4]; qb = bf ? hq[7] : hq[5];
+		ta = bf ? ht[6] : ht[4]; tb = bf ? ht[7] : ht[5];
+	}
+	uint32_t sel = 0;
+	{
+		const int ca[3] = {differential ? ex5((int)(qa & 255u)) : ex4((int)(qa & 255u)),
+			differential ? ex5((int)((qa >> 8) & 255u)) : ex4((int)((qa >> 8) & 255u)),
+			differential ? ex5((int)((qa >> 16) & 255u)) : ex4((int)((qa >> 16) & 255u))};
+		const int cb[3] = {differential ? ex5((int)(qb & 255u)) : ex4((int)(qb & 255u)),
+			differential ? ex5((int)((qb >> 8) & 255u)) : ex4((int)((qb >> 8) & 255u)),
+			differential ? ex5((int)((qb >> 16) & 255u)) : ex4((int)((qb >> 16) & 255u))};
+		half_err<true>(tp, o, half_mask(bf, 0u), ca, (int)ta, sel);
+		half_err<true>(tp, o, half_mask(bf, 1u), cb, (int)tb, sel);
+	}
+	uint32_t hi = 0, lo = 0;
+#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		const uint32_t a = (qa >> (8*c)) & 255u, b = (qb >> (8*c)) & 255u;
+		if (differential)
+			hi |= (a << (27 - 8*c)) | (((b - a) & 7u) << (24 - 8*c));
+		else
+			hi |= (a << (28 - 8*c)) | (b << (24 - 8*c));
+	}
+	const uint32_t diff_bit = o.a1 ? (o.punch ? 0u : 1u) : (differential ? 1u : 0u);
+	hi |= (ta << 5) | (tb << 2) | (diff_bit << 1) | bf;
+#pragma unroll 1
+	for (uint32_t i = 0; i < 16u; ++i) {
+		const uint32_t x = i & 3u, y = i >> 2, k = x*4u + y, s = (sel >> (2u*i)) & 3u;
+		lo |= ((s >> 1) << (16u + k)) | ((s & 1u) << k);
+	}
+	return make_uint2(bswap32(hi), bswap32(lo));
+}
+
+// kind: 0 alpha8 (byte `ch` of the RGBA8 word), 1 R11, 2 signed R11 (int16 half `ch` of the word)
+__device__ __forceinline__ int eac_value(const uint32_t* tp, uint32_t i, int kind, int ch)
+{
+	const uint32_t p = tp[i];
+	if (kind == 0)
+		return (int)((p >> (8*ch)) & 255u);
+	return (int)(short)((p >> (16*ch)) & 0xFFFFu);
+}
+
+__device__ __forceinline__ int eac_decode(int kind, int base, int m, int mult)
+{
+	if (kind == 0) return clamp255(base + m*mult);
+	if (kind == 1) return clampi(base*8 + 4 + m*mult*8, 0, 2047);
+	return clampi(base*8 + m*mult*8, -1023, 1023);
+}
+
+__device__ __forceinline__ uint2 eac_search(const uint32_t* tp, int kind, int ch, uint32_t active,
+	int R, uint32_t lane)
+{
+	int lo = 1 << 30, hi = -(1 << 30);
+#pragma unroll 1
+	for (uint32_t i = 0; i < 16u; ++i) {
+		if ((active >> i) & 1u) {
+			const int v = eac_value(tp, i, kind, ch);
+			lo = v < lo ? v : lo;
+			hi = v > hi ? v : hi;
+		}
+	}
+	if (lo > hi)
+		lo = hi = 0;
+	const int step = kind == 0 ? 1 : 8;
+	const int bmin = kind == 2 ? -127 : 0, bmax = kind == 2 ? 127 : 255;
+	unsigned long long key = ~0ull;
+	uint32_t pay = 0;
+	if (lane < 48u) {
+		const int t = (int)(lane/3u), dm = (int)(lane - 3u*(uint32_t)t) - 1;
+		const int span = k_eac_mod[t][7] - k_eac_mod[t][3];
+		const int m0 = ((hi - lo) + (span*step)/2)/(span*step);
+		const int mult = clampi(m0 + dm, 1, 15);
+		const int centre = (lo + hi - (k_eac_mod[t][7] + k_eac_mod[t][3])*mult*step)/2;
+		const int b0 = kind == 1 ? (centre - 4)/8 : (kind == 2 ? centre/8 : centre);
+		uint32_t berr = 0xFFFFFFFFu;
+		int bbase = 0, bdb = 0;
+		for (int db = -R; db <= R; ++db) {
+			const int base = clampi(b0 + db, bmin, bmax);
+			uint32_t err = 0;
+#pragma unroll 1
+			for (uint32_t i = 0; i < 16u; ++i) {
+				if (!((active >> i) & 1u))
+					continue;
+				const int v = eac_value(tp, i, kind, ch);
+				uint32_t be = 0xFFFFFFFFu;
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					const int d = eac_decode(kind, base, k_eac_mod[t][k], mult) - v;
+					const uint32_t e = (uint32_t)(d*d);
+					be = e < be ? e : be;
+				}
+				err += be;
+			}
+			if (err < berr) { berr = err; bbase = base; bdb = db + R; }
+		}
+		key = ((unsigned long long)berr << 32) | (uint32_t)(((t*3 + dm + 1)*(2*R + 1)) + bdb);
+		pay = (uint32_t)(bbase & 0xFFFF) | ((uint32_t)mult << 16) | ((uint32_t)t << 24);
+	}
+	const unsigned long long kmin = cf_wave_min_u64(key);
+	const uint32_t wl = (uint32_t)__builtin_ctzll(__ballot(key == kmin));
+	pay = (uint32_t)__shfl((int)pay, (int)wl, 64);
+	const int base = (int)(short)(pay & 0xFFFFu), mult = (int)((pay >> 16) & 255u),
+		table = (int)(pay >> 24);
+	unsigned long long bits = 0ull;
+#pragma unroll 1
+	for (uint32_t i = 0; i < 16u; ++i) {
+		const uint32_t x = i & 3u, y = i >> 2, k = x*4u + y;
+		const int v = eac_value(tp, i, kind, ch);
+		uint32_t be = 0xFFFFFFFFu, bk = 0;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const int d = eac_decode(kind, base, k_eac_mod[table][j], mult) - v;
+			const uint32_t e = (uint32_t)(d*d);
+			if (e < be) { be = e; bk = (uint32_t)j; }
+		}
+		bits |= (unsigned long long)bk << (45u - 3u*k);
+	}
+	// bytes: base, mult<<4|table, then the 48 index bits big-endian
+	const uint32_t b0 = (uint32_t)(base & 255), b1 = ((uint32_t)mult << 4) | (uint32_t)table;
+	const uint32_t w0 = b0 | (b1 << 8) | ((uint32_t)((bits >> 40) & 255ull) << 16) |
+		((uint32_t)((bits >> 32) & 255ull) << 24);
+	const uint32_t w1 = bswap32((uint32_t)bits);
+	return make_uint2(w0, w1);
+}
+
+__device__ __forceinline__ uint32_t r11_word(float f, bool snorm)
+{
+	int v;
+	if (snorm) {
+		f = f < -1.0f ? -1.0f : (f > 1.0f ? 1.0f : f);
+		v = (int)roundf(f*1023.0f);
+	} else {
+		f = f < 0.0f ? 0.0f : (f > 1.0f ? 1.0f : f);
+		v = (int)roundf(f*2047.0f);
+	}
+	return (uint32_t)v & 0xFFFFu;
+}
+
+} // namespace
+
+template <int PIX, int FMT, bool SNORM>
+__global__ void __launch_bounds__(CF_WG_THREADS)
+cfhip_etc_encode_kernel(cf_kparams kp)
+{
+	constexpr bool IS_EAC = FMT == E_R11 || FMT == E_RG11;
+	constexpr uint32_t BYTES = (FMT == E_A8 || FMT == E_RG11) ? 16u : 8u;
+	__shared__ uint32_t tile[CF_BLOCKS_PER_WG*16];
+	__shared__ uint32_t outb[CF_BLOCKS_PER_WG*4];
+	const uint32_t bx0 = blockIdx.x*CF_BLOCKS_PER_WG;
+	const uint32_t byy = blockIdx.y;
+	{
+		const uint32_t t = threadIdx.x;
+		const uint32_t row = t >> 6, col = t & 63u;
+		uint32_t x = bx0*4u + col, y = byy*4u + row;
+		x = x < kp.width ? x : kp.width - 1u;
+		y = y < kp.height ? y : kp.height - 1u;
+		const uint8_t* rowp = kp.src + (long long)y*kp.pitch;
+		uint32_t px;
+		if (PIX == 0) {
+			px = *reinterpret_cast<const uint32_t*>(rowp + (size_t)x*4u);
+			if (IS_EAC)
+				px = r11_word((float)(px & 255u)/255.0f, SNORM) |
+					(r11_word((float)((px >> 8) & 255u)/255.0f, SNORM) << 16);
+		} else {
+			const float4 f = *reinterpret_cast<const float4*>(rowp + (size_t)x*16u);
+			if (IS_EAC)
+				px = r11_word(f.x, SNORM) | (r11_word(f.y, SNORM) << 16);
+			else
+				px = cf_unorm8(f.x) | (cf_unorm8(f.y) << 8) | (cf_unorm8(f.z) << 16) |
+					(cf_unorm8(f.w) << 24);
+		}
+		tile[(col >> 2)*16u + row*4u + (col & 3u)] = px;
+	}
+	__syncthreads();
+
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const uint32_t q = kp.quality;
+	const int R = q <= 1u ? 1 : (q == 2u ? 2 : 4);
+	for (uint32_t j = 0; j < 4u; ++j) {
+		const uint32_t b = wave*4u + j;
+		if (bx0 + b >= kp.bx)
+			break;
+		const uint32_t* tp = tile + b*16u;
+		// texels inside the image (EtcConverter.cpp:122-129)
+		uint32_t valid = 0;
+#pragma unroll
+		for (uint32_t i = 0; i < 16u; ++i)
+			if ((bx0 + b)*4u + (i & 3u) < kp.width && byy*4u + (i >> 2) < kp.height)
+				valid |= 1u << i;
+		RgbOpts o;
+		o.allow_indiv = false; o.allow_planar = false; o.punch = false; o.a1 = false;
+		o.active = valid; o.transparent = 0;
+		o.wt[0] = (int)kp.wt[0]; o.wt[1] = (int)kp.wt[1]; o.wt[2] = (int)kp.wt[2];
+		o.radius = q >= 3u ? 2 : 1;
+		uint2 w0 = make_uint2(0, 0), w1 = make_uint2(0, 0);
+		if (FMT == E_ETC1) {
+			o.allow_indiv = true;
+			w0 = rgb_search(tp, o, lane);
+		} else if (FMT == E_RGB) {
+			o.allow_indiv = true; o.allow_planar = true;
+			w0 = rgb_search(tp, o, lane);
+		} else if (FMT == E_A1) {
+			const uint32_t transp = (uint32_t)__ballot(lane < 16u && (tp[lane & 15u] >> 24) < 128u) & valid;
+			o.a1 = true; o.punch = transp != 0u; o.transparent = transp;
+			o.active = valid & ~transp;
+			o.allow_planar = true;
+			w0 = rgb_search(tp, o, lane);
+		} else if (FMT == E_A8) {
+			w0 = eac_search(tp, 0, 3, valid, R, lane);
+			o.allow_indiv = true; o.allow_planar = true;
+			w1 = rgb_search(tp, o, lane);
+		} else {
+			w0 = eac_search(tp, SNORM ? 2 : 1, 0, valid, R, lane);
+			if (FMT == E_RG11)
+				w1 = eac_search(tp, SNORM ? 2 : 1, 1, valid, R, lane);
+		}
+		if (lane == 0u) {
+			if (BYTES == 8u) {
+				outb[b*2u] = w0.x; outb[b*2u + 1u] = w0.y;
+			} else {
+				outb[b*4u] = w0.x; outb[b*4u + 1u] = w0.y;
+				outb[b*4u + 2u] = w1.x; outb[b*4u + 3u] = w1.y;
+			}
+		}
+	}
+	__syncthreads();
+	const uint32_t t = threadIdx.x;
+	constexpr uint32_t WPB = BYTES/4u;
+	if (t < CF_BLOCKS_PER_WG*WPB) {
+		const uint32_t b = t/WPB;
+		if (bx0 + b < kp.bx) {
+			uint32_t* dst = reinterpret_cast<uint32_t*>(kp.out + ((size_t)byy*kp.bx + bx0)*BYTES);
+			dst[t] = outb[t];
+		}
+	}
+}
+
+template <int PIX>
+static hipError_t etc_launch_fmt(const cf_kparams* kp, int format, int snorm, dim3 grid, dim3 block,
+	hipStream_t stream)
+{
+#define CF_E(F, S) hipLaunchKernelGGL((cfhip_etc_encode_kernel<PIX, F, S>), grid, block, 0, stream, *kp)
+	switch (format) {
+		case E_ETC1: CF_E(E_ETC1, false); break;
+		case E_RGB: CF_E(E_RGB, false); break;
+		case E_A1: CF_E(E_A1, false); break;
+		case E_A8: CF_E(E_A8, false); break;
+		case E_R11: if (snorm) CF_E(E_R11, true); else CF_E(E_R11, false); break;
+		case E_RG11: if (snorm) CF_E(E_RG11, true); else CF_E(E_RG11, false); break;
+		default: return hipErrorInvalidValue;
+	}
+#undef CF_E
+	return hipGetLastError();
+}
+
+extern "C" hipError_t cfhip_launch_etc(const cf_kparams* kp, int format, int pixel_type, int snorm,
+	hipStream_t stream)
+{
+	dim3 grid((kp->bx + CF_BLOCKS_PER_WG - 1)/CF_BLOCKS_PER_WG, kp->by, 1);
+	dim3 block(CF_WG_THREADS, 1, 1);
+	if (pixel_type == 0)
+		return etc_launch_fmt<0>(kp, format, snorm, grid, block, stream);
+	return etc_launch_fmt<1>(kp, format, snorm, grid, block, stream);
+}

@@ -28,7 +28,8 @@ import numpy as np
 from . import api
 from .api import Alpha, ColorSpace, Format, Quality, Type
 
-_NATIVE_SRGB = {Format.BC1_RGB, Format.BC1_RGBA, Format.BC2, Format.BC3, Format.BC7}
+_NATIVE_SRGB = {Format.BC1_RGB, Format.BC1_RGBA, Format.BC2, Format.BC3, Format.BC7,
+                Format.ETC2_R8G8B8, Format.ETC2_R8G8B8A1, Format.ETC2_R8G8B8A8}
 
 
 class Texture:

@@ -41,7 +41,13 @@ enum cfhip_format {
 	CFHIP_FORMAT_BC4 = 33,
 	CFHIP_FORMAT_BC5 = 34,
 	CFHIP_FORMAT_BC6H = 35,
-	CFHIP_FORMAT_BC7 = 36
+	CFHIP_FORMAT_BC7 = 36,
+	CFHIP_FORMAT_ETC1 = 37,
+	CFHIP_FORMAT_ETC2_R8G8B8 = 38,
+	CFHIP_FORMAT_ETC2_R8G8B8A1 = 39,
+	CFHIP_FORMAT_ETC2_R8G8B8A8 = 40,
+	CFHIP_FORMAT_EAC_R11 = 41,
+	CFHIP_FORMAT_EAC_R11G11 = 42
 };
 
 /* cuttlefish::Texture::Type (Texture.h:135-143) */

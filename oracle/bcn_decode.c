@@ -252,6 +252,8 @@ int cfo_block_info(int format, int* bw, int* bh, int* bytes)
 		case CFO_FMT_BC1_RGB: case CFO_FMT_BC1_RGBA: case CFO_FMT_BC4: sz = 8; break;
 		case CFO_FMT_BC2: case CFO_FMT_BC3: case CFO_FMT_BC5:
 		case CFO_FMT_BC6H: case CFO_FMT_BC7: sz = 16; break;
+		case 37: case 38: case 39: case 41: sz = 8; break;    /* ETC1, ETC2 RGB, RGBA1, EAC R11 */
+		case 40: case 42: sz = 16; break;                     /* ETC2 RGBA8, EAC RG11 */
 		default: return -1;
 	}
 	if (bw) *bw = 4;

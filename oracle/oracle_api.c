@@ -20,6 +20,10 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 int cfo_encode_bc15_block(const float rgbaf[64], const uint8_t rgba[64], uint8_t* out,
 	const cfo_params* p);
 void cfo_encode_bc6h_block(const uint16_t rgba_half[64], uint8_t out[16], const cfo_params* p);
+int cfo_encode_etc_block(const float rgbaf[64], const uint8_t rgba[64], unsigned valid,
+	uint8_t* out, const cfo_params* p);
+void cfo_decode_etc_rgb(const uint8_t* blk, int a1, uint8_t* rgba64);
+void cfo_decode_eac(const uint8_t* blk, int kind, int* out16);
 int cfo_decode_bc6h(const uint8_t* blk, int flags, uint16_t* rgb48);
 
 typedef struct {
@@ -149,6 +153,15 @@ static void* worker(void* arg)
 				}
 			}
 			cfo_encode_bc6h_block(hb, dst, j->p);
+		} else if (j->p->format >= 37 && j->p->format <= 42) {
+			/* EtcConverter::process (EtcConverter.cpp:122-129): only in-image texels count */
+			unsigned valid = 0;
+			for (uint32_t r = 0; r < 4; ++r)
+				for (uint32_t c = 0; c < 4; ++c)
+					if (x*4 + c < j->width && y*4 + r < j->height)
+						valid |= 1u << (r*4 + c);
+			if (cfo_encode_etc_block(f, u, valid, dst, j->p) != 0)
+				j->status = -1;
 		} else if (j->p->format == CFO_FMT_BC7)
 			cfo_encode_bc7_block(u, dst, j->p);
 		else if (cfo_encode_bc15_block(f, u, dst, j->p) != 0)
@@ -213,5 +226,51 @@ int cfo_decode_bc6h_image(const void* blocks, int type, uint32_t width, uint32_t
 				for (uint32_t i = 0; i < 4 && x*4 + i < width; ++i)
 					memcpy(rgb_out + (((size_t)y*4 + j)*width + x*4 + i)*3, px + (j*4 + i)*3, 6);
 		}
+	return 0;
+}
+
+/* Decode an ETC1 / ETC2 RGB / RGBA1 / RGBA8 payload to RGBA8. */
+int cfo_decode_etc_image(int format, const void* blocks, uint32_t width, uint32_t height,
+	uint8_t* rgba_out)
+{
+	uint32_t bx = (width + 3)/4, by = (height + 3)/4;
+	int bs = format == 40 ? 16 : 8;
+	const uint8_t* src = (const uint8_t*)blocks;
+	for (uint32_t y = 0; y < by; ++y)
+		for (uint32_t x = 0; x < bx; ++x) {
+			const uint8_t* blk = src + ((size_t)y*bx + x)*(size_t)bs;
+			uint8_t px[64];
+			cfo_decode_etc_rgb(format == 40 ? blk + 8 : blk, format == 39, px);
+			if (format == 40) {
+				int a[16];
+				cfo_decode_eac(blk, 0, a);
+				for (int i = 0; i < 16; ++i)
+					px[4*i + 3] = (uint8_t)a[i];
+			}
+			for (uint32_t j = 0; j < 4 && y*4 + j < height; ++j)
+				for (uint32_t i = 0; i < 4 && x*4 + i < width; ++i)
+					memcpy(rgba_out + (((size_t)y*4 + j)*width + x*4 + i)*4, px + (j*4 + i)*4, 4);
+		}
+	return 0;
+}
+
+/* Decode an EAC R11 / RG11 payload to int32 per channel (w*h*nch), unsigned 0..2047 or
+ * signed -1023..1023. */
+int cfo_decode_eac_image(int format, int type, const void* blocks, uint32_t width,
+	uint32_t height, int32_t* out)
+{
+	uint32_t bx = (width + 3)/4, by = (height + 3)/4;
+	int nch = format == 42 ? 2 : 1;
+	const uint8_t* src = (const uint8_t*)blocks;
+	for (uint32_t y = 0; y < by; ++y)
+		for (uint32_t x = 0; x < bx; ++x)
+			for (int ch = 0; ch < nch; ++ch) {
+				int v[16];
+				cfo_decode_eac(src + (((size_t)y*bx + x)*(size_t)nch + (size_t)ch)*8,
+					type == CFO_TYPE_SNORM ? 2 : 1, v);
+				for (uint32_t j = 0; j < 4 && y*4 + j < height; ++j)
+					for (uint32_t i = 0; i < 4 && x*4 + i < width; ++i)
+						out[(((size_t)y*4 + j)*width + x*4 + i)*(size_t)nch + (size_t)ch] = v[j*4 + i];
+			}
 	return 0;
 }

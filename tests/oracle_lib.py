@@ -107,6 +107,32 @@ def decode_bc6h(blocks: np.ndarray, width: int, height: int, typ=4) -> np.ndarra
     return out.view(np.float16)
 
 
+def decode_etc(blocks: np.ndarray, fmt, width: int, height: int) -> np.ndarray:
+    """ETC1 / ETC2 RGB / RGBA1 / RGBA8 (fmt 37..40) -> (h, w, 4) uint8."""
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
+    out = np.zeros((height, width, 4), np.uint8)
+    L = lib()
+    L.cfo_decode_etc_image.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32,
+                                       ctypes.c_uint32, ctypes.c_void_p]
+    if L.cfo_decode_etc_image(int(fmt), blocks.ctypes.data, width, height, out.ctypes.data) != 0:
+        raise RuntimeError("cfo_decode_etc_image failed")
+    return out
+
+
+def decode_eac(blocks: np.ndarray, fmt, width: int, height: int, typ=0) -> np.ndarray:
+    """EAC R11 / RG11 (fmt 41/42) -> (h, w, nch) int32 (0..2047 or -1023..1023)."""
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
+    nch = 2 if int(fmt) == 42 else 1
+    out = np.zeros((height, width, nch), np.int32)
+    L = lib()
+    L.cfo_decode_eac_image.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                       ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    if L.cfo_decode_eac_image(int(fmt), int(typ), blocks.ctypes.data, width, height,
+                              out.ctypes.data) != 0:
+        raise RuntimeError("cfo_decode_eac_image failed")
+    return out
+
+
 def decode(blocks: np.ndarray, fmt, width: int, height: int, typ=0) -> np.ndarray:
     blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
     out = np.zeros((height, width, 4), np.uint8)
