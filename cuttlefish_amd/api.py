@@ -32,6 +32,20 @@ class Format(enum.IntEnum):
     ETC2_R8G8B8A8 = 40
     EAC_R11 = 41
     EAC_R11G11 = 42
+    ASTC_4x4 = 43
+    ASTC_5x4 = 44
+    ASTC_5x5 = 45
+    ASTC_6x5 = 46
+    ASTC_6x6 = 47
+    ASTC_8x5 = 48
+    ASTC_8x6 = 49
+    ASTC_8x8 = 50
+    ASTC_10x5 = 51
+    ASTC_10x6 = 52
+    ASTC_10x8 = 53
+    ASTC_10x10 = 54
+    ASTC_12x10 = 55
+    ASTC_12x12 = 56
 
 
 class Type(enum.IntEnum):

@@ -1,0 +1,394 @@
+// astc_encode.hip -- ASTC 2-D LDR block encoder (restricted subset) for gfx950, one
+// wavefront per block, lane = (weight-grid config, endpoint-inset variant).
+//
+// Replaces, behind cfhip_encode(), the per-block astcenc_compress_image call of
+// AstcConverter::process (lib/src/AstcConverter.cpp:208-230; ARM astc-encoder, absent).
+// Twin of oracle/astc_codec.c (byte-identical).  Emitted subset: void-extent blocks and
+// single-partition CEM 8/12 blocks with 8-bit endpoints, pure-bit weight ranges and the
+// specification's bilinear weight infill, for all 14 footprints (4x4 .. 12x12).  No ASTC
+// decoder exists in this environment: validity rests on the specification and on the
+// self-consistent decoder of the oracle (DESIGN.md states this).
+//
+// Data: the workgroup (4 waves) stages a strip of 16 blocks (16*bw x bh texels) in LDS;
+// the per-config infill tables (base grid index + 4 bilinear factors per texel, and the
+// per-grid-point factor sums) are built once per format on the host (cfhip_api.hip) and
+// read through L1/L2; each lane keeps its grid accumulators / quantised weights in a
+// private LDS column ([grid point][lane], conflict-free for a fixed grid point).
+#include "cf_device.h"
+
+#define ASTC_MAX_TEXELS 144
+#define ASTC_CFG_STRIDE 1288   // bytes per config record (see AstcCfgDev in cfhip_api.hip)
+
+namespace {
+
+// config record accessors (layout: N, M, bits, ng, mode16, pad16, den[64] u16, infill[144] u32x2)
+struct CfgView {
+	const uint8_t* p;
+	__device__ __forceinline__ uint32_t N() const { return p[0]; }
+	__device__ __forceinline__ uint32_t M() const { return p[1]; }
+	__device__ __forceinline__ uint32_t bits() const { return p[2]; }
+	__device__ __forceinline__ uint32_t ng() const { return p[3]; }
+	__device__ __forceinline__ uint32_t mode() const { return *reinterpret_cast<const uint16_t*>(p + 4); }
+	__device__ __forceinline__ uint32_t den(uint32_t j) const
+	{
+		return reinterpret_cast<const uint16_t*>(p + 8)[j];
+	}
+	__device__ __forceinline__ uint2 infill(uint32_t i) const
+	{
+		return reinterpret_cast<const uint2*>(p + 136)[i];
+	}
+};
+
+__device__ __forceinline__ int unq_weight(int q, int bits)
+{
+	int v;
+	switch (bits) {
+		case 1: v = q ? 63 : 0; break;
+		case 2: v = (q << 4) | (q << 2) | q; break;
+		case 3: v = (q << 3) | q; break;
+		case 4: v = (q << 2) | (q >> 2); break;
+		default: v = (q << 1) | (q >> 4); break;
+	}
+	return v > 32 ? v + 1 : v;
+}
+
+__device__ __forceinline__ float clampf255(float x) { return x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x); }
+
+__device__ const uint8_t k_inset[8][2] = {{0, 0}, {1, 1}, {2, 2}, {3, 3}, {1, 0}, {0, 1}, {2, 0},
+	{0, 2}};
+
+// reconstructed weight of texel i from this lane's quantised grid (private LDS column)
+__device__ __forceinline__ int texel_weight(const CfgView& cfg, uint32_t i, const uint8_t* qcol,
+	uint32_t N, int bits)
+{
+	const uint2 f = cfg.infill(i);
+	const uint32_t v0 = f.x & 255u, w00 = (f.x >> 8) & 255u, w01 = (f.x >> 16) & 255u,
+		w10 = f.x >> 24, w11 = f.y & 255u;
+	int v = (int)w00*unq_weight(qcol[v0*64u], bits) + 8;
+	if (w01) v += (int)w01*unq_weight(qcol[(v0 + 1u)*64u], bits);
+	if (w10) v += (int)w10*unq_weight(qcol[(v0 + N)*64u], bits);
+	if (w11) v += (int)w11*unq_weight(qcol[(v0 + N + 1u)*64u], bits);
+	return v >> 4;
+}
+
+__device__ __forceinline__ uint32_t astc_error(const uint32_t* tp, uint32_t n, uint32_t nc,
+	const int (&e0)[4], const int (&e1)[4], const CfgView& cfg, const uint8_t* qcol, uint32_t N, int bits)
+{
+	uint32_t err = 0;
+#pragma unroll 1
+	for (uint32_t i = 0; i < n; ++i) {
+		const int w = texel_weight(cfg, i, qcol, N, bits);
+		const uint32_t p = tp[i];
+#pragma unroll
+		for (uint32_t c = 0; c < 4u; ++c) {
+			if (c < nc) {
+				const int v = ((e0[c]*257*(64 - w) + e1[c]*257*w + 32) >> 6) >> 8;
+				const int d = v - (int)((p >> (8u*c)) & 255u);
+				err += (uint32_t)(d*d);
+			}
+		}
+	}
+	return err;
+}
+
+} // namespace
+
+template <int PIX>
+__global__ void __launch_bounds__(CF_WG_THREADS)
+cfhip_astc_encode_kernel(cf_kparams kp)
+{
+	__shared__ uint32_t tile[CF_BLOCKS_PER_WG*ASTC_MAX_TEXELS];
+	__shared__ uint16_t lane_num[4][64*64];     // [wave][grid point * 64 + lane]
+	__shared__ uint8_t lane_q[4][64*64];
+	__shared__ uint4 outb[CF_BLOCKS_PER_WG];
+	const uint32_t bw = kp.flags & 255u, bh = (kp.flags >> 8) & 255u, n = bw*bh;
+	const uint32_t bx0 = blockIdx.x*CF_BLOCKS_PER_WG, byy = blockIdx.y;
+	{
+		// stage 16 blocks: (16*bw) x bh texels, coalesced along x, stored block-major
+		const uint32_t sw = CF_BLOCKS_PER_WG*bw, total = sw*bh;
+		for (uint32_t idx = threadIdx.x; idx < total; idx += CF_WG_THREADS) {
+			const uint32_t row = idx/sw, col = idx - row*sw;
+			const uint32_t blk = col/bw, cx = col - blk*bw;
+			uint32_t x = bx0*bw + col, y = byy*bh + row;
+			x = x < kp.width ? x : kp.width - 1u;
+			y = y < kp.height ? y : kp.height - 1u;
+			const uint8_t* rowp = kp.src + (long long)y*kp.pitch;
+			uint32_t px;
+			if (PIX == 0)
+				px = *reinterpret_cast<const uint32_t*>(rowp + (size_t)x*4u);
+			else {
+				const float4 f = *reinterpret_cast<const float4*>(rowp + (size_t)x*16u);
+				px = cf_unorm8(f.x) | (cf_unorm8(f.y) << 8) | (cf_unorm8(f.z) << 16) |
+					(cf_unorm8(f.w) << 24);
+			}
+			// swizzle from colour mask / alpha type (AstcConverter.cpp:140-149)
+			tile[blk*ASTC_MAX_TEXELS + row*bw + cx] = (px & kp.keep_mask) | kp.set_mask;
+		}
+	}
+	__syncthreads();
+
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const uint8_t* tables = reinterpret_cast<const uint8_t*>(kp.aux);
+	const uint32_t q = kp.quality > 4u ? 4u : kp.quality;
+	const uint32_t qcfg = q == 0u ? 1u : (q == 1u ? 2u : (q == 2u ? 4u : 8u));
+	const uint32_t qvar = q == 0u ? 1u : (q == 1u ? 2u : 8u);
+	const bool refit = q >= 2u;
+	uint16_t* ncol = lane_num[wave] + lane;
+	uint8_t* qcol = lane_q[wave] + lane;
+
+	for (uint32_t j = 0; j < 4u; ++j) {
+		const uint32_t b = wave*4u + j;
+		if (bx0 + b >= kp.bx)
+			break;
+		const uint32_t* tp = tile + b*ASTC_MAX_TEXELS;
+		// solid / alpha tests over the texels (lanes stride)
+		const uint32_t p0 = tp[0];
+		bool diff = false, alpha = false;
+		for (uint32_t i = lane; i < n; i += 64u) {
+			const uint32_t p = tp[i];
+			diff = diff || p != p0;
+			alpha = alpha || (p >> 24) != 255u;
+		}
+		const bool solid = __ballot(diff) == 0ull;
+		const bool has_alpha = __ballot(alpha) != 0ull;
+		if (solid) {
+			if (lane == 0u) {
+				// void-extent block: 0xFFFFFFFFFFFFFDFC + RGBA as UNORM16 (c * 257)
+				const uint32_t r = p0 & 255u, g = (p0 >> 8) & 255u, bl = (p0 >> 16) & 255u, a = p0 >> 24;
+				outb[b] = make_uint4(0xFFFFFDFCu, 0xFFFFFFFFu, (r*257u) | ((g*257u) << 16),
+					(bl*257u) | ((a*257u) << 16));
+			}
+			continue;
+		}
+		const uint32_t nc = has_alpha ? 4u : 3u;
+		const uint8_t* set = tables + (has_alpha ? 8u + 8u*ASTC_CFG_STRIDE : 8u);
+		const uint32_t ncfg_all = tables[has_alpha ? 1 : 0];
+		const uint32_t use_cfg = ncfg_all < qcfg ? ncfg_all : qcfg;
+
+		// PCA extremes of the block (uniform work, same float order as the oracle)
+		int sum[4] = {0, 0, 0, 0};
+#pragma unroll 1
+		for (uint32_t i = 0; i < n; ++i) {
+			const uint32_t p = tp[i];
+#pragma unroll
+			for (uint32_t c = 0; c < 4u; ++c)
+				sum[c] += c < nc ? (int)((p >> (8u*c)) & 255u) : 0;
+		}
+		const float in = 1.0f/(float)n;
+		float mean[4];
+#pragma unroll
+		for (int c = 0; c < 4; ++c)
+			mean[c] = (float)sum[c]*in;
+		float C00 = 0, C01 = 0, C02 = 0, C03 = 0, C11 = 0, C12 = 0, C13 = 0, C22 = 0, C23 = 0, C33 = 0;
+#pragma unroll 1
+		for (uint32_t i = 0; i < n; ++i) {
+			const uint32_t p = tp[i];
+			const float d0 = (float)(p & 255u) - mean[0], d1 = (float)((p >> 8) & 255u) - mean[1];
+			const float d2 = (float)((p >> 16) & 255u) - mean[2];
+			const float d3 = nc == 4u ? (float)(p >> 24) - mean[3] : 0.0f;
+			C00 = fmaf(d0, d0, C00); C01 = fmaf(d0, d1, C01); C02 = fmaf(d0, d2, C02); C03 = fmaf(d0, d3, C03);
+			C11 = fmaf(d1, d1, C11); C12 = fmaf(d1, d2, C12); C13 = fmaf(d1, d3, C13);
+			C22 = fmaf(d2, d2, C22); C23 = fmaf(d2, d3, C23);
+			C33 = fmaf(d3, d3, C33);
+		}
+		float bestd = C00, v0 = C00, v1 = C01, v2 = C02, v3 = C03;
+		if (C11 > bestd) { bestd = C11; v0 = C01; v1 = C11; v2 = C12; v3 = C13; }
+		if (C22 > bestd) { bestd = C22; v0 = C02; v1 = C12; v2 = C22; v3 = C23; }
+		if (C33 > bestd) { bestd = C33; v0 = C03; v1 = C13; v2 = C23; v3 = C33; }
+#pragma unroll
+		for (int it = 0; it < 3; ++it) {
+			const float m = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
+			if (m > 0.0f) {
+				const float im = 1.0f/m;
+				v0 = v0*im; v1 = v1*im; v2 = v2*im; v3 = v3*im;
+			}
+			float r0 = C00*v0; r0 = fmaf(C01, v1, r0); r0 = fmaf(C02, v2, r0); r0 = fmaf(C03, v3, r0);
+			float r1 = C01*v0; r1 = fmaf(C11, v1, r1); r1 = fmaf(C12, v2, r1); r1 = fmaf(C13, v3, r1);
+			float r2 = C02*v0; r2 = fmaf(C12, v1, r2); r2 = fmaf(C22, v2, r2); r2 = fmaf(C23, v3, r2);
+			float r3 = C03*v0; r3 = fmaf(C13, v1, r3); r3 = fmaf(C23, v2, r3); r3 = fmaf(C33, v3, r3);
+			v0 = r0; v1 = r1; v2 = r2; v3 = r3;
+		}
+		const float mx = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
+		float axis[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+		if (mx > 0.0f) {
+			const float im = 1.0f/mx;
+			v0 = v0*im; v1 = v1*im; v2 = v2*im; v3 = v3*im;
+			float l2 = v0*v0;
+			l2 = fmaf(v1, v1, l2);
+			l2 = fmaf(v2, v2, l2);
+			l2 = fmaf(v3, v3, l2);
+			const float is = 1.0f/sqrtf(l2);
+			axis[0] = v0*is; axis[1] = v1*is; axis[2] = v2*is; axis[3] = v3*is;
+		}
+		float tmin = 3.0e38f, tmax = -3.0e38f;
+#pragma unroll 1
+		for (uint32_t i = 0; i < n; ++i) {
+			const uint32_t p = tp[i];
+			float t = axis[0]*((float)(p & 255u) - mean[0]);
+			t = fmaf(axis[1], (float)((p >> 8) & 255u) - mean[1], t);
+			t = fmaf(axis[2], (float)((p >> 16) & 255u) - mean[2], t);
+			t = fmaf(axis[3], (nc == 4u ? (float)(p >> 24) : 0.0f) - mean[3], t);
+			tmin = fminf(tmin, t);
+			tmax = fmaxf(tmax, t);
+		}
+		float lo[4], hi[4];
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			lo[c] = clampf255(fmaf(axis[c], tmin, mean[c]));
+			hi[c] = clampf255(fmaf(axis[c], tmax, mean[c]));
+		}
+
+		// ---- lane = (config, inset variant) ----
+		const uint32_t k = lane >> 3, var = lane & 7u;
+		const bool active = k < use_cfg && var < qvar;
+		uint32_t err = 0xFFFFFFFFu;
+		int e0[4] = {0, 0, 0, 255}, e1[4] = {0, 0, 0, 255};
+		CfgView cfg = {set + (active ? k : 0u)*ASTC_CFG_STRIDE};
+		const uint32_t N = cfg.N(), ng = cfg.ng();
+		const int bits = (int)cfg.bits(), qmax = (1 << bits) - 1;
+		if (active) {
+			const float tl = (float)k_inset[var][0]*(1.0f/32.0f), th = (float)k_inset[var][1]*(1.0f/32.0f);
+#pragma unroll
+			for (uint32_t c = 0; c < 4u; ++c) {
+				if (c < nc) {
+					const float d = hi[c] - lo[c];
+					const float a = fmaf(d, tl, lo[c]), bb = fmaf(-d, th, hi[c]);
+					e0[c] = (int)floorf(clampf255(a) + 0.5f);
+					e1[c] = (int)floorf(clampf255(bb) + 0.5f);
+				}
+			}
+			if (e1[0] + e1[1] + e1[2] < e0[0] + e0[1] + e0[2]) {
+#pragma unroll
+				for (int c = 0; c < 4; ++c) { const int t = e0[c]; e0[c] = e1[c]; e1[c] = t; }
+			}
+			int dv[4] = {0, 0, 0, 0}, dd = 0;
+#pragma unroll
+			for (uint32_t c = 0; c < 4u; ++c) {
+				if (c < nc) {
+					dv[c] = e1[c] - e0[c];
+					dd += dv[c]*dv[c];
+				}
+			}
+			for (uint32_t g = 0; g < ng; ++g)
+				ncol[g*64u] = 0;
+#pragma unroll 1
+			for (uint32_t i = 0; i < n; ++i) {
+				const uint32_t p = tp[i];
+				int t = 0, T = 0;
+#pragma unroll
+				for (uint32_t c = 0; c < 4u; ++c)
+					t += c < nc ? ((int)((p >> (8u*c)) & 255u) - e0[c])*dv[c] : 0;
+				if (t > 0 && dd > 0) {
+					T = (128*t + dd)/(2*dd);
+					T = T > 64 ? 64 : T;
+				}
+				const uint2 f = cfg.infill(i);
+				const uint32_t g0 = f.x & 255u, w00 = (f.x >> 8) & 255u, w01 = (f.x >> 16) & 255u,
+					w10 = f.x >> 24, w11 = f.y & 255u;
+				ncol[g0*64u] = (uint16_t)(ncol[g0*64u] + w00*(uint32_t)T);
+				if (w01) ncol[(g0 + 1u)*64u] = (uint16_t)(ncol[(g0 + 1u)*64u] + w01*(uint32_t)T);
+				if (w10) ncol[(g0 + N)*64u] = (uint16_t)(ncol[(g0 + N)*64u] + w10*(uint32_t)T);
+				if (w11) ncol[(g0 + N + 1u)*64u] = (uint16_t)(ncol[(g0 + N + 1u)*64u] + w11*(uint32_t)T);
+			}
+			for (uint32_t g = 0; g < ng; ++g) {
+				const uint32_t den = cfg.den(g);
+				const uint32_t gv = den ? ((uint32_t)ncol[g*64u] + den/2u)/den : 0u;
+				qcol[g*64u] = (uint8_t)((gv*(uint32_t)qmax + 32u) >> 6);
+			}
+			err = astc_error(tp, n, nc, e0, e1, cfg, qcol, N, bits);
+			if (refit) {
+				int S = 0, A = 0, B = 0, C = 0, U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
+#pragma unroll 1
+				for (uint32_t i = 0; i < n; ++i) {
+					const int wi = texel_weight(cfg, i, qcol, N, bits), iw = 64 - wi;
+					const uint32_t p = tp[i];
+					S += wi; A += iw*iw; B += iw*wi; C += wi*wi;
+#pragma unroll
+					for (uint32_t c = 0; c < 4u; ++c) {
+						if (c < nc) {
+							U[c] += iw*(int)((p >> (8u*c)) & 255u);
+							V[c] += wi*(int)((p >> (8u*c)) & 255u);
+						}
+					}
+				}
+				const int det = (int)n*C - S*S;
+				if (det > 0) {
+					const float inv = 1.0f/(64.0f*(float)det);
+					const float fA = (float)A, fB = (float)B, fC = (float)C;
+					int r0[4] = {0, 0, 0, 255}, r1[4] = {0, 0, 0, 255};
+#pragma unroll
+					for (uint32_t c = 0; c < 4u; ++c) {
+						if (c < nc) {
+							const float fU = (float)U[c], fV = (float)V[c];
+							const float t0 = fB*fV;
+							const float n0 = fmaf(fC, fU, -t0);
+							const float t1 = fB*fU;
+							const float n1 = fmaf(fA, fV, -t1);
+							r0[c] = (int)floorf(clampf255(n0*inv) + 0.5f);
+							r1[c] = (int)floorf(clampf255(n1*inv) + 0.5f);
+						}
+					}
+					if (r1[0] + r1[1] + r1[2] >= r0[0] + r0[1] + r0[2]) {
+						const uint32_t e = astc_error(tp, n, nc, r0, r1, cfg, qcol, N, bits);
+						if (e < err) {
+							err = e;
+#pragma unroll
+							for (int c = 0; c < 4; ++c) { e0[c] = r0[c]; e1[c] = r1[c]; }
+						}
+					}
+				}
+			}
+		}
+		const unsigned long long key = ((unsigned long long)err << 32) | lane;   // id = cfg*8 + variant
+		const unsigned long long kmin = cf_wave_min_u64(key);
+		if (key == kmin) {
+			// pack: mode (11) | partitions-1 (2) | CEM (4) | 8-bit endpoint values | ... | weights
+			unsigned long long lo64 = (unsigned long long)cfg.mode() | ((unsigned long long)(has_alpha ? 12u : 8u) << 13);
+			unsigned long long hi64 = 0ull;
+			const int vals[8] = {e0[0], e1[0], e0[1], e1[1], e0[2], e1[2], e0[3], e1[3]};
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				if (i < (has_alpha ? 8 : 6)) {
+					const uint32_t pos = 17u + 8u*(uint32_t)i;
+					const unsigned long long vv = (unsigned long long)(uint32_t)vals[i];
+					if (pos < 64u) {
+						lo64 |= vv << pos;
+						if (pos + 8u > 64u) hi64 |= vv >> (64u - pos);
+					} else
+						hi64 |= vv << (pos - 64u);
+				}
+			}
+			for (uint32_t g = 0; g < ng; ++g) {
+				const uint32_t qv = qcol[g*64u];
+				for (int kb = 0; kb < bits; ++kb) {
+					if ((qv >> kb) & 1u) {
+						const uint32_t pos = 127u - (g*(uint32_t)bits + (uint32_t)kb);
+						if (pos < 64u) lo64 |= 1ull << pos; else hi64 |= 1ull << (pos - 64u);
+					}
+				}
+			}
+			outb[b] = make_uint4((uint32_t)lo64, (uint32_t)(lo64 >> 32), (uint32_t)hi64, (uint32_t)(hi64 >> 32));
+		}
+	}
+	__syncthreads();
+	const uint32_t t = threadIdx.x;
+	if (t < 64u) {
+		const uint32_t b = t >> 2;
+		if (bx0 + b < kp.bx) {
+			const uint32_t* o = reinterpret_cast<const uint32_t*>(outb);
+			uint32_t* dst = reinterpret_cast<uint32_t*>(kp.out + ((size_t)byy*kp.bx + bx0)*16u);
+			dst[t] = o[t];
+		}
+	}
+}
+
+extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, hipStream_t stream)
+{
+	dim3 grid((kp->bx + CF_BLOCKS_PER_WG - 1)/CF_BLOCKS_PER_WG, kp->by, 1);
+	dim3 block(CF_WG_THREADS, 1, 1);
+	if (pixel_type == 0)
+		hipLaunchKernelGGL((cfhip_astc_encode_kernel<0>), grid, block, 0, stream, *kp);
+	else
+		hipLaunchKernelGGL((cfhip_astc_encode_kernel<1>), grid, block, 0, stream, *kp);
+	return hipGetLastError();
+}

@@ -25,7 +25,8 @@ struct cf_kparams {
 	uint32_t keep_mask;    // byte mask of channels kept (colour mask)
 	uint32_t set_mask;     // bytes forced on masked channels (alpha -> 255)
 	uint32_t wt[4];        // channel error weights
-	uint32_t flags;        // format specific
+	uint32_t flags;        // format specific (ASTC: footprint bw | bh << 8)
+	const void* aux;       // format specific device table (ASTC: config / infill records)
 };
 
 __device__ __forceinline__ uint32_t cf_rfl(uint32_t v)

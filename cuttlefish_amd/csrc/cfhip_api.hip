@@ -13,11 +13,14 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <algorithm>
+#include <map>
 #include <string>
 #include <vector>
 
 extern "C" hipError_t cfhip_launch_bc7(const cf_kparams* kp, int pixel_type, int unit_weights,
 	hipStream_t stream);
+extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, hipStream_t stream);
 extern "C" hipError_t cfhip_launch_etc(const cf_kparams* kp, int format, int pixel_type, int snorm,
 	hipStream_t stream);
 extern "C" hipError_t cfhip_launch_bc6h(const cf_kparams* kp, int pixel_type, int is_signed,
@@ -32,6 +35,7 @@ struct cfhip_ctx {
 	size_t src_cap = 0;
 	void* d_out = nullptr;
 	size_t out_cap = 0;
+	std::map<int, void*> astc_tables; // per-format device tables (built on first use)
 	std::vector<hipEvent_t> events;   // start/stop pairs of the last call
 	size_t events_used = 0;
 	hipStream_t events_stream = nullptr;
@@ -62,6 +66,116 @@ int fail(cfhip_ctx* ctx, int code, const char* fmt, ...)
 #define HIP_TRY(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
 	return fail((ctx), CFHIP_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
+// ---- ASTC: weight-grid configs and infill tables (ASTC specification: block mode layout,
+// weight infill).  Built once per format on the host; astc_encode.hip reads the records.
+// Record (ASTC_CFG_STRIDE = 1288 B): N, M, bits, ng, mode u16, pad u16, den[64] u16,
+// infill[144] {v0 | w00<<8 | w01<<16 | w10<<24, w11}.  Table: ncfg(rgb), ncfg(rgba), pad[6],
+// 8 RGB records, 8 RGBA records.
+struct AstcCfgHost { int N, M, bits, mode; };
+
+bool astc_footprint(int format, int* bw, int* bh)
+{
+	static const unsigned char fp[14][2] = {{4, 4}, {5, 4}, {5, 5}, {6, 5}, {6, 6}, {8, 5}, {8, 6},
+		{8, 8}, {10, 5}, {10, 6}, {10, 8}, {10, 10}, {12, 10}, {12, 12}};
+	if (format < CFHIP_FORMAT_ASTC_4x4 || format > CFHIP_FORMAT_ASTC_12x12)
+		return false;
+	*bw = fp[format - CFHIP_FORMAT_ASTC_4x4][0];
+	*bh = fp[format - CFHIP_FORMAT_ASTC_4x4][1];
+	return true;
+}
+
+int astc_block_mode(int N, int M, int bits)
+{
+	int H, r;
+	switch (bits) {
+		case 1: H = 0; r = 2; break;
+		case 2: H = 0; r = 4; break;
+		case 3: H = 0; r = 7; break;
+		case 4: H = 1; r = 4; break;
+		case 5: H = 1; r = 7; break;
+		default: return -1;
+	}
+	const int R0 = r & 1, R1 = (r >> 1) & 1, R2 = (r >> 2) & 1;
+	const int lowA = (H << 9) | (R0 << 4) | (R2 << 1) | R1;
+	const int lowB = (H << 9) | (R0 << 4) | (R2 << 3) | (R1 << 2);
+	if (N >= 4 && N <= 7 && M >= 2 && M <= 5) return lowA | ((N - 4) << 7) | ((M - 2) << 5);
+	if (N >= 8 && N <= 11 && M >= 2 && M <= 5) return lowA | ((N - 8) << 7) | ((M - 2) << 5) | (1 << 2);
+	if (N >= 2 && N <= 5 && M >= 8 && M <= 11) return lowA | ((M - 8) << 7) | ((N - 2) << 5) | (2 << 2);
+	if (N >= 2 && N <= 5 && M >= 6 && M <= 7) return lowA | ((M - 6) << 7) | ((N - 2) << 5) | (3 << 2);
+	if (N >= 2 && N <= 3 && M >= 2 && M <= 5)
+		return lowA | (1 << 8) | ((N - 2) << 7) | ((M - 2) << 5) | (3 << 2);
+	if (N == 12 && M >= 2 && M <= 5) return lowB | ((M - 2) << 5);
+	if (M == 12 && N >= 2 && N <= 5) return lowB | (1 << 7) | ((N - 2) << 5);
+	if (N == 6 && M == 10) return lowB | (3 << 7);
+	if (N == 10 && M == 6) return lowB | (3 << 7) | (1 << 5);
+	if (!H && N >= 6 && N <= 9 && M >= 6 && M <= 9)
+		return (R0 << 4) | (R2 << 3) | (R1 << 2) | (1 << 8) | ((N - 6) << 5) | ((M - 6) << 9);
+	return -1;
+}
+
+std::vector<AstcCfgHost> astc_configs(int bw, int bh, int nvals)
+{
+	std::vector<AstcCfgHost> all;
+	const int budget = 128 - 17 - 8*nvals;
+	for (int N = 2; N <= bw && N <= 12; ++N)
+		for (int M = 2; M <= bh && M <= 12; ++M)
+			for (int b = 1; b <= 5; ++b) {
+				const int wb = N*M*b, mode = astc_block_mode(N, M, b);
+				if (N*M > 64 || wb < 24 || wb > 96 || wb > budget || mode < 0)
+					continue;
+				all.push_back({N, M, b, mode});
+			}
+	// more weight bits, then more weights, then wider grid first (a strict total order)
+	std::sort(all.begin(), all.end(), [](const AstcCfgHost& a, const AstcCfgHost& b) {
+		const int ka = a.N*a.M*a.bits, kb = b.N*b.M*b.bits;
+		if (ka != kb) return ka > kb;
+		if (a.N*a.M != b.N*b.M) return a.N*a.M > b.N*b.M;
+		return a.N > b.N;
+	});
+	if (all.size() > 8)
+		all.resize(8);
+	return all;
+}
+
+const size_t kAstcStride = 1288;
+
+std::vector<uint8_t> astc_build_tables(int bw, int bh)
+{
+	std::vector<uint8_t> t(8 + 16*kAstcStride, 0);
+	for (int set = 0; set < 2; ++set) {
+		const std::vector<AstcCfgHost> cfgs = astc_configs(bw, bh, set ? 8 : 6);
+		t[set] = (uint8_t)cfgs.size();
+		for (size_t k = 0; k < cfgs.size(); ++k) {
+			uint8_t* r = t.data() + 8 + ((size_t)set*8 + k)*kAstcStride;
+			const int N = cfgs[k].N, M = cfgs[k].M;
+			r[0] = (uint8_t)N; r[1] = (uint8_t)M; r[2] = (uint8_t)cfgs[k].bits; r[3] = (uint8_t)(N*M);
+			const uint16_t mode = (uint16_t)cfgs[k].mode;
+			memcpy(r + 4, &mode, 2);
+			uint16_t den[64] = {0};
+			const int Ds = (1024 + bw/2)/(bw - 1), Dt = (1024 + bh/2)/(bh - 1);
+			for (int tt = 0; tt < bh; ++tt)
+				for (int s = 0; s < bw; ++s) {
+					const int cs = Ds*s, ct = Dt*tt;
+					const int gs = (cs*(N - 1) + 32) >> 6, gt = (ct*(M - 1) + 32) >> 6;
+					const int js = gs >> 4, fs = gs & 15, jt = gt >> 4, ft = gt & 15;
+					const int w11 = (fs*ft + 8) >> 4, w10 = ft - w11, w01 = fs - w11;
+					const int w00 = 16 - fs - ft + w11, v0 = js + jt*N;
+					const uint32_t a = (uint32_t)v0 | ((uint32_t)w00 << 8) | ((uint32_t)w01 << 16) |
+						((uint32_t)w10 << 24), b = (uint32_t)w11;
+					uint8_t* e = r + 136 + (size_t)(tt*bw + s)*8;
+					memcpy(e, &a, 4);
+					memcpy(e + 4, &b, 4);
+					den[v0] = (uint16_t)(den[v0] + w00);
+					if (w01) den[v0 + 1] = (uint16_t)(den[v0 + 1] + w01);
+					if (w10) den[v0 + N] = (uint16_t)(den[v0 + N] + w10);
+					if (w11) den[v0 + N + 1] = (uint16_t)(den[v0 + N + 1] + w11);
+				}
+			memcpy(r + 8, den, sizeof(den));
+		}
+	}
+	return t;
+}
+
 int block_bytes(int format)
 {
 	switch (format) {
@@ -76,15 +190,24 @@ int block_bytes(int format)
 		case CFHIP_FORMAT_ETC2_R8G8B8A8:
 		case CFHIP_FORMAT_EAC_R11G11:
 			return 16;
+		default:
+			if (format >= CFHIP_FORMAT_ASTC_4x4 && format <= CFHIP_FORMAT_ASTC_12x12)
+				return 16;
+			return 0;
 		case CFHIP_FORMAT_BC2:
 		case CFHIP_FORMAT_BC3:
 		case CFHIP_FORMAT_BC5:
 		case CFHIP_FORMAT_BC6H:
 		case CFHIP_FORMAT_BC7:
 			return 16;
-		default:
-			return 0;
 	}
+}
+
+void block_dims(int format, int* bw, int* bh)
+{
+	*bw = 4;
+	*bh = 4;
+	astc_footprint(format, bw, bh);
 }
 
 // createConverter's legality matrix, Converter.cpp:339-412
@@ -110,13 +233,17 @@ bool type_valid(int format, int type)
 		case CFHIP_FORMAT_BC6H:
 			return type == CFHIP_TYPE_UFLOAT || type == CFHIP_TYPE_FLOAT;
 		default:
+			// ASTC: UNorm (LDR) and UFloat (HDR) are legal (Converter.cpp:431-488)
+			if (format >= CFHIP_FORMAT_ASTC_4x4 && format <= CFHIP_FORMAT_ASTC_12x12)
+				return type == CFHIP_TYPE_UNORM || type == CFHIP_TYPE_UFLOAT;
 			return false;
 	}
 }
 
 bool format_implemented(int format, int type)
 {
-	(void)type;
+	if (format >= CFHIP_FORMAT_ASTC_4x4 && format <= CFHIP_FORMAT_ASTC_12x12)
+		return type == CFHIP_TYPE_UNORM;   // LDR subset only; the HDR profile is not built yet
 	switch (format) {
 		case CFHIP_FORMAT_BC1_RGB:
 		case CFHIP_FORMAT_BC1_RGBA:
@@ -172,8 +299,11 @@ void fill_kparams(cf_kparams& kp, const cfhip_params& p, const void* src, void* 
 	kp.pitch = pitch;
 	kp.width = w;
 	kp.height = h;
-	kp.bx = (w + 3u)/4u;
-	kp.by = (h + 3u)/4u;
+	int fbw, fbh;
+	block_dims(p.format, &fbw, &fbh);
+	kp.bx = (w + (uint32_t)fbw - 1u)/(uint32_t)fbw;
+	kp.by = (h + (uint32_t)fbh - 1u)/(uint32_t)fbh;
+	kp.flags = (uint32_t)fbw | ((uint32_t)fbh << 8);
 	kp.quality = (uint32_t)p.quality;
 	kp.type = (uint32_t)p.type;
 	// Colour mask (Texture::ColorMask; S3tcConverter.cpp:217-224 zeroes the weights):
@@ -199,6 +329,15 @@ void fill_kparams(cf_kparams& kp, const cfhip_params& p, const void* src, void* 
 		for (int c = 0; c < 3; ++c)
 			kp.wt[c] = w[c];
 	}
+	if (p.format >= CFHIP_FORMAT_ASTC_4x4 && p.format <= CFHIP_FORMAT_ASTC_12x12) {
+		// astcenc swizzle (AstcConverter.cpp:140-149): masked channel -> 0; alpha reads 1
+		// when the texture has no alpha (Alpha::None), 0 when alpha is masked
+		if (p.mask_rgba[3] && p.alpha == CFHIP_ALPHA_NONE) {
+			kp.keep_mask &= 0x00FFFFFFu;
+			kp.set_mask = 0xFF000000u;
+		} else if (!p.mask_rgba[3])
+			kp.set_mask = 0;
+	}
 	if (p.format == CFHIP_FORMAT_BC1_RGBA) {
 		// punch-through blocks (squish path, S3tcConverter.cpp:294-330): Rec.709-like
 		// integer weights for sRGB images, colour mask zeroes a channel's weight
@@ -220,6 +359,27 @@ int launch(cfhip_ctx* ctx, const cf_kparams& kp, const cfhip_params& p, int pixe
 			const int unit = kp.wt[0] == 1 && kp.wt[1] == 1 && kp.wt[2] == 1 && kp.wt[3] == 1;
 			e = cfhip_launch_bc7(&kp, pixel_type == CFHIP_PIXEL_RGBA32F ? 1 : 0, unit, stream);
 			ctx->last_kernel = "cfhip_bc7_encode_kernel";
+			break;
+		}
+		case CFHIP_FORMAT_ASTC_4x4: case CFHIP_FORMAT_ASTC_5x4: case CFHIP_FORMAT_ASTC_5x5:
+		case CFHIP_FORMAT_ASTC_6x5: case CFHIP_FORMAT_ASTC_6x6: case CFHIP_FORMAT_ASTC_8x5:
+		case CFHIP_FORMAT_ASTC_8x6: case CFHIP_FORMAT_ASTC_8x8: case CFHIP_FORMAT_ASTC_10x5:
+		case CFHIP_FORMAT_ASTC_10x6: case CFHIP_FORMAT_ASTC_10x8: case CFHIP_FORMAT_ASTC_10x10:
+		case CFHIP_FORMAT_ASTC_12x10: case CFHIP_FORMAT_ASTC_12x12: {
+			if (pixel_type != CFHIP_PIXEL_RGBA8 && pixel_type != CFHIP_PIXEL_RGBA32F)
+				return fail(ctx, CFHIP_E_UNSUPPORTED, "ASTC LDR takes RGBA8 or RGBA32F pixels");
+			void*& tab = ctx->astc_tables[p.format];
+			if (!tab) {
+				int fbw, fbh;
+				astc_footprint(p.format, &fbw, &fbh);
+				const std::vector<uint8_t> host = astc_build_tables(fbw, fbh);
+				HIP_TRY(ctx, hipMalloc(&tab, host.size()));
+				HIP_TRY(ctx, hipMemcpy(tab, host.data(), host.size(), hipMemcpyHostToDevice));
+			}
+			cf_kparams k2 = kp;
+			k2.aux = tab;
+			e = cfhip_launch_astc(&k2, pixel_type == CFHIP_PIXEL_RGBA32F ? 1 : 0, stream);
+			ctx->last_kernel = "cfhip_astc_encode_kernel";
 			break;
 		}
 		case CFHIP_FORMAT_ETC1:
@@ -359,6 +519,8 @@ void cfhip_destroy(cfhip_ctx* ctx)
 	}
 	for (hipEvent_t ev : ctx->events)
 		(void)hipEventDestroy(ev);
+	for (auto& kv : ctx->astc_tables)
+		if (kv.second) (void)hipFree(kv.second);
 	if (ctx->d_src) (void)hipFree(ctx->d_src);
 	if (ctx->d_out) (void)hipFree(ctx->d_out);
 	delete ctx;
@@ -369,8 +531,10 @@ int cfhip_query(int format, int type, int* block_w, int* block_h, int* bytes)
 	const int bs = block_bytes(format);
 	if (!bs || !type_valid(format, type))
 		return CFHIP_E_UNSUPPORTED;
-	if (block_w) *block_w = 4;
-	if (block_h) *block_h = 4;
+	int fbw, fbh;
+	block_dims(format, &fbw, &fbh);
+	if (block_w) *block_w = fbw;
+	if (block_h) *block_h = fbh;
 	if (bytes) *bytes = bs;
 	return CFHIP_OK;
 }
@@ -415,7 +579,10 @@ static int encode_impl(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n,
 		if (s.row_pitch_bytes < 0 || (size_t)s.row_pitch_bytes < row_bytes)
 			return fail(ctx, CFHIP_E_INVALID, "surface %zu: row pitch %td < row size %zu", i,
 				s.row_pitch_bytes, row_bytes);
-		const uint32_t bx = (s.width + 3u)/4u, by = (s.height + 3u)/4u;
+		int fbw, fbh;
+		block_dims(params->format, &fbw, &fbh);
+		const uint32_t bx = (s.width + (uint32_t)fbw - 1u)/(uint32_t)fbw;
+		const uint32_t by = (s.height + (uint32_t)fbh - 1u)/(uint32_t)fbh;
 		const size_t out_bytes = (size_t)bx*by*(size_t)bs;
 		if (s.out_capacity < out_bytes)
 			return fail(ctx, CFHIP_E_CAPACITY, "surface %zu: out_capacity %zu < %zu", i,

@@ -47,7 +47,21 @@ enum cfhip_format {
 	CFHIP_FORMAT_ETC2_R8G8B8A1 = 39,
 	CFHIP_FORMAT_ETC2_R8G8B8A8 = 40,
 	CFHIP_FORMAT_EAC_R11 = 41,
-	CFHIP_FORMAT_EAC_R11G11 = 42
+	CFHIP_FORMAT_EAC_R11G11 = 42,
+	CFHIP_FORMAT_ASTC_4x4 = 43,
+	CFHIP_FORMAT_ASTC_5x4 = 44,
+	CFHIP_FORMAT_ASTC_5x5 = 45,
+	CFHIP_FORMAT_ASTC_6x5 = 46,
+	CFHIP_FORMAT_ASTC_6x6 = 47,
+	CFHIP_FORMAT_ASTC_8x5 = 48,
+	CFHIP_FORMAT_ASTC_8x6 = 49,
+	CFHIP_FORMAT_ASTC_8x8 = 50,
+	CFHIP_FORMAT_ASTC_10x5 = 51,
+	CFHIP_FORMAT_ASTC_10x6 = 52,
+	CFHIP_FORMAT_ASTC_10x8 = 53,
+	CFHIP_FORMAT_ASTC_10x10 = 54,
+	CFHIP_FORMAT_ASTC_12x10 = 55,
+	CFHIP_FORMAT_ASTC_12x12 = 56
 };
 
 /* cuttlefish::Texture::Type (Texture.h:135-143) */

@@ -245,9 +245,19 @@ void cfo_decode_bc7(const uint8_t* blk, uint8_t* rgba64)
 	}
 }
 
+int cfo_astc_footprint(int format, int* bw, int* bh);
+
 int cfo_block_info(int format, int* bw, int* bh, int* bytes)
 {
 	int sz;
+	if (format >= 43 && format <= 56) {   /* ASTC_4x4 .. ASTC_12x12 */
+		int w, h;
+		cfo_astc_footprint(format, &w, &h);
+		if (bw) *bw = w;
+		if (bh) *bh = h;
+		if (bytes) *bytes = 16;
+		return 0;
+	}
 	switch (format) {
 		case CFO_FMT_BC1_RGB: case CFO_FMT_BC1_RGBA: case CFO_FMT_BC4: sz = 8; break;
 		case CFO_FMT_BC2: case CFO_FMT_BC3: case CFO_FMT_BC5:

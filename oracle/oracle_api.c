@@ -23,6 +23,9 @@ void cfo_encode_bc6h_block(const uint16_t rgba_half[64], uint8_t out[16], const 
 int cfo_encode_etc_block(const float rgbaf[64], const uint8_t rgba[64], unsigned valid,
 	uint8_t* out, const cfo_params* p);
 void cfo_decode_etc_rgb(const uint8_t* blk, int a1, uint8_t* rgba64);
+int cfo_astc_footprint(int format, int* bw, int* bh);
+void cfo_encode_astc_block(const int px[][4], int bw, int bh, int quality, uint8_t out[16]);
+int cfo_decode_astc_block(const uint8_t* blk, int bw, int bh, uint8_t* rgba);
 void cfo_decode_eac(const uint8_t* blk, int kind, int* out16);
 int cfo_decode_bc6h(const uint8_t* blk, int flags, uint16_t* rgb48);
 
@@ -30,6 +33,7 @@ typedef struct {
 	const uint8_t* pixels;
 	int pixel_type;
 	uint32_t width, height, bx, by;
+	uint32_t bw, bh;   /* block footprint */
 	ptrdiff_t pitch;
 	uint8_t* out;
 	int bytes;
@@ -129,10 +133,40 @@ static void* worker(void* arg)
 		if (job >= total)
 			return NULL;
 		uint32_t x = job % j->bx, y = job / j->bx;
+		uint8_t* dst = j->out + (size_t)job*(size_t)j->bytes;
+		if (j->p->format >= 43 && j->p->format <= 56) {
+			/* AstcConverter::process (AstcConverter.cpp:208-225): edge-replicated bw x bh tile;
+			 * swizzle from the colour mask / alpha type (:140-149); LDR path quantises to
+			 * UNORM8 like toColorBlock */
+			int apx[144][4];
+			for (uint32_t r = 0; r < j->bh; ++r) {
+				uint32_t sy = y*j->bh + r;
+				if (sy > j->height - 1) sy = j->height - 1;
+				const uint8_t* row = j->pixels + (ptrdiff_t)sy*j->pitch;
+				for (uint32_t c = 0; c < j->bw; ++c) {
+					uint32_t sx = x*j->bw + c;
+					if (sx > j->width - 1) sx = j->width - 1;
+					int* o = apx[r*j->bw + c];
+					for (int k = 0; k < 4; ++k) {
+						if (j->pixel_type == CFO_PIX_RGBA8)
+							o[k] = row[sx*4 + k];
+						else if (j->pixel_type == CFO_PIX_RGBA32F)
+							o[k] = unorm8(((const float*)(row + (size_t)sx*16))[k]);
+						else
+							o[k] = unorm8(half_to_float(((const uint16_t*)(row + (size_t)sx*8))[k]));
+					}
+					for (int k = 0; k < 3; ++k)
+						if (!j->p->mask[k]) o[k] = 0;
+					if (!j->p->mask[3]) o[3] = 0;
+					else if (j->p->alpha == 0) o[3] = 255;
+				}
+			}
+			cfo_encode_astc_block((const int (*)[4])apx, (int)j->bw, (int)j->bh, j->p->quality, dst);
+			continue;
+		}
 		float f[64];
 		uint8_t u[64];
 		gather(j, x, y, f, u);
-		uint8_t* dst = j->out + (size_t)job*(size_t)j->bytes;
 		if (j->p->format == CFO_FMT_BC6H) {
 			/* packHalfFloatBlockHardware (S3tcConverter.cpp:113-129): fp32 -> fp16 RNE;
 			 * RGBA16F sources are passed through bit-exactly */
@@ -183,8 +217,10 @@ int cfo_encode(const void* pixels, int pixel_type, uint32_t width, uint32_t heig
 	j.pixel_type = pixel_type;
 	j.width = width;
 	j.height = height;
-	j.bx = (width + 3)/4;
-	j.by = (height + 3)/4;
+	j.bw = (uint32_t)bw;
+	j.bh = (uint32_t)bh;
+	j.bx = (width + j.bw - 1)/j.bw;
+	j.by = (height + j.bh - 1)/j.bh;
 	j.pitch = row_pitch;
 	j.out = (uint8_t*)out;
 	j.bytes = bytes;
@@ -273,4 +309,27 @@ int cfo_decode_eac_image(int format, int type, const void* blocks, uint32_t widt
 						out[(((size_t)y*4 + j)*width + x*4 + i)*(size_t)nch + (size_t)ch] = v[j*4 + i];
 			}
 	return 0;
+}
+
+/* Decode an ASTC payload (emitted subset) to RGBA8; returns the number of blocks outside
+ * the subset (0 for our own output). */
+int cfo_decode_astc_image(int format, const void* blocks, uint32_t width, uint32_t height,
+	uint8_t* rgba_out)
+{
+	int bw, bh, bad = 0;
+	if (cfo_astc_footprint(format, &bw, &bh) != 0)
+		return -1;
+	uint32_t bx = (width + (uint32_t)bw - 1)/(uint32_t)bw, by = (height + (uint32_t)bh - 1)/(uint32_t)bh;
+	const uint8_t* src = (const uint8_t*)blocks;
+	for (uint32_t y = 0; y < by; ++y)
+		for (uint32_t x = 0; x < bx; ++x) {
+			uint8_t px[144*4];
+			if (cfo_decode_astc_block(src + ((size_t)y*bx + x)*16, bw, bh, px) != 0)
+				++bad;
+			for (uint32_t j = 0; j < (uint32_t)bh && y*(uint32_t)bh + j < height; ++j)
+				for (uint32_t i = 0; i < (uint32_t)bw && x*(uint32_t)bw + i < width; ++i)
+					memcpy(rgba_out + (((size_t)y*(uint32_t)bh + j)*width + x*(uint32_t)bw + i)*4,
+						px + (j*(uint32_t)bw + i)*4, 4);
+		}
+	return bad;
 }

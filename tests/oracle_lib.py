@@ -84,7 +84,10 @@ def encode(img: np.ndarray, fmt, typ=0, quality=2, threads=1, **kw) -> np.ndarra
     assert img.ndim == 3 and img.shape[2] == 4
     img = np.ascontiguousarray(img)
     h, w = img.shape[:2]
-    n = ((w + 3) // 4) * ((h + 3) // 4) * block_bytes(fmt)
+    bw, bh, bs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    if lib().cfo_block_info(int(fmt), bw, bh, bs) != 0:
+        raise ValueError("unsupported format %r" % (fmt,))
+    n = ((w + bw.value - 1) // bw.value) * ((h + bh.value - 1) // bh.value) * bs.value
     out = np.zeros(n, np.uint8)
     p = make_params(fmt, typ, quality, **kw)
     rc = lib().cfo_encode(img.ctypes.data, _pixel_type(img), w, h, img.strides[0],
@@ -117,6 +120,19 @@ def decode_etc(blocks: np.ndarray, fmt, width: int, height: int) -> np.ndarray:
     if L.cfo_decode_etc_image(int(fmt), blocks.ctypes.data, width, height, out.ctypes.data) != 0:
         raise RuntimeError("cfo_decode_etc_image failed")
     return out
+
+
+def decode_astc(blocks: np.ndarray, fmt, width: int, height: int):
+    """ASTC (fmt 43..56), emitted subset only -> ((h, w, 4) uint8, blocks outside the subset)."""
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
+    out = np.zeros((height, width, 4), np.uint8)
+    L = lib()
+    L.cfo_decode_astc_image.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32,
+                                        ctypes.c_uint32, ctypes.c_void_p]
+    bad = L.cfo_decode_astc_image(int(fmt), blocks.ctypes.data, width, height, out.ctypes.data)
+    if bad < 0:
+        raise RuntimeError("cfo_decode_astc_image failed")
+    return out, bad
 
 
 def decode_eac(blocks: np.ndarray, fmt, width: int, height: int, typ=0) -> np.ndarray:
