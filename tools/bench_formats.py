@@ -30,7 +30,12 @@ def main():
     cases = [(Format.BC1_RGB, Type.UNorm), (Format.BC1_RGBA, Type.UNorm), (Format.BC2, Type.UNorm),
              (Format.BC3, Type.UNorm), (Format.BC4, Type.UNorm), (Format.BC4, Type.SNorm),
              (Format.BC5, Type.UNorm), (Format.BC5, Type.SNorm), (Format.BC6H, Type.UFloat),
-             (Format.BC6H, Type.Float), (Format.BC7, Type.UNorm)]
+             (Format.BC6H, Type.Float), (Format.BC7, Type.UNorm),
+             (Format.ETC1, Type.UNorm), (Format.ETC2_R8G8B8, Type.UNorm),
+             (Format.ETC2_R8G8B8A1, Type.UNorm), (Format.ETC2_R8G8B8A8, Type.UNorm),
+             (Format.EAC_R11, Type.UNorm), (Format.EAC_R11G11, Type.SNorm),
+             (Format.ASTC_4x4, Type.UNorm), (Format.ASTC_6x6, Type.UNorm),
+             (Format.ASTC_8x8, Type.UNorm), (Format.ASTC_12x12, Type.UNorm)]
     for fmt, typ in cases:
         is_hdr = fmt == Format.BC6H
         src = hdr if is_hdr else ldr
