@@ -95,7 +95,11 @@ void HipConverter::process(unsigned int, unsigned int, ThreadData*)
 
 	// Image::scanline(y) is top-down (Image.cpp:340-343) but rows are separate pointers.
 	std::vector<std::uint8_t> staging;
-	if (m_type == Texture::Type::UNorm)
+	// 8-bit staging only where the block encoder consumes 8-bit texels; EAC R11/RG11 keep the
+	// float scanlines (11-bit targets), as do SNorm and float formats.
+	bool stage8 = m_type == Texture::Type::UNorm && m_format != Texture::Format::EAC_R11 &&
+		m_format != Texture::Format::EAC_R11G11;
+	if (stage8)
 	{
 		staging.resize(static_cast<std::size_t>(width)*height*4);
 		for (unsigned int y = 0; y < height; ++y)
