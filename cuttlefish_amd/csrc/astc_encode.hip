@@ -102,7 +102,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	__shared__ uint8_t lane_q[4][64*64];
 	__shared__ uint4 outb[CF_BLOCKS_PER_WG];
 	const uint32_t bw = kp.flags & 255u, bh = (kp.flags >> 8) & 255u, n = bw*bh;
-	const uint32_t bx0 = blockIdx.x*CF_BLOCKS_PER_WG, byy = blockIdx.y;
+	uint32_t gx_, gy_;
+	cf_resolve(kp, gx_, gy_);
+	const uint32_t bx0 = gx_*CF_BLOCKS_PER_WG, byy = gy_;
 	{
 		// stage 16 blocks: (16*bw) x bh texels, coalesced along x, stored block-major
 		const uint32_t sw = CF_BLOCKS_PER_WG*bw, total = sw*bh;
@@ -385,6 +387,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, hipStream_t stream)
 {
 	dim3 grid((kp->bx + CF_BLOCKS_PER_WG - 1)/CF_BLOCKS_PER_WG, kp->by, 1);
+	if (kp->batch)
+		grid = dim3(kp->total_wg, 1, 1);
 	dim3 block(CF_WG_THREADS, 1, 1);
 	if (pixel_type == 0)
 		hipLaunchKernelGGL((cfhip_astc_encode_kernel<0>), grid, block, 0, stream, *kp);

@@ -459,8 +459,10 @@ cfhip_bc15_encode_kernel(cf_kparams kp)
 	constexpr uint32_t BYTES = (FMT == F_BC1 || FMT == F_BC1A || FMT == F_BC4) ? 8u : 16u;
 	__shared__ __attribute__((aligned(16))) uint32_t tile[CF_BLOCKS_PER_WG*16];
 	__shared__ uint32_t outb[CF_BLOCKS_PER_WG*4];
-	const uint32_t bx0 = blockIdx.x*CF_BLOCKS_PER_WG;
-	const uint32_t byy = blockIdx.y;
+	uint32_t gx_, gy_;
+	cf_resolve(kp, gx_, gy_);
+	const uint32_t bx0 = gx_*CF_BLOCKS_PER_WG;
+	const uint32_t byy = gy_;
 	load_tile<PIX, SNORM>(kp, bx0, byy, tile);
 	__syncthreads();
 
@@ -564,6 +566,8 @@ extern "C" hipError_t cfhip_launch_bc15(const cf_kparams* kp, int format, int pi
 	int snorm, hipStream_t stream)
 {
 	dim3 grid((kp->bx + CF_BLOCKS_PER_WG - 1)/CF_BLOCKS_PER_WG, kp->by, 1);
+	if (kp->batch)
+		grid = dim3(kp->total_wg, 1, 1);
 	dim3 block(CF_WG_THREADS, 1, 1);
 	if (pixel_type == 0)
 		return launch_fmt<0>(kp, format, snorm, grid, block, stream);

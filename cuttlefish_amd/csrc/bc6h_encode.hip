@@ -436,8 +436,10 @@ cfhip_bc6h_encode_kernel(cf_kparams kp)
 {
 	__shared__ uint32_t tile[CF_BLOCKS_PER_WG*16*3];
 	__shared__ uint4 outb[CF_BLOCKS_PER_WG];
-	const uint32_t bx0 = blockIdx.x*CF_BLOCKS_PER_WG;
-	const uint32_t byy = blockIdx.y;
+	uint32_t gx_, gy_;
+	cf_resolve(kp, gx_, gy_);
+	const uint32_t bx0 = gx_*CF_BLOCKS_PER_WG;
+	const uint32_t byy = gy_;
 	{
 		const uint32_t t = threadIdx.x;
 		const uint32_t row = t >> 6, col = t & 63u;
@@ -510,6 +512,8 @@ extern "C" hipError_t cfhip_launch_bc6h(const cf_kparams* kp, int pixel_type, in
 	hipStream_t stream)
 {
 	dim3 grid((kp->bx + CF_BLOCKS_PER_WG - 1)/CF_BLOCKS_PER_WG, kp->by, 1);
+	if (kp->batch)
+		grid = dim3(kp->total_wg, 1, 1);
 	dim3 block(CF_WG_THREADS, 1, 1);
 #define CF_L(P, S) hipLaunchKernelGGL((cfhip_bc6h_encode_kernel<P, S>), grid, block, 0, stream, *kp)
 	if (pixel_type == 0) { if (is_signed) CF_L(0, true); else CF_L(0, false); }

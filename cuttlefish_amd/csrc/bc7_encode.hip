@@ -1178,8 +1178,10 @@ cfhip_bc7_encode_kernel(cf_kparams kp)
 	__shared__ __attribute__((aligned(16))) uint32_t tile[CF_BLOCKS_PER_WG*16];
 	__shared__ __attribute__((aligned(16))) uint32_t plan[CF_BLOCKS_PER_WG*16];
 	__shared__ uint4 outb[CF_BLOCKS_PER_WG];
-	const uint32_t bx0 = blockIdx.x*CF_BLOCKS_PER_WG;
-	const uint32_t byy = blockIdx.y;
+	uint32_t gx_, gy_;
+	cf_resolve(kp, gx_, gy_);
+	const uint32_t bx0 = gx_*CF_BLOCKS_PER_WG;
+	const uint32_t byy = gy_;
 	cf_load_tile_rgba8<PIX>(kp, bx0, byy, tile);
 	__syncthreads();
 	{
@@ -1219,6 +1221,8 @@ extern "C" hipError_t cfhip_launch_bc7(const cf_kparams* kp, int pixel_type, int
 	hipStream_t stream)
 {
 	dim3 grid((kp->bx + CF_BLOCKS_PER_WG - 1)/CF_BLOCKS_PER_WG, kp->by, 1);
+	if (kp->batch)
+		grid = dim3(kp->total_wg, 1, 1);
 	dim3 block(CF_WG_THREADS, 1, 1);
 	if (pixel_type == 0) {
 		if (unit_weights)

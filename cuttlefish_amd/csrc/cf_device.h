@@ -27,7 +27,44 @@ struct cf_kparams {
 	uint32_t wt[4];        // channel error weights
 	uint32_t flags;        // format specific (ASTC: footprint bw | bh << 8)
 	const void* aux;       // format specific device table (ASTC: config / infill records)
+	const struct cf_batch_entry* batch;   // non-null: one launch covers nbatch surfaces
+	uint32_t nbatch;
+	uint32_t total_wg;     // batched launches: grid size
 };
+
+// One surface of a batched launch (mip tails / texture arrays: thousands of tiny surfaces
+// would otherwise each pay a launch and leave most CUs idle).  Workgroups are numbered
+// consecutively over the surfaces; wg_begin is the first workgroup of this surface.
+struct cf_batch_entry {
+	const uint8_t* src;
+	uint8_t* out;
+	long long pitch;
+	uint32_t width, height, bx, by;
+	uint32_t wg_begin, wgx;   // wgx = workgroups per block row = ceil(bx/16)
+};
+
+// Resolve the surface and the workgroup's position in it.  Plain launches: grid (wgx, by).
+// Batched launches: 1-D grid; a uniform binary search over wg_begin picks the surface.
+__device__ __forceinline__ void cf_resolve(cf_kparams& kp, uint32_t& gx, uint32_t& gy)
+{
+	if (!kp.batch) {
+		gx = blockIdx.x;
+		gy = blockIdx.y;
+		return;
+	}
+	const uint32_t wg = blockIdx.x;
+	uint32_t lo = 0, hi = kp.nbatch - 1u;
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi + 1u) >> 1;
+		if (kp.batch[mid].wg_begin <= wg) lo = mid; else hi = mid - 1u;
+	}
+	const cf_batch_entry e = kp.batch[lo];
+	const uint32_t local = wg - e.wg_begin;
+	gy = local/e.wgx;
+	gx = local - gy*e.wgx;
+	kp.src = e.src; kp.out = e.out; kp.pitch = e.pitch;
+	kp.width = e.width; kp.height = e.height; kp.bx = e.bx; kp.by = e.by;
+}
 
 __device__ __forceinline__ uint32_t cf_rfl(uint32_t v)
 {

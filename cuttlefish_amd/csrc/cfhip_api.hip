@@ -35,6 +35,8 @@ struct cfhip_ctx {
 	size_t src_cap = 0;
 	void* d_out = nullptr;
 	size_t out_cap = 0;
+	void* d_batch = nullptr;          // cf_batch_entry[] of the current batched launch
+	size_t batch_cap = 0;
 	std::map<int, void*> astc_tables; // per-format device tables (built on first use)
 	std::vector<hipEvent_t> events;   // start/stop pairs of the last call
 	size_t events_used = 0;
@@ -462,6 +464,36 @@ int reserve(cfhip_ctx* ctx, void** buf, size_t* cap, size_t need)
 	return CFHIP_OK;
 }
 
+// One launch for many surfaces (same format / pixel type): workgroups are numbered across
+// the surfaces, the kernel resolves its surface with a uniform binary search (cf_resolve).
+int batched_launch(cfhip_ctx* ctx, const std::vector<cf_kparams>& kps, const cfhip_params& p,
+	int pixel_type, hipStream_t stream)
+{
+	if (kps.size() == 1)
+		return timed_launch(ctx, kps[0], p, pixel_type, stream);
+	std::vector<cf_batch_entry> entries(kps.size());
+	uint32_t wg = 0;
+	for (size_t i = 0; i < kps.size(); ++i) {
+		cf_batch_entry& e = entries[i];
+		e.src = kps[i].src; e.out = kps[i].out; e.pitch = kps[i].pitch;
+		e.width = kps[i].width; e.height = kps[i].height; e.bx = kps[i].bx; e.by = kps[i].by;
+		e.wgx = (kps[i].bx + CF_BLOCKS_PER_WG - 1)/CF_BLOCKS_PER_WG;
+		e.wg_begin = wg;
+		wg += e.wgx*kps[i].by;
+	}
+	const size_t bytes = entries.size()*sizeof(cf_batch_entry);
+	int rc = reserve(ctx, &ctx->d_batch, &ctx->batch_cap, bytes);
+	if (rc != CFHIP_OK)
+		return rc;
+	// pageable source: the runtime stages the copy before returning, so `entries` may die
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_batch, entries.data(), bytes, hipMemcpyHostToDevice, stream));
+	cf_kparams kp = kps[0];
+	kp.batch = static_cast<const cf_batch_entry*>(ctx->d_batch);
+	kp.nbatch = (uint32_t)entries.size();
+	kp.total_wg = wg;
+	return timed_launch(ctx, kp, p, pixel_type, stream);
+}
+
 } // namespace
 
 extern "C" {
@@ -521,6 +553,7 @@ void cfhip_destroy(cfhip_ctx* ctx)
 		(void)hipEventDestroy(ev);
 	for (auto& kv : ctx->astc_tables)
 		if (kv.second) (void)hipFree(kv.second);
+	if (ctx->d_batch) (void)hipFree(ctx->d_batch);
 	if (ctx->d_src) (void)hipFree(ctx->d_src);
 	if (ctx->d_out) (void)hipFree(ctx->d_out);
 	delete ctx;
@@ -570,6 +603,11 @@ static int encode_impl(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n,
 	ctx->last_ms = -1.0f;
 	const int bs = block_bytes(params->format);
 
+	// validate everything first, compute sizes
+	struct Item { size_t src_bytes, out_bytes, row_bytes; };
+	std::vector<Item> items(n);
+	int fbw, fbh;
+	block_dims(params->format, &fbw, &fbh);
 	for (size_t i = 0; i < n; ++i) {
 		const cfhip_surface& s = surfaces[i];
 		const size_t pb = pixel_bytes(s.pixel_type);
@@ -579,43 +617,90 @@ static int encode_impl(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n,
 		if (s.row_pitch_bytes < 0 || (size_t)s.row_pitch_bytes < row_bytes)
 			return fail(ctx, CFHIP_E_INVALID, "surface %zu: row pitch %td < row size %zu", i,
 				s.row_pitch_bytes, row_bytes);
-		int fbw, fbh;
-		block_dims(params->format, &fbw, &fbh);
 		const uint32_t bx = (s.width + (uint32_t)fbw - 1u)/(uint32_t)fbw;
 		const uint32_t by = (s.height + (uint32_t)fbh - 1u)/(uint32_t)fbh;
 		const size_t out_bytes = (size_t)bx*by*(size_t)bs;
 		if (s.out_capacity < out_bytes)
 			return fail(ctx, CFHIP_E_CAPACITY, "surface %zu: out_capacity %zu < %zu", i,
 				s.out_capacity, out_bytes);
+		items[i] = {row_bytes*(size_t)s.height, out_bytes, row_bytes};
+	}
 
-		cf_kparams kp;
-		if (device_mem) {
-			fill_kparams(kp, *params, s.pixels, s.out, (long long)s.row_pitch_bytes, s.width,
-				s.height);
-			rc = timed_launch(ctx, kp, *params, s.pixel_type, stream);
+	if (device_mem) {
+		size_t i0 = 0;
+		while (i0 < n) {
+			std::vector<cf_kparams> kps;
+			size_t i1 = i0;
+			while (i1 < n && surfaces[i1].pixel_type == surfaces[i0].pixel_type && kps.size() < 65536) {
+				const cfhip_surface& s = surfaces[i1];
+				cf_kparams kp;
+				fill_kparams(kp, *params, s.pixels, s.out, (long long)s.row_pitch_bytes, s.width,
+					s.height);
+				kps.push_back(kp);
+				++i1;
+			}
+			rc = batched_launch(ctx, kps, *params, surfaces[i0].pixel_type, stream);
 			if (rc != CFHIP_OK)
 				return rc;
-			continue;
+			i0 = i1;
 		}
-		// host surface: tight upload, encode, download (stream ordered, buffers reused)
-		const size_t src_bytes = row_bytes*(size_t)s.height;
-		rc = reserve(ctx, &ctx->d_src, &ctx->src_cap, src_bytes);
-		if (rc != CFHIP_OK) return rc;
-		rc = reserve(ctx, &ctx->d_out, &ctx->out_cap, out_bytes);
-		if (rc != CFHIP_OK) return rc;
-		if ((size_t)s.row_pitch_bytes == row_bytes)
-			HIP_TRY(ctx, hipMemcpyAsync(ctx->d_src, s.pixels, src_bytes, hipMemcpyHostToDevice,
-				stream));
-		else
-			HIP_TRY(ctx, hipMemcpy2DAsync(ctx->d_src, row_bytes, s.pixels,
-				(size_t)s.row_pitch_bytes, row_bytes, s.height, hipMemcpyHostToDevice, stream));
-		fill_kparams(kp, *params, ctx->d_src, ctx->d_out, (long long)row_bytes, s.width, s.height);
-		rc = timed_launch(ctx, kp, *params, s.pixel_type, stream);
-		if (rc != CFHIP_OK)
-			return rc;
-		HIP_TRY(ctx, hipMemcpyAsync(s.out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost, stream));
-		// the staging buffers are reused by the next surface
-		HIP_TRY(ctx, hipStreamSynchronize(stream));
+	} else {
+		// Host surfaces are processed in groups: every surface of a group is uploaded into
+		// one staging buffer, all kernels are enqueued, all payloads downloaded, and the
+		// stream is synchronised ONCE per group (Converter::convert instead joins its worker
+		// threads once per surface, Converter.cpp:580-583 -- ruinous for mip tails).
+		const size_t kGroupBytes = (size_t)512 << 20;
+		size_t g0 = 0;
+		while (g0 < n) {
+			size_t g1 = g0, src_total = 0, out_total = 0;
+			while (g1 < n && (g1 == g0 || src_total + items[g1].src_bytes <= kGroupBytes)) {
+				src_total += (items[g1].src_bytes + 255) & ~(size_t)255;
+				out_total += (items[g1].out_bytes + 255) & ~(size_t)255;
+				++g1;
+			}
+			rc = reserve(ctx, &ctx->d_src, &ctx->src_cap, src_total);
+			if (rc != CFHIP_OK) return rc;
+			rc = reserve(ctx, &ctx->d_out, &ctx->out_cap, out_total);
+			if (rc != CFHIP_OK) return rc;
+			size_t so = 0, oo = 0;
+			std::vector<size_t> out_off(g1 - g0);
+			std::vector<cf_kparams> kps;
+			int run_type = surfaces[g0].pixel_type;
+			for (size_t i = g0; i < g1; ++i) {
+				const cfhip_surface& s = surfaces[i];
+				uint8_t* dsrc = static_cast<uint8_t*>(ctx->d_src) + so;
+				uint8_t* dout = static_cast<uint8_t*>(ctx->d_out) + oo;
+				if ((size_t)s.row_pitch_bytes == items[i].row_bytes)
+					HIP_TRY(ctx, hipMemcpyAsync(dsrc, s.pixels, items[i].src_bytes,
+						hipMemcpyHostToDevice, stream));
+				else
+					HIP_TRY(ctx, hipMemcpy2DAsync(dsrc, items[i].row_bytes, s.pixels,
+						(size_t)s.row_pitch_bytes, items[i].row_bytes, s.height, hipMemcpyHostToDevice,
+						stream));
+				if (s.pixel_type != run_type && !kps.empty()) {
+					rc = batched_launch(ctx, kps, *params, run_type, stream);
+					if (rc != CFHIP_OK)
+						return rc;
+					kps.clear();
+				}
+				run_type = s.pixel_type;
+				cf_kparams kp;
+				fill_kparams(kp, *params, dsrc, dout, (long long)items[i].row_bytes, s.width, s.height);
+				kps.push_back(kp);
+				out_off[i - g0] = oo;
+				so += (items[i].src_bytes + 255) & ~(size_t)255;
+				oo += (items[i].out_bytes + 255) & ~(size_t)255;
+			}
+			rc = batched_launch(ctx, kps, *params, run_type, stream);
+			if (rc != CFHIP_OK)
+				return rc;
+			for (size_t i = g0; i < g1; ++i)
+				HIP_TRY(ctx, hipMemcpyAsync(surfaces[i].out,
+					static_cast<uint8_t*>(ctx->d_out) + out_off[i - g0], items[i].out_bytes,
+					hipMemcpyDeviceToHost, stream));
+			HIP_TRY(ctx, hipStreamSynchronize(stream));   // staging buffers are reused
+			g0 = g1;
+		}
 	}
 	if (!device_mem || !user_stream)
 		HIP_TRY(ctx, hipStreamSynchronize(stream));

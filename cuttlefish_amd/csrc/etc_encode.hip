@@ -461,8 +461,10 @@ cfhip_etc_encode_kernel(cf_kparams kp)
 	constexpr uint32_t BYTES = (FMT == E_A8 || FMT == E_RG11) ? 16u : 8u;
 	__shared__ uint32_t tile[CF_BLOCKS_PER_WG*16];
 	__shared__ uint32_t outb[CF_BLOCKS_PER_WG*4];
-	const uint32_t bx0 = blockIdx.x*CF_BLOCKS_PER_WG;
-	const uint32_t byy = blockIdx.y;
+	uint32_t gx_, gy_;
+	cf_resolve(kp, gx_, gy_);
+	const uint32_t bx0 = gx_*CF_BLOCKS_PER_WG;
+	const uint32_t byy = gy_;
 	{
 		const uint32_t t = threadIdx.x;
 		const uint32_t row = t >> 6, col = t & 63u;
@@ -572,6 +574,8 @@ extern "C" hipError_t cfhip_launch_etc(const cf_kparams* kp, int format, int pix
 	hipStream_t stream)
 {
 	dim3 grid((kp->bx + CF_BLOCKS_PER_WG - 1)/CF_BLOCKS_PER_WG, kp->by, 1);
+	if (kp->batch)
+		grid = dim3(kp->total_wg, 1, 1);
 	dim3 block(CF_WG_THREADS, 1, 1);
 	if (pixel_type == 0)
 		return etc_launch_fmt<0>(kp, format, snorm, grid, block, stream);
