@@ -516,19 +516,23 @@ __device__ __forceinline__ void fit_scalar(const Tex& tx, uint32_t ab, uint32_t 
 
 struct RowFit {
 	uint32_t e0, e1, q0, q1, pb, err;
-	uint32_t wrow;          // weights of this lane's row
+	uint32_t wrow[2];       // weights of this lane's row(s)
 	float nx0[4], nx1[4];
 	bool ok;
 };
 
-__device__ __forceinline__ uint32_t quad_sum(uint32_t v)
+// exact sum over the lanes that share one fit: 4 lanes with one texel row each (R = 1)
+// or 2 lanes with two rows each (R = 2)
+template <int R>
+__device__ __forceinline__ uint32_t group_sum(uint32_t v)
 {
 	v += (uint32_t)__shfl_xor((int)v, 1, 64);
-	v += (uint32_t)__shfl_xor((int)v, 2, 64);
+	if (R == 1)
+		v += (uint32_t)__shfl_xor((int)v, 2, 64);
 	return v;
 }
 
-template <bool UNITW, bool ROT>
+template <bool UNITW, bool ROT, int R>
 __device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t mask, uint32_t row, bool m6,
 	uint32_t khalf, uint32_t ib, const uint32_t (&wt)[4], bool want_lsq, RowFit& f)
 {
@@ -552,64 +556,88 @@ __device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t mask, ui
 				: (int)w;
 		}
 	}
-	const uint4 rw = *reinterpret_cast<const uint4*>(tx.tp + 4u*row);
-	const uint32_t raw[4] = {rw.x, rw.y, rw.z, rw.w};
-	const uint32_t mrow = (mask >> (4u*row)) & 15u;
-	uint32_t err = 0, wrow = 0;
+	uint32_t err = 0;
+	uint32_t S = 0, A = 0, B = 0, C = 0, U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
+	uint32_t wprev = 0, wlast = 0;
+#pragma unroll 1
+	for (uint32_t rr = 0; rr < (uint32_t)R; ++rr) {
+		uint32_t r = (uint32_t)R*row + rr;
+		// opaque to the optimiser: the texel loads below are invariant across refit rounds
+		// and would otherwise be hoisted (with all their unpacked forms) out of the round loop
+		asm volatile("" : "+v"(r));
+		const uint4 rw = *reinterpret_cast<const uint4*>(tx.tp + 4u*r);
+		const uint32_t raw[4] = {rw.x, rw.y, rw.z, rw.w};
+		const uint32_t mrow = (mask >> (4u*r)) & 15u;
+		uint32_t wrow = 0;
 #pragma unroll
-	for (int j = 0; j < 4; ++j) {
-		const uint32_t p = texel<ROT>(tx, raw[j]);
-		uint32_t key;
-		if (UNITW) {
-			int bestk = 0x7FFFFFFF;
+		for (int j = 0; j < 4; ++j) {
+			const uint32_t p = texel<ROT>(tx, raw[j]);
+			uint32_t key;
+			if (UNITW) {
+				int bestk = 0x7FFFFFFF;
 #pragma unroll
-			for (int k = 0; k < 8; ++k) {
-				if ((uint32_t)k < nk) {
-					const int dt = (int)__builtin_amdgcn_udot4(p, pal[k], 0u, false);
-					const int v = base[k] - (dt << 8);
-					bestk = v < bestk ? v : bestk;
+				for (int k = 0; k < 8; ++k) {
+					if ((uint32_t)k < nk) {
+						const int dt = (int)__builtin_amdgcn_udot4(p, pal[k], 0u, false);
+						const int v = base[k] - (dt << 8);
+						bestk = v < bestk ? v : bestk;
+					}
+				}
+				key = (uint32_t)bestk + (__builtin_amdgcn_udot4(p, p, 0u, false) << 7);
+			} else {
+				key = 0xFFFFFFFFu;
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					if ((uint32_t)k < nk) {
+						const int d0 = (int)ub(p, 0) - (int)ub(pal[k], 0);
+						const int d1 = (int)ub(p, 1) - (int)ub(pal[k], 1);
+						const int d2 = (int)ub(p, 2) - (int)ub(pal[k], 2);
+						const int d3 = (int)ub(p, 3) - (int)ub(pal[k], 3);
+						const uint32_t dist = wt[0]*(uint32_t)(d0*d0) + wt[1]*(uint32_t)(d1*d1) +
+							wt[2]*(uint32_t)(d2*d2) + wt[3]*(uint32_t)(d3*d3);
+						const uint32_t v = (dist << 7) | (uint32_t)base[k];
+						key = v < key ? v : key;
+					}
 				}
 			}
-			key = (uint32_t)bestk + (__builtin_amdgcn_udot4(p, p, 0u, false) << 7);
-		} else {
-			key = 0xFFFFFFFFu;
+			if (R == 1) {
+				// mode 6: the other palette half lives in lane ^ 4
+				const uint32_t other = (uint32_t)__shfl_xor((int)key, 4, 64);
+				key = (m6 && other < key) ? other : key;
+			}
+			const bool m = (mrow >> j) & 1u;
+			err += m ? (key >> 7) : 0u;
+			wrow |= (m ? (key & 127u) : 0u) << (8*j);
+		}
+		wprev = wlast;
+		wlast = wrow;
+		if (want_lsq) {
+			const uint32_t iwrow = (0x40404040u - wrow) & bytemask4(mrow);
+			uint32_t P[4];
+			planes<ROT>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
+			S = __builtin_amdgcn_udot4(wrow, 0x01010101u, S, false);
+			A = __builtin_amdgcn_udot4(iwrow, iwrow, A, false);
+			B = __builtin_amdgcn_udot4(iwrow, wrow, B, false);
+			C = __builtin_amdgcn_udot4(wrow, wrow, C, false);
 #pragma unroll
-			for (int k = 0; k < 8; ++k) {
-				if ((uint32_t)k < nk) {
-					const int d0 = (int)ub(p, 0) - (int)ub(pal[k], 0);
-					const int d1 = (int)ub(p, 1) - (int)ub(pal[k], 1);
-					const int d2 = (int)ub(p, 2) - (int)ub(pal[k], 2);
-					const int d3 = (int)ub(p, 3) - (int)ub(pal[k], 3);
-					const uint32_t dist = wt[0]*(uint32_t)(d0*d0) + wt[1]*(uint32_t)(d1*d1) +
-						wt[2]*(uint32_t)(d2*d2) + wt[3]*(uint32_t)(d3*d3);
-					const uint32_t v = (dist << 7) | (uint32_t)base[k];
-					key = v < key ? v : key;
-				}
+			for (int c = 0; c < 4; ++c) {
+				U[c] = __builtin_amdgcn_udot4(iwrow, P[c], U[c], false);
+				V[c] = __builtin_amdgcn_udot4(wrow, P[c], V[c], false);
 			}
 		}
-		// mode 6: the other palette half lives in lane ^ 4
-		const uint32_t other = (uint32_t)__shfl_xor((int)key, 4, 64);
-		key = (m6 && other < key) ? other : key;
-		const bool m = (mrow >> j) & 1u;
-		err += m ? (key >> 7) : 0u;
-		wrow |= (m ? (key & 127u) : 0u) << (8*j);
 	}
-	f.err = quad_sum(err);
-	f.wrow = wrow;
-
-	uint32_t S = 0, A = 0, B = 0, C = 0, U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
+	f.wrow[0] = R == 1 ? wlast : wprev;
+	f.wrow[1] = R == 1 ? 0u : wlast;
+	f.err = group_sum<R>(err);
 	if (want_lsq) {
-		const uint32_t iwrow = (0x40404040u - wrow) & bytemask4(mrow);
-		uint32_t P[4];
-		planes<ROT>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*row), P);
-		S = quad_sum(__builtin_amdgcn_udot4(wrow, 0x01010101u, 0u, false));
-		A = quad_sum(__builtin_amdgcn_udot4(iwrow, iwrow, 0u, false));
-		B = quad_sum(__builtin_amdgcn_udot4(iwrow, wrow, 0u, false));
-		C = quad_sum(__builtin_amdgcn_udot4(wrow, wrow, 0u, false));
+		S = group_sum<R>(S);
+		A = group_sum<R>(A);
+		B = group_sum<R>(B);
+		C = group_sum<R>(C);
 #pragma unroll
 		for (int c = 0; c < 4; ++c) {
-			U[c] = quad_sum(__builtin_amdgcn_udot4(iwrow, P[c], 0u, false));
-			V[c] = quad_sum(__builtin_amdgcn_udot4(wrow, P[c], 0u, false));
+			U[c] = group_sum<R>(U[c]);
+			V[c] = group_sum<R>(V[c]);
 		}
 	}
 	const int det = (int)((uint32_t)__builtin_popcount(mask)*C) - (int)(S*S);
@@ -633,7 +661,7 @@ __device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t mask, ui
 	}
 }
 
-template <bool UNITW, bool ROT>
+template <bool UNITW, bool ROT, int R>
 __device__ __forceinline__ void fit_vec_rows(const Tex& tx, uint32_t mask, uint32_t row, bool m6,
 	uint32_t khalf, uint32_t cb, uint32_t ab, uint32_t pbk, uint32_t ib, uint32_t iters,
 	const uint32_t (&wt)[4], RowFit& best)
@@ -704,24 +732,30 @@ __device__ __forceinline__ void fit_vec_rows(const Tex& tx, uint32_t mask, uint3
 		mean[c] = (float)s[c]*in;
 	float tmin = 3.0e38f, tmax = -3.0e38f;
 	{
-		const uint4 rw = *reinterpret_cast<const uint4*>(tx.tp + 4u*row);
-		const uint32_t raw[4] = {rw.x, rw.y, rw.z, rw.w};
-		const uint32_t mrow = (mask >> (4u*row)) & 15u;
 #pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			const uint32_t p = texel<ROT>(tx, raw[j]);
-			const bool m = (mrow >> j) & 1u;
-			float t = axis[0]*(fb(p, 0) - mean[0]);
-			t = fmaf(axis[1], fb(p, 1) - mean[1], t);
-			t = fmaf(axis[2], fb(p, 2) - mean[2], t);
-			t = fmaf(axis[3], fb(p, 3) - mean[3], t);
-			tmin = m ? fminf(tmin, t) : tmin;
-			tmax = m ? fmaxf(tmax, t) : tmax;
+		for (int rr = 0; rr < R; ++rr) {
+			const uint32_t r = (uint32_t)R*row + (uint32_t)rr;
+			const uint4 rw = *reinterpret_cast<const uint4*>(tx.tp + 4u*r);
+			const uint32_t raw[4] = {rw.x, rw.y, rw.z, rw.w};
+			const uint32_t mrow = (mask >> (4u*r)) & 15u;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				const uint32_t p = texel<ROT>(tx, raw[j]);
+				const bool m = (mrow >> j) & 1u;
+				float t = axis[0]*(fb(p, 0) - mean[0]);
+				t = fmaf(axis[1], fb(p, 1) - mean[1], t);
+				t = fmaf(axis[2], fb(p, 2) - mean[2], t);
+				t = fmaf(axis[3], fb(p, 3) - mean[3], t);
+				tmin = m ? fminf(tmin, t) : tmin;
+				tmax = m ? fmaxf(tmax, t) : tmax;
+			}
 		}
 		tmin = fminf(tmin, __shfl_xor(tmin, 1, 64));
-		tmin = fminf(tmin, __shfl_xor(tmin, 2, 64));
 		tmax = fmaxf(tmax, __shfl_xor(tmax, 1, 64));
-		tmax = fmaxf(tmax, __shfl_xor(tmax, 2, 64));
+		if (R == 1) {
+			tmin = fminf(tmin, __shfl_xor(tmin, 2, 64));
+			tmax = fmaxf(tmax, __shfl_xor(tmax, 2, 64));
+		}
 	}
 	float x0[4], x1[4];
 #pragma unroll
@@ -737,12 +771,12 @@ __device__ __forceinline__ void fit_vec_rows(const Tex& tx, uint32_t mask, uint3
 	SubFit q;
 	quantize(x0, x1, cb, ab, pbk, fwt, q);
 	best.e0 = q.e0; best.e1 = q.e1; best.q0 = q.q0; best.q1 = q.q1; best.pb = q.pb;
-	assign_lsq_rows<UNITW, ROT>(tx, mask, row, m6, khalf, ib, wt, iters > 0u, best);
+	assign_lsq_rows<UNITW, ROT, R>(tx, mask, row, m6, khalf, ib, wt, iters > 0u, best);
 	for (uint32_t r = 0; r < iters; ++r) {
 		RowFit cur;
 		quantize(best.nx0, best.nx1, cb, ab, pbk, fwt, q);
 		cur.e0 = q.e0; cur.e1 = q.e1; cur.q0 = q.q0; cur.q1 = q.q1; cur.pb = q.pb;
-		assign_lsq_rows<UNITW, ROT>(tx, mask, row, m6, khalf, ib, wt, r + 1u < iters, cur);
+		assign_lsq_rows<UNITW, ROT, R>(tx, mask, row, m6, khalf, ib, wt, r + 1u < iters, cur);
 		if (best.ok && cur.err < best.err)
 			best = cur;
 	}
@@ -777,12 +811,12 @@ __device__ __forceinline__ void fit_scalar_rows(const Tex& tx, uint32_t row, uin
 	SubFit q;
 	quantize(x0, x1, 0u, ab, 0u, fwt, q);
 	best.e0 = q.e0; best.e1 = q.e1; best.q0 = q.q0; best.q1 = q.q1; best.pb = q.pb;
-	assign_lsq_rows<UNITW, true>(tx, 0xFFFFu, row, false, 0u, ib, swt, iters > 0u, best);
+	assign_lsq_rows<UNITW, true, 1>(tx, 0xFFFFu, row, false, 0u, ib, swt, iters > 0u, best);
 	for (uint32_t r = 0; r < iters; ++r) {
 		RowFit cur;
 		quantize(best.nx0, best.nx1, 0u, ab, 0u, fwt, q);
 		cur.e0 = q.e0; cur.e1 = q.e1; cur.q0 = q.q0; cur.q1 = q.q1; cur.pb = q.pb;
-		assign_lsq_rows<UNITW, true>(tx, 0xFFFFu, row, false, 0u, ib, swt, r + 1u < iters, cur);
+		assign_lsq_rows<UNITW, true, 1>(tx, 0xFFFFu, row, false, 0u, ib, swt, r + 1u < iters, cur);
 		if (best.ok && cur.err < best.err)
 			best = cur;
 	}
@@ -941,12 +975,103 @@ __device__ __forceinline__ uint4 pack_block(const Cand& c)
 		(uint32_t)(bw.hi >> 32));
 }
 
+// Partition score of the two-phase search (oracle: subset_residual): the scatter of the
+// subset that no line through its mean can capture, (trace(C) - a'Ca)/n, with a = the
+// power-iterated principal axis.  Same statistics and axis arithmetic as fit_vec.
+__device__ __forceinline__ float subset_residual(const Tex& tx, uint32_t mask)
+{
+	const uint32_t n = (uint32_t)__builtin_popcount(mask);
+	uint32_t s[4] = {0, 0, 0, 0};
+	uint32_t q00 = 0, q01 = 0, q02 = 0, q03 = 0, q11 = 0, q12 = 0, q13 = 0, q22 = 0, q23 = 0,
+		q33 = 0;
+#pragma unroll 1
+	for (uint32_t r = 0; r < 4u; ++r) {
+		uint32_t P[4];
+		planes<false>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
+		const uint32_t m4 = bytemask4((mask >> (4u*r)) & 15u);
+		const uint32_t M0 = P[0] & m4, M1 = P[1] & m4, M2 = P[2] & m4, M3 = P[3] & m4;
+		s[0] = __builtin_amdgcn_udot4(M0, 0x01010101u, s[0], false);
+		s[1] = __builtin_amdgcn_udot4(M1, 0x01010101u, s[1], false);
+		s[2] = __builtin_amdgcn_udot4(M2, 0x01010101u, s[2], false);
+		s[3] = __builtin_amdgcn_udot4(M3, 0x01010101u, s[3], false);
+		q00 = __builtin_amdgcn_udot4(M0, P[0], q00, false);
+		q01 = __builtin_amdgcn_udot4(M0, P[1], q01, false);
+		q02 = __builtin_amdgcn_udot4(M0, P[2], q02, false);
+		q03 = __builtin_amdgcn_udot4(M0, P[3], q03, false);
+		q11 = __builtin_amdgcn_udot4(M1, P[1], q11, false);
+		q12 = __builtin_amdgcn_udot4(M1, P[2], q12, false);
+		q13 = __builtin_amdgcn_udot4(M1, P[3], q13, false);
+		q22 = __builtin_amdgcn_udot4(M2, P[2], q22, false);
+		q23 = __builtin_amdgcn_udot4(M2, P[3], q23, false);
+		q33 = __builtin_amdgcn_udot4(M3, P[3], q33, false);
+	}
+	const float C00 = (float)(int)(n*q00 - s[0]*s[0]), C01 = (float)(int)(n*q01 - s[0]*s[1]);
+	const float C02 = (float)(int)(n*q02 - s[0]*s[2]), C03 = (float)(int)(n*q03 - s[0]*s[3]);
+	const float C11 = (float)(int)(n*q11 - s[1]*s[1]), C12 = (float)(int)(n*q12 - s[1]*s[2]);
+	const float C13 = (float)(int)(n*q13 - s[1]*s[3]), C22 = (float)(int)(n*q22 - s[2]*s[2]);
+	const float C23 = (float)(int)(n*q23 - s[2]*s[3]), C33 = (float)(int)(n*q33 - s[3]*s[3]);
+	float bestd = C00;
+	float v0 = C00, v1 = C01, v2 = C02, v3 = C03;
+	if (C11 > bestd) { bestd = C11; v0 = C01; v1 = C11; v2 = C12; v3 = C13; }
+	if (C22 > bestd) { bestd = C22; v0 = C02; v1 = C12; v2 = C22; v3 = C23; }
+	if (C33 > bestd) { bestd = C33; v0 = C03; v1 = C13; v2 = C23; v3 = C33; }
+#pragma unroll
+	for (int it = 0; it < 3; ++it) {
+		float r0 = C00*v0; r0 = fmaf(C01, v1, r0); r0 = fmaf(C02, v2, r0); r0 = fmaf(C03, v3, r0);
+		float r1 = C01*v0; r1 = fmaf(C11, v1, r1); r1 = fmaf(C12, v2, r1); r1 = fmaf(C13, v3, r1);
+		float r2 = C02*v0; r2 = fmaf(C12, v1, r2); r2 = fmaf(C22, v2, r2); r2 = fmaf(C23, v3, r2);
+		float r3 = C03*v0; r3 = fmaf(C13, v1, r3); r3 = fmaf(C23, v2, r3); r3 = fmaf(C33, v3, r3);
+		v0 = r0; v1 = r1; v2 = r2; v3 = r3;
+	}
+	const float mx = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
+	float tr = C00 + C11;
+	tr = tr + C22;
+	tr = tr + C33;
+	float res = 0.0f;
+	if (mx > 0.0f) {
+		const float im = 1.0f/mx;
+		v0 = v0*im; v1 = v1*im; v2 = v2*im; v3 = v3*im;
+		float w0 = C00*v0; w0 = fmaf(C01, v1, w0); w0 = fmaf(C02, v2, w0); w0 = fmaf(C03, v3, w0);
+		float w1 = C01*v0; w1 = fmaf(C11, v1, w1); w1 = fmaf(C12, v2, w1); w1 = fmaf(C13, v3, w1);
+		float w2 = C02*v0; w2 = fmaf(C12, v1, w2); w2 = fmaf(C22, v2, w2); w2 = fmaf(C23, v3, w2);
+		float w3 = C03*v0; w3 = fmaf(C13, v1, w3); w3 = fmaf(C23, v2, w3); w3 = fmaf(C33, v3, w3);
+		float num = v0*w0;
+		num = fmaf(v1, w1, num);
+		num = fmaf(v2, w2, num);
+		num = fmaf(v3, w3, num);
+		float den = v0*v0;
+		den = fmaf(v1, v1, den);
+		den = fmaf(v2, v2, den);
+		den = fmaf(v3, v3, den);
+		const float lam = num*(1.0f/den);
+		res = (tr - lam)*(1.0f/(float)n);
+		res = res > 0.0f ? res : 0.0f;
+	}
+	return res;
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t k)
+{
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) {
+		const uint32_t o = (uint32_t)__shfl_xor((int)k, off, 64);
+		k = o < k ? o : k;
+	}
+	return k;
+}
+
+// Timing-ablation switches for tools/ab_bench.sh (never set in the product build).
+#ifndef CF_BC7_ABLATE
+#define CF_BC7_ABLATE 0
+#endif
+
 // Encode one block with the whole wavefront.  tp: the block's 16 texels in LDS
 // (colour mask already applied), identical for every lane.
 template <bool UNITW>
 __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t* pl,
-	const cf_kparams& kp, uint32_t lane, bool& is_winner)
+	const cf_kparams& kp, uint32_t lane0, bool& is_winner)
 {
+	uint32_t lane = lane0;
 	const bool has_alpha = __ballot(lane < 16u && (tp[lane & 15u] >> 24) != 255u) != 0ull;
 	const uint32_t quality = kp.quality;
 	const uint32_t iters = quality < 4u ? quality : 4u;
@@ -987,10 +1112,12 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 			else if (rot == 2u) { wl[3] = wl[1]; wl[1] = t3; }
 			else { wl[3] = wl[2]; wl[2] = t3; }
 		}
+		if (CF_BC7_ABLATE & 1) active = active && m6;
+		if (CF_BC7_ABLATE & 16) active = false;
 		if (active) {   // groups of 4 (mode 6: 8) lanes are active together
 			RowFit fv;
 			const uint32_t wv[4] = {wl[0], wl[1], wl[2], abv ? wl[3] : 0u};
-			fit_vec_rows<UNITW, true>(make_tex(tp, pl, rot, abv ? 15u : 7u), 0xFFFFu, row, m6,
+			fit_vec_rows<UNITW, true, 1>(make_tex(tp, pl, rot, abv ? 15u : 7u), 0xFFFFu, row, m6,
 				lane >> 2, cb, abv, pbk, ibc, iters, wv, fv);
 			Cand c;
 			c.err = fv.err;
@@ -1000,7 +1127,7 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 			const int g0 = (int)(lane & ~3u);
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
-				c.w[k] = (uint32_t)__shfl((int)fv.wrow, g0 + k, 64);
+				c.w[k] = (uint32_t)__shfl((int)fv.wrow[0], g0 + k, 64);
 				c.w2[k] = 0;
 			}
 			if (absc) {
@@ -1011,7 +1138,7 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 				c.q[5] = fs.q1 & 0xFF000000u;
 #pragma unroll
 				for (int k = 0; k < 4; ++k)
-					c.w2[k] = (uint32_t)__shfl((int)fs.wrow, g0 + k, 64);
+					c.w2[k] = (uint32_t)__shfl((int)fs.wrow[0], g0 + k, 64);
 			}
 			// one lane per candidate registers it
 			if ((m6 ? lane == 0u : row == 0u) && c.err < best.err)
@@ -1023,17 +1150,12 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 	// remaining passes may be skipped without changing the payload.
 	bool solved = __ballot(best.err == 0u) != 0ull;
 
-	// ---- partitioned passes: lane = partition ----
-	if (quality >= 1u && !solved) {
-		// list of modes for this block (uniform), one nibble each
+	// ---- partitioned modes ----
+	if (quality >= 4u && !solved && !(CF_BC7_ABLATE & 32)) {
+		// Highest: lane = partition, every partition gets all the refit rounds
 		uint32_t modes, nmodes;
-		if (has_alpha) {
-			modes = 7u; nmodes = 1u;
-		} else {
-			modes = 1u; nmodes = 1u;
-			if (quality >= 2u) { modes |= 3u << 4; nmodes = 2u; }
-			if (quality >= 3u) { modes |= (0u << 8) | (2u << 12); nmodes = 4u; }
-		}
+		if (has_alpha) { modes = 7u; nmodes = 1u; }
+		else { modes = 1u | (3u << 4) | (0u << 8) | (2u << 12); nmodes = 4u; }
 		const uint32_t p2 = k_part2[lane], p3 = k_part3[lane];
 		uint32_t m30 = 0, m31 = 0, m32 = 0;
 #pragma unroll
@@ -1055,8 +1177,6 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 			}
 			const Tex tx = make_tex(tp, pl, 0u, ab ? 15u : 7u);   // opaque modes do not code alpha
 			const uint32_t wv[4] = {wt[0], wt[1], wt[2], ab ? wt[3] : 0u};
-			const bool exhaustive = quality >= 4u;
-			// ---- stage 1: lane = partition; round-0 fit (all rounds when exhaustive) ----
 			Cand c;
 			c.err = 0;
 			c.id = idbase + lane;
@@ -1072,7 +1192,7 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 				else
 					mask = s == 0u ? m30 : (s == 1u ? m31 : m32);
 				SubFit f;
-				fit_vec<UNITW, false, 8>(tx, mask, cb, ab, pbk, ib, exhaustive ? iters : 0u, wv, f);
+				fit_vec<UNITW, false, 8>(tx, mask, cb, ab, pbk, ib, iters, wv, f);
 				c.err += f.err;
 				if (s == 0u) { c.q[0] = f.q0; c.q[1] = f.q1; c.pb |= f.pb; }
 				else if (s == 1u) { c.q[2] = f.q0; c.q[3] = f.q1; c.pb |= f.pb << 2; }
@@ -1080,78 +1200,118 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 #pragma unroll
 				for (int k = 0; k < 4; ++k) c.w[k] |= f.w[k];
 			}
-			const uint32_t err0 = c.err;
 			if (lane < npart && c.err < best.err)
 				best = c;
 			solved = __ballot(best.err == 0u) != 0ull;
-			if (!exhaustive && iters > 0u && !solved) {
-				// ---- select the T partitions with the smallest (round-0 error, id) ----
-				// ---- stage 2: lane = (rank, subset, texel row): all refit rounds ----
-				const uint32_t gl = 4u*ns;                       // lanes per partition
-				const uint32_t T = ns == 2u ? 8u : 5u;
-				const uint32_t rank = lane/gl, sub = (lane - rank*gl) >> 2, row = lane & 3u;
-				uint32_t key = lane < npart ? ((err0 << 6) | lane) : 0xFFFFFFFFu;
-				uint32_t mypart = 0;
-				for (uint32_t t = 0; t < T; ++t) {
-					uint32_t kmin = key;
-#pragma unroll
-					for (int off = 32; off >= 1; off >>= 1) {
-						const uint32_t o = (uint32_t)__shfl_xor((int)kmin, off, 64);
-						kmin = o < kmin ? o : kmin;
-					}
-					mypart = rank == t ? (kmin & 63u) : mypart;
-					key = key == kmin ? 0xFFFFFFFFu : key;
-				}
-				const bool act = rank < T;
-				const uint32_t sp2 = k_part2[mypart], sp3 = k_part3[mypart];
-				uint32_t smask;
-				if (ns == 2u)
-					smask = sub ? sp2 : (~sp2 & 0xFFFFu);
+		}
+	} else if (quality >= 1u && !solved && !(CF_BC7_ABLATE & 64)) {
+		// Two-phase search.  Phase 1 (lane = partition): score every partition with the
+		// residual estimator -- once per subset count, the score does not depend on the
+		// mode.  Phase 2 (lane = (mode, rank, subset, row pair)): full fit with all refit
+		// rounds of the best partitions of every mode of the group, two lanes per subset.
+		//   two-subset group:   modes 1 + 3 with 8 partitions each, or one mode (1 or 7) with 16
+		//   three-subset group: modes 0 + 2 with 5 partitions each (Production and up)
+		const Tex tx = make_tex(tp, pl, 0u, has_alpha ? 15u : 7u);
+		const uint32_t wv[4] = {wt[0], wt[1], wt[2], has_alpha ? wt[3] : 0u};
+		const uint32_t ngroups = (!has_alpha && quality >= 3u) ? 2u : 1u;
+		if (CF_BC7_ABLATE & 2) solved = true;
+#pragma unroll 1
+		for (uint32_t g = 0; g < ngroups && !solved; ++g) {
+			asm volatile("" : "+v"(lane));   // roles below are recomputed per group, not kept
+			const uint32_t ns = 2u + g, gl = 2u*ns;
+			const uint32_t p2 = k_part2[lane], p3 = k_part3[lane];
+			float sc = 0.0f;
+			for (uint32_t sb = 0; sb < ns; ++sb) {
+				uint32_t mask;
+				if (g == 0u)
+					mask = sb ? p2 : (~p2 & 0xFFFFu);
 				else {
-					smask = 0;
+					mask = 0;
 #pragma unroll
 					for (int i = 0; i < 16; ++i)
-						smask |= (((sp3 >> (2*i)) & 3u) == sub ? 1u : 0u) << i;
+						mask |= (((p3 >> (2*i)) & 3u) == sb ? 1u : 0u) << i;
 				}
-				RowFit rf;
-				rf.err = 0; rf.q0 = 0; rf.q1 = 0; rf.pb = 0; rf.wrow = 0;
-				if (act)
-					fit_vec_rows<UNITW, false>(tx, smask, row, false, 0u, cb, ab, pbk, ib, iters, wv,
-						rf);
-				// gather the partition's subsets into the leader lane (sub 0, row 0)
-				const int g0 = (int)(rank*gl);
-				Cand r2;
-				r2.id = idbase + mypart;
-				r2.err = 0;
-				r2.pb = 0;
-#pragma unroll
-				for (int k = 0; k < 6; ++k) r2.q[k] = 0;
-#pragma unroll
-				for (int k = 0; k < 4; ++k) { r2.w[k] = 0; r2.w2[k] = 0; }
-#pragma unroll
-				for (int sb = 0; sb < 3; ++sb) {
-					const int src = g0 + 4*sb;
-					const uint32_t e = (uint32_t)__shfl((int)rf.err, src, 64);
-					const uint32_t a0 = (uint32_t)__shfl((int)rf.q0, src, 64);
-					const uint32_t a1 = (uint32_t)__shfl((int)rf.q1, src, 64);
-					const uint32_t pbs = (uint32_t)__shfl((int)rf.pb, src, 64);
-					uint32_t wr[4];
-#pragma unroll
-					for (int k = 0; k < 4; ++k)
-						wr[k] = (uint32_t)__shfl((int)rf.wrow, src + k, 64);
-					if ((uint32_t)sb < ns) {
-						r2.err += e;
-						r2.q[2*sb] = a0; r2.q[2*sb + 1] = a1;
-						r2.pb |= pbs << (2*sb);
-#pragma unroll
-						for (int k = 0; k < 4; ++k) r2.w[k] |= wr[k];
-					}
-				}
-				// (error, id) order: a refined partition may carry a lower id than this lane's best
-				if (act && sub == 0u && row == 0u &&
-					(r2.err < best.err || (r2.err == best.err && r2.id < best.id)))
-					best = r2;
+				sc = sc + subset_residual(tx, mask);
 			}
+			const uint32_t key0 = (__float_as_uint(sc) & ~63u) | lane;
+			// lane roles in phase 2
+			const bool twomodes = g == 1u || (!has_alpha && quality >= 2u);
+			const uint32_t per = g == 1u ? 5u : (twomodes ? 8u : 16u);   // partitions per mode
+			const uint32_t rankall = lane/gl;
+			const uint32_t mi = (twomodes && rankall >= per) ? 1u : 0u;
+			const uint32_t rank = rankall - mi*per;
+			const uint32_t sub = (lane - rankall*gl) >> 1, rp = lane & 1u;
+			const bool act = rankall < (twomodes ? 2u*per : per);
+			uint32_t mypart = 0;
+			const uint32_t nruns = g == 1u ? 2u : 1u;   // mode 0 ranks its own 16 partitions
+			for (uint32_t run = 0; run < nruns; ++run) {
+				const uint32_t npart = (g == 1u && run == 0u) ? 16u : 64u;
+				uint32_t key = lane < npart ? key0 : 0xFFFFFFFFu;
+				for (uint32_t t = 0; t < per; ++t) {
+					const uint32_t kmin = wave_min_u32(key);
+					const bool mine = rank == t && (g == 0u || mi == run);
+					mypart = mine ? (kmin & 63u) : mypart;
+					key = key == kmin ? 0xFFFFFFFFu : key;
+				}
+			}
+			uint32_t mode;
+			if (g == 1u) mode = mi ? 2u : 0u;
+			else mode = has_alpha ? 7u : (mi ? 3u : 1u);
+			uint32_t cb, ab, pbk, ib, idbase;
+			switch (mode) {
+				case 1: cb = 6; ab = 0; pbk = 2; ib = 3; idbase = 64; break;
+				case 3: cb = 7; ab = 0; pbk = 1; ib = 2; idbase = 128; break;
+				case 0: cb = 4; ab = 0; pbk = 1; ib = 3; idbase = 192; break;
+				case 2: cb = 5; ab = 0; pbk = 0; ib = 2; idbase = 256; break;
+				default: cb = 5; ab = 5; pbk = 1; ib = 2; idbase = 320; break;
+			}
+			const uint32_t sp2 = k_part2[mypart], sp3 = k_part3[mypart];
+			uint32_t smask;
+			if (g == 0u)
+				smask = sub ? sp2 : (~sp2 & 0xFFFFu);
+			else {
+				smask = 0;
+#pragma unroll
+				for (int i = 0; i < 16; ++i)
+					smask |= (((sp3 >> (2*i)) & 3u) == sub ? 1u : 0u) << i;
+			}
+			RowFit rf;
+			rf.err = 0; rf.q0 = 0; rf.q1 = 0; rf.pb = 0; rf.wrow[0] = 0; rf.wrow[1] = 0;
+			if (act)
+				fit_vec_rows<UNITW, false, 2>(tx, smask, rp, false, 0u, cb, ab, pbk, ib, iters, wv,
+					rf);
+			// gather the partition's subsets into the leader lane (subset 0, row pair 0)
+			const int g0 = (int)(rankall*gl);
+			Cand r2;
+			r2.id = idbase + mypart;
+			r2.err = 0;
+			r2.pb = 0;
+#pragma unroll
+			for (int k = 0; k < 6; ++k) r2.q[k] = 0;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { r2.w[k] = 0; r2.w2[k] = 0; }
+#pragma unroll
+			for (int sb = 0; sb < 3; ++sb) {
+				const int src = g0 + 2*sb;
+				const uint32_t e = (uint32_t)__shfl((int)rf.err, src, 64);
+				const uint32_t a0 = (uint32_t)__shfl((int)rf.q0, src, 64);
+				const uint32_t a1 = (uint32_t)__shfl((int)rf.q1, src, 64);
+				const uint32_t pbs = (uint32_t)__shfl((int)rf.pb, src, 64);
+				uint32_t wr[4];
+#pragma unroll
+				for (int k = 0; k < 4; ++k)
+					wr[k] = (uint32_t)__shfl((int)rf.wrow[k & 1], src + (k >> 1), 64);
+				if ((uint32_t)sb < ns) {
+					r2.err += e;
+					r2.q[2*sb] = a0; r2.q[2*sb + 1] = a1;
+					r2.pb |= pbs << (2*sb);
+#pragma unroll
+					for (int k = 0; k < 4; ++k) r2.w[k] |= wr[k];
+				}
+			}
+			if (act && sub == 0u && rp == 0u &&
+				(r2.err < best.err || (r2.err == best.err && r2.id < best.id)))
+				best = r2;
 			solved = __ballot(best.err == 0u) != 0ull;
 		}
 	}
@@ -1199,7 +1359,11 @@ cfhip_bc7_encode_kernel(cf_kparams kp)
 		if (bx0 + b >= kp.bx)
 			break;
 		bool win;
-		const uint4 blk = encode_block<UNITW>(tile + b*16u, plan + b*16u, kp, lane, win);
+		// opaque copy: keeps the (many) lane-role values of encode_block from being hoisted
+		// out of this loop and held in registers across all phases
+		uint32_t ln = lane;
+		asm volatile("" : "+v"(ln));
+		const uint4 blk = encode_block<UNITW>(tile + b*16u, plan + b*16u, kp, ln, win);
 		if (win)
 			outb[b] = blk;
 	}

@@ -327,6 +327,97 @@ static void fit_scalar(const int px[16][4], const int wt[4], int abits, int ib, 
 	}
 }
 
+/* Partition score for the two-phase search: the part of the subsets' scatter that no
+ * line through the subset mean can capture, sum over subsets of (trace(C) - a'Ca)/n
+ * with a = the power-iterated principal axis (same statistics and axis arithmetic as
+ * fit_subset).  Cheap (no quantisation, no selector assignment) and shared by every
+ * mode with the same subset count. */
+static float subset_residual(const int px[16][4], unsigned mask, const int bits[4])
+{
+	int n = 0, sum[4] = {0, 0, 0, 0}, sq[4][4];
+	memset(sq, 0, sizeof(sq));
+	for (int i = 0; i < 16; ++i) {
+		if (!((mask >> i) & 1))
+			continue;
+		++n;
+		for (int a = 0; a < 4; ++a) {
+			if (!bits[a])
+				continue;
+			sum[a] += px[i][a];
+			for (int b = a; b < 4; ++b)
+				if (bits[b])
+					sq[a][b] += px[i][a]*px[i][b];
+		}
+	}
+	float Cm[4][4];
+	for (int a = 0; a < 4; ++a)
+		for (int b = a; b < 4; ++b)
+			Cm[a][b] = Cm[b][a] = (float)(n*sq[a][b] - sum[a]*sum[b]);
+	int amax = 0;
+	for (int a = 1; a < 4; ++a)
+		if (Cm[a][a] > Cm[amax][amax])
+			amax = a;
+	float v[4];
+	for (int a = 0; a < 4; ++a)
+		v[a] = Cm[amax][a];
+	for (int it = 0; it < 3; ++it) {
+		float r[4];
+		for (int a = 0; a < 4; ++a) {
+			float t = Cm[a][0]*v[0];
+			t = fmaf(Cm[a][1], v[1], t);
+			t = fmaf(Cm[a][2], v[2], t);
+			t = fmaf(Cm[a][3], v[3], t);
+			r[a] = t;
+		}
+		memcpy(v, r, sizeof(v));
+	}
+	float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+	float tr = Cm[0][0] + Cm[1][1];
+	tr = tr + Cm[2][2];
+	tr = tr + Cm[3][3];
+	if (!(m > 0.0f))
+		return 0.0f;
+	float im = 1.0f/m;
+	for (int a = 0; a < 4; ++a)
+		v[a] = v[a]*im;
+	float w[4];
+	for (int a = 0; a < 4; ++a) {
+		float t = Cm[a][0]*v[0];
+		t = fmaf(Cm[a][1], v[1], t);
+		t = fmaf(Cm[a][2], v[2], t);
+		t = fmaf(Cm[a][3], v[3], t);
+		w[a] = t;
+	}
+	float num = v[0]*w[0];
+	num = fmaf(v[1], w[1], num);
+	num = fmaf(v[2], w[2], num);
+	num = fmaf(v[3], w[3], num);
+	float den = v[0]*v[0];
+	den = fmaf(v[1], v[1], den);
+	den = fmaf(v[2], v[2], den);
+	den = fmaf(v[3], v[3], den);
+	float lam = num*(1.0f/den);
+	float res = (tr - lam)*(1.0f/(float)n);
+	return res > 0.0f ? res : 0.0f;
+}
+
+static float partition_score(const int px[16][4], int ns, int part, const int bits[4])
+{
+	unsigned masks[3];
+	if (ns == 2) {
+		masks[1] = cfo_part2[part];
+		masks[0] = ~masks[1] & 0xFFFFu;
+	} else {
+		masks[0] = masks[1] = masks[2] = 0;
+		for (int i = 0; i < 16; ++i)
+			masks[(cfo_part3[part] >> (2*i)) & 3] |= 1u << i;
+	}
+	float sc = 0.0f;
+	for (int s = 0; s < ns; ++s)
+		sc = sc + subset_residual(px, masks[s], bits);
+	return sc;
+}
+
 static void eval_candidate(const int px[16][4], const int wt[4], int id, int iters, cand* c)
 {
 	memset(c, 0, sizeof(*c));
@@ -569,46 +660,65 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 		if (b.rot)
 			for (int k = 0; k < 8; ++k)
 				TRY(5 + k);
-		/* Partitioned modes.  Below Highest the refit rounds are spent only on the T
-		 * partitions with the smallest round-0 error (T = 8 for two-subset modes, 5 for
-		 * three-subset modes): phase 1 scores every partition with the round-0 fit
-		 * (ids as usual), phase 2 re-fits the T best with all rounds.  The HIP kernel
-		 * runs phase 1 with lane = partition and phase 2 with lane = (rank, subset,
-		 * texel row).  Highest refits every partition. */
-		int bases[4], counts[4], nm = 0;
-		if (!has_alpha) {
-			if (b.two) { bases[nm] = 64; counts[nm++] = 64; }
-			if (b.mode3) { bases[nm] = 128; counts[nm++] = 64; }
-			if (b.three) {
-				bases[nm] = 192; counts[nm++] = 16;
-				bases[nm] = 256; counts[nm++] = 64;
+		/* Partitioned modes.  Highest refits every partition of every mode.  Below that
+		 * the search is two-phase per subset count (group): phase 1 scores every
+		 * partition with the residual estimator (partition_score; independent of the
+		 * mode), phase 2 runs the full fit with all refit rounds on the best partitions
+		 * of each mode of the group, ranked by (score bits with the low 6 bits cleared,
+		 * partition index):
+		 *   two-subset group:   modes 1 + 3 with 8 partitions each, or a single mode
+		 *                       (1 below Normal, 7 for blocks with alpha) with 16
+		 *   three-subset group: modes 0 (its 16 partitions) + 2 with 5 partitions each
+		 * The HIP kernel runs phase 1 with lane = partition and phase 2 of a whole group
+		 * in one pass with lane = (mode, rank, subset, row pair). */
+		if (p->quality >= 4) {
+			if (has_alpha) {
+				for (int k = 0; k < 64 && best.err != 0; ++k)
+					TRY(320 + k);
+			} else {
+				static const int bases[4] = {64, 128, 192, 256}, counts[4] = {64, 64, 16, 64};
+				for (int mi = 0; mi < 4 && best.err != 0; ++mi)
+					for (int k = 0; k < counts[mi]; ++k)
+						TRY(bases[mi] + k);
 			}
-		} else if (b.two) { bases[nm] = 320; counts[nm++] = 64; }
-		for (int mi = 0; mi < nm && best.err != 0; ++mi) {
-			if (p->quality >= 4) {
-				for (int k = 0; k < counts[mi]; ++k)
-					TRY(bases[mi] + k);
-				continue;
-			}
-			uint32_t e0[64];
-			for (int k = 0; k < counts[mi]; ++k) {
-				eval_candidate(px, wt, bases[mi] + k, 0, &cur);
-				e0[k] = cur.err;
-				if (BETTER(cur, best))
-					best = cur;
-			}
-			if (b.iters == 0 || best.err == 0)
-				continue;
-			int T = (bases[mi] == 192 || bases[mi] == 256) ? 5 : 8;
-			for (int r = 0; r < T; ++r) {
-				int bk = -1;
-				for (int k = 0; k < counts[mi]; ++k)
-					if (e0[k] != 0xFFFFFFFFu && (bk < 0 || e0[k] < e0[bk]))
-						bk = k;
-				if (bk < 0)
-					break;
-				e0[bk] = 0xFFFFFFFFu;
-				TRY(bases[mi] + bk);
+		} else if (b.two) {
+			const int bits[4] = {1, 1, 1, has_alpha};
+			const int ngroups = (!has_alpha && b.three) ? 2 : 1;
+			for (int g = 0; g < ngroups && best.err != 0; ++g) {
+				uint32_t key0[64];
+				for (int k = 0; k < 64; ++k) {
+					float sc = partition_score(px, 2 + g, k, bits);
+					uint32_t u;
+					memcpy(&u, &sc, 4);
+					key0[k] = (u & ~63u) | (uint32_t)k;
+				}
+				int bases[2], counts[2], nm = 0, per;
+				if (g == 1) {
+					bases[nm] = 192; counts[nm++] = 16;
+					bases[nm] = 256; counts[nm++] = 64;
+					per = 5;
+				} else if (has_alpha) {
+					bases[nm] = 320; counts[nm++] = 64;
+					per = 16;
+				} else {
+					bases[nm] = 64; counts[nm++] = 64;
+					if (b.mode3) { bases[nm] = 128; counts[nm++] = 64; }
+					per = nm == 2 ? 8 : 16;
+				}
+				for (int mi = 0; mi < nm; ++mi) {
+					uint32_t key[64];
+					memcpy(key, key0, sizeof(key));
+					for (int r = 0; r < per; ++r) {
+						int bk = -1;
+						for (int k = 0; k < counts[mi]; ++k)
+							if (key[k] != 0xFFFFFFFFu && (bk < 0 || key[k] < key[bk]))
+								bk = k;
+						if (bk < 0)
+							break;
+						key[bk] = 0xFFFFFFFFu;
+						TRY(bases[mi] + bk);
+					}
+				}
 			}
 		}
 	}
