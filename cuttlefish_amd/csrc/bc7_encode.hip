@@ -93,6 +93,32 @@ struct Cand {
 	uint32_t w2[4];    // scalar-plane weights per pixel (modes 4/5)
 };
 
+// A lane's best candidate so far lives in LDS (field-major, one column per thread):
+// only (error, id) stay in registers.  15 words: q[6], pb, w[4], w2[4].
+#define CF_BC7_CAND_WORDS 15
+__device__ __forceinline__ void cand_store(uint32_t* slot, const Cand& c)
+{
+#pragma unroll
+	for (int k = 0; k < 6; ++k) slot[k*CF_WG_THREADS] = c.q[k];
+	slot[6*CF_WG_THREADS] = c.pb;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		slot[(7 + k)*CF_WG_THREADS] = c.w[k];
+		slot[(11 + k)*CF_WG_THREADS] = c.w2[k];
+	}
+}
+__device__ __forceinline__ void cand_load(const uint32_t* slot, Cand& c)
+{
+#pragma unroll
+	for (int k = 0; k < 6; ++k) c.q[k] = slot[k*CF_WG_THREADS];
+	c.pb = slot[6*CF_WG_THREADS];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		c.w[k] = slot[(7 + k)*CF_WG_THREADS];
+		c.w2[k] = slot[(11 + k)*CF_WG_THREADS];
+	}
+}
+
 __device__ __forceinline__ uint32_t ub(uint32_t v, int c) { return (v >> (8*c)) & 255u; }
 __device__ __forceinline__ float fb(uint32_t v, int c) { return (float)((v >> (8*c)) & 255u); }
 
@@ -472,41 +498,6 @@ __device__ __forceinline__ void fit_vec(const Tex& tx, uint32_t mask, uint32_t c
 	}
 }
 
-// Scalar fit of channel 3 (after rotation) over all 16 texels: alpha plane of modes 4/5.
-// tx.chmask must be 8 (only the rotated alpha channel).
-template <bool UNITW>
-__device__ __forceinline__ void fit_scalar(const Tex& tx, uint32_t ab, uint32_t ib, uint32_t iters,
-	const uint32_t (&wt)[4], SubFit& best)
-{
-	uint32_t lo = 255u, hi = 0u;
-#pragma unroll 1
-	for (uint32_t r = 0; r < 4u; ++r) {
-		const uint4 row = *reinterpret_cast<const uint4*>(tx.tp + 4u*r);
-		const uint32_t raw[4] = {row.x, row.y, row.z, row.w};
-#pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			const uint32_t a = texel<true>(tx, raw[j]) >> 24;
-			lo = a < lo ? a : lo;
-			hi = a > hi ? a : hi;
-		}
-	}
-	float x0[4] = {0.0f, 0.0f, 0.0f, (float)lo}, x1[4] = {0.0f, 0.0f, 0.0f, (float)hi};
-	float fwt[4];
-#pragma unroll
-	for (int c = 0; c < 4; ++c)
-		fwt[c] = (float)wt[c];
-	const uint32_t swt[4] = {0u, 0u, 0u, wt[3]};
-	quantize(x0, x1, 0u, ab, 0u, fwt, best);
-	assign_lsq<UNITW, true, 8>(tx, 0xFFFFu, ib, swt, iters > 0u, best);
-	for (uint32_t r = 0; r < iters; ++r) {
-		SubFit cur;
-		quantize(best.nx0, best.nx1, 0u, ab, 0u, fwt, cur);
-		assign_lsq<UNITW, true, 8>(tx, 0xFFFFu, ib, swt, r + 1u < iters, cur);
-		if (best.ok && cur.err < best.err)
-			best = cur;
-	}
-}
-
 // ---------------------------------------------------------------------------
 // Row-split fits for the single-subset pass: one candidate is spread over 4 lanes
 // (lane = texel row), mode 6 additionally over 2 palette halves (lane ^ 4).  Sums
@@ -517,8 +508,6 @@ __device__ __forceinline__ void fit_scalar(const Tex& tx, uint32_t ab, uint32_t 
 struct RowFit {
 	uint32_t e0, e1, q0, q1, pb, err;
 	uint32_t wrow[2];       // weights of this lane's row(s)
-	float nx0[4], nx1[4];
-	bool ok;
 };
 
 // exact sum over the lanes that share one fit: 4 lanes with one texel row each (R = 1)
@@ -526,15 +515,16 @@ struct RowFit {
 template <int R>
 __device__ __forceinline__ uint32_t group_sum(uint32_t v)
 {
-	v += (uint32_t)__shfl_xor((int)v, 1, 64);
+	v += cf_xor1(v);
 	if (R == 1)
-		v += (uint32_t)__shfl_xor((int)v, 2, 64);
+		v += cf_xor2(v);
 	return v;
 }
 
 template <bool UNITW, bool ROT, int R>
 __device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t mask, uint32_t row, bool m6,
-	uint32_t khalf, uint32_t ib, const uint32_t (&wt)[4], bool want_lsq, RowFit& f)
+	uint32_t khalf, uint32_t ib, const uint32_t (&wt)[4], bool want_lsq, RowFit& f,
+	float (&nx0)[4], float (&nx1)[4], bool& ok)
 {
 	const uint32_t nk = m6 ? 8u : (1u << ib), kbase = m6 ? 8u*khalf : 0u;
 	const uint32_t e00 = ub(f.e0, 0), e01 = ub(f.e0, 1), e02 = ub(f.e0, 2), e03 = ub(f.e0, 3);
@@ -600,9 +590,10 @@ __device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t mask, ui
 					}
 				}
 			}
-			if (R == 1) {
-				// mode 6: the other palette half lives in lane ^ 4
-				const uint32_t other = (uint32_t)__shfl_xor((int)key, 4, 64);
+			if (ROT) {
+				// mode 6 (single-subset pass only): the other palette half lives in the
+				// neighbouring lane group
+				const uint32_t other = R == 1 ? (uint32_t)__shfl_xor((int)key, 4, 64) : cf_xor2(key);
 				key = (m6 && other < key) ? other : key;
 			}
 			const bool m = (mrow >> j) & 1u;
@@ -641,7 +632,7 @@ __device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t mask, ui
 		}
 	}
 	const int det = (int)((uint32_t)__builtin_popcount(mask)*C) - (int)(S*S);
-	f.ok = det > 0;
+	ok = det > 0;
 	const float inv = 1.0f/(64.0f*(float)(det > 0 ? det : 1));
 	const float fA = (float)A, fB = (float)B, fC = (float)C;
 #pragma unroll
@@ -652,11 +643,11 @@ __device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t mask, ui
 			const float n0 = fmaf(fC, fU, -t0);
 			const float t1 = fB*fU;
 			const float n1 = fmaf(fA, fV, -t1);
-			f.nx0[c] = clamp255(n0*inv);
-			f.nx1[c] = clamp255(n1*inv);
+			nx0[c] = clamp255(n0*inv);
+			nx1[c] = clamp255(n1*inv);
 		} else {
-			f.nx0[c] = 0.0f;
-			f.nx1[c] = 0.0f;
+			nx0[c] = 0.0f;
+			nx1[c] = 0.0f;
 		}
 	}
 }
@@ -664,7 +655,7 @@ __device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t mask, ui
 template <bool UNITW, bool ROT, int R>
 __device__ __forceinline__ void fit_vec_rows(const Tex& tx, uint32_t mask, uint32_t row, bool m6,
 	uint32_t khalf, uint32_t cb, uint32_t ab, uint32_t pbk, uint32_t ib, uint32_t iters,
-	const uint32_t (&wt)[4], RowFit& best)
+	const uint32_t (&wt)[4], bool scalar, RowFit& best)
 {
 	// A: statistics of the subset (every lane of the group computes them)
 	uint32_t s[4] = {0, 0, 0, 0};
@@ -750,11 +741,11 @@ __device__ __forceinline__ void fit_vec_rows(const Tex& tx, uint32_t mask, uint3
 				tmax = m ? fmaxf(tmax, t) : tmax;
 			}
 		}
-		tmin = fminf(tmin, __shfl_xor(tmin, 1, 64));
-		tmax = fmaxf(tmax, __shfl_xor(tmax, 1, 64));
+		tmin = fminf(tmin, cf_xor1f(tmin));
+		tmax = fmaxf(tmax, cf_xor1f(tmax));
 		if (R == 1) {
-			tmin = fminf(tmin, __shfl_xor(tmin, 2, 64));
-			tmax = fmaxf(tmax, __shfl_xor(tmax, 2, 64));
+			tmin = fminf(tmin, cf_xor2f(tmin));
+			tmax = fmaxf(tmax, cf_xor2f(tmax));
 		}
 	}
 	float x0[4], x1[4];
@@ -763,69 +754,58 @@ __device__ __forceinline__ void fit_vec_rows(const Tex& tx, uint32_t mask, uint3
 		x0[c] = clamp255(fmaf(axis[c], tmin, mean[c]));
 		x1[c] = clamp255(fmaf(axis[c], tmax, mean[c]));
 	}
+	if (ROT) {
+		// scalar plane of modes 4/5 (only the rotated alpha channel is coded): the start
+		// endpoints are the exact extremes of that channel (oracle: fit_scalar)
+		uint32_t lo = 255u, hi = 0u;
+#pragma unroll
+		for (int rr = 0; rr < R; ++rr) {
+			const uint4 pr = *reinterpret_cast<const uint4*>(tx.pl + 4u*((uint32_t)R*row + (uint32_t)rr));
+			const uint32_t a4 = tx.rot == 0u ? pr.w : (tx.rot == 1u ? pr.x : (tx.rot == 2u ? pr.y : pr.z));
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				const uint32_t a = (a4 >> (8*j)) & 255u;
+				lo = a < lo ? a : lo;
+				hi = a > hi ? a : hi;
+			}
+		}
+		uint32_t o;
+		o = cf_xor1(lo); lo = o < lo ? o : lo;
+		o = cf_xor1(hi); hi = o > hi ? o : hi;
+		if (R == 1) {
+			o = cf_xor2(lo); lo = o < lo ? o : lo;
+			o = cf_xor2(hi); hi = o > hi ? o : hi;
+		}
+		if (scalar) {
+			x0[0] = 0.0f; x0[1] = 0.0f; x0[2] = 0.0f; x0[3] = (float)lo;
+			x1[0] = 0.0f; x1[1] = 0.0f; x1[2] = 0.0f; x1[3] = (float)hi;
+		}
+	}
 	float fwt[4];
 #pragma unroll
 	for (int c = 0; c < 4; ++c)
 		fwt[c] = (float)wt[c];
 
+	// C/D then E rounds.  A round that does not improve ends the lane's search (the same
+	// input would give the same output again): x0/x1 always hold the refit of the newest
+	// selectors and `live` says whether they belong to the best fit so far.
 	SubFit q;
 	quantize(x0, x1, cb, ab, pbk, fwt, q);
 	best.e0 = q.e0; best.e1 = q.e1; best.q0 = q.q0; best.q1 = q.q1; best.pb = q.pb;
-	assign_lsq_rows<UNITW, ROT, R>(tx, mask, row, m6, khalf, ib, wt, iters > 0u, best);
+	bool live;
+	assign_lsq_rows<UNITW, ROT, R>(tx, mask, row, m6, khalf, ib, wt, iters > 0u, best, x0, x1, live);
 	for (uint32_t r = 0; r < iters; ++r) {
 		RowFit cur;
-		quantize(best.nx0, best.nx1, cb, ab, pbk, fwt, q);
+		bool ok;
+		quantize(x0, x1, cb, ab, pbk, fwt, q);
 		cur.e0 = q.e0; cur.e1 = q.e1; cur.q0 = q.q0; cur.q1 = q.q1; cur.pb = q.pb;
-		assign_lsq_rows<UNITW, ROT, R>(tx, mask, row, m6, khalf, ib, wt, r + 1u < iters, cur);
-		if (best.ok && cur.err < best.err)
+		assign_lsq_rows<UNITW, ROT, R>(tx, mask, row, m6, khalf, ib, wt, r + 1u < iters, cur, x0, x1,
+			ok);
+		const bool better = live && cur.err < best.err;
+		if (better)
 			best = cur;
+		live = better && ok;
 	}
-}
-
-template <bool UNITW>
-__device__ __forceinline__ void fit_scalar_rows(const Tex& tx, uint32_t row, uint32_t ab,
-	uint32_t ib, uint32_t iters, const uint32_t (&wt)[4], RowFit& best)
-{
-	uint32_t lo = 255u, hi = 0u;
-	{
-		const uint4 rw = *reinterpret_cast<const uint4*>(tx.tp + 4u*row);
-		const uint32_t raw[4] = {rw.x, rw.y, rw.z, rw.w};
-#pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			const uint32_t a = texel<true>(tx, raw[j]) >> 24;
-			lo = a < lo ? a : lo;
-			hi = a > hi ? a : hi;
-		}
-		uint32_t o;
-		o = (uint32_t)__shfl_xor((int)lo, 1, 64); lo = o < lo ? o : lo;
-		o = (uint32_t)__shfl_xor((int)lo, 2, 64); lo = o < lo ? o : lo;
-		o = (uint32_t)__shfl_xor((int)hi, 1, 64); hi = o > hi ? o : hi;
-		o = (uint32_t)__shfl_xor((int)hi, 2, 64); hi = o > hi ? o : hi;
-	}
-	float x0[4] = {0.0f, 0.0f, 0.0f, (float)lo}, x1[4] = {0.0f, 0.0f, 0.0f, (float)hi};
-	float fwt[4];
-#pragma unroll
-	for (int c = 0; c < 4; ++c)
-		fwt[c] = (float)wt[c];
-	const uint32_t swt[4] = {0u, 0u, 0u, wt[3]};
-	SubFit q;
-	quantize(x0, x1, 0u, ab, 0u, fwt, q);
-	best.e0 = q.e0; best.e1 = q.e1; best.q0 = q.q0; best.q1 = q.q1; best.pb = q.pb;
-	assign_lsq_rows<UNITW, true, 1>(tx, 0xFFFFu, row, false, 0u, ib, swt, iters > 0u, best);
-	for (uint32_t r = 0; r < iters; ++r) {
-		RowFit cur;
-		quantize(best.nx0, best.nx1, 0u, ab, 0u, fwt, q);
-		cur.e0 = q.e0; cur.e1 = q.e1; cur.q0 = q.q0; cur.q1 = q.q1; cur.pb = q.pb;
-		assign_lsq_rows<UNITW, true, 1>(tx, 0xFFFFu, row, false, 0u, ib, swt, r + 1u < iters, cur);
-		if (best.ok && cur.err < best.err)
-			best = cur;
-	}
-}
-
-__device__ __forceinline__ void cand_take(Cand& best, const Cand& c, bool take)
-{
-	if (take)
-		best = c;
 }
 
 struct BitWriter {
@@ -1050,16 +1030,6 @@ __device__ __forceinline__ float subset_residual(const Tex& tx, uint32_t mask)
 	return res;
 }
 
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t k)
-{
-#pragma unroll
-	for (int off = 32; off >= 1; off >>= 1) {
-		const uint32_t o = (uint32_t)__shfl_xor((int)k, off, 64);
-		k = o < k ? o : k;
-	}
-	return k;
-}
-
 // Timing-ablation switches for tools/ab_bench.sh (never set in the product build).
 #ifndef CF_BC7_ABLATE
 #define CF_BC7_ABLATE 0
@@ -1067,9 +1037,9 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t k)
 
 // Encode one block with the whole wavefront.  tp: the block's 16 texels in LDS
 // (colour mask already applied), identical for every lane.
-template <bool UNITW>
+template <bool UNITW, bool EXH>
 __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t* pl,
-	const cf_kparams& kp, uint32_t lane0, bool& is_winner)
+	uint32_t* cslot, const cf_kparams& kp, uint32_t lane0, bool& is_winner)
 {
 	uint32_t lane = lane0;
 	const bool has_alpha = __ballot(lane < 16u && (tp[lane & 15u] >> 24) != 255u) != 0ull;
@@ -1077,31 +1047,28 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 	const uint32_t iters = quality < 4u ? quality : 4u;
 	const uint32_t wt[4] = {kp.wt[0], kp.wt[1], kp.wt[2], kp.wt[3]};
 
-	Cand best;
-	best.err = 0xFFFFFFFFu;
-	best.id = 0x7FFFFFFFu;
-#pragma unroll
-	for (int k = 0; k < 6; ++k) best.q[k] = 0;
-	best.pb = 0;
-#pragma unroll
-	for (int k = 0; k < 4; ++k) { best.w[k] = 0; best.w2[k] = 0; }
+	uint32_t best_err = 0xFFFFFFFFu, best_id = 0x7FFFFFFFu;   // payload fields: cslot (LDS)
 
-	// ---- pass 0: single-subset modes, 4 lanes per candidate (lane = texel row) ----
-	//   lanes 0..7  : mode 6, row = lane & 3, palette half = lane >> 2
-	//   lanes 8..55 : candidate 1 + (lane-8)/4 (mode 5 x rot, mode 4 x rot x isel), row = lane & 3
+	// ---- pass 0: single-subset modes, one pass; 2 lanes per fit (lane = pair of texel rows) ----
+	//   lanes  0..3  : mode 6, row pair = lane & 1, palette half = lane >> 1
+	//   lanes  4..27 : vector plane of candidate 1 + (lane-4)/2 (mode 5 x rot, mode 4 x rot x isel)
+	//   lanes 28..51 : scalar plane (rotated alpha) of candidate 1 + (lane-28)/2
 	{
-		const uint32_t row = lane & 3u;
-		const bool m6 = lane < 8u;
-		const uint32_t cid = m6 ? 0u : 1u + ((lane - 8u) >> 2);      // candidate id 0..12 (13+: idle)
-		uint32_t rot = 0, isel = 0, cb = 7, abv = 7, absc = 0, pbk = 1, ibc = 4, iba = 0;
+		const uint32_t rp = lane & 1u;
+		const bool m6 = lane < 4u;
+		const bool sca = lane >= 28u;
+		const uint32_t cid = m6 ? 0u : 1u + ((lane - (sca ? 28u : 4u)) >> 1);   // 13+: idle
+		uint32_t rot = 0, cb = 7, ab = 7, pbk = 1, ib = 4;
 		bool active = m6;
 		if (cid >= 1u && cid <= 4u) {
-			rot = cid - 1u; cb = 7; abv = 0; absc = 8; pbk = 0; ibc = 2; iba = 2;
+			rot = cid - 1u; pbk = 0; ib = 2;
+			cb = sca ? 0u : 7u; ab = sca ? 8u : 0u;
 			active = quality >= 2u || (quality == 1u ? cid == 1u : (cid == 1u && has_alpha));
 		} else if (cid >= 5u && cid <= 12u) {
-			rot = (cid - 5u) & 3u; isel = (cid - 5u) >> 2;
-			cb = 5; abv = 0; absc = 6; pbk = 0;
-			ibc = isel ? 3u : 2u; iba = isel ? 2u : 3u;
+			const uint32_t isel = (cid - 5u) >> 2;
+			rot = (cid - 5u) & 3u; pbk = 0;
+			cb = sca ? 0u : 5u; ab = sca ? 6u : 0u;
+			ib = (isel != 0u) == sca ? 2u : 3u;   // isel 0: 2-bit colour / 3-bit alpha indices
 			active = quality >= 2u;
 		} else if (cid > 12u)
 			active = false;
@@ -1114,44 +1081,52 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 		}
 		if (CF_BC7_ABLATE & 1) active = active && m6;
 		if (CF_BC7_ABLATE & 16) active = false;
-		if (active) {   // groups of 4 (mode 6: 8) lanes are active together
+		if (active) {   // the lanes of one candidate (vector + scalar plane) are active together
 			RowFit fv;
-			const uint32_t wv[4] = {wl[0], wl[1], wl[2], abv ? wl[3] : 0u};
-			fit_vec_rows<UNITW, true, 1>(make_tex(tp, pl, rot, abv ? 15u : 7u), 0xFFFFu, row, m6,
-				lane >> 2, cb, abv, pbk, ibc, iters, wv, fv);
+			const bool scal = sca && !m6;
+			const bool vecp = !m6 && !sca;
+			const uint32_t wv[4] = {scal ? 0u : wl[0], scal ? 0u : wl[1], scal ? 0u : wl[2],
+				vecp ? 0u : wl[3]};
+			fit_vec_rows<UNITW, true, 2>(make_tex(tp, pl, rot, m6 ? 15u : (scal ? 8u : 7u)), 0xFFFFu,
+				rp, m6, (lane >> 1) & 1u, cb, ab, pbk, ib, iters, wv, scal, fv);
 			Cand c;
 			c.err = fv.err;
 			c.id = cid;
 			c.q[0] = fv.q0; c.q[1] = fv.q1; c.q[2] = 0; c.q[3] = 0; c.q[4] = 0; c.q[5] = 0;
 			c.pb = fv.pb;
-			const int g0 = (int)(lane & ~3u);
+			const int g0 = (int)(lane & ~1u), gs = (int)((g0 + 24) & 63);
+#pragma unroll
+			for (int k = 0; k < 4; ++k)
+				c.w[k] = (uint32_t)__shfl((int)fv.wrow[k & 1], g0 + (k >> 1), 64);
+			// the scalar plane of this candidate lives 24 lanes up
+			const uint32_t serr = (uint32_t)__shfl((int)fv.err, gs, 64);
+			const uint32_t sq0 = (uint32_t)__shfl((int)fv.q0, gs, 64);
+			const uint32_t sq1 = (uint32_t)__shfl((int)fv.q1, gs, 64);
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
-				c.w[k] = (uint32_t)__shfl((int)fv.wrow[0], g0 + k, 64);
-				c.w2[k] = 0;
+				const uint32_t sw = (uint32_t)__shfl((int)fv.wrow[k & 1], gs + (k >> 1), 64);
+				c.w2[k] = vecp ? sw : 0u;
 			}
-			if (absc) {
-				RowFit fs;
-				fit_scalar_rows<UNITW>(make_tex(tp, pl, rot, 8u), row, absc, iba, iters, wl, fs);
-				c.err += fs.err;
-				c.q[4] = fs.q0 & 0xFF000000u;   // parked for pack_block
-				c.q[5] = fs.q1 & 0xFF000000u;
-#pragma unroll
-				for (int k = 0; k < 4; ++k)
-					c.w2[k] = (uint32_t)__shfl((int)fs.wrow[0], g0 + k, 64);
+			if (vecp) {
+				c.err += serr;
+				c.q[4] = sq0 & 0xFF000000u;   // parked for pack_block
+				c.q[5] = sq1 & 0xFF000000u;
 			}
 			// one lane per candidate registers it
-			if ((m6 ? lane == 0u : row == 0u) && c.err < best.err)
-				best = c;
+			if ((m6 ? lane == 0u : (vecp && rp == 0u)) && c.err < best_err) {
+				best_err = c.err;
+				best_id = c.id;
+				cand_store(cslot, c);
+			}
 		}
 	}
 
 	// A zero-error candidate cannot be beaten (ties go to the lowest id), so the
 	// remaining passes may be skipped without changing the payload.
-	bool solved = __ballot(best.err == 0u) != 0ull;
+	bool solved = __ballot(best_err == 0u) != 0ull;
 
 	// ---- partitioned modes ----
-	if (quality >= 4u && !solved && !(CF_BC7_ABLATE & 32)) {
+	if (EXH && !solved) {
 		// Highest: lane = partition, every partition gets all the refit rounds
 		uint32_t modes, nmodes;
 		if (has_alpha) { modes = 7u; nmodes = 1u; }
@@ -1200,11 +1175,14 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 #pragma unroll
 				for (int k = 0; k < 4; ++k) c.w[k] |= f.w[k];
 			}
-			if (lane < npart && c.err < best.err)
-				best = c;
-			solved = __ballot(best.err == 0u) != 0ull;
+			if (lane < npart && c.err < best_err) {
+				best_err = c.err;
+				best_id = c.id;
+				cand_store(cslot, c);
+			}
+			solved = __ballot(best_err == 0u) != 0ull;
 		}
-	} else if (quality >= 1u && !solved && !(CF_BC7_ABLATE & 64)) {
+	} else if (!EXH && quality >= 1u && !solved) {
 		// Two-phase search.  Phase 1 (lane = partition): score every partition with the
 		// residual estimator -- once per subset count, the score does not depend on the
 		// mode.  Phase 2 (lane = (mode, rank, subset, row pair)): full fit with all refit
@@ -1248,7 +1226,7 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 				const uint32_t npart = (g == 1u && run == 0u) ? 16u : 64u;
 				uint32_t key = lane < npart ? key0 : 0xFFFFFFFFu;
 				for (uint32_t t = 0; t < per; ++t) {
-					const uint32_t kmin = wave_min_u32(key);
+					const uint32_t kmin = cf_wave_min_u32(key);
 					const bool mine = rank == t && (g == 0u || mi == run);
 					mypart = mine ? (kmin & 63u) : mypart;
 					key = key == kmin ? 0xFFFFFFFFu : key;
@@ -1279,7 +1257,7 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 			rf.err = 0; rf.q0 = 0; rf.q1 = 0; rf.pb = 0; rf.wrow[0] = 0; rf.wrow[1] = 0;
 			if (act)
 				fit_vec_rows<UNITW, false, 2>(tx, smask, rp, false, 0u, cb, ab, pbk, ib, iters, wv,
-					rf);
+					false, rf);
 			// gather the partition's subsets into the leader lane (subset 0, row pair 0)
 			const int g0 = (int)(rankall*gl);
 			Cand r2;
@@ -1310,31 +1288,45 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 				}
 			}
 			if (act && sub == 0u && rp == 0u &&
-				(r2.err < best.err || (r2.err == best.err && r2.id < best.id)))
-				best = r2;
-			solved = __ballot(best.err == 0u) != 0ull;
+				(r2.err < best_err || (r2.err == best_err && r2.id < best_id))) {
+				best_err = r2.err;
+				best_id = r2.id;
+				cand_store(cslot, r2);
+			}
+			solved = __ballot(best_err == 0u) != 0ull;
 		}
 	}
 
 	// ---- wave argmin on (error, id); winner packs ----
-	const unsigned long long key = ((unsigned long long)best.err << 32) | best.id;
+	const unsigned long long key = ((unsigned long long)best_err << 32) | best_id;
 	const unsigned long long kmin = cf_wave_min_u64(key);
 	is_winner = key == kmin;
 	uint4 blk = make_uint4(0, 0, 0, 0);
 	if (is_winner)
+	{
+		Cand best;
+		best.err = best_err;
+		best.id = best_id;
+		cand_load(cslot, best);
 		blk = pack_block(best);
+	}
 	return blk;
 }
 
 } // namespace
 
-template <int PIX, bool UNITW>
+// Waves per SIMD the register allocation is held to: the search is a chain of small
+// dependent steps (LDS reads, cross-lane moves, table loads), so occupancy pays more than
+// a roomier register file.  The Highest kernel keeps the per-lane 16-texel fits and needs 3.
 #ifndef CF_BC7_WAVES
-#define CF_BC7_WAVES 3
+#define CF_BC7_WAVES 4
 #endif
-__global__ void __launch_bounds__(CF_WG_THREADS) __attribute__((amdgpu_waves_per_eu(CF_BC7_WAVES, CF_BC7_WAVES)))
+template <int PIX, bool UNITW, bool EXH>
+__global__ void __launch_bounds__(CF_WG_THREADS)
+__attribute__((amdgpu_waves_per_eu(EXH ? 3 : CF_BC7_WAVES, EXH ? 3 : CF_BC7_WAVES)))
 cfhip_bc7_encode_kernel(cf_kparams kp)
 {
+	__shared__ uint32_t cands[CF_BC7_CAND_WORDS*CF_WG_THREADS];
 	__shared__ __attribute__((aligned(16))) uint32_t tile[CF_BLOCKS_PER_WG*16];
 	__shared__ __attribute__((aligned(16))) uint32_t plan[CF_BLOCKS_PER_WG*16];
 	__shared__ uint4 outb[CF_BLOCKS_PER_WG];
@@ -1363,7 +1355,8 @@ cfhip_bc7_encode_kernel(cf_kparams kp)
 		// out of this loop and held in registers across all phases
 		uint32_t ln = lane;
 		asm volatile("" : "+v"(ln));
-		const uint4 blk = encode_block<UNITW>(tile + b*16u, plan + b*16u, kp, ln, win);
+		const uint4 blk = encode_block<UNITW, EXH>(tile + b*16u, plan + b*16u, cands + threadIdx.x,
+			kp, ln, win);
 		if (win)
 			outb[b] = blk;
 	}
@@ -1388,16 +1381,16 @@ extern "C" hipError_t cfhip_launch_bc7(const cf_kparams* kp, int pixel_type, int
 	if (kp->batch)
 		grid = dim3(kp->total_wg, 1, 1);
 	dim3 block(CF_WG_THREADS, 1, 1);
+	const bool exh = kp->quality >= 4u;   // Highest: every partition gets every refit round
+#define CF_BC7_LAUNCH(P, U, E) \
+	hipLaunchKernelGGL((cfhip_bc7_encode_kernel<P, U, E>), grid, block, 0, stream, *kp)
 	if (pixel_type == 0) {
-		if (unit_weights)
-			hipLaunchKernelGGL((cfhip_bc7_encode_kernel<0, true>), grid, block, 0, stream, *kp);
-		else
-			hipLaunchKernelGGL((cfhip_bc7_encode_kernel<0, false>), grid, block, 0, stream, *kp);
+		if (unit_weights) { if (exh) CF_BC7_LAUNCH(0, true, true); else CF_BC7_LAUNCH(0, true, false); }
+		else { if (exh) CF_BC7_LAUNCH(0, false, true); else CF_BC7_LAUNCH(0, false, false); }
 	} else {
-		if (unit_weights)
-			hipLaunchKernelGGL((cfhip_bc7_encode_kernel<1, true>), grid, block, 0, stream, *kp);
-		else
-			hipLaunchKernelGGL((cfhip_bc7_encode_kernel<1, false>), grid, block, 0, stream, *kp);
+		if (unit_weights) { if (exh) CF_BC7_LAUNCH(1, true, true); else CF_BC7_LAUNCH(1, true, false); }
+		else { if (exh) CF_BC7_LAUNCH(1, false, true); else CF_BC7_LAUNCH(1, false, false); }
 	}
+#undef CF_BC7_LAUNCH
 	return hipGetLastError();
 }

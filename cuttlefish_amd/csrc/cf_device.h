@@ -103,15 +103,57 @@ __device__ __forceinline__ void cf_load_tile_rgba8(const cf_kparams& kp, uint32_
 	tile[(col >> 2)*16u + row*4u + (col & 3u)] = (px & kp.keep_mask) | kp.set_mask;
 }
 
-// wave64 argmin of a 64-bit key; every lane gets the minimum.
+// Cross-lane moves on the DPP path (a VALU operand modifier, a few cycles) instead of
+// ds_bpermute (an LDS-crossbar round trip): the searches are chains of small dependent
+// reductions, so shuffle latency is what the wave waits on.  Source lanes must be active.
+//   0xB1 = quad_perm [1,0,3,2] (lane ^ 1)     0x4E = quad_perm [2,3,0,1] (lane ^ 2)
+//   0x141 = row_half_mirror (i -> 7-i in 8)   0x140 = row_mirror (i -> 15-i in 16)
+template <int CTRL>
+__device__ __forceinline__ uint32_t cf_dpp(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t cf_xor1(uint32_t v) { return cf_dpp<0xB1>(v); }
+__device__ __forceinline__ uint32_t cf_xor2(uint32_t v) { return cf_dpp<0x4E>(v); }
+__device__ __forceinline__ float cf_xor1f(float v) { return __uint_as_float(cf_dpp<0xB1>(__float_as_uint(v))); }
+__device__ __forceinline__ float cf_xor2f(float v) { return __uint_as_float(cf_dpp<0x4E>(__float_as_uint(v))); }
+
+// wave64 minimum of a 32-bit key, uniform result (all 64 lanes must be active)
+__device__ __forceinline__ uint32_t cf_wave_min_u32(uint32_t k)
+{
+	uint32_t o;
+	o = cf_dpp<0xB1>(k); k = o < k ? o : k;
+	o = cf_dpp<0x4E>(k); k = o < k ? o : k;
+	o = cf_dpp<0x141>(k); k = o < k ? o : k;
+	o = cf_dpp<0x140>(k); k = o < k ? o : k;
+	// every lane of a row of 16 now holds the row minimum
+	const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)k, 0);
+	const uint32_t r1 = (uint32_t)__builtin_amdgcn_readlane((int)k, 16);
+	const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)k, 32);
+	const uint32_t r3 = (uint32_t)__builtin_amdgcn_readlane((int)k, 48);
+	const uint32_t a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+	return a < b ? a : b;
+}
+
+// wave64 argmin of a 64-bit key; every lane gets the minimum (all lanes active).
 __device__ __forceinline__ unsigned long long cf_wave_min_u64(unsigned long long k)
 {
+#define CF_MIN64_STEP(CTRL) { \
+		const uint32_t lo = cf_dpp<CTRL>((uint32_t)k), hi = cf_dpp<CTRL>((uint32_t)(k >> 32)); \
+		const unsigned long long o = ((unsigned long long)hi << 32) | lo; \
+		k = o < k ? o : k; }
+	CF_MIN64_STEP(0xB1)
+	CF_MIN64_STEP(0x4E)
+	CF_MIN64_STEP(0x141)
+	CF_MIN64_STEP(0x140)
+#undef CF_MIN64_STEP
+	unsigned long long r[4];
 #pragma unroll
-	for (int off = 32; off >= 1; off >>= 1) {
-		const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)k, off, 64);
-		const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(k >> 32), off, 64);
-		const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-		k = o < k ? o : k;
+	for (int i = 0; i < 4; ++i) {
+		const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, 16*i);
+		const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k >> 32), 16*i);
+		r[i] = ((unsigned long long)hi << 32) | lo;
 	}
-	return k;
+	const unsigned long long a = r[0] < r[1] ? r[0] : r[1], b = r[2] < r[3] ? r[2] : r[3];
+	return a < b ? a : b;
 }
