@@ -69,12 +69,6 @@ __device__ const uint8_t k_anchor3b[64] = {
 	15, 3,15,15,15,15,15,15, 15,15,15,15, 3,15,15, 8
 };
 
-// (2^t - 1)/255, folded at compile time exactly like the oracle's expression
-__device__ const float k_sc[9] = {
-	0.0f/255.0f, 1.0f/255.0f, 3.0f/255.0f, 7.0f/255.0f, 15.0f/255.0f,
-	31.0f/255.0f, 63.0f/255.0f, 127.0f/255.0f, 255.0f/255.0f
-};
-
 struct SubFit {
 	uint32_t e0, e1;   // dequantised endpoints, bytes r,g,b,a
 	uint32_t q0, q1;   // quantised fields, bytes r,g,b,a
@@ -137,35 +131,54 @@ __device__ __forceinline__ uint32_t bc7_weight(uint32_t ib, uint32_t k)
 {
 	const uint32_t d = (1u << ib) - 1u;
 	const uint32_t mg = ib == 2u ? 21846u : (ib == 3u ? 9363u : 4370u);
-	return ((k*64u + (d >> 1))*mg) >> 16;
+	return __umul24(k*64u + (d >> 1), mg) >> 16;
+}
+
+// (2^t - 1)/255 for a per-lane t: a select chain on literals instead of a table load
+// (a divergent index would make it a vector memory load on the critical path).
+__device__ __forceinline__ float sc_of(uint32_t t)
+{
+	float r = 0.0f/255.0f;
+	r = t == 4u ? 15.0f/255.0f : r;
+	r = t == 5u ? 31.0f/255.0f : r;
+	r = t == 6u ? 63.0f/255.0f : r;
+	r = t == 7u ? 127.0f/255.0f : r;
+	r = t == 8u ? 255.0f/255.0f : r;
+	return r;
 }
 
 // C: quantise float endpoints.  cb: bits of channels 0..2, ab: bits of channel 3
-// (0 = channel not coded).  pbk: 0 none, 1 per endpoint, 2 shared.
+// (0 = channel not coded).  pbk: 0 none, 1 per endpoint, 2 shared.  All four may differ
+// per lane, so the body is straight-line code: a channel that is not coded has x = 0 and
+// comes out as 0 through the arithmetic (its dequantised p-bit pattern is masked).
 __device__ __forceinline__ void quantize(const float (&x0)[4], const float (&x1)[4], uint32_t cb,
 	uint32_t ab, uint32_t pbk, const float (&fwt)[4], SubFit& f)
 {
 	if (pbk == 0u) {
+		const float scc = sc_of(cb), sca = sc_of(ab);
+		const int qmc = (1 << cb) - 1, qma = (1 << ab) - 1;
+		const uint32_t shc = cb ? cb : 8u, sha = ab ? ab : 8u;   // dequant shifts (value is 0 anyway)
 		uint32_t q0 = 0, q1 = 0, e0 = 0, e1 = 0;
 #pragma unroll
 		for (int c = 0; c < 4; ++c) {
-			const uint32_t t = c < 3 ? cb : ab;
-			if (t) {
-				const float sc = k_sc[t];
-				const int qmax = (1 << t) - 1;
-				int a = (int)floorf(x0[c]*sc + 0.5f);
-				int b = (int)floorf(x1[c]*sc + 0.5f);
-				a = a < 0 ? 0 : (a > qmax ? qmax : a);
-				b = b < 0 ? 0 : (b > qmax ? qmax : b);
-				q0 |= (uint32_t)a << (8*c);
-				q1 |= (uint32_t)b << (8*c);
-				e0 |= dequant((uint32_t)a, t) << (8*c);
-				e1 |= dequant((uint32_t)b, t) << (8*c);
-			}
+			const float sc = c < 3 ? scc : sca;
+			const int qmax = c < 3 ? qmc : qma;
+			const uint32_t t = c < 3 ? shc : sha;
+			int a = (int)floorf(x0[c]*sc + 0.5f);
+			int b = (int)floorf(x1[c]*sc + 0.5f);
+			a = a < 0 ? 0 : (a > qmax ? qmax : a);
+			b = b < 0 ? 0 : (b > qmax ? qmax : b);
+			q0 |= (uint32_t)a << (8*c);
+			q1 |= (uint32_t)b << (8*c);
+			e0 |= dequant((uint32_t)a, t) << (8*c);
+			e1 |= dequant((uint32_t)b, t) << (8*c);
 		}
 		f.q0 = q0; f.q1 = q1; f.e0 = e0; f.e1 = e1; f.pb = 0;
 		return;
 	}
+	const float scc = sc_of(cb + 1u), sca = sc_of(ab + 1u);
+	const int qmc = (1 << cb) - 1, qma = (1 << ab) - 1;
+	const uint32_t amask = ab ? 255u : 0u;
 	// [endpoint][p]
 	uint32_t q[2][2] = {{0, 0}, {0, 0}}, d[2][2] = {{0, 0}, {0, 0}};
 	float er[2][2];
@@ -176,23 +189,22 @@ __device__ __forceinline__ void quantize(const float (&x0)[4], const float (&x1)
 			float acc = 0.0f;
 #pragma unroll
 			for (int c = 0; c < 4; ++c) {
-				const uint32_t bits = c < 3 ? cb : ab;
-				if (bits) {
-					const uint32_t t = bits + 1u;
-					const float xv = e ? x1[c] : x0[c];
-					const float sc = k_sc[t];
-					const float y = xv*sc;
-					const float u = (y - (float)p)*0.5f;
-					int qq = (int)floorf(u + 0.5f);
-					const int qmax = (1 << bits) - 1;
-					qq = qq < 0 ? 0 : (qq > qmax ? qmax : qq);
-					const uint32_t dd = dequant(((uint32_t)qq << 1) | (uint32_t)p, t);
-					const float dx = (float)dd - xv;
-					const float t2 = dx*dx;
-					acc = fmaf(fwt[c], t2, acc);
-					q[e][p] |= (uint32_t)qq << (8*c);
-					d[e][p] |= dd << (8*c);
-				}
+				const uint32_t t = c < 3 ? cb + 1u : (ab ? ab + 1u : 8u);
+				const float sc = c < 3 ? scc : sca;
+				const int qmax = c < 3 ? qmc : qma;
+				const float xv = e ? x1[c] : x0[c];
+				const float y = xv*sc;
+				const float u = (y - (float)p)*0.5f;
+				int qq = (int)floorf(u + 0.5f);
+				qq = qq < 0 ? 0 : (qq > qmax ? qmax : qq);
+				uint32_t dd = dequant(((uint32_t)qq << 1) | (uint32_t)p, t);
+				if (c == 3)
+					dd &= amask;
+				const float dx = (float)dd - xv;
+				const float t2 = dx*dx;
+				acc = fmaf(fwt[c], t2, acc);
+				q[e][p] |= (uint32_t)qq << (8*c);
+				d[e][p] |= dd << (8*c);
 			}
 			er[e][p] = acc;
 		}
@@ -417,11 +429,11 @@ __device__ __forceinline__ void fit_vec(const Tex& tx, uint32_t mask, uint32_t c
 		q23 = __builtin_amdgcn_udot4(M2, P[3], q23, false);
 		q33 = __builtin_amdgcn_udot4(M3, P[3], q33, false);
 	}
-	const float C00 = (float)(int)(n*q00 - s[0]*s[0]), C01 = (float)(int)(n*q01 - s[0]*s[1]);
-	const float C02 = (float)(int)(n*q02 - s[0]*s[2]), C03 = (float)(int)(n*q03 - s[0]*s[3]);
-	const float C11 = (float)(int)(n*q11 - s[1]*s[1]), C12 = (float)(int)(n*q12 - s[1]*s[2]);
-	const float C13 = (float)(int)(n*q13 - s[1]*s[3]), C22 = (float)(int)(n*q22 - s[2]*s[2]);
-	const float C23 = (float)(int)(n*q23 - s[2]*s[3]), C33 = (float)(int)(n*q33 - s[3]*s[3]);
+	const float C00 = (float)(int)(__umul24(n, q00) - __umul24(s[0], s[0])), C01 = (float)(int)(__umul24(n, q01) - __umul24(s[0], s[1]));
+	const float C02 = (float)(int)(__umul24(n, q02) - __umul24(s[0], s[2])), C03 = (float)(int)(__umul24(n, q03) - __umul24(s[0], s[3]));
+	const float C11 = (float)(int)(__umul24(n, q11) - __umul24(s[1], s[1])), C12 = (float)(int)(__umul24(n, q12) - __umul24(s[1], s[2]));
+	const float C13 = (float)(int)(__umul24(n, q13) - __umul24(s[1], s[3])), C22 = (float)(int)(__umul24(n, q22) - __umul24(s[2], s[2]));
+	const float C23 = (float)(int)(__umul24(n, q23) - __umul24(s[2], s[3])), C33 = (float)(int)(__umul24(n, q33) - __umul24(s[3], s[3]));
 
 	// principal axis: C^4 e_amax
 	float bestd = C00;
@@ -529,22 +541,23 @@ __device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t mask, ui
 	const uint32_t nk = m6 ? 8u : (1u << ib), kbase = m6 ? 8u*khalf : 0u;
 	const uint32_t e00 = ub(f.e0, 0), e01 = ub(f.e0, 1), e02 = ub(f.e0, 2), e03 = ub(f.e0, 3);
 	const uint32_t e10 = ub(f.e1, 0), e11 = ub(f.e1, 1), e12 = ub(f.e1, 2), e13 = ub(f.e1, 3);
+	// straight-line palette: entries past this lane's 2^ib get a key that never wins
 	uint32_t pal[8];
 	int base[8];
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
-		pal[k] = 0;
-		base[k] = 0;
-		if ((uint32_t)k < nk) {
-			const uint32_t w = bc7_weight(ib, kbase + (uint32_t)k), iw = 64u - w;
-			const uint32_t c0 = (iw*e00 + w*e10 + 32u) >> 6;
-			const uint32_t c1 = (iw*e01 + w*e11 + 32u) >> 6;
-			const uint32_t c2 = (iw*e02 + w*e12 + 32u) >> 6;
-			const uint32_t c3 = (iw*e03 + w*e13 + 32u) >> 6;
-			pal[k] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-			base[k] = UNITW ? (int)((__builtin_amdgcn_udot4(pal[k], pal[k], 0u, false) << 7) | w)
-				: (int)w;
-		}
+		const uint32_t w = bc7_weight(ib, kbase + (uint32_t)k), iw = 64u - w;
+		const uint32_t c0 = (__umul24(iw, e00) + __umul24(w, e10) + 32u) >> 6;
+		const uint32_t c1 = (__umul24(iw, e01) + __umul24(w, e11) + 32u) >> 6;
+		const uint32_t c2 = (__umul24(iw, e02) + __umul24(w, e12) + 32u) >> 6;
+		const uint32_t c3 = (__umul24(iw, e03) + __umul24(w, e13) + 32u) >> 6;
+		pal[k] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+		const bool valid = (uint32_t)k < nk;
+		if (UNITW)
+			base[k] = valid ? (int)((__builtin_amdgcn_udot4(pal[k], pal[k], 0u, false) << 7) | w)
+				: 0x3FFFFFFF;
+		else
+			base[k] = valid ? (int)w : -1;
 	}
 	uint32_t err = 0;
 	uint32_t S = 0, A = 0, B = 0, C = 0, U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
@@ -567,27 +580,23 @@ __device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t mask, ui
 				int bestk = 0x7FFFFFFF;
 #pragma unroll
 				for (int k = 0; k < 8; ++k) {
-					if ((uint32_t)k < nk) {
-						const int dt = (int)__builtin_amdgcn_udot4(p, pal[k], 0u, false);
-						const int v = base[k] - (dt << 8);
-						bestk = v < bestk ? v : bestk;
-					}
+					const int dt = (int)__builtin_amdgcn_udot4(p, pal[k], 0u, false);
+					const int v = base[k] - (dt << 8);
+					bestk = v < bestk ? v : bestk;
 				}
 				key = (uint32_t)bestk + (__builtin_amdgcn_udot4(p, p, 0u, false) << 7);
 			} else {
 				key = 0xFFFFFFFFu;
 #pragma unroll
 				for (int k = 0; k < 8; ++k) {
-					if ((uint32_t)k < nk) {
-						const int d0 = (int)ub(p, 0) - (int)ub(pal[k], 0);
-						const int d1 = (int)ub(p, 1) - (int)ub(pal[k], 1);
-						const int d2 = (int)ub(p, 2) - (int)ub(pal[k], 2);
-						const int d3 = (int)ub(p, 3) - (int)ub(pal[k], 3);
-						const uint32_t dist = wt[0]*(uint32_t)(d0*d0) + wt[1]*(uint32_t)(d1*d1) +
-							wt[2]*(uint32_t)(d2*d2) + wt[3]*(uint32_t)(d3*d3);
-						const uint32_t v = (dist << 7) | (uint32_t)base[k];
-						key = v < key ? v : key;
-					}
+					const int d0 = (int)ub(p, 0) - (int)ub(pal[k], 0);
+					const int d1 = (int)ub(p, 1) - (int)ub(pal[k], 1);
+					const int d2 = (int)ub(p, 2) - (int)ub(pal[k], 2);
+					const int d3 = (int)ub(p, 3) - (int)ub(pal[k], 3);
+					const uint32_t dist = wt[0]*(uint32_t)(d0*d0) + wt[1]*(uint32_t)(d1*d1) +
+						wt[2]*(uint32_t)(d2*d2) + wt[3]*(uint32_t)(d3*d3);
+					const uint32_t v = (dist << 7) | (uint32_t)base[k];   // invalid: 0xFFFFFFFF
+					key = v < key ? v : key;
 				}
 			}
 			if (ROT) {
@@ -683,11 +692,11 @@ __device__ __forceinline__ void fit_vec_rows(const Tex& tx, uint32_t mask, uint3
 		q33 = __builtin_amdgcn_udot4(M3, P[3], q33, false);
 	}
 	const uint32_t n = (uint32_t)__builtin_popcount(mask);
-	const float C00 = (float)(int)(n*q00 - s[0]*s[0]), C01 = (float)(int)(n*q01 - s[0]*s[1]);
-	const float C02 = (float)(int)(n*q02 - s[0]*s[2]), C03 = (float)(int)(n*q03 - s[0]*s[3]);
-	const float C11 = (float)(int)(n*q11 - s[1]*s[1]), C12 = (float)(int)(n*q12 - s[1]*s[2]);
-	const float C13 = (float)(int)(n*q13 - s[1]*s[3]), C22 = (float)(int)(n*q22 - s[2]*s[2]);
-	const float C23 = (float)(int)(n*q23 - s[2]*s[3]), C33 = (float)(int)(n*q33 - s[3]*s[3]);
+	const float C00 = (float)(int)(__umul24(n, q00) - __umul24(s[0], s[0])), C01 = (float)(int)(__umul24(n, q01) - __umul24(s[0], s[1]));
+	const float C02 = (float)(int)(__umul24(n, q02) - __umul24(s[0], s[2])), C03 = (float)(int)(__umul24(n, q03) - __umul24(s[0], s[3]));
+	const float C11 = (float)(int)(__umul24(n, q11) - __umul24(s[1], s[1])), C12 = (float)(int)(__umul24(n, q12) - __umul24(s[1], s[2]));
+	const float C13 = (float)(int)(__umul24(n, q13) - __umul24(s[1], s[3])), C22 = (float)(int)(__umul24(n, q22) - __umul24(s[2], s[2]));
+	const float C23 = (float)(int)(__umul24(n, q23) - __umul24(s[2], s[3])), C33 = (float)(int)(__umul24(n, q33) - __umul24(s[3], s[3]));
 
 	float bestd = C00;
 	float v0 = C00, v1 = C01, v2 = C02, v3 = C03;
@@ -985,11 +994,11 @@ __device__ __forceinline__ float subset_residual(const Tex& tx, uint32_t mask)
 		q23 = __builtin_amdgcn_udot4(M2, P[3], q23, false);
 		q33 = __builtin_amdgcn_udot4(M3, P[3], q33, false);
 	}
-	const float C00 = (float)(int)(n*q00 - s[0]*s[0]), C01 = (float)(int)(n*q01 - s[0]*s[1]);
-	const float C02 = (float)(int)(n*q02 - s[0]*s[2]), C03 = (float)(int)(n*q03 - s[0]*s[3]);
-	const float C11 = (float)(int)(n*q11 - s[1]*s[1]), C12 = (float)(int)(n*q12 - s[1]*s[2]);
-	const float C13 = (float)(int)(n*q13 - s[1]*s[3]), C22 = (float)(int)(n*q22 - s[2]*s[2]);
-	const float C23 = (float)(int)(n*q23 - s[2]*s[3]), C33 = (float)(int)(n*q33 - s[3]*s[3]);
+	const float C00 = (float)(int)(__umul24(n, q00) - __umul24(s[0], s[0])), C01 = (float)(int)(__umul24(n, q01) - __umul24(s[0], s[1]));
+	const float C02 = (float)(int)(__umul24(n, q02) - __umul24(s[0], s[2])), C03 = (float)(int)(__umul24(n, q03) - __umul24(s[0], s[3]));
+	const float C11 = (float)(int)(__umul24(n, q11) - __umul24(s[1], s[1])), C12 = (float)(int)(__umul24(n, q12) - __umul24(s[1], s[2]));
+	const float C13 = (float)(int)(__umul24(n, q13) - __umul24(s[1], s[3])), C22 = (float)(int)(__umul24(n, q22) - __umul24(s[2], s[2]));
+	const float C23 = (float)(int)(__umul24(n, q23) - __umul24(s[2], s[3])), C33 = (float)(int)(__umul24(n, q33) - __umul24(s[3], s[3]));
 	float bestd = C00;
 	float v0 = C00, v1 = C01, v2 = C02, v3 = C03;
 	if (C11 > bestd) { bestd = C11; v0 = C01; v1 = C11; v2 = C12; v3 = C13; }
