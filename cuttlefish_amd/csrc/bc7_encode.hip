@@ -511,31 +511,23 @@ __device__ __forceinline__ void fit_vec(const Tex& tx, uint32_t mask, uint32_t c
 }
 
 // ---------------------------------------------------------------------------
-// Row-split fits for the single-subset pass: one candidate is spread over 4 lanes
-// (lane = texel row), mode 6 additionally over 2 palette halves (lane ^ 4).  Sums
-// are integers, so the 4-lane reductions are exact and every lane of a group
-// continues with identical values; min/max of floats are exact as well.  This is
-// the same arithmetic as fit_vec/fit_scalar, only distributed differently.
+// One fit per lane.  Every VALU instruction costs the wave the same issue time whatever
+// the number of active lanes (tools/ubench/valu_rate.hip: 4 cycles per integer
+// wave-instruction, 2 for fp32 fma/mul/add), so the cheapest schedule is the one where
+// every lane carries a different fit through ONE instruction stream: all of mode, rotation,
+// channel set, endpoint precision, p-bit kind, index width and subset mask are per-lane
+// values here.  Mode 6 alone is spread over a lane pair (16 palette entries, 8 per lane;
+// the per-texel keys meet through a DPP lane^1 exchange).  Same arithmetic as
+// fit_vec/assign_lsq (the oracle's fit_subset / fit_scalar).
 
-struct RowFit {
+struct LaneFit {
 	uint32_t e0, e1, q0, q1, pb, err;
-	uint32_t wrow[2];       // weights of this lane's row(s)
+	uint32_t w[4];          // weights per texel (bytes), 0 outside the subset
 };
 
-// exact sum over the lanes that share one fit: 4 lanes with one texel row each (R = 1)
-// or 2 lanes with two rows each (R = 2)
-template <int R>
-__device__ __forceinline__ uint32_t group_sum(uint32_t v)
-{
-	v += cf_xor1(v);
-	if (R == 1)
-		v += cf_xor2(v);
-	return v;
-}
-
-template <bool UNITW, bool ROT, int R>
-__device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t mask, uint32_t row, bool m6,
-	uint32_t khalf, uint32_t ib, const uint32_t (&wt)[4], bool want_lsq, RowFit& f,
+template <bool UNITW>
+__device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bool m6,
+	uint32_t khalf, uint32_t ib, const uint32_t (&wt)[4], bool want_lsq, LaneFit& f,
 	float (&nx0)[4], float (&nx1)[4], bool& ok)
 {
 	const uint32_t nk = m6 ? 8u : (1u << ib), kbase = m6 ? 8u*khalf : 0u;
@@ -561,27 +553,23 @@ __device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t mask, ui
 	}
 	uint32_t err = 0;
 	uint32_t S = 0, A = 0, B = 0, C = 0, U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
-	uint32_t wprev = 0, wlast = 0;
+	uint32_t wp0 = 0, wp1 = 0, wp2 = 0, wp3 = 0;
 #pragma unroll 1
-	for (uint32_t rr = 0; rr < (uint32_t)R; ++rr) {
-		uint32_t r = (uint32_t)R*row + rr;
-		// opaque to the optimiser: the texel loads below are invariant across refit rounds
-		// and would otherwise be hoisted (with all their unpacked forms) out of the round loop
-		asm volatile("" : "+v"(r));
+	for (uint32_t r = 0; r < 4u; ++r) {
 		const uint4 rw = *reinterpret_cast<const uint4*>(tx.tp + 4u*r);
 		const uint32_t raw[4] = {rw.x, rw.y, rw.z, rw.w};
 		const uint32_t mrow = (mask >> (4u*r)) & 15u;
 		uint32_t wrow = 0;
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
-			const uint32_t p = texel<ROT>(tx, raw[j]);
+			const uint32_t p = texel<true>(tx, raw[j]);
 			uint32_t key;
 			if (UNITW) {
 				int bestk = 0x7FFFFFFF;
 #pragma unroll
 				for (int k = 0; k < 8; ++k) {
 					const int dt = (int)__builtin_amdgcn_udot4(p, pal[k], 0u, false);
-					const int v = base[k] - (dt << 8);
+					const int v = __mul24(dt, -256) + base[k];
 					bestk = v < bestk ? v : bestk;
 				}
 				key = (uint32_t)bestk + (__builtin_amdgcn_udot4(p, p, 0u, false) << 7);
@@ -599,22 +587,18 @@ __device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t mask, ui
 					key = v < key ? v : key;
 				}
 			}
-			if (ROT) {
-				// mode 6 (single-subset pass only): the other palette half lives in the
-				// neighbouring lane group
-				const uint32_t other = R == 1 ? (uint32_t)__shfl_xor((int)key, 4, 64) : cf_xor2(key);
-				key = (m6 && other < key) ? other : key;
-			}
+			// mode 6: the other palette half lives in the neighbouring lane
+			const uint32_t other = cf_xor1(key);
+			key = (m6 && other < key) ? other : key;
 			const bool m = (mrow >> j) & 1u;
 			err += m ? (key >> 7) : 0u;
 			wrow |= (m ? (key & 127u) : 0u) << (8*j);
 		}
-		wprev = wlast;
-		wlast = wrow;
-		if (want_lsq) {
+		wp0 = wp1; wp1 = wp2; wp2 = wp3; wp3 = wrow;
+		if (want_lsq) {   // uniform: the last round's refit would never be used
 			const uint32_t iwrow = (0x40404040u - wrow) & bytemask4(mrow);
 			uint32_t P[4];
-			planes<ROT>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
+			planes<true>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
 			S = __builtin_amdgcn_udot4(wrow, 0x01010101u, S, false);
 			A = __builtin_amdgcn_udot4(iwrow, iwrow, A, false);
 			B = __builtin_amdgcn_udot4(iwrow, wrow, B, false);
@@ -626,21 +610,9 @@ __device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t mask, ui
 			}
 		}
 	}
-	f.wrow[0] = R == 1 ? wlast : wprev;
-	f.wrow[1] = R == 1 ? 0u : wlast;
-	f.err = group_sum<R>(err);
-	if (want_lsq) {
-		S = group_sum<R>(S);
-		A = group_sum<R>(A);
-		B = group_sum<R>(B);
-		C = group_sum<R>(C);
-#pragma unroll
-		for (int c = 0; c < 4; ++c) {
-			U[c] = group_sum<R>(U[c]);
-			V[c] = group_sum<R>(V[c]);
-		}
-	}
-	const int det = (int)((uint32_t)__builtin_popcount(mask)*C) - (int)(S*S);
+	f.err = err;
+	f.w[0] = wp0; f.w[1] = wp1; f.w[2] = wp2; f.w[3] = wp3;
+	const int det = (int)__umul24((uint32_t)__builtin_popcount(mask), C) - (int)__umul24(S, S);
 	ok = det > 0;
 	const float inv = 1.0f/(64.0f*(float)(det > 0 ? det : 1));
 	const float fA = (float)A, fB = (float)B, fC = (float)C;
@@ -661,19 +633,31 @@ __device__ __forceinline__ void assign_lsq_rows(const Tex& tx, uint32_t mask, ui
 	}
 }
 
-template <bool UNITW, bool ROT, int R>
-__device__ __forceinline__ void fit_vec_rows(const Tex& tx, uint32_t mask, uint32_t row, bool m6,
-	uint32_t khalf, uint32_t cb, uint32_t ab, uint32_t pbk, uint32_t ib, uint32_t iters,
-	const uint32_t (&wt)[4], bool scalar, RowFit& best)
+// scalar: the fit codes only the rotated alpha channel (modes 4/5 second plane); its start
+// endpoints are the exact extremes of that channel (oracle: fit_scalar).
+template <bool UNITW>
+__device__ __forceinline__ void fit_lane(const Tex& tx, uint32_t mask, bool m6, uint32_t khalf,
+	uint32_t cb, uint32_t ab, uint32_t pbk, uint32_t ib, uint32_t iters, const uint32_t (&wt)[4],
+	bool scalar, LaneFit& best)
 {
-	// A: statistics of the subset (every lane of the group computes them)
+	// A: statistics of the subset + extremes of the (rotated) alpha channel
+	const uint32_t n = (uint32_t)__builtin_popcount(mask);
 	uint32_t s[4] = {0, 0, 0, 0};
 	uint32_t q00 = 0, q01 = 0, q02 = 0, q03 = 0, q11 = 0, q12 = 0, q13 = 0, q22 = 0, q23 = 0,
 		q33 = 0;
+	uint32_t lo = 255u, hi = 0u;
 #pragma unroll 1
 	for (uint32_t r = 0; r < 4u; ++r) {
 		uint32_t P[4];
-		planes<ROT>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
+		const uint4 pr = *reinterpret_cast<const uint4*>(tx.pl + 4u*r);
+		planes<true>(tx, pr, P);
+		const uint32_t a4 = tx.rot == 0u ? pr.w : (tx.rot == 1u ? pr.x : (tx.rot == 2u ? pr.y : pr.z));
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const uint32_t a = (a4 >> (8*j)) & 255u;
+			lo = a < lo ? a : lo;
+			hi = a > hi ? a : hi;
+		}
 		const uint32_t m4 = bytemask4((mask >> (4u*r)) & 15u);
 		const uint32_t M0 = P[0] & m4, M1 = P[1] & m4, M2 = P[2] & m4, M3 = P[3] & m4;
 		s[0] = __builtin_amdgcn_udot4(M0, 0x01010101u, s[0], false);
@@ -691,7 +675,6 @@ __device__ __forceinline__ void fit_vec_rows(const Tex& tx, uint32_t mask, uint3
 		q23 = __builtin_amdgcn_udot4(M2, P[3], q23, false);
 		q33 = __builtin_amdgcn_udot4(M3, P[3], q33, false);
 	}
-	const uint32_t n = (uint32_t)__builtin_popcount(mask);
 	const float C00 = (float)(int)(__umul24(n, q00) - __umul24(s[0], s[0])), C01 = (float)(int)(__umul24(n, q01) - __umul24(s[0], s[1]));
 	const float C02 = (float)(int)(__umul24(n, q02) - __umul24(s[0], s[2])), C03 = (float)(int)(__umul24(n, q03) - __umul24(s[0], s[3]));
 	const float C11 = (float)(int)(__umul24(n, q11) - __umul24(s[1], s[1])), C12 = (float)(int)(__umul24(n, q12) - __umul24(s[1], s[2]));
@@ -724,37 +707,28 @@ __device__ __forceinline__ void fit_vec_rows(const Tex& tx, uint32_t mask, uint3
 		axis[0] = v0*is; axis[1] = v1*is; axis[2] = v2*is; axis[3] = v3*is;
 	}
 
-	// B: projection extremes: own row, then exact min/max over the 4 lanes
+	// B: extremes of the projection on the axis
 	const float in = 1.0f/(float)n;
 	float mean[4];
 #pragma unroll
 	for (int c = 0; c < 4; ++c)
 		mean[c] = (float)s[c]*in;
 	float tmin = 3.0e38f, tmax = -3.0e38f;
-	{
+#pragma unroll 1
+	for (uint32_t r = 0; r < 4u; ++r) {
+		const uint4 rw = *reinterpret_cast<const uint4*>(tx.tp + 4u*r);
+		const uint32_t raw[4] = {rw.x, rw.y, rw.z, rw.w};
+		const uint32_t mrow = (mask >> (4u*r)) & 15u;
 #pragma unroll
-		for (int rr = 0; rr < R; ++rr) {
-			const uint32_t r = (uint32_t)R*row + (uint32_t)rr;
-			const uint4 rw = *reinterpret_cast<const uint4*>(tx.tp + 4u*r);
-			const uint32_t raw[4] = {rw.x, rw.y, rw.z, rw.w};
-			const uint32_t mrow = (mask >> (4u*r)) & 15u;
-#pragma unroll
-			for (int j = 0; j < 4; ++j) {
-				const uint32_t p = texel<ROT>(tx, raw[j]);
-				const bool m = (mrow >> j) & 1u;
-				float t = axis[0]*(fb(p, 0) - mean[0]);
-				t = fmaf(axis[1], fb(p, 1) - mean[1], t);
-				t = fmaf(axis[2], fb(p, 2) - mean[2], t);
-				t = fmaf(axis[3], fb(p, 3) - mean[3], t);
-				tmin = m ? fminf(tmin, t) : tmin;
-				tmax = m ? fmaxf(tmax, t) : tmax;
-			}
-		}
-		tmin = fminf(tmin, cf_xor1f(tmin));
-		tmax = fmaxf(tmax, cf_xor1f(tmax));
-		if (R == 1) {
-			tmin = fminf(tmin, cf_xor2f(tmin));
-			tmax = fmaxf(tmax, cf_xor2f(tmax));
+		for (int j = 0; j < 4; ++j) {
+			const uint32_t p = texel<true>(tx, raw[j]);
+			const bool m = (mrow >> j) & 1u;
+			float t = axis[0]*(fb(p, 0) - mean[0]);
+			t = fmaf(axis[1], fb(p, 1) - mean[1], t);
+			t = fmaf(axis[2], fb(p, 2) - mean[2], t);
+			t = fmaf(axis[3], fb(p, 3) - mean[3], t);
+			tmin = m ? fminf(tmin, t) : tmin;
+			tmax = m ? fmaxf(tmax, t) : tmax;
 		}
 	}
 	float x0[4], x1[4];
@@ -763,32 +737,9 @@ __device__ __forceinline__ void fit_vec_rows(const Tex& tx, uint32_t mask, uint3
 		x0[c] = clamp255(fmaf(axis[c], tmin, mean[c]));
 		x1[c] = clamp255(fmaf(axis[c], tmax, mean[c]));
 	}
-	if (ROT) {
-		// scalar plane of modes 4/5 (only the rotated alpha channel is coded): the start
-		// endpoints are the exact extremes of that channel (oracle: fit_scalar)
-		uint32_t lo = 255u, hi = 0u;
-#pragma unroll
-		for (int rr = 0; rr < R; ++rr) {
-			const uint4 pr = *reinterpret_cast<const uint4*>(tx.pl + 4u*((uint32_t)R*row + (uint32_t)rr));
-			const uint32_t a4 = tx.rot == 0u ? pr.w : (tx.rot == 1u ? pr.x : (tx.rot == 2u ? pr.y : pr.z));
-#pragma unroll
-			for (int j = 0; j < 4; ++j) {
-				const uint32_t a = (a4 >> (8*j)) & 255u;
-				lo = a < lo ? a : lo;
-				hi = a > hi ? a : hi;
-			}
-		}
-		uint32_t o;
-		o = cf_xor1(lo); lo = o < lo ? o : lo;
-		o = cf_xor1(hi); hi = o > hi ? o : hi;
-		if (R == 1) {
-			o = cf_xor2(lo); lo = o < lo ? o : lo;
-			o = cf_xor2(hi); hi = o > hi ? o : hi;
-		}
-		if (scalar) {
-			x0[0] = 0.0f; x0[1] = 0.0f; x0[2] = 0.0f; x0[3] = (float)lo;
-			x1[0] = 0.0f; x1[1] = 0.0f; x1[2] = 0.0f; x1[3] = (float)hi;
-		}
+	if (scalar) {
+		x0[0] = 0.0f; x0[1] = 0.0f; x0[2] = 0.0f; x0[3] = (float)lo;
+		x1[0] = 0.0f; x1[1] = 0.0f; x1[2] = 0.0f; x1[3] = (float)hi;
 	}
 	float fwt[4];
 #pragma unroll
@@ -802,14 +753,13 @@ __device__ __forceinline__ void fit_vec_rows(const Tex& tx, uint32_t mask, uint3
 	quantize(x0, x1, cb, ab, pbk, fwt, q);
 	best.e0 = q.e0; best.e1 = q.e1; best.q0 = q.q0; best.q1 = q.q1; best.pb = q.pb;
 	bool live;
-	assign_lsq_rows<UNITW, ROT, R>(tx, mask, row, m6, khalf, ib, wt, iters > 0u, best, x0, x1, live);
+	assign_lsq_lane<UNITW>(tx, mask, m6, khalf, ib, wt, iters > 0u, best, x0, x1, live);
 	for (uint32_t r = 0; r < iters; ++r) {
-		RowFit cur;
+		LaneFit cur;
 		bool ok;
 		quantize(x0, x1, cb, ab, pbk, fwt, q);
 		cur.e0 = q.e0; cur.e1 = q.e1; cur.q0 = q.q0; cur.q1 = q.q1; cur.pb = q.pb;
-		assign_lsq_rows<UNITW, ROT, R>(tx, mask, row, m6, khalf, ib, wt, r + 1u < iters, cur, x0, x1,
-			ok);
+		assign_lsq_lane<UNITW>(tx, mask, m6, khalf, ib, wt, r + 1u < iters, cur, x0, x1, ok);
 		const bool better = live && cur.err < best.err;
 		if (better)
 			best = cur;
@@ -1058,83 +1008,182 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 
 	uint32_t best_err = 0xFFFFFFFFu, best_id = 0x7FFFFFFFu;   // payload fields: cslot (LDS)
 
-	// ---- pass 0: single-subset modes, one pass; 2 lanes per fit (lane = pair of texel rows) ----
-	//   lanes  0..3  : mode 6, row pair = lane & 1, palette half = lane >> 1
-	//   lanes  4..27 : vector plane of candidate 1 + (lane-4)/2 (mode 5 x rot, mode 4 x rot x isel)
-	//   lanes 28..51 : scalar plane (rotated alpha) of candidate 1 + (lane-28)/2
+	// ---- fit streams: one fit per lane (fit_lane) ----
+	// stream 0:  lanes  0..1  : mode 6, palette half = lane
+	//            lanes  2..13 : vector plane of candidate 1 + (lane-2) (mode 5 x rot, mode 4 x rot x isel)
+	//            lanes 14..25 : scalar plane (rotated alpha) of candidate 1 + (lane-14)
+	//            lanes 26..57 : two-subset partitions, 16 x 2 subsets: modes 1 + 3 with their
+	//                           8 best partitions each, or one mode (1 below Normal, 7 for
+	//                           blocks with alpha) with its 16 best
+	// stream 1 (Production and up, opaque blocks):
+	//            lanes  0..29 : three-subset partitions, modes 0 + 2 with 5 partitions each
+	// The partitions come from phase 1 (lane = partition): every partition is scored once per
+	// subset count with the residual estimator and the best are taken in (score, index) order.
+	// Highest instead refits every partition (below), after a stream 0 without partitions.
+	bool solved = false;
 	{
-		const uint32_t rp = lane & 1u;
-		const bool m6 = lane < 4u;
-		const bool sca = lane >= 28u;
-		const uint32_t cid = m6 ? 0u : 1u + ((lane - (sca ? 28u : 4u)) >> 1);   // 13+: idle
-		uint32_t rot = 0, cb = 7, ab = 7, pbk = 1, ib = 4;
-		bool active = m6;
-		if (cid >= 1u && cid <= 4u) {
-			rot = cid - 1u; pbk = 0; ib = 2;
-			cb = sca ? 0u : 7u; ab = sca ? 8u : 0u;
-			active = quality >= 2u || (quality == 1u ? cid == 1u : (cid == 1u && has_alpha));
-		} else if (cid >= 5u && cid <= 12u) {
-			const uint32_t isel = (cid - 5u) >> 2;
-			rot = (cid - 5u) & 3u; pbk = 0;
-			cb = sca ? 0u : 5u; ab = sca ? 6u : 0u;
-			ib = (isel != 0u) == sca ? 2u : 3u;   // isel 0: 2-bit colour / 3-bit alpha indices
-			active = quality >= 2u;
-		} else if (cid > 12u)
-			active = false;
-		uint32_t wl[4] = {wt[0], wt[1], wt[2], wt[3]};
-		if (!UNITW && rot) {
-			const uint32_t t3 = wl[3];
-			if (rot == 1u) { wl[3] = wl[0]; wl[0] = t3; }
-			else if (rot == 2u) { wl[3] = wl[1]; wl[1] = t3; }
-			else { wl[3] = wl[2]; wl[2] = t3; }
-		}
-		if (CF_BC7_ABLATE & 1) active = active && m6;
-		if (CF_BC7_ABLATE & 16) active = false;
-		if (active) {   // the lanes of one candidate (vector + scalar plane) are active together
-			RowFit fv;
-			const bool scal = sca && !m6;
-			const bool vecp = !m6 && !sca;
-			const uint32_t wv[4] = {scal ? 0u : wl[0], scal ? 0u : wl[1], scal ? 0u : wl[2],
-				vecp ? 0u : wl[3]};
-			fit_vec_rows<UNITW, true, 2>(make_tex(tp, pl, rot, m6 ? 15u : (scal ? 8u : 7u)), 0xFFFFu,
-				rp, m6, (lane >> 1) & 1u, cb, ab, pbk, ib, iters, wv, scal, fv);
-			Cand c;
-			c.err = fv.err;
-			c.id = cid;
-			c.q[0] = fv.q0; c.q[1] = fv.q1; c.q[2] = 0; c.q[3] = 0; c.q[4] = 0; c.q[5] = 0;
-			c.pb = fv.pb;
-			const int g0 = (int)(lane & ~1u), gs = (int)((g0 + 24) & 63);
+		const uint32_t nstreams = (!EXH && !has_alpha && quality >= 3u) ? 2u : 1u;
+		const Tex txp = make_tex(tp, pl, 0u, has_alpha ? 15u : 7u);   // partition fits: no rotation
+#pragma unroll 1
+		for (uint32_t st = 0; st < nstreams && !solved; ++st) {
+			asm volatile("" : "+v"(lane));   // roles are recomputed per stream, not kept
+			const uint32_t ns = 2u + st;
+			const bool parts = !EXH && quality >= 1u;
+			// ---- phase 1: partition scores and selection ----
+			const bool twomodes = st == 1u || (!has_alpha && quality >= 2u);
+			const uint32_t per = st == 1u ? 5u : (twomodes ? 8u : 16u);   // partitions per mode
+			const uint32_t pl0 = st == 1u ? 0u : 26u;                     // first partition lane
+			const uint32_t pidx = lane - pl0;                             // wraps for lanes below pl0
+			const uint32_t rankall = st == 1u ? pidx/3u : pidx >> 1;
+			const uint32_t sub = pidx - rankall*ns;
+			const bool plane = parts && lane >= pl0 && rankall < (twomodes ? 2u*per : per);
+			const uint32_t mi = (twomodes && rankall >= per) ? 1u : 0u;
+			const uint32_t rank = rankall - mi*per;
+			uint32_t mypart = 0;
+			if (parts) {
+				const uint32_t p2 = k_part2[lane], p3 = k_part3[lane];
+				float sc = 0.0f;
+				for (uint32_t sb = 0; sb < ns; ++sb) {
+					uint32_t mask;
+					if (st == 0u)
+						mask = sb ? p2 : (~p2 & 0xFFFFu);
+					else {
+						mask = 0;
 #pragma unroll
-			for (int k = 0; k < 4; ++k)
-				c.w[k] = (uint32_t)__shfl((int)fv.wrow[k & 1], g0 + (k >> 1), 64);
-			// the scalar plane of this candidate lives 24 lanes up
-			const uint32_t serr = (uint32_t)__shfl((int)fv.err, gs, 64);
-			const uint32_t sq0 = (uint32_t)__shfl((int)fv.q0, gs, 64);
-			const uint32_t sq1 = (uint32_t)__shfl((int)fv.q1, gs, 64);
+						for (int i = 0; i < 16; ++i)
+							mask |= (((p3 >> (2*i)) & 3u) == sb ? 1u : 0u) << i;
+					}
+					sc = sc + subset_residual(txp, mask);
+				}
+				const uint32_t key0 = (__float_as_uint(sc) & ~63u) | lane;
+				const uint32_t nruns = st == 1u ? 2u : 1u;   // mode 0 ranks its own 16 partitions
+				for (uint32_t run = 0; run < nruns; ++run) {
+					const uint32_t npart = (st == 1u && run == 0u) ? 16u : 64u;
+					uint32_t key = lane < npart ? key0 : 0xFFFFFFFFu;
+					for (uint32_t t = 0; t < per; ++t) {
+						const uint32_t kmin = cf_wave_min_u32(key);
+						const bool mine = rank == t && (st == 0u || mi == run);
+						mypart = mine ? (kmin & 63u) : mypart;
+						key = key == kmin ? 0xFFFFFFFFu : key;
+					}
+				}
+			}
+			// ---- lane roles ----
+			const bool m6 = st == 0u && lane < 2u;
+			const bool sca = st == 0u && lane >= 14u && lane < 26u;
+			const bool vecp = st == 0u && lane >= 2u && lane < 14u;
+			const uint32_t cid = m6 ? 0u : 1u + (lane - (sca ? 14u : 2u));   // meaningful for vecp / sca
+			uint32_t rot = 0, cb = 7, ab = 7, pbk = 1, ib = 4, idbase = 0, mask = 0xFFFFu;
+			bool active = m6;
+			if (vecp || sca) {
+				if (cid <= 4u) {
+					rot = cid - 1u; pbk = 0; ib = 2;
+					cb = sca ? 0u : 7u; ab = sca ? 8u : 0u;
+					active = quality >= 2u || (quality == 1u ? cid == 1u : (cid == 1u && has_alpha));
+				} else {
+					const uint32_t isel = (cid - 5u) >> 2;
+					rot = (cid - 5u) & 3u; pbk = 0;
+					cb = sca ? 0u : 5u; ab = sca ? 6u : 0u;
+					ib = (isel != 0u) == sca ? 2u : 3u;   // isel 0: 2-bit colour / 3-bit alpha indices
+					active = quality >= 2u;
+				}
+			} else if (plane) {
+				uint32_t mode;
+				if (st == 1u) mode = mi ? 2u : 0u;
+				else mode = has_alpha ? 7u : (mi ? 3u : 1u);
+				switch (mode) {
+					case 1: cb = 6; ab = 0; pbk = 2; ib = 3; idbase = 64; break;
+					case 3: cb = 7; ab = 0; pbk = 1; ib = 2; idbase = 128; break;
+					case 0: cb = 4; ab = 0; pbk = 1; ib = 3; idbase = 192; break;
+					case 2: cb = 5; ab = 0; pbk = 0; ib = 2; idbase = 256; break;
+					default: cb = 5; ab = 5; pbk = 1; ib = 2; idbase = 320; break;
+				}
+				const uint32_t sp2 = k_part2[mypart], sp3 = k_part3[mypart];
+				if (st == 0u)
+					mask = sub ? sp2 : (~sp2 & 0xFFFFu);
+				else {
+					mask = 0;
+#pragma unroll
+					for (int i = 0; i < 16; ++i)
+						mask |= (((sp3 >> (2*i)) & 3u) == sub ? 1u : 0u) << i;
+				}
+				active = true;
+			}
+			if (CF_BC7_ABLATE & 1) active = active && (m6 || plane);
+			if (CF_BC7_ABLATE & 2) active = active && !plane;
+			uint32_t wl[4] = {wt[0], wt[1], wt[2], wt[3]};
+			if (!UNITW && rot) {
+				const uint32_t t3 = wl[3];
+				if (rot == 1u) { wl[3] = wl[0]; wl[0] = t3; }
+				else if (rot == 2u) { wl[3] = wl[1]; wl[1] = t3; }
+				else { wl[3] = wl[2]; wl[2] = t3; }
+			}
+			// channels this fit codes (after rotation) and their weights
+			const uint32_t chm = m6 ? 15u : (sca ? 8u : (vecp ? 7u : (has_alpha ? 15u : 7u)));
+			const uint32_t wv[4] = {(chm & 1u) ? wl[0] : 0u, (chm & 2u) ? wl[1] : 0u,
+				(chm & 4u) ? wl[2] : 0u, (chm & 8u) ? wl[3] : 0u};
+			LaneFit lf;
+			lf.err = 0; lf.q0 = 0; lf.q1 = 0; lf.pb = 0; lf.e0 = 0; lf.e1 = 0;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) lf.w[k] = 0;
+			if (active)
+				fit_lane<UNITW>(make_tex(tp, pl, rot, chm), mask, m6, lane & 1u, cb, ab, pbk, ib, iters,
+					wv, sca, lf);
+			// ---- assemble candidates in their leader lanes ----
+			//   mode 6: lane 0;  mode 4/5: vector lane (scalar plane 12 lanes up);
+			//   partitions: subset-0 lane (the other subsets in the next lanes)
+			const int s1 = (int)((lane + 1u) & 63u);
+			const int s2 = (int)((lane + (st == 0u ? 12u : 2u)) & 63u);
+			const uint32_t e1 = (uint32_t)__shfl((int)lf.err, s1, 64), e2 = (uint32_t)__shfl((int)lf.err, s2, 64);
+			const uint32_t a01 = (uint32_t)__shfl((int)lf.q0, s1, 64), a02 = (uint32_t)__shfl((int)lf.q0, s2, 64);
+			const uint32_t a11 = (uint32_t)__shfl((int)lf.q1, s1, 64), a12 = (uint32_t)__shfl((int)lf.q1, s2, 64);
+			const uint32_t pb1 = (uint32_t)__shfl((int)lf.pb, s1, 64), pb2 = (uint32_t)__shfl((int)lf.pb, s2, 64);
+			uint32_t w1[4], w2[4];
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
-				const uint32_t sw = (uint32_t)__shfl((int)fv.wrow[k & 1], gs + (k >> 1), 64);
-				c.w2[k] = vecp ? sw : 0u;
+				w1[k] = (uint32_t)__shfl((int)lf.w[k], s1, 64);
+				w2[k] = (uint32_t)__shfl((int)lf.w[k], s2, 64);
 			}
+			Cand c;
+			c.err = lf.err;
+			c.id = m6 ? 0u : (vecp ? cid : idbase + mypart);
+			c.q[0] = lf.q0; c.q[1] = lf.q1; c.q[2] = 0; c.q[3] = 0; c.q[4] = 0; c.q[5] = 0;
+			c.pb = lf.pb;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { c.w[k] = lf.w[k]; c.w2[k] = 0; }
 			if (vecp) {
-				c.err += serr;
-				c.q[4] = sq0 & 0xFF000000u;   // parked for pack_block
-				c.q[5] = sq1 & 0xFF000000u;
+				c.err += e2;
+				c.q[4] = a02 & 0xFF000000u;   // parked for pack_block
+				c.q[5] = a12 & 0xFF000000u;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) c.w2[k] = w2[k];
+			} else if (plane) {
+				c.err += e1;
+				c.q[2] = a01; c.q[3] = a11;
+				c.pb |= pb1 << 2;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) c.w[k] |= w1[k];
+				if (st == 1u) {
+					c.err += e2;
+					c.q[4] = a02; c.q[5] = a12;
+					c.pb |= pb2 << 4;
+#pragma unroll
+					for (int k = 0; k < 4; ++k) c.w[k] |= w2[k];
+				}
 			}
-			// one lane per candidate registers it
-			if ((m6 ? lane == 0u : (vecp && rp == 0u)) && c.err < best_err) {
+			const bool leader = active && (m6 ? lane == 0u : (vecp || (plane && sub == 0u)));
+			if (leader && (c.err < best_err || (c.err == best_err && c.id < best_id))) {
 				best_err = c.err;
 				best_id = c.id;
 				cand_store(cslot, c);
 			}
+			// A zero-error candidate cannot be beaten by a later one (ids grow with the
+			// streams), so the remaining work may be skipped without changing the payload.
+			solved = __ballot(best_err == 0u) != 0ull;
 		}
 	}
 
-	// A zero-error candidate cannot be beaten (ties go to the lowest id), so the
-	// remaining passes may be skipped without changing the payload.
-	bool solved = __ballot(best_err == 0u) != 0ull;
-
-	// ---- partitioned modes ----
+	// ---- Highest: every partition of every mode gets all the refit rounds (lane = partition) ----
 	if (EXH && !solved) {
 		// Highest: lane = partition, every partition gets all the refit rounds
 		uint32_t modes, nmodes;
@@ -1188,119 +1237,6 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 				best_err = c.err;
 				best_id = c.id;
 				cand_store(cslot, c);
-			}
-			solved = __ballot(best_err == 0u) != 0ull;
-		}
-	} else if (!EXH && quality >= 1u && !solved) {
-		// Two-phase search.  Phase 1 (lane = partition): score every partition with the
-		// residual estimator -- once per subset count, the score does not depend on the
-		// mode.  Phase 2 (lane = (mode, rank, subset, row pair)): full fit with all refit
-		// rounds of the best partitions of every mode of the group, two lanes per subset.
-		//   two-subset group:   modes 1 + 3 with 8 partitions each, or one mode (1 or 7) with 16
-		//   three-subset group: modes 0 + 2 with 5 partitions each (Production and up)
-		const Tex tx = make_tex(tp, pl, 0u, has_alpha ? 15u : 7u);
-		const uint32_t wv[4] = {wt[0], wt[1], wt[2], has_alpha ? wt[3] : 0u};
-		const uint32_t ngroups = (!has_alpha && quality >= 3u) ? 2u : 1u;
-		if (CF_BC7_ABLATE & 2) solved = true;
-#pragma unroll 1
-		for (uint32_t g = 0; g < ngroups && !solved; ++g) {
-			asm volatile("" : "+v"(lane));   // roles below are recomputed per group, not kept
-			const uint32_t ns = 2u + g, gl = 2u*ns;
-			const uint32_t p2 = k_part2[lane], p3 = k_part3[lane];
-			float sc = 0.0f;
-			for (uint32_t sb = 0; sb < ns; ++sb) {
-				uint32_t mask;
-				if (g == 0u)
-					mask = sb ? p2 : (~p2 & 0xFFFFu);
-				else {
-					mask = 0;
-#pragma unroll
-					for (int i = 0; i < 16; ++i)
-						mask |= (((p3 >> (2*i)) & 3u) == sb ? 1u : 0u) << i;
-				}
-				sc = sc + subset_residual(tx, mask);
-			}
-			const uint32_t key0 = (__float_as_uint(sc) & ~63u) | lane;
-			// lane roles in phase 2
-			const bool twomodes = g == 1u || (!has_alpha && quality >= 2u);
-			const uint32_t per = g == 1u ? 5u : (twomodes ? 8u : 16u);   // partitions per mode
-			const uint32_t rankall = lane/gl;
-			const uint32_t mi = (twomodes && rankall >= per) ? 1u : 0u;
-			const uint32_t rank = rankall - mi*per;
-			const uint32_t sub = (lane - rankall*gl) >> 1, rp = lane & 1u;
-			const bool act = rankall < (twomodes ? 2u*per : per);
-			uint32_t mypart = 0;
-			const uint32_t nruns = g == 1u ? 2u : 1u;   // mode 0 ranks its own 16 partitions
-			for (uint32_t run = 0; run < nruns; ++run) {
-				const uint32_t npart = (g == 1u && run == 0u) ? 16u : 64u;
-				uint32_t key = lane < npart ? key0 : 0xFFFFFFFFu;
-				for (uint32_t t = 0; t < per; ++t) {
-					const uint32_t kmin = cf_wave_min_u32(key);
-					const bool mine = rank == t && (g == 0u || mi == run);
-					mypart = mine ? (kmin & 63u) : mypart;
-					key = key == kmin ? 0xFFFFFFFFu : key;
-				}
-			}
-			uint32_t mode;
-			if (g == 1u) mode = mi ? 2u : 0u;
-			else mode = has_alpha ? 7u : (mi ? 3u : 1u);
-			uint32_t cb, ab, pbk, ib, idbase;
-			switch (mode) {
-				case 1: cb = 6; ab = 0; pbk = 2; ib = 3; idbase = 64; break;
-				case 3: cb = 7; ab = 0; pbk = 1; ib = 2; idbase = 128; break;
-				case 0: cb = 4; ab = 0; pbk = 1; ib = 3; idbase = 192; break;
-				case 2: cb = 5; ab = 0; pbk = 0; ib = 2; idbase = 256; break;
-				default: cb = 5; ab = 5; pbk = 1; ib = 2; idbase = 320; break;
-			}
-			const uint32_t sp2 = k_part2[mypart], sp3 = k_part3[mypart];
-			uint32_t smask;
-			if (g == 0u)
-				smask = sub ? sp2 : (~sp2 & 0xFFFFu);
-			else {
-				smask = 0;
-#pragma unroll
-				for (int i = 0; i < 16; ++i)
-					smask |= (((sp3 >> (2*i)) & 3u) == sub ? 1u : 0u) << i;
-			}
-			RowFit rf;
-			rf.err = 0; rf.q0 = 0; rf.q1 = 0; rf.pb = 0; rf.wrow[0] = 0; rf.wrow[1] = 0;
-			if (act)
-				fit_vec_rows<UNITW, false, 2>(tx, smask, rp, false, 0u, cb, ab, pbk, ib, iters, wv,
-					false, rf);
-			// gather the partition's subsets into the leader lane (subset 0, row pair 0)
-			const int g0 = (int)(rankall*gl);
-			Cand r2;
-			r2.id = idbase + mypart;
-			r2.err = 0;
-			r2.pb = 0;
-#pragma unroll
-			for (int k = 0; k < 6; ++k) r2.q[k] = 0;
-#pragma unroll
-			for (int k = 0; k < 4; ++k) { r2.w[k] = 0; r2.w2[k] = 0; }
-#pragma unroll
-			for (int sb = 0; sb < 3; ++sb) {
-				const int src = g0 + 2*sb;
-				const uint32_t e = (uint32_t)__shfl((int)rf.err, src, 64);
-				const uint32_t a0 = (uint32_t)__shfl((int)rf.q0, src, 64);
-				const uint32_t a1 = (uint32_t)__shfl((int)rf.q1, src, 64);
-				const uint32_t pbs = (uint32_t)__shfl((int)rf.pb, src, 64);
-				uint32_t wr[4];
-#pragma unroll
-				for (int k = 0; k < 4; ++k)
-					wr[k] = (uint32_t)__shfl((int)rf.wrow[k & 1], src + (k >> 1), 64);
-				if ((uint32_t)sb < ns) {
-					r2.err += e;
-					r2.q[2*sb] = a0; r2.q[2*sb + 1] = a1;
-					r2.pb |= pbs << (2*sb);
-#pragma unroll
-					for (int k = 0; k < 4; ++k) r2.w[k] |= wr[k];
-				}
-			}
-			if (act && sub == 0u && rp == 0u &&
-				(r2.err < best_err || (r2.err == best_err && r2.id < best_id))) {
-				best_err = r2.err;
-				best_id = r2.id;
-				cand_store(cslot, r2);
 			}
 			solved = __ballot(best_err == 0u) != 0ull;
 		}
