@@ -148,37 +148,22 @@ __device__ __forceinline__ float sc_of(uint32_t t)
 }
 
 // C: quantise float endpoints.  cb: bits of channels 0..2, ab: bits of channel 3
-// (0 = channel not coded).  pbk: 0 none, 1 per endpoint, 2 shared.  All four may differ
-// per lane, so the body is straight-line code: a channel that is not coded has x = 0 and
-// comes out as 0 through the arithmetic (its dequantised p-bit pattern is masked).
+// (0 = channel not coded).  pbk: 0 none, 1 per endpoint, 2 shared.  All may differ per lane,
+// so there is ONE straight-line path: both p-bit candidates of both endpoints are formed as
+//   q = clamp(floor((x*sc(T) - P)*H + 0.5)),  code = (q << S) | P,  d = dequant(code, T)
+// with (T, H, S) = (bits+1, 0.5, 1) for p-bit modes and (bits, 1.0, 0) with P forced to 0
+// otherwise -- for those lanes (y - 0)*1 is exact, both candidates coincide and p = 0 wins.
+// A channel that is not coded has x = 0 and comes out as 0 (its dequantised pattern is masked).
 __device__ __forceinline__ void quantize(const float (&x0)[4], const float (&x1)[4], uint32_t cb,
 	uint32_t ab, uint32_t pbk, const float (&fwt)[4], SubFit& f)
 {
-	if (pbk == 0u) {
-		const float scc = sc_of(cb), sca = sc_of(ab);
-		const int qmc = (1 << cb) - 1, qma = (1 << ab) - 1;
-		const uint32_t shc = cb ? cb : 8u, sha = ab ? ab : 8u;   // dequant shifts (value is 0 anyway)
-		uint32_t q0 = 0, q1 = 0, e0 = 0, e1 = 0;
-#pragma unroll
-		for (int c = 0; c < 4; ++c) {
-			const float sc = c < 3 ? scc : sca;
-			const int qmax = c < 3 ? qmc : qma;
-			const uint32_t t = c < 3 ? shc : sha;
-			int a = (int)floorf(x0[c]*sc + 0.5f);
-			int b = (int)floorf(x1[c]*sc + 0.5f);
-			a = a < 0 ? 0 : (a > qmax ? qmax : a);
-			b = b < 0 ? 0 : (b > qmax ? qmax : b);
-			q0 |= (uint32_t)a << (8*c);
-			q1 |= (uint32_t)b << (8*c);
-			e0 |= dequant((uint32_t)a, t) << (8*c);
-			e1 |= dequant((uint32_t)b, t) << (8*c);
-		}
-		f.q0 = q0; f.q1 = q1; f.e0 = e0; f.e1 = e1; f.pb = 0;
-		return;
-	}
-	const float scc = sc_of(cb + 1u), sca = sc_of(ab + 1u);
+	const uint32_t S = pbk ? 1u : 0u;
+	const float H = pbk ? 0.5f : 1.0f;
+	const uint32_t Tc = cb + S, Ta = ab + S;
+	const float scc = cb ? sc_of(Tc) : 0.0f, sca = ab ? sc_of(Ta) : 0.0f;
 	const int qmc = (1 << cb) - 1, qma = (1 << ab) - 1;
-	const uint32_t amask = ab ? 255u : 0u;
+	const uint32_t shc = cb ? Tc : 8u, sha = ab ? Ta : 8u;   // dequant shifts (masked when not coded)
+	const uint32_t cmask = cb ? 255u : 0u, amask = ab ? 255u : 0u;
 	// [endpoint][p]
 	uint32_t q[2][2] = {{0, 0}, {0, 0}}, d[2][2] = {{0, 0}, {0, 0}};
 	float er[2][2];
@@ -186,20 +171,20 @@ __device__ __forceinline__ void quantize(const float (&x0)[4], const float (&x1)
 	for (int e = 0; e < 2; ++e) {
 #pragma unroll
 		for (int p = 0; p < 2; ++p) {
+			const uint32_t P = pbk ? (uint32_t)p : 0u;
+			const float Pf = (float)P;
 			float acc = 0.0f;
 #pragma unroll
 			for (int c = 0; c < 4; ++c) {
-				const uint32_t t = c < 3 ? cb + 1u : (ab ? ab + 1u : 8u);
+				const uint32_t t = c < 3 ? shc : sha;
 				const float sc = c < 3 ? scc : sca;
 				const int qmax = c < 3 ? qmc : qma;
 				const float xv = e ? x1[c] : x0[c];
 				const float y = xv*sc;
-				const float u = (y - (float)p)*0.5f;
+				const float u = (y - Pf)*H;
 				int qq = (int)floorf(u + 0.5f);
 				qq = qq < 0 ? 0 : (qq > qmax ? qmax : qq);
-				uint32_t dd = dequant(((uint32_t)qq << 1) | (uint32_t)p, t);
-				if (c == 3)
-					dd &= amask;
+				const uint32_t dd = dequant(((uint32_t)qq << S) | P, t) & (c < 3 ? cmask : amask);
 				const float dx = (float)dd - xv;
 				const float t2 = dx*dx;
 				acc = fmaf(fwt[c], t2, acc);
@@ -210,13 +195,14 @@ __device__ __forceinline__ void quantize(const float (&x0)[4], const float (&x1)
 		}
 	}
 	uint32_t p0, p1;
-	if (pbk == 1u) {
-		p0 = er[0][1] < er[0][0] ? 1u : 0u;
-		p1 = er[1][1] < er[1][0] ? 1u : 0u;
-	} else {
+	{
+		const uint32_t i0 = er[0][1] < er[0][0] ? 1u : 0u;
+		const uint32_t i1 = er[1][1] < er[1][0] ? 1u : 0u;
 		const float s0 = er[0][0] + er[1][0];
 		const float s1 = er[0][1] + er[1][1];
-		p0 = p1 = s1 < s0 ? 1u : 0u;
+		const uint32_t sh = s1 < s0 ? 1u : 0u;
+		p0 = pbk == 1u ? i0 : (pbk == 2u ? sh : 0u);
+		p1 = pbk == 1u ? i1 : (pbk == 2u ? sh : 0u);
 	}
 	f.q0 = p0 ? q[0][1] : q[0][0];
 	f.e0 = p0 ? d[0][1] : d[0][0];
@@ -527,7 +513,7 @@ struct LaneFit {
 
 template <bool UNITW>
 __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bool m6,
-	uint32_t khalf, uint32_t ib, const uint32_t (&wt)[4], bool want_lsq, LaneFit& f,
+	uint32_t khalf, uint32_t ib, const uint32_t (&wt)[4], uint32_t pp_sum, bool want_lsq, LaneFit& f,
 	float (&nx0)[4], float (&nx1)[4], bool& ok)
 {
 	const uint32_t nk = m6 ? 8u : (1u << ib), kbase = m6 ? 8u*khalf : 0u;
@@ -545,13 +531,16 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 		const uint32_t c3 = (__umul24(iw, e03) + __umul24(w, e13) + 32u) >> 6;
 		pal[k] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
 		const bool valid = (uint32_t)k < nk;
+		// UNITW: the NEGATED key constant, -(128 |c_k|^2 + w_k): a texel's key is
+		// (p.c_k << 8) + base[k] = -(128 (|c_k|^2 - 2 p.c_k) + w_k), maximised over k, so one
+		// v_lshl_add per entry; |p|^2 is added per subset (pp_sum), not per texel.
 		if (UNITW)
-			base[k] = valid ? (int)((__builtin_amdgcn_udot4(pal[k], pal[k], 0u, false) << 7) | w)
-				: 0x3FFFFFFF;
+			base[k] = valid ? -(int)((__builtin_amdgcn_udot4(pal[k], pal[k], 0u, false) << 7) | w)
+				: -0x3FFFFFFF;
 		else
 			base[k] = valid ? (int)w : -1;
 	}
-	uint32_t err = 0;
+	uint32_t err = UNITW ? pp_sum : 0u;
 	uint32_t S = 0, A = 0, B = 0, C = 0, U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
 	uint32_t wp0 = 0, wp1 = 0, wp2 = 0, wp3 = 0;
 #pragma unroll 1
@@ -565,14 +554,17 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 			const uint32_t p = texel<true>(tx, raw[j]);
 			uint32_t key;
 			if (UNITW) {
-				int bestk = 0x7FFFFFFF;
+				int bestk = -0x7FFFFFFF;
 #pragma unroll
 				for (int k = 0; k < 8; ++k) {
 					const int dt = (int)__builtin_amdgcn_udot4(p, pal[k], 0u, false);
-					const int v = __mul24(dt, -256) + base[k];
-					bestk = v < bestk ? v : bestk;
+					const int v = (dt << 8) + base[k];
+					bestk = v > bestk ? v : bestk;
 				}
-				key = (uint32_t)bestk + (__builtin_amdgcn_udot4(p, p, 0u, false) << 7);
+				// mode 6: the other palette half lives in the neighbouring lane
+				const int other = (int)cf_xor1((uint32_t)bestk);
+				bestk = (m6 && other > bestk) ? other : bestk;
+				key = (uint32_t)(-bestk);   // 128 (|c|^2 - 2 p.c) + w, two's complement
 			} else {
 				key = 0xFFFFFFFFu;
 #pragma unroll
@@ -587,12 +579,13 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 					key = v < key ? v : key;
 				}
 			}
-			// mode 6: the other palette half lives in the neighbouring lane
-			const uint32_t other = cf_xor1(key);
-			key = (m6 && other < key) ? other : key;
-			const bool m = (mrow >> j) & 1u;
-			err += m ? (key >> 7) : 0u;
-			wrow |= (m ? (key & 127u) : 0u) << (8*j);
+			if (!UNITW) {
+				const uint32_t other = cf_xor1(key);
+				key = (m6 && other < key) ? other : key;
+			}
+			key = ((mrow >> j) & 1u) ? key : 0u;
+			err += UNITW ? (uint32_t)((int)key >> 7) : (key >> 7);
+			wrow |= (key & 127u) << (8*j);
 		}
 		wp0 = wp1; wp1 = wp2; wp2 = wp3; wp3 = wrow;
 		if (want_lsq) {   // uniform: the last round's refit would never be used
@@ -753,13 +746,14 @@ __device__ __forceinline__ void fit_lane(const Tex& tx, uint32_t mask, bool m6, 
 	quantize(x0, x1, cb, ab, pbk, fwt, q);
 	best.e0 = q.e0; best.e1 = q.e1; best.q0 = q.q0; best.q1 = q.q1; best.pb = q.pb;
 	bool live;
-	assign_lsq_lane<UNITW>(tx, mask, m6, khalf, ib, wt, iters > 0u, best, x0, x1, live);
+	const uint32_t pp_sum = q00 + q11 + q22 + q33;   // sum of |p|^2 over the subset's coded channels
+	assign_lsq_lane<UNITW>(tx, mask, m6, khalf, ib, wt, pp_sum, iters > 0u, best, x0, x1, live);
 	for (uint32_t r = 0; r < iters; ++r) {
 		LaneFit cur;
 		bool ok;
 		quantize(x0, x1, cb, ab, pbk, fwt, q);
 		cur.e0 = q.e0; cur.e1 = q.e1; cur.q0 = q.q0; cur.q1 = q.q1; cur.pb = q.pb;
-		assign_lsq_lane<UNITW>(tx, mask, m6, khalf, ib, wt, r + 1u < iters, cur, x0, x1, ok);
+		assign_lsq_lane<UNITW>(tx, mask, m6, khalf, ib, wt, pp_sum, r + 1u < iters, cur, x0, x1, ok);
 		const bool better = live && cur.err < best.err;
 		if (better)
 			best = cur;

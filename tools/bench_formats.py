@@ -15,6 +15,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--formats", default="", help="comma list of Format names (default: all)")
+    ap.add_argument("--qualities", default="0,2,4")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -36,6 +38,10 @@ def main():
              (Format.EAC_R11, Type.UNorm), (Format.EAC_R11G11, Type.SNorm),
              (Format.ASTC_4x4, Type.UNorm), (Format.ASTC_6x6, Type.UNorm),
              (Format.ASTC_8x8, Type.UNorm), (Format.ASTC_12x12, Type.UNorm)]
+    if args.formats:
+        want = set(args.formats.split(","))
+        cases = [c for c in cases if c[0].name in want]
+    quals = [int(q) for q in args.qualities.split(",")]
     for fmt, typ in cases:
         is_hdr = fmt == Format.BC6H
         src = hdr if is_hdr else ldr
@@ -45,7 +51,7 @@ def main():
                  PixelType.RGBA8, "width": n, "height": n,
                  "row_pitch_bytes": n * (8 if is_hdr else 4), "out": out.data_ptr(),
                  "out_capacity": nbytes}]
-        for q in (0, 2, 4):
+        for q in quals:
             p = make_params(fmt, typ, q)
             ctx.encode_device(surf, p, stream)
             torch.cuda.synchronize()
