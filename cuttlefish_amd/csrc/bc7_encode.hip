@@ -101,18 +101,6 @@ __device__ __forceinline__ void cand_store(uint32_t* slot, const Cand& c)
 		slot[(11 + k)*CF_WG_THREADS] = c.w2[k];
 	}
 }
-__device__ __forceinline__ void cand_load(const uint32_t* slot, Cand& c)
-{
-#pragma unroll
-	for (int k = 0; k < 6; ++k) c.q[k] = slot[k*CF_WG_THREADS];
-	c.pb = slot[6*CF_WG_THREADS];
-#pragma unroll
-	for (int k = 0; k < 4; ++k) {
-		c.w[k] = slot[(7 + k)*CF_WG_THREADS];
-		c.w2[k] = slot[(11 + k)*CF_WG_THREADS];
-	}
-}
-
 __device__ __forceinline__ uint32_t ub(uint32_t v, int c) { return (v >> (8*c)) & 255u; }
 __device__ __forceinline__ float fb(uint32_t v, int c) { return (float)((v >> (8*c)) & 255u); }
 
@@ -761,34 +749,32 @@ __device__ __forceinline__ void fit_lane(const Tex& tx, uint32_t mask, bool m6, 
 	}
 }
 
-struct BitWriter {
-	unsigned long long lo, hi;
-	uint32_t pos;
-	__device__ __forceinline__ void put(uint32_t v, uint32_t n)
-	{
-		if (n == 0u)
-			return;
-		const unsigned long long vv = (unsigned long long)(v & ((1u << n) - 1u));
-		if (pos < 64u) {
-			lo |= vv << pos;
-			if (pos + n > 64u)
-				hi |= vv >> (64u - pos);
-		} else
-			hi |= vv << (pos - 64u);
-		pos += n;
-	}
-};
-
 __device__ __forceinline__ uint32_t w2i(uint32_t w, uint32_t ib)
 {
 	return (w*((1u << ib) - 1u) + 32u) >> 6;
 }
 
-// Bit-pack the winning candidate (mirrors pack() of the oracle).
-__device__ __forceinline__ uint4 pack_block(const Cand& c)
+// OR over the wavefront, uniform result (all 64 lanes active).
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
+{
+	v |= cf_dpp<0xB1>(v);
+	v |= cf_dpp<0x4E>(v);
+	v |= cf_dpp<0x141>(v);
+	v |= cf_dpp<0x140>(v);
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16) |
+		(uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
+// Bit-pack the winning candidate with the whole wavefront (same layout as pack_block /
+// the oracle's pack()): the winner's fields are read from its LDS column by every lane,
+// each lane forms ONE bit field (value, offset, width) and the 128-bit block is the OR of
+// all of them.
+//   lanes  0..15 : first index field, texel = lane        lanes 16..31 : second index field
+//   lanes 32..55 : endpoint field (channel-major)         lanes 56..61 : p-bits
+//   lane  62     : mode / partition / rotation / index-selector header
+__device__ __forceinline__ uint4 pack_block_wave(const uint32_t* wcol, uint32_t id, uint32_t lane)
 {
 	uint32_t mode, part = 0, rot = 0, isel = 0;
-	const uint32_t id = c.id;
 	if (id == 0u) mode = 6;
 	else if (id < 5u) { mode = 5; rot = id - 1u; }
 	else if (id < 13u) { mode = 4; rot = (id - 5u) & 3u; isel = (id - 5u) >> 2; }
@@ -797,115 +783,104 @@ __device__ __forceinline__ uint4 pack_block(const Cand& c)
 	else if (id < 256u) { mode = 0; part = id - 192u; }
 	else if (id < 320u) { mode = 2; part = id - 256u; }
 	else { mode = 7; part = id - 320u; }
-	// field widths: ns, pb, rb, isb, cb, ab, pbits, ib, ib2 packed as nibbles
-	//                       mode: 0          1          2          3          4          5          6          7
-	const uint32_t tab_ns[8]  = {3, 2, 3, 2, 1, 1, 1, 2};
-	const uint32_t tab_pb[8]  = {4, 6, 6, 6, 0, 0, 0, 6};
-	const uint32_t tab_cb[8]  = {4, 6, 5, 7, 5, 7, 7, 5};
-	const uint32_t tab_ab[8]  = {0, 0, 0, 0, 6, 8, 7, 5};
-	const uint32_t tab_pk[8]  = {1, 2, 0, 1, 0, 0, 1, 1};
-	const uint32_t tab_ib[8]  = {3, 3, 2, 2, 2, 2, 4, 2};
-	const uint32_t tab_ib2[8] = {0, 0, 0, 0, 3, 2, 0, 0};
-	uint32_t ns = 0, pbn = 0, cb = 0, ab = 0, pk = 0, ib = 0, ib2 = 0;
-#pragma unroll
-	for (int m = 0; m < 8; ++m) {
-		if (mode == (uint32_t)m) {
-			ns = tab_ns[m]; pbn = tab_pb[m]; cb = tab_cb[m]; ab = tab_ab[m];
-			pk = tab_pk[m]; ib = tab_ib[m]; ib2 = tab_ib2[m];
-		}
-	}
+	// per-mode constants, one nibble per mode (mode 0 in the low nibble)
+	const uint32_t ns  = (0x21112323u >> (4u*mode)) & 15u;
+	const uint32_t pbn = (0x60006664u >> (4u*mode)) & 15u;
+	const uint32_t cb  = (0x57757564u >> (4u*mode)) & 15u;
+	const uint32_t ab  = (0x57860000u >> (4u*mode)) & 15u;
+	const uint32_t pk  = (0x11001021u >> (4u*mode)) & 15u;
+	const uint32_t ib  = (0x24222233u >> (4u*mode)) & 15u;
+	const uint32_t ib2 = (0x00230000u >> (4u*mode)) & 15u;
 	uint32_t ibc = ib, iba = ib2;
-	if (mode == 4u && isel) { ibc = 3u; iba = 2u; }
-
+	const bool swapsets = mode == 4u && isel != 0u;
+	if (swapsets) { ibc = 3u; iba = 2u; }
 	const uint32_t p2 = k_part2[part], p3 = k_part3[part];
 	uint32_t a1 = 0, a2 = 0;
 	if (ns == 2u) a1 = k_anchor2[part];
 	else if (ns == 3u) { a1 = k_anchor3a[part]; a2 = k_anchor3b[part]; }
 
-	uint32_t sub[16], idx[16], idx2[16];
-	uint32_t ia0 = 0, ia1 = 0, ia2 = 0;
-#pragma unroll
-	for (int i = 0; i < 16; ++i) {
-		sub[i] = ns == 1u ? 0u : (ns == 2u ? ((p2 >> i) & 1u) : ((p3 >> (2*i)) & 3u));
-		const uint32_t wv = (c.w[i >> 2] >> (8*(i & 3))) & 255u;
-		const uint32_t ws = (c.w2[i >> 2] >> (8*(i & 3))) & 255u;
-		idx[i] = w2i(wv, ibc);
-		idx2[i] = iba ? w2i(ws, iba) : 0u;
-		if (i == 0) ia0 = idx[i];
-		if ((uint32_t)i == a1) ia1 = idx[i];
-		if ((uint32_t)i == a2) ia2 = idx[i];
-	}
-	const uint32_t sw0 = ia0 >> (ibc - 1u);
-	const uint32_t sw1 = ns > 1u ? ia1 >> (ibc - 1u) : 0u;
-	const uint32_t sw2 = ns > 2u ? ia2 >> (ibc - 1u) : 0u;
-	const uint32_t maxi = (1u << ibc) - 1u;
-#pragma unroll
-	for (int i = 0; i < 16; ++i) {
-		const uint32_t sw = sub[i] == 0u ? sw0 : (sub[i] == 1u ? sw1 : sw2);
-		idx[i] = sw ? maxi - idx[i] : idx[i];
-	}
-	uint32_t q[6], pb[6];
-	q[0] = sw0 ? c.q[1] : c.q[0]; q[1] = sw0 ? c.q[0] : c.q[1];
-	q[2] = sw1 ? c.q[3] : c.q[2]; q[3] = sw1 ? c.q[2] : c.q[3];
-	q[4] = sw2 ? c.q[5] : c.q[4]; q[5] = sw2 ? c.q[4] : c.q[5];
-	pb[0] = (c.pb >> (sw0 ? 1 : 0)) & 1u; pb[1] = (c.pb >> (sw0 ? 0 : 1)) & 1u;
-	pb[2] = (c.pb >> (sw1 ? 3 : 2)) & 1u; pb[3] = (c.pb >> (sw1 ? 2 : 3)) & 1u;
-	pb[4] = (c.pb >> (sw2 ? 5 : 4)) & 1u; pb[5] = (c.pb >> (sw2 ? 4 : 5)) & 1u;
-	if (iba) {
-		// separate scalar plane: own anchor (pixel 0) and endpoint order; its
-		// endpoints travel in byte 3 of w2's fit, stored in q[0]/q[1] byte 3 by caller
-		const uint32_t sws = idx2[0] >> (iba - 1u);
-		const uint32_t s0 = c.q[4] >> 24, s1 = c.q[5] >> 24;   // scalar endpoints parked in q[4],q[5]
-		q[0] = (q[0] & 0x00FFFFFFu) | ((sws ? s1 : s0) << 24);
-		q[1] = (q[1] & 0x00FFFFFFu) | ((sws ? s0 : s1) << 24);
-		const uint32_t maxa = (1u << iba) - 1u;
-#pragma unroll
-		for (int i = 0; i < 16; ++i)
-			idx2[i] = sws ? maxa - idx2[i] : idx2[i];
-	}
+	// texel t = lane & 15: subset, both indices
+	const uint32_t t = lane & 15u;
+	const uint32_t sb = ns == 1u ? 0u : (ns == 2u ? ((p2 >> t) & 1u) : ((p3 >> (2u*t)) & 3u));
+	const uint32_t wv = (wcol[(7u + (t >> 2))*CF_WG_THREADS] >> (8u*(t & 3u))) & 255u;
+	const uint32_t ws = (wcol[(11u + (t >> 2))*CF_WG_THREADS] >> (8u*(t & 3u))) & 255u;
+	uint32_t idxv = w2i(wv, ibc);
+	uint32_t idxs = iba ? w2i(ws, iba) : 0u;
+	// anchors decide the endpoint order of their subset
+	const uint32_t sw0 = (uint32_t)__builtin_amdgcn_readlane((int)idxv, 0) >> (ibc - 1u);
+	const uint32_t sw1 = ns > 1u ? (uint32_t)__builtin_amdgcn_readlane((int)idxv, (int)a1) >> (ibc - 1u) : 0u;
+	const uint32_t sw2 = ns > 2u ? (uint32_t)__builtin_amdgcn_readlane((int)idxv, (int)a2) >> (ibc - 1u) : 0u;
+	const uint32_t sws = iba ? (uint32_t)__builtin_amdgcn_readlane((int)idxs, 0) >> (iba - 1u) : 0u;
+	const uint32_t swmask = sw0 | (sw1 << 1) | (sw2 << 2);
+	idxv = ((swmask >> sb) & 1u) ? ((1u << ibc) - 1u) - idxv : idxv;
+	idxs = sws ? ((1u << iba) - 1u) - idxs : idxs;
 
-	BitWriter bw = {0ull, 0ull, 0u};
-	bw.put(1u << mode, mode + 1u);
-	bw.put(part, pbn);
-	bw.put(rot, (mode == 4u || mode == 5u) ? 2u : 0u);
-	bw.put(isel, mode == 4u ? 1u : 0u);
 	const uint32_t ne = 2u*ns;
-#pragma unroll
-	for (int ch = 0; ch < 3; ++ch) {
-#pragma unroll
-		for (int e = 0; e < 6; ++e)
-			if ((uint32_t)e < ne)
-				bw.put(ub(q[e], ch), cb);
+	const uint32_t hdr = mode + 1u + pbn + ((mode == 4u || mode == 5u) ? 2u : 0u) + (mode == 4u ? 1u : 0u);
+	const uint32_t base_pb = hdr + ne*(3u*cb + ab);
+	const uint32_t npb = pk == 1u ? ne : (pk == 2u ? 2u : 0u);
+	const uint32_t baseA = base_pb + npb;
+	const uint32_t baseB = baseA + 16u*ib - ns;
+
+	uint32_t val = 0, off = 0;
+	bool have = false;
+	if (lane < 16u) {
+		const uint32_t before = (t > 0u ? 1u : 0u) + ((ns >= 2u && t > a1) ? 1u : 0u) +
+			((ns == 3u && t > a2) ? 1u : 0u);
+		val = swapsets ? idxs : idxv;
+		off = baseA + t*ib - before;
+		have = true;
+	} else if (lane < 32u) {
+		val = swapsets ? idxv : idxs;
+		off = baseB + t*ib2 - (t > 0u ? 1u : 0u);
+		have = ib2 != 0u;
+	} else if (lane < 56u) {
+		const uint32_t f = lane - 32u;
+		const uint32_t ch = f/ne, e = f - ch*ne;
+		const uint32_t es = e ^ ((swmask >> (e >> 1)) & 1u);          // endpoint order after the swap
+		const uint32_t qw = wcol[es*CF_WG_THREADS];
+		if (ch < 3u) {
+			val = (qw >> (8u*ch)) & 255u;
+			off = hdr + (ch*ne + e)*cb;
+			have = true;
+		} else if (ch == 3u && ab) {
+			// modes 4/5: the scalar plane's endpoints are parked in q[4], q[5] (byte 3)
+			const uint32_t sq = wcol[(4u + ((e ^ sws) & 1u))*CF_WG_THREADS];
+			val = (iba ? sq : qw) >> 24;
+			off = hdr + 3u*ne*cb + e*ab;
+			have = true;
+		}
+	} else if (lane < 62u) {
+		const uint32_t e = lane - 56u;
+		const uint32_t pbw = wcol[6u*CF_WG_THREADS];
+		if (pk == 1u && e < ne) {
+			val = (pbw >> (e ^ ((swmask >> (e >> 1)) & 1u))) & 1u;
+			off = base_pb + e;
+			have = true;
+		} else if (pk == 2u && e < 2u) {
+			// shared p-bit of subset e: both endpoint bits are equal
+			val = (pbw >> (2u*e)) & 1u;
+			off = base_pb + e;
+			have = true;
+		}
+	} else if (lane == 62u) {
+		val = (1u << mode) | (part << (mode + 1u)) | (rot << (mode + 1u + pbn)) |
+			(isel << (mode + 1u + pbn + 2u));
+		if (!(mode == 4u || mode == 5u))
+			val = (1u << mode) | (part << (mode + 1u));
+		off = 0;
+		have = true;
 	}
-	if (ab) {
-#pragma unroll
-		for (int e = 0; e < 6; ++e)
-			if ((uint32_t)e < ne)
-				bw.put(q[e] >> 24, ab);
-	}
-	if (pk == 1u) {
-#pragma unroll
-		for (int e = 0; e < 6; ++e)
-			if ((uint32_t)e < ne)
-				bw.put(pb[e], 1u);
-	} else if (pk == 2u) {
-		bw.put(pb[0], 1u);
-		bw.put(pb[2], 1u);
-	}
-	const bool swapsets = mode == 4u && isel;
-#pragma unroll
-	for (int i = 0; i < 16; ++i) {
-		const uint32_t anchor = sub[i] == 0u ? 0u : (sub[i] == 1u ? a1 : a2);
-		const uint32_t nb = ib - ((uint32_t)i == anchor ? 1u : 0u);
-		bw.put(swapsets ? idx2[i] : idx[i], nb);
-	}
-	if (ib2) {
-#pragma unroll
-		for (int i = 0; i < 16; ++i)
-			bw.put(swapsets ? idx[i] : idx2[i], ib2 - (i == 0 ? 1u : 0u));
-	}
-	return make_uint4((uint32_t)bw.lo, (uint32_t)(bw.lo >> 32), (uint32_t)bw.hi,
-		(uint32_t)(bw.hi >> 32));
+	val = have ? val : 0u;
+	const uint32_t wi = off >> 5, sh = off & 31u;
+	const unsigned long long vv = (unsigned long long)val << sh;
+	const uint32_t lo = (uint32_t)vv, hi = (uint32_t)(vv >> 32);
+	uint4 r;
+	r.x = wave_or_u32(wi == 0u ? lo : 0u);
+	r.y = wave_or_u32(wi == 1u ? lo : (wi == 0u ? hi : 0u));
+	r.z = wave_or_u32(wi == 2u ? lo : (wi == 1u ? hi : 0u));
+	r.w = wave_or_u32(wi == 3u ? lo : (wi == 2u ? hi : 0u));
+	return r;
 }
 
 // Partition score of the two-phase search (oracle: subset_residual): the scatter of the
@@ -1236,20 +1211,12 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 		}
 	}
 
-	// ---- wave argmin on (error, id); winner packs ----
+	// ---- wave argmin on (error, id); the whole wave packs the winner's candidate ----
 	const unsigned long long key = ((unsigned long long)best_err << 32) | best_id;
 	const unsigned long long kmin = cf_wave_min_u64(key);
-	is_winner = key == kmin;
-	uint4 blk = make_uint4(0, 0, 0, 0);
-	if (is_winner)
-	{
-		Cand best;
-		best.err = best_err;
-		best.id = best_id;
-		cand_load(cslot, best);
-		blk = pack_block(best);
-	}
-	return blk;
+	const uint32_t wl = (uint32_t)__ffsll((long long)__ballot(key == kmin)) - 1u;   // winner lane (unique key)
+	is_winner = lane0 == 0u;   // the result is uniform; lane 0 stores it
+	return pack_block_wave(cslot - lane0 + wl, (uint32_t)kmin, lane0);
 }
 
 } // namespace
