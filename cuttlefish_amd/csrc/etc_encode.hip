@@ -95,6 +95,80 @@ __device__ __forceinline__ uint32_t half_err(const uint32_t* tp, const RgbOpts& 
 	return total;
 }
 
+// The lane's half as 8 texels in registers + which of them carry error weight, so that the
+// base-colour walk below touches neither LDS nor masks.  (Every VALU instruction costs the
+// wave the same whatever the number of active lanes: per-lane `continue`s save nothing.)
+struct HalfTex {
+	uint32_t px[8];      // RGB bytes, alpha dropped
+	uint32_t counted;    // bit j: texel j contributes error (inside the image, not transparent)
+	uint32_t pp;         // sum over counted texels of sum_c w_c p_c^2
+};
+
+__device__ __forceinline__ HalfTex load_half(const uint32_t* tp, const RgbOpts& o, uint32_t flip,
+	uint32_t sub)
+{
+	HalfTex h;
+	h.counted = 0;
+	h.pp = 0;
+	const uint32_t okmask = o.active & ~o.transparent;
+#pragma unroll
+	for (uint32_t j = 0; j < 8u; ++j) {
+		const uint32_t i = flip ? (sub*8u + j) : ((j >> 1)*4u + sub*2u + (j & 1u));
+		const uint32_t p = tp[i] & 0x00FFFFFFu;
+		h.px[j] = p;
+		const uint32_t c = (okmask >> i) & 1u;
+		h.counted |= c << j;
+		const uint32_t p0 = p & 255u, p1 = (p >> 8) & 255u, p2 = p >> 16;
+		const uint32_t e = (uint32_t)o.wt[0]*p0*p0 + (uint32_t)o.wt[1]*p1*p1 + (uint32_t)o.wt[2]*p2*p2;
+		h.pp += c ? e : 0u;
+	}
+	return h;
+}
+
+// half_err<false> on a HalfTex: sum over counted texels of min_v sum_c w_c (clamp(c+m_v) - p_c)^2,
+// expanded as |p|^2 - 2 p.(w q_v) + sum w q_v^2 with the cross term on v_dot4 (w q_v <= 2550 is
+// split into a low and a high byte plane when the weights are not all 1).
+template <bool UNITW>
+__device__ __forceinline__ uint32_t half_err_fast(const HalfTex& h, const RgbOpts& o,
+	const int (&c)[3], int ma, int mb)
+{
+	uint32_t ql[4], qh[4];
+	int nb[4];
+#pragma unroll
+	for (int v = 0; v < 4; ++v) {
+		const int m = v == 0 ? ma : (v == 1 ? mb : (v == 2 ? -ma : -mb));
+		const uint32_t q0 = (uint32_t)clamp255(c[0] + m), q1 = (uint32_t)clamp255(c[1] + m),
+			q2 = (uint32_t)clamp255(c[2] + m);
+		if (UNITW) {
+			ql[v] = q0 | (q1 << 8) | (q2 << 16);
+			qh[v] = 0;
+			nb[v] = -(int)__builtin_amdgcn_udot4(ql[v], ql[v], 0u, false);
+		} else {
+			const uint32_t w0 = (uint32_t)o.wt[0]*q0, w1 = (uint32_t)o.wt[1]*q1, w2 = (uint32_t)o.wt[2]*q2;
+			ql[v] = (w0 & 255u) | ((w1 & 255u) << 8) | ((w2 & 255u) << 16);
+			qh[v] = (w0 >> 8) | ((w1 >> 8) << 8) | ((w2 >> 8) << 16);
+			nb[v] = -(int)(w0*q0 + w1*q1 + w2*q2);
+		}
+		if (v == 2 && o.punch)
+			nb[v] = -0x3FFFFFFF;   // punch-through: selector 2 is the transparent one
+	}
+	uint32_t total = h.pp;
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		int best = -0x7FFFFFFF;
+#pragma unroll
+		for (int v = 0; v < 4; ++v) {
+			int d = (int)__builtin_amdgcn_udot4(h.px[j], ql[v], 0u, false);
+			if (!UNITW)
+				d += (int)__builtin_amdgcn_udot4(h.px[j], qh[v], 0u, false) << 8;
+			const int k = (d << 1) + nb[v];   // -(sum w q^2 - 2 p.(w q))
+			best = k > best ? k : best;
+		}
+		total += ((h.counted >> j) & 1u) ? (uint32_t)(-best) : 0u;
+	}
+	return total;
+}
+
 struct PlanarQ { int O[3], H[3], V[3]; };
 
 __device__ __forceinline__ uint32_t planar_err(const uint32_t* tp, const RgbOpts& o, const PlanarQ& q)
@@ -198,6 +272,9 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 		q0[c] = (mean*maxq + 127)/255;
 	}
 	uint32_t berr = 0xFFFFFFFFu, bcand = 0, bq = 0, dummy = 0;
+	const HalfTex ht8 = load_half(tp, o, flip, sub);
+	const bool unitw = o.wt[0] == 1 && o.wt[1] == 1 && o.wt[2] == 1;   // uniform
+	const int tma = o.punch ? 0 : k_etc_mod[t][0], tmb = k_etc_mod[t][1];
 	if (!fam4 || o.allow_indiv) {
 		const int r = o.radius;
 		uint32_t cand = 0;
@@ -208,7 +285,8 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 						clampi(q0[2] + db, 0, maxq)};
 					const int c[3] = {fam4 ? ex4(q[0]) : ex5(q[0]), fam4 ? ex4(q[1]) : ex5(q[1]),
 						fam4 ? ex4(q[2]) : ex5(q[2])};
-					const uint32_t e = half_err<false>(tp, o, hmask, c, (int)t, dummy);
+					const uint32_t e = unitw ? half_err_fast<true>(ht8, o, c, tma, tmb)
+						: half_err_fast<false>(ht8, o, c, tma, tmb);
 					if (e < berr) {
 						berr = e; bcand = cand;
 						bq = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16);
