@@ -143,7 +143,7 @@ __device__ __forceinline__ float sc_of(uint32_t t)
 // otherwise -- for those lanes (y - 0)*1 is exact, both candidates coincide and p = 0 wins.
 // A channel that is not coded has x = 0 and comes out as 0 (its dequantised pattern is masked).
 __device__ __forceinline__ void quantize(const float (&x0)[4], const float (&x1)[4], uint32_t cb,
-	uint32_t ab, uint32_t pbk, const float (&fwt)[4], SubFit& f)
+	uint32_t ab, uint32_t pbk, const uint32_t (&wt)[4], SubFit& f)
 {
 	const uint32_t S = pbk ? 1u : 0u;
 	const float H = pbk ? 0.5f : 1.0f;
@@ -175,7 +175,7 @@ __device__ __forceinline__ void quantize(const float (&x0)[4], const float (&x1)
 				const uint32_t dd = dequant(((uint32_t)qq << S) | P, t) & (c < 3 ? cmask : amask);
 				const float dx = (float)dd - xv;
 				const float t2 = dx*dx;
-				acc = fmaf(fwt[c], t2, acc);
+				acc = fmaf((float)wt[c], t2, acc);
 				q[e][p] |= (uint32_t)qq << (8*c);
 				d[e][p] |= dd << (8*c);
 			}
@@ -467,17 +467,12 @@ __device__ __forceinline__ void fit_vec(const Tex& tx, uint32_t mask, uint32_t c
 		x1[c] = clamp255(fmaf(axis[c], tmax, mean[c]));
 	}
 
-	float fwt[4];
-#pragma unroll
-	for (int c = 0; c < 4; ++c)
-		fwt[c] = (float)wt[c];
-
 	// C/D then E rounds, always restarting from the best
-	quantize(x0, x1, cb, ab, pbk, fwt, best);
+	quantize(x0, x1, cb, ab, pbk, wt, best);
 	assign_lsq<UNITW, ROT, NKMAX>(tx, mask, ib, wt, iters > 0u, best);
 	for (uint32_t r = 0; r < iters; ++r) {
 		SubFit cur;
-		quantize(best.nx0, best.nx1, cb, ab, pbk, fwt, cur);
+		quantize(best.nx0, best.nx1, cb, ab, pbk, wt, cur);
 		assign_lsq<UNITW, ROT, NKMAX>(tx, mask, ib, wt, r + 1u < iters, cur);
 		if (best.ok && cur.err < best.err)
 			best = cur;
@@ -529,7 +524,6 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 			base[k] = valid ? (int)w : -1;
 	}
 	uint32_t err = UNITW ? pp_sum : 0u;
-	uint32_t S = 0, A = 0, B = 0, C = 0, U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
 	uint32_t wp0 = 0, wp1 = 0, wp2 = 0, wp3 = 0;
 #pragma unroll 1
 	for (uint32_t r = 0; r < 4u; ++r) {
@@ -539,7 +533,11 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 		uint32_t wrow = 0;
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
-			const uint32_t p = texel<true>(tx, raw[j]);
+			uint32_t rawj = raw[j];
+			// one texel at a time: interleaving the 32 dot products of a row for ILP costs
+			// ~20 registers, and the kernel is issue-bound, not latency-bound
+			asm volatile("" : "+v"(rawj), "+v"(wrow));
+			const uint32_t p = texel<true>(tx, rawj);
 			uint32_t key;
 			if (UNITW) {
 				int bestk = -0x7FFFFFFF;
@@ -576,8 +574,18 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 			wrow |= (key & 127u) << (8*j);
 		}
 		wp0 = wp1; wp1 = wp2; wp2 = wp3; wp3 = wrow;
-		if (want_lsq) {   // uniform: the last round's refit would never be used
-			const uint32_t iwrow = (0x40404040u - wrow) & bytemask4(mrow);
+	}
+	f.err = err;
+	f.w[0] = wp0; f.w[1] = wp1; f.w[2] = wp2; f.w[3] = wp3;
+	// the refit sums in a loop of their own: their 12 accumulators and the planar rows are
+	// then not live across the texel search above (which holds the 16 palette registers)
+	uint32_t S = 0, A = 0, B = 0, C = 0, U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
+	if (want_lsq) {   // uniform: the last round's refit would never be used
+#pragma unroll 1
+		for (uint32_t r = 0; r < 4u; ++r) {
+			const uint32_t wrow = wp0;
+			wp0 = wp1; wp1 = wp2; wp2 = wp3; wp3 = wrow;   // rotates back to the start after 4 trips
+			const uint32_t iwrow = (0x40404040u - wrow) & bytemask4((mask >> (4u*r)) & 15u);
 			uint32_t P[4];
 			planes<true>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
 			S = __builtin_amdgcn_udot4(wrow, 0x01010101u, S, false);
@@ -591,8 +599,6 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 			}
 		}
 	}
-	f.err = err;
-	f.w[0] = wp0; f.w[1] = wp1; f.w[2] = wp2; f.w[3] = wp3;
 	const int det = (int)__umul24((uint32_t)__builtin_popcount(mask), C) - (int)__umul24(S, S);
 	ok = det > 0;
 	const float inv = 1.0f/(64.0f*(float)(det > 0 ? det : 1));
@@ -722,16 +728,11 @@ __device__ __forceinline__ void fit_lane(const Tex& tx, uint32_t mask, bool m6, 
 		x0[0] = 0.0f; x0[1] = 0.0f; x0[2] = 0.0f; x0[3] = (float)lo;
 		x1[0] = 0.0f; x1[1] = 0.0f; x1[2] = 0.0f; x1[3] = (float)hi;
 	}
-	float fwt[4];
-#pragma unroll
-	for (int c = 0; c < 4; ++c)
-		fwt[c] = (float)wt[c];
-
 	// C/D then E rounds.  A round that does not improve ends the lane's search (the same
 	// input would give the same output again): x0/x1 always hold the refit of the newest
 	// selectors and `live` says whether they belong to the best fit so far.
 	SubFit q;
-	quantize(x0, x1, cb, ab, pbk, fwt, q);
+	quantize(x0, x1, cb, ab, pbk, wt, q);
 	best.e0 = q.e0; best.e1 = q.e1; best.q0 = q.q0; best.q1 = q.q1; best.pb = q.pb;
 	bool live;
 	const uint32_t pp_sum = q00 + q11 + q22 + q33;   // sum of |p|^2 over the subset's coded channels
@@ -739,7 +740,7 @@ __device__ __forceinline__ void fit_lane(const Tex& tx, uint32_t mask, bool m6, 
 	for (uint32_t r = 0; r < iters; ++r) {
 		LaneFit cur;
 		bool ok;
-		quantize(x0, x1, cb, ab, pbk, fwt, q);
+		quantize(x0, x1, cb, ab, pbk, wt, q);
 		cur.e0 = q.e0; cur.e1 = q.e1; cur.q0 = q.q0; cur.q1 = q.q1; cur.pb = q.pb;
 		assign_lsq_lane<UNITW>(tx, mask, m6, khalf, ib, wt, pp_sum, r + 1u < iters, cur, x0, x1, ok);
 		const bool better = live && cur.err < best.err;
@@ -1038,6 +1039,7 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 				}
 			}
 			// ---- lane roles ----
+			asm volatile("" : "+v"(lane), "+v"(mypart));   // nothing of phase 1 but mypart lives on
 			const bool m6 = st == 0u && lane < 2u;
 			const bool sca = st == 0u && lane >= 14u && lane < 26u;
 			const bool vecp = st == 0u && lane >= 2u && lane < 14u;
@@ -1103,48 +1105,43 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 			//   partitions: subset-0 lane (the other subsets in the next lanes)
 			const int s1 = (int)((lane + 1u) & 63u);
 			const int s2 = (int)((lane + (st == 0u ? 12u : 2u)) & 63u);
+			// error and id first: only a leader whose candidate beats its best so far stores
+			// the payload fields, straight from the shuffles into its LDS column
 			const uint32_t e1 = (uint32_t)__shfl((int)lf.err, s1, 64), e2 = (uint32_t)__shfl((int)lf.err, s2, 64);
-			const uint32_t a01 = (uint32_t)__shfl((int)lf.q0, s1, 64), a02 = (uint32_t)__shfl((int)lf.q0, s2, 64);
-			const uint32_t a11 = (uint32_t)__shfl((int)lf.q1, s1, 64), a12 = (uint32_t)__shfl((int)lf.q1, s2, 64);
-			const uint32_t pb1 = (uint32_t)__shfl((int)lf.pb, s1, 64), pb2 = (uint32_t)__shfl((int)lf.pb, s2, 64);
-			uint32_t w1[4], w2[4];
-#pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				w1[k] = (uint32_t)__shfl((int)lf.w[k], s1, 64);
-				w2[k] = (uint32_t)__shfl((int)lf.w[k], s2, 64);
+			const bool use1 = plane, use2 = vecp || (plane && st == 1u);
+			const uint32_t cerr = lf.err + (use1 ? e1 : 0u) + (use2 ? e2 : 0u);
+			const uint32_t cidv = m6 ? 0u : (vecp ? cid : idbase + mypart);
+			const bool leader = active && (m6 ? lane == 0u : (vecp || (plane && sub == 0u)));
+			const bool take = leader && (cerr < best_err || (cerr == best_err && cidv < best_id));
+			if (take) {
+				best_err = cerr;
+				best_id = cidv;
 			}
-			Cand c;
-			c.err = lf.err;
-			c.id = m6 ? 0u : (vecp ? cid : idbase + mypart);
-			c.q[0] = lf.q0; c.q[1] = lf.q1; c.q[2] = 0; c.q[3] = 0; c.q[4] = 0; c.q[5] = 0;
-			c.pb = lf.pb;
-#pragma unroll
-			for (int k = 0; k < 4; ++k) { c.w[k] = lf.w[k]; c.w2[k] = 0; }
-			if (vecp) {
-				c.err += e2;
-				c.q[4] = a02 & 0xFF000000u;   // parked for pack_block
-				c.q[5] = a12 & 0xFF000000u;
-#pragma unroll
-				for (int k = 0; k < 4; ++k) c.w2[k] = w2[k];
-			} else if (plane) {
-				c.err += e1;
-				c.q[2] = a01; c.q[3] = a11;
-				c.pb |= pb1 << 2;
-#pragma unroll
-				for (int k = 0; k < 4; ++k) c.w[k] |= w1[k];
-				if (st == 1u) {
-					c.err += e2;
-					c.q[4] = a02; c.q[5] = a12;
-					c.pb |= pb2 << 4;
-#pragma unroll
-					for (int k = 0; k < 4; ++k) c.w[k] |= w2[k];
+			{
+				const uint32_t a01 = (uint32_t)__shfl((int)lf.q0, s1, 64), a11 = (uint32_t)__shfl((int)lf.q1, s1, 64);
+				const uint32_t a02 = (uint32_t)__shfl((int)lf.q0, s2, 64), a12 = (uint32_t)__shfl((int)lf.q1, s2, 64);
+				const uint32_t pb1 = (uint32_t)__shfl((int)lf.pb, s1, 64), pb2 = (uint32_t)__shfl((int)lf.pb, s2, 64);
+				if (take) {
+					cslot[0*CF_WG_THREADS] = lf.q0;
+					cslot[1*CF_WG_THREADS] = lf.q1;
+					cslot[2*CF_WG_THREADS] = plane ? a01 : 0u;
+					cslot[3*CF_WG_THREADS] = plane ? a11 : 0u;
+					// modes 4/5: the scalar plane's endpoints are parked in q[4], q[5] (byte 3)
+					cslot[4*CF_WG_THREADS] = vecp ? (a02 & 0xFF000000u) : ((plane && st == 1u) ? a02 : 0u);
+					cslot[5*CF_WG_THREADS] = vecp ? (a12 & 0xFF000000u) : ((plane && st == 1u) ? a12 : 0u);
+					cslot[6*CF_WG_THREADS] = lf.pb | (plane ? (pb1 << 2) : 0u) |
+						((plane && st == 1u) ? (pb2 << 4) : 0u);
 				}
 			}
-			const bool leader = active && (m6 ? lane == 0u : (vecp || (plane && sub == 0u)));
-			if (leader && (c.err < best_err || (c.err == best_err && c.id < best_id))) {
-				best_err = c.err;
-				best_id = c.id;
-				cand_store(cslot, c);
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const uint32_t w1 = (uint32_t)__shfl((int)lf.w[k], s1, 64);
+				const uint32_t w2 = (uint32_t)__shfl((int)lf.w[k], s2, 64);
+				if (take) {
+					cslot[(7 + k)*CF_WG_THREADS] = lf.w[k] | (plane ? w1 : 0u) |
+						((plane && st == 1u) ? w2 : 0u);
+					cslot[(11 + k)*CF_WG_THREADS] = vecp ? w2 : 0u;
+				}
 			}
 			// A zero-error candidate cannot be beaten by a later one (ids grow with the
 			// streams), so the remaining work may be skipped without changing the payload.
@@ -1221,11 +1218,12 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 
 } // namespace
 
-// Waves per SIMD the register allocation is held to: the search is a chain of small
-// dependent steps (LDS reads, cross-lane moves, table loads), so occupancy pays more than
-// a roomier register file.  The Highest kernel keeps the per-lane 16-texel fits and needs 3.
+// Waves per SIMD the register allocation is held to.  The kernel is VALU-issue-bound
+// (tools/ubench/valu_rate.hip), 3 waves hide the LDS / cross-lane latencies as well as 4 do,
+// and 168 registers hold the search without scratch (4 waves = 128 registers would spill,
+// and scratch traffic is HBM traffic).
 #ifndef CF_BC7_WAVES
-#define CF_BC7_WAVES 4
+#define CF_BC7_WAVES 3
 #endif
 template <int PIX, bool UNITW, bool EXH>
 __global__ void __launch_bounds__(CF_WG_THREADS)
