@@ -35,6 +35,7 @@ SIZE = 4096
 FORMAT_NAME = "BC7"
 QUALITY_NAME = "Normal"
 HBM_PEAK_GBPS = 8000.0
+GPU_CLOCK_HZ = 2.4e9          # MI355X peak engine clock (MI355X_MICROARCH.md)
 ALGO_BYTES_PER_PIXEL = 5.0   # 4 B RGBA8 read + 16 B / 16 px payload write
 
 
@@ -167,8 +168,8 @@ def main():
                          "traffic": None, "kernel": ctx.last_kernel_name(),
                          "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
                          "algorithmic_bytes_per_launch": int(algo_bytes),
-                         "note": "VALU-bound search; HBM fraction is expected to be tiny "
-                                 "(DESIGN.md roofline section)"},
+                         "note": "VALU-issue-bound search (see valu_issue); the HBM fraction is "
+                                 "tiny by construction (DESIGN.md roofline section)"},
         }
         # HBM traffic per launch from the committed PMC profile of this kernel (rocprofv3
         # --pmc passes cannot run inside the timed benchmark); null when not applicable.
@@ -177,6 +178,18 @@ def main():
             tj = json.load(open(tpath))
             line["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
             line["roofline"]["traffic_source"] = tj["source"]
+            if tj.get("valu_wave_insts_per_launch"):
+                # what actually bounds the kernel: VALU issue.  Peak = one integer wave64
+                # instruction per 4 cycles per SIMD (tools/ubench/valu_rate.hip), 1024 SIMDs.
+                insts = tj["valu_wave_insts_per_launch"]
+                peak = 1024 * GPU_CLOCK_HZ / 4.0
+                line["roofline"]["valu_issue"] = {
+                    "wave_insts_per_launch": insts,
+                    "achieved_ginst_s": round(insts / avg_kernel_s / 1e9, 2),
+                    "peak_ginst_s": round(peak / 1e9, 2),
+                    "frac": round(insts / avg_kernel_s / peak, 4),
+                    "note": "integer-rate peak; fp32 fma/mul/add issue at twice that rate, so a "
+                            "mixed stream can read slightly above 1"}
         if world == 1 and not args.no_cpu_baseline and size == SIZE:
             payload = out.cpu().numpy()
             line["cpu_baseline"] = cpu_baseline(img, payload, size)
