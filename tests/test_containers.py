@@ -1,0 +1,128 @@
+"""Container writers: DDS-DX10 / KTX1 serialisation of the payloads.
+
+The DDS files are opened with Pillow -- an independent reader AND an independent BCn decoder --
+and the pixels must equal the oracle decoder's on the same payload: this pins the whole chain
+payload layout -> container -> third-party decode.  Mirrors lib/test/TextureSaveTest.cpp:77-266
+(16x16 black image saved in every legal (format, type); illegal pairs are Unsupported).
+"""
+import io
+import struct
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from cuttlefish_amd import ColorSpace, Format, Type, payload_size, synth
+from cuttlefish_amd import containers as C
+
+
+def _mips(img, levels):
+    out = [img]
+    for _ in range(1, levels):
+        a = out[-1].astype(np.uint16)
+        h, w = a.shape[:2]
+        a = a[:h // 2 * 2, :w // 2 * 2]
+        out.append(((a[0::2, 0::2] + a[1::2, 0::2] + a[0::2, 1::2] + a[1::2, 1::2] + 2) // 4)
+                   .astype(np.uint8))
+    return out
+
+
+@pytest.mark.parametrize("fmt,typ", [(Format.BC1_RGB, Type.UNorm), (Format.BC2, Type.UNorm),
+                                     (Format.BC3, Type.UNorm), (Format.BC4, Type.UNorm),
+                                     (Format.BC5, Type.UNorm), (Format.BC7, Type.UNorm)])
+def test_dds_opens_in_pillow_and_matches_oracle_decode(fmt, typ):
+    PIL = pytest.importorskip("PIL.Image")
+    img = synth.photo(64, 64, seed=3)
+    levels = [O.encode(m, int(fmt), int(typ), quality=1) for m in _mips(img, 5)]   # 64 .. 4
+    buf = io.BytesIO()
+    n = C.write_dds(buf, fmt, typ, 64, 64, levels)
+    data = buf.getvalue()
+    assert n == len(data) == 148 + sum(l.nbytes for l in levels)
+    info = C.read_dds(data)
+    assert (info["width"], info["height"], info["levels"], info["elements"]) == (64, 64, 5, 1)
+    assert data[info["offset"]:info["offset"] + levels[0].nbytes] == levels[0].tobytes()
+    im = PIL.open(io.BytesIO(data))
+    im.load()
+    got = np.asarray(im)
+    ref = O.decode(levels[0], int(fmt), 64, 64, int(typ))
+    if got.ndim == 2:
+        assert np.array_equal(got, ref[..., 0])
+    elif fmt == Format.BC5:
+        assert np.array_equal(got[..., :2], ref[..., :2])
+    else:
+        c = got.shape[2]
+        assert np.array_equal(got, ref[..., :c])
+
+
+def test_dds_header_fields_follow_savedds():
+    black = np.zeros((16, 16, 4), np.uint8)
+    black[..., 3] = 255                       # TextureSaveTest.cpp:83-91
+    pay = O.encode(black, int(Format.BC7), 0, quality=0)
+    buf = io.BytesIO()
+    C.write_dds(buf, Format.BC7, Type.UNorm, 16, 16, [pay], color_space=ColorSpace.sRGB)
+    d = buf.getvalue()
+    magic, size, flags, h, w, pitch, depth, mips = struct.unpack_from("<8I", d, 0)
+    assert magic == 0x20534444 and size == 124
+    assert flags == (0x1 | 0x2 | 0x4 | 0x1000 | 0x20000 | 0x8)   # Required | MipmapCount | Pitch
+    assert (h, w, depth, mips) == (16, 16, 0, 1)
+    assert pitch == 4 * 16                                        # blocks per row * block size
+    pf_size, pf_flags = struct.unpack_from("<2I", d, 4 + 72)
+    assert (pf_size, pf_flags, d[4 + 80:4 + 84]) == (32, 0x4, b"DX10")
+    assert struct.unpack_from("<I", d, 4 + 104)[0] == 0x1000      # caps: texture only
+    dxgi, dim, misc, array, misc2 = struct.unpack_from("<5I", d, 128)
+    assert (dxgi, dim, misc, array, misc2) == (99, 3, 0, 1, 1)    # BC7_UNORM_SRGB, 2-D, straight alpha
+    assert len(d) == 148 + 256
+
+
+def test_dds_unsupported_pairs_and_size_checks():
+    with pytest.raises(ValueError):
+        C.write_dds(io.BytesIO(), Format.ETC1, Type.UNorm, 16, 16, [b"\0" * 128])   # no DXGI format
+    with pytest.raises(ValueError):
+        C.write_dds(io.BytesIO(), Format.BC1_RGB, Type.UNorm, 16, 16, [b"\0" * 100])
+
+
+def test_dds_array_order_is_element_then_mip():
+    a = [bytes([1]) * 128, bytes([2]) * 32]     # 16x16 BC1 + 8x8 mip
+    b = [bytes([3]) * 128, bytes([4]) * 32]
+    buf = io.BytesIO()
+    C.write_dds(buf, Format.BC1_RGB, Type.UNorm, 16, 16, [a, b])
+    d = buf.getvalue()
+    info = C.read_dds(d)
+    assert info["elements"] == 2 and info["levels"] == 2
+    body = d[info["offset"]:]
+    assert body == a[0] + a[1] + b[0] + b[1]
+    assert struct.unpack_from("<I", d, 4 + 104)[0] == (0x1000 | 0x400000 | 0x8)   # texture|mipmap|complex
+
+
+@pytest.mark.parametrize("fmt,typ,internal,base", [
+    (Format.BC7, Type.UNorm, 0x8E8C, 0x1908), (Format.ETC2_R8G8B8A8, Type.UNorm, 0x9278, 0x1908),
+    (Format.ASTC_6x6, Type.UNorm, 0x93B4, 0x1908), (Format.EAC_R11, Type.SNorm, 0x9271, 0x1903),
+    (Format.BC6H, Type.UFloat, 0x8E8F, 0x1907)])
+def test_ktx_layout_follows_savektx(fmt, typ, internal, base):
+    w, h = 24, 16
+    dims = C.mip_dims(w, h, 3)
+    levels = [bytes([i + 1]) * payload_size(fmt, typ, dw, dh) for i, (dw, dh) in enumerate(dims)]
+    buf = io.BytesIO()
+    n = C.write_ktx(buf, fmt, typ, w, h, levels)
+    d = buf.getvalue()
+    assert n == len(d) == 64 + sum(4 + len(l) for l in levels)
+    assert d[:12] == bytes([0xAB, 0x4B, 0x54, 0x58, 0x20, 0x31, 0x31, 0xBB, 0x0D, 0x0A, 0x1A, 0x0A])
+    f = struct.unpack_from("<13I", d, 12)
+    assert f[0] == 0x04030201
+    assert f[1:6] == (0, 1, 0, internal, base)            # type, typeSize, format, internal, base
+    assert f[6:13] == (w, h, 0, 0, 1, 3, 0)               # w, h, depth, array, faces, mips, kv bytes
+    off = 64
+    for l in levels:
+        assert struct.unpack_from("<I", d, off)[0] == len(l)
+        assert d[off + 4:off + 4 + len(l)] == l
+        off += 4 + len(l)
+
+
+def test_ktx_srgb_and_array():
+    lv = [bytes(16 * 4)]                                   # one 8x8 BC7 level per element
+    buf = io.BytesIO()
+    C.write_ktx(buf, Format.BC7, Type.UNorm, 8, 8, [lv, lv, lv], color_space=ColorSpace.sRGB)
+    d = buf.getvalue()
+    f = struct.unpack_from("<13I", d, 12)
+    assert f[4] == 0x8E8D and f[9] == 3                    # sRGB BPTC, 3 array elements
+    assert struct.unpack_from("<I", d, 64)[0] == 3 * 64    # imageSize covers all elements
