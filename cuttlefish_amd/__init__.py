@@ -5,11 +5,12 @@ include/cuttlefish_hip.h.  This package holds the host-side mirror of the
 reference interface for that one path (Texture.convert / Converter) used by the
 parity tests and bench.py; it never falls back to a CPU encoder.
 """
-from .api import (Alpha, CfhipError, ColorSpace, Context, Format, PixelType, Quality, Type,  # noqa: F401
+from .api import (Alpha, CfhipError, ColorSpace, Context, Format, PixelType, Quality,  # noqa: F401
+                  ResizeFilter, Type,
                   device_count, load_library, make_params, payload_size, query, shard_rows)
 from . import shard  # noqa: F401
 from .texture import Texture  # noqa: F401
 
 __all__ = ["Alpha", "CfhipError", "ColorSpace", "Context", "Format", "PixelType", "Quality",
-           "Type", "Texture", "device_count", "load_library", "make_params", "payload_size",
+           "ResizeFilter", "Type", "Texture", "device_count", "load_library", "make_params", "payload_size",
            "query", "shard", "shard_rows"]

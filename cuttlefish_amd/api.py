@@ -81,6 +81,15 @@ class ColorSpace(enum.IntEnum):
     sRGB = 1
 
 
+class ResizeFilter(enum.IntEnum):
+    """cuttlefish::Image::ResizeFilter (Image.h:79-86)."""
+    Box = 0
+    Linear = 1
+    Cubic = 2
+    CatmullRom = 3
+    BSpline = 4
+
+
 class PixelType(enum.IntEnum):
     RGBA8 = 0
     RGBA32F = 1
@@ -92,7 +101,7 @@ E_INVALID, E_UNSUPPORTED, E_CAPACITY, E_DEVICE, E_NO_DEVICE = -1, -2, -3, -4, -5
 EXPORTS = ["cfhip_abi_version", "cfhip_device_count", "cfhip_create", "cfhip_destroy",
            "cfhip_query", "cfhip_encode", "cfhip_encode_device", "cfhip_shard_rows",
            "cfhip_last_kernel_ms", "cfhip_last_kernel_name", "cfhip_last_error",
-           "cfhip_profile_begin", "cfhip_profile_end"]
+           "cfhip_profile_begin", "cfhip_profile_end", "cfhip_generate_mips_device"]
 
 
 class Params(ctypes.Structure):
@@ -162,6 +171,11 @@ def load_library(path: Optional[str] = None):
     L.cfhip_profile_end.restype = ctypes.c_int
     L.cfhip_last_error.argtypes = [ctypes.c_void_p]
     L.cfhip_last_error.restype = ctypes.c_char_p
+    L.cfhip_generate_mips_device.argtypes = [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32,
+        ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+        ctypes.c_uint32, ctypes.c_void_p]
+    L.cfhip_generate_mips_device.restype = ctypes.c_int
     _lib = L
     return L
 
@@ -281,6 +295,18 @@ class Context:
         self._check(self._lib.cfhip_encode_device(self._h, surf, len(surfaces),
                                                    ctypes.byref(params),
                                                    ctypes.c_void_p(stream) if stream else None))
+
+    def generate_mips_device(self, src: int, pixel_type, width: int, height: int,
+                             row_pitch_bytes: int, dst_levels: Sequence[int],
+                             color_space=ColorSpace.Linear, filter=0, stream: int = 0):
+        """Texture::generateMipmaps on the GPU: level k (k = 1..len(dst_levels)) of a width x height
+        texture into dst_levels[k-1] (device pointers, RGBA32F tightly packed), each level resized
+        from the previous one in linear space.  filter: ResizeFilter (0 Box, 1 Linear)."""
+        n = len(dst_levels) + 1
+        arr = (ctypes.c_void_p * max(len(dst_levels), 1))(*[ctypes.c_void_p(int(p)) for p in dst_levels])
+        self._check(self._lib.cfhip_generate_mips_device(
+            self._h, ctypes.c_void_p(int(src)), int(pixel_type), width, height, row_pitch_bytes,
+            int(color_space), int(filter), arr, n, ctypes.c_void_p(stream) if stream else None))
 
     def last_kernel_ms(self) -> float:
         return float(self._lib.cfhip_last_kernel_ms(self._h))

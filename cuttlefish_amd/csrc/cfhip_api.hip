@@ -25,6 +25,9 @@ extern "C" hipError_t cfhip_launch_etc(const cf_kparams* kp, int format, int pix
 	hipStream_t stream);
 extern "C" hipError_t cfhip_launch_bc6h(const cf_kparams* kp, int pixel_type, int is_signed,
 	hipStream_t stream);
+extern "C" hipError_t cfhip_launch_mip_resize(const void* src, int src_pixel_type, size_t pitch,
+	uint32_t sw, uint32_t sh, void* dst, uint32_t dw, uint32_t dh, int filter, int srgb,
+	hipStream_t stream);
 extern "C" hipError_t cfhip_launch_bc15(const cf_kparams* kp, int format, int pixel_type,
 	int snorm, hipStream_t stream);
 
@@ -717,6 +720,56 @@ int cfhip_encode_device(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n_
 	const cfhip_params* params, void* stream)
 {
 	return encode_impl(ctx, surfaces, n_surfaces, params, true, static_cast<hipStream_t>(stream));
+}
+
+int cfhip_generate_mips_device(cfhip_ctx* ctx, const void* src, int src_pixel_type,
+	uint32_t width, uint32_t height, size_t src_pitch_bytes, int color_space, int filter,
+	void* const* dst_levels, uint32_t levels, void* stream_)
+{
+	if (!ctx)
+		return fail(nullptr, CFHIP_E_INVALID, "ctx is NULL");
+	std::lock_guard<std::mutex> guard(ctx->lock);
+	if (!src || !width || !height || !levels || (levels > 1 && !dst_levels))
+		return fail(ctx, CFHIP_E_INVALID, "mip generation: NULL or empty argument");
+	if (src_pixel_type < CFHIP_PIXEL_RGBA8 || src_pixel_type > CFHIP_PIXEL_RGBA16F)
+		return fail(ctx, CFHIP_E_INVALID, "mip generation: pixel type %d", src_pixel_type);
+	if (color_space != CFHIP_COLOR_LINEAR && color_space != CFHIP_COLOR_SRGB)
+		return fail(ctx, CFHIP_E_INVALID, "mip generation: colour space %d", color_space);
+	if (filter != CFHIP_FILTER_BOX && filter != CFHIP_FILTER_LINEAR)
+		return fail(ctx, CFHIP_E_UNSUPPORTED, "resize filter %d is implemented by FreeImage_Rescale "
+			"in the reference (third-party, absent); only Box and Linear (the in-tree fallback, "
+			"Image.cpp:1393-1505) exist here", filter);
+	// maxMipmapLevels for a 2-D texture: floor(log2(max(w, h))) + 1 (Texture.cpp)
+	uint32_t max_levels = 1;
+	for (uint32_t d = width > height ? width : height; d > 1; d >>= 1)
+		++max_levels;
+	if (levels > max_levels)
+		return fail(ctx, CFHIP_E_INVALID, "%u mip levels requested, a %ux%u texture has %u", levels,
+			width, height, max_levels);
+	const size_t texel = src_pixel_type == CFHIP_PIXEL_RGBA8 ? 4 : (src_pixel_type == CFHIP_PIXEL_RGBA32F ? 16 : 8);
+	if (src_pitch_bytes < (size_t)width*texel)
+		return fail(ctx, CFHIP_E_INVALID, "mip generation: row pitch smaller than a row");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : ctx->stream;
+	// level k from level k-1, as Texture::generateMipmaps does (Texture.cpp:1480-1487)
+	const void* prev = src;
+	int prev_type = src_pixel_type;
+	size_t prev_pitch = src_pitch_bytes;
+	uint32_t pw = width, ph = height;
+	for (uint32_t k = 1; k < levels; ++k) {
+		if (!dst_levels[k - 1])
+			return fail(ctx, CFHIP_E_INVALID, "mip generation: dst_levels[%u] is NULL", k - 1);
+		const uint32_t w = (width >> k) ? (width >> k) : 1u, h = (height >> k) ? (height >> k) : 1u;
+		HIP_TRY(ctx, cfhip_launch_mip_resize(prev, prev_type, prev_pitch, pw, ph, dst_levels[k - 1], w, h,
+			filter, color_space == CFHIP_COLOR_SRGB ? 1 : 0, stream));
+		prev = dst_levels[k - 1];
+		prev_type = CFHIP_PIXEL_RGBA32F;
+		prev_pitch = (size_t)w*16u;
+		pw = w; ph = h;
+	}
+	if (!stream_)
+		HIP_TRY(ctx, hipStreamSynchronize(stream));
+	return CFHIP_OK;
 }
 
 float cfhip_last_kernel_ms(cfhip_ctx* ctx)

@@ -1,0 +1,143 @@
+// mipgen.hip -- mip-level resize on the GPU: one thread per output
+// texel, double arithmetic, float storage -- the arithmetic of the reference's in-tree
+// Image::resize fallback (lib/src/Image.cpp:1393-1505) with its linear-space wrapper (:1337-1346)
+// and Color.h's sRGBToLinear / linearToSRGB (:224-242).  Twin of oracle/mipgen.c; the only
+// difference a GPU can show is the last bit of pow() (ocml vs libm), i.e. <= 1 float ulp after
+// the float store, which tests/test_gpu_mipgen.py bounds.
+//
+// HBM-bound by construction (16 B written per texel, 4 x 4..16 B read), the opposite corner
+// of the roofline from the encoders; it exists so that a mip chain can be produced next to
+// the encoder's input without a host round trip.
+#include "cf_device.h"
+
+namespace {
+
+__device__ __forceinline__ double srgb_to_linear(double c)
+{
+	if (c <= 0.04045)
+		return c/12.92;
+	return pow((c + 0.055)/1.055, 2.4);
+}
+
+__device__ __forceinline__ double linear_to_srgb(double c)
+{
+	if (c <= 0.0031308)
+		return c*12.92;
+	return 1.055*pow(c, 1.0/2.4) - 0.055;
+}
+
+// source texel as the reference's RGBAF storage holds it
+template <int SRC_PIX>
+__device__ __forceinline__ float4 load_rgbaf(const uint8_t* row, uint32_t x)
+{
+	if (SRC_PIX == 0) {
+		const uint32_t p = *reinterpret_cast<const uint32_t*>(row + (size_t)x*4u);
+		// Image::convert RGBA8 -> RGBAF: toDoubleNorm (v/255.0, Image.cpp:293-296), float store
+		return make_float4((float)((double)(p & 255u)/255.0), (float)((double)((p >> 8) & 255u)/255.0),
+			(float)((double)((p >> 16) & 255u)/255.0), (float)((double)(p >> 24)/255.0));
+	} else if (SRC_PIX == 1) {
+		return *reinterpret_cast<const float4*>(row + (size_t)x*16u);
+	} else {
+		const uint2 h = *reinterpret_cast<const uint2*>(row + (size_t)x*8u);
+		union { unsigned short u; _Float16 f; } c0, c1, c2, c3;
+		c0.u = (unsigned short)(h.x & 0xFFFFu); c1.u = (unsigned short)(h.x >> 16);
+		c2.u = (unsigned short)(h.y & 0xFFFFu); c3.u = (unsigned short)(h.y >> 16);
+		return make_float4((float)c0.f, (float)c1.f, (float)c2.f, (float)c3.f);
+	}
+}
+
+template <int SRC_PIX>
+__global__ void __launch_bounds__(256)
+cfhip_mip_resize_kernel(const uint8_t* __restrict__ src, size_t pitch, uint32_t sw, uint32_t sh,
+	float4* __restrict__ dst, uint32_t dw, uint32_t dh, int filter, int srgb)
+{
+	const uint32_t x = blockIdx.x*64u + (threadIdx.x & 63u);
+	const uint32_t y = blockIdx.y*4u + (threadIdx.x >> 6);
+	if (x >= dw || y >= dh)
+		return;
+	const double invScaleX = (double)sw/(double)dw, invScaleY = (double)sh/(double)dh;
+	double offsetX = invScaleX > 1.0 ? invScaleX : 1.0;
+	double offsetY = invScaleY > 1.0 ? invScaleY : 1.0;
+	const double filterScaleX = 1.0/offsetX, filterScaleY = 1.0/offsetY;
+	if (filter == 0) {
+		offsetX *= 0.5;
+		offsetY *= 0.5;
+	}
+	const double centerY = ((double)y + 0.5)*invScaleY, centerX = ((double)x + 0.5)*invScaleX;
+	const int t0 = (int)(centerY - offsetY + 0.5), l0 = (int)(centerX - offsetX + 0.5);
+	const uint32_t top = (uint32_t)(t0 > 0 ? t0 : 0), left = (uint32_t)(l0 > 0 ? l0 : 0);
+	uint32_t bottom = (uint32_t)(centerY + offsetY + 0.5), right = (uint32_t)(centerX + offsetX + 0.5);
+	bottom = bottom < sh ? bottom : sh;
+	right = right < sw ? right : sw;
+	double c0 = 0, c1 = 0, c2 = 0, c3 = 0, total = 0;
+	for (uint32_t i = top; i < bottom; ++i) {
+		const double dy = fabs((double)i + 0.5 - centerY)*filterScaleY;
+		double scaleY;
+		if (filter == 0) {
+			if (dy > 0.5)
+				continue;
+			scaleY = 1.0;
+		} else {
+			scaleY = 1.0 - dy;
+			scaleY = scaleY > 0.0 ? scaleY : 0.0;
+			if (scaleY == 0.0)
+				continue;
+		}
+		const uint8_t* row = src + (size_t)i*pitch;
+		for (uint32_t j = left; j < right; ++j) {
+			const double dx = fabs((double)j + 0.5 - centerX)*filterScaleX;
+			double scaleX;
+			if (filter == 0) {
+				if (dx > 0.5)
+					continue;
+				scaleX = 1.0;
+			} else {
+				scaleX = 1.0 - dx;
+				scaleX = scaleX > 0.0 ? scaleX : 0.0;
+				if (scaleX == 0.0)
+					continue;
+			}
+			float4 p = load_rgbaf<SRC_PIX>(row, j);
+			if (srgb) {   // the linear copy of the source level is an RGBAF image: float store
+				p.x = (float)srgb_to_linear((double)p.x);
+				p.y = (float)srgb_to_linear((double)p.y);
+				p.z = (float)srgb_to_linear((double)p.z);
+			}
+			if (filter == 0) {
+				c0 += (double)p.x; c1 += (double)p.y; c2 += (double)p.z; c3 += (double)p.w;
+				total += 1.0;   // the reference counts texels in an unsigned: exact either way
+			} else {
+				const double scale = scaleX*scaleY;
+				c0 += (double)p.x*scale; c1 += (double)p.y*scale; c2 += (double)p.z*scale;
+				c3 += (double)p.w*scale;
+				total += scale;
+			}
+		}
+	}
+	float4 o = make_float4((float)(c0/total), (float)(c1/total), (float)(c2/total), (float)(c3/total));
+	if (srgb) {
+		o.x = (float)linear_to_srgb((double)o.x);
+		o.y = (float)linear_to_srgb((double)o.y);
+		o.z = (float)linear_to_srgb((double)o.z);
+	}
+	dst[(size_t)y*dw + x] = o;
+}
+
+} // namespace
+
+// one level: src (any pixel type) -> dst (RGBA32F, tightly packed)
+extern "C" hipError_t cfhip_launch_mip_resize(const void* src, int src_pixel_type, size_t pitch,
+	uint32_t sw, uint32_t sh, void* dst, uint32_t dw, uint32_t dh, int filter, int srgb,
+	hipStream_t stream)
+{
+	const dim3 grid((dw + 63u)/64u, (dh + 3u)/4u, 1), block(256, 1, 1);
+	const uint8_t* s = static_cast<const uint8_t*>(src);
+	float4* d = static_cast<float4*>(dst);
+	if (src_pixel_type == 0)
+		hipLaunchKernelGGL((cfhip_mip_resize_kernel<0>), grid, block, 0, stream, s, pitch, sw, sh, d, dw, dh, filter, srgb);
+	else if (src_pixel_type == 1)
+		hipLaunchKernelGGL((cfhip_mip_resize_kernel<1>), grid, block, 0, stream, s, pitch, sw, sh, d, dw, dh, filter, srgb);
+	else
+		hipLaunchKernelGGL((cfhip_mip_resize_kernel<2>), grid, block, 0, stream, s, pitch, sw, sh, d, dw, dh, filter, srgb);
+	return hipGetLastError();
+}

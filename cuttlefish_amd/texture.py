@@ -85,6 +85,33 @@ class Texture:
         self._images[mip][depth] = image
         return True
 
+    def generate_mipmaps(self, filter=api.ResizeFilter.CatmullRom, mip_levels: Optional[int] = None) -> bool:
+        """Texture::generateMipmaps (Texture.cpp:1320-1514, 2-D path): every level from the
+        previous one through Image::resize in linear space, on the GPU
+        (cfhip_generate_mips_device).  The reference's default CatmullRom (and Cubic, BSpline) is
+        FreeImage code that is absent: those return False here; Box and Linear are the in-tree
+        fallback arithmetic.  Levels come back as RGBAF (float32) images, like the reference's."""
+        if self._textures or self._depth or any(im is None for im in self._images[0]):
+            return False
+        w, h = self._w, self._h
+        max_levels = max(w, h).bit_length()
+        levels = max_levels if mip_levels is None else min(max(int(mip_levels), 1), max_levels)
+        if api.ResizeFilter(filter) not in (api.ResizeFilter.Box, api.ResizeFilter.Linear):
+            return False
+        import torch  # device memory + stream: plumbing only
+        if self._ctx is None:
+            self._ctx = api.Context(self._device_id)
+        base = np.ascontiguousarray(self._images[0][0])
+        src = torch.from_numpy(base).to("cuda:%d" % self._device_id)
+        dsts = [torch.empty((max(1, h >> k), max(1, w >> k), 4), dtype=torch.float32,
+                            device=src.device) for k in range(1, levels)]
+        self._ctx.generate_mips_device(src.data_ptr(), api.pixel_type_of(base), w, h,
+                                       base.strides[0], [d.data_ptr() for d in dsts],
+                                       color_space=self._color_space, filter=int(filter))
+        self._mips = levels
+        self._images = [[base]] + [[d.cpu().numpy()] for d in dsts]
+        return True
+
     def images_complete(self) -> bool:
         return all(im is not None for level in self._images for im in level)
 

@@ -169,6 +169,32 @@ int cfhip_encode(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n_surface
 int cfhip_encode_device(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n_surfaces,
 	const cfhip_params* params, void* stream);
 
+/* Mip-chain generation on the GPU, feeding cfhip_encode_device
+ * without a host round trip.  Stands in for Texture::generateMipmaps (lib/src/Texture.cpp:
+ * 1320-1514, 2-D path :1442-1511): level k = Image::resize(level k-1, max(1, w >> k),
+ * max(1, h >> k), filter) (lib/src/Image.cpp:1324-1511), resized in LINEAR space -- an sRGB
+ * image is converted with sRGBToLinear, resized and converted back with linearToSRGB
+ * (Image.cpp:1337-1346, Color.h:224-242; alpha is not converted) -- on RGBAF images whose
+ * float storage rounds every intermediate.  Filters: the reference's in-tree fallback Box
+ * (Image.cpp:1393-1447) and Linear (:1448-1505) arithmetic; its default CatmullRom and the
+ * other FreeImage_Rescale filters are third-party code that is absent, so they return
+ * CFHIP_E_UNSUPPORTED.
+ *   src / src_pixel_type / src_pitch_bytes : level 0 on the device (RGBA8 is read as v/255.0,
+ *                                            RGBA16F / RGBA32F as stored)
+ *   dst_levels[k-1], k = 1..levels-1       : device buffers that receive level k as tightly
+ *                                            packed RGBA32F (16 B/texel), the reference's RGBAF
+ * Kernels are enqueued on `stream` (NULL = the context's stream, then the call synchronises). */
+enum cfhip_resize_filter {     /* Image::ResizeFilter (Image.h), same values */
+	CFHIP_FILTER_BOX = 0,
+	CFHIP_FILTER_LINEAR = 1,
+	CFHIP_FILTER_CUBIC = 2,
+	CFHIP_FILTER_CATMULL_ROM = 3,
+	CFHIP_FILTER_BSPLINE = 4
+};
+int cfhip_generate_mips_device(cfhip_ctx* ctx, const void* src, int src_pixel_type,
+	uint32_t width, uint32_t height, size_t src_pitch_bytes, int color_space, int filter,
+	void* const* dst_levels, uint32_t levels, void* stream);
+
 /* Block-row sharding of one surface across `world` ranks:
  * rank r owns block rows [*row_begin, *row_end).  Pure function, no communication. */
 int cfhip_shard_rows(uint32_t block_rows, int rank, int world, uint32_t* row_begin,

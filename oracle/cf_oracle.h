@@ -75,6 +75,13 @@ int cfo_decode_bc6h_image(const void* blocks, int type, uint32_t width, uint32_t
 	uint16_t* rgb_out);
 uint16_t cfo_float_to_half(float f);
 
+/* mip-level resize of RGBAF images (mipgen.c): Image::resize's in-tree Box (0) / Linear (1)
+ * fallback in linear space, with the sRGB round trip of Image.cpp:1337-1346 */
+double cfo_srgb_to_linear(double c);
+double cfo_linear_to_srgb(double c);
+int cfo_resize_rgbaf(const float* src, unsigned sw, unsigned sh, float* dst, unsigned dw,
+	unsigned dh, int filter, int color_space);
+
 /* single-block encoders (inputs already quantised as the reference does) */
 void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p);
 

@@ -156,3 +156,59 @@ def decode(blocks: np.ndarray, fmt, width: int, height: int, typ=0) -> np.ndarra
     if rc != 0:
         raise RuntimeError("cfo_decode failed: %d" % rc)
     return out
+
+
+# ---- mip-level resize (oracle/mipgen.c) --------------------------------------------------
+
+def resize_rgbaf(img: np.ndarray, width: int, height: int, filter=0, color_space=0) -> np.ndarray:
+    """Image::resize of an RGBAF image (h, w, 4) float32 -> (height, width, 4) float32."""
+    img = np.ascontiguousarray(img, np.float32)
+    h, w = img.shape[:2]
+    out = np.zeros((height, width, 4), np.float32)
+    L = lib()
+    L.cfo_resize_rgbaf.restype = ctypes.c_int
+    L.cfo_resize_rgbaf.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p,
+                                   ctypes.c_uint, ctypes.c_uint, ctypes.c_int, ctypes.c_int]
+    rc = L.cfo_resize_rgbaf(img.ctypes.data, w, h, out.ctypes.data, width, height, int(filter),
+                            int(color_space))
+    if rc != 0:
+        raise RuntimeError("cfo_resize_rgbaf failed: %d" % rc)
+    return out
+
+
+def mip_chain(img: np.ndarray, levels: int, filter=0, color_space=0):
+    """Texture::generateMipmaps (2-D): [level 0 as RGBAF, level 1, ...], level k from level k-1."""
+    if img.dtype == np.uint8:
+        base = (img.astype(np.float64) / 255.0).astype(np.float32)     # toDoubleNorm, float store
+    else:
+        base = img.astype(np.float32)
+    h, w = base.shape[:2]
+    out = [base]
+    for k in range(1, levels):
+        out.append(resize_rgbaf(out[-1], max(1, w >> k), max(1, h >> k), filter, color_space))
+    return out
+
+
+def color_fns():
+    L = lib()
+    for n in ("cfo_srgb_to_linear", "cfo_linear_to_srgb"):
+        getattr(L, n).restype = ctypes.c_double
+        getattr(L, n).argtypes = [ctypes.c_double]
+    return L.cfo_srgb_to_linear, L.cfo_linear_to_srgb
+
+
+REF_LIB_PATH = os.path.join(ORACLE_DIR, "_ref", "libcf_ref.so")
+
+
+def ref_lib():
+    """oracle/_ref/libcf_ref.so: the reference's own Color.h compiled (`make -C oracle ref`, only
+    where /root/reference is mounted; the built file travels to the GPU box).  None if absent."""
+    if not os.path.exists(REF_LIB_PATH):
+        return None
+    R = ctypes.CDLL(REF_LIB_PATH)
+    for n in ("cfref_srgb_to_linear", "cfref_linear_to_srgb"):
+        getattr(R, n).restype = ctypes.c_double
+        getattr(R, n).argtypes = [ctypes.c_double]
+    R.cfref_to_grayscale.restype = ctypes.c_double
+    R.cfref_to_grayscale.argtypes = [ctypes.c_double] * 3
+    return R

@@ -1,0 +1,132 @@
+"""GPU mip-chain generation (cfhip_generate_mips_device) vs the oracle restatement of
+Texture::generateMipmaps / Image::resize.
+
+Tolerance (floating-point path): the linear-colour-space resize is pure double add / divide
+with float stores -> bit-exact.  The sRGB round trip goes through pow(): ocml (GPU) and libm
+(CPU) may differ in the last bit of the double, which can move the float store by 1 ulp; the
+test allows 2 float ulps per level-to-level step and reports how many texels differ at all.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from cuttlefish_amd import CfhipError, ColorSpace, Context, Format, PixelType, Type, make_params, \
+    payload_size, synth
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _gpu_chain(ctx, base, levels, color_space, filt):
+    h, w = base.shape[:2]
+    src = torch.from_numpy(np.ascontiguousarray(base)).cuda()
+    if base.dtype == np.uint8:
+        pt, pitch = PixelType.RGBA8, w*4
+    elif base.dtype == np.float16:
+        pt, pitch = PixelType.RGBA16F, w*8
+    else:
+        pt, pitch = PixelType.RGBA32F, w*16
+    dsts = [torch.empty((max(1, h >> k), max(1, w >> k), 4), dtype=torch.float32, device="cuda")
+            for k in range(1, levels)]
+    ctx.generate_mips_device(src.data_ptr(), pt, w, h, pitch, [d.data_ptr() for d in dsts],
+                             color_space=color_space, filter=filt)
+    return [d.cpu().numpy() for d in dsts], dsts, src
+
+
+def _ulps(a, b):
+    ai = a.view(np.int32).astype(np.int64)
+    bi = b.view(np.int32).astype(np.int64)
+    return np.abs(ai - bi)
+
+
+@pytest.mark.parametrize("filt", [0, 1])
+def test_linear_space_chain_is_bit_exact(filt):
+    rng = np.random.default_rng(1)
+    base = rng.random((192, 256, 4)).astype(np.float32)
+    with Context(0) as ctx:
+        got, _, _ = _gpu_chain(ctx, base, 9, ColorSpace.Linear, filt)
+    ref = O.mip_chain(base, 9, filter=filt, color_space=0)[1:]
+    for g, r in zip(got, ref):
+        assert g.shape == r.shape
+        assert np.array_equal(g, r)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float16])
+def test_base_level_pixel_types(dtype):
+    img = synth.photo(96, 64, seed=2)
+    base = img if dtype == np.uint8 else (img.astype(np.float32)/255.0).astype(np.float16)
+    with Context(0) as ctx:
+        got, _, _ = _gpu_chain(ctx, base, 7, ColorSpace.Linear, 0)
+    ref = O.mip_chain(base, 7)[1:]
+    for g, r in zip(got, ref):
+        assert np.array_equal(g, r)
+
+
+def test_srgb_chain_within_pow_rounding():
+    img = synth.photo(256, 256, seed=4)
+    with Context(0) as ctx:
+        got, _, _ = _gpu_chain(ctx, img, 9, ColorSpace.sRGB, 0)
+        # level k from the GPU's own level k-1 on the CPU: isolates one resize step
+        prev = (img.astype(np.float64)/255.0).astype(np.float32)
+        worst, differing, total = 0, 0, 0
+        for k, g in enumerate(got, start=1):
+            r = O.resize_rgbaf(prev, g.shape[1], g.shape[0], 0, 1)
+            u = _ulps(g, r)
+            worst = max(worst, int(u.max()))
+            differing += int((u > 0).sum())
+            total += u.size
+            assert np.array_equal(g[..., 3], r[..., 3])          # alpha never sees pow()
+            prev = g
+    assert worst <= 2, worst
+    assert differing <= total*0.02, (differing, total)
+
+
+def test_unsupported_filter_and_bad_arguments():
+    x = torch.zeros((8, 8, 4), dtype=torch.float32, device="cuda")
+    d = torch.zeros((4, 4, 4), dtype=torch.float32, device="cuda")
+    with Context(0) as ctx:
+        with pytest.raises(CfhipError) as e:
+            ctx.generate_mips_device(x.data_ptr(), PixelType.RGBA32F, 8, 8, 128, [d.data_ptr()], filter=3)
+        assert e.value.code == -2                                # CFHIP_E_UNSUPPORTED: FreeImage's filter
+        with pytest.raises(CfhipError) as e:
+            ctx.generate_mips_device(x.data_ptr(), PixelType.RGBA32F, 8, 8, 64, [d.data_ptr()])
+        assert e.value.code == -1                                # pitch smaller than a row
+        with pytest.raises(CfhipError):
+            ctx.generate_mips_device(x.data_ptr(), PixelType.RGBA32F, 8, 8, 128, [d.data_ptr()]*6)   # > 4 levels
+
+
+def test_mips_feed_the_encoder_without_leaving_the_gpu():
+    img = synth.photo(512, 512, seed=6)
+    fmt, typ = Format.BC7, Type.UNorm
+    with Context(0) as ctx:
+        got, dsts, src = _gpu_chain(ctx, img, 8, ColorSpace.Linear, 0)
+        p = make_params(fmt, typ, 2)
+        surfaces, outs = [], []
+        levels = [(src, PixelType.RGBA8, 512, 512, 512*4)] + \
+            [(d, PixelType.RGBA32F, d.shape[1], d.shape[0], d.shape[1]*16) for d in dsts]
+        for t, pt, w, h, pitch in levels:
+            o = torch.empty(payload_size(fmt, typ, w, h), dtype=torch.uint8, device="cuda")
+            outs.append(o)
+            surfaces.append({"pixels": t.data_ptr(), "pixel_type": pt, "width": w, "height": h,
+                             "row_pitch_bytes": pitch, "out": o.data_ptr(), "out_capacity": o.numel()})
+        ctx.encode_device(surfaces, p)                           # one batched launch, all 8 levels
+        torch.cuda.synchronize()
+    ref_chain = O.mip_chain(img, 8)
+    for k, o in enumerate(outs):
+        src_k = img if k == 0 else ref_chain[k]                  # linear space: GPU mips == oracle mips
+        assert np.array_equal(o.cpu().numpy(), O.encode(src_k, int(fmt), 0, quality=2, threads=8))
+
+
+def test_texture_generate_mipmaps_mirror():
+    from cuttlefish_amd import Quality, ResizeFilter, Texture
+    img = synth.photo(64, 32, seed=8)
+    t = Texture(64, 32)
+    assert t.set_image(img)
+    assert not t.generate_mipmaps()                      # default CatmullRom: FreeImage only
+    assert t.generate_mipmaps(ResizeFilter.Box)
+    assert t.mip_level_count() == 7                      # 64x32 .. 1x1
+    assert t.convert(Format.BC7, Type.UNorm, Quality.Low)
+    ref = O.mip_chain(img, 7)
+    for k in range(7):
+        src_k = img if k == 0 else ref[k]
+        assert np.array_equal(np.asarray(t.data(k)), O.encode(src_k, int(Format.BC7), 0, quality=1))

@@ -1,0 +1,117 @@
+"""Mip-level resize oracle (oracle/mipgen.c), SURVEY section 8(f) row 1.
+
+Pinning: the colour-space functions against the REFERENCE's own Color.h compiled into
+oracle/_ref/libcf_ref.so (bit for bit, when that build is present); the resize loops against a
+direct Python transcription of the fallback's index arithmetic and against closed forms.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+
+def test_color_functions_equal_the_reference_build():
+    R = O.ref_lib()
+    if R is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference): make -C oracle ref")
+    s2l, l2s = O.color_fns()
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([np.linspace(0.0, 1.0, 4097), rng.random(20000), [0.04045, 0.0031308, 1.5, 4.0]])
+    for x in xs:
+        x = float(x)
+        assert s2l(x) == R.cfref_srgb_to_linear(x)
+        assert l2s(x) == R.cfref_linear_to_srgb(x)
+
+
+def test_color_function_known_values():
+    s2l, l2s = O.color_fns()
+    assert s2l(0.0) == 0.0 and l2s(0.0) == 0.0
+    assert abs(s2l(1.0) - 1.0) < 1e-15 and abs(l2s(1.0) - 1.0) < 1e-15
+    assert s2l(0.04045) == 0.04045/12.92                      # the linear toe, Color.h:226-227
+    assert l2s(0.0031308) == 0.0031308*12.92
+    assert abs(s2l(0.5) - 0.21404114048223255) < 1e-15        # ((0.5+0.055)/1.055)^2.4
+    for x in (0.001, 0.2, 0.7):
+        assert abs(l2s(s2l(x)) - x) < 1e-12
+
+
+def _box_py(src, dw, dh):
+    """Image.cpp:1393-1447 transcribed with Python floats (= C doubles)."""
+    sh, sw = src.shape[:2]
+    isx, isy = sw/dw, sh/dh
+    ox, oy = max(isx, 1.0), max(isy, 1.0)
+    fx, fy = 1.0/ox, 1.0/oy
+    ox *= 0.5
+    oy *= 0.5
+    out = np.zeros((dh, dw, 4), np.float32)
+    for y in range(dh):
+        cy = (y + 0.5)*isy
+        top, bottom = max(int(cy - oy + 0.5), 0), min(int(cy + oy + 0.5), sh)
+        for x in range(dw):
+            cx = (x + 0.5)*isx
+            left, right = max(int(cx - ox + 0.5), 0), min(int(cx + ox + 0.5), sw)
+            acc, n = [0.0]*4, 0
+            for i in range(top, bottom):
+                if abs(i + 0.5 - cy)*fy > 0.5:
+                    continue
+                for j in range(left, right):
+                    if abs(j + 0.5 - cx)*fx > 0.5:
+                        continue
+                    for k in range(4):
+                        acc[k] += float(src[i, j, k])
+                    n += 1
+            out[y, x] = [np.float32(a/n) for a in acc]
+    return out
+
+
+@pytest.mark.parametrize("sw,sh,dw,dh", [(16, 16, 8, 8), (10, 6, 5, 3), (7, 5, 3, 2), (9, 1, 4, 1),
+                                         (1, 8, 1, 4), (5, 5, 2, 2), (3, 3, 1, 1), (8, 8, 3, 5)])
+def test_box_resize_matches_the_transcribed_loops(sw, sh, dw, dh):
+    rng = np.random.default_rng(sw*100 + sh)
+    src = rng.random((sh, sw, 4)).astype(np.float32)
+    got = O.resize_rgbaf(src, dw, dh, filter=0, color_space=0)
+    assert np.array_equal(got, _box_py(src, dw, dh))
+
+
+def test_box_halving_is_the_2x2_mean_in_double():
+    rng = np.random.default_rng(9)
+    src = rng.random((32, 48, 4)).astype(np.float32)
+    got = O.resize_rgbaf(src, 24, 16)
+    s = src.astype(np.float64)
+    ref = ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2])/4.0).astype(np.float32)
+    assert np.array_equal(got, ref)
+
+
+def test_linear_filter_properties():
+    const = np.full((12, 20, 4), 0.375, np.float32)
+    assert np.array_equal(O.resize_rgbaf(const, 10, 6, filter=1), np.full((6, 10, 4), 0.375, np.float32))
+    # horizontal ramp stays a ramp under the triangle filter (interior texels)
+    ramp = np.tile(np.linspace(0, 1, 32, dtype=np.float32)[None, :, None], (8, 1, 4))
+    out = O.resize_rgbaf(ramp, 16, 4, filter=1)
+    d = np.diff(out[0, 2:-2, 0].astype(np.float64))
+    assert np.allclose(d, d[0], rtol=0, atol=1e-6)
+
+
+def test_srgb_round_trip_and_alpha_untouched():
+    rng = np.random.default_rng(3)
+    src = rng.random((16, 16, 4)).astype(np.float32)
+    lin = O.resize_rgbaf(src, 8, 8, color_space=0)
+    srgb = O.resize_rgbaf(src, 8, 8, color_space=1)
+    assert np.array_equal(lin[..., 3], srgb[..., 3])           # alpha is averaged as stored
+    assert np.all(srgb[..., :3] >= lin[..., :3] - 1e-6)        # mean in linear light is brighter (convexity)
+    # explicit model of Image.cpp:1337-1346 on one texel
+    s2l, l2s = O.color_fns()
+    blk = src[0:2, 0:2, 0]
+    lin4 = [np.float32(s2l(float(v))) for v in (blk[0, 0], blk[0, 1], blk[1, 0], blk[1, 1])]
+    m = np.float32((float(lin4[0]) + float(lin4[1]) + float(lin4[2]) + float(lin4[3]))/4)
+    assert srgb[0, 0, 0] == np.float32(l2s(float(m)))
+
+
+def test_chain_and_errors():
+    img = (np.arange(64*32*4) % 251).astype(np.uint8).reshape(32, 64, 4)
+    chain = O.mip_chain(img, 7)
+    assert [c.shape[:2] for c in chain] == [(32, 64), (16, 32), (8, 16), (4, 8), (2, 4), (1, 2), (1, 1)]
+    assert chain[0].dtype == np.float32 and chain[0][0, 0, 1] == np.float32(1/255.0)
+    with pytest.raises(RuntimeError):
+        O.resize_rgbaf(chain[0], 8, 8, filter=3)               # CatmullRom: FreeImage only
