@@ -41,15 +41,24 @@ struct CfgView {
 
 __device__ __forceinline__ int unq_weight(int q, int bits)
 {
-	int v;
-	switch (bits) {
-		case 1: v = q ? 63 : 0; break;
-		case 2: v = (q << 4) | (q << 2) | q; break;
-		case 3: v = (q << 3) | q; break;
-		case 4: v = (q << 2) | (q >> 2); break;
-		default: v = (q << 1) | (q >> 4); break;
-	}
+	// bit replication of a `bits`-wide value to 6 bits: q * rep >> sh with
+	// (rep, sh) = (63,0) (21,0) (9,0) (17,2) (33,4) for bits = 1..5
+	const int rep = bits == 1 ? 63 : (bits == 2 ? 21 : (bits == 3 ? 9 : (bits == 4 ? 17 : 33)));
+	const int sh = bits == 4 ? 2 : (bits == 5 ? 4 : 0);
+	const int v = (q*rep) >> sh;
 	return v > 32 ? v + 1 : v;
+}
+
+// floor(num/den) for num < 2^26, den > 0, quotient < 2^16: float estimate + exact fix-up
+// (a full 32-bit integer division is ~35 VALU instructions and the kernel is issue-bound)
+__device__ __forceinline__ uint32_t div_small(uint32_t num, uint32_t den, float rden)
+{
+	uint32_t q = (uint32_t)((float)num*rden);
+	int r = (int)num - (int)(q*den);
+	q = r < 0 ? q - 1u : q;
+	r = r < 0 ? r + (int)den : r;
+	q = r >= (int)den ? q + 1u : q;
+	return q;
 }
 
 __device__ __forceinline__ float clampf255(float x) { return x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x); }
@@ -64,10 +73,13 @@ __device__ __forceinline__ int texel_weight(const CfgView& cfg, uint32_t i, cons
 	const uint2 f = cfg.infill(i);
 	const uint32_t v0 = f.x & 255u, w00 = (f.x >> 8) & 255u, w01 = (f.x >> 16) & 255u,
 		w10 = f.x >> 24, w11 = f.y & 255u;
-	int v = (int)w00*unq_weight(qcol[v0*64u], bits) + 8;
-	if (w01) v += (int)w01*unq_weight(qcol[(v0 + 1u)*64u], bits);
-	if (w10) v += (int)w10*unq_weight(qcol[(v0 + N)*64u], bits);
-	if (w11) v += (int)w11*unq_weight(qcol[(v0 + N + 1u)*64u], bits);
+	// straight-line: a zero factor reads a neighbour inside the lane's 64-entry column (grid
+	// index clamped) and multiplies it away -- no per-lane branches on the load chain
+	const uint32_t g1 = v0 + 1u < 64u ? v0 + 1u : v0, g2 = v0 + N < 64u ? v0 + N : v0,
+		g3 = v0 + N + 1u < 64u ? v0 + N + 1u : v0;
+	const int q0 = qcol[v0*64u], q1 = qcol[g1*64u], q2 = qcol[g2*64u], q3 = qcol[g3*64u];
+	const int v = (int)w00*unq_weight(q0, bits) + (int)w01*unq_weight(q1, bits) +
+		(int)w10*unq_weight(q2, bits) + (int)w11*unq_weight(q3, bits) + 8;
 	return v >> 4;
 }
 
@@ -75,7 +87,7 @@ __device__ __forceinline__ uint32_t astc_error(const uint32_t* tp, uint32_t n, u
 	const int (&e0)[4], const int (&e1)[4], const CfgView& cfg, const uint8_t* qcol, uint32_t N, int bits)
 {
 	uint32_t err = 0;
-#pragma unroll 1
+#pragma unroll 4
 	for (uint32_t i = 0; i < n; ++i) {
 		const int w = texel_weight(cfg, i, qcol, N, bits);
 		const uint32_t p = tp[i];
@@ -101,6 +113,15 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	__shared__ uint16_t lane_num[4][64*64];     // [wave][grid point * 64 + lane]
 	__shared__ uint8_t lane_q[4][64*64];
 	__shared__ uint4 outb[CF_BLOCKS_PER_WG];
+	// both config sets (RGB, RGBA) of this footprint: the infill records are read 3-4 times
+	// per texel and lane, and a global (L1/L2) load on that chain costs several hundred
+	// cycles at 2 waves/SIMD -- an LDS read costs ~64
+	__shared__ __attribute__((aligned(16))) uint32_t tabs[(8 + 16*ASTC_CFG_STRIDE)/4];
+	{
+		const uint32_t* g = reinterpret_cast<const uint32_t*>(kp.aux);
+		for (uint32_t i = threadIdx.x; i < (8u + 16u*ASTC_CFG_STRIDE)/4u; i += CF_WG_THREADS)
+			tabs[i] = g[i];
+	}
 	const uint32_t bw = kp.flags & 255u, bh = (kp.flags >> 8) & 255u, n = bw*bh;
 	uint32_t gx_, gy_;
 	cf_resolve(kp, gx_, gy_);
@@ -130,7 +151,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	__syncthreads();
 
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	const uint8_t* tables = reinterpret_cast<const uint8_t*>(kp.aux);
+	const uint8_t* tables = reinterpret_cast<const uint8_t*>(tabs);
 	const uint32_t q = kp.quality > 4u ? 4u : kp.quality;
 	const uint32_t qcfg = q == 0u ? 1u : (q == 1u ? 2u : (q == 2u ? 4u : 8u));
 	const uint32_t qvar = q == 0u ? 1u : (q == 1u ? 2u : 8u);
@@ -271,6 +292,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					dd += dv[c]*dv[c];
 				}
 			}
+			const float rdd2 = dd > 0 ? 1.0f/(float)(2*dd) : 0.0f;
 			for (uint32_t g = 0; g < ng; ++g)
 				ncol[g*64u] = 0;
 #pragma unroll 1
@@ -281,7 +303,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				for (uint32_t c = 0; c < 4u; ++c)
 					t += c < nc ? ((int)((p >> (8u*c)) & 255u) - e0[c])*dv[c] : 0;
 				if (t > 0 && dd > 0) {
-					T = (128*t + dd)/(2*dd);
+					// (128 t + dd)/(2 dd); t <= dd' such that the quotient stays small: clamp t first
+					const int tc = t > dd ? dd : t;            // t >= dd gives T >= 64 -> 64 either way
+					T = (int)div_small((uint32_t)(128*tc + dd), (uint32_t)(2*dd), rdd2);
 					T = T > 64 ? 64 : T;
 				}
 				const uint2 f = cfg.infill(i);
@@ -294,13 +318,13 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			}
 			for (uint32_t g = 0; g < ng; ++g) {
 				const uint32_t den = cfg.den(g);
-				const uint32_t gv = den ? ((uint32_t)ncol[g*64u] + den/2u)/den : 0u;
+				const uint32_t gv = den ? div_small((uint32_t)ncol[g*64u] + den/2u, den, 1.0f/(float)den) : 0u;
 				qcol[g*64u] = (uint8_t)((gv*(uint32_t)qmax + 32u) >> 6);
 			}
 			err = astc_error(tp, n, nc, e0, e1, cfg, qcol, N, bits);
 			if (refit) {
 				int S = 0, A = 0, B = 0, C = 0, U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
-#pragma unroll 1
+#pragma unroll 4
 				for (uint32_t i = 0; i < n; ++i) {
 					const int wi = texel_weight(cfg, i, qcol, N, bits), iw = 64 - wi;
 					const uint32_t p = tp[i];
