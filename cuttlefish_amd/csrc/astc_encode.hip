@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(CF_WG_THREADS)
 cfhip_astc_encode_kernel(cf_kparams kp)
 {
 	__shared__ uint32_t tile[CF_BLOCKS_PER_WG*ASTC_MAX_TEXELS];
-	__shared__ uint16_t lane_num[4][64*64];     // [wave][grid point * 64 + lane]
+	__shared__ uint16_t lane_num[4][65*64];     // [wave][grid point * 64 + lane]; row 64 = dummy
 	__shared__ uint8_t lane_q[4][64*64];
 	__shared__ uint4 outb[CF_BLOCKS_PER_WG];
 	// both config sets (RGB, RGBA) of this footprint: the infill records are read 3-4 times
@@ -311,10 +311,16 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				const uint2 f = cfg.infill(i);
 				const uint32_t g0 = f.x & 255u, w00 = (f.x >> 8) & 255u, w01 = (f.x >> 16) & 255u,
 					w10 = f.x >> 24, w11 = f.y & 255u;
-				ncol[g0*64u] = (uint16_t)(ncol[g0*64u] + w00*(uint32_t)T);
-				if (w01) ncol[(g0 + 1u)*64u] = (uint16_t)(ncol[(g0 + 1u)*64u] + w01*(uint32_t)T);
-				if (w10) ncol[(g0 + N)*64u] = (uint16_t)(ncol[(g0 + N)*64u] + w10*(uint32_t)T);
-				if (w11) ncol[(g0 + N + 1u)*64u] = (uint16_t)(ncol[(g0 + N + 1u)*64u] + w11*(uint32_t)T);
+				// straight-line read-modify-write of the four grid accumulators: neighbours that do
+				// not exist go to the column's dummy row 64 with a zero factor; the real entries
+				// are distinct (N >= 2), so all loads can be issued before the stores
+				const uint32_t g1 = g0 + 1u < 64u ? g0 + 1u : 64u, g2 = g0 + N < 64u ? g0 + N : 64u,
+					g3 = g0 + N + 1u < 64u ? g0 + N + 1u : 64u;
+				const uint32_t a0 = ncol[g0*64u], a1 = ncol[g1*64u], a2 = ncol[g2*64u], a3 = ncol[g3*64u];
+				ncol[g0*64u] = (uint16_t)(a0 + w00*(uint32_t)T);
+				ncol[g1*64u] = (uint16_t)(a1 + w01*(uint32_t)T);
+				ncol[g2*64u] = (uint16_t)(a2 + w10*(uint32_t)T);
+				ncol[g3*64u] = (uint16_t)(a3 + w11*(uint32_t)T);
 			}
 			for (uint32_t g = 0; g < ng; ++g) {
 				const uint32_t den = cfg.den(g);
