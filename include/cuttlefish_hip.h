@@ -130,7 +130,9 @@ typedef struct cfhip_params {
 
 /* One surface = one (mip, depth, face) image of Converter::convert's loop
  * (Converter.cpp:521-527).  pixels: top-down rows (Image::scanline order,
- * Image.cpp:340-343), row_pitch_bytes apart.  out receives
+ * Image.cpp:340-343), row_pitch_bytes apart: `pixels` addresses row 0 and the pitch may be
+ * NEGATIVE (the reference's FreeImage bitmaps are stored bottom-up, so a Converter can hand
+ * over image.scanline(0) and scanline(1) - scanline(0) without touching a pixel).  out receives
  * ceil(w/bw)*ceil(h/bh)*block_bytes, blocks row-major (S3tcConverter.cpp:239,244).
  * Partial edge blocks replicate the last row/column (S3tcConverter.cpp:246-252). */
 typedef struct cfhip_surface {
@@ -161,6 +163,12 @@ int cfhip_query(int format, int type, int* block_w, int* block_h, int* block_byt
  * surface, encodes on the GPU, downloads the payload.  Blocking. */
 int cfhip_encode(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n_surfaces,
 	const cfhip_params* params);
+/* Host pipeline of cfhip_encode: small surfaces of a call are
+ * uploaded together and encoded in ONE batched launch with one synchronisation; a large
+ * RGBA32F surface of an 8-bit format, or any bottom-up surface, is cut into strips of whole
+ * block rows that host threads gather -- and quantise to UNORM8 with the arithmetic of
+ * toColorBlock (S3tcConverter.cpp:97-111) -- into pinned memory while earlier strips upload and
+ * encode.  The payload is byte-identical whichever way a surface travels. */
 
 /* Device-buffer entry point: pixels/out of every surface are device pointers on
  * ctx's GPU (e.g. produced by a GPU mip generator).  Kernels are enqueued on

@@ -33,15 +33,6 @@ cfhip_ctx* sharedContext()
 	return ctx;
 }
 
-// Same quantisation as toColorBlock (S3tcConverter.cpp:97-111): uploading RGBA8 instead
-// of ColorRGBAf scanlines cuts the PCIe traffic by 4x and is exactly what the UNorm block
-// encoders consume.  SNorm / float formats keep the float scanlines.
-inline std::uint8_t toUNorm8(float v)
-{
-	v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-	return static_cast<std::uint8_t>(std::round(v*0xFF));
-}
-
 } // namespace
 
 bool HipConverter::available()
@@ -93,42 +84,39 @@ void HipConverter::process(unsigned int, unsigned int, ThreadData*)
 	surface.out = data().data();
 	surface.out_capacity = data().size();
 
-	// Image::scanline(y) is top-down (Image.cpp:340-343) but rows are separate pointers.
+	// Image::scanline(y) is top-down (Image.cpp:340-343) over a bottom-up FreeImage bitmap: the
+	// rows are one contiguous allocation with a constant (negative) pitch, which the backend
+	// takes as is -- its host pipeline gathers the rows and, for the 8-bit formats, quantises
+	// them with the arithmetic of toColorBlock (S3tcConverter.cpp:97-111) on host threads while
+	// earlier strips upload and encode.  No per-pixel work is left in the adapter.
 	std::vector<std::uint8_t> staging;
-	// 8-bit staging only where the block encoder consumes 8-bit texels; EAC R11/RG11 keep the
-	// float scanlines (11-bit targets), as do SNorm and float formats.
-	bool stage8 = m_type == Texture::Type::UNorm && m_format != Texture::Format::EAC_R11 &&
-		m_format != Texture::Format::EAC_R11G11;
-	if (stage8)
+	surface.pixel_type = CFHIP_PIXEL_RGBA32F;
+	surface.pixels = source.scanline(0);
+	std::ptrdiff_t pitch = static_cast<std::ptrdiff_t>(width*sizeof(ColorRGBAf));
+	bool uniform = true;
+	if (height > 1)
 	{
-		staging.resize(static_cast<std::size_t>(width)*height*4);
-		for (unsigned int y = 0; y < height; ++y)
+		pitch = reinterpret_cast<const char*>(source.scanline(1)) -
+			reinterpret_cast<const char*>(source.scanline(0));
+		for (unsigned int y = 2; y < height && uniform; ++y)
 		{
-			auto scanline = reinterpret_cast<const ColorRGBAf*>(source.scanline(y));
-			std::uint8_t* row = staging.data() + static_cast<std::size_t>(y)*width*4;
-			for (unsigned int x = 0; x < width; ++x)
-			{
-				row[x*4] = toUNorm8(scanline[x].r);
-				row[x*4 + 1] = toUNorm8(scanline[x].g);
-				row[x*4 + 2] = toUNorm8(scanline[x].b);
-				row[x*4 + 3] = toUNorm8(scanline[x].a);
-			}
+			uniform = reinterpret_cast<const char*>(source.scanline(y)) ==
+				reinterpret_cast<const char*>(source.scanline(0)) + static_cast<std::ptrdiff_t>(y)*pitch;
 		}
-		surface.pixel_type = CFHIP_PIXEL_RGBA8;
-		surface.row_pitch_bytes = static_cast<std::ptrdiff_t>(width)*4;
 	}
-	else
+	surface.row_pitch_bytes = pitch;
+	if (!uniform)
 	{
+		// not a single allocation after all: gather the rows here
 		staging.resize(static_cast<std::size_t>(width)*height*sizeof(ColorRGBAf));
 		for (unsigned int y = 0; y < height; ++y)
 		{
 			std::memcpy(staging.data() + static_cast<std::size_t>(y)*width*sizeof(ColorRGBAf),
 				source.scanline(y), width*sizeof(ColorRGBAf));
 		}
-		surface.pixel_type = CFHIP_PIXEL_RGBA32F;
+		surface.pixels = staging.data();
 		surface.row_pitch_bytes = static_cast<std::ptrdiff_t>(width*sizeof(ColorRGBAf));
 	}
-	surface.pixels = staging.data();
 
 	cfhip_ctx* ctx = sharedContext();
 	if (ctx && cfhip_encode(ctx, &surface, 1, &params) == CFHIP_OK)

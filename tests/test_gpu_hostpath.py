@@ -1,0 +1,51 @@
+"""Host-buffer entry point cfhip_encode: the pipelined strip path must
+give the bytes of the plain path / the oracle for every source layout it accepts."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from cuttlefish_amd import Context, Format, Type, make_params, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    with Context(0) as c:
+        yield c
+
+
+def test_large_float_surface_goes_through_strips_and_matches_oracle(ctx):
+    img = synth.photo(1280, 1030, seed=21)            # 1030 rows: partial last block row in the last strip
+    f = img.astype(np.float32)/np.float32(255.0)      # 21 MB of floats: pipelined, several strips
+    got = ctx.encode([f], make_params(Format.BC7, Type.UNorm, 1))[0]
+    assert np.array_equal(got, O.encode(img, int(Format.BC7), 0, quality=1, threads=16))
+
+
+@pytest.mark.parametrize("fmt", [Format.BC1_RGB, Format.BC3, Format.BC7, Format.ETC2_R8G8B8A8, Format.ASTC_6x6])
+def test_float_sources_are_quantised_on_the_host_like_toColorBlock(ctx, fmt):
+    rng = np.random.default_rng(int(fmt))
+    f = (rng.random((520, 1024, 4)).astype(np.float32)*1.2 - 0.1)     # out-of-range values clamp
+    f[0, 0] = [np.nan, -0.0, 1e30, 0.5/255.0]                        # NaN -> 0, tie rounds away from zero
+    u8 = np.round(np.clip(np.nan_to_num(f.astype(np.float64), nan=0.0), 0.0, 1.0)*np.float32(255.0))
+    u8 = np.floor(np.clip(np.nan_to_num(f, nan=0.0), 0, 1).astype(np.float32)*np.float32(255) + np.float32(0.5)).astype(np.uint8)
+    p = make_params(fmt, Type.UNorm, 1)
+    got = ctx.encode([f], p)[0]                       # 8.5 MB of floats: pipelined + host quantisation
+    ref = ctx.encode([u8], p)[0]                      # 2 MB of bytes: plain path
+    assert np.array_equal(got, ref)
+
+
+def test_bottom_up_image_negative_pitch(ctx):
+    img = synth.photo(256, 192, seed=5)
+    flipped_storage = np.ascontiguousarray(img[::-1])
+    view = flipped_storage[::-1]                      # top-down view of bottom-up storage
+    assert view.strides[0] < 0 and np.array_equal(view, img)
+    p = make_params(Format.BC3, Type.UNorm, 2)
+    assert np.array_equal(ctx.encode([view], p)[0], ctx.encode([img], p)[0])
+
+
+def test_float_formats_keep_float_pixels_in_the_pipeline(ctx):
+    hdr = synth.hdr_probe(1024, 512, seed=3).astype(np.float32)      # 8 MB RGBA32F -> BC6H
+    p = make_params(Format.BC6H, Type.UFloat, 1)
+    got = ctx.encode([hdr], p)[0]
+    assert np.array_equal(got, O.encode(hdr, int(Format.BC6H), int(Type.UFloat), quality=1, threads=16))

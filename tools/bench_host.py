@@ -25,6 +25,18 @@ def main():
     dt = (time.perf_counter() - t0) / reps
     print(json.dumps({"case": "BC7 Normal 4096x4096 RGBA8, host buffers", "ms": round(dt * 1e3, 2),
                       "mpix_s": round(16.777216 / dt, 1), "kernel_ms": round(ctx.last_kernel_ms(), 2)}))
+    # what the Converter adapter holds: RGBAF scanlines, bottom-up (FreeImage) -> negative pitch
+    imgf = np.ascontiguousarray((img.astype(np.float32) / 255.0)[::-1])[::-1]
+    assert imgf.strides[0] < 0
+    ctx.encode([imgf], p)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        outf = ctx.encode([imgf], p)
+    dt = (time.perf_counter() - t0) / reps
+    same = bool(np.array_equal(outf[0], ctx.encode([img], p)[0]))
+    print(json.dumps({"case": "BC7 Normal 4096x4096 RGBA32F bottom-up host image (quantised by host threads)",
+                      "ms": round(dt * 1e3, 2), "mpix_s": round(16.777216 / dt, 1),
+                      "kernel_ms": round(ctx.last_kernel_ms(), 2), "same_payload_as_rgba8": same}))
     # C5 shape, scaled: 16 textures x (1024^2 + full mip chain) in ONE call
     base = synth.photo(1024, 1024, seed=2)
     chain = []
