@@ -11,7 +11,7 @@
 //   mean, exact SSE with the per-texel best modifier; 3-step group argmin on (error, id);
 //   the differential pair is clamped into the [-4,3] window (re-scored on 16 lanes);
 //   ETC2 planar: closed-form integer least squares + 2 rounds where lanes 0..17 score the
-//   single-field +-1 moves.  T/H modes are never emitted.
+//   single-field +-1 moves; ETC2 T / H modes: two cluster colours + distance (th_search).
 // EAC block: lanes 0..47 = 16 tables x 3 multipliers, each walks the 2R+1 base values.
 // Texels outside the image carry no error weight (EtcConverter.cpp:122-129).
 #include "cf_device.h"
@@ -235,6 +235,256 @@ __device__ __forceinline__ uint2 pack_planar(const PlanarQ& p)
 	return make_uint2(bswap32(hi), bswap32(lo));
 }
 
+// ---- ETC2 T / H modes (twin of th_search / pack_th in oracle/etc_codec.c) ----
+__device__ const int k_etc_dist[8] = {3, 6, 11, 16, 23, 32, 41, 64};
+
+struct ThCand {
+	int mode;          // 1 T, 2 H
+	uint32_t c0, c1;   // RGB444, r | g << 4 | b << 8
+	int di;
+	uint32_t err;
+};
+
+__device__ __forceinline__ int th_field(uint32_t c, int ch) { return (int)((c >> (4*ch)) & 15u); }
+
+__device__ __forceinline__ bool th_encodable(const ThCand& t)
+{
+	if (t.mode != 2)
+		return true;
+	// lexicographic R,G,B compare of the two RGB444 colours
+	const uint32_t w1 = (uint32_t)(th_field(t.c0, 0) << 8 | th_field(t.c0, 1) << 4 | th_field(t.c0, 2));
+	const uint32_t w2 = (uint32_t)(th_field(t.c1, 0) << 8 | th_field(t.c1, 1) << 4 | th_field(t.c1, 2));
+	return w1 != w2 || (t.di & 1);
+}
+
+// the four paint colours as RGB byte words
+__device__ __forceinline__ void th_paint(const ThCand& t, uint32_t (&paint)[4])
+{
+	const int d = k_etc_dist[t.di];
+	paint[0] = paint[1] = paint[2] = paint[3] = 0;
+#pragma unroll
+	for (int ch = 0; ch < 3; ++ch) {
+		const int a = ex4(th_field(t.c0, ch)), b = ex4(th_field(t.c1, ch));
+		int p0, p1, p2, p3;
+		if (t.mode == 1) { p0 = a; p1 = clamp255(b + d); p2 = b; p3 = clamp255(b - d); }
+		else { p0 = clamp255(a + d); p1 = clamp255(a - d); p2 = clamp255(b + d); p3 = clamp255(b - d); }
+		paint[0] |= (uint32_t)p0 << (8*ch); paint[1] |= (uint32_t)p1 << (8*ch);
+		paint[2] |= (uint32_t)p2 << (8*ch); paint[3] |= (uint32_t)p3 << (8*ch);
+	}
+}
+
+// error of candidate t over the texels of `active` (exact weighted SSE through the dot4
+// expansion, as half_err_fast); px: the 16 texels' RGB bytes, pp: sum_active sum_c w_c p_c^2
+template <bool UNITW>
+__device__ __forceinline__ uint32_t th_err(const uint32_t (&px)[16], uint32_t active, uint32_t pp,
+	const RgbOpts& o, const ThCand& t)
+{
+	if (!th_encodable(t))
+		return 0xFFFFFFFFu;
+	uint32_t paint[4];
+	th_paint(t, paint);
+	uint32_t ql[4], qh[4];
+	int nb[4];
+#pragma unroll
+	for (int v = 0; v < 4; ++v) {
+		const uint32_t q0 = paint[v] & 255u, q1 = (paint[v] >> 8) & 255u, q2 = paint[v] >> 16;
+		if (UNITW) {
+			ql[v] = paint[v]; qh[v] = 0;
+			nb[v] = -(int)__builtin_amdgcn_udot4(paint[v], paint[v], 0u, false);
+		} else {
+			const uint32_t w0 = (uint32_t)o.wt[0]*q0, w1 = (uint32_t)o.wt[1]*q1, w2 = (uint32_t)o.wt[2]*q2;
+			ql[v] = (w0 & 255u) | ((w1 & 255u) << 8) | ((w2 & 255u) << 16);
+			qh[v] = (w0 >> 8) | ((w1 >> 8) << 8) | ((w2 >> 8) << 16);
+			nb[v] = -(int)(w0*q0 + w1*q1 + w2*q2);
+		}
+	}
+	uint32_t total = pp;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		int best = -0x7FFFFFFF;
+#pragma unroll
+		for (int v = 0; v < 4; ++v) {
+			int d = (int)__builtin_amdgcn_udot4(px[i], ql[v], 0u, false);
+			if (!UNITW)
+				d += (int)__builtin_amdgcn_udot4(px[i], qh[v], 0u, false) << 8;
+			const int k = (d << 1) + nb[v];
+			best = k > best ? k : best;
+		}
+		total += ((active >> i) & 1u) ? (uint32_t)(-best) : 0u;
+	}
+	return total;
+}
+
+// selector (lowest index among equal errors) of texel p
+template <bool UNITW>
+__device__ __forceinline__ uint32_t th_selector(uint32_t p, const RgbOpts& o, const uint32_t (&paint)[4])
+{
+	uint32_t best = 0xFFFFFFFFu, bv = 0;
+#pragma unroll
+	for (int v = 0; v < 4; ++v) {
+		const int d0 = (int)(paint[v] & 255u) - (int)(p & 255u), d1 = (int)((paint[v] >> 8) & 255u) - (int)((p >> 8) & 255u),
+			d2 = (int)(paint[v] >> 16) - (int)((p >> 16) & 255u);
+		const uint32_t e = (uint32_t)(o.wt[0]*d0*d0) + (uint32_t)(o.wt[1]*d1*d1) + (uint32_t)(o.wt[2]*d2*d2);
+		if (e < best) { best = e; bv = (uint32_t)v; }
+	}
+	return bv;
+}
+
+// Search (uniform result in every lane).  Returns false when the block has no two-cluster
+// structure.  Lanes 0..23 = (variant, distance) candidates, then `rounds` rounds where lanes
+// 0..13 score the single +-1 moves.
+template <bool UNITW>
+__device__ __forceinline__ bool th_search(const uint32_t* tp, const RgbOpts& o, int rounds, uint32_t lane,
+	ThCand& best)
+{
+	uint32_t px[16];
+	int n = 0, sum[3] = {0, 0, 0};
+	uint32_t pp = 0;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		px[i] = tp[i] & 0x00FFFFFFu;
+		const bool a = (o.active >> i) & 1u;
+		const int p0 = (int)(px[i] & 255u), p1 = (int)((px[i] >> 8) & 255u), p2 = (int)(px[i] >> 16);
+		n += a ? 1 : 0;
+		sum[0] += a ? p0 : 0; sum[1] += a ? p1 : 0; sum[2] += a ? p2 : 0;
+		pp += a ? (uint32_t)(o.wt[0]*p0*p0 + o.wt[1]*p1*p1 + o.wt[2]*p2*p2) : 0u;
+	}
+	if (n < 2)
+		return false;
+	int mean[3];
+#pragma unroll
+	for (int c = 0; c < 3; ++c)
+		mean[c] = (2*sum[c] + n)/(2*n);
+	int c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		if ((o.active >> i) & 1u) {
+			const int d0 = (int)(px[i] & 255u) - mean[0], d1 = (int)((px[i] >> 8) & 255u) - mean[1],
+				d2 = (int)(px[i] >> 16) - mean[2];
+			c00 += d0*d0; c01 += d0*d1; c02 += d0*d2; c11 += d1*d1; c12 += d1*d2; c22 += d2*d2;
+		}
+	}
+	int k = 0, vk = c00;
+	if (c11 > vk) { k = 1; vk = c11; }
+	if (c22 > vk) { k = 2; vk = c22; }
+	if (vk == 0)
+		return false;
+	const int a0 = k == 0 ? c00 : (k == 1 ? c01 : c02), a1 = k == 0 ? c01 : (k == 1 ? c11 : c12),
+		a2 = k == 0 ? c02 : (k == 1 ? c12 : c22);
+	int n1 = 0, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		if ((o.active >> i) & 1u) {
+			const int p0 = (int)(px[i] & 255u), p1 = (int)((px[i] >> 8) & 255u), p2 = (int)(px[i] >> 16);
+			const int t = a0*(p0 - mean[0]) + a1*(p1 - mean[1]) + a2*(p2 - mean[2]);
+			const bool hi = t >= 0;
+			n1 += hi ? 1 : 0;
+			s1[0] += hi ? p0 : 0; s1[1] += hi ? p1 : 0; s1[2] += hi ? p2 : 0;
+			s0[0] += hi ? 0 : p0; s0[1] += hi ? 0 : p1; s0[2] += hi ? 0 : p2;
+		}
+	}
+	const int n0 = n - n1;
+	if (!n0 || !n1)
+		return false;
+	uint32_t m0 = 0, m1 = 0;
+#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		const int a = (2*s0[c] + n0)/(2*n0), b = (2*s1[c] + n1)/(2*n1);
+		m0 |= (uint32_t)((a*15 + 127)/255) << (4*c);
+		m1 |= (uint32_t)((b*15 + 127)/255) << (4*c);
+	}
+	// candidates: id = 5 + lane, lane = variant*8 + distance
+	ThCand t;
+	{
+		const uint32_t v = lane >> 3;
+		t.mode = v == 2u ? 2 : 1;
+		t.di = (int)(lane & 7u);
+		t.c0 = v == 1u ? m1 : m0;
+		t.c1 = v == 1u ? m0 : m1;
+		t.err = lane < 24u ? th_err<UNITW>(px, o.active, pp, o, t) : 0xFFFFFFFFu;
+	}
+	unsigned long long key = ((unsigned long long)t.err << 32) | lane;
+	unsigned long long kmin = cf_wave_min_u64(key);
+	if ((uint32_t)(kmin >> 32) == 0xFFFFFFFFu)
+		return false;
+	{
+		const int src = (int)(uint32_t)kmin;   // winning lane
+		best.mode = __shfl(t.mode, src, 64);
+		best.c0 = (uint32_t)__shfl((int)t.c0, src, 64);
+		best.c1 = (uint32_t)__shfl((int)t.c1, src, 64);
+		best.di = __shfl(t.di, src, 64);
+		best.err = (uint32_t)(kmin >> 32);
+	}
+	for (int r = 0; r < rounds; ++r) {
+		ThCand mvc = best;
+		bool ok = lane < 14u;
+		const int d = (lane & 1u) ? 1 : -1;
+		if (lane < 12u) {
+			const int f = (int)(lane >> 1);
+			const uint32_t cw = f < 3 ? mvc.c0 : mvc.c1;
+			const int sh = 4*(f % 3), nv = (int)((cw >> sh) & 15u) + d;
+			ok = nv >= 0 && nv <= 15;
+			const uint32_t nw = (cw & ~(15u << sh)) | ((uint32_t)(nv & 15) << sh);
+			if (f < 3) mvc.c0 = nw; else mvc.c1 = nw;
+		} else {
+			const int nv = mvc.di + d;
+			ok = ok && nv >= 0 && nv <= 7;
+			mvc.di = nv & 7;
+		}
+		const uint32_t e = ok ? th_err<UNITW>(px, o.active, pp, o, mvc) : 0xFFFFFFFFu;
+		key = ((unsigned long long)e << 32) | lane;
+		kmin = cf_wave_min_u64(key);
+		if ((uint32_t)(kmin >> 32) >= best.err)
+			break;
+		const int src = (int)(uint32_t)kmin;
+		best.c0 = (uint32_t)__shfl((int)mvc.c0, src, 64);
+		best.c1 = (uint32_t)__shfl((int)mvc.c1, src, 64);
+		best.di = __shfl(mvc.di, src, 64);
+		best.err = (uint32_t)(kmin >> 32);
+	}
+	return true;
+}
+
+template <bool UNITW>
+__device__ __forceinline__ uint2 pack_th(const uint32_t* tp, const RgbOpts& o, ThCand t, uint32_t lane)
+{
+	if (t.mode == 2) {
+		const uint32_t w1 = (uint32_t)(th_field(t.c0, 0) << 8 | th_field(t.c0, 1) << 4 | th_field(t.c0, 2));
+		const uint32_t w2 = (uint32_t)(th_field(t.c1, 0) << 8 | th_field(t.c1, 1) << 4 | th_field(t.c1, 2));
+		if ((w1 >= w2) != ((t.di & 1) != 0)) {
+			const uint32_t tmp = t.c0; t.c0 = t.c1; t.c1 = tmp;
+		}
+	}
+	uint32_t paint[4];
+	th_paint(t, paint);
+	// lane L < 16 owns selector bit position k = L: texel x = L >> 2, y = L & 3
+	const uint32_t L = lane & 15u, i = (L & 3u)*4u + (L >> 2);
+	const uint32_t sel = th_selector<UNITW>(tp[i] & 0x00FFFFFFu, o, paint);
+	const uint32_t lsb = (uint32_t)__ballot(lane < 16u && (sel & 1u)) & 0xFFFFu;
+	const uint32_t msb = (uint32_t)__ballot(lane < 16u && (sel >> 1)) & 0xFFFFu;
+	const uint32_t lo = (msb << 16) | lsb;
+	uint32_t hi = 0;
+	const int r1 = th_field(t.c0, 0), g1 = th_field(t.c0, 1), b1 = th_field(t.c0, 2);
+	const int r2 = th_field(t.c1, 0), g2 = th_field(t.c1, 1), b2 = th_field(t.c1, 2);
+	if (t.mode == 1) {
+		const int r1a = r1 >> 2, r1b = r1 & 3;
+		hi |= (r1a + r1b >= 4) ? (7u << 29) : (1u << 26);
+		hi |= (uint32_t)r1a << 27 | (uint32_t)r1b << 24 | (uint32_t)g1 << 20 | (uint32_t)b1 << 16;
+		hi |= (uint32_t)r2 << 12 | (uint32_t)g2 << 8 | (uint32_t)b2 << 4;
+		hi |= (uint32_t)(t.di >> 1) << 2 | 1u << 1 | (uint32_t)(t.di & 1);
+	} else {
+		const int g1a = g1 >> 1, g1b = g1 & 1, b1a = b1 >> 3, b1b = b1 & 7;
+		if (g1a >= 4) hi |= 1u << 31;
+		hi |= (uint32_t)r1 << 27 | (uint32_t)g1a << 24;
+		const int a = (g1b << 1) | b1a, b = b1b >> 1;
+		hi |= (a + b >= 4) ? (7u << 21) : (1u << 18);
+		hi |= (uint32_t)g1b << 20 | (uint32_t)b1a << 19 | (uint32_t)b1b << 15;
+		hi |= (uint32_t)r2 << 11 | (uint32_t)g2 << 7 | (uint32_t)b2 << 3;
+		hi |= (uint32_t)((t.di >> 2) & 1) << 2 | 1u << 1 | (uint32_t)((t.di >> 1) & 1);
+	}
+	return make_uint2(bswap32(hi), bswap32(lo));
+}
+
 // (key, payload) argmin over the 8 lanes of a group
 __device__ __forceinline__ void group_min8(unsigned long long& key, uint32_t& pay)
 {
@@ -381,7 +631,18 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 			const int id = (int)(uint32_t)mm;
 			planar_move(pq, id >> 1, (id & 1) ? 1 : -1);
 		}
-		if (ep < best_err)
+		bool use_planar = false;
+		if (ep < best_err) {
+			best_err = ep;
+			use_planar = true;
+		}
+		// ETC2 T / H modes (ids after planar)
+		ThCand th;
+		const bool have_th = unitw ? th_search<true>(tp, o, o.radius, lane, th)
+			: th_search<false>(tp, o, o.radius, lane, th);
+		if (have_th && th.err < best_err)
+			return unitw ? pack_th<true>(tp, o, th, lane) : pack_th<false>(tp, o, th, lane);
+		if (use_planar)
 			return pack_planar(pq);
 	}
 	const bool differential = best_id < 2u;

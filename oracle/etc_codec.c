@@ -17,7 +17,7 @@
  *   mean in 5-bit (differential) and 4-bit (individual) precision x 8 modifier tables,
  *   exact SSE with per-texel best modifier; differential pairs are clamped into the
  *   [-4,3] delta window; ETC2 adds the planar mode (closed-form integer least squares +
- *   two rounds of best single-field +-1 move).  T and H modes are decoded but never emitted.
+ *   two rounds of best single-field +-1 move) and ETC2's T / H modes (two cluster colours + distance).
  *   EAC block: 16 tables x 3 multipliers around the range-matching one x (2R+1) bases.
  *   Texels outside the image (partial edge blocks) carry no error weight, like
  *   etc2comp's border texels.
@@ -432,6 +432,215 @@ static void pack_etc(int diff_bit, int flip, const int q[2][3], const int table[
 	put_be32(out + 4, lo);
 }
 
+/* ---------------------------------------------------------------- ETC2 T / H modes */
+
+/* Two base colours (RGB444) + one of 8 distances, 2-bit selector per texel over the whole
+ * block (ETC2 specification, "T" and "H" modes).  T: paint = {A, B+d, B, B-d};
+ * H: paint = {A+d, A-d, B+d, B-d}.  Search: split the texels by the sign of their projection
+ * on C e_k (k = channel of largest variance), take the two cluster means as base colours,
+ * score T(A=m0,B=m1), T(A=m1,B=m0) and H(m0,m1) for the 8 distances (ids 5 + variant*8 + di),
+ * then `rounds` rounds of the best single +-1 move of one RGB444 field or of the distance
+ * index (lane-parallel form in the HIP kernel).  All integer. */
+typedef struct { int mode; int c[2][3]; int di; uint32_t err; int id; } th_cand;
+
+static void th_paint(const th_cand* t, int paint[4][3])
+{
+	int d = etc_dist[t->di];
+	for (int ch = 0; ch < 3; ++ch) {
+		int a = ex4(t->c[0][ch]), b = ex4(t->c[1][ch]);
+		if (t->mode == 1) {
+			paint[0][ch] = a; paint[1][ch] = clamp255(b + d);
+			paint[2][ch] = b; paint[3][ch] = clamp255(b - d);
+		} else {
+			paint[0][ch] = clamp255(a + d); paint[1][ch] = clamp255(a - d);
+			paint[2][ch] = clamp255(b + d); paint[3][ch] = clamp255(b - d);
+		}
+	}
+}
+
+/* H mode stores the distance index's low bit in the order of the two colours */
+static int th_encodable(const th_cand* t)
+{
+	if (t->mode != 2)
+		return 1;
+	int w1 = (t->c[0][0] << 8) | (t->c[0][1] << 4) | t->c[0][2];
+	int w2 = (t->c[1][0] << 8) | (t->c[1][1] << 4) | t->c[1][2];
+	return w1 != w2 || (t->di & 1);
+}
+
+static uint32_t th_err(const int px[16][4], const rgb_opts* o, const th_cand* t, uint8_t* sel)
+{
+	if (!th_encodable(t))
+		return 0xFFFFFFFFu;
+	int paint[4][3];
+	th_paint(t, paint);
+	uint32_t total = 0;
+	for (int i = 0; i < 16; ++i) {
+		uint32_t best = 0xFFFFFFFFu;
+		int bv = 0;
+		for (int v = 0; v < 4; ++v) {
+			uint32_t e = 0;
+			for (int ch = 0; ch < 3; ++ch) {
+				int d = paint[v][ch] - px[i][ch];
+				e += (uint32_t)(o->wt[ch]*d*d);
+			}
+			if (e < best) {
+				best = e;
+				bv = v;
+			}
+		}
+		if (sel) sel[i] = (uint8_t)bv;
+		if ((o->active >> i) & 1)
+			total += best;
+	}
+	return total;
+}
+
+/* returns 0 when the block has no two-cluster structure to offer */
+static int th_search(const int px[16][4], const rgb_opts* o, int rounds, th_cand* best)
+{
+	int n = 0, sum[3] = {0, 0, 0};
+	for (int i = 0; i < 16; ++i)
+		if ((o->active >> i) & 1) {
+			++n;
+			for (int c = 0; c < 3; ++c)
+				sum[c] += px[i][c];
+		}
+	if (n < 2)
+		return 0;
+	int mean[3];
+	for (int c = 0; c < 3; ++c)
+		mean[c] = (2*sum[c] + n)/(2*n);
+	int cov[3][3];
+	memset(cov, 0, sizeof(cov));
+	for (int i = 0; i < 16; ++i)
+		if ((o->active >> i) & 1)
+			for (int a = 0; a < 3; ++a)
+				for (int b = 0; b < 3; ++b)
+					cov[a][b] += (px[i][a] - mean[a])*(px[i][b] - mean[b]);
+	int k = 0;
+	for (int c = 1; c < 3; ++c)
+		if (cov[c][c] > cov[k][k])
+			k = c;
+	if (cov[k][k] == 0)
+		return 0;
+	int n1 = 0, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
+	for (int i = 0; i < 16; ++i) {
+		if (!((o->active >> i) & 1))
+			continue;
+		long long t = 0;
+		for (int c = 0; c < 3; ++c)
+			t += (long long)cov[c][k]*(px[i][c] - mean[c]);
+		if (t >= 0) {
+			++n1;
+			for (int c = 0; c < 3; ++c) s1[c] += px[i][c];
+		} else
+			for (int c = 0; c < 3; ++c) s0[c] += px[i][c];
+	}
+	int n0 = n - n1;
+	if (!n0 || !n1)
+		return 0;
+	int m[2][3];
+	for (int c = 0; c < 3; ++c) {
+		int a = (2*s0[c] + n0)/(2*n0), b = (2*s1[c] + n1)/(2*n1);
+		m[0][c] = (a*15 + 127)/255;
+		m[1][c] = (b*15 + 127)/255;
+	}
+	best->err = 0xFFFFFFFFu;
+	best->id = 0x7FFFFFFF;
+	for (int v = 0; v < 3; ++v)
+		for (int di = 0; di < 8; ++di) {
+			th_cand t;
+			t.mode = v == 2 ? 2 : 1;
+			t.di = di;
+			t.id = 5 + v*8 + di;
+			memcpy(t.c[0], m[v == 1 ? 1 : 0], sizeof(t.c[0]));
+			memcpy(t.c[1], m[v == 1 ? 0 : 1], sizeof(t.c[1]));
+			t.err = th_err(px, o, &t, NULL);
+			if (t.err < best->err || (t.err == best->err && t.id < best->id))
+				*best = t;
+		}
+	if (best->err == 0xFFFFFFFFu)
+		return 0;
+	/* moves 0..11: field f = mv >> 1 (c[0].rgb, c[1].rgb), delta -1 / +1; 12, 13: di -1 / +1 */
+	for (int r = 0; r < rounds; ++r) {
+		th_cand bt = *best;
+		int bmv = -1;
+		for (int mv = 0; mv < 14; ++mv) {
+			th_cand t = *best;
+			int d = (mv & 1) ? 1 : -1;
+			if (mv < 12) {
+				int f = mv >> 1, nv = t.c[f/3][f % 3] + d;
+				if (nv < 0 || nv > 15)
+					continue;
+				t.c[f/3][f % 3] = nv;
+			} else {
+				int nv = t.di + d;
+				if (nv < 0 || nv > 7)
+					continue;
+				t.di = nv;
+			}
+			t.err = th_err(px, o, &t, NULL);
+			if (t.err < bt.err) {
+				bt = t;
+				bmv = mv;
+			}
+		}
+		if (bmv < 0)
+			break;
+		*best = bt;
+	}
+	return 1;
+}
+
+static void pack_th(const th_cand* tc, const int px[16][4], const rgb_opts* o, uint8_t out[8])
+{
+	th_cand t = *tc;
+	uint32_t hi = 0, lo = 0;
+	uint8_t sel[16];
+	if (t.mode == 2) {
+		/* order the colours so that (w1 >= w2) equals the low bit of the distance index;
+		 * swapping them swaps the paint pairs {0,1} <-> {2,3}, so score after the swap */
+		int w1 = (t.c[0][0] << 8) | (t.c[0][1] << 4) | t.c[0][2];
+		int w2 = (t.c[1][0] << 8) | (t.c[1][1] << 4) | t.c[1][2];
+		if ((w1 >= w2) != (t.di & 1)) {
+			int tmp[3];
+			memcpy(tmp, t.c[0], sizeof(tmp));
+			memcpy(t.c[0], t.c[1], sizeof(tmp));
+			memcpy(t.c[1], tmp, sizeof(tmp));
+		}
+	}
+	th_err(px, o, &t, sel);
+	if (t.mode == 1) {
+		int r1a = t.c[0][0] >> 2, r1b = t.c[0][0] & 3;
+		/* R + dR must leave [0,31]: 111xx + 0yy when the low parts sum to >= 4, else 000xx + 1yy */
+		if (r1a + r1b >= 4) hi |= 7u << 29; else hi |= 1u << 26;
+		hi |= (uint32_t)r1a << 27 | (uint32_t)r1b << 24;
+		hi |= (uint32_t)t.c[0][1] << 20 | (uint32_t)t.c[0][2] << 16;
+		hi |= (uint32_t)t.c[1][0] << 12 | (uint32_t)t.c[1][1] << 8 | (uint32_t)t.c[1][2] << 4;
+		hi |= (uint32_t)(t.di >> 1) << 2 | 1u << 1 | (uint32_t)(t.di & 1);
+	} else {
+		int r1 = t.c[0][0], g1 = t.c[0][1], b1 = t.c[0][2];
+		int g1a = g1 >> 1, g1b = g1 & 1, b1a = b1 >> 3, b1b = b1 & 7;
+		/* R must stay inside: the free top bit of R follows the sign of dR (= g1a as int3) */
+		if (g1a >= 4) hi |= 1u << 31;
+		hi |= (uint32_t)r1 << 27 | (uint32_t)g1a << 24;
+		/* G must overflow: G = xxx g1b b1a, dG = y b1b[2:1] */
+		int a = (g1b << 1) | b1a, b = b1b >> 1;
+		if (a + b >= 4) hi |= 7u << 21; else hi |= 1u << 18;
+		hi |= (uint32_t)g1b << 20 | (uint32_t)b1a << 19 | (uint32_t)b1b << 15;
+		hi |= (uint32_t)t.c[1][0] << 11 | (uint32_t)t.c[1][1] << 7 | (uint32_t)t.c[1][2] << 3;
+		hi |= (uint32_t)((t.di >> 2) & 1) << 2 | 1u << 1 | (uint32_t)((t.di >> 1) & 1);
+	}
+	for (int i = 0; i < 16; ++i) {
+		int x = i & 3, y = i >> 2, k = x*4 + y;
+		lo |= (uint32_t)(sel[i] >> 1) << (16 + k);
+		lo |= (uint32_t)(sel[i] & 1) << k;
+	}
+	put_be32(out, hi);
+	put_be32(out + 4, lo);
+}
+
 /* px: row-major RGBA u8 (texels outside the image already edge-replicated) */
 void cfo_etc_rgb_search(const int px[16][4], const rgb_opts* o, uint8_t out[8])
 {
@@ -487,13 +696,25 @@ void cfo_etc_rgb_search(const int px[16][4], const rgb_opts* o, uint8_t out[8])
 			}
 		}
 	}
+	planar_q pq;
+	int use_planar = 0;
 	if (o->allow_planar && !o->punch) {
-		planar_q pq;
 		uint32_t ep = planar_fit(px, o, &pq);
 		if (ep < best_err) {
-			pack_planar(&pq, out);
+			best_err = ep;
+			use_planar = 1;
+		}
+	}
+	if (o->allow_planar && !o->punch) {   /* ETC2: T / H modes, ids after planar */
+		th_cand th;
+		if (th_search(px, o, o->radius, &th) && th.err < best_err) {
+			pack_th(&th, px, o, out);
 			return;
 		}
+	}
+	if (use_planar) {
+		pack_planar(&pq, out);
+		return;
 	}
 	int differential = best_id < 2;
 	uint8_t sel[16];

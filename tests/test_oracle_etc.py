@@ -110,3 +110,74 @@ def test_partial_blocks_ignore_out_of_image_texels():
 def test_threads_deterministic():
     img = synth.photo(64, 64, seed=2)
     assert np.array_equal(O.encode(img, A8, threads=1), O.encode(img, A8, threads=4))
+
+
+def _etc_mode(block8):
+    """0 individual/differential, 1 T, 2 H, 3 planar -- from the overflow rules of the ETC2 spec."""
+    hi = int.from_bytes(bytes(block8[:4]), "big")
+    if not (hi >> 1) & 1:
+        return 0
+    sx = lambda v: v - 8 if v >= 4 else v
+    r, dr = (hi >> 27) & 31, sx((hi >> 24) & 7)
+    g, dg = (hi >> 19) & 31, sx((hi >> 16) & 7)
+    b, db = (hi >> 11) & 31, sx((hi >> 8) & 7)
+    if not 0 <= r + dr <= 31:
+        return 1
+    if not 0 <= g + dg <= 31:
+        return 2
+    if not 0 <= b + db <= 31:
+        return 3
+    return 0
+
+
+def test_two_colour_blocks_use_t_or_h_mode_and_etc1_never_does():
+    rng = np.random.default_rng(12)
+    img = np.zeros((16, 16, 4), np.uint8)
+    img[..., 3] = 255
+    cols = [((200, 40, 30), (20, 60, 220)), ((250, 250, 10), (10, 120, 10)),
+            ((128, 0, 128), (0, 160, 160)), ((255, 255, 255), (180, 20, 20))]
+    k = 0
+    for by in range(0, 16, 4):
+        for bx in range(0, 16, 4):
+            a, b = cols[k % 4]
+            k += 1
+            m = rng.random((4, 4)) < 0.45                      # scattered two-colour pattern
+            blk = np.where(m[..., None], np.array(a), np.array(b)).astype(np.int16)
+            blk += rng.integers(-3, 4, blk.shape)
+            img[by:by + 4, bx:bx + 4, :3] = np.clip(blk, 0, 255)
+    out2 = O.encode(img, 38, quality=2)                        # ETC2 RGB
+    modes = [_etc_mode(out2[i:i + 8]) for i in range(0, out2.size, 8)]
+    assert sum(m in (1, 2) for m in modes) >= 12, modes         # chroma edges need two base colours
+    dec2 = O.decode_etc(out2, 38, 16, 16)
+    out1 = O.encode(img, 37, quality=2)                        # ETC1: no ETC2 modes available
+    assert all(_etc_mode(out1[i:i + 8]) == 0 for i in range(0, out1.size, 8))
+    dec1 = O.decode_etc(out1, 37, 16, 16)
+    e2 = np.mean((dec2[..., :3].astype(float) - img[..., :3])**2)
+    e1 = np.mean((dec1[..., :3].astype(float) - img[..., :3])**2)
+    assert e2 < 40 and e2 < e1/4, (e1, e2)
+
+
+def test_hand_built_t_and_h_blocks_decode_to_their_paint_colours():
+    # T: A = (15,0,0) -> 255,0,0; B = (0,0,15); distance index 3 (16); selectors 0,1,2,3 in column 0
+    def be(hi, lo):
+        return np.frombuffer(hi.to_bytes(4, "big") + lo.to_bytes(4, "big"), np.uint8)
+    r1a, r1b = 3, 3
+    hi = (7 << 29) | (r1a << 27) | (r1b << 24) | (0 << 20) | (0 << 16) | (0 << 12) | (0 << 8) | (15 << 4) | \
+        ((3 >> 1) << 2) | (1 << 1) | (3 & 1)
+    sel = [0, 1, 2, 3]                                         # texels (x=0, y=0..3): k = y
+    lo = sum(((s >> 1) << (16 + k)) | ((s & 1) << k) for k, s in enumerate(sel))
+    px = O.decode_etc(be(hi, lo), 38, 4, 4)
+    assert px[0, 0, :3].tolist() == [255, 0, 0]
+    assert px[1, 0, :3].tolist() == [16, 16, 255]              # B + 16, clamped
+    assert px[2, 0, :3].tolist() == [0, 0, 255]
+    assert px[3, 0, :3].tolist() == [0, 0, 239]                # B - 16, clamped at 0
+    # H: c1 = (8,8,8) = 136, c2 = (2,2,2) = 34, w1 >= w2 -> low bit of the index set: da=0, db=1 -> index 3 (16)
+    r1, g1, b1, r2, g2, b2 = 8, 8, 8, 2, 2, 2
+    g1a, g1b, b1a, b1b = g1 >> 1, g1 & 1, b1 >> 3, b1 & 7
+    hi = (1 << 31 if g1a >= 4 else 0) | (r1 << 27) | (g1a << 24) | (g1b << 20) | (b1a << 19) | (b1b << 15) | \
+        (r2 << 11) | (g2 << 7) | (b2 << 3) | (0 << 2) | (1 << 1) | 1
+    a, b = (g1b << 1) | b1a, b1b >> 1
+    hi |= (7 << 21) if a + b >= 4 else (1 << 18)
+    px = O.decode_etc(be(hi, lo), 38, 4, 4)
+    assert _etc_mode(be(hi, lo)) == 2
+    assert [px[y, 0, 0] for y in range(4)] == [136 + 16, 136 - 16, 34 + 16, 34 - 16]
