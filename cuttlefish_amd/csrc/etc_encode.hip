@@ -276,7 +276,7 @@ __device__ __forceinline__ void th_paint(const ThCand& t, uint32_t (&paint)[4])
 // error of candidate t over the texels of `active` (exact weighted SSE through the dot4
 // expansion, as half_err_fast); px: the 16 texels' RGB bytes, pp: sum_active sum_c w_c p_c^2
 template <bool UNITW>
-__device__ __forceinline__ uint32_t th_err(const uint32_t (&px)[16], uint32_t active, uint32_t pp,
+__device__ __forceinline__ uint32_t th_err(const uint32_t* tp, uint32_t active, uint32_t pp,
 	const RgbOpts& o, const ThCand& t)
 {
 	if (!th_encodable(t))
@@ -299,14 +299,17 @@ __device__ __forceinline__ uint32_t th_err(const uint32_t (&px)[16], uint32_t ac
 		}
 	}
 	uint32_t total = pp;
-#pragma unroll
-	for (int i = 0; i < 16; ++i) {
+	// texels from LDS (wave-uniform address) in a rolled loop: a register copy of the block
+	// would cost the kernel a wave of occupancy
+#pragma unroll 2
+	for (uint32_t i = 0; i < 16u; ++i) {
+		const uint32_t p = tp[i] & 0x00FFFFFFu;
 		int best = -0x7FFFFFFF;
 #pragma unroll
 		for (int v = 0; v < 4; ++v) {
-			int d = (int)__builtin_amdgcn_udot4(px[i], ql[v], 0u, false);
+			int d = (int)__builtin_amdgcn_udot4(p, ql[v], 0u, false);
 			if (!UNITW)
-				d += (int)__builtin_amdgcn_udot4(px[i], qh[v], 0u, false) << 8;
+				d += (int)__builtin_amdgcn_udot4(p, qh[v], 0u, false) << 8;
 			const int k = (d << 1) + nb[v];
 			best = k > best ? k : best;
 		}
@@ -337,14 +340,13 @@ template <bool UNITW>
 __device__ __forceinline__ bool th_search(const uint32_t* tp, const RgbOpts& o, int rounds, uint32_t lane,
 	ThCand& best)
 {
-	uint32_t px[16];
 	int n = 0, sum[3] = {0, 0, 0};
 	uint32_t pp = 0;
-#pragma unroll
-	for (int i = 0; i < 16; ++i) {
-		px[i] = tp[i] & 0x00FFFFFFu;
+#pragma unroll 2
+	for (uint32_t i = 0; i < 16u; ++i) {
+		const uint32_t p = tp[i];
 		const bool a = (o.active >> i) & 1u;
-		const int p0 = (int)(px[i] & 255u), p1 = (int)((px[i] >> 8) & 255u), p2 = (int)(px[i] >> 16);
+		const int p0 = (int)(p & 255u), p1 = (int)((p >> 8) & 255u), p2 = (int)((p >> 16) & 255u);
 		n += a ? 1 : 0;
 		sum[0] += a ? p0 : 0; sum[1] += a ? p1 : 0; sum[2] += a ? p2 : 0;
 		pp += a ? (uint32_t)(o.wt[0]*p0*p0 + o.wt[1]*p1*p1 + o.wt[2]*p2*p2) : 0u;
@@ -356,11 +358,12 @@ __device__ __forceinline__ bool th_search(const uint32_t* tp, const RgbOpts& o, 
 	for (int c = 0; c < 3; ++c)
 		mean[c] = (2*sum[c] + n)/(2*n);
 	int c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
-#pragma unroll
-	for (int i = 0; i < 16; ++i) {
+#pragma unroll 2
+	for (uint32_t i = 0; i < 16u; ++i) {
 		if ((o.active >> i) & 1u) {
-			const int d0 = (int)(px[i] & 255u) - mean[0], d1 = (int)((px[i] >> 8) & 255u) - mean[1],
-				d2 = (int)(px[i] >> 16) - mean[2];
+			const uint32_t p = tp[i];
+			const int d0 = (int)(p & 255u) - mean[0], d1 = (int)((p >> 8) & 255u) - mean[1],
+				d2 = (int)((p >> 16) & 255u) - mean[2];
 			c00 += d0*d0; c01 += d0*d1; c02 += d0*d2; c11 += d1*d1; c12 += d1*d2; c22 += d2*d2;
 		}
 	}
@@ -372,10 +375,11 @@ __device__ __forceinline__ bool th_search(const uint32_t* tp, const RgbOpts& o, 
 	const int a0 = k == 0 ? c00 : (k == 1 ? c01 : c02), a1 = k == 0 ? c01 : (k == 1 ? c11 : c12),
 		a2 = k == 0 ? c02 : (k == 1 ? c12 : c22);
 	int n1 = 0, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
-#pragma unroll
-	for (int i = 0; i < 16; ++i) {
+#pragma unroll 2
+	for (uint32_t i = 0; i < 16u; ++i) {
 		if ((o.active >> i) & 1u) {
-			const int p0 = (int)(px[i] & 255u), p1 = (int)((px[i] >> 8) & 255u), p2 = (int)(px[i] >> 16);
+			const uint32_t p = tp[i];
+			const int p0 = (int)(p & 255u), p1 = (int)((p >> 8) & 255u), p2 = (int)((p >> 16) & 255u);
 			const int t = a0*(p0 - mean[0]) + a1*(p1 - mean[1]) + a2*(p2 - mean[2]);
 			const bool hi = t >= 0;
 			n1 += hi ? 1 : 0;
@@ -401,7 +405,7 @@ __device__ __forceinline__ bool th_search(const uint32_t* tp, const RgbOpts& o, 
 		t.di = (int)(lane & 7u);
 		t.c0 = v == 1u ? m1 : m0;
 		t.c1 = v == 1u ? m0 : m1;
-		t.err = lane < 24u ? th_err<UNITW>(px, o.active, pp, o, t) : 0xFFFFFFFFu;
+		t.err = lane < 24u ? th_err<UNITW>(tp, o.active, pp, o, t) : 0xFFFFFFFFu;
 	}
 	unsigned long long key = ((unsigned long long)t.err << 32) | lane;
 	unsigned long long kmin = cf_wave_min_u64(key);
@@ -431,7 +435,7 @@ __device__ __forceinline__ bool th_search(const uint32_t* tp, const RgbOpts& o, 
 			ok = ok && nv >= 0 && nv <= 7;
 			mvc.di = nv & 7;
 		}
-		const uint32_t e = ok ? th_err<UNITW>(px, o.active, pp, o, mvc) : 0xFFFFFFFFu;
+		const uint32_t e = ok ? th_err<UNITW>(tp, o.active, pp, o, mvc) : 0xFFFFFFFFu;
 		key = ((unsigned long long)e << 32) | lane;
 		kmin = cf_wave_min_u64(key);
 		if ((uint32_t)(kmin >> 32) >= best.err)
@@ -792,8 +796,11 @@ __device__ __forceinline__ uint32_t r11_word(float f, bool snorm)
 
 } // namespace
 
+// register budget: 4 waves/SIMD (128 VGPRs) holds every variant without scratch except
+// ETC2 RGBA8 (RGB search + EAC alpha in one kernel), which gets 3
 template <int PIX, int FMT, bool SNORM>
 __global__ void __launch_bounds__(CF_WG_THREADS)
+__attribute__((amdgpu_waves_per_eu(FMT == E_A8 ? 3 : 4, 8)))
 cfhip_etc_encode_kernel(cf_kparams kp)
 {
 	constexpr bool IS_EAC = FMT == E_R11 || FMT == E_RG11;
