@@ -29,6 +29,9 @@ extern "C" hipError_t cfhip_launch_bc6h(const cf_kparams* kp, int pixel_type, in
 extern "C" hipError_t cfhip_launch_mip_resize(const void* src, int src_pixel_type, size_t pitch,
 	uint32_t sw, uint32_t sh, void* dst, uint32_t dw, uint32_t dh, int filter, int srgb,
 	hipStream_t stream);
+extern "C" hipError_t cfhip_launch_mip_pass(const void* src, int src_pixel_type, size_t pitch,
+	uint32_t src_n, void* dst, uint32_t dst_w, uint32_t dst_h, int along_x, int filter, int to_linear,
+	int to_srgb, hipStream_t stream);
 extern "C" hipError_t cfhip_launch_bc15(const cf_kparams* kp, int format, int pixel_type,
 	int snorm, hipStream_t stream);
 
@@ -879,10 +882,8 @@ int cfhip_generate_mips_device(cfhip_ctx* ctx, const void* src, int src_pixel_ty
 		return fail(ctx, CFHIP_E_INVALID, "mip generation: pixel type %d", src_pixel_type);
 	if (color_space != CFHIP_COLOR_LINEAR && color_space != CFHIP_COLOR_SRGB)
 		return fail(ctx, CFHIP_E_INVALID, "mip generation: colour space %d", color_space);
-	if (filter != CFHIP_FILTER_BOX && filter != CFHIP_FILTER_LINEAR)
-		return fail(ctx, CFHIP_E_UNSUPPORTED, "resize filter %d is implemented by FreeImage_Rescale "
-			"in the reference (third-party, absent); only Box and Linear (the in-tree fallback, "
-			"Image.cpp:1393-1505) exist here", filter);
+	if (filter < CFHIP_FILTER_BOX || filter > CFHIP_FILTER_BSPLINE)
+		return fail(ctx, CFHIP_E_INVALID, "resize filter %d", filter);
 	// maxMipmapLevels for a 2-D texture: floor(log2(max(w, h))) + 1 (Texture.cpp)
 	uint32_t max_levels = 1;
 	for (uint32_t d = width > height ? width : height; d > 1; d >>= 1)
@@ -904,8 +905,29 @@ int cfhip_generate_mips_device(cfhip_ctx* ctx, const void* src, int src_pixel_ty
 		if (!dst_levels[k - 1])
 			return fail(ctx, CFHIP_E_INVALID, "mip generation: dst_levels[%u] is NULL", k - 1);
 		const uint32_t w = (width >> k) ? (width >> k) : 1u, h = (height >> k) ? (height >> k) : 1u;
-		HIP_TRY(ctx, cfhip_launch_mip_resize(prev, prev_type, prev_pitch, pw, ph, dst_levels[k - 1], w, h,
-			filter, color_space == CFHIP_COLOR_SRGB ? 1 : 0, stream));
+		const int srgb = color_space == CFHIP_COLOR_SRGB ? 1 : 0;
+		if (filter <= CFHIP_FILTER_LINEAR) {
+			HIP_TRY(ctx, cfhip_launch_mip_resize(prev, prev_type, prev_pitch, pw, ph, dst_levels[k - 1], w, h,
+				filter, srgb, stream));
+		} else {
+			// FreeImage_Rescale's two passes, horizontal first when dst_w*src_h <= dst_h*src_w, with a
+			// float intermediate image in the context's staging buffer; a pass whose size does
+			// not change is skipped (the other one then does both colour conversions)
+			const bool x_first = (unsigned long long)w*ph <= (unsigned long long)h*pw;
+			const bool need_x = w != pw, need_y = h != ph;
+			if (need_x && need_y) {
+				const uint32_t tw = x_first ? w : pw, th = x_first ? ph : h;
+				int rc = reserve(ctx, &ctx->d_src, &ctx->src_cap, (size_t)tw*th*16u);
+				if (rc != CFHIP_OK) return rc;
+				HIP_TRY(ctx, cfhip_launch_mip_pass(prev, prev_type, prev_pitch, x_first ? pw : ph, ctx->d_src, tw, th,
+					x_first ? 1 : 0, filter, srgb, 0, stream));
+				HIP_TRY(ctx, cfhip_launch_mip_pass(ctx->d_src, CFHIP_PIXEL_RGBA32F, (size_t)tw*16u, x_first ? ph : pw,
+					dst_levels[k - 1], w, h, x_first ? 0 : 1, filter, 0, srgb, stream));
+			} else {
+				HIP_TRY(ctx, cfhip_launch_mip_pass(prev, prev_type, prev_pitch, need_x ? pw : ph, dst_levels[k - 1], w, h,
+					need_x ? 1 : 0, filter, srgb, srgb, stream));
+			}
+		}
 		prev = dst_levels[k - 1];
 		prev_type = CFHIP_PIXEL_RGBA32F;
 		prev_pitch = (size_t)w*16u;

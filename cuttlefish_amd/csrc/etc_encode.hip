@@ -53,12 +53,6 @@ __device__ __forceinline__ uint32_t half_mask(uint32_t flip, uint32_t sub)
 	return flip ? (sub ? 0xFF00u : 0x00FFu) : (sub ? 0xCCCCu : 0x3333u);
 }
 
-__device__ __forceinline__ int etc_modifier(int t, int v, bool punch)
-{
-	const int a = punch ? 0 : k_etc_mod[t][0], b = k_etc_mod[t][1];
-	return v == 0 ? a : (v == 1 ? b : (v == 2 ? -a : -b));
-}
-
 // error of one half for base colour c and table t; sel (2 bits per texel) when WANT_SEL
 template <bool WANT_SEL>
 __device__ __forceinline__ uint32_t half_err(const uint32_t* tp, const RgbOpts& o, uint32_t hmask,

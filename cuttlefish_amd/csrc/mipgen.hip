@@ -123,7 +123,104 @@ cfhip_mip_resize_kernel(const uint8_t* __restrict__ src, size_t pitch, uint32_t 
 	dst[(size_t)y*dw + x] = o;
 }
 
+// ---- Cubic / CatmullRom / BSpline: FreeImage_Rescale's algorithm (absent third-party code,
+// restated from its published source -- parity unpinned; oracle/mipgen.c: fi_filter / fi_pass)
+__device__ __forceinline__ double fi_filter(int filter, double v)
+{
+	if (filter == 3) {
+		if (v < -2.0) return 0.0;
+		if (v < -1.0) return 0.5*(4.0 + v*(8.0 + v*(5.0 + v)));
+		if (v < 0.0) return 0.5*(2.0 + v*v*(-5.0 - 3.0*v));
+		if (v < 1.0) return 0.5*(2.0 + v*v*(-5.0 + 3.0*v));
+		if (v < 2.0) return 0.5*(4.0 + v*(-8.0 + v*(5.0 - v)));
+		return 0.0;
+	}
+	if (filter == 4) {
+		v = fabs(v);
+		if (v < 1.0) return (4.0 + v*v*(-6.0 + 3.0*v))/6.0;
+		if (v < 2.0) { const double t = 2.0 - v; return t*t*t/6.0; }
+		return 0.0;
+	}
+	const double b = 1.0/3.0, c = 1.0/3.0;
+	const double p0 = (6.0 - 2.0*b)/6.0, p2 = (-18.0 + 12.0*b + 6.0*c)/6.0, p3 = (12.0 - 9.0*b - 6.0*c)/6.0;
+	const double q0 = (8.0*b + 24.0*c)/6.0, q1 = (-12.0*b - 48.0*c)/6.0, q2 = (6.0*b + 30.0*c)/6.0,
+		q3 = (-b - 6.0*c)/6.0;
+	v = fabs(v);
+	if (v < 1.0) return p0 + v*v*(p2 + v*p3);
+	if (v < 2.0) return q0 + v*(q1 + v*(q2 + v*q3));
+	return 0.0;
+}
+
+// One separable pass: output (u, l) = sum_i w_i * src(i, l) along x (ALONG_X) or y, weights
+// normalised per output coordinate.  TO_LINEAR converts the source texel (sRGB image, first
+// pass); TO_SRGB converts the result (last pass).  Float store after every step, as RGBAF.
+template <int SRC_PIX, bool ALONG_X>
+__global__ void __launch_bounds__(256)
+cfhip_mip_pass_kernel(const uint8_t* __restrict__ src, size_t pitch, uint32_t src_n, float4* __restrict__ dst,
+	uint32_t dst_w, uint32_t dst_h, int filter, int to_linear, int to_srgb)
+{
+	const uint32_t x = blockIdx.x*64u + (threadIdx.x & 63u);
+	const uint32_t y = blockIdx.y*4u + (threadIdx.x >> 6);
+	if (x >= dst_w || y >= dst_h)
+		return;
+	const uint32_t dst_n = ALONG_X ? dst_w : dst_h, u = ALONG_X ? x : y;
+	const double scale = (double)dst_n/(double)src_n;
+	double width = 2.0, fscale = 1.0;
+	if (scale < 1.0) {
+		width = 2.0/scale;
+		fscale = scale;
+	}
+	const double center = (double)u/scale + 0.5/scale;
+	int left = (int)(center - width + 0.5);
+	left = left < 0 ? 0 : left;
+	int right = (int)(center + width + 0.5);
+	right = right > (int)src_n ? (int)src_n : right;
+	double total = 0.0;
+	for (int i = left; i < right; ++i)
+		total += fscale*fi_filter(filter, fscale*((double)i + 0.5 - center));
+	double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+	for (int i = left; i < right; ++i) {
+		double w = fscale*fi_filter(filter, fscale*((double)i + 0.5 - center));
+		if (total > 0.0 && total != 1.0)
+			w /= total;
+		float4 p = ALONG_X ? load_rgbaf<SRC_PIX>(src + (size_t)y*pitch, (uint32_t)i)
+			: load_rgbaf<SRC_PIX>(src + (size_t)i*pitch, x);
+		if (to_linear) {
+			p.x = (float)srgb_to_linear((double)p.x);
+			p.y = (float)srgb_to_linear((double)p.y);
+			p.z = (float)srgb_to_linear((double)p.z);
+		}
+		c0 += w*(double)p.x; c1 += w*(double)p.y; c2 += w*(double)p.z; c3 += w*(double)p.w;
+	}
+	float4 o = make_float4((float)c0, (float)c1, (float)c2, (float)c3);
+	if (to_srgb) {
+		o.x = (float)linear_to_srgb((double)o.x);
+		o.y = (float)linear_to_srgb((double)o.y);
+		o.z = (float)linear_to_srgb((double)o.z);
+	}
+	dst[(size_t)y*dst_w + x] = o;
+}
+
 } // namespace
+
+// one separable pass (filters 2..4): src (any pixel type, `pitch`) -> dst (RGBA32F, dst_w x dst_h)
+extern "C" hipError_t cfhip_launch_mip_pass(const void* src, int src_pixel_type, size_t pitch,
+	uint32_t src_n, void* dst, uint32_t dst_w, uint32_t dst_h, int along_x, int filter, int to_linear,
+	int to_srgb, hipStream_t stream)
+{
+	const dim3 grid((dst_w + 63u)/64u, (dst_h + 3u)/4u, 1), block(256, 1, 1);
+	const uint8_t* s = static_cast<const uint8_t*>(src);
+	float4* d = static_cast<float4*>(dst);
+#define CF_PASS(P, AX) hipLaunchKernelGGL((cfhip_mip_pass_kernel<P, AX>), grid, block, 0, stream, s, pitch, \
+	src_n, d, dst_w, dst_h, filter, to_linear, to_srgb)
+	if (along_x) {
+		if (src_pixel_type == 0) CF_PASS(0, true); else if (src_pixel_type == 1) CF_PASS(1, true); else CF_PASS(2, true);
+	} else {
+		if (src_pixel_type == 0) CF_PASS(0, false); else if (src_pixel_type == 1) CF_PASS(1, false); else CF_PASS(2, false);
+	}
+#undef CF_PASS
+	return hipGetLastError();
+}
 
 // one level: src (any pixel type) -> dst (RGBA32F, tightly packed)
 extern "C" hipError_t cfhip_launch_mip_resize(const void* src, int src_pixel_type, size_t pitch,

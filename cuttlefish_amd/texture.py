@@ -88,15 +88,17 @@ class Texture:
     def generate_mipmaps(self, filter=api.ResizeFilter.CatmullRom, mip_levels: Optional[int] = None) -> bool:
         """Texture::generateMipmaps (Texture.cpp:1320-1514, 2-D path): every level from the
         previous one through Image::resize in linear space, on the GPU
-        (cfhip_generate_mips_device).  The reference's default CatmullRom (and Cubic, BSpline) is
-        FreeImage code that is absent: those return False here; Box and Linear are the in-tree
-        fallback arithmetic.  Levels come back as RGBAF (float32) images, like the reference's."""
+        (cfhip_generate_mips_device).  Box / Linear: the in-tree fallback arithmetic; Cubic,
+        CatmullRom (default, as in the reference) and BSpline: FreeImage's resampler restated
+        (FreeImage is absent: parity unpinned).  Levels come back as RGBAF (float32) images."""
         if self._textures or self._depth or any(im is None for im in self._images[0]):
             return False
         w, h = self._w, self._h
         max_levels = max(w, h).bit_length()
         levels = max_levels if mip_levels is None else min(max(int(mip_levels), 1), max_levels)
-        if api.ResizeFilter(filter) not in (api.ResizeFilter.Box, api.ResizeFilter.Linear):
+        try:
+            filter = api.ResizeFilter(filter)
+        except ValueError:
             return False
         import torch  # device memory + stream: plumbing only
         if self._ctx is None:

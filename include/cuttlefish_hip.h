@@ -183,10 +183,11 @@ int cfhip_encode_device(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n_
  * max(1, h >> k), filter) (lib/src/Image.cpp:1324-1511), resized in LINEAR space -- an sRGB
  * image is converted with sRGBToLinear, resized and converted back with linearToSRGB
  * (Image.cpp:1337-1346, Color.h:224-242; alpha is not converted) -- on RGBAF images whose
- * float storage rounds every intermediate.  Filters: the reference's in-tree fallback Box
- * (Image.cpp:1393-1447) and Linear (:1448-1505) arithmetic; its default CatmullRom and the
- * other FreeImage_Rescale filters are third-party code that is absent, so they return
- * CFHIP_E_UNSUPPORTED.
+ * float storage rounds every intermediate.  Filters: Box and Linear run the reference's in-tree
+ * fallback arithmetic (Image.cpp:1393-1447, :1448-1505).  Cubic, CatmullRom (the reference's
+ * default) and BSpline are FreeImage_Rescale in the reference (Image.cpp:1348-1380), a
+ * third-party library that is absent: they run a restatement of FreeImage's published
+ * two-pass weights-table resampler -- same results class, parity unpinned.
  *   src / src_pixel_type / src_pitch_bytes : level 0 on the device (RGBA8 is read as v/255.0,
  *                                            RGBA16F / RGBA32F as stored)
  *   dst_levels[k-1], k = 1..levels-1       : device buffers that receive level k as tightly

@@ -12,8 +12,8 @@
  * Pinning: the two colour-space functions are checked bit for bit against the reference's own
  * Color.h compiled into oracle/_ref (tests/test_oracle_mipgen.py); the resize loops cannot be
  * compiled (Image.cpp needs FreeImage, absent) and are restated line by line.  The reference
- * reaches these loops only when FreeImage_Rescale fails; FreeImage's own filters (its default
- * CatmullRom included) are third-party code that is absent -- "parity unpinned" for those.
+ * reaches these loops only when FreeImage_Rescale fails.  Cubic / CatmullRom (default) / BSpline
+ * exist only inside FreeImage (absent): their restatement further down is "PARITY UNPINNED".
  *
  * All images are RGBAF: float storage, double arithmetic, every stored value rounded to float
  * (setPixelNoGrayscaleImpl's static_cast<float>).
@@ -106,12 +106,124 @@ static void resize_linear_space(const float* src, unsigned sw, unsigned sh, floa
 	}
 }
 
-/* Image::resize for an RGBAF image in `color_space` (0 linear, 1 sRGB); filter 0 Box, 1 Linear.
- * Returns 0, or -2 for the filters only FreeImage implements. */
+/* ---- Cubic / CatmullRom / BSpline: the FreeImage_Rescale path -------------------------------
+ * Image::resize hands these filters to FreeImage_Rescale (Image.cpp:1348-1380); FreeImage is a
+ * third-party library that is ABSENT from /root/reference (3.18.0 is what Cuttlefish's build
+ * looks for; version unpinned by the tree) -- "PARITY UNPINNED" for this part.  What follows
+ * restates FreeImage's published resampling algorithm (Source/FreeImageToolkit/Resize.cpp,
+ * Filters.h): a weights table per output coordinate,
+ *     scale = dst/src;  width = W/scale and fscale = scale when minifying, else W and 1
+ *     center = u/scale + 0.5/scale;  left = max(0, (int)(center - width + 0.5));
+ *     right = min((int)(center + width + 0.5), src);  w_i = fscale*F(fscale*(i + 0.5 - center))
+ *     weights normalised to sum 1
+ * applied in two passes (horizontal first when dst_w*src_h <= dst_h*src_w) with a float
+ * intermediate image, double accumulation, no clamping for float pixels.  The in-tree fallback
+ * above (Image.cpp:1393-1505) is visibly modelled on the same table arithmetic.  Filter kernels
+ * (all of support W = 2): Catmull-Rom, Mitchell-Netravali B = C = 1/3 ("bicubic"), cubic
+ * B-spline. */
+static double fi_filter(int filter, double v)
+{
+	if (filter == 3) {   /* FILTER_CATMULLROM */
+		if (v < -2.0) return 0.0;
+		if (v < -1.0) return 0.5*(4.0 + v*(8.0 + v*(5.0 + v)));
+		if (v < 0.0) return 0.5*(2.0 + v*v*(-5.0 - 3.0*v));
+		if (v < 1.0) return 0.5*(2.0 + v*v*(-5.0 + 3.0*v));
+		if (v < 2.0) return 0.5*(4.0 + v*(-8.0 + v*(5.0 - v)));
+		return 0.0;
+	}
+	if (filter == 4) {   /* FILTER_BSPLINE */
+		v = fabs(v);
+		if (v < 1.0) return (4.0 + v*v*(-6.0 + 3.0*v))/6.0;
+		if (v < 2.0) { double t = 2.0 - v; return t*t*t/6.0; }
+		return 0.0;
+	}
+	/* FILTER_BICUBIC: Mitchell & Netravali, B = C = 1/3 */
+	const double b = 1.0/3.0, c = 1.0/3.0;
+	const double p0 = (6.0 - 2.0*b)/6.0, p2 = (-18.0 + 12.0*b + 6.0*c)/6.0, p3 = (12.0 - 9.0*b - 6.0*c)/6.0;
+	const double q0 = (8.0*b + 24.0*c)/6.0, q1 = (-12.0*b - 48.0*c)/6.0, q2 = (6.0*b + 30.0*c)/6.0,
+		q3 = (-b - 6.0*c)/6.0;
+	v = fabs(v);
+	if (v < 1.0) return p0 + v*v*(p2 + v*p3);
+	if (v < 2.0) return q0 + v*(q1 + v*(q2 + v*q3));
+	return 0.0;
+}
+
+/* one pass along x (stride_px = 1) or y (stride_px = row length), `lines` independent lines */
+static void fi_pass(const float* src, unsigned src_n, unsigned src_line_stride, unsigned src_px_stride,
+	float* dst, unsigned dst_n, unsigned dst_line_stride, unsigned dst_px_stride, unsigned lines, int filter)
+{
+	const double scale = (double)dst_n/(double)src_n;
+	double width = 2.0, fscale = 1.0;
+	if (scale < 1.0) {
+		width = 2.0/scale;
+		fscale = scale;
+	}
+	const double offset = 0.5/scale;
+	for (unsigned u = 0; u < dst_n; ++u) {
+		const double center = (double)u/scale + offset;
+		int left = (int)(center - width + 0.5);
+		if (left < 0) left = 0;
+		int right = (int)(center + width + 0.5);
+		if (right > (int)src_n) right = (int)src_n;
+		double total = 0.0;
+		for (int i = left; i < right; ++i)
+			total += fscale*fi_filter(filter, fscale*((double)i + 0.5 - center));
+		for (unsigned l = 0; l < lines; ++l) {
+			double c[4] = {0, 0, 0, 0};
+			for (int i = left; i < right; ++i) {
+				double w = fscale*fi_filter(filter, fscale*((double)i + 0.5 - center));
+				if (total > 0.0 && total != 1.0)
+					w /= total;
+				const float* p = src + ((size_t)l*src_line_stride + (size_t)i*src_px_stride)*4;
+				c[0] += w*(double)p[0]; c[1] += w*(double)p[1]; c[2] += w*(double)p[2]; c[3] += w*(double)p[3];
+			}
+			float* o = dst + ((size_t)l*dst_line_stride + (size_t)u*dst_px_stride)*4;
+			o[0] = (float)c[0]; o[1] = (float)c[1]; o[2] = (float)c[2]; o[3] = (float)c[3];
+		}
+	}
+}
+
+static int resize_freeimage(const float* src, unsigned sw, unsigned sh, float* dst, unsigned dw, unsigned dh,
+	int filter)
+{
+	if ((unsigned long long)dw*sh <= (unsigned long long)dh*sw) {
+		/* horizontal, then vertical */
+		float* tmp = (float*)malloc((size_t)dw*sh*16);
+		if (!tmp) return -3;
+		if (dw == sw) memcpy(tmp, src, (size_t)sw*sh*16);
+		else fi_pass(src, sw, sw, 1, tmp, dw, dw, 1, sh, filter);
+		if (dh == sh) memcpy(dst, tmp, (size_t)dw*dh*16);
+		else fi_pass(tmp, sh, 1, dw, dst, dh, 1, dw, dw, filter);
+		free(tmp);
+	} else {
+		float* tmp = (float*)malloc((size_t)sw*dh*16);
+		if (!tmp) return -3;
+		if (dh == sh) memcpy(tmp, src, (size_t)sw*sh*16);
+		else fi_pass(src, sh, 1, sw, tmp, dh, 1, sw, sw, filter);
+		if (dw == sw) memcpy(dst, tmp, (size_t)dw*dh*16);
+		else fi_pass(tmp, sw, sw, 1, dst, dw, dw, 1, dh, filter);
+		free(tmp);
+	}
+	return 0;
+}
+
+static int resize_any(const float* src, unsigned sw, unsigned sh, float* dst, unsigned dw, unsigned dh,
+	int filter)
+{
+	if (filter <= 1) {
+		resize_linear_space(src, sw, sh, dst, dw, dh, filter);
+		return 0;
+	}
+	return resize_freeimage(src, sw, sh, dst, dw, dh, filter);
+}
+
+/* Image::resize for an RGBAF image in `color_space` (0 linear, 1 sRGB); filter = ResizeFilter
+ * (0 Box, 1 Linear: in-tree fallback arithmetic; 2 Cubic, 3 CatmullRom, 4 BSpline: FreeImage's
+ * algorithm restated, parity unpinned).  Returns 0 or a negative error. */
 int cfo_resize_rgbaf(const float* src, unsigned sw, unsigned sh, float* dst, unsigned dw, unsigned dh,
 	int filter, int color_space)
 {
-	if (filter != 0 && filter != 1)
+	if (filter < 0 || filter > 4)
 		return -2;
 	if (!sw || !sh || !dw || !dh)
 		return -1;
@@ -119,10 +231,8 @@ int cfo_resize_rgbaf(const float* src, unsigned sw, unsigned sh, float* dst, uns
 		memcpy(dst, src, (size_t)sw*sh*16);
 		return 0;
 	}
-	if (color_space == 0) {
-		resize_linear_space(src, sw, sh, dst, dw, dh, filter);
-		return 0;
-	}
+	if (color_space == 0)
+		return resize_any(src, sw, sh, dst, dw, dh, filter);
 	/* resize in linear space: convert a copy (stored as float), resize, convert back */
 	float* lin = (float*)malloc((size_t)sw*sh*16);
 	if (!lin)
@@ -133,8 +243,10 @@ int cfo_resize_rgbaf(const float* src, unsigned sw, unsigned sh, float* dst, uns
 		lin[4*i + 2] = (float)cfo_srgb_to_linear(src[4*i + 2]);
 		lin[4*i + 3] = src[4*i + 3];
 	}
-	resize_linear_space(lin, sw, sh, dst, dw, dh, filter);
+	int rc = resize_any(lin, sw, sh, dst, dw, dh, filter);
 	free(lin);
+	if (rc)
+		return rc;
 	for (size_t i = 0; i < (size_t)dw*dh; ++i) {
 		dst[4*i + 0] = (float)cfo_linear_to_srgb(dst[4*i + 0]);
 		dst[4*i + 1] = (float)cfo_linear_to_srgb(dst[4*i + 1]);

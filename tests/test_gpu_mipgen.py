@@ -39,7 +39,7 @@ def _ulps(a, b):
     return np.abs(ai - bi)
 
 
-@pytest.mark.parametrize("filt", [0, 1])
+@pytest.mark.parametrize("filt", [0, 1, 2, 3, 4])
 def test_linear_space_chain_is_bit_exact(filt):
     rng = np.random.default_rng(1)
     base = rng.random((192, 256, 4)).astype(np.float32)
@@ -62,20 +62,22 @@ def test_base_level_pixel_types(dtype):
         assert np.array_equal(g, r)
 
 
-def test_srgb_chain_within_pow_rounding():
+@pytest.mark.parametrize("filt", [0, 3])
+def test_srgb_chain_within_pow_rounding(filt):
     img = synth.photo(256, 256, seed=4)
     with Context(0) as ctx:
-        got, _, _ = _gpu_chain(ctx, img, 9, ColorSpace.sRGB, 0)
+        got, _, _ = _gpu_chain(ctx, img, 9, ColorSpace.sRGB, filt)
         # level k from the GPU's own level k-1 on the CPU: isolates one resize step
         prev = (img.astype(np.float64)/255.0).astype(np.float32)
         worst, differing, total = 0, 0, 0
         for k, g in enumerate(got, start=1):
-            r = O.resize_rgbaf(prev, g.shape[1], g.shape[0], 0, 1)
+            r = O.resize_rgbaf(prev, g.shape[1], g.shape[0], filt, 1)
             u = _ulps(g, r)
             worst = max(worst, int(u.max()))
             differing += int((u > 0).sum())
             total += u.size
             assert np.array_equal(g[..., 3], r[..., 3])          # alpha never sees pow()
+            prev_ok = True
             prev = g
     assert worst <= 2, worst
     assert differing <= total*0.02, (differing, total)
@@ -86,8 +88,8 @@ def test_unsupported_filter_and_bad_arguments():
     d = torch.zeros((4, 4, 4), dtype=torch.float32, device="cuda")
     with Context(0) as ctx:
         with pytest.raises(CfhipError) as e:
-            ctx.generate_mips_device(x.data_ptr(), PixelType.RGBA32F, 8, 8, 128, [d.data_ptr()], filter=3)
-        assert e.value.code == -2                                # CFHIP_E_UNSUPPORTED: FreeImage's filter
+            ctx.generate_mips_device(x.data_ptr(), PixelType.RGBA32F, 8, 8, 128, [d.data_ptr()], filter=9)
+        assert e.value.code == -1                                # not a ResizeFilter
         with pytest.raises(CfhipError) as e:
             ctx.generate_mips_device(x.data_ptr(), PixelType.RGBA32F, 8, 8, 64, [d.data_ptr()])
         assert e.value.code == -1                                # pitch smaller than a row
@@ -122,7 +124,6 @@ def test_texture_generate_mipmaps_mirror():
     img = synth.photo(64, 32, seed=8)
     t = Texture(64, 32)
     assert t.set_image(img)
-    assert not t.generate_mipmaps()                      # default CatmullRom: FreeImage only
     assert t.generate_mipmaps(ResizeFilter.Box)
     assert t.mip_level_count() == 7                      # 64x32 .. 1x1
     assert t.convert(Format.BC7, Type.UNorm, Quality.Low)
@@ -130,3 +131,17 @@ def test_texture_generate_mipmaps_mirror():
     for k in range(7):
         src_k = img if k == 0 else ref[k]
         assert np.array_equal(np.asarray(t.data(k)), O.encode(src_k, int(Format.BC7), 0, quality=1))
+
+
+def test_default_catmull_rom_chain_through_the_texture_mirror():
+    from cuttlefish_amd import Quality, Texture
+    img = synth.photo(96, 64, seed=9)
+    t = Texture(96, 64)
+    assert t.set_image(img)
+    assert t.generate_mipmaps()                          # Image::ResizeFilter::CatmullRom, all levels
+    assert t.mip_level_count() == 7
+    assert t.convert(Format.BC1_RGB, Type.UNorm, Quality.Normal)
+    ref = O.mip_chain(img, 7, filter=3)
+    for k in range(7):
+        src_k = img if k == 0 else ref[k]
+        assert np.array_equal(np.asarray(t.data(k)), O.encode(src_k, int(Format.BC1_RGB), 0, quality=2))

@@ -114,4 +114,42 @@ def test_chain_and_errors():
     assert [c.shape[:2] for c in chain] == [(32, 64), (16, 32), (8, 16), (4, 8), (2, 4), (1, 2), (1, 1)]
     assert chain[0].dtype == np.float32 and chain[0][0, 0, 1] == np.float32(1/255.0)
     with pytest.raises(RuntimeError):
-        O.resize_rgbaf(chain[0], 8, 8, filter=3)               # CatmullRom: FreeImage only
+        O.resize_rgbaf(chain[0], 8, 8, filter=7)               # not a ResizeFilter
+
+
+@pytest.mark.parametrize("filt", [2, 3, 4])
+def test_freeimage_style_filters_properties(filt):
+    """Cubic / CatmullRom / BSpline (FreeImage_Rescale's algorithm restated, parity unpinned):
+    normalised weights keep constants, the interior of a ramp stays a ramp, the kernel is
+    symmetric (mirrored input -> mirrored output), and the separable passes commute with a
+    transpose."""
+    const = np.full((20, 28, 4), 0.625, np.float32)
+    assert np.allclose(O.resize_rgbaf(const, 14, 10, filter=filt), 0.625, rtol=0, atol=1e-7)
+    ramp = np.tile(np.linspace(0, 1, 64, dtype=np.float32)[None, :, None], (8, 1, 4))
+    d = np.diff(O.resize_rgbaf(ramp, 32, 4, filter=filt)[0, 4:-4, 0].astype(np.float64))
+    assert np.allclose(d, d[0], rtol=0, atol=2e-7)
+    rng = np.random.default_rng(filt)
+    img = rng.random((24, 40, 4)).astype(np.float32)
+    a = O.resize_rgbaf(img, 20, 12, filter=filt)
+    b = O.resize_rgbaf(img[:, ::-1].copy(), 20, 12, filter=filt)[:, ::-1]
+    assert np.allclose(a, b, rtol=0, atol=1e-6)
+    t = O.resize_rgbaf(np.ascontiguousarray(img.transpose(1, 0, 2)), 12, 20, filter=filt).transpose(1, 0, 2)
+    assert np.allclose(a, t, rtol=0, atol=1e-6)
+
+
+def test_catmull_rom_halving_weights_known_answer():
+    """2:1 minification: width 4, fscale 1/2, taps at +-0.25, +-0.75, +-1.25, +-1.75 of the
+    stretched kernel -> weights (before normalisation) F(x)/2 with the Catmull-Rom polynomial."""
+    def F(v):
+        v = abs(v)
+        if v < 1: return 0.5*(2 + v*v*(-5 + 3*v))
+        if v < 2: return 0.5*(4 + v*(-8 + v*(5 - v)))
+        return 0.0
+    w = np.array([F(x) for x in (-1.75, -1.25, -0.75, -0.25, 0.25, 0.75, 1.25, 1.75)])
+    w /= w.sum()
+    row = np.zeros((1, 32, 4), np.float32)
+    row[0, :, 0] = np.random.default_rng(1).random(32).astype(np.float32)
+    out = O.resize_rgbaf(row, 16, 1, filter=3)
+    u = 6                                                      # centre 12.999..: taps 9..16
+    ref = float(np.dot(w, row[0, 2*u - 3:2*u + 5, 0].astype(np.float64)))
+    assert abs(out[0, u, 0] - ref) < 1e-6
