@@ -502,28 +502,38 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 	const uint32_t nk = m6 ? 8u : (1u << ib), kbase = m6 ? 8u*khalf : 0u;
 	const uint32_t e00 = ub(f.e0, 0), e01 = ub(f.e0, 1), e02 = ub(f.e0, 2), e03 = ub(f.e0, 3);
 	const uint32_t e10 = ub(f.e1, 0), e11 = ub(f.e1, 1), e12 = ub(f.e1, 2), e13 = ub(f.e1, 3);
-	// straight-line palette: entries past this lane's 2^ib get a key that never wins
-	uint32_t pal[8];
+	// straight-line palette: entries past this lane's 2^ib get a key that never wins.
+	// A texel's key is the NEGATED 128 (sum_c w_c c_k^2 - 2 sum_c p_c (w_c c_k)) + weight_k,
+	// maximised over k; sum_c w_c p_c^2 is added once per subset (pp_sum).  Unit weights: the
+	// cross term is one v_dot4(p, c_k).  General weights (<= 7): w_c c_k <= 1785 is split into
+	// a low and a high byte plane, two v_dot4.
+	uint32_t pal[8], palh[8];
 	int base[8];
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
-		const uint32_t w = bc7_weight(ib, kbase + (uint32_t)k), iw = 64u - w;
+		const bool valid = (uint32_t)k < nk;
+		// an entry past 2^ib interpolates with weight 0: its colour stays a byte vector, so the
+		// dot products below stay in range and its constant keeps it from ever winning
+		const uint32_t w = bc7_weight(ib, valid ? kbase + (uint32_t)k : 0u), iw = 64u - w;
 		const uint32_t c0 = (__umul24(iw, e00) + __umul24(w, e10) + 32u) >> 6;
 		const uint32_t c1 = (__umul24(iw, e01) + __umul24(w, e11) + 32u) >> 6;
 		const uint32_t c2 = (__umul24(iw, e02) + __umul24(w, e12) + 32u) >> 6;
 		const uint32_t c3 = (__umul24(iw, e03) + __umul24(w, e13) + 32u) >> 6;
-		pal[k] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-		const bool valid = (uint32_t)k < nk;
-		// UNITW: the NEGATED key constant, -(128 |c_k|^2 + w_k): a texel's key is
-		// (p.c_k << 8) + base[k] = -(128 (|c_k|^2 - 2 p.c_k) + w_k), maximised over k, so one
-		// v_lshl_add per entry; |p|^2 is added per subset (pp_sum), not per texel.
-		if (UNITW)
+		if (UNITW) {
+			pal[k] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+			palh[k] = 0;
 			base[k] = valid ? -(int)((__builtin_amdgcn_udot4(pal[k], pal[k], 0u, false) << 7) | w)
 				: -0x3FFFFFFF;
-		else
-			base[k] = valid ? (int)w : -1;
+		} else {
+			const uint32_t m0 = __umul24(wt[0], c0), m1 = __umul24(wt[1], c1), m2 = __umul24(wt[2], c2),
+				m3 = __umul24(wt[3], c3);
+			pal[k] = (m0 & 255u) | ((m1 & 255u) << 8) | ((m2 & 255u) << 16) | ((m3 & 255u) << 24);
+			palh[k] = (m0 >> 8) | ((m1 >> 8) << 8) | ((m2 >> 8) << 16) | ((m3 >> 8) << 24);
+			const uint32_t qq = __umul24(m0, c0) + __umul24(m1, c1) + __umul24(m2, c2) + __umul24(m3, c3);
+			base[k] = valid ? -(int)((qq << 7) | w) : -0x3FFFFFFF;
+		}
 	}
-	uint32_t err = UNITW ? pp_sum : 0u;
+	uint32_t err = pp_sum;
 	uint32_t wp0 = 0, wp1 = 0, wp2 = 0, wp3 = 0;
 #pragma unroll 1
 	for (uint32_t r = 0; r < 4u; ++r) {
@@ -539,38 +549,23 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 			asm volatile("" : "+v"(rawj), "+v"(wrow));
 			const uint32_t p = texel<true>(tx, rawj);
 			uint32_t key;
-			if (UNITW) {
+			{
 				int bestk = -0x7FFFFFFF;
 #pragma unroll
 				for (int k = 0; k < 8; ++k) {
-					const int dt = (int)__builtin_amdgcn_udot4(p, pal[k], 0u, false);
+					int dt = (int)__builtin_amdgcn_udot4(p, pal[k], 0u, false);
+					if (!UNITW)
+						dt += (int)__builtin_amdgcn_udot4(p, palh[k], 0u, false) << 8;
 					const int v = (dt << 8) + base[k];
 					bestk = v > bestk ? v : bestk;
 				}
 				// mode 6: the other palette half lives in the neighbouring lane
 				const int other = (int)cf_xor1((uint32_t)bestk);
 				bestk = (m6 && other > bestk) ? other : bestk;
-				key = (uint32_t)(-bestk);   // 128 (|c|^2 - 2 p.c) + w, two's complement
-			} else {
-				key = 0xFFFFFFFFu;
-#pragma unroll
-				for (int k = 0; k < 8; ++k) {
-					const int d0 = (int)ub(p, 0) - (int)ub(pal[k], 0);
-					const int d1 = (int)ub(p, 1) - (int)ub(pal[k], 1);
-					const int d2 = (int)ub(p, 2) - (int)ub(pal[k], 2);
-					const int d3 = (int)ub(p, 3) - (int)ub(pal[k], 3);
-					const uint32_t dist = wt[0]*(uint32_t)(d0*d0) + wt[1]*(uint32_t)(d1*d1) +
-						wt[2]*(uint32_t)(d2*d2) + wt[3]*(uint32_t)(d3*d3);
-					const uint32_t v = (dist << 7) | (uint32_t)base[k];   // invalid: 0xFFFFFFFF
-					key = v < key ? v : key;
-				}
-			}
-			if (!UNITW) {
-				const uint32_t other = cf_xor1(key);
-				key = (m6 && other < key) ? other : key;
+				key = (uint32_t)(-bestk);   // 128 (sum w c^2 - 2 p.(w c)) + weight, two's complement
 			}
 			key = ((mrow >> j) & 1u) ? key : 0u;
-			err += UNITW ? (uint32_t)((int)key >> 7) : (key >> 7);
+			err += (uint32_t)((int)key >> 7);
 			wrow |= (key & 127u) << (8*j);
 		}
 		wp0 = wp1; wp1 = wp2; wp2 = wp3; wp3 = wrow;
@@ -735,7 +730,9 @@ __device__ __forceinline__ void fit_lane(const Tex& tx, uint32_t mask, bool m6, 
 	quantize(x0, x1, cb, ab, pbk, wt, q);
 	best.e0 = q.e0; best.e1 = q.e1; best.q0 = q.q0; best.q1 = q.q1; best.pb = q.pb;
 	bool live;
-	const uint32_t pp_sum = q00 + q11 + q22 + q33;   // sum of |p|^2 over the subset's coded channels
+	// sum over the subset of sum_c w_c p_c^2 (channels that are not coded have p = 0)
+	const uint32_t pp_sum = UNITW ? q00 + q11 + q22 + q33
+		: __umul24(wt[0], q00) + __umul24(wt[1], q11) + __umul24(wt[2], q22) + __umul24(wt[3], q33);
 	assign_lsq_lane<UNITW>(tx, mask, m6, khalf, ib, wt, pp_sum, iters > 0u, best, x0, x1, live);
 	for (uint32_t r = 0; r < iters; ++r) {
 		LaneFit cur;

@@ -109,3 +109,13 @@ def test_full_size_properties_4096(gpu_ctx):
     strip = img[2048:2048 + 16]                                 # 4 block rows incl. alpha band
     ref = O.encode(strip, BC7, quality=2, threads=8)
     assert np.array_equal(ref, a.reshape(1024, 1024 * 16)[512:516].reshape(-1))
+
+
+@pytest.mark.parametrize("quality", [2, 3])
+def test_perceptual_weights_kernel_matches_oracle_on_a_larger_tile(gpu_ctx, quality):
+    """sRGB images at >= Normal use channel weights 3:7:1:2 (S3tcConverter.cpp:196-199): the
+    weighted kernel variant (cross term split into two byte planes for v_dot4) must reproduce
+    the oracle's exact weighted errors, rotations and the alpha band included."""
+    img = synth.photo(256, 256, seed=31)
+    ref = O.encode(img, BC7, quality=quality, threads=16, color_space=1)
+    assert np.array_equal(ref, _gpu(gpu_ctx, img, quality, color_space=ColorSpace.sRGB))
