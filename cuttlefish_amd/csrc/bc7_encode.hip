@@ -253,232 +253,6 @@ __device__ __forceinline__ uint32_t bytemask4(uint32_t m)
 	return ((m*0x00204081u) & 0x01010101u)*0xFFu;
 }
 
-// D+E fused: exhaustive selector assignment over the 2^ib palette entries of
-// (f.e0, f.e1) with integer error, plus (want_lsq) the sums of the closed-form
-// least-squares refit, whose solution is left in f.nx0/nx1.
-// Texel-outer / palette-inner: the palette (<= 16 entries) lives in registers, the
-// texels are re-read from LDS one row (4 texels) per trip of a ROLLED loop -- the
-// texels are invariant across refit rounds and a fully unrolled body would be
-// hoisted by LICM into >64 live registers.  The refit sums are row operations on
-// the channel-planar copy: 12 v_dot4 per row instead of ~20 MADs per texel.
-template <bool UNITW, bool ROT, int NKMAX>
-__device__ __forceinline__ void assign_lsq(const Tex& tx, uint32_t mask, uint32_t ib,
-	const uint32_t (&wt)[4], bool want_lsq, SubFit& f)
-{
-	const uint32_t nk = 1u << ib;
-	const uint32_t e00 = ub(f.e0, 0), e01 = ub(f.e0, 1), e02 = ub(f.e0, 2), e03 = ub(f.e0, 3);
-	const uint32_t e10 = ub(f.e1, 0), e11 = ub(f.e1, 1), e12 = ub(f.e1, 2), e13 = ub(f.e1, 3);
-	uint32_t pal[NKMAX];
-	int base[NKMAX];
-#pragma unroll
-	for (int k = 0; k < NKMAX; ++k) {
-		pal[k] = 0;
-		base[k] = 0;
-		if ((uint32_t)k < nk) {
-			const uint32_t w = bc7_weight(ib, (uint32_t)k), iw = 64u - w;
-			const uint32_t c0 = (iw*e00 + w*e10 + 32u) >> 6;
-			const uint32_t c1 = (iw*e01 + w*e11 + 32u) >> 6;
-			const uint32_t c2 = (iw*e02 + w*e12 + 32u) >> 6;
-			const uint32_t c3 = (iw*e03 + w*e13 + 32u) >> 6;
-			pal[k] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-			base[k] = UNITW ? (int)((__builtin_amdgcn_udot4(pal[k], pal[k], 0u, false) << 7) | w)
-				: (int)w;
-		}
-	}
-	uint32_t err = 0, S = 0, A = 0, B = 0, C = 0;
-	uint32_t U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
-	uint32_t wp0 = 0, wp1 = 0, wp2 = 0, wp3 = 0;
-#pragma unroll 1
-	for (uint32_t r = 0; r < 4u; ++r) {
-		const uint32_t mrow = (mask >> (4u*r)) & 15u;
-		uint32_t wrow = 0;
-		const uint4 row = *reinterpret_cast<const uint4*>(tx.tp + 4u*r);
-		const uint32_t raw[4] = {row.x, row.y, row.z, row.w};
-#pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			const uint32_t p = texel<ROT>(tx, raw[j]);
-			uint32_t key;
-			if (UNITW) {
-				int bestk = 0x7FFFFFFF;
-#pragma unroll
-				for (int k = 0; k < NKMAX; ++k) {
-					if ((uint32_t)k < nk) {
-						const int dt = (int)__builtin_amdgcn_udot4(p, pal[k], 0u, false);
-						const int v = base[k] - (dt << 8);
-						bestk = v < bestk ? v : bestk;
-					}
-				}
-				key = (uint32_t)bestk + (__builtin_amdgcn_udot4(p, p, 0u, false) << 7);
-			} else {
-				key = 0xFFFFFFFFu;
-#pragma unroll
-				for (int k = 0; k < NKMAX; ++k) {
-					if ((uint32_t)k < nk) {
-						const int d0 = (int)ub(p, 0) - (int)ub(pal[k], 0);
-						const int d1 = (int)ub(p, 1) - (int)ub(pal[k], 1);
-						const int d2 = (int)ub(p, 2) - (int)ub(pal[k], 2);
-						const int d3 = (int)ub(p, 3) - (int)ub(pal[k], 3);
-						const uint32_t dist = wt[0]*(uint32_t)(d0*d0) + wt[1]*(uint32_t)(d1*d1) +
-							wt[2]*(uint32_t)(d2*d2) + wt[3]*(uint32_t)(d3*d3);
-						const uint32_t v = (dist << 7) | (uint32_t)base[k];
-						key = v < key ? v : key;
-					}
-				}
-			}
-			const bool m = (mrow >> j) & 1u;
-			err += m ? (key >> 7) : 0u;
-			wrow |= (m ? (key & 127u) : 0u) << (8*j);
-		}
-		wp0 = wp1; wp1 = wp2; wp2 = wp3; wp3 = wrow;
-		if (want_lsq) {   // uniform: the last round's refit would never be used
-			const uint32_t iwrow = (0x40404040u - wrow) & bytemask4(mrow);
-			uint32_t P[4];
-			planes<ROT>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
-			S = __builtin_amdgcn_udot4(wrow, 0x01010101u, S, false);
-			A = __builtin_amdgcn_udot4(iwrow, iwrow, A, false);
-			B = __builtin_amdgcn_udot4(iwrow, wrow, B, false);
-			C = __builtin_amdgcn_udot4(wrow, wrow, C, false);
-#pragma unroll
-			for (int c = 0; c < 4; ++c) {
-				U[c] = __builtin_amdgcn_udot4(iwrow, P[c], U[c], false);
-				V[c] = __builtin_amdgcn_udot4(wrow, P[c], V[c], false);
-			}
-		}
-	}
-	f.err = err;
-	f.w[0] = wp0; f.w[1] = wp1; f.w[2] = wp2; f.w[3] = wp3;
-
-	// closed-form least squares given these selectors
-	const uint32_t n = (uint32_t)__builtin_popcount(mask);
-	const int det = (int)(n*C) - (int)(S*S);   // = (A*C - B*B)/4096, exact
-	f.ok = det > 0;
-	const float inv = 1.0f/(64.0f*(float)(det > 0 ? det : 1));
-	const float fA = (float)A, fB = (float)B, fC = (float)C;
-#pragma unroll
-	for (int c = 0; c < 4; ++c) {
-		if ((tx.chmask >> c) & 1u) {
-			const float fU = (float)U[c], fV = (float)V[c];
-			const float t0 = fB*fV;
-			const float n0 = fmaf(fC, fU, -t0);
-			const float t1 = fB*fU;
-			const float n1 = fmaf(fA, fV, -t1);
-			f.nx0[c] = clamp255(n0*inv);
-			f.nx1[c] = clamp255(n1*inv);
-		} else {
-			f.nx0[c] = 0.0f;
-			f.nx1[c] = 0.0f;
-		}
-	}
-}
-
-// Vector fit of the texels selected by mask over the channels of tx.chmask.
-// Mirrors fit_subset() of the oracle.
-template <bool UNITW, bool ROT, int NKMAX>
-__device__ __forceinline__ void fit_vec(const Tex& tx, uint32_t mask, uint32_t cb, uint32_t ab,
-	uint32_t pbk, uint32_t ib, uint32_t iters, const uint32_t (&wt)[4], SubFit& best)
-{
-	// A: integer statistics of the subset, as row dot products on the planar copy
-	const uint32_t n = (uint32_t)__builtin_popcount(mask);
-	uint32_t s[4] = {0, 0, 0, 0};
-	uint32_t q00 = 0, q01 = 0, q02 = 0, q03 = 0, q11 = 0, q12 = 0, q13 = 0, q22 = 0, q23 = 0,
-		q33 = 0;
-#pragma unroll 1
-	for (uint32_t r = 0; r < 4u; ++r) {
-		uint32_t P[4];
-		planes<ROT>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
-		const uint32_t m4 = bytemask4((mask >> (4u*r)) & 15u);
-		const uint32_t M0 = P[0] & m4, M1 = P[1] & m4, M2 = P[2] & m4, M3 = P[3] & m4;
-		s[0] = __builtin_amdgcn_udot4(M0, 0x01010101u, s[0], false);
-		s[1] = __builtin_amdgcn_udot4(M1, 0x01010101u, s[1], false);
-		s[2] = __builtin_amdgcn_udot4(M2, 0x01010101u, s[2], false);
-		s[3] = __builtin_amdgcn_udot4(M3, 0x01010101u, s[3], false);
-		q00 = __builtin_amdgcn_udot4(M0, P[0], q00, false);
-		q01 = __builtin_amdgcn_udot4(M0, P[1], q01, false);
-		q02 = __builtin_amdgcn_udot4(M0, P[2], q02, false);
-		q03 = __builtin_amdgcn_udot4(M0, P[3], q03, false);
-		q11 = __builtin_amdgcn_udot4(M1, P[1], q11, false);
-		q12 = __builtin_amdgcn_udot4(M1, P[2], q12, false);
-		q13 = __builtin_amdgcn_udot4(M1, P[3], q13, false);
-		q22 = __builtin_amdgcn_udot4(M2, P[2], q22, false);
-		q23 = __builtin_amdgcn_udot4(M2, P[3], q23, false);
-		q33 = __builtin_amdgcn_udot4(M3, P[3], q33, false);
-	}
-	const float C00 = (float)(int)(__umul24(n, q00) - __umul24(s[0], s[0])), C01 = (float)(int)(__umul24(n, q01) - __umul24(s[0], s[1]));
-	const float C02 = (float)(int)(__umul24(n, q02) - __umul24(s[0], s[2])), C03 = (float)(int)(__umul24(n, q03) - __umul24(s[0], s[3]));
-	const float C11 = (float)(int)(__umul24(n, q11) - __umul24(s[1], s[1])), C12 = (float)(int)(__umul24(n, q12) - __umul24(s[1], s[2]));
-	const float C13 = (float)(int)(__umul24(n, q13) - __umul24(s[1], s[3])), C22 = (float)(int)(__umul24(n, q22) - __umul24(s[2], s[2]));
-	const float C23 = (float)(int)(__umul24(n, q23) - __umul24(s[2], s[3])), C33 = (float)(int)(__umul24(n, q33) - __umul24(s[3], s[3]));
-
-	// principal axis: C^4 e_amax
-	float bestd = C00;
-	float v0 = C00, v1 = C01, v2 = C02, v3 = C03;
-	if (C11 > bestd) { bestd = C11; v0 = C01; v1 = C11; v2 = C12; v3 = C13; }
-	if (C22 > bestd) { bestd = C22; v0 = C02; v1 = C12; v2 = C22; v3 = C23; }
-	if (C33 > bestd) { bestd = C33; v0 = C03; v1 = C13; v2 = C23; v3 = C33; }
-#pragma unroll
-	for (int it = 0; it < 3; ++it) {
-		float r0 = C00*v0; r0 = fmaf(C01, v1, r0); r0 = fmaf(C02, v2, r0); r0 = fmaf(C03, v3, r0);
-		float r1 = C01*v0; r1 = fmaf(C11, v1, r1); r1 = fmaf(C12, v2, r1); r1 = fmaf(C13, v3, r1);
-		float r2 = C02*v0; r2 = fmaf(C12, v1, r2); r2 = fmaf(C22, v2, r2); r2 = fmaf(C23, v3, r2);
-		float r3 = C03*v0; r3 = fmaf(C13, v1, r3); r3 = fmaf(C23, v2, r3); r3 = fmaf(C33, v3, r3);
-		v0 = r0; v1 = r1; v2 = r2; v3 = r3;
-	}
-	const float mx = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
-	float axis[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-	if (mx > 0.0f) {
-		const float im = 1.0f/mx;
-		v0 = v0*im; v1 = v1*im; v2 = v2*im; v3 = v3*im;
-		float l2 = v0*v0;
-		l2 = fmaf(v1, v1, l2);
-		l2 = fmaf(v2, v2, l2);
-		l2 = fmaf(v3, v3, l2);
-		const float is = 1.0f/sqrtf(l2);
-		axis[0] = v0*is; axis[1] = v1*is; axis[2] = v2*is; axis[3] = v3*is;
-	}
-
-	// B: extremes of the projection on the axis
-	const float in = 1.0f/(float)n;
-	float mean[4];
-#pragma unroll
-	for (int c = 0; c < 4; ++c)
-		mean[c] = (float)s[c]*in;
-	float tmin = 3.0e38f, tmax = -3.0e38f;
-#pragma unroll 1
-	for (uint32_t r = 0; r < 4u; ++r) {
-		const uint4 row = *reinterpret_cast<const uint4*>(tx.tp + 4u*r);
-		const uint32_t raw[4] = {row.x, row.y, row.z, row.w};
-		const uint32_t mrow = (mask >> (4u*r)) & 15u;
-#pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			const uint32_t p = texel<ROT>(tx, raw[j]);
-			const bool m = (mrow >> j) & 1u;
-			float t = axis[0]*(fb(p, 0) - mean[0]);
-			t = fmaf(axis[1], fb(p, 1) - mean[1], t);
-			t = fmaf(axis[2], fb(p, 2) - mean[2], t);
-			t = fmaf(axis[3], fb(p, 3) - mean[3], t);
-			tmin = m ? fminf(tmin, t) : tmin;
-			tmax = m ? fmaxf(tmax, t) : tmax;
-		}
-	}
-	float x0[4], x1[4];
-#pragma unroll
-	for (int c = 0; c < 4; ++c) {
-		x0[c] = clamp255(fmaf(axis[c], tmin, mean[c]));
-		x1[c] = clamp255(fmaf(axis[c], tmax, mean[c]));
-	}
-
-	// C/D then E rounds, always restarting from the best
-	quantize(x0, x1, cb, ab, pbk, wt, best);
-	assign_lsq<UNITW, ROT, NKMAX>(tx, mask, ib, wt, iters > 0u, best);
-	for (uint32_t r = 0; r < iters; ++r) {
-		SubFit cur;
-		quantize(best.nx0, best.nx1, cb, ab, pbk, wt, cur);
-		assign_lsq<UNITW, ROT, NKMAX>(tx, mask, ib, wt, r + 1u < iters, cur);
-		if (best.ok && cur.err < best.err)
-			best = cur;
-	}
-}
-
 // ---------------------------------------------------------------------------
 // One fit per lane.  Every VALU instruction costs the wave the same issue time whatever
 // the number of active lanes (tools/ubench/valu_rate.hip: 4 cycles per integer
@@ -487,7 +261,7 @@ __device__ __forceinline__ void fit_vec(const Tex& tx, uint32_t mask, uint32_t c
 // channel set, endpoint precision, p-bit kind, index width and subset mask are per-lane
 // values here.  Mode 6 alone is spread over a lane pair (16 palette entries, 8 per lane;
 // the per-texel keys meet through a DPP lane^1 exchange).  Same arithmetic as
-// fit_vec/assign_lsq (the oracle's fit_subset / fit_scalar).
+// the oracle's fit_subset / fit_scalar.
 
 struct LaneFit {
 	uint32_t e0, e1, q0, q1, pb, err;
@@ -883,7 +657,7 @@ __device__ __forceinline__ uint4 pack_block_wave(const uint32_t* wcol, uint32_t 
 
 // Partition score of the two-phase search (oracle: subset_residual): the scatter of the
 // subset that no line through its mean can capture, (trace(C) - a'Ca)/n, with a = the
-// power-iterated principal axis.  Same statistics and axis arithmetic as fit_vec.
+// power-iterated principal axis.  Same statistics and axis arithmetic as fit_lane.
 __device__ __forceinline__ float subset_residual(const Tex& tx, uint32_t mask)
 {
 	const uint32_t n = (uint32_t)__builtin_popcount(mask);
@@ -1187,8 +961,8 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 					mask = s ? p2 : (~p2 & 0xFFFFu);
 				else
 					mask = s == 0u ? m30 : (s == 1u ? m31 : m32);
-				SubFit f;
-				fit_vec<UNITW, false, 8>(tx, mask, cb, ab, pbk, ib, iters, wv, f);
+				LaneFit f;
+				fit_lane<UNITW>(tx, mask, false, 0u, cb, ab, pbk, ib, iters, wv, false, f);
 				c.err += f.err;
 				if (s == 0u) { c.q[0] = f.q0; c.q[1] = f.q1; c.pb |= f.pb; }
 				else if (s == 1u) { c.q[2] = f.q0; c.q[3] = f.q1; c.pb |= f.pb << 2; }
