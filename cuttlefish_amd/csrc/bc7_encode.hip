@@ -526,17 +526,6 @@ __device__ __forceinline__ uint32_t w2i(uint32_t w, uint32_t ib)
 	return (w*((1u << ib) - 1u) + 32u) >> 6;
 }
 
-// OR over the wavefront, uniform result (all 64 lanes active).
-__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
-{
-	v |= cf_dpp<0xB1>(v);
-	v |= cf_dpp<0x4E>(v);
-	v |= cf_dpp<0x141>(v);
-	v |= cf_dpp<0x140>(v);
-	return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16) |
-		(uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-}
-
 // Bit-pack the winning candidate with the whole wavefront (same layout as pack_block /
 // the oracle's pack()): the winner's fields are read from its LDS column by every lane,
 // each lane forms ONE bit field (value, offset, width) and the 128-bit block is the OR of
@@ -648,10 +637,10 @@ __device__ __forceinline__ uint4 pack_block_wave(const uint32_t* wcol, uint32_t 
 	const unsigned long long vv = (unsigned long long)val << sh;
 	const uint32_t lo = (uint32_t)vv, hi = (uint32_t)(vv >> 32);
 	uint4 r;
-	r.x = wave_or_u32(wi == 0u ? lo : 0u);
-	r.y = wave_or_u32(wi == 1u ? lo : (wi == 0u ? hi : 0u));
-	r.z = wave_or_u32(wi == 2u ? lo : (wi == 1u ? hi : 0u));
-	r.w = wave_or_u32(wi == 3u ? lo : (wi == 2u ? hi : 0u));
+	r.x = cf_wave_or_u32(wi == 0u ? lo : 0u);
+	r.y = cf_wave_or_u32(wi == 1u ? lo : (wi == 0u ? hi : 0u));
+	r.z = cf_wave_or_u32(wi == 2u ? lo : (wi == 1u ? hi : 0u));
+	r.w = cf_wave_or_u32(wi == 3u ? lo : (wi == 2u ? hi : 0u));
 	return r;
 }
 

@@ -135,6 +135,17 @@ __device__ __forceinline__ uint32_t cf_wave_min_u32(uint32_t k)
 	return a < b ? a : b;
 }
 
+// OR over the wavefront, uniform result (all 64 lanes active).
+__device__ __forceinline__ uint32_t cf_wave_or_u32(uint32_t v)
+{
+	v |= cf_dpp<0xB1>(v);
+	v |= cf_dpp<0x4E>(v);
+	v |= cf_dpp<0x141>(v);
+	v |= cf_dpp<0x140>(v);
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16) |
+		(uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
 // wave64 argmin of a 64-bit key; every lane gets the minimum (all lanes active).
 __device__ __forceinline__ unsigned long long cf_wave_min_u64(unsigned long long k)
 {

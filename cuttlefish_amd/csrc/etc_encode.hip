@@ -726,22 +726,29 @@ __device__ __forceinline__ uint2 eac_search(const uint32_t* tp, int kind, int ch
 		const int b0 = kind == 1 ? (centre - 4)/8 : (kind == 2 ? centre/8 : centre);
 		uint32_t berr = 0xFFFFFFFFu;
 		int bbase = 0, bdb = 0;
+		int mods[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k)
+			mods[k] = k_eac_mod[t][k];
 		for (int db = -R; db <= R; ++db) {
 			const int base = clampi(b0 + db, bmin, bmax);
+			// the eight decoded values of this (base, table, multiplier): once per base, not per texel
+			int dec[8];
+#pragma unroll
+			for (int k = 0; k < 8; ++k)
+				dec[k] = eac_decode(kind, base, mods[k], mult);
 			uint32_t err = 0;
-#pragma unroll 1
+#pragma unroll 4
 			for (uint32_t i = 0; i < 16u; ++i) {
-				if (!((active >> i) & 1u))
-					continue;
 				const int v = eac_value(tp, i, kind, ch);
 				uint32_t be = 0xFFFFFFFFu;
 #pragma unroll
 				for (int k = 0; k < 8; ++k) {
-					const int d = eac_decode(kind, base, k_eac_mod[t][k], mult) - v;
+					const int d = dec[k] - v;
 					const uint32_t e = (uint32_t)(d*d);
 					be = e < be ? e : be;
 				}
-				err += be;
+				err += ((active >> i) & 1u) ? be : 0u;
 			}
 			if (err < berr) { berr = err; bbase = base; bdb = db + R; }
 		}
@@ -753,10 +760,10 @@ __device__ __forceinline__ uint2 eac_search(const uint32_t* tp, int kind, int ch
 	pay = (uint32_t)__shfl((int)pay, (int)wl, 64);
 	const int base = (int)(short)(pay & 0xFFFFu), mult = (int)((pay >> 16) & 255u),
 		table = (int)(pay >> 24);
-	unsigned long long bits = 0ull;
-#pragma unroll 1
-	for (uint32_t i = 0; i < 16u; ++i) {
-		const uint32_t x = i & 3u, y = i >> 2, k = x*4u + y;
+	// selectors: lane i < 16 owns texel i, the 48 index bits are the OR of the 16 contributions
+	unsigned long long bits;
+	{
+		const uint32_t i = lane & 15u, x = i & 3u, y = i >> 2, k = x*4u + y;
 		const int v = eac_value(tp, i, kind, ch);
 		uint32_t be = 0xFFFFFFFFu, bk = 0;
 #pragma unroll
@@ -765,7 +772,9 @@ __device__ __forceinline__ uint2 eac_search(const uint32_t* tp, int kind, int ch
 			const uint32_t e = (uint32_t)(d*d);
 			if (e < be) { be = e; bk = (uint32_t)j; }
 		}
-		bits |= (unsigned long long)bk << (45u - 3u*k);
+		const unsigned long long mine = lane < 16u ? (unsigned long long)bk << (45u - 3u*k) : 0ull;
+		bits = ((unsigned long long)cf_wave_or_u32((uint32_t)(mine >> 32)) << 32) |
+			cf_wave_or_u32((uint32_t)mine);
 	}
 	// bytes: base, mult<<4|table, then the 48 index bits big-endian
 	const uint32_t b0 = (uint32_t)(base & 255), b1 = ((uint32_t)mult << 4) | (uint32_t)table;
