@@ -64,10 +64,16 @@ def cpu_baseline(img, gpu_payload, width, budget_s=15.0):
     mpix = strip.shape[0] * strip.shape[1] / 1e6
     bw = width // 4
     got = gpu_payload.reshape(-1, bw * 16)[y0 // 4:y0 // 4 + rows].reshape(-1)
+    # single-thread figure on a few block rows of the same strip (SURVEY 8d asks for T and T=1)
+    t1_rows = min(rows, 2)
+    t0 = time.perf_counter()
+    O.encode(strip[:t1_rows * 4], fmt, quality=2, threads=1)
+    dt1 = time.perf_counter() - t0
     dec_cpu = O.decode(ref, fmt, width, rows * 4)
     dec_gpu = O.decode(got, fmt, width, rows * 4)
     return {
         "value": round(mpix / dt, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+        "value_1_thread": round(t1_rows * 4 * strip.shape[1] / 1e6 / dt1, 4),
         "sample": "rows %d..%d of the same 4096x4096 tile (%d blocks, %.1f s)" %
                   (y0, y0 + rows * 4, rows * bw, dt),
         "psnr_y_cpu": round(synth.psnr_y(strip, dec_cpu), 3),
