@@ -526,15 +526,17 @@ __device__ __forceinline__ uint32_t w2i(uint32_t w, uint32_t ib)
 	return (w*((1u << ib) - 1u) + 32u) >> 6;
 }
 
-// Bit-pack the winning candidate with the whole wavefront (same layout as pack_block /
-// the oracle's pack()): the winner's fields are read from its LDS column by every lane,
-// each lane forms ONE bit field (value, offset, width) and the 128-bit block is the OR of
-// all of them.
-//   lanes  0..15 : first index field, texel = lane        lanes 16..31 : second index field
-//   lanes 32..55 : endpoint field (channel-major)         lanes 56..61 : p-bits
-//   lane  62     : mode / partition / rotation / index-selector header
-__device__ __forceinline__ uint4 pack_block_wave(const uint32_t* wcol, uint32_t id, uint32_t lane)
+// Bit-pack the winning candidate(s) with the whole wavefront (same layout as the oracle's
+// pack()).  One block per wave (pair = false, 64 lanes) or two (pair = true, 32 lanes each):
+// every lane reads its block's winner from that lane's LDS column, forms its bit fields
+// (value, offset) and the 128-bit block is the OR of the contributions of the group.
+// Field slots f (a lane owns slot hl, and hl + 32 too when its group has only 32 lanes):
+//    0..15 : first index field, texel = f        16..31 : second index field, texel = f - 16
+//   32..55 : endpoint field (channel-major)      56..61 : p-bits      62 : mode/partition/... header
+__device__ __forceinline__ uint4 pack_block_group(const uint32_t* wcol, uint32_t id, uint32_t lane,
+	bool pair)
 {
+	const uint32_t h = lane >> 5, hl = pair ? (lane & 31u) : lane, hbase = pair ? (lane & 32u) : 0u;
 	uint32_t mode, part = 0, rot = 0, isel = 0;
 	if (id == 0u) mode = 6;
 	else if (id < 5u) { mode = 5; rot = id - 1u; }
@@ -560,18 +562,22 @@ __device__ __forceinline__ uint4 pack_block_wave(const uint32_t* wcol, uint32_t 
 	if (ns == 2u) a1 = k_anchor2[part];
 	else if (ns == 3u) { a1 = k_anchor3a[part]; a2 = k_anchor3b[part]; }
 
-	// texel t = lane & 15: subset, both indices
-	const uint32_t t = lane & 15u;
+	// texel t = hl & 15: subset, both indices
+	const uint32_t t = hl & 15u;
 	const uint32_t sb = ns == 1u ? 0u : (ns == 2u ? ((p2 >> t) & 1u) : ((p3 >> (2u*t)) & 3u));
 	const uint32_t wv = (wcol[(7u + (t >> 2))*CF_WG_THREADS] >> (8u*(t & 3u))) & 255u;
 	const uint32_t ws = (wcol[(11u + (t >> 2))*CF_WG_THREADS] >> (8u*(t & 3u))) & 255u;
 	uint32_t idxv = w2i(wv, ibc);
 	uint32_t idxs = iba ? w2i(ws, iba) : 0u;
-	// anchors decide the endpoint order of their subset
-	const uint32_t sw0 = (uint32_t)__builtin_amdgcn_readlane((int)idxv, 0) >> (ibc - 1u);
-	const uint32_t sw1 = ns > 1u ? (uint32_t)__builtin_amdgcn_readlane((int)idxv, (int)a1) >> (ibc - 1u) : 0u;
-	const uint32_t sw2 = ns > 2u ? (uint32_t)__builtin_amdgcn_readlane((int)idxv, (int)a2) >> (ibc - 1u) : 0u;
-	const uint32_t sws = iba ? (uint32_t)__builtin_amdgcn_readlane((int)idxs, 0) >> (iba - 1u) : 0u;
+	// anchors decide the endpoint order of their subset (texel a lives in lane hbase + a)
+	const uint32_t i0 = (uint32_t)__shfl((int)idxv, (int)hbase, 64);
+	const uint32_t i1 = (uint32_t)__shfl((int)idxv, (int)(hbase + a1), 64);
+	const uint32_t i2 = (uint32_t)__shfl((int)idxv, (int)(hbase + a2), 64);
+	const uint32_t is0 = (uint32_t)__shfl((int)idxs, (int)hbase, 64);
+	const uint32_t sw0 = i0 >> (ibc - 1u);
+	const uint32_t sw1 = ns > 1u ? i1 >> (ibc - 1u) : 0u;
+	const uint32_t sw2 = ns > 2u ? i2 >> (ibc - 1u) : 0u;
+	const uint32_t sws = iba ? is0 >> (iba - 1u) : 0u;
 	const uint32_t swmask = sw0 | (sw1 << 1) | (sw2 << 2);
 	idxv = ((swmask >> sb) & 1u) ? ((1u << ibc) - 1u) - idxv : idxv;
 	idxs = sws ? ((1u << iba) - 1u) - idxs : idxs;
@@ -583,64 +589,73 @@ __device__ __forceinline__ uint4 pack_block_wave(const uint32_t* wcol, uint32_t 
 	const uint32_t baseA = base_pb + npb;
 	const uint32_t baseB = baseA + 16u*ib - ns;
 
-	uint32_t val = 0, off = 0;
-	bool have = false;
-	if (lane < 16u) {
-		const uint32_t before = (t > 0u ? 1u : 0u) + ((ns >= 2u && t > a1) ? 1u : 0u) +
-			((ns == 3u && t > a2) ? 1u : 0u);
-		val = swapsets ? idxs : idxv;
-		off = baseA + t*ib - before;
-		have = true;
-	} else if (lane < 32u) {
-		val = swapsets ? idxv : idxs;
-		off = baseB + t*ib2 - (t > 0u ? 1u : 0u);
-		have = ib2 != 0u;
-	} else if (lane < 56u) {
-		const uint32_t f = lane - 32u;
-		const uint32_t ch = f/ne, e = f - ch*ne;
-		const uint32_t es = e ^ ((swmask >> (e >> 1)) & 1u);          // endpoint order after the swap
-		const uint32_t qw = wcol[es*CF_WG_THREADS];
-		if (ch < 3u) {
-			val = (qw >> (8u*ch)) & 255u;
-			off = hdr + (ch*ne + e)*cb;
+	uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+	const uint32_t npass = pair ? 2u : 1u;
+	for (uint32_t pass = 0; pass < npass; ++pass) {
+		const uint32_t f = hl + 32u*pass;
+		uint32_t val = 0, off = 0;
+		bool have = false;
+		if (f < 16u) {
+			const uint32_t before = (t > 0u ? 1u : 0u) + ((ns >= 2u && t > a1) ? 1u : 0u) +
+				((ns == 3u && t > a2) ? 1u : 0u);
+			val = swapsets ? idxs : idxv;
+			off = baseA + t*ib - before;
 			have = true;
-		} else if (ch == 3u && ab) {
-			// modes 4/5: the scalar plane's endpoints are parked in q[4], q[5] (byte 3)
-			const uint32_t sq = wcol[(4u + ((e ^ sws) & 1u))*CF_WG_THREADS];
-			val = (iba ? sq : qw) >> 24;
-			off = hdr + 3u*ne*cb + e*ab;
+		} else if (f < 32u) {
+			val = swapsets ? idxv : idxs;
+			off = baseB + t*ib2 - (t > 0u ? 1u : 0u);
+			have = ib2 != 0u;
+		} else if (f < 56u) {
+			const uint32_t g = f - 32u;
+			const uint32_t ch = g/ne, e = g - ch*ne;
+			const uint32_t es = e ^ ((swmask >> (e >> 1)) & 1u);          // endpoint order after the swap
+			const uint32_t qw = wcol[es*CF_WG_THREADS];
+			if (ch < 3u) {
+				val = (qw >> (8u*ch)) & 255u;
+				off = hdr + (ch*ne + e)*cb;
+				have = true;
+			} else if (ch == 3u && ab) {
+				// modes 4/5: the scalar plane's endpoints are parked in q[4], q[5] (byte 3)
+				const uint32_t sq = wcol[(4u + ((e ^ sws) & 1u))*CF_WG_THREADS];
+				val = (iba ? sq : qw) >> 24;
+				off = hdr + 3u*ne*cb + e*ab;
+				have = true;
+			}
+		} else if (f < 62u) {
+			const uint32_t e = f - 56u;
+			const uint32_t pbw = wcol[6u*CF_WG_THREADS];
+			if (pk == 1u && e < ne) {
+				val = (pbw >> (e ^ ((swmask >> (e >> 1)) & 1u))) & 1u;
+				off = base_pb + e;
+				have = true;
+			} else if (pk == 2u && e < 2u) {
+				// shared p-bit of subset e: both endpoint bits are equal
+				val = (pbw >> (2u*e)) & 1u;
+				off = base_pb + e;
+				have = true;
+			}
+		} else if (f == 62u) {
+			val = (1u << mode) | (part << (mode + 1u)) | (rot << (mode + 1u + pbn)) |
+				(isel << (mode + 1u + pbn + 2u));
+			if (!(mode == 4u || mode == 5u))
+				val = (1u << mode) | (part << (mode + 1u));
+			off = 0;
 			have = true;
 		}
-	} else if (lane < 62u) {
-		const uint32_t e = lane - 56u;
-		const uint32_t pbw = wcol[6u*CF_WG_THREADS];
-		if (pk == 1u && e < ne) {
-			val = (pbw >> (e ^ ((swmask >> (e >> 1)) & 1u))) & 1u;
-			off = base_pb + e;
-			have = true;
-		} else if (pk == 2u && e < 2u) {
-			// shared p-bit of subset e: both endpoint bits are equal
-			val = (pbw >> (2u*e)) & 1u;
-			off = base_pb + e;
-			have = true;
-		}
-	} else if (lane == 62u) {
-		val = (1u << mode) | (part << (mode + 1u)) | (rot << (mode + 1u + pbn)) |
-			(isel << (mode + 1u + pbn + 2u));
-		if (!(mode == 4u || mode == 5u))
-			val = (1u << mode) | (part << (mode + 1u));
-		off = 0;
-		have = true;
+		val = have ? val : 0u;
+		const uint32_t wi = off >> 5, sh = off & 31u;
+		const unsigned long long vv = (unsigned long long)val << sh;
+		const uint32_t lo = (uint32_t)vv, hi = (uint32_t)(vv >> 32);
+		w0 |= wi == 0u ? lo : 0u;
+		w1 |= wi == 1u ? lo : (wi == 0u ? hi : 0u);
+		w2 |= wi == 2u ? lo : (wi == 1u ? hi : 0u);
+		w3 |= wi == 3u ? lo : (wi == 2u ? hi : 0u);
 	}
-	val = have ? val : 0u;
-	const uint32_t wi = off >> 5, sh = off & 31u;
-	const unsigned long long vv = (unsigned long long)val << sh;
-	const uint32_t lo = (uint32_t)vv, hi = (uint32_t)(vv >> 32);
 	uint4 r;
-	r.x = cf_wave_or_u32(wi == 0u ? lo : 0u);
-	r.y = cf_wave_or_u32(wi == 1u ? lo : (wi == 0u ? hi : 0u));
-	r.z = cf_wave_or_u32(wi == 2u ? lo : (wi == 1u ? hi : 0u));
-	r.w = cf_wave_or_u32(wi == 3u ? lo : (wi == 2u ? hi : 0u));
+	r.x = cf_group_or_u32(w0, pair, h);
+	r.y = cf_group_or_u32(w1, pair, h);
+	r.z = cf_group_or_u32(w2, pair, h);
+	r.w = cf_group_or_u32(w3, pair, h);
 	return r;
 }
 
@@ -727,11 +742,15 @@ __device__ __forceinline__ float subset_residual(const Tex& tx, uint32_t mask)
 // Encode one block with the whole wavefront.  tp: the block's 16 texels in LDS
 // (colour mask already applied), identical for every lane.
 template <bool UNITW, bool EXH>
-__device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t* pl,
-	uint32_t* cslot, const cf_kparams& kp, uint32_t lane0, bool& is_winner)
+__device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint32_t* plan, uint32_t b,
+	bool pair, uint32_t* cslot, const cf_kparams& kp, uint32_t lane0)
 {
 	uint32_t lane = lane0;
-	const bool has_alpha = __ballot(lane < 16u && (tp[lane & 15u] >> 24) != 255u) != 0ull;
+	// pair: blocks b and b + 1, both opaque, Low or Normal: one per half wavefront
+	const uint32_t h = lane >> 5, hbase = pair ? (lane & 32u) : 0u;
+	const uint32_t* tp = tile + (pair ? b + h : b)*16u;
+	const uint32_t* pl = plan + (pair ? b + h : b)*16u;
+	const bool has_alpha = !pair && __ballot(lane < 16u && (tp[lane & 15u] >> 24) != 255u) != 0ull;
 	const uint32_t quality = kp.quality;
 	const uint32_t iters = (0x32110u >> (4u*(quality < 4u ? quality : 4u))) & 15u;   // refit rounds 0,1,1,2,3
 	const uint32_t wt[4] = {kp.wt[0], kp.wt[1], kp.wt[2], kp.wt[3]};
@@ -739,17 +758,25 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 	uint32_t best_err = 0xFFFFFFFFu, best_id = 0x7FFFFFFFu;   // payload fields: cslot (LDS)
 
 	// ---- fit streams: one fit per lane (fit_lane) ----
-	// stream 0:  lanes  0..1  : mode 6, palette half = lane
+	// Opaque blocks at Low / Normal use the 32-lane layout (two such blocks share a wave):
+	//    hl  0..1  : mode 6, palette half = hl
+	//    Normal: hl 2..5 / 6..9 : vector / scalar plane of mode 5, rotation hl-2 / hl-6
+	//            hl 10..21 : mode 1, its 6 best partitions x 2 subsets; hl 22..31 : mode 3, 5 best
+	//    Low:    hl 2 / 3 : mode 5 rotation 0;  hl 4..31 : mode 1, its 14 best partitions
+	// Everything else uses the 64-lane layout:
+	// stream 0:  lanes  0..1  : mode 6
 	//            lanes  2..13 : vector plane of candidate 1 + (lane-2) (mode 5 x rot, mode 4 x rot x isel)
 	//            lanes 14..25 : scalar plane (rotated alpha) of candidate 1 + (lane-14)
-	//            lanes 26..57 : two-subset partitions, 16 x 2 subsets: modes 1 + 3 with their
-	//                           8 best partitions each, or one mode (1 below Normal, 7 for
-	//                           blocks with alpha) with its 16 best
-	// stream 1 (Production and up, opaque blocks):
+	//            lanes 26..57 : two-subset partitions, 16 x 2 subsets: mode 7 with its 16 best
+	//                           (blocks with alpha) or modes 1 + 3 with 8 each (High, opaque)
+	// stream 1 (High, opaque blocks):
 	//            lanes  0..29 : three-subset partitions, modes 0 + 2 with 5 partitions each
-	// The partitions come from phase 1 (lane = partition): every partition is scored once per
-	// subset count with the residual estimator and the best are taken in (score, index) order.
+	// The partitions come from phase 1: every partition is scored once per subset count with
+	// the residual estimator and the best are taken in (score, index) order.
 	// Highest instead refits every partition (below), after a stream 0 without partitions.
+	const bool lay32 = !EXH && !has_alpha && (quality == 1u || quality == 2u);
+	const uint32_t hl = lay32 ? (lane & 31u) : lane;
+	const bool slot_ok = !lay32 || pair || lane < 32u;
 	bool solved = false;
 	{
 		const uint32_t nstreams = (!EXH && !has_alpha && quality >= 3u) ? 2u : 1u;
@@ -759,51 +786,80 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 			asm volatile("" : "+v"(lane));   // roles are recomputed per stream, not kept
 			const uint32_t ns = 2u + st;
 			const bool parts = !EXH && quality >= 1u;
-			// ---- phase 1: partition scores and selection ----
-			const bool twomodes = st == 1u || (!has_alpha && quality >= 2u);
-			const uint32_t per = st == 1u ? 5u : (twomodes ? 8u : 16u);   // partitions per mode
-			const uint32_t pl0 = st == 1u ? 0u : 26u;                     // first partition lane
-			const uint32_t pidx = lane - pl0;                             // wraps for lanes below pl0
-			const uint32_t rankall = st == 1u ? pidx/3u : pidx >> 1;
-			const uint32_t sub = pidx - rankall*ns;
-			const bool plane = parts && lane >= pl0 && rankall < (twomodes ? 2u*per : per);
-			const uint32_t mi = (twomodes && rankall >= per) ? 1u : 0u;
-			const uint32_t rank = rankall - mi*per;
+			// partition lanes: first lane, slots of the first mode, slots in all
+			uint32_t pfirst, nper0, nslots;
+			if (lay32) {
+				if (quality == 2u) { pfirst = 10u; nper0 = 6u; nslots = 11u; }
+				else { pfirst = 4u; nper0 = 14u; nslots = 14u; }
+			} else if (st == 1u) { pfirst = 0u; nper0 = 5u; nslots = 10u; }
+			else if (has_alpha) { pfirst = 26u; nper0 = 16u; nslots = 16u; }
+			else { pfirst = 26u; nper0 = 8u; nslots = 16u; }
+			const uint32_t rel = hl - pfirst;                            // wraps below pfirst
+			const uint32_t slotidx = st == 1u ? rel/3u : rel >> 1;
+			const uint32_t sub = rel - slotidx*ns;
+			const bool plane = parts && slot_ok && hl >= pfirst && slotidx < nslots;
+			const uint32_t mi = slotidx >= nper0 ? 1u : 0u;
+			const uint32_t rank = slotidx - mi*nper0;
 			uint32_t mypart = 0;
+			// ---- phase 1: partition scores (one partition per lane, two when the group has
+			// only 32 lanes) and selection of the nper0 best by iterated group minimum ----
 			if (parts) {
-				const uint32_t p2 = k_part2[lane], p3 = k_part3[lane];
-				float sc = 0.0f;
-				for (uint32_t sb = 0; sb < ns; ++sb) {
-					uint32_t mask;
-					if (st == 0u)
-						mask = sb ? p2 : (~p2 & 0xFFFFu);
-					else {
-						mask = 0;
+				uint32_t key0[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+				const uint32_t npi = pair ? 2u : 1u;
+				for (uint32_t pi = 0; pi < npi; ++pi) {
+					const uint32_t part = pair ? hl + 32u*pi : lane;
+					const uint32_t p2 = k_part2[part], p3 = k_part3[part];
+					float sc = 0.0f;
+					for (uint32_t sb = 0; sb < ns; ++sb) {
+						uint32_t mask;
+						if (st == 0u)
+							mask = sb ? p2 : (~p2 & 0xFFFFu);
+						else {
+							mask = 0;
 #pragma unroll
-						for (int i = 0; i < 16; ++i)
-							mask |= (((p3 >> (2*i)) & 3u) == sb ? 1u : 0u) << i;
+							for (int i = 0; i < 16; ++i)
+								mask |= (((p3 >> (2*i)) & 3u) == sb ? 1u : 0u) << i;
+						}
+						sc = sc + subset_residual(txp, mask);
 					}
-					sc = sc + subset_residual(txp, mask);
+					const uint32_t kk = (__float_as_uint(sc) & ~63u) | part;
+					if (pi == 0u) key0[0] = kk; else key0[1] = kk;
 				}
-				const uint32_t key0 = (__float_as_uint(sc) & ~63u) | lane;
 				const uint32_t nruns = st == 1u ? 2u : 1u;   // mode 0 ranks its own 16 partitions
 				for (uint32_t run = 0; run < nruns; ++run) {
 					const uint32_t npart = (st == 1u && run == 0u) ? 16u : 64u;
-					uint32_t key = lane < npart ? key0 : 0xFFFFFFFFu;
-					for (uint32_t t = 0; t < per; ++t) {
-						const uint32_t kmin = cf_wave_min_u32(key);
+					uint32_t ka = (key0[0] & 63u) < npart ? key0[0] : 0xFFFFFFFFu, kb = key0[1];
+					for (uint32_t t = 0; t < nper0; ++t) {
+						const uint32_t kmin = cf_group_min_u32(ka < kb ? ka : kb, pair, h);
 						const bool mine = rank == t && (st == 0u || mi == run);
 						mypart = mine ? (kmin & 63u) : mypart;
-						key = key == kmin ? 0xFFFFFFFFu : key;
+						ka = ka == kmin ? 0xFFFFFFFFu : ka;
+						kb = kb == kmin ? 0xFFFFFFFFu : kb;
 					}
 				}
 			}
 			// ---- lane roles ----
 			asm volatile("" : "+v"(lane), "+v"(mypart));   // nothing of phase 1 but mypart lives on
-			const bool m6 = st == 0u && lane < 2u;
-			const bool sca = st == 0u && lane >= 14u && lane < 26u;
-			const bool vecp = st == 0u && lane >= 2u && lane < 14u;
-			const uint32_t cid = m6 ? 0u : 1u + (lane - (sca ? 14u : 2u));   // meaningful for vecp / sca
+			const bool m6 = st == 0u && slot_ok && hl < 2u;
+			bool sca, vecp;
+			uint32_t cid;
+			if (lay32) {
+				if (quality == 2u) {
+					vecp = slot_ok && hl >= 2u && hl < 6u;
+					sca = slot_ok && hl >= 6u && hl < 10u;
+					cid = hl - (sca ? 5u : 1u);
+				} else {
+					vecp = slot_ok && hl == 2u;
+					sca = slot_ok && hl == 3u;
+					cid = 1u;
+				}
+			} else {
+				sca = st == 0u && lane >= 14u && lane < 26u;
+				vecp = st == 0u && lane >= 2u && lane < 14u;
+				cid = 1u + (lane - (sca ? 14u : 2u));
+			}
+			const uint32_t s2off = lay32 ? (quality == 2u ? 4u : 1u) : (st == 0u ? 12u : 2u);
+			cid = m6 ? 0u : cid;   // meaningful for vecp / sca
 			uint32_t rot = 0, cb = 7, ab = 7, pbk = 1, ib = 4, idbase = 0, mask = 0xFFFFu;
 			bool active = m6;
 			if (vecp || sca) {
@@ -816,7 +872,7 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 					rot = (cid - 5u) & 3u; pbk = 0;
 					cb = sca ? 0u : 5u; ab = sca ? 6u : 0u;
 					ib = (isel != 0u) == sca ? 2u : 3u;   // isel 0: 2-bit colour / 3-bit alpha indices
-					active = quality >= 2u;
+					active = quality >= 2u;     // (64-lane layout: blocks with alpha, or High)
 				}
 			} else if (plane) {
 				uint32_t mode;
@@ -861,17 +917,17 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 				fit_lane<UNITW>(make_tex(tp, pl, rot, chm), mask, m6, lane & 1u, cb, ab, pbk, ib, iters,
 					wv, sca, lf);
 			// ---- assemble candidates in their leader lanes ----
-			//   mode 6: lane 0;  mode 4/5: vector lane (scalar plane 12 lanes up);
+			//   mode 6: its first lane;  mode 4/5: vector lane (scalar plane s2off lanes up);
 			//   partitions: subset-0 lane (the other subsets in the next lanes)
 			const int s1 = (int)((lane + 1u) & 63u);
-			const int s2 = (int)((lane + (st == 0u ? 12u : 2u)) & 63u);
+			const int s2 = (int)((lane + s2off) & 63u);
 			// error and id first: only a leader whose candidate beats its best so far stores
 			// the payload fields, straight from the shuffles into its LDS column
 			const uint32_t e1 = (uint32_t)__shfl((int)lf.err, s1, 64), e2 = (uint32_t)__shfl((int)lf.err, s2, 64);
 			const bool use1 = plane, use2 = vecp || (plane && st == 1u);
 			const uint32_t cerr = lf.err + (use1 ? e1 : 0u) + (use2 ? e2 : 0u);
 			const uint32_t cidv = m6 ? 0u : (vecp ? cid : idbase + mypart);
-			const bool leader = active && (m6 ? lane == 0u : (vecp || (plane && sub == 0u)));
+			const bool leader = active && (m6 ? hl == 0u : (vecp || (plane && sub == 0u)));
 			const bool take = leader && (cerr < best_err || (cerr == best_err && cidv < best_id));
 			if (take) {
 				best_err = cerr;
@@ -968,12 +1024,14 @@ __device__ __forceinline__ uint4 encode_block(const uint32_t* tp, const uint32_t
 		}
 	}
 
-	// ---- wave argmin on (error, id); the whole wave packs the winner's candidate ----
+	// ---- group argmin on (error, id); the group packs its winner's candidate ----
 	const unsigned long long key = ((unsigned long long)best_err << 32) | best_id;
-	const unsigned long long kmin = cf_wave_min_u64(key);
-	const uint32_t wl = (uint32_t)__ffsll((long long)__ballot(key == kmin)) - 1u;   // winner lane (unique key)
-	is_winner = lane0 == 0u;   // the result is uniform; lane 0 stores it
-	return pack_block_wave(cslot - lane0 + wl, (uint32_t)kmin, lane0);
+	const unsigned long long kmin = cf_group_min_u64(key, pair, h);
+	const unsigned long long bal = __ballot(key == kmin);
+	const uint32_t gmask = pair ? (h ? (uint32_t)(bal >> 32) : (uint32_t)bal) : 0u;
+	const uint32_t wl = pair ? hbase + (uint32_t)__ffs((int)gmask) - 1u
+		: (uint32_t)__ffsll((long long)bal) - 1u;   // winner lane (unique key in its group)
+	return pack_block_group(cslot - lane0 + wl, (uint32_t)kmin, lane0, pair);
 }
 
 } // namespace
@@ -1010,19 +1068,27 @@ cfhip_bc7_encode_kernel(cf_kparams kp)
 	__syncthreads();
 
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	for (uint32_t j = 0; j < 4u; ++j) {
+	// the wave's 4 blocks; two neighbouring opaque blocks at Low / Normal share one pass
+	for (uint32_t j = 0; j < 4u;) {
 		const uint32_t b = wave*4u + j;
 		if (bx0 + b >= kp.bx)
 			break;
-		bool win;
-		// opaque copy: keeps the (many) lane-role values of encode_block from being hoisted
+		// alpha test, lanes 0..15: block b, 16..31: block b + 1
+		const uint32_t bn = b + (lane >> 4) < CF_BLOCKS_PER_WG ? b + (lane >> 4) : b;
+		const uint32_t amask = (uint32_t)__ballot(lane < 32u && (tile[bn*16u + (lane & 15u)] >> 24) != 255u);
+		const bool pair = !EXH && (kp.quality == 1u || kp.quality == 2u) && j < 3u && bx0 + b + 1u < kp.bx &&
+			amask == 0u && !(CF_BC7_ABLATE & 4);
+		// opaque copy: keeps the (many) lane-role values of encode_blocks from being hoisted
 		// out of this loop and held in registers across all phases
 		uint32_t ln = lane;
 		asm volatile("" : "+v"(ln));
-		const uint4 blk = encode_block<UNITW, EXH>(tile + b*16u, plan + b*16u, cands + threadIdx.x,
-			kp, ln, win);
-		if (win)
+		const uint4 blk = encode_blocks<UNITW, EXH>(tile, plan, b, pair, cands + threadIdx.x, kp, ln);
+		if (pair) {
+			if ((lane & 31u) == 0u)
+				outb[b + (lane >> 5)] = blk;
+		} else if (lane == 0u)
 			outb[b] = blk;
+		j += pair ? 2u : 1u;
 	}
 	__syncthreads();
 	// coalesced payload store: 16 blocks x 16 B = 256 B contiguous

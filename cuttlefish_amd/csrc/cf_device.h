@@ -146,6 +146,57 @@ __device__ __forceinline__ uint32_t cf_wave_or_u32(uint32_t v)
 		(uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 
+// Group forms: the wavefront is one group of 64 lanes (pair = false) or two groups of 32
+// (pair = true; h = lane >> 5 picks the group): after the DPP reduction inside each row of
+// 16 lanes the four row results are combined per group.  All 64 lanes must be active.
+__device__ __forceinline__ uint32_t cf_group_min_u32(uint32_t k, bool pair, uint32_t h)
+{
+	uint32_t o;
+	o = cf_dpp<0xB1>(k); k = o < k ? o : k;
+	o = cf_dpp<0x4E>(k); k = o < k ? o : k;
+	o = cf_dpp<0x141>(k); k = o < k ? o : k;
+	o = cf_dpp<0x140>(k); k = o < k ? o : k;
+	const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)k, 0);
+	const uint32_t r1 = (uint32_t)__builtin_amdgcn_readlane((int)k, 16);
+	const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)k, 32);
+	const uint32_t r3 = (uint32_t)__builtin_amdgcn_readlane((int)k, 48);
+	const uint32_t a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+	return pair ? (h ? b : a) : (a < b ? a : b);
+}
+
+__device__ __forceinline__ uint32_t cf_group_or_u32(uint32_t v, bool pair, uint32_t h)
+{
+	v |= cf_dpp<0xB1>(v);
+	v |= cf_dpp<0x4E>(v);
+	v |= cf_dpp<0x141>(v);
+	v |= cf_dpp<0x140>(v);
+	const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+	const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+	return pair ? (h ? b : a) : (a | b);
+}
+
+__device__ __forceinline__ unsigned long long cf_group_min_u64(unsigned long long k, bool pair, uint32_t h)
+{
+#define CF_MIN64_STEP(CTRL) { \
+		const uint32_t lo = cf_dpp<CTRL>((uint32_t)k), hi = cf_dpp<CTRL>((uint32_t)(k >> 32)); \
+		const unsigned long long o = ((unsigned long long)hi << 32) | lo; \
+		k = o < k ? o : k; }
+	CF_MIN64_STEP(0xB1)
+	CF_MIN64_STEP(0x4E)
+	CF_MIN64_STEP(0x141)
+	CF_MIN64_STEP(0x140)
+#undef CF_MIN64_STEP
+	unsigned long long r[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, 16*i);
+		const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k >> 32), 16*i);
+		r[i] = ((unsigned long long)hi << 32) | lo;
+	}
+	const unsigned long long a = r[0] < r[1] ? r[0] : r[1], b = r[2] < r[3] ? r[2] : r[3];
+	return pair ? (h ? b : a) : (a < b ? a : b);
+}
+
 // wave64 argmin of a 64-bit key; every lane gets the minimum (all lanes active).
 __device__ __forceinline__ unsigned long long cf_wave_min_u64(unsigned long long k)
 {

@@ -659,7 +659,10 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 		int nrot = b.rot ? 4 : 1;
 		for (int r = 0; r < nrot; ++r)
 			TRY(1 + r);
-		if (b.rot)
+		/* mode 4 (rotation x index selector): blocks with alpha, and opaque blocks from High up
+		 * (worth 0.012 dB on opaque photographic content; leaving it out lets the kernel fit an
+		 * opaque block's whole candidate set into half a wavefront) */
+		if (b.rot && (has_alpha || p->quality >= 3))
 			for (int k = 0; k < 8; ++k)
 				TRY(5 + k);
 		/* Partitioned modes.  Highest refits every partition of every mode.  Below that
@@ -668,9 +671,10 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 		 * mode), phase 2 runs the full fit with all refit rounds on the best partitions
 		 * of each mode of the group, ranked by (score bits with the low 6 bits cleared,
 		 * partition index):
-		 *   two-subset group:   modes 1 + 3 with 8 partitions each, or a single mode
-		 *                       (1 below Normal, 7 for blocks with alpha) with 16
-		 *   three-subset group: modes 0 (its 16 partitions) + 2 with 5 partitions each
+		 *   two-subset group:   blocks with alpha: mode 7 with 16 partitions;
+		 *                       opaque: Low mode 1 with 14, Normal modes 1 / 3 with 6 / 5 (an opaque
+		 *                       block then needs 32 lanes: 2 + 8 + 22), High modes 1 + 3 with 8 each
+		 *   three-subset group: modes 0 (its 16 partitions) + 2 with 5 partitions each (High)
 		 * The HIP kernel runs phase 1 with lane = partition and phase 2 of a whole group
 		 * in one pass with lane = (mode, rank, subset, row pair). */
 		if (p->quality >= 4) {
@@ -694,23 +698,22 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 					memcpy(&u, &sc, 4);
 					key0[k] = (u & ~63u) | (uint32_t)k;
 				}
-				int bases[2], counts[2], nm = 0, per;
+				int bases[2], counts[2], pers[2] = {0, 0}, nm = 0;
 				if (g == 1) {
-					bases[nm] = 192; counts[nm++] = 16;
-					bases[nm] = 256; counts[nm++] = 64;
-					per = 5;
+					bases[nm] = 192; counts[nm] = 16; pers[nm++] = 5;
+					bases[nm] = 256; counts[nm] = 64; pers[nm++] = 5;
 				} else if (has_alpha) {
-					bases[nm] = 320; counts[nm++] = 64;
-					per = 16;
+					bases[nm] = 320; counts[nm] = 64; pers[nm++] = 16;
+				} else if (!b.mode3) {
+					bases[nm] = 64; counts[nm] = 64; pers[nm++] = 14;
 				} else {
-					bases[nm] = 64; counts[nm++] = 64;
-					if (b.mode3) { bases[nm] = 128; counts[nm++] = 64; }
-					per = nm == 2 ? 8 : 16;
+					bases[nm] = 64; counts[nm] = 64; pers[nm++] = b.three ? 8 : 6;
+					bases[nm] = 128; counts[nm] = 64; pers[nm++] = b.three ? 8 : 5;
 				}
 				for (int mi = 0; mi < nm; ++mi) {
 					uint32_t key[64];
 					memcpy(key, key0, sizeof(key));
-					for (int r = 0; r < per; ++r) {
+					for (int r = 0; r < pers[mi]; ++r) {
 						int bk = -1;
 						for (int k = 0; k < counts[mi]; ++k)
 							if (key[k] != 0xFFFFFFFFu && (bk < 0 || key[k] < key[bk]))
