@@ -119,3 +119,25 @@ def test_perceptual_weights_kernel_matches_oracle_on_a_larger_tile(gpu_ctx, qual
     img = synth.photo(256, 256, seed=31)
     ref = O.encode(img, BC7, quality=quality, threads=16, color_space=1)
     assert np.array_equal(ref, _gpu(gpu_ctx, img, quality, color_space=ColorSpace.sRGB))
+
+
+@pytest.mark.parametrize("quality", [1, 2])
+def test_pairing_is_invisible_in_the_payload(gpu_ctx, quality):
+    """Neighbouring opaque blocks share a wavefront at Low / Normal; blocks with alpha and opaque
+    blocks without an opaque neighbour run alone.  9 blocks per row with alpha in blocks 2 and 5:
+    pairs (0,1) (3,4) (6,7), alpha singles 2 and 5, an unpaired opaque single 8 -- every layout
+    must give the oracle's bytes."""
+    img = synth.photo(36, 16, seed=41).copy()
+    img[..., 3] = 255
+    img[:, 8:12, 3] = np.arange(4*16, dtype=np.uint8).reshape(16, 4)*3       # block column 2
+    img[4:8, 20:24, 3] = 17                                                   # one block of column 5
+    ref = O.encode(img, BC7, quality=quality, threads=4)
+    assert np.array_equal(ref, _gpu(gpu_ctx, img, quality))
+    # the same blocks, shifted by one block so that every pairing changes
+    img2 = np.ascontiguousarray(img[:, 4:])
+    ref2 = O.encode(img2, BC7, quality=quality, threads=4)
+    got2 = _gpu(gpu_ctx, img2, quality)
+    assert np.array_equal(ref2, got2)
+    a = ref.reshape(4, 9, 16)[:, 1:]
+    b = ref2.reshape(4, 8, 16)
+    assert np.array_equal(a, b)               # a block's payload does not depend on its neighbours
