@@ -746,11 +746,15 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	bool pair, uint32_t* cslot, const cf_kparams& kp, uint32_t lane0)
 {
 	uint32_t lane = lane0;
-	// pair: blocks b and b + 1, both opaque, Low or Normal: one per half wavefront
+	// pair: blocks b and b + 1 at Low or Normal, one per half wavefront
 	const uint32_t h = lane >> 5, hbase = pair ? (lane & 32u) : 0u;
 	const uint32_t* tp = tile + (pair ? b + h : b)*16u;
 	const uint32_t* pl = plan + (pair ? b + h : b)*16u;
-	const bool has_alpha = !pair && __ballot(lane < 16u && (tp[lane & 15u] >> 24) != 255u) != 0ull;
+	// lanes 0..15 of each group test their block's alpha
+	const unsigned long long abal = __ballot((lane & 31u) < 16u && (tp[lane & 15u] >> 24) != 255u);
+	const bool has_alpha = pair ? ((uint32_t)(h ? abal >> 32 : abal) & 0xFFFFu) != 0u
+		: ((uint32_t)abal & 0xFFFFu) != 0u;
+	const bool any_alpha = pair ? abal != 0ull : has_alpha;
 	const uint32_t quality = kp.quality;
 	const uint32_t iters = (0x32110u >> (4u*(quality < 4u ? quality : 4u))) & 15u;   // refit rounds 0,1,1,2,3
 	const uint32_t wt[4] = {kp.wt[0], kp.wt[1], kp.wt[2], kp.wt[3]};
@@ -758,12 +762,14 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	uint32_t best_err = 0xFFFFFFFFu, best_id = 0x7FFFFFFFu;   // payload fields: cslot (LDS)
 
 	// ---- fit streams: one fit per lane (fit_lane) ----
-	// Opaque blocks at Low / Normal use the 32-lane layout (two such blocks share a wave):
+	// Lowest / Low / Normal use the 32-lane layout (two blocks share a wave):
 	//    hl  0..1  : mode 6, palette half = hl
 	//    Normal: hl 2..5 / 6..9 : vector / scalar plane of mode 5, rotation hl-2 / hl-6
 	//            hl 10..21 : mode 1, its 6 best partitions x 2 subsets; hl 22..31 : mode 3, 5 best
-	//    Low:    hl 2 / 3 : mode 5 rotation 0;  hl 4..31 : mode 1, its 14 best partitions
-	// Everything else uses the 64-lane layout:
+	//            (block with alpha: hl 10..31 : mode 7, its 11 best)
+	//    Low:    hl 2 / 3 : mode 5 rotation 0;  hl 4..31 : mode 1 (alpha: 7), its 14 best partitions
+	//    Lowest: hl 2 / 3 : mode 5 rotation 0 for blocks with alpha; no partitions
+	// High and Highest use the 64-lane layout:
 	// stream 0:  lanes  0..1  : mode 6
 	//            lanes  2..13 : vector plane of candidate 1 + (lane-2) (mode 5 x rot, mode 4 x rot x isel)
 	//            lanes 14..25 : scalar plane (rotated alpha) of candidate 1 + (lane-14)
@@ -774,7 +780,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	// The partitions come from phase 1: every partition is scored once per subset count with
 	// the residual estimator and the best are taken in (score, index) order.
 	// Highest instead refits every partition (below), after a stream 0 without partitions.
-	const bool lay32 = !EXH && !has_alpha && (quality == 1u || quality == 2u);
+	const bool lay32 = !EXH && quality <= 2u;
 	const uint32_t hl = lay32 ? (lane & 31u) : lane;
 	const bool slot_ok = !lay32 || pair || lane < 32u;
 	bool solved = false;
@@ -789,7 +795,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			// partition lanes: first lane, slots of the first mode, slots in all
 			uint32_t pfirst, nper0, nslots;
 			if (lay32) {
-				if (quality == 2u) { pfirst = 10u; nper0 = 6u; nslots = 11u; }
+				if (quality == 2u) { pfirst = 10u; nper0 = has_alpha ? 11u : 6u; nslots = 11u; }
 				else { pfirst = 4u; nper0 = 14u; nslots = 14u; }
 			} else if (st == 1u) { pfirst = 0u; nper0 = 5u; nslots = 10u; }
 			else if (has_alpha) { pfirst = 26u; nper0 = 16u; nslots = 16u; }
@@ -829,7 +835,9 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 				for (uint32_t run = 0; run < nruns; ++run) {
 					const uint32_t npart = (st == 1u && run == 0u) ? 16u : 64u;
 					uint32_t ka = (key0[0] & 63u) < npart ? key0[0] : 0xFFFFFFFFu, kb = key0[1];
-					for (uint32_t t = 0; t < nper0; ++t) {
+					// uniform trip count: the larger of the groups' needs
+					const uint32_t nsel = lay32 ? (quality == 2u ? (any_alpha ? 11u : 6u) : 14u) : nper0;
+					for (uint32_t t = 0; t < nsel; ++t) {
 						const uint32_t kmin = cf_group_min_u32(ka < kb ? ka : kb, pair, h);
 						const bool mine = rank == t && (st == 0u || mi == run);
 						mypart = mine ? (kmin & 63u) : mypart;
@@ -872,7 +880,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 					rot = (cid - 5u) & 3u; pbk = 0;
 					cb = sca ? 0u : 5u; ab = sca ? 6u : 0u;
 					ib = (isel != 0u) == sca ? 2u : 3u;   // isel 0: 2-bit colour / 3-bit alpha indices
-					active = quality >= 2u;     // (64-lane layout: blocks with alpha, or High)
+					active = quality >= 2u;     // (mode 4 exists only in the 64-lane layout: High)
 				}
 			} else if (plane) {
 				uint32_t mode;
@@ -1068,16 +1076,13 @@ cfhip_bc7_encode_kernel(cf_kparams kp)
 	__syncthreads();
 
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	// the wave's 4 blocks; two neighbouring opaque blocks at Low / Normal share one pass
+	// the wave's 4 blocks; up to Normal two neighbouring blocks share one pass
 	for (uint32_t j = 0; j < 4u;) {
 		const uint32_t b = wave*4u + j;
 		if (bx0 + b >= kp.bx)
 			break;
-		// alpha test, lanes 0..15: block b, 16..31: block b + 1
-		const uint32_t bn = b + (lane >> 4) < CF_BLOCKS_PER_WG ? b + (lane >> 4) : b;
-		const uint32_t amask = (uint32_t)__ballot(lane < 32u && (tile[bn*16u + (lane & 15u)] >> 24) != 255u);
-		const bool pair = !EXH && (kp.quality == 1u || kp.quality == 2u) && j < 3u && bx0 + b + 1u < kp.bx &&
-			amask == 0u && !(CF_BC7_ABLATE & 4);
+		const bool pair = !EXH && kp.quality <= 2u && j < 3u && bx0 + b + 1u < kp.bx &&
+			!(CF_BC7_ABLATE & 4);
 		// opaque copy: keeps the (many) lane-role values of encode_blocks from being hoisted
 		// out of this loop and held in registers across all phases
 		uint32_t ln = lane;

@@ -659,10 +659,10 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 		int nrot = b.rot ? 4 : 1;
 		for (int r = 0; r < nrot; ++r)
 			TRY(1 + r);
-		/* mode 4 (rotation x index selector): blocks with alpha, and opaque blocks from High up
-		 * (worth 0.012 dB on opaque photographic content; leaving it out lets the kernel fit an
-		 * opaque block's whole candidate set into half a wavefront) */
-		if (b.rot && (has_alpha || p->quality >= 3))
+		/* mode 4 (rotation x index selector): from High up (worth 0.012 dB on opaque and
+		 * 0.006 dB on alpha-carrying content; leaving it out lets the kernel fit a block's
+		 * whole candidate set into half a wavefront) */
+		if (b.rot && p->quality >= 3)
 			for (int k = 0; k < 8; ++k)
 				TRY(5 + k);
 		/* Partitioned modes.  Highest refits every partition of every mode.  Below that
@@ -671,9 +671,10 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 		 * mode), phase 2 runs the full fit with all refit rounds on the best partitions
 		 * of each mode of the group, ranked by (score bits with the low 6 bits cleared,
 		 * partition index):
-		 *   two-subset group:   blocks with alpha: mode 7 with 16 partitions;
-		 *                       opaque: Low mode 1 with 14, Normal modes 1 / 3 with 6 / 5 (an opaque
-		 *                       block then needs 32 lanes: 2 + 8 + 22), High modes 1 + 3 with 8 each
+		 *   two-subset group:   Low: mode 1 (blocks with alpha: mode 7) with 14 partitions;
+		 *                       Normal: modes 1 / 3 with 6 / 5 (alpha: mode 7 with 11) -- a block
+		 *                       then needs 32 lanes: 2 + 8 + 22; High: modes 1 + 3 with 8 each
+		 *                       (alpha: mode 7 with 16)
 		 *   three-subset group: modes 0 (its 16 partitions) + 2 with 5 partitions each (High)
 		 * The HIP kernel runs phase 1 with lane = partition and phase 2 of a whole group
 		 * in one pass with lane = (mode, rank, subset, row pair). */
@@ -703,7 +704,7 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 					bases[nm] = 192; counts[nm] = 16; pers[nm++] = 5;
 					bases[nm] = 256; counts[nm] = 64; pers[nm++] = 5;
 				} else if (has_alpha) {
-					bases[nm] = 320; counts[nm] = 64; pers[nm++] = 16;
+					bases[nm] = 320; counts[nm] = 64; pers[nm++] = b.three ? 16 : (b.mode3 ? 11 : 14);
 				} else if (!b.mode3) {
 					bases[nm] = 64; counts[nm] = 64; pers[nm++] = 14;
 				} else {

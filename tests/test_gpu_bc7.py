@@ -121,12 +121,12 @@ def test_perceptual_weights_kernel_matches_oracle_on_a_larger_tile(gpu_ctx, qual
     assert np.array_equal(ref, _gpu(gpu_ctx, img, quality, color_space=ColorSpace.sRGB))
 
 
-@pytest.mark.parametrize("quality", [1, 2])
+@pytest.mark.parametrize("quality", [0, 1, 2])
 def test_pairing_is_invisible_in_the_payload(gpu_ctx, quality):
-    """Neighbouring opaque blocks share a wavefront at Low / Normal; blocks with alpha and opaque
-    blocks without an opaque neighbour run alone.  9 blocks per row with alpha in blocks 2 and 5:
-    pairs (0,1) (3,4) (6,7), alpha singles 2 and 5, an unpaired opaque single 8 -- every layout
-    must give the oracle's bytes."""
+    """Neighbouring blocks share a wavefront up to Normal (32 lanes each); a block without a
+    neighbour in its strip runs alone in lanes 0..31.  9 blocks per row, alpha in blocks 2 and 5,
+    then the same blocks shifted by one so that every pairing changes: a block's payload must be
+    the oracle's whatever it was paired with."""
     img = synth.photo(36, 16, seed=41).copy()
     img[..., 3] = 255
     img[:, 8:12, 3] = np.arange(4*16, dtype=np.uint8).reshape(16, 4)*3       # block column 2
