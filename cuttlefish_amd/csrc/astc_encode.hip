@@ -159,30 +159,40 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	uint16_t* ncol = lane_num[wave] + lane;
 	uint8_t* qcol = lane_q[wave] + lane;
 
-	for (uint32_t j = 0; j < 4u; ++j) {
-		const uint32_t b = wave*4u + j;
-		if (bx0 + b >= kp.bx)
+	// Up to Normal a block's candidates (<= 4 configs x 8 variants) fill half a wavefront: two
+	// neighbouring blocks then share one pass (lane group h = lane >> 5), which is worth nearly
+	// 2x here because the kernel waits on LDS latency, not on issue slots.
+	const bool can_pair = q <= 2u;
+	for (uint32_t j = 0; j < 4u;) {
+		const uint32_t b0 = wave*4u + j;
+		if (bx0 + b0 >= kp.bx)
 			break;
+		const bool pair = can_pair && j < 3u && bx0 + b0 + 1u < kp.bx;
+		j += pair ? 2u : 1u;
+		const uint32_t h = lane >> 5, hl = pair ? (lane & 31u) : lane, gsz = pair ? 32u : 64u;
+		const uint32_t b = pair ? b0 + h : b0;
 		const uint32_t* tp = tile + b*ASTC_MAX_TEXELS;
-		// solid / alpha tests over the texels (lanes stride)
+		// solid / alpha tests over the texels (the group's lanes stride)
 		const uint32_t p0 = tp[0];
 		bool diff = false, alpha = false;
-		for (uint32_t i = lane; i < n; i += 64u) {
+		for (uint32_t i = hl; i < n; i += gsz) {
 			const uint32_t p = tp[i];
 			diff = diff || p != p0;
 			alpha = alpha || (p >> 24) != 255u;
 		}
-		const bool solid = __ballot(diff) == 0ull;
-		const bool has_alpha = __ballot(alpha) != 0ull;
-		if (solid) {
-			if (lane == 0u) {
-				// void-extent block: 0xFFFFFFFFFFFFFDFC + RGBA as UNORM16 (c * 257)
-				const uint32_t r = p0 & 255u, g = (p0 >> 8) & 255u, bl = (p0 >> 16) & 255u, a = p0 >> 24;
-				outb[b] = make_uint4(0xFFFFFDFCu, 0xFFFFFFFFu, (r*257u) | ((g*257u) << 16),
-					(bl*257u) | ((a*257u) << 16));
-			}
-			continue;
+		const unsigned long long dbal = __ballot(diff), abal = __ballot(alpha);
+		const uint32_t dgrp = pair ? (uint32_t)(h ? dbal >> 32 : dbal) : (uint32_t)(dbal | (dbal >> 32));
+		const uint32_t agrp = pair ? (uint32_t)(h ? abal >> 32 : abal) : (uint32_t)(abal | (abal >> 32));
+		const bool solid = dgrp == 0u;
+		const bool has_alpha = agrp != 0u;
+		if (solid && hl == 0u) {
+			// void-extent block: 0xFFFFFFFFFFFFFDFC + RGBA as UNORM16 (c * 257)
+			const uint32_t r = p0 & 255u, g = (p0 >> 8) & 255u, bl = (p0 >> 16) & 255u, a = p0 >> 24;
+			outb[b] = make_uint4(0xFFFFFDFCu, 0xFFFFFFFFu, (r*257u) | ((g*257u) << 16),
+				(bl*257u) | ((a*257u) << 16));
 		}
+		if (__ballot(!solid) == 0ull)
+			continue;   // nothing but constant blocks in this pass
 		const uint32_t nc = has_alpha ? 4u : 3u;
 		const uint8_t* set = tables + (has_alpha ? 8u + 8u*ASTC_CFG_STRIDE : 8u);
 		const uint32_t ncfg_all = tables[has_alpha ? 1 : 0];
@@ -262,8 +272,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		}
 
 		// ---- lane = (config, inset variant) ----
-		const uint32_t k = lane >> 3, var = lane & 7u;
-		const bool active = k < use_cfg && var < qvar;
+		const uint32_t k = hl >> 3, var = hl & 7u;
+		const bool active = !solid && k < use_cfg && var < qvar;
 		uint32_t err = 0xFFFFFFFFu;
 		int e0[4] = {0, 0, 0, 255}, e1[4] = {0, 0, 0, 255};
 		CfgView cfg = {set + (active ? k : 0u)*ASTC_CFG_STRIDE};
@@ -371,9 +381,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				}
 			}
 		}
-		const unsigned long long key = ((unsigned long long)err << 32) | lane;   // id = cfg*8 + variant
-		const unsigned long long kmin = cf_wave_min_u64(key);
-		if (key == kmin) {
+		const unsigned long long key = ((unsigned long long)err << 32) | hl;   // id = cfg*8 + variant
+		const unsigned long long kmin = cf_group_min_u64(key, pair, h);
+		if (!solid && key == kmin && (pair || lane < 64u)) {
 			// pack: mode (11) | partitions-1 (2) | CEM (4) | 8-bit endpoint values | ... | weights
 			unsigned long long lo64 = (unsigned long long)cfg.mode() | ((unsigned long long)(has_alpha ? 12u : 8u) << 13);
 			unsigned long long hi64 = 0ull;
