@@ -5,19 +5,23 @@
 // bc7enc_compress_block / ispc::bc7e_compress_blocks(1, ...), with the per-quality
 // budgets of createBc7BlockParams (S3tcConverter.cpp:170-227).
 //
-// Mapping (DESIGN.md "BC7 kernel"):
-//   * workgroup = 4 wave64 = 16 adjacent blocks, tile staged in LDS by coalesced
-//     row loads (cf_device.h); the 16 texels of a block are then wave-uniform
-//     (SGPR operands), so per-lane work carries no texel registers.
-//   * lane = search candidate.  Pass 0: lane 0 = mode 6, lanes 1..4 = mode 5 x
-//     rotation, lanes 5..12 = mode 4 x rotation x index-selector.  Partitioned
-//     passes (modes 1,3,0,2 opaque / 7 alpha): lane = partition id, every lane
-//     runs the full fit (PCA axis -> extremes -> p-bit quantise -> exhaustive
+// Mapping:
+//   * workgroup = 4 wave64 = a strip of 16 adjacent blocks; the tile and a channel-planar
+//     copy of it are staged in LDS by coalesced row loads (cf_device.h).
+//   * the kernel is VALU-issue-bound and an instruction costs the same whatever the number
+//     of active lanes, so ONE fit per lane and ONE instruction stream: mode, rotation, channel
+//     set, precision, p-bit kind, index width and subset mask are per-lane values (fit_lane:
+//     integer statistics -> covariance -> principal axis -> extremes -> quantise -> exhaustive
 //     selectors via v_dot4_u32_u8 -> closed-form least-squares refit rounds).
-//   * all error arithmetic is integer; each lane keeps its best (error, id,
-//     endpoints, selectors); a 6-step wave argmin on (error,id) picks the block
-//     and only the winning lane bit-packs 16 B, written out coalesced via LDS.
-//   * no MFMA: branchy integer/float search, VALU-bound (roofline in DESIGN.md).
+//   * up to Normal a block's candidates fill 32 lanes (mode 6, mode 5 x rotations, modes 1/3
+//     or 7 on their best partitions) and two neighbouring blocks share a wavefront; High uses
+//     64 lanes and a second stream for the three-subset modes; Highest refits every partition.
+//   * partitions are ranked once per subset count by a residual estimator (subset_residual)
+//     and the best are taken by an iterated group minimum (DPP rows + v_readlane).
+//   * all error arithmetic is integer; a lane keeps (error, id) in registers and its best
+//     candidate's fields in its LDS column; group argmin on (error, id); the whole group then
+//     bit-packs the winner (one bit field per lane, OR-reduced), written out coalesced via LDS.
+//   * no MFMA: integer/float search (roofline in DESIGN.md section 4).
 //
 // Candidate ids and every float operation order are identical to the CPU oracle
 // (oracle/bc7_encode.c), so the payload is byte-identical to it.
