@@ -68,28 +68,29 @@ __device__ const uint8_t k_inset[8][2] = {{0, 0}, {1, 1}, {2, 2}, {3, 3}, {1, 0}
 
 // reconstructed weight of texel i from this lane's quantised grid (private LDS column)
 __device__ __forceinline__ int texel_weight(const CfgView& cfg, uint32_t i, const uint8_t* qcol,
-	uint32_t N, int bits)
+	uint32_t N, int bits, uint32_t rows)
 {
 	const uint2 f = cfg.infill(i);
 	const uint32_t v0 = f.x & 255u, w00 = (f.x >> 8) & 255u, w01 = (f.x >> 16) & 255u,
 		w10 = f.x >> 24, w11 = f.y & 255u;
 	// straight-line: a zero factor reads a neighbour inside the lane's 64-entry column (grid
 	// index clamped) and multiplies it away -- no per-lane branches on the load chain
-	const uint32_t g1 = v0 + 1u < 64u ? v0 + 1u : v0, g2 = v0 + N < 64u ? v0 + N : v0,
-		g3 = v0 + N + 1u < 64u ? v0 + N + 1u : v0;
-	const int q0 = qcol[v0*64u], q1 = qcol[g1*64u], q2 = qcol[g2*64u], q3 = qcol[g3*64u];
+	const uint32_t g1 = v0 + 1u < rows ? v0 + 1u : v0, g2 = v0 + N < rows ? v0 + N : v0,
+		g3 = v0 + N + 1u < rows ? v0 + N + 1u : v0;
+	const int q0 = qcol[v0*128u], q1 = qcol[g1*128u], q2 = qcol[g2*128u], q3 = qcol[g3*128u];
 	const int v = (int)w00*unq_weight(q0, bits) + (int)w01*unq_weight(q1, bits) +
 		(int)w10*unq_weight(q2, bits) + (int)w11*unq_weight(q3, bits) + 8;
 	return v >> 4;
 }
 
 __device__ __forceinline__ uint32_t astc_error(const uint32_t* tp, uint32_t n, uint32_t nc,
-	const int (&e0)[4], const int (&e1)[4], const CfgView& cfg, const uint8_t* qcol, uint32_t N, int bits)
+	const int (&e0)[4], const int (&e1)[4], const CfgView& cfg, const uint8_t* qcol, uint32_t N, int bits,
+	uint32_t rows)
 {
 	uint32_t err = 0;
-#pragma unroll 4
+#pragma unroll 1
 	for (uint32_t i = 0; i < n; ++i) {
-		const int w = texel_weight(cfg, i, qcol, N, bits);
+		const int w = texel_weight(cfg, i, qcol, N, bits, rows);
 		const uint32_t p = tp[i];
 #pragma unroll
 		for (uint32_t c = 0; c < 4u; ++c) {
@@ -105,24 +106,44 @@ __device__ __forceinline__ uint32_t astc_error(const uint32_t* tp, uint32_t n, u
 
 } // namespace
 
+#ifndef CF_ASTC_WAVES
+#define CF_ASTC_WAVES 3
+#endif
 template <int PIX>
 __global__ void __launch_bounds__(CF_WG_THREADS)
+__attribute__((amdgpu_waves_per_eu(CF_ASTC_WAVES, 8)))
 cfhip_astc_encode_kernel(cf_kparams kp)
 {
-	__shared__ uint32_t tile[CF_BLOCKS_PER_WG*ASTC_MAX_TEXELS];
-	__shared__ uint16_t lane_num[4][65*64];     // [wave][grid point * 64 + lane]; row 64 = dummy
-	__shared__ uint8_t lane_q[4][64*64];
+	// All of the workgroup's LDS is sized at launch for the footprint (fewer bytes = more waves
+	// per SIMD to hide the LDS latency this kernel lives on):
+	//   tile  : 16 blocks x bw*bh texels
+	//   tabs  : both config sets (RGB, RGBA), records compacted to 136 + 8*bw*bh bytes -- the
+	//           infill records are read 3-4 times per texel and lane; from L1/L2 each read
+	//           costs several hundred cycles, from LDS ~64
+	//   cols  : per-lane grid columns [wave][grid point * 64 + lane] u16, one row per grid
+	//           point of the footprint's largest weight grid + 1 dummy row: accumulators first,
+	//           then (low byte of the same slots) the quantised weights
+	extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
 	__shared__ uint4 outb[CF_BLOCKS_PER_WG];
-	// both config sets (RGB, RGBA) of this footprint: the infill records are read 3-4 times
-	// per texel and lane, and a global (L1/L2) load on that chain costs several hundred
-	// cycles at 2 waves/SIMD -- an LDS read costs ~64
-	__shared__ __attribute__((aligned(16))) uint32_t tabs[(8 + 16*ASTC_CFG_STRIDE)/4];
+	const uint32_t bw = kp.flags & 255u, bh = (kp.flags >> 8) & 255u, n = bw*bh;
+	const uint32_t rows = (kp.flags >> 16) & 255u;   // largest ng of any config + 1
+	const uint32_t cstride = 136u + 8u*n;            // compact record stride (bytes)
+	const uint32_t tab_words = (8u + 16u*cstride)/4u;
+	uint32_t* tile = dyn_lds;
+	uint32_t* tabs = dyn_lds + CF_BLOCKS_PER_WG*n;
+	uint16_t* lane_cols = reinterpret_cast<uint16_t*>(tabs + tab_words);
 	{
 		const uint32_t* g = reinterpret_cast<const uint32_t*>(kp.aux);
-		for (uint32_t i = threadIdx.x; i < (8u + 16u*ASTC_CFG_STRIDE)/4u; i += CF_WG_THREADS)
-			tabs[i] = g[i];
+		for (uint32_t i = threadIdx.x; i < tab_words; i += CF_WG_THREADS) {
+			// word i of the compact table <- word of the ASTC_CFG_STRIDE-strided table
+			uint32_t src = i;
+			if (i >= 2u) {
+				const uint32_t rec = (i - 2u)/(cstride/4u), off = (i - 2u) - rec*(cstride/4u);
+				src = 2u + rec*(ASTC_CFG_STRIDE/4u) + off;
+			}
+			tabs[i] = g[src];
+		}
 	}
-	const uint32_t bw = kp.flags & 255u, bh = (kp.flags >> 8) & 255u, n = bw*bh;
 	uint32_t gx_, gy_;
 	cf_resolve(kp, gx_, gy_);
 	const uint32_t bx0 = gx_*CF_BLOCKS_PER_WG, byy = gy_;
@@ -145,7 +166,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					(cf_unorm8(f.w) << 24);
 			}
 			// swizzle from colour mask / alpha type (AstcConverter.cpp:140-149)
-			tile[blk*ASTC_MAX_TEXELS + row*bw + cx] = (px & kp.keep_mask) | kp.set_mask;
+			tile[blk*n + row*bw + cx] = (px & kp.keep_mask) | kp.set_mask;
 		}
 	}
 	__syncthreads();
@@ -156,8 +177,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	const uint32_t qcfg = q == 0u ? 1u : (q == 1u ? 2u : (q == 2u ? 4u : 8u));
 	const uint32_t qvar = q == 0u ? 1u : (q == 1u ? 2u : 8u);
 	const bool refit = q >= 2u;
-	uint16_t* ncol = lane_num[wave] + lane;
-	uint8_t* qcol = lane_q[wave] + lane;
+	uint16_t* ncol = lane_cols + wave*rows*64u + lane;
+	const uint8_t* qcol = reinterpret_cast<const uint8_t*>(ncol);   // entry g: byte offset g*128
+	const uint32_t dummy = rows - 1u;
 
 	// Up to Normal a block's candidates (<= 4 configs x 8 variants) fill half a wavefront: two
 	// neighbouring blocks then share one pass (lane group h = lane >> 5), which is worth nearly
@@ -171,7 +193,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		j += pair ? 2u : 1u;
 		const uint32_t h = lane >> 5, hl = pair ? (lane & 31u) : lane, gsz = pair ? 32u : 64u;
 		const uint32_t b = pair ? b0 + h : b0;
-		const uint32_t* tp = tile + b*ASTC_MAX_TEXELS;
+		const uint32_t* tp = tile + b*n;
 		// solid / alpha tests over the texels (the group's lanes stride)
 		const uint32_t p0 = tp[0];
 		bool diff = false, alpha = false;
@@ -194,7 +216,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		if (__ballot(!solid) == 0ull)
 			continue;   // nothing but constant blocks in this pass
 		const uint32_t nc = has_alpha ? 4u : 3u;
-		const uint8_t* set = tables + (has_alpha ? 8u + 8u*ASTC_CFG_STRIDE : 8u);
+		const uint8_t* set = tables + (has_alpha ? 8u + 8u*cstride : 8u);
 		const uint32_t ncfg_all = tables[has_alpha ? 1 : 0];
 		const uint32_t use_cfg = ncfg_all < qcfg ? ncfg_all : qcfg;
 
@@ -276,7 +298,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		const bool active = !solid && k < use_cfg && var < qvar;
 		uint32_t err = 0xFFFFFFFFu;
 		int e0[4] = {0, 0, 0, 255}, e1[4] = {0, 0, 0, 255};
-		CfgView cfg = {set + (active ? k : 0u)*ASTC_CFG_STRIDE};
+		CfgView cfg = {set + (active ? k : 0u)*cstride};
 		const uint32_t N = cfg.N(), ng = cfg.ng();
 		const int bits = (int)cfg.bits(), qmax = (1 << bits) - 1;
 		if (active) {
@@ -324,8 +346,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				// straight-line read-modify-write of the four grid accumulators: neighbours that do
 				// not exist go to the column's dummy row 64 with a zero factor; the real entries
 				// are distinct (N >= 2), so all loads can be issued before the stores
-				const uint32_t g1 = g0 + 1u < 64u ? g0 + 1u : 64u, g2 = g0 + N < 64u ? g0 + N : 64u,
-					g3 = g0 + N + 1u < 64u ? g0 + N + 1u : 64u;
+				const uint32_t g1 = g0 + 1u < dummy ? g0 + 1u : dummy, g2 = g0 + N < dummy ? g0 + N : dummy,
+					g3 = g0 + N + 1u < dummy ? g0 + N + 1u : dummy;
 				const uint32_t a0 = ncol[g0*64u], a1 = ncol[g1*64u], a2 = ncol[g2*64u], a3 = ncol[g3*64u];
 				ncol[g0*64u] = (uint16_t)(a0 + w00*(uint32_t)T);
 				ncol[g1*64u] = (uint16_t)(a1 + w01*(uint32_t)T);
@@ -335,14 +357,14 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			for (uint32_t g = 0; g < ng; ++g) {
 				const uint32_t den = cfg.den(g);
 				const uint32_t gv = den ? div_small((uint32_t)ncol[g*64u] + den/2u, den, 1.0f/(float)den) : 0u;
-				qcol[g*64u] = (uint8_t)((gv*(uint32_t)qmax + 32u) >> 6);
+				ncol[g*64u] = (uint16_t)((gv*(uint32_t)qmax + 32u) >> 6);   // quantised weight, read back as a byte
 			}
-			err = astc_error(tp, n, nc, e0, e1, cfg, qcol, N, bits);
+			err = astc_error(tp, n, nc, e0, e1, cfg, qcol, N, bits, rows);
 			if (refit) {
 				int S = 0, A = 0, B = 0, C = 0, U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
-#pragma unroll 4
+#pragma unroll 1
 				for (uint32_t i = 0; i < n; ++i) {
-					const int wi = texel_weight(cfg, i, qcol, N, bits), iw = 64 - wi;
+					const int wi = texel_weight(cfg, i, qcol, N, bits, rows), iw = 64 - wi;
 					const uint32_t p = tp[i];
 					S += wi; A += iw*iw; B += iw*wi; C += wi*wi;
 #pragma unroll
@@ -371,7 +393,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						}
 					}
 					if (r1[0] + r1[1] + r1[2] >= r0[0] + r0[1] + r0[2]) {
-						const uint32_t e = astc_error(tp, n, nc, r0, r1, cfg, qcol, N, bits);
+						const uint32_t e = astc_error(tp, n, nc, r0, r1, cfg, qcol, N, bits, rows);
 						if (e < err) {
 							err = e;
 #pragma unroll
@@ -401,7 +423,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				}
 			}
 			for (uint32_t g = 0; g < ng; ++g) {
-				const uint32_t qv = qcol[g*64u];
+				const uint32_t qv = qcol[g*128u];
 				for (int kb = 0; kb < bits; ++kb) {
 					if ((qv >> kb) & 1u) {
 						const uint32_t pos = 127u - (g*(uint32_t)bits + (uint32_t)kb);
@@ -430,9 +452,13 @@ extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, hi
 	if (kp->batch)
 		grid = dim3(kp->total_wg, 1, 1);
 	dim3 block(CF_WG_THREADS, 1, 1);
+	const uint32_t n_ = (kp->flags & 255u)*((kp->flags >> 8) & 255u), rows_ = (kp->flags >> 16) & 255u;
+	// tile + compact tables + 4 waves x rows x 64 lanes of u16 (same layout as in the kernel)
+	const size_t dyn = (size_t)CF_BLOCKS_PER_WG*n_*4u + (8u + 16u*(136u + 8u*n_)) +
+		(size_t)4*rows_*64u*sizeof(uint16_t);
 	if (pixel_type == 0)
-		hipLaunchKernelGGL((cfhip_astc_encode_kernel<0>), grid, block, 0, stream, *kp);
+		hipLaunchKernelGGL((cfhip_astc_encode_kernel<0>), grid, block, dyn, stream, *kp);
 	else
-		hipLaunchKernelGGL((cfhip_astc_encode_kernel<1>), grid, block, 0, stream, *kp);
+		hipLaunchKernelGGL((cfhip_astc_encode_kernel<1>), grid, block, dyn, stream, *kp);
 	return hipGetLastError();
 }

@@ -391,6 +391,15 @@ int launch(cfhip_ctx* ctx, const cf_kparams& kp, const cfhip_params& p, int pixe
 			}
 			cf_kparams k2 = kp;
 			k2.aux = tab;
+			{
+				// rows of the per-lane LDS grid columns: largest weight grid of the footprint + 1
+				int fbw, fbh, ng_max = 1;
+				astc_footprint(p.format, &fbw, &fbh);
+				for (int values = 6; values <= 8; values += 2)
+					for (const AstcCfgHost& c : astc_configs(fbw, fbh, values))
+						ng_max = std::max(ng_max, c.N*c.M);
+				k2.flags |= (uint32_t)(ng_max + 1) << 16;
+			}
 			e = cfhip_launch_astc(&k2, pixel_type == CFHIP_PIXEL_RGBA32F ? 1 : 0, stream);
 			ctx->last_kernel = "cfhip_astc_encode_kernel";
 			break;
