@@ -18,6 +18,34 @@ LIB_PATH = os.path.join(PKG, "libcuttlefish_hip.so")
 
 class Format(enum.IntEnum):
     """cuttlefish::Texture::Format values (lib/include/cuttlefish/Texture.h:59-130)."""
+    R4G4 = 1
+    R4G4B4A4 = 2
+    B4G4R4A4 = 3
+    A4R4G4B4 = 4
+    R5G6B5 = 5
+    B5G6R5 = 6
+    R5G5B5A1 = 7
+    B5G5R5A1 = 8
+    A1R5G5B5 = 9
+    R8 = 10
+    R8G8 = 11
+    R8G8B8 = 12
+    B8G8R8 = 13
+    R8G8B8A8 = 14
+    B8G8R8A8 = 15
+    A8B8G8R8 = 16
+    A2R10G10B10 = 17
+    A2B10G10R10 = 18
+    R16 = 19
+    R16G16 = 20
+    R16G16B16 = 21
+    R16G16B16A16 = 22
+    R32 = 23
+    R32G32 = 24
+    R32G32B32 = 25
+    R32G32B32A32 = 26
+    B10G11R11_UFloat = 27
+    E5B9G9R9_UFloat = 28
     BC1_RGB = 29
     BC1_RGBA = 30
     BC2 = 31

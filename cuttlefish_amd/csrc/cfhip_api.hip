@@ -33,6 +33,8 @@ extern "C" hipError_t cfhip_launch_mip_resize(const void* src, int src_pixel_typ
 extern "C" hipError_t cfhip_launch_mip_pass(const void* src, int src_pixel_type, size_t pitch,
 	uint32_t src_n, void* dst, uint32_t dst_w, uint32_t dst_h, int along_x, int filter, int to_linear,
 	int to_srgb, hipStream_t stream);
+extern "C" hipError_t cfhip_launch_std_pack(const cf_kparams* kp, int pixel_type, int bytes_per_pixel,
+	hipStream_t stream);
 extern "C" hipError_t cfhip_launch_bc15(const cf_kparams* kp, int format, int pixel_type,
 	int snorm, hipStream_t stream);
 
@@ -189,6 +191,47 @@ std::vector<uint8_t> astc_build_tables(int bw, int bh)
 	return t;
 }
 
+// ---- uncompressed ("standard") formats, Texture::Format 1..28 ----
+// bytes per pixel for the (format, type) pairs createConverter accepts (Converter.cpp:38-337),
+// 0 for the pairs it answers with nullptr.
+bool is_std_format(int format)
+{
+	return format >= CFHIP_FORMAT_R4G4 && format <= CFHIP_FORMAT_E5B9G9R9_UFLOAT;
+}
+
+int std_pixel_bytes(int format, int type)
+{
+	const bool norm_or_int = type >= CFHIP_TYPE_UNORM && type <= CFHIP_TYPE_INT;
+	switch (format) {
+		case CFHIP_FORMAT_R4G4:
+			return type == CFHIP_TYPE_UNORM ? 1 : 0;
+		case CFHIP_FORMAT_R4G4B4A4: case CFHIP_FORMAT_B4G4R4A4: case CFHIP_FORMAT_A4R4G4B4:
+		case CFHIP_FORMAT_R5G6B5: case CFHIP_FORMAT_B5G6R5: case CFHIP_FORMAT_R5G5B5A1:
+		case CFHIP_FORMAT_B5G5R5A1: case CFHIP_FORMAT_A1R5G5B5:
+			return type == CFHIP_TYPE_UNORM ? 2 : 0;
+		case CFHIP_FORMAT_R8: return norm_or_int ? 1 : 0;
+		case CFHIP_FORMAT_R8G8: return norm_or_int ? 2 : 0;
+		case CFHIP_FORMAT_R8G8B8: return norm_or_int ? 3 : 0;
+		case CFHIP_FORMAT_R8G8B8A8: return norm_or_int ? 4 : 0;
+		case CFHIP_FORMAT_B8G8R8: return type == CFHIP_TYPE_UNORM ? 3 : 0;
+		case CFHIP_FORMAT_B8G8R8A8: case CFHIP_FORMAT_A8B8G8R8:
+			return type == CFHIP_TYPE_UNORM ? 4 : 0;
+		case CFHIP_FORMAT_A2R10G10B10: case CFHIP_FORMAT_A2B10G10R10:
+			return (type == CFHIP_TYPE_UNORM || type == CFHIP_TYPE_UINT) ? 4 : 0;
+		case CFHIP_FORMAT_R16: case CFHIP_FORMAT_R16G16: case CFHIP_FORMAT_R16G16B16:
+		case CFHIP_FORMAT_R16G16B16A16:
+			return (norm_or_int || type == CFHIP_TYPE_FLOAT) ? 2*(format - CFHIP_FORMAT_R16 + 1) : 0;
+		case CFHIP_FORMAT_R32: case CFHIP_FORMAT_R32G32: case CFHIP_FORMAT_R32G32B32:
+		case CFHIP_FORMAT_R32G32B32A32:
+			return (type == CFHIP_TYPE_UINT || type == CFHIP_TYPE_INT || type == CFHIP_TYPE_FLOAT)
+				? 4*(format - CFHIP_FORMAT_R32 + 1) : 0;
+		case CFHIP_FORMAT_B10G11R11_UFLOAT: case CFHIP_FORMAT_E5B9G9R9_UFLOAT:
+			return type == CFHIP_TYPE_UFLOAT ? 4 : 0;
+		default:
+			return 0;
+	}
+}
+
 int block_bytes(int format)
 {
 	switch (format) {
@@ -218,14 +261,21 @@ int block_bytes(int format)
 
 void block_dims(int format, int* bw, int* bh)
 {
-	*bw = 4;
-	*bh = 4;
+	*bw = *bh = is_std_format(format) ? 1 : 4;
 	astc_footprint(format, bw, bh);
+}
+
+// bytes of one output unit: a block, or a pixel of a standard format
+int unit_bytes(int format, int type)
+{
+	return is_std_format(format) ? std_pixel_bytes(format, type) : block_bytes(format);
 }
 
 // createConverter's legality matrix, Converter.cpp:339-412
 bool type_valid(int format, int type)
 {
+	if (is_std_format(format))
+		return std_pixel_bytes(format, type) != 0;
 	switch (format) {
 		case CFHIP_FORMAT_BC1_RGB:
 		case CFHIP_FORMAT_BC1_RGBA:
@@ -255,6 +305,8 @@ bool type_valid(int format, int type)
 
 bool format_implemented(int format, int type)
 {
+	if (is_std_format(format))
+		return true;
 	if (format >= CFHIP_FORMAT_ASTC_4x4 && format <= CFHIP_FORMAT_ASTC_12x12)
 		return type == CFHIP_TYPE_UNORM;   // LDR subset only; the HDR profile is not built yet
 	switch (format) {
@@ -292,8 +344,8 @@ int check_params(cfhip_ctx* ctx, const cfhip_params* p)
 {
 	if (!p)
 		return fail(ctx, CFHIP_E_INVALID, "params is NULL");
-	if (!block_bytes(p->format) || !type_valid(p->format, p->type))
-		return fail(ctx, CFHIP_E_UNSUPPORTED, "format %d / type %d is not a legal block format "
+	if (!unit_bytes(p->format, p->type) || !type_valid(p->format, p->type))
+		return fail(ctx, CFHIP_E_UNSUPPORTED, "format %d / type %d is not a legal format "
 			"(createConverter returns nullptr)", p->format, p->type);
 	if (!format_implemented(p->format, p->type))
 		return fail(ctx, CFHIP_E_UNSUPPORTED, "format %d / type %d has no gfx950 kernel yet",
@@ -316,7 +368,7 @@ void fill_kparams(cf_kparams& kp, const cfhip_params& p, const void* src, void* 
 	block_dims(p.format, &fbw, &fbh);
 	kp.bx = (w + (uint32_t)fbw - 1u)/(uint32_t)fbw;
 	kp.by = (h + (uint32_t)fbh - 1u)/(uint32_t)fbh;
-	kp.flags = (uint32_t)fbw | ((uint32_t)fbh << 8);
+	kp.flags = is_std_format(p.format) ? (uint32_t)p.format : ((uint32_t)fbw | ((uint32_t)fbh << 8));
 	kp.quality = (uint32_t)p.quality;
 	kp.type = (uint32_t)p.type;
 	// Colour mask (Texture::ColorMask; S3tcConverter.cpp:217-224 zeroes the weights):
@@ -365,6 +417,13 @@ int launch(cfhip_ctx* ctx, const cf_kparams& kp, const cfhip_params& p, int pixe
 	hipStream_t stream)
 {
 	hipError_t e;
+	if (is_std_format(p.format)) {
+		e = cfhip_launch_std_pack(&kp, pixel_type, std_pixel_bytes(p.format, p.type), stream);
+		ctx->last_kernel = "cfhip_std_pack_kernel";
+		if (e != hipSuccess)
+			return fail(ctx, CFHIP_E_DEVICE, "kernel launch: %s", hipGetErrorString(e));
+		return CFHIP_OK;
+	}
 	switch (p.format) {
 		case CFHIP_FORMAT_BC7: {
 			if (pixel_type != CFHIP_PIXEL_RGBA8 && pixel_type != CFHIP_PIXEL_RGBA32F)
@@ -491,6 +550,15 @@ int batched_launch(cfhip_ctx* ctx, const std::vector<cf_kparams>& kps, const cfh
 {
 	if (kps.size() == 1)
 		return timed_launch(ctx, kps[0], p, pixel_type, stream);
+	if (is_std_format(p.format)) {
+		// bandwidth-bound per-pixel work with no workgroup tiling to share: one launch each
+		for (const cf_kparams& k : kps) {
+			const int rc = timed_launch(ctx, k, p, pixel_type, stream);
+			if (rc != CFHIP_OK)
+				return rc;
+		}
+		return CFHIP_OK;
+	}
 	std::vector<cf_batch_entry> entries(kps.size());
 	uint32_t wg = 0;
 	for (size_t i = 0; i < kps.size(); ++i) {
@@ -525,7 +593,7 @@ int batched_launch(cfhip_ctx* ctx, const std::vector<cf_kparams>& kps, const cfh
 // formats whose kernels consume 8-bit texels for UNorm: their RGBA32F loader is cf_unorm8
 bool takes_unorm8(const cfhip_params& p)
 {
-	if (p.type != CFHIP_TYPE_UNORM)
+	if (p.type != CFHIP_TYPE_UNORM || is_std_format(p.format))
 		return false;
 	if (p.format == CFHIP_FORMAT_EAC_R11 || p.format == CFHIP_FORMAT_EAC_R11G11 ||
 		p.format == CFHIP_FORMAT_BC6H)
@@ -565,7 +633,7 @@ int encode_host_pipelined(cfhip_ctx* ctx, const cfhip_surface& s, const cfhip_pa
 {
 	int fbw, fbh;
 	block_dims(p.format, &fbw, &fbh);
-	const int bs = block_bytes(p.format);
+	const int bs = unit_bytes(p.format, p.type);
 	const bool quantise = s.pixel_type == CFHIP_PIXEL_RGBA32F && takes_unorm8(p);
 	const int dev_type = quantise ? CFHIP_PIXEL_RGBA8 : s.pixel_type;
 	const size_t dev_row = (size_t)s.width*pixel_bytes(dev_type);
@@ -575,6 +643,8 @@ int encode_host_pipelined(cfhip_ctx* ctx, const cfhip_surface& s, const cfhip_pa
 	// strips of whole block rows, ~8 MB of device pixels each, at least 4 of them
 	uint32_t strip_brows = (uint32_t)std::max<size_t>(1, ((size_t)8 << 20)/(dev_row*(size_t)fbh));
 	strip_brows = std::min(strip_brows, std::max(1u, by/4u));
+	if (is_std_format(p.format))
+		strip_brows = (strip_brows + 3u) & ~3u;   // every strip's output stays 4-byte aligned
 	const size_t strip_bytes = (size_t)strip_brows*(size_t)fbh*dev_row;
 	int rc = reserve(ctx, &ctx->d_src, &ctx->src_cap, dev_row*(size_t)s.height);
 	if (rc != CFHIP_OK) return rc;
@@ -702,7 +772,7 @@ void cfhip_destroy(cfhip_ctx* ctx)
 
 int cfhip_query(int format, int type, int* block_w, int* block_h, int* bytes)
 {
-	const int bs = block_bytes(format);
+	const int bs = unit_bytes(format, type);
 	if (!bs || !type_valid(format, type))
 		return CFHIP_E_UNSUPPORTED;
 	int fbw, fbh;
@@ -742,7 +812,7 @@ static int encode_impl(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n,
 		ctx->events_used = 0;
 	ctx->events_stream = stream;
 	ctx->last_ms = -1.0f;
-	const int bs = block_bytes(params->format);
+	const int bs = unit_bytes(params->format, params->type);
 
 	// validate everything first, compute sizes
 	struct Item { size_t src_bytes, out_bytes, row_bytes; };
@@ -765,6 +835,10 @@ static int encode_impl(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n,
 		if (s.out_capacity < out_bytes)
 			return fail(ctx, CFHIP_E_CAPACITY, "surface %zu: out_capacity %zu < %zu", i,
 				s.out_capacity, out_bytes);
+		if (device_mem && is_std_format(params->format) &&
+			((((uintptr_t)s.out) & 15u) || (((uintptr_t)s.pixels) & (pb - 1)) || (apitch & (pb - 1))))
+			return fail(ctx, CFHIP_E_INVALID, "surface %zu: standard formats need a 16-byte aligned "
+				"device output and pixel-aligned source rows", i);
 		items[i] = {row_bytes*(size_t)s.height, out_bytes, row_bytes};
 	}
 

@@ -34,6 +34,41 @@ extern "C" {
 
 /* Values mirror cuttlefish::Texture::Format (lib/include/cuttlefish/Texture.h:59-130). */
 enum cfhip_format {
+	/* Uncompressed ("standard") formats: one output pixel per source pixel, row-major, tightly
+	 * packed; cfhip_query answers block 1x1 and the bytes per pixel.  Replaces the
+	 * StandardConverter family (lib/src/StandardConverter.h:44-515, StandardConverter.cpp:22-467)
+	 * with the (format, type) legality of createConverter (lib/src/Converter.cpp:38-337).
+	 * quality / alpha / mask / color_space are ignored, as the reference's converters ignore them.
+	 * NaN converts to 0 and float -> integer conversions saturate (undefined in the reference). */
+	CFHIP_FORMAT_R4G4 = 1,
+	CFHIP_FORMAT_R4G4B4A4 = 2,
+	CFHIP_FORMAT_B4G4R4A4 = 3,
+	CFHIP_FORMAT_A4R4G4B4 = 4,
+	CFHIP_FORMAT_R5G6B5 = 5,
+	CFHIP_FORMAT_B5G6R5 = 6,
+	CFHIP_FORMAT_R5G5B5A1 = 7,
+	CFHIP_FORMAT_B5G5R5A1 = 8,
+	CFHIP_FORMAT_A1R5G5B5 = 9,
+	CFHIP_FORMAT_R8 = 10,
+	CFHIP_FORMAT_R8G8 = 11,
+	CFHIP_FORMAT_R8G8B8 = 12,
+	CFHIP_FORMAT_B8G8R8 = 13,
+	CFHIP_FORMAT_R8G8B8A8 = 14,
+	CFHIP_FORMAT_B8G8R8A8 = 15,
+	CFHIP_FORMAT_A8B8G8R8 = 16,
+	CFHIP_FORMAT_A2R10G10B10 = 17,
+	CFHIP_FORMAT_A2B10G10R10 = 18,
+	CFHIP_FORMAT_R16 = 19,
+	CFHIP_FORMAT_R16G16 = 20,
+	CFHIP_FORMAT_R16G16B16 = 21,
+	CFHIP_FORMAT_R16G16B16A16 = 22,
+	CFHIP_FORMAT_R32 = 23,
+	CFHIP_FORMAT_R32G32 = 24,
+	CFHIP_FORMAT_R32G32B32 = 25,
+	CFHIP_FORMAT_R32G32B32A32 = 26,
+	CFHIP_FORMAT_B10G11R11_UFLOAT = 27,
+	CFHIP_FORMAT_E5B9G9R9_UFLOAT = 28,
+	/* Block-compressed formats. */
 	CFHIP_FORMAT_BC1_RGB = 29,
 	CFHIP_FORMAT_BC1_RGBA = 30,
 	CFHIP_FORMAT_BC2 = 31,

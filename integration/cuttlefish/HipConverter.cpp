@@ -42,6 +42,12 @@ bool HipConverter::available()
 
 bool HipConverter::supports(Texture::Format format, Texture::Type type)
 {
+	// The backend also packs the uncompressed formats (StandardConverter family), but from host
+	// scanlines that is a 16 byte/pixel upload for a few bytes of trivially computed output:
+	// the stock converters stay in charge here.  The GPU packers serve surfaces that are already
+	// resident (mip chains generated on the GPU) through cfhip_encode_device.
+	if (format < Texture::Format::BC1_RGB)
+		return false;
 	int blockW, blockH, blockBytes;
 	return cfhip_query(static_cast<int>(format), static_cast<int>(type), &blockW, &blockH,
 		&blockBytes) == CFHIP_OK;

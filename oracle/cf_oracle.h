@@ -82,6 +82,12 @@ double cfo_linear_to_srgb(double c);
 int cfo_resize_rgbaf(const float* src, unsigned sw, unsigned sh, float* dst, unsigned dw,
 	unsigned dh, int filter, int color_space);
 
+/* uncompressed ("standard") converters (std_pack.c): bytes per pixel (0 = illegal pair) and the
+ * whole-image pack of RGBA32F rows into width*height tightly packed pixels */
+int cfo_std_pixel_bytes(int format, int type);
+int cfo_std_pack(int format, int type, const float* pixels, uint32_t width, uint32_t height,
+	ptrdiff_t row_pitch, uint8_t* out, size_t out_capacity);
+
 /* single-block encoders (inputs already quantised as the reference does) */
 void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p);
 

@@ -212,3 +212,38 @@ def ref_lib():
     R.cfref_to_grayscale.restype = ctypes.c_double
     R.cfref_to_grayscale.argtypes = [ctypes.c_double] * 3
     return R
+
+
+# ---- uncompressed ("standard") converters (oracle/std_pack.c) ------------------------------
+
+def std_pixel_bytes(fmt: int, typ: int) -> int:
+    L = lib()
+    L.cfo_std_pixel_bytes.restype = ctypes.c_int
+    L.cfo_std_pixel_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+    return L.cfo_std_pixel_bytes(int(fmt), int(typ))
+
+
+def as_rgbaf(img: np.ndarray) -> np.ndarray:
+    """The reference's RGBAF view of a source image: u8/255 (toDoubleNorm + float store, which for
+    8-bit values equals the float division), half -> float exact, float as is."""
+    if img.dtype == np.uint8:
+        return (img.astype(np.float64)/255.0).astype(np.float32)
+    return np.ascontiguousarray(img.astype(np.float32))
+
+
+def std_pack(img: np.ndarray, fmt: int, typ: int) -> np.ndarray:
+    """StandardConverter family: (h, w, 4) image -> h*w*bytes_per_pixel payload bytes."""
+    f = np.ascontiguousarray(as_rgbaf(img))
+    h, w = f.shape[:2]
+    bpp = std_pixel_bytes(fmt, typ)
+    if not bpp:
+        raise ValueError("illegal (format, type) = (%d, %d)" % (fmt, typ))
+    out = np.zeros(h*w*bpp, np.uint8)
+    L = lib()
+    L.cfo_std_pack.restype = ctypes.c_int
+    L.cfo_std_pack.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32,
+                               ctypes.c_uint32, ctypes.c_ssize_t, ctypes.c_void_p, ctypes.c_size_t]
+    rc = L.cfo_std_pack(int(fmt), int(typ), f.ctypes.data, w, h, f.strides[0], out.ctypes.data, out.nbytes)
+    if rc != 0:
+        raise RuntimeError("cfo_std_pack failed: %d" % rc)
+    return out
