@@ -1,11 +1,16 @@
-"""DDS (DX10 header) and KTX 1.1 writers for block-compressed payloads -- SURVEY section 8(f)
-row 2: "container writers ... so outputs open in standard viewers".
+"""DDS (DX10 header), KTX 1.1 and PVR v3 writers -- SURVEY section 8(f) row 2: "container writers
+(DDS-DX10 / KTX1 / PVR3) ... so outputs open in standard viewers".
 
 Pure serialisation, host side, mirrors the reference writers field for field:
   saveDds   lib/src/SaveDds.cpp:565-683   (header flags :578-598, DX10 header :604-652,
                                             surface order element -> face -> mip :657-680)
   saveKtx   lib/src/SaveKtx.cpp:1189-1290 (header :1198-1221, per level imageSize :1224-1248,
                                             then depth -> face payloads :1250-1262)
+  savePvr   lib/src/SavePvr.cpp:478-600   (header :487-524, CTFS metadata :526-575,
+                                            surface order mip -> depth -> face :580-595;
+                                            pixel format :272-470, channel type :107-268)
+DDS and PVR cover the uncompressed formats of csrc/std_pack.hip too (getDdsFormat,
+SaveDds.cpp:252-440); KTX is kept to the block-compressed formats.
 Only 2-D textures and 2-D arrays of the formats this backend encodes are covered (cube maps
 and 3-D textures are containers of the same surfaces in a different order: not needed by the
 hot path's tests).  `read_dds` parses what `write_dds` emits (round-trip tests; Pillow is the
@@ -54,11 +59,45 @@ _GL = {
     (Format.EAC_R11, Type.UNorm): (0x9270, None, _GL_RED), (Format.EAC_R11, Type.SNorm): (0x9271, None, _GL_RED),
     (Format.EAC_R11G11, Type.UNorm): (0x9272, None, _GL_RG), (Format.EAC_R11G11, Type.SNorm): (0x9273, None, _GL_RG),
 }
+# uncompressed formats, getDdsFormat (SaveDds.cpp:252-440): (format, type) -> DXGI (linear, sRGB)
+_U, _S, _UI, _I, _UF, _F = Type.UNorm, Type.SNorm, Type.UInt, Type.Int, Type.UFloat, Type.Float
+_DXGI.update({
+    (Format.R4G4, _U): (112, None), (Format.A4R4G4B4, _U): (115, None), (Format.R5G6B5, _U): (85, None),
+    (Format.A1R5G5B5, _U): (86, None),
+    (Format.R8, _U): (61, None), (Format.R8, _UI): (62, None), (Format.R8, _S): (63, None), (Format.R8, _I): (64, None),
+    (Format.R8G8, _U): (49, None), (Format.R8G8, _UI): (50, None), (Format.R8G8, _S): (51, None), (Format.R8G8, _I): (52, None),
+    (Format.R8G8B8A8, _U): (28, 29), (Format.R8G8B8A8, _UI): (30, None), (Format.R8G8B8A8, _S): (31, None),
+    (Format.R8G8B8A8, _I): (32, None), (Format.B8G8R8A8, _U): (87, 91),
+    (Format.A2B10G10R10, _U): (24, None), (Format.A2B10G10R10, _UI): (25, None),
+    (Format.R16, _F): (54, None), (Format.R16, _U): (56, None), (Format.R16, _UI): (57, None),
+    (Format.R16, _S): (58, None), (Format.R16, _I): (59, None),
+    (Format.R16G16, _F): (34, None), (Format.R16G16, _U): (35, None), (Format.R16G16, _UI): (36, None),
+    (Format.R16G16, _S): (37, None), (Format.R16G16, _I): (38, None),
+    (Format.R16G16B16A16, _F): (10, None), (Format.R16G16B16A16, _U): (11, None), (Format.R16G16B16A16, _UI): (12, None),
+    (Format.R16G16B16A16, _S): (13, None), (Format.R16G16B16A16, _I): (14, None),
+    (Format.R32, _F): (41, None), (Format.R32, _UI): (42, None), (Format.R32, _I): (43, None),
+    (Format.R32G32, _F): (16, None), (Format.R32G32, _UI): (17, None), (Format.R32G32, _I): (18, None),
+    (Format.R32G32B32, _F): (6, None), (Format.R32G32B32, _UI): (7, None), (Format.R32G32B32, _I): (8, None),
+    (Format.R32G32B32A32, _F): (2, None), (Format.R32G32B32A32, _UI): (3, None), (Format.R32G32B32A32, _I): (4, None),
+    (Format.B10G11R11_UFloat, _UF): (26, None), (Format.E5B9G9R9_UFloat, _UF): (67, None),
+})
+
 _ASTC = [Format.ASTC_4x4, Format.ASTC_5x4, Format.ASTC_5x5, Format.ASTC_6x5, Format.ASTC_6x6,
          Format.ASTC_8x5, Format.ASTC_8x6, Format.ASTC_8x8, Format.ASTC_10x5, Format.ASTC_10x6,
          Format.ASTC_10x8, Format.ASTC_10x10, Format.ASTC_12x10, Format.ASTC_12x12]
 for _i, _f in enumerate(_ASTC):
     _GL[(_f, Type.UNorm)] = (0x93B0 + _i, 0x93D0 + _i, _GL_RGBA)
+
+# Texture::hasAlpha (Texture.cpp:467-512)
+_HAS_ALPHA = {Format.R4G4B4A4, Format.B4G4R4A4, Format.R5G5B5A1, Format.B5G5R5A1, Format.A1R5G5B5,
+              Format.R8G8B8A8, Format.B8G8R8A8, Format.A8B8G8R8, Format.A2R10G10B10, Format.A2B10G10R10,
+              Format.R16G16B16A16, Format.R32G32B32A32, Format.BC1_RGBA, Format.BC2, Format.BC3,
+              Format.BC7, Format.ETC2_R8G8B8A1, Format.ETC2_R8G8B8A8} | set(_ASTC)
+
+
+def has_alpha(fmt) -> bool:
+    return Format(fmt) in _HAS_ALPHA
+
 
 KTX_IDENTIFIER = bytes([0xAB, 0x4B, 0x54, 0x58, 0x20, 0x31, 0x31, 0xBB, 0x0D, 0x0A, 0x1A, 0x0A])
 KTX_ENDIANNESS = 0x04030201
@@ -114,8 +153,7 @@ def write_dds(stream, fmt, typ, width: int, height: int, levels_or_elements: Seq
         caps |= _DDSCAPS_MIPMAP
     if levels > 1 or len(elements) > 1:
         caps |= _DDSCAPS_COMPLEX
-    has_alpha = fmt in (Format.BC1_RGBA, Format.BC2, Format.BC3, Format.BC7)
-    misc2 = _ALPHA_MODE[Alpha(alpha)] if has_alpha else 3
+    misc2 = _ALPHA_MODE[Alpha(alpha)] if has_alpha(fmt) else 3
     out = struct.pack("<I", DDS_MAGIC)
     out += struct.pack("<7I44x", 124, flags, height, width, pitch, 0, levels)
     out += struct.pack("<2I4s5I", 32, _DDPF_FOURCC, b"DX10", 0, 0, 0, 0, 0)
@@ -165,3 +203,118 @@ def write_ktx(stream, fmt, typ, width: int, height: int, levels_or_elements: Seq
             out += e[l]
     stream.write(out)
     return len(out)
+
+
+# ---- PVR v3 (savePvr, SavePvr.cpp:478-600) ---------------------------------------------------
+
+def _fourcc(a, b, c, d) -> int:
+    o = lambda x: x if isinstance(x, int) else ord(x)
+    return o(a) | (o(b) << 8) | (o(c) << 16) | (o(d) << 24)
+
+
+def _pvr_generic(*pairs) -> int:
+    """PVR_GENERIC_FORMAT (SavePvr.cpp:23-27): channel letters in the low dword, bit counts above."""
+    v = 0
+    for i, (ch, bits) in enumerate(pairs):
+        v |= (ord(ch) if ch else 0) << (8*i)
+        v |= bits << (32 + 8*i)
+    return v
+
+
+# PvrSpecialFormat (SavePvr.cpp:53-105)
+_PVR_SPECIAL = {
+    Format.ETC1: 6, Format.BC1_RGB: 7, Format.BC1_RGBA: 7, Format.BC2: 9, Format.BC3: 11, Format.BC4: 12,
+    Format.BC5: 13, Format.BC6H: 14, Format.BC7: 15, Format.E5B9G9R9_UFloat: 19,
+    Format.ETC2_R8G8B8: 22, Format.ETC2_R8G8B8A8: 23, Format.ETC2_R8G8B8A1: 24, Format.EAC_R11: 25,
+    Format.EAC_R11G11: 26,
+}
+for _i, _f in enumerate(_ASTC):
+    _PVR_SPECIAL[_f] = 27 + _i
+_PVR_GENERIC = {
+    Format.R4G4: "r4g4", Format.R4G4B4A4: "r4g4b4a4", Format.B4G4R4A4: "b4g4r4a4", Format.A4R4G4B4: "a4r4g4b4",
+    Format.R5G6B5: "r5g6b5", Format.B5G6R5: "b5g6r5", Format.R5G5B5A1: "r5g5b5a1", Format.B5G5R5A1: "b5g5r5a1",
+    Format.A1R5G5B5: "a1r5g5b5", Format.R8: "r8", Format.R8G8: "r8g8", Format.R8G8B8: "r8g8b8",
+    Format.B8G8R8: "b8g8r8", Format.R8G8B8A8: "r8g8b8a8", Format.B8G8R8A8: "b8g8r8a8",
+    Format.A8B8G8R8: "a8b8g8r8", Format.A2R10G10B10: "a2r10g10b10", Format.A2B10G10R10: "a2b10g10r10",
+    Format.R16: "r16", Format.R16G16: "r16g16", Format.R16G16B16: "r16g16b16",
+    Format.R16G16B16A16: "r16g16b16a16", Format.R32: "r32", Format.R32G32: "r32g32",
+    Format.R32G32B32: "r32g32b32", Format.R32G32B32A32: "r32g32b32a32", Format.B10G11R11_UFloat: "b10g11r11",
+}
+
+
+def pvr_pixel_format(fmt, alpha=Alpha.Standard) -> int:
+    """getPixelFormat (SavePvr.cpp:272-470)."""
+    fmt = Format(fmt)
+    if fmt in _PVR_GENERIC:
+        import re
+        return _pvr_generic(*[(c, int(b)) for c, b in re.findall(r"([rgba])(\d+)", _PVR_GENERIC[fmt])])
+    if Alpha(alpha) == Alpha.PreMultiplied and fmt in (Format.BC2, Format.BC3):
+        return 8 if fmt == Format.BC2 else 10                # DXT2 / DXT4
+    return _PVR_SPECIAL[fmt]
+
+
+_PVR_BYTE = {Format.R4G4, Format.R8, Format.R8G8, Format.R8G8B8, Format.B8G8R8, Format.R8G8B8A8,
+             Format.B8G8R8A8, Format.A8B8G8R8}
+_PVR_SHORT = {Format.R4G4B4A4, Format.B4G4R4A4, Format.A4R4G4B4, Format.R5G6B5, Format.B5G6R5,
+              Format.R5G5B5A1, Format.B5G5R5A1, Format.A1R5G5B5, Format.R16, Format.R16G16,
+              Format.R16G16B16, Format.R16G16B16A16}
+_PVR_INT = {Format.A2R10G10B10, Format.A2B10G10R10, Format.R32, Format.R32G32, Format.R32G32B32,
+            Format.R32G32B32A32}
+
+
+def pvr_channel_type(fmt, typ) -> int:
+    """getChannelType (SavePvr.cpp:107-268): PvrChannelType index."""
+    fmt, typ = Format(fmt), Type(typ)
+    if typ == Type.UFloat:
+        return 13
+    if typ == Type.Float:
+        return 12
+    norm = typ in (Type.UNorm, Type.SNorm)
+    signed = typ in (Type.SNorm, Type.Int)
+    byte_like = fmt in _PVR_BYTE or (norm and fmt in (Format.BC4, Format.BC5))
+    short_like = fmt in _PVR_SHORT or (norm and fmt in (Format.EAC_R11, Format.EAC_R11G11))
+    if byte_like:
+        base = 0
+    elif short_like:
+        base = 4
+    elif fmt in _PVR_INT:
+        base = 8
+    else:                                                     # the default: rows of the switch
+        return {Type.UNorm: 0, Type.SNorm: 1, Type.UInt: 2, Type.Int: 2}[typ]
+    return base + (0 if norm else 2) + (1 if signed else 0)
+
+
+def write_pvr(stream, fmt, typ, width: int, height: int, levels_or_elements: Sequence,
+              color_space=ColorSpace.Linear, alpha=Alpha.Standard) -> int:
+    """Write a PVR v3 file of a 2-D texture or 2-D array (surface order mip -> element)."""
+    fmt, typ = Format(fmt), Type(typ)
+    elements = [[_b(m) for m in e] for e in _as_elements(levels_or_elements)]
+    levels = _check_levels(fmt, typ, width, height, elements)
+    is_array = len(elements) > 1
+    out = struct.pack("<II", _fourcc("P", "V", "R", 3), 0x2 if Alpha(alpha) == Alpha.PreMultiplied else 0)
+    out += struct.pack("<Q", pvr_pixel_format(fmt, alpha))
+    out += struct.pack("<II", 1 if ColorSpace(color_space) == ColorSpace.sRGB else 0, pvr_channel_type(fmt, typ))
+    out += struct.pack("<6I", height, width, 1, len(elements) if is_array else 1, 1, levels)
+    meta = b""
+    if fmt in (Format.BC1_RGB, Format.BC1_RGBA):              # BC1 alpha is told apart by metadata
+        code = _fourcc("B", "C", "1", "A") if fmt == Format.BC1_RGBA else _fourcc("B", "C", "1", 0)
+        meta += struct.pack("<4I", _fourcc("C", "T", "F", "S"), code, 4, 0)
+    if is_array:
+        meta += struct.pack("<4I", _fourcc("C", "T", "F", "S"), _fourcc("A", "R", "R", "Y"), 4, 0)
+    out += struct.pack("<I", len(meta)) + meta
+    for l in range(levels):
+        for e in elements:
+            out += e[l]
+    stream.write(out)
+    return len(out)
+
+
+def read_pvr(data: bytes):
+    """Parse the header of a PVR v3 file (round-trip tests)."""
+    version, flags, pixfmt, cspace, chtype, height, width, depth, surfaces, faces, levels, meta = \
+        struct.unpack_from("<IIQIIIIIIIII", data, 0)
+    if version != _fourcc("P", "V", "R", 3):
+        raise ValueError("not a PVR v3 file")
+    return {"flags": flags, "pixel_format": pixfmt, "color_space": cspace, "channel_type": chtype,
+            "width": width, "height": height, "depth": depth, "elements": surfaces, "faces": faces,
+            "levels": levels, "metadata": data[52:52 + meta], "offset": 52 + meta}

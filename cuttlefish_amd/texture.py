@@ -28,7 +28,8 @@ import numpy as np
 from . import api
 from .api import Alpha, ColorSpace, Format, Quality, Type
 
-_NATIVE_SRGB = {Format.BC1_RGB, Format.BC1_RGBA, Format.BC2, Format.BC3, Format.BC7,
+_NATIVE_SRGB = {Format.R8G8B8, Format.B8G8R8, Format.R8G8B8A8, Format.B8G8R8A8, Format.A8B8G8R8,
+                Format.BC1_RGB, Format.BC1_RGBA, Format.BC2, Format.BC3, Format.BC7,
                 Format.ETC2_R8G8B8, Format.ETC2_R8G8B8A1, Format.ETC2_R8G8B8A8} | \
     {Format(v) for v in range(43, 57)}
 

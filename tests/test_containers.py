@@ -126,3 +126,68 @@ def test_ktx_srgb_and_array():
     f = struct.unpack_from("<13I", d, 12)
     assert f[4] == 0x8E8D and f[9] == 3                    # sRGB BPTC, 3 array elements
     assert struct.unpack_from("<I", d, 64)[0] == 3 * 64    # imageSize covers all elements
+
+
+# ---- PVR v3 and the uncompressed formats ------------------------------------------------------
+
+def test_pvr_header_metadata_and_surface_order_follow_savepvr():
+    img = synth.photo(32, 16, seed=2)
+    e0 = [O.encode(m, int(Format.BC1_RGBA), 0, quality=0) for m in _mips(img, 3)]
+    e1 = [O.encode(m[::-1].copy(), int(Format.BC1_RGBA), 0, quality=0) for m in _mips(img, 3)]
+    buf = io.BytesIO()
+    n = C.write_pvr(buf, Format.BC1_RGBA, Type.UNorm, 32, 16, [e0, e1], color_space=ColorSpace.sRGB)
+    data = buf.getvalue()
+    assert n == len(data)
+    h = C.read_pvr(data)
+    assert data[:4] == b"PVR\x03"
+    assert (h["width"], h["height"], h["depth"], h["elements"], h["faces"], h["levels"]) == (32, 16, 1, 2, 1, 3)
+    assert h["pixel_format"] == 7 and h["channel_type"] == 0 and h["color_space"] == 1 and h["flags"] == 0
+    # two CTFS blocks: BC1A marker, then the array marker (SavePvr.cpp:526-560)
+    assert h["metadata"] == (b"CTFSBC1A" + struct.pack("<II", 4, 0) + b"CTFSARRY" + struct.pack("<II", 4, 0))
+    body = data[h["offset"]:]
+    want = b"".join(bytes(e[l]) for l in range(3) for e in (e0, e1))      # mip -> element
+    assert body == want
+    buf = io.BytesIO()
+    C.write_pvr(buf, Format.BC7, Type.UNorm, 32, 16, e0[:1]*0 + [O.encode(img, int(Format.BC7), 0, quality=0)])
+    h = C.read_pvr(buf.getvalue())
+    assert h["metadata"] == b"" and h["offset"] == 52 and h["pixel_format"] == 15
+
+
+def test_pvr_pixel_formats_and_channel_types():
+    g = C.pvr_pixel_format
+    assert g(Format.R5G6B5) == (ord("r") | ord("g") << 8 | ord("b") << 16 | 5 << 32 | 6 << 40 | 5 << 48)
+    assert g(Format.A2B10G10R10) == (ord("a") | ord("b") << 8 | ord("g") << 16 | ord("r") << 24 |
+                                      2 << 32 | 10 << 40 | 10 << 48 | 10 << 56)
+    assert g(Format.R8) == (ord("r") | 8 << 32)
+    assert g(Format.E5B9G9R9_UFloat) == 19 and g(Format.ETC1) == 6 and g(Format.ASTC_4x4) == 27
+    assert g(Format.ASTC_12x12) == 40 and g(Format.EAC_R11G11) == 26 and g(Format.ETC2_R8G8B8A1) == 24
+    assert g(Format.BC2, alpha=2) == 8 and g(Format.BC3, alpha=2) == 10 and g(Format.BC3) == 11
+    t = C.pvr_channel_type
+    assert [t(Format.R8G8B8A8, k) for k in (Type.UNorm, Type.SNorm, Type.UInt, Type.Int)] == [0, 1, 2, 3]
+    assert [t(Format.R16G16, k) for k in (Type.UNorm, Type.SNorm, Type.UInt, Type.Int, Type.Float)] == [4, 5, 6, 7, 12]
+    assert [t(Format.R32, k) for k in (Type.UInt, Type.Int, Type.Float)] == [10, 11, 12]
+    assert t(Format.A2R10G10B10, Type.UNorm) == 8 and t(Format.R5G6B5, Type.UNorm) == 4
+    assert t(Format.BC5, Type.SNorm) == 1 and t(Format.EAC_R11, Type.UNorm) == 4 and t(Format.BC7, Type.UNorm) == 0
+    assert t(Format.BC6H, Type.UFloat) == 13 and t(Format.BC6H, Type.Float) == 12
+    assert t(Format.B10G11R11_UFloat, Type.UFloat) == 13
+
+
+def test_uncompressed_dds_opens_in_pillow():
+    PIL = pytest.importorskip("PIL.Image")
+    img = synth.photo(40, 24, seed=8)
+    payload = O.std_pack(img, int(Format.R8G8B8A8), int(Type.UNorm))
+    buf = io.BytesIO()
+    C.write_dds(buf, Format.R8G8B8A8, Type.UNorm, 40, 24, [payload])
+    hdr = C.read_dds(buf.getvalue())
+    assert hdr["dxgi"] == 28 and hdr["pitch"] == 160 and hdr["alpha_mode"] == 1
+    got = np.asarray(PIL.open(io.BytesIO(buf.getvalue())).convert("RGBA"))
+    assert np.array_equal(got, img)
+    for fmt, typ, dxgi in ((Format.R16G16B16A16, Type.Float, 10), (Format.R32G32B32, Type.Float, 6),
+                           (Format.R5G6B5, Type.UNorm, 85), (Format.E5B9G9R9_UFloat, Type.UFloat, 67),
+                           (Format.B10G11R11_UFloat, Type.UFloat, 26), (Format.R8, Type.SNorm, 63)):
+        buf = io.BytesIO()
+        C.write_dds(buf, fmt, typ, 40, 24, [O.std_pack(img, int(fmt), int(typ))])
+        assert C.read_dds(buf.getvalue())["dxgi"] == dxgi
+    for fmt, typ in ((Format.R8G8B8, Type.UNorm), (Format.B8G8R8, Type.UNorm), (Format.R4G4B4A4, Type.UNorm)):
+        with pytest.raises(ValueError):                      # getDdsFormat has no entry: Unsupported
+            C.write_dds(io.BytesIO(), fmt, typ, 40, 24, [O.std_pack(img, int(fmt), int(typ))])

@@ -37,3 +37,25 @@ def test_gpu_payload_in_dds_decodes_in_pillow(fmt):
     assert np.array_equal(got[..., :c], ref[..., :c])
     # and the payload itself is the oracle's (same search, byte for byte)
     assert np.array_equal(levels[0], O.encode(base, int(fmt), 0, quality=2, threads=8))
+
+
+def test_gpu_packed_uncompressed_texture_in_dds_and_pvr(tmp_path):
+    """Texture.convert to an uncompressed format (csrc/std_pack.hip) -> DDS -> Pillow."""
+    PIL = pytest.importorskip("PIL.Image")
+    base = synth.photo(96, 64, seed=12)
+    f = base.astype(np.float32)/np.float32(255.0)
+    t = Texture(96, 64)
+    assert t.set_image(f)
+    assert not t.convert(Format.R5G6B5, Type.Float)            # createConverter -> nullptr
+    assert t.convert(Format.R8G8B8A8, Type.UNorm)
+    assert t.data_size() == 96*64*4
+    payload = np.asarray(t.data()).copy()
+    assert np.array_equal(payload.reshape(64, 96, 4), base)     # u8 -> float -> UNorm8 round trip
+    buf = io.BytesIO()
+    C.write_dds(buf, Format.R8G8B8A8, Type.UNorm, 96, 64, [payload])
+    got = np.asarray(PIL.open(io.BytesIO(buf.getvalue())).convert("RGBA"))
+    assert np.array_equal(got, base)
+    buf = io.BytesIO()
+    C.write_pvr(buf, Format.R8G8B8A8, Type.UNorm, 96, 64, [payload])
+    h = C.read_pvr(buf.getvalue())
+    assert buf.getvalue()[h["offset"]:] == payload.tobytes() and h["channel_type"] == 0
