@@ -118,6 +118,36 @@ __device__ __forceinline__ uint32_t cf_xor2(uint32_t v) { return cf_dpp<0x4E>(v)
 __device__ __forceinline__ float cf_xor1f(float v) { return __uint_as_float(cf_dpp<0xB1>(__float_as_uint(v))); }
 __device__ __forceinline__ float cf_xor2f(float v) { return __uint_as_float(cf_dpp<0x4E>(__float_as_uint(v))); }
 
+// Sum over the 16 lanes of each DPP row; every lane of the row gets the row's sum (all lanes
+// active).  With texel (lane & 15) in every row, all four rows hold the same, block-wide sum.
+__device__ __forceinline__ uint32_t cf_row_sum_u32(uint32_t v)
+{
+	v += cf_dpp<0xB1>(v);
+	v += cf_dpp<0x4E>(v);
+	v += cf_dpp<0x141>(v);
+	v += cf_dpp<0x140>(v);
+	return v;
+}
+
+// cf_row_sum_u32 when the four rows hold the same data: the block-wide sum as a wave-uniform
+// (scalar register) value, so what is computed from it stays off the vector registers
+__device__ __forceinline__ uint32_t cf_row_sum_uniform(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_readfirstlane((int)cf_row_sum_u32(v));
+}
+
+// floor(num/den) for num < 2^22, den > 0: reciprocal estimate + exact fix-up (a full 32-bit
+// integer division is ~35 VALU instructions and these kernels are issue-bound)
+__device__ __forceinline__ uint32_t cf_div_small(uint32_t num, uint32_t den)
+{
+	uint32_t q = (uint32_t)((float)num*__builtin_amdgcn_rcpf((float)den));
+	int r = (int)num - (int)(q*den);
+	q = r < 0 ? q - 1u : q;
+	r = r < 0 ? r + (int)den : r;
+	q = r >= (int)den ? q + 1u : q;
+	return q;
+}
+
 // wave64 minimum of a 32-bit key, uniform result (all 64 lanes must be active)
 __device__ __forceinline__ uint32_t cf_wave_min_u32(uint32_t k)
 {

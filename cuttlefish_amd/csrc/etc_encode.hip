@@ -46,6 +46,7 @@ struct RgbOpts {
 	uint32_t active, transparent;
 	int wt[3];
 	int radius;
+	bool refine;   // false: Lowest -- no planar move rounds, no T/H modes
 };
 
 __device__ __forceinline__ uint32_t half_mask(uint32_t flip, uint32_t sub)
@@ -191,6 +192,26 @@ __device__ __forceinline__ uint32_t planar_err(const uint32_t* tp, const RgbOpts
 	return e;
 }
 
+// planar_err with one texel per lane (texel lane & 15 in every DPP row): same sum, every lane
+// gets it (all 64 lanes active)
+__device__ __forceinline__ uint32_t planar_err_rows(const uint32_t* tp, const RgbOpts& o, const PlanarQ& q,
+	uint32_t lane)
+{
+	const uint32_t ti = lane & 15u;
+	const int x = (int)(ti & 3u), y = (int)(ti >> 2);
+	const uint32_t p = tp[ti];
+	uint32_t e = 0;
+#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		const int O = c == 1 ? ex7(q.O[c]) : ex6(q.O[c]), H = c == 1 ? ex7(q.H[c]) : ex6(q.H[c]),
+			V = c == 1 ? ex7(q.V[c]) : ex6(q.V[c]);
+		const int v = clamp255((x*(H - O) + y*(V - O) + 4*O + 2) >> 2);
+		const int d = v - (int)((p >> (8*c)) & 255u);
+		e += (uint32_t)(o.wt[c]*d*d);
+	}
+	return cf_row_sum_u32(((o.active >> ti) & 1u) ? e : 0u);
+}
+
 // add d to field f (0..8 = O.rgb, H.rgb, V.rgb) without dynamic register indexing;
 // returns false when the field would leave its range
 __device__ __forceinline__ bool planar_move(PlanarQ& q, int f, int d)
@@ -334,33 +355,27 @@ template <bool UNITW>
 __device__ __forceinline__ bool th_search(const uint32_t* tp, const RgbOpts& o, int rounds, uint32_t lane,
 	ThCand& best)
 {
-	int n = 0, sum[3] = {0, 0, 0};
-	uint32_t pp = 0;
-#pragma unroll 2
-	for (uint32_t i = 0; i < 16u; ++i) {
-		const uint32_t p = tp[i];
-		const bool a = (o.active >> i) & 1u;
-		const int p0 = (int)(p & 255u), p1 = (int)((p >> 8) & 255u), p2 = (int)((p >> 16) & 255u);
-		n += a ? 1 : 0;
-		sum[0] += a ? p0 : 0; sum[1] += a ? p1 : 0; sum[2] += a ? p2 : 0;
-		pp += a ? (uint32_t)(o.wt[0]*p0*p0 + o.wt[1]*p1*p1 + o.wt[2]*p2*p2) : 0u;
-	}
+	// block statistics with one texel per lane (texel lane & 15 in every DPP row): packed
+	// integer sums reduced inside the row, so every lane ends up with the block-wide values
+	const uint32_t ti = lane & 15u;
+	const uint32_t px = tp[ti];
+	const bool act = (o.active >> ti) & 1u;
+	const int p0 = (int)(px & 255u), p1 = (int)((px >> 8) & 255u), p2 = (int)((px >> 16) & 255u);
+	const uint32_t w01 = cf_row_sum_uniform(act ? (uint32_t)p0 | ((uint32_t)p1 << 16) : 0u);
+	const uint32_t w2n = cf_row_sum_uniform(act ? (uint32_t)p2 | (1u << 16) : 0u);
+	const uint32_t pp = cf_row_sum_uniform(act ? (uint32_t)(o.wt[0]*p0*p0 + o.wt[1]*p1*p1 + o.wt[2]*p2*p2) : 0u);
+	const int n = (int)(w2n >> 16);
+	const int sum[3] = {(int)(w01 & 0xFFFFu), (int)(w01 >> 16), (int)(w2n & 0xFFFFu)};
 	if (n < 2)
 		return false;
 	int mean[3];
 #pragma unroll
 	for (int c = 0; c < 3; ++c)
-		mean[c] = (2*sum[c] + n)/(2*n);
-	int c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
-#pragma unroll 2
-	for (uint32_t i = 0; i < 16u; ++i) {
-		if ((o.active >> i) & 1u) {
-			const uint32_t p = tp[i];
-			const int d0 = (int)(p & 255u) - mean[0], d1 = (int)((p >> 8) & 255u) - mean[1],
-				d2 = (int)((p >> 16) & 255u) - mean[2];
-			c00 += d0*d0; c01 += d0*d1; c02 += d0*d2; c11 += d1*d1; c12 += d1*d2; c22 += d2*d2;
-		}
-	}
+		mean[c] = (int)cf_div_small((uint32_t)(2*sum[c] + n), (uint32_t)(2*n));
+	const int d0 = act ? p0 - mean[0] : 0, d1 = act ? p1 - mean[1] : 0, d2 = act ? p2 - mean[2] : 0;
+	const int c00 = (int)cf_row_sum_uniform((uint32_t)(d0*d0)), c01 = (int)cf_row_sum_uniform((uint32_t)(d0*d1)),
+		c02 = (int)cf_row_sum_uniform((uint32_t)(d0*d2)), c11 = (int)cf_row_sum_uniform((uint32_t)(d1*d1)),
+		c12 = (int)cf_row_sum_uniform((uint32_t)(d1*d2)), c22 = (int)cf_row_sum_uniform((uint32_t)(d2*d2));
 	int k = 0, vk = c00;
 	if (c11 > vk) { k = 1; vk = c11; }
 	if (c22 > vk) { k = 2; vk = c22; }
@@ -368,26 +383,20 @@ __device__ __forceinline__ bool th_search(const uint32_t* tp, const RgbOpts& o, 
 		return false;
 	const int a0 = k == 0 ? c00 : (k == 1 ? c01 : c02), a1 = k == 0 ? c01 : (k == 1 ? c11 : c12),
 		a2 = k == 0 ? c02 : (k == 1 ? c12 : c22);
-	int n1 = 0, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
-#pragma unroll 2
-	for (uint32_t i = 0; i < 16u; ++i) {
-		if ((o.active >> i) & 1u) {
-			const uint32_t p = tp[i];
-			const int p0 = (int)(p & 255u), p1 = (int)((p >> 8) & 255u), p2 = (int)((p >> 16) & 255u);
-			const int t = a0*(p0 - mean[0]) + a1*(p1 - mean[1]) + a2*(p2 - mean[2]);
-			const bool hi = t >= 0;
-			n1 += hi ? 1 : 0;
-			s1[0] += hi ? p0 : 0; s1[1] += hi ? p1 : 0; s1[2] += hi ? p2 : 0;
-			s0[0] += hi ? 0 : p0; s0[1] += hi ? 0 : p1; s0[2] += hi ? 0 : p2;
-		}
-	}
+	const bool hi = act && a0*d0 + a1*d1 + a2*d2 >= 0;
+	const uint32_t h01 = cf_row_sum_uniform(hi ? (uint32_t)p0 | ((uint32_t)p1 << 16) : 0u);
+	const uint32_t h2n = cf_row_sum_uniform(hi ? (uint32_t)p2 | (1u << 16) : 0u);
+	const int n1 = (int)(h2n >> 16);
+	const int s1[3] = {(int)(h01 & 0xFFFFu), (int)(h01 >> 16), (int)(h2n & 0xFFFFu)};
+	const int s0[3] = {sum[0] - s1[0], sum[1] - s1[1], sum[2] - s1[2]};
 	const int n0 = n - n1;
 	if (!n0 || !n1)
 		return false;
 	uint32_t m0 = 0, m1 = 0;
 #pragma unroll
 	for (int c = 0; c < 3; ++c) {
-		const int a = (2*s0[c] + n0)/(2*n0), b = (2*s1[c] + n1)/(2*n1);
+		const int a = (int)cf_div_small((uint32_t)(2*s0[c] + n0), (uint32_t)(2*n0)),
+			b = (int)cf_div_small((uint32_t)(2*s1[c] + n1), (uint32_t)(2*n1));
 		m0 |= (uint32_t)((a*15 + 127)/255) << (4*c);
 		m1 |= (uint32_t)((b*15 + 127)/255) << (4*c);
 	}
@@ -516,7 +525,7 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 	int q0[3];
 #pragma unroll
 	for (int c = 0; c < 3; ++c) {
-		const int mean = n ? (2*sum[c] + n)/(2*n) : 0;
+		const int mean = n ? (int)cf_div_small((uint32_t)(2*sum[c] + n), (uint32_t)(2*n)) : 0;
 		q0[c] = (mean*maxq + 127)/255;
 	}
 	uint32_t berr = 0xFFFFFFFFu, bcand = 0, bq = 0, dummy = 0;
@@ -599,22 +608,26 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 	if (o.allow_planar && !o.punch) {
 		// closed-form least squares on the 4x4 grid (uniform), then 2 rounds of moves
 		PlanarQ pq;
+		{
+			// sums over the 16 texels, one texel per lane: S | Sx << 16 in one word (the low field
+			// never borrows, so the signed high field is exact), Sy in another
+			const uint32_t ti = lane & 15u;
+			const int x = (int)(ti & 3u), y = (int)(ti >> 2);
+			const uint32_t p = tp[ti];
 #pragma unroll
-		for (int c = 0; c < 3; ++c) {
-			int S = 0, Sx = 0, Sy = 0;
-#pragma unroll 1
-			for (uint32_t i = 0; i < 16u; ++i) {
-				const int x = (int)(i & 3u), y = (int)(i >> 2);
-				const int v = (int)((tp[i] >> (8*c)) & 255u);
-				S += v; Sx += (2*x - 3)*v; Sy += (2*y - 3)*v;
+			for (int c = 0; c < 3; ++c) {
+				const int v = (int)((p >> (8*c)) & 255u);
+				const int ssx = (int)cf_row_sum_uniform((uint32_t)(v + (((2*x - 3)*v) << 16)));
+				const int S = ssx & 0xFFFF, Sx = ssx >> 16;
+				const int Sy = (int)cf_row_sum_uniform((uint32_t)((2*y - 3)*v));
+				const int mq = c == 1 ? 127 : 63;
+				pq.O[c] = (clampi(5*S - 3*Sx - 3*Sy, 0, 255*80)*mq + 10200)/20400;
+				pq.H[c] = (clampi(5*S + 5*Sx - 3*Sy, 0, 255*80)*mq + 10200)/20400;
+				pq.V[c] = (clampi(5*S - 3*Sx + 5*Sy, 0, 255*80)*mq + 10200)/20400;
 			}
-			const int mq = c == 1 ? 127 : 63;
-			pq.O[c] = (clampi(5*S - 3*Sx - 3*Sy, 0, 255*80)*mq + 10200)/20400;
-			pq.H[c] = (clampi(5*S + 5*Sx - 3*Sy, 0, 255*80)*mq + 10200)/20400;
-			pq.V[c] = (clampi(5*S - 3*Sx + 5*Sy, 0, 255*80)*mq + 10200)/20400;
 		}
-		uint32_t ep = planar_err(tp, o, pq);
-		for (int round = 0; round < 2; ++round) {
+		uint32_t ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)planar_err_rows(tp, o, pq, lane));
+		for (int round = 0; round < (o.refine ? 2 : 0); ++round) {
 			unsigned long long mk = ~0ull;
 			if (lane < 18u) {
 				const int f = (int)(lane >> 1), d = (lane & 1u) ? 1 : -1;
@@ -636,8 +649,10 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 		}
 		// ETC2 T / H modes (ids after planar)
 		ThCand th;
-		const bool have_th = unitw ? th_search<true>(tp, o, o.radius, lane, th)
-			: th_search<false>(tp, o, o.radius, lane, th);
+		bool have_th = false;
+		if (o.refine)
+			have_th = unitw ? th_search<true>(tp, o, o.radius, lane, th)
+				: th_search<false>(tp, o, o.radius, lane, th);
 		if (have_th && th.err < best_err)
 			return unitw ? pack_th<true>(tp, o, th, lane) : pack_th<false>(tp, o, th, lane);
 		if (use_planar)
@@ -653,18 +668,40 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 		qa = bf ? hq[6] : hq[4]; qb = bf ? hq[7] : hq[5];
 		ta = bf ? ht[6] : ht[4]; tb = bf ? ht[7] : ht[5];
 	}
-	uint32_t sel = 0;
+	// selectors: lane L < 16 owns the texel whose bits sit at position k = L of the two
+	// selector planes (x = k >> 2, y = k & 3); the planes come out of two ballots
+	uint32_t lo;
 	{
-		const int ca[3] = {differential ? ex5((int)(qa & 255u)) : ex4((int)(qa & 255u)),
-			differential ? ex5((int)((qa >> 8) & 255u)) : ex4((int)((qa >> 8) & 255u)),
-			differential ? ex5((int)((qa >> 16) & 255u)) : ex4((int)((qa >> 16) & 255u))};
-		const int cb[3] = {differential ? ex5((int)(qb & 255u)) : ex4((int)(qb & 255u)),
-			differential ? ex5((int)((qb >> 8) & 255u)) : ex4((int)((qb >> 8) & 255u)),
-			differential ? ex5((int)((qb >> 16) & 255u)) : ex4((int)((qb >> 16) & 255u))};
-		half_err<true>(tp, o, half_mask(bf, 0u), ca, (int)ta, sel);
-		half_err<true>(tp, o, half_mask(bf, 1u), cb, (int)tb, sel);
+		const uint32_t k = lane & 15u, i = (k & 3u)*4u + (k >> 2);
+		const uint32_t sub = bf ? (i >> 3) : ((i >> 1) & 1u);
+		const uint32_t q = sub ? qb : qa, tt = sub ? tb : ta;
+		int c[3];
+#pragma unroll
+		for (int ch = 0; ch < 3; ++ch) {
+			const int v = (int)((q >> (8*ch)) & 255u);
+			c[ch] = differential ? ex5(v) : ex4(v);
+		}
+		const int ma = o.punch ? 0 : k_etc_mod[tt][0], mb = k_etc_mod[tt][1];
+		const uint32_t p = tp[i];
+		const int p0 = (int)(p & 255u), p1 = (int)((p >> 8) & 255u), p2 = (int)((p >> 16) & 255u);
+		uint32_t best = 0xFFFFFFFFu, bv = 0;
+#pragma unroll
+		for (int v = 0; v < 4; ++v) {
+			const int m = v == 0 ? ma : (v == 1 ? mb : (v == 2 ? -ma : -mb));
+			const int d0 = clamp255(c[0] + m) - p0, d1 = clamp255(c[1] + m) - p1,
+				d2 = clamp255(c[2] + m) - p2;
+			uint32_t e = (uint32_t)(o.wt[0]*d0*d0) + (uint32_t)(o.wt[1]*d1*d1) +
+				(uint32_t)(o.wt[2]*d2*d2);
+			if (v == 2 && o.punch)
+				e = 0xFFFFFFFFu;   // selector 2 is the transparent one
+			if (e < best) { best = e; bv = (uint32_t)v; }
+		}
+		const uint32_t sv = ((o.transparent >> i) & 1u) ? 2u : bv;
+		const uint32_t lsb = (uint32_t)__ballot(lane < 16u && (sv & 1u)) & 0xFFFFu;
+		const uint32_t msb = (uint32_t)__ballot(lane < 16u && (sv >> 1)) & 0xFFFFu;
+		lo = (msb << 16) | lsb;
 	}
-	uint32_t hi = 0, lo = 0;
+	uint32_t hi = 0;
 #pragma unroll
 	for (int c = 0; c < 3; ++c) {
 		const uint32_t a = (qa >> (8*c)) & 255u, b = (qb >> (8*c)) & 255u;
@@ -675,11 +712,6 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 	}
 	const uint32_t diff_bit = o.a1 ? (o.punch ? 0u : 1u) : (differential ? 1u : 0u);
 	hi |= (ta << 5) | (tb << 2) | (diff_bit << 1) | bf;
-#pragma unroll 1
-	for (uint32_t i = 0; i < 16u; ++i) {
-		const uint32_t x = i & 3u, y = i >> 2, k = x*4u + y, s = (sel >> (2u*i)) & 3u;
-		lo |= ((s >> 1) << (16u + k)) | ((s & 1u) << k);
-	}
 	return make_uint2(bswap32(hi), bswap32(lo));
 }
 
@@ -857,7 +889,8 @@ cfhip_etc_encode_kernel(cf_kparams kp)
 		o.allow_indiv = false; o.allow_planar = false; o.punch = false; o.a1 = false;
 		o.active = valid; o.transparent = 0;
 		o.wt[0] = (int)kp.wt[0]; o.wt[1] = (int)kp.wt[1]; o.wt[2] = (int)kp.wt[2];
-		o.radius = q >= 3u ? 2 : 1;
+		o.radius = q >= 3u ? 2 : (q == 2u ? 1 : 0);   // effort ladder, see oracle/etc_codec.c
+		o.refine = q >= 1u;
 		uint2 w0 = make_uint2(0, 0), w1 = make_uint2(0, 0);
 		if (FMT == E_ETC1) {
 			o.allow_indiv = true;

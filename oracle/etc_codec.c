@@ -209,6 +209,7 @@ typedef struct {
 	unsigned transparent; /* A1: texels that must decode transparent */
 	int wt[3];
 	int radius;
+	int refine;           /* 0: Lowest -- no planar move rounds, no T/H modes */
 } rgb_opts;
 
 typedef struct { uint32_t err; int q[3], table; } half_best;
@@ -347,7 +348,7 @@ static uint32_t planar_fit(const int px[16][4], const rgb_opts* o, planar_q* bes
 	uint32_t err = planar_err(px, o, best);
 	/* two rounds: evaluate the 18 single-field +-1 moves (id = field*2 + (d > 0)) from the
 	 * current fit, apply the best one if it is a strict improvement (lane-parallel form) */
-	for (int round = 0; round < 2; ++round) {
+	for (int round = 0; round < (o->refine ? 2 : 0); ++round) {
 		uint32_t be = err;
 		int bid = -1;
 		planar_q bq = *best;
@@ -705,7 +706,7 @@ void cfo_etc_rgb_search(const int px[16][4], const rgb_opts* o, uint8_t out[8])
 			use_planar = 1;
 		}
 	}
-	if (o->allow_planar && !o->punch) {   /* ETC2: T / H modes, ids after planar */
+	if (o->allow_planar && !o->punch && o->refine) {   /* ETC2: T / H modes, ids after planar */
 		th_cand th;
 		if (th_search(px, o, o->radius, &th) && th.err < best_err) {
 			pack_th(&th, px, o, out);
@@ -808,8 +809,10 @@ void cfo_eac_search(const int v[16], int kind, unsigned active, int R, uint8_t o
 
 static int effort_radius(int quality)
 {
-	/* stands in for etc2comp's effort ladder (EtcConverter.cpp:34-54) */
-	return quality >= 3 ? 2 : 1;
+	/* stands in for etc2comp's effort ladder (EtcConverter.cpp:34-54): base colours within
+	 * `radius` quantisation steps of each half's mean -- 1 / 1 / 27 / 125 / 125 per half and table
+	 * for Lowest .. Highest; Lowest also drops the planar refinement and the T/H modes */
+	return quality >= 3 ? 2 : (quality == 2 ? 1 : 0);
 }
 
 /* rgbaf: 16 texels float RGBA row-major (edge-replicated), rgba: the same as u8,
@@ -828,6 +831,7 @@ int cfo_encode_etc_block(const float rgbaf[64], const uint8_t rgba[64], unsigned
 	memcpy(o.wt, p->color_space == 1 ? rec709 : lin, sizeof(o.wt));
 	o.active = valid;
 	o.radius = effort_radius(p->quality);
+	o.refine = p->quality >= 1;
 	int R = p->quality <= 1 ? 1 : (p->quality == 2 ? 2 : 4);
 	switch (p->format) {
 		case FMT_ETC1:
