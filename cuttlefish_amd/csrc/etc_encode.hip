@@ -731,9 +731,34 @@ __device__ __forceinline__ int eac_decode(int kind, int base, int m, int mult)
 	return clampi(base*8 + m*mult*8, -1023, 1023);
 }
 
-__device__ __forceinline__ uint2 eac_search(const uint32_t* tp, int kind, int ch, uint32_t active,
-	int R, uint32_t lane)
+// pre: 256 words of wave-private LDS, used for kind 0 (8-bit values) only: the block's prefix
+// table pre[x] = (number of active texels <= x) << 16 | (sum of those texels).  The eight
+// decoded values of a candidate are monotone in the order k = 3,2,1,0,4,5,6,7 (every modifier
+// table is four descending negatives then four ascending non-negatives, and clamping keeps the
+// order), so the midpoints between neighbours cut the value axis into the texels each entry
+// wins and error = sum v^2 + sum_k q_k (n_k q_k - 2 s_k) exactly -- 7 table lookups per
+// candidate instead of 16 texels x 8 entries (the scheme of bc4_search in bc15_encode.hip).
+__device__ __forceinline__ uint2 eac_search(const uint32_t* tp, uint32_t* pre, int kind, int ch,
+	uint32_t active, int R, uint32_t lane)
 {
+	uint32_t sum2 = 0, all = 0;
+	if (kind == 0) {
+		uint32_t acc[4] = {0u, 0u, 0u, 0u};
+		const uint32_t x0 = lane*4u;
+#pragma unroll 1
+		for (uint32_t i = 0; i < 16u; ++i) {
+			const uint32_t uv = (tp[i] >> (8*ch)) & 255u;
+			const bool a = (active >> i) & 1u;
+			const uint32_t w = a ? (0x10000u | uv) : 0u;
+			sum2 += a ? uv*uv : 0u;
+#pragma unroll
+			for (uint32_t e = 0; e < 4u; ++e)
+				acc[e] += uv <= x0 + e ? w : 0u;
+		}
+		*reinterpret_cast<uint4*>(pre + x0) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+		__builtin_amdgcn_wave_barrier();
+		all = pre[255];
+	}
 	int lo = 1 << 30, hi = -(1 << 30);
 #pragma unroll 1
 	for (uint32_t i = 0; i < 16u; ++i) {
@@ -770,17 +795,32 @@ __device__ __forceinline__ uint2 eac_search(const uint32_t* tp, int kind, int ch
 			for (int k = 0; k < 8; ++k)
 				dec[k] = eac_decode(kind, base, mods[k], mult);
 			uint32_t err = 0;
-#pragma unroll 4
-			for (uint32_t i = 0; i < 16u; ++i) {
-				const int v = eac_value(tp, i, kind, ch);
-				uint32_t be = 0xFFFFFFFFu;
+			if (kind == 0) {
+				const int q[8] = {dec[3], dec[2], dec[1], dec[0], dec[4], dec[5], dec[6], dec[7]};
+				int e = (int)sum2;
+				uint32_t below = 0u;
 #pragma unroll
 				for (int k = 0; k < 8; ++k) {
-					const int d = dec[k] - v;
-					const uint32_t e = (uint32_t)(d*d);
-					be = e < be ? e : be;
+					const uint32_t upto = k < 7 ? pre[(uint32_t)(q[k] + q[k < 7 ? k + 1 : 7]) >> 1] : all;
+					const uint32_t seg = upto - below;   // n << 16 | s
+					below = upto;
+					const int n = (int)(seg >> 16), sk = (int)(seg & 0xFFFFu);
+					e += q[k]*(n*q[k] - 2*sk);
 				}
-				err += ((active >> i) & 1u) ? be : 0u;
+				err = (uint32_t)e;
+			} else {
+#pragma unroll 4
+				for (uint32_t i = 0; i < 16u; ++i) {
+					const int v = eac_value(tp, i, kind, ch);
+					uint32_t be = 0xFFFFFFFFu;
+#pragma unroll
+					for (int k = 0; k < 8; ++k) {
+						const int d = dec[k] - v;
+						const uint32_t e = (uint32_t)(d*d);
+						be = e < be ? e : be;
+					}
+					err += ((active >> i) & 1u) ? be : 0u;
+				}
 			}
 			if (err < berr) { berr = err; bbase = base; bdb = db + R; }
 		}
@@ -842,6 +882,8 @@ cfhip_etc_encode_kernel(cf_kparams kp)
 	constexpr uint32_t BYTES = (FMT == E_A8 || FMT == E_RG11) ? 16u : 8u;
 	__shared__ uint32_t tile[CF_BLOCKS_PER_WG*16];
 	__shared__ uint32_t outb[CF_BLOCKS_PER_WG*4];
+	// ETC2 RGBA8: one 256-entry prefix table per wavefront for the 8-bit alpha search
+	__shared__ __attribute__((aligned(16))) uint32_t pre_tab[FMT == E_A8 ? (CF_WG_THREADS/64)*256 : 4];
 	uint32_t gx_, gy_;
 	cf_resolve(kp, gx_, gy_);
 	const uint32_t bx0 = gx_*CF_BLOCKS_PER_WG;
@@ -872,6 +914,7 @@ cfhip_etc_encode_kernel(cf_kparams kp)
 	__syncthreads();
 
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	uint32_t* pre = pre_tab + (FMT == E_A8 ? wave*256u : 0u);
 	const uint32_t q = kp.quality;
 	const int R = q <= 1u ? 1 : (q == 2u ? 2 : 4);
 	for (uint32_t j = 0; j < 4u; ++j) {
@@ -905,13 +948,13 @@ cfhip_etc_encode_kernel(cf_kparams kp)
 			o.allow_planar = true;
 			w0 = rgb_search(tp, o, lane);
 		} else if (FMT == E_A8) {
-			w0 = eac_search(tp, 0, 3, valid, R, lane);
+			w0 = eac_search(tp, pre, 0, 3, valid, R, lane);
 			o.allow_indiv = true; o.allow_planar = true;
 			w1 = rgb_search(tp, o, lane);
 		} else {
-			w0 = eac_search(tp, SNORM ? 2 : 1, 0, valid, R, lane);
+			w0 = eac_search(tp, pre, SNORM ? 2 : 1, 0, valid, R, lane);
 			if (FMT == E_RG11)
-				w1 = eac_search(tp, SNORM ? 2 : 1, 1, valid, R, lane);
+				w1 = eac_search(tp, pre, SNORM ? 2 : 1, 1, valid, R, lane);
 		}
 		if (lane == 0u) {
 			if (BYTES == 8u) {
