@@ -188,6 +188,7 @@ struct COpts {
 	uint32_t wt[3];
 	uint32_t active;   // bit i: texel i takes part
 	uint32_t rounds;
+	uint32_t pp;       // sum over the active texels of r^2 + g^2 + b^2 (set by bc1_search)
 };
 
 __device__ __forceinline__ uint32_t expand565(uint32_t c)
@@ -269,12 +270,66 @@ __device__ __forceinline__ uint32_t bc1_error(const uint32_t* tp, const COpts& o
 	return err;
 }
 
+// Both orders of one endpoint pair in ONE pass over the texels (unit weights, BC1 proper): the
+// 4-colour palette {hi, lo, (2hi+lo)/3, (hi+2lo)/3} and the 3-colour palette {lo, hi, (lo+hi)/2
+// [, black]} share their two endpoints, so five dot products per texel serve both.  Distances in
+// max form: |p - q|^2 = |p|^2 - (2 p.q - |q|^2), the sum of |p|^2 over the block is o.pp.
+__device__ __forceinline__ void bc1_error_both(const uint32_t* tp, const COpts& o, uint32_t a, uint32_t b,
+	uint32_t& err4, uint32_t& err3)
+{
+	const uint32_t chi = a > b ? a : b, clo = a > b ? b : a;
+	const uint32_t eh = expand565(chi), el = expand565(clo);
+	uint32_t p2 = 0, p3 = 0, pm = 0;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		const uint32_t x = ub(eh, k), y = ub(el, k);
+		p2 |= div3(2u*x + y) << (8*k);
+		p3 |= div3(x + 2u*y) << (8*k);
+		pm |= ((x + y) >> 1) << (8*k);
+	}
+	const int nh = -(int)__builtin_amdgcn_udot4(eh, eh, 0u, false), nl = -(int)__builtin_amdgcn_udot4(el, el, 0u, false),
+		n2 = -(int)__builtin_amdgcn_udot4(p2, p2, 0u, false), n3 = -(int)__builtin_amdgcn_udot4(p3, p3, 0u, false),
+		nm = -(int)__builtin_amdgcn_udot4(pm, pm, 0u, false);
+	int acc4 = 0, acc3 = 0;
+#pragma unroll 1
+	for (uint32_t i = 0; i < 16u; ++i) {
+		const uint32_t p = tp[i] & 0x00FFFFFFu;
+		const int kh = (int)(__builtin_amdgcn_udot4(p, eh, 0u, false) << 1) + nh;
+		const int kl = (int)(__builtin_amdgcn_udot4(p, el, 0u, false) << 1) + nl;
+		const int k2 = (int)(__builtin_amdgcn_udot4(p, p2, 0u, false) << 1) + n2;
+		const int k3 = (int)(__builtin_amdgcn_udot4(p, p3, 0u, false) << 1) + n3;
+		const int km = (int)(__builtin_amdgcn_udot4(p, pm, 0u, false) << 1) + nm;
+		const int m01 = kh > kl ? kh : kl;
+		int m4 = m01 > k2 ? m01 : k2;
+		m4 = m4 > k3 ? m4 : k3;
+		int m3 = m01 > km ? m01 : km;
+		m3 = (o.black && m3 < 0) ? 0 : m3;   // black: q = 0, 2 p.q - |q|^2 = 0
+		const bool act = (o.active >> i) & 1u;
+		acc4 += act ? m4 : 0;
+		acc3 += act ? m3 : 0;
+	}
+	err4 = (chi == clo && !o.force4) ? 0xFFFFFFFFu : o.pp - (uint32_t)acc4;
+	err3 = o.pp - (uint32_t)acc3;
+}
+
 struct CBest { uint32_t err, id, a, b, mode3; };
 
 template <bool UNITW>
 __device__ __forceinline__ void consider(const uint32_t* tp, const COpts& o, uint32_t a, uint32_t b,
 	uint32_t idbase, CBest& best)
 {
+	if (UNITW && o.allow3 == 1u) {
+		uint32_t e[2];
+		bc1_error_both(tp, o, a, b, e[0], e[1]);
+#pragma unroll
+		for (uint32_t mode3 = 0; mode3 < 2u; ++mode3) {
+			const uint32_t id = idbase + mode3;
+			if (e[mode3] < best.err || (e[mode3] == best.err && id < best.id)) {
+				best.err = e[mode3]; best.id = id; best.a = a; best.b = b; best.mode3 = mode3;
+			}
+		}
+		return;
+	}
 #pragma unroll
 	for (uint32_t mode3 = 0; mode3 < 2u; ++mode3) {
 		if (mode3 && !o.allow3)
@@ -326,26 +381,34 @@ __device__ __forceinline__ void move565(uint32_t m, uint32_t a, uint32_t b, uint
 
 // Returns the 8-byte colour block in every lane.
 template <bool UNITW>
-__device__ __forceinline__ uint2 bc1_search(const uint32_t* tp, const COpts& o, uint32_t lane)
+__device__ __forceinline__ uint2 bc1_search(const uint32_t* tp, const COpts& o_in, uint32_t lane)
 {
-	if (!o.active)
+	if (!o_in.active)
 		return make_uint2(0u, 0xFFFFFFFFu);
-	// bounding box + covariance signs against the channel of largest range
-	int n = 0, mn[3] = {255, 255, 255}, mx[3] = {0, 0, 0}, s[3] = {0, 0, 0};
-	int s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0;
-#pragma unroll 1
-	for (uint32_t i = 0; i < 16u; ++i) {
-		const uint32_t p = tp[i];
-		if ((o.active >> i) & 1u) {
-			const int r = (int)ub(p, 0), g = (int)ub(p, 1), b = (int)ub(p, 2);
-			++n;
-			mn[0] = r < mn[0] ? r : mn[0]; mx[0] = r > mx[0] ? r : mx[0];
-			mn[1] = g < mn[1] ? g : mn[1]; mx[1] = g > mx[1] ? g : mx[1];
-			mn[2] = b < mn[2] ? b : mn[2]; mx[2] = b > mx[2] ? b : mx[2];
-			s[0] += r; s[1] += g; s[2] += b;
-			s00 += r*r; s01 += r*g; s02 += r*b; s11 += g*g; s12 += g*b; s22 += b*b;
-		}
+	// bounding box + covariance signs against the channel of largest range: one texel per lane
+	// (texel lane & 15 in every DPP row), row reductions, results in scalar registers
+	COpts o = o_in;
+	const int n = __popc(o.active);
+	int mn[3], mx[3], s[3];
+	int s00, s01, s02, s11, s12, s22;
+	{
+		const uint32_t ti = lane & 15u, p = tp[ti];
+		const bool act = (o.active >> ti) & 1u;
+		const uint32_t r = ub(p, 0), g = ub(p, 1), b = ub(p, 2);
+		mn[0] = __builtin_amdgcn_readfirstlane((int)cf_row_min_u32(act ? r : 255u));
+		mn[1] = __builtin_amdgcn_readfirstlane((int)cf_row_min_u32(act ? g : 255u));
+		mn[2] = __builtin_amdgcn_readfirstlane((int)cf_row_min_u32(act ? b : 255u));
+		mx[0] = __builtin_amdgcn_readfirstlane((int)cf_row_max_u32(act ? r : 0u));
+		mx[1] = __builtin_amdgcn_readfirstlane((int)cf_row_max_u32(act ? g : 0u));
+		mx[2] = __builtin_amdgcn_readfirstlane((int)cf_row_max_u32(act ? b : 0u));
+		const uint32_t srg = cf_row_sum_uniform(act ? r | (g << 16) : 0u);
+		s[0] = (int)(srg & 0xFFFFu); s[1] = (int)(srg >> 16);
+		s[2] = (int)cf_row_sum_uniform(act ? b : 0u);
+		s00 = (int)cf_row_sum_uniform(act ? r*r : 0u); s01 = (int)cf_row_sum_uniform(act ? r*g : 0u);
+		s02 = (int)cf_row_sum_uniform(act ? r*b : 0u); s11 = (int)cf_row_sum_uniform(act ? g*g : 0u);
+		s12 = (int)cf_row_sum_uniform(act ? g*b : 0u); s22 = (int)cf_row_sum_uniform(act ? b*b : 0u);
 	}
+	o.pp = (uint32_t)(s00 + s11 + s22);
 	int ref = 0;
 	if (mx[1] - mn[1] > mx[0] - mn[0]) ref = 1;
 	if (mx[2] - mn[2] > mx[ref == 1 ? 1 : 0] - mn[ref == 1 ? 1 : 0]) ref = 2;
@@ -414,10 +477,10 @@ __device__ __forceinline__ uint2 bc1_search(const uint32_t* tp, const COpts& o, 
 	const uint32_t c0 = mode3 ? (cur.a < cur.b ? cur.a : cur.b) : (cur.a > cur.b ? cur.a : cur.b);
 	const uint32_t c1 = mode3 ? (cur.a < cur.b ? cur.b : cur.a) : (cur.a > cur.b ? cur.b : cur.a);
 	const uint32_t np = mode3 ? (o.black ? 4u : 3u) : 4u;
-	uint32_t sel = 0;
-#pragma unroll 1
-	for (uint32_t i = 0; i < 16u; ++i) {
-		const uint32_t p = tp[i] & 0x00FFFFFFu;
+	// selectors: lane i < 16 owns texel i (two bits at 2i), the word is the OR over the lanes
+	uint32_t sel;
+	{
+		const uint32_t i = lane & 15u, p = tp[i] & 0x00FFFFFFu;
 		uint32_t bk = 3u;
 		if ((o.active >> i) & 1u) {
 			uint32_t bd = 0xFFFFFFFFu;
@@ -429,7 +492,7 @@ __device__ __forceinline__ uint2 bc1_search(const uint32_t* tp, const COpts& o, 
 				}
 			}
 		}
-		sel |= bk << (2u*i);
+		sel = cf_wave_or_u32(lane < 16u ? bk << (2u*i) : 0u);
 	}
 	return make_uint2(c0 | (c1 << 16), sel);
 }

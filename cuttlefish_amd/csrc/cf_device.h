@@ -129,6 +129,26 @@ __device__ __forceinline__ uint32_t cf_row_sum_u32(uint32_t v)
 	return v;
 }
 
+// minimum / maximum over the 16 lanes of each DPP row (all lanes active)
+__device__ __forceinline__ uint32_t cf_row_min_u32(uint32_t v)
+{
+	uint32_t o;
+	o = cf_dpp<0xB1>(v); v = o < v ? o : v;
+	o = cf_dpp<0x4E>(v); v = o < v ? o : v;
+	o = cf_dpp<0x141>(v); v = o < v ? o : v;
+	o = cf_dpp<0x140>(v); v = o < v ? o : v;
+	return v;
+}
+__device__ __forceinline__ uint32_t cf_row_max_u32(uint32_t v)
+{
+	uint32_t o;
+	o = cf_dpp<0xB1>(v); v = o > v ? o : v;
+	o = cf_dpp<0x4E>(v); v = o > v ? o : v;
+	o = cf_dpp<0x141>(v); v = o > v ? o : v;
+	o = cf_dpp<0x140>(v); v = o > v ? o : v;
+	return v;
+}
+
 // cf_row_sum_u32 when the four rows hold the same data: the block-wide sum as a wave-uniform
 // (scalar register) value, so what is computed from it stays off the vector registers
 __device__ __forceinline__ uint32_t cf_row_sum_uniform(uint32_t v)
