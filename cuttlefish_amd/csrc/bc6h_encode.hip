@@ -422,6 +422,67 @@ __device__ __forceinline__ uint4 pack_bc6h(const HCand& c)
 	return make_uint4((uint32_t)b.lo, (uint32_t)(b.lo >> 32), (uint32_t)b.hi, (uint32_t)(b.hi >> 32));
 }
 
+// pack_bc6h spread over the wavefront (a serial pack by the winning lane costs the whole wave
+// ~1300 instructions: 24 bit runs x a 13-way field select + the 16 index fields).  The winner's
+// candidate is broadcast with v_readlane, lane r < 24 places bit run r, lane 24 the mode bits,
+// lanes 32..47 one texel index each (its bit position is a closed form of the two anchors),
+// and the 128-bit block is the OR over the lanes.  Uniform result in every lane.
+__device__ __forceinline__ uint4 pack_bc6h_wave(const HCand& mine, uint32_t wl, uint32_t lane)
+{
+	HCand c;
+	c.mode = (uint32_t)__builtin_amdgcn_readlane((int)mine.mode, wl);
+	c.part = (uint32_t)__builtin_amdgcn_readlane((int)mine.part, wl);
+	c.idx = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine.idx >> 32), wl) << 32) |
+		(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine.idx, wl);
+#pragma unroll
+	for (int k = 0; k < 4; ++k)
+#pragma unroll
+		for (int ch = 0; ch < 3; ++ch)
+			c.q[k][ch] = __builtin_amdgcn_readlane(mine.q[k][ch], wl);
+	const Bc6Mode md = k_bc6_modes[c.mode];
+	Bits128 b = {0ull, 0ull};
+	if (lane < md.nruns) {
+		// field values: RW RX RY RZ GW GX GY GZ BW BX BY BZ D
+		const uint32_t rw = k_bc6_runs[c.mode][lane];
+		const uint32_t start = rw & 255u, field = (rw >> 8) & 15u, flo = (rw >> 12) & 15u;
+		const int count = (int)(signed char)((rw >> 16) & 255u);
+		const uint32_t ne = md.two_subsets ? 4u : 2u;
+		uint32_t fv = 0;
+#pragma unroll
+		for (int ch = 0; ch < 3; ++ch) {
+			const uint32_t f0 = (uint32_t)c.q[0][ch] & ((1u << md.ebits) - 1u);
+			fv = field == (uint32_t)(4*ch) ? f0 : fv;
+#pragma unroll
+			for (int k = 1; k < 4; ++k) {
+				const int val = md.transformed ? c.q[k][ch] - c.q[0][ch] : c.q[k][ch];
+				const uint32_t fk = (uint32_t)k < ne ? ((uint32_t)val & ((1u << md.d[ch]) - 1u)) : 0u;
+				fv = field == (uint32_t)(4*ch + k) ? fk : fv;
+			}
+		}
+		fv = field == 12u ? c.part : fv;
+		if (count > 0)
+			b.put(start, fv >> flo, (uint32_t)count);
+		else
+			for (int i = 0; i < -count; ++i)
+				b.put(start + (uint32_t)i, (fv >> (flo - (uint32_t)i)) & 1u, 1u);
+	} else if (lane == 24u)
+		b.put(0u, md.mode_val, md.mode_bits);
+	else if (lane >= 32u && lane < 48u) {
+		const uint32_t i = lane - 32u;
+		const uint32_t ib = md.two_subsets ? 3u : 4u;
+		const uint32_t anchor1 = md.two_subsets ? (uint32_t)k6_anchor2[c.part] : 0u;
+		const uint32_t m1 = md.two_subsets ? (uint32_t)k6_part2[c.part] : 0u;
+		// texels before i that dropped a bit: texel 0, and the second anchor (always in subset 1)
+		const uint32_t dropped = (i > 0u ? 1u : 0u) + ((md.two_subsets && i > anchor1) ? 1u : 0u);
+		const uint32_t pos = (md.two_subsets ? 82u : 65u) + ib*i - dropped;
+		const uint32_t s = (m1 >> i) & 1u;
+		const uint32_t nb = ib - ((i == 0u || (s && i == anchor1)) ? 1u : 0u);
+		b.put(pos, (uint32_t)((c.idx >> (4u*i)) & 15ull), nb);
+	}
+	return make_uint4(cf_wave_or_u32((uint32_t)b.lo), cf_wave_or_u32((uint32_t)(b.lo >> 32)),
+		cf_wave_or_u32((uint32_t)b.hi), cf_wave_or_u32((uint32_t)(b.hi >> 32)));
+}
+
 __device__ __forceinline__ uint32_t to_half_bits(float f)
 {
 	return (uint32_t)__half_as_ushort(__float2half_rn(f));   // v_cvt_f16_f32, RNE
@@ -493,8 +554,10 @@ cfhip_bc6h_encode_kernel(cf_kparams kp)
 		// error < 2^37, id < 64
 		const unsigned long long key = lane < ncand ? ((c.err << 6) | c.id) : ~0ull;
 		const unsigned long long kmin = cf_wave_min_u64(key);
-		if (key == kmin)
-			outb[b] = pack_bc6h(c);
+		const uint32_t wl = (uint32_t)__builtin_ctzll(__ballot(key == kmin));   // keys are distinct (id)
+		const uint4 blk = pack_bc6h_wave(c, wl, lane);
+		if (lane == 0u)
+			outb[b] = blk;
 	}
 	__syncthreads();
 	const uint32_t t = threadIdx.x;
