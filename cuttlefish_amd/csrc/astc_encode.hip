@@ -220,32 +220,44 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		const uint32_t ncfg_all = tables[has_alpha ? 1 : 0];
 		const uint32_t use_cfg = ncfg_all < qcfg ? ncfg_all : qcfg;
 
-		// PCA extremes of the block (uniform work, same float order as the oracle)
-		int sum[4] = {0, 0, 0, 0};
-#pragma unroll 1
-		for (uint32_t i = 0; i < n; ++i) {
-			const uint32_t p = tp[i];
-#pragma unroll
-			for (uint32_t c = 0; c < 4u; ++c)
-				sum[c] += c < nc ? (int)((p >> (8u*c)) & 255u) : 0;
+		// PCA extremes of the block.  The moments are exact integers summed with the group's
+		// lanes striding over the texels (order-free, so the oracle's plain loops give the same
+		// numbers); covariance up to the factor n^2 as n*S_ab - S_a*S_b, one rounding to float.
+		int sum[4];
+		float C00, C01, C02, C03, C11, C12, C13, C22, C23, C33;
+		{
+			uint32_t s01 = 0, s23 = 0, m00 = 0, m01 = 0, m02 = 0, m03 = 0, m11 = 0, m12 = 0, m13 = 0,
+				m22 = 0, m23 = 0, m33 = 0;
+			for (uint32_t i = hl; i < n; i += gsz) {
+				const uint32_t p = tp[i];
+				const uint32_t c0 = p & 255u, c1 = (p >> 8) & 255u, c2 = (p >> 16) & 255u,
+					c3 = nc == 4u ? p >> 24 : 0u;
+				s01 += c0 | (c1 << 16); s23 += c2 | (c3 << 16);
+				m00 += c0*c0; m01 += c0*c1; m02 += c0*c2; m03 += c0*c3;
+				m11 += c1*c1; m12 += c1*c2; m13 += c1*c3;
+				m22 += c2*c2; m23 += c2*c3; m33 += c3*c3;
+			}
+			s01 = cf_group_sum_u32(s01, pair, h); s23 = cf_group_sum_u32(s23, pair, h);
+			sum[0] = (int)(s01 & 0xFFFFu); sum[1] = (int)(s01 >> 16);
+			sum[2] = (int)(s23 & 0xFFFFu); sum[3] = (int)(s23 >> 16);
+			const int ni = (int)n;
+			C00 = (float)(ni*(int)cf_group_sum_u32(m00, pair, h) - sum[0]*sum[0]);
+			C01 = (float)(ni*(int)cf_group_sum_u32(m01, pair, h) - sum[0]*sum[1]);
+			C02 = (float)(ni*(int)cf_group_sum_u32(m02, pair, h) - sum[0]*sum[2]);
+			C11 = (float)(ni*(int)cf_group_sum_u32(m11, pair, h) - sum[1]*sum[1]);
+			C12 = (float)(ni*(int)cf_group_sum_u32(m12, pair, h) - sum[1]*sum[2]);
+			C22 = (float)(ni*(int)cf_group_sum_u32(m22, pair, h) - sum[2]*sum[2]);
+			// alpha moments only matter for blocks with alpha (zero otherwise)
+			C03 = (float)(ni*(int)cf_group_sum_u32(m03, pair, h) - sum[0]*sum[3]);
+			C13 = (float)(ni*(int)cf_group_sum_u32(m13, pair, h) - sum[1]*sum[3]);
+			C23 = (float)(ni*(int)cf_group_sum_u32(m23, pair, h) - sum[2]*sum[3]);
+			C33 = (float)(ni*(int)cf_group_sum_u32(m33, pair, h) - sum[3]*sum[3]);
 		}
 		const float in = 1.0f/(float)n;
 		float mean[4];
 #pragma unroll
 		for (int c = 0; c < 4; ++c)
 			mean[c] = (float)sum[c]*in;
-		float C00 = 0, C01 = 0, C02 = 0, C03 = 0, C11 = 0, C12 = 0, C13 = 0, C22 = 0, C23 = 0, C33 = 0;
-#pragma unroll 1
-		for (uint32_t i = 0; i < n; ++i) {
-			const uint32_t p = tp[i];
-			const float d0 = (float)(p & 255u) - mean[0], d1 = (float)((p >> 8) & 255u) - mean[1];
-			const float d2 = (float)((p >> 16) & 255u) - mean[2];
-			const float d3 = nc == 4u ? (float)(p >> 24) - mean[3] : 0.0f;
-			C00 = fmaf(d0, d0, C00); C01 = fmaf(d0, d1, C01); C02 = fmaf(d0, d2, C02); C03 = fmaf(d0, d3, C03);
-			C11 = fmaf(d1, d1, C11); C12 = fmaf(d1, d2, C12); C13 = fmaf(d1, d3, C13);
-			C22 = fmaf(d2, d2, C22); C23 = fmaf(d2, d3, C23);
-			C33 = fmaf(d3, d3, C33);
-		}
 		float bestd = C00, v0 = C00, v1 = C01, v2 = C02, v3 = C03;
 		if (C11 > bestd) { bestd = C11; v0 = C01; v1 = C11; v2 = C12; v3 = C13; }
 		if (C22 > bestd) { bestd = C22; v0 = C02; v1 = C12; v2 = C22; v3 = C23; }
@@ -276,8 +288,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			axis[0] = v0*is; axis[1] = v1*is; axis[2] = v2*is; axis[3] = v3*is;
 		}
 		float tmin = 3.0e38f, tmax = -3.0e38f;
-#pragma unroll 1
-		for (uint32_t i = 0; i < n; ++i) {
+		for (uint32_t i = hl; i < n; i += gsz) {
 			const uint32_t p = tp[i];
 			float t = axis[0]*((float)(p & 255u) - mean[0]);
 			t = fmaf(axis[1], (float)((p >> 8) & 255u) - mean[1], t);
@@ -286,6 +297,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			tmin = fminf(tmin, t);
 			tmax = fmaxf(tmax, t);
 		}
+		tmin = cf_group_min_f32(tmin, pair, h);
+		tmax = cf_group_max_f32(tmax, pair, h);
 		float lo[4], hi[4];
 #pragma unroll
 		for (int c = 0; c < 4; ++c) {
@@ -405,33 +418,50 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		}
 		const unsigned long long key = ((unsigned long long)err << 32) | hl;   // id = cfg*8 + variant
 		const unsigned long long kmin = cf_group_min_u64(key, pair, h);
-		if (!solid && key == kmin && (pair || lane < 64u)) {
-			// pack: mode (11) | partitions-1 (2) | CEM (4) | 8-bit endpoint values | ... | weights
-			unsigned long long lo64 = (unsigned long long)cfg.mode() | ((unsigned long long)(has_alpha ? 12u : 8u) << 13);
-			unsigned long long hi64 = 0ull;
-			const int vals[8] = {e0[0], e1[0], e0[1], e1[1], e0[2], e1[2], e0[3], e1[3]};
+		// pack, spread over the group: the winner (its id is the low word of the key) hands its
+		// endpoints over through two shuffles, its quantised weights sit in its LDS column, and
+		// each lane places the bit-reversed fields of the grid points it strides over; the block
+		// is the OR over the group.  (A serial pack by the winning lane costs the wavefront one
+		// iteration per weight BIT.)
+		{
+			const uint32_t whl = (uint32_t)kmin & 63u, wlane = pair ? h*32u + whl : whl;
+			const uint32_t e0w = (uint32_t)__shfl((int)((uint32_t)e0[0] | ((uint32_t)e0[1] << 8) | ((uint32_t)e0[2] << 16) | ((uint32_t)e0[3] << 24)), (int)wlane, 64);
+			const uint32_t e1w = (uint32_t)__shfl((int)((uint32_t)e1[0] | ((uint32_t)e1[1] << 8) | ((uint32_t)e1[2] << 16) | ((uint32_t)e1[3] << 24)), (int)wlane, 64);
+			const CfgView wcfg = {set + (whl >> 3)*cstride};
+			const uint32_t wng = wcfg.ng(), wbits = wcfg.bits();
+			const uint8_t* wq = reinterpret_cast<const uint8_t*>(lane_cols + wave*rows*64u + wlane);
+			unsigned long long lo64 = 0ull, hi64 = 0ull;
+			if (hl == 0u) {
+				// mode (11) | partitions-1 (2) | CEM (4) | 8-bit endpoint values e0.r e1.r e0.g ...
+				lo64 = (unsigned long long)wcfg.mode() | ((unsigned long long)(has_alpha ? 12u : 8u) << 13);
 #pragma unroll
-			for (int i = 0; i < 8; ++i) {
-				if (i < (has_alpha ? 8 : 6)) {
-					const uint32_t pos = 17u + 8u*(uint32_t)i;
-					const unsigned long long vv = (unsigned long long)(uint32_t)vals[i];
-					if (pos < 64u) {
-						lo64 |= vv << pos;
-						if (pos + 8u > 64u) hi64 |= vv >> (64u - pos);
-					} else
-						hi64 |= vv << (pos - 64u);
-				}
-			}
-			for (uint32_t g = 0; g < ng; ++g) {
-				const uint32_t qv = qcol[g*128u];
-				for (int kb = 0; kb < bits; ++kb) {
-					if ((qv >> kb) & 1u) {
-						const uint32_t pos = 127u - (g*(uint32_t)bits + (uint32_t)kb);
-						if (pos < 64u) lo64 |= 1ull << pos; else hi64 |= 1ull << (pos - 64u);
+				for (int i = 0; i < 8; ++i) {
+					if (i < (has_alpha ? 8 : 6)) {
+						const uint32_t pos = 17u + 8u*(uint32_t)i;
+						const unsigned long long vv = (unsigned long long)((((i & 1) ? e1w : e0w) >> (8*(i >> 1))) & 255u);
+						if (pos < 64u) {
+							lo64 |= vv << pos;
+							if (pos + 8u > 64u) hi64 |= vv >> (64u - pos);
+						} else
+							hi64 |= vv << (pos - 64u);
 					}
 				}
 			}
-			outb[b] = make_uint4((uint32_t)lo64, (uint32_t)(lo64 >> 32), (uint32_t)hi64, (uint32_t)(hi64 >> 32));
+			for (uint32_t g = hl; g < wng; g += gsz) {
+				// weight g: its bits go to 127 - (g*bits + kb), i.e. the reversed field at 128 - (g+1)*bits
+				const uint32_t fld = __brev((uint32_t)wq[g*128u]) >> (32u - wbits);
+				const uint32_t pos = 128u - (g + 1u)*wbits;
+				const unsigned long long vv = (unsigned long long)fld;
+				if (pos < 64u) {
+					lo64 |= vv << pos;
+					if (pos + wbits > 64u) hi64 |= vv >> (64u - pos);
+				} else
+					hi64 |= vv << (pos - 64u);
+			}
+			const uint32_t w0 = cf_group_or_u32((uint32_t)lo64, pair, h), w1 = cf_group_or_u32((uint32_t)(lo64 >> 32), pair, h),
+				w2 = cf_group_or_u32((uint32_t)hi64, pair, h), w3 = cf_group_or_u32((uint32_t)(hi64 >> 32), pair, h);
+			if (!solid && hl == 0u)
+				outb[b] = make_uint4(w0, w1, w2, w3);
 		}
 	}
 	__syncthreads();

@@ -214,6 +214,37 @@ __device__ __forceinline__ uint32_t cf_group_min_u32(uint32_t k, bool pair, uint
 	return pair ? (h ? b : a) : (a < b ? a : b);
 }
 
+// sum over the group (order-free: integers)
+__device__ __forceinline__ uint32_t cf_group_sum_u32(uint32_t v, bool pair, uint32_t h)
+{
+	v = cf_row_sum_u32(v);
+	const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+	const uint32_t r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+	const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
+	const uint32_t r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+	const uint32_t a = r0 + r1, b = r2 + r3;
+	return pair ? (h ? b : a) : a + b;
+}
+
+// float minimum / maximum over the group (exact whatever the order)
+__device__ __forceinline__ float cf_group_min_f32(float k, bool pair, uint32_t h)
+{
+	k = fminf(k, __uint_as_float(cf_dpp<0xB1>(__float_as_uint(k))));
+	k = fminf(k, __uint_as_float(cf_dpp<0x4E>(__float_as_uint(k))));
+	k = fminf(k, __uint_as_float(cf_dpp<0x141>(__float_as_uint(k))));
+	k = fminf(k, __uint_as_float(cf_dpp<0x140>(__float_as_uint(k))));
+	const float r0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(k), 0));
+	const float r1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(k), 16));
+	const float r2 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(k), 32));
+	const float r3 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(k), 48));
+	const float a = fminf(r0, r1), b = fminf(r2, r3);
+	return pair ? (h ? b : a) : fminf(a, b);
+}
+__device__ __forceinline__ float cf_group_max_f32(float k, bool pair, uint32_t h)
+{
+	return -cf_group_min_f32(-k, pair, h);
+}
+
 __device__ __forceinline__ uint32_t cf_group_or_u32(uint32_t v, bool pair, uint32_t h)
 {
 	v |= cf_dpp<0xB1>(v);

@@ -450,15 +450,20 @@ void cfo_encode_astc_block(const int px[][4], int bw, int bh, int quality, uint8
 	float in = 1.0f/(float)n, mean[4] = {0, 0, 0, 0};
 	for (int c = 0; c < nc; ++c)
 		mean[c] = (float)sum[c]*in;
+	/* covariance up to the factor n^2, from exact integer moments: n*S_ab - S_a*S_b fits 32 bits
+	 * (n <= 144, 8-bit texels) and does not depend on the order the texels are summed in, so
+	 * the GPU can sum them with one texel per lane; one rounding, at the conversion to float */
 	float Cm[4][4];
-	memset(Cm, 0, sizeof(Cm));
-	for (int i = 0; i < n; ++i) {
-		float d[4] = {0, 0, 0, 0};
-		for (int c = 0; c < nc; ++c)
-			d[c] = (float)px[i][c] - mean[c];
+	{
+		int SS[4][4];
+		memset(SS, 0, sizeof(SS));
+		for (int i = 0; i < n; ++i)
+			for (int a = 0; a < nc; ++a)
+				for (int b = a; b < nc; ++b)
+					SS[a][b] += px[i][a]*px[i][b];
 		for (int a = 0; a < 4; ++a)
 			for (int b = a; b < 4; ++b)
-				Cm[a][b] = fmaf(d[a], d[b], Cm[a][b]);
+				Cm[a][b] = (a < nc && b < nc) ? (float)(n*SS[a][b] - sum[a]*sum[b]) : 0.0f;
 	}
 	for (int a = 0; a < 4; ++a)
 		for (int b = 0; b < a; ++b)
