@@ -72,28 +72,16 @@ __device__ __forceinline__ void bc4_palette(int a0, int a1, bool mode6, int e0, 
 __device__ __forceinline__ uint2 bc4_search(const uint32_t* tp, uint32_t* pre, int ch, int vmin,
 	int radius, uint32_t lane)
 {
-	int lo = 255, hi = 0, lo6 = 255, hi6 = vmin;
-	uint32_t sum2 = 0;
-	uint32_t acc[4] = {0u, 0u, 0u, 0u};
-	const uint32_t x0 = lane*4u;
-#pragma unroll 1
-	for (uint32_t i = 0; i < 16u; ++i) {
-		const uint32_t uv = ub(tp[i], ch);
-		const int v = (int)uv;
-		lo = v < lo ? v : lo;
-		hi = v > hi ? v : hi;
-		lo6 = (v != vmin && v < lo6) ? v : lo6;
-		hi6 = (v != 255 && v > hi6) ? v : hi6;
-		sum2 += uv*uv;
-		const uint32_t w = 0x10000u | uv;
-#pragma unroll
-		for (uint32_t e = 0; e < 4u; ++e)
-			acc[e] += uv <= x0 + e ? w : 0u;
-	}
+	// block statistics with one texel per lane (texel lane & 15 in every DPP row)
+	const uint32_t uv = ub(tp[lane & 15u], ch);
+	const int lo = __builtin_amdgcn_readfirstlane((int)cf_row_min_u32(uv));
+	const int hi = __builtin_amdgcn_readfirstlane((int)cf_row_max_u32(uv));
+	int lo6 = __builtin_amdgcn_readfirstlane((int)cf_row_min_u32(uv != (uint32_t)vmin ? uv : 255u));
+	int hi6 = __builtin_amdgcn_readfirstlane((int)cf_row_max_u32(uv != 255u ? uv : (uint32_t)vmin));
+	const uint32_t sum2 = cf_row_sum_uniform(uv*uv);
 	if (lo6 > hi6)
 		lo6 = hi6 = vmin;
-	*reinterpret_cast<uint4*>(pre + x0) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
-	__builtin_amdgcn_wave_barrier();
+	cf_prefix_table_u8(pre, uv, lane < 16u, lane);
 	const uint32_t all = pre[255];   // 16 << 16 | sum
 	const uint32_t span = 2u*(uint32_t)radius + 1u, span2 = span*span, total = 2u*span2;
 	const float inv_span = 1.0f/(float)span;
@@ -160,18 +148,18 @@ __device__ __forceinline__ uint2 bc4_search(const uint32_t* tp, uint32_t* pre, i
 	const int a0 = __shfl(best_a0, (int)wl, 64), a1 = __shfl(best_a1, (int)wl, 64);
 	int pal[8];
 	bc4_palette(a0, a1, a0 <= a1, vmin, pal);
-	unsigned long long sel = 0ull;
-#pragma unroll 1
-	for (uint32_t i = 0; i < 16u; ++i) {
-		const uint32_t v = ub(tp[i], ch);
+	// selectors: lane i < 16 owns texel i (three bits at 3i), OR over the wavefront
+	unsigned long long sel;
+	{
 		uint32_t bestk = 0xFFFFFFFFu;
 #pragma unroll
 		for (int k = 0; k < 8; ++k) {
-			const uint32_t ad = __builtin_amdgcn_sad_u8(v, (uint32_t)pal[k], 0u);
+			const uint32_t ad = __builtin_amdgcn_sad_u8(uv, (uint32_t)pal[k], 0u);
 			const uint32_t kk = (ad << 3) | (uint32_t)k;   // |d| orders like d*d; ties -> lowest k
 			bestk = kk < bestk ? kk : bestk;
 		}
-		sel |= (unsigned long long)(bestk & 7u) << (3u*i);
+		const unsigned long long mine = lane < 16u ? (unsigned long long)(bestk & 7u) << (3u*(lane & 15u)) : 0ull;
+		sel = ((unsigned long long)cf_wave_or_u32((uint32_t)(mine >> 32)) << 32) | cf_wave_or_u32((uint32_t)mine);
 	}
 	uint2 out;
 	out.x = (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)(sel & 0xFFFFull) << 16);

@@ -168,6 +168,37 @@ __device__ __forceinline__ uint32_t cf_div_small(uint32_t num, uint32_t den)
 	return q;
 }
 
+// Prefix table of a block's 8-bit values in 256 words of wave-private LDS:
+//   pre[x] = (number of contributing texels <= x) << 16 | (sum of those texels).
+// Histogram by LDS atomics (`mine`: this lane contributes value v), then a scan: every lane
+// owns four consecutive entries, scans them, and adds the exclusive prefix of the lanes before
+// it (Hillis-Steele inside each DPP row, row totals carried over through v_readlane).  All 64
+// lanes active.  Users: bc4_search (bc15_encode.hip), eac_search (etc_encode.hip).
+__device__ __forceinline__ void cf_prefix_table_u8(uint32_t* pre, uint32_t v, bool mine, uint32_t lane)
+{
+	const uint32_t x0 = lane*4u;
+	*reinterpret_cast<uint4*>(pre + x0) = make_uint4(0u, 0u, 0u, 0u);
+	__builtin_amdgcn_wave_barrier();
+	if (mine)
+		atomicAdd(pre + v, 0x10000u | v);
+	__builtin_amdgcn_wave_barrier();
+	uint4 e = *reinterpret_cast<const uint4*>(pre + x0);
+	e.y += e.x; e.z += e.y; e.w += e.z;
+	uint32_t sc = e.w;
+	sc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sc, 0x111, 0xF, 0xF, false);   // row_shr:1
+	sc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sc, 0x112, 0xF, 0xF, false);   // row_shr:2
+	sc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sc, 0x114, 0xF, 0xF, false);   // row_shr:4
+	sc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sc, 0x118, 0xF, 0xF, false);   // row_shr:8
+	const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)sc, 15);
+	const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)sc, 31);
+	const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)sc, 47);
+	const uint32_t row = lane >> 4;
+	const uint32_t before = (row == 0u ? 0u : (row == 1u ? t0 : (row == 2u ? t0 + t1 : t0 + t1 + t2))) + sc - e.w;
+	e.x += before; e.y += before; e.z += before; e.w += before;
+	*reinterpret_cast<uint4*>(pre + x0) = e;
+	__builtin_amdgcn_wave_barrier();
+}
+
 // wave64 minimum of a 32-bit key, uniform result (all 64 lanes must be active)
 __device__ __forceinline__ uint32_t cf_wave_min_u32(uint32_t k)
 {

@@ -743,20 +743,10 @@ __device__ __forceinline__ uint2 eac_search(const uint32_t* tp, uint32_t* pre, i
 {
 	uint32_t sum2 = 0, all = 0;
 	if (kind == 0) {
-		uint32_t acc[4] = {0u, 0u, 0u, 0u};
-		const uint32_t x0 = lane*4u;
-#pragma unroll 1
-		for (uint32_t i = 0; i < 16u; ++i) {
-			const uint32_t uv = (tp[i] >> (8*ch)) & 255u;
-			const bool a = (active >> i) & 1u;
-			const uint32_t w = a ? (0x10000u | uv) : 0u;
-			sum2 += a ? uv*uv : 0u;
-#pragma unroll
-			for (uint32_t e = 0; e < 4u; ++e)
-				acc[e] += uv <= x0 + e ? w : 0u;
-		}
-		*reinterpret_cast<uint4*>(pre + x0) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
-		__builtin_amdgcn_wave_barrier();
+		const uint32_t ti = lane & 15u, uv = (tp[ti] >> (8*ch)) & 255u;
+		const bool act = (active >> ti) & 1u;
+		sum2 = cf_row_sum_uniform(act ? uv*uv : 0u);
+		cf_prefix_table_u8(pre, uv, lane < 16u && act, lane);
 		all = pre[255];
 	}
 	int lo = 1 << 30, hi = -(1 << 30);
