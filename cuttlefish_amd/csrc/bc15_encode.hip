@@ -278,15 +278,18 @@ __device__ __forceinline__ void bc1_error_both(const uint32_t* tp, const COpts& 
 	const int nh = -(int)__builtin_amdgcn_udot4(eh, eh, 0u, false), nl = -(int)__builtin_amdgcn_udot4(el, el, 0u, false),
 		n2 = -(int)__builtin_amdgcn_udot4(p2, p2, 0u, false), n3 = -(int)__builtin_amdgcn_udot4(p3, p3, 0u, false),
 		nm = -(int)__builtin_amdgcn_udot4(pm, pm, 0u, false);
+	int nhv = nh, nlv = nl, n2v = n2, n3v = n3, nmv = nm;
+	// hide that these are negations: "(dot << 1) + n" then stays one v_lshl_add_u32
+	asm volatile("" : "+v"(nhv), "+v"(nlv), "+v"(n2v), "+v"(n3v), "+v"(nmv));
 	int acc4 = 0, acc3 = 0;
 #pragma unroll 1
 	for (uint32_t i = 0; i < 16u; ++i) {
 		const uint32_t p = tp[i] & 0x00FFFFFFu;
-		const int kh = (int)(__builtin_amdgcn_udot4(p, eh, 0u, false) << 1) + nh;
-		const int kl = (int)(__builtin_amdgcn_udot4(p, el, 0u, false) << 1) + nl;
-		const int k2 = (int)(__builtin_amdgcn_udot4(p, p2, 0u, false) << 1) + n2;
-		const int k3 = (int)(__builtin_amdgcn_udot4(p, p3, 0u, false) << 1) + n3;
-		const int km = (int)(__builtin_amdgcn_udot4(p, pm, 0u, false) << 1) + nm;
+		const int kh = (int)(__builtin_amdgcn_udot4(p, eh, 0u, false) << 1) + nhv;
+		const int kl = (int)(__builtin_amdgcn_udot4(p, el, 0u, false) << 1) + nlv;
+		const int k2 = (int)(__builtin_amdgcn_udot4(p, p2, 0u, false) << 1) + n2v;
+		const int k3 = (int)(__builtin_amdgcn_udot4(p, p3, 0u, false) << 1) + n3v;
+		const int km = (int)(__builtin_amdgcn_udot4(p, pm, 0u, false) << 1) + nmv;
 		const int m01 = kh > kl ? kh : kl;
 		int m4 = m01 > k2 ? m01 : k2;
 		m4 = m4 > k3 ? m4 : k3;

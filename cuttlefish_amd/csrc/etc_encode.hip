@@ -146,6 +146,9 @@ __device__ __forceinline__ uint32_t half_err_fast(const HalfTex& h, const RgbOpt
 		}
 		if (v == 2 && o.punch)
 			nb[v] = -0x3FFFFFFF;   // punch-through: selector 2 is the transparent one
+		// hide that nb is a negation: "(d << 1) + nb" then stays ONE v_lshl_add_u32 per palette
+		// entry and texel instead of a shift and a subtract (a quarter of the loop's instructions)
+		asm volatile("" : "+v"(nb[v]));
 	}
 	uint32_t total = h.pp;
 #pragma unroll
@@ -153,10 +156,10 @@ __device__ __forceinline__ uint32_t half_err_fast(const HalfTex& h, const RgbOpt
 		int best = -0x7FFFFFFF;
 #pragma unroll
 		for (int v = 0; v < 4; ++v) {
-			int d = (int)__builtin_amdgcn_udot4(h.px[j], ql[v], 0u, false);
+			// -(sum w q^2 - 2 p.(w q)) as one v_lshl_add_u32 per byte plane
+			int k = (int)(__builtin_amdgcn_udot4(h.px[j], ql[v], 0u, false) << 1) + nb[v];
 			if (!UNITW)
-				d += (int)__builtin_amdgcn_udot4(h.px[j], qh[v], 0u, false) << 8;
-			const int k = (d << 1) + nb[v];   // -(sum w q^2 - 2 p.(w q))
+				k = (int)(__builtin_amdgcn_udot4(h.px[j], qh[v], 0u, false) << 9) + k;
 			best = k > best ? k : best;
 		}
 		total += ((h.counted >> j) & 1u) ? (uint32_t)(-best) : 0u;
@@ -312,6 +315,7 @@ __device__ __forceinline__ uint32_t th_err(const uint32_t* tp, uint32_t active, 
 			qh[v] = (w0 >> 8) | ((w1 >> 8) << 8) | ((w2 >> 8) << 16);
 			nb[v] = -(int)(w0*q0 + w1*q1 + w2*q2);
 		}
+		asm volatile("" : "+v"(nb[v]));   // keep (d << 1) + nb one v_lshl_add_u32 (see half_err_fast)
 	}
 	uint32_t total = pp;
 	// texels from LDS (wave-uniform address) in a rolled loop: a register copy of the block
@@ -322,10 +326,9 @@ __device__ __forceinline__ uint32_t th_err(const uint32_t* tp, uint32_t active, 
 		int best = -0x7FFFFFFF;
 #pragma unroll
 		for (int v = 0; v < 4; ++v) {
-			int d = (int)__builtin_amdgcn_udot4(p, ql[v], 0u, false);
+			int k = (int)(__builtin_amdgcn_udot4(p, ql[v], 0u, false) << 1) + nb[v];
 			if (!UNITW)
-				d += (int)__builtin_amdgcn_udot4(p, qh[v], 0u, false) << 8;
-			const int k = (d << 1) + nb[v];
+				k = (int)(__builtin_amdgcn_udot4(p, qh[v], 0u, false) << 9) + k;
 			best = k > best ? k : best;
 		}
 		total += ((active >> i) & 1u) ? (uint32_t)(-best) : 0u;
