@@ -1,0 +1,49 @@
+"""BASELINE configs 3 and 4 at their full sizes (config 2 lives in test_gpu_bc7.py): the oracle
+cannot finish these in seconds, so the checks are size-independent properties -- payload size,
+determinism, a PSNR floor through the oracle DECODER, and byte parity with the oracle ENCODER on
+a strip of block rows cut out of the big payload (blocks are independent)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from cuttlefish_amd import Context, Format, Type, make_params, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    with Context(0) as c:
+        yield c
+
+
+def test_config3_astc_6x6_4096(ctx):
+    img = synth.photo(4096, 4096, seed=1)
+    p = make_params(Format.ASTC_6x6, Type.UNorm, 3)                 # High: "thorough"
+    a = ctx.encode([img], p)[0]
+    bx = (4096 + 5)//6
+    assert a.nbytes == bx*bx*16
+    assert np.array_equal(a, ctx.encode([img], p)[0])               # deterministic
+    dec, outside = O.decode_astc(a, int(Format.ASTC_6x6), 4096, 4096)
+    assert outside == 0 and synth.psnr(img, dec) > 40.0
+    # block rows 340..343 (texel rows 2040..2063, inside the alpha band) against the oracle encoder
+    strip = img[340*6:344*6]
+    ref = O.encode(strip, int(Format.ASTC_6x6), 0, quality=3, threads=16)
+    assert np.array_equal(ref, a.reshape(bx, bx*16)[340:344].reshape(-1))
+
+
+def test_config4_bc6h_2048_rgba16f(ctx):
+    hdr = synth.hdr_probe(2048, 2048, seed=4).astype(np.float16)
+    p = make_params(Format.BC6H, Type.UFloat, 2)
+    a = ctx.encode([hdr], p)[0]
+    assert a.nbytes == 512*512*16
+    assert np.array_equal(a, ctx.encode([hdr], p)[0])
+    dec = O.decode_bc6h(a, 2048, 2048)                              # (h, w, 3) half bits
+    x = hdr[..., :3].astype(np.float64)
+    y = dec.astype(np.float64)
+    lx, ly = np.log2(1.0 + np.maximum(x, 0)), np.log2(1.0 + np.maximum(y, 0))
+    mse = np.mean((lx - ly)**2)
+    assert 10*np.log10(lx.max()**2/mse) > 45.0                      # PSNR of log2(1+x), SURVEY 8(d)
+    strip = hdr[1024:1024 + 16]                                     # 4 block rows through the middle
+    ref = O.encode(strip, int(Format.BC6H), int(Type.UFloat), quality=2, threads=16)
+    assert np.array_equal(ref, a.reshape(512, 512*16)[256:260].reshape(-1))

@@ -63,8 +63,24 @@ def run(format_name, cases, seed, verbose=True):
             mask = tuple(int(v) for v in (rng.random(4) < 0.85)) if case % 5 == 0 else (1, 1, 1, 1)
             if not any(mask):
                 mask = (1, 1, 1, 1)
-            ref = O.encode(img, int(fmt), 0, quality=q, threads=16, color_space=cs, mask=mask)
-            got = ctx.encode([img], make_params(fmt, Type.UNorm, q, color_space=ColorSpace(cs),
+            typ = Type.UNorm
+            if fmt == Format.BC6H:
+                # HDR content: exp2 of the byte image over 18 stops, +-Inf / huge / tiny / negative
+                # values sprinkled in; RGBA16F, RGBA32F and RGBA8 sources; UFloat and Float
+                typ = Type.UFloat if rng.integers(0, 2) else Type.Float
+                f = np.exp2(img.astype(np.float32)/255.0*18.0 - 9.0)
+                if typ == Type.Float:
+                    f = f*np.where(rng.random(f.shape) < 0.3, -1.0, 1.0).astype(np.float32)
+                sp = rng.random(f.shape) < 0.01
+                f = np.where(sp, rng.choice(np.array([0.0, 65504.0, 1e9, -1e9, 6e-8, np.inf], np.float32), f.shape), f)
+                k = int(rng.integers(0, 3))
+                img = f.astype(np.float16) if k == 0 else (f.astype(np.float32) if k == 1 else img)
+                cs, mask = 0, (1, 1, 1, 1)
+            elif fmt in (Format.BC4, Format.BC5, Format.EAC_R11, Format.EAC_R11G11) and rng.integers(0, 2):
+                typ = Type.SNorm
+                cs = 0
+            ref = O.encode(img, int(fmt), int(typ), quality=q, threads=16, color_space=cs, mask=mask)
+            got = ctx.encode([img], make_params(fmt, typ, q, color_space=ColorSpace(cs),
                                                 color_mask=tuple(bool(m) for m in mask)))[0]
             if not np.array_equal(ref, got):
                 bad += 1
