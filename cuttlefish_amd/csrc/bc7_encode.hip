@@ -759,8 +759,10 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	const bool has_alpha = pair ? ((uint32_t)(h ? abal >> 32 : abal) & 0xFFFFu) != 0u
 		: ((uint32_t)abal & 0xFFFFu) != 0u;
 	const bool any_alpha = pair ? abal != 0ull : has_alpha;
-	const uint32_t quality = kp.quality;
-	const uint32_t iters = (0x32110u >> (4u*(quality < 4u ? quality : 4u))) & 15u;   // refit rounds 0,1,1,2,3
+	// Low runs Normal's candidate set without the refit round (oracle: quality_budget): `quality`
+	// below selects the LAYOUT, so Low is mapped onto Normal's
+	const uint32_t iters = (0x32100u >> (4u*(kp.quality < 4u ? kp.quality : 4u))) & 15u;   // refit rounds 0,0,1,2,3
+	const uint32_t quality = kp.quality == 1u ? 2u : kp.quality;
 	const uint32_t wt[4] = {kp.wt[0], kp.wt[1], kp.wt[2], kp.wt[3]};
 
 	uint32_t best_err = 0xFFFFFFFFu, best_id = 0x7FFFFFFFu;   // payload fields: cslot (LDS)
@@ -771,7 +773,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	//    Normal: hl 2..5 / 6..9 : vector / scalar plane of mode 5, rotation hl-2 / hl-6
 	//            hl 10..21 : mode 1, its 6 best partitions x 2 subsets; hl 22..31 : mode 3, 5 best
 	//            (block with alpha: hl 10..31 : mode 7, its 11 best)
-	//    Low:    hl 2 / 3 : mode 5 rotation 0;  hl 4..31 : mode 1 (alpha: 7), its 14 best partitions
+	//    Low:    Normal's layout, no refit round
 	//    Lowest: hl 2 / 3 : mode 5 rotation 0 for blocks with alpha; no partitions
 	// High and Highest use the 64-lane layout:
 	// stream 0:  lanes  0..1  : mode 6

@@ -606,7 +606,7 @@ static budget quality_budget(int quality)
 		/* refit rounds: the second round is worth ~0.004 dB on photographic content, so it is
 		 * only spent from High up */
 		case 0: b = (budget){0, 1, 0, 0, 0, 0}; break;
-		case 1: b = (budget){1, 0, 1, 0, 0, 0}; break;
+		case 1: b = (budget){0, 0, 1, 1, 0, 1}; break;   /* Low: Normal's candidate set without the refit round */
 		case 2: b = (budget){1, 0, 1, 1, 0, 1}; break;
 		case 3: b = (budget){2, 0, 1, 1, 1, 1}; break;
 		default: b = (budget){3, 0, 1, 1, 1, 1}; break;
@@ -671,8 +671,7 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 		 * mode), phase 2 runs the full fit with all refit rounds on the best partitions
 		 * of each mode of the group, ranked by (score bits with the low 6 bits cleared,
 		 * partition index):
-		 *   two-subset group:   Low: mode 1 (blocks with alpha: mode 7) with 14 partitions;
-		 *                       Normal: modes 1 / 3 with 6 / 5 (alpha: mode 7 with 11) -- a block
+		 *   two-subset group:   Low and Normal: modes 1 / 3 with 6 / 5 (alpha: mode 7 with 11) -- a block
 		 *                       then needs 32 lanes: 2 + 8 + 22; High: modes 1 + 3 with 8 each
 		 *                       (alpha: mode 7 with 16)
 		 *   three-subset group: modes 0 (its 16 partitions) + 2 with 5 partitions each (High)
