@@ -5,8 +5,8 @@
 // and CompressBlockBC6 (Compressonator, signed), including the fp32 -> fp16 round-to-
 // nearest-even packing of the block (:113-129, HalfFloat.h:96-136).
 //
-// Mapping: lane 0 = one-subset candidate (modes 14/13/12/11), lanes 1..32 = the 32
-// two-subset partitions (ten modes).  Per subset: PCA axis in the decoder's 16-bit
+// Candidates: id 0 = one subset (modes 14/13/12/11), ids 1..32 = the 32 two-subset partitions
+// (ten modes); a wavefront's four blocks take three passes (see the kernel body).  Per subset: PCA axis in the decoder's 16-bit
 // interpolation space -> extremes -> refit rounds (projection selectors, closed-form
 // least squares) -> anchor fix-up -> highest-precision mode whose deltas fit -> exact
 // integer error in half-bit space (64-bit).  Wave argmin on (error, id), the winning lane
@@ -424,21 +424,34 @@ __device__ __forceinline__ uint4 pack_bc6h(const HCand& c)
 
 // pack_bc6h spread over the wavefront (a serial pack by the winning lane costs the whole wave
 // ~1300 instructions: 24 bit runs x a 13-way field select + the 16 index fields).  The winner's
-// candidate is broadcast with v_readlane, lane r < 24 places bit run r, lane 24 the mode bits,
+// candidate is read from its LDS slot, lane r < 24 places bit run r, lane 24 the mode bits,
 // lanes 32..47 one texel index each (its bit position is a closed form of the two anchors),
 // and the 128-bit block is the OR over the lanes.  Uniform result in every lane.
-__device__ __forceinline__ uint4 pack_bc6h_wave(const HCand& mine, uint32_t wl, uint32_t lane)
+// A block's best candidate so far lives in a 20-dword slot of wave-private LDS:
+// key (2), mode, part, idx (2), q[4][3]
+__device__ __forceinline__ void store_cand(uint32_t* slot, const HCand& c, unsigned long long key)
 {
-	HCand c;
-	c.mode = (uint32_t)__builtin_amdgcn_readlane((int)mine.mode, wl);
-	c.part = (uint32_t)__builtin_amdgcn_readlane((int)mine.part, wl);
-	c.idx = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine.idx >> 32), wl) << 32) |
-		(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine.idx, wl);
+	slot[0] = (uint32_t)key; slot[1] = (uint32_t)(key >> 32);
+	slot[2] = c.mode; slot[3] = c.part;
+	slot[4] = (uint32_t)c.idx; slot[5] = (uint32_t)(c.idx >> 32);
 #pragma unroll
 	for (int k = 0; k < 4; ++k)
 #pragma unroll
 		for (int ch = 0; ch < 3; ++ch)
-			c.q[k][ch] = __builtin_amdgcn_readlane(mine.q[k][ch], wl);
+			slot[6 + 3*k + ch] = (uint32_t)c.q[k][ch];
+}
+
+__device__ __forceinline__ uint4 pack_bc6h_wave(const uint32_t* slot, uint32_t lane)
+{
+	HCand c;   // wave-uniform: every lane reads the same slot
+	c.mode = slot[2];
+	c.part = slot[3];
+	c.idx = ((unsigned long long)slot[5] << 32) | slot[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k)
+#pragma unroll
+		for (int ch = 0; ch < 3; ++ch)
+			c.q[k][ch] = (int)slot[6 + 3*k + ch];
 	const Bc6Mode md = k_bc6_modes[c.mode];
 	Bits128 b = {0ull, 0ull};
 	if (lane < md.nruns) {
@@ -497,6 +510,7 @@ cfhip_bc6h_encode_kernel(cf_kparams kp)
 {
 	__shared__ uint32_t tile[CF_BLOCKS_PER_WG*16*3];
 	__shared__ uint4 outb[CF_BLOCKS_PER_WG];
+	__shared__ uint32_t cand_lds[(CF_WG_THREADS/64)*4*20];   // parked candidates, see below
 	uint32_t gx_, gy_;
 	cf_resolve(kp, gx_, gy_);
 	const uint32_t bx0 = gx_*CF_BLOCKS_PER_WG;
@@ -537,27 +551,58 @@ cfhip_bc6h_encode_kernel(cf_kparams kp)
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	const uint32_t quality = kp.quality;
 	const uint32_t iters = quality <= 1u ? 0u : (quality == 2u ? 1u : (quality == 3u ? 2u : 3u));
-	const uint32_t ncand = quality == 0u ? 1u : 33u;
-	for (uint32_t j = 0; j < 4u; ++j) {
-		const uint32_t b = wave*4u + j;
-		if (bx0 + b >= kp.bx)
-			break;
-		const uint32_t* tp = tile + b*48u;
+	// Schedule of a wavefront's four blocks (33 candidates each would leave 31 lanes idle, and
+	// the one-subset candidate is one fit where a partition is two):
+	//   pass 0: lanes 0..3 fit the one-subset candidate of blocks 0..3 and park it in LDS;
+	//   2 passes: two blocks per pass, lane group h = lane >> 5 owns the block's 32 partitions;
+	//            the group's best replaces the parked candidate if its (error, id) key is smaller;
+	//   then every block is packed by the whole wavefront from its slot.
+	// 1 + 2 x 2 subset fits per wavefront instead of 4 x 2; Lowest is pass 0 alone.
+	uint32_t* slots = cand_lds + wave*80u;
+	const uint32_t first = wave*4u;
+	const uint32_t nblk = bx0 + first >= kp.bx ? 0u : (kp.bx - bx0 - first < 4u ? kp.bx - bx0 - first : 4u);
+	{
 		HCand c;
 		c.err = ~0ull; c.id = 63u; c.mode = 10u; c.part = 0u; c.idx = 0ull;
 #pragma unroll
 		for (int k = 0; k < 4; ++k)
 			for (int ch = 0; ch < 3; ++ch)
 				c.q[k][ch] = 0;
-		if (lane < ncand)
-			eval_candidate<SIGNED>(tp, lane, iters, c);
-		// error < 2^37, id < 64
-		const unsigned long long key = lane < ncand ? ((c.err << 6) | c.id) : ~0ull;
-		const unsigned long long kmin = cf_wave_min_u64(key);
-		const uint32_t wl = (uint32_t)__builtin_ctzll(__ballot(key == kmin));   // keys are distinct (id)
-		const uint4 blk = pack_bc6h_wave(c, wl, lane);
+		if (lane < nblk) {
+			eval_candidate<SIGNED>(tile + (first + lane)*48u, 0u, iters, c);
+			store_cand(slots + lane*20u, c, (c.err << 6) | c.id);   // error < 2^37, id < 64
+		}
+	}
+	__builtin_amdgcn_wave_barrier();
+	if (quality != 0u) {
+		const uint32_t h = lane >> 5;
+#pragma unroll 1
+		for (uint32_t jp = 0; jp < 2u; ++jp) {
+			if (2u*jp >= nblk)
+				break;
+			const uint32_t bi = 2u*jp + h;
+			const bool exists = bi < nblk;
+			HCand c;
+			c.err = ~0ull; c.id = 63u; c.mode = 10u; c.part = 0u; c.idx = 0ull;
+#pragma unroll
+			for (int k = 0; k < 4; ++k)
+				for (int ch = 0; ch < 3; ++ch)
+					c.q[k][ch] = 0;
+			if (exists)
+				eval_candidate<SIGNED>(tile + (first + bi)*48u, 1u + (lane & 31u), iters, c);
+			const unsigned long long key = exists ? ((c.err << 6) | c.id) : ~0ull;
+			const unsigned long long kmin = cf_group_min_u64(key, true, h);
+			uint32_t* slot = slots + (exists ? bi : 0u)*20u;
+			const unsigned long long parked = ((unsigned long long)slot[1] << 32) | slot[0];
+			if (exists && key == kmin && kmin < parked)   // keys are distinct (id): one lane per group
+				store_cand(slot, c, key);
+			__builtin_amdgcn_wave_barrier();
+		}
+	}
+	for (uint32_t j = 0; j < nblk; ++j) {
+		const uint4 blk = pack_bc6h_wave(slots + j*20u, lane);
 		if (lane == 0u)
-			outb[b] = blk;
+			outb[first + j] = blk;
 	}
 	__syncthreads();
 	const uint32_t t = threadIdx.x;
