@@ -126,9 +126,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
 	__shared__ uint4 outb[CF_BLOCKS_PER_WG];
 	const uint32_t bw = kp.flags & 255u, bh = (kp.flags >> 8) & 255u, n = bw*bh;
-	const uint32_t rows = (kp.flags >> 16) & 255u;   // largest ng of any config + 1
+	const uint32_t rows = (kp.flags >> 16) & 255u;   // largest ng of the staged configs + 1
+	const uint32_t ncs = (kp.flags >> 24) & 15u;     // configs staged per set (the quality's budget)
 	const uint32_t cstride = 136u + 8u*n;            // compact record stride (bytes)
-	const uint32_t tab_words = (8u + 16u*cstride)/4u;
+	const uint32_t tab_words = (8u + 2u*ncs*cstride)/4u;
 	uint32_t* tile = dyn_lds;
 	uint32_t* tabs = dyn_lds + CF_BLOCKS_PER_WG*n;
 	uint16_t* lane_cols = reinterpret_cast<uint16_t*>(tabs + tab_words);
@@ -139,7 +140,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			uint32_t src = i;
 			if (i >= 2u) {
 				const uint32_t rec = (i - 2u)/(cstride/4u), off = (i - 2u) - rec*(cstride/4u);
-				src = 2u + rec*(ASTC_CFG_STRIDE/4u) + off;
+				const uint32_t set_ = rec >= ncs ? 1u : 0u, k_ = rec - set_*ncs;   // source: 8 records per set
+				src = 2u + (set_*8u + k_)*(ASTC_CFG_STRIDE/4u) + off;
 			}
 			tabs[i] = g[src];
 		}
@@ -216,7 +218,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		if (__ballot(!solid) == 0ull)
 			continue;   // nothing but constant blocks in this pass
 		const uint32_t nc = has_alpha ? 4u : 3u;
-		const uint8_t* set = tables + (has_alpha ? 8u + 8u*cstride : 8u);
+		const uint8_t* set = tables + (has_alpha ? 8u + ncs*cstride : 8u);
 		const uint32_t ncfg_all = tables[has_alpha ? 1 : 0];
 		const uint32_t use_cfg = ncfg_all < qcfg ? ncfg_all : qcfg;
 
@@ -484,7 +486,8 @@ extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, hi
 	dim3 block(CF_WG_THREADS, 1, 1);
 	const uint32_t n_ = (kp->flags & 255u)*((kp->flags >> 8) & 255u), rows_ = (kp->flags >> 16) & 255u;
 	// tile + compact tables + 4 waves x rows x 64 lanes of u16 (same layout as in the kernel)
-	const size_t dyn = (size_t)CF_BLOCKS_PER_WG*n_*4u + (8u + 16u*(136u + 8u*n_)) +
+	const uint32_t ncs_ = (kp->flags >> 24) & 15u;
+	const size_t dyn = (size_t)CF_BLOCKS_PER_WG*n_*4u + (8u + 2u*ncs_*(136u + 8u*n_)) +
 		(size_t)4*rows_*64u*sizeof(uint16_t);
 	if (pixel_type == 0)
 		hipLaunchKernelGGL((cfhip_astc_encode_kernel<0>), grid, block, dyn, stream, *kp);

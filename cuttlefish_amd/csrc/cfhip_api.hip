@@ -452,12 +452,17 @@ int launch(cfhip_ctx* ctx, const cf_kparams& kp, const cfhip_params& p, int pixe
 			k2.aux = tab;
 			{
 				// rows of the per-lane LDS grid columns: largest weight grid of the footprint + 1
+				// ... of the configs this quality level walks (1 / 2 / 4 / 8 / 8 per set: the kernel
+				// stages only those, bits 24..27), so that Lowest..Normal fit more workgroups per CU
 				int fbw, fbh, ng_max = 1;
 				astc_footprint(p.format, &fbw, &fbh);
-				for (int values = 6; values <= 8; values += 2)
-					for (const AstcCfgHost& c : astc_configs(fbw, fbh, values))
-						ng_max = std::max(ng_max, c.N*c.M);
-				k2.flags |= (uint32_t)(ng_max + 1) << 16;
+				const int ncs = p.quality == 0 ? 1 : (p.quality == 1 ? 2 : (p.quality == 2 ? 4 : 8));
+				for (int values = 6; values <= 8; values += 2) {
+					const std::vector<AstcCfgHost> cfgs = astc_configs(fbw, fbh, values);
+					for (size_t k = 0; k < cfgs.size() && (int)k < ncs; ++k)
+						ng_max = std::max(ng_max, cfgs[k].N*cfgs[k].M);
+				}
+				k2.flags |= ((uint32_t)(ng_max + 1) << 16) | ((uint32_t)ncs << 24);
 			}
 			e = cfhip_launch_astc(&k2, pixel_type == CFHIP_PIXEL_RGBA32F ? 1 : 0, stream);
 			ctx->last_kernel = "cfhip_astc_encode_kernel";
