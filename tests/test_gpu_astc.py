@@ -44,7 +44,7 @@ def test_float_source_noise_swizzle_and_solid(gpu_ctx):
     assert np.array_equal(ref, _gpu(gpu_ctx, solid, Format.ASTC_8x8))
 
 
-def test_texture_convert_size_contract_and_hdr_rejected(gpu_ctx):
+def test_texture_convert_size_contract_and_type_legality(gpu_ctx):
     img = np.zeros((16, 16, 4), np.float32)
     img[..., 3] = 1.0
     t = Texture(16, 16)
@@ -54,7 +54,8 @@ def test_texture_convert_size_contract_and_hdr_rejected(gpu_ctx):
     t = Texture(16, 16)
     t.set_image(img)
     assert not t.convert(Format.ASTC_6x6, Type.SNorm)      # createConverter -> nullptr
-    assert not t.convert(Format.ASTC_6x6, Type.UFloat)     # HDR profile: not built yet
+    assert t.convert(Format.ASTC_6x6, Type.UFloat)         # HDR profile: accepted, LDR endpoint modes
+    assert t.data_size() == 9 * 16
 
 
 def test_config3_full_size_properties_4096(gpu_ctx):
