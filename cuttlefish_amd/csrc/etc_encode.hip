@@ -752,14 +752,18 @@ __device__ __forceinline__ uint2 eac_search(const uint32_t* tp, uint32_t* pre, i
 		cf_prefix_table_u8(pre, uv, lane < 16u && act, lane);
 		all = pre[255];
 	}
-	int lo = 1 << 30, hi = -(1 << 30);
-#pragma unroll 1
-	for (uint32_t i = 0; i < 16u; ++i) {
-		if ((active >> i) & 1u) {
-			const int v = eac_value(tp, i, kind, ch);
-			lo = v < lo ? v : lo;
-			hi = v > hi ? v : hi;
-		}
+	// range of the active texels and (11-bit kinds) the sum of their squares: one texel per lane
+	int lo, hi;
+	uint32_t vv2 = 0;
+	{
+		const uint32_t ti = lane & 15u;
+		const int v = eac_value(tp, ti, kind, ch);
+		const bool act = (active >> ti) & 1u;
+		const uint32_t bv = (uint32_t)(v + 1024);   // biased: signed R11 is -1023..1023
+		lo = __builtin_amdgcn_readfirstlane((int)cf_row_min_u32(act ? bv : 0xFFFFu)) - 1024;
+		hi = __builtin_amdgcn_readfirstlane((int)cf_row_max_u32(act ? bv : 0u)) - 1024;
+		if (kind != 0)
+			vv2 = cf_row_sum_uniform(act ? (uint32_t)__mul24(v, v) : 0u);
 	}
 	if (lo > hi)
 		lo = hi = 0;
@@ -770,7 +774,7 @@ __device__ __forceinline__ uint2 eac_search(const uint32_t* tp, uint32_t* pre, i
 	if (lane < 48u) {
 		const int t = (int)(lane/3u), dm = (int)(lane - 3u*(uint32_t)t) - 1;
 		const int span = k_eac_mod[t][7] - k_eac_mod[t][3];
-		const int m0 = ((hi - lo) + (span*step)/2)/(span*step);
+		const int m0 = (int)cf_div_small((uint32_t)((hi - lo) + (span*step)/2), (uint32_t)(span*step));
 		const int mult = clampi(m0 + dm, 1, 15);
 		const int centre = (lo + hi - (k_eac_mod[t][7] + k_eac_mod[t][3])*mult*step)/2;
 		const int b0 = kind == 1 ? (centre - 4)/8 : (kind == 2 ? centre/8 : centre);
@@ -802,18 +806,29 @@ __device__ __forceinline__ uint2 eac_search(const uint32_t* tp, uint32_t* pre, i
 				}
 				err = (uint32_t)e;
 			} else {
+				// (dec - v)^2 = v^2 - (2 dec v - dec^2): one multiply-add per entry and a max, the
+				// sum of v^2 over the active texels (vv2) once per block
+				int d2[8], nd[8];
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					d2[k] = 2*dec[k];
+					nd[k] = -__mul24(dec[k], dec[k]);
+					asm volatile("" : "+v"(nd[k]));   // keep v*d2 + nd ONE v_mad_i32_i24 (not a multiply and a subtract)
+				}
+				int acc = 0;
 #pragma unroll 4
 				for (uint32_t i = 0; i < 16u; ++i) {
 					const int v = eac_value(tp, i, kind, ch);
-					uint32_t be = 0xFFFFFFFFu;
+					// 24-bit multiplies (|v| <= 2047, 2 dec <= 4094): full rate, unlike v_mul_lo_u32
+					int best = __mul24(v, d2[0]) + nd[0];
 #pragma unroll
-					for (int k = 0; k < 8; ++k) {
-						const int d = dec[k] - v;
-						const uint32_t e = (uint32_t)(d*d);
-						be = e < be ? e : be;
+					for (int k = 1; k < 8; ++k) {
+						const int kk = __mul24(v, d2[k]) + nd[k];
+						best = kk > best ? kk : best;
 					}
-					err += ((active >> i) & 1u) ? be : 0u;
+					acc += ((active >> i) & 1u) ? best : 0;
 				}
+				err = vv2 - (uint32_t)acc;
 			}
 			if (err < berr) { berr = err; bbase = base; bdb = db + R; }
 		}
