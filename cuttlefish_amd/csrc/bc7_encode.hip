@@ -666,6 +666,9 @@ __device__ __forceinline__ uint4 pack_block_group(const uint32_t* wcol, uint32_t
 // Partition score of the two-phase search (oracle: subset_residual): the scatter of the
 // subset that no line through its mean can capture, (trace(C) - a'Ca)/n, with a = the
 // power-iterated principal axis.  Same statistics and axis arithmetic as fit_lane.
+// A4 = false: the block is opaque (the alpha plane is masked to zero), so every term that
+// carries the fourth channel is an exact zero and is left out -- same result, bit for bit.
+template <bool A4>
 __device__ __forceinline__ float subset_residual(const Tex& tx, uint32_t mask)
 {
 	const uint32_t n = (uint32_t)__builtin_popcount(mask);
@@ -677,21 +680,21 @@ __device__ __forceinline__ float subset_residual(const Tex& tx, uint32_t mask)
 		uint32_t P[4];
 		planes<false>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
 		const uint32_t m4 = bytemask4((mask >> (4u*r)) & 15u);
-		const uint32_t M0 = P[0] & m4, M1 = P[1] & m4, M2 = P[2] & m4, M3 = P[3] & m4;
+		const uint32_t M0 = P[0] & m4, M1 = P[1] & m4, M2 = P[2] & m4, M3 = A4 ? P[3] & m4 : 0u;
 		s[0] = __builtin_amdgcn_udot4(M0, 0x01010101u, s[0], false);
 		s[1] = __builtin_amdgcn_udot4(M1, 0x01010101u, s[1], false);
 		s[2] = __builtin_amdgcn_udot4(M2, 0x01010101u, s[2], false);
-		s[3] = __builtin_amdgcn_udot4(M3, 0x01010101u, s[3], false);
+		if (A4) s[3] = __builtin_amdgcn_udot4(M3, 0x01010101u, s[3], false);
 		q00 = __builtin_amdgcn_udot4(M0, P[0], q00, false);
 		q01 = __builtin_amdgcn_udot4(M0, P[1], q01, false);
 		q02 = __builtin_amdgcn_udot4(M0, P[2], q02, false);
-		q03 = __builtin_amdgcn_udot4(M0, P[3], q03, false);
+		if (A4) q03 = __builtin_amdgcn_udot4(M0, P[3], q03, false);
 		q11 = __builtin_amdgcn_udot4(M1, P[1], q11, false);
 		q12 = __builtin_amdgcn_udot4(M1, P[2], q12, false);
-		q13 = __builtin_amdgcn_udot4(M1, P[3], q13, false);
+		if (A4) q13 = __builtin_amdgcn_udot4(M1, P[3], q13, false);
 		q22 = __builtin_amdgcn_udot4(M2, P[2], q22, false);
-		q23 = __builtin_amdgcn_udot4(M2, P[3], q23, false);
-		q33 = __builtin_amdgcn_udot4(M3, P[3], q33, false);
+		if (A4) q23 = __builtin_amdgcn_udot4(M2, P[3], q23, false);
+		if (A4) q33 = __builtin_amdgcn_udot4(M3, P[3], q33, false);
 	}
 	const float C00 = (float)(int)(__umul24(n, q00) - __umul24(s[0], s[0])), C01 = (float)(int)(__umul24(n, q01) - __umul24(s[0], s[1]));
 	const float C02 = (float)(int)(__umul24(n, q02) - __umul24(s[0], s[2])), C03 = (float)(int)(__umul24(n, q03) - __umul24(s[0], s[3]));
@@ -702,39 +705,42 @@ __device__ __forceinline__ float subset_residual(const Tex& tx, uint32_t mask)
 	float v0 = C00, v1 = C01, v2 = C02, v3 = C03;
 	if (C11 > bestd) { bestd = C11; v0 = C01; v1 = C11; v2 = C12; v3 = C13; }
 	if (C22 > bestd) { bestd = C22; v0 = C02; v1 = C12; v2 = C22; v3 = C23; }
-	if (C33 > bestd) { bestd = C33; v0 = C03; v1 = C13; v2 = C23; v3 = C33; }
+	if (A4 && C33 > bestd) { bestd = C33; v0 = C03; v1 = C13; v2 = C23; v3 = C33; }
+	// C * v; the fourth row and column are exact zeros for an opaque block
+#define CF_MATVEC(o0, o1, o2, o3) \
+	float o0 = C00*v0; o0 = fmaf(C01, v1, o0); o0 = fmaf(C02, v2, o0); if (A4) o0 = fmaf(C03, v3, o0); \
+	float o1 = C01*v0; o1 = fmaf(C11, v1, o1); o1 = fmaf(C12, v2, o1); if (A4) o1 = fmaf(C13, v3, o1); \
+	float o2 = C02*v0; o2 = fmaf(C12, v1, o2); o2 = fmaf(C22, v2, o2); if (A4) o2 = fmaf(C23, v3, o2); \
+	float o3 = 0.0f; \
+	if (A4) { o3 = C03*v0; o3 = fmaf(C13, v1, o3); o3 = fmaf(C23, v2, o3); o3 = fmaf(C33, v3, o3); }
 #pragma unroll
 	for (int it = 0; it < 3; ++it) {
-		float r0 = C00*v0; r0 = fmaf(C01, v1, r0); r0 = fmaf(C02, v2, r0); r0 = fmaf(C03, v3, r0);
-		float r1 = C01*v0; r1 = fmaf(C11, v1, r1); r1 = fmaf(C12, v2, r1); r1 = fmaf(C13, v3, r1);
-		float r2 = C02*v0; r2 = fmaf(C12, v1, r2); r2 = fmaf(C22, v2, r2); r2 = fmaf(C23, v3, r2);
-		float r3 = C03*v0; r3 = fmaf(C13, v1, r3); r3 = fmaf(C23, v2, r3); r3 = fmaf(C33, v3, r3);
+		CF_MATVEC(r0, r1, r2, r3)
 		v0 = r0; v1 = r1; v2 = r2; v3 = r3;
 	}
-	const float mx = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
+	float mx = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fabsf(v2));
+	if (A4) mx = fmaxf(mx, fabsf(v3));
 	float tr = C00 + C11;
 	tr = tr + C22;
-	tr = tr + C33;
+	if (A4) tr = tr + C33;
 	float res = 0.0f;
 	if (mx > 0.0f) {
 		const float im = 1.0f/mx;
-		v0 = v0*im; v1 = v1*im; v2 = v2*im; v3 = v3*im;
-		float w0 = C00*v0; w0 = fmaf(C01, v1, w0); w0 = fmaf(C02, v2, w0); w0 = fmaf(C03, v3, w0);
-		float w1 = C01*v0; w1 = fmaf(C11, v1, w1); w1 = fmaf(C12, v2, w1); w1 = fmaf(C13, v3, w1);
-		float w2 = C02*v0; w2 = fmaf(C12, v1, w2); w2 = fmaf(C22, v2, w2); w2 = fmaf(C23, v3, w2);
-		float w3 = C03*v0; w3 = fmaf(C13, v1, w3); w3 = fmaf(C23, v2, w3); w3 = fmaf(C33, v3, w3);
+		v0 = v0*im; v1 = v1*im; v2 = v2*im; v3 = A4 ? v3*im : 0.0f;
+		CF_MATVEC(w0, w1, w2, w3)
 		float num = v0*w0;
 		num = fmaf(v1, w1, num);
 		num = fmaf(v2, w2, num);
-		num = fmaf(v3, w3, num);
+		if (A4) num = fmaf(v3, w3, num);
 		float den = v0*v0;
 		den = fmaf(v1, v1, den);
 		den = fmaf(v2, v2, den);
-		den = fmaf(v3, v3, den);
+		if (A4) den = fmaf(v3, v3, den);
 		const float lam = num*(1.0f/den);
 		res = (tr - lam)*(1.0f/(float)n);
 		res = res > 0.0f ? res : 0.0f;
 	}
+#undef CF_MATVEC
 	return res;
 }
 
@@ -832,7 +838,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 							for (int i = 0; i < 16; ++i)
 								mask |= (((p3 >> (2*i)) & 3u) == sb ? 1u : 0u) << i;
 						}
-						sc = sc + subset_residual(txp, mask);
+						sc = sc + (any_alpha ? subset_residual<true>(txp, mask) : subset_residual<false>(txp, mask));
 					}
 					const uint32_t kk = (__float_as_uint(sc) & ~63u) | part;
 					if (pi == 0u) key0[0] = kk; else key0[1] = kk;
