@@ -531,7 +531,7 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 		const int mean = n ? (int)cf_div_small((uint32_t)(2*sum[c] + n), (uint32_t)(2*n)) : 0;
 		q0[c] = (mean*maxq + 127)/255;
 	}
-	uint32_t berr = 0xFFFFFFFFu, bcand = 0, bq = 0, dummy = 0;
+	uint32_t berr = 0xFFFFFFFFu, bcand = 0, bq = 0;
 	const HalfTex ht8 = load_half(tp, o, flip, sub);
 	const bool unitw = o.wt[0] == 1 && o.wt[1] == 1 && o.wt[2] == 1;   // uniform
 	const int tma = o.punch ? 0 : k_etc_mod[t][0], tmb = k_etc_mod[t][1];
@@ -566,6 +566,7 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 	// group index = fam4*4 + flip*2 + sub
 	// differential: pull the second base colour into the delta window of the first
 	uint32_t q2p[2], e2[2], t2[2];
+	bool need[2];
 #pragma unroll
 	for (int f = 0; f < 2; ++f) {
 		const uint32_t a = hq[2*f], b = hq[2*f + 1];
@@ -582,16 +583,24 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 		q2p[f] = qq;
 		e2[f] = herr[2*f + 1];
 		t2[f] = ht[2*f + 1];
-		const bool need = !inside;   // uniform across the wave
-		if (need) {
-			const int c[3] = {ex5((int)(qq & 255u)), ex5((int)((qq >> 8) & 255u)),
-				ex5((int)((qq >> 16) & 255u))};
-			const uint32_t e = half_err<false>(tp, o, half_mask((uint32_t)f, 1u), c, (int)t, dummy);
-			unsigned long long k2 = ((unsigned long long)e << 32) | t;
-			uint32_t pay = 0;
-			group_min8(k2, pay);
-			e2[f] = (uint32_t)__shfl((int)(uint32_t)(k2 >> 32), 0, 64);
-			t2[f] = (uint32_t)__shfl((int)(uint32_t)k2, 0, 64) & 7u;
+		need[f] = !inside;   // uniform across the wave
+	}
+	if (need[0] || need[1]) {
+		// re-score the clamped second colours: the lanes of group (5-bit, flip f, second half)
+		// hold exactly that half in registers (ht8) and their table, so ONE pass of the fast
+		// error serves both flips; the other groups compute along and are ignored
+		const uint32_t qq = flip ? q2p[1] : q2p[0];
+		const int c[3] = {ex5((int)(qq & 255u)), ex5((int)((qq >> 8) & 255u)), ex5((int)((qq >> 16) & 255u))};
+		const uint32_t e = unitw ? half_err_fast<true>(ht8, o, c, tma, tmb) : half_err_fast<false>(ht8, o, c, tma, tmb);
+		unsigned long long k2 = ((unsigned long long)e << 32) | t;
+		uint32_t pay = 0;
+		group_min8(k2, pay);
+#pragma unroll
+		for (int f = 0; f < 2; ++f) {
+			const uint32_t ef = (uint32_t)__shfl((int)(uint32_t)(k2 >> 32), 8*(2*f + 1), 64);
+			const uint32_t tf = (uint32_t)__shfl((int)(uint32_t)k2, 8*(2*f + 1), 64) & 7u;
+			e2[f] = need[f] ? ef : e2[f];
+			t2[f] = need[f] ? tf : t2[f];
 		}
 	}
 	// candidates in id order: 0,1 differential (flip 0,1); 2,3 individual
