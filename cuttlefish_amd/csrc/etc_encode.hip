@@ -169,7 +169,9 @@ __device__ __forceinline__ uint32_t half_err_fast(const HalfTex& h, const RgbOpt
 
 struct PlanarQ { int O[3], H[3], V[3]; };
 
-__device__ __forceinline__ uint32_t planar_err(const uint32_t* tp, const RgbOpts& o, const PlanarQ& q)
+// sum over texels [i0, i0 + cnt) (a move is scored by two lanes, eight texels each)
+__device__ __forceinline__ uint32_t planar_err(const uint32_t* tp, const RgbOpts& o, const PlanarQ& q,
+	uint32_t i0, uint32_t cnt)
 {
 	int O[3], H[3], V[3];
 #pragma unroll
@@ -180,7 +182,7 @@ __device__ __forceinline__ uint32_t planar_err(const uint32_t* tp, const RgbOpts
 	}
 	uint32_t e = 0;
 #pragma unroll 1
-	for (uint32_t i = 0; i < 16u; ++i) {
+	for (uint32_t i = i0; i < i0 + cnt; ++i) {
 		if (!((o.active >> i) & 1u))
 			continue;
 		const int x = (int)(i & 3u), y = (int)(i >> 2);
@@ -293,8 +295,11 @@ __device__ __forceinline__ void th_paint(const ThCand& t, uint32_t (&paint)[4])
 
 // error of candidate t over the texels of `active` (exact weighted SSE through the dot4
 // expansion, as half_err_fast); px: the 16 texels' RGB bytes, pp: sum_active sum_c w_c p_c^2
+// The sum runs over texels [i0, i0 + cnt): a candidate is scored by 2 or 4 neighbouring lanes,
+// each taking a share of the block (the caller adds the shares up and adds pp).  Returns
+// 0xFFFFFFFF for a candidate that cannot be encoded.
 template <bool UNITW>
-__device__ __forceinline__ uint32_t th_err(const uint32_t* tp, uint32_t active, uint32_t pp,
+__device__ __forceinline__ uint32_t th_err(const uint32_t* tp, uint32_t active, uint32_t i0, uint32_t cnt,
 	const RgbOpts& o, const ThCand& t)
 {
 	if (!th_encodable(t))
@@ -317,11 +322,11 @@ __device__ __forceinline__ uint32_t th_err(const uint32_t* tp, uint32_t active, 
 		}
 		asm volatile("" : "+v"(nb[v]));   // keep (d << 1) + nb one v_lshl_add_u32 (see half_err_fast)
 	}
-	uint32_t total = pp;
-	// texels from LDS (wave-uniform address) in a rolled loop: a register copy of the block
-	// would cost the kernel a wave of occupancy
+	uint32_t total = 0;
+	// texels from LDS in a rolled loop: a register copy of the block would cost the kernel a
+	// wave of occupancy
 #pragma unroll 2
-	for (uint32_t i = 0; i < 16u; ++i) {
+	for (uint32_t i = i0; i < i0 + cnt; ++i) {
 		const uint32_t p = tp[i] & 0x00FFFFFFu;
 		int best = -0x7FFFFFFF;
 #pragma unroll
@@ -403,22 +408,26 @@ __device__ __forceinline__ bool th_search(const uint32_t* tp, const RgbOpts& o, 
 		m0 |= (uint32_t)((a*15 + 127)/255) << (4*c);
 		m1 |= (uint32_t)((b*15 + 127)/255) << (4*c);
 	}
-	// candidates: id = 5 + lane, lane = variant*8 + distance
+	// candidates: id = 5 + cand, cand = variant*8 + distance; two lanes per candidate, eight
+	// texels each (lanes 2c and 2c + 1, shares added through DPP)
 	ThCand t;
+	const uint32_t cand = lane >> 1;
 	{
-		const uint32_t v = lane >> 3;
+		const uint32_t v = cand >> 3;
 		t.mode = v == 2u ? 2 : 1;
-		t.di = (int)(lane & 7u);
+		t.di = (int)(cand & 7u);
 		t.c0 = v == 1u ? m1 : m0;
 		t.c1 = v == 1u ? m0 : m1;
-		t.err = lane < 24u ? th_err<UNITW>(tp, o.active, pp, o, t) : 0xFFFFFFFFu;
+		const uint32_t part = th_err<UNITW>(tp, o.active, (lane & 1u)*8u, 8u, o, t);
+		const uint32_t both = part + cf_xor1(part);
+		t.err = (cand < 24u && part != 0xFFFFFFFFu) ? pp + both : 0xFFFFFFFFu;
 	}
-	unsigned long long key = ((unsigned long long)t.err << 32) | lane;
+	unsigned long long key = ((unsigned long long)t.err << 32) | cand;
 	unsigned long long kmin = cf_wave_min_u64(key);
 	if ((uint32_t)(kmin >> 32) == 0xFFFFFFFFu)
 		return false;
 	{
-		const int src = (int)(uint32_t)kmin;   // winning lane
+		const int src = (int)(2u*(uint32_t)kmin);   // first lane of the winning candidate
 		best.mode = __shfl(t.mode, src, 64);
 		best.c0 = (uint32_t)__shfl((int)t.c0, src, 64);
 		best.c1 = (uint32_t)__shfl((int)t.c1, src, 64);
@@ -426,11 +435,13 @@ __device__ __forceinline__ bool th_search(const uint32_t* tp, const RgbOpts& o, 
 		best.err = (uint32_t)(kmin >> 32);
 	}
 	for (int r = 0; r < rounds; ++r) {
+		// 14 single moves, four lanes per move (four texels each)
 		ThCand mvc = best;
-		bool ok = lane < 14u;
-		const int d = (lane & 1u) ? 1 : -1;
-		if (lane < 12u) {
-			const int f = (int)(lane >> 1);
+		const uint32_t mv = lane >> 2;
+		bool ok = mv < 14u;
+		const int d = (mv & 1u) ? 1 : -1;
+		if (mv < 12u) {
+			const int f = (int)(mv >> 1);
 			const uint32_t cw = f < 3 ? mvc.c0 : mvc.c1;
 			const int sh = 4*(f % 3), nv = (int)((cw >> sh) & 15u) + d;
 			ok = nv >= 0 && nv <= 15;
@@ -441,12 +452,15 @@ __device__ __forceinline__ bool th_search(const uint32_t* tp, const RgbOpts& o, 
 			ok = ok && nv >= 0 && nv <= 7;
 			mvc.di = nv & 7;
 		}
-		const uint32_t e = ok ? th_err<UNITW>(tp, o.active, pp, o, mvc) : 0xFFFFFFFFu;
-		key = ((unsigned long long)e << 32) | lane;
+		const uint32_t part = th_err<UNITW>(tp, o.active, (lane & 3u)*4u, 4u, o, mvc);
+		uint32_t sum4 = part + cf_xor1(part);
+		sum4 += cf_xor2(sum4);
+		const uint32_t e = (ok && part != 0xFFFFFFFFu) ? pp + sum4 : 0xFFFFFFFFu;
+		key = ((unsigned long long)e << 32) | mv;
 		kmin = cf_wave_min_u64(key);
 		if ((uint32_t)(kmin >> 32) >= best.err)
 			break;
-		const int src = (int)(uint32_t)kmin;
+		const int src = (int)(4u*(uint32_t)kmin);
 		best.c0 = (uint32_t)__shfl((int)mvc.c0, src, 64);
 		best.c1 = (uint32_t)__shfl((int)mvc.c1, src, 64);
 		best.di = __shfl(mvc.di, src, 64);
@@ -640,12 +654,17 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 		}
 		uint32_t ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)planar_err_rows(tp, o, pq, lane));
 		for (int round = 0; round < (o.refine ? 2 : 0); ++round) {
+			// 18 single-field moves, two lanes per move (eight texels each)
 			unsigned long long mk = ~0ull;
-			if (lane < 18u) {
-				const int f = (int)(lane >> 1), d = (lane & 1u) ? 1 : -1;
+			{
+				const uint32_t mv = lane >> 1;
+				const int f = (int)(mv >> 1), d = (mv & 1u) ? 1 : -1;
 				PlanarQ tq = pq;
-				if (planar_move(tq, f, d))
-					mk = ((unsigned long long)planar_err(tp, o, tq) << 32) | lane;
+				const bool okm = planar_move(tq, mv < 18u ? f : 0, d) && mv < 18u;
+				const uint32_t part = planar_err(tp, o, tq, (lane & 1u)*8u, 8u);
+				const uint32_t both = part + cf_xor1(part);
+				if (okm)
+					mk = ((unsigned long long)both << 32) | mv;
 			}
 			const unsigned long long mm = cf_wave_min_u64(mk);
 			if ((uint32_t)(mm >> 32) >= ep)
@@ -892,7 +911,7 @@ __device__ __forceinline__ uint32_t r11_word(float f, bool snorm)
 // ETC2 RGBA8 (RGB search + EAC alpha in one kernel), which gets 3
 template <int PIX, int FMT, bool SNORM>
 __global__ void __launch_bounds__(CF_WG_THREADS)
-__attribute__((amdgpu_waves_per_eu(FMT == E_A8 ? 3 : 4, 8)))
+__attribute__((amdgpu_waves_per_eu((FMT == E_A8 || FMT == E_A1) ? 3 : 4, 8)))
 cfhip_etc_encode_kernel(cf_kparams kp)
 {
 	constexpr bool IS_EAC = FMT == E_R11 || FMT == E_RG11;
