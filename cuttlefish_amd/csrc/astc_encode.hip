@@ -66,7 +66,8 @@ __device__ __forceinline__ float clampf255(float x) { return x < 0.0f ? 0.0f : (
 __device__ const uint8_t k_inset[8][2] = {{0, 0}, {1, 1}, {2, 2}, {3, 3}, {1, 0}, {0, 1}, {2, 0},
 	{0, 2}};
 
-// reconstructed weight of texel i from this lane's quantised grid (private LDS column)
+// reconstructed weight of texel i from this lane's quantised grid (private LDS column; the
+// slots hold unquantised | quantised << 8, so the bit replication is done once per grid point)
 __device__ __forceinline__ int texel_weight(const CfgView& cfg, uint32_t i, const uint8_t* qcol,
 	uint32_t N, int bits, uint32_t rows)
 {
@@ -77,9 +78,10 @@ __device__ __forceinline__ int texel_weight(const CfgView& cfg, uint32_t i, cons
 	// index clamped) and multiplies it away -- no per-lane branches on the load chain
 	const uint32_t g1 = v0 + 1u < rows ? v0 + 1u : v0, g2 = v0 + N < rows ? v0 + N : v0,
 		g3 = v0 + N + 1u < rows ? v0 + N + 1u : v0;
-	const int q0 = qcol[v0*128u], q1 = qcol[g1*128u], q2 = qcol[g2*128u], q3 = qcol[g3*128u];
-	const int v = (int)w00*unq_weight(q0, bits) + (int)w01*unq_weight(q1, bits) +
-		(int)w10*unq_weight(q2, bits) + (int)w11*unq_weight(q3, bits) + 8;
+	// low byte of a slot: the weight already unquantised to 0..64 (high byte: its quantised form)
+	const int u0 = qcol[v0*128u], u1 = qcol[g1*128u], u2 = qcol[g2*128u], u3 = qcol[g3*128u];
+	(void)bits;
+	const int v = (int)w00*u0 + (int)w01*u1 + (int)w10*u2 + (int)w11*u3 + 8;
 	return v >> 4;
 }
 
@@ -87,6 +89,13 @@ __device__ __forceinline__ uint32_t astc_error(const uint32_t* tp, uint32_t n, u
 	const int (&e0)[4], const int (&e1)[4], const CfgView& cfg, const uint8_t* qcol, uint32_t N, int bits,
 	uint32_t rows)
 {
+	// ((e0*257*(64 - w) + e1*257*w + 32) >> 6) >> 8  ==  (base + slope*w) >> 14, all terms >= 0
+	int base[4], slope[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		base[c] = e0[c]*257*64 + 32;
+		slope[c] = (e1[c] - e0[c])*257;
+	}
 	uint32_t err = 0;
 #pragma unroll 1
 	for (uint32_t i = 0; i < n; ++i) {
@@ -95,7 +104,7 @@ __device__ __forceinline__ uint32_t astc_error(const uint32_t* tp, uint32_t n, u
 #pragma unroll
 		for (uint32_t c = 0; c < 4u; ++c) {
 			if (c < nc) {
-				const int v = ((e0[c]*257*(64 - w) + e1[c]*257*w + 32) >> 6) >> 8;
+				const int v = (base[c] + slope[c]*w) >> 14;
 				const int d = v - (int)((p >> (8u*c)) & 255u);
 				err += (uint32_t)(d*d);
 			}
@@ -372,11 +381,22 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			for (uint32_t g = 0; g < ng; ++g) {
 				const uint32_t den = cfg.den(g);
 				const uint32_t gv = den ? div_small((uint32_t)ncol[g*64u] + den/2u, den, 1.0f/(float)den) : 0u;
-				ncol[g*64u] = (uint16_t)((gv*(uint32_t)qmax + 32u) >> 6);   // quantised weight, read back as a byte
+				const uint32_t qv = (gv*(uint32_t)qmax + 32u) >> 6;         // quantised weight
+				ncol[g*64u] = (uint16_t)((uint32_t)unq_weight((int)qv, bits) | (qv << 8));
 			}
-			err = astc_error(tp, n, nc, e0, e1, cfg, qcol, N, bits, rows);
-			if (refit) {
+			if (!refit)
+				err = astc_error(tp, n, nc, e0, e1, cfg, qcol, N, bits, rows);
+			else {
+				// the first error and the least-squares sums of the refit in ONE pass over the
+				// texels: each texel's weight is reconstructed once for both
 				int S = 0, A = 0, B = 0, C = 0, U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
+				int base[4], slope[4];
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					base[c] = e0[c]*257*64 + 32;
+					slope[c] = (e1[c] - e0[c])*257;
+				}
+				err = 0;
 #pragma unroll 1
 				for (uint32_t i = 0; i < n; ++i) {
 					const int wi = texel_weight(cfg, i, qcol, N, bits, rows), iw = 64 - wi;
@@ -385,8 +405,11 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 #pragma unroll
 					for (uint32_t c = 0; c < 4u; ++c) {
 						if (c < nc) {
-							U[c] += iw*(int)((p >> (8u*c)) & 255u);
-							V[c] += wi*(int)((p >> (8u*c)) & 255u);
+							const int pc = (int)((p >> (8u*c)) & 255u);
+							U[c] += iw*pc;
+							V[c] += wi*pc;
+							const int d = ((base[c] + slope[c]*wi) >> 14) - pc;
+							err += (uint32_t)(d*d);
 						}
 					}
 				}
@@ -451,7 +474,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			}
 			for (uint32_t g = hl; g < wng; g += gsz) {
 				// weight g: its bits go to 127 - (g*bits + kb), i.e. the reversed field at 128 - (g+1)*bits
-				const uint32_t fld = __brev((uint32_t)wq[g*128u]) >> (32u - wbits);
+				const uint32_t fld = __brev((uint32_t)wq[g*128u + 1u]) >> (32u - wbits);   // high byte: quantised
 				const uint32_t pos = 128u - (g + 1u)*wbits;
 				const unsigned long long vv = (unsigned long long)fld;
 				if (pos < 64u) {
