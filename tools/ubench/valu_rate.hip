@@ -46,6 +46,25 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, uint32_t seed)
 	if (OP == 20) BODY("v_sub_u32 %0, %1, %0", )
 	if (OP == 21) BODY("v_lshl_or_b32 %0, %0, 8, %1", )
 	if (OP == 22) BODY("v_add3_u32 %0, %0, %1, %2", )
+	if (OP == 23) BODY("v_mad_i32_i24 %0, %0, %1, %2", )
+	if (OP == 24) BODY("v_mul_i32_i24 %0, %0, %1", )
+	if (OP == 25) BODY("v_sad_u8 %0, %0, %1, %2", )
+	if (OP == 26) BODY("v_med3_i32 %0, %0, %1, %2", )
+	if (OP == 27) BODY("v_ashrrev_i32 %0, 3, %0", )
+	if (OP == 28) {   // 64-bit accumulate: the destination is a register pair
+		unsigned long long acc[8];
+#pragma unroll
+		for (int i = 0; i < 8; ++i) acc[i] = a[i];
+		for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+			for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+				for (int i = 0; i < 8; ++i)
+					asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(b), "v"(c) : "vcc");
+		}
+#pragma unroll
+		for (int i = 0; i < 8; ++i) a[i] = (uint32_t)acc[i] ^ (uint32_t)(acc[i] >> 32);
+	}
 	uint32_t r = 0;
 #pragma unroll
 	for (int i = 0; i < 16; ++i) r ^= a[i];
@@ -89,6 +108,8 @@ int main()
 		run<2>("v_dot4_u32_u8", w);   run<14>("v_mov_b32_dpp", w);
 		run<10>("v_cvt_f32_u32", w);  run<19>("v_cvt_f32_ubyte0", w); run<11>("v_floor_f32", w);
 		run<1>("v_fma_f32", w);       run<15>("v_mul_f32", w);     run<16>("v_add_f32", w);
+		run<23>("v_mad_i32_i24", w);  run<24>("v_mul_i32_i24", w); run<25>("v_sad_u8", w);
+		run<26>("v_med3_i32", w);     run<27>("v_ashrrev_i32", w); run<28>("v_mad_u64_u32", w);
 	}
 	return 0;
 }
