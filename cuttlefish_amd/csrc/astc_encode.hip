@@ -71,13 +71,14 @@ __device__ const uint8_t k_inset[8][2] = {{0, 0}, {1, 1}, {2, 2}, {3, 3}, {1, 0}
 __device__ __forceinline__ int texel_weight(const CfgView& cfg, uint32_t i, const uint8_t* qcol,
 	uint32_t N, int bits, uint32_t rows)
 {
-	const uint2 f = cfg.infill(i);
-	const uint32_t v0 = f.x & 255u, w00 = (f.x >> 8) & 255u, w01 = (f.x >> 16) & 255u,
-		w10 = f.x >> 24, w11 = f.y & 255u;
-	// straight-line: a zero factor reads a neighbour inside the lane's 64-entry column (grid
-	// index clamped) and multiplies it away -- no per-lane branches on the load chain
-	const uint32_t g1 = v0 + 1u < rows ? v0 + 1u : v0, g2 = v0 + N < rows ? v0 + N : v0,
-		g3 = v0 + N + 1u < rows ? v0 + N + 1u : v0;
+	const uint2 f = cfg.infill(i);   // .x: the four grid points (255 = none), .y: their factors
+	const uint32_t w00 = f.y & 255u, w01 = (f.y >> 8) & 255u, w10 = (f.y >> 16) & 255u, w11 = f.y >> 24;
+	// straight-line: a missing neighbour reads the column's dummy row (rows - 1) and is
+	// multiplied away by its zero factor -- no per-lane branches on the load chain
+	const uint32_t dummy = rows - 1u;
+	(void)N;
+	const uint32_t v0 = f.x & 255u, g1 = min((f.x >> 8) & 255u, dummy), g2 = min((f.x >> 16) & 255u, dummy),
+		g3 = min(f.x >> 24, dummy);
 	// low byte of a slot: the weight already unquantised to 0..64 (high byte: its quantised form)
 	const int u0 = qcol[v0*128u], u1 = qcol[g1*128u], u2 = qcol[g2*128u], u3 = qcol[g3*128u];
 	(void)bits;
@@ -365,13 +366,12 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					T = T > 64 ? 64 : T;
 				}
 				const uint2 f = cfg.infill(i);
-				const uint32_t g0 = f.x & 255u, w00 = (f.x >> 8) & 255u, w01 = (f.x >> 16) & 255u,
-					w10 = f.x >> 24, w11 = f.y & 255u;
+				const uint32_t w00 = f.y & 255u, w01 = (f.y >> 8) & 255u, w10 = (f.y >> 16) & 255u, w11 = f.y >> 24;
 				// straight-line read-modify-write of the four grid accumulators: neighbours that do
-				// not exist go to the column's dummy row 64 with a zero factor; the real entries
-				// are distinct (N >= 2), so all loads can be issued before the stores
-				const uint32_t g1 = g0 + 1u < dummy ? g0 + 1u : dummy, g2 = g0 + N < dummy ? g0 + N : dummy,
-					g3 = g0 + N + 1u < dummy ? g0 + N + 1u : dummy;
+				// not exist (255 in the record) go to the column's dummy row with a zero factor; the
+				// real entries are distinct (N >= 2), so all loads can be issued before the stores
+				const uint32_t g0 = f.x & 255u, g1 = min((f.x >> 8) & 255u, dummy), g2 = min((f.x >> 16) & 255u, dummy),
+					g3 = min(f.x >> 24, dummy);
 				const uint32_t a0 = ncol[g0*64u], a1 = ncol[g1*64u], a2 = ncol[g2*64u], a3 = ncol[g3*64u];
 				ncol[g0*64u] = (uint16_t)(a0 + w00*(uint32_t)T);
 				ncol[g1*64u] = (uint16_t)(a1 + w01*(uint32_t)T);

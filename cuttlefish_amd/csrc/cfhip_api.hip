@@ -175,8 +175,12 @@ std::vector<uint8_t> astc_build_tables(int bw, int bh)
 					const int js = gs >> 4, fs = gs & 15, jt = gt >> 4, ft = gt & 15;
 					const int w11 = (fs*ft + 8) >> 4, w10 = ft - w11, w01 = fs - w11;
 					const int w00 = 16 - fs - ft + w11, v0 = js + jt*N;
-					const uint32_t a = (uint32_t)v0 | ((uint32_t)w00 << 8) | ((uint32_t)w01 << 16) |
-						((uint32_t)w10 << 24), b = (uint32_t)w11;
+					// the four grid points of the texel (255: no such neighbour, its factor is 0 --
+					// the kernel sends those to the dummy row of its column) and their factors
+					const uint32_t a = (uint32_t)v0 | ((uint32_t)(w01 ? v0 + 1 : 255) << 8) |
+						((uint32_t)(w10 ? v0 + N : 255) << 16) | ((uint32_t)(w11 ? v0 + N + 1 : 255) << 24);
+					const uint32_t b = (uint32_t)w00 | ((uint32_t)w01 << 8) | ((uint32_t)w10 << 16) |
+						((uint32_t)w11 << 24);
 					uint8_t* e = r + 136 + (size_t)(tt*bw + s)*8;
 					memcpy(e, &a, 4);
 					memcpy(e + 4, &b, 4);
