@@ -114,8 +114,39 @@ __device__ __forceinline__ uint32_t astc_error(const uint32_t* tp, uint32_t n, u
 	return err;
 }
 
+// astc_error with the texel weights read back from the lane's cache rows (footprints of up to
+// 40 texels: the refit pass stored them, two per u16 slot, behind the grid rows of the column)
+__device__ __forceinline__ uint32_t astc_error_cached(const uint32_t* tp, uint32_t n, uint32_t nc,
+	const int (&e0)[4], const int (&e1)[4], const uint8_t* wcache)
+{
+	int base[4], slope[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		base[c] = e0[c]*257*64 + 32;
+		slope[c] = (e1[c] - e0[c])*257;
+	}
+	uint32_t err = 0;
+#pragma unroll 1
+	for (uint32_t i = 0; i < n; ++i) {
+		const int w = wcache[(i >> 1)*128u + (i & 1u)];
+		const uint32_t p = tp[i];
+#pragma unroll
+		for (uint32_t c = 0; c < 4u; ++c) {
+			if (c < nc) {
+				const int v = (base[c] + slope[c]*w) >> 14;
+				const int d = v - (int)((p >> (8u*c)) & 255u);
+				err += (uint32_t)(d*d);
+			}
+		}
+	}
+	return err;
+}
+
 } // namespace
 
+#ifndef CF_ASTC_CACHE_MAX
+#define CF_ASTC_CACHE_MAX 40   // largest footprint (texels) that keeps the texel-weight cache
+#endif
 #ifndef CF_ASTC_WAVES
 #define CF_ASTC_WAVES 3
 #endif
@@ -189,7 +220,11 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	const uint32_t qcfg = q == 0u ? 1u : (q == 1u ? 2u : (q == 2u ? 4u : 8u));
 	const uint32_t qvar = q == 0u ? 1u : (q == 1u ? 2u : 8u);
 	const bool refit = q >= 2u;
-	uint16_t* ncol = lane_cols + wave*rows*64u + lane;
+	// footprints of up to 40 texels keep a per-lane cache of the reconstructed texel weights
+	// behind the grid rows (ceil(n/2) more rows): the error after the refit reads them back
+	const bool wcached = n <= (uint32_t)CF_ASTC_CACHE_MAX;   // larger footprints: the extra LDS costs more occupancy than it saves
+	const uint32_t col_rows = rows + (wcached ? (n + 1u)/2u : 0u);
+	uint16_t* ncol = lane_cols + wave*col_rows*64u + lane;
 	const uint8_t* qcol = reinterpret_cast<const uint8_t*>(ncol);   // entry g: byte offset g*128
 	const uint32_t dummy = rows - 1u;
 
@@ -400,6 +435,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 #pragma unroll 1
 				for (uint32_t i = 0; i < n; ++i) {
 					const int wi = texel_weight(cfg, i, qcol, N, bits, rows), iw = 64 - wi;
+					if (wcached)
+						const_cast<uint8_t*>(qcol)[(rows + (i >> 1))*128u + (i & 1u)] = (uint8_t)wi;
 					const uint32_t p = tp[i];
 					S += wi; A += iw*iw; B += iw*wi; C += wi*wi;
 #pragma unroll
@@ -431,7 +468,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						}
 					}
 					if (r1[0] + r1[1] + r1[2] >= r0[0] + r0[1] + r0[2]) {
-						const uint32_t e = astc_error(tp, n, nc, r0, r1, cfg, qcol, N, bits, rows);
+						const uint32_t e = wcached ? astc_error_cached(tp, n, nc, r0, r1, qcol + rows*128u)
+							: astc_error(tp, n, nc, r0, r1, cfg, qcol, N, bits, rows);
 						if (e < err) {
 							err = e;
 #pragma unroll
@@ -454,7 +492,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			const uint32_t e1w = (uint32_t)__shfl((int)((uint32_t)e1[0] | ((uint32_t)e1[1] << 8) | ((uint32_t)e1[2] << 16) | ((uint32_t)e1[3] << 24)), (int)wlane, 64);
 			const CfgView wcfg = {set + (whl >> 3)*cstride};
 			const uint32_t wng = wcfg.ng(), wbits = wcfg.bits();
-			const uint8_t* wq = reinterpret_cast<const uint8_t*>(lane_cols + wave*rows*64u + wlane);
+			const uint8_t* wq = reinterpret_cast<const uint8_t*>(lane_cols + wave*col_rows*64u + wlane);
 			unsigned long long lo64 = 0ull, hi64 = 0ull;
 			if (hl == 0u) {
 				// mode (11) | partitions-1 (2) | CEM (4) | 8-bit endpoint values e0.r e1.r e0.g ...
@@ -510,8 +548,9 @@ extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, hi
 	const uint32_t n_ = (kp->flags & 255u)*((kp->flags >> 8) & 255u), rows_ = (kp->flags >> 16) & 255u;
 	// tile + compact tables + 4 waves x rows x 64 lanes of u16 (same layout as in the kernel)
 	const uint32_t ncs_ = (kp->flags >> 24) & 15u;
+	const uint32_t col_rows_ = rows_ + (n_ <= (uint32_t)CF_ASTC_CACHE_MAX ? (n_ + 1u)/2u : 0u);   // + the texel-weight cache rows
 	const size_t dyn = (size_t)CF_BLOCKS_PER_WG*n_*4u + (8u + 2u*ncs_*(136u + 8u*n_)) +
-		(size_t)4*rows_*64u*sizeof(uint16_t);
+		(size_t)4*col_rows_*64u*sizeof(uint16_t);
 	if (pixel_type == 0)
 		hipLaunchKernelGGL((cfhip_astc_encode_kernel<0>), grid, block, dyn, stream, *kp);
 	else
