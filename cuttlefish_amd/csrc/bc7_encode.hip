@@ -310,6 +310,9 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 			const uint32_t qq = __umul24(m0, c0) + __umul24(m1, c1) + __umul24(m2, c2) + __umul24(m3, c3);
 			base[k] = valid ? -(int)((qq << 7) | w) : -0x3FFFFFFF;
 		}
+		// hide that base is a negation: "(dt << 8) + base" then stays ONE v_lshl_add_u32 per entry
+		// and texel (the compiler otherwise emits a shift and a subtract for half of them)
+		asm volatile("" : "+v"(base[k]));
 	}
 	uint32_t err = pp_sum;
 	uint32_t wp0 = 0, wp1 = 0, wp2 = 0, wp3 = 0;
