@@ -242,6 +242,31 @@ __device__ __forceinline__ uint32_t bc1_error(const uint32_t* tp, const COpts& o
 	if (!bc1_palette(a, b, mode3, o.force4, pal))
 		return 0xFFFFFFFFu;
 	const bool use3 = !mode3 || o.black;
+	if (UNITW) {
+		// max form, as in bc1_error_both: |p - q|^2 = |p|^2 - (2 p.q - |q|^2), sum |p|^2 = o.pp
+		int nq[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			nq[k] = -(int)__builtin_amdgcn_udot4(pal[k], pal[k], 0u, false);
+			if (k == 3 && !use3)
+				nq[k] = -0x3FFFFFFF;
+			asm volatile("" : "+v"(nq[k]));   // keep (dot << 1) + nq one v_lshl_add_u32
+		}
+		int acc = 0;
+#pragma unroll 1
+		for (uint32_t i = 0; i < 16u; ++i) {
+			const uint32_t p = tp[i] & 0x00FFFFFFu;
+			const int k0 = (int)(__builtin_amdgcn_udot4(p, pal[0], 0u, false) << 1) + nq[0];
+			const int k1 = (int)(__builtin_amdgcn_udot4(p, pal[1], 0u, false) << 1) + nq[1];
+			const int k2 = (int)(__builtin_amdgcn_udot4(p, pal[2], 0u, false) << 1) + nq[2];
+			const int k3 = (int)(__builtin_amdgcn_udot4(p, pal[3], 0u, false) << 1) + nq[3];
+			int m = k0 > k1 ? k0 : k1;
+			m = m > k2 ? m : k2;
+			m = m > k3 ? m : k3;
+			acc += ((o.active >> i) & 1u) ? m : 0;
+		}
+		return o.pp - (uint32_t)acc;
+	}
 	uint32_t err = 0;
 #pragma unroll 1
 	for (uint32_t i = 0; i < 16u; ++i) {
