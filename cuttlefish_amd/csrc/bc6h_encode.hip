@@ -376,52 +376,6 @@ struct Bits128 {
 	}
 };
 
-__device__ __forceinline__ uint4 pack_bc6h(const HCand& c)
-{
-	const Bc6Mode md = k_bc6_modes[c.mode];
-	Bits128 b = {0ull, 0ull};
-	b.put(0u, md.mode_val, md.mode_bits);
-	// field values: RW RX RY RZ GW GX GY GZ BW BX BY BZ D
-	uint32_t f[13];
-	const uint32_t ne = md.two_subsets ? 4u : 2u;
-#pragma unroll
-	for (int ch = 0; ch < 3; ++ch) {
-		f[4*ch] = (uint32_t)c.q[0][ch] & ((1u << md.ebits) - 1u);
-#pragma unroll
-		for (int k = 1; k < 4; ++k) {
-			const int val = md.transformed ? c.q[k][ch] - c.q[0][ch] : c.q[k][ch];
-			f[4*ch + k] = (uint32_t)k < ne ? ((uint32_t)val & ((1u << md.d[ch]) - 1u)) : 0u;
-		}
-	}
-	f[12] = c.part;
-	for (uint32_t ri = 0; ri < md.nruns; ++ri) {
-		const uint32_t rw = k_bc6_runs[c.mode][ri];
-		const uint32_t start = rw & 255u, field = (rw >> 8) & 15u, flo = (rw >> 12) & 15u;
-		const int count = (int)(signed char)((rw >> 16) & 255u);
-		uint32_t fv = 0;
-#pragma unroll
-		for (int k = 0; k < 13; ++k)
-			fv = field == (uint32_t)k ? f[k] : fv;
-		if (count > 0)
-			b.put(start, fv >> flo, (uint32_t)count);
-		else
-			for (int i = 0; i < -count; ++i)
-				b.put(start + (uint32_t)i, (fv >> (flo - (uint32_t)i)) & 1u, 1u);
-	}
-	uint32_t pos = md.two_subsets ? 82u : 65u;
-	const uint32_t ib = md.two_subsets ? 3u : 4u;
-	const uint32_t anchor1 = md.two_subsets ? (uint32_t)k6_anchor2[c.part] : 0u;
-	const uint32_t m1 = md.two_subsets ? (uint32_t)k6_part2[c.part] : 0u;
-#pragma unroll 1
-	for (uint32_t i = 0; i < 16u; ++i) {
-		const uint32_t s = (m1 >> i) & 1u;
-		const uint32_t nb = ib - ((i == 0u || (s && i == anchor1)) ? 1u : 0u);
-		b.put(pos, (uint32_t)((c.idx >> (4u*i)) & 15ull), nb);
-		pos += nb;
-	}
-	return make_uint4((uint32_t)b.lo, (uint32_t)(b.lo >> 32), (uint32_t)b.hi, (uint32_t)(b.hi >> 32));
-}
-
 // pack_bc6h spread over the wavefront (a serial pack by the winning lane costs the whole wave
 // ~1300 instructions: 24 bit runs x a 13-way field select + the 16 index fields).  The winner's
 // candidate is read from its LDS slot, lane r < 24 places bit run r, lane 24 the mode bits,

@@ -54,42 +54,6 @@ __device__ __forceinline__ uint32_t half_mask(uint32_t flip, uint32_t sub)
 	return flip ? (sub ? 0xFF00u : 0x00FFu) : (sub ? 0xCCCCu : 0x3333u);
 }
 
-// error of one half for base colour c and table t; sel (2 bits per texel) when WANT_SEL
-template <bool WANT_SEL>
-__device__ __forceinline__ uint32_t half_err(const uint32_t* tp, const RgbOpts& o, uint32_t hmask,
-	const int (&c)[3], int t, uint32_t& sel)
-{
-	uint32_t total = 0;
-	const int ma = o.punch ? 0 : k_etc_mod[t][0], mb = k_etc_mod[t][1];
-#pragma unroll 1
-	for (uint32_t i = 0; i < 16u; ++i) {
-		if (!((hmask >> i) & 1u))
-			continue;
-		if ((o.transparent >> i) & 1u) {
-			if (WANT_SEL) sel |= 2u << (2u*i);
-			continue;
-		}
-		const uint32_t p = tp[i];
-		const int p0 = (int)(p & 255u), p1 = (int)((p >> 8) & 255u), p2 = (int)((p >> 16) & 255u);
-		uint32_t best = 0xFFFFFFFFu;
-		uint32_t bv = 0;
-#pragma unroll
-		for (int v = 0; v < 4; ++v) {
-			if (v == 2 && o.punch)
-				continue;
-			const int m = v == 0 ? ma : (v == 1 ? mb : (v == 2 ? -ma : -mb));
-			const int d0 = clamp255(c[0] + m) - p0, d1 = clamp255(c[1] + m) - p1,
-				d2 = clamp255(c[2] + m) - p2;
-			const uint32_t e = (uint32_t)(o.wt[0]*d0*d0) + (uint32_t)(o.wt[1]*d1*d1) +
-				(uint32_t)(o.wt[2]*d2*d2);
-			if (e < best) { best = e; bv = (uint32_t)v; }
-		}
-		if (WANT_SEL) sel |= bv << (2u*i);
-		total += ((o.active >> i) & 1u) ? best : 0u;
-	}
-	return total;
-}
-
 // The lane's half as 8 texels in registers + which of them carry error weight, so that the
 // base-colour walk below touches neither LDS nor masks.  (Every VALU instruction costs the
 // wave the same whatever the number of active lanes: per-lane `continue`s save nothing.)
@@ -120,7 +84,7 @@ __device__ __forceinline__ HalfTex load_half(const uint32_t* tp, const RgbOpts& 
 	return h;
 }
 
-// half_err<false> on a HalfTex: sum over counted texels of min_v sum_c w_c (clamp(c+m_v) - p_c)^2,
+// Error of the lane's half (a HalfTex): sum over counted texels of min_v sum_c w_c (clamp(c+m_v) - p_c)^2,
 // expanded as |p|^2 - 2 p.(w q_v) + sum w q_v^2 with the cross term on v_dot4 (w q_v <= 2550 is
 // split into a low and a high byte plane when the weights are not all 1).
 template <bool UNITW>
