@@ -241,6 +241,18 @@ __device__ __forceinline__ bool th_encodable(const ThCand& t)
 	return w1 != w2 || (t.di & 1);
 }
 
+// H mode: the order of the two colours the block must store (it carries di's low bit)
+__device__ __forceinline__ void th_canonical(ThCand& t)
+{
+	if (t.mode == 2) {
+		const uint32_t w1 = (uint32_t)(th_field(t.c0, 0) << 8 | th_field(t.c0, 1) << 4 | th_field(t.c0, 2));
+		const uint32_t w2 = (uint32_t)(th_field(t.c1, 0) << 8 | th_field(t.c1, 1) << 4 | th_field(t.c1, 2));
+		if ((w1 >= w2) != ((t.di & 1) != 0)) {
+			const uint32_t tmp = t.c0; t.c0 = t.c1; t.c1 = tmp;
+		}
+	}
+}
+
 // the four paint colours as RGB byte words
 __device__ __forceinline__ void th_paint(const ThCand& t, uint32_t (&paint)[4])
 {
@@ -269,7 +281,14 @@ __device__ __forceinline__ uint32_t th_err(const uint32_t* tp, uint32_t active, 
 	if (!th_encodable(t))
 		return 0xFFFFFFFFu;
 	uint32_t paint[4];
-	th_paint(t, paint);
+	if (o.punch) {
+		// punch-through: paint colour 2 is the transparent one, so the pairs are not symmetric in
+		// H mode any more -- score the candidate in the colour order the block will store
+		ThCand tc = t;
+		th_canonical(tc);
+		th_paint(tc, paint);
+	} else
+		th_paint(t, paint);
 	uint32_t ql[4], qh[4];
 	int nb[4];
 #pragma unroll
@@ -284,6 +303,8 @@ __device__ __forceinline__ uint32_t th_err(const uint32_t* tp, uint32_t active, 
 			qh[v] = (w0 >> 8) | ((w1 >> 8) << 8) | ((w2 >> 8) << 16);
 			nb[v] = -(int)(w0*q0 + w1*q1 + w2*q2);
 		}
+		if (v == 2 && o.punch)
+			nb[v] = -0x3FFFFFFF;   // opaque texels cannot take the transparent selector
 		asm volatile("" : "+v"(nb[v]));   // keep (d << 1) + nb one v_lshl_add_u32 (see half_err_fast)
 	}
 	uint32_t total = 0;
@@ -314,7 +335,9 @@ __device__ __forceinline__ uint32_t th_selector(uint32_t p, const RgbOpts& o, co
 	for (int v = 0; v < 4; ++v) {
 		const int d0 = (int)(paint[v] & 255u) - (int)(p & 255u), d1 = (int)((paint[v] >> 8) & 255u) - (int)((p >> 8) & 255u),
 			d2 = (int)(paint[v] >> 16) - (int)((p >> 16) & 255u);
-		const uint32_t e = (uint32_t)(o.wt[0]*d0*d0) + (uint32_t)(o.wt[1]*d1*d1) + (uint32_t)(o.wt[2]*d2*d2);
+		uint32_t e = (uint32_t)(o.wt[0]*d0*d0) + (uint32_t)(o.wt[1]*d1*d1) + (uint32_t)(o.wt[2]*d2*d2);
+		if (v == 2 && o.punch)
+			e = 0xFFFFFFFFu;
 		if (e < best) { best = e; bv = (uint32_t)v; }
 	}
 	return bv;
@@ -436,18 +459,14 @@ __device__ __forceinline__ bool th_search(const uint32_t* tp, const RgbOpts& o, 
 template <bool UNITW>
 __device__ __forceinline__ uint2 pack_th(const uint32_t* tp, const RgbOpts& o, ThCand t, uint32_t lane)
 {
-	if (t.mode == 2) {
-		const uint32_t w1 = (uint32_t)(th_field(t.c0, 0) << 8 | th_field(t.c0, 1) << 4 | th_field(t.c0, 2));
-		const uint32_t w2 = (uint32_t)(th_field(t.c1, 0) << 8 | th_field(t.c1, 1) << 4 | th_field(t.c1, 2));
-		if ((w1 >= w2) != ((t.di & 1) != 0)) {
-			const uint32_t tmp = t.c0; t.c0 = t.c1; t.c1 = tmp;
-		}
-	}
+	th_canonical(t);
 	uint32_t paint[4];
 	th_paint(t, paint);
 	// lane L < 16 owns selector bit position k = L: texel x = L >> 2, y = L & 3
 	const uint32_t L = lane & 15u, i = (L & 3u)*4u + (L >> 2);
-	const uint32_t sel = th_selector<UNITW>(tp[i] & 0x00FFFFFFu, o, paint);
+	const uint32_t sel = ((o.transparent >> i) & 1u) ? 2u : th_selector<UNITW>(tp[i] & 0x00FFFFFFu, o, paint);
+	// bit 33: the differential flag, or RGB8A1's opaque flag (clear in a punch-through block)
+	const uint32_t flag = (o.a1 && o.punch) ? 0u : 1u;
 	const uint32_t lsb = (uint32_t)__ballot(lane < 16u && (sel & 1u)) & 0xFFFFu;
 	const uint32_t msb = (uint32_t)__ballot(lane < 16u && (sel >> 1)) & 0xFFFFu;
 	const uint32_t lo = (msb << 16) | lsb;
@@ -459,7 +478,7 @@ __device__ __forceinline__ uint2 pack_th(const uint32_t* tp, const RgbOpts& o, T
 		hi |= (r1a + r1b >= 4) ? (7u << 29) : (1u << 26);
 		hi |= (uint32_t)r1a << 27 | (uint32_t)r1b << 24 | (uint32_t)g1 << 20 | (uint32_t)b1 << 16;
 		hi |= (uint32_t)r2 << 12 | (uint32_t)g2 << 8 | (uint32_t)b2 << 4;
-		hi |= (uint32_t)(t.di >> 1) << 2 | 1u << 1 | (uint32_t)(t.di & 1);
+		hi |= (uint32_t)(t.di >> 1) << 2 | flag << 1 | (uint32_t)(t.di & 1);
 	} else {
 		const int g1a = g1 >> 1, g1b = g1 & 1, b1a = b1 >> 3, b1b = b1 & 7;
 		if (g1a >= 4) hi |= 1u << 31;
@@ -468,7 +487,7 @@ __device__ __forceinline__ uint2 pack_th(const uint32_t* tp, const RgbOpts& o, T
 		hi |= (a + b >= 4) ? (7u << 21) : (1u << 18);
 		hi |= (uint32_t)g1b << 20 | (uint32_t)b1a << 19 | (uint32_t)b1b << 15;
 		hi |= (uint32_t)r2 << 11 | (uint32_t)g2 << 7 | (uint32_t)b2 << 3;
-		hi |= (uint32_t)((t.di >> 2) & 1) << 2 | 1u << 1 | (uint32_t)((t.di >> 1) & 1);
+		hi |= (uint32_t)((t.di >> 2) & 1) << 2 | flag << 1 | (uint32_t)((t.di >> 1) & 1);
 	}
 	return make_uint2(bswap32(hi), bswap32(lo));
 }
@@ -595,9 +614,12 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 			if (ei < best_err) { best_err = ei; best_id = 2u + (uint32_t)f; }
 		}
 	}
-	if (o.allow_planar && !o.punch) {
-		// closed-form least squares on the 4x4 grid (uniform), then 2 rounds of moves
+	if (o.allow_planar) {
 		PlanarQ pq;
+		bool use_planar = false;
+		// planar has no selectors, so it cannot express transparency: opaque blocks only.
+		// Closed-form least squares on the 4x4 grid (uniform), then 2 rounds of moves.
+		if (!o.punch) {
 		{
 			// sums over the 16 texels, one texel per lane: S | Sx << 16 in one word (the low field
 			// never borrows, so the signed high field is exact), Sy in another
@@ -637,12 +659,12 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 			const int id = (int)(uint32_t)mm;
 			planar_move(pq, id >> 1, (id & 1) ? 1 : -1);
 		}
-		bool use_planar = false;
 		if (ep < best_err) {
 			best_err = ep;
 			use_planar = true;
 		}
-		// ETC2 T / H modes (ids after planar)
+		}
+		// ETC2 T / H modes (ids after planar), also in punch-through blocks
 		ThCand th;
 		bool have_th = false;
 		if (o.refine)

@@ -469,17 +469,45 @@ static int th_encodable(const th_cand* t)
 	return w1 != w2 || (t->di & 1);
 }
 
-static uint32_t th_err(const int px[16][4], const rgb_opts* o, const th_cand* t, uint8_t* sel)
+/* H mode: the order of the two colours that pack_th must store (it carries di's low bit) */
+static void th_canonical(th_cand* t)
 {
-	if (!th_encodable(t))
+	if (t->mode != 2)
+		return;
+	int w1 = (t->c[0][0] << 8) | (t->c[0][1] << 4) | t->c[0][2];
+	int w2 = (t->c[1][0] << 8) | (t->c[1][1] << 4) | t->c[1][2];
+	if ((w1 >= w2) != (t->di & 1)) {
+		int tmp[3];
+		memcpy(tmp, t->c[0], sizeof(tmp));
+		memcpy(t->c[0], t->c[1], sizeof(tmp));
+		memcpy(t->c[1], tmp, sizeof(tmp));
+	}
+}
+
+/* Punch-through blocks (RGB8A1 with the opaque bit clear): paint colour 2 is the transparent
+ * one -- opaque texels choose among 0, 1, 3, transparent texels take 2 and carry no error.  The
+ * paint pairs are then no longer symmetric in H mode, so the candidate is scored in the colour
+ * order the block will store. */
+static uint32_t th_err(const int px[16][4], const rgb_opts* o, const th_cand* tc, uint8_t* sel)
+{
+	if (!th_encodable(tc))
 		return 0xFFFFFFFFu;
+	th_cand t = *tc;
+	if (o->punch)
+		th_canonical(&t);
 	int paint[4][3];
-	th_paint(t, paint);
+	th_paint(&t, paint);
 	uint32_t total = 0;
 	for (int i = 0; i < 16; ++i) {
 		uint32_t best = 0xFFFFFFFFu;
 		int bv = 0;
+		if ((o->transparent >> i) & 1) {
+			if (sel) sel[i] = 2;
+			continue;
+		}
 		for (int v = 0; v < 4; ++v) {
+			if (o->punch && v == 2)
+				continue;
 			uint32_t e = 0;
 			for (int ch = 0; ch < 3; ++ch) {
 				int d = paint[v][ch] - px[i][ch];
@@ -599,19 +627,12 @@ static void pack_th(const th_cand* tc, const int px[16][4], const rgb_opts* o, u
 	th_cand t = *tc;
 	uint32_t hi = 0, lo = 0;
 	uint8_t sel[16];
-	if (t.mode == 2) {
-		/* order the colours so that (w1 >= w2) equals the low bit of the distance index;
-		 * swapping them swaps the paint pairs {0,1} <-> {2,3}, so score after the swap */
-		int w1 = (t.c[0][0] << 8) | (t.c[0][1] << 4) | t.c[0][2];
-		int w2 = (t.c[1][0] << 8) | (t.c[1][1] << 4) | t.c[1][2];
-		if ((w1 >= w2) != (t.di & 1)) {
-			int tmp[3];
-			memcpy(tmp, t.c[0], sizeof(tmp));
-			memcpy(t.c[0], t.c[1], sizeof(tmp));
-			memcpy(t.c[1], tmp, sizeof(tmp));
-		}
-	}
+	/* order the colours so that (w1 >= w2) equals the low bit of the distance index; swapping
+	 * them swaps the paint pairs {0,1} <-> {2,3}, so the selectors are taken after the swap */
+	th_canonical(&t);
 	th_err(px, o, &t, sel);
+	/* bit 33: the differential flag, or RGB8A1's opaque flag (clear in a punch-through block) */
+	const uint32_t flag = (o->a1 && o->punch) ? 0u : 1u;
 	if (t.mode == 1) {
 		int r1a = t.c[0][0] >> 2, r1b = t.c[0][0] & 3;
 		/* R + dR must leave [0,31]: 111xx + 0yy when the low parts sum to >= 4, else 000xx + 1yy */
@@ -619,7 +640,7 @@ static void pack_th(const th_cand* tc, const int px[16][4], const rgb_opts* o, u
 		hi |= (uint32_t)r1a << 27 | (uint32_t)r1b << 24;
 		hi |= (uint32_t)t.c[0][1] << 20 | (uint32_t)t.c[0][2] << 16;
 		hi |= (uint32_t)t.c[1][0] << 12 | (uint32_t)t.c[1][1] << 8 | (uint32_t)t.c[1][2] << 4;
-		hi |= (uint32_t)(t.di >> 1) << 2 | 1u << 1 | (uint32_t)(t.di & 1);
+		hi |= (uint32_t)(t.di >> 1) << 2 | flag << 1 | (uint32_t)(t.di & 1);
 	} else {
 		int r1 = t.c[0][0], g1 = t.c[0][1], b1 = t.c[0][2];
 		int g1a = g1 >> 1, g1b = g1 & 1, b1a = b1 >> 3, b1b = b1 & 7;
@@ -631,7 +652,7 @@ static void pack_th(const th_cand* tc, const int px[16][4], const rgb_opts* o, u
 		if (a + b >= 4) hi |= 7u << 21; else hi |= 1u << 18;
 		hi |= (uint32_t)g1b << 20 | (uint32_t)b1a << 19 | (uint32_t)b1b << 15;
 		hi |= (uint32_t)t.c[1][0] << 11 | (uint32_t)t.c[1][1] << 7 | (uint32_t)t.c[1][2] << 3;
-		hi |= (uint32_t)((t.di >> 2) & 1) << 2 | 1u << 1 | (uint32_t)((t.di >> 1) & 1);
+		hi |= (uint32_t)((t.di >> 2) & 1) << 2 | flag << 1 | (uint32_t)((t.di >> 1) & 1);
 	}
 	for (int i = 0; i < 16; ++i) {
 		int x = i & 3, y = i >> 2, k = x*4 + y;
@@ -706,7 +727,7 @@ void cfo_etc_rgb_search(const int px[16][4], const rgb_opts* o, uint8_t out[8])
 			use_planar = 1;
 		}
 	}
-	if (o->allow_planar && !o->punch && o->refine) {   /* ETC2: T / H modes, ids after planar */
+	if (o->allow_planar && o->refine) {   /* ETC2: T / H modes (also in punch-through blocks), ids after planar */
 		th_cand th;
 		if (th_search(px, o, o->radius, &th) && th.err < best_err) {
 			pack_th(&th, px, o, out);

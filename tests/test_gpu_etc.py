@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from cuttlefish_amd import ColorSpace, Format, Texture, Type, make_params, synth
+from cuttlefish_amd import ColorSpace, Context, Format, Texture, Type, make_params, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -86,3 +86,15 @@ def test_full_size_properties_etc2_2048(gpu_ctx):
     strip = img[1024:1040]
     ref = O.encode(strip, int(Format.ETC2_R8G8B8A8), quality=2, threads=8)
     assert np.array_equal(ref, a.reshape(512, 512 * 16)[256:260].reshape(-1))
+
+
+@pytest.mark.parametrize("quality", [0, 1, 2, 3])
+def test_punch_through_blocks_with_th_modes_match_the_oracle(quality):
+    rng = np.random.default_rng(11)
+    img = synth.photo(96, 64, seed=9).copy()
+    img[..., 3] = np.where(rng.random((64, 96)) < 0.25, 0, 255)
+    img[:8, :8, 3] = 0                                   # fully transparent blocks
+    img[8:16, :, 3] = 255                                # fully opaque block rows
+    with Context(0) as ctx:
+        got = ctx.encode([img], make_params(Format.ETC2_R8G8B8A1, Type.UNorm, quality))[0]
+    assert np.array_equal(got, O.encode(img, int(Format.ETC2_R8G8B8A1), 0, quality=quality, threads=8))

@@ -181,3 +181,29 @@ def test_hand_built_t_and_h_blocks_decode_to_their_paint_colours():
     px = O.decode_etc(be(hi, lo), 38, 4, 4)
     assert _etc_mode(be(hi, lo)) == 2
     assert [px[y, 0, 0] for y in range(4)] == [136 + 16, 136 - 16, 34 + 16, 34 - 16]
+
+
+def test_th_modes_in_punch_through_blocks():
+    """RGB8A1 blocks with transparent texels may use the T / H modes too (paint colour 2 is the
+    transparent one): the alpha mask must survive exactly and the opaque texels gain quality."""
+    rng = np.random.default_rng(0)
+    img = synth.photo(128, 128, seed=3).copy()
+    img[..., 3] = np.where(rng.random((128, 128)) < 0.2, 0, 255)
+    opaque = img[..., 3] == 255
+    psnr = {}
+    for q in (0, 1, 2):
+        enc = O.encode(img, A1, quality=q, threads=4)
+        dec = O.decode_etc(enc, A1, 128, 128)
+        assert np.array_equal(dec[..., 3] == 255, opaque)
+        d = (dec[..., :3].astype(np.float64) - img[..., :3].astype(np.float64))[opaque]
+        psnr[q] = 10*np.log10(255.0**2/np.mean(d*d))
+        if q >= 1:
+            # the T / H encodings are in use: opaque flag clear (bit 33) with an R or G overflow
+            hi = enc.reshape(-1, 8)[:, :4].astype(np.uint32)
+            w = (hi[:, 0] << 24) | (hi[:, 1] << 16) | (hi[:, 2] << 8) | hi[:, 3]
+            r = (w >> 27) & 31
+            dr = ((w >> 24) & 7).astype(np.int64)
+            dr = np.where(dr >= 4, dr - 8, dr)
+            punch = ((w >> 1) & 1) == 0
+            assert np.any(punch & ((r.astype(np.int64) + dr < 0) | (r.astype(np.int64) + dr > 31)))
+    assert psnr[1] > psnr[0] + 2.0 and psnr[2] >= psnr[1]
