@@ -87,6 +87,18 @@ __device__ __forceinline__ HalfTex load_half(const uint32_t* tp, const RgbOpts& 
 // Error of the lane's half (a HalfTex): sum over counted texels of min_v sum_c w_c (clamp(c+m_v) - p_c)^2,
 // expanded as |p|^2 - 2 p.(w q_v) + sum w q_v^2 with the cross term on v_dot4 (w q_v <= 2550 is
 // split into a low and a high byte plane when the weights are not all 1).
+// Weighted cross term (sRGB images: REC709-like weights 3, 10, 1): 2 sum_c w_c q_c p_c - sum w q^2
+// as ONE 16-bit dot product over (R, G) with the accumulator input + one 24-bit multiply-add for
+// B, instead of two byte-plane dot4s, two shifts and an add: A = 2 w_r q_r | 2 w_g q_g << 16
+// (<= 5100 each), B = 2 w_b q_b, prg = p_r | p_g << 16.
+typedef unsigned short cf_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int wkey(uint32_t prg, uint32_t pb, uint32_t A, uint32_t B, int nb)
+{
+	const uint32_t t = __builtin_amdgcn_udot2(__builtin_bit_cast(cf_us2, prg), __builtin_bit_cast(cf_us2, A),
+		(uint32_t)nb, false);
+	return (int)(__umul24(pb, B) + t);
+}
+
 template <bool UNITW>
 __device__ __forceinline__ uint32_t half_err_fast(const HalfTex& h, const RgbOpts& o,
 	const int (&c)[3], int ma, int mb)
@@ -104,8 +116,8 @@ __device__ __forceinline__ uint32_t half_err_fast(const HalfTex& h, const RgbOpt
 			nb[v] = -(int)__builtin_amdgcn_udot4(ql[v], ql[v], 0u, false);
 		} else {
 			const uint32_t w0 = (uint32_t)o.wt[0]*q0, w1 = (uint32_t)o.wt[1]*q1, w2 = (uint32_t)o.wt[2]*q2;
-			ql[v] = (w0 & 255u) | ((w1 & 255u) << 8) | ((w2 & 255u) << 16);
-			qh[v] = (w0 >> 8) | ((w1 >> 8) << 8) | ((w2 >> 8) << 16);
+			ql[v] = (2u*w0) | ((2u*w1) << 16);   // A
+			qh[v] = 2u*w2;                        // B
 			nb[v] = -(int)(w0*q0 + w1*q1 + w2*q2);
 		}
 		if (v == 2 && o.punch)
@@ -118,12 +130,13 @@ __device__ __forceinline__ uint32_t half_err_fast(const HalfTex& h, const RgbOpt
 #pragma unroll
 	for (int j = 0; j < 8; ++j) {
 		int best = -0x7FFFFFFF;
+		const uint32_t prg = UNITW ? 0u : __builtin_amdgcn_perm(0u, h.px[j], 0x0C010C00u);   // p_r | p_g << 16
+		const uint32_t pb = UNITW ? 0u : h.px[j] >> 16;
 #pragma unroll
 		for (int v = 0; v < 4; ++v) {
-			// -(sum w q^2 - 2 p.(w q)) as one v_lshl_add_u32 per byte plane
-			int k = (int)(__builtin_amdgcn_udot4(h.px[j], ql[v], 0u, false) << 1) + nb[v];
-			if (!UNITW)
-				k = (int)(__builtin_amdgcn_udot4(h.px[j], qh[v], 0u, false) << 9) + k;
+			// -(sum w q^2 - 2 p.(w q)): unit weights one dot4 + one v_lshl_add_u32
+			const int k = UNITW ? (int)(__builtin_amdgcn_udot4(h.px[j], ql[v], 0u, false) << 1) + nb[v]
+				: wkey(prg, pb, ql[v], qh[v], nb[v]);
 			best = k > best ? k : best;
 		}
 		total += ((h.counted >> j) & 1u) ? (uint32_t)(-best) : 0u;
@@ -299,8 +312,8 @@ __device__ __forceinline__ uint32_t th_err(const uint32_t* tp, uint32_t active, 
 			nb[v] = -(int)__builtin_amdgcn_udot4(paint[v], paint[v], 0u, false);
 		} else {
 			const uint32_t w0 = (uint32_t)o.wt[0]*q0, w1 = (uint32_t)o.wt[1]*q1, w2 = (uint32_t)o.wt[2]*q2;
-			ql[v] = (w0 & 255u) | ((w1 & 255u) << 8) | ((w2 & 255u) << 16);
-			qh[v] = (w0 >> 8) | ((w1 >> 8) << 8) | ((w2 >> 8) << 16);
+			ql[v] = (2u*w0) | ((2u*w1) << 16);   // A, B of wkey()
+			qh[v] = 2u*w2;
 			nb[v] = -(int)(w0*q0 + w1*q1 + w2*q2);
 		}
 		if (v == 2 && o.punch)
@@ -314,11 +327,11 @@ __device__ __forceinline__ uint32_t th_err(const uint32_t* tp, uint32_t active, 
 	for (uint32_t i = i0; i < i0 + cnt; ++i) {
 		const uint32_t p = tp[i] & 0x00FFFFFFu;
 		int best = -0x7FFFFFFF;
+		const uint32_t prg = UNITW ? 0u : __builtin_amdgcn_perm(0u, p, 0x0C010C00u), pb = UNITW ? 0u : p >> 16;
 #pragma unroll
 		for (int v = 0; v < 4; ++v) {
-			int k = (int)(__builtin_amdgcn_udot4(p, ql[v], 0u, false) << 1) + nb[v];
-			if (!UNITW)
-				k = (int)(__builtin_amdgcn_udot4(p, qh[v], 0u, false) << 9) + k;
+			const int k = UNITW ? (int)(__builtin_amdgcn_udot4(p, ql[v], 0u, false) << 1) + nb[v]
+				: wkey(prg, pb, ql[v], qh[v], nb[v]);
 			best = k > best ? k : best;
 		}
 		total += ((active >> i) & 1u) ? (uint32_t)(-best) : 0u;
@@ -897,7 +910,7 @@ __device__ __forceinline__ uint32_t r11_word(float f, bool snorm)
 // ETC2 RGBA8 (RGB search + EAC alpha in one kernel), which gets 3
 template <int PIX, int FMT, bool SNORM>
 __global__ void __launch_bounds__(CF_WG_THREADS)
-__attribute__((amdgpu_waves_per_eu((FMT == E_A8 || FMT == E_A1) ? 3 : 4, 8)))
+__attribute__((amdgpu_waves_per_eu((FMT == E_A8 || FMT == E_A1 || FMT == E_RGB) ? 3 : 4, 8)))
 cfhip_etc_encode_kernel(cf_kparams kp)
 {
 	constexpr bool IS_EAC = FMT == E_R11 || FMT == E_RG11;
