@@ -305,8 +305,9 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 		} else {
 			const uint32_t m0 = __umul24(wt[0], c0), m1 = __umul24(wt[1], c1), m2 = __umul24(wt[2], c2),
 				m3 = __umul24(wt[3], c3);
-			pal[k] = (m0 & 255u) | ((m1 & 255u) << 8) | ((m2 & 255u) << 16) | ((m3 & 255u) << 24);
-			palh[k] = (m0 >> 8) | ((m1 >> 8) << 8) | ((m2 >> 8) << 16) | ((m3 >> 8) << 24);
+			// 16-bit pairs for v_dot2_u32_u16: (w0 c0, w1 c1) and (w2 c2, w3 c3), each <= 1785
+			pal[k] = m0 | (m1 << 16);
+			palh[k] = m2 | (m3 << 16);
 			const uint32_t qq = __umul24(m0, c0) + __umul24(m1, c1) + __umul24(m2, c2) + __umul24(m3, c3);
 			base[k] = valid ? -(int)((qq << 7) | w) : -0x3FFFFFFF;
 		}
@@ -332,11 +333,18 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 			uint32_t key;
 			{
 				int bestk = -0x7FFFFFFF;
+				// general weights: the texel as two 16-bit pairs, two chained 16-bit dot products
+				typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+				const uint32_t prg = UNITW ? 0u : __builtin_amdgcn_perm(0u, p, 0x0C010C00u);
+				const uint32_t pba = UNITW ? 0u : __builtin_amdgcn_perm(0u, p, 0x0C030C02u);
 #pragma unroll
 				for (int k = 0; k < 8; ++k) {
-					int dt = (int)__builtin_amdgcn_udot4(p, pal[k], 0u, false);
-					if (!UNITW)
-						dt += (int)__builtin_amdgcn_udot4(p, palh[k], 0u, false) << 8;
+					int dt;
+					if (UNITW)
+						dt = (int)__builtin_amdgcn_udot4(p, pal[k], 0u, false);
+					else
+						dt = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, pba), __builtin_bit_cast(us2, palh[k]),
+							__builtin_amdgcn_udot2(__builtin_bit_cast(us2, prg), __builtin_bit_cast(us2, pal[k]), 0u, false), false);
 					const int v = (dt << 8) + base[k];
 					bestk = v > bestk ? v : bestk;
 				}
