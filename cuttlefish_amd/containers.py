@@ -9,8 +9,8 @@ Pure serialisation, host side, mirrors the reference writers field for field:
   savePvr   lib/src/SavePvr.cpp:478-600   (header :487-524, CTFS metadata :526-575,
                                             surface order mip -> depth -> face :580-595;
                                             pixel format :272-470, channel type :107-268)
-DDS and PVR cover the uncompressed formats of csrc/std_pack.hip too (getDdsFormat,
-SaveDds.cpp:252-440); KTX is kept to the block-compressed formats.
+All three cover the uncompressed formats of csrc/std_pack.hip too (getDdsFormat,
+SaveDds.cpp:252-440; getFormatInfo, SaveKtx.cpp:200-630, rows padded to 4 bytes :1240-1285).
 Only 2-D textures and 2-D arrays of the formats this backend encodes are covered (cube maps
 and 3-D textures are containers of the same surfaces in a different order: not needed by the
 hot path's tests).  `read_dds` parses what `write_dds` emits (round-trip tests; Pillow is the
@@ -99,6 +99,52 @@ def has_alpha(fmt) -> bool:
     return Format(fmt) in _HAS_ALPHA
 
 
+# uncompressed formats, getFormatInfo (SaveKtx.cpp:200-630):
+#   (format, type) -> (glType, glTypeSize, glFormat, (internal linear, internal sRGB), baseInternal)
+# R4G4, A4R4G4B4 and B8G8R8 have no KTX form (SaveKtx.cpp:1174-1176).
+_GL_UB, _GL_B, _GL_US, _GL_S, _GL_UINT, _GL_INT, _GL_HF, _GL_FL = 0x1401, 0x1400, 0x1403, 0x1402, 0x1405, 0x1404, 0x140B, 0x1406
+_GL_LUM, _GL_LUMA, _GL_BGRA, _GL_RGBA_INT, _GL_BGRA_INT = 0x1909, 0x190A, 0x80E1, 0x8D99, 0x8D9B
+_GLU = {
+    (Format.R4G4B4A4, _U): (0x8033, 2, _GL_RGBA, (0x8056, None), _GL_RGBA),
+    (Format.B4G4R4A4, _U): (0x8033, 2, _GL_BGRA, (0x8056, None), _GL_BGRA),
+    (Format.R5G6B5, _U): (0x8363, 2, _GL_RGB, (0x8D62, None), _GL_RGB),
+    (Format.B5G6R5, _U): (0x8364, 2, _GL_RGB, (0x8D62, None), _GL_RGB),
+    (Format.R5G5B5A1, _U): (0x8034, 2, _GL_RGBA, (0x8057, None), _GL_RGBA),
+    (Format.B5G5R5A1, _U): (0x8034, 2, _GL_BGRA, (0x8057, None), _GL_BGRA),
+    (Format.A1R5G5B5, _U): (0x8366, 2, _GL_BGRA, (0x8057, None), _GL_BGRA),
+    (Format.R8, _U): (_GL_UB, 1, _GL_RED, (0x8229, None), _GL_LUM), (Format.R8, _S): (_GL_B, 1, _GL_RED, (0x8F94, None), _GL_LUM),
+    (Format.R8, _UI): (_GL_UB, 1, _GL_RED, (0x8232, None), _GL_LUM), (Format.R8, _I): (_GL_B, 1, _GL_RED, (0x8231, None), _GL_LUM),
+    (Format.R8G8, _U): (_GL_UB, 1, _GL_RG, (0x822B, None), _GL_LUMA), (Format.R8G8, _S): (_GL_UB, 1, _GL_RG, (0x8F95, None), _GL_LUMA),
+    (Format.R8G8, _UI): (_GL_UB, 1, _GL_RG, (0x8238, None), _GL_LUMA), (Format.R8G8, _I): (_GL_UB, 1, _GL_RG, (0x8237, None), _GL_LUMA),
+    (Format.R8G8B8, _U): (_GL_UB, 1, _GL_RGB, (0x8051, 0x8C41), _GL_RGB), (Format.R8G8B8, _S): (_GL_B, 1, _GL_RGB, (0x8F96, None), _GL_RGB),
+    (Format.R8G8B8, _UI): (_GL_UB, 1, _GL_RGB, (0x8D7D, None), _GL_RGB), (Format.R8G8B8, _I): (_GL_B, 1, _GL_RGB, (0x8D8F, None), _GL_RGB),
+    (Format.R8G8B8A8, _U): (_GL_UB, 1, _GL_RGBA, (0x8058, 0x8C43), _GL_RGBA), (Format.R8G8B8A8, _S): (_GL_B, 1, _GL_RGBA, (0x8F97, None), _GL_RGBA),
+    (Format.R8G8B8A8, _UI): (_GL_UB, 1, _GL_RGBA_INT, (0x8D7C, None), _GL_RGBA), (Format.R8G8B8A8, _I): (_GL_B, 1, _GL_RGBA_INT, (0x8D8E, None), _GL_RGBA),
+    (Format.B8G8R8A8, _U): (0x8035, 4, _GL_BGRA, (0x8058, 0x8C43), _GL_BGRA),
+    (Format.A8B8G8R8, _U): (0x8367, 4, _GL_RGBA, (0x8058, 0x8C43), _GL_RGBA),
+    (Format.A2R10G10B10, _U): (0x8368, 4, _GL_BGRA, (0x8059, None), _GL_BGRA), (Format.A2R10G10B10, _UI): (0x8368, 4, _GL_BGRA_INT, (0x906F, None), _GL_BGRA),
+    (Format.A2B10G10R10, _U): (0x8368, 4, _GL_RGBA, (0x8059, None), _GL_RGBA), (Format.A2B10G10R10, _UI): (0x8368, 4, _GL_RGBA_INT, (0x906F, None), _GL_RGBA),
+    (Format.B10G11R11_UFloat, _UF): (0x8C3B, 4, _GL_RGB, (0x8C3A, None), _GL_RGB),
+    (Format.E5B9G9R9_UFloat, _UF): (0x8C3E, 4, _GL_RGB, (0x8C3D, None), _GL_RGB),
+}
+for _f, _glf, _base, _i16, _i32 in (
+        (Format.R16, _GL_RED, _GL_LUM, (0x822A, 0x8F98, 0x8234, 0x8233, 0x822D), None),
+        (Format.R16G16, _GL_RG, _GL_LUMA, (0x822C, 0x8F99, 0x823A, 0x8239, 0x822F), None),
+        (Format.R16G16B16, _GL_RGB, _GL_RGB, (0x8054, 0x8F9A, 0x8D77, 0x8D89, 0x881B), None),
+        (Format.R16G16B16A16, _GL_RGBA, _GL_RGBA, (0x805B, 0x8F9B, 0x8D76, 0x8D88, 0x881A), None),
+        (Format.R32, _GL_RED, _GL_LUM, None, (0x8236, 0x8235, 0x822E)),
+        (Format.R32G32, _GL_RG, _GL_LUMA, None, (0x823C, 0x823B, 0x8230)),
+        (Format.R32G32B32, _GL_RGB, _GL_RGB, None, (0x8D71, 0x8D83, 0x8815)),
+        (Format.R32G32B32A32, _GL_RGBA, _GL_RGBA, None, (0x8D70, 0x8D82, 0x8814))):
+    if _i16:
+        for _t, _gt, _int in zip((_U, _S, _UI, _I, _F), (_GL_US, _GL_S, _GL_US, _GL_S, _GL_HF), _i16):
+            _GLU[(_f, _t)] = (_gt, 2, _glf, (_int, None), _base)
+    else:
+        for _t, _gt, _int in zip((_UI, _I, _F), (_GL_UINT, _GL_INT, _GL_FL), _i32):
+            _GLU[(_f, _t)] = (_gt, 4, _glf, (_int, None), _base)
+for _f in _ASTC:                                        # the HDR profile shares the enums (SaveKtx.cpp)
+    _GL[(_f, Type.UFloat)] = _GL[(_f, Type.UNorm)]
+
 KTX_IDENTIFIER = bytes([0xAB, 0x4B, 0x54, 0x58, 0x20, 0x31, 0x31, 0xBB, 0x0D, 0x0A, 0x1A, 0x0A])
 KTX_ENDIANNESS = 0x04030201
 
@@ -182,25 +228,44 @@ def read_dds(data: bytes):
 
 def write_ktx(stream, fmt, typ, width: int, height: int, levels_or_elements: Sequence,
               color_space=ColorSpace.Linear) -> int:
-    """Write a KTX 1.1 file (compressed formats only)."""
+    """Write a KTX 1.1 file (block-compressed formats, and the uncompressed ones with padded rows)."""
     fmt, typ = Format(fmt), Type(typ)
     key = (fmt, typ)
-    if key not in _GL:
+    srgb_wanted = ColorSpace(color_space) == ColorSpace.sRGB
+    if key in _GL:
+        lin, srgb, base = _GL[key]
+        gl_type, type_size, gl_format, compressed = 0, 1, 0, True
+    elif key in _GLU:
+        gl_type, type_size, gl_format, (lin, srgb), base = _GLU[key]
+        compressed = False
+    else:
         raise ValueError("no KTX format for %s/%s (saveKtx returns Unsupported)" % (fmt.name, typ.name))
-    lin, srgb, base = _GL[key]
-    internal = srgb if (ColorSpace(color_space) == ColorSpace.sRGB and srgb) else lin
+    internal = srgb if (srgb_wanted and srgb) else lin
     elements = [[_b(m) for m in e] for e in _as_elements(levels_or_elements)]
     levels = _check_levels(fmt, typ, width, height, elements)
     is_array = len(elements) > 1
     out = KTX_IDENTIFIER + struct.pack("<I", KTX_ENDIANNESS)
-    out += struct.pack("<5I", 0, 1, 0, internal, base)       # type, typeSize, format, internal, base
+    out += struct.pack("<5I", gl_type, type_size, gl_format, internal, base)
     out += struct.pack("<7I", width, height, 0, len(elements) if is_array else 0, 1, levels, 0)
+    bpp = query(fmt, typ)[2]
+    dims = mip_dims(width, height, levels)
     for l in range(levels):
-        size = sum(len(e[l]) for e in elements)              # SaveKtx.cpp:1224-1248
+        w, h = dims[l]
+        if compressed:
+            size = sum(len(e[l]) for e in elements)          # SaveKtx.cpp:1224-1248
+            pad = 0
+        else:
+            row = w*bpp                                      # scanlines are 4-byte aligned (:1240-1285)
+            pad = (4 - row % 4) % 4
+            size = (row + pad)*h*len(elements)
         assert size % 4 == 0
         out += struct.pack("<I", size)
         for e in elements:                                   # depth (array element) -> face
-            out += e[l]
+            if pad == 0:
+                out += e[l]
+            else:
+                for y in range(h):
+                    out += e[l][y*row:(y + 1)*row] + b"\0"*pad
     stream.write(out)
     return len(out)
 

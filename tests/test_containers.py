@@ -191,3 +191,31 @@ def test_uncompressed_dds_opens_in_pillow():
     for fmt, typ in ((Format.R8G8B8, Type.UNorm), (Format.B8G8R8, Type.UNorm), (Format.R4G4B4A4, Type.UNorm)):
         with pytest.raises(ValueError):                      # getDdsFormat has no entry: Unsupported
             C.write_dds(io.BytesIO(), fmt, typ, 40, 24, [O.std_pack(img, int(fmt), int(typ))])
+
+
+def test_ktx_uncompressed_formats_follow_getformatinfo_and_pad_rows():
+    img = synth.photo(5, 3, seed=4)                      # 5 pixels: 15-byte RGB8 rows -> 1 byte of padding
+    payload = O.std_pack(img, int(Format.R8G8B8), int(Type.UNorm))
+    buf = io.BytesIO()
+    n = C.write_ktx(buf, Format.R8G8B8, Type.UNorm, 5, 3, [payload], color_space=ColorSpace.sRGB)
+    data = buf.getvalue()
+    assert n == len(data) == 64 + 4 + 3*16
+    gl_type, type_size, gl_format, internal, base = struct.unpack_from("<5I", data, 16)
+    assert (gl_type, type_size, gl_format, internal, base) == (0x1401, 1, 0x1907, 0x8C41, 0x1907)
+    assert struct.unpack_from("<I", data, 64)[0] == 48
+    rows = np.frombuffer(data, np.uint8, offset=68).reshape(3, 16)
+    assert np.array_equal(rows[:, :15].reshape(3, 5, 3), img[..., :3]) and (rows[:, 15] == 0).all()
+    for fmt, typ, want in ((Format.R5G6B5, Type.UNorm, (0x8363, 2, 0x1907, 0x8D62, 0x1907)),
+                           (Format.R8, Type.SNorm, (0x1400, 1, 0x1903, 0x8F94, 0x1909)),
+                           (Format.R8G8, Type.SNorm, (0x1401, 1, 0x8227, 0x8F95, 0x190A)),
+                           (Format.R8G8B8A8, Type.UInt, (0x1401, 1, 0x8D99, 0x8D7C, 0x1908)),
+                           (Format.A2R10G10B10, Type.UInt, (0x8368, 4, 0x8D9B, 0x906F, 0x80E1)),
+                           (Format.R16G16B16A16, Type.Float, (0x140B, 2, 0x1908, 0x881A, 0x1908)),
+                           (Format.R32G32, Type.Int, (0x1404, 4, 0x8227, 0x823B, 0x190A)),
+                           (Format.E5B9G9R9_UFloat, Type.UFloat, (0x8C3E, 4, 0x1907, 0x8C3D, 0x1907))):
+        buf = io.BytesIO()
+        C.write_ktx(buf, fmt, typ, 5, 3, [O.std_pack(img, int(fmt), int(typ))])
+        assert struct.unpack_from("<5I", buf.getvalue(), 16) == want, fmt
+    for fmt in (Format.R4G4, Format.A4R4G4B4, Format.B8G8R8):                 # SaveKtx.cpp:1174-1176
+        with pytest.raises(ValueError):
+            C.write_ktx(io.BytesIO(), fmt, Type.UNorm, 5, 3, [O.std_pack(img, int(fmt), 0)])
