@@ -219,3 +219,35 @@ def test_ktx_uncompressed_formats_follow_getformatinfo_and_pad_rows():
     for fmt in (Format.R4G4, Format.A4R4G4B4, Format.B8G8R8):                 # SaveKtx.cpp:1174-1176
         with pytest.raises(ValueError):
             C.write_ktx(io.BytesIO(), fmt, Type.UNorm, 5, 3, [O.std_pack(img, int(fmt), 0)])
+
+
+def test_writers_accept_exactly_what_the_reference_save_tests_expect():
+    """lib/test/TextureSaveTest.cpp:268-700 lists, per container, which (format, type) pairs save
+    and which are Unsupported (fixture: tests/golden/save_expectations.json, extracted by
+    tests/golden/make_save_expectations.py).  The same 16x16 texture: header sizes 148 / 68 / 52
+    bytes + payload (TextureSaveTest.cpp:252-265)."""
+    import json
+    import os
+    from cuttlefish_amd import api
+    exp = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "save_expectations.json")))
+    writers = {"DDS": (C.write_dds, 148), "KTX": (C.write_ktx, 68), "PVR": (C.write_pvr, 52)}
+    checked = 0
+    for kind, (writer, header) in writers.items():
+        for key, ok in exp[kind].items():
+            fname, tname = key.split("/")
+            if fname.startswith("PVRTC"):
+                continue                                   # closed-source codec: not in this backend
+            fmt, typ = getattr(Format, fname), getattr(Type, tname)
+            size = payload_size(fmt, typ, 16, 16)
+            buf = io.BytesIO()
+            try:
+                n = writer(buf, fmt, typ, 16, 16, [bytes(size)])
+                got = True
+            except ValueError:
+                got = False
+            assert got == ok, (kind, key)
+            if ok:
+                extra = 16 if (kind == "PVR" and fname.startswith("BC1")) else 0   # the BC1/BC1A metadata block
+                assert n == header + extra + size, (kind, key, n)
+            checked += 1
+    assert checked > 250
