@@ -153,3 +153,17 @@ def test_catmull_rom_halving_weights_known_answer():
     u = 6                                                      # centre 12.999..: taps 9..16
     ref = float(np.dot(w, row[0, 2*u - 3:2*u + 5, 0].astype(np.float64)))
     assert abs(out[0, u, 0] - ref) < 1e-6
+
+
+def test_colour_functions_reproduce_the_reference_known_answers():
+    """ColorTest.SRGBConversion (lib/test/ImageTest.cpp:140-153): the reference's own golden
+    values for linearToSRGB / sRGBToLinear, to EXPECT_DOUBLE_EQ's 4 ulps."""
+    to_lin, to_srgb = O.color_fns()
+    for x, want in ((0.0, 0.0), (0.01, 0.0998528227341283), (0.25, 0.537098730483194),
+                    (0.75, 0.8808250210903), (1.0, 1.0)):
+        got = to_srgb(x)
+        assert abs(got - want) <= 4*np.spacing(want) + 1e-15, (x, got, want)
+    for x, want in ((0.0, 0.0), (0.01, 0.000773993808049536), (0.25, 0.0508760881715568),
+                    (0.75, 0.522521553968392), (1.0, 1.0)):
+        got = to_lin(x)
+        assert abs(got - want) <= 4*np.spacing(want) + 1e-15, (x, got, want)
