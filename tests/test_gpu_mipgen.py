@@ -145,3 +145,17 @@ def test_default_catmull_rom_chain_through_the_texture_mirror():
     for k in range(7):
         src_k = img if k == 0 else ref[k]
         assert np.array_equal(np.asarray(t.data(k)), O.encode(src_k, int(Format.BC1_RGB), 0, quality=2))
+
+
+def test_generate_mipmaps_level_dimensions_as_in_the_reference_test():
+    """TextureTest.GenerateMipmaps (lib/test/TextureTest.cpp:539-568): a 15x10 texture gets 4
+    levels of 15x10, 7x5, 3x2 and 1x1 (2-D form of the reference's cube-array case); an image of
+    the wrong size is refused."""
+    from cuttlefish_amd import Texture
+    t = Texture(15, 10)
+    assert not t.set_image(np.zeros((15, 10, 4), np.float32))       # 10 wide, 15 high: wrong size
+    assert not t.images_complete()
+    assert t.set_image(np.zeros((10, 15, 4), np.float32))
+    assert t.images_complete() and t.generate_mipmaps() and t.images_complete()
+    assert t.mip_level_count() == 4
+    assert [t._images[k][0].shape[:2] for k in range(4)] == [(10, 15), (5, 7), (2, 3), (1, 1)]
