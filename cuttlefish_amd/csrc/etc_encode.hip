@@ -569,9 +569,10 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 	uint32_t herr[8], hq[8], ht[8];
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
-		herr[k] = (uint32_t)__shfl((int)(uint32_t)(key >> 32), 8*k, 64);
-		hq[k] = (uint32_t)__shfl((int)bq, 8*k, 64);
-		ht[k] = (uint32_t)__shfl((int)(uint32_t)key, 8*k, 64) & 7u;
+		// constant source lanes: v_readlane puts the group results in scalar registers
+		herr[k] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), 8*k);
+		hq[k] = (uint32_t)__builtin_amdgcn_readlane((int)bq, 8*k);
+		ht[k] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, 8*k) & 7u;
 	}
 	// group index = fam4*4 + flip*2 + sub
 	// differential: pull the second base colour into the delta window of the first
@@ -607,8 +608,8 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 		group_min8(k2, pay);
 #pragma unroll
 		for (int f = 0; f < 2; ++f) {
-			const uint32_t ef = (uint32_t)__shfl((int)(uint32_t)(k2 >> 32), 8*(2*f + 1), 64);
-			const uint32_t tf = (uint32_t)__shfl((int)(uint32_t)k2, 8*(2*f + 1), 64) & 7u;
+			const uint32_t ef = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k2 >> 32), 8*(2*f + 1));
+			const uint32_t tf = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k2, 8*(2*f + 1)) & 7u;
 			e2[f] = need[f] ? ef : e2[f];
 			t2[f] = need[f] ? tf : t2[f];
 		}
