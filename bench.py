@@ -83,6 +83,32 @@ def cpu_baseline(img, gpu_payload, width, budget_s=15.0):
     }
 
 
+def _cached_photo(synth, size, seed):
+    """synth.photo takes ~40 s for 4096x4096 (single-threaded numpy): keep the deterministic tile
+    in a git-ignored cache next to the repo so that back-to-back runs (N = 1, 2, 4, 8) reuse it.
+    Any cache problem falls back to generating it."""
+    import numpy as np
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), ".bench_cache",
+                        "photo_%d_seed%d.npy" % (size, seed))
+    try:
+        if os.path.exists(path):
+            img = np.load(path)
+            if img.shape == (size, size, 4) and img.dtype == np.uint8:
+                return img
+    except Exception:
+        pass
+    img = synth.photo(size, size, seed=seed)
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = path + ".%d.tmp" % os.getpid()
+        with open(tmp, "wb") as f:          # np.save on a path would append ".npy" to the temp name
+            np.save(f, img)
+        os.replace(tmp, path)
+    except Exception:
+        pass
+    return img
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,7 +149,7 @@ def main():
 
     size = args.size
     # every rank encodes its own tile (independent surfaces; weak scaling)
-    img = synth.photo(size, size, seed=1 + rank)
+    img = _cached_photo(synth, size, 1 + rank)
     src = torch.from_numpy(img).cuda()
     out = torch.empty((size // 4) * (size // 4) * 16, dtype=torch.uint8, device="cuda")
     params = make_params(Format.BC7, Type.UNorm, args.quality)
