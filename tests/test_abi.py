@@ -74,3 +74,26 @@ def test_texture_convert_rejects_illegal_combinations(hip_lib):
     s = Texture(16, 16, color_space=ColorSpace.sRGB)
     assert s.set_image(np.zeros((16, 16, 4), np.float32))
     assert not s.convert(Format.BC4, Type.UNorm)          # no native sRGB (Texture.cpp:421-465)
+
+
+def test_query_accepts_exactly_the_pairs_the_reference_convert_tests_list(hip_lib):
+    """lib/test/TextureTest.cpp:869-985 instantiates TextureConvertTest / TextureConvertSpecialTest
+    with every (format, type) pair Texture::convert must accept (fixture
+    tests/golden/convert_expectations.json, extracted by tests/golden/make_convert_expectations.py);
+    createConverter answers nullptr for every other pair.  cfhip_query is the backend's statement
+    of the same matrix (no GPU needed).  PVRTC is the one family this backend does not have."""
+    import json
+    from cuttlefish_amd import api
+    listed = set(json.load(open(os.path.join(ROOT, "tests", "golden", "convert_expectations.json"))))
+    listed = {p for p in listed if not p.startswith("PVRTC")}
+    # ASTC_6x6 is missing from the reference's list (TextureTest.cpp:941-954) although legal
+    listed |= {"ASTC_6x6/UNorm", "ASTC_6x6/UFloat"}
+    accepted = set()
+    for fmt in api.Format:
+        for typ in api.Type:
+            try:
+                api.query(fmt, typ)
+                accepted.add("%s/%s" % (fmt.name, typ.name))
+            except api.CfhipError:
+                pass
+    assert accepted == listed, (sorted(accepted - listed), sorted(listed - accepted))
