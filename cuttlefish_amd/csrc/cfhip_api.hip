@@ -311,12 +311,11 @@ bool format_implemented(int format, int type)
 {
 	if (is_std_format(format))
 		return true;
-	// ASTC UFloat (the HDR profile, Converter.cpp:431-488) is ACCEPTED and encoded with the LDR
-	// endpoint modes, which every HDR-profile decoder reads as value/65535: the stream is valid
-	// and the size contract of TextureConvertSpecialTest holds, but source values outside [0, 1]
-	// clamp -- there are no HDR endpoint modes in this encoder (known gaps)
+	// ASTC UFloat (the HDR profile, AstcConverter.cpp:150-162) is a legal pair (cfhip_query
+	// answers it) but is REFUSED here until the HDR endpoint modes exist: encoding it with the
+	// LDR modes would clamp the data to [0, 1] silently.  The adapter falls back to astcenc.
 	if (format >= CFHIP_FORMAT_ASTC_4x4 && format <= CFHIP_FORMAT_ASTC_12x12)
-		return type == CFHIP_TYPE_UNORM || type == CFHIP_TYPE_UFLOAT;
+		return type == CFHIP_TYPE_UNORM;
 	switch (format) {
 		case CFHIP_FORMAT_BC1_RGB:
 		case CFHIP_FORMAT_BC1_RGBA:
