@@ -34,18 +34,7 @@
 typedef struct { uint8_t N, M, bits; uint16_t mode; } astc_cfg;
 
 /* per-texel infill record: grid index of the top-left weight + the four 0..16 factors */
-typedef struct { uint8_t v0, w00, w01, w10, w11; } astc_infill;
-
-int cfo_astc_footprint(int format, int* bw, int* bh)
-{
-	static const uint8_t fp[14][2] = {{4, 4}, {5, 4}, {5, 5}, {6, 5}, {6, 6}, {8, 5}, {8, 6}, {8, 8},
-		{10, 5}, {10, 6}, {10, 8}, {10, 10}, {12, 10}, {12, 12}};
-	if (format < 43 || format > 56)
-		return -1;
-	*bw = fp[format - 43][0];
-	*bh = fp[format - 43][1];
-	return 0;
-}
+typedef struct { uint8_t v0, w00, w01, w10, w11; } astc_infill_old;
 
 /* weight unquantisation for pure-bit ranges: replicate to 6 bits, +1 above 32 */
 static int unq_weight(int q, int bits)
@@ -144,7 +133,7 @@ static int parse_block_mode(int mode, int* N, int* M, int* bits, int* dual)
 
 /* infill table of an N x M grid under a bw x bh footprint (specification 23.17 "weight
  * infill"): per texel the base grid index and the four bilinear factors */
-static void build_infill(int bw, int bh, int N, int M, astc_infill* tab, int* den)
+static void build_infill(int bw, int bh, int N, int M, astc_infill_old* tab, int* den)
 {
 	int Ds = (1024 + bw/2)/(bw - 1), Dt = (1024 + bh/2)/(bh - 1);
 	for (int j = 0; j < N*M; ++j)
@@ -156,7 +145,7 @@ static void build_infill(int bw, int bh, int N, int M, astc_infill* tab, int* de
 			int js = gs >> 4, fs = gs & 15, jt = gt >> 4, ft = gt & 15;
 			int w11 = (fs*ft + 8) >> 4, w10 = ft - w11, w01 = fs - w11;
 			int w00 = 16 - fs - ft + w11;
-			astc_infill* e = &tab[t*bw + s];
+			astc_infill_old* e = &tab[t*bw + s];
 			e->v0 = (uint8_t)(js + jt*N);
 			e->w00 = (uint8_t)w00; e->w01 = (uint8_t)w01; e->w10 = (uint8_t)w10; e->w11 = (uint8_t)w11;
 			int v0 = e->v0;
@@ -200,83 +189,6 @@ int cfo_astc_configs(int bw, int bh, int nvals, astc_cfg* out)
 	return k;
 }
 
-/* ---------------------------------------------------------------- decode */
-
-static unsigned getbits(const uint8_t* blk, int pos, int n)
-{
-	unsigned v = 0;
-	for (int i = 0; i < n; ++i)
-		v |= (unsigned)((blk[(pos + i) >> 3] >> ((pos + i) & 7)) & 1) << i;
-	return v;
-}
-
-/* Decodes the emitted subset to RGBA8 (bw*bh texels, row-major).  Returns -1 (and magenta)
- * for anything outside it. */
-int cfo_decode_astc_block(const uint8_t* blk, int bw, int bh, uint8_t* rgba)
-{
-	int n = bw*bh;
-	unsigned mode = getbits(blk, 0, 11);
-	if ((mode & 0x1FF) == 0x1FC) {                 /* void extent */
-		if ((mode >> 9) & 1)
-			goto fail;                             /* HDR constant */
-		for (int i = 0; i < n; ++i)
-			for (int c = 0; c < 4; ++c)
-				rgba[4*i + c] = blk[8 + 2*c + 1];  /* UNORM16 -> top byte */
-		return 0;
-	}
-	int N, M, bits, dual;
-	if (parse_block_mode((int)mode, &N, &M, &bits, &dual) != 0 || dual)
-		goto fail;
-	if (getbits(blk, 11, 2) != 0 || N > bw || M > bh)
-		goto fail;
-	int cem = (int)getbits(blk, 13, 4);
-	if (cem != 8 && cem != 12)
-		goto fail;
-	int nvals = cem == 8 ? 6 : 8;
-	if (128 - 17 - N*M*bits < 8*nvals)
-		goto fail;                                 /* endpoints would use a trit/quint range */
-	int v[8];
-	for (int i = 0; i < nvals; ++i)
-		v[i] = (int)getbits(blk, 17 + 8*i, 8);
-	int e0[4] = {v[0], v[2], v[4], cem == 12 ? v[6] : 255};
-	int e1[4] = {v[1], v[3], v[5], cem == 12 ? v[7] : 255};
-	if (v[1] + v[3] + v[5] < v[0] + v[2] + v[4]) {
-		/* blue contraction + swap */
-		int a0[4] = {(v[1] + v[5]) >> 1, (v[3] + v[5]) >> 1, v[5], e1[3]};
-		int a1[4] = {(v[0] + v[4]) >> 1, (v[2] + v[4]) >> 1, v[4], e0[3]};
-		memcpy(e0, a0, sizeof(a0));
-		memcpy(e1, a1, sizeof(a1));
-	}
-	int gw[64];
-	for (int j = 0; j < N*M; ++j) {
-		int q = 0;
-		for (int k = 0; k < bits; ++k)
-			q |= (int)((blk[(127 - (j*bits + k)) >> 3] >> ((127 - (j*bits + k)) & 7)) & 1) << k;
-		gw[j] = unq_weight(q, bits);
-	}
-	astc_infill tab[ASTC_MAX_TEXELS];
-	int den[64];
-	build_infill(bw, bh, N, M, tab, den);
-	for (int i = 0; i < n; ++i) {
-		const astc_infill* f = &tab[i];
-		int w = f->w00*gw[f->v0] + 8;
-		if (f->w01) w += f->w01*gw[f->v0 + 1];
-		if (f->w10) w += f->w10*gw[f->v0 + N];
-		if (f->w11) w += f->w11*gw[f->v0 + N + 1];
-		w >>= 4;
-		for (int c = 0; c < 4; ++c) {
-			int C0 = e0[c]*257, C1 = e1[c]*257;
-			rgba[4*i + c] = (uint8_t)(((C0*(64 - w) + C1*w + 32) >> 6) >> 8);
-		}
-	}
-	return 0;
-fail:
-	for (int i = 0; i < n; ++i) {
-		rgba[4*i] = 255; rgba[4*i + 1] = 0; rgba[4*i + 2] = 255; rgba[4*i + 3] = 255;
-	}
-	return -1;
-}
-
 /* ---------------------------------------------------------------- encode */
 
 static const uint8_t inset_tab[8][2] = {{0, 0}, {1, 1}, {2, 2}, {3, 3}, {1, 0}, {0, 1}, {2, 0},
@@ -309,7 +221,7 @@ static void eval_config(const int px[][4], int n, int nc, int bw, int bh, const 
 	const float lo[4], const float hi[4], int variant, int refit, acand* c)
 {
 	int N = cfg->N, M = cfg->M, bits = cfg->bits, ng = N*M, qmax = (1 << bits) - 1;
-	astc_infill tab[ASTC_MAX_TEXELS];
+	astc_infill_old tab[ASTC_MAX_TEXELS];
 	int den[64], num[64];
 	build_infill(bw, bh, N, M, tab, den);
 
@@ -343,7 +255,7 @@ static void eval_config(const int px[][4], int n, int nc, int bw, int bh, const 
 			T = (128*t + dd)/(2*dd);
 			if (T > 64) T = 64;
 		}
-		const astc_infill* f = &tab[i];
+		const astc_infill_old* f = &tab[i];
 		num[f->v0] += f->w00*T;
 		if (f->w01) num[f->v0 + 1] += f->w01*T;
 		if (f->w10) num[f->v0 + N] += f->w10*T;
@@ -358,7 +270,7 @@ static void eval_config(const int px[][4], int n, int nc, int bw, int bh, const 
 	}
 	uint8_t w[ASTC_MAX_TEXELS];
 	for (int i = 0; i < n; ++i) {
-		const astc_infill* f = &tab[i];
+		const astc_infill_old* f = &tab[i];
 		int v = f->w00*gw[f->v0] + 8;
 		if (f->w01) v += f->w01*gw[f->v0 + 1];
 		if (f->w10) v += f->w10*gw[f->v0 + N];

@@ -96,3 +96,46 @@ def test_astc_encoder_output_decodes_identically_under_mesa(fmt):
         mine, bad = O.decode_astc(blk, fmt, 72, 60)
         assert bad == 0
         assert np.array_equal(mine, M.decode(fmt, blk, 72, 60))
+
+
+# ---- ASTC: the full LDR decoder against Mesa (fixture: make_mesa_astc_fixture.py) ----------
+
+AFIX = np.load(os.path.join(os.path.dirname(__file__), "golden", "mesa_astc.npz"))
+FOOTPRINTS = [(4, 4), (5, 4), (5, 5), (6, 5), (6, 6), (8, 5), (8, 6), (8, 8), (10, 5), (10, 6),
+              (10, 8), (10, 10), (12, 10), (12, 12)]
+
+
+@pytest.mark.parametrize("fi", range(14))
+def test_astc_decoder_equals_mesa_on_structured_random_blocks(fi):
+    """1-4 partitions (hash), dual plane, all LDR endpoint modes, trit/quint sequences, void
+    extent, illegal encodings and HDR modes in the LDR profile (error colour, per partition)."""
+    bw, bh = FOOTPRINTS[fi]
+    blk = AFIX["blocks_%dx%d" % (bw, bh)]
+    want = AFIX["rgba_%dx%d" % (bw, bh)]
+    n = blk.shape[0]
+    got, _ = O.decode_astc(blk.reshape(-1), 43 + fi, bw*n, bh)
+    got = got.reshape(bh, n, bw, 4).transpose(1, 0, 2, 3).reshape(n, bh*bw, 4)
+    assert np.array_equal(got, want)
+
+
+def test_astc_fixture_covers_the_format_features():
+    parts = np.zeros(5, int)
+    dual = trit = quint = 0
+    cems = set()
+    for bw, bh in FOOTPRINTS:
+        blk = AFIX["blocks_%dx%d" % (bw, bh)][:160]            # the valid ones
+        lo = blk.view(np.uint64).reshape(-1, 2)[:, 0]
+        for v in lo:
+            v = int(v)
+            if (v & 0x1FF) == 0x1FC:
+                continue
+            p = ((v >> 11) & 3) + 1
+            parts[p] += 1
+            dual += (v >> 10) & 1 if (v & 3) or ((v >> 7) & 3) != 2 else 0
+            cems.add((v >> 13) & 15 if p == 1 else -1)
+            r = ((v >> 4) & 1) | ((v & 3) << 1 if v & 3 else ((v >> 2) & 3) << 1)
+            trit += r in (3, 6)
+            quint += r == 5
+    assert parts[1] > 300 and parts[2] > 200 and parts[3] > 100 and parts[4] > 50
+    assert dual > 200 and trit > 200 and quint > 100
+    assert {0, 1, 4, 5, 6, 8, 9, 10, 12, 13} <= cems
