@@ -1,56 +1,43 @@
-// astc_encode.hip -- ASTC 2-D LDR block encoder (restricted subset) for gfx950, one
-// wavefront per block, lane = (weight-grid config, endpoint-inset variant).
+// astc_encode.hip -- ASTC 2-D LDR block encoder for gfx950.
 //
 // Replaces, behind cfhip_encode(), the per-block astcenc_compress_image call of
-// AstcConverter::process (lib/src/AstcConverter.cpp:208-230; ARM astc-encoder, absent).
-// Twin of oracle/astc_codec.c (byte-identical).  Emitted subset: void-extent blocks and
-// single-partition CEM 8/12 blocks with 8-bit endpoints, pure-bit weight ranges and the
-// specification's bilinear weight infill, for all 14 footprints (4x4 .. 12x12).  No ASTC
-// decoder exists in this environment: validity rests on the specification and on the
-// self-consistent decoder of the oracle (DESIGN.md states this).
+// AstcConverter::process (lib/src/AstcConverter.cpp:208-230; ARM astc-encoder, absent
+// submodule) with the flags / presets of AstcConverter's constructor (:134-201).  Twin of
+// oracle/astc_encode.c (byte-identical); every emitted block also decodes under Mesa's
+// independent ASTC decoder (tests/test_oracle_mesa.py).
 //
-// Data: the workgroup (4 waves) stages a strip of 16 blocks (16*bw x bh texels) in LDS;
-// the per-config infill tables (base grid index + 4 bilinear factors per texel, and the
-// per-grid-point factor sums) are built once per format on the host (cfhip_api.hip) and
-// read through L1/L2; each lane keeps its grid accumulators / quantised weights in a
-// private LDS column ([grid point][lane], conflict-free for a fixed grid point).
+// Emitted: void extent; 1-4 partitions (partition hash, shortlist by k-means cluster matching
+// against the canonical seed list); single / dual plane; every weight grid N x M <= footprint
+// and weight range (bits, trits, quints); endpoint modes 8/12 (with and without blue
+// contraction), 6/10, 0/4 at the colour quantisation level the remaining bits allow.
+//
+// One wavefront per block (two blocks per wavefront up to Quality::Normal), every lane a
+// different unit of search work in ONE instruction stream:
+//   stats     texels strided over the lanes: moments -> principal axis, k-means clusters
+//   shortlist lane = partition-table entry: popcount overlap with the clusters
+//   phase A   lane = (candidate, subset / plane): moments -> axis -> ideal endpoints, weights
+//   grids     lane = weight grid: decimation error of the ideal weights
+//   ranking   lane = config of the candidate's class: estimated error, K smallest
+//   phase B   lane = (candidate, config): decimate, quantise, least squares, endpoint mode and
+//             quantisation, EXACT error through the decode arithmetic
+//   argmin (error, id) over the lanes and the passes; the group packs the winner (ISE).
+// Data: the workgroup stages a strip of 16 blocks, the footprint's infill / factor-sum tables
+// and the colour / weight quantisation tables in LDS; each lane owns an LDS column for its grid
+// accumulators and quantised weights ([row][lane], conflict-free for a fixed row).
 #include "cf_device.h"
+#include "astc_tables.h"
 
-#define ASTC_MAX_TEXELS 144
-#define ASTC_CFG_STRIDE 1288   // bytes per config record (see AstcCfgDev in cfhip_api.hip)
+using cfastc::AstcBlobHeader;
+using cfastc::AstcCfgRec;
 
 namespace {
 
-// config record accessors (layout: N, M, bits, ng, mode16, pad16, den[64] u16, infill[144] u32x2)
-struct CfgView {
-	const uint8_t* p;
-	__device__ __forceinline__ uint32_t N() const { return p[0]; }
-	__device__ __forceinline__ uint32_t M() const { return p[1]; }
-	__device__ __forceinline__ uint32_t bits() const { return p[2]; }
-	__device__ __forceinline__ uint32_t ng() const { return p[3]; }
-	__device__ __forceinline__ uint32_t mode() const { return *reinterpret_cast<const uint16_t*>(p + 4); }
-	__device__ __forceinline__ uint32_t den(uint32_t j) const
-	{
-		return reinterpret_cast<const uint16_t*>(p + 8)[j];
-	}
-	__device__ __forceinline__ uint2 infill(uint32_t i) const
-	{
-		return reinterpret_cast<const uint2*>(p + 136)[i];
-	}
-};
+#define ASTC_FLAG_ALPHA_WEIGHT 1u
+#define ASTC_FLAG_PERCEPTUAL 2u
 
-__device__ __forceinline__ int unq_weight(int q, int bits)
-{
-	// bit replication of a `bits`-wide value to 6 bits: q * rep >> sh with
-	// (rep, sh) = (63,0) (21,0) (9,0) (17,2) (33,4) for bits = 1..5
-	const int rep = bits == 1 ? 63 : (bits == 2 ? 21 : (bits == 3 ? 9 : (bits == 4 ? 17 : 33)));
-	const int sh = bits == 4 ? 2 : (bits == 5 ? 4 : 0);
-	const int v = (q*rep) >> sh;
-	return v > 32 ? v + 1 : v;
-}
+__device__ __forceinline__ float clampf255(float x) { return x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x); }
 
-// floor(num/den) for num < 2^26, den > 0, quotient < 2^16: float estimate + exact fix-up
-// (a full 32-bit integer division is ~35 VALU instructions and the kernel is issue-bound)
+// floor(num/den), num < 2^26, den > 0, quotient < 2^16 (rden = 1/den, correctly rounded)
 __device__ __forceinline__ uint32_t div_small(uint32_t num, uint32_t den, float rden)
 {
 	uint32_t q = (uint32_t)((float)num*rden);
@@ -61,137 +48,326 @@ __device__ __forceinline__ uint32_t div_small(uint32_t num, uint32_t den, float 
 	return q;
 }
 
-__device__ __forceinline__ float clampf255(float x) { return x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x); }
-
-__device__ const uint8_t k_inset[8][2] = {{0, 0}, {1, 1}, {2, 2}, {3, 3}, {1, 0}, {0, 1}, {2, 0},
-	{0, 2}};
-
-// reconstructed weight of texel i from this lane's quantised grid (private LDS column; the
-// slots hold unquantised | quantised << 8, so the bit replication is done once per grid point)
-__device__ __forceinline__ int texel_weight(const CfgView& cfg, uint32_t i, const uint8_t* qcol,
-	uint32_t N, int bits, uint32_t rows)
+struct Ladder { uint32_t K, limit, j2, j3, j4, nd; };
+__device__ __forceinline__ Ladder ladder(uint32_t q)
 {
-	const uint2 f = cfg.infill(i);   // .x: the four grid points (255 = none), .y: their factors
-	const uint32_t w00 = f.y & 255u, w01 = (f.y >> 8) & 255u, w10 = (f.y >> 16) & 255u, w11 = f.y >> 24;
-	// straight-line: a missing neighbour reads the column's dummy row (rows - 1) and is
-	// multiplied away by its zero factor -- no per-lane branches on the load chain
-	const uint32_t dummy = rows - 1u;
-	(void)N;
-	const uint32_t v0 = f.x & 255u, g1 = min((f.x >> 8) & 255u, dummy), g2 = min((f.x >> 16) & 255u, dummy),
-		g3 = min(f.x >> 24, dummy);
-	// low byte of a slot: the weight already unquantised to 0..64 (high byte: its quantised form)
-	const int u0 = qcol[v0*128u], u1 = qcol[g1*128u], u2 = qcol[g2*128u], u3 = qcol[g3*128u];
-	(void)bits;
-	const int v = (int)w00*u0 + (int)w01*u1 + (int)w10*u2 + (int)w11*u3 + 8;
-	return v >> 4;
+	// twin of k_ladder in oracle/astc_encode.c (stands in for astcenc's presets)
+	switch (q) {
+		case 0: return {2, 0, 0, 0, 0, 0};
+		case 1: return {4, 16, 2, 0, 0, 1};
+		case 2: return {4, 32, 3, 2, 0, 2};
+		case 3: return {8, 96, 8, 5, 0, 2};
+		default: return {8, 256, 14, 9, 6, 2};
+	}
 }
 
-__device__ __forceinline__ uint32_t astc_error(const uint32_t* tp, uint32_t n, uint32_t nc,
-	const int (&e0)[4], const int (&e1)[4], const CfgView& cfg, const uint8_t* qcol, uint32_t N, int bits,
-	uint32_t rows)
+// candidate descriptor: P | dual << 3 | ccs << 4 | cls << 6 | table index << 16
+__device__ __forceinline__ uint32_t pc_make(uint32_t P, uint32_t dual, uint32_t ccs, uint32_t cls, uint32_t tab)
 {
-	// ((e0*257*(64 - w) + e1*257*w + 32) >> 6) >> 8  ==  (base + slope*w) >> 14, all terms >= 0
-	int base[4], slope[4];
+	return P | (dual << 3) | (ccs << 4) | (cls << 6) | (tab << 16);
+}
+__device__ __forceinline__ uint32_t pc_P(uint32_t d) { return d & 7u; }
+__device__ __forceinline__ uint32_t pc_dual(uint32_t d) { return (d >> 3) & 1u; }
+__device__ __forceinline__ uint32_t pc_ccs(uint32_t d) { return (d >> 4) & 3u; }
+__device__ __forceinline__ uint32_t pc_cls(uint32_t d) { return (d >> 6) & 7u; }
+__device__ __forceinline__ uint32_t pc_tab(uint32_t d) { return d >> 16; }
+
+// principal axis: three normalised power iterations from the column of the largest diagonal
+struct Cov { float c00, c01, c02, c03, c11, c12, c13, c22, c23, c33; };
+__device__ __forceinline__ void principal_axis(const Cov& C, float (&axis)[4])
+{
+	float bestd = C.c00, v0 = C.c00, v1 = C.c01, v2 = C.c02, v3 = C.c03;
+	if (C.c11 > bestd) { bestd = C.c11; v0 = C.c01; v1 = C.c11; v2 = C.c12; v3 = C.c13; }
+	if (C.c22 > bestd) { bestd = C.c22; v0 = C.c02; v1 = C.c12; v2 = C.c22; v3 = C.c23; }
+	if (C.c33 > bestd) { bestd = C.c33; v0 = C.c03; v1 = C.c13; v2 = C.c23; v3 = C.c33; }
 #pragma unroll
-	for (int c = 0; c < 4; ++c) {
-		base[c] = e0[c]*257*64 + 32;
-		slope[c] = (e1[c] - e0[c])*257;
-	}
-	uint32_t err = 0;
-#pragma unroll 1
-	for (uint32_t i = 0; i < n; ++i) {
-		const int w = texel_weight(cfg, i, qcol, N, bits, rows);
-		const uint32_t p = tp[i];
-#pragma unroll
-		for (uint32_t c = 0; c < 4u; ++c) {
-			if (c < nc) {
-				const int v = (base[c] + slope[c]*w) >> 14;
-				const int d = v - (int)((p >> (8u*c)) & 255u);
-				err += (uint32_t)(d*d);
-			}
+	for (int it = 0; it < 3; ++it) {
+		const float m = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
+		if (m > 0.0f) {
+			const float im = 1.0f/m;
+			v0 = v0*im; v1 = v1*im; v2 = v2*im; v3 = v3*im;
 		}
+		float r0 = C.c00*v0; r0 = fmaf(C.c01, v1, r0); r0 = fmaf(C.c02, v2, r0); r0 = fmaf(C.c03, v3, r0);
+		float r1 = C.c01*v0; r1 = fmaf(C.c11, v1, r1); r1 = fmaf(C.c12, v2, r1); r1 = fmaf(C.c13, v3, r1);
+		float r2 = C.c02*v0; r2 = fmaf(C.c12, v1, r2); r2 = fmaf(C.c22, v2, r2); r2 = fmaf(C.c23, v3, r2);
+		float r3 = C.c03*v0; r3 = fmaf(C.c13, v1, r3); r3 = fmaf(C.c23, v2, r3); r3 = fmaf(C.c33, v3, r3);
+		v0 = r0; v1 = r1; v2 = r2; v3 = r3;
 	}
-	return err;
+	const float mx = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
+	axis[0] = axis[1] = axis[2] = axis[3] = 0.0f;
+	if (mx > 0.0f) {
+		const float im = 1.0f/mx;
+		v0 = v0*im; v1 = v1*im; v2 = v2*im; v3 = v3*im;
+		float l2 = v0*v0;
+		l2 = fmaf(v1, v1, l2);
+		l2 = fmaf(v2, v2, l2);
+		l2 = fmaf(v3, v3, l2);
+		const float is = 1.0f/sqrtf(l2);
+		axis[0] = v0*is; axis[1] = v1*is; axis[2] = v2*is; axis[3] = v3*is;
+	}
 }
 
-// astc_error with the texel weights read back from the lane's cache rows (footprints of up to
-// 40 texels: the refit pass stored them, two per u16 slot, behind the grid rows of the column)
-__device__ __forceinline__ uint32_t astc_error_cached(const uint32_t* tp, uint32_t n, uint32_t nc,
-	const int (&e0)[4], const int (&e1)[4], const uint8_t* wcache)
+__device__ __forceinline__ float quad_est(float fA, float fB, float fC, float d0, float d1)
 {
-	int base[4], slope[4];
+	float t = fA*d0;
+	t = fmaf(fB, d1, t);
+	float u = fB*d0;
+	u = fmaf(fC, d1, u);
+	float q = t*d0;
+	q = fmaf(u, d1, q);
+	return q;
+}
+
+// the workgroup's shared tables in LDS
+struct Shared {
+	const uint32_t* infill;   // [grid][n]
+	const uint16_t* den;      // [grid][64]
+	const uint8_t* grid;      // [grid][4]: N, M, ng
+	const uint8_t* cunq;      // [17][256]
+	const uint8_t* cnear;     // [17][256]
+	const uint8_t* wunq;      // [12][32]
+	const uint8_t* wnear;     // [12][68]
+};
+
+// per (wave, block slot) scratch in LDS
+struct Slot {
+	uint8_t* T;        // [8][2][npad]
+	uint8_t* pid;      // [8][npad]
+	uint32_t* e0;      // [32]
+	uint32_t* e1;      // [32]
+	uint32_t* span;    // [32]
+	uint32_t* edec;    // [32]
+	uint8_t* order;    // [8][8]
+	uint32_t* pcs;     // [40]
+	uint32_t* best;    // [28]: meta[4], cvals[5 words], weights[16 words]
+};
+
+__device__ __forceinline__ int quant_c(const Shared& sh, uint32_t lv, float x, uint32_t& stored)
+{
+	const uint32_t xi = (uint32_t)(int)floorf(clampf255(x) + 0.5f);
+	stored = sh.cnear[lv*256u + xi];
+	return (int)sh.cunq[lv*256u + stored];
+}
+
+// One endpoint-mode option of one partition: estimate, and (when `emit`) the decoded endpoint
+// bytes and the stored ISE values.  o: 0 direct (CEM 8/12), 1 base+scale (6/10), 2 luminance (0/4).
+// r0 / r1: least-squares endpoints (alpha = 255 for blocks without alpha); A/B/C per channel.
+// Returns false when the option cannot represent the pair (direct with neither order valid).
+__device__ __forceinline__ bool cem_option(const Shared& sh, int o, uint32_t lv, bool has_alpha,
+	const float (&r0)[4], const float (&r1)[4], const float (&fA)[4], const float (&fB)[4],
+	const float (&fC)[4], const uint32_t (&cw)[4], float& est, uint32_t& d0p, uint32_t& d1p,
+	uint32_t (&vals)[8])
+{
+	int d0[4], d1[4];
+	d0[3] = 255; d1[3] = 255;
+	uint32_t s;
+	if (o == 0) {
+		int dd0[3], dd1[3], sd0 = 0, sd1 = 0;
+		uint32_t st[6];
 #pragma unroll
-	for (int c = 0; c < 4; ++c) {
-		base[c] = e0[c]*257*64 + 32;
-		slope[c] = (e1[c] - e0[c])*257;
-	}
-	uint32_t err = 0;
-#pragma unroll 1
-	for (uint32_t i = 0; i < n; ++i) {
-		const int w = wcache[(i >> 1)*128u + (i & 1u)];
-		const uint32_t p = tp[i];
+		for (int c = 0; c < 3; ++c) {
+			dd0[c] = quant_c(sh, lv, r0[c], st[2*c]);
+			dd1[c] = quant_c(sh, lv, r1[c], st[2*c + 1]);
+			sd0 += dd0[c]; sd1 += dd1[c];
+		}
+		float ed = 3.0e38f, ec = 3.0e38f;
+		if (sd1 >= sd0) {
+			ed = 0.0f;
 #pragma unroll
-		for (uint32_t c = 0; c < 4u; ++c) {
-			if (c < nc) {
-				const int v = (base[c] + slope[c]*w) >> 14;
-				const int d = v - (int)((p >> (8u*c)) & 255u);
-				err += (uint32_t)(d*d);
+			for (int c = 0; c < 3; ++c)
+				ed = fmaf((float)cw[c], quad_est(fA[c], fB[c], fC[c], (float)dd0[c] - r0[c], (float)dd1[c] - r1[c]), ed);
+		}
+		const float i0[3] = {fmaf(2.0f, r0[0], -r0[2]), fmaf(2.0f, r0[1], -r0[2]), r0[2]};
+		const float i1[3] = {fmaf(2.0f, r1[0], -r1[2]), fmaf(2.0f, r1[1], -r1[2]), r1[2]};
+		bool cok = true;
+#pragma unroll
+		for (int c = 0; c < 3; ++c)
+			cok = cok && i0[c] >= 0.0f && i0[c] <= 255.0f && i1[c] >= 0.0f && i1[c] <= 255.0f;
+		uint32_t sc[6] = {0, 0, 0, 0, 0, 0};
+		int c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
+		if (cok) {
+			int u0[3], u1[3], sc0 = 0, sc1 = 0;
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				u0[c] = quant_c(sh, lv, i0[c], sc[2*c + 1]);
+				u1[c] = quant_c(sh, lv, i1[c], sc[2*c]);
+				sc1 += u0[c]; sc0 += u1[c];
+			}
+			if (sc1 < sc0) {
+				c0[0] = (u0[0] + u0[2]) >> 1; c0[1] = (u0[1] + u0[2]) >> 1; c0[2] = u0[2];
+				c1[0] = (u1[0] + u1[2]) >> 1; c1[1] = (u1[1] + u1[2]) >> 1; c1[2] = u1[2];
+				ec = 0.0f;
+#pragma unroll
+				for (int c = 0; c < 3; ++c)
+					ec = fmaf((float)cw[c], quad_est(fA[c], fB[c], fC[c], (float)c0[c] - r0[c], (float)c1[c] - r1[c]), ec);
 			}
 		}
+		if (ed >= 3.0e38f && ec >= 3.0e38f)
+			return false;
+		const bool contract = ec < ed;
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			d0[c] = contract ? c0[c] : dd0[c];
+			d1[c] = contract ? c1[c] : dd1[c];
+			vals[2*c] = contract ? sc[2*c] : st[2*c];
+			vals[2*c + 1] = contract ? sc[2*c + 1] : st[2*c + 1];
+		}
+		est += contract ? ec : ed;
+		if (has_alpha) {
+			uint32_t s6, s7;
+			d0[3] = quant_c(sh, lv, r0[3], s6);
+			d1[3] = quant_c(sh, lv, r1[3], s7);
+			vals[6] = contract ? s7 : s6;
+			vals[7] = contract ? s6 : s7;
+			est = fmaf((float)cw[3], quad_est(fA[3], fB[3], fC[3], (float)d0[3] - r0[3], (float)d1[3] - r1[3]), est);
+		}
+	} else if (o == 1) {
+		float num = 0.0f, dn = 0.0f;
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			d1[c] = quant_c(sh, lv, r1[c], s);
+			vals[c] = s;
+			num = fmaf(r0[c], (float)d1[c], num);
+			dn = fmaf((float)d1[c], (float)d1[c], dn);
+		}
+		const float sf = dn > 0.0f ? num*(256.0f/dn) : 0.0f;
+		const int sq = quant_c(sh, lv, sf, s);
+		vals[3] = s;
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			d0[c] = (d1[c]*sq) >> 8;
+			est = fmaf((float)cw[c], quad_est(fA[c], fB[c], fC[c], (float)d0[c] - r0[c], (float)d1[c] - r1[c]), est);
+		}
+		if (has_alpha) {
+			uint32_t s4, s5;
+			d0[3] = quant_c(sh, lv, r0[3], s4);
+			d1[3] = quant_c(sh, lv, r1[3], s5);
+			vals[4] = s4; vals[5] = s5;
+			est = fmaf((float)cw[3], quad_est(fA[3], fB[3], fC[3], (float)d0[3] - r0[3], (float)d1[3] - r1[3]), est);
+		}
+	} else {
+		uint32_t s0, s1;
+		const int l0 = quant_c(sh, lv, r0[0], s0), l1 = quant_c(sh, lv, r1[0], s1);
+		vals[0] = s0; vals[1] = s1;
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			d0[c] = l0; d1[c] = l1;
+			est = fmaf((float)cw[c], quad_est(fA[c], fB[c], fC[c], (float)l0 - r0[c], (float)l1 - r1[c]), est);
+		}
+		if (has_alpha) {
+			uint32_t s2, s3;
+			d0[3] = quant_c(sh, lv, r0[3], s2);
+			d1[3] = quant_c(sh, lv, r1[3], s3);
+			vals[2] = s2; vals[3] = s3;
+			est = fmaf((float)cw[3], quad_est(fA[3], fB[3], fC[3], (float)d0[3] - r0[3], (float)d1[3] - r1[3]), est);
+		}
 	}
-	return err;
+	d0p = (uint32_t)d0[0] | ((uint32_t)d0[1] << 8) | ((uint32_t)d0[2] << 16) | ((uint32_t)d0[3] << 24);
+	d1p = (uint32_t)d1[0] | ((uint32_t)d1[1] << 8) | ((uint32_t)d1[2] << 16) | ((uint32_t)d1[3] << 24);
+	return true;
+}
+
+// bits [pos, pos + n) of a 128-bit block held as two u64 halves
+__device__ __forceinline__ void put128(unsigned long long& lo, unsigned long long& hi, uint32_t pos, unsigned long long v, uint32_t n)
+{
+	if (n == 0u)
+		return;
+	if (pos < 64u) {
+		lo |= v << pos;
+		if (pos + n > 64u)
+			hi |= v >> (64u - pos);
+	} else
+		hi |= v << (pos - 64u);
+}
+
+// size in bits of `count` ISE values of a range (bits, trits, quints)
+__device__ __forceinline__ uint32_t ise_size(uint32_t count, uint32_t bits, uint32_t trits, uint32_t quints)
+{
+	return count*bits + (trits ? (8u*count + 4u)/5u : 0u) + (quints ? (7u*count + 2u)/3u : 0u);
+}
+
+// the ISE bit string of one group of values (5 with trits, 3 with quints, 1 otherwise), little
+// endian, `cnt` values present; returns the string and its length
+__device__ __forceinline__ unsigned long long ise_group(const uint8_t* ise, const uint32_t (&v)[5], uint32_t cnt,
+	uint32_t bits, uint32_t trits, uint32_t quints, uint32_t& len)
+{
+	const uint32_t mask = (1u << bits) - 1u;
+	unsigned long long out = 0;     // up to 5 x 6 + 8 = 38 bits (colour trits)
+	uint32_t pos = 0;
+	if (trits) {
+		const uint32_t T = ise[(v[0] >> bits) + 3u*(v[1] >> bits) + 9u*(v[2] >> bits) + 27u*(v[3] >> bits) + 81u*(v[4] >> bits)];
+		const uint32_t tb[5] = {2, 2, 1, 2, 1}, ts[5] = {0, 2, 4, 5, 7};
+#pragma unroll
+		for (uint32_t k = 0; k < 5u; ++k) {
+			if (k < cnt) {
+				out |= (unsigned long long)(v[k] & mask) << pos; pos += bits;
+				out |= (unsigned long long)((T >> ts[k]) & ((1u << tb[k]) - 1u)) << pos; pos += tb[k];
+			}
+		}
+	} else if (quints) {
+		const uint32_t Q = ise[256u + (v[0] >> bits) + 5u*(v[1] >> bits) + 25u*(v[2] >> bits)];
+		const uint32_t qb[3] = {3, 2, 2}, qs[3] = {0, 3, 5};
+#pragma unroll
+		for (uint32_t k = 0; k < 3u; ++k) {
+			if (k < cnt) {
+				out |= (unsigned long long)(v[k] & mask) << pos; pos += bits;
+				out |= (unsigned long long)((Q >> qs[k]) & ((1u << qb[k]) - 1u)) << pos; pos += qb[k];
+			}
+		}
+	} else {
+		out = v[0] & mask;
+		pos = bits;
+	}
+	len = pos;
+	return out;
 }
 
 } // namespace
 
-#ifndef CF_ASTC_CACHE_MAX
-#define CF_ASTC_CACHE_MAX 40   // largest footprint (texels) that keeps the texel-weight cache
-#endif
-#ifndef CF_ASTC_WAVES
-#define CF_ASTC_WAVES 3
-#endif
 template <int PIX>
 __global__ void __launch_bounds__(CF_WG_THREADS)
-__attribute__((amdgpu_waves_per_eu(CF_ASTC_WAVES, 8)))
 cfhip_astc_encode_kernel(cf_kparams kp)
 {
-	// All of the workgroup's LDS is sized at launch for the footprint (fewer bytes = more waves
-	// per SIMD to hide the LDS latency this kernel lives on):
-	//   tile  : 16 blocks x bw*bh texels
-	//   tabs  : both config sets (RGB, RGBA), records compacted to 136 + 8*bw*bh bytes -- the
-	//           infill records are read 3-4 times per texel and lane; from L1/L2 each read
-	//           costs several hundred cycles, from LDS ~64
-	//   cols  : per-lane grid columns [wave][grid point * 64 + lane] u16, one row per grid
-	//           point of the footprint's largest weight grid + 1 dummy row: accumulators first,
-	//           then (low byte of the same slots) the quantised weights
 	extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
 	__shared__ uint4 outb[CF_BLOCKS_PER_WG];
-	const uint32_t bw = kp.flags & 255u, bh = (kp.flags >> 8) & 255u, n = bw*bh;
-	const uint32_t rows = (kp.flags >> 16) & 255u;   // largest ng of the staged configs + 1
-	const uint32_t ncs = (kp.flags >> 24) & 15u;     // configs staged per set (the quality's budget)
-	const uint32_t cstride = 136u + 8u*n;            // compact record stride (bytes)
-	const uint32_t tab_words = (8u + 2u*ncs*cstride)/4u;
-	uint32_t* tile = dyn_lds;
-	uint32_t* tabs = dyn_lds + CF_BLOCKS_PER_WG*n;
-	uint16_t* lane_cols = reinterpret_cast<uint16_t*>(tabs + tab_words);
-	{
-		const uint32_t* g = reinterpret_cast<const uint32_t*>(kp.aux);
-		for (uint32_t i = threadIdx.x; i < tab_words; i += CF_WG_THREADS) {
-			// word i of the compact table <- word of the ASTC_CFG_STRIDE-strided table
-			uint32_t src = i;
-			if (i >= 2u) {
-				const uint32_t rec = (i - 2u)/(cstride/4u), off = (i - 2u) - rec*(cstride/4u);
-				const uint32_t set_ = rec >= ncs ? 1u : 0u, k_ = rec - set_*ncs;   // source: 8 records per set
-				src = 2u + (set_*8u + k_)*(ASTC_CFG_STRIDE/4u) + off;
-			}
-			tabs[i] = g[src];
-		}
-	}
+	const uint8_t* blob = reinterpret_cast<const uint8_t*>(kp.aux);
+	const AstcBlobHeader* H = reinterpret_cast<const AstcBlobHeader*>(blob);
+	const uint32_t n = H->n, bw = H->bw, bh = H->bh, ngrids = H->ngrids, npad = H->npad;
+	const uint32_t col_rows = H->col_rows;
+	const uint32_t aflags = (kp.flags >> 16) & 3u;
+	const bool wcached = n <= 64u;
+	const uint32_t wc_rows = wcached ? 2u*((n + 3u)/4u) : 0u;
+
+	// ---- LDS carve-up (byte offsets, 16-byte aligned sections) ----
+	uint8_t* lds = reinterpret_cast<uint8_t*>(dyn_lds);
+	uint32_t off = 0;
+	uint32_t* tile = reinterpret_cast<uint32_t*>(lds + off); off += CF_BLOCKS_PER_WG*n*4u;
+	off = (off + 15u) & ~15u;
+	uint32_t* sh_infill = reinterpret_cast<uint32_t*>(lds + off); off += ngrids*n*4u; off = (off + 15u) & ~15u;
+	uint16_t* sh_den = reinterpret_cast<uint16_t*>(lds + off); off += ngrids*128u;
+	uint8_t* sh_grid = lds + off; off += (ngrids*4u + 15u) & ~15u;
+	uint8_t* sh_ctab = lds + off; off += 2u*17u*256u;
+	uint8_t* sh_wtab = lds + off; off += 1216u;
+	const uint32_t slot_bytes = ((8u*2u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*4u + 64u + 40u*4u + 28u*4u;
+	const uint32_t wave_bytes = ((col_rows*128u + wc_rows*256u + 15u) & ~15u) + 2u*slot_bytes;
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	uint8_t* wbase = lds + off + wave*wave_bytes;
+
+	for (uint32_t i = threadIdx.x; i < ngrids*n; i += CF_WG_THREADS)
+		sh_infill[i] = reinterpret_cast<const uint32_t*>(blob + H->off_infill)[i];
+	for (uint32_t i = threadIdx.x; i < ngrids*64u; i += CF_WG_THREADS)
+		sh_den[i] = reinterpret_cast<const uint16_t*>(blob + H->off_den)[i];
+	for (uint32_t i = threadIdx.x; i < ngrids; i += CF_WG_THREADS)
+		reinterpret_cast<uint32_t*>(sh_grid)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_grid)[i];
+	for (uint32_t i = threadIdx.x; i < 2u*17u*64u; i += CF_WG_THREADS)
+		reinterpret_cast<uint32_t*>(sh_ctab)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_ctab)[i];
+	for (uint32_t i = threadIdx.x; i < 304u; i += CF_WG_THREADS)
+		reinterpret_cast<uint32_t*>(sh_wtab)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_wtab)[i];
+
 	uint32_t gx_, gy_;
 	cf_resolve(kp, gx_, gy_);
 	const uint32_t bx0 = gx_*CF_BLOCKS_PER_WG, byy = gy_;
 	{
-		// stage 16 blocks: (16*bw) x bh texels, coalesced along x, stored block-major
 		const uint32_t sw = CF_BLOCKS_PER_WG*bw, total = sw*bh;
 		for (uint32_t idx = threadIdx.x; idx < total; idx += CF_WG_THREADS) {
 			const uint32_t row = idx/sw, col = idx - row*sw;
@@ -205,8 +381,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				px = *reinterpret_cast<const uint32_t*>(rowp + (size_t)x*4u);
 			else {
 				const float4 f = *reinterpret_cast<const float4*>(rowp + (size_t)x*16u);
-				px = cf_unorm8(f.x) | (cf_unorm8(f.y) << 8) | (cf_unorm8(f.z) << 16) |
-					(cf_unorm8(f.w) << 24);
+				px = cf_unorm8(f.x) | (cf_unorm8(f.y) << 8) | (cf_unorm8(f.z) << 16) | (cf_unorm8(f.w) << 24);
 			}
 			// swizzle from colour mask / alpha type (AstcConverter.cpp:140-149)
 			tile[blk*n + row*bw + cx] = (px & kp.keep_mask) | kp.set_mask;
@@ -214,126 +389,99 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	}
 	__syncthreads();
 
-	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	const uint8_t* tables = reinterpret_cast<const uint8_t*>(tabs);
-	const uint32_t q = kp.quality > 4u ? 4u : kp.quality;
-	const uint32_t qcfg = q == 0u ? 1u : (q == 1u ? 2u : (q == 2u ? 4u : 8u));
-	const uint32_t qvar = q == 0u ? 1u : (q == 1u ? 2u : 8u);
-	const bool refit = q >= 2u;
-	// footprints of up to 40 texels keep a per-lane cache of the reconstructed texel weights
-	// behind the grid rows (ceil(n/2) more rows): the error after the refit reads them back
-	const bool wcached = n <= (uint32_t)CF_ASTC_CACHE_MAX;   // larger footprints: the extra LDS costs more occupancy than it saves
-	const uint32_t col_rows = rows + (wcached ? (n + 1u)/2u : 0u);
-	uint16_t* ncol = lane_cols + wave*col_rows*64u + lane;
-	const uint8_t* qcol = reinterpret_cast<const uint8_t*>(ncol);   // entry g: byte offset g*128
-	const uint32_t dummy = rows - 1u;
+	Shared sh;
+	sh.infill = sh_infill; sh.den = sh_den; sh.grid = sh_grid;
+	sh.cunq = sh_ctab; sh.cnear = sh_ctab + 17u*256u;
+	sh.wunq = sh_wtab; sh.wnear = sh_wtab + 12u*32u;
+	const int8_t* clevel = reinterpret_cast<const int8_t*>(blob + H->off_clevel);
+	const uint8_t* ise = blob + H->off_ise;
+	const AstcCfgRec* cfgs = reinterpret_cast<const AstcCfgRec*>(blob + H->off_cfg);
+	const uint8_t* ncfgs = blob + H->off_ncfg;
 
-	// Up to Normal a block's candidates (<= 4 configs x 8 variants) fill half a wavefront: two
-	// neighbouring blocks then share one pass (lane group h = lane >> 5), which is worth nearly
-	// 2x here because the kernel waits on LDS latency, not on issue slots.
+	uint16_t* col = reinterpret_cast<uint16_t*>(wbase) + lane;                 // row r: col[r*64]
+	uint32_t* wcache = reinterpret_cast<uint32_t*>(wbase + col_rows*128u) + lane;   // row r: wcache[r*64]
+	uint8_t* slot0 = wbase + ((col_rows*128u + wc_rows*256u + 15u) & ~15u);
+
+	const uint32_t q = kp.quality > 4u ? 4u : kp.quality;
+	const Ladder lad = ladder(q);
 	const bool can_pair = q <= 2u;
-	for (uint32_t j = 0; j < 4u;) {
-		const uint32_t b0 = wave*4u + j;
+	uint32_t cw[4] = {1u, 1u, 1u, 1u};
+	if (aflags & ASTC_FLAG_PERCEPTUAL) { cw[0] = 11u; cw[1] = 21u; cw[2] = 4u; cw[3] = 16u; }
+	const uint32_t recip_n = 65536u/n;                                          // x / n as (x * recip_n) >> 16, like the oracle
+
+	for (uint32_t jb = 0; jb < 4u;) {
+		const uint32_t b0 = wave*4u + jb;
 		if (bx0 + b0 >= kp.bx)
 			break;
-		const bool pair = can_pair && j < 3u && bx0 + b0 + 1u < kp.bx;
-		j += pair ? 2u : 1u;
-		const uint32_t h = lane >> 5, hl = pair ? (lane & 31u) : lane, gsz = pair ? 32u : 64u;
-		const uint32_t b = pair ? b0 + h : b0;
+		const bool pair = can_pair && jb < 3u && bx0 + b0 + 1u < kp.bx;
+		jb += pair ? 2u : 1u;
+		const uint32_t h = pair ? lane >> 5 : 0u, hl = pair ? (lane & 31u) : lane, gsz = pair ? 32u : 64u;
+		const uint32_t b = b0 + h;
 		const uint32_t* tp = tile + b*n;
-		// solid / alpha tests over the texels (the group's lanes stride)
+		Slot S;
+		{
+			uint8_t* sp = slot0 + h*slot_bytes;
+			S.T = sp; S.pid = sp + 16u*npad;
+			uint32_t* w32 = reinterpret_cast<uint32_t*>(sp + ((24u*npad + 15u) & ~15u));
+			S.e0 = w32; S.e1 = w32 + 32; S.span = w32 + 64; S.edec = w32 + 96;
+			S.order = reinterpret_cast<uint8_t*>(w32 + 128);
+			S.pcs = w32 + 144; S.best = w32 + 184;
+		}
+
+		// ---- block statistics (texels strided over the group) ----
 		const uint32_t p0 = tp[0];
-		bool diff = false, alpha = false;
+		bool diff = false, alpha = false, colour = false;
+		uint32_t s01 = 0, s23 = 0, m00 = 0, m01 = 0, m02 = 0, m03 = 0, m11 = 0, m12 = 0, m13 = 0, m22 = 0, m23 = 0, m33 = 0;
 		for (uint32_t i = hl; i < n; i += gsz) {
 			const uint32_t p = tp[i];
 			diff = diff || p != p0;
 			alpha = alpha || (p >> 24) != 255u;
+			const uint32_t c0 = p & 255u, c1 = (p >> 8) & 255u, c2 = (p >> 16) & 255u;
+			colour = colour || c0 != c1 || c0 != c2;
 		}
-		const unsigned long long dbal = __ballot(diff), abal = __ballot(alpha);
-		const uint32_t dgrp = pair ? (uint32_t)(h ? dbal >> 32 : dbal) : (uint32_t)(dbal | (dbal >> 32));
-		const uint32_t agrp = pair ? (uint32_t)(h ? abal >> 32 : abal) : (uint32_t)(abal | (abal >> 32));
-		const bool solid = dgrp == 0u;
-		const bool has_alpha = agrp != 0u;
+		const unsigned long long dbal = __ballot(diff), abal = __ballot(alpha), cbal = __ballot(colour);
+		const bool solid = (pair ? (uint32_t)(h ? dbal >> 32 : dbal) : (uint32_t)(dbal | (dbal >> 32))) == 0u;
+		const bool has_alpha = (pair ? (uint32_t)(h ? abal >> 32 : abal) : (uint32_t)(abal | (abal >> 32))) != 0u;
+		const bool grey = (pair ? (uint32_t)(h ? cbal >> 32 : cbal) : (uint32_t)(cbal | (cbal >> 32))) == 0u;
 		if (solid && hl == 0u) {
-			// void-extent block: 0xFFFFFFFFFFFFFDFC + RGBA as UNORM16 (c * 257)
 			const uint32_t r = p0 & 255u, g = (p0 >> 8) & 255u, bl = (p0 >> 16) & 255u, a = p0 >> 24;
-			outb[b] = make_uint4(0xFFFFFDFCu, 0xFFFFFFFFu, (r*257u) | ((g*257u) << 16),
-				(bl*257u) | ((a*257u) << 16));
+			outb[b] = make_uint4(0xFFFFFDFCu, 0xFFFFFFFFu, (r*257u) | ((g*257u) << 16), (bl*257u) | ((a*257u) << 16));
 		}
 		if (__ballot(!solid) == 0ull)
-			continue;   // nothing but constant blocks in this pass
+			continue;
 		const uint32_t nc = has_alpha ? 4u : 3u;
-		const uint8_t* set = tables + (has_alpha ? 8u + ncs*cstride : 8u);
-		const uint32_t ncfg_all = tables[has_alpha ? 1 : 0];
-		const uint32_t use_cfg = ncfg_all < qcfg ? ncfg_all : qcfg;
-
-		// PCA extremes of the block.  The moments are exact integers summed with the group's
-		// lanes striding over the texels (order-free, so the oracle's plain loops give the same
-		// numbers); covariance up to the factor n^2 as n*S_ab - S_a*S_b, one rounding to float.
+		for (uint32_t i = hl; i < n; i += gsz) {
+			const uint32_t p = tp[i];
+			const uint32_t c0 = p & 255u, c1 = (p >> 8) & 255u, c2 = (p >> 16) & 255u, c3 = nc == 4u ? p >> 24 : 0u;
+			s01 += c0 | (c1 << 16); s23 += c2 | (c3 << 16);
+			m00 += c0*c0; m01 += c0*c1; m02 += c0*c2; m03 += c0*c3;
+			m11 += c1*c1; m12 += c1*c2; m13 += c1*c3;
+			m22 += c2*c2; m23 += c2*c3; m33 += c3*c3;
+		}
 		int sum[4];
-		float C00, C01, C02, C03, C11, C12, C13, C22, C23, C33;
+		Cov C;
 		{
-			uint32_t s01 = 0, s23 = 0, m00 = 0, m01 = 0, m02 = 0, m03 = 0, m11 = 0, m12 = 0, m13 = 0,
-				m22 = 0, m23 = 0, m33 = 0;
-			for (uint32_t i = hl; i < n; i += gsz) {
-				const uint32_t p = tp[i];
-				const uint32_t c0 = p & 255u, c1 = (p >> 8) & 255u, c2 = (p >> 16) & 255u,
-					c3 = nc == 4u ? p >> 24 : 0u;
-				s01 += c0 | (c1 << 16); s23 += c2 | (c3 << 16);
-				m00 += c0*c0; m01 += c0*c1; m02 += c0*c2; m03 += c0*c3;
-				m11 += c1*c1; m12 += c1*c2; m13 += c1*c3;
-				m22 += c2*c2; m23 += c2*c3; m33 += c3*c3;
-			}
 			s01 = cf_group_sum_u32(s01, pair, h); s23 = cf_group_sum_u32(s23, pair, h);
 			sum[0] = (int)(s01 & 0xFFFFu); sum[1] = (int)(s01 >> 16);
 			sum[2] = (int)(s23 & 0xFFFFu); sum[3] = (int)(s23 >> 16);
 			const int ni = (int)n;
-			C00 = (float)(ni*(int)cf_group_sum_u32(m00, pair, h) - sum[0]*sum[0]);
-			C01 = (float)(ni*(int)cf_group_sum_u32(m01, pair, h) - sum[0]*sum[1]);
-			C02 = (float)(ni*(int)cf_group_sum_u32(m02, pair, h) - sum[0]*sum[2]);
-			C11 = (float)(ni*(int)cf_group_sum_u32(m11, pair, h) - sum[1]*sum[1]);
-			C12 = (float)(ni*(int)cf_group_sum_u32(m12, pair, h) - sum[1]*sum[2]);
-			C22 = (float)(ni*(int)cf_group_sum_u32(m22, pair, h) - sum[2]*sum[2]);
-			// alpha moments only matter for blocks with alpha (zero otherwise)
-			C03 = (float)(ni*(int)cf_group_sum_u32(m03, pair, h) - sum[0]*sum[3]);
-			C13 = (float)(ni*(int)cf_group_sum_u32(m13, pair, h) - sum[1]*sum[3]);
-			C23 = (float)(ni*(int)cf_group_sum_u32(m23, pair, h) - sum[2]*sum[3]);
-			C33 = (float)(ni*(int)cf_group_sum_u32(m33, pair, h) - sum[3]*sum[3]);
+			C.c00 = (float)(ni*(int)cf_group_sum_u32(m00, pair, h) - sum[0]*sum[0]);
+			C.c01 = (float)(ni*(int)cf_group_sum_u32(m01, pair, h) - sum[0]*sum[1]);
+			C.c02 = (float)(ni*(int)cf_group_sum_u32(m02, pair, h) - sum[0]*sum[2]);
+			C.c03 = (float)(ni*(int)cf_group_sum_u32(m03, pair, h) - sum[0]*sum[3]);
+			C.c11 = (float)(ni*(int)cf_group_sum_u32(m11, pair, h) - sum[1]*sum[1]);
+			C.c12 = (float)(ni*(int)cf_group_sum_u32(m12, pair, h) - sum[1]*sum[2]);
+			C.c13 = (float)(ni*(int)cf_group_sum_u32(m13, pair, h) - sum[1]*sum[3]);
+			C.c22 = (float)(ni*(int)cf_group_sum_u32(m22, pair, h) - sum[2]*sum[2]);
+			C.c23 = (float)(ni*(int)cf_group_sum_u32(m23, pair, h) - sum[2]*sum[3]);
+			C.c33 = (float)(ni*(int)cf_group_sum_u32(m33, pair, h) - sum[3]*sum[3]);
 		}
 		const float in = 1.0f/(float)n;
-		float mean[4];
+		float mean[4], axis[4];
 #pragma unroll
 		for (int c = 0; c < 4; ++c)
 			mean[c] = (float)sum[c]*in;
-		float bestd = C00, v0 = C00, v1 = C01, v2 = C02, v3 = C03;
-		if (C11 > bestd) { bestd = C11; v0 = C01; v1 = C11; v2 = C12; v3 = C13; }
-		if (C22 > bestd) { bestd = C22; v0 = C02; v1 = C12; v2 = C22; v3 = C23; }
-		if (C33 > bestd) { bestd = C33; v0 = C03; v1 = C13; v2 = C23; v3 = C33; }
-#pragma unroll
-		for (int it = 0; it < 3; ++it) {
-			const float m = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
-			if (m > 0.0f) {
-				const float im = 1.0f/m;
-				v0 = v0*im; v1 = v1*im; v2 = v2*im; v3 = v3*im;
-			}
-			float r0 = C00*v0; r0 = fmaf(C01, v1, r0); r0 = fmaf(C02, v2, r0); r0 = fmaf(C03, v3, r0);
-			float r1 = C01*v0; r1 = fmaf(C11, v1, r1); r1 = fmaf(C12, v2, r1); r1 = fmaf(C13, v3, r1);
-			float r2 = C02*v0; r2 = fmaf(C12, v1, r2); r2 = fmaf(C22, v2, r2); r2 = fmaf(C23, v3, r2);
-			float r3 = C03*v0; r3 = fmaf(C13, v1, r3); r3 = fmaf(C23, v2, r3); r3 = fmaf(C33, v3, r3);
-			v0 = r0; v1 = r1; v2 = r2; v3 = r3;
-		}
-		const float mx = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
-		float axis[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-		if (mx > 0.0f) {
-			const float im = 1.0f/mx;
-			v0 = v0*im; v1 = v1*im; v2 = v2*im; v3 = v3*im;
-			float l2 = v0*v0;
-			l2 = fmaf(v1, v1, l2);
-			l2 = fmaf(v2, v2, l2);
-			l2 = fmaf(v3, v3, l2);
-			const float is = 1.0f/sqrtf(l2);
-			axis[0] = v0*is; axis[1] = v1*is; axis[2] = v2*is; axis[3] = v3*is;
-		}
+		principal_axis(C, axis);
 		float tmin = 3.0e38f, tmax = -3.0e38f;
 		for (uint32_t i = hl; i < n; i += gsz) {
 			const uint32_t p = tp[i];
@@ -346,186 +494,737 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		}
 		tmin = cf_group_min_f32(tmin, pair, h);
 		tmax = cf_group_max_f32(tmax, pair, h);
-		float lo[4], hi[4];
+		uint32_t lowc = 0;
+		{
+			const float Cd[3] = {C.c00, C.c11, C.c22}, Co[3] = {C.c12, C.c02, C.c01};
+			float score[3];
 #pragma unroll
-		for (int c = 0; c < 4; ++c) {
-			lo[c] = clampf255(fmaf(axis[c], tmin, mean[c]));
-			hi[c] = clampf255(fmaf(axis[c], tmax, mean[c]));
+			for (int c = 0; c < 3; ++c) {
+				const int o1 = (c + 1) % 3, o2 = (c + 2) % 3;
+				const float c1 = Co[o2], c2 = Co[o1];
+				const float d1 = Cd[c]*Cd[o1], d2 = Cd[c]*Cd[o2];
+				const float s1 = d1 > 0.0f ? (c1*c1)/d1 : 1.0f, s2 = d2 > 0.0f ? (c2*c2)/d2 : 1.0f;
+				score[c] = s1 + s2;
+			}
+			if (score[1] < score[lowc]) lowc = 1;
+			if (score[2] < score[lowc]) lowc = 2;
 		}
 
-		// ---- lane = (config, inset variant) ----
-		const uint32_t k = hl >> 3, var = hl & 7u;
-		const bool active = !solid && k < use_cfg && var < qvar;
-		uint32_t err = 0xFFFFFFFFu;
-		int e0[4] = {0, 0, 0, 255}, e1[4] = {0, 0, 0, 255};
-		CfgView cfg = {set + (active ? k : 0u)*cstride};
-		const uint32_t N = cfg.N(), ng = cfg.ng();
-		const int bits = (int)cfg.bits(), qmax = (1 << bits) - 1;
-		if (active) {
-			const float tl = (float)k_inset[var][0]*(1.0f/32.0f), th = (float)k_inset[var][1]*(1.0f/32.0f);
-#pragma unroll
-			for (uint32_t c = 0; c < 4u; ++c) {
-				if (c < nc) {
-					const float d = hi[c] - lo[c];
-					const float a = fmaf(d, tl, lo[c]), bb = fmaf(-d, th, hi[c]);
-					e0[c] = (int)floorf(clampf255(a) + 0.5f);
-					e1[c] = (int)floorf(clampf255(bb) + 0.5f);
-				}
+		// ---- candidate list (ids as in the oracle) ----
+		uint32_t npc = 0;
+		if (hl == 0u)
+			S.pcs[0] = pc_make(1, 0, 0, 0, 0);
+		npc = 1;
+		if (lad.nd >= 1u) {
+			if (has_alpha) {
+				if (hl == 0u) S.pcs[npc] = pc_make(1, 1, 3, 1, 0);
+				++npc;
+			} else if (lad.nd >= 2u && !grey) {
+				if (hl == 0u) S.pcs[npc] = pc_make(1, 1, lowc, 1, 0);
+				++npc;
 			}
-			if (e1[0] + e1[1] + e1[2] < e0[0] + e0[1] + e0[2]) {
-#pragma unroll
-				for (int c = 0; c < 4; ++c) { const int t = e0[c]; e0[c] = e1[c]; e1[c] = t; }
-			}
-			int dv[4] = {0, 0, 0, 0}, dd = 0;
-#pragma unroll
-			for (uint32_t c = 0; c < 4u; ++c) {
-				if (c < nc) {
-					dv[c] = e1[c] - e0[c];
-					dd += dv[c]*dv[c];
-				}
-			}
-			const float rdd2 = dd > 0 ? 1.0f/(float)(2*dd) : 0.0f;
-			for (uint32_t g = 0; g < ng; ++g)
-				ncol[g*64u] = 0;
-#pragma unroll 1
-			for (uint32_t i = 0; i < n; ++i) {
+		}
+		if (lad.nd >= 2u && has_alpha && !grey) {
+			if (hl == 0u) S.pcs[npc] = pc_make(1, 1, lowc, 1, 0);
+			++npc;
+		}
+		// k-means clusters along the principal axis + one Lloyd step, then the partition shortlist
+		for (uint32_t P = 2; P <= 4u; ++P) {
+			const uint32_t want = P == 2u ? lad.j2 : (P == 3u ? lad.j3 : lad.j4);
+			if (!want)
+				continue;
+			const float step = (tmax - tmin)*(1.0f/(float)P);
+			uint32_t ks01[4] = {0, 0, 0, 0}, ks23[4] = {0, 0, 0, 0}, kcnt[4] = {0, 0, 0, 0};
+			for (uint32_t i = hl; i < n; i += gsz) {
 				const uint32_t p = tp[i];
-				int t = 0, T = 0;
+				const uint32_t c0 = p & 255u, c1 = (p >> 8) & 255u, c2 = (p >> 16) & 255u, c3 = nc == 4u ? p >> 24 : 0u;
+				float t = axis[0]*((float)c0 - mean[0]);
+				t = fmaf(axis[1], (float)c1 - mean[1], t);
+				t = fmaf(axis[2], (float)c2 - mean[2], t);
+				t = fmaf(axis[3], (float)c3 - mean[3], t);
+				uint32_t k = 0;
 #pragma unroll
-				for (uint32_t c = 0; c < 4u; ++c)
-					t += c < nc ? ((int)((p >> (8u*c)) & 255u) - e0[c])*dv[c] : 0;
-				if (t > 0 && dd > 0) {
-					// (128 t + dd)/(2 dd); t <= dd' such that the quotient stays small: clamp t first
-					const int tc = t > dd ? dd : t;            // t >= dd gives T >= 64 -> 64 either way
-					T = (int)div_small((uint32_t)(128*tc + dd), (uint32_t)(2*dd), rdd2);
-					T = T > 64 ? 64 : T;
+				for (uint32_t m = 1; m < 4u; ++m)
+					if (m < P && t > fmaf(step, (float)m, tmin)) k = m;
+#pragma unroll
+				for (uint32_t a = 0; a < 4u; ++a) {
+					const bool mine = k == a;
+					ks01[a] += mine ? (c0 | (c1 << 16)) : 0u;
+					ks23[a] += mine ? (c2 | (c3 << 16)) : 0u;
+					kcnt[a] += mine ? 1u : 0u;
 				}
-				const uint2 f = cfg.infill(i);
-				const uint32_t w00 = f.y & 255u, w01 = (f.y >> 8) & 255u, w10 = (f.y >> 16) & 255u, w11 = f.y >> 24;
-				// straight-line read-modify-write of the four grid accumulators: neighbours that do
-				// not exist (255 in the record) go to the column's dummy row with a zero factor; the
-				// real entries are distinct (N >= 2), so all loads can be issued before the stores
-				const uint32_t g0 = f.x & 255u, g1 = min((f.x >> 8) & 255u, dummy), g2 = min((f.x >> 16) & 255u, dummy),
-					g3 = min(f.x >> 24, dummy);
-				const uint32_t a0 = ncol[g0*64u], a1 = ncol[g1*64u], a2 = ncol[g2*64u], a3 = ncol[g3*64u];
-				ncol[g0*64u] = (uint16_t)(a0 + w00*(uint32_t)T);
-				ncol[g1*64u] = (uint16_t)(a1 + w01*(uint32_t)T);
-				ncol[g2*64u] = (uint16_t)(a2 + w10*(uint32_t)T);
-				ncol[g3*64u] = (uint16_t)(a3 + w11*(uint32_t)T);
 			}
-			for (uint32_t g = 0; g < ng; ++g) {
-				const uint32_t den = cfg.den(g);
-				const uint32_t gv = den ? div_small((uint32_t)ncol[g*64u] + den/2u, den, 1.0f/(float)den) : 0u;
-				const uint32_t qv = (gv*(uint32_t)qmax + 32u) >> 6;         // quantised weight
-				ncol[g*64u] = (uint16_t)((uint32_t)unq_weight((int)qv, bits) | (qv << 8));
+			float cen[4][4];
+			bool live[4];
+#pragma unroll
+			for (uint32_t a = 0; a < 4u; ++a) {
+				if (a < P) {
+					const uint32_t t01 = cf_group_sum_u32(ks01[a], pair, h), t23 = cf_group_sum_u32(ks23[a], pair, h);
+					const uint32_t cn = cf_group_sum_u32(kcnt[a], pair, h);
+					const float ic = cn ? 1.0f/(float)cn : 0.0f;
+					cen[a][0] = (float)(t01 & 0xFFFFu)*ic; cen[a][1] = (float)(t01 >> 16)*ic;
+					cen[a][2] = (float)(t23 & 0xFFFFu)*ic; cen[a][3] = (float)(t23 >> 16)*ic;
+					live[a] = cn != 0u;
+				} else {
+					cen[a][0] = cen[a][1] = cen[a][2] = cen[a][3] = 0.0f;
+					live[a] = false;
+				}
 			}
-			if (!refit)
-				err = astc_error(tp, n, nc, e0, e1, cfg, qcol, N, bits, rows);
-			else {
-				// the first error and the least-squares sums of the refit in ONE pass over the
-				// texels: each texel's weight is reconstructed once for both
-				int S = 0, A = 0, B = 0, C = 0, U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
-				int base[4], slope[4];
+			unsigned long long km[4][3];
 #pragma unroll
-				for (int c = 0; c < 4; ++c) {
-					base[c] = e0[c]*257*64 + 32;
-					slope[c] = (e1[c] - e0[c])*257;
-				}
-				err = 0;
-#pragma unroll 1
-				for (uint32_t i = 0; i < n; ++i) {
-					const int wi = texel_weight(cfg, i, qcol, N, bits, rows), iw = 64 - wi;
-					if (wcached)
-						const_cast<uint8_t*>(qcol)[(rows + (i >> 1))*128u + (i & 1u)] = (uint8_t)wi;
-					const uint32_t p = tp[i];
-					S += wi; A += iw*iw; B += iw*wi; C += wi*wi;
+			for (int a = 0; a < 4; ++a)
+				km[a][0] = km[a][1] = km[a][2] = 0ull;
+			const uint32_t rounds = (n + gsz - 1u)/gsz;
 #pragma unroll
-					for (uint32_t c = 0; c < 4u; ++c) {
-						if (c < nc) {
-							const int pc = (int)((p >> (8u*c)) & 255u);
-							U[c] += iw*pc;
-							V[c] += wi*pc;
-							const int d = ((base[c] + slope[c]*wi) >> 14) - pc;
-							err += (uint32_t)(d*d);
+			for (uint32_t r = 0; r < 5u; ++r) {
+				if (r < rounds) {
+					const uint32_t i = r*gsz + hl;
+					uint32_t bk = 0;
+					if (i < n) {
+						const uint32_t p = tp[i];
+						const float f0 = (float)(p & 255u), f1 = (float)((p >> 8) & 255u), f2 = (float)((p >> 16) & 255u);
+						const float f3 = nc == 4u ? (float)(p >> 24) : 0.0f;
+						float bd = 3.0e38f;
+#pragma unroll
+						for (uint32_t a = 0; a < 4u; ++a) {
+							if (a < P) {
+								const float e0 = f0 - cen[a][0], e1 = f1 - cen[a][1], e2 = f2 - cen[a][2], e3 = f3 - cen[a][3];
+								float d = e0*e0;
+								d = fmaf(e1, e1, d);
+								d = fmaf(e2, e2, d);
+								d = fmaf(e3, e3, d);
+								if (live[a] && d < bd) { bd = d; bk = a; }
+							}
+						}
+					}
+#pragma unroll
+					for (uint32_t a = 0; a < 4u; ++a) {
+						if (a < P) {
+							const unsigned long long bal = __ballot(i < n && bk == a);
+							if (pair) {
+								const unsigned long long g32 = h ? bal >> 32 : (bal & 0xFFFFFFFFull);
+								km[a][r >> 1] |= g32 << (32u*(r & 1u));
+							} else if (r < 3u)
+								km[a][r] |= bal;
 						}
 					}
 				}
-				const int det = (int)n*C - S*S;
-				if (det > 0) {
-					const float inv = 1.0f/(64.0f*(float)det);
-					const float fA = (float)A, fB = (float)B, fC = (float)C;
-					int r0[4] = {0, 0, 0, 255}, r1[4] = {0, 0, 0, 255};
+			}
+			// lane = table entry: mismatch = n - best label-permuted overlap
+			const uint32_t np = H->npart[P - 2u] < lad.limit ? H->npart[P - 2u] : lad.limit;
+			const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(blob + H->off_mask[P - 2u]);
+			uint32_t keys[4];
 #pragma unroll
-					for (uint32_t c = 0; c < 4u; ++c) {
-						if (c < nc) {
-							const float fU = (float)U[c], fV = (float)V[c];
-							const float t0 = fB*fV;
-							const float n0 = fmaf(fC, fU, -t0);
-							const float t1 = fB*fU;
-							const float n1 = fmaf(fA, fV, -t1);
-							r0[c] = (int)floorf(clampf255(n0*inv) + 0.5f);
-							r1[c] = (int)floorf(clampf255(n1*inv) + 0.5f);
-						}
-					}
-					if (r1[0] + r1[1] + r1[2] >= r0[0] + r0[1] + r0[2]) {
-						const uint32_t e = wcached ? astc_error_cached(tp, n, nc, r0, r1, qcol + rows*128u)
-							: astc_error(tp, n, nc, r0, r1, cfg, qcol, N, bits, rows);
-						if (e < err) {
-							err = e;
+			for (uint32_t m = 0; m < 4u; ++m) {
+				keys[m] = 0xFFFFFFFFu;
+				const uint32_t e = hl + gsz*m;
+				if (e < np) {
+					uint32_t O[4][4];
 #pragma unroll
-							for (int c = 0; c < 4; ++c) { e0[c] = r0[c]; e1[c] = r1[c]; }
+					for (uint32_t a = 0; a < 4u; ++a)
+#pragma unroll
+						for (uint32_t c = 0; c < 4u; ++c) {
+							O[a][c] = 0;
+							if (a < P && c < P) {
+								const unsigned long long* pm = masks + ((size_t)e*4u + c)*3u;
+								uint32_t o = (uint32_t)__popcll(km[a][0] & pm[0]);
+								if (n > 64u)
+									o += (uint32_t)__popcll(km[a][1] & pm[1]) + (uint32_t)__popcll(km[a][2] & pm[2]);
+								O[a][c] = o;
+							}
 						}
+					uint32_t best = 0;
+					if (P == 2u)
+						best = max(O[0][0] + O[1][1], O[0][1] + O[1][0]);
+					else if (P == 3u) {
+						best = max(max(O[0][0] + O[1][1] + O[2][2], O[0][0] + O[1][2] + O[2][1]),
+							max(max(O[0][1] + O[1][0] + O[2][2], O[0][1] + O[1][2] + O[2][0]),
+								max(O[0][2] + O[1][0] + O[2][1], O[0][2] + O[1][1] + O[2][0])));
+					} else {
+#pragma unroll
+						for (uint32_t a = 0; a < 4u; ++a)
+#pragma unroll
+							for (uint32_t c = 0; c < 4u; ++c)
+#pragma unroll
+								for (uint32_t d = 0; d < 4u; ++d) {
+									const uint32_t e4 = 6u - a - c - d;
+									if (a != c && a != d && c != d)
+										best = max(best, O[0][a] + O[1][c] + O[2][d] + O[3][e4]);
+								}
 					}
+					keys[m] = ((n - best) << 16) | e;
+				}
+			}
+			for (uint32_t jj = 0; jj < want; ++jj) {
+				uint32_t mk = keys[0];
+#pragma unroll
+				for (uint32_t m = 1; m < 4u; ++m)
+					mk = keys[m] < mk ? keys[m] : mk;
+				const uint32_t gmin = cf_group_min_u32(mk, pair, h);
+#pragma unroll
+				for (uint32_t m = 0; m < 4u; ++m)
+					keys[m] = keys[m] == gmin ? 0xFFFFFFFFu : keys[m];
+				if (gmin != 0xFFFFFFFFu) {
+					if (hl == 0u) S.pcs[npc] = pc_make(P, 0, 0, P, gmin & 0xFFFFu);
+					++npc;
 				}
 			}
 		}
-		const unsigned long long key = ((unsigned long long)err << 32) | hl;   // id = cfg*8 + variant
-		const unsigned long long kmin = cf_group_min_u64(key, pair, h);
-		// pack, spread over the group: the winner (its id is the low word of the key) hands its
-		// endpoints over through two shuffles, its quantised weights sit in its LDS column, and
-		// each lane places the bit-reversed fields of the grid points it strides over; the block
-		// is the OR over the group.  (A serial pack by the winning lane costs the wavefront one
-		// iteration per weight BIT.)
-		{
-			const uint32_t whl = (uint32_t)kmin & 63u, wlane = pair ? h*32u + whl : whl;
-			const uint32_t e0w = (uint32_t)__shfl((int)((uint32_t)e0[0] | ((uint32_t)e0[1] << 8) | ((uint32_t)e0[2] << 16) | ((uint32_t)e0[3] << 24)), (int)wlane, 64);
-			const uint32_t e1w = (uint32_t)__shfl((int)((uint32_t)e1[0] | ((uint32_t)e1[1] << 8) | ((uint32_t)e1[2] << 16) | ((uint32_t)e1[3] << 24)), (int)wlane, 64);
-			const CfgView wcfg = {set + (whl >> 3)*cstride};
-			const uint32_t wng = wcfg.ng(), wbits = wcfg.bits();
-			const uint8_t* wq = reinterpret_cast<const uint8_t*>(lane_cols + wave*col_rows*64u + wlane);
-			unsigned long long lo64 = 0ull, hi64 = 0ull;
-			if (hl == 0u) {
-				// mode (11) | partitions-1 (2) | CEM (4) | 8-bit endpoint values e0.r e1.r e0.g ...
-				lo64 = (unsigned long long)wcfg.mode() | ((unsigned long long)(has_alpha ? 12u : 8u) << 13);
-#pragma unroll
-				for (int i = 0; i < 8; ++i) {
-					if (i < (has_alpha ? 8 : 6)) {
-						const uint32_t pos = 17u + 8u*(uint32_t)i;
-						const unsigned long long vv = (unsigned long long)((((i & 1) ? e1w : e0w) >> (8*(i >> 1))) & 255u);
-						if (pos < 64u) {
-							lo64 |= vv << pos;
-							if (pos + 8u > 64u) hi64 |= vv >> (64u - pos);
-						} else
-							hi64 |= vv << (pos - 64u);
-					}
+		__builtin_amdgcn_wave_barrier();
+
+		// ---- passes of (gsz / K) candidates x K configs ----
+		const uint32_t K = lad.K, kshift = K == 2u ? 1u : (K == 4u ? 2u : 3u), per_pass = gsz >> kshift;
+		unsigned long long bestkey = ~0ull;
+		const uint32_t alpha_i = has_alpha ? 1u : 0u;
+		uint32_t npc_max = npc;
+		if (pair) {
+			const uint32_t o = (uint32_t)__shfl_xor((int)npc, 32, 64);
+			npc_max = max(npc, o);
+		}
+		for (uint32_t base = 0, pass = 0; base < npc_max; base += per_pass, ++pass) {
+			const uint32_t cnt = base >= npc ? 0u : (npc - base < per_pass ? npc - base : per_pass);
+			// partition rows of this pass's candidates
+			for (uint32_t j = 0; j < cnt; ++j) {
+				const uint32_t d = S.pcs[base + j];
+				if (pc_P(d) >= 2u) {
+					const uint8_t* src = blob + H->off_ids[pc_P(d) - 2u] + (size_t)pc_tab(d)*npad;
+					for (uint32_t i = hl*4u; i < npad; i += gsz*4u)
+						*reinterpret_cast<uint32_t*>(S.pid + j*npad + i) = *reinterpret_cast<const uint32_t*>(src + i);
 				}
 			}
-			for (uint32_t g = hl; g < wng; g += gsz) {
-				// weight g: its bits go to 127 - (g*bits + kb), i.e. the reversed field at 128 - (g+1)*bits
-				const uint32_t fld = __brev((uint32_t)wq[g*128u + 1u]) >> (32u - wbits);   // high byte: quantised
-				const uint32_t pos = 128u - (g + 1u)*wbits;
-				const unsigned long long vv = (unsigned long long)fld;
-				if (pos < 64u) {
-					lo64 |= vv << pos;
-					if (pos + wbits > 64u) hi64 |= vv >> (64u - pos);
-				} else
-					hi64 |= vv << (pos - 64u);
+			__builtin_amdgcn_wave_barrier();
+
+			// ---- phase A: lane = (candidate j, slot s) ----
+			{
+				const uint32_t j = hl >> 2, s = hl & 3u;
+				const uint32_t d = j < cnt ? S.pcs[base + j] : 0u;
+				const uint32_t P = pc_P(d), dual = pc_dual(d), ccs = pc_ccs(d);
+				const bool active = !solid && j < cnt && hl < 32u && s < (dual ? 2u : P);
+				if (active) {
+					uint32_t chmask = (1u << nc) - 1u;
+					if (dual)
+						chmask = s == 1u ? (1u << ccs) : (chmask & ~(1u << ccs));
+					const uint32_t bytemask = ((chmask & 1u) ? 0xFFu : 0u) | ((chmask & 2u) ? 0xFF00u : 0u) |
+						((chmask & 4u) ? 0xFF0000u : 0u) | ((chmask & 8u) ? 0xFF000000u : 0u);
+					const uint8_t* prow = S.pid + j*npad;
+					const bool byp = dual || P == 1u;
+					int a0 = 0, a1 = 0, a2 = 0, a3 = 0, cnt_t = 0;
+					int q00 = 0, q01 = 0, q02 = 0, q03 = 0, q11 = 0, q12 = 0, q13 = 0, q22 = 0, q23 = 0, q33 = 0;
+#pragma unroll 1
+					for (uint32_t i = 0; i < n; ++i) {
+						const bool in_ = byp || prow[i] == s;
+						const uint32_t p = in_ ? (tp[i] & bytemask) : 0u;
+						const int c0 = (int)(p & 255u), c1 = (int)((p >> 8) & 255u), c2 = (int)((p >> 16) & 255u), c3 = (int)(p >> 24);
+						cnt_t += in_ ? 1 : 0;
+						a0 += c0; a1 += c1; a2 += c2; a3 += c3;
+						q00 += c0*c0; q01 += c0*c1; q02 += c0*c2; q03 += c0*c3;
+						q11 += c1*c1; q12 += c1*c2; q13 += c1*c3;
+						q22 += c2*c2; q23 += c2*c3; q33 += c3*c3;
+					}
+					Cov Cs;
+					Cs.c00 = (float)(cnt_t*q00 - a0*a0); Cs.c01 = (float)(cnt_t*q01 - a0*a1);
+					Cs.c02 = (float)(cnt_t*q02 - a0*a2); Cs.c03 = (float)(cnt_t*q03 - a0*a3);
+					Cs.c11 = (float)(cnt_t*q11 - a1*a1); Cs.c12 = (float)(cnt_t*q12 - a1*a2);
+					Cs.c13 = (float)(cnt_t*q13 - a1*a3); Cs.c22 = (float)(cnt_t*q22 - a2*a2);
+					Cs.c23 = (float)(cnt_t*q23 - a2*a3); Cs.c33 = (float)(cnt_t*q33 - a3*a3);
+					const float ic = 1.0f/(float)cnt_t;
+					const float mn[4] = {(float)a0*ic, (float)a1*ic, (float)a2*ic, (float)a3*ic};
+					float ax[4];
+					principal_axis(Cs, ax);
+					float lo_t = 3.0e38f, hi_t = -3.0e38f;
+#pragma unroll 1
+					for (uint32_t i = 0; i < n; ++i) {
+						const bool in_ = byp || prow[i] == s;
+						const uint32_t p = tp[i] & bytemask;
+						float t = ax[0]*((float)(p & 255u) - mn[0]);
+						t = fmaf(ax[1], (float)((p >> 8) & 255u) - mn[1], t);
+						t = fmaf(ax[2], (float)((p >> 16) & 255u) - mn[2], t);
+						t = fmaf(ax[3], (float)(p >> 24) - mn[3], t);
+						lo_t = in_ ? fminf(lo_t, t) : lo_t;
+						hi_t = in_ ? fmaxf(hi_t, t) : hi_t;
+					}
+					int e0[4] = {0, 0, 0, 0}, e1[4] = {0, 0, 0, 0}, s0 = 0, s1 = 0;
+#pragma unroll
+					for (uint32_t c = 0; c < 4u; ++c) {
+						if ((chmask >> c) & 1u) {
+							e0[c] = (int)floorf(clampf255(fmaf(ax[c], lo_t, mn[c])) + 0.5f);
+							e1[c] = (int)floorf(clampf255(fmaf(ax[c], hi_t, mn[c])) + 0.5f);
+							if (c < 3u || chmask == 8u) { s0 += e0[c]; s1 += e1[c]; }
+						}
+					}
+					if (s1 < s0) {
+#pragma unroll
+						for (int c = 0; c < 4; ++c) { const int t = e0[c]; e0[c] = e1[c]; e1[c] = t; }
+					}
+					int dv[4], dd = 0;
+#pragma unroll
+					for (int c = 0; c < 4; ++c) {
+						dv[c] = e1[c] - e0[c];
+						dd += dv[c]*dv[c];
+					}
+					const float rdd2 = dd > 0 ? 1.0f/(float)(2*dd) : 0.0f;
+					uint8_t* Trow = S.T + (j*2u + (dual ? s : 0u))*npad;
+#pragma unroll 1
+					for (uint32_t i = 0; i < n; ++i) {
+						const bool in_ = byp || prow[i] == s;
+						const uint32_t p = tp[i];
+						int t = ((int)(p & 255u) - e0[0])*dv[0] + ((int)((p >> 8) & 255u) - e0[1])*dv[1] +
+							((int)((p >> 16) & 255u) - e0[2])*dv[2] + ((int)(p >> 24) - e0[3])*dv[3];
+						int Tw = 0;
+						if (t > 0 && dd > 0) {
+							const int tc = t > dd ? dd : t;
+							Tw = (int)div_small((uint32_t)(128*tc + dd), (uint32_t)(2*dd), rdd2);
+							Tw = Tw > 64 ? 64 : Tw;
+						}
+						if (in_)
+							Trow[i] = (uint8_t)Tw;
+					}
+					int sp = 0;
+#pragma unroll
+					for (uint32_t c = 0; c < 4u; ++c)
+						sp += ((chmask >> c) & 1u) ? (int)cw[c]*dv[c]*dv[c] : 0;
+					S.span[hl] = (uint32_t)(sp*cnt_t);
+					// the slot's endpoints as masked bytes: the (up to two) planes of a dual-plane
+					// candidate OR into subset 0
+					const uint32_t pe0 = (uint32_t)e0[0] | ((uint32_t)e0[1] << 8) | ((uint32_t)e0[2] << 16) | ((uint32_t)e0[3] << 24);
+					const uint32_t pe1 = (uint32_t)e1[0] | ((uint32_t)e1[1] << 8) | ((uint32_t)e1[2] << 16) | ((uint32_t)e1[3] << 24);
+					S.e0[hl] = pe0;
+					S.e1[hl] = pe1;
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+
+			// ---- lane = weight grid: decimation error of candidate 0's ideal weights (pass 0) ----
+			if (pass == 0u) {
+				const uint32_t g = hl;
+				if (!solid && g < ngrids) {
+					const uint32_t N = sh.grid[g*4u], ng = sh.grid[g*4u + 2u];
+					const uint32_t* inf = sh.infill + g*n;
+					const uint8_t* Trow = S.T;
+					for (uint32_t r = 0; r < ng + N + 2u; ++r)
+						col[r*64u] = 0;
+#pragma unroll 1
+					for (uint32_t i = 0; i < n; ++i) {
+						const uint32_t rec = inf[i], T = Trow[i];
+						const uint32_t g0 = rec & 255u, f00 = (rec >> 8) & 31u, f01 = (rec >> 13) & 31u, f10 = (rec >> 18) & 31u, f11 = rec >> 23;
+						const uint32_t v0 = col[g0*64u], v1 = col[(g0 + 1u)*64u], v2 = col[(g0 + N)*64u], v3 = col[(g0 + N + 1u)*64u];
+						col[g0*64u] = (uint16_t)(v0 + f00*T);
+						col[(g0 + 1u)*64u] = (uint16_t)(v1 + f01*T);
+						col[(g0 + N)*64u] = (uint16_t)(v2 + f10*T);
+						col[(g0 + N + 1u)*64u] = (uint16_t)(v3 + f11*T);
+					}
+					for (uint32_t r = 0; r < ng; ++r) {
+						const uint32_t den = sh.den[g*64u + r];
+						col[r*64u] = (uint16_t)(den ? div_small((uint32_t)col[r*64u] + den/2u, den, 1.0f/(float)den) : 0u);
+					}
+					uint32_t e = 0;
+#pragma unroll 1
+					for (uint32_t i = 0; i < n; ++i) {
+						const uint32_t rec = inf[i];
+						const uint32_t g0 = rec & 255u, f00 = (rec >> 8) & 31u, f01 = (rec >> 13) & 31u, f10 = (rec >> 18) & 31u, f11 = rec >> 23;
+						const uint32_t acc = 8u + f00*col[g0*64u] + f01*col[(g0 + 1u)*64u] + f10*col[(g0 + N)*64u] + f11*col[(g0 + N + 1u)*64u];
+						const int dgt = (int)(acc >> 4) - (int)Trow[i];
+						e += (uint32_t)(dgt*dgt);
+					}
+					S.edec[g] = e;
+				}
+				__builtin_amdgcn_wave_barrier();
+			}
+
+			// ---- ranking: lane = config of the candidate's class, K smallest estimates ----
+			for (uint32_t j = 0; j < (per_pass < 8u ? per_pass : 8u); ++j) {
+				const bool jact = j < cnt;
+				const uint32_t d = jact ? S.pcs[base + j] : 0u;
+				const uint32_t cls = pc_cls(d), slots = pc_dual(d) ? 2u : pc_P(d);
+				uint32_t spn = 0;
+#pragma unroll
+				for (uint32_t s = 0; s < 4u; ++s)
+					spn += (jact && s < slots) ? S.span[j*4u + s] : 0u;
+				const unsigned long long span2 = ((unsigned long long)spn*recip_n) >> 16;
+				const uint32_t ncfg = jact ? ncfgs[cls*2u + alpha_i] : 0u;
+				const AstcCfgRec* list = cfgs + (cls*2u + alpha_i)*64u;
+				unsigned long long key[2];
+#pragma unroll
+				for (uint32_t m = 0; m < 2u; ++m) {
+					const uint32_t k = hl + gsz*m;
+					key[m] = ~0ull;
+					if (k < ncfg && k < 64u) {
+						const AstcCfgRec c = list[k];
+						const unsigned long long wn = (unsigned long long)S.edec[c.grid]*40ull + (unsigned long long)(n*c.wq16);
+						const unsigned long long est = ((span2*wn) >> 12) + (unsigned long long)(n*nc)*c.cq16;
+						key[m] = (est << 8) | k;
+					}
+				}
+				for (uint32_t it = 0; it < K; ++it) {
+					const unsigned long long mk = key[0] < key[1] ? key[0] : key[1];
+					const unsigned long long gmin = cf_group_min_u64(mk, pair, h);
+					key[0] = key[0] == gmin ? ~0ull : key[0];
+					key[1] = key[1] == gmin ? ~0ull : key[1];
+					if (hl == 0u && jact)
+						S.order[j*8u + it] = gmin == ~0ull ? (uint8_t)255 : (uint8_t)(gmin & 255ull);
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+
+			// ---- phase B: lane = (candidate j, rank ks) ----
+			unsigned long long err = ~0ull;
+			uint32_t r_cem = 0, r_lv = 0, r_ncv = 0, r_cfg = 0;
+			uint32_t r_cv[5] = {0, 0, 0, 0, 0};
+			{
+				const uint32_t j = hl >> kshift, ks = hl & (K - 1u);
+				const uint32_t d = j < cnt ? S.pcs[base + j] : 0u;
+				const uint32_t P = pc_P(d), dual = pc_dual(d), ccs = pc_ccs(d), cls = pc_cls(d);
+				const uint32_t oi = (j < cnt) ? S.order[j*8u + ks] : 255u;
+				const bool active = !solid && j < cnt && oi != 255u;
+				const AstcCfgRec cfg = cfgs[(cls*2u + alpha_i)*64u + (active ? oi : 0u)];
+				r_cfg = oi;
+				const uint32_t planes = dual ? 2u : 1u, N = cfg.N, ng = cfg.ng, wq = cfg.wq;
+				const uint32_t* inf = sh.infill + (uint32_t)cfg.grid*n;
+				const uint16_t* den = sh.den + (uint32_t)cfg.grid*64u;
+				const uint8_t* prow = S.pid + j*npad;
+				const bool byp = P <= 1u;
+				if (active) {
+					// 1. decimate + quantise (slots: unquantised | quantised << 8)
+					for (uint32_t r = 0; r < (ng + N + 2u)*planes; ++r)
+						col[r*64u] = 0;
+#pragma unroll 1
+					for (uint32_t pl = 0; pl < planes; ++pl) {
+						const uint8_t* Trow = S.T + (j*2u + pl)*npad;
+#pragma unroll 1
+						for (uint32_t i = 0; i < n; ++i) {
+							const uint32_t rec = inf[i], T = Trow[i];
+							const uint32_t g0 = rec & 255u, f00 = (rec >> 8) & 31u, f01 = (rec >> 13) & 31u, f10 = (rec >> 18) & 31u, f11 = rec >> 23;
+							const uint32_t i0 = (g0*planes + pl)*64u, i1 = i0 + planes*64u, i2 = i0 + N*planes*64u, i3 = i2 + planes*64u;
+							const uint32_t v0 = col[i0], v1 = col[i1], v2 = col[i2], v3 = col[i3];
+							col[i0] = (uint16_t)(v0 + f00*T);
+							col[i1] = (uint16_t)(v1 + f01*T);
+							col[i2] = (uint16_t)(v2 + f10*T);
+							col[i3] = (uint16_t)(v3 + f11*T);
+						}
+					}
+					for (uint32_t g = 0; g < ng; ++g) {
+						const uint32_t dn = den[g];
+						const float rd = 1.0f/(float)dn;
+#pragma unroll 1
+						for (uint32_t pl = 0; pl < planes; ++pl) {
+							const uint32_t gi = dn ? div_small((uint32_t)col[(g*planes + pl)*64u] + dn/2u, dn, rd) : 0u;
+							const uint32_t qv = sh.wnear[wq*68u + gi];
+							col[(g*planes + pl)*64u] = (uint16_t)((uint32_t)sh.wunq[wq*32u + qv] | (qv << 8));
+						}
+					}
+					// 2. + 3. texel weights and the least-squares sums per set (subset, or plane)
+					const uint32_t nset = dual ? 2u : P;
+					uint32_t Ssum[4] = {0, 0, 0, 0}, A[4] = {0, 0, 0, 0}, Bm[4] = {0, 0, 0, 0}, Cc[4] = {0, 0, 0, 0}, cn[4] = {0, 0, 0, 0};
+					uint32_t U[4][4], V[4][4];
+#pragma unroll
+					for (int a = 0; a < 4; ++a)
+#pragma unroll
+						for (int c = 0; c < 4; ++c) { U[a][c] = 0; V[a][c] = 0; }
+					// channels a set fits: all of them for subsets; for planes, ccs <-> the others
+					uint32_t keep[4];
+#pragma unroll
+					for (uint32_t st = 0; st < 4u; ++st) {
+						uint32_t m = nc == 4u ? 0xFFFFFFFFu : 0x00FFFFFFu;
+						if (dual) {
+							const uint32_t cb = 0xFFu << (8u*ccs);
+							m = st == 1u ? (m & cb) : (m & ~cb);
+						}
+						keep[st] = m;
+					}
+					uint32_t wpack0 = 0, wpack1 = 0;
+#pragma unroll 1
+					for (uint32_t i = 0; i < n; ++i) {
+						const uint32_t rec = inf[i];
+						const uint32_t g0 = rec & 255u, f00 = (rec >> 8) & 31u, f01 = (rec >> 13) & 31u, f10 = (rec >> 18) & 31u, f11 = rec >> 23;
+						uint32_t wA, wB;
+						{
+							const uint32_t i0 = (g0*planes)*64u, i1 = i0 + planes*64u, i2 = i0 + N*planes*64u, i3 = i2 + planes*64u;
+							wA = (8u + f00*(col[i0] & 255u) + f01*(col[i1] & 255u) + f10*(col[i2] & 255u) + f11*(col[i3] & 255u)) >> 4;
+							wB = wA;
+							if (dual)
+								wB = (8u + f00*(col[i0 + 64u] & 255u) + f01*(col[i1 + 64u] & 255u) + f10*(col[i2 + 64u] & 255u) + f11*(col[i3 + 64u] & 255u)) >> 4;
+						}
+						if (wcached) {
+							wpack0 |= wA << (8u*(i & 3u));
+							wpack1 |= wB << (8u*(i & 3u));
+							if ((i & 3u) == 3u || i == n - 1u) {
+								wcache[((i >> 2)*2u)*64u] = wpack0;
+								wcache[((i >> 2)*2u + 1u)*64u] = wpack1;
+								wpack0 = 0; wpack1 = 0;
+							}
+						}
+						const uint32_t p = tp[i];
+						const uint32_t part = byp ? 0u : prow[i];
+#pragma unroll
+						for (uint32_t st = 0; st < 4u; ++st) {
+							if (st < nset) {
+								const uint32_t member = dual ? 1u : (part == st ? 1u : 0u);
+								const uint32_t wi = (dual && st == 1u) ? wB : wA, iw = 64u - wi;
+								const uint32_t wm = wi*member, iwm = iw*member;
+								Ssum[st] += wm; A[st] += iwm*iw; Bm[st] += iwm*wi; Cc[st] += wm*wi; cn[st] += member;
+								const uint32_t pk = p & keep[st];
+#pragma unroll
+								for (uint32_t c = 0; c < 4u; ++c) {
+									const uint32_t pc_ = (pk >> (8u*c)) & 255u;
+									U[st][c] += iwm*pc_;
+									V[st][c] += wm*pc_;
+								}
+							}
+						}
+					}
+					// least-squares endpoints: r0/r1[subset][channel]; fA/fB/fC per (subset, channel)
+					float r0[4][4], r1[4][4], fAs[4], fBs[4], fCs[4], invs[4];
+					bool dets[4];
+#pragma unroll
+					for (uint32_t st = 0; st < 4u; ++st) {
+						const int det = (int)(cn[st]*Cc[st]) - (int)(Ssum[st]*Ssum[st]);
+						fAs[st] = (float)A[st]; fBs[st] = (float)Bm[st]; fCs[st] = (float)Cc[st];
+						dets[st] = st < nset && det > 0;
+						invs[st] = dets[st] ? 1.0f/(64.0f*(float)det) : 0.0f;
+					}
+#pragma unroll
+					for (uint32_t sub = 0; sub < 4u; ++sub) {
+#pragma unroll
+						for (uint32_t c = 0; c < 4u; ++c) {
+							const uint32_t st = dual ? (c == ccs ? 1u : 0u) : sub;
+							// ideal endpoints of phase A: subset `sub` (dual: planes 0 and 1 of subset 0)
+							const uint32_t slot_i = j*4u + (dual ? (c == ccs ? 1u : 0u) : sub);
+							const float i0 = (float)((S.e0[slot_i & 31u] >> (8u*c)) & 255u), i1 = (float)((S.e1[slot_i & 31u] >> (8u*c)) & 255u);
+							float a = i0, bq = i1;
+							// select the set's sums without dynamic register indexing
+							const float sA = st == 0u ? fAs[0] : (st == 1u ? fAs[1] : (st == 2u ? fAs[2] : fAs[3]));
+							const float sB = st == 0u ? fBs[0] : (st == 1u ? fBs[1] : (st == 2u ? fBs[2] : fBs[3]));
+							const float sC = st == 0u ? fCs[0] : (st == 1u ? fCs[1] : (st == 2u ? fCs[2] : fCs[3]));
+							const float si = st == 0u ? invs[0] : (st == 1u ? invs[1] : (st == 2u ? invs[2] : invs[3]));
+							const bool sd = st == 0u ? dets[0] : (st == 1u ? dets[1] : (st == 2u ? dets[2] : dets[3]));
+							const uint32_t uu = st == 0u ? U[0][c] : (st == 1u ? U[1][c] : (st == 2u ? U[2][c] : U[3][c]));
+							const uint32_t vv = st == 0u ? V[0][c] : (st == 1u ? V[1][c] : (st == 2u ? V[2][c] : V[3][c]));
+							if (sd) {
+								const float fU = (float)uu, fV = (float)vv;
+								const float t0 = sB*fV;
+								const float n0 = fmaf(sC, fU, -t0);
+								const float t1 = sB*fU;
+								const float n1 = fmaf(sA, fV, -t1);
+								a = clampf255(n0*si);
+								bq = clampf255(n1*si);
+							}
+							if (c == 3u && nc == 3u) { a = 255.0f; bq = 255.0f; }
+							r0[sub][c] = a;
+							r1[sub][c] = bq;
+						}
+					}
+					// 4. endpoint mode by the quadratic estimate (same mode for every partition)
+					float best_est = 3.0e38f;
+					int best_opt = -1;
+					uint32_t best_lv = 0;
+#pragma unroll 1
+					for (int o = 0; o < 3; ++o) {
+						const uint32_t nv = (has_alpha ? 8u : 6u) - 2u*(uint32_t)o;
+						if (nv*P > 18u || (o == 2 && !grey) || (o > 0 && dual && ccs < 3u))
+							continue;
+						const int lv = clevel[(nv*P/2u)*132u + cfg.cbits];
+						if (lv < 0)
+							continue;
+						float est = 0.0f;
+						bool ok = true;
+#pragma unroll
+						for (uint32_t p = 0; p < 4u; ++p) {
+							if (p < P && ok) {
+								float cA[4], cB[4], cC[4];
+#pragma unroll
+								for (uint32_t c = 0; c < 4u; ++c) {
+									const uint32_t st = dual ? (c == ccs ? 1u : 0u) : p;
+									cA[c] = st == 0u ? fAs[0] : (st == 1u ? fAs[1] : (st == 2u ? fAs[2] : fAs[3]));
+									cB[c] = st == 0u ? fBs[0] : (st == 1u ? fBs[1] : (st == 2u ? fBs[2] : fBs[3]));
+									cC[c] = st == 0u ? fCs[0] : (st == 1u ? fCs[1] : (st == 2u ? fCs[2] : fCs[3]));
+								}
+								uint32_t d0p, d1p, vals[8];
+								ok = cem_option(sh, o, (uint32_t)lv, has_alpha, r0[p], r1[p], cA, cB, cC, cw, est, d0p, d1p, vals);
+							}
+						}
+						if (ok && est < best_est) {
+							best_est = est;
+							best_opt = o;
+							best_lv = (uint32_t)lv;
+						}
+					}
+					if (best_opt >= 0) {
+						// materialise the chosen option: decoded endpoints + stored values
+						uint32_t D0[4] = {0, 0, 0, 0}, D1[4] = {0, 0, 0, 0};
+						const uint32_t nv = (has_alpha ? 8u : 6u) - 2u*(uint32_t)best_opt;
+						uint32_t cvb[20];
+#pragma unroll
+						for (int k = 0; k < 20; ++k) cvb[k] = 0;
+#pragma unroll
+						for (uint32_t p = 0; p < 4u; ++p) {
+							if (p < P) {
+								float cA[4], cB[4], cC[4];
+#pragma unroll
+								for (uint32_t c = 0; c < 4u; ++c) {
+									const uint32_t st = dual ? (c == ccs ? 1u : 0u) : p;
+									cA[c] = st == 0u ? fAs[0] : (st == 1u ? fAs[1] : (st == 2u ? fAs[2] : fAs[3]));
+									cB[c] = st == 0u ? fBs[0] : (st == 1u ? fBs[1] : (st == 2u ? fBs[2] : fBs[3]));
+									cC[c] = st == 0u ? fCs[0] : (st == 1u ? fCs[1] : (st == 2u ? fCs[2] : fCs[3]));
+								}
+								float e_ = 0.0f;
+								uint32_t vals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+								cem_option(sh, best_opt, best_lv, has_alpha, r0[p], r1[p], cA, cB, cC, cw, e_, D0[p], D1[p], vals);
+								// stored values, partition by partition: byte (p*nv + k) of the list
+#pragma unroll
+								for (uint32_t k = 0; k < 8u; ++k) {
+									if (k < nv) {
+										const uint32_t pos = p*nv + k;
+#pragma unroll
+										for (uint32_t wd = 0; wd < 5u; ++wd)
+											if ((pos >> 2) == wd)
+												r_cv[wd] |= vals[k] << (8u*(pos & 3u));
+									}
+								}
+							}
+						}
+						(void)cvb;
+						// 5. exact error through the decode arithmetic
+						unsigned long long e64 = 0;
+#pragma unroll 1
+						for (uint32_t i = 0; i < n; ++i) {
+							uint32_t w0, w1;
+							if (wcached) {
+								w0 = (wcache[((i >> 2)*2u)*64u] >> (8u*(i & 3u))) & 255u;
+								w1 = (wcache[((i >> 2)*2u + 1u)*64u] >> (8u*(i & 3u))) & 255u;
+							} else {
+								const uint32_t rec = inf[i];
+								const uint32_t g0 = rec & 255u, f00 = (rec >> 8) & 31u, f01 = (rec >> 13) & 31u, f10 = (rec >> 18) & 31u, f11 = rec >> 23;
+								const uint32_t i0 = (g0*planes)*64u, i1 = i0 + planes*64u, i2 = i0 + N*planes*64u, i3 = i2 + planes*64u;
+								w0 = (8u + f00*(col[i0] & 255u) + f01*(col[i1] & 255u) + f10*(col[i2] & 255u) + f11*(col[i3] & 255u)) >> 4;
+								w1 = w0;
+								if (dual)
+									w1 = (8u + f00*(col[i0 + 64u] & 255u) + f01*(col[i1 + 64u] & 255u) + f10*(col[i2 + 64u] & 255u) + f11*(col[i3 + 64u] & 255u)) >> 4;
+							}
+							const uint32_t part = byp ? 0u : prow[i];
+							const uint32_t q0 = part == 0u ? D0[0] : (part == 1u ? D0[1] : (part == 2u ? D0[2] : D0[3]));
+							const uint32_t q1 = part == 0u ? D1[0] : (part == 1u ? D1[1] : (part == 2u ? D1[2] : D1[3]));
+							const uint32_t p = tp[i];
+							uint32_t ergb = 0, ea = 0;
+#pragma unroll
+							for (uint32_t c = 0; c < 4u; ++c) {
+								if (c < nc) {
+									const uint32_t wi = (dual && c == ccs) ? w1 : w0;
+									const uint32_t ea0 = (q0 >> (8u*c)) & 255u, eb0 = (q1 >> (8u*c)) & 255u;
+									const int v = (int)(((ea0*257u*(64u - wi) + eb0*257u*wi + 32u) >> 6) >> 8);
+									const int dd_ = v - (int)((p >> (8u*c)) & 255u);
+									if (c < 3u) ergb += cw[c]*(uint32_t)(dd_*dd_);
+									else ea = cw[3]*(uint32_t)(dd_*dd_);
+								}
+							}
+							const uint32_t wa = (aflags & ASTC_FLAG_ALPHA_WEIGHT) ? (p >> 24) : 255u;
+							e64 += (unsigned long long)ergb*wa + (unsigned long long)ea*255ull;
+						}
+						err = e64;
+						r_cem = (has_alpha ? 12u : 8u) - (best_opt == 1 ? 2u : (best_opt == 2 ? 8u : 0u));
+						r_lv = best_lv;
+						r_ncv = nv*P;
+					}
+				}
+				// ---- argmin (error, id); the winner parks its result in the block's slot ----
+				const uint32_t id = pass*64u + hl;
+				unsigned long long key = err == ~0ull ? ~0ull : ((err << 10) | id);
+				const unsigned long long kmin = cf_group_min_u64(key, pair, h);
+				if (kmin != ~0ull && kmin < bestkey) {
+					bestkey = kmin;
+					if (key == kmin) {
+						S.best[0] = d;
+						S.best[1] = r_cfg | (r_cem << 8) | (r_lv << 16) | (r_ncv << 24);
+#pragma unroll
+						for (int k = 0; k < 5; ++k)
+							S.best[4 + k] = r_cv[k];
+						// quantised weights in stream order (high byte of the column slots)
+						const uint32_t nw = cfg.nw;
+						uint8_t* wdst = reinterpret_cast<uint8_t*>(S.best + 12);
+						for (uint32_t g = 0; g < nw; ++g)
+							wdst[g] = (uint8_t)(col[g*64u] >> 8);
+					}
+				}
+				__builtin_amdgcn_wave_barrier();
+			}
+		}
+
+		// ---- pack the winner, spread over the group ----
+		{
+			unsigned long long lo64 = 0ull, hi64 = 0ull;
+			const bool have = bestkey != ~0ull;
+			if (!solid && !have) {
+				// no valid candidate (cannot happen for legal tables): mean colour as a void extent
+				if (hl == 0u) {
+					uint32_t cavg[4];
+#pragma unroll
+					for (int c = 0; c < 4; ++c)
+						cavg[c] = (uint32_t)((2*sum[c] + (int)n)/(2*(int)n));
+					if (nc == 3u) cavg[3] = 255u;
+					outb[b] = make_uint4(0xFFFFFDFCu, 0xFFFFFFFFu, (cavg[0]*257u) | ((cavg[1]*257u) << 16), (cavg[2]*257u) | ((cavg[3]*257u) << 16));
+				}
+			} else if (!solid) {
+				const uint32_t d = S.best[0], meta = S.best[1];
+				const uint32_t P = pc_P(d), dual = pc_dual(d), ccs = pc_ccs(d), cls = pc_cls(d);
+				const AstcCfgRec cfg = cfgs[(cls*2u + alpha_i)*64u + (meta & 255u)];
+				const uint32_t cem = (meta >> 8) & 255u, lv = (meta >> 16) & 255u, ncv = meta >> 24;
+				const uint8_t* cvals = reinterpret_cast<const uint8_t*>(S.best + 4);
+				const uint8_t* wvals = reinterpret_cast<const uint8_t*>(S.best + 12);
+				const uint8_t* wd = ise + 384u + (uint32_t)cfg.wq*4u;
+				const uint8_t* cd = ise + 384u + 48u + lv*4u;
+				const uint32_t cstart = P == 1u ? 17u : 29u;
+				if (hl == 0u) {
+					lo64 = (unsigned long long)cfg.mode | ((unsigned long long)(P - 1u) << 11);
+					if (P == 1u)
+						lo64 |= (unsigned long long)cem << 13;
+					else {
+						const uint32_t seed = reinterpret_cast<const uint16_t*>(blob + H->off_seed[P - 2u])[pc_tab(d)];
+						lo64 |= ((unsigned long long)seed << 13) | ((unsigned long long)cem << 25);
+					}
+					if (dual)
+						put128(lo64, hi64, 128u - cfg.wbits - 2u, ccs, 2u);
+				}
+				// colour values: lane = ISE group
+				{
+					const uint32_t cb = cd[0], ct = cd[1], cq = cd[2];
+					const uint32_t per = ct ? 5u : (cq ? 3u : 1u);
+					const uint32_t g = hl, first = g*per;
+					if (first < ncv) {
+						uint32_t v[5] = {0, 0, 0, 0, 0};
+						const uint32_t cntv = ncv - first < per ? ncv - first : per;
+#pragma unroll
+						for (uint32_t k = 0; k < 5u; ++k)
+							if (k < cntv) v[k] = cvals[first + k];
+						uint32_t len;
+						const unsigned long long bits = ise_group(ise, v, cntv, cb, ct, cq, len);
+						put128(lo64, hi64, cstart + ise_size(first, cb, ct, cq), bits, len);
+					}
+				}
+				// weights: lane = ISE group, bit-reversed from the top of the block
+				{
+					const uint32_t wb = wd[0], wt = wd[1], wqn = wd[2];
+					const uint32_t per = wt ? 5u : (wqn ? 3u : 1u);
+					const uint32_t nw = cfg.nw;
+					for (uint32_t g = hl; g*per < nw; g += gsz) {
+						const uint32_t first = g*per;
+						uint32_t v[5] = {0, 0, 0, 0, 0};
+						const uint32_t cntv = nw - first < per ? nw - first : per;
+#pragma unroll
+						for (uint32_t k = 0; k < 5u; ++k)
+							if (k < cntv) v[k] = wvals[first + k];
+						uint32_t len;
+						const uint32_t bits = (uint32_t)ise_group(ise, v, cntv, wb, wt, wqn, len);   // <= 23 bits
+						const uint32_t spos = ise_size(first, wb, wt, wqn);     // stream position
+						const uint32_t rev = __brev(bits) >> (32u - len);
+						put128(lo64, hi64, 128u - spos - len, rev, len);
+					}
+				}
 			}
 			const uint32_t w0 = cf_group_or_u32((uint32_t)lo64, pair, h), w1 = cf_group_or_u32((uint32_t)(lo64 >> 32), pair, h),
 				w2 = cf_group_or_u32((uint32_t)hi64, pair, h), w3 = cf_group_or_u32((uint32_t)(hi64 >> 32), pair, h);
-			if (!solid && hl == 0u)
+			if (!solid && have && hl == 0u)
 				outb[b] = make_uint4(w0, w1, w2, w3);
 		}
+		__builtin_amdgcn_wave_barrier();
 	}
 	__syncthreads();
 	const uint32_t t = threadIdx.x;
@@ -539,21 +1238,38 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	}
 }
 
-extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, hipStream_t stream)
+// dynamic LDS of a launch for this footprint (same carve-up as in the kernel)
+extern "C" size_t cfhip_astc_lds_bytes(const cfastc::AstcBlobHeader* h)
+{
+	const uint32_t n = h->n, ngrids = h->ngrids, npad = h->npad;
+	uint32_t off = CF_BLOCKS_PER_WG*n*4u;
+	off = (off + 15u) & ~15u;
+	off += ngrids*n*4u; off = (off + 15u) & ~15u;
+	off += ngrids*128u;
+	off += (ngrids*4u + 15u) & ~15u;
+	off += 2u*17u*256u + 1216u;
+	const uint32_t wc_rows = n <= 64u ? 2u*((n + 3u)/4u) : 0u;
+	const uint32_t slot_bytes = ((8u*2u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*4u + 64u + 40u*4u + 28u*4u;
+	const uint32_t wave_bytes = ((h->col_rows*128u + wc_rows*256u + 15u) & ~15u) + 2u*slot_bytes;
+	return (size_t)off + 4u*(size_t)wave_bytes;
+}
+
+extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, size_t lds_bytes, hipStream_t stream)
 {
 	dim3 grid((kp->bx + CF_BLOCKS_PER_WG - 1)/CF_BLOCKS_PER_WG, kp->by, 1);
 	if (kp->batch)
 		grid = dim3(kp->total_wg, 1, 1);
 	dim3 block(CF_WG_THREADS, 1, 1);
-	const uint32_t n_ = (kp->flags & 255u)*((kp->flags >> 8) & 255u), rows_ = (kp->flags >> 16) & 255u;
-	// tile + compact tables + 4 waves x rows x 64 lanes of u16 (same layout as in the kernel)
-	const uint32_t ncs_ = (kp->flags >> 24) & 15u;
-	const uint32_t col_rows_ = rows_ + (n_ <= (uint32_t)CF_ASTC_CACHE_MAX ? (n_ + 1u)/2u : 0u);   // + the texel-weight cache rows
-	const size_t dyn = (size_t)CF_BLOCKS_PER_WG*n_*4u + (8u + 2u*ncs_*(136u + 8u*n_)) +
-		(size_t)4*col_rows_*64u*sizeof(uint16_t);
+	static bool attr_set = false;
+	if (!attr_set) {
+		// more than 64 KB of dynamic LDS needs the opt-in (160 KB per CU on gfx950)
+		hipFuncSetAttribute(reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 1024);
+		hipFuncSetAttribute(reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 1024);
+		attr_set = true;
+	}
 	if (pixel_type == 0)
-		hipLaunchKernelGGL((cfhip_astc_encode_kernel<0>), grid, block, dyn, stream, *kp);
+		hipLaunchKernelGGL((cfhip_astc_encode_kernel<0>), grid, block, lds_bytes, stream, *kp);
 	else
-		hipLaunchKernelGGL((cfhip_astc_encode_kernel<1>), grid, block, dyn, stream, *kp);
+		hipLaunchKernelGGL((cfhip_astc_encode_kernel<1>), grid, block, lds_bytes, stream, *kp);
 	return hipGetLastError();
 }

@@ -6,6 +6,7 @@
 // payload.  There is deliberately no CPU fallback here: without a HIP device
 // cfhip_create() fails and the caller (HipConverter) keeps the reference path.
 #include "cf_device.h"
+#include "astc_tables.h"
 #include "../../include/cuttlefish_hip.h"
 
 #include <cstdarg>
@@ -22,7 +23,8 @@
 
 extern "C" hipError_t cfhip_launch_bc7(const cf_kparams* kp, int pixel_type, int unit_weights,
 	hipStream_t stream);
-extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, hipStream_t stream);
+extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, size_t lds_bytes, hipStream_t stream);
+extern "C" size_t cfhip_astc_lds_bytes(const cfastc::AstcBlobHeader* h);
 extern "C" hipError_t cfhip_launch_etc(const cf_kparams* kp, int format, int pixel_type, int snorm,
 	hipStream_t stream);
 extern "C" hipError_t cfhip_launch_bc6h(const cf_kparams* kp, int pixel_type, int is_signed,
@@ -51,6 +53,7 @@ struct cfhip_ctx {
 	size_t pin_cap = 0;
 	hipEvent_t pin_free[2] = {nullptr, nullptr};   // slot's upload has left the host buffer
 	std::map<int, void*> astc_tables; // per-format device tables (built on first use)
+	std::map<int, size_t> astc_lds;   // dynamic LDS of a launch per format
 	std::vector<hipEvent_t> events;   // start/stop pairs of the last call
 	size_t events_used = 0;
 	hipStream_t events_stream = nullptr;
@@ -81,13 +84,8 @@ int fail(cfhip_ctx* ctx, int code, const char* fmt, ...)
 #define HIP_TRY(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
 	return fail((ctx), CFHIP_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
-// ---- ASTC: weight-grid configs and infill tables (ASTC specification: block mode layout,
-// weight infill).  Built once per format on the host; astc_encode.hip reads the records.
-// Record (ASTC_CFG_STRIDE = 1288 B): N, M, bits, ng, mode u16, pad u16, den[64] u16,
-// infill[144] {v0 | w00<<8 | w01<<16 | w10<<24, w11}.  Table: ncfg(rgb), ncfg(rgba), pad[6],
-// 8 RGB records, 8 RGBA records.
-struct AstcCfgHost { int N, M, bits, mode; };
-
+// ---- ASTC: footprints.  The per-footprint device table (partition lists, config lists, infill
+// and quantisation tables) is built by csrc/astc_tables.h once per format and context.
 bool astc_footprint(int format, int* bw, int* bh)
 {
 	static const unsigned char fp[14][2] = {{4, 4}, {5, 4}, {5, 5}, {6, 5}, {6, 6}, {8, 5}, {8, 6},
@@ -97,102 +95,6 @@ bool astc_footprint(int format, int* bw, int* bh)
 	*bw = fp[format - CFHIP_FORMAT_ASTC_4x4][0];
 	*bh = fp[format - CFHIP_FORMAT_ASTC_4x4][1];
 	return true;
-}
-
-int astc_block_mode(int N, int M, int bits)
-{
-	int H, r;
-	switch (bits) {
-		case 1: H = 0; r = 2; break;
-		case 2: H = 0; r = 4; break;
-		case 3: H = 0; r = 7; break;
-		case 4: H = 1; r = 4; break;
-		case 5: H = 1; r = 7; break;
-		default: return -1;
-	}
-	const int R0 = r & 1, R1 = (r >> 1) & 1, R2 = (r >> 2) & 1;
-	const int lowA = (H << 9) | (R0 << 4) | (R2 << 1) | R1;
-	const int lowB = (H << 9) | (R0 << 4) | (R2 << 3) | (R1 << 2);
-	if (N >= 4 && N <= 7 && M >= 2 && M <= 5) return lowA | ((N - 4) << 7) | ((M - 2) << 5);
-	if (N >= 8 && N <= 11 && M >= 2 && M <= 5) return lowA | ((N - 8) << 7) | ((M - 2) << 5) | (1 << 2);
-	if (N >= 2 && N <= 5 && M >= 8 && M <= 11) return lowA | ((M - 8) << 7) | ((N - 2) << 5) | (2 << 2);
-	if (N >= 2 && N <= 5 && M >= 6 && M <= 7) return lowA | ((M - 6) << 7) | ((N - 2) << 5) | (3 << 2);
-	if (N >= 2 && N <= 3 && M >= 2 && M <= 5)
-		return lowA | (1 << 8) | ((N - 2) << 7) | ((M - 2) << 5) | (3 << 2);
-	if (N == 12 && M >= 2 && M <= 5) return lowB | ((M - 2) << 5);
-	if (M == 12 && N >= 2 && N <= 5) return lowB | (1 << 7) | ((N - 2) << 5);
-	if (N == 6 && M == 10) return lowB | (3 << 7);
-	if (N == 10 && M == 6) return lowB | (3 << 7) | (1 << 5);
-	if (!H && N >= 6 && N <= 9 && M >= 6 && M <= 9)
-		return (R0 << 4) | (R2 << 3) | (R1 << 2) | (1 << 8) | ((N - 6) << 5) | ((M - 6) << 9);
-	return -1;
-}
-
-std::vector<AstcCfgHost> astc_configs(int bw, int bh, int nvals)
-{
-	std::vector<AstcCfgHost> all;
-	const int budget = 128 - 17 - 8*nvals;
-	for (int N = 2; N <= bw && N <= 12; ++N)
-		for (int M = 2; M <= bh && M <= 12; ++M)
-			for (int b = 1; b <= 5; ++b) {
-				const int wb = N*M*b, mode = astc_block_mode(N, M, b);
-				if (N*M > 64 || wb < 24 || wb > 96 || wb > budget || mode < 0)
-					continue;
-				all.push_back({N, M, b, mode});
-			}
-	// more weight bits, then more weights, then wider grid first (a strict total order)
-	std::sort(all.begin(), all.end(), [](const AstcCfgHost& a, const AstcCfgHost& b) {
-		const int ka = a.N*a.M*a.bits, kb = b.N*b.M*b.bits;
-		if (ka != kb) return ka > kb;
-		if (a.N*a.M != b.N*b.M) return a.N*a.M > b.N*b.M;
-		return a.N > b.N;
-	});
-	if (all.size() > 8)
-		all.resize(8);
-	return all;
-}
-
-const size_t kAstcStride = 1288;
-
-std::vector<uint8_t> astc_build_tables(int bw, int bh)
-{
-	std::vector<uint8_t> t(8 + 16*kAstcStride, 0);
-	for (int set = 0; set < 2; ++set) {
-		const std::vector<AstcCfgHost> cfgs = astc_configs(bw, bh, set ? 8 : 6);
-		t[set] = (uint8_t)cfgs.size();
-		for (size_t k = 0; k < cfgs.size(); ++k) {
-			uint8_t* r = t.data() + 8 + ((size_t)set*8 + k)*kAstcStride;
-			const int N = cfgs[k].N, M = cfgs[k].M;
-			r[0] = (uint8_t)N; r[1] = (uint8_t)M; r[2] = (uint8_t)cfgs[k].bits; r[3] = (uint8_t)(N*M);
-			const uint16_t mode = (uint16_t)cfgs[k].mode;
-			memcpy(r + 4, &mode, 2);
-			uint16_t den[64] = {0};
-			const int Ds = (1024 + bw/2)/(bw - 1), Dt = (1024 + bh/2)/(bh - 1);
-			for (int tt = 0; tt < bh; ++tt)
-				for (int s = 0; s < bw; ++s) {
-					const int cs = Ds*s, ct = Dt*tt;
-					const int gs = (cs*(N - 1) + 32) >> 6, gt = (ct*(M - 1) + 32) >> 6;
-					const int js = gs >> 4, fs = gs & 15, jt = gt >> 4, ft = gt & 15;
-					const int w11 = (fs*ft + 8) >> 4, w10 = ft - w11, w01 = fs - w11;
-					const int w00 = 16 - fs - ft + w11, v0 = js + jt*N;
-					// the four grid points of the texel (255: no such neighbour, its factor is 0 --
-					// the kernel sends those to the dummy row of its column) and their factors
-					const uint32_t a = (uint32_t)v0 | ((uint32_t)(w01 ? v0 + 1 : 255) << 8) |
-						((uint32_t)(w10 ? v0 + N : 255) << 16) | ((uint32_t)(w11 ? v0 + N + 1 : 255) << 24);
-					const uint32_t b = (uint32_t)w00 | ((uint32_t)w01 << 8) | ((uint32_t)w10 << 16) |
-						((uint32_t)w11 << 24);
-					uint8_t* e = r + 136 + (size_t)(tt*bw + s)*8;
-					memcpy(e, &a, 4);
-					memcpy(e + 4, &b, 4);
-					den[v0] = (uint16_t)(den[v0] + w00);
-					if (w01) den[v0 + 1] = (uint16_t)(den[v0 + 1] + w01);
-					if (w10) den[v0 + N] = (uint16_t)(den[v0 + N] + w10);
-					if (w11) den[v0 + N + 1] = (uint16_t)(den[v0 + N + 1] + w11);
-				}
-			memcpy(r + 8, den, sizeof(den));
-		}
-	}
-	return t;
 }
 
 // ---- uncompressed ("standard") formats, Texture::Format 1..28 ----
@@ -448,30 +350,22 @@ int launch(cfhip_ctx* ctx, const cf_kparams& kp, const cfhip_params& p, int pixe
 			if (pixel_type != CFHIP_PIXEL_RGBA8 && pixel_type != CFHIP_PIXEL_RGBA32F)
 				return fail(ctx, CFHIP_E_UNSUPPORTED, "ASTC LDR takes RGBA8 or RGBA32F pixels");
 			void*& tab = ctx->astc_tables[p.format];
+			size_t& lds = ctx->astc_lds[p.format];
 			if (!tab) {
 				int fbw, fbh;
 				astc_footprint(p.format, &fbw, &fbh);
-				const std::vector<uint8_t> host = astc_build_tables(fbw, fbh);
+				const std::vector<uint8_t> host = cfastc::build_blob(fbw, fbh);
+				lds = cfhip_astc_lds_bytes(reinterpret_cast<const cfastc::AstcBlobHeader*>(host.data()));
 				HIP_TRY(ctx, hipMalloc(&tab, host.size()));
 				HIP_TRY(ctx, hipMemcpy(tab, host.data(), host.size(), hipMemcpyHostToDevice));
 			}
 			cf_kparams k2 = kp;
 			k2.aux = tab;
-			{
-				// rows of the per-lane LDS grid columns: largest weight grid of the footprint + 1
-				// ... of the configs this quality level walks (1 / 2 / 4 / 8 / 8 per set: the kernel
-				// stages only those, bits 24..27), so that Lowest..Normal fit more workgroups per CU
-				int fbw, fbh, ng_max = 1;
-				astc_footprint(p.format, &fbw, &fbh);
-				const int ncs = p.quality == 0 ? 1 : (p.quality == 1 ? 2 : (p.quality == 2 ? 4 : 8));
-				for (int values = 6; values <= 8; values += 2) {
-					const std::vector<AstcCfgHost> cfgs = astc_configs(fbw, fbh, values);
-					for (size_t k = 0; k < cfgs.size() && (int)k < ncs; ++k)
-						ng_max = std::max(ng_max, cfgs[k].N*cfgs[k].M);
-				}
-				k2.flags |= ((uint32_t)(ng_max + 1) << 16) | ((uint32_t)ncs << 24);
-			}
-			e = cfhip_launch_astc(&k2, pixel_type == CFHIP_PIXEL_RGBA32F ? 1 : 0, stream);
+			// ASTCENC_FLG_USE_ALPHA_WEIGHT for Alpha::Standard / PreMultiplied, USE_PERCEPTUAL for sRGB
+			// images (AstcConverter.cpp:163-172)
+			k2.flags |= ((p.alpha == CFHIP_ALPHA_STANDARD || p.alpha == CFHIP_ALPHA_PREMULTIPLIED) ? 1u << 16 : 0u) |
+				(p.color_space == CFHIP_COLOR_SRGB ? 1u << 17 : 0u);
+			e = cfhip_launch_astc(&k2, pixel_type == CFHIP_PIXEL_RGBA32F ? 1 : 0, lds, stream);
 			ctx->last_kernel = "cfhip_astc_encode_kernel";
 			break;
 		}
@@ -793,6 +687,24 @@ int cfhip_query(int format, int type, int* block_w, int* block_h, int* bytes)
 	if (block_h) *block_h = fbh;
 	if (bytes) *bytes = bs;
 	return CFHIP_OK;
+}
+
+// Host-only introspection of the ASTC tables (tests/test_astc_tables.py compares them with the
+// oracle's independently built tables): counts of canonical partitions, configs per class x alpha,
+// and (mode | wq << 11) of every listed config.  Not part of the drop-in surface.
+int cfhip_debug_astc_table_info(int bw, int bh, int* npart3, int* ncfg10, uint16_t* cfg_modes)
+{
+	const std::vector<uint8_t> blob = cfastc::build_blob(bw, bh);
+	const cfastc::AstcBlobHeader* h = reinterpret_cast<const cfastc::AstcBlobHeader*>(blob.data());
+	for (int t = 0; t < 3; ++t)
+		npart3[t] = (int)h->npart[t];
+	const cfastc::AstcCfgRec* cfgs = reinterpret_cast<const cfastc::AstcCfgRec*>(blob.data() + h->off_cfg);
+	for (int i = 0; i < 10; ++i) {
+		ncfg10[i] = blob[h->off_ncfg + i];
+		for (int k = 0; k < 64; ++k)
+			cfg_modes[i*64 + k] = k < ncfg10[i] ? (uint16_t)(cfgs[i*64 + k].mode | (cfgs[i*64 + k].wq << 11)) : 0xFFFF;
+	}
+	return (int)h->total;
 }
 
 int cfhip_shard_rows(uint32_t block_rows, int rank, int world, uint32_t* row_begin,

@@ -1,0 +1,984 @@
+/*
+ * oracle/astc_encode.c -- TEST INFRASTRUCTURE (see cf_oracle.h header).
+ *
+ * ASTC 2-D LDR encoder: CPU restatement of the ASTC leg of the reference hot path
+ *   AstcConverter ctor (swizzle / profile / flags / preset)   lib/src/AstcConverter.cpp:134-201
+ *   AstcConverter::process (edge-replicated bw x bh tile -> astcenc_compress_image)  :208-230
+ * The reference forwards to ARM astc-encoder (absent submodule: "parity unpinned"); this is a
+ * from-specification encoder of the same class and the scalar twin of csrc/astc_encode.hip
+ * (byte-identical).  Every block it emits is decoded by Mesa's independent ASTC decoder in the
+ * tests (tests/test_oracle_mesa.py), so the bitstream side is pinned.
+ *
+ * Emitted: void extent; 1-4 partitions (partition hash, canonical de-duplicated seed list,
+ * shortlist by k-means cluster matching); single and dual plane; weight grids N x M <= footprint
+ * with every weight range (bits / trits / quints); endpoint modes 8/12 (direct, with and
+ * without blue contraction), 6/10 (base + scale), 0/4 (luminance), all at the colour
+ * quantisation level the remaining bits allow (ISE).  ASTCENC_FLG_USE_ALPHA_WEIGHT and
+ * ASTCENC_FLG_USE_PERCEPTUAL (AstcConverter.cpp:163-172) enter the error metric.
+ *
+ * Search (lane = (partitioning candidate, weight-grid config), ids fixed = the GPU's):
+ *   phase A  lane = (candidate, subset/plane): integer moments -> principal axis -> extremes
+ *            -> ideal endpoints and ideal per-texel weights 0..64
+ *   phase B  lane = (candidate, config): infill-weighted grid averages -> nearest quantised
+ *            weights -> per-subset least-squares endpoints -> endpoint mode and quantisation
+ *            by a quadratic error estimate -> EXACT error through the decode arithmetic
+ *   winner = min (error, id); packed with the ISE coder.
+ */
+#include "astc_common.h"
+#include "cf_oracle.h"
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ASTC_FLAG_ALPHA_WEIGHT 1
+#define ASTC_FLAG_PERCEPTUAL 2
+#define ASTC_MAX_CFG 64        /* configs listed per class; K of them are tried per candidate */
+#define ASTC_MAX_GRIDS 24
+#define ASTC_MAX_PARTS 1024
+
+typedef struct {
+	uint8_t N, M, wq, grid, ng, nw, wbits, cbits;
+	uint16_t mode;
+	uint16_t wq16, cq16;               /* noise terms of the ranking estimate (x16) */
+} astc_cfg;
+
+/* classes of partitioning candidates: 0 one partition, 1 one partition + dual plane, 2..4 = P */
+typedef struct {
+	int bw, bh, n;
+	astc_cfg cfg[5][2][ASTC_MAX_CFG];
+	int ncfg[5][2];
+	int ngrids;
+	uint8_t gN[ASTC_MAX_GRIDS], gM[ASTC_MAX_GRIDS];
+	astc_infill infill[ASTC_MAX_GRIDS][ASTC_MAX_TEXELS];
+	uint16_t den[ASTC_MAX_GRIDS][ASTC_MAX_WEIGHTS];
+	int npart[3];
+	uint16_t pseed[3][ASTC_MAX_PARTS];
+	uint8_t pid[3][ASTC_MAX_PARTS][ASTC_MAX_TEXELS];
+	uint64_t pmask[3][ASTC_MAX_PARTS][4][3];
+} astc_fmt;
+
+static astc_fmt* g_fmt[14];
+static pthread_mutex_t g_fmt_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static int q_levels(const astc_quant* q) { return q->levels; }
+
+/* integer score of a config (smaller = tried first): modelled weight-quantisation, colour-
+ * quantisation and decimation noise (x1000) for a typical endpoint span of 48 */
+static int cfg_score(int bw, int bh, int N, int M, int Lw, int Lc)
+{
+	int sw = (48*48*1000)/(12*(Lw - 1)*(Lw - 1));
+	int sc = (255*255*1000)/(12*(Lc - 1)*(Lc - 1))/2;
+	int sd = (16000*(bw*bh - N*M))/(N*M);
+	return sw + sc + sd;
+}
+
+static int grid_index(astc_fmt* f, int N, int M)
+{
+	for (int g = 0; g < f->ngrids; ++g)
+		if (f->gN[g] == N && f->gM[g] == M)
+			return g;
+	if (f->ngrids >= ASTC_MAX_GRIDS)
+		return -1;
+	int g = f->ngrids++;
+	f->gN[g] = (uint8_t)N; f->gM[g] = (uint8_t)M;
+	astc_build_infill(f->bw, f->bh, N, M, f->infill[g]);
+	memset(f->den[g], 0, sizeof(f->den[g]));
+	for (int i = 0; i < f->n; ++i)
+		for (int k = 0; k < 4; ++k)
+			if (f->infill[g][i].f[k])
+				f->den[g][f->infill[g][i].g[k]] += f->infill[g][i].f[k];
+	return g;
+}
+
+static void build_configs(astc_fmt* f, int cls, int alpha)
+{
+	const astc_tables* T = astc_get_tables();
+	int P = cls <= 1 ? 1 : cls, dual = cls == 1;
+	int nv0 = alpha ? 8 : 6;
+	if (P*nv0 > 18) nv0 = 6;
+	if (P*nv0 > 18) nv0 = 4;
+	int minlv = P == 1 ? 4 : 2;
+	typedef struct { int score, N, M, wq, lv; } cand;
+	cand all[2048];
+	int n = 0;
+	for (int N = 2; N <= f->bw && N <= 12; ++N)
+		for (int M = 2; M <= f->bh && M <= 12; ++M)
+			for (int wq = 0; wq < ASTC_NWQ; ++wq) {
+				int nw = N*M*(dual ? 2 : 1);
+				if (nw > ASTC_MAX_WEIGHTS)
+					continue;
+				int wbits = astc_ise_bits(nw, &astc_wq[wq]);
+				if (wbits < 24 || wbits > 96 || astc_make_block_mode(N, M, wq, dual) < 0)
+					continue;
+				int cbits = 128 - wbits - (P == 1 ? 17 : 29) - (dual ? 2 : 0);
+				if (cbits < 0)
+					continue;
+				int lv = T->c_level[P*nv0/2][cbits];
+				if (lv < minlv)
+					continue;
+				all[n].score = cfg_score(f->bw, f->bh, N, M, q_levels(&astc_wq[wq]), q_levels(&astc_cq[lv]));
+				all[n].N = N; all[n].M = M; all[n].wq = wq; all[n].lv = lv;
+				++n;
+			}
+	for (int i = 0; i < n; ++i)
+		for (int j = i + 1; j < n; ++j) {
+			const cand *a = &all[i], *b = &all[j];
+			int swap = b->score < a->score || (b->score == a->score && (b->N*b->M > a->N*a->M ||
+				(b->N*b->M == a->N*a->M && (b->N > a->N || (b->N == a->N && b->wq > a->wq)))));
+			if (swap) { cand t = all[i]; all[i] = all[j]; all[j] = t; }
+		}
+	int k = 0;
+	for (int i = 0; i < n && k < ASTC_MAX_CFG; ++i) {
+		int g = grid_index(f, all[i].N, all[i].M);
+		if (g < 0)
+			continue;
+		astc_cfg* c = &f->cfg[cls][alpha][k++];
+		int nw = all[i].N*all[i].M*(dual ? 2 : 1);
+		c->N = (uint8_t)all[i].N; c->M = (uint8_t)all[i].M; c->wq = (uint8_t)all[i].wq;
+		c->grid = (uint8_t)g; c->ng = (uint8_t)(all[i].N*all[i].M); c->nw = (uint8_t)nw;
+		c->wbits = (uint8_t)astc_ise_bits(nw, &astc_wq[all[i].wq]);
+		c->cbits = (uint8_t)(128 - c->wbits - (P == 1 ? 17 : 29) - (dual ? 2 : 0));
+		c->mode = (uint16_t)astc_make_block_mode(all[i].N, all[i].M, all[i].wq, dual);
+		int Lw = q_levels(&astc_wq[all[i].wq]), Lc = q_levels(&astc_cq[all[i].lv]);
+		c->wq16 = (uint16_t)((16*64*64)/(12*(Lw - 1)*(Lw - 1)));
+		c->cq16 = (uint16_t)((16*255*255)/(18*(Lc - 1)*(Lc - 1)));
+	}
+	f->ncfg[cls][alpha] = k;
+}
+
+static void build_partitions(astc_fmt* f, int P)
+{
+	int t = P - 2, n = f->n, small = n < 31, kept = 0;
+	static uint8_t canon[ASTC_MAX_PARTS][ASTC_MAX_TEXELS];
+	for (int seed = 0; seed < 1024; ++seed) {
+		uint8_t ids[ASTC_MAX_TEXELS], cn[ASTC_MAX_TEXELS], map[4] = {255, 255, 255, 255};
+		int cnt[4] = {0, 0, 0, 0}, next = 0;
+		for (int i = 0; i < n; ++i) {
+			ids[i] = (uint8_t)astc_select_partition(seed, i % f->bw, i / f->bw, P, small);
+			cnt[ids[i]]++;
+			if (map[ids[i]] == 255) map[ids[i]] = (uint8_t)next++;
+			cn[i] = map[ids[i]];
+		}
+		int ok = 1;
+		for (int p = 0; p < P; ++p) ok = ok && cnt[p] > 0;
+		for (int j = 0; j < kept && ok; ++j)
+			if (memcmp(canon[j], cn, (size_t)n) == 0) ok = 0;
+		if (!ok)
+			continue;
+		memcpy(canon[kept], cn, (size_t)n);
+		f->pseed[t][kept] = (uint16_t)seed;
+		memcpy(f->pid[t][kept], ids, (size_t)n);
+		memset(f->pmask[t][kept], 0, sizeof(f->pmask[t][kept]));
+		for (int i = 0; i < n; ++i)
+			f->pmask[t][kept][ids[i]][i >> 6] |= 1ull << (i & 63);
+		++kept;
+	}
+	f->npart[t] = kept;
+}
+
+static const astc_fmt* get_fmt(int bw, int bh)
+{
+	static const uint8_t fp[14][2] = {{4, 4}, {5, 4}, {5, 5}, {6, 5}, {6, 6}, {8, 5}, {8, 6}, {8, 8},
+		{10, 5}, {10, 6}, {10, 8}, {10, 10}, {12, 10}, {12, 12}};
+	int idx = -1;
+	for (int i = 0; i < 14; ++i)
+		if (fp[i][0] == bw && fp[i][1] == bh) idx = i;
+	if (idx < 0)
+		return NULL;
+	pthread_mutex_lock(&g_fmt_lock);
+	if (!g_fmt[idx]) {
+		astc_fmt* f = (astc_fmt*)calloc(1, sizeof(astc_fmt));
+		f->bw = bw; f->bh = bh; f->n = bw*bh;
+		for (int cls = 0; cls < 5; ++cls)
+			for (int a = 0; a < 2; ++a)
+				build_configs(f, cls, a);
+		for (int P = 2; P <= 4; ++P)
+			build_partitions(f, P);
+		g_fmt[idx] = f;
+	}
+	pthread_mutex_unlock(&g_fmt_lock);
+	return g_fmt[idx];
+}
+
+/* introspection for the tests / the table cross-check with the HIP library */
+int cfo_astc_table_info(int bw, int bh, int* npart3, int* ncfg10, uint16_t* cfg_modes)
+{
+	const astc_fmt* f = get_fmt(bw, bh);
+	if (!f)
+		return -1;
+	for (int t = 0; t < 3; ++t) npart3[t] = f->npart[t];
+	for (int cls = 0; cls < 5; ++cls)
+		for (int a = 0; a < 2; ++a) {
+			ncfg10[cls*2 + a] = f->ncfg[cls][a];
+			for (int k = 0; k < ASTC_MAX_CFG; ++k)
+				cfg_modes[(cls*2 + a)*ASTC_MAX_CFG + k] = k < f->ncfg[cls][a] ?
+					(uint16_t)(f->cfg[cls][a][k].mode | (f->cfg[cls][a][k].wq << 11)) : 0xFFFF;
+		}
+	return 0;
+}
+
+/* ------------------------------------------------------------------ block state */
+
+typedef struct {
+	int P, dual, ccs, cls, tab;        /* tab: index into the partition table (P >= 2) */
+} astc_pc;
+
+typedef struct {
+	const astc_fmt* f;
+	int n, nc, has_alpha, grey, flags;
+	int px[ASTC_MAX_TEXELS][4];
+	int cw[4];                          /* channel weights of the error metric */
+	int wa[ASTC_MAX_TEXELS];            /* texel weight of the RGB error (alpha or 255) */
+	/* phase A results per (candidate, subset-or-plane) */
+	int e0[8][4][4], e1[8][4][4];
+	int span2n[8][4];                   /* per slot: texel count x weighted squared endpoint distance */
+	uint8_t T[8][2][ASTC_MAX_TEXELS];
+	int edec[ASTC_MAX_GRIDS];           /* decimation error of candidate 0's ideal weights per grid */
+} astc_blk;
+
+static float clampf255(float x) { return x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x); }
+
+static int pc_part(const astc_blk* b, const astc_pc* pc, int i)
+{
+	return pc->P == 1 ? 0 : b->f->pid[pc->P - 2][pc->tab][i];
+}
+
+/* principal axis of a covariance (upper triangle filled, inactive channels zero): three
+ * normalised power iterations from the column of the largest diagonal entry */
+static void principal_axis(float Cm[4][4], float axis[4])
+{
+	for (int a = 0; a < 4; ++a)
+		for (int c = 0; c < a; ++c)
+			Cm[a][c] = Cm[c][a];
+	int amax = 0;
+	for (int a = 1; a < 4; ++a)
+		if (Cm[a][a] > Cm[amax][amax])
+			amax = a;
+	float v[4];
+	for (int a = 0; a < 4; ++a)
+		v[a] = Cm[amax][a];
+	for (int it = 0; it < 3; ++it) {
+		float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+		if (m > 0.0f) {
+			float im = 1.0f/m;
+			for (int a = 0; a < 4; ++a)
+				v[a] = v[a]*im;
+		}
+		float r[4];
+		for (int a = 0; a < 4; ++a) {
+			float t = Cm[a][0]*v[0];
+			t = fmaf(Cm[a][1], v[1], t);
+			t = fmaf(Cm[a][2], v[2], t);
+			t = fmaf(Cm[a][3], v[3], t);
+			r[a] = t;
+		}
+		memcpy(v, r, sizeof(r));
+	}
+	float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+	axis[0] = axis[1] = axis[2] = axis[3] = 0.0f;
+	if (m > 0.0f) {
+		float im = 1.0f/m;
+		for (int a = 0; a < 4; ++a)
+			v[a] = v[a]*im;
+		float l2 = v[0]*v[0];
+		l2 = fmaf(v[1], v[1], l2);
+		l2 = fmaf(v[2], v[2], l2);
+		l2 = fmaf(v[3], v[3], l2);
+		float is = 1.0f/sqrtf(l2);
+		for (int a = 0; a < 4; ++a)
+			axis[a] = v[a]*is;
+	}
+}
+
+/* phase A, lane = (candidate j, slot s): slot = subset for partitioned candidates, plane for the
+ * dual-plane candidate.  chmask: the channels this slot fits. */
+static void phase_a(astc_blk* b, int j, const astc_pc* pc, int s)
+{
+	int n = b->n, chmask;
+	if (pc->dual)
+		chmask = s == 1 ? (1 << pc->ccs) : (((1 << b->nc) - 1) & ~(1 << pc->ccs));
+	else
+		chmask = (1 << b->nc) - 1;
+	int sum[4] = {0, 0, 0, 0}, SS[4][4], cnt = 0;
+	memset(SS, 0, sizeof(SS));
+	for (int i = 0; i < n; ++i) {
+		if (!pc->dual && pc_part(b, pc, i) != s)
+			continue;
+		++cnt;
+		for (int a = 0; a < 4; ++a)
+			if ((chmask >> a) & 1) {
+				sum[a] += b->px[i][a];
+				for (int c = a; c < 4; ++c)
+					if ((chmask >> c) & 1)
+						SS[a][c] += b->px[i][a]*b->px[i][c];
+			}
+	}
+	float Cm[4][4], mean[4], axis[4];
+	float ic = 1.0f/(float)cnt;
+	for (int a = 0; a < 4; ++a) {
+		mean[a] = (float)sum[a]*ic;
+		for (int c = a; c < 4; ++c)
+			Cm[a][c] = (float)(cnt*SS[a][c] - sum[a]*sum[c]);
+	}
+	principal_axis(Cm, axis);
+	float tmin = 3.0e38f, tmax = -3.0e38f;
+	for (int i = 0; i < n; ++i) {
+		if (!pc->dual && pc_part(b, pc, i) != s)
+			continue;
+		float t = axis[0]*((float)(((chmask >> 0) & 1) ? b->px[i][0] : 0) - mean[0]);
+		t = fmaf(axis[1], (float)(((chmask >> 1) & 1) ? b->px[i][1] : 0) - mean[1], t);
+		t = fmaf(axis[2], (float)(((chmask >> 2) & 1) ? b->px[i][2] : 0) - mean[2], t);
+		t = fmaf(axis[3], (float)(((chmask >> 3) & 1) ? b->px[i][3] : 0) - mean[3], t);
+		tmin = fminf(tmin, t);
+		tmax = fmaxf(tmax, t);
+	}
+	int e0[4] = {0, 0, 0, 0}, e1[4] = {0, 0, 0, 0}, s0 = 0, s1 = 0;
+	for (int c = 0; c < 4; ++c)
+		if ((chmask >> c) & 1) {
+			e0[c] = (int)floorf(clampf255(fmaf(axis[c], tmin, mean[c])) + 0.5f);
+			e1[c] = (int)floorf(clampf255(fmaf(axis[c], tmax, mean[c])) + 0.5f);
+			if (c < 3 || chmask == 8) { s0 += e0[c]; s1 += e1[c]; }
+		}
+	if (s1 < s0)
+		for (int c = 0; c < 4; ++c) { int t = e0[c]; e0[c] = e1[c]; e1[c] = t; }
+	int dv[4], dd = 0;
+	for (int c = 0; c < 4; ++c) {
+		dv[c] = e1[c] - e0[c];
+		dd += dv[c]*dv[c];
+	}
+	int plane = pc->dual ? s : 0;
+	for (int i = 0; i < n; ++i) {
+		if (!pc->dual && pc_part(b, pc, i) != s)
+			continue;
+		int t = 0, Tw = 0;
+		for (int c = 0; c < 4; ++c)
+			if ((chmask >> c) & 1)
+				t += (b->px[i][c] - e0[c])*dv[c];
+		if (t > 0 && dd > 0) {
+			int tc = t > dd ? dd : t;
+			Tw = (128*tc + dd)/(2*dd);
+			if (Tw > 64) Tw = 64;
+		}
+		b->T[j][plane][i] = (uint8_t)Tw;
+	}
+	int sp = 0;
+	for (int c = 0; c < 4; ++c)
+		if ((chmask >> c) & 1) {
+			b->e0[j][pc->dual ? 0 : s][c] = e0[c];
+			b->e1[j][pc->dual ? 0 : s][c] = e1[c];
+			sp += b->cw[c]*dv[c]*dv[c];
+		}
+	b->span2n[j][s] = sp*cnt;
+}
+
+/* decimation error of candidate 0's ideal weights under grid g (lane = grid): unquantised grid
+ * averages, infilled back, squared difference to the ideal weights */
+static int grid_decimation_error(const astc_blk* b, int g)
+{
+	const astc_fmt* f = b->f;
+	const astc_infill* inf = f->infill[g];
+	int num[ASTC_MAX_WEIGHTS], gi[ASTC_MAX_WEIGHTS], ng = f->gN[g]*f->gM[g], e = 0;
+	memset(num, 0, sizeof(num));
+	for (int i = 0; i < b->n; ++i)
+		for (int k = 0; k < 4; ++k)
+			if (inf[i].f[k])
+				num[inf[i].g[k]] += inf[i].f[k]*b->T[0][0][i];
+	for (int x = 0; x < ng; ++x)
+		gi[x] = f->den[g][x] ? (num[x] + f->den[g][x]/2)/f->den[g][x] : 0;
+	for (int i = 0; i < b->n; ++i) {
+		int acc = 8;
+		for (int k = 0; k < 4; ++k)
+			if (inf[i].f[k])
+				acc += inf[i].f[k]*gi[inf[i].g[k]];
+		int d = (acc >> 4) - b->T[0][0][i];
+		e += d*d;
+	}
+	return e;
+}
+
+/* the K configs of a candidate's class with the smallest estimated error
+ *   span^2 (2.5 decimation + weight quantisation noise) / 4096 + colour quantisation noise,
+ * in (estimate, list index) order (lane = config, K group-min steps) */
+static int rank_configs(const astc_blk* b, int j, const astc_pc* pc, int K, int* order)
+{
+	const astc_fmt* f = b->f;
+	int ncfg = f->ncfg[pc->cls][b->has_alpha], slots = pc->dual ? 2 : pc->P, spn = 0;
+	for (int s = 0; s < slots; ++s)
+		spn += b->span2n[j][s];
+	uint64_t span2 = ((uint64_t)(uint32_t)spn*(65536u/(uint32_t)b->n)) >> 16;
+	uint64_t key[ASTC_MAX_CFG];
+	for (int k = 0; k < ncfg; ++k) {
+		const astc_cfg* c = &f->cfg[pc->cls][b->has_alpha][k];
+		uint64_t wn = (uint64_t)b->edec[c->grid]*40u + (uint64_t)b->n*c->wq16;
+		uint64_t est = ((span2*wn) >> 12) + (uint64_t)(b->n*b->nc)*c->cq16;
+		key[k] = (est << 8) | (uint64_t)k;
+	}
+	int got = 0;
+	for (; got < K && got < ncfg; ++got) {
+		int bi = -1;
+		for (int k = 0; k < ncfg; ++k)
+			if (key[k] != ~0ull && (bi < 0 || key[k] < key[bi]))
+				bi = k;
+		order[got] = (int)(key[bi] & 255u);
+		key[bi] = ~0ull;
+	}
+	return got;
+}
+
+/* result of one (candidate, config) lane */
+typedef struct {
+	uint64_t err;
+	int valid, cem, lv;
+	uint8_t cvals[18];                 /* ISE colour values, partition by partition */
+	int ncv;
+	uint8_t wq[ASTC_MAX_WEIGHTS];      /* quantised weights in stream order */
+} astc_lane;
+
+static int quant_c(const astc_tables* T, int lv, float x, int* stored)
+{
+	int xi = (int)floorf(clampf255(x) + 0.5f);
+	int q = T->c_near[lv][xi];
+	*stored = q;
+	return T->c_unq[lv][q];
+}
+
+/* quadratic estimate of the error an endpoint pair (D0, D1) adds over the least-squares pair
+ * (r0, r1) of one channel: (A d0^2 + 2 B d0 d1 + C d1^2) */
+static float quad_est(float fA, float fB, float fC, float d0, float d1)
+{
+	float t = fA*d0;
+	t = fmaf(fB, d1, t);
+	float u = fB*d0;
+	u = fmaf(fC, d1, u);
+	float q = t*d0;
+	q = fmaf(u, d1, q);
+	return q;
+}
+
+static void phase_b(const astc_blk* b, int j, const astc_pc* pc, const astc_cfg* cfg, astc_lane* L)
+{
+	const astc_tables* T = astc_get_tables();
+	const astc_fmt* f = b->f;
+	int n = b->n, planes = pc->dual ? 2 : 1, ng = cfg->ng, P = pc->P;
+	const astc_infill* inf = f->infill[cfg->grid];
+	const uint16_t* den = f->den[cfg->grid];
+	uint8_t w[2][ASTC_MAX_TEXELS];
+	memset(L, 0, sizeof(*L));
+	L->err = ~0ull;
+	/* 1. decimate + quantise the weights, 2. reconstruct the texel weights */
+	for (int pl = 0; pl < planes; ++pl) {
+		int num[ASTC_MAX_WEIGHTS], unq[ASTC_MAX_WEIGHTS];
+		memset(num, 0, sizeof(num));
+		for (int i = 0; i < n; ++i)
+			for (int k = 0; k < 4; ++k)
+				if (inf[i].f[k])
+					num[inf[i].g[k]] += inf[i].f[k]*b->T[j][pl][i];
+		for (int g = 0; g < ng; ++g) {
+			int gi = den[g] ? (num[g] + den[g]/2)/den[g] : 0;
+			int q = T->w_near[cfg->wq][gi];
+			L->wq[g*planes + pl] = (uint8_t)q;
+			unq[g] = T->w_unq[cfg->wq][q];
+		}
+		for (int i = 0; i < n; ++i) {
+			int acc = 8;
+			for (int k = 0; k < 4; ++k)
+				if (inf[i].f[k])
+					acc += inf[i].f[k]*unq[inf[i].g[k]];
+			w[pl][i] = (uint8_t)(acc >> 4);
+		}
+	}
+	/* 3. least-squares endpoints per set (set = subset, or plane for dual) */
+	int nset = pc->dual ? 2 : P;
+	int S[4] = {0}, A[4] = {0}, B[4] = {0}, C[4] = {0}, cnt[4] = {0}, U[4][4], V[4][4];
+	memset(U, 0, sizeof(U));
+	memset(V, 0, sizeof(V));
+	for (int i = 0; i < n; ++i) {
+		int part = pc_part(b, pc, i);
+		for (int st = 0; st < nset; ++st) {
+			if (!pc->dual && st != part)
+				continue;
+			int wi = w[pc->dual ? st : 0][i], iw = 64 - wi;
+			S[st] += wi; A[st] += iw*iw; B[st] += iw*wi; C[st] += wi*wi; cnt[st]++;
+		}
+		for (int c = 0; c < b->nc; ++c) {
+			int st = pc->dual ? (c == pc->ccs) : part;
+			int wi = w[pc->dual ? st : 0][i], iw = 64 - wi;
+			U[st][c] += iw*b->px[i][c];
+			V[st][c] += wi*b->px[i][c];
+		}
+	}
+	float r0[4][4], r1[4][4], fA[4], fB[4], fC[4];
+	for (int st = 0; st < nset; ++st) {
+		int det = cnt[st]*C[st] - S[st]*S[st];
+		fA[st] = (float)A[st]; fB[st] = (float)B[st]; fC[st] = (float)C[st];
+		float inv = det > 0 ? 1.0f/(64.0f*(float)det) : 0.0f;
+		for (int c = 0; c < b->nc; ++c) {
+			if (pc->dual && (c == pc->ccs) != st)
+				continue;
+			int sub = pc->dual ? 0 : st;
+			if (det > 0) {
+				float fU = (float)U[st][c], fV = (float)V[st][c];
+				float t0 = fB[st]*fV;
+				float n0 = fmaf(fC[st], fU, -t0);
+				float t1 = fB[st]*fU;
+				float n1 = fmaf(fA[st], fV, -t1);
+				r0[sub][c] = clampf255(n0*inv);
+				r1[sub][c] = clampf255(n1*inv);
+			} else {
+				r0[sub][c] = (float)b->e0[j][sub][c];
+				r1[sub][c] = (float)b->e1[j][sub][c];
+			}
+		}
+	}
+	if (b->nc == 3)
+		for (int p = 0; p < P; ++p) { r0[p][3] = 255.0f; r1[p][3] = 255.0f; }
+	/* 4. endpoint mode + quantisation: options 0 = direct RGB(A) (CEM 8 / 12, blue contraction
+	 * decided per partition), 1 = base + scale (6 / 10), 2 = luminance (0 / 4) */
+	int nvo[3] = {b->has_alpha ? 8 : 6, b->has_alpha ? 6 : 4, b->has_alpha ? 4 : 2};
+	int cemo[3] = {b->has_alpha ? 12 : 8, b->has_alpha ? 10 : 6, b->has_alpha ? 4 : 0};
+	float best_est = 3.0e38f;
+	int best_opt = -1;
+	int D0[3][4][4], D1[3][4][4];
+	uint8_t cv[3][18];
+	for (int o = 0; o < 3; ++o) {
+		int nv = nvo[o];
+		if (nv*P > 18 || (o == 2 && !b->grey) || (o > 0 && pc->dual && pc->ccs < 3))
+			continue;
+		int lv = T->c_level[nv*P/2][cfg->cbits];
+		if (lv < 0 || cfg->cbits < (13*nv*P + 4)/5)
+			continue;
+		float est = 0.0f;
+		int ok = 1;
+		for (int p = 0; p < P && ok; ++p) {
+			uint8_t* vals = cv[o] + p*nv;
+			int st[8];
+			int* d0 = D0[o][p];
+			int* d1 = D1[o][p];
+			int aset = pc->dual ? (pc->ccs == 3) : p;      /* LSQ set of the alpha channel */
+			int cset[4];
+			for (int c = 0; c < 4; ++c)
+				cset[c] = pc->dual ? (c == pc->ccs) : p;
+			if (o == 0) {
+				/* direct */
+				int dd0[4], dd1[4], sd0 = 0, sd1 = 0;
+				for (int c = 0; c < 3; ++c) {
+					dd0[c] = quant_c(T, lv, r0[p][c], &st[2*c]);
+					dd1[c] = quant_c(T, lv, r1[p][c], &st[2*c + 1]);
+					sd0 += dd0[c]; sd1 += dd1[c];
+				}
+				float ed = 3.0e38f, ec = 3.0e38f;
+				if (sd1 >= sd0) {
+					ed = 0.0f;
+					for (int c = 0; c < 3; ++c)
+						ed = fmaf((float)b->cw[c], quad_est(fA[cset[c]], fB[cset[c]], fC[cset[c]],
+							(float)dd0[c] - r0[p][c], (float)dd1[c] - r1[p][c]), ed);
+				}
+				/* blue contraction: stored = (2r - b, 2g - b, b), endpoints swapped */
+				int sc[8], c0[4], c1[4], sc0 = 0, sc1 = 0, cok = 1;
+				float i0[3] = {fmaf(2.0f, r0[p][0], -r0[p][2]), fmaf(2.0f, r0[p][1], -r0[p][2]), r0[p][2]};
+				float i1[3] = {fmaf(2.0f, r1[p][0], -r1[p][2]), fmaf(2.0f, r1[p][1], -r1[p][2]), r1[p][2]};
+				for (int c = 0; c < 3; ++c)
+					cok = cok && i0[c] >= 0.0f && i0[c] <= 255.0f && i1[c] >= 0.0f && i1[c] <= 255.0f;
+				if (cok) {
+					int u0[3], u1[3];
+					for (int c = 0; c < 3; ++c) {
+						u0[c] = quant_c(T, lv, i0[c], &sc[2*c + 1]);   /* endpoint 0 sits in the odd values */
+						u1[c] = quant_c(T, lv, i1[c], &sc[2*c]);
+						sc1 += u0[c]; sc0 += u1[c];
+					}
+					if (sc1 < sc0) {
+						c0[0] = (u0[0] + u0[2]) >> 1; c0[1] = (u0[1] + u0[2]) >> 1; c0[2] = u0[2];
+						c1[0] = (u1[0] + u1[2]) >> 1; c1[1] = (u1[1] + u1[2]) >> 1; c1[2] = u1[2];
+						ec = 0.0f;
+						for (int c = 0; c < 3; ++c)
+							ec = fmaf((float)b->cw[c], quad_est(fA[cset[c]], fB[cset[c]], fC[cset[c]],
+								(float)c0[c] - r0[p][c], (float)c1[c] - r1[p][c]), ec);
+					}
+				}
+				if (ed >= 3.0e38f && ec >= 3.0e38f) { ok = 0; break; }
+				int contract = ec < ed;
+				for (int c = 0; c < 3; ++c) {
+					d0[c] = contract ? c0[c] : dd0[c];
+					d1[c] = contract ? c1[c] : dd1[c];
+					vals[2*c] = (uint8_t)(contract ? sc[2*c] : st[2*c]);
+					vals[2*c + 1] = (uint8_t)(contract ? sc[2*c + 1] : st[2*c + 1]);
+				}
+				est += contract ? ec : ed;
+				d0[3] = 255; d1[3] = 255;
+				if (b->has_alpha) {
+					int s6, s7;
+					d0[3] = quant_c(T, lv, r0[p][3], &s6);
+					d1[3] = quant_c(T, lv, r1[p][3], &s7);
+					vals[6] = (uint8_t)(contract ? s7 : s6);
+					vals[7] = (uint8_t)(contract ? s6 : s7);
+					est = fmaf((float)b->cw[3], quad_est(fA[aset], fB[aset], fC[aset],
+						(float)d0[3] - r0[p][3], (float)d1[3] - r1[p][3]), est);
+				}
+			} else if (o == 1) {
+				/* base + scale: e1 = (v0, v1, v2), e0 = e1 * v3 >> 8 */
+				float num = 0.0f, dn = 0.0f;
+				for (int c = 0; c < 3; ++c) {
+					d1[c] = quant_c(T, lv, r1[p][c], &st[c]);
+					vals[c] = (uint8_t)st[c];
+					num = fmaf(r0[p][c], (float)d1[c], num);
+					dn = fmaf((float)d1[c], (float)d1[c], dn);
+				}
+				float sf = dn > 0.0f ? num*(256.0f/dn) : 0.0f;
+				int s3, sq = quant_c(T, lv, sf, &s3);
+				vals[3] = (uint8_t)s3;
+				for (int c = 0; c < 3; ++c) {
+					d0[c] = (d1[c]*sq) >> 8;
+					est = fmaf((float)b->cw[c], quad_est(fA[cset[c]], fB[cset[c]], fC[cset[c]],
+						(float)d0[c] - r0[p][c], (float)d1[c] - r1[p][c]), est);
+				}
+				d0[3] = 255; d1[3] = 255;
+				if (b->has_alpha) {
+					int s4, s5;
+					d0[3] = quant_c(T, lv, r0[p][3], &s4);
+					d1[3] = quant_c(T, lv, r1[p][3], &s5);
+					vals[4] = (uint8_t)s4; vals[5] = (uint8_t)s5;
+					est = fmaf((float)b->cw[3], quad_est(fA[aset], fB[aset], fC[aset],
+						(float)d0[3] - r0[p][3], (float)d1[3] - r1[p][3]), est);
+				}
+			} else {
+				/* luminance (grey blocks: r = g = b) */
+				int s0, s1;
+				int l0 = quant_c(T, lv, r0[p][0], &s0), l1 = quant_c(T, lv, r1[p][0], &s1);
+				vals[0] = (uint8_t)s0; vals[1] = (uint8_t)s1;
+				for (int c = 0; c < 3; ++c) {
+					d0[c] = l0; d1[c] = l1;
+					est = fmaf((float)b->cw[c], quad_est(fA[cset[c]], fB[cset[c]], fC[cset[c]],
+						(float)l0 - r0[p][c], (float)l1 - r1[p][c]), est);
+				}
+				d0[3] = 255; d1[3] = 255;
+				if (b->has_alpha) {
+					int s2, s3;
+					d0[3] = quant_c(T, lv, r0[p][3], &s2);
+					d1[3] = quant_c(T, lv, r1[p][3], &s3);
+					vals[2] = (uint8_t)s2; vals[3] = (uint8_t)s3;
+					est = fmaf((float)b->cw[3], quad_est(fA[aset], fB[aset], fC[aset],
+						(float)d0[3] - r0[p][3], (float)d1[3] - r1[p][3]), est);
+				}
+			}
+		}
+		if (ok && est < best_est) {
+			best_est = est;
+			best_opt = o;
+		}
+	}
+	if (best_opt < 0)
+		return;
+	/* 5. exact error through the decode arithmetic */
+	uint64_t err = 0;
+	for (int i = 0; i < n; ++i) {
+		int p = pc_part(b, pc, i);
+		uint32_t ergb = 0, ea = 0;
+		for (int c = 0; c < b->nc; ++c) {
+			int wi = w[(pc->dual && c == pc->ccs) ? 1 : 0][i];
+			int v = ((D0[best_opt][p][c]*257*(64 - wi) + D1[best_opt][p][c]*257*wi + 32) >> 6) >> 8;
+			int d = v - b->px[i][c];
+			if (c < 3) ergb += (uint32_t)(b->cw[c]*d*d);
+			else ea = (uint32_t)(b->cw[3]*d*d);
+		}
+		err += (uint64_t)ergb*(uint64_t)b->wa[i] + (uint64_t)ea*255u;
+	}
+	L->err = err;
+	L->valid = 1;
+	L->cem = cemo[best_opt];
+	L->ncv = nvo[best_opt]*P;
+	L->lv = T->c_level[L->ncv/2][cfg->cbits];
+	memcpy(L->cvals, cv[best_opt], (size_t)L->ncv);
+}
+
+/* ------------------------------------------------------------------ candidates */
+
+/* 2..4 clusters along the principal axis + one Lloyd step; returns per-texel cluster ids */
+static void kmeans(const astc_blk* b, int K, const float axis[4], const float mean[4], float tmin,
+	float tmax, uint8_t* cl)
+{
+	int n = b->n;
+	float step = (tmax - tmin)*(1.0f/(float)K);
+	for (int i = 0; i < n; ++i) {
+		float t = axis[0]*((float)b->px[i][0] - mean[0]);
+		t = fmaf(axis[1], (float)b->px[i][1] - mean[1], t);
+		t = fmaf(axis[2], (float)b->px[i][2] - mean[2], t);
+		t = fmaf(axis[3], (b->nc == 4 ? (float)b->px[i][3] : 0.0f) - mean[3], t);
+		int k = 0;
+		for (int m = 1; m < K; ++m)
+			if (t > fmaf(step, (float)m, tmin)) k = m;
+		cl[i] = (uint8_t)k;
+	}
+	int sum[4][4], cnt[4] = {0, 0, 0, 0};
+	memset(sum, 0, sizeof(sum));
+	for (int i = 0; i < n; ++i) {
+		cnt[cl[i]]++;
+		for (int c = 0; c < b->nc; ++c)
+			sum[cl[i]][c] += b->px[i][c];
+	}
+	float cen[4][4];
+	for (int k = 0; k < K; ++k) {
+		float ic = cnt[k] ? 1.0f/(float)cnt[k] : 0.0f;
+		for (int c = 0; c < 4; ++c)
+			cen[k][c] = c < b->nc ? (float)sum[k][c]*ic : 0.0f;
+	}
+	for (int i = 0; i < n; ++i) {
+		float bd = 3.0e38f;
+		int bk = 0;
+		for (int k = 0; k < K; ++k) {
+			if (!cnt[k])
+				continue;
+			float d0 = (float)b->px[i][0] - cen[k][0], d1 = (float)b->px[i][1] - cen[k][1];
+			float d2 = (float)b->px[i][2] - cen[k][2];
+			float d3 = (b->nc == 4 ? (float)b->px[i][3] : 0.0f) - cen[k][3];
+			float d = d0*d0;
+			d = fmaf(d1, d1, d);
+			d = fmaf(d2, d2, d);
+			d = fmaf(d3, d3, d);
+			if (d < bd) { bd = d; bk = k; }
+		}
+		cl[i] = (uint8_t)bk;
+	}
+}
+
+static int popc64(uint64_t v) { return __builtin_popcountll(v); }
+
+/* mismatch between a clustering and table partition t: n - best label-permuted overlap */
+static int part_mismatch(const astc_fmt* f, int P, int t, uint64_t km[4][3])
+{
+	int O[4][4];
+	for (int a = 0; a < P; ++a)
+		for (int c = 0; c < P; ++c)
+			O[a][c] = popc64(km[a][0] & f->pmask[P - 2][t][c][0]) + popc64(km[a][1] & f->pmask[P - 2][t][c][1]) +
+				popc64(km[a][2] & f->pmask[P - 2][t][c][2]);
+	int best = 0;
+	if (P == 2)
+		best = O[0][0] + O[1][1] > O[0][1] + O[1][0] ? O[0][0] + O[1][1] : O[0][1] + O[1][0];
+	else if (P == 3) {
+		static const uint8_t pm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+		for (int k = 0; k < 6; ++k) {
+			int v = O[0][pm[k][0]] + O[1][pm[k][1]] + O[2][pm[k][2]];
+			if (v > best) best = v;
+		}
+	} else {
+		for (int a = 0; a < 4; ++a)
+			for (int c = 0; c < 4; ++c)
+				for (int d = 0; d < 4; ++d)
+					for (int e = 0; e < 4; ++e) {
+						if (a == c || a == d || a == e || c == d || c == e || d == e)
+							continue;
+						int v = O[0][a] + O[1][c] + O[2][d] + O[3][e];
+						if (v > best) best = v;
+					}
+	}
+	return f->n - best;
+}
+
+/* the `want` best table partitions of P subsets among the first `limit`, by (mismatch, index) */
+static int shortlist(const astc_blk* b, int P, int limit, int want, const float axis[4],
+	const float mean[4], float tmin, float tmax, int* out)
+{
+	const astc_fmt* f = b->f;
+	uint8_t cl[ASTC_MAX_TEXELS];
+	uint64_t km[4][3];
+	kmeans(b, P, axis, mean, tmin, tmax, cl);
+	memset(km, 0, sizeof(km));
+	for (int i = 0; i < b->n; ++i)
+		km[cl[i]][i >> 6] |= 1ull << (i & 63);
+	int np = f->npart[P - 2] < limit ? f->npart[P - 2] : limit;
+	uint32_t key[ASTC_MAX_PARTS];
+	for (int t = 0; t < np; ++t)
+		key[t] = ((uint32_t)part_mismatch(f, P, t, km) << 16) | (uint32_t)t;
+	int got = 0;
+	for (; got < want && got < np; ++got) {
+		int bi = -1;
+		for (int t = 0; t < np; ++t)
+			if (key[t] != 0xFFFFFFFFu && (bi < 0 || key[t] < key[bi]))
+				bi = t;
+		out[got] = (int)(key[bi] & 0xFFFFu);
+		key[bi] = 0xFFFFFFFFu;
+	}
+	return got;
+}
+
+/* quality ladder (stands in for astcenc's presets FASTEST .. EXHAUSTIVE, AstcConverter.cpp:174-195):
+ * configs per candidate, partitions searched, shortlisted 2/3/4-partition candidates, dual planes */
+typedef struct { int K, limit, j2, j3, j4, nd; } astc_ladder;
+static const astc_ladder k_ladder[5] = {
+	{2, 0, 0, 0, 0, 0}, {4, 16, 2, 0, 0, 1}, {4, 32, 3, 2, 0, 2}, {8, 96, 8, 5, 0, 2},
+	{8, 256, 14, 9, 6, 2}};
+
+static void putbits(uint8_t* out, int pos, unsigned v, int n)
+{
+	for (int i = 0; i < n; ++i)
+		if ((v >> i) & 1)
+			out[(pos + i) >> 3] |= (uint8_t)(1u << ((pos + i) & 7));
+}
+
+static void void_extent(const int c[4], uint8_t out[16])
+{
+	static const uint8_t hdr[8] = {0xFC, 0xFD, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF};
+	memcpy(out, hdr, 8);
+	for (int k = 0; k < 4; ++k) {
+		out[8 + 2*k] = (uint8_t)c[k];
+		out[8 + 2*k + 1] = (uint8_t)c[k];
+	}
+}
+
+/* px: bw*bh texels RGBA u8 (swizzled, edge-replicated) */
+void cfo_encode_astc_block(const int px[][4], int bw, int bh, int quality, int flags, uint8_t out[16])
+{
+	const astc_fmt* f = get_fmt(bw, bh);
+	astc_blk* b = (astc_blk*)malloc(sizeof(astc_blk));
+	int n = bw*bh, solid = 1;
+	memset(out, 0, 16);
+	b->f = f; b->n = n; b->flags = flags; b->has_alpha = 0; b->grey = 1;
+	for (int i = 0; i < n; ++i) {
+		memcpy(b->px[i], px[i], sizeof(b->px[i]));
+		if (memcmp(px[i], px[0], 4*sizeof(int)) != 0) solid = 0;
+		if (px[i][3] != 255) b->has_alpha = 1;
+		if (px[i][0] != px[i][1] || px[i][0] != px[i][2]) b->grey = 0;
+		b->wa[i] = (flags & ASTC_FLAG_ALPHA_WEIGHT) ? px[i][3] : 255;
+	}
+	if (solid) {
+		void_extent(px[0], out);
+		free(b);
+		return;
+	}
+	b->nc = b->has_alpha ? 4 : 3;
+	static const int cw_uniform[4] = {1, 1, 1, 1}, cw_perceptual[4] = {11, 21, 4, 16};
+	memcpy(b->cw, (flags & ASTC_FLAG_PERCEPTUAL) ? cw_perceptual : cw_uniform, sizeof(b->cw));
+	int q = quality < 0 ? 0 : (quality > 4 ? 4 : quality);
+	const astc_ladder* lad = &k_ladder[q];
+
+	/* block statistics: principal axis, extremes, the least correlated colour channel */
+	int sum[4] = {0, 0, 0, 0}, SS[4][4];
+	memset(SS, 0, sizeof(SS));
+	for (int i = 0; i < n; ++i)
+		for (int a = 0; a < b->nc; ++a) {
+			sum[a] += px[i][a];
+			for (int c = a; c < b->nc; ++c)
+				SS[a][c] += px[i][a]*px[i][c];
+		}
+	float Cm[4][4], mean[4], axis[4], in = 1.0f/(float)n;
+	for (int a = 0; a < 4; ++a) {
+		mean[a] = (float)sum[a]*in;
+		for (int c = a; c < 4; ++c)
+			Cm[a][c] = (float)(n*SS[a][c] - sum[a]*sum[c]);
+	}
+	float Cd[3] = {Cm[0][0], Cm[1][1], Cm[2][2]}, Co[3] = {Cm[1][2], Cm[0][2], Cm[0][1]};
+	principal_axis(Cm, axis);
+	float tmin = 3.0e38f, tmax = -3.0e38f;
+	for (int i = 0; i < n; ++i) {
+		float t = axis[0]*((float)px[i][0] - mean[0]);
+		t = fmaf(axis[1], (float)px[i][1] - mean[1], t);
+		t = fmaf(axis[2], (float)px[i][2] - mean[2], t);
+		t = fmaf(axis[3], (b->nc == 4 ? (float)px[i][3] : 0.0f) - mean[3], t);
+		tmin = fminf(tmin, t);
+		tmax = fmaxf(tmax, t);
+	}
+	/* channel c's squared correlation with the other two, summed: Co[k] is the covariance of the
+	 * pair that EXCLUDES channel k */
+	int lowc = 0;
+	{
+		float score[3];
+		for (int c = 0; c < 3; ++c) {
+			int o1 = (c + 1) % 3, o2 = (c + 2) % 3;
+			float c1 = Co[o2], c2 = Co[o1];          /* cov(c, o1) excludes o2; cov(c, o2) excludes o1 */
+			float d1 = Cd[c]*Cd[o1], d2 = Cd[c]*Cd[o2];
+			float s1 = d1 > 0.0f ? (c1*c1)/d1 : 1.0f, s2 = d2 > 0.0f ? (c2*c2)/d2 : 1.0f;
+			score[c] = s1 + s2;
+		}
+		for (int c = 1; c < 3; ++c)
+			if (score[c] < score[lowc]) lowc = c;
+	}
+
+	/* the candidate list, in id order */
+	astc_pc pcs[40];
+	int npc = 0;
+	pcs[npc++] = (astc_pc){1, 0, 0, 0, 0};
+	if (lad->nd >= 1) {
+		if (b->has_alpha) pcs[npc++] = (astc_pc){1, 1, 3, 1, 0};
+		else if (lad->nd >= 2 && !b->grey) pcs[npc++] = (astc_pc){1, 1, lowc, 1, 0};
+	}
+	if (lad->nd >= 2 && b->has_alpha && !b->grey)
+		pcs[npc++] = (astc_pc){1, 1, lowc, 1, 0};
+	int sl[16];
+	for (int P = 2; P <= 4; ++P) {
+		int want = P == 2 ? lad->j2 : (P == 3 ? lad->j3 : lad->j4);
+		if (!want)
+			continue;
+		int got = shortlist(b, P, lad->limit, want, axis, mean, tmin, tmax, sl);
+		for (int k = 0; k < got; ++k)
+			pcs[npc++] = (astc_pc){P, 0, 0, P, sl[k]};
+	}
+
+	/* passes of (group size / K) candidates x K configs */
+	int gsz = q <= 2 ? 32 : 64, per_pass = gsz/lad->K;
+	astc_lane best, cur;
+	memset(&best, 0, sizeof(best));
+	best.err = ~0ull;
+	uint32_t best_id = 0xFFFFFFFFu;
+	int best_pc = 0, best_k = 0;
+	for (int base = 0, pass = 0; base < npc; base += per_pass, ++pass) {
+		int cnt = npc - base < per_pass ? npc - base : per_pass;
+		for (int j = 0; j < cnt; ++j) {
+			const astc_pc* pc = &pcs[base + j];
+			int slots = pc->dual ? 2 : pc->P;
+			for (int s = 0; s < slots; ++s)
+				phase_a(b, j, pc, s);
+		}
+		if (pass == 0)
+			for (int g = 0; g < f->ngrids; ++g)
+				b->edec[g] = grid_decimation_error(b, g);
+		for (int j = 0; j < cnt; ++j) {
+			const astc_pc* pc = &pcs[base + j];
+			int order[ASTC_MAX_CFG];
+			int nk = rank_configs(b, j, pc, lad->K, order);
+			for (int k = 0; k < nk; ++k) {
+				phase_b(b, j, pc, &f->cfg[pc->cls][b->has_alpha][order[k]], &cur);
+				uint32_t id = (uint32_t)(pass*64 + j*lad->K + k);
+				if (cur.valid && (cur.err < best.err || (cur.err == best.err && id < best_id))) {
+					best = cur;
+					best_id = id;
+					best_pc = base + j;
+					best_k = order[k];
+				}
+			}
+		}
+	}
+	if (best_id == 0xFFFFFFFFu) {
+		int c[4];
+		for (int k = 0; k < 4; ++k)
+			c[k] = (2*sum[k] + n)/(2*n);
+		if (b->nc == 3) c[3] = 255;
+		void_extent(c, out);
+		free(b);
+		return;
+	}
+	/* pack */
+	const astc_pc* pc = &pcs[best_pc];
+	const astc_cfg* cfg = &f->cfg[pc->cls][b->has_alpha][best_k];
+	putbits(out, 0, cfg->mode, 11);
+	putbits(out, 11, (unsigned)(pc->P - 1), 2);
+	int cstart;
+	if (pc->P == 1) {
+		putbits(out, 13, (unsigned)best.cem, 4);
+		cstart = 17;
+	} else {
+		putbits(out, 13, f->pseed[pc->P - 2][pc->tab], 10);
+		putbits(out, 23, 0, 2);
+		putbits(out, 25, (unsigned)best.cem, 4);
+		cstart = 29;
+	}
+	astc_ise_encode(&astc_cq[best.lv], best.cvals, best.ncv, out, cstart);
+	if (pc->dual)
+		putbits(out, 128 - cfg->wbits - 2, (unsigned)pc->ccs, 2);
+	uint8_t ws[16];
+	memset(ws, 0, sizeof(ws));
+	astc_ise_encode(&astc_wq[cfg->wq], best.wq, cfg->nw, ws, 0);
+	for (int i = 0; i < cfg->wbits; ++i)
+		if ((ws[i >> 3] >> (i & 7)) & 1)
+			out[(127 - i) >> 3] |= (uint8_t)(1u << ((127 - i) & 7));
+	free(b);
+}

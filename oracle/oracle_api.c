@@ -24,7 +24,7 @@ int cfo_encode_etc_block(const float rgbaf[64], const uint8_t rgba[64], unsigned
 	uint8_t* out, const cfo_params* p);
 void cfo_decode_etc_rgb(const uint8_t* blk, int a1, uint8_t* rgba64);
 int cfo_astc_footprint(int format, int* bw, int* bh);
-void cfo_encode_astc_block(const int px[][4], int bw, int bh, int quality, uint8_t out[16]);
+void cfo_encode_astc_block(const int px[][4], int bw, int bh, int quality, int flags, uint8_t out[16]);
 int cfo_decode_astc_block(const uint8_t* blk, int bw, int bh, uint8_t* rgba);
 void cfo_decode_eac(const uint8_t* blk, int kind, int* out16);
 int cfo_decode_bc6h(const uint8_t* blk, int flags, uint16_t* rgb48);
@@ -161,7 +161,10 @@ static void* worker(void* arg)
 					else if (j->p->alpha == 0) o[3] = 255;
 				}
 			}
-			cfo_encode_astc_block((const int (*)[4])apx, (int)j->bw, (int)j->bh, j->p->quality, dst);
+			/* ASTCENC_FLG_USE_ALPHA_WEIGHT for Alpha::Standard / PreMultiplied, USE_PERCEPTUAL for
+			 * sRGB images (AstcConverter.cpp:163-172) */
+			int aflags = ((j->p->alpha == 1 || j->p->alpha == 2) ? 1 : 0) | (j->p->color_space == 1 ? 2 : 0);
+			cfo_encode_astc_block((const int (*)[4])apx, (int)j->bw, (int)j->bh, j->p->quality, aflags, dst);
 			continue;
 		}
 		float f[64];
