@@ -1,6 +1,6 @@
-"""ASTC oracle (restricted LDR subset): structural checks against the public specification,
-self-consistent decode, footprints, swizzle and quality ladder.  No independent ASTC decoder
-exists in this environment -- parity for ASTC is self-consistency only."""
+"""ASTC oracle encoder: size contract, structural checks against the public specification,
+footprints, swizzle, flags and quality ladder.  The decoder used here is itself pinned to Mesa's
+independent ASTC decoder (tests/test_oracle_mesa.py), which also decodes this encoder's output."""
 import numpy as np
 import pytest
 
@@ -20,7 +20,7 @@ def test_payload_size_and_self_decode_all_footprints(fmt):
     assert blk.nbytes == ((50 + bw - 1) // bw) * ((38 + bh - 1) // bh) * 16
     dec, bad = O.decode_astc(blk, fmt, 50, 38)
     assert bad == 0
-    assert synth.psnr(img, dec, slice(0, 3)) > 30.0
+    assert synth.psnr(img, dec, slice(0, 3)) > (34.0 if bw*bh <= 48 else 29.0)
 
 
 def test_solid_blocks_are_void_extent_per_spec():
@@ -38,22 +38,52 @@ def test_solid_blocks_are_void_extent_per_spec():
     assert bad == 0 and (dec[..., 1] == 128).all() and (dec[..., 3] == 255).all()
 
 
-def test_block_header_fields():
-    """Non-constant blocks: single partition (bits 11-12 = 0), CEM 8 for opaque / 12 for alpha
-    (bits 13-16), and the endpoint sum rule that avoids blue contraction (s1 >= s0)."""
-    img = synth.photo(48, 48, seed=5, alpha=True)
-    blk = O.encode(img, 47, quality=2, threads=4).reshape(-1, 16)
-    lo = blk[:, 0].astype(np.uint32) | (blk[:, 1].astype(np.uint32) << 8) | (blk[:, 2].astype(np.uint32) << 16)
-    nonvoid = (lo & 0x1FF) != 0x1FC
-    assert nonvoid.any()
-    parts = (lo >> 11) & 3
-    cem = (lo >> 13) & 15
-    assert (parts[nonvoid] == 0).all()
-    assert set(np.unique(cem[nonvoid])) <= {8, 12} and 12 in cem and 8 in cem
-    for b in blk[nonvoid][:64]:
-        bits = int.from_bytes(bytes(b), "little")
-        v = [(bits >> (17 + 8 * i)) & 255 for i in range(6)]
-        assert v[1] + v[3] + v[5] >= v[0] + v[2] + v[4]
+def test_block_header_fields_and_features_in_use():
+    """Non-constant blocks: legal partition counts, the endpoint modes this encoder emits
+    (0/4 luminance, 6/10 base + scale, 8/12 direct), and -- on content with hard edges, an alpha
+    band and smooth areas -- multi-partition blocks, dual-plane blocks and trit / quint weight
+    ranges are all actually chosen."""
+    img = synth.photo(144, 144, seed=5, alpha=True)
+    blk = O.encode(img, 47, quality=3, threads=8).reshape(-1, 16)
+    dec, bad = O.decode_astc(blk.reshape(-1), 47, 144, 144)
+    assert bad == 0
+    parts = np.zeros(5, int)
+    cems, dual, triq = set(), 0, 0
+    for b in blk:
+        v = int.from_bytes(bytes(b), "little")
+        if (v & 0x1FF) == 0x1FC:
+            continue
+        p = ((v >> 11) & 3) + 1
+        parts[p] += 1
+        cems.add((v >> 13) & 15 if p == 1 else (v >> 25) & 15)
+        if p > 1:
+            assert (v >> 23) & 3 == 0                       # one endpoint mode for all partitions
+        if (v & 3) or ((v >> 7) & 3) != 2:
+            dual += (v >> 10) & 1
+        r = ((v >> 4) & 1) | (((v & 3) if v & 3 else (v >> 2) & 3) << 1)
+        triq += r in (3, 5, 6)
+    assert cems <= {0, 4, 6, 8, 10, 12} and len(cems) >= 3
+    assert parts[1] > 0 and parts[2] > 0 and parts[3] > 0 and parts[4] == 0
+    assert dual > 0 and triq > 0
+
+
+def test_alpha_weight_and_perceptual_flags_change_the_search():
+    """ASTCENC_FLG_USE_ALPHA_WEIGHT (Alpha::Standard / PreMultiplied) and USE_PERCEPTUAL (sRGB),
+    AstcConverter.cpp:163-172: transparent texels stop constraining RGB; luma-weighted channels."""
+    img = synth.photo(72, 72, seed=8, alpha=True)
+    img[12:40, 12:60, 3] = 0
+    a = O.encode(img, 47, quality=2, threads=4, alpha=1)     # Standard: alpha-weighted
+    b = O.encode(img, 47, quality=2, threads=4, alpha=3)     # Encoded: plain RGBA error
+    c = O.encode(img, 47, quality=2, threads=4, alpha=3, color_space=1)
+    assert not np.array_equal(a, b) and not np.array_equal(b, c)
+    da, _ = O.decode_astc(a, 47, 72, 72)
+    db, _ = O.decode_astc(b, 47, 72, 72)
+
+    def weighted(d):      # the alpha-weighted metric: texel alpha scales its RGB error
+        e = (d.astype(np.int64) - img)**2
+        return int((e[..., :3].sum(-1)*img[..., 3]).sum() + 255*e[..., 3].sum())
+    # both searches walk the same candidates; the flag only changes which one wins
+    assert weighted(da) <= weighted(db)
 
 
 def test_quality_ladder_6x6():
@@ -64,7 +94,7 @@ def test_quality_ladder_6x6():
         p = synth.psnr(img, dec, slice(0, 3))
         assert bad == 0 and p >= last - 1e-9
         last = p
-    assert last > 42.0
+    assert last > 43.0
 
 
 def test_swizzle_from_color_mask_and_alpha_type():
