@@ -26,6 +26,8 @@
 // accumulators and quantised weights ([row][lane], conflict-free for a fixed row).
 #include "cf_device.h"
 #include "astc_tables.h"
+#include <cstdio>
+#include <cstdlib>
 
 using cfastc::AstcBlobHeader;
 using cfastc::AstcCfgRec;
@@ -77,8 +79,11 @@ struct Cov { float c00, c01, c02, c03, c11, c12, c13, c22, c23, c33; };
 __device__ __forceinline__ void principal_axis(const Cov& C, float (&axis)[4])
 {
 	float bestd = C.c00, v0 = C.c00, v1 = C.c01, v2 = C.c02, v3 = C.c03;
+	// (the empty asm keeps the compiler from turning this chain into an indexed table in scratch)
 	if (C.c11 > bestd) { bestd = C.c11; v0 = C.c01; v1 = C.c11; v2 = C.c12; v3 = C.c13; }
+	asm volatile("" : "+v"(bestd));
 	if (C.c22 > bestd) { bestd = C.c22; v0 = C.c02; v1 = C.c12; v2 = C.c22; v3 = C.c23; }
+	asm volatile("" : "+v"(bestd));
 	if (C.c33 > bestd) { bestd = C.c33; v0 = C.c03; v1 = C.c13; v2 = C.c23; v3 = C.c33; }
 #pragma unroll
 	for (int it = 0; it < 3; ++it) {
@@ -136,6 +141,9 @@ struct Slot {
 	uint32_t* e0;      // [32]
 	uint32_t* e1;      // [32]
 	uint32_t* span;    // [32]
+	uint32_t* sum01;   // [32] slot sums r | g << 16 (masked channels zero)
+	uint32_t* sum23;   // [32] b | a << 16
+	uint32_t* scnt;    // [32] texels of the slot
 	uint32_t* edec;    // [32]
 	uint8_t* order;    // [8][8]
 	uint32_t* pcs;     // [40]
@@ -205,12 +213,15 @@ __device__ __forceinline__ bool cem_option(const Shared& sh, int o, uint32_t lv,
 		if (ed >= 3.0e38f && ec >= 3.0e38f)
 			return false;
 		const bool contract = ec < ed;
+		const uint32_t cm = contract ? 0xFFFFFFFFu : 0u;
 #pragma unroll
 		for (int c = 0; c < 3; ++c) {
-			d0[c] = contract ? c0[c] : dd0[c];
-			d1[c] = contract ? c1[c] : dd1[c];
-			vals[2*c] = contract ? sc[2*c] : st[2*c];
-			vals[2*c + 1] = contract ? sc[2*c + 1] : st[2*c + 1];
+			// (mask arithmetic, not selects: a select between elements of two local arrays ends up
+			// as an indexed access in scratch)
+			d0[c] = dd0[c] ^ ((dd0[c] ^ c0[c]) & (int)cm);
+			d1[c] = dd1[c] ^ ((dd1[c] ^ c1[c]) & (int)cm);
+			vals[2*c] = st[2*c] ^ ((st[2*c] ^ sc[2*c]) & cm);
+			vals[2*c + 1] = st[2*c + 1] ^ ((st[2*c + 1] ^ sc[2*c + 1]) & cm);
 		}
 		est += contract ? ec : ed;
 		if (has_alpha) {
@@ -348,8 +359,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	uint8_t* sh_grid = lds + off; off += (ngrids*4u + 15u) & ~15u;
 	uint8_t* sh_ctab = lds + off; off += 2u*17u*256u;
 	uint8_t* sh_wtab = lds + off; off += 1216u;
-	const uint32_t slot_bytes = ((8u*2u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*4u + 64u + 40u*4u + 28u*4u;
-	const uint32_t wave_bytes = ((col_rows*128u + wc_rows*256u + 15u) & ~15u) + 2u*slot_bytes;
+	const uint32_t slot_bytes = ((8u*2u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
+	const uint32_t wave_bytes = ((((col_rows + 1u)/2u)*256u + wc_rows*256u + 15u) & ~15u) + (kp.quality <= 2u ? 2u : 1u)*slot_bytes;
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	uint8_t* wbase = lds + off + wave*wave_bytes;
 
@@ -398,9 +409,13 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	const AstcCfgRec* cfgs = reinterpret_cast<const AstcCfgRec*>(blob + H->off_cfg);
 	const uint8_t* ncfgs = blob + H->off_ncfg;
 
-	uint16_t* col = reinterpret_cast<uint16_t*>(wbase) + lane;                 // row r: col[r*64]
-	uint32_t* wcache = reinterpret_cast<uint32_t*>(wbase + col_rows*128u) + lane;   // row r: wcache[r*64]
-	uint8_t* slot0 = wbase + ((col_rows*128u + wc_rows*256u + 15u) & ~15u);
+	// a lane's grid column: row r is the (r & 1) half of 32-bit word [r >> 1][lane] -- a wave-level
+	// access then touches 32 consecutive banks per half-wave whatever rows the lanes address
+	// (with 16-bit elements [row][lane] two lanes share a bank and conflict when their rows differ)
+	uint16_t* colb = reinterpret_cast<uint16_t*>(wbase) + lane*2u;
+#define COLR(r) colb[((r) >> 1)*128u + ((r) & 1u)]
+	uint32_t* wcache = reinterpret_cast<uint32_t*>(wbase + ((col_rows + 1u)/2u)*256u) + lane;   // row r: wcache[r*64]
+	uint8_t* slot0 = wbase + ((((col_rows + 1u)/2u)*256u + wc_rows*256u + 15u) & ~15u);
 
 	const uint32_t q = kp.quality > 4u ? 4u : kp.quality;
 	const Ladder lad = ladder(q);
@@ -424,8 +439,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			S.T = sp; S.pid = sp + 16u*npad;
 			uint32_t* w32 = reinterpret_cast<uint32_t*>(sp + ((24u*npad + 15u) & ~15u));
 			S.e0 = w32; S.e1 = w32 + 32; S.span = w32 + 64; S.edec = w32 + 96;
-			S.order = reinterpret_cast<uint8_t*>(w32 + 128);
-			S.pcs = w32 + 144; S.best = w32 + 184;
+			S.sum01 = w32 + 128; S.sum23 = w32 + 160; S.scnt = w32 + 192;
+			S.order = reinterpret_cast<uint8_t*>(w32 + 224);
+			S.pcs = w32 + 240; S.best = w32 + 280;
 		}
 
 		// ---- block statistics (texels strided over the group) ----
@@ -506,8 +522,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				const float s1 = d1 > 0.0f ? (c1*c1)/d1 : 1.0f, s2 = d2 > 0.0f ? (c2*c2)/d2 : 1.0f;
 				score[c] = s1 + s2;
 			}
-			if (score[1] < score[lowc]) lowc = 1;
-			if (score[2] < score[lowc]) lowc = 2;
+			float sbest = score[0];
+			if (score[1] < sbest) { sbest = score[1]; lowc = 1; }
+			if (score[2] < sbest) lowc = 2;
 		}
 
 		// ---- candidate list (ids as in the oracle) ----
@@ -728,7 +745,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					Cs.c13 = (float)(cnt_t*q13 - a1*a3); Cs.c22 = (float)(cnt_t*q22 - a2*a2);
 					Cs.c23 = (float)(cnt_t*q23 - a2*a3); Cs.c33 = (float)(cnt_t*q33 - a3*a3);
 					const float ic = 1.0f/(float)cnt_t;
-					const float mn[4] = {(float)a0*ic, (float)a1*ic, (float)a2*ic, (float)a3*ic};
+					float mn[4];
+					mn[0] = (float)a0*ic; mn[1] = (float)a1*ic; mn[2] = (float)a2*ic; mn[3] = (float)a3*ic;
 					float ax[4];
 					principal_axis(Cs, ax);
 					float lo_t = 3.0e38f, hi_t = -3.0e38f;
@@ -790,6 +808,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					const uint32_t pe1 = (uint32_t)e1[0] | ((uint32_t)e1[1] << 8) | ((uint32_t)e1[2] << 16) | ((uint32_t)e1[3] << 24);
 					S.e0[hl] = pe0;
 					S.e1[hl] = pe1;
+					S.sum01[hl] = (uint32_t)a0 | ((uint32_t)a1 << 16);
+					S.sum23[hl] = (uint32_t)a2 | ((uint32_t)a3 << 16);
+					S.scnt[hl] = (uint32_t)cnt_t;
 				}
 			}
 			__builtin_amdgcn_wave_barrier();
@@ -802,27 +823,27 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					const uint32_t* inf = sh.infill + g*n;
 					const uint8_t* Trow = S.T;
 					for (uint32_t r = 0; r < ng + N + 2u; ++r)
-						col[r*64u] = 0;
+						COLR(r) = 0;
 #pragma unroll 1
 					for (uint32_t i = 0; i < n; ++i) {
 						const uint32_t rec = inf[i], T = Trow[i];
 						const uint32_t g0 = rec & 255u, f00 = (rec >> 8) & 31u, f01 = (rec >> 13) & 31u, f10 = (rec >> 18) & 31u, f11 = rec >> 23;
-						const uint32_t v0 = col[g0*64u], v1 = col[(g0 + 1u)*64u], v2 = col[(g0 + N)*64u], v3 = col[(g0 + N + 1u)*64u];
-						col[g0*64u] = (uint16_t)(v0 + f00*T);
-						col[(g0 + 1u)*64u] = (uint16_t)(v1 + f01*T);
-						col[(g0 + N)*64u] = (uint16_t)(v2 + f10*T);
-						col[(g0 + N + 1u)*64u] = (uint16_t)(v3 + f11*T);
+						const uint32_t v0 = COLR(g0), v1 = COLR(g0 + 1u), v2 = COLR(g0 + N), v3 = COLR(g0 + N + 1u);
+						COLR(g0) = (uint16_t)(v0 + f00*T);
+						COLR(g0 + 1u) = (uint16_t)(v1 + f01*T);
+						COLR(g0 + N) = (uint16_t)(v2 + f10*T);
+						COLR(g0 + N + 1u) = (uint16_t)(v3 + f11*T);
 					}
 					for (uint32_t r = 0; r < ng; ++r) {
 						const uint32_t den = sh.den[g*64u + r];
-						col[r*64u] = (uint16_t)(den ? div_small((uint32_t)col[r*64u] + den/2u, den, 1.0f/(float)den) : 0u);
+						COLR(r) = (uint16_t)(den ? div_small((uint32_t)COLR(r) + den/2u, den, 1.0f/(float)den) : 0u);
 					}
 					uint32_t e = 0;
 #pragma unroll 1
 					for (uint32_t i = 0; i < n; ++i) {
 						const uint32_t rec = inf[i];
 						const uint32_t g0 = rec & 255u, f00 = (rec >> 8) & 31u, f01 = (rec >> 13) & 31u, f10 = (rec >> 18) & 31u, f11 = rec >> 23;
-						const uint32_t acc = 8u + f00*col[g0*64u] + f01*col[(g0 + 1u)*64u] + f10*col[(g0 + N)*64u] + f11*col[(g0 + N + 1u)*64u];
+						const uint32_t acc = 8u + f00*COLR(g0) + f01*COLR(g0 + 1u) + f10*COLR(g0 + N) + f11*COLR(g0 + N + 1u);
 						const int dgt = (int)(acc >> 4) - (int)Trow[i];
 						e += (uint32_t)(dgt*dgt);
 					}
@@ -843,25 +864,26 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				const unsigned long long span2 = ((unsigned long long)spn*recip_n) >> 16;
 				const uint32_t ncfg = jact ? ncfgs[cls*2u + alpha_i] : 0u;
 				const AstcCfgRec* list = cfgs + (cls*2u + alpha_i)*64u;
-				unsigned long long key[2];
+				// keys: (estimate >> 8, clamped to 26 bits) << 6 | list index
+				uint32_t key[2];
 #pragma unroll
 				for (uint32_t m = 0; m < 2u; ++m) {
 					const uint32_t k = hl + gsz*m;
-					key[m] = ~0ull;
+					key[m] = 0xFFFFFFFFu;
 					if (k < ncfg && k < 64u) {
 						const AstcCfgRec c = list[k];
 						const unsigned long long wn = (unsigned long long)S.edec[c.grid]*40ull + (unsigned long long)(n*c.wq16);
-						const unsigned long long est = ((span2*wn) >> 12) + (unsigned long long)(n*nc)*c.cq16;
-						key[m] = (est << 8) | k;
+						const unsigned long long est = (((span2*wn) >> 12) + (unsigned long long)(n*nc)*c.cq16) >> 8;
+						key[m] = ((est > 0x3FFFFFEull ? 0x3FFFFFEu : (uint32_t)est) << 6) | k;
 					}
 				}
 				for (uint32_t it = 0; it < K; ++it) {
-					const unsigned long long mk = key[0] < key[1] ? key[0] : key[1];
-					const unsigned long long gmin = cf_group_min_u64(mk, pair, h);
-					key[0] = key[0] == gmin ? ~0ull : key[0];
-					key[1] = key[1] == gmin ? ~0ull : key[1];
+					const uint32_t mk = key[0] < key[1] ? key[0] : key[1];
+					const uint32_t gmin = cf_group_min_u32(mk, pair, h);
+					key[0] = key[0] == gmin ? 0xFFFFFFFFu : key[0];
+					key[1] = key[1] == gmin ? 0xFFFFFFFFu : key[1];
 					if (hl == 0u && jact)
-						S.order[j*8u + it] = gmin == ~0ull ? (uint8_t)255 : (uint8_t)(gmin & 255ull);
+						S.order[j*8u + it] = gmin == 0xFFFFFFFFu ? (uint8_t)255 : (uint8_t)(gmin & 63u);
 				}
 			}
 			__builtin_amdgcn_wave_barrier();
@@ -886,7 +908,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				if (active) {
 					// 1. decimate + quantise (slots: unquantised | quantised << 8)
 					for (uint32_t r = 0; r < (ng + N + 2u)*planes; ++r)
-						col[r*64u] = 0;
+						COLR(r) = 0;
 #pragma unroll 1
 					for (uint32_t pl = 0; pl < planes; ++pl) {
 						const uint8_t* Trow = S.T + (j*2u + pl)*npad;
@@ -894,12 +916,12 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						for (uint32_t i = 0; i < n; ++i) {
 							const uint32_t rec = inf[i], T = Trow[i];
 							const uint32_t g0 = rec & 255u, f00 = (rec >> 8) & 31u, f01 = (rec >> 13) & 31u, f10 = (rec >> 18) & 31u, f11 = rec >> 23;
-							const uint32_t i0 = (g0*planes + pl)*64u, i1 = i0 + planes*64u, i2 = i0 + N*planes*64u, i3 = i2 + planes*64u;
-							const uint32_t v0 = col[i0], v1 = col[i1], v2 = col[i2], v3 = col[i3];
-							col[i0] = (uint16_t)(v0 + f00*T);
-							col[i1] = (uint16_t)(v1 + f01*T);
-							col[i2] = (uint16_t)(v2 + f10*T);
-							col[i3] = (uint16_t)(v3 + f11*T);
+							const uint32_t i0 = g0*planes + pl, i1 = i0 + planes, i2 = i0 + N*planes, i3 = i2 + planes;
+							const uint32_t v0 = COLR(i0), v1 = COLR(i1), v2 = COLR(i2), v3 = COLR(i3);
+							COLR(i0) = (uint16_t)(v0 + f00*T);
+							COLR(i1) = (uint16_t)(v1 + f01*T);
+							COLR(i2) = (uint16_t)(v2 + f10*T);
+							COLR(i3) = (uint16_t)(v3 + f11*T);
 						}
 					}
 					for (uint32_t g = 0; g < ng; ++g) {
@@ -907,30 +929,20 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						const float rd = 1.0f/(float)dn;
 #pragma unroll 1
 						for (uint32_t pl = 0; pl < planes; ++pl) {
-							const uint32_t gi = dn ? div_small((uint32_t)col[(g*planes + pl)*64u] + dn/2u, dn, rd) : 0u;
+							const uint32_t gi = dn ? div_small((uint32_t)COLR(g*planes + pl) + dn/2u, dn, rd) : 0u;
 							const uint32_t qv = sh.wnear[wq*68u + gi];
-							col[(g*planes + pl)*64u] = (uint16_t)((uint32_t)sh.wunq[wq*32u + qv] | (qv << 8));
+							COLR(g*planes + pl) = (uint16_t)((uint32_t)sh.wunq[wq*32u + qv] | (qv << 8));
 						}
 					}
 					// 2. + 3. texel weights and the least-squares sums per set (subset, or plane)
 					const uint32_t nset = dual ? 2u : P;
-					uint32_t Ssum[4] = {0, 0, 0, 0}, A[4] = {0, 0, 0, 0}, Bm[4] = {0, 0, 0, 0}, Cc[4] = {0, 0, 0, 0}, cn[4] = {0, 0, 0, 0};
-					uint32_t U[4][4], V[4][4];
-#pragma unroll
-					for (int a = 0; a < 4; ++a)
-#pragma unroll
-						for (int c = 0; c < 4; ++c) { U[a][c] = 0; V[a][c] = 0; }
-					// channels a set fits: all of them for subsets; for planes, ccs <-> the others
-					uint32_t keep[4];
-#pragma unroll
-					for (uint32_t st = 0; st < 4u; ++st) {
-						uint32_t m = nc == 4u ? 0xFFFFFFFFu : 0x00FFFFFFu;
-						if (dual) {
-							const uint32_t cb = 0xFFu << (8u*ccs);
-							m = st == 1u ? (m & cb) : (m & ~cb);
-						}
-						keep[st] = m;
-					}
+					// per set only S = sum w, C = sum w^2 and V_c = sum w p_c are accumulated: with the
+					// slot's texel count and channel sums from phase A, A = sum (64-w)^2 = 4096 cnt - 128 S + C,
+					// B = sum (64-w) w = 64 S - C and U_c = sum (64-w) p_c = 64 sum p_c - V_c (exact integers)
+					// (named scalars per set, not arrays: selecting among array elements by a run-time set
+					// index makes the compiler keep the arrays in scratch)
+					struct SetAcc { uint32_t S, C, V0, V1, V2, V3, cn, p01, p23; };
+					SetAcc q0 = {0, 0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;
 					uint32_t wpack0 = 0, wpack1 = 0;
 #pragma unroll 1
 					for (uint32_t i = 0; i < n; ++i) {
@@ -938,11 +950,11 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						const uint32_t g0 = rec & 255u, f00 = (rec >> 8) & 31u, f01 = (rec >> 13) & 31u, f10 = (rec >> 18) & 31u, f11 = rec >> 23;
 						uint32_t wA, wB;
 						{
-							const uint32_t i0 = (g0*planes)*64u, i1 = i0 + planes*64u, i2 = i0 + N*planes*64u, i3 = i2 + planes*64u;
-							wA = (8u + f00*(col[i0] & 255u) + f01*(col[i1] & 255u) + f10*(col[i2] & 255u) + f11*(col[i3] & 255u)) >> 4;
+							const uint32_t i0 = g0*planes, i1 = i0 + planes, i2 = i0 + N*planes, i3 = i2 + planes;
+							wA = (8u + f00*(COLR(i0) & 255u) + f01*(COLR(i1) & 255u) + f10*(COLR(i2) & 255u) + f11*(COLR(i3) & 255u)) >> 4;
 							wB = wA;
 							if (dual)
-								wB = (8u + f00*(col[i0 + 64u] & 255u) + f01*(col[i1 + 64u] & 255u) + f10*(col[i2 + 64u] & 255u) + f11*(col[i3 + 64u] & 255u)) >> 4;
+								wB = (8u + f00*(COLR(i0 + 1u) & 255u) + f01*(COLR(i1 + 1u) & 255u) + f10*(COLR(i2 + 1u) & 255u) + f11*(COLR(i3 + 1u) & 255u)) >> 4;
 						}
 						if (wcached) {
 							wpack0 |= wA << (8u*(i & 3u));
@@ -955,134 +967,114 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						}
 						const uint32_t p = tp[i];
 						const uint32_t part = byp ? 0u : prow[i];
-#pragma unroll
-						for (uint32_t st = 0; st < 4u; ++st) {
-							if (st < nset) {
-								const uint32_t member = dual ? 1u : (part == st ? 1u : 0u);
-								const uint32_t wi = (dual && st == 1u) ? wB : wA, iw = 64u - wi;
-								const uint32_t wm = wi*member, iwm = iw*member;
-								Ssum[st] += wm; A[st] += iwm*iw; Bm[st] += iwm*wi; Cc[st] += wm*wi; cn[st] += member;
-								const uint32_t pk = p & keep[st];
-#pragma unroll
-								for (uint32_t c = 0; c < 4u; ++c) {
-									const uint32_t pc_ = (pk >> (8u*c)) & 255u;
-									U[st][c] += iwm*pc_;
-									V[st][c] += wm*pc_;
-								}
-							}
-						}
+						const uint32_t pc0_ = p & 255u, pc1_ = (p >> 8) & 255u, pc2_ = (p >> 16) & 255u, pc3_ = p >> 24;
+#define ASTC_ACC(Q, ST) if (ST < nset) { \
+							const uint32_t wi = (dual && ST == 1u) ? wB : wA; \
+							const uint32_t wm = dual ? wi : (part == ST ? wi : 0u); \
+							Q.S += wm; Q.C += wm*wi; \
+							Q.V0 += wm*pc0_; Q.V1 += wm*pc1_; Q.V2 += wm*pc2_; Q.V3 += wm*pc3_; }
+						ASTC_ACC(q0, 0u) ASTC_ACC(q1, 1u) ASTC_ACC(q2, 2u) ASTC_ACC(q3, 3u)
+#undef ASTC_ACC
 					}
-					// least-squares endpoints: r0/r1[subset][channel]; fA/fB/fC per (subset, channel)
-					float r0[4][4], r1[4][4], fAs[4], fBs[4], fCs[4], invs[4];
-					bool dets[4];
-#pragma unroll
-					for (uint32_t st = 0; st < 4u; ++st) {
-						const int det = (int)(cn[st]*Cc[st]) - (int)(Ssum[st]*Ssum[st]);
-						fAs[st] = (float)A[st]; fBs[st] = (float)Bm[st]; fCs[st] = (float)Cc[st];
-						dets[st] = st < nset && det > 0;
-						invs[st] = dets[st] ? 1.0f/(64.0f*(float)det) : 0.0f;
-					}
-#pragma unroll
-					for (uint32_t sub = 0; sub < 4u; ++sub) {
+					// texel count and channel sums of every set: the subset's slot, or (dual) the whole
+					// block = the OR of the two planes' masked sums
+#define ASTC_SETSUM(Q, ST) { \
+						const uint32_t sl = (j*4u + (dual ? 0u : ST)) & 31u; \
+						Q.cn = ST < nset ? S.scnt[sl] : 0u; \
+						Q.p01 = S.sum01[sl]; Q.p23 = S.sum23[sl]; \
+						if (dual) { Q.p01 |= S.sum01[(sl + 1u) & 31u]; Q.p23 |= S.sum23[(sl + 1u) & 31u]; } }
+					ASTC_SETSUM(q0, 0u) ASTC_SETSUM(q1, 1u) ASTC_SETSUM(q2, 2u) ASTC_SETSUM(q3, 3u)
+#undef ASTC_SETSUM
+#define SEL4(i, a0, a1, a2, a3) ((i) == 0u ? (a0) : ((i) == 1u ? (a1) : ((i) == 2u ? (a2) : (a3))))
+					// least-squares endpoints of partition p, one partition at a time (nothing but the
+					// sums stays live across partitions): channel c fits with set st = p, or its plane
+					auto solve = [&](uint32_t p, float (&r0)[4], float (&r1)[4], float (&cA)[4], float (&cB)[4], float (&cC)[4]) __attribute__((always_inline)) {
 #pragma unroll
 						for (uint32_t c = 0; c < 4u; ++c) {
-							const uint32_t st = dual ? (c == ccs ? 1u : 0u) : sub;
-							// ideal endpoints of phase A: subset `sub` (dual: planes 0 and 1 of subset 0)
-							const uint32_t slot_i = j*4u + (dual ? (c == ccs ? 1u : 0u) : sub);
-							const float i0 = (float)((S.e0[slot_i & 31u] >> (8u*c)) & 255u), i1 = (float)((S.e1[slot_i & 31u] >> (8u*c)) & 255u);
-							float a = i0, bq = i1;
-							// select the set's sums without dynamic register indexing
-							const float sA = st == 0u ? fAs[0] : (st == 1u ? fAs[1] : (st == 2u ? fAs[2] : fAs[3]));
-							const float sB = st == 0u ? fBs[0] : (st == 1u ? fBs[1] : (st == 2u ? fBs[2] : fBs[3]));
-							const float sC = st == 0u ? fCs[0] : (st == 1u ? fCs[1] : (st == 2u ? fCs[2] : fCs[3]));
-							const float si = st == 0u ? invs[0] : (st == 1u ? invs[1] : (st == 2u ? invs[2] : invs[3]));
-							const bool sd = st == 0u ? dets[0] : (st == 1u ? dets[1] : (st == 2u ? dets[2] : dets[3]));
-							const uint32_t uu = st == 0u ? U[0][c] : (st == 1u ? U[1][c] : (st == 2u ? U[2][c] : U[3][c]));
-							const uint32_t vv = st == 0u ? V[0][c] : (st == 1u ? V[1][c] : (st == 2u ? V[2][c] : V[3][c]));
-							if (sd) {
-								const float fU = (float)uu, fV = (float)vv;
-								const float t0 = sB*fV;
-								const float n0 = fmaf(sC, fU, -t0);
-								const float t1 = sB*fU;
-								const float n1 = fmaf(sA, fV, -t1);
-								a = clampf255(n0*si);
-								bq = clampf255(n1*si);
+							const uint32_t st = dual ? (c == ccs ? 1u : 0u) : p;
+							const uint32_t Ss = SEL4(st, q0.S, q1.S, q2.S, q3.S), Cs = SEL4(st, q0.C, q1.C, q2.C, q3.C);
+							const uint32_t Vc = c == 0u ? SEL4(st, q0.V0, q1.V0, q2.V0, q3.V0) : (c == 1u ? SEL4(st, q0.V1, q1.V1, q2.V1, q3.V1) :
+								(c == 2u ? SEL4(st, q0.V2, q1.V2, q2.V2, q3.V2) : SEL4(st, q0.V3, q1.V3, q2.V3, q3.V3)));
+							const uint32_t cnt_s = SEL4(st, q0.cn, q1.cn, q2.cn, q3.cn);
+							const uint32_t ps = c < 2u ? SEL4(st, q0.p01, q1.p01, q2.p01, q3.p01) : SEL4(st, q0.p23, q1.p23, q2.p23, q3.p23);
+							const uint32_t sumP = (c & 1u) ? ps >> 16 : ps & 0xFFFFu;
+							const uint32_t Aq = 4096u*cnt_s - 128u*Ss + Cs, Bq = 64u*Ss - Cs, Uq = 64u*sumP - Vc;
+							const int det = (int)(cnt_s*Cs) - (int)(Ss*Ss);
+							cA[c] = (float)Aq; cB[c] = (float)Bq; cC[c] = (float)Cs;
+							// ideal endpoints of phase A: subset p (dual: planes 0 and 1 of subset 0)
+							const uint32_t slot_i = (j*4u + (dual ? (c == ccs ? 1u : 0u) : p)) & 31u;
+							float a = (float)((S.e0[slot_i] >> (8u*c)) & 255u), bq = (float)((S.e1[slot_i] >> (8u*c)) & 255u);
+							if (det > 0) {
+								const float inv = 1.0f/(64.0f*(float)det);
+								const float fU = (float)Uq, fV = (float)Vc;
+								const float t0 = cB[c]*fV;
+								const float n0 = fmaf(cC[c], fU, -t0);
+								const float t1 = cB[c]*fU;
+								const float n1 = fmaf(cA[c], fV, -t1);
+								a = clampf255(n0*inv);
+								bq = clampf255(n1*inv);
 							}
 							if (c == 3u && nc == 3u) { a = 255.0f; bq = 255.0f; }
-							r0[sub][c] = a;
-							r1[sub][c] = bq;
+							r0[c] = a;
+							r1[c] = bq;
 						}
+					};
+					// 4. endpoint mode by the quadratic estimate (same mode for every partition):
+					// option o = 0 direct (CEM 8/12), 1 base + scale (6/10), 2 luminance (0/4)
+					float est[3] = {0.0f, 0.0f, 0.0f};
+					bool okk[3];
+					int lvs[3];
+#pragma unroll
+					for (int o = 0; o < 3; ++o) {
+						const uint32_t nv = (has_alpha ? 8u : 6u) - 2u*(uint32_t)o;
+						okk[o] = !(nv*P > 18u || (o == 2 && !grey) || (o > 0 && dual && ccs < 3u));
+						lvs[o] = okk[o] ? (int)clevel[(nv*P/2u)*132u + cfg.cbits] : -1;
+						okk[o] = okk[o] && lvs[o] >= 0;
 					}
-					// 4. endpoint mode by the quadratic estimate (same mode for every partition)
+#pragma unroll 1
+					for (uint32_t p = 0; p < P; ++p) {
+						float r0[4], r1[4], cA[4], cB[4], cC[4];
+						solve(p, r0, r1, cA, cB, cC);
+						uint32_t d0p, d1p, vals[8];
+#pragma unroll
+						for (int o = 0; o < 3; ++o)
+							if (okk[o])
+								okk[o] = cem_option(sh, o, (uint32_t)lvs[o], has_alpha, r0, r1, cA, cB, cC, cw, est[o], d0p, d1p, vals);
+					}
 					float best_est = 3.0e38f;
 					int best_opt = -1;
 					uint32_t best_lv = 0;
-#pragma unroll 1
-					for (int o = 0; o < 3; ++o) {
-						const uint32_t nv = (has_alpha ? 8u : 6u) - 2u*(uint32_t)o;
-						if (nv*P > 18u || (o == 2 && !grey) || (o > 0 && dual && ccs < 3u))
-							continue;
-						const int lv = clevel[(nv*P/2u)*132u + cfg.cbits];
-						if (lv < 0)
-							continue;
-						float est = 0.0f;
-						bool ok = true;
 #pragma unroll
-						for (uint32_t p = 0; p < 4u; ++p) {
-							if (p < P && ok) {
-								float cA[4], cB[4], cC[4];
-#pragma unroll
-								for (uint32_t c = 0; c < 4u; ++c) {
-									const uint32_t st = dual ? (c == ccs ? 1u : 0u) : p;
-									cA[c] = st == 0u ? fAs[0] : (st == 1u ? fAs[1] : (st == 2u ? fAs[2] : fAs[3]));
-									cB[c] = st == 0u ? fBs[0] : (st == 1u ? fBs[1] : (st == 2u ? fBs[2] : fBs[3]));
-									cC[c] = st == 0u ? fCs[0] : (st == 1u ? fCs[1] : (st == 2u ? fCs[2] : fCs[3]));
-								}
-								uint32_t d0p, d1p, vals[8];
-								ok = cem_option(sh, o, (uint32_t)lv, has_alpha, r0[p], r1[p], cA, cB, cC, cw, est, d0p, d1p, vals);
-							}
-						}
-						if (ok && est < best_est) {
-							best_est = est;
-							best_opt = o;
-							best_lv = (uint32_t)lv;
-						}
-					}
+					for (int o = 0; o < 3; ++o)
+						if (okk[o] && est[o] < best_est) { best_est = est[o]; best_opt = o; best_lv = (uint32_t)lvs[o]; }
 					if (best_opt >= 0) {
 						// materialise the chosen option: decoded endpoints + stored values
 						uint32_t D0[4] = {0, 0, 0, 0}, D1[4] = {0, 0, 0, 0};
 						const uint32_t nv = (has_alpha ? 8u : 6u) - 2u*(uint32_t)best_opt;
-						uint32_t cvb[20];
+#pragma unroll 1
+						for (uint32_t p = 0; p < P; ++p) {
+							float r0[4], r1[4], cA[4], cB[4], cC[4];
+							solve(p, r0, r1, cA, cB, cC);
+							float e_ = 0.0f;
+							uint32_t d0p = 0, d1p = 0, vals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+							cem_option(sh, best_opt, best_lv, has_alpha, r0, r1, cA, cB, cC, cw, e_, d0p, d1p, vals);
 #pragma unroll
-						for (int k = 0; k < 20; ++k) cvb[k] = 0;
+							for (uint32_t k = 0; k < 4u; ++k) {
+								D0[k] = p == k ? d0p : D0[k];
+								D1[k] = p == k ? d1p : D1[k];
+							}
+							// stored values, partition by partition: byte (p*nv + k) of the list
 #pragma unroll
-						for (uint32_t p = 0; p < 4u; ++p) {
-							if (p < P) {
-								float cA[4], cB[4], cC[4];
+							for (uint32_t k = 0; k < 8u; ++k) {
+								if (k < nv) {
+									const uint32_t pos = p*nv + k;
 #pragma unroll
-								for (uint32_t c = 0; c < 4u; ++c) {
-									const uint32_t st = dual ? (c == ccs ? 1u : 0u) : p;
-									cA[c] = st == 0u ? fAs[0] : (st == 1u ? fAs[1] : (st == 2u ? fAs[2] : fAs[3]));
-									cB[c] = st == 0u ? fBs[0] : (st == 1u ? fBs[1] : (st == 2u ? fBs[2] : fBs[3]));
-									cC[c] = st == 0u ? fCs[0] : (st == 1u ? fCs[1] : (st == 2u ? fCs[2] : fCs[3]));
-								}
-								float e_ = 0.0f;
-								uint32_t vals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-								cem_option(sh, best_opt, best_lv, has_alpha, r0[p], r1[p], cA, cB, cC, cw, e_, D0[p], D1[p], vals);
-								// stored values, partition by partition: byte (p*nv + k) of the list
-#pragma unroll
-								for (uint32_t k = 0; k < 8u; ++k) {
-									if (k < nv) {
-										const uint32_t pos = p*nv + k;
-#pragma unroll
-										for (uint32_t wd = 0; wd < 5u; ++wd)
-											if ((pos >> 2) == wd)
-												r_cv[wd] |= vals[k] << (8u*(pos & 3u));
-									}
+									for (uint32_t wd = 0; wd < 5u; ++wd)
+										r_cv[wd] |= (pos >> 2) == wd ? vals[k] << (8u*(pos & 3u)) : 0u;
 								}
 							}
 						}
-						(void)cvb;
+#undef SEL4
 						// 5. exact error through the decode arithmetic
 						unsigned long long e64 = 0;
 #pragma unroll 1
@@ -1094,11 +1086,11 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							} else {
 								const uint32_t rec = inf[i];
 								const uint32_t g0 = rec & 255u, f00 = (rec >> 8) & 31u, f01 = (rec >> 13) & 31u, f10 = (rec >> 18) & 31u, f11 = rec >> 23;
-								const uint32_t i0 = (g0*planes)*64u, i1 = i0 + planes*64u, i2 = i0 + N*planes*64u, i3 = i2 + planes*64u;
-								w0 = (8u + f00*(col[i0] & 255u) + f01*(col[i1] & 255u) + f10*(col[i2] & 255u) + f11*(col[i3] & 255u)) >> 4;
+								const uint32_t i0 = g0*planes, i1 = i0 + planes, i2 = i0 + N*planes, i3 = i2 + planes;
+								w0 = (8u + f00*(COLR(i0) & 255u) + f01*(COLR(i1) & 255u) + f10*(COLR(i2) & 255u) + f11*(COLR(i3) & 255u)) >> 4;
 								w1 = w0;
 								if (dual)
-									w1 = (8u + f00*(col[i0 + 64u] & 255u) + f01*(col[i1 + 64u] & 255u) + f10*(col[i2 + 64u] & 255u) + f11*(col[i3 + 64u] & 255u)) >> 4;
+									w1 = (8u + f00*(COLR(i0 + 1u) & 255u) + f01*(COLR(i1 + 1u) & 255u) + f10*(COLR(i2 + 1u) & 255u) + f11*(COLR(i3 + 1u) & 255u)) >> 4;
 							}
 							const uint32_t part = byp ? 0u : prow[i];
 							const uint32_t q0 = part == 0u ? D0[0] : (part == 1u ? D0[1] : (part == 2u ? D0[2] : D0[3]));
@@ -1141,7 +1133,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						const uint32_t nw = cfg.nw;
 						uint8_t* wdst = reinterpret_cast<uint8_t*>(S.best + 12);
 						for (uint32_t g = 0; g < nw; ++g)
-							wdst[g] = (uint8_t)(col[g*64u] >> 8);
+							wdst[g] = (uint8_t)(COLR(g) >> 8);
 					}
 				}
 				__builtin_amdgcn_wave_barrier();
@@ -1239,7 +1231,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 }
 
 // dynamic LDS of a launch for this footprint (same carve-up as in the kernel)
-extern "C" size_t cfhip_astc_lds_bytes(const cfastc::AstcBlobHeader* h)
+extern "C" size_t cfhip_astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality)
 {
 	const uint32_t n = h->n, ngrids = h->ngrids, npad = h->npad;
 	uint32_t off = CF_BLOCKS_PER_WG*n*4u;
@@ -1249,8 +1241,8 @@ extern "C" size_t cfhip_astc_lds_bytes(const cfastc::AstcBlobHeader* h)
 	off += (ngrids*4u + 15u) & ~15u;
 	off += 2u*17u*256u + 1216u;
 	const uint32_t wc_rows = n <= 64u ? 2u*((n + 3u)/4u) : 0u;
-	const uint32_t slot_bytes = ((8u*2u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*4u + 64u + 40u*4u + 28u*4u;
-	const uint32_t wave_bytes = ((h->col_rows*128u + wc_rows*256u + 15u) & ~15u) + 2u*slot_bytes;
+	const uint32_t slot_bytes = ((8u*2u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
+	const uint32_t wave_bytes = ((((h->col_rows + 1u)/2u)*256u + wc_rows*256u + 15u) & ~15u) + (quality <= 2u ? 2u : 1u)*slot_bytes;
 	return (size_t)off + 4u*(size_t)wave_bytes;
 }
 
@@ -1266,6 +1258,11 @@ extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, si
 		hipFuncSetAttribute(reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 1024);
 		hipFuncSetAttribute(reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 1024);
 		attr_set = true;
+	}
+	if (getenv("CFHIP_ASTC_DEBUG")) {
+		int nb = -1;
+		hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0>), CF_WG_THREADS, lds_bytes);
+		fprintf(stderr, "[astc] dynamic LDS %zu B, workgroups per CU %d (%s), grid %u x %u\n", lds_bytes, nb, hipGetErrorString(oe), grid.x, grid.y);
 	}
 	if (pixel_type == 0)
 		hipLaunchKernelGGL((cfhip_astc_encode_kernel<0>), grid, block, lds_bytes, stream, *kp);

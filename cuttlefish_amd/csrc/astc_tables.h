@@ -294,7 +294,9 @@ inline std::vector<uint8_t> build_blob(int bw, int bh)
 				for (int M = 2; M <= bh && M <= 12; ++M)
 					for (int wq = 0; wq < 12; ++wq) {
 						const int nw = N*M*(dual ? 2 : 1);
-						if (nw > 64)
+						// a lane's LDS column holds the grid (planes interleaved) plus the rows the unmasked
+						// neighbour accesses of the last grid point reach: 64 rows
+						if (nw > 64 || nw + (dual ? 2 : 1)*(N + 2) > 64)
 							continue;
 						const int wbits = ise_bits(nw, WQ[wq]);
 						if (wbits < 24 || wbits > 96 || block_mode(N, M, wq, dual) < 0)

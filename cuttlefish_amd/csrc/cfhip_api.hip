@@ -24,7 +24,7 @@
 extern "C" hipError_t cfhip_launch_bc7(const cf_kparams* kp, int pixel_type, int unit_weights,
 	hipStream_t stream);
 extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, size_t lds_bytes, hipStream_t stream);
-extern "C" size_t cfhip_astc_lds_bytes(const cfastc::AstcBlobHeader* h);
+extern "C" size_t cfhip_astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality);
 extern "C" hipError_t cfhip_launch_etc(const cf_kparams* kp, int format, int pixel_type, int snorm,
 	hipStream_t stream);
 extern "C" hipError_t cfhip_launch_bc6h(const cf_kparams* kp, int pixel_type, int is_signed,
@@ -53,7 +53,7 @@ struct cfhip_ctx {
 	size_t pin_cap = 0;
 	hipEvent_t pin_free[2] = {nullptr, nullptr};   // slot's upload has left the host buffer
 	std::map<int, void*> astc_tables; // per-format device tables (built on first use)
-	std::map<int, size_t> astc_lds;   // dynamic LDS of a launch per format
+	std::map<int, cfastc::AstcBlobHeader> astc_hdr;   // their headers (sizes the launch's dynamic LDS)
 	std::vector<hipEvent_t> events;   // start/stop pairs of the last call
 	size_t events_used = 0;
 	hipStream_t events_stream = nullptr;
@@ -350,12 +350,12 @@ int launch(cfhip_ctx* ctx, const cf_kparams& kp, const cfhip_params& p, int pixe
 			if (pixel_type != CFHIP_PIXEL_RGBA8 && pixel_type != CFHIP_PIXEL_RGBA32F)
 				return fail(ctx, CFHIP_E_UNSUPPORTED, "ASTC LDR takes RGBA8 or RGBA32F pixels");
 			void*& tab = ctx->astc_tables[p.format];
-			size_t& lds = ctx->astc_lds[p.format];
+			cfastc::AstcBlobHeader& hdr = ctx->astc_hdr[p.format];
 			if (!tab) {
 				int fbw, fbh;
 				astc_footprint(p.format, &fbw, &fbh);
 				const std::vector<uint8_t> host = cfastc::build_blob(fbw, fbh);
-				lds = cfhip_astc_lds_bytes(reinterpret_cast<const cfastc::AstcBlobHeader*>(host.data()));
+				memcpy(&hdr, host.data(), sizeof(hdr));
 				HIP_TRY(ctx, hipMalloc(&tab, host.size()));
 				HIP_TRY(ctx, hipMemcpy(tab, host.data(), host.size(), hipMemcpyHostToDevice));
 			}
@@ -365,7 +365,7 @@ int launch(cfhip_ctx* ctx, const cf_kparams& kp, const cfhip_params& p, int pixe
 			// images (AstcConverter.cpp:163-172)
 			k2.flags |= ((p.alpha == CFHIP_ALPHA_STANDARD || p.alpha == CFHIP_ALPHA_PREMULTIPLIED) ? 1u << 16 : 0u) |
 				(p.color_space == CFHIP_COLOR_SRGB ? 1u << 17 : 0u);
-			e = cfhip_launch_astc(&k2, pixel_type == CFHIP_PIXEL_RGBA32F ? 1 : 0, lds, stream);
+			e = cfhip_launch_astc(&k2, pixel_type == CFHIP_PIXEL_RGBA32F ? 1 : 0, cfhip_astc_lds_bytes(&hdr, kp.quality), stream);
 			ctx->last_kernel = "cfhip_astc_encode_kernel";
 			break;
 		}

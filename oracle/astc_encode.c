@@ -106,7 +106,9 @@ static void build_configs(astc_fmt* f, int cls, int alpha)
 		for (int M = 2; M <= f->bh && M <= 12; ++M)
 			for (int wq = 0; wq < ASTC_NWQ; ++wq) {
 				int nw = N*M*(dual ? 2 : 1);
-				if (nw > ASTC_MAX_WEIGHTS)
+				/* the kernel's per-lane LDS column holds 64 rows: the grid (planes interleaved) plus
+				 * the rows its unmasked neighbour accesses reach */
+				if (nw > ASTC_MAX_WEIGHTS || nw + (dual ? 2 : 1)*(N + 2) > 64)
 					continue;
 				int wbits = astc_ise_bits(nw, &astc_wq[wq]);
 				if (wbits < 24 || wbits > 96 || astc_make_block_mode(N, M, wq, dual) < 0)
@@ -407,21 +409,21 @@ static int rank_configs(const astc_blk* b, int j, const astc_pc* pc, int K, int*
 	for (int s = 0; s < slots; ++s)
 		spn += b->span2n[j][s];
 	uint64_t span2 = ((uint64_t)(uint32_t)spn*(65536u/(uint32_t)b->n)) >> 16;
-	uint64_t key[ASTC_MAX_CFG];
+	uint32_t key[ASTC_MAX_CFG];
 	for (int k = 0; k < ncfg; ++k) {
 		const astc_cfg* c = &f->cfg[pc->cls][b->has_alpha][k];
 		uint64_t wn = (uint64_t)b->edec[c->grid]*40u + (uint64_t)b->n*c->wq16;
-		uint64_t est = ((span2*wn) >> 12) + (uint64_t)(b->n*b->nc)*c->cq16;
-		key[k] = (est << 8) | (uint64_t)k;
+		uint64_t est = (((span2*wn) >> 12) + (uint64_t)(b->n*b->nc)*c->cq16) >> 8;
+		key[k] = ((est > 0x3FFFFFEull ? 0x3FFFFFEu : (uint32_t)est) << 6) | (uint32_t)k;
 	}
 	int got = 0;
 	for (; got < K && got < ncfg; ++got) {
 		int bi = -1;
 		for (int k = 0; k < ncfg; ++k)
-			if (key[k] != ~0ull && (bi < 0 || key[k] < key[bi]))
+			if (key[k] != 0xFFFFFFFFu && (bi < 0 || key[k] < key[bi]))
 				bi = k;
-		order[got] = (int)(key[bi] & 255u);
-		key[bi] = ~0ull;
+		order[got] = (int)(key[bi] & 63u);
+		key[bi] = 0xFFFFFFFFu;
 	}
 	return got;
 }
