@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the block-encode hot path (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): BC7 UNORM,
+Default workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): BC7 UNORM,
 Texture::Quality::Normal ("quality"), one 4096x4096 RGBA8 synthetic photographic
 tile per GPU, resident in HBM when the timed region starts.  A "step" = one pass of
 the hot path (cfhip_encode_device) over that tile.  Multi-GPU: independent tiles,
@@ -12,13 +12,21 @@ max-over-ranks of the elapsed time.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--config c5` runs BASELINE.json configs[4] instead: a texture array of 256 x
+(2048x2048 RGBA8 + its 12-level mip chain), BC7 Normal, the textures LPT-sharded over the N
+ranks (cuttlefish_amd/shard.py), mips generated on the GPU, ONE batched encode per rank, payload
+gathered to rank 0 as exact-size device buffers over RCCL, and a sub-sample of the gathered
+payload checked byte-for-byte against a local re-encode ("strong" scaling: the batch is fixed).
+
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM
 (8 TB/s, /opt/skills/guides/MI355X_MICROARCH.md): algorithmic bytes = 5 B/px
 (read RGBA8 once + write 1 B/px payload once) x 16 777 216 px per launch, divided by
-the kernel's average duration from hipEvents recorded on the launch stream.
+the kernel's average duration from hipEvents recorded on the launch stream.  What really
+bounds the kernel is VALU issue: `roofline.valu_issue` prices the kernel's OWN instruction mix
+(tools/isa_mix.py, read from the library that runs) so its fraction is <= 1 by construction.
 `cpu_baseline` times the CPU oracle ("port": our from-spec encoder at the same
 search settings, NOT bc7enc_rdo -- its sources are absent) on a bounded strip of
-the same tile on this box's host cores (rank 0, N=1 only).
+the same tile on this box's usable host cores (rank 0, N=1 only).
 """
 from __future__ import annotations
 
@@ -33,49 +41,78 @@ sys.path.insert(0, ROOT)
 
 SIZE = 4096
 FORMAT_NAME = "BC7"
-QUALITY_NAME = "Normal"
 HBM_PEAK_GBPS = 8000.0
 GPU_CLOCK_HZ = 2.4e9          # MI355X peak engine clock (MI355X_MICROARCH.md)
+N_SIMD = 1024                 # 256 CUs x 4 SIMDs
 ALGO_BYTES_PER_PIXEL = 5.0   # 4 B RGBA8 read + 16 B / 16 px payload write
+QNAMES = ["Lowest", "Low", "Normal", "High", "Highest"]
 
 
-def cpu_baseline(img, gpu_payload, width, budget_s=15.0):
-    """Time the CPU oracle on a strip of the tile (about budget_s of host work) and check
-    the GPU payload of the same strip against it.  This is the only place bench.py touches
+def usable_cpus() -> int:
+    """Host threads this process may really use: the scheduler affinity, capped by the cgroup
+    CPU quota (os.cpu_count() reports the machine, not the container's share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def cpu_baseline(img, gpu_payload, width, quality, budget_s=12.0):
+    """Time the CPU oracle on a strip of the tile (>= 10 s of host work on all usable cores) and
+    check the GPU payload of the same strip against it.  This is the only place bench.py touches
     oracle/ (test infrastructure)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
     from cuttlefish_amd import Format, synth
 
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     fmt = int(Format.BC7)
-    # calibrate on 2 block rows, then size the sample
+    bw = width // 4
+    # single-thread rate on two block rows, then the thread-scaling ladder on a short strip
     t0 = time.perf_counter()
-    O.encode(img[:8], fmt, quality=2, threads=cores)
-    dt = max(time.perf_counter() - t0, 1e-3)
-    rows = int(min(SIZE // 4, max(2, budget_s / (dt / 2))))
+    O.encode(img[:8], fmt, quality=quality, threads=1)
+    dt1 = max(time.perf_counter() - t0, 1e-3)
+    rate1 = 8 * width / 1e6 / dt1
+    ladder = {}
+    for t in sorted({max(1, cores // 4), cores}):
+        rows_t = max(2, min(SIZE // 4, int(1.5 * t * rate1 * 1e6 / (4 * width))))
+        t0 = time.perf_counter()
+        O.encode(img[:rows_t * 4], fmt, quality=quality, threads=t)
+        ladder[t] = rows_t * 4 * width / 1e6 / max(time.perf_counter() - t0, 1e-3)
+    rows = int(min(SIZE // 4, max(2, budget_s * ladder[cores] * 1e6 / (4 * width))))
     y0 = (SIZE // 2) - (rows * 4) // 2          # centred: includes the alpha band
     y0 -= y0 % 4
+    y0 = max(0, y0)
     strip = img[y0:y0 + rows * 4]
     t0 = time.perf_counter()
-    ref = O.encode(strip, fmt, quality=2, threads=cores)
+    ref = O.encode(strip, fmt, quality=quality, threads=cores)
     dt = time.perf_counter() - t0
     mpix = strip.shape[0] * strip.shape[1] / 1e6
-    bw = width // 4
     got = gpu_payload.reshape(-1, bw * 16)[y0 // 4:y0 // 4 + rows].reshape(-1)
-    # single-thread figure on a few block rows of the same strip (SURVEY 8d asks for T and T=1)
-    t1_rows = min(rows, 2)
-    t0 = time.perf_counter()
-    O.encode(strip[:t1_rows * 4], fmt, quality=2, threads=1)
-    dt1 = time.perf_counter() - t0
     dec_cpu = O.decode(ref, fmt, width, rows * 4)
     dec_gpu = O.decode(got, fmt, width, rows * 4)
     return {
         "value": round(mpix / dt, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-        "value_1_thread": round(t1_rows * 4 * strip.shape[1] / 1e6 / dt1, 4),
-        "sample": "rows %d..%d of the same 4096x4096 tile (%d blocks, %.1f s)" %
-                  (y0, y0 + rows * 4, rows * bw, dt),
+        "value_1_thread": round(rate1, 4),
+        "scaling": {str(t): round(v, 3) for t, v in ladder.items()},
+        "host_threads_visible": os.cpu_count(),
+        "sample": "rows %d..%d of the same 4096x4096 tile (%d blocks): %.1f s wall on %d threads = %.0f "
+                  "core-seconds of CPU work" % (y0, y0 + rows * 4, rows * bw, dt, cores, dt * cores),
         "psnr_y_cpu": round(synth.psnr_y(strip, dec_cpu), 3),
         "psnr_y_gpu": round(synth.psnr_y(strip, dec_gpu), 3),
         "psnr_rgba_gpu": round(synth.psnr(strip, dec_gpu), 3),
@@ -88,8 +125,7 @@ def _cached_photo(synth, size, seed):
     in a git-ignored cache next to the repo so that back-to-back runs (N = 1, 2, 4, 8) reuse it.
     Any cache problem falls back to generating it."""
     import numpy as np
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), ".bench_cache",
-                        "photo_%d_seed%d.npy" % (size, seed))
+    path = os.path.join(ROOT, ".bench_cache", "photo_%d_seed%d.npy" % (size, seed))
     try:
         if os.path.exists(path):
             img = np.load(path)
@@ -109,15 +145,214 @@ def _cached_photo(synth, size, seed):
     return img
 
 
+def valu_issue_view(kernel_substr, avg_kernel_s):
+    """The kernel's mix-weighted VALU issue ceiling.  The instruction mix comes from the device
+    code inside the library that just ran (tools/isa_mix.py); the dynamic instruction counts
+    (SQ_INSTS_VALU and the per-class counters) and the HBM traffic come from the committed
+    rocprofv3 PMC pass of the SAME code (profiles/bc7_pmc.json, matched by the code hash --
+    PMC passes cannot run inside the timed benchmark).  Returns (valu_issue, traffic, source)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import isa_mix
+        mix = isa_mix.kernel_mix(os.path.join(ROOT, "cuttlefish_amd", "libcuttlefish_hip.so"), kernel_substr)
+    except BaseException as e:        # no llvm tools on this box: report nothing rather than guess
+        return {"error": "isa mix unavailable: %s" % (e,)}, None, None
+    view = {"kernel": mix["kernel"], "code_sha256": mix["code_sha256"],
+            "static_valu_fast_share": mix["valu_fast_share"],
+            "static_cycles_per_valu_inst": mix["valu_cycles_per_inst"],
+            "classes": "2-cycle: fp32 fma/mul/add, plain add/sub/and/or/xor/mov/ashr; 4-cycle: the rest "
+                       "(tools/ubench/valu_rate.hip, profiles/r01_valu_rate.txt)"}
+    traffic = source = None
+    ppath = os.path.join(ROOT, "profiles", "bc7_pmc.json")
+    if os.path.exists(ppath):
+        pj = json.load(open(ppath))
+        if pj.get("code_sha256") == mix["code_sha256"]:
+            traffic = pj.get("traffic_bytes_per_launch")
+            source = "from committed profile %s (same code hash %s)" % (pj.get("source"), mix["code_sha256"])
+            insts = pj.get("valu_wave_insts_per_launch")
+            if insts:
+                cyc = pj.get("valu_issue_cycles_per_launch")     # sum over classes of count x class cycles
+                if not cyc:
+                    cyc = insts * mix["valu_cycles_per_inst"]
+                ceiling_s = cyc / N_SIMD / GPU_CLOCK_HZ
+                view.update({"wave_insts_per_launch": insts,
+                             "issue_cycles_per_launch": int(cyc),
+                             "cycles_per_inst": round(cyc / insts, 4),
+                             "class_source": pj.get("class_source", "static ISA mix"),
+                             "ceiling_ms": round(ceiling_s * 1e3, 4),
+                             "frac": round(ceiling_s / avg_kernel_s, 4),
+                             "note": "frac = (sum over instruction classes of count x issue cycles) / "
+                                     "(1024 SIMDs x 2.4 GHz x kernel time): the share of the kernel's "
+                                     "time the VALU needs at full issue rate for ITS mix"})
+        else:
+            view["note"] = "profiles/bc7_pmc.json describes other code (hash %s): no PMC-derived figures" % \
+                pj.get("code_sha256")
+    return view, traffic, source
+
+
+def gpu_texture(torch, size, seed, device):
+    """Deterministic synthetic RGBA8 texture generated ON the GPU (C5 needs 256 of them; the numpy
+    generator of the C2 tile takes seconds per texture): smooth luminance + chroma fields from
+    bilinearly upsampled low-resolution noise, hard-edged rectangles, +-2 LSB grain, opaque alpha
+    with one ramped band.  Same seed -> same bytes on every MI355X."""
+    g = torch.Generator(device=device)
+    g.manual_seed(0xC0FFEE + seed)
+    lo = torch.rand((1, 4, 33, 33), generator=g, device=device)
+    lum = torch.rand((1, 1, 9, 9), generator=g, device=device)
+    up = torch.nn.functional.interpolate
+    f = 0.45 * up(lo, size=(size, size), mode="bilinear", align_corners=True) + \
+        0.55 * up(lum, size=(size, size), mode="bilinear", align_corners=True)
+    f = f[0].permute(1, 2, 0).contiguous()
+    rects = torch.randint(0, size, (24, 4), generator=g, device=device)
+    cols = torch.rand((24, 3), generator=g, device=device)
+    for r in range(24):
+        x0, y0, w, h = [int(v) for v in rects[r].tolist()]
+        f[y0:y0 + 1 + h // 6, x0:x0 + 1 + w // 6, :3] = cols[r]
+    f[..., 3] = 1.0
+    band = slice(size // 2, size // 2 + size // 8)
+    f[band, :, 3] = torch.linspace(0.0, 1.0, size, device=device)[None, :]
+    grain = (torch.rand((size, size, 4), generator=g, device=device) * 5.0 - 2.0).floor()
+    grain[..., 3] = 0.0
+    return (f * 255.0 + grain).round().clamp(0, 255).to(torch.uint8).contiguous()
+
+
+def run_c5(args, rank, local_rank, world, backend):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from cuttlefish_amd import ColorSpace, Context, Format, PixelType, Type, make_params, payload_size, shard
+
+    dev = torch.device("cuda", local_rank)
+    n, T = args.tex_size, args.textures
+    levels = n.bit_length()
+    dims = [max(1, n >> k) for k in range(levels)]
+    px_chain = sum(d * d for d in dims)
+    nbytes = [payload_size(Format.BC7, Type.UNorm, d, d) for d in dims]
+    chain_bytes = sum(nbytes)
+    blocks_chain = sum(shard.block_count(d, d) for d in dims)
+    plan = shard.assign_surfaces([blocks_chain] * T, world)      # units = textures (a chain stays on its rank)
+    mine = plan[rank]
+    ctx = Context(local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    params = make_params(Format.BC7, Type.UNorm, args.quality)
+
+    bases = [gpu_texture(torch, n, t, dev) for t in mine]
+    chains = [[torch.empty((d, d, 4), dtype=torch.float32, device=dev) for d in dims[1:]] for _ in mine]
+    out = torch.empty(len(mine) * chain_bytes, dtype=torch.uint8, device=dev)
+
+    def surfaces(base_list, chain_list, out_buf):
+        s = []
+        for i in range(len(base_list)):
+            off = i * chain_bytes
+            for k, d in enumerate(dims):
+                src = base_list[i] if k == 0 else chain_list[i][k - 1]
+                s.append({"pixels": src.data_ptr(), "pixel_type": PixelType.RGBA8 if k == 0 else PixelType.RGBA32F,
+                          "width": d, "height": d, "row_pitch_bytes": d * (4 if k == 0 else 16),
+                          "out": out_buf.data_ptr() + off, "out_capacity": nbytes[k]})
+                off += nbytes[k]
+        s.sort(key=lambda e: int(e["pixel_type"]))            # one batched launch per source type
+        return s
+    surf = surfaces(bases, chains, out)
+    sizes = [len(plan[r]) * chain_bytes for r in range(world)]
+
+    def step(gather=True):
+        for i in range(len(mine)):
+            ctx.generate_mips_device(bases[i].data_ptr(), PixelType.RGBA8, n, n, n * 4,
+                                     [c.data_ptr() for c in chains[i]], color_space=ColorSpace.Linear,
+                                     filter=0, stream=stream)
+        if surf:
+            ctx.encode_device(surf, params, stream)
+        if gather and world > 1:
+            torch.cuda.current_stream().synchronize()
+            return shard.exchange(out, sizes, rank, world, dst=0)
+        return None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    ctx.profile_begin()
+    t0 = time.perf_counter()
+    parts = None
+    for _ in range(args.steps):
+        parts = step()
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = ctx.profile_end()
+    # encode-only time of this rank's share (no gather), for the per-rank load table
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    step(gather=False)
+    torch.cuda.synchronize()
+    local_ms = (time.perf_counter() - t1) * 1e3
+    stats = torch.tensor([elapsed, local_ms, float(len(mine))], dtype=torch.float64,
+                         device=dev if backend == "nccl" else "cpu")
+    allstats = [stats.clone() for _ in range(world)]
+    if world > 1:
+        dist.all_gather(allstats, stats)
+    elapsed = max(float(s[0]) for s in allstats)
+
+    if rank == 0:
+        # byte-equality of the sharded result against a local re-encode on a sub-sample of the
+        # textures OTHER ranks own (regenerated from their seeds)
+        check = {"textures_checked": [], "equal": True}
+        if world > 1 and parts is not None:
+            for r in sorted({1, world - 1}):
+                for pos in sorted({0, len(plan[r]) - 1}):
+                    t = plan[r][pos]
+                    b = [gpu_texture(torch, n, t, dev)]
+                    c = [[torch.empty((d, d, 4), dtype=torch.float32, device=dev) for d in dims[1:]]]
+                    o = torch.empty(chain_bytes, dtype=torch.uint8, device=dev)
+                    ctx.generate_mips_device(b[0].data_ptr(), PixelType.RGBA8, n, n, n * 4,
+                                             [x.data_ptr() for x in c[0]], color_space=ColorSpace.Linear,
+                                             filter=0, stream=stream)
+                    ctx.encode_device(surfaces(b, c, o), params, stream)
+                    torch.cuda.synchronize()
+                    same = bool(torch.equal(o, parts[r][pos * chain_bytes:(pos + 1) * chain_bytes]))
+                    check["textures_checked"].append(t)
+                    check["equal"] = check["equal"] and same
+        pixels = float(T) * px_chain
+        line = {
+            "metric": "Mpixels/s encode, BC7 texture-array batch (256 x 2048x2048 RGBA8 mip chains)",
+            "value": round(pixels * args.steps / elapsed / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic (generated on the GPU from per-texture seeds)",
+            "config": {"workload": "C5: %d textures x (%dx%d RGBA8 + %d-level Box mip chain generated on the "
+                                   "GPU), BC7 UNORM Texture::Quality::%s, textures LPT-sharded over the ranks, "
+                                   "one batched encode per rank, exact-size device gather to rank 0 over %s"
+                                   % (T, n, n, levels, QNAMES[args.quality], "RCCL" if backend == "nccl" else backend),
+                       "format": FORMAT_NAME, "quality": args.quality, "textures": T,
+                       "surfaces": T * levels, "blocks": T * blocks_chain,
+                       "parallelism": "texture-sharded x%d" % world},
+            "per_rank": [{"rank": r, "textures": int(allstats[r][2]), "encode_ms": round(float(allstats[r][1]), 3),
+                          "gather_bytes": sizes[r]} for r in range(world)],
+            "kernel_ms_rank0": round(kernel_ms / max(args.steps, 1), 3),
+            "sharded_equals_local": check,
+            "roofline": None, "cpu_baseline": None,
+        }
+        print(json.dumps(line), flush=True)
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--quality", type=int, default=2)
     ap.add_argument("--size", type=int, default=SIZE)
+    ap.add_argument("--config", default="c2", choices=["c2", "c5"])
+    ap.add_argument("--textures", type=int, default=256, help="c5: textures in the array")
+    ap.add_argument("--tex-size", type=int, default=2048, help="c5: base level size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 20 if args.config == "c2" else 3
+    if args.warmup is None:
+        args.warmup = 3 if args.config == "c2" else 1
 
     import numpy as np
     import torch
@@ -146,6 +381,12 @@ def main():
                                     device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+
+    if args.config == "c5":
+        run_c5(args, rank, local_rank, world, backend)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     size = args.size
     # every rank encodes its own tile (independent surfaces; weak scaling)
@@ -197,9 +438,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "BC7 UNORM Texture::Quality::%s, one %dx%d RGBA8 synthetic "
-                                   "photo tile per GPU, resident in HBM" %
-                                   (["Lowest", "Low", "Normal", "High", "Highest"][args.quality],
-                                    size, size),
+                                   "photo tile per GPU, resident in HBM" % (QNAMES[args.quality], size, size),
                        "format": FORMAT_NAME, "quality": args.quality,
                        "blocks_per_launch": (size // 4) ** 2, "parallelism": "surface-per-gpu x%d"
                        % world},
@@ -211,28 +450,16 @@ def main():
                          "note": "VALU-issue-bound search (see valu_issue); the HBM fraction is "
                                  "tiny by construction (DESIGN.md roofline section)"},
         }
-        # HBM traffic per launch from the committed PMC profile of this kernel (rocprofv3
-        # --pmc passes cannot run inside the timed benchmark); null when not applicable.
-        tpath = os.path.join(ROOT, "profiles", "bc7_traffic.json")
-        if size == SIZE and args.quality == 2 and os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            line["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
-            line["roofline"]["traffic_source"] = tj["source"]
-            if tj.get("valu_wave_insts_per_launch"):
-                # what actually bounds the kernel: VALU issue.  Peak = one integer wave64
-                # instruction per 4 cycles per SIMD (tools/ubench/valu_rate.hip), 1024 SIMDs.
-                insts = tj["valu_wave_insts_per_launch"]
-                peak = 1024 * GPU_CLOCK_HZ / 4.0
-                line["roofline"]["valu_issue"] = {
-                    "wave_insts_per_launch": insts,
-                    "achieved_ginst_s": round(insts / avg_kernel_s / 1e9, 2),
-                    "peak_ginst_s": round(peak / 1e9, 2),
-                    "frac": round(insts / avg_kernel_s / peak, 4),
-                    "note": "integer-rate peak; fp32 fma/mul/add issue at twice that rate, so a "
-                            "mixed stream can read slightly above 1"}
+        if size == SIZE:
+            ksub = "cfhip_bc7_encode_kernelILi0ELb1ELb%dE" % (1 if args.quality == 4 else 0)
+            view, traffic, source = valu_issue_view(ksub, avg_kernel_s)
+            line["roofline"]["valu_issue"] = view
+            if args.quality == 2 and traffic is not None:
+                line["roofline"]["traffic"] = traffic
+                line["roofline"]["traffic_source"] = source
         if world == 1 and not args.no_cpu_baseline and size == SIZE:
             payload = out.cpu().numpy()
-            line["cpu_baseline"] = cpu_baseline(img, payload, size)
+            line["cpu_baseline"] = cpu_baseline(img, payload, size, args.quality)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -128,10 +128,18 @@ static void* worker(void* arg)
 {
 	job_ctx* j = (job_ctx*)arg;
 	unsigned total = j->bx*j->by;
-	for (;;) {
-		unsigned job = atomic_fetch_add(&j->next, 1u);
-		if (job >= total)
-			return NULL;
+	/* Converter::convert hands out jobs through one atomic counter (Converter.cpp:563-578); with
+	 * hundreds of host threads that cache line becomes the bottleneck, so a worker claims a run
+	 * of CFO_JOB_RUN consecutive blocks per fetch (the same jobs in the same places) */
+	enum { CFO_JOB_RUN = 32 };
+	unsigned job = 0, job_end = 0;
+	for (;; ++job) {
+		if (job >= job_end) {
+			job = atomic_fetch_add(&j->next, (unsigned)CFO_JOB_RUN);
+			if (job >= total)
+				return NULL;
+			job_end = job + CFO_JOB_RUN < total ? job + CFO_JOB_RUN : total;
+		}
 		uint32_t x = job % j->bx, y = job / j->bx;
 		uint8_t* dst = j->out + (size_t)job*(size_t)j->bytes;
 		if (j->p->format >= 43 && j->p->format <= 56) {

@@ -1,0 +1,78 @@
+"""The sharded encode path with the PRODUCT encoder (Context.encode) on the GPU: world 1 in
+process, and world 2 (two ranks, RCCL when two devices are visible, otherwise both ranks share
+the device over gloo) -- the N-way result is byte-identical to the 1-way result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cuttlefish_amd import Context, Format, Type, make_params, shard, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _chain():
+    imgs = [synth.photo(64 >> i, 64 >> i, seed=30 + i) for i in range(7)]
+    return imgs + [synth.photo(52, 20, seed=40), synth.photo(9, 70, seed=41)]
+
+
+def test_world1_sharded_equals_direct(gpu_ctx):
+    p = make_params(Format.BC7, Type.UNorm, 2)
+    imgs = _chain()
+    direct = gpu_ctx.encode(imgs, p)
+    got = shard.encode_surfaces_sharded(imgs, p, gpu_ctx.encode, 0, 1)
+    assert all(np.array_equal(a, b) for a, b in zip(direct, got))
+    big = synth.photo(64, 100, seed=7)
+    for fmt in (Format.BC7, Format.ASTC_8x6, Format.ETC2_R8G8B8):
+        q = make_params(fmt, Type.UNorm, 1)
+        whole = gpu_ctx.encode([big], q)[0]
+        parts = [shard.encode_rows_sharded(big, q, gpu_ctx.encode, r, 3, gather=False) for r in range(3)]
+        assert np.array_equal(np.concatenate(parts), whole), fmt
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, backend, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        with Context(dev) as ctx:
+            p = make_params(Format.BC7, Type.UNorm, 2)
+            got = shard.encode_surfaces_sharded(_chain(), p, ctx.encode, rank, world)
+            rows = shard.encode_rows_sharded(synth.photo(64, 100, seed=7), p, ctx.encode, rank, world)
+        q.put((rank, [g.tobytes() for g in got], rows.tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_world2_equals_world1(gpu_ctx):
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    port = _free_port()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_worker, args=(r, 2, port, backend, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=480) for _ in range(2)]
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    p = make_params(Format.BC7, Type.UNorm, 2)
+    want = [o.tobytes() for o in gpu_ctx.encode(_chain(), p)]
+    want_rows = gpu_ctx.encode([synth.photo(64, 100, seed=7)], p)[0].tobytes()
+    for rank, got, rows in results:
+        assert got == want and rows == want_rows, "rank %d" % rank

@@ -37,7 +37,13 @@ def _worker(rank, world, port, q):
         got = shard.encode_surfaces_sharded(chain, params, _oracle_encode, rank, world)
         img = synth.photo(40, 52, seed=80)
         rows = shard.encode_rows_sharded(img, params, _oracle_encode, rank, world)
-        q.put((rank, [g.tobytes() for g in got], rows.tobytes()))
+        # a footprint whose block height is not 4: shards must start on ASTC block rows
+        ap = make_params(Format.ASTC_6x6, Type.UNorm, 0)
+        aimg = synth.photo(30, 44, seed=81)
+        arows = shard.encode_rows_sharded(aimg, ap, _oracle_encode, rank, world)
+        asurf = shard.encode_surfaces_sharded([aimg, aimg[:13, :7]], ap, _oracle_encode, rank, world)
+        q.put((rank, [g.tobytes() for g in got], rows.tobytes(), arows.tobytes(),
+               [g.tobytes() for g in asurf]))
     finally:
         dist.destroy_process_group()
 
@@ -72,6 +78,29 @@ def test_world2_gloo_matches_single_rank():
     want = [o.tobytes() for o in _oracle_encode(chain, params)]
     img = synth.photo(40, 52, seed=80)
     want_rows = _oracle_encode([img], params)[0].tobytes()
-    for rank, got, rows in results:
+    ap = make_params(Format.ASTC_6x6, Type.UNorm, 0)
+    aimg = synth.photo(30, 44, seed=81)
+    want_a = [o.tobytes() for o in _oracle_encode([aimg, aimg[:13, :7]], ap)]
+    assert len(want_a[0]) == 5*8*16                     # ceil(30/6) x ceil(44/6) blocks
+    for rank, got, rows, arows, asurf in results:
         assert got == want, "rank %d surfaces differ" % rank
         assert rows == want_rows, "rank %d row shards differ" % rank
+        assert arows == want_a[0], "rank %d ASTC 6x6 row shards differ" % rank
+        assert asurf == want_a, "rank %d ASTC surfaces differ" % rank
+
+
+def test_row_shards_follow_the_format_block_height():
+    """h = 24 with ASTC 6x6 is 4 block rows (not 6): every shard boundary is a multiple of 6."""
+    from cuttlefish_amd import api
+    seen = []
+
+    def spy(images, params):
+        seen.append(images[0].shape[0])
+        return _oracle_encode(images, params)
+    img = synth.photo(12, 24, seed=5)
+    ap = make_params(Format.ASTC_6x6, Type.UNorm, 0)
+    whole = _oracle_encode([img], ap)[0]
+    parts = [shard.encode_rows_sharded(img, ap, spy, r, 4, gather=False) for r in range(4)]
+    assert seen == [6, 6, 6, 6]
+    assert np.array_equal(np.concatenate(parts), whole)
+    assert shard.block_count(12, 24, *api.query(Format.ASTC_6x6, Type.UNorm)[:2]) == 2*4
