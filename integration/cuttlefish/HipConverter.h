@@ -1,26 +1,30 @@
 /*
- * HipConverter.h -- drop-in cuttlefish::Converter that forwards a whole surface to the
- * MI355X backend through the C-ABI of include/cuttlefish_hip.h.
+ * HipConverter.h -- drop-in binding of the MI355X backend (include/cuttlefish_hip.h) for
+ * Cuttlefish.  Lives in lib/src/ of a Cuttlefish checkout (next to S3tcConverter.h).
  *
- * Lives in lib/src/ of a Cuttlefish checkout (next to S3tcConverter.h).  It follows the
- * whole-surface pattern of PvrtcConverter (lib/src/PvrtcConverter.h:37-38: jobsX() ==
- * jobsY() == 1), so Converter::convert (lib/src/Converter.cpp:508-593) runs process(0,0)
- * on the calling thread (:549-554) and moves data() out afterwards (:587).
+ * Two entry points, both behind CUTTLEFISH_HAS_HIP alone (the backend serves BCn, ETC/EAC and
+ * ASTC, so it does not depend on which CPU codecs were compiled in):
  *
- * process() has no error channel (Converter.h:70): on any backend failure the adapter
- * encodes the surface with the stock CPU converter it wraps (the reference path), so the
- * observable behaviour of Texture::convert is unchanged.
+ *  - HipConverter::convertAll: what the patched Converter::convert (lib/src/Converter.cpp:
+ *    508-593) tries first.  The reference walks [mip][depth][face] serially, one converter and
+ *    one thread fork/join per surface (:521-589); here ALL surfaces of the texture go to the
+ *    backend in ONE cfhip_encode call (one upload, one batched launch, one download), which is
+ *    what makes mip tails and texture arrays (BASELINE config 5: 3072 surfaces) cheap.
+ *  - class HipConverter: a whole-surface cuttlefish::Converter (PvrtcConverter pattern,
+ *    lib/src/PvrtcConverter.h:37-38: jobsX() == jobsY() == 1) for callers that drive single
+ *    converters.  process() has no error channel (Converter.h:70): on a backend failure it
+ *    builds the stock CPU converter THEN (lazily, through the factory it was given) and runs
+ *    it, so the observable behaviour of Texture::convert is unchanged.
  */
 #pragma once
 
 #include <cuttlefish/Config.h>
 #include "Converter.h"
 
-#if CUTTLEFISH_HAS_S3TC && CUTTLEFISH_HAS_HIP
+#if CUTTLEFISH_HAS_HIP
 
+#include <functional>
 #include <memory>
-
-struct cfhip_ctx;
 
 namespace cuttlefish
 {
@@ -28,16 +32,27 @@ namespace cuttlefish
 class HipConverter : public Converter
 {
 public:
+	using Factory = std::function<std::unique_ptr<Converter>()>;
+
 	// True if a HIP device and the backend library are usable (probed once).
 	static bool available();
 
-	// True for the (format, type) pairs the backend encodes (cfhip_query).
+	// True for the (format, type) pairs the backend encodes today (cfhip_query answers the
+	// legality matrix of createConverter; pairs the backend lists but refuses at encode time
+	// fall back to the CPU path through the failure handling below).
 	static bool supports(Texture::Format format, Texture::Type type);
 
-	// fallback: the stock converter createConverter would have returned; used only if the
-	// backend fails at process() time.
+	// Encodes every image of the texture in one backend call.  On success textureData holds
+	// the payloads (same sizes and order as Converter::convert produces), the source images
+	// are released like Converter.cpp:586 does, and true is returned.  On any failure nothing
+	// is modified and false is returned: the caller continues with the stock loop.
+	static bool convertAll(const Texture& texture, MipImageList& images,
+		MipTextureList& textureData, Texture::Quality quality);
+
+	// fallback: builds the converter the stock createConverter would have returned; invoked
+	// only if the backend fails at process() time.
 	HipConverter(const Texture& texture, const Image& image, Texture::Quality quality,
-		std::unique_ptr<Converter> fallback);
+		Factory fallback);
 
 	unsigned int jobsX() const override {return 1;}
 	unsigned int jobsY() const override {return 1;}
@@ -50,7 +65,7 @@ private:
 	Texture::Alpha m_alphaType;
 	Texture::ColorMask m_colorMask;
 	ColorSpace m_colorSpace;
-	std::unique_ptr<Converter> m_fallback;
+	Factory m_fallback;
 };
 
 } // namespace cuttlefish

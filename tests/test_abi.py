@@ -97,3 +97,12 @@ def test_query_accepts_exactly_the_pairs_the_reference_convert_tests_list(hip_li
             except api.CfhipError:
                 pass
     assert accepted == listed, (sorted(accepted - listed), sorted(listed - accepted))
+
+
+def test_header_compiles_as_plain_c99(tmp_path):
+    """integration/check_header.c: a C translation unit including include/cuttlefish_hip.h,
+    -std=c99 -pedantic-errors (the boundary is a C ABI, not a C++ one)."""
+    import subprocess
+    src = os.path.join(ROOT, "integration", "check_header.c")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic-errors", "-Wall", "-Wextra", "-Werror", "-c",
+                           "-I" + os.path.join(ROOT, "include"), src, "-o", str(tmp_path / "h.o")])
