@@ -52,6 +52,12 @@ struct cfhip_ctx {
 	void* h_pin[2] = {nullptr, nullptr};   // pinned strip slots of the pipelined host path
 	size_t pin_cap = 0;
 	hipEvent_t pin_free[2] = {nullptr, nullptr};   // slot's upload has left the host buffer
+	// d_src / d_out / d_batch are shared by every entry point, and calls on a caller's stream
+	// return without synchronising: the last asynchronous user records this event and a call on
+	// ANOTHER stream waits for it before touching the buffers (same-stream reuse is ordered anyway)
+	hipEvent_t staging_done = nullptr;
+	hipStream_t staging_stream = nullptr;
+	bool staging_busy = false;
 	std::map<int, void*> astc_tables; // per-format device tables (built on first use)
 	std::map<int, cfastc::AstcBlobHeader> astc_hdr;   // their headers (sizes the launch's dynamic LDS)
 	std::vector<hipEvent_t> events;   // start/stop pairs of the last call
@@ -449,6 +455,23 @@ int reserve(cfhip_ctx* ctx, void** buf, size_t* cap, size_t need)
 	return CFHIP_OK;
 }
 
+int staging_acquire(cfhip_ctx* ctx, hipStream_t stream)
+{
+	if (ctx->staging_busy && ctx->staging_stream != stream)
+		HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->staging_done, 0));
+	return CFHIP_OK;
+}
+
+int staging_release(cfhip_ctx* ctx, hipStream_t stream)
+{
+	if (!ctx->staging_done)
+		HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->staging_done, hipEventDisableTiming));
+	HIP_TRY(ctx, hipEventRecord(ctx->staging_done, stream));
+	ctx->staging_stream = stream;
+	ctx->staging_busy = true;
+	return CFHIP_OK;
+}
+
 // One launch for many surfaces (same format / pixel type): workgroups are numbered across
 // the surfaces, the kernel resolves its surface with a uniform binary search (cf_resolve).
 int batched_launch(cfhip_ctx* ctx, const std::vector<cf_kparams>& kps, const cfhip_params& p,
@@ -476,7 +499,10 @@ int batched_launch(cfhip_ctx* ctx, const std::vector<cf_kparams>& kps, const cfh
 		wg += e.wgx*kps[i].by;
 	}
 	const size_t bytes = entries.size()*sizeof(cf_batch_entry);
-	int rc = reserve(ctx, &ctx->d_batch, &ctx->batch_cap, bytes);
+	int rc = staging_acquire(ctx, stream);
+	if (rc != CFHIP_OK)
+		return rc;
+	rc = reserve(ctx, &ctx->d_batch, &ctx->batch_cap, bytes);
 	if (rc != CFHIP_OK)
 		return rc;
 	// pageable source: the runtime stages the copy before returning, so `entries` may die
@@ -485,7 +511,10 @@ int batched_launch(cfhip_ctx* ctx, const std::vector<cf_kparams>& kps, const cfh
 	kp.batch = static_cast<const cf_batch_entry*>(ctx->d_batch);
 	kp.nbatch = (uint32_t)entries.size();
 	kp.total_wg = wg;
-	return timed_launch(ctx, kp, p, pixel_type, stream);
+	rc = timed_launch(ctx, kp, p, pixel_type, stream);
+	if (rc != CFHIP_OK)
+		return rc;
+	return staging_release(ctx, stream);
 }
 
 // ---- pipelined host path ----------------------------------------
@@ -513,7 +542,9 @@ inline uint8_t host_unorm8(float f)
 	if (!(f > 0.0f))
 		return 0;
 	f = f > 1.0f ? 1.0f : f;
-	return (uint8_t)(f*255.0f + 0.5f);   // = round-half-away for non-negative values
+	// roundf, like cf_unorm8 on the device and std::round in the reference: f*255 + 0.5 rounds UP
+	// in float arithmetic for f*255 = 0.5 - 2^-25, where round() says 0
+	return (uint8_t)roundf(f*255.0f);
 }
 
 void stage_rows(const cfhip_surface& s, uint32_t y0, uint32_t y1, size_t row_bytes, bool quantise,
@@ -552,7 +583,9 @@ int encode_host_pipelined(cfhip_ctx* ctx, const cfhip_surface& s, const cfhip_pa
 	if (is_std_format(p.format))
 		strip_brows = (strip_brows + 3u) & ~3u;   // every strip's output stays 4-byte aligned
 	const size_t strip_bytes = (size_t)strip_brows*(size_t)fbh*dev_row;
-	int rc = reserve(ctx, &ctx->d_src, &ctx->src_cap, dev_row*(size_t)s.height);
+	int rc = staging_acquire(ctx, stream);
+	if (rc != CFHIP_OK) return rc;
+	rc = reserve(ctx, &ctx->d_src, &ctx->src_cap, dev_row*(size_t)s.height);
 	if (rc != CFHIP_OK) return rc;
 	rc = reserve(ctx, &ctx->d_out, &ctx->out_cap, (size_t)bx*by*(size_t)bs);
 	if (rc != CFHIP_OK) return rc;
@@ -604,6 +637,7 @@ int encode_host_pipelined(cfhip_ctx* ctx, const cfhip_surface& s, const cfhip_pa
 	HIP_TRY(ctx, hipMemcpyAsync(s.out, ctx->d_out, (size_t)bx*by*(size_t)bs, hipMemcpyDeviceToHost,
 		stream));
 	HIP_TRY(ctx, hipStreamSynchronize(stream));
+	ctx->staging_busy = false;
 	return CFHIP_OK;
 }
 
@@ -670,6 +704,7 @@ void cfhip_destroy(cfhip_ctx* ctx)
 		if (ctx->h_pin[i]) (void)hipHostFree(ctx->h_pin[i]);
 		if (ctx->pin_free[i]) (void)hipEventDestroy(ctx->pin_free[i]);
 	}
+	if (ctx->staging_done) (void)hipEventDestroy(ctx->staging_done);
 	if (ctx->d_batch) (void)hipFree(ctx->d_batch);
 	if (ctx->d_src) (void)hipFree(ctx->d_src);
 	if (ctx->d_out) (void)hipFree(ctx->d_out);
@@ -816,6 +851,8 @@ static int encode_impl(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n,
 				out_total += (items[g1].out_bytes + 255) & ~(size_t)255;
 				++g1;
 			}
+			rc = staging_acquire(ctx, stream);
+			if (rc != CFHIP_OK) return rc;
 			rc = reserve(ctx, &ctx->d_src, &ctx->src_cap, src_total);
 			if (rc != CFHIP_OK) return rc;
 			rc = reserve(ctx, &ctx->d_out, &ctx->out_cap, out_total);
@@ -857,6 +894,7 @@ static int encode_impl(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n,
 					static_cast<uint8_t*>(ctx->d_out) + out_off[i - g0], items[i].out_bytes,
 					hipMemcpyDeviceToHost, stream));
 			HIP_TRY(ctx, hipStreamSynchronize(stream));   // staging buffers are reused
+			ctx->staging_busy = false;
 			g0 = g1;
 		}
 	}
@@ -908,6 +946,7 @@ int cfhip_generate_mips_device(cfhip_ctx* ctx, const void* src, int src_pixel_ty
 	const void* prev = src;
 	int prev_type = src_pixel_type;
 	size_t prev_pitch = src_pitch_bytes;
+	bool used_staging = false;
 	uint32_t pw = width, ph = height;
 	for (uint32_t k = 1; k < levels; ++k) {
 		if (!dst_levels[k - 1])
@@ -925,8 +964,11 @@ int cfhip_generate_mips_device(cfhip_ctx* ctx, const void* src, int src_pixel_ty
 			const bool need_x = w != pw, need_y = h != ph;
 			if (need_x && need_y) {
 				const uint32_t tw = x_first ? w : pw, th = x_first ? ph : h;
-				int rc = reserve(ctx, &ctx->d_src, &ctx->src_cap, (size_t)tw*th*16u);
+				int rc = staging_acquire(ctx, stream);
 				if (rc != CFHIP_OK) return rc;
+				rc = reserve(ctx, &ctx->d_src, &ctx->src_cap, (size_t)tw*th*16u);
+				if (rc != CFHIP_OK) return rc;
+				used_staging = true;
 				HIP_TRY(ctx, cfhip_launch_mip_pass(prev, prev_type, prev_pitch, x_first ? pw : ph, ctx->d_src, tw, th,
 					x_first ? 1 : 0, filter, srgb, 0, stream));
 				HIP_TRY(ctx, cfhip_launch_mip_pass(ctx->d_src, CFHIP_PIXEL_RGBA32F, (size_t)tw*16u, x_first ? ph : pw,
@@ -941,8 +983,14 @@ int cfhip_generate_mips_device(cfhip_ctx* ctx, const void* src, int src_pixel_ty
 		prev_pitch = (size_t)w*16u;
 		pw = w; ph = h;
 	}
-	if (!stream_)
+	if (used_staging) {
+		const int rc = staging_release(ctx, stream);
+		if (rc != CFHIP_OK) return rc;
+	}
+	if (!stream_) {
 		HIP_TRY(ctx, hipStreamSynchronize(stream));
+		ctx->staging_busy = false;
+	}
 	return CFHIP_OK;
 }
 

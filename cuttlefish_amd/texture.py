@@ -140,6 +140,11 @@ class Texture:
         params = api.make_params(format, type, quality, alpha_type, color_mask,
                                  self._color_space)
         flat = [im for level in self._images for im in level]
+        # the reference converts every image to RGBAF before it reaches a converter
+        # (Converter.h:52-56): half-float images are bit-exact sources for BC6H and the
+        # uncompressed packers, every other block kernel takes them as floats
+        if not (format == Format.BC6H or int(format) < int(Format.BC1_RGB)):
+            flat = [im.astype(np.float32) if im.dtype == np.float16 else im for im in flat]
         try:
             outs = self._ctx.encode(flat, params)
         except api.CfhipError as e:

@@ -79,3 +79,16 @@ def test_astc_hdr_profile_request_is_refused_not_clamped():
     t = Texture(36, 24)
     assert t.set_image(img) and not t.convert(Format.ASTC_6x6, UF)
     assert not t.converted()
+
+
+def test_half_float_images_convert_to_every_block_format():
+    """The reference turns every image into RGBAF first, so a float16 image is a legal source
+    for every (format, type) pair -- not only for BC6H."""
+    rng = np.random.default_rng(9)
+    img16 = rng.random((16, 16, 4)).astype(np.float16)
+    for fmt, typ in ((Format.BC7, U), (Format.BC1_RGB, U), (Format.ETC2_R8G8B8, U),
+                     (Format.ASTC_6x6, U), (Format.BC6H, UF), (Format.R8G8B8A8, U)):
+        a, b = Texture(16, 16), Texture(16, 16)
+        assert a.set_image(img16) and b.set_image(img16.astype(np.float32))
+        assert a.convert(fmt, typ) and b.convert(fmt, typ), fmt
+        assert np.array_equal(np.asarray(a.data()), np.asarray(b.data())), fmt
