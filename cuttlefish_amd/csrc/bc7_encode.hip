@@ -13,9 +13,13 @@
 //     set, precision, p-bit kind, index width and subset mask are per-lane values (fit_lane:
 //     integer statistics -> covariance -> principal axis -> extremes -> quantise -> exhaustive
 //     selectors via v_dot4_u32_u8 -> closed-form least-squares refit rounds).
-//   * up to Normal a block's candidates fill 32 lanes (mode 6, mode 5 x rotations, modes 1/3
-//     or 7 on their best partitions) and two neighbouring blocks share a wavefront; High uses
-//     64 lanes and a second stream for the three-subset modes; Highest refits every partition.
+//   * up to High a block's candidates fill 32 lanes (mode 6, mode 5 x rotations, modes 1/3
+//     or 7 on their best partitions) and two neighbouring blocks share a wavefront; Highest uses
+//     64 lanes (mode 4, 16 two-subset partitions) and a second stream for the three-subset modes.
+//   * High / Highest then perturb the winner ("uber" levels of bc7enc, S3tcConverter.cpp:200-215):
+//     lane = (fit of the winner, one of 16 +-1 endpoint / p-bit moves), exact error by the same
+//     selector assignment, best move per fit per round -- the extra work is extra LANES of one
+//     more assignment pass, not extra candidates walked in sequence.
 //   * partitions are ranked once per subset count by a residual estimator (subset_residual)
 //     and the best are taken by an iterated group minimum (DPP rows + v_readlane).
 //   * all error arithmetic is integer; a lane keeps (error, id) in registers and its best
@@ -92,8 +96,9 @@ struct Cand {
 };
 
 // A lane's best candidate so far lives in LDS (field-major, one column per thread):
-// only (error, id) stay in registers.  15 words: q[6], pb, w[4], w2[4].
-#define CF_BC7_CAND_WORDS 15
+// only (error, id) stay in registers.  18 words: q[6], pb, w[4], w2[4], the errors of its (up to
+// three) fits -- what the perturbation rounds of High / Highest compare against.
+#define CF_BC7_CAND_WORDS 18
 __device__ __forceinline__ void cand_store(uint32_t* slot, const Cand& c)
 {
 #pragma unroll
@@ -762,7 +767,7 @@ __device__ __forceinline__ float subset_residual(const Tex& tx, uint32_t mask)
 
 // Encode one block with the whole wavefront.  tp: the block's 16 texels in LDS
 // (colour mask already applied), identical for every lane.
-template <bool UNITW, bool EXH>
+template <bool UNITW, bool WIDE>
 __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint32_t* plan, uint32_t b,
 	bool pair, uint32_t* cslot, const cf_kparams& kp, uint32_t lane0)
 {
@@ -778,8 +783,10 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	const bool any_alpha = pair ? abal != 0ull : has_alpha;
 	// Low runs Normal's candidate set without the refit round (oracle: quality_budget): `quality`
 	// below selects the LAYOUT, so Low is mapped onto Normal's
-	const uint32_t iters = (0x32100u >> (4u*(kp.quality < 4u ? kp.quality : 4u))) & 15u;   // refit rounds 0,0,1,2,3
-	const uint32_t quality = kp.quality == 1u ? 2u : kp.quality;
+	const uint32_t iters = (0x21100u >> (4u*(kp.quality < 4u ? kp.quality : 4u))) & 15u;   // refit rounds 0,0,1,1,2
+	// WIDE (Highest): the 64-lane layout with both streams.  Otherwise the 32-lane layouts: Low and
+	// High walk Normal's candidate set (High adds a refit round and the perturbation rounds below)
+	const uint32_t quality = WIDE ? 3u : ((kp.quality == 1u || kp.quality >= 3u) ? 2u : kp.quality);
 	const uint32_t wt[4] = {kp.wt[0], kp.wt[1], kp.wt[2], kp.wt[3]};
 
 	uint32_t best_err = 0xFFFFFFFFu, best_id = 0x7FFFFFFFu;   // payload fields: cslot (LDS)
@@ -803,18 +810,18 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	// The partitions come from phase 1: every partition is scored once per subset count with
 	// the residual estimator and the best are taken in (score, index) order.
 	// Highest instead refits every partition (below), after a stream 0 without partitions.
-	const bool lay32 = !EXH && quality <= 2u;
+	const bool lay32 = !WIDE;
 	const uint32_t hl = lay32 ? (lane & 31u) : lane;
 	const bool slot_ok = !lay32 || pair || lane < 32u;
 	bool solved = false;
 	{
-		const uint32_t nstreams = (!EXH && !has_alpha && quality >= 3u) ? 2u : 1u;
+		const uint32_t nstreams = (WIDE && !has_alpha) ? 2u : 1u;
 		const Tex txp = make_tex(tp, pl, 0u, has_alpha ? 15u : 7u);   // partition fits: no rotation
 #pragma unroll 1
 		for (uint32_t st = 0; st < nstreams && !solved; ++st) {
 			asm volatile("" : "+v"(lane));   // roles are recomputed per stream, not kept
 			const uint32_t ns = 2u + st;
-			const bool parts = !EXH && quality >= 1u;
+			const bool parts = quality >= 1u;
 			// partition lanes: first lane, slots of the first mode, slots in all
 			uint32_t pfirst, nper0, nslots;
 			if (lay32) {
@@ -978,6 +985,11 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 					cslot[5*CF_WG_THREADS] = vecp ? (a12 & 0xFF000000u) : ((plane && st == 1u) ? a12 : 0u);
 					cslot[6*CF_WG_THREADS] = lf.pb | (plane ? (pb1 << 2) : 0u) |
 						((plane && st == 1u) ? (pb2 << 4) : 0u);
+					// errors of the candidate's fits: subset 0 / vector plane / mode 6, then subset 1 or
+					// the scalar plane, then subset 2
+					cslot[15*CF_WG_THREADS] = lf.err;
+					cslot[16*CF_WG_THREADS] = plane ? e1 : (vecp ? e2 : 0u);
+					cslot[17*CF_WG_THREADS] = (plane && st == 1u) ? e2 : 0u;
 				}
 			}
 #pragma unroll
@@ -993,65 +1005,10 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			// A zero-error candidate cannot be beaten by a later one (ids grow with the
 			// streams), so the remaining work may be skipped without changing the payload.
 			solved = __ballot(best_err == 0u) != 0ull;
-		}
-	}
-
-	// ---- Highest: every partition of every mode gets all the refit rounds (lane = partition) ----
-	if (EXH && !solved) {
-		// Highest: lane = partition, every partition gets all the refit rounds
-		uint32_t modes, nmodes;
-		if (has_alpha) { modes = 7u; nmodes = 1u; }
-		else { modes = 1u | (3u << 4) | (0u << 8) | (2u << 12); nmodes = 4u; }
-		const uint32_t p2 = k_part2[lane], p3 = k_part3[lane];
-		uint32_t m30 = 0, m31 = 0, m32 = 0;
-#pragma unroll
-		for (int i = 0; i < 16; ++i) {
-			const uint32_t sb = (p3 >> (2*i)) & 3u;
-			m30 |= (sb == 0u ? 1u : 0u) << i;
-			m31 |= (sb == 1u ? 1u : 0u) << i;
-			m32 |= (sb == 2u ? 1u : 0u) << i;
-		}
-		for (uint32_t mi = 0; mi < nmodes && !solved; ++mi) {
-			const uint32_t mode = (modes >> (4u*mi)) & 15u;
-			uint32_t ns, cb, ab, pbk, ib, npart, idbase;
-			switch (mode) {
-				case 1: ns = 2; cb = 6; ab = 0; pbk = 2; ib = 3; npart = 64; idbase = 64; break;
-				case 3: ns = 2; cb = 7; ab = 0; pbk = 1; ib = 2; npart = 64; idbase = 128; break;
-				case 0: ns = 3; cb = 4; ab = 0; pbk = 1; ib = 3; npart = 16; idbase = 192; break;
-				case 2: ns = 3; cb = 5; ab = 0; pbk = 0; ib = 2; npart = 64; idbase = 256; break;
-				default: ns = 2; cb = 5; ab = 5; pbk = 1; ib = 2; npart = 64; idbase = 320; break;
-			}
-			const Tex tx = make_tex(tp, pl, 0u, ab ? 15u : 7u);   // opaque modes do not code alpha
-			const uint32_t wv[4] = {wt[0], wt[1], wt[2], ab ? wt[3] : 0u};
-			Cand c;
-			c.err = 0;
-			c.id = idbase + lane;
-#pragma unroll
-			for (int k = 0; k < 6; ++k) c.q[k] = 0;
-			c.pb = 0;
-#pragma unroll
-			for (int k = 0; k < 4; ++k) { c.w[k] = 0; c.w2[k] = 0; }
-			for (uint32_t s = 0; s < ns; ++s) {
-				uint32_t mask;
-				if (ns == 2u)
-					mask = s ? p2 : (~p2 & 0xFFFFu);
-				else
-					mask = s == 0u ? m30 : (s == 1u ? m31 : m32);
-				LaneFit f;
-				fit_lane<UNITW>(tx, mask, false, 0u, cb, ab, pbk, ib, iters, wv, false, f);
-				c.err += f.err;
-				if (s == 0u) { c.q[0] = f.q0; c.q[1] = f.q1; c.pb |= f.pb; }
-				else if (s == 1u) { c.q[2] = f.q0; c.q[3] = f.q1; c.pb |= f.pb << 2; }
-				else { c.q[4] = f.q0; c.q[5] = f.q1; c.pb |= f.pb << 4; }
-#pragma unroll
-				for (int k = 0; k < 4; ++k) c.w[k] |= f.w[k];
-			}
-			if (lane < npart && c.err < best_err) {
-				best_err = c.err;
-				best_id = c.id;
-				cand_store(cslot, c);
-			}
-			solved = __ballot(best_err == 0u) != 0ull;
+			// the three-subset stream only for blocks whose best candidate so far leaves an error
+			// of at least 48 (oracle: same rule); one block per wave here, so this is uniform
+			if (WIDE && cf_wave_min_u32(best_err) < 48u)
+				solved = true;
 		}
 	}
 
@@ -1062,7 +1019,156 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	const uint32_t gmask = pair ? (h ? (uint32_t)(bal >> 32) : (uint32_t)bal) : 0u;
 	const uint32_t wl = pair ? hbase + (uint32_t)__ffs((int)gmask) - 1u
 		: (uint32_t)__ffsll((long long)bal) - 1u;   // winner lane (unique key in its group)
-	return pack_block_group(cslot - lane0 + wl, (uint32_t)kmin, lane0, pair);
+	uint32_t* wc = cslot - lane0 + wl;              // the winner's column
+
+	// ---- High / Highest: endpoint perturbation of the winner (oracle: uber_refine) ----
+	// lane = (fit of the winner, move slot): 16 slots per fit -- endpoint m >> 3, channel (m >> 1) & 3,
+	// direction m & 1: +-1 on that quantised field, the slots of a channel the fit does not code
+	// flip p-bits -- scored by the exhaustive selector assignment; per fit (= per DPP row of 16
+	// lanes; mode 6 spreads its 16 palette entries over lane pairs and fills two rows) the best
+	// move is applied when it lowers the fit's error.  Fits are independent, so all of them move
+	// in the same round.
+	const uint32_t uber = kp.quality >= 4u ? 3u : (kp.quality == 3u ? 2u : 0u);
+	if (uber) {
+		__builtin_amdgcn_wave_barrier();
+		const uint32_t id = (uint32_t)kmin;
+		uint32_t mode, part = 0, rot = 0, isel = 0;
+		if (id == 0u) mode = 6;
+		else if (id < 5u) { mode = 5; rot = id - 1u; }
+		else if (id < 13u) { mode = 4; rot = (id - 5u) & 3u; isel = (id - 5u) >> 2; }
+		else if (id < 128u) { mode = 1; part = id - 64u; }
+		else if (id < 192u) { mode = 3; part = id - 128u; }
+		else if (id < 256u) { mode = 0; part = id - 192u; }
+		else if (id < 320u) { mode = 2; part = id - 256u; }
+		else { mode = 7; part = id - 320u; }
+		const uint32_t ns = (0x21112323u >> (4u*mode)) & 15u;
+		const bool m6 = mode == 6u, planes45 = mode == 4u || mode == 5u;
+		const uint32_t nfits = planes45 ? 2u : ns;
+		const uint32_t kf = m6 ? 0u : (hl >> 4), mv = m6 ? (hl >> 1) & 15u : (hl & 15u);
+		const bool act = slot_ok && hl < 64u && (m6 ? hl < 32u : kf < nfits) && (uint32_t)(kmin >> 32) != 0u;
+		uint32_t cb, ab, pbk, ib, mask = 0xFFFFu, chm;
+		const bool sca = planes45 && kf == 1u;
+		if (planes45) {
+			const uint32_t ibc = mode == 5u ? 2u : (isel ? 3u : 2u), iba = mode == 5u ? 2u : (isel ? 2u : 3u);
+			cb = sca ? 0u : (mode == 5u ? 7u : 5u);
+			ab = sca ? (mode == 5u ? 8u : 6u) : 0u;
+			ib = sca ? iba : ibc;
+			pbk = 0;
+			chm = sca ? 8u : 7u;
+		} else {
+			cb = (0x57757564u >> (4u*mode)) & 15u;
+			ab = (0x57860000u >> (4u*mode)) & 15u;
+			pbk = (0x11001021u >> (4u*mode)) & 15u;
+			ib = (0x24222233u >> (4u*mode)) & 15u;
+			chm = ab ? 15u : 7u;
+			if (ns == 2u) {
+				const uint32_t p2 = k_part2[part];
+				mask = kf ? p2 : (~p2 & 0xFFFFu);
+			} else if (ns == 3u) {
+				const uint32_t p3 = k_part3[part];
+				mask = 0;
+#pragma unroll
+				for (int i = 0; i < 16; ++i)
+					mask |= (((p3 >> (2*i)) & 3u) == kf ? 1u : 0u) << i;
+			}
+		}
+		uint32_t wlr[4] = {wt[0], wt[1], wt[2], wt[3]};
+		if (!UNITW && rot) {
+			const uint32_t t3 = wlr[3];
+			if (rot == 1u) { wlr[3] = wlr[0]; wlr[0] = t3; }
+			else if (rot == 2u) { wlr[3] = wlr[1]; wlr[1] = t3; }
+			else { wlr[3] = wlr[2]; wlr[2] = t3; }
+		}
+		const uint32_t wv[4] = {(chm & 1u) ? wlr[0] : 0u, (chm & 2u) ? wlr[1] : 0u,
+			(chm & 4u) ? wlr[2] : 0u, (chm & 8u) ? wlr[3] : 0u};
+		const Tex tx = make_tex(tp, pl, rot, chm);
+		// sum over the fit's texels of sum_c w_c p_c^2 (the constant part of its error)
+		uint32_t pp_sum = 0;
+#pragma unroll 1
+		for (uint32_t r = 0; r < 4u; ++r) {
+			uint32_t P[4];
+			planes<true>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
+			const uint32_t m4 = bytemask4((mask >> (4u*r)) & 15u);
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const uint32_t d = __builtin_amdgcn_udot4(P[c] & m4, P[c], 0u, false);
+				pp_sum += UNITW ? d : __umul24(wv[c], d);
+			}
+		}
+		const uint32_t S = pbk ? 1u : 0u;
+		const uint32_t fq0 = planes45 ? (sca ? 4u : 0u) : 2u*kf, fq1 = fq0 + 1u;   // column words of the fit's fields
+#pragma unroll 1
+		for (uint32_t r = 0; r < uber; ++r) {
+			const uint32_t q0 = wc[fq0*CF_WG_THREADS], q1 = wc[fq1*CF_WG_THREADS];
+			const uint32_t pbv = planes45 ? 0u : (wc[6*CF_WG_THREADS] >> (2u*kf)) & 3u;
+			const uint32_t cur_err = wc[(15u + kf)*CF_WG_THREADS];
+			const uint32_t e = mv >> 3, ch = (mv >> 1) & 3u, up = mv & 1u;
+			const uint32_t bits_c = ch < 3u ? cb : ab;
+			bool valid = act;
+			uint32_t nq0 = q0, nq1 = q1, npb = pbv;
+			if (bits_c) {
+				const uint32_t src = e ? q1 : q0;
+				const int nv = (int)((src >> (8u*ch)) & 255u) + (up ? 1 : -1);
+				valid = valid && nv >= 0 && nv <= (int)((1u << bits_c) - 1u);
+				const uint32_t nw = (src & ~(255u << (8u*ch))) | (((uint32_t)nv & 255u) << (8u*ch));
+				nq0 = e ? q0 : nw;
+				nq1 = e ? nw : q1;
+			} else if (pbk == 1u && e == 0u)
+				npb = pbv ^ (1u << up);
+			else if (pbk == 2u && e == 0u && up == 0u)
+				npb = pbv ^ 3u;
+			else
+				valid = false;
+			LaneFit f;
+			f.q0 = nq0; f.q1 = nq1; f.pb = npb; f.err = 0; f.e0 = 0; f.e1 = 0;
+#pragma unroll
+			for (uint32_t c = 0; c < 4u; ++c) {
+				const uint32_t bc = c < 3u ? cb : ab;
+				if (bc) {       // (uniform per lane group of a fit; a select chain otherwise)
+					f.e0 |= dequant((((nq0 >> (8u*c)) & 255u) << S) | (npb & S), bc + S) << (8u*c);
+					f.e1 |= dequant((((nq1 >> (8u*c)) & 255u) << S) | ((npb >> 1) & S), bc + S) << (8u*c);
+				}
+			}
+#pragma unroll
+			for (int k = 0; k < 4; ++k) f.w[k] = 0;
+			float x0[4], x1[4];
+			bool okk;
+			assign_lsq_lane<UNITW>(tx, mask, m6, hl & 1u, ib, wv, pp_sum, false, f, x0, x1, okk);
+			uint32_t key = valid ? ((f.err << 4) | mv) : 0xFFFFFFFFu;
+			uint32_t fitmin = cf_row_min_u32(key);
+			if (m6) {
+				const uint32_t other = (uint32_t)__shfl_xor((int)fitmin, 16, 64);
+				fitmin = other < fitmin ? other : fitmin;
+			}
+			const bool win = valid && key == fitmin && f.err < cur_err && (!m6 || (hl & 1u) == 0u);
+			// one fit at a time: the fits share the p-bit word and the weight words of the column
+#pragma unroll 1
+			for (uint32_t k = 0; k < 3u; ++k) {
+				if (win && kf == k) {
+					wc[fq0*CF_WG_THREADS] = nq0;
+					wc[fq1*CF_WG_THREADS] = nq1;
+					wc[(15u + kf)*CF_WG_THREADS] = f.err;
+					if (!planes45) {
+						const uint32_t pw = wc[6*CF_WG_THREADS];
+						wc[6*CF_WG_THREADS] = (pw & ~(3u << (2u*kf))) | (npb << (2u*kf));
+					}
+#pragma unroll
+					for (uint32_t rr = 0; rr < 4u; ++rr) {
+						if (sca)
+							wc[(11u + rr)*CF_WG_THREADS] = f.w[rr];
+						else {
+							const uint32_t mb = bytemask4((mask >> (4u*rr)) & 15u);
+							wc[(7u + rr)*CF_WG_THREADS] = (wc[(7u + rr)*CF_WG_THREADS] & ~mb) | f.w[rr];
+						}
+					}
+				}
+				__builtin_amdgcn_wave_barrier();
+			}
+			if (__ballot(win) == 0ull)
+				break;       // no fit of any block of this wave moved: later rounds would repeat this one
+		}
+	}
+	return pack_block_group(wc, (uint32_t)kmin, lane0, pair);
 }
 
 } // namespace
@@ -1074,9 +1180,9 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 #ifndef CF_BC7_WAVES
 #define CF_BC7_WAVES 3
 #endif
-template <int PIX, bool UNITW, bool EXH>
+template <int PIX, bool UNITW, bool WIDE>
 __global__ void __launch_bounds__(CF_WG_THREADS)
-__attribute__((amdgpu_waves_per_eu(EXH ? 3 : CF_BC7_WAVES, EXH ? 3 : CF_BC7_WAVES)))
+__attribute__((amdgpu_waves_per_eu(CF_BC7_WAVES, CF_BC7_WAVES)))
 cfhip_bc7_encode_kernel(cf_kparams kp)
 {
 	__shared__ uint32_t cands[CF_BC7_CAND_WORDS*CF_WG_THREADS];
@@ -1099,18 +1205,18 @@ cfhip_bc7_encode_kernel(cf_kparams kp)
 	__syncthreads();
 
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	// the wave's 4 blocks; up to Normal two neighbouring blocks share one pass
+	// the wave's 4 blocks; up to High two neighbouring blocks share one pass
 	for (uint32_t j = 0; j < 4u;) {
 		const uint32_t b = wave*4u + j;
 		if (bx0 + b >= kp.bx)
 			break;
-		const bool pair = !EXH && kp.quality <= 2u && j < 3u && bx0 + b + 1u < kp.bx &&
+		const bool pair = !WIDE && j < 3u && bx0 + b + 1u < kp.bx &&
 			!(CF_BC7_ABLATE & 4);
 		// opaque copy: keeps the (many) lane-role values of encode_blocks from being hoisted
 		// out of this loop and held in registers across all phases
 		uint32_t ln = lane;
 		asm volatile("" : "+v"(ln));
-		const uint4 blk = encode_blocks<UNITW, EXH>(tile, plan, b, pair, cands + threadIdx.x, kp, ln);
+		const uint4 blk = encode_blocks<UNITW, WIDE>(tile, plan, b, pair, cands + threadIdx.x, kp, ln);
 		if (pair) {
 			if ((lane & 31u) == 0u)
 				outb[b + (lane >> 5)] = blk;
@@ -1139,7 +1245,7 @@ extern "C" hipError_t cfhip_launch_bc7(const cf_kparams* kp, int pixel_type, int
 	if (kp->batch)
 		grid = dim3(kp->total_wg, 1, 1);
 	dim3 block(CF_WG_THREADS, 1, 1);
-	const bool exh = kp->quality >= 4u;   // Highest: every partition gets every refit round
+	const bool exh = kp->quality >= 4u;   // Highest: the wide (64-lane, two-stream) candidate set
 #define CF_BC7_LAUNCH(P, U, E) \
 	hipLaunchKernelGGL((cfhip_bc7_encode_kernel<P, U, E>), grid, block, 0, stream, *kp)
 	if (pixel_type == 0) {

@@ -493,6 +493,99 @@ static void eval_candidate(const int px[16][4], const int wt[4], int id, int ite
 	}
 }
 
+
+/* ---- endpoint perturbation of the winner ("uber" levels of bc7enc, S3tcConverter.cpp:200-215) ----
+ * Every fit of the winning candidate (subset, or the vector / scalar plane of modes 4 and 5) has 16
+ * move slots m: endpoint m >> 3, channel (m >> 1) & 3, direction m & 1 -- +-1 on that quantised
+ * field; the slots of a channel the fit does not code flip p-bits instead (endpoint-0 slots:
+ * p-bit of endpoint `direction` for per-endpoint p-bits, both for a shared p-bit).  A round
+ * scores all 16 moves of every fit with the exhaustive selector assignment and applies, per fit,
+ * the best one if it lowers the fit's error (ties: lowest slot).  On the GPU lane = (fit, slot). */
+static void fit_geometry(const cand* c, int which, int bits[4], int* pbk, int* ib, unsigned* mask)
+{
+	const cfo_bc7_mode* m = &cfo_bc7_modes[c->mode];
+	if (c->mode == 4 || c->mode == 5) {
+		int cb = c->mode == 5 ? 7 : 5, ab = c->mode == 5 ? 8 : 6;
+		int ibc = c->mode == 5 ? 2 : (c->isel ? 3 : 2), iba = c->mode == 5 ? 2 : (c->isel ? 2 : 3);
+		bits[0] = bits[1] = bits[2] = which ? 0 : cb;
+		bits[3] = which ? ab : 0;
+		*ib = which ? iba : ibc;
+		*pbk = 0;
+		*mask = 0xFFFF;
+		return;
+	}
+	bits[0] = bits[1] = bits[2] = m->cb;
+	bits[3] = m->ab;
+	*pbk = m->pbits;
+	*ib = m->ib;
+	*mask = 0;
+	for (int i = 0; i < 16; ++i) {
+		int sb = m->ns == 1 ? 0 : (m->ns == 2 ? (int)((cfo_part2[c->part] >> i) & 1) :
+			(int)((cfo_part3[c->part] >> (2*i)) & 3));
+		if (sb == which)
+			*mask |= 1u << i;
+	}
+}
+
+static void uber_refine(const int px_in[16][4], const int wt_in[4], cand* c, int rounds)
+{
+	int px[16][4], wt[4];
+	memcpy(px, px_in, sizeof(px));
+	memcpy(wt, wt_in, sizeof(wt));
+	int planes = c->mode == 4 || c->mode == 5;
+	if (planes && c->rot) {
+		for (int i = 0; i < 16; ++i) {
+			int t = px[i][3];
+			px[i][3] = px[i][c->rot - 1];
+			px[i][c->rot - 1] = t;
+		}
+		int t = wt[3];
+		wt[3] = wt[c->rot - 1];
+		wt[c->rot - 1] = t;
+	}
+	int nfits = planes ? 2 : c->ns;
+	for (int r = 0; r < rounds && c->err != 0; ++r) {
+		int any = 0;
+		for (int k = 0; k < nfits; ++k) {
+			sfit* f = planes ? (k ? &c->sca : &c->vec[0]) : &c->vec[k];
+			int bits[4], pbk, ib;
+			unsigned mask;
+			fit_geometry(c, k, bits, &pbk, &ib, &mask);
+			sfit bestf = *f;
+			for (int m = 0; m < 16; ++m) {
+				int e = m >> 3, ch = (m >> 1) & 3, up = m & 1;
+				sfit t = *f;
+				if (bits[ch]) {
+					int q = t.q[e][ch] + (up ? 1 : -1);
+					if (q < 0 || q > (1 << bits[ch]) - 1)
+						continue;
+					t.q[e][ch] = q;
+				} else if (pbk == 1 && e == 0)
+					t.pb[up] ^= 1;
+				else if (pbk == 2 && e == 0 && up == 0) {
+					t.pb[0] ^= 1;
+					t.pb[1] ^= 1;
+				} else
+					continue;
+				for (int ee = 0; ee < 2; ++ee)
+					for (int cc = 0; cc < 4; ++cc)
+						t.e[ee][cc] = !bits[cc] ? 0 : (pbk ? dequant((t.q[ee][cc] << 1) | t.pb[ee], bits[cc] + 1)
+							: dequant(t.q[ee][cc], bits[cc]));
+				assign(px, wt, mask, bits, ib, &t);
+				if (t.err < bestf.err)
+					bestf = t;
+			}
+			if (bestf.err < f->err) {
+				c->err -= f->err - bestf.err;
+				*f = bestf;
+				any = 1;
+			}
+		}
+		if (!any)
+			break;
+	}
+}
+
 /* ---- bit packing ---- */
 typedef struct { uint8_t* p; unsigned pos; } bitwr;
 
@@ -596,8 +689,10 @@ static void pack(const cand* c, uint8_t out[16])
 			put(&b, (unsigned)sec[i], (unsigned)m->ib2 - (i == 0 ? 1u : 0u));
 }
 
-/* Search budget per Texture::Quality (S3tcConverter.cpp:170-227 / :600-620). */
-typedef struct { int iters; int m6only; int two; int mode3; int three; int rot; } budget;
+/* Search budget per Texture::Quality (S3tcConverter.cpp:170-227 / :600-620).  uber = rounds of
+ * endpoint perturbation of the winner (bc7enc's m_uber_level is 0 up to Normal and 4 from High,
+ * :200-215). */
+typedef struct { int iters; int m6only; int two; int mode3; int three; int rot; int uber; } budget;
 
 static budget quality_budget(int quality)
 {
@@ -605,11 +700,19 @@ static budget quality_budget(int quality)
 	switch (quality) {
 		/* refit rounds: the second round is worth ~0.004 dB on photographic content, so it is
 		 * only spent from High up */
-		case 0: b = (budget){0, 1, 0, 0, 0, 0}; break;
-		case 1: b = (budget){0, 0, 1, 1, 0, 1}; break;   /* Low: Normal's candidate set without the refit round */
-		case 2: b = (budget){1, 0, 1, 1, 0, 1}; break;
-		case 3: b = (budget){2, 0, 1, 1, 1, 1}; break;
-		default: b = (budget){3, 0, 1, 1, 1, 1}; break;
+		case 0: b = (budget){0, 1, 0, 0, 0, 0, 0}; break;
+		case 1: b = (budget){0, 0, 1, 1, 0, 1, 0}; break;   /* Low: Normal's candidate set without the refit round */
+		case 2: b = (budget){1, 0, 1, 1, 0, 1, 0}; break;
+		/* High: Normal's candidate set (half a wavefront per block), then two perturbation rounds
+		 * on the winner: +0.24 dB over Normal on the bench content, where the wider mode set High
+		 * used to walk bought +0.03 dB for four times the work (a second refit round before the
+		 * perturbation is worth 0.000 dB: the perturbation finds what it would have found) */
+		case 3: b = (budget){1, 0, 1, 1, 0, 1, 2}; break;
+		/* Highest: the wide set (mode 4, 16 two-subset partitions, the three-subset modes), two
+		 * refit rounds, three perturbation rounds (a third refit round or a fourth perturbation
+		 * round moves PSNR by 0.001 dB).  Refitting EVERY partition (what this level did before)
+		 * was worth 0.015 dB over this and cost five times the time. */
+		default: b = (budget){2, 0, 1, 1, 1, 1, 3}; break;
 	}
 	return b;
 }
@@ -662,7 +765,7 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 		/* mode 4 (rotation x index selector): from High up (worth 0.012 dB on opaque and
 		 * 0.006 dB on alpha-carrying content; leaving it out lets the kernel fit a block's
 		 * whole candidate set into half a wavefront) */
-		if (b.rot && p->quality >= 3)
+		if (b.rot && b.three)
 			for (int k = 0; k < 8; ++k)
 				TRY(5 + k);
 		/* Partitioned modes.  Highest refits every partition of every mode.  Below that
@@ -677,20 +780,13 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 		 *   three-subset group: modes 0 (its 16 partitions) + 2 with 5 partitions each (High)
 		 * The HIP kernel runs phase 1 with lane = partition and phase 2 of a whole group
 		 * in one pass with lane = (mode, rank, subset, row pair). */
-		if (p->quality >= 4) {
-			if (has_alpha) {
-				for (int k = 0; k < 64 && best.err != 0; ++k)
-					TRY(320 + k);
-			} else {
-				static const int bases[4] = {64, 128, 192, 256}, counts[4] = {64, 64, 16, 64};
-				for (int mi = 0; mi < 4 && best.err != 0; ++mi)
-					for (int k = 0; k < counts[mi]; ++k)
-						TRY(bases[mi] + k);
-			}
-		} else if (b.two) {
+		if (b.two) {
 			const int bits[4] = {1, 1, 1, has_alpha};
 			const int ngroups = (!has_alpha && b.three) ? 2 : 1;
-			for (int g = 0; g < ngroups && best.err != 0; ++g) {
+			/* the three-subset modes are only tried on blocks the candidates so far leave with an
+			 * error of at least 48 (0.75 per channel-texel): three colour regions in a block that
+			 * already codes this well are rare, and the stream costs a third of Highest's time */
+			for (int g = 0; g < ngroups && best.err != 0 && (g == 0 || best.err >= 48u); ++g) {
 				uint32_t key0[64];
 				for (int k = 0; k < 64; ++k) {
 					float sc = partition_score(px, 2 + g, k, bits);
@@ -729,5 +825,7 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 	}
 #undef TRY
 #undef BETTER
+	if (b.uber)
+		uber_refine(px, wt, &best, b.uber);
 	pack(&best, out);
 }
