@@ -45,7 +45,8 @@ struct RgbOpts {
 	bool allow_indiv, allow_planar, punch, a1;
 	uint32_t active, transparent;
 	int wt[3];
-	int radius;
+	int radius;    // move rounds of the T / H search
+	int walk;      // base-colour walk of the half search: 1 / 7 / 27 / 125 / 125 + 2 descent steps
 	bool refine;   // false: Lowest -- no planar move rounds, no T/H modes
 };
 
@@ -546,22 +547,58 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 	const bool unitw = o.wt[0] == 1 && o.wt[1] == 1 && o.wt[2] == 1;   // uniform
 	const int tma = o.punch ? 0 : k_etc_mod[t][0], tmb = k_etc_mod[t][1];
 	if (!fam4 || o.allow_indiv) {
-		const int r = o.radius;
-		uint32_t cand = 0;
-		for (int dr = -r; dr <= r; ++dr)
-			for (int dg = -r; dg <= r; ++dg)
-				for (int db = -r; db <= r; ++db, ++cand) {
-					const int q[3] = {clampi(q0[0] + dr, 0, maxq), clampi(q0[1] + dg, 0, maxq),
-						clampi(q0[2] + db, 0, maxq)};
+		// candidates in id order (oracle: search_half): the quantised half mean; + its six axis
+		// neighbours; the 3x3x3 cube; the 5x5x5 cube; out-of-range coordinates clamp
+		const int walk = o.walk;
+		const int ncand = walk == 0 ? 1 : (walk == 1 ? 7 : (walk == 2 ? 27 : 125));
+		const int r = walk == 2 ? 1 : 2;
+		int o0 = -r, o1 = -r, o2 = -r;      // cube odometer (blue fastest): no divisions in the walk
+#pragma unroll 1
+		for (int cand = 0; cand < ncand; ++cand) {
+			int d0 = 0, d1 = 0, d2 = 0;
+			if (walk == 1) {
+				const int ax = (cand - 1) >> 1, dd = cand == 0 ? 0 : (((cand - 1) & 1) ? 1 : -1);
+				d0 = ax == 0 ? dd : 0; d1 = ax == 1 ? dd : 0; d2 = ax == 2 ? dd : 0;
+			} else if (walk >= 2) {
+				d0 = o0; d1 = o1; d2 = o2;
+				++o2;
+				if (o2 > r) { o2 = -r; ++o1; }
+				if (o1 > r) { o1 = -r; ++o0; }
+			}
+			const int q[3] = {clampi(q0[0] + d0, 0, maxq), clampi(q0[1] + d1, 0, maxq), clampi(q0[2] + d2, 0, maxq)};
+			const int c[3] = {fam4 ? ex4(q[0]) : ex5(q[0]), fam4 ? ex4(q[1]) : ex5(q[1]),
+				fam4 ? ex4(q[2]) : ex5(q[2])};
+			const uint32_t e = unitw ? half_err_fast<true>(ht8, o, c, tma, tmb)
+				: half_err_fast<false>(ht8, o, c, tma, tmb);
+			if (e < berr) {
+				berr = e; bcand = (uint32_t)cand;
+				bq = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16);
+			}
+		}
+		// Highest: two descent steps over the six axis neighbours of this table's best so far
+		if (walk >= 4) {
+#pragma unroll 1
+			for (int step = 0; step < 2; ++step) {
+				uint32_t be = berr, bqn = bq, bc = bcand;
+#pragma unroll 1
+				for (int m = 0; m < 6; ++m) {
+					int q[3] = {(int)(bq & 255u), (int)((bq >> 8) & 255u), (int)((bq >> 16) & 255u)};
+					const int dd = (m & 1) ? 1 : -1, ax = m >> 1;
+					q[0] = clampi(q[0] + (ax == 0 ? dd : 0), 0, maxq);
+					q[1] = clampi(q[1] + (ax == 1 ? dd : 0), 0, maxq);
+					q[2] = clampi(q[2] + (ax == 2 ? dd : 0), 0, maxq);
 					const int c[3] = {fam4 ? ex4(q[0]) : ex5(q[0]), fam4 ? ex4(q[1]) : ex5(q[1]),
 						fam4 ? ex4(q[2]) : ex5(q[2])};
 					const uint32_t e = unitw ? half_err_fast<true>(ht8, o, c, tma, tmb)
 						: half_err_fast<false>(ht8, o, c, tma, tmb);
-					if (e < berr) {
-						berr = e; bcand = cand;
-						bq = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16);
+					if (e < be) {
+						be = e; bc = 125u + (uint32_t)(step*6 + m);
+						bqn = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16);
 					}
 				}
+				berr = be; bq = bqn; bcand = bc;
+			}
+		}
 	}
 	unsigned long long key = ((unsigned long long)berr << 32) | (bcand*8u + t);
 	group_min8(key, bq);
@@ -968,7 +1005,8 @@ cfhip_etc_encode_kernel(cf_kparams kp)
 		o.allow_indiv = false; o.allow_planar = false; o.punch = false; o.a1 = false;
 		o.active = valid; o.transparent = 0;
 		o.wt[0] = (int)kp.wt[0]; o.wt[1] = (int)kp.wt[1]; o.wt[2] = (int)kp.wt[2];
-		o.radius = q >= 3u ? 2 : (q == 2u ? 1 : 0);   // effort ladder, see oracle/etc_codec.c
+		o.radius = q >= 4u ? 3 : (q >= 3u ? 2 : (q == 2u ? 1 : 0));   // T / H move rounds (oracle: effort_radius)
+		o.walk = q > 4u ? 4 : (int)q;                                  // five distinct effort levels
 		o.refine = q >= 1u;
 		uint2 w0 = make_uint2(0, 0), w1 = make_uint2(0, 0);
 		if (FMT == E_ETC1) {

@@ -208,7 +208,8 @@ typedef struct {
 	unsigned active;      /* texels that carry error weight (in-image, and opaque for A1) */
 	unsigned transparent; /* A1: texels that must decode transparent */
 	int wt[3];
-	int radius;
+	int radius;      /* move rounds of the T / H search */
+	int walk;        /* base-colour walk of the half search, see search_half */
 	int refine;           /* 0: Lowest -- no planar move rounds, no T/H modes */
 } rgb_opts;
 
@@ -276,25 +277,80 @@ static void search_half(const int px[16][4], const rgb_opts* o, int flip, int su
 		int mean = n ? (2*sum[c] + n)/(2*n) : 0;
 		q0[c] = (mean*maxq + 127)/255;
 	}
-	hb->err = 0xFFFFFFFFu;
-	int r = o->radius;
-	for (int dr = -r; dr <= r; ++dr)
-		for (int dg = -r; dg <= r; ++dg)
-			for (int db = -r; db <= r; ++db) {
-				int q[3] = {clampi(q0[0] + dr, 0, maxq), clampi(q0[1] + dg, 0, maxq),
-					clampi(q0[2] + db, 0, maxq)};
-				int c[3];
-				for (int ch = 0; ch < 3; ++ch)
-					c[ch] = bits == 5 ? ex5(q[ch]) : ex4(q[ch]);
-				for (int t = 0; t < 8; ++t) {
+	/* the base-colour walk, per modifier table (lane = table on the GPU): candidates in id order,
+	 * the table's best = first candidate of its smallest error
+	 *   walk 0: the quantised half mean                                   (1 candidate)
+	 *   walk 1: + its six axis neighbours                                 (7)
+	 *   walk 2: the 3x3x3 cube around it                                  (27)
+	 *   walk 3: the 5x5x5 cube                                            (125)
+	 *   walk 4: the 5x5x5 cube, then two descent steps over the six axis neighbours of the
+	 *           table's best so far                                       (125 + 2 x 6)
+	 * out-of-range coordinates clamp (duplicates are harmless) */
+	uint32_t terr[8];
+	int tq[8][3], tcand[8];
+	for (int t = 0; t < 8; ++t) {
+		terr[t] = 0xFFFFFFFFu;
+		tcand[t] = 0;
+		tq[t][0] = tq[t][1] = tq[t][2] = 0;
+	}
+	int ncand = o->walk == 0 ? 1 : (o->walk == 1 ? 7 : (o->walk == 2 ? 27 : 125));
+	int r = o->walk == 2 ? 1 : 2, side = 2*r + 1;
+	for (int cand = 0; cand < ncand; ++cand) {
+		int d[3] = {0, 0, 0};
+		if (o->walk == 1) {
+			if (cand > 0)
+				d[(cand - 1) >> 1] = ((cand - 1) & 1) ? 1 : -1;
+		} else if (o->walk >= 2) {
+			d[0] = cand/(side*side) - r;
+			d[1] = (cand/side) % side - r;
+			d[2] = cand % side - r;
+		}
+		int q[3], c[3];
+		for (int ch = 0; ch < 3; ++ch) {
+			q[ch] = clampi(q0[ch] + d[ch], 0, maxq);
+			c[ch] = bits == 5 ? ex5(q[ch]) : ex4(q[ch]);
+		}
+		for (int t = 0; t < 8; ++t) {
+			uint32_t e = half_err(px, o, flip, sub, c, t, NULL);
+			if (e < terr[t]) {
+				terr[t] = e;
+				tcand[t] = cand;
+				memcpy(tq[t], q, sizeof(q));
+			}
+		}
+	}
+	if (o->walk >= 4)
+		for (int step = 0; step < 2; ++step)
+			for (int t = 0; t < 8; ++t) {
+				uint32_t be = terr[t];
+				int bq[3] = {tq[t][0], tq[t][1], tq[t][2]}, bc = tcand[t];
+				for (int m = 0; m < 6; ++m) {
+					int q[3] = {tq[t][0], tq[t][1], tq[t][2]}, c[3];
+					q[m >> 1] = clampi(q[m >> 1] + ((m & 1) ? 1 : -1), 0, maxq);
+					for (int ch = 0; ch < 3; ++ch)
+						c[ch] = bits == 5 ? ex5(q[ch]) : ex4(q[ch]);
 					uint32_t e = half_err(px, o, flip, sub, c, t, NULL);
-					if (e < hb->err) {
-						hb->err = e;
-						hb->table = t;
-						memcpy(hb->q, q, sizeof(q));
+					if (e < be) {
+						be = e;
+						bc = 125 + step*6 + m;
+						memcpy(bq, q, sizeof(q));
 					}
 				}
+				terr[t] = be;
+				tcand[t] = bc;
+				memcpy(tq[t], bq, sizeof(bq));
 			}
+	hb->err = 0xFFFFFFFFu;
+	int bkey = 0;
+	for (int t = 0; t < 8; ++t) {
+		int key = tcand[t]*8 + t;
+		if (terr[t] < hb->err || (terr[t] == hb->err && key < bkey)) {
+			hb->err = terr[t];
+			hb->table = t;
+			bkey = key;
+			memcpy(hb->q, tq[t], sizeof(hb->q));
+		}
+	}
 }
 
 typedef struct { int O[3], H[3], V[3]; } planar_q;   /* 6/7/6-bit fields */
@@ -830,10 +886,11 @@ void cfo_eac_search(const int v[16], int kind, unsigned active, int R, uint8_t o
 
 static int effort_radius(int quality)
 {
-	/* stands in for etc2comp's effort ladder (EtcConverter.cpp:34-54): base colours within
-	 * `radius` quantisation steps of each half's mean -- 1 / 1 / 27 / 125 / 125 per half and table
-	 * for Lowest .. Highest; Lowest also drops the planar refinement and the T/H modes */
-	return quality >= 3 ? 2 : (quality == 2 ? 1 : 0);
+	/* stands in for etc2comp's five effort levels (EtcConverter.cpp:34-54), all distinct: base
+	 * colours walked per half and table 1 / 7 / 27 / 125 / 125 + 12 (search_half's walk = the
+	 * quality), T / H move rounds 0 / 0 / 1 / 2 / 3 (this value); Lowest also drops the planar
+	 * refinement and the T / H modes */
+	return quality >= 4 ? 3 : (quality >= 3 ? 2 : (quality == 2 ? 1 : 0));
 }
 
 /* rgbaf: 16 texels float RGBA row-major (edge-replicated), rgba: the same as u8,
@@ -852,6 +909,7 @@ int cfo_encode_etc_block(const float rgbaf[64], const uint8_t rgba[64], unsigned
 	memcpy(o.wt, p->color_space == 1 ? rec709 : lin, sizeof(o.wt));
 	o.active = valid;
 	o.radius = effort_radius(p->quality);
+	o.walk = p->quality < 0 ? 0 : (p->quality > 4 ? 4 : p->quality);
 	o.refine = p->quality >= 1;
 	int R = p->quality <= 1 ? 1 : (p->quality == 2 ? 2 : 4);
 	switch (p->format) {
