@@ -32,6 +32,10 @@
 using cfastc::AstcBlobHeader;
 using cfastc::AstcCfgRec;
 
+#ifndef CF_ASTC_ABLATE
+#define CF_ASTC_ABLATE 0   // timing experiments only (tools/dbg/astc_ablate.sh): phases switched off
+#endif
+
 namespace {
 
 #define ASTC_FLAG_ALPHA_WEIGHT 1u
@@ -136,7 +140,8 @@ struct Shared {
 
 // per (wave, block slot) scratch in LDS
 struct Slot {
-	uint8_t* T;        // [8][2][npad]
+	uint8_t* T;        // [8 + 2][npad]: plane 0 of the pass's 8 candidates, then plane 1 of the (at most two)
+	                   // dual-plane candidates, which are candidates 1 and 2 of pass 0
 	uint8_t* pid;      // [8][npad]
 	uint32_t* e0;      // [32]
 	uint32_t* e1;      // [32]
@@ -346,7 +351,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	const uint32_t n = H->n, bw = H->bw, bh = H->bh, ngrids = H->ngrids, npad = H->npad;
 	const uint32_t col_rows = H->col_rows;
 	const uint32_t aflags = (kp.flags >> 16) & 3u;
-	const bool wcached = n <= 64u;
+	// texel-weight cache rows: only above Normal -- up to Normal two blocks share a wave and need two
+	// block slots, and without the cache the workgroup's LDS allows two workgroups per CU
+	const bool wcached = n <= 36u && kp.quality > 2u;
 	const uint32_t wc_rows = wcached ? 2u*((n + 3u)/4u) : 0u;
 
 	// ---- LDS carve-up (byte offsets, 16-byte aligned sections) ----
@@ -359,7 +366,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	uint8_t* sh_grid = lds + off; off += (ngrids*4u + 15u) & ~15u;
 	uint8_t* sh_ctab = lds + off; off += 2u*17u*256u;
 	uint8_t* sh_wtab = lds + off; off += 1216u;
-	const uint32_t slot_bytes = ((8u*2u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
+	const uint32_t slot_bytes = ((10u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
 	const uint32_t wave_bytes = ((((col_rows + 1u)/2u)*256u + wc_rows*256u + 15u) & ~15u) + (kp.quality <= 2u ? 2u : 1u)*slot_bytes;
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	uint8_t* wbase = lds + off + wave*wave_bytes;
@@ -436,8 +443,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		Slot S;
 		{
 			uint8_t* sp = slot0 + h*slot_bytes;
-			S.T = sp; S.pid = sp + 16u*npad;
-			uint32_t* w32 = reinterpret_cast<uint32_t*>(sp + ((24u*npad + 15u) & ~15u));
+			S.T = sp; S.pid = sp + 10u*npad;
+			uint32_t* w32 = reinterpret_cast<uint32_t*>(sp + ((18u*npad + 15u) & ~15u));
 			S.e0 = w32; S.e1 = w32 + 32; S.span = w32 + 64; S.edec = w32 + 96;
 			S.sum01 = w32 + 128; S.sum23 = w32 + 160; S.scnt = w32 + 192;
 			S.order = reinterpret_cast<uint8_t*>(w32 + 224);
@@ -547,7 +554,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		}
 		// k-means clusters along the principal axis + one Lloyd step, then the partition shortlist
 		for (uint32_t P = 2; P <= 4u; ++P) {
-			const uint32_t want = P == 2u ? lad.j2 : (P == 3u ? lad.j3 : lad.j4);
+			const uint32_t want = (CF_ASTC_ABLATE & 8) ? 0u : (P == 2u ? lad.j2 : (P == 3u ? lad.j3 : lad.j4));
 			if (!want)
 				continue;
 			const float step = (tmax - tmin)*(1.0f/(float)P);
@@ -716,7 +723,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				const uint32_t j = hl >> 2, s = hl & 3u;
 				const uint32_t d = j < cnt ? S.pcs[base + j] : 0u;
 				const uint32_t P = pc_P(d), dual = pc_dual(d), ccs = pc_ccs(d);
-				const bool active = !solid && j < cnt && hl < 32u && s < (dual ? 2u : P);
+				const bool active = !(CF_ASTC_ABLATE & 2) && !solid && j < cnt && hl < 32u && s < (dual ? 2u : P);
 				if (active) {
 					uint32_t chmask = (1u << nc) - 1u;
 					if (dual)
@@ -781,7 +788,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						dd += dv[c]*dv[c];
 					}
 					const float rdd2 = dd > 0 ? 1.0f/(float)(2*dd) : 0.0f;
-					uint8_t* Trow = S.T + (j*2u + (dual ? s : 0u))*npad;
+					uint8_t* Trow = S.T + ((dual && s == 1u) ? 8u + ((j - 1u) & 1u) : j)*npad;
 #pragma unroll 1
 					for (uint32_t i = 0; i < n; ++i) {
 						const bool in_ = byp || prow[i] == s;
@@ -818,7 +825,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			// ---- lane = weight grid: decimation error of candidate 0's ideal weights (pass 0) ----
 			if (pass == 0u) {
 				const uint32_t g = hl;
-				if (!solid && g < ngrids) {
+				if (!(CF_ASTC_ABLATE & 4) && !solid && g < ngrids) {
 					const uint32_t N = sh.grid[g*4u], ng = sh.grid[g*4u + 2u];
 					const uint32_t* inf = sh.infill + g*n;
 					const uint8_t* Trow = S.T;
@@ -897,7 +904,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				const uint32_t d = j < cnt ? S.pcs[base + j] : 0u;
 				const uint32_t P = pc_P(d), dual = pc_dual(d), ccs = pc_ccs(d), cls = pc_cls(d);
 				const uint32_t oi = (j < cnt) ? S.order[j*8u + ks] : 255u;
-				const bool active = !solid && j < cnt && oi != 255u;
+				const bool active = !(CF_ASTC_ABLATE & 1) && !solid && j < cnt && oi != 255u;
 				const AstcCfgRec cfg = cfgs[(cls*2u + alpha_i)*64u + (active ? oi : 0u)];
 				r_cfg = oi;
 				const uint32_t planes = dual ? 2u : 1u, N = cfg.N, ng = cfg.ng, wq = cfg.wq;
@@ -911,10 +918,15 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						COLR(r) = 0;
 #pragma unroll 1
 					for (uint32_t pl = 0; pl < planes; ++pl) {
-						const uint8_t* Trow = S.T + (j*2u + pl)*npad;
+						const uint8_t* Trow = S.T + (pl ? 8u + ((j - 1u) & 1u) : j)*npad;
+						// the next texel's record and ideal weight are fetched before this texel's stores: the
+						// compiler cannot move LDS loads above LDS stores it cannot disambiguate, and the
+						// read-modify-write chain below is what the wave waits on
+						uint32_t rec = inf[0], T = Trow[0];
 #pragma unroll 1
 						for (uint32_t i = 0; i < n; ++i) {
-							const uint32_t rec = inf[i], T = Trow[i];
+							const uint32_t nx = i + 1u < n ? i + 1u : i;
+							const uint32_t nrec = inf[nx], nT = Trow[nx];
 							const uint32_t g0 = rec & 255u, f00 = (rec >> 8) & 31u, f01 = (rec >> 13) & 31u, f10 = (rec >> 18) & 31u, f11 = rec >> 23;
 							const uint32_t i0 = g0*planes + pl, i1 = i0 + planes, i2 = i0 + N*planes, i3 = i2 + planes;
 							const uint32_t v0 = COLR(i0), v1 = COLR(i1), v2 = COLR(i2), v3 = COLR(i3);
@@ -922,6 +934,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							COLR(i1) = (uint16_t)(v1 + f01*T);
 							COLR(i2) = (uint16_t)(v2 + f10*T);
 							COLR(i3) = (uint16_t)(v3 + f11*T);
+							rec = nrec; T = nT;
 						}
 					}
 					for (uint32_t g = 0; g < ng; ++g) {
@@ -944,9 +957,11 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					struct SetAcc { uint32_t S, C, V0, V1, V2, V3, cn, p01, p23; };
 					SetAcc q0 = {0, 0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;
 					uint32_t wpack0 = 0, wpack1 = 0;
+					uint32_t rec = inf[0], p = tp[0], part = byp ? 0u : prow[0];
 #pragma unroll 1
 					for (uint32_t i = 0; i < n; ++i) {
-						const uint32_t rec = inf[i];
+						const uint32_t nx = i + 1u < n ? i + 1u : i;
+						const uint32_t nrec = inf[nx], np = tp[nx], npart = byp ? 0u : prow[nx];   // before the cache stores
 						const uint32_t g0 = rec & 255u, f00 = (rec >> 8) & 31u, f01 = (rec >> 13) & 31u, f10 = (rec >> 18) & 31u, f11 = rec >> 23;
 						uint32_t wA, wB;
 						{
@@ -965,8 +980,6 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 								wpack0 = 0; wpack1 = 0;
 							}
 						}
-						const uint32_t p = tp[i];
-						const uint32_t part = byp ? 0u : prow[i];
 						const uint32_t pc0_ = p & 255u, pc1_ = (p >> 8) & 255u, pc2_ = (p >> 16) & 255u, pc3_ = p >> 24;
 #define ASTC_ACC(Q, ST) if (ST < nset) { \
 							const uint32_t wi = (dual && ST == 1u) ? wB : wA; \
@@ -975,6 +988,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							Q.V0 += wm*pc0_; Q.V1 += wm*pc1_; Q.V2 += wm*pc2_; Q.V3 += wm*pc3_; }
 						ASTC_ACC(q0, 0u) ASTC_ACC(q1, 1u) ASTC_ACC(q2, 2u) ASTC_ACC(q3, 3u)
 #undef ASTC_ACC
+						rec = nrec; p = np; part = npart;
 					}
 					// texel count and channel sums of every set: the subset's slot, or (dual) the whole
 					// block = the OR of the two planes' masked sums
@@ -1240,8 +1254,8 @@ extern "C" size_t cfhip_astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t
 	off += ngrids*128u;
 	off += (ngrids*4u + 15u) & ~15u;
 	off += 2u*17u*256u + 1216u;
-	const uint32_t wc_rows = n <= 64u ? 2u*((n + 3u)/4u) : 0u;
-	const uint32_t slot_bytes = ((8u*2u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
+	const uint32_t wc_rows = (n <= 36u && quality > 2u) ? 2u*((n + 3u)/4u) : 0u;
+	const uint32_t slot_bytes = ((10u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
 	const uint32_t wave_bytes = ((((h->col_rows + 1u)/2u)*256u + wc_rows*256u + 15u) & ~15u) + (quality <= 2u ? 2u : 1u)*slot_bytes;
 	return (size_t)off + 4u*(size_t)wave_bytes;
 }
