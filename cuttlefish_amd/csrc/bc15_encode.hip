@@ -176,6 +176,7 @@ struct COpts {
 	uint32_t wt[3];
 	uint32_t active;   // bit i: texel i takes part
 	uint32_t rounds;
+	uint32_t cluster;  // iterations of the cluster fit (0 = none)
 	uint32_t pp;       // sum over the active texels of r^2 + g^2 + b^2 (set by bc1_search)
 };
 
@@ -396,6 +397,185 @@ __device__ __forceinline__ void move565(uint32_t m, uint32_t a, uint32_t b, uint
 }
 
 // Returns the 8-byte colour block in every lane.
+
+// ---- cluster fit (oracle: cluster_fit): ordered splits along the principal axis + closed-form
+// least squares -- rgbcx's "total orderings" levels / squish's (Iterative)ClusterFit.
+// Lane = split: the 969 triples (i <= j <= k <= 16) of the 4-colour order (weights 1, 2/3, 1/3, 0);
+// those with k = n are also the (i <= j) splits of the 3-colour order (1, 1/2, 0).  The texels are
+// ranked by (projection on the axis, index) with one texel per lane, the prefix sums of the
+// ranked colours sit in lanes 0..16 and every split fetches its three with shuffles; endpoints by
+// one correctly rounded float division per channel and endpoint, rounded to RGB565, ranked by
+// the split's closed-form error (an exact integer, 36 x the squared error of the clusters).
+struct SplitTab { uint16_t v[969]; };
+constexpr SplitTab make_splits()
+{
+	SplitTab t{};
+	int n = 0;
+	for (int i = 0; i <= 16; ++i)
+		for (int j = i; j <= 16; ++j)
+			for (int k = j; k <= 16; ++k)
+				t.v[n++] = (uint16_t)(i | (j << 5) | (k << 10));
+	return t;
+}
+__device__ const SplitTab k_splits = make_splits();
+
+__device__ __forceinline__ int cf_q(float v, bool six)
+{
+	v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+	return (int)floorf(v*(six ? 63.0f/255.0f : 31.0f/255.0f) + 0.5f);
+}
+
+template <bool UNITW>
+__device__ __forceinline__ void cluster_fit(const uint32_t* tp, const COpts& o, int n, const int (&s)[3],
+	int s00, int s01, int s02, int s11, int s12, int s22, uint32_t lane, CBest& cur)
+{
+	// principal axis (uniform): three max-normalised power iterations
+	const float C00 = (float)(n*s00 - s[0]*s[0]), C01 = (float)(n*s01 - s[0]*s[1]), C02 = (float)(n*s02 - s[0]*s[2]);
+	const float C11 = (float)(n*s11 - s[1]*s[1]), C12 = (float)(n*s12 - s[1]*s[2]), C22 = (float)(n*s22 - s[2]*s[2]);
+	float a0 = C00, a1 = C01, a2 = C02, bestd = C00;
+	if (C11 > bestd) { bestd = C11; a0 = C01; a1 = C11; a2 = C12; }
+	asm volatile("" : "+v"(bestd));
+	if (C22 > bestd) { a0 = C02; a1 = C12; a2 = C22; }
+#pragma unroll
+	for (int it = 0; it < 3; ++it) {
+		const float m = fmaxf(fabsf(a0), fmaxf(fabsf(a1), fabsf(a2)));
+		if (m > 0.0f) {
+			const float im = 1.0f/m;
+			a0 = a0*im; a1 = a1*im; a2 = a2*im;
+		}
+		float r0 = C00*a0; r0 = fmaf(C01, a1, r0); r0 = fmaf(C02, a2, r0);
+		float r1 = C01*a0; r1 = fmaf(C11, a1, r1); r1 = fmaf(C12, a2, r1);
+		float r2 = C02*a0; r2 = fmaf(C12, a1, r2); r2 = fmaf(C22, a2, r2);
+		a0 = r0; a1 = r1; a2 = r2;
+	}
+	const int sq[3] = {s00, s11, s22};
+	const uint32_t ti = lane & 15u;
+	const uint32_t pme = tp[ti];
+	const bool act_me = (o.active >> ti) & 1u;
+#pragma unroll 1
+	for (uint32_t iter = 0; iter < o.cluster; ++iter) {
+		// rank of my texel (texel lane & 15 in every row of 16 lanes)
+		float t = a0*(float)ub(pme, 0);
+		t = fmaf(a1, (float)ub(pme, 1), t);
+		t = fmaf(a2, (float)ub(pme, 2), t);
+		uint32_t rank = 0;
+#pragma unroll 1
+		for (uint32_t j = 0; j < 16u; ++j) {
+			const float tj = __shfl(t, (int)((lane & 48u) + j), 64);
+			const bool before = ((o.active >> j) & 1u) && (tj < t || (tj == t && j < ti));
+			rank += before ? 1u : 0u;
+		}
+		// prefix sums of the ranked colours: lane k (< 17) holds P[k] = sum of texels of rank < k
+		uint32_t P01 = 0, P2 = 0;
+#pragma unroll 1
+		for (uint32_t i = 0; i < 16u; ++i) {
+			const uint32_t ri = (uint32_t)__shfl((int)rank, (int)i, 64), pi = tp[i];
+			const bool in = ((o.active >> i) & 1u) && ri < lane;
+			P01 += in ? (ub(pi, 0) | (ub(pi, 1) << 16)) : 0u;
+			P2 += in ? ub(pi, 2) : 0u;
+		}
+		const uint32_t Pn01 = (uint32_t)__shfl((int)P01, n, 64), Pn2 = (uint32_t)__shfl((int)P2, n, 64);
+		unsigned long long bkey = ~0ull;
+		uint32_t bab = 0;
+		const int Pn[3] = {(int)(Pn01 & 0xFFFFu), (int)(Pn01 >> 16), (int)Pn2};
+		// one split: least-squares endpoints (one division), RGB565 rounding, closed-form error
+		auto score = [&](bool m3, bool want, uint32_t id, int aa, int bbv, int ab, const int (&ax)[3], const int (&bx)[3])
+			__attribute__((always_inline)) {
+			const int D = m3 ? 2 : 3;
+			const int det = aa*bbv - ab*ab;
+			if (want && det > 0) {
+				const float inv = 1.0f/(float)det;
+				int qa[3], qb[3];
+#pragma unroll
+				for (int c = 0; c < 3; ++c) {
+					const float ea = (float)(D*(ax[c]*bbv - bx[c]*ab))*inv;
+					const float eb = (float)(D*(bx[c]*aa - ax[c]*ab))*inv;
+					qa[c] = cf_q(ea, c == 1);
+					qb[c] = cf_q(eb, c == 1);
+				}
+				const uint32_t a = pack565(qa[0], qa[1], qa[2]), b = pack565(qb[0], qb[1], qb[2]);
+				const uint32_t xa = expand565(a), xb = expand565(b);
+				int e = 0;
+#pragma unroll
+				for (int c = 0; c < 3; ++c) {
+					const int A = (int)ub(xa, c), B = (int)ub(xb, c);
+					const int ec = D*D*sq[c] + A*A*aa + B*B*bbv + 2*A*B*ab - 2*D*(A*ax[c] + B*bx[c]);
+					e += (int)o.wt[c]*ec;
+				}
+				const uint32_t e36 = (uint32_t)e*(m3 ? 9u : 4u);
+				const unsigned long long key = ((unsigned long long)e36 << 32) | id;
+				if (key < bkey) {
+					bkey = key;
+					bab = a | (b << 16);
+				}
+			}
+		};
+		// 4-colour splits: ids 0..968
+		if (o.allow3 != 2u) {
+#pragma unroll 1
+			for (uint32_t tt = 0; tt < 16u; ++tt) {
+				const uint32_t sidx = lane + 64u*tt;
+				const uint32_t ent = sidx < 969u ? k_splits.v[sidx] : 0x7FFFu;
+				const uint32_t i = ent & 31u, j = (ent >> 5) & 31u, k = (ent >> 10) & 31u;
+				const bool want = sidx < 969u && k <= (uint32_t)n;
+				const uint32_t Pi01 = (uint32_t)__shfl((int)P01, (int)i, 64), Pi2 = (uint32_t)__shfl((int)P2, (int)i, 64);
+				const uint32_t Pj01 = (uint32_t)__shfl((int)P01, (int)j, 64), Pj2 = (uint32_t)__shfl((int)P2, (int)j, 64);
+				const uint32_t Pk01 = (uint32_t)__shfl((int)P01, (int)k, 64), Pk2 = (uint32_t)__shfl((int)P2, (int)k, 64);
+				const int Pi[3] = {(int)(Pi01 & 0xFFFFu), (int)(Pi01 >> 16), (int)Pi2};
+				const int Pj[3] = {(int)(Pj01 & 0xFFFFu), (int)(Pj01 >> 16), (int)Pj2};
+				const int Pk[3] = {(int)(Pk01 & 0xFFFFu), (int)(Pk01 >> 16), (int)Pk2};
+				const int n0 = (int)i, n1 = (int)(j - i), n2 = (int)(k - j), n3 = n - (int)k;
+				int ax[3], bx[3];
+#pragma unroll
+				for (int c = 0; c < 3; ++c) {
+					const int S0 = Pi[c], S1 = Pj[c] - Pi[c], S2 = Pk[c] - Pj[c], S3 = Pn[c] - Pk[c];
+					ax[c] = 3*S0 + 2*S1 + S2;
+					bx[c] = S1 + 2*S2 + 3*S3;
+				}
+				score(false, want, sidx, 9*n0 + 4*n1 + n2, n1 + 4*n2 + 9*n3, 2*n1 + 2*n2, ax, bx);
+			}
+		}
+		// 3-colour splits: the 153 pairs i <= j <= 16 (table entries with k = 16, in order): ids 1024 + t
+		if (o.allow3 != 0u) {
+#pragma unroll 1
+			for (uint32_t tt = 0; tt < 3u; ++tt) {
+				const uint32_t t3 = lane + 64u*tt;
+				// pair number t3 -> (i, j): row i holds 17 - i pairs
+				uint32_t i = 0, rem = t3;
+#pragma unroll 1
+				while (i < 17u && rem >= 17u - i) { rem -= 17u - i; ++i; }
+				const uint32_t j = i + rem;
+				const bool want = t3 < 153u && j <= (uint32_t)n;
+				const uint32_t ii = i & 31u, jj = j & 31u;
+				const uint32_t Pi01 = (uint32_t)__shfl((int)P01, (int)ii, 64), Pi2 = (uint32_t)__shfl((int)P2, (int)ii, 64);
+				const uint32_t Pj01 = (uint32_t)__shfl((int)P01, (int)jj, 64), Pj2 = (uint32_t)__shfl((int)P2, (int)jj, 64);
+				const int Pi[3] = {(int)(Pi01 & 0xFFFFu), (int)(Pi01 >> 16), (int)Pi2};
+				const int Pj[3] = {(int)(Pj01 & 0xFFFFu), (int)(Pj01 >> 16), (int)Pj2};
+				const int n0 = (int)i, n1 = (int)(j - i), n3 = n - (int)j;
+				int ax[3], bx[3];
+#pragma unroll
+				for (int c = 0; c < 3; ++c) {
+					const int S0 = Pi[c], S1 = Pj[c] - Pi[c], S3 = Pn[c] - Pj[c];
+					ax[c] = 2*S0 + S1;
+					bx[c] = S1 + 2*S3;
+				}
+				score(true, want, 1024u + t3, 4*n0 + n1, n1 + 4*n3, n1, ax, bx);
+			}
+		}
+		const unsigned long long kmin = cf_wave_min_u64(bkey);
+		if (kmin == ~0ull)
+			break;
+		const uint32_t wl = (uint32_t)__builtin_ctzll(__ballot(bkey == kmin));
+		const uint32_t wab = (uint32_t)__shfl((int)bab, (int)wl, 64);
+		const uint32_t ba = wab & 0xFFFFu, bb = wab >> 16;
+		consider<UNITW>(tp, o, ba, bb, 0x10000u + 2u*iter, cur);   // uniform: every lane, same pair
+		const uint32_t xa = expand565(ba), xb = expand565(bb);
+		a0 = (float)((int)ub(xa, 0) - (int)ub(xb, 0));
+		a1 = (float)((int)ub(xa, 1) - (int)ub(xb, 1));
+		a2 = (float)((int)ub(xa, 2) - (int)ub(xb, 2));
+	}
+}
+
 template <bool UNITW>
 __device__ __forceinline__ uint2 bc1_search(const uint32_t* tp, const COpts& o_in, uint32_t lane)
 {
@@ -469,6 +649,8 @@ __device__ __forceinline__ uint2 bc1_search(const uint32_t* tp, const COpts& o_i
 	cur.b = (uint32_t)__shfl((int)best.b, (int)wl, 64);
 	cur.mode3 = (uint32_t)__shfl((int)best.mode3, (int)wl, 64);
 
+	if (o.cluster)
+		cluster_fit<UNITW>(tp, o, n, s, s00, s01, s02, s11, s12, s22, lane, cur);
 	for (uint32_t r = 1; r <= o.rounds; ++r) {
 		uint32_t na, nb;
 		move565(lane, cur.a, cur.b, na, nb);
@@ -593,6 +775,8 @@ cfhip_bc15_encode_kernel(cf_kparams kp)
 		o.wt[0] = o.wt[1] = o.wt[2] = 1u;
 		o.active = 0xFFFFu;
 		o.rounds = colour_rounds(kp.quality);
+		// cluster fit from High, iterated at Highest; punch-through blocks from Normal (oracle)
+		o.cluster = kp.quality >= 4u ? 2u : (kp.quality >= 3u ? 1u : 0u);
 		const int radius = alpha_radius(kp.quality);
 		uint2 w0 = make_uint2(0, 0), w1 = make_uint2(0, 0);
 		if (FMT == F_BC1) {
@@ -603,6 +787,7 @@ cfhip_bc15_encode_kernel(cf_kparams kp)
 			const uint32_t opaque = (uint32_t)__ballot(lane < 16u && (tp[lane & 15u] >> 24) >= 128u);
 			if (opaque != 0xFFFFu) {
 				o.allow3 = 2; o.black = false; o.active = opaque;
+				if (kp.quality == 2u) o.cluster = 1u;
 				o.wt[0] = kp.wt[0]; o.wt[1] = kp.wt[1]; o.wt[2] = kp.wt[2];
 				w0 = bc1_search<false>(tp, o, lane);
 			} else {

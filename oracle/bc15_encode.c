@@ -152,6 +152,7 @@ typedef struct {
 	int wt[3];       /* channel weights */
 	unsigned active; /* bit i: pixel i takes part (punch-through: opaque pixels) */
 	int rounds;
+	int cluster;     /* iterations of the cluster fit (0 = none) */
 } c_opts;
 
 typedef struct { uint32_t err, id; int a, b, mode3; } c_cand;   /* a, b: RGB565 words */
@@ -273,6 +274,193 @@ static void move565(int m, int a, int b, int* na, int* nb)
 	*nb = pack565(br, bg, bb);
 }
 
+
+/* ---- cluster fit: ordered splits along the principal axis + closed-form least squares ----
+ * What rgbcx's "total orderings" levels and squish's ClusterFit / IterativeClusterFit do (the
+ * reference picks them by quality, S3tcConverter.cpp:66-71, :273-279).  The active texels are
+ * ordered by their projection on the principal axis (ties: texel index); every split of that
+ * order into the palette's clusters -- (i <= j <= k) for the 4-colour order with weights 1, 2/3,
+ * 1/3, 0, (i <= j) for the 3-colour order with 1, 1/2, 0 -- gives least-squares endpoints from
+ * prefix sums; they are rounded to RGB565 and ranked by the closed-form error of the split,
+ * 36 sum_c w_c sum_i (p_i - alpha_i A - beta_i B)^2, an exact integer.  The best split's endpoint
+ * pair then gets the exact decoder-side evaluation like every other candidate.  A further
+ * iteration re-orders the texels along the axis between that pair.  On the GPU lane = split. */
+static int cf_splits[969][3], cf_nsplits;
+
+static void cf_init(void)
+{
+	if (cf_nsplits)
+		return;
+	int n = 0;
+	for (int i = 0; i <= 16; ++i)
+		for (int j = i; j <= 16; ++j)
+			for (int k = j; k <= 16; ++k) {
+				cf_splits[n][0] = i; cf_splits[n][1] = j; cf_splits[n][2] = k;
+				++n;
+			}
+	cf_nsplits = n;
+}
+
+static int cf_q(float v, int maxq)
+{
+	v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+	return (int)floorf(v*(maxq == 31 ? 31.0f/255.0f : 63.0f/255.0f) + 0.5f);
+}
+
+static void cluster_fit(const int px[16][4], const c_opts* o, int iters, c_cand* best)
+{
+	cf_init();
+	int n = 0, s[3] = {0, 0, 0}, sq[3][3];
+	memset(sq, 0, sizeof(sq));
+	for (int i = 0; i < 16; ++i) {
+		if (!((o->active >> i) & 1))
+			continue;
+		++n;
+		for (int c = 0; c < 3; ++c) {
+			s[c] += px[i][c];
+			for (int d = 0; d < 3; ++d)
+				sq[c][d] += px[i][c]*px[i][d];
+		}
+	}
+	/* principal axis: three max-normalised power iterations from the column of the largest variance */
+	float C[3][3], axis[3];
+	for (int a = 0; a < 3; ++a)
+		for (int b = 0; b < 3; ++b)
+			C[a][b] = (float)(n*sq[a][b] - s[a]*s[b]);
+	int amax = 0;
+	for (int a = 1; a < 3; ++a)
+		if (C[a][a] > C[amax][amax])
+			amax = a;
+	for (int a = 0; a < 3; ++a)
+		axis[a] = C[amax][a];
+	for (int it = 0; it < 3; ++it) {
+		float m = fmaxf(fabsf(axis[0]), fmaxf(fabsf(axis[1]), fabsf(axis[2])));
+		if (m > 0.0f) {
+			float im = 1.0f/m;
+			for (int a = 0; a < 3; ++a)
+				axis[a] = axis[a]*im;
+		}
+		float r[3];
+		for (int a = 0; a < 3; ++a) {
+			float t = C[a][0]*axis[0];
+			t = fmaf(C[a][1], axis[1], t);
+			t = fmaf(C[a][2], axis[2], t);
+			r[a] = t;
+		}
+		memcpy(axis, r, sizeof(r));
+	}
+	int pp9[3];
+	for (int c = 0; c < 3; ++c)
+		pp9[c] = 9*sq[c][c];
+	for (int iter = 0; iter < iters; ++iter) {
+		/* rank of every active texel in (projection, index) order; prefix sums in that order */
+		float t[16];
+		int rank[16], P[17][3];
+		for (int i = 0; i < 16; ++i) {
+			float v = axis[0]*(float)px[i][0];
+			v = fmaf(axis[1], (float)px[i][1], v);
+			v = fmaf(axis[2], (float)px[i][2], v);
+			t[i] = v;
+		}
+		for (int i = 0; i < 16; ++i) {
+			rank[i] = 0;
+			for (int j = 0; j < 16; ++j)
+				if (((o->active >> j) & 1) && (t[j] < t[i] || (t[j] == t[i] && j < i)))
+					++rank[i];
+		}
+		for (int k = 0; k <= 16; ++k)
+			for (int c = 0; c < 3; ++c) {
+				P[k][c] = 0;
+				for (int i = 0; i < 16; ++i)
+					if (((o->active >> i) & 1) && rank[i] < k)
+						P[k][c] += px[i][c];
+			}
+		uint64_t bkey = ~0ull;
+		int ba = 0, bb = 0;
+		/* ids: 4-colour splits 0..968 in table order; 3-colour splits 1024 + (their index among
+		 * the table entries with k = 16, i.e. the pairs i <= j <= 16 in order), valid when j <= n */
+		for (int pass3 = 0; pass3 < 2; ++pass3) {
+			if (pass3 ? !o->allow3 : o->allow3 == 2)
+				continue;
+			int t3 = 0;
+			for (int sidx = 0; sidx < cf_nsplits; ++sidx) {
+				int i = cf_splits[sidx][0], j = cf_splits[sidx][1], k = cf_splits[sidx][2];
+				uint32_t id;
+				if (pass3) {
+					if (k != 16)
+						continue;
+					id = 1024u + (uint32_t)t3++;
+					if (j > n)
+						continue;
+				} else {
+					if (k > n)
+						continue;
+					id = (uint32_t)sidx;
+				}
+				/* aa = sum alpha^2, bb = sum beta^2, ab = sum alpha beta, ax / bx = sum alpha p / beta p,
+				 * scaled by D^2 resp. D (D = 3 for the 4-colour, 2 for the 3-colour weights) */
+				int D = pass3 ? 2 : 3, aa, bbv, ab, ax[3], bx[3];
+				if (!pass3) {
+					int n0 = i, n1 = j - i, n2 = k - j, n3 = n - k;
+					aa = 9*n0 + 4*n1 + n2; bbv = n1 + 4*n2 + 9*n3; ab = 2*n1 + 2*n2;
+					for (int c = 0; c < 3; ++c) {
+						int S0 = P[i][c], S1 = P[j][c] - P[i][c], S2 = P[k][c] - P[j][c], S3 = P[n][c] - P[k][c];
+						ax[c] = 3*S0 + 2*S1 + S2;
+						bx[c] = S1 + 2*S2 + 3*S3;
+					}
+				} else {
+					int n0 = i, n1 = j - i, n3 = n - j;
+					aa = 4*n0 + n1; bbv = n1 + 4*n3; ab = n1;
+					for (int c = 0; c < 3; ++c) {
+						int S0 = P[i][c], S1 = P[j][c] - P[i][c], S3 = P[n][c] - P[j][c];
+						ax[c] = 2*S0 + S1;
+						bx[c] = S1 + 2*S3;
+					}
+				}
+				int det = aa*bbv - ab*ab;
+				if (det <= 0)
+					continue;
+				float inv = 1.0f/(float)det;      /* one division; the endpoints are products with it */
+				int qa[3], qb[3];
+				for (int c = 0; c < 3; ++c) {
+					float ea = (float)(D*(ax[c]*bbv - bx[c]*ab))*inv;
+					float eb = (float)(D*(bx[c]*aa - ax[c]*ab))*inv;
+					qa[c] = cf_q(ea, c == 1 ? 63 : 31);
+					qb[c] = cf_q(eb, c == 1 ? 63 : 31);
+				}
+				int a = pack565(qa[0], qa[1], qa[2]), b = pack565(qb[0], qb[1], qb[2]);
+				int xa[3], xb[3];
+				expand565(a, xa);
+				expand565(b, xb);
+				/* D^2 x the split's squared error (32-bit: <= 2.4e8 for the weights in use), then
+				 * brought to the common scale 36 */
+				int32_t e = 0;
+				for (int c = 0; c < 3; ++c) {
+					int A = xa[c], B = xb[c];
+					int32_t ec = D*D*sq[c][c] + A*A*aa + B*B*bbv + 2*A*B*ab - 2*D*(A*ax[c] + B*bx[c]);
+					e += o->wt[c]*ec;
+				}
+				uint32_t e36 = (uint32_t)e*(pass3 ? 9u : 4u);
+				uint64_t key = ((uint64_t)e36 << 32) | id;
+				if (key < bkey) {
+					bkey = key;
+					ba = a;
+					bb = b;
+				}
+			}
+		}
+		(void)pp9;
+		if (bkey == ~0ull)
+			break;
+		consider(px, o, ba, bb, 0x10000u + 2u*(uint32_t)iter, best);
+		int xa[3], xb[3];
+		expand565(ba, xa);
+		expand565(bb, xb);
+		for (int c = 0; c < 3; ++c)
+			axis[c] = (float)(xa[c] - xb[c]);
+	}
+}
+
 /* px: 16 x RGBA (u8 values), out: 8 bytes */
 void cfo_bc1_search(const int px[16][4], const c_opts* o, uint8_t out[8])
 {
@@ -326,6 +514,8 @@ void cfo_bc1_search(const int px[16][4], const c_opts* o, uint8_t out[8])
 		int b = pack565(q5(eb[0]), q6(eb[1]), q5(eb[2]));
 		consider(px, o, a, b, (uint32_t)(2*L), &best);
 	}
+	if (o->cluster)
+		cluster_fit(px, o, o->cluster, &best);
 	for (int r = 1; r <= o->rounds; ++r) {
 		c_cand nb = best;
 		for (int m = 0; m < 64; ++m) {
@@ -416,6 +606,10 @@ int cfo_encode_bc15_block(const float rgbaf[64], const uint8_t rgba[64], uint8_t
 	o.wt[0] = o.wt[1] = o.wt[2] = 1;
 	o.active = 0xFFFF;
 	o.rounds = colour_rounds(p->quality);
+	/* cluster fit from High (rgbcx levels 13 and 18 of getRgbcxQualityLevel are "total orderings"
+	 * levels), iterated at Highest; punch-through blocks get it from Normal, as squish's ClusterFit /
+	 * IterativeClusterFit ladder does (S3tcConverter.cpp:273-279) */
+	o.cluster = p->quality >= 4 ? 2 : (p->quality >= 3 ? 1 : 0);
 	int radius = alpha_radius(p->quality);
 
 	switch (p->format) {
@@ -439,6 +633,8 @@ int cfo_encode_bc15_block(const float rgbaf[64], const uint8_t rgba[64], uint8_t
 				o.active = opaque;
 				o.allow3 = 2;
 				o.black = 0;
+				if (p->quality == 2)
+					o.cluster = 1;
 			} else {
 				o.allow3 = 1;
 				o.black = 0;
