@@ -24,6 +24,8 @@
 #include <cstring>
 #include <vector>
 
+#include "astc_cfg_rank.h"
+
 namespace cfastc {
 
 struct AstcBlobHeader {
@@ -257,6 +259,12 @@ struct CfgCand { int score, N, M, wq, lv; };
 inline std::vector<uint8_t> build_blob(int bw, int bh)
 {
 	const int n = bw*bh;
+	static const unsigned char fps[14][2] = {{4, 4}, {5, 4}, {5, 5}, {6, 5}, {6, 6}, {8, 5}, {8, 6}, {8, 8},
+		{10, 5}, {10, 6}, {10, 8}, {10, 10}, {12, 10}, {12, 12}};
+	int fp = 0;
+	for (int i = 0; i < 14; ++i)
+		if (fps[i][0] == bw && fps[i][1] == bh)
+			fp = i;
 	const Quant* WQ = weight_quants();
 	const Quant* CQ = colour_quants();
 	// colour level table
@@ -318,6 +326,21 @@ inline std::vector<uint8_t> build_blob(int bw, int bh)
 				if (a.N != b.N) return a.N > b.N;
 				return a.wq > b.wq;
 			});
+			// where tools/astc_rank_configs.py has ranked this class (how often each config was the best
+			// of ALL legal configs over a census of synthetic content), that ranking goes first
+			{
+				const unsigned short* rk = astc_cfg_rank[fp][cls*2 + alpha];
+				size_t placed = 0;
+				for (int r = 0; r < 64 && rk[r]; ++r) {
+					const int N = rk[r] & 15, M = (rk[r] >> 4) & 15, wq = rk[r] >> 8;
+					for (size_t i = placed; i < all.size(); ++i)
+						if (all[i].N == N && all[i].M == M && all[i].wq == wq) {
+							std::rotate(all.begin() + (long)placed, all.begin() + (long)i, all.begin() + (long)i + 1);
+							++placed;
+							break;
+						}
+				}
+			}
 			int k = 0;
 			for (size_t i = 0; i < all.size() && k < 64; ++i) {
 				const int g = grid_index(all[i].N, all[i].M);

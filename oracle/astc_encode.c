@@ -25,6 +25,7 @@
  *   winner = min (error, id); packed with the ISE coder.
  */
 #include "astc_common.h"
+#include "astc_cfg_rank.h"
 #include "cf_oracle.h"
 #include <math.h>
 #include <pthread.h>
@@ -33,8 +34,10 @@
 
 #define ASTC_FLAG_ALPHA_WEIGHT 1
 #define ASTC_FLAG_PERCEPTUAL 2
-#define ASTC_MAX_CFG 64        /* configs listed per class; K of them are tried per candidate */
-#define ASTC_MAX_GRIDS 24
+#define ASTC_MAX_CFG 200       /* array bound; a class lists at most 64 (200 only in the census build) */
+#define ASTC_LIST_CFG 64       /* configs listed per class; K of them are tried per candidate */
+#define ASTC_MAX_GRIDS 128     /* array bound; 24 distinct grids per footprint (all in the census build) */
+#define ASTC_LIST_GRIDS 24
 #define ASTC_MAX_PARTS 1024
 
 typedef struct {
@@ -45,7 +48,7 @@ typedef struct {
 
 /* classes of partitioning candidates: 0 one partition, 1 one partition + dual plane, 2..4 = P */
 typedef struct {
-	int bw, bh, n;
+	int bw, bh, n, fp, census;          /* fp: footprint index 0..13; census: list everything */
 	astc_cfg cfg[5][2][ASTC_MAX_CFG];
 	int ncfg[5][2];
 	int ngrids;
@@ -78,7 +81,7 @@ static int grid_index(astc_fmt* f, int N, int M)
 	for (int g = 0; g < f->ngrids; ++g)
 		if (f->gN[g] == N && f->gM[g] == M)
 			return g;
-	if (f->ngrids >= ASTC_MAX_GRIDS)
+	if (f->ngrids >= (f->census ? ASTC_MAX_GRIDS : ASTC_LIST_GRIDS))
 		return -1;
 	int g = f->ngrids++;
 	f->gN[g] = (uint8_t)N; f->gM[g] = (uint8_t)M;
@@ -130,8 +133,25 @@ static void build_configs(astc_fmt* f, int cls, int alpha)
 				(b->N*b->M == a->N*a->M && (b->N > a->N || (b->N == a->N && b->wq > a->wq)))));
 			if (swap) { cand t = all[i]; all[i] = all[j]; all[j] = t; }
 		}
+	/* order of the list: where tools/astc_rank_configs.py has ranked this class (how often each
+	 * config was the best one of ALL legal configs over a census of synthetic content:
+	 * astc_cfg_rank.h, the same data in the library), that ranking first; then the noise model */
+	if (!f->census) {
+		const uint16_t* rk = astc_cfg_rank[f->fp][cls*2 + alpha];
+		int placed = 0;
+		for (int r = 0; r < 64 && rk[r]; ++r) {
+			int N = rk[r] & 15, M = (rk[r] >> 4) & 15, wq = rk[r] >> 8;
+			for (int i = placed; i < n; ++i)
+				if (all[i].N == N && all[i].M == M && all[i].wq == wq) {
+					cand t = all[i];
+					memmove(&all[placed + 1], &all[placed], (size_t)(i - placed)*sizeof(cand));
+					all[placed++] = t;
+					break;
+				}
+		}
+	}
 	int k = 0;
-	for (int i = 0; i < n && k < ASTC_MAX_CFG; ++i) {
+	for (int i = 0; i < n && k < (f->census ? ASTC_MAX_CFG : ASTC_LIST_CFG); ++i) {
 		int g = grid_index(f, all[i].N, all[i].M);
 		if (g < 0)
 			continue;
@@ -191,7 +211,7 @@ static const astc_fmt* get_fmt(int bw, int bh)
 	pthread_mutex_lock(&g_fmt_lock);
 	if (!g_fmt[idx]) {
 		astc_fmt* f = (astc_fmt*)calloc(1, sizeof(astc_fmt));
-		f->bw = bw; f->bh = bh; f->n = bw*bh;
+		f->bw = bw; f->bh = bh; f->n = bw*bh; f->fp = idx;
 		for (int cls = 0; cls < 5; ++cls)
 			for (int a = 0; a < 2; ++a)
 				build_configs(f, cls, a);
@@ -213,8 +233,8 @@ int cfo_astc_table_info(int bw, int bh, int* npart3, int* ncfg10, uint16_t* cfg_
 	for (int cls = 0; cls < 5; ++cls)
 		for (int a = 0; a < 2; ++a) {
 			ncfg10[cls*2 + a] = f->ncfg[cls][a];
-			for (int k = 0; k < ASTC_MAX_CFG; ++k)
-				cfg_modes[(cls*2 + a)*ASTC_MAX_CFG + k] = k < f->ncfg[cls][a] ?
+			for (int k = 0; k < ASTC_LIST_CFG; ++k)
+				cfg_modes[(cls*2 + a)*ASTC_LIST_CFG + k] = k < f->ncfg[cls][a] ?
 					(uint16_t)(f->cfg[cls][a][k].mode | (f->cfg[cls][a][k].wq << 11)) : 0xFFFF;
 		}
 	return 0;
@@ -983,4 +1003,102 @@ void cfo_encode_astc_block(const int px[][4], int bw, int bh, int quality, int f
 		if ((ws[i >> 3] >> (i & 7)) & 1)
 			out[(127 - i) >> 3] |= (uint8_t)(1u << ((127 - i) & 7));
 	free(b);
+}
+
+
+/* ------------------------------------------------------------------ census (tools/astc_rank_configs.py)
+ * For every non-constant block of an RGBA8 image and every candidate class (one partition, dual
+ * plane, 2 / 3 / 4 partitions -- the class's best shortlisted candidate): which of ALL legal
+ * configs gives the smallest exact error.  counts[(cls*2 + alpha)*4096 + (N | M << 4 | wq << 8)]. */
+int cfo_astc_census_image(const uint8_t* rgba, int w, int h, int bw, int bh, int flags, uint32_t* counts)
+{
+	static astc_fmt* cf[14];
+	const astc_fmt* base = get_fmt(bw, bh);
+	if (!base)
+		return -1;
+	pthread_mutex_lock(&g_fmt_lock);
+	if (!cf[base->fp]) {
+		astc_fmt* f = (astc_fmt*)calloc(1, sizeof(astc_fmt));
+		f->bw = bw; f->bh = bh; f->n = bw*bh; f->fp = base->fp; f->census = 1;
+		for (int cls = 0; cls < 5; ++cls)
+			for (int a = 0; a < 2; ++a)
+				build_configs(f, cls, a);
+		memcpy(f->npart, base->npart, sizeof(f->npart));
+		memcpy(f->pseed, base->pseed, sizeof(f->pseed));
+		memcpy(f->pid, base->pid, sizeof(f->pid));
+		memcpy(f->pmask, base->pmask, sizeof(f->pmask));
+		cf[base->fp] = f;
+	}
+	pthread_mutex_unlock(&g_fmt_lock);
+	const astc_fmt* f = cf[base->fp];
+	int n = bw*bh;
+	astc_blk* b = (astc_blk*)malloc(sizeof(astc_blk));
+	for (int by = 0; by + bh <= h; by += bh)
+		for (int bx = 0; bx + bw <= w; bx += bw) {
+			int solid = 1;
+			b->f = f; b->n = n; b->flags = flags; b->has_alpha = 0; b->grey = 1;
+			for (int i = 0; i < n; ++i) {
+				const uint8_t* p = rgba + ((size_t)(by + i/bw)*w + bx + i % bw)*4;
+				for (int c = 0; c < 4; ++c) b->px[i][c] = p[c];
+				if (memcmp(b->px[i], b->px[0], 4*sizeof(int)) != 0) solid = 0;
+				if (p[3] != 255) b->has_alpha = 1;
+				if (p[0] != p[1] || p[0] != p[2]) b->grey = 0;
+				b->wa[i] = (flags & ASTC_FLAG_ALPHA_WEIGHT) ? p[3] : 255;
+			}
+			if (solid)
+				continue;
+			b->nc = b->has_alpha ? 4 : 3;
+			b->cw[0] = b->cw[1] = b->cw[2] = b->cw[3] = 1;
+			int sum[4] = {0, 0, 0, 0}, SS[4][4];
+			memset(SS, 0, sizeof(SS));
+			for (int i = 0; i < n; ++i)
+				for (int a = 0; a < b->nc; ++a) {
+					sum[a] += b->px[i][a];
+					for (int c = a; c < b->nc; ++c)
+						SS[a][c] += b->px[i][a]*b->px[i][c];
+				}
+			float Cm[4][4], mean[4], axis[4], in = 1.0f/(float)n;
+			for (int a = 0; a < 4; ++a) {
+				mean[a] = (float)sum[a]*in;
+				for (int c = a; c < 4; ++c)
+					Cm[a][c] = (float)(n*SS[a][c] - sum[a]*sum[c]);
+			}
+			principal_axis(Cm, axis);
+			float tmin = 3.0e38f, tmax = -3.0e38f;
+			for (int i = 0; i < n; ++i) {
+				float t = axis[0]*((float)b->px[i][0] - mean[0]);
+				t = fmaf(axis[1], (float)b->px[i][1] - mean[1], t);
+				t = fmaf(axis[2], (float)b->px[i][2] - mean[2], t);
+				t = fmaf(axis[3], (b->nc == 4 ? (float)b->px[i][3] : 0.0f) - mean[3], t);
+				tmin = fminf(tmin, t);
+				tmax = fmaxf(tmax, t);
+			}
+			astc_pc pcs[5];
+			int npc = 0, sl[2];
+			pcs[npc++] = (astc_pc){1, 0, 0, 0, 0};
+			if (b->has_alpha) pcs[npc++] = (astc_pc){1, 1, 3, 1, 0};
+			else if (!b->grey) pcs[npc++] = (astc_pc){1, 1, 1, 1, 0};
+			for (int P = 2; P <= 4; ++P)
+				if (shortlist(b, P, 64, 1, axis, mean, tmin, tmax, sl) == 1)
+					pcs[npc++] = (astc_pc){P, 0, 0, P, sl[0]};
+			for (int j = 0; j < npc; ++j) {
+				const astc_pc* pc = &pcs[j];
+				int slots = pc->dual ? 2 : pc->P;
+				for (int s = 0; s < slots; ++s)
+					phase_a(b, 0, pc, s);
+				uint64_t be = ~0ull;
+				int bk = -1;
+				astc_lane cur;
+				for (int k = 0; k < f->ncfg[pc->cls][b->has_alpha]; ++k) {
+					phase_b(b, 0, pc, &f->cfg[pc->cls][b->has_alpha][k], &cur);
+					if (cur.valid && cur.err < be) { be = cur.err; bk = k; }
+				}
+				if (bk >= 0) {
+					const astc_cfg* c = &f->cfg[pc->cls][b->has_alpha][bk];
+					counts[(pc->cls*2 + b->has_alpha)*4096 + (c->N | (c->M << 4) | (c->wq << 8))]++;
+				}
+			}
+		}
+	free(b);
+	return 0;
 }

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Ranks the ASTC weight-grid configs per footprint and candidate class from a census.
+
+The encoder can afford to LIST 64 configs per class (and keep 24 weight grids' infill tables in
+LDS); which ones is a data question, as in astcenc's block-mode percentile tables.  The census
+(oracle/astc_encode.c: cfo_astc_census_image) encodes synthetic content -- the bench "photo"
+generator with and without its alpha band, smooth gradients, noise, hard-edged shapes -- and, for
+every block and class (one partition, dual plane, 2 / 3 / 4 partitions), finds the best of ALL legal
+configs by exact error.  Configs are ranked by win count; the top 64 per class go, in that order,
+into astc_cfg_rank.h -- written twice with identical content, for the oracle (oracle/) and for the
+library (cuttlefish_amd/csrc/), which must build the same lists.
+
+    python tools/astc_rank_configs.py [--size 256]
+"""
+import argparse
+import ctypes
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+from cuttlefish_amd import synth  # noqa: E402
+
+FP = [(4, 4), (5, 4), (5, 5), (6, 5), (6, 6), (8, 5), (8, 6), (8, 8), (10, 5), (10, 6), (10, 8),
+      (10, 10), (12, 10), (12, 12)]
+
+
+def content(size):
+    """census images: RGBA8, size x size"""
+    rng = np.random.default_rng(0xA57C)
+    out = []
+    for seed in (201, 202, 203):
+        out.append(synth.photo(size, size, seed=seed))                      # with the alpha band
+        o = synth.photo(size, size, seed=seed + 10)
+        o[..., 3] = 255
+        out.append(o)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float64)
+    g = np.stack([128 + 100*np.sin(xx/37 + yy/71), 128 + 90*np.cos(xx/53 - yy/29),
+                  128 + 80*np.sin(xx/23 + yy/41 + 1), 0*xx + 255], -1)
+    out.append(g.round().clip(0, 255).astype(np.uint8))                     # smooth
+    g2 = g.copy()
+    g2[..., 3] = 128 + 120*np.sin(xx/61 + yy/17)
+    out.append(g2.round().clip(0, 255).astype(np.uint8))                    # smooth, independent alpha
+    n = (g + rng.normal(0, 12, g.shape)).round().clip(0, 255).astype(np.uint8)
+    n[..., 3] = 255
+    out.append(n)                                                           # textured
+    e = np.zeros((size, size, 4), np.uint8)
+    e[..., 3] = 255
+    for _ in range(size*size//600):
+        x, y, w, h = rng.integers(0, size, 4)
+        e[y:y + h//8 + 2, x:x + w//8 + 2, :3] = rng.integers(0, 256, 3)
+    out.append(e)                                                           # hard edges
+    return [np.ascontiguousarray(i) for i in out]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=240)
+    ap.add_argument("--grids", default="global", choices=["global", "class"],
+                    help="global: the 24 grids with the largest share of wins, lists restricted to them; "
+                         "class: plain per-class ranking (the builders stop adding grids at 24)")
+    ap.add_argument("--out", default="", help="write only this one file (experiments)")
+    ap.add_argument("--static-for", default="8x8,10x6,10x8,10x10,12x10",
+                    help="footprints that keep the fixed noise-model order (empty lists): on held-out content\n"
+                         "(bench tile crops, not in the census) their census lists scored 0.4-1.2 dB lower --\n"
+                         "24 grids cover only 55-75 %% of the winning configs of the large footprints")
+    args = ap.parse_args()
+    L = O.lib()
+    L.cfo_astc_census_image.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    imgs = content(args.size)
+    table = np.zeros((14, 10, 64), np.uint16)
+
+    def census(fi):
+        bw, bh = FP[fi]
+        counts = np.zeros(10*4096, np.uint32)
+        for im in imgs:
+            L.cfo_astc_census_image(im.ctypes.data, args.size, args.size, bw, bh, 0, counts.ctypes.data)
+        return fi, counts.reshape(10, 4096)
+
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
+        for fi, counts in ex.map(census, range(14)):
+            # the library keeps 24 weight grids' infill tables in LDS per footprint: pick them by
+            # their share of the wins (each class normalised, classes weighted by how often their
+            # candidates win a block: one partition 3, two partitions 2, dual plane 1, three 1, four 0.5)
+            cw = [3.0, 1.0, 2.0, 1.0, 0.5]
+            gscore = np.zeros(256)
+            codes = np.arange(4096)
+            gid = codes & 255                                   # N | M << 4
+            for k in range(10):
+                tot = counts[k].sum()
+                if tot:
+                    np.add.at(gscore, gid, cw[k//2]*counts[k]/tot)
+            grids = set(int(g) for g in np.argsort(-gscore, kind="stable")[:24] if gscore[g] > 0)
+            for k in range(10):
+                order = np.argsort(-counts[k].astype(np.int64), kind="stable")
+                order = [int(c) for c in order if counts[k][c] > 0 and (args.grids == "class" or (c & 255) in grids)][:64]
+                table[fi, k, :len(order)] = order
+                tot = int(counts[k].sum())
+                cov = int(counts[k][order].sum()) if order else 0
+                print("footprint %dx%d class %d alpha %d: %d blocks, %d configs won at least once, "
+                      "listed %d on the 24 chosen grids cover %.1f %%" % (
+                          FP[fi][0], FP[fi][1], k//2, k & 1, tot, int((counts[k] > 0).sum()), len(order),
+                          100.0*cov/max(tot, 1)), flush=True)
+    for name in [x for x in args.static_for.split(",") if x]:
+        bw, bh = [int(v) for v in name.split("x")]
+        table[FP.index((bw, bh))] = 0
+    lines = ["/* astc_cfg_rank.h -- GENERATED by tools/astc_rank_configs.py (do not edit): per footprint and",
+             " * candidate class x alpha, the weight-grid configs (N | M << 4 | weight range << 8) ranked by how",
+             " * often each was the best of ALL legal configs in a census of synthetic content; 0 ends a list",
+             " * (an empty list = the fixed noise-model order).  The library and the oracle carry the same data. */",
+             "static const unsigned short astc_cfg_rank[14][10][64] = {"]
+    for fi in range(14):
+        lines.append("\t{ /* %dx%d */" % FP[fi])
+        for k in range(10):
+            lines.append("\t\t{" + ", ".join(str(int(v)) for v in table[fi, k]) + "},")
+        lines.append("\t},")
+    lines.append("};")
+    txt = "\n".join(lines) + "\n"
+    paths = [args.out] if args.out else [os.path.join(ROOT, "oracle", "astc_cfg_rank.h"),
+                                         os.path.join(ROOT, "cuttlefish_amd", "csrc", "astc_cfg_rank.h")]
+    for path in paths:
+        open(path, "w").write(txt)
+    print("wrote astc_cfg_rank.h (oracle/ and cuttlefish_amd/csrc/)")
+
+
+if __name__ == "__main__":
+    main()
