@@ -63,8 +63,19 @@ def test_block_header_fields_and_features_in_use():
         r = ((v >> 4) & 1) | (((v & 3) if v & 3 else (v >> 2) & 3) << 1)
         triq += r in (3, 5, 6)
     assert cems <= {0, 4, 6, 8, 10, 12} and len(cems) >= 3
-    assert parts[1] > 0 and parts[2] > 0 and parts[3] > 0 and parts[4] == 0
+    assert parts[1] > 0 and parts[2] > 0 and parts[4] == 0
     assert dual > 0 and triq > 0
+    # three flat colour regions crossing the blocks: three-partition blocks are chosen too
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:96, 0:96]
+    cols = np.array([[220, 40, 30, 255], [30, 200, 60, 255], [40, 50, 230, 255]])
+    img = (cols[((xx*0.9 + yy*0.5)//7).astype(int) % 3] + rng.integers(-6, 7, (96, 96, 4))).clip(0, 255).astype(np.uint8)
+    img[..., 3] = 255
+    three = 0
+    for b in O.encode(img, 47, quality=3, threads=8).reshape(-1, 16):
+        v = int.from_bytes(bytes(b), "little")
+        three += (v & 0x1FF) != 0x1FC and ((v >> 11) & 3) == 2
+    assert three > 0
 
 
 def test_alpha_weight_and_perceptual_flags_change_the_search():
