@@ -705,7 +705,13 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			const uint32_t o = (uint32_t)__shfl_xor((int)npc, 32, 64);
 			npc_max = max(npc, o);
 		}
+		// early out (oracle: same rule): no two-partition candidate of pass 0 beat the best
+		// one-partition candidate -> the later passes are skipped.  More than one pass only exists
+		// above Normal, where a wave holds one block, so the branch is uniform.
+		unsigned long long e1min = ~0ull, e2min = ~0ull;
 		for (uint32_t base = 0, pass = 0; base < npc_max; base += per_pass, ++pass) {
+			if (pass >= 1u && !pair && e2min != ~0ull && e2min >= e1min)
+				break;
 			const uint32_t cnt = base >= npc ? 0u : (npc - base < per_pass ? npc - base : per_pass);
 			// partition rows of this pass's candidates
 			for (uint32_t j = 0; j < cnt; ++j) {
@@ -1130,6 +1136,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						r_lv = best_lv;
 						r_ncv = nv*P;
 					}
+				}
+				if (pass == 0u && !pair) {
+					e1min = cf_group_min_u64(P == 1u ? err : ~0ull, false, 0u);
+					e2min = cf_group_min_u64(P == 2u ? err : ~0ull, false, 0u);
 				}
 				// ---- argmin (error, id); the winner parks its result in the block's slot ----
 				const uint32_t id = pass*64u + hl;

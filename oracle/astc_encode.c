@@ -942,7 +942,14 @@ void cfo_encode_astc_block(const int px[][4], int bw, int bh, int quality, int f
 	best.err = ~0ull;
 	uint32_t best_id = 0xFFFFFFFFu;
 	int best_pc = 0, best_k = 0;
+	/* early out (astcenc's partition early-out limits play this role): when no two-partition
+	 * candidate of the first pass beats the best one-partition candidate, the later passes --
+	 * more two-partition seeds, three and four partitions -- are skipped (0.03 dB on the test
+	 * content, half of High's and two thirds of Highest's work) */
+	uint64_t e1 = ~0ull, e2 = ~0ull;
 	for (int base = 0, pass = 0; base < npc; base += per_pass, ++pass) {
+		if (pass >= 1 && e2 != ~0ull && e2 >= e1)
+			break;
 		int cnt = npc - base < per_pass ? npc - base : per_pass;
 		for (int j = 0; j < cnt; ++j) {
 			const astc_pc* pc = &pcs[base + j];
@@ -959,6 +966,8 @@ void cfo_encode_astc_block(const int px[][4], int bw, int bh, int quality, int f
 			int nk = rank_configs(b, j, pc, lad->K, order);
 			for (int k = 0; k < nk; ++k) {
 				phase_b(b, j, pc, &f->cfg[pc->cls][b->has_alpha][order[k]], &cur);
+				if (cur.valid && pass == 0 && pc->P == 1 && cur.err < e1) e1 = cur.err;
+				if (cur.valid && pass == 0 && pc->P == 2 && cur.err < e2) e2 = cur.err;
 				uint32_t id = (uint32_t)(pass*64 + j*lad->K + k);
 				if (cur.valid && (cur.err < best.err || (cur.err == best.err && id < best_id))) {
 					best = cur;
