@@ -340,26 +340,31 @@ __device__ __forceinline__ unsigned long long ise_group(const uint8_t* ise, cons
 
 } // namespace
 
-template <int PIX>
-__global__ void __launch_bounds__(CF_WG_THREADS)
+// A workgroup is 4, 8 or 12 waves (4 blocks per wave): the launcher picks the shape that puts the
+// most waves on a CU within the 160 KB of LDS -- the kernel is latency bound (dependent LDS
+// gathers, cross-lane reductions), so the third wave per SIMD is worth more than the registers it
+// costs.  MAXW is the launch bound: 12 waves cap the kernel at 168 VGPRs, 8 waves leave it 256.
+template <int PIX, int MAXW>
+__global__ void __launch_bounds__(MAXW*64)
 cfhip_astc_encode_kernel(cf_kparams kp)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
-	__shared__ uint4 outb[CF_BLOCKS_PER_WG];
+	__shared__ uint4 outb[MAXW*4];
+	const uint32_t nthreads = blockDim.x, nblk = blockDim.x >> 4;
 	const uint8_t* blob = reinterpret_cast<const uint8_t*>(kp.aux);
 	const AstcBlobHeader* H = reinterpret_cast<const AstcBlobHeader*>(blob);
 	const uint32_t n = H->n, bw = H->bw, bh = H->bh, ngrids = H->ngrids, npad = H->npad;
 	const uint32_t col_rows = H->col_rows;
 	const uint32_t aflags = (kp.flags >> 16) & 3u;
-	// texel-weight cache rows: only above Normal -- up to Normal two blocks share a wave and need two
-	// block slots, and without the cache the workgroup's LDS allows two workgroups per CU
-	const bool wcached = n <= 36u && kp.quality > 2u;
+	// texel-weight cache rows: a launch-time choice (cfhip_astc_plan) -- on when they fit without
+	// costing a wave of occupancy; the cache never changes a result
+	const bool wcached = (kp.flags >> 18) & 1u;
 	const uint32_t wc_rows = wcached ? 2u*((n + 3u)/4u) : 0u;
 
 	// ---- LDS carve-up (byte offsets, 16-byte aligned sections) ----
 	uint8_t* lds = reinterpret_cast<uint8_t*>(dyn_lds);
 	uint32_t off = 0;
-	uint32_t* tile = reinterpret_cast<uint32_t*>(lds + off); off += CF_BLOCKS_PER_WG*n*4u;
+	uint32_t* tile = reinterpret_cast<uint32_t*>(lds + off); off += nblk*n*4u;
 	off = (off + 15u) & ~15u;
 	uint32_t* sh_infill = reinterpret_cast<uint32_t*>(lds + off); off += ngrids*n*4u; off = (off + 15u) & ~15u;
 	uint16_t* sh_den = reinterpret_cast<uint16_t*>(lds + off); off += ngrids*128u;
@@ -371,23 +376,23 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	uint8_t* wbase = lds + off + wave*wave_bytes;
 
-	for (uint32_t i = threadIdx.x; i < ngrids*n; i += CF_WG_THREADS)
+	for (uint32_t i = threadIdx.x; i < ngrids*n; i += nthreads)
 		sh_infill[i] = reinterpret_cast<const uint32_t*>(blob + H->off_infill)[i];
-	for (uint32_t i = threadIdx.x; i < ngrids*64u; i += CF_WG_THREADS)
+	for (uint32_t i = threadIdx.x; i < ngrids*64u; i += nthreads)
 		sh_den[i] = reinterpret_cast<const uint16_t*>(blob + H->off_den)[i];
-	for (uint32_t i = threadIdx.x; i < ngrids; i += CF_WG_THREADS)
+	for (uint32_t i = threadIdx.x; i < ngrids; i += nthreads)
 		reinterpret_cast<uint32_t*>(sh_grid)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_grid)[i];
-	for (uint32_t i = threadIdx.x; i < 2u*17u*64u; i += CF_WG_THREADS)
+	for (uint32_t i = threadIdx.x; i < 2u*17u*64u; i += nthreads)
 		reinterpret_cast<uint32_t*>(sh_ctab)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_ctab)[i];
-	for (uint32_t i = threadIdx.x; i < 304u; i += CF_WG_THREADS)
+	for (uint32_t i = threadIdx.x; i < 304u; i += nthreads)
 		reinterpret_cast<uint32_t*>(sh_wtab)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_wtab)[i];
 
 	uint32_t gx_, gy_;
 	cf_resolve(kp, gx_, gy_);
-	const uint32_t bx0 = gx_*CF_BLOCKS_PER_WG, byy = gy_;
+	const uint32_t bx0 = gx_*nblk, byy = gy_;
 	{
-		const uint32_t sw = CF_BLOCKS_PER_WG*bw, total = sw*bh;
-		for (uint32_t idx = threadIdx.x; idx < total; idx += CF_WG_THREADS) {
+		const uint32_t sw = nblk*bw, total = sw*bh;
+		for (uint32_t idx = threadIdx.x; idx < total; idx += nthreads) {
 			const uint32_t row = idx/sw, col = idx - row*sw;
 			const uint32_t blk = col/bw, cx = col - blk*bw;
 			uint32_t x = bx0*bw + col, y = byy*bh + row;
@@ -1244,7 +1249,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	}
 	__syncthreads();
 	const uint32_t t = threadIdx.x;
-	if (t < 64u) {
+	if (t < nblk*4u) {
 		const uint32_t b = t >> 2;
 		if (bx0 + b < kp.bx) {
 			const uint32_t* o = reinterpret_cast<const uint32_t*>(outb);
@@ -1255,42 +1260,86 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 }
 
 // dynamic LDS of a launch for this footprint (same carve-up as in the kernel)
-extern "C" size_t cfhip_astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality)
+static size_t astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality, uint32_t nwaves, bool wcached)
 {
 	const uint32_t n = h->n, ngrids = h->ngrids, npad = h->npad;
-	uint32_t off = CF_BLOCKS_PER_WG*n*4u;
+	uint32_t off = nwaves*4u*n*4u;
 	off = (off + 15u) & ~15u;
 	off += ngrids*n*4u; off = (off + 15u) & ~15u;
 	off += ngrids*128u;
 	off += (ngrids*4u + 15u) & ~15u;
 	off += 2u*17u*256u + 1216u;
-	const uint32_t wc_rows = (n <= 36u && quality > 2u) ? 2u*((n + 3u)/4u) : 0u;
+	const uint32_t wc_rows = wcached ? 2u*((n + 3u)/4u) : 0u;
 	const uint32_t slot_bytes = ((10u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
 	const uint32_t wave_bytes = ((((h->col_rows + 1u)/2u)*256u + wc_rows*256u + 15u) & ~15u) + (quality <= 2u ? 2u : 1u)*slot_bytes;
-	return (size_t)off + 4u*(size_t)wave_bytes;
+	return (size_t)off + nwaves*(size_t)wave_bytes;
 }
 
-extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, size_t lds_bytes, hipStream_t stream)
+// Launch shape of a footprint / quality: waves per workgroup (4, 8 or 12; a workgroup covers
+// 4 blocks per wave of one block row) and whether the texel-weight cache rows are carved.  The
+// choice maximises the waves resident on a CU (12 = three per SIMD with the 168-register build,
+// else 8), then prefers the cache, then the smaller workgroup (finer scheduling grain).
+extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t quality, uint32_t* nwaves, uint32_t* wcached, size_t* lds_bytes)
 {
-	dim3 grid((kp->bx + CF_BLOCKS_PER_WG - 1)/CF_BLOCKS_PER_WG, kp->by, 1);
+	const size_t cu_lds = 160u*1024u, wg_max = 160u*1024u - 1024u;
+	const bool can_cache = h->n <= 36u;
+	uint32_t best_w = 0, best_nw = 4, best_c = 0;
+	const char* force = getenv("CFHIP_ASTC_WAVES");
+	for (uint32_t c = 0; c < 2u; ++c) {
+		if (c && !can_cache)
+			break;
+		for (uint32_t nw = 4; nw <= 12u; nw += 4u) {
+			if (force && (uint32_t)atoi(force) != nw)
+				continue;
+			const size_t b = astc_lds_bytes(h, quality, nw, c != 0u);
+			if (b > wg_max)
+				continue;
+			uint32_t w = (uint32_t)(cu_lds/(b + 1024u))*nw;      // 1024: the static outb + allocation granule
+			w = w >= 12u ? 12u : (w >= 8u ? 8u : w);
+			if (w > best_w || (w == best_w && c > best_c)) {
+				best_w = w; best_nw = nw; best_c = c;
+			}
+		}
+	}
+	*nwaves = best_nw;
+	*wcached = best_c;
+	*lds_bytes = astc_lds_bytes(h, quality, best_nw, best_c != 0u);
+}
+
+extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, uint32_t nwaves, size_t lds_bytes, hipStream_t stream)
+{
+	dim3 grid((kp->bx + nwaves*4u - 1u)/(nwaves*4u), kp->by, 1);
 	if (kp->batch)
 		grid = dim3(kp->total_wg, 1, 1);
-	dim3 block(CF_WG_THREADS, 1, 1);
+	dim3 block(nwaves*64u, 1, 1);
 	static bool attr_set = false;
 	if (!attr_set) {
 		// more than 64 KB of dynamic LDS needs the opt-in (160 KB per CU on gfx950)
-		hipFuncSetAttribute(reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 1024);
-		hipFuncSetAttribute(reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<1, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 1024);
 		attr_set = true;
 	}
+	// the 168-register build only where three waves per SIMD actually become resident
+	const bool dense = (160u*1024u/(lds_bytes + 1024u))*nwaves >= 12u && !getenv("CFHIP_ASTC_NO_DENSE");
 	if (getenv("CFHIP_ASTC_DEBUG")) {
 		int nb = -1;
-		hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0>), CF_WG_THREADS, lds_bytes);
-		fprintf(stderr, "[astc] dynamic LDS %zu B, workgroups per CU %d (%s), grid %u x %u\n", lds_bytes, nb, hipGetErrorString(oe), grid.x, grid.y);
+		const void* fn = dense ? reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 12>) : reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 8>);
+		hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, (int)(nwaves*64u), lds_bytes);
+		fprintf(stderr, "[astc] %u waves per workgroup, dynamic LDS %zu B, %s build, workgroups per CU %d (%s), grid %u x %u\n",
+			nwaves, lds_bytes, dense ? "168-VGPR" : "256-VGPR", nb, hipGetErrorString(oe), grid.x, grid.y);
 	}
-	if (pixel_type == 0)
-		hipLaunchKernelGGL((cfhip_astc_encode_kernel<0>), grid, block, lds_bytes, stream, *kp);
-	else
-		hipLaunchKernelGGL((cfhip_astc_encode_kernel<1>), grid, block, lds_bytes, stream, *kp);
+	if (dense) {
+		if (pixel_type == 0)
+			hipLaunchKernelGGL((cfhip_astc_encode_kernel<0, 12>), grid, block, lds_bytes, stream, *kp);
+		else
+			hipLaunchKernelGGL((cfhip_astc_encode_kernel<1, 12>), grid, block, lds_bytes, stream, *kp);
+	} else {
+		if (pixel_type == 0)
+			hipLaunchKernelGGL((cfhip_astc_encode_kernel<0, 8>), grid, block, lds_bytes, stream, *kp);
+		else
+			hipLaunchKernelGGL((cfhip_astc_encode_kernel<1, 8>), grid, block, lds_bytes, stream, *kp);
+	}
 	return hipGetLastError();
 }

@@ -23,8 +23,8 @@
 
 extern "C" hipError_t cfhip_launch_bc7(const cf_kparams* kp, int pixel_type, int unit_weights,
 	hipStream_t stream);
-extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, size_t lds_bytes, hipStream_t stream);
-extern "C" size_t cfhip_astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality);
+extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, uint32_t nwaves, size_t lds_bytes, hipStream_t stream);
+extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t quality, uint32_t* nwaves, uint32_t* wcached, size_t* lds_bytes);
 extern "C" hipError_t cfhip_launch_etc(const cf_kparams* kp, int format, int pixel_type, int snorm,
 	hipStream_t stream);
 extern "C" hipError_t cfhip_launch_bc6h(const cf_kparams* kp, int pixel_type, int is_signed,
@@ -328,6 +328,37 @@ void fill_kparams(cf_kparams& kp, const cfhip_params& p, const void* src, void* 
 	}
 }
 
+// the footprint's device tables, built on first use
+int astc_prepare(cfhip_ctx* ctx, int format)
+{
+	void*& tab = ctx->astc_tables[format];
+	if (tab)
+		return CFHIP_OK;
+	int fbw, fbh;
+	astc_footprint(format, &fbw, &fbh);
+	const std::vector<uint8_t> host = cfastc::build_blob(fbw, fbh);
+	memcpy(&ctx->astc_hdr[format], host.data(), sizeof(cfastc::AstcBlobHeader));
+	HIP_TRY(ctx, hipMalloc(&tab, host.size()));
+	HIP_TRY(ctx, hipMemcpy(tab, host.data(), host.size(), hipMemcpyHostToDevice));
+	return CFHIP_OK;
+}
+
+// blocks of one block row a workgroup covers (the ASTC launch shape depends on the footprint)
+int blocks_per_wg(cfhip_ctx* ctx, const cfhip_params& p, uint32_t quality, uint32_t* out)
+{
+	*out = CF_BLOCKS_PER_WG;
+	if (p.format >= CFHIP_FORMAT_ASTC_4x4 && p.format <= CFHIP_FORMAT_ASTC_12x12) {
+		const int rc = astc_prepare(ctx, p.format);
+		if (rc != CFHIP_OK)
+			return rc;
+		uint32_t nwaves, wcached;
+		size_t lds_bytes;
+		cfhip_astc_plan(&ctx->astc_hdr[p.format], quality, &nwaves, &wcached, &lds_bytes);
+		*out = nwaves*4u;
+	}
+	return CFHIP_OK;
+}
+
 int launch(cfhip_ctx* ctx, const cf_kparams& kp, const cfhip_params& p, int pixel_type,
 	hipStream_t stream)
 {
@@ -355,23 +386,20 @@ int launch(cfhip_ctx* ctx, const cf_kparams& kp, const cfhip_params& p, int pixe
 		case CFHIP_FORMAT_ASTC_12x10: case CFHIP_FORMAT_ASTC_12x12: {
 			if (pixel_type != CFHIP_PIXEL_RGBA8 && pixel_type != CFHIP_PIXEL_RGBA32F)
 				return fail(ctx, CFHIP_E_UNSUPPORTED, "ASTC LDR takes RGBA8 or RGBA32F pixels");
-			void*& tab = ctx->astc_tables[p.format];
-			cfastc::AstcBlobHeader& hdr = ctx->astc_hdr[p.format];
-			if (!tab) {
-				int fbw, fbh;
-				astc_footprint(p.format, &fbw, &fbh);
-				const std::vector<uint8_t> host = cfastc::build_blob(fbw, fbh);
-				memcpy(&hdr, host.data(), sizeof(hdr));
-				HIP_TRY(ctx, hipMalloc(&tab, host.size()));
-				HIP_TRY(ctx, hipMemcpy(tab, host.data(), host.size(), hipMemcpyHostToDevice));
-			}
+			const int trc = astc_prepare(ctx, p.format);
+			if (trc != CFHIP_OK)
+				return trc;
+			uint32_t nwaves, wcached;
+			size_t lds_bytes;
+			cfhip_astc_plan(&ctx->astc_hdr[p.format], kp.quality, &nwaves, &wcached, &lds_bytes);
 			cf_kparams k2 = kp;
-			k2.aux = tab;
+			k2.aux = ctx->astc_tables[p.format];
+			k2.flags |= wcached << 18;
 			// ASTCENC_FLG_USE_ALPHA_WEIGHT for Alpha::Standard / PreMultiplied, USE_PERCEPTUAL for sRGB
 			// images (AstcConverter.cpp:163-172)
 			k2.flags |= ((p.alpha == CFHIP_ALPHA_STANDARD || p.alpha == CFHIP_ALPHA_PREMULTIPLIED) ? 1u << 16 : 0u) |
 				(p.color_space == CFHIP_COLOR_SRGB ? 1u << 17 : 0u);
-			e = cfhip_launch_astc(&k2, pixel_type == CFHIP_PIXEL_RGBA32F ? 1 : 0, cfhip_astc_lds_bytes(&hdr, kp.quality), stream);
+			e = cfhip_launch_astc(&k2, pixel_type == CFHIP_PIXEL_RGBA32F ? 1 : 0, nwaves, lds_bytes, stream);
 			ctx->last_kernel = "cfhip_astc_encode_kernel";
 			break;
 		}
@@ -489,17 +517,20 @@ int batched_launch(cfhip_ctx* ctx, const std::vector<cf_kparams>& kps, const cfh
 		return CFHIP_OK;
 	}
 	std::vector<cf_batch_entry> entries(kps.size());
-	uint32_t wg = 0;
+	uint32_t wg = 0, per_wg;
+	int rc = blocks_per_wg(ctx, p, kps[0].quality, &per_wg);
+	if (rc != CFHIP_OK)
+		return rc;
 	for (size_t i = 0; i < kps.size(); ++i) {
 		cf_batch_entry& e = entries[i];
 		e.src = kps[i].src; e.out = kps[i].out; e.pitch = kps[i].pitch;
 		e.width = kps[i].width; e.height = kps[i].height; e.bx = kps[i].bx; e.by = kps[i].by;
-		e.wgx = (kps[i].bx + CF_BLOCKS_PER_WG - 1)/CF_BLOCKS_PER_WG;
+		e.wgx = (kps[i].bx + per_wg - 1)/per_wg;
 		e.wg_begin = wg;
 		wg += e.wgx*kps[i].by;
 	}
 	const size_t bytes = entries.size()*sizeof(cf_batch_entry);
-	int rc = staging_acquire(ctx, stream);
+	rc = staging_acquire(ctx, stream);
 	if (rc != CFHIP_OK)
 		return rc;
 	rc = reserve(ctx, &ctx->d_batch, &ctx->batch_cap, bytes);
