@@ -87,6 +87,11 @@ def kernel_mix(lib, kernel_substr):
     total = sum(valu.values())
     fast = sum(v for k, v in valu.items() if re.sub(r"_(e32|e64|dpp|sdwa|e64_dpp)$", "", k) in FAST)
     cpi = (2.0*fast + 4.0*(total - fast))/total
+    # the same price without the fp32 fma/mul/add/min/max opcodes: the PMC class counters count those
+    # dynamically (SQ_INSTS_VALU_FMA_F32 / _MUL_F32 / _ADD_F32), the static mix prices only the rest
+    fp = sum(v for k, v in valu.items() if re.sub(r"_(e32|e64|dpp|sdwa|e64_dpp)$", "", k) in FAST and k.split("_")[-2 if k.endswith(("_e32", "_e64", "_dpp", "_sdwa")) else -1] == "f32")
+    rest_total, rest_fast = total - fp, fast - fp
+    cpi_rest = (2.0*rest_fast + 4.0*(rest_total - rest_fast))/max(rest_total, 1)
     return {
         "kernel": name,
         "code_sha256": hashlib.sha256(" ".join(ops).encode()).hexdigest()[:16],
@@ -94,6 +99,8 @@ def kernel_mix(lib, kernel_substr):
         "lds": sum(v for k, v in hist.items() if k.startswith("ds_")),
         "valu_fast_share": round(fast/total, 4),
         "valu_cycles_per_inst": round(cpi, 4),
+        "valu_fp32_fast_share": round(fp/total, 4),
+        "valu_cycles_per_non_fp32_inst": round(cpi_rest, 4),
         "top_valu": sorted(valu.items(), key=lambda kv: -kv[1])[:16],
         "classes": "2 cycles: " + ", ".join(sorted(FAST)) + "; 4 cycles: every other VALU opcode "
                    "(profiles/r01_valu_rate.txt)",
