@@ -21,7 +21,7 @@
 //   phase B   lane = (candidate, config): decimate, quantise, least squares, endpoint mode and
 //             quantisation, EXACT error through the decode arithmetic
 //   argmin (error, id) over the lanes and the passes; the group packs the winner (ISE).
-// Data: the workgroup stages a strip of 16 blocks, the footprint's infill / factor-sum tables
+// Data: the workgroup (4, 8 or 12 waves, cfhip_astc_plan) stages a strip of 4 blocks per wave, the footprint's infill / factor-sum tables
 // and the colour / weight quantisation tables in LDS; each lane owns an LDS column for its grid
 // accumulators and quantised weights ([row][lane], conflict-free for a fixed row).
 #include "cf_device.h"
