@@ -62,7 +62,7 @@ __device__ __forceinline__ Ladder ladder(uint32_t q)
 		case 0: return {2, 0, 0, 0, 0, 0};
 		case 1: return {4, 16, 2, 0, 0, 1};
 		case 2: return {4, 32, 3, 2, 0, 2};
-		case 3: return {8, 96, 8, 5, 0, 2};
+		case 3: return {8, 256, 8, 5, 0, 2};
 		default: return {8, 256, 14, 9, 6, 2};
 	}
 }

@@ -46,7 +46,7 @@ struct RgbOpts {
 	uint32_t active, transparent;
 	int wt[3];
 	int radius;    // move rounds of the T / H search
-	int walk;      // base-colour walk of the half search: 1 / 7 / 27 / 125 / 125 + 2 descent steps
+	int walk;      // base-colour walk of the half search: 1 / 3 / 9 / 27 / 125 + 2 descent steps
 	bool refine;   // false: Lowest -- no planar move rounds, no T/H modes
 };
 
@@ -547,19 +547,21 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 	const bool unitw = o.wt[0] == 1 && o.wt[1] == 1 && o.wt[2] == 1;   // uniform
 	const int tma = o.punch ? 0 : k_etc_mod[t][0], tmb = k_etc_mod[t][1];
 	if (!fam4 || o.allow_indiv) {
-		// candidates in id order (oracle: search_half): the quantised half mean; + its six axis
-		// neighbours; the 3x3x3 cube; the 5x5x5 cube; out-of-range coordinates clamp
+		// candidates in id order (oracle: search_half): the quantised half mean; + its two grey-
+		// diagonal neighbours; + its six axis neighbours; the 3x3x3 cube; the 5x5x5 cube;
+		// out-of-range coordinates clamp
 		const int walk = o.walk;
-		const int ncand = walk == 0 ? 1 : (walk == 1 ? 7 : (walk == 2 ? 27 : 125));
-		const int r = walk == 2 ? 1 : 2;
+		const int ncand = walk == 0 ? 1 : (walk == 1 ? 3 : (walk == 2 ? 9 : (walk == 3 ? 27 : 125)));
+		const int r = walk == 3 ? 1 : 2;
 		int o0 = -r, o1 = -r, o2 = -r;      // cube odometer (blue fastest): no divisions in the walk
 #pragma unroll 1
 		for (int cand = 0; cand < ncand; ++cand) {
 			int d0 = 0, d1 = 0, d2 = 0;
-			if (walk == 1) {
-				const int ax = (cand - 1) >> 1, dd = cand == 0 ? 0 : (((cand - 1) & 1) ? 1 : -1);
-				d0 = ax == 0 ? dd : 0; d1 = ax == 1 ? dd : 0; d2 = ax == 2 ? dd : 0;
-			} else if (walk >= 2) {
+			if (walk <= 2) {
+				const int dg = cand == 1 ? 1 : (cand == 2 ? -1 : 0);
+				const int ax = (cand - 3) >> 1, dd = cand < 3 ? 0 : (((cand - 3) & 1) ? 1 : -1);
+				d0 = dg + (ax == 0 ? dd : 0); d1 = dg + (ax == 1 ? dd : 0); d2 = dg + (ax == 2 ? dd : 0);
+			} else if (walk >= 3) {
 				d0 = o0; d1 = o1; d2 = o2;
 				++o2;
 				if (o2 > r) { o2 = -r; ++o1; }
@@ -1005,7 +1007,7 @@ cfhip_etc_encode_kernel(cf_kparams kp)
 		o.allow_indiv = false; o.allow_planar = false; o.punch = false; o.a1 = false;
 		o.active = valid; o.transparent = 0;
 		o.wt[0] = (int)kp.wt[0]; o.wt[1] = (int)kp.wt[1]; o.wt[2] = (int)kp.wt[2];
-		o.radius = q >= 4u ? 3 : (q >= 3u ? 2 : (q == 2u ? 1 : 0));   // T / H move rounds (oracle: effort_radius)
+		o.radius = q >= 4u ? 3 : (q >= 3u ? 1 : 0);                    // T / H move rounds (oracle: effort_radius)
 		o.walk = q > 4u ? 4 : (int)q;                                  // five distinct effort levels
 		o.refine = q >= 1u;
 		uint2 w0 = make_uint2(0, 0), w1 = make_uint2(0, 0);

@@ -827,7 +827,7 @@ static int shortlist(const astc_blk* b, int P, int limit, int want, const float 
  * configs per candidate, partitions searched, shortlisted 2/3/4-partition candidates, dual planes */
 typedef struct { int K, limit, j2, j3, j4, nd; } astc_ladder;
 static const astc_ladder k_ladder[5] = {
-	{2, 0, 0, 0, 0, 0}, {4, 16, 2, 0, 0, 1}, {4, 32, 3, 2, 0, 2}, {8, 96, 8, 5, 0, 2},
+	{2, 0, 0, 0, 0, 0}, {4, 16, 2, 0, 0, 1}, {4, 32, 3, 2, 0, 2}, {8, 256, 8, 5, 0, 2},
 	{8, 256, 14, 9, 6, 2}};
 
 static void putbits(uint8_t* out, int pos, unsigned v, int n)

@@ -293,14 +293,16 @@ static void search_half(const int px[16][4], const rgb_opts* o, int flip, int su
 		tcand[t] = 0;
 		tq[t][0] = tq[t][1] = tq[t][2] = 0;
 	}
-	int ncand = o->walk == 0 ? 1 : (o->walk == 1 ? 7 : (o->walk == 2 ? 27 : 125));
-	int r = o->walk == 2 ? 1 : 2, side = 2*r + 1;
+	int ncand = o->walk == 0 ? 1 : (o->walk == 1 ? 3 : (o->walk == 2 ? 9 : (o->walk == 3 ? 27 : 125)));
+	int r = o->walk == 3 ? 1 : 2, side = 2*r + 1;
 	for (int cand = 0; cand < ncand; ++cand) {
 		int d[3] = {0, 0, 0};
-		if (o->walk == 1) {
-			if (cand > 0)
-				d[(cand - 1) >> 1] = ((cand - 1) & 1) ? 1 : -1;
-		} else if (o->walk >= 2) {
+		if (o->walk == 1 || o->walk == 2) {
+			if (cand == 1 || cand == 2)
+				d[0] = d[1] = d[2] = cand == 1 ? 1 : -1;
+			else if (cand > 2)
+				d[(cand - 3) >> 1] = ((cand - 3) & 1) ? 1 : -1;
+		} else if (o->walk >= 3) {
 			d[0] = cand/(side*side) - r;
 			d[1] = (cand/side) % side - r;
 			d[2] = cand % side - r;
@@ -887,10 +889,11 @@ void cfo_eac_search(const int v[16], int kind, unsigned active, int R, uint8_t o
 static int effort_radius(int quality)
 {
 	/* stands in for etc2comp's five effort levels (EtcConverter.cpp:34-54), all distinct: base
-	 * colours walked per half and table 1 / 7 / 27 / 125 / 125 + 12 (search_half's walk = the
-	 * quality), T / H move rounds 0 / 0 / 1 / 2 / 3 (this value); Lowest also drops the planar
-	 * refinement and the T / H modes */
-	return quality >= 4 ? 3 : (quality >= 3 ? 2 : (quality == 2 ? 1 : 0));
+	 * colours walked per half and table 1 / 3 / 9 / 27 / 125 + 12 (search_half's walk = the
+	 * quality), T / H move rounds 0 / 0 / 0 / 1 / 3 (this value); Lowest also drops the planar
+	 * refinement and the T / H modes.  (Round 2 measured 0.06 dB between a 7- and the
+	 * 27-candidate walk for twice the time: Normal takes the 9.) */
+	return quality >= 4 ? 3 : (quality >= 3 ? 1 : 0);
 }
 
 /* rgbaf: 16 texels float RGBA row-major (edge-replicated), rgba: the same as u8,
