@@ -214,17 +214,18 @@ __device__ __forceinline__ void quantize(const float (&x0)[4], const float (&x1)
 struct Tex {
 	const uint32_t* tp;
 	const uint32_t* pl;
+	const uint32_t* yc;    // perceptual metric only: the texels as (Y | Cr << 16, Cb | A << 16) word pairs
 	uint32_t sel;      // v_perm_b32 selector of the rotation
 	uint32_t rot;      // 0..3
 	uint32_t chmask;   // bit c: rotated channel c is coded by this fit
 	uint32_t vmask;    // byte mask of chmask
 };
 
-__device__ __forceinline__ Tex make_tex(const uint32_t* tp, const uint32_t* pl, uint32_t rot,
+__device__ __forceinline__ Tex make_tex(const uint32_t* tp, const uint32_t* pl, const uint32_t* yc, uint32_t rot,
 	uint32_t chmask)
 {
 	Tex t;
-	t.tp = tp; t.pl = pl; t.rot = rot; t.chmask = chmask;
+	t.tp = tp; t.pl = pl; t.yc = yc; t.rot = rot; t.chmask = chmask;
 	t.sel = rot == 0u ? 0x03020100u : (rot == 1u ? 0x00020103u :
 		(rot == 2u ? 0x01020300u : 0x02030100u));
 	t.vmask = ((chmask & 1u) ? 0xFFu : 0u) | ((chmask & 2u) ? 0xFF00u : 0u) |
@@ -272,6 +273,49 @@ __device__ __forceinline__ uint32_t bytemask4(uint32_t m)
 // the per-texel keys meet through a DPP lane^1 exchange).  Same arithmetic as
 // the oracle's fit_subset / fit_scalar.
 
+// ---- perceptual metric (UNITW = false; oracle: to_ycc / assign) ----
+// sRGB images at >= Normal ask for bc7enc's perceptual error (S3tcConverter.cpp:196-199): texels and
+// palette colours are compared in (Y, Cr, Cb, A), Y = (109 R + 366 G + 37 B + 256) >> 9,
+// Cr = R - Y + 255, Cb = B - Y + 255, with axis weights 16, 8, 2, 1.  Values fit 16 bits, so a texel
+// is two words of 16-bit pairs and sum_ax w_ax p_ax q_ax is two chained v_dot2_u32_u16.  A fit's
+// weight pair yw carries its channel set: zero weights on the axes it does not code.
+typedef unsigned short cf_us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_mul_u16(uint32_t a, uint32_t b)
+{
+	return __builtin_bit_cast(uint32_t, (cf_us2)(__builtin_bit_cast(cf_us2, a)*__builtin_bit_cast(cf_us2, b)));
+}
+
+__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t acc)
+{
+	return __builtin_amdgcn_udot2(__builtin_bit_cast(cf_us2, a), __builtin_bit_cast(cf_us2, b), acc, false);
+}
+
+__device__ __forceinline__ void ycc_pairs(uint32_t r, uint32_t g, uint32_t b, uint32_t a, uint32_t& prg, uint32_t& pba)
+{
+	const uint32_t y = (109u*r + 366u*g + 37u*b + 256u) >> 9;
+	prg = y | ((r + 255u - y) << 16);
+	pba = (b + 255u - y) | (a << 16);
+}
+
+// sum over the texels of mask of sum_ax w_ax p_ax^2: the constant part of a fit's error
+__device__ __forceinline__ uint32_t ycc_pp_sum(const Tex& tx, uint32_t mask, const uint32_t (&yw)[2])
+{
+	uint32_t pp = 0;
+#pragma unroll 1
+	for (uint32_t r = 0; r < 4u; ++r) {
+		const uint4 ya = *reinterpret_cast<const uint4*>(tx.yc + 8u*r);
+		const uint4 yb = *reinterpret_cast<const uint4*>(tx.yc + 8u*r + 4u);
+		const uint32_t pr[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const uint32_t t = dot2_u16(pk_mul_u16(pr[2*j], yw[0]), pr[2*j], dot2_u16(pk_mul_u16(pr[2*j + 1], yw[1]), pr[2*j + 1], 0u));
+			pp += ((mask >> (4u*r + (uint32_t)j)) & 1u) ? t : 0u;
+		}
+	}
+	return pp;
+}
+
 struct LaneFit {
 	uint32_t e0, e1, q0, q1, pb, err;
 	uint32_t w[4];          // weights per texel (bytes), 0 outside the subset
@@ -279,7 +323,7 @@ struct LaneFit {
 
 template <bool UNITW>
 __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bool m6,
-	uint32_t khalf, uint32_t ib, const uint32_t (&wt)[4], uint32_t pp_sum, bool want_lsq, LaneFit& f,
+	uint32_t khalf, uint32_t ib, const uint32_t (&yw)[2], uint32_t pp_sum, bool want_lsq, LaneFit& f,
 	float (&nx0)[4], float (&nx1)[4], bool& ok)
 {
 	const uint32_t nk = m6 ? 8u : (1u << ib), kbase = m6 ? 8u*khalf : 0u;
@@ -288,8 +332,8 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 	// straight-line palette: entries past this lane's 2^ib get a key that never wins.
 	// A texel's key is the NEGATED 128 (sum_c w_c c_k^2 - 2 sum_c p_c (w_c c_k)) + weight_k,
 	// maximised over k; sum_c w_c p_c^2 is added once per subset (pp_sum).  Unit weights: the
-	// cross term is one v_dot4(p, c_k).  General weights (<= 7): w_c c_k <= 1785 is split into
-	// a low and a high byte plane, two v_dot4.
+	// cross term is one v_dot4(p, c_k).  Perceptual metric: the palette entry goes to (Y, Cr, Cb, A),
+	// its weighted form is two words of 16-bit pairs, the cross term two v_dot2_u32_u16.
 	uint32_t pal[8], palh[8];
 	int base[8];
 #pragma unroll
@@ -308,12 +352,13 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 			base[k] = valid ? -(int)((__builtin_amdgcn_udot4(pal[k], pal[k], 0u, false) << 7) | w)
 				: -0x3FFFFFFF;
 		} else {
-			const uint32_t m0 = __umul24(wt[0], c0), m1 = __umul24(wt[1], c1), m2 = __umul24(wt[2], c2),
-				m3 = __umul24(wt[3], c3);
-			// 16-bit pairs for v_dot2_u32_u16: (w0 c0, w1 c1) and (w2 c2, w3 c3), each <= 1785
-			pal[k] = m0 | (m1 << 16);
-			palh[k] = m2 | (m3 << 16);
-			const uint32_t qq = __umul24(m0, c0) + __umul24(m1, c1) + __umul24(m2, c2) + __umul24(m3, c3);
+			uint32_t qrg, qba;
+			ycc_pairs(c0, c1, c2, c3, qrg, qba);
+			// (wY Y, wCr Cr) and (wCb Cb, wA A), each <= 4080; an entry past 2^ib repeats entry 0's
+			// colour with a larger constant, so it never wins
+			pal[k] = pk_mul_u16(qrg, yw[0]);
+			palh[k] = pk_mul_u16(qba, yw[1]);
+			const uint32_t qq = dot2_u16(pal[k], qrg, dot2_u16(palh[k], qba, 0u));   // <= 3.7e6
 			base[k] = valid ? -(int)((qq << 7) | w) : -0x3FFFFFFF;
 		}
 		// hide that base is a negation: "(dt << 8) + base" then stays ONE v_lshl_add_u32 per entry
@@ -324,8 +369,18 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 	uint32_t wp0 = 0, wp1 = 0, wp2 = 0, wp3 = 0;
 #pragma unroll 1
 	for (uint32_t r = 0; r < 4u; ++r) {
-		const uint4 rw = *reinterpret_cast<const uint4*>(tx.tp + 4u*r);
-		const uint32_t raw[4] = {rw.x, rw.y, rw.z, rw.w};
+		// unit weights: the row's packed RGBA texels; perceptual: its (Y | Cr, Cb | A) word pairs
+		uint32_t raw[4], rawh[4];
+		if (UNITW) {
+			const uint4 rw = *reinterpret_cast<const uint4*>(tx.tp + 4u*r);
+			raw[0] = rw.x; raw[1] = rw.y; raw[2] = rw.z; raw[3] = rw.w;
+			rawh[0] = rawh[1] = rawh[2] = rawh[3] = 0u;
+		} else {
+			const uint4 ya = *reinterpret_cast<const uint4*>(tx.yc + 8u*r);
+			const uint4 yb = *reinterpret_cast<const uint4*>(tx.yc + 8u*r + 4u);
+			raw[0] = ya.x; raw[1] = ya.z; raw[2] = yb.x; raw[3] = yb.z;
+			rawh[0] = ya.y; rawh[1] = ya.w; rawh[2] = yb.y; rawh[3] = yb.w;
+		}
 		const uint32_t mrow = (mask >> (4u*r)) & 15u;
 		uint32_t wrow = 0;
 #pragma unroll
@@ -334,22 +389,18 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 			// one texel at a time: interleaving the 32 dot products of a row for ILP costs
 			// ~20 registers, and the kernel is issue-bound, not latency-bound
 			asm volatile("" : "+v"(rawj), "+v"(wrow));
-			const uint32_t p = texel<true>(tx, rawj);
+			const uint32_t p = UNITW ? texel<true>(tx, rawj) : 0u;
 			uint32_t key;
 			{
 				int bestk = -0x7FFFFFFF;
-				// general weights: the texel as two 16-bit pairs, two chained 16-bit dot products
-				typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-				const uint32_t prg = UNITW ? 0u : __builtin_amdgcn_perm(0u, p, 0x0C010C00u);
-				const uint32_t pba = UNITW ? 0u : __builtin_amdgcn_perm(0u, p, 0x0C030C02u);
+				const uint32_t prg = rawj, pba = rawh[j];
 #pragma unroll
 				for (int k = 0; k < 8; ++k) {
 					int dt;
 					if (UNITW)
 						dt = (int)__builtin_amdgcn_udot4(p, pal[k], 0u, false);
 					else
-						dt = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, pba), __builtin_bit_cast(us2, palh[k]),
-							__builtin_amdgcn_udot2(__builtin_bit_cast(us2, prg), __builtin_bit_cast(us2, pal[k]), 0u, false), false);
+						dt = (int)dot2_u16(pba, palh[k], dot2_u16(prg, pal[k], 0u));
 					const int v = (dt << 8) + base[k];
 					bestk = v > bestk ? v : bestk;
 				}
@@ -414,7 +465,7 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 template <bool UNITW>
 __device__ __forceinline__ void fit_lane(const Tex& tx, uint32_t mask, bool m6, uint32_t khalf,
 	uint32_t cb, uint32_t ab, uint32_t pbk, uint32_t ib, uint32_t iters, const uint32_t (&wt)[4],
-	bool scalar, LaneFit& best)
+	const uint32_t (&yw)[2], bool scalar, LaneFit& best)
 {
 	// A: statistics of the subset + extremes of the (rotated) alpha channel
 	const uint32_t n = (uint32_t)__builtin_popcount(mask);
@@ -524,16 +575,16 @@ __device__ __forceinline__ void fit_lane(const Tex& tx, uint32_t mask, bool m6, 
 	quantize(x0, x1, cb, ab, pbk, wt, q);
 	best.e0 = q.e0; best.e1 = q.e1; best.q0 = q.q0; best.q1 = q.q1; best.pb = q.pb;
 	bool live;
-	// sum over the subset of sum_c w_c p_c^2 (channels that are not coded have p = 0)
-	const uint32_t pp_sum = UNITW ? q00 + q11 + q22 + q33
-		: __umul24(wt[0], q00) + __umul24(wt[1], q11) + __umul24(wt[2], q22) + __umul24(wt[3], q33);
-	assign_lsq_lane<UNITW>(tx, mask, m6, khalf, ib, wt, pp_sum, iters > 0u, best, x0, x1, live);
+	// sum over the subset of sum_c p_c^2 (channels that are not coded have p = 0), or of the
+	// weighted squares on the perceptual axes
+	const uint32_t pp_sum = UNITW ? q00 + q11 + q22 + q33 : ycc_pp_sum(tx, mask, yw);
+	assign_lsq_lane<UNITW>(tx, mask, m6, khalf, ib, yw, pp_sum, iters > 0u, best, x0, x1, live);
 	for (uint32_t r = 0; r < iters; ++r) {
 		LaneFit cur;
 		bool ok;
 		quantize(x0, x1, cb, ab, pbk, wt, q);
 		cur.e0 = q.e0; cur.e1 = q.e1; cur.q0 = q.q0; cur.q1 = q.q1; cur.pb = q.pb;
-		assign_lsq_lane<UNITW>(tx, mask, m6, khalf, ib, wt, pp_sum, r + 1u < iters, cur, x0, x1, ok);
+		assign_lsq_lane<UNITW>(tx, mask, m6, khalf, ib, yw, pp_sum, r + 1u < iters, cur, x0, x1, ok);
 		const bool better = live && cur.err < best.err;
 		if (better)
 			best = cur;
@@ -768,7 +819,7 @@ __device__ __forceinline__ float subset_residual(const Tex& tx, uint32_t mask)
 // Encode one block with the whole wavefront.  tp: the block's 16 texels in LDS
 // (colour mask already applied), identical for every lane.
 template <bool UNITW, bool WIDE>
-__device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint32_t* plan, uint32_t b,
+__device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint32_t* plan, const uint32_t* yccp, uint32_t b,
 	bool pair, uint32_t* cslot, const cf_kparams& kp, uint32_t lane0)
 {
 	uint32_t lane = lane0;
@@ -776,6 +827,10 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	const uint32_t h = lane >> 5, hbase = pair ? (lane & 32u) : 0u;
 	const uint32_t* tp = tile + (pair ? b + h : b)*16u;
 	const uint32_t* pl = plan + (pair ? b + h : b)*16u;
+	const uint32_t* yc = UNITW ? yccp : yccp + (pair ? b + h : b)*32u;
+	// perceptual axis weights as 16-bit pairs (wY | wCr << 16, wCb | wA << 16); kp.flags holds the bytes
+	const uint32_t ywrg = (kp.flags & 255u) | (((kp.flags >> 8) & 255u) << 16);
+	const uint32_t ywba = ((kp.flags >> 16) & 255u) | (((kp.flags >> 24) & 127u) << 16);
 	// lanes 0..15 of each group test their block's alpha
 	const unsigned long long abal = __ballot((lane & 31u) < 16u && (tp[lane & 15u] >> 24) != 255u);
 	const bool has_alpha = pair ? ((uint32_t)(h ? abal >> 32 : abal) & 0xFFFFu) != 0u
@@ -816,7 +871,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	bool solved = false;
 	{
 		const uint32_t nstreams = (WIDE && !has_alpha) ? 2u : 1u;
-		const Tex txp = make_tex(tp, pl, 0u, has_alpha ? 15u : 7u);   // partition fits: no rotation
+		const Tex txp = make_tex(tp, pl, yc, 0u, has_alpha ? 15u : 7u);   // partition fits: no rotation
 #pragma unroll 1
 		for (uint32_t st = 0; st < nstreams && !solved; ++st) {
 			asm volatile("" : "+v"(lane));   // roles are recomputed per stream, not kept
@@ -905,12 +960,15 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 					rot = cid - 1u; pbk = 0; ib = 2;
 					cb = sca ? 0u : 7u; ab = sca ? 8u : 0u;
 					active = quality >= 2u || (quality == 1u ? cid == 1u : (cid == 1u && has_alpha));
+					// the perceptual metric couples R, G and B: no plane split that moves a colour
+					// channel into the scalar plane (oracle: nrot)
+					active = active && (UNITW || rot == 0u);
 				} else {
 					const uint32_t isel = (cid - 5u) >> 2;
 					rot = (cid - 5u) & 3u; pbk = 0;
 					cb = sca ? 0u : 5u; ab = sca ? 6u : 0u;
 					ib = (isel != 0u) == sca ? 2u : 3u;   // isel 0: 2-bit colour / 3-bit alpha indices
-					active = quality >= 2u;     // (mode 4 exists only in the 64-lane layout: High)
+					active = quality >= 2u && (UNITW || rot == 0u);     // (mode 4 exists only in the 64-lane layout: Highest)
 				}
 			} else if (plane) {
 				uint32_t mode;
@@ -951,9 +1009,12 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			lf.err = 0; lf.q0 = 0; lf.q1 = 0; lf.pb = 0; lf.e0 = 0; lf.e1 = 0;
 #pragma unroll
 			for (int k = 0; k < 4; ++k) lf.w[k] = 0;
+			// perceptual weight pairs of this fit: zero on the axes it does not code
+			const uint32_t yw[2] = {(chm & 7u) ? ywrg : 0u,
+				((chm & 7u) ? (ywba & 0xFFFFu) : 0u) | ((chm & 8u) ? (ywba & 0xFFFF0000u) : 0u)};
 			if (active)
-				fit_lane<UNITW>(make_tex(tp, pl, rot, chm), mask, m6, lane & 1u, cb, ab, pbk, ib, iters,
-					wv, sca, lf);
+				fit_lane<UNITW>(make_tex(tp, pl, yc, rot, chm), mask, m6, lane & 1u, cb, ab, pbk, ib, iters,
+					wv, yw, sca, lf);
 			// ---- assemble candidates in their leader lanes ----
 			//   mode 6: its first lane;  mode 4/5: vector lane (scalar plane s2off lanes up);
 			//   partitions: subset-0 lane (the other subsets in the next lanes)
@@ -1072,29 +1133,23 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 					mask |= (((p3 >> (2*i)) & 3u) == kf ? 1u : 0u) << i;
 			}
 		}
-		uint32_t wlr[4] = {wt[0], wt[1], wt[2], wt[3]};
-		if (!UNITW && rot) {
-			const uint32_t t3 = wlr[3];
-			if (rot == 1u) { wlr[3] = wlr[0]; wlr[0] = t3; }
-			else if (rot == 2u) { wlr[3] = wlr[1]; wlr[1] = t3; }
-			else { wlr[3] = wlr[2]; wlr[2] = t3; }
-		}
-		const uint32_t wv[4] = {(chm & 1u) ? wlr[0] : 0u, (chm & 2u) ? wlr[1] : 0u,
-			(chm & 4u) ? wlr[2] : 0u, (chm & 8u) ? wlr[3] : 0u};
-		const Tex tx = make_tex(tp, pl, rot, chm);
-		// sum over the fit's texels of sum_c w_c p_c^2 (the constant part of its error)
+		const Tex tx = make_tex(tp, pl, yc, rot, chm);
+		const uint32_t yw[2] = {(chm & 7u) ? ywrg : 0u,
+			((chm & 7u) ? (ywba & 0xFFFFu) : 0u) | ((chm & 8u) ? (ywba & 0xFFFF0000u) : 0u)};
+		// sum over the fit's texels of sum_c p_c^2 (the constant part of its error)
 		uint32_t pp_sum = 0;
+		if (UNITW) {
 #pragma unroll 1
-		for (uint32_t r = 0; r < 4u; ++r) {
-			uint32_t P[4];
-			planes<true>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
-			const uint32_t m4 = bytemask4((mask >> (4u*r)) & 15u);
+			for (uint32_t r = 0; r < 4u; ++r) {
+				uint32_t P[4];
+				planes<true>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
+				const uint32_t m4 = bytemask4((mask >> (4u*r)) & 15u);
 #pragma unroll
-			for (int c = 0; c < 4; ++c) {
-				const uint32_t d = __builtin_amdgcn_udot4(P[c] & m4, P[c], 0u, false);
-				pp_sum += UNITW ? d : __umul24(wv[c], d);
+				for (int c = 0; c < 4; ++c)
+					pp_sum += __builtin_amdgcn_udot4(P[c] & m4, P[c], 0u, false);
 			}
-		}
+		} else
+			pp_sum = ycc_pp_sum(tx, mask, yw);
 		const uint32_t S = pbk ? 1u : 0u;
 		const uint32_t fq0 = planes45 ? (sca ? 4u : 0u) : 2u*kf, fq1 = fq0 + 1u;   // column words of the fit's fields
 #pragma unroll 1
@@ -1133,7 +1188,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			for (int k = 0; k < 4; ++k) f.w[k] = 0;
 			float x0[4], x1[4];
 			bool okk;
-			assign_lsq_lane<UNITW>(tx, mask, m6, hl & 1u, ib, wv, pp_sum, false, f, x0, x1, okk);
+			assign_lsq_lane<UNITW>(tx, mask, m6, hl & 1u, ib, yw, pp_sum, false, f, x0, x1, okk);
 			uint32_t key = valid ? ((f.err << 4) | mv) : 0xFFFFFFFFu;
 			uint32_t fitmin = cf_row_min_u32(key);
 			if (m6) {
@@ -1189,12 +1244,21 @@ cfhip_bc7_encode_kernel(cf_kparams kp)
 	__shared__ __attribute__((aligned(16))) uint32_t tile[CF_BLOCKS_PER_WG*16];
 	__shared__ __attribute__((aligned(16))) uint32_t plan[CF_BLOCKS_PER_WG*16];
 	__shared__ uint4 outb[CF_BLOCKS_PER_WG];
+	__shared__ __attribute__((aligned(16))) uint32_t yccp[UNITW ? 4 : CF_BLOCKS_PER_WG*32];
 	uint32_t gx_, gy_;
 	cf_resolve(kp, gx_, gy_);
 	const uint32_t bx0 = gx_*CF_BLOCKS_PER_WG;
 	const uint32_t byy = gy_;
 	cf_load_tile_rgba8<PIX>(kp, bx0, byy, tile);
 	__syncthreads();
+	if (!UNITW) {
+		// perceptual metric: every texel once as (Y | Cr << 16, Cb | A << 16)
+		const uint32_t t = threadIdx.x, p = tile[t];
+		uint32_t prg, pba;
+		ycc_pairs(p & 255u, (p >> 8) & 255u, (p >> 16) & 255u, p >> 24, prg, pba);
+		yccp[2u*t] = prg;
+		yccp[2u*t + 1u] = pba;
+	}
 	{
 		// channel-planar copy: plan[b*16 + r*4 + c] = channel c of the 4 texels of row r
 		const uint32_t t = threadIdx.x, c = t & 3u;
@@ -1216,7 +1280,7 @@ cfhip_bc7_encode_kernel(cf_kparams kp)
 		// out of this loop and held in registers across all phases
 		uint32_t ln = lane;
 		asm volatile("" : "+v"(ln));
-		const uint4 blk = encode_blocks<UNITW, WIDE>(tile, plan, b, pair, cands + threadIdx.x, kp, ln);
+		const uint4 blk = encode_blocks<UNITW, WIDE>(tile, plan, yccp, b, pair, cands + threadIdx.x, kp, ln);
 		if (pair) {
 			if ((lane & 31u) == 0u)
 				outb[b + (lane >> 5)] = blk;

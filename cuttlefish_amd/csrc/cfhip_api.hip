@@ -295,12 +295,22 @@ void fill_kparams(cf_kparams& kp, const cfhip_params& p, const void* src, void* 
 			kp.keep_mask |= 0xFFu << (8*c);
 	if (!p.mask_rgba[3])
 		kp.set_mask = 0xFF000000u;
-	// channel weights: linear 1,1,1,1; sRGB at >= Normal: perceptual 3,7,1,2
-	// (S3tcConverter.cpp:196-199); masked channels are constant so weight 1 is harmless
-	static const uint32_t lin[4] = {1, 1, 1, 1}, perc[4] = {3, 7, 1, 2};
-	const uint32_t* wsel = (p.color_space == CFHIP_COLOR_SRGB && p.quality >= 2) ? perc : lin;
+	// channel weights: linear 1,1,1,1; sRGB at >= Normal asks for bc7enc's perceptual metric
+	// (S3tcConverter.cpp:196-199): BC7 measures selector errors in (Y, Cr, Cb, A) with the axis
+	// weights 16, 8, 2, 1 (kp.flags, one byte each; the colour mask zeroes the axis of its index
+	// like the reference zeroes m_weights[c], :217-224) and uses the diagonal of that form,
+	// 6,13,2,1, where a per-channel weight is needed; masked channels are constant so weight 1 is
+	// harmless there
+	static const uint32_t lin[4] = {1, 1, 1, 1}, perc[4] = {6, 13, 2, 1}, axes[4] = {16, 8, 2, 1};
+	const bool perceptual = p.color_space == CFHIP_COLOR_SRGB && p.quality >= 2;
+	const uint32_t* wsel = perceptual ? perc : lin;
 	for (int c = 0; c < 4; ++c)
 		kp.wt[c] = p.mask_rgba[c] ? wsel[c] : 1u;
+	if (p.format == CFHIP_FORMAT_BC7) {
+		kp.flags = perceptual ? 1u << 31 : 0u;     // bit 31: the perceptual kernel variant
+		for (int c = 0; c < 4 && perceptual; ++c)
+			kp.flags |= (p.mask_rgba[c] ? axes[c] : 0u) << (8*c);
+	}
 	if (p.format >= CFHIP_FORMAT_ETC1 && p.format <= CFHIP_FORMAT_EAC_R11G11) {
 		// RGBX/RGBA metric for linear images, REC709 for sRGB (EtcConverter.cpp:60-88);
 		// EtcConverter ignores the colour mask
@@ -374,7 +384,7 @@ int launch(cfhip_ctx* ctx, const cf_kparams& kp, const cfhip_params& p, int pixe
 		case CFHIP_FORMAT_BC7: {
 			if (pixel_type != CFHIP_PIXEL_RGBA8 && pixel_type != CFHIP_PIXEL_RGBA32F)
 				return fail(ctx, CFHIP_E_UNSUPPORTED, "BC7 takes RGBA8 or RGBA32F pixels");
-			const int unit = kp.wt[0] == 1 && kp.wt[1] == 1 && kp.wt[2] == 1 && kp.wt[3] == 1;
+			const int unit = !(kp.flags >> 31);
 			e = cfhip_launch_bc7(&kp, pixel_type == CFHIP_PIXEL_RGBA32F ? 1 : 0, unit, stream);
 			ctx->last_kernel = "cfhip_bc7_encode_kernel";
 			break;

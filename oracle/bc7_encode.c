@@ -31,6 +31,8 @@
 #include <math.h>
 #include <string.h>
 
+#define CFO_BC7_NW 9   /* entries of a weight vector, see assign() */
+
 typedef struct {
 	int e[2][4];     /* dequantised 8-bit endpoints */
 	int q[2][4];     /* quantised endpoint fields (without p-bit) */
@@ -63,7 +65,7 @@ static int dequant(int v, int t)
 
 /* Quantise the float endpoints x[2][4] of the coded channels (bits[c] > 0).
  * pbk: 0 none, 1 one p-bit per endpoint, 2 one p-bit shared by both. */
-static void quantize_endpoints(float x[2][4], const int bits[4], int pbk, const int wt[4],
+static void quantize_endpoints(float x[2][4], const int bits[4], int pbk, const int wt[CFO_BC7_NW],
 	sfit* f)
 {
 	if (!pbk) {
@@ -132,22 +134,57 @@ static void quantize_endpoints(float x[2][4], const int bits[4], int pbk, const 
 	}
 }
 
+/* The weight vector every function below takes as `wt` has CFO_BC7_NW entries: [0..3] the
+ * diagonal channel weights (p-bit choice, scalar planes, and the whole metric when [4] is 0),
+ * [4] = 1 selects bc7enc's perceptual metric for the colour channels of vector fits -- the error
+ * of a texel against a palette colour is measured in (Y, Cr, Cb, A),
+ *     Y = (109 R + 366 G + 37 B + 256) >> 9,  Cr = R - Y + 255,  Cb = B - Y + 255
+ * (bc7enc's integer luma coefficients, /512), with the axis weights [5..8] = 16, 8, 2, 1 --
+ * bc7enc's 128, 64, 16, 32 on its doubled Y / Cr / Cb differences
+ * (bc7enc_compress_block_params_init_perceptual_weights, asked for by S3tcConverter.cpp:196-199). */
+
+static void to_ycc(const int c[4], int out[4])
+{
+	int y = (109*c[0] + 366*c[1] + 37*c[2] + 256) >> 9;
+	out[0] = y;
+	out[1] = c[0] - y + 255;
+	out[2] = c[2] - y + 255;
+	out[3] = c[3];
+}
+
 /* exhaustive selector assignment; integer error */
-static void assign(const int px[16][4], const int wt[4], unsigned mask, const int bits[4],
+static void assign(const int px[16][4], const int wt[CFO_BC7_NW], unsigned mask, const int bits[4],
 	int ib, sfit* f)
 {
 	const uint8_t* wtab = weight_table(ib);
 	int n = 1 << ib;
 	uint32_t total = 0;
+	const int ycc = wt[4] && bits[0];
 	for (int i = 0; i < 16; ++i) {
 		f->w[i] = 0;
 		if (!((mask >> i) & 1))
 			continue;
 		uint32_t best = 0xFFFFFFFFu;
+		int pt[4] = {0, 0, 0, 0};
+		if (ycc) {
+			const int pm[4] = {px[i][0], px[i][1], px[i][2], bits[3] ? px[i][3] : 0};
+			to_ycc(pm, pt);
+		}
 		for (int k = 0; k < n; ++k) {
 			int w = wtab[k];
 			uint32_t dist = 0;
-			for (int c = 0; c < 4; ++c) {
+			if (ycc) {
+				int pal[4] = {0, 0, 0, 0}, qt[4];
+				for (int c = 0; c < 4; ++c)
+					if (bits[c])
+						pal[c] = ((64 - w)*f->e[0][c] + w*f->e[1][c] + 32) >> 6;
+				to_ycc(pal, qt);
+				for (int c = 0; c < 4; ++c) {
+					int dd = pt[c] - qt[c];
+					dist += (uint32_t)(wt[5 + c]*dd*dd);
+				}
+			}
+			for (int c = 0; c < 4 && !ycc; ++c) {
 				if (!bits[c])
 					continue;
 				int pal = ((64 - w)*f->e[0][c] + w*f->e[1][c] + 32) >> 6;
@@ -206,7 +243,7 @@ static int lsq(const int px[16][4], unsigned mask, const int bits[4], const sfit
 }
 
 /* Vector fit of the pixels selected by mask over the channels with bits[c] > 0. */
-static void fit_subset(const int px[16][4], const int wt[4], unsigned mask, const int bits[4],
+static void fit_subset(const int px[16][4], const int wt[CFO_BC7_NW], unsigned mask, const int bits[4],
 	int pbk, int ib, int iters, sfit* best)
 {
 	/* A: integer statistics */
@@ -302,7 +339,7 @@ static void fit_subset(const int px[16][4], const int wt[4], unsigned mask, cons
 }
 
 /* Scalar fit of channel 3 of px over all 16 pixels (modes 4/5 alpha plane). */
-static void fit_scalar(const int px[16][4], const int wt[4], int abits, int ib, int iters,
+static void fit_scalar(const int px[16][4], const int wt[CFO_BC7_NW], int abits, int ib, int iters,
 	sfit* best)
 {
 	const int bits[4] = {0, 0, 0, abits};
@@ -418,7 +455,7 @@ static float partition_score(const int px[16][4], int ns, int part, const int bi
 	return sc;
 }
 
-static void eval_candidate(const int px[16][4], const int wt[4], int id, int iters, cand* c)
+static void eval_candidate(const int px[16][4], const int wt[CFO_BC7_NW], int id, int iters, cand* c)
 {
 	memset(c, 0, sizeof(*c));
 	c->id = id;
@@ -447,7 +484,7 @@ static void eval_candidate(const int px[16][4], const int wt[4], int id, int ite
 		c->ns = 1;
 		c->rot = rot;
 		c->isel = isel;
-		int rp[16][4], rw[4];
+		int rp[16][4], rw[CFO_BC7_NW];
 		memcpy(rp, px, sizeof(rp));
 		memcpy(rw, wt, sizeof(rw));
 		if (rot) {
@@ -527,9 +564,9 @@ static void fit_geometry(const cand* c, int which, int bits[4], int* pbk, int* i
 	}
 }
 
-static void uber_refine(const int px_in[16][4], const int wt_in[4], cand* c, int rounds)
+static void uber_refine(const int px_in[16][4], const int wt_in[CFO_BC7_NW], cand* c, int rounds)
 {
-	int px[16][4], wt[4];
+	int px[16][4], wt[CFO_BC7_NW];
 	memcpy(px, px_in, sizeof(px));
 	memcpy(wt, wt_in, sizeof(wt));
 	int planes = c->mode == 4 || c->mode == 5;
@@ -717,20 +754,26 @@ static budget quality_budget(int quality)
 	return b;
 }
 
-void cfo_bc7_weights(const cfo_params* p, int wt[4])
+void cfo_bc7_weights(const cfo_params* p, int wt[CFO_BC7_NW])
 {
-	/* Linear: 1,1,1,1 (bc7enc_compress_block_params_init_linear_weights).  sRGB
-	 * images ask for perceptual weights (S3tcConverter.cpp:196-199); we use the
-	 * rounded diagonal of bc7enc's YCbCr form, 3:7:1 with alpha 2. */
-	static const int lin[4] = {1, 1, 1, 1}, perc[4] = {3, 7, 1, 2};
-	const int* w = (p->color_space == 1 && p->quality >= 2) ? perc : lin;
-	for (int c = 0; c < 4; ++c)
+	/* Linear: 1,1,1,1 (bc7enc_compress_block_params_init_linear_weights).  sRGB images at
+	 * >= Normal ask for the perceptual metric (S3tcConverter.cpp:196-199): the YCbCr form for
+	 * the selector assignment (see assign), and the rounded diagonal of that form, 6:13:2 with
+	 * alpha 1, wherever a per-channel weight is needed (the p-bit choice). */
+	static const int lin[4] = {1, 1, 1, 1}, diag[4] = {6, 13, 2, 1}, axes[4] = {16, 8, 2, 1};
+	const int perceptual = p->color_space == 1 && p->quality >= 2;
+	const int* w = perceptual ? diag : lin;
+	for (int c = 0; c < 4; ++c) {
 		wt[c] = p->mask[c] ? w[c] : 0;   /* colour mask zeroes weights (:217-224) */
+		/* the reference zeroes m_weights[c], which in perceptual mode are the Y, Cr, Cb, A weights */
+		wt[5 + c] = p->mask[c] ? axes[c] : 0;
+	}
+	wt[4] = perceptual;
 }
 
 void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p)
 {
-	int px[16][4], wt[4];
+	int px[16][4], wt[CFO_BC7_NW];
 	cfo_bc7_weights(p, wt);
 	int has_alpha = 0;
 	for (int i = 0; i < 16; ++i) {
@@ -759,7 +802,9 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 		if (has_alpha)
 			TRY(1);
 	} else {
-		int nrot = b.rot ? 4 : 1;
+		/* the perceptual metric couples R, G and B, so a plane split that moves a colour channel
+		 * into the scalar plane has no separable error: rotation 0 only (bc7enc does the same) */
+		int nrot = (b.rot && !wt[4]) ? 4 : 1;
 		for (int r = 0; r < nrot; ++r)
 			TRY(1 + r);
 		/* mode 4 (rotation x index selector): from High up (worth 0.012 dB on opaque and
@@ -767,7 +812,8 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 		 * whole candidate set into half a wavefront) */
 		if (b.rot && b.three)
 			for (int k = 0; k < 8; ++k)
-				TRY(5 + k);
+				if (!wt[4] || (k & 3) == 0)
+					TRY(5 + k);
 		/* Partitioned modes.  Highest refits every partition of every mode.  Below that
 		 * the search is two-phase per subset count (group): phase 1 scores every
 		 * partition with the residual estimator (partition_score; independent of the

@@ -26,12 +26,18 @@ CASES = [("BC1_RGB", 29, 0, "opaque"), ("BC1_RGBA", 30, 0, "cutout"), ("BC2", 31
          ("BC3", 32, 0, "alpha"), ("BC4_UNorm", 33, 0, "alpha"), ("BC4_SNorm", 33, 1, "float"),
          ("BC5_UNorm", 34, 0, "alpha"), ("BC5_SNorm", 34, 1, "float"), ("BC6H_UFloat", 35, 4, "hdr"),
          ("BC6H_Float", 35, 5, "hdr"), ("BC7", 36, 0, "alpha"), ("BC7_opaque", 36, 0, "opaque"),
+         ("BC7_sRGB", 36, 0, "alpha"), ("ETC2_R8G8B8_sRGB", 38, 0, "opaque"),
          ("ETC1", 37, 0, "opaque"), ("ETC2_R8G8B8", 38, 0, "opaque"), ("ETC2_R8G8B8A1", 39, 0, "cutout"),
          ("ETC2_R8G8B8A8", 40, 0, "alpha"), ("EAC_R11_UNorm", 41, 0, "alpha"), ("EAC_R11_SNorm", 41, 1, "float"),
          ("EAC_R11G11_UNorm", 42, 0, "alpha"), ("EAC_R11G11_SNorm", 42, 1, "float")] + \
         [("ASTC_%dx%d" % fp, 43 + i, 0, "alpha") for i, fp in enumerate(
             [(4, 4), (5, 4), (5, 5), (6, 5), (6, 6), (8, 5), (8, 6), (8, 8), (10, 5), (10, 6), (10, 8),
              (10, 10), (12, 10), (12, 12)])]
+
+
+def color_space(name):
+    """cases named *_sRGB are encoded as sRGB images (perceptual metrics at >= Normal)"""
+    return 1 if name.endswith("_sRGB") else 0
 
 
 def image(kind):
@@ -79,7 +85,7 @@ def build():
     for name, fmt, typ, kind in CASES:
         img = image(kind)
         for q in range(5):
-            payload = O.encode(img, fmt, typ=typ, quality=q, threads=8)
+            payload = O.encode(img, fmt, typ=typ, quality=q, threads=8, color_space=color_space(name))
             out["%s/q%d" % (name, q)] = {"sha256": hashlib.sha256(payload.tobytes()).hexdigest(),
                                           "psnr": quality_metric(name, fmt, typ, img, payload)}
     return out

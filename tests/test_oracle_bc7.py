@@ -102,3 +102,29 @@ def test_mode_usage_is_sane():
     m = _modes(O.encode(img, BC7, quality=2, threads=4))
     assert m[7] == 0            # opaque image never needs mode 7
     assert m.sum() == 32 * 32
+
+
+def test_perceptual_metric_is_the_ycbcr_form_and_drops_rotations():
+    """sRGB images at >= Normal (S3tcConverter.cpp:196-199) are searched with bc7enc's perceptual
+    metric: luma error falls against the linear-metric encoding of the same pixels, RGB PSNR is
+    traded for it, and modes 4 / 5 use rotation 0 only (the metric is not separable over a plane
+    split that moves a colour channel)."""
+    img = synth.photo(128, 128, seed=21)
+
+    def errors(cs, q):
+        enc = O.encode(img, BC7, quality=q, threads=4, color_space=cs)
+        d = O.decode(enc, BC7, 128, 128).astype(np.float64) - img.astype(np.float64)
+        y = (109*d[..., 0] + 366*d[..., 1] + 37*d[..., 2])/512.0
+        return enc, float(np.mean(y*y)), float(np.mean(d[..., :3]**2))
+    for q in (2, 3):
+        _, y_lin, rgb_lin = errors(0, q)
+        enc, y_srgb, rgb_srgb = errors(1, q)
+        assert y_srgb < y_lin and rgb_srgb > rgb_lin
+        blocks = enc.reshape(-1, 16)
+        mode = np.array([(int(b[0]) & -int(b[0])).bit_length() - 1 for b in blocks])
+        rot5 = (blocks[mode == 5, 0] >> 6) & 3
+        rot4 = (blocks[mode == 4, 0] >> 5) & 3
+        assert not rot5.any() and not rot4.any()
+    # below Normal the metric is linear whatever the colour space
+    assert np.array_equal(O.encode(img, BC7, quality=1, threads=4, color_space=1),
+                          O.encode(img, BC7, quality=1, threads=4, color_space=0))

@@ -25,7 +25,7 @@ def test_oracle_payload_hashes_unchanged(case):
     name, fmt, typ, kind = case
     img = G.image(kind)
     for q in range(5):
-        payload = O.encode(img, fmt, typ=typ, quality=q, threads=4)
+        payload = O.encode(img, fmt, typ=typ, quality=q, threads=4, color_space=G.color_space(name))
         want = HASHES["%s/q%d" % (name, q)]
         assert hashlib.sha256(payload.tobytes()).hexdigest() == want["sha256"], \
             "%s quality %d: the oracle's output changed -- regenerate the fixture and review " \
@@ -39,8 +39,8 @@ def test_quality_never_costs_quality():
     from it) and must never lose."""
     for name, fmt, typ, kind in G.CASES:
         ps = [HASHES["%s/q%d" % (name, q)]["psnr"] for q in range(5)]
-        if ps[0] is None:
-            continue
+        if ps[0] is None or G.color_space(name):
+            continue      # (sRGB cases minimise a perceptual error, not the recorded PSNR)
         slack = 0.5 if name.startswith("ASTC") else 0.01
         for a, b in zip(ps, ps[1:]):
             assert b >= a - slack, (name, ps)
@@ -51,10 +51,10 @@ def test_quality_never_costs_quality():
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", G.CASES, ids=lambda c: c[0])
 def test_gpu_payload_hashes(gpu_ctx, case):
-    from cuttlefish_amd import Format, Type, make_params
+    from cuttlefish_amd import ColorSpace, Format, Type, make_params
     name, fmt, typ, kind = case
     img = G.image(kind)
     for q in range(5):
-        got = gpu_ctx.encode([img], make_params(Format(fmt), Type(typ), q))[0]
+        got = gpu_ctx.encode([img], make_params(Format(fmt), Type(typ), q, color_space=ColorSpace(G.color_space(name))))[0]
         assert hashlib.sha256(np.asarray(got).tobytes()).hexdigest() == HASHES["%s/q%d" % (name, q)]["sha256"], \
             "%s quality %d" % (name, q)
