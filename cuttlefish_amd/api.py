@@ -127,7 +127,7 @@ class PixelType(enum.IntEnum):
 E_INVALID, E_UNSUPPORTED, E_CAPACITY, E_DEVICE, E_NO_DEVICE = -1, -2, -3, -4, -5
 
 EXPORTS = ["cfhip_abi_version", "cfhip_device_count", "cfhip_create", "cfhip_destroy",
-           "cfhip_query", "cfhip_encode", "cfhip_encode_device", "cfhip_shard_rows",
+           "cfhip_query", "cfhip_encode", "cfhip_encode_multi", "cfhip_encode_device", "cfhip_shard_rows",
            "cfhip_last_kernel_ms", "cfhip_last_kernel_name", "cfhip_last_error",
            "cfhip_profile_begin", "cfhip_profile_end", "cfhip_generate_mips_device"]
 
@@ -181,6 +181,9 @@ def load_library(path: Optional[str] = None):
     L.cfhip_encode.argtypes = [ctypes.c_void_p, ctypes.POINTER(Surface), ctypes.c_size_t,
                                ctypes.POINTER(Params)]
     L.cfhip_encode.restype = ctypes.c_int
+    L.cfhip_encode_multi.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.POINTER(Surface),
+                                     ctypes.c_size_t, ctypes.POINTER(Params)]
+    L.cfhip_encode_multi.restype = ctypes.c_int
     L.cfhip_encode_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(Surface), ctypes.c_size_t,
                                       ctypes.POINTER(Params), ctypes.c_void_p]
     L.cfhip_encode_device.restype = ctypes.c_int
@@ -287,10 +290,14 @@ class Context:
     def encode(self, images: Iterable[np.ndarray], params: Params):
         """Host-buffer path (what HipConverter::process calls): list of (h, w, 4) arrays
         -> list of payload byte arrays."""
+        surf, outs, keep = self._host_surfaces(images, params)
+        self._check(self._lib.cfhip_encode(self._h, surf, len(outs), ctypes.byref(params)))
+        return outs
+
+    def _host_surfaces(self, images, params):
         images = [np.asarray(im) for im in images]
         surf = (Surface * len(images))()
-        outs = []
-        keep = []
+        outs, keep = [], []
         for i, im in enumerate(images):
             if im.ndim != 3 or im.shape[2] != 4:
                 raise ValueError("surface %d: expected (h, w, 4)" % i)
@@ -306,7 +313,18 @@ class Context:
             surf[i].row_pitch_bytes = im.strides[0]
             surf[i].out = out.ctypes.data
             surf[i].out_capacity = out.nbytes
-        self._check(self._lib.cfhip_encode(self._h, surf, len(images), ctypes.byref(params)))
+        return surf, outs, keep
+
+    def encode_multi(self, others: Sequence["Context"], images: Iterable[np.ndarray], params: Params):
+        """cfhip_encode_multi: this context plus `others` (one per GPU of this process) share the
+        surfaces of the call by block count; same payloads as encode()."""
+        ctxs = [self] + list(others)
+        surf, outs, keep = self._host_surfaces(images, params)
+        arr = (ctypes.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+        rc = self._lib.cfhip_encode_multi(arr, len(ctxs), surf, len(outs), ctypes.byref(params))
+        if rc != 0:
+            for c in ctxs:
+                c._check(rc)
         return outs
 
     def encode_device(self, surfaces: Sequence[dict], params: Params, stream: int = 0):

@@ -451,7 +451,6 @@ __device__ __forceinline__ void cluster_fit(const uint32_t* tp, const COpts& o, 
 	const int sq[3] = {s00, s11, s22};
 	const uint32_t ti = lane & 15u;
 	const uint32_t pme = tp[ti];
-	const bool act_me = (o.active >> ti) & 1u;
 #pragma unroll 1
 	for (uint32_t iter = 0; iter < o.cluster; ++iter) {
 		// rank of my texel (texel lane & 15 in every row of 16 lanes)

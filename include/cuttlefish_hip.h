@@ -198,6 +198,15 @@ int cfhip_query(int format, int type, int* block_w, int* block_h, int* block_byt
  * surface, encodes on the GPU, downloads the payload.  Blocking. */
 int cfhip_encode(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n_surfaces,
 	const cfhip_params* params);
+/* Several GPUs from ONE process (the reference's CLI and library are a single process; the
+ * surfaces of a call are independent, Converter.cpp:521-589): the surfaces are assigned to the
+ * contexts -- one per device -- by block count (longest-processing-time, SURVEY.md section 8e(i);
+ * deterministic), and every context encodes its share with cfhip_encode on a host thread of its
+ * own.  Same result as cfhip_encode(ctxs[0], ...) byte for byte; the first failure is returned
+ * (its text through cfhip_last_error of that context) and the payload buffers are then
+ * unspecified.  n_ctx == 1 is exactly cfhip_encode. */
+int cfhip_encode_multi(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface* surfaces,
+	size_t n_surfaces, const cfhip_params* params);
 /* Host pipeline of cfhip_encode: small surfaces of a call are
  * uploaded together and encoded in ONE batched launch with one synchronisation; a large
  * RGBA32F surface of an 8-bit format, or any bottom-up surface, is cut into strips of whole

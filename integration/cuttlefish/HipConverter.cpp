@@ -10,6 +10,7 @@
 #include <cuttlefish_hip.h>
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -21,16 +22,31 @@ namespace
 {
 
 // One backend context per process, created on first use (cfhip contexts are thread-safe).
-cfhip_ctx* sharedContext()
+// One context per visible GPU (CUTTLEFISH_HIP_DEVICES limits the count), created once.
+const std::vector<cfhip_ctx*>& sharedContexts()
 {
 	static std::once_flag once;
-	static cfhip_ctx* ctx = nullptr;
+	static std::vector<cfhip_ctx*> contexts;
 	std::call_once(once, []()
 		{
-			if (cfhip_abi_version() == CFHIP_ABI_VERSION && cfhip_device_count() > 0)
-				ctx = cfhip_create(0, 0, nullptr);
+			if (cfhip_abi_version() != CFHIP_ABI_VERSION)
+				return;
+			int count = cfhip_device_count();
+			if (const char* limit = std::getenv("CUTTLEFISH_HIP_DEVICES"))
+				count = std::min(count, std::max(1, std::atoi(limit)));
+			for (int device = 0; device < count; ++device)
+			{
+				if (cfhip_ctx* ctx = cfhip_create(device, 0, nullptr))
+					contexts.push_back(ctx);
+			}
 		});
-	return ctx;
+	return contexts;
+}
+
+cfhip_ctx* sharedContext()
+{
+	const std::vector<cfhip_ctx*>& contexts = sharedContexts();
+	return contexts.empty() ? nullptr : contexts.front();
 }
 
 cfhip_params makeParams(Texture::Format format, Texture::Type type, Texture::Quality quality,
@@ -159,7 +175,10 @@ bool HipConverter::convertAll(const Texture& texture, MipImageList& images,
 
 	const cfhip_params params = makeParams(texture.format(), texture.type(), quality,
 		texture.alphaType(), texture.colorMask(), colorSpace);
-	if (cfhip_encode(ctx, surfaces.data(), surfaces.size(), &params) != CFHIP_OK)
+	// every visible GPU takes a share of the surfaces (by block count); one GPU: plain cfhip_encode
+	const std::vector<cfhip_ctx*>& contexts = sharedContexts();
+	if (cfhip_encode_multi(contexts.data(), static_cast<int>(contexts.size()), surfaces.data(),
+			surfaces.size(), &params) != CFHIP_OK)
 		return false;
 
 	// success: hand the payloads over and release the sources (Converter.cpp:586-587)
