@@ -129,7 +129,8 @@ E_INVALID, E_UNSUPPORTED, E_CAPACITY, E_DEVICE, E_NO_DEVICE = -1, -2, -3, -4, -5
 EXPORTS = ["cfhip_abi_version", "cfhip_device_count", "cfhip_create", "cfhip_destroy",
            "cfhip_query", "cfhip_encode", "cfhip_encode_multi", "cfhip_encode_device", "cfhip_shard_rows",
            "cfhip_last_kernel_ms", "cfhip_last_kernel_name", "cfhip_last_error",
-           "cfhip_profile_begin", "cfhip_profile_end", "cfhip_generate_mips_device"]
+           "cfhip_profile_begin", "cfhip_profile_end", "cfhip_generate_mips_device",
+           "cfhip_generate_mips3d_device"]
 
 
 class Params(ctypes.Structure):
@@ -207,6 +208,11 @@ def load_library(path: Optional[str] = None):
         ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
         ctypes.c_uint32, ctypes.c_void_p]
     L.cfhip_generate_mips_device.restype = ctypes.c_int
+    L.cfhip_generate_mips3d_device.argtypes = [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+        ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+        ctypes.c_uint32, ctypes.c_void_p]
+    L.cfhip_generate_mips3d_device.restype = ctypes.c_int
     _lib = L
     return L
 
@@ -353,6 +359,18 @@ class Context:
         self._check(self._lib.cfhip_generate_mips_device(
             self._h, ctypes.c_void_p(int(src)), int(pixel_type), width, height, row_pitch_bytes,
             int(color_space), int(filter), arr, n, ctypes.c_void_p(stream) if stream else None))
+
+    def generate_mips3d_device(self, src: int, pixel_type, width: int, height: int, depth: int,
+                               row_pitch_bytes: int, slice_pitch_bytes: int, dst_levels: Sequence[int],
+                               color_space=ColorSpace.Linear, filter=0, stream: int = 0):
+        """Texture::generateMipmaps for a 3-D texture on the GPU: level k into dst_levels[k-1] as
+        max(1, depth >> k) tightly packed RGBA32F slices."""
+        n = len(dst_levels) + 1
+        arr = (ctypes.c_void_p * max(len(dst_levels), 1))(*[ctypes.c_void_p(int(p)) for p in dst_levels])
+        self._check(self._lib.cfhip_generate_mips3d_device(
+            self._h, ctypes.c_void_p(int(src)), int(pixel_type), width, height, depth, row_pitch_bytes,
+            slice_pitch_bytes, int(color_space), int(filter), arr, n,
+            ctypes.c_void_p(stream) if stream else None))
 
     def last_kernel_ms(self) -> float:
         return float(self._lib.cfhip_last_kernel_ms(self._h))

@@ -35,6 +35,8 @@ extern "C" hipError_t cfhip_launch_mip_resize(const void* src, int src_pixel_typ
 extern "C" hipError_t cfhip_launch_mip_pass(const void* src, int src_pixel_type, size_t pitch,
 	uint32_t src_n, void* dst, uint32_t dst_w, uint32_t dst_h, int along_x, int filter, int to_linear,
 	int to_srgb, hipStream_t stream);
+extern "C" hipError_t cfhip_launch_mip_depth(const void* prev, uint32_t n_prev, uint32_t texels, void* dst,
+	uint32_t depth, int box, int srgb, hipStream_t stream);
 extern "C" hipError_t cfhip_launch_std_pack(const cf_kparams* kp, int pixel_type, int bytes_per_pixel,
 	hipStream_t stream);
 extern "C" hipError_t cfhip_launch_bc15(const cf_kparams* kp, int format, int pixel_type,
@@ -58,6 +60,8 @@ struct cfhip_ctx {
 	hipEvent_t staging_done = nullptr;
 	hipStream_t staging_stream = nullptr;
 	bool staging_busy = false;
+	void* d_mip3d = nullptr;          // 3-D mip generation: the previous level's slices resized in x, y
+	size_t mip3d_cap = 0;
 	std::map<int, void*> astc_tables; // per-format device tables (built on first use)
 	std::map<int, cfastc::AstcBlobHeader> astc_hdr;   // their headers (sizes the launch's dynamic LDS)
 	std::vector<hipEvent_t> events;   // start/stop pairs of the last call
@@ -747,6 +751,7 @@ void cfhip_destroy(cfhip_ctx* ctx)
 	}
 	if (ctx->staging_done) (void)hipEventDestroy(ctx->staging_done);
 	if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+	if (ctx->d_mip3d) (void)hipFree(ctx->d_mip3d);
 	if (ctx->d_src) (void)hipFree(ctx->d_src);
 	if (ctx->d_out) (void)hipFree(ctx->d_out);
 	delete ctx;
@@ -1008,6 +1013,44 @@ int cfhip_encode_device(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n_
 	return encode_impl(ctx, surfaces, n_surfaces, params, true, static_cast<hipStream_t>(stream));
 }
 
+// One 2-D resize of Image::resize (Image.cpp:1324-1511): prev (any pixel type) -> dst (RGBA32F,
+// tightly packed w x h).  Box / Linear: one kernel; the cubic family: FreeImage_Rescale's two passes.
+static int mip_level_2d(cfhip_ctx* ctx, const void* prev, int prev_type, size_t prev_pitch, uint32_t pw,
+	uint32_t ph, void* dst, uint32_t w, uint32_t h, int filter, int srgb, hipStream_t stream, bool* used_staging_)
+{
+	bool& used_staging = *used_staging_;
+	void* const dst_levels[1] = {dst};
+	const uint32_t k = 1;
+	{
+		if (filter <= CFHIP_FILTER_LINEAR) {
+			HIP_TRY(ctx, cfhip_launch_mip_resize(prev, prev_type, prev_pitch, pw, ph, dst_levels[k - 1], w, h,
+				filter, srgb, stream));
+		} else {
+			// FreeImage_Rescale's two passes, horizontal first when dst_w*src_h <= dst_h*src_w, with a
+			// float intermediate image in the context's staging buffer; a pass whose size does
+			// not change is skipped (the other one then does both colour conversions)
+			const bool x_first = (unsigned long long)w*ph <= (unsigned long long)h*pw;
+			const bool need_x = w != pw, need_y = h != ph;
+			if (need_x && need_y) {
+				const uint32_t tw = x_first ? w : pw, th = x_first ? ph : h;
+				int rc = staging_acquire(ctx, stream);
+				if (rc != CFHIP_OK) return rc;
+				rc = reserve(ctx, &ctx->d_src, &ctx->src_cap, (size_t)tw*th*16u);
+				if (rc != CFHIP_OK) return rc;
+				used_staging = true;
+				HIP_TRY(ctx, cfhip_launch_mip_pass(prev, prev_type, prev_pitch, x_first ? pw : ph, ctx->d_src, tw, th,
+					x_first ? 1 : 0, filter, srgb, 0, stream));
+				HIP_TRY(ctx, cfhip_launch_mip_pass(ctx->d_src, CFHIP_PIXEL_RGBA32F, (size_t)tw*16u, x_first ? ph : pw,
+					dst_levels[k - 1], w, h, x_first ? 0 : 1, filter, 0, srgb, stream));
+			} else {
+				HIP_TRY(ctx, cfhip_launch_mip_pass(prev, prev_type, prev_pitch, need_x ? pw : ph, dst_levels[k - 1], w, h,
+					need_x ? 1 : 0, filter, srgb, srgb, stream));
+			}
+		}
+	}
+	return CFHIP_OK;
+}
+
 int cfhip_generate_mips_device(cfhip_ctx* ctx, const void* src, int src_pixel_type,
 	uint32_t width, uint32_t height, size_t src_pitch_bytes, int color_space, int filter,
 	void* const* dst_levels, uint32_t levels, void* stream_)
@@ -1045,36 +1088,95 @@ int cfhip_generate_mips_device(cfhip_ctx* ctx, const void* src, int src_pixel_ty
 		if (!dst_levels[k - 1])
 			return fail(ctx, CFHIP_E_INVALID, "mip generation: dst_levels[%u] is NULL", k - 1);
 		const uint32_t w = (width >> k) ? (width >> k) : 1u, h = (height >> k) ? (height >> k) : 1u;
-		const int srgb = color_space == CFHIP_COLOR_SRGB ? 1 : 0;
-		if (filter <= CFHIP_FILTER_LINEAR) {
-			HIP_TRY(ctx, cfhip_launch_mip_resize(prev, prev_type, prev_pitch, pw, ph, dst_levels[k - 1], w, h,
-				filter, srgb, stream));
-		} else {
-			// FreeImage_Rescale's two passes, horizontal first when dst_w*src_h <= dst_h*src_w, with a
-			// float intermediate image in the context's staging buffer; a pass whose size does
-			// not change is skipped (the other one then does both colour conversions)
-			const bool x_first = (unsigned long long)w*ph <= (unsigned long long)h*pw;
-			const bool need_x = w != pw, need_y = h != ph;
-			if (need_x && need_y) {
-				const uint32_t tw = x_first ? w : pw, th = x_first ? ph : h;
-				int rc = staging_acquire(ctx, stream);
-				if (rc != CFHIP_OK) return rc;
-				rc = reserve(ctx, &ctx->d_src, &ctx->src_cap, (size_t)tw*th*16u);
-				if (rc != CFHIP_OK) return rc;
-				used_staging = true;
-				HIP_TRY(ctx, cfhip_launch_mip_pass(prev, prev_type, prev_pitch, x_first ? pw : ph, ctx->d_src, tw, th,
-					x_first ? 1 : 0, filter, srgb, 0, stream));
-				HIP_TRY(ctx, cfhip_launch_mip_pass(ctx->d_src, CFHIP_PIXEL_RGBA32F, (size_t)tw*16u, x_first ? ph : pw,
-					dst_levels[k - 1], w, h, x_first ? 0 : 1, filter, 0, srgb, stream));
-			} else {
-				HIP_TRY(ctx, cfhip_launch_mip_pass(prev, prev_type, prev_pitch, need_x ? pw : ph, dst_levels[k - 1], w, h,
-					need_x ? 1 : 0, filter, srgb, srgb, stream));
-			}
-		}
+		const int rc2 = mip_level_2d(ctx, prev, prev_type, prev_pitch, pw, ph, dst_levels[k - 1], w, h, filter,
+			color_space == CFHIP_COLOR_SRGB ? 1 : 0, stream, &used_staging);
+		if (rc2 != CFHIP_OK)
+			return rc2;
 		prev = dst_levels[k - 1];
 		prev_type = CFHIP_PIXEL_RGBA32F;
 		prev_pitch = (size_t)w*16u;
 		pw = w; ph = h;
+	}
+	if (used_staging) {
+		const int rc = staging_release(ctx, stream);
+		if (rc != CFHIP_OK) return rc;
+	}
+	if (!stream_) {
+		HIP_TRY(ctx, hipStreamSynchronize(stream));
+		ctx->staging_busy = false;
+	}
+	return CFHIP_OK;
+}
+
+int cfhip_generate_mips3d_device(cfhip_ctx* ctx, const void* src, int src_pixel_type,
+	uint32_t width, uint32_t height, uint32_t depth, size_t src_pitch_bytes, size_t src_slice_pitch_bytes,
+	int color_space, int filter, void* const* dst_levels, uint32_t levels, void* stream_)
+{
+	if (!ctx)
+		return fail(nullptr, CFHIP_E_INVALID, "ctx is NULL");
+	std::lock_guard<std::mutex> guard(ctx->lock);
+	if (!src || !width || !height || !depth || !levels || (levels > 1 && !dst_levels))
+		return fail(ctx, CFHIP_E_INVALID, "3-D mip generation: NULL or empty argument");
+	if (src_pixel_type < CFHIP_PIXEL_RGBA8 || src_pixel_type > CFHIP_PIXEL_RGBA16F)
+		return fail(ctx, CFHIP_E_INVALID, "3-D mip generation: pixel type %d", src_pixel_type);
+	if (color_space != CFHIP_COLOR_LINEAR && color_space != CFHIP_COLOR_SRGB)
+		return fail(ctx, CFHIP_E_INVALID, "3-D mip generation: colour space %d", color_space);
+	if (filter < CFHIP_FILTER_BOX || filter > CFHIP_FILTER_BSPLINE)
+		return fail(ctx, CFHIP_E_INVALID, "resize filter %d", filter);
+	// maxMipmapLevels for a 3-D texture: floor(log2(max(w, h, d))) + 1
+	uint32_t max_levels = 1, big = width > height ? width : height;
+	big = big > depth ? big : depth;
+	for (uint32_t d = big; d > 1; d >>= 1)
+		++max_levels;
+	if (levels > max_levels)
+		return fail(ctx, CFHIP_E_INVALID, "%u mip levels requested, a %ux%ux%u texture has %u", levels,
+			width, height, depth, max_levels);
+	const size_t texel = src_pixel_type == CFHIP_PIXEL_RGBA8 ? 4 : (src_pixel_type == CFHIP_PIXEL_RGBA32F ? 16 : 8);
+	if (src_pitch_bytes < (size_t)width*texel || src_slice_pitch_bytes < src_pitch_bytes*height)
+		return fail(ctx, CFHIP_E_INVALID, "3-D mip generation: pitch smaller than a row / slice");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : ctx->stream;
+	const int srgb = color_space == CFHIP_COLOR_SRGB ? 1 : 0;
+	// level k (Texture.cpp:1345-1402): every slice of level k-1 is resized to the level's width and
+	// height with Image::resize, then generateMips3d interpolates the slices along the depth
+	const uint8_t* prev = static_cast<const uint8_t*>(src);
+	int prev_type = src_pixel_type;
+	size_t prev_pitch = src_pitch_bytes, prev_slice = src_slice_pitch_bytes;
+	uint32_t pw = width, ph = height, pd = depth;
+	// the slice buffer is a context buffer like the staging buffers: ordered by the same event
+	bool used_staging = levels > 1;
+	if (used_staging) {
+		const int rc = staging_acquire(ctx, stream);
+		if (rc != CFHIP_OK) return rc;
+	}
+	for (uint32_t k = 1; k < levels; ++k) {
+		if (!dst_levels[k - 1])
+			return fail(ctx, CFHIP_E_INVALID, "3-D mip generation: dst_levels[%u] is NULL", k - 1);
+		const uint32_t w = (width >> k) ? (width >> k) : 1u, h = (height >> k) ? (height >> k) : 1u,
+			d = (depth >> k) ? (depth >> k) : 1u;
+		const size_t slice_bytes = (size_t)w*h*16u;
+		int rc = reserve(ctx, &ctx->d_mip3d, &ctx->mip3d_cap, slice_bytes*pd);
+		if (rc != CFHIP_OK)
+			return rc;
+		for (uint32_t i = 0; i < pd; ++i) {
+			uint8_t* dst = static_cast<uint8_t*>(ctx->d_mip3d) + slice_bytes*i;
+			if (w == pw && h == ph)    // Image::resize returns a copy (Image.cpp:1330-1334): an exact Box identity
+				HIP_TRY(ctx, cfhip_launch_mip_resize(prev + prev_slice*i, prev_type, prev_pitch, pw, ph, dst, w, h,
+					CFHIP_FILTER_BOX, 0, stream));
+			else {
+				rc = mip_level_2d(ctx, prev + prev_slice*i, prev_type, prev_pitch, pw, ph, dst, w, h, filter, srgb,
+					stream, &used_staging);
+				if (rc != CFHIP_OK)
+					return rc;
+			}
+		}
+		HIP_TRY(ctx, cfhip_launch_mip_depth(ctx->d_mip3d, pd, w*h, dst_levels[k - 1], d,
+			filter == CFHIP_FILTER_BOX ? 1 : 0, srgb, stream));
+		prev = static_cast<const uint8_t*>(dst_levels[k - 1]);
+		prev_type = CFHIP_PIXEL_RGBA32F;
+		prev_pitch = (size_t)w*16u;
+		prev_slice = slice_bytes;
+		pw = w; ph = h; pd = d;
 	}
 	if (used_staging) {
 		const int rc = staging_release(ctx, stream);

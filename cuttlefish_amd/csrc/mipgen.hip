@@ -201,6 +201,63 @@ cfhip_mip_pass_kernel(const uint8_t* __restrict__ src, size_t pitch, uint32_t sr
 	dst[(size_t)y*dst_w + x] = o;
 }
 
+// generateMips3d (lib/src/Texture.cpp:103-227): the depth pass of one mip level of a 3-D texture.
+// One thread per output texel; prev = n_prev tightly packed RGBA32F slices of w x h (the previous
+// level's slices resized in x and y), out = depth slices.  Twin of cfo_mip_depth_pass.
+__global__ void __launch_bounds__(256)
+cfhip_mip_depth_kernel(const float4* __restrict__ prev, uint32_t n_prev, uint32_t texels,
+	float4* __restrict__ out, uint32_t depth, int box, int srgb)
+{
+	const uint32_t t = blockIdx.x*256u + threadIdx.x, d = blockIdx.y;
+	if (t >= texels)
+		return;
+	const double invScale = (double)n_prev/(double)depth;
+	const double offset = invScale > 1.0 ? invScale : 1.0;
+	const double filterScale = 1.0/offset;
+	const double center = ((double)d + 0.5)*invScale;
+	const int s0 = (int)(center - offset + 0.5);
+	const uint32_t start = s0 > 0 ? (uint32_t)s0 : 0u;
+	const uint32_t e0 = (uint32_t)(center + offset + 0.5);
+	const uint32_t end = e0 < n_prev ? e0 : n_prev;
+	double cr = 0.0, cg = 0.0, cb = 0.0, ca = 0.0, total = 0.0;
+	for (uint32_t i = start; i < end; ++i) {
+		double scale;
+		if (box) {
+			if (fabs((double)i + 0.5 - center)*filterScale > 0.5)
+				continue;
+			scale = 1.0;
+		} else {
+			scale = 1.0 - fabs((double)i + 0.5 - center)*filterScale;
+			scale = scale > 0.0 ? scale : 0.0;
+			if (scale == 0.0)
+				continue;
+		}
+		float4 s = prev[(size_t)i*texels + t];
+		if (srgb) {
+			s.x = (float)srgb_to_linear((double)s.x);
+			s.y = (float)srgb_to_linear((double)s.y);
+			s.z = (float)srgb_to_linear((double)s.z);
+		}
+		if (box) {
+			cr += (double)s.x; cg += (double)s.y; cb += (double)s.z; ca += (double)s.w;
+		} else {
+			// separate multiply and add, like the reference's `color.r += srcColor.r*scale`
+			cr = __dadd_rn(cr, __dmul_rn((double)s.x, scale));
+			cg = __dadd_rn(cg, __dmul_rn((double)s.y, scale));
+			cb = __dadd_rn(cb, __dmul_rn((double)s.z, scale));
+			ca = __dadd_rn(ca, __dmul_rn((double)s.w, scale));
+		}
+		total += scale;
+	}
+	float4 o = make_float4((float)(cr/total), (float)(cg/total), (float)(cb/total), (float)(ca/total));
+	if (srgb) {
+		o.x = (float)linear_to_srgb((double)o.x);
+		o.y = (float)linear_to_srgb((double)o.y);
+		o.z = (float)linear_to_srgb((double)o.z);
+	}
+	out[(size_t)d*texels + t] = o;
+}
+
 } // namespace
 
 // one separable pass (filters 2..4): src (any pixel type, `pitch`) -> dst (RGBA32F, dst_w x dst_h)
@@ -236,5 +293,15 @@ extern "C" hipError_t cfhip_launch_mip_resize(const void* src, int src_pixel_typ
 		hipLaunchKernelGGL((cfhip_mip_resize_kernel<1>), grid, block, 0, stream, s, pitch, sw, sh, d, dw, dh, filter, srgb);
 	else
 		hipLaunchKernelGGL((cfhip_mip_resize_kernel<2>), grid, block, 0, stream, s, pitch, sw, sh, d, dw, dh, filter, srgb);
+	return hipGetLastError();
+}
+
+// depth pass of a 3-D mip level: prev (n_prev slices) -> dst (depth slices), both RGBA32F, w*h texels per slice
+extern "C" hipError_t cfhip_launch_mip_depth(const void* prev, uint32_t n_prev, uint32_t texels, void* dst,
+	uint32_t depth, int box, int srgb, hipStream_t stream)
+{
+	const dim3 grid((texels + 255u)/256u, depth, 1), block(256, 1, 1);
+	hipLaunchKernelGGL(cfhip_mip_depth_kernel, grid, block, 0, stream, static_cast<const float4*>(prev), n_prev,
+		texels, static_cast<float4*>(dst), depth, box, srgb);
 	return hipGetLastError();
 }

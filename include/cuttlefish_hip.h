@@ -248,6 +248,17 @@ int cfhip_generate_mips_device(cfhip_ctx* ctx, const void* src, int src_pixel_ty
 	uint32_t width, uint32_t height, size_t src_pitch_bytes, int color_space, int filter,
 	void* const* dst_levels, uint32_t levels, void* stream);
 
+/* The same for a 3-D texture (Texture::generateMipmaps, Dim3D branch, lib/src/Texture.cpp:1345-1440):
+ * level k = every slice of level k-1 resized to max(1, w >> k) x max(1, h >> k) by Image::resize, then
+ * generateMips3d (Texture.cpp:103-227) along the depth to max(1, depth >> k) slices -- Box counts
+ * the slices inside the footprint, every other filter weights them with a tent.  src: `depth`
+ * slices, src_slice_pitch_bytes apart; dst_levels[k - 1]: level k as tightly packed RGBA32F
+ * slices (w_k * h_k * 16 bytes each, depth_k of them). */
+int cfhip_generate_mips3d_device(cfhip_ctx* ctx, const void* src, int src_pixel_type,
+	uint32_t width, uint32_t height, uint32_t depth, size_t src_pitch_bytes,
+	size_t src_slice_pitch_bytes, int color_space, int filter, void* const* dst_levels,
+	uint32_t levels, void* stream);
+
 /* Block-row sharding of one surface across `world` ranks:
  * rank r owns block rows [*row_begin, *row_end).  Pure function, no communication. */
 int cfhip_shard_rows(uint32_t block_rows, int rank, int world, uint32_t* row_begin,

@@ -254,3 +254,65 @@ int cfo_resize_rgbaf(const float* src, unsigned sw, unsigned sh, float* dst, uns
 	}
 	return 0;
 }
+
+
+/* generateMips3d (lib/src/Texture.cpp:103-227): the DEPTH pass of one mip level of a 3-D texture.
+ * prev: n_prev slices of w x h RGBAF texels -- the previous level's slices, already resized to
+ * this level's width and height by Image::resize (Texture.cpp:1388-1399) -- out: `depth` slices.
+ * filter 0 (Box) counts the slices whose centre lies within half a footprint (:114-165); every
+ * other filter takes the tent-weighted branch (:166-225).  Averages in linear space for sRGB
+ * textures, double accumulation, every stored value rounded to float -- operation for operation. */
+int cfo_mip_depth_pass(const float* prev, unsigned n_prev, unsigned w, unsigned h, float* out,
+	unsigned depth, int filter, int color_space)
+{
+	if (!prev || !out || !n_prev || !w || !h || !depth)
+		return -1;
+	const size_t slice = (size_t)w*h*4;
+	double invScale = (double)n_prev/(double)depth;
+	double offset = invScale > 1.0 ? invScale : 1.0;
+	double filterScale = 1.0/offset;
+	for (unsigned d = 0; d < depth; ++d) {
+		double center = (d + 0.5)*invScale;
+		unsigned start = (unsigned)imax((int)(center - offset + 0.5), 0);
+		unsigned end = umin((unsigned)(center + offset + 0.5), n_prev);
+		for (size_t t = 0; t < (size_t)w*h; ++t) {
+			double color[4] = {0, 0, 0, 0};
+			double totalScale = 0;
+			for (unsigned i = start; i < end; ++i) {
+				double scale;
+				if (filter == 0) {
+					if (fabs(i + 0.5 - center)*filterScale > 0.5)
+						continue;
+					scale = 1.0;
+				} else {
+					scale = 1.0 - fabs(i + 0.5 - center)*filterScale;
+					scale = scale > 0.0 ? scale : 0.0;
+					if (scale == 0.0)
+						continue;
+				}
+				const float* sp = prev + i*slice + 4*t;
+				float src[4] = {sp[0], sp[1], sp[2], sp[3]};
+				if (color_space == 1) {
+					src[0] = (float)cfo_srgb_to_linear(src[0]);
+					src[1] = (float)cfo_srgb_to_linear(src[1]);
+					src[2] = (float)cfo_srgb_to_linear(src[2]);
+				}
+				if (filter == 0) {
+					for (int c = 0; c < 4; ++c)
+						color[c] += src[c];
+				} else {
+					for (int c = 0; c < 4; ++c)
+						color[c] += src[c]*scale;
+				}
+				totalScale += scale;
+			}
+			float* op = out + d*slice + 4*t;
+			for (int c = 0; c < 4; ++c)
+				op[c] = (float)(color[c]/totalScale);
+			if (color_space == 1)
+				for (int c = 0; c < 3; ++c)
+					op[c] = (float)cfo_linear_to_srgb(op[c]);
+		}
+	}
+	return 0;
+}

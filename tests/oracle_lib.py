@@ -189,6 +189,38 @@ def mip_chain(img: np.ndarray, levels: int, filter=0, color_space=0):
     return out
 
 
+def mip_depth_pass(prev: np.ndarray, depth: int, filter=0, color_space=0) -> np.ndarray:
+    """generateMips3d (Texture.cpp:103-227): (n_prev, h, w, 4) float32 slices -> (depth, h, w, 4)."""
+    prev = np.ascontiguousarray(prev, np.float32)
+    n, h, w = prev.shape[:3]
+    out = np.zeros((depth, h, w, 4), np.float32)
+    L = lib()
+    L.cfo_mip_depth_pass.restype = ctypes.c_int
+    L.cfo_mip_depth_pass.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint,
+                                     ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, ctypes.c_int]
+    rc = L.cfo_mip_depth_pass(prev.ctypes.data, n, w, h, out.ctypes.data, depth, int(filter), int(color_space))
+    if rc != 0:
+        raise RuntimeError("cfo_mip_depth_pass failed: %d" % rc)
+    return out
+
+
+def mip_chain3d(vol: np.ndarray, levels: int, filter=0, color_space=0):
+    """Texture::generateMipmaps, Dim3D branch (Texture.cpp:1345-1440): vol (d, h, w, 4); every slice
+    of level k-1 is resized in x, y, then the depth pass."""
+    if vol.dtype == np.uint8:
+        base = (vol.astype(np.float64) / 255.0).astype(np.float32)
+    else:
+        base = vol.astype(np.float32)
+    d0, h0, w0 = base.shape[:3]
+    out = [base]
+    for k in range(1, levels):
+        w, h, d = max(1, w0 >> k), max(1, h0 >> k), max(1, d0 >> k)
+        prev = out[-1]
+        resized = np.stack([resize_rgbaf(prev[i], w, h, filter, color_space) for i in range(prev.shape[0])])
+        out.append(mip_depth_pass(resized, d, filter, color_space))
+    return out
+
+
 def color_fns():
     L = lib()
     for n in ("cfo_srgb_to_linear", "cfo_linear_to_srgb"):

@@ -159,3 +159,56 @@ def test_generate_mipmaps_level_dimensions_as_in_the_reference_test():
     assert t.images_complete() and t.generate_mipmaps() and t.images_complete()
     assert t.mip_level_count() == 4
     assert [t._images[k][0].shape[:2] for k in range(4)] == [(10, 15), (5, 7), (2, 3), (1, 1)]
+
+
+def _gpu_chain3d(ctx, vol, levels, color_space, filt):
+    d, h, w = vol.shape[:3]
+    src = torch.from_numpy(np.ascontiguousarray(vol)).cuda()
+    if vol.dtype == np.uint8:
+        pt, texel = PixelType.RGBA8, 4
+    else:
+        pt, texel = PixelType.RGBA32F, 16
+    dsts = [torch.empty((max(1, d >> k), max(1, h >> k), max(1, w >> k), 4), dtype=torch.float32, device="cuda")
+            for k in range(1, levels)]
+    ctx.generate_mips3d_device(src.data_ptr(), pt, w, h, d, w*texel, w*h*texel, [t.data_ptr() for t in dsts],
+                               color_space=color_space, filter=filt)
+    return [t.cpu().numpy() for t in dsts]
+
+
+@pytest.mark.parametrize("filt", [0, 1, 3])
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_3d_chain_linear_space_is_bit_exact(filt, dtype):
+    """Texture::generateMipmaps for Dim3D (Texture.cpp:1345-1440): x / y resize of every slice, then
+    generateMips3d along the depth; non-power-of-two sizes, down to 1x1x1."""
+    rng = np.random.default_rng(11)
+    vol = (rng.random((12, 20, 28, 4))*255).astype(np.uint8)
+    if dtype == np.float32:
+        vol = (vol.astype(np.float32)/255.0)*np.float32(1.5)
+    with Context(0) as ctx:
+        got = _gpu_chain3d(ctx, vol, 5, ColorSpace.Linear, filt)
+    want = O.mip_chain3d(vol, 5, filter=filt, color_space=0)[1:]
+    assert [g.shape for g in got] == [w.shape for w in want]
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert np.array_equal(g, w), "level %d differs" % (k + 1)
+
+
+def test_3d_chain_srgb_within_pow_rounding():
+    rng = np.random.default_rng(12)
+    vol = (rng.random((8, 16, 16, 4))*255).astype(np.uint8)
+    with Context(0) as ctx:
+        got = _gpu_chain3d(ctx, vol, 4, ColorSpace.sRGB, 0)
+    want = O.mip_chain3d(vol, 4, filter=0, color_space=1)[1:]
+    for k, (g, w) in enumerate(zip(got, want)):
+        # two pow round trips per level (x / y resize, depth pass): 2 ulps each, accumulated over levels
+        assert _ulps(g, w).max() <= 4*(k + 1), "level %d" % (k + 1)
+        assert np.array_equal(g[..., 3], w[..., 3])
+
+
+def test_3d_bad_arguments():
+    with Context(0) as ctx:
+        t = torch.zeros((4, 4, 4, 4), dtype=torch.uint8, device="cuda")
+        o = torch.zeros((2, 2, 2, 4), dtype=torch.float32, device="cuda")
+        with pytest.raises(CfhipError):
+            ctx.generate_mips3d_device(t.data_ptr(), PixelType.RGBA8, 4, 4, 4, 16, 64, [o.data_ptr()]*3)   # 4 levels of a 4^3
+        with pytest.raises(CfhipError):
+            ctx.generate_mips3d_device(t.data_ptr(), PixelType.RGBA8, 4, 4, 4, 16, 32, [o.data_ptr()])     # slice pitch < slice
