@@ -145,7 +145,7 @@ def _cached_photo(synth, size, seed):
     return img
 
 
-def valu_issue_view(kernel_substr, avg_kernel_s):
+def valu_issue_view(kernel_substr, avg_kernel_s, quality=2):
     """The kernel's mix-weighted VALU issue ceiling.  The instruction mix comes from the device
     code inside the library that just ran (tools/isa_mix.py); the dynamic instruction counts
     (SQ_INSTS_VALU and the per-class counters) and the HBM traffic come from the committed
@@ -163,10 +163,12 @@ def valu_issue_view(kernel_substr, avg_kernel_s):
             "classes": "2-cycle: fp32 fma/mul/add, plain add/sub/and/or/xor/mov/ashr; 4-cycle: the rest "
                        "(tools/ubench/valu_rate.hip, profiles/r01_valu_rate.txt)"}
     traffic = source = None
-    ppath = os.path.join(ROOT, "profiles", "bc7_pmc.json")
+    # one committed PMC file per quality level (the dynamic counts depend on it)
+    pname = "bc7_pmc.json" if quality == 2 else "bc7_pmc_q%d.json" % quality
+    ppath = os.path.join(ROOT, "profiles", pname)
     if os.path.exists(ppath):
         pj = json.load(open(ppath))
-        if pj.get("code_sha256") == mix["code_sha256"]:
+        if pj.get("code_sha256") == mix["code_sha256"] and pj.get("quality", 2) == quality:
             traffic = pj.get("traffic_bytes_per_launch")
             source = "from committed profile %s (same code hash %s)" % (pj.get("source"), mix["code_sha256"])
             insts = pj.get("valu_wave_insts_per_launch")
@@ -185,8 +187,8 @@ def valu_issue_view(kernel_substr, avg_kernel_s):
                                      "(1024 SIMDs x 2.4 GHz x kernel time): the share of the kernel's "
                                      "time the VALU needs at full issue rate for ITS mix"})
         else:
-            view["note"] = "profiles/bc7_pmc.json describes other code (hash %s): no PMC-derived figures" % \
-                pj.get("code_sha256")
+            view["note"] = "profiles/%s describes other code (hash %s): no PMC-derived figures" % \
+                (pname, pj.get("code_sha256"))
     return view, traffic, source
 
 
@@ -452,9 +454,9 @@ def main():
         }
         if size == SIZE:
             ksub = "cfhip_bc7_encode_kernelILi0ELb1ELb%dE" % (1 if args.quality == 4 else 0)
-            view, traffic, source = valu_issue_view(ksub, avg_kernel_s)
+            view, traffic, source = valu_issue_view(ksub, avg_kernel_s, args.quality)
             line["roofline"]["valu_issue"] = view
-            if args.quality == 2 and traffic is not None:
+            if traffic is not None:
                 line["roofline"]["traffic"] = traffic
                 line["roofline"]["traffic_source"] = source
         if world == 1 and not args.no_cpu_baseline and size == SIZE:

@@ -1284,7 +1284,7 @@ extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t qualit
 	const size_t cu_lds = 160u*1024u, wg_max = 160u*1024u - 1024u;
 	const bool can_cache = h->n <= 36u;
 	uint32_t best_w = 0, best_nw = 4, best_c = 0;
-	const char* force = getenv("CFHIP_ASTC_WAVES");
+	static const char* const force = getenv("CFHIP_ASTC_WAVES");     // experiments: pin the workgroup shape
 	for (uint32_t c = 0; c < 2u; ++c) {
 		if (c && !can_cache)
 			break;
@@ -1322,8 +1322,9 @@ extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, ui
 		attr_set = true;
 	}
 	// the 168-register build only where three waves per SIMD actually become resident
-	const bool dense = (160u*1024u/(lds_bytes + 1024u))*nwaves >= 12u && !getenv("CFHIP_ASTC_NO_DENSE");
-	if (getenv("CFHIP_ASTC_DEBUG")) {
+	static const bool no_dense = getenv("CFHIP_ASTC_NO_DENSE") != nullptr, debug = getenv("CFHIP_ASTC_DEBUG") != nullptr;
+	const bool dense = (160u*1024u/(lds_bytes + 1024u))*nwaves >= 12u && !no_dense;
+	if (debug) {
 		int nb = -1;
 		const void* fn = dense ? reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 12>) : reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 8>);
 		hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, (int)(nwaves*64u), lds_bytes);

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round-end evidence pass on the GPU box: bash tools/final_evidence.sh <tag>
+# profile passes (kernel trace + PMC, separate runs) for BC7 at Normal / High / Highest, the bench
+# lines that quote them, the formats table, the BASELINE configs, C5, and the parity sweep.
+tag=${1:-r02b}
+R=${GRAFT_REPO_ROOT:-$PWD}
+G=$R/gpurun_out
+mkdir -p $G
+for q in 2 3 4; do
+  sfx=""; [ $q != 2 ] && sfx="_q$q"
+  kern="cfhip_bc7_encode_kernel<0, true, false>"; mang="cfhip_bc7_encode_kernelILi0ELb1ELb0E"
+  [ $q = 4 ] && kern="cfhip_bc7_encode_kernel<0, true, true>" && mang="cfhip_bc7_encode_kernelILi0ELb1ELb1E"
+  bash $R/tools/profile.sh ${tag}$sfx --quality $q > $G/${tag}${sfx}_bc7_pmc_summary.txt 2>&1
+  python $R/tools/pmc_to_json.py $G/prof_${tag}$sfx --tag ${tag}$sfx --quality $q --kernel "$kern" --mangled "$mang" --out $G/bc7_pmc$sfx.json > /dev/null \
+    && cp $G/bc7_pmc$sfx.json $R/profiles/bc7_pmc$sfx.json
+  for f in $(find $G/prof_${tag}$sfx/stats -name "*kernel_stats.csv"); do cp $f $G/${tag}${sfx}_bc7_kernel_stats.csv; done
+  extra=""; [ $q != 2 ] && extra="--no-cpu-baseline"
+  python $R/bench.py --quality $q $extra > $G/${tag}${sfx}_bench.json 2> $G/${tag}${sfx}_bench.err
+done
+python $R/tools/bench_formats.py --size 2048 --steps 3 --qualities 0,1,2,3,4 2>/dev/null | grep format > $G/${tag}_formats_2048.jsonl
+python $R/tools/bench_configs.py 2>/dev/null | grep "^{" > $G/${tag}_baseline_configs.jsonl
+python $R/bench.py --config c5 --textures 16 2>/dev/null | grep "^{" > $G/${tag}_c5_16tex.json
+python $R/tools/bench_srgb.py 2>/dev/null | grep "^{" > $G/${tag}_srgb_vs_linear.jsonl
+bash $R/tools/fuzz_all.sh 300 7 > $G/${tag}_fuzz.txt 2>&1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $G/prof_${tag}_formats -o trace -- python $R/tools/bench_formats.py --size 2048 --steps 3 --qualities 2,3 > /dev/null 2>&1
+for f in $(find $G/prof_${tag}_formats -name "*kernel_stats.csv"); do cp $f $G/${tag}_formats_kernel_stats.csv; done
+tail -c 1500 $G/${tag}_bench.json; echo; grep -c "0 mismatching" $G/${tag}_fuzz.txt

@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--tag", required=True)
     ap.add_argument("--kernel", default="cfhip_bc7_encode_kernel<0, true, false>")
     ap.add_argument("--mangled", default="cfhip_bc7_encode_kernelILi0ELb1ELb0E")
+    ap.add_argument("--quality", type=int, default=2, help="Texture::Quality the passes ran at")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "bc7_pmc.json"))
     a = ap.parse_args()
     c = per_dispatch(a.prof_dir, a.kernel)
@@ -49,7 +50,7 @@ def main():
     mix = isa_mix.kernel_mix(os.path.join(ROOT, "cuttlefish_amd", "libcuttlefish_hip.so"), a.mangled)
     insts = c["SQ_INSTS_VALU"]
     out = {
-        "kernel": a.kernel, "build": a.tag, "code_sha256": mix["code_sha256"],
+        "kernel": a.kernel, "build": a.tag, "quality": a.quality, "code_sha256": mix["code_sha256"],
         "source": "profiles/%s_bc7_pmc_summary.txt (rocprofv3 --pmc passes of tools/profile.sh, one counter group per run)" % a.tag,
         "valu_wave_insts_per_launch": insts,
         "salu_wave_insts_per_launch": c.get("SQ_INSTS_SALU"),
