@@ -26,6 +26,7 @@
 // accumulators and quantised weights ([row][lane], conflict-free for a fixed row).
 #include "cf_device.h"
 #include "astc_tables.h"
+#include <hip/hip_fp16.h>
 #include <cstdio>
 #include <cstdlib>
 
@@ -40,6 +41,8 @@ namespace {
 
 #define ASTC_FLAG_ALPHA_WEIGHT 1u
 #define ASTC_FLAG_PERCEPTUAL 2u
+#define ASTC_FLAG_HDR 8u           // kp.flags bit 19: HDR profile, the colour channels are 8-bit LNS codes
+#define ASTC_FLAG_HDR_ALPHA 16u    // bit 20: alpha is an LNS code too (ASTCENC_PRF_HDR), else LDR alpha
 
 __device__ __forceinline__ float clampf255(float x) { return x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x); }
 
@@ -134,6 +137,7 @@ struct Shared {
 	const uint8_t* grid;      // [grid][4]: N, M, ng
 	const uint8_t* cunq;      // [17][256]
 	const uint8_t* cnear;     // [17][256]
+	const uint8_t* cnear_hi;  // [17][256] HDR launches only: nearest index among values with bit 7 set
 	const uint8_t* wunq;      // [12][32]
 	const uint8_t* wnear;     // [12][68]
 };
@@ -166,7 +170,52 @@ __device__ __forceinline__ int quant_c(const Shared& sh, uint32_t lv, float x, u
 // bytes and the stored ISE values.  o: 0 direct (CEM 8/12), 1 base+scale (6/10), 2 luminance (0/4).
 // r0 / r1: least-squares endpoints (alpha = 255 for blocks without alpha); A/B/C per channel.
 // Returns false when the option cannot represent the pair (direct with neither order valid).
-__device__ __forceinline__ bool cem_option(const Shared& sh, int o, uint32_t lv, bool has_alpha,
+// constant-colour block: UNORM16 (LDR) or, with bit 9 of the header set, four halves (HDR profile)
+__device__ __forceinline__ uint4 void_extent(uint32_t r, uint32_t g, uint32_t b, uint32_t a, uint32_t hdrf);
+
+// HDR direct sub-mode: blue / HDR alpha go through the values with bit 7 set, decode (u & 0x7F) << 1
+__device__ __forceinline__ int quant_hi(const Shared& sh, uint32_t lv, float x, uint32_t& stored)
+{
+	const uint32_t xi = (uint32_t)(int)floorf(clampf255(x) + 0.5f);
+	stored = sh.cnear_hi[lv*256u + xi];
+	return (int)((sh.cunq[lv*256u + stored] & 0x7Fu) << 1);
+}
+
+// HDR profile (oracle: cfo_astc_hdr_code): a channel is searched as the top 8 bits of its 16-bit
+// LNS value, code = round(LNS16(half(x)) / 256); negative / NaN -> 0, beyond 65504 -> 65504
+__device__ __forceinline__ uint32_t hdr_code(float x)
+{
+	if (!(x > 0.0f))
+		return 0u;
+	uint32_t hb = (uint32_t)__half_as_ushort(__float2half_rn(x > 65504.0f ? 65504.0f : x));   // v_cvt_f16_f32, RNE
+	hb = hb > 0x7BFFu ? 0x7BFFu : hb;
+	const uint32_t e = hb >> 10, m10 = hb & 1023u;
+	uint32_t m = m10 < 192u ? (8u*m10 + 1u)/3u : (m10 < 704u ? 2u*m10 + 128u : (8u*m10 + 2050u)/5u);
+	m = m > 2047u ? 2047u : m;
+	const uint32_t c = (((e << 11) | m) + 128u) >> 8;
+	return c > 255u ? 255u : c;
+}
+
+// the half an 8-bit LNS code decodes to (specification: LNS -> half; oracle: lns_code_to_half)
+__device__ __forceinline__ uint32_t lns_code_to_half(uint32_t code)
+{
+	const uint32_t c = code << 8, e = c >> 11, m = c & 0x7FFu;
+	const uint32_t mt = m < 512u ? 3u*m : (m < 1536u ? 4u*m - 512u : 5u*m - 2048u);
+	const uint32_t hb = (e << 10) + (mt >> 3);
+	return hb > 0x7BFFu ? 0x7BFFu : hb;
+}
+
+__device__ __forceinline__ uint4 void_extent(uint32_t r, uint32_t g, uint32_t b, uint32_t a, uint32_t hdrf)
+{
+	if (!hdrf)
+		return make_uint4(0xFFFFFDFCu, 0xFFFFFFFFu, (r*257u) | ((g*257u) << 16), (b*257u) | ((a*257u) << 16));
+	const uint32_t ha = (hdrf & 2u) ? lns_code_to_half(a)
+		: (uint32_t)__half_as_ushort(__float2half_rn((float)a*(1.0f/255.0f)));
+	return make_uint4(0xFFFFFFFCu, 0xFFFFFFFFu, lns_code_to_half(r) | (lns_code_to_half(g) << 16),
+		lns_code_to_half(b) | (ha << 16));
+}
+
+__device__ __forceinline__ bool cem_option(const Shared& sh, int o, uint32_t lv, bool has_alpha, uint32_t hdr,
 	const float (&r0)[4], const float (&r1)[4], const float (&fA)[4], const float (&fB)[4],
 	const float (&fC)[4], const uint32_t (&cw)[4], float& est, uint32_t& d0p, uint32_t& d1p,
 	uint32_t (&vals)[8])
@@ -174,7 +223,36 @@ __device__ __forceinline__ bool cem_option(const Shared& sh, int o, uint32_t lv,
 	int d0[4], d1[4];
 	d0[3] = 255; d1[3] = 255;
 	uint32_t s;
-	if (o == 0) {
+	if (o == 0 && hdr) {
+		// HDR direct sub-mode (CEM 11 / 14 / 15, major component 3): v0..v3 = the 8-bit red and green
+		// endpoints, v4, v5 = 0x80 | 7 bits of blue; no ordering rule, no blue contraction (uniform
+		// per launch: `hdr` comes from the launch flags)
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			uint32_t s0, s1;
+			if (c < 2) {
+				d0[c] = quant_c(sh, lv, r0[c], s0);
+				d1[c] = quant_c(sh, lv, r1[c], s1);
+			} else {
+				d0[c] = quant_hi(sh, lv, r0[c], s0);
+				d1[c] = quant_hi(sh, lv, r1[c], s1);
+			}
+			vals[2*c] = s0; vals[2*c + 1] = s1;
+			est = fmaf((float)cw[c], quad_est(fA[c], fB[c], fC[c], (float)d0[c] - r0[c], (float)d1[c] - r1[c]), est);
+		}
+		if (has_alpha) {
+			uint32_t s6, s7;
+			if (hdr & 2u) {
+				d0[3] = quant_hi(sh, lv, r0[3], s6);
+				d1[3] = quant_hi(sh, lv, r1[3], s7);
+			} else {
+				d0[3] = quant_c(sh, lv, r0[3], s6);
+				d1[3] = quant_c(sh, lv, r1[3], s7);
+			}
+			vals[6] = s6; vals[7] = s7;
+			est = fmaf((float)cw[3], quad_est(fA[3], fB[3], fC[3], (float)d0[3] - r0[3], (float)d1[3] - r1[3]), est);
+		}
+	} else if (o == 0) {
 		int dd0[3], dd1[3], sd0 = 0, sd1 = 0;
 		uint32_t st[6];
 #pragma unroll
@@ -356,6 +434,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	const uint32_t n = H->n, bw = H->bw, bh = H->bh, ngrids = H->ngrids, npad = H->npad;
 	const uint32_t col_rows = H->col_rows;
 	const uint32_t aflags = (kp.flags >> 16) & 3u;
+	// HDR profile (Type::UFloat, AstcConverter.cpp:150-162): bit 0 = HDR colour, bit 1 = HDR alpha too
+	const uint32_t hdrf = (kp.flags >> 19) & 3u;
 	// texel-weight cache rows: a launch-time choice (cfhip_astc_plan) -- on when they fit without
 	// costing a wave of occupancy; the cache never changes a result
 	const bool wcached = (kp.flags >> 18) & 1u;
@@ -369,7 +449,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	uint32_t* sh_infill = reinterpret_cast<uint32_t*>(lds + off); off += ngrids*n*4u; off = (off + 15u) & ~15u;
 	uint16_t* sh_den = reinterpret_cast<uint16_t*>(lds + off); off += ngrids*128u;
 	uint8_t* sh_grid = lds + off; off += (ngrids*4u + 15u) & ~15u;
-	uint8_t* sh_ctab = lds + off; off += 2u*17u*256u;
+	uint8_t* sh_ctab = lds + off; off += (hdrf ? 3u : 2u)*17u*256u;
 	uint8_t* sh_wtab = lds + off; off += 1216u;
 	const uint32_t slot_bytes = ((10u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
 	const uint32_t wave_bytes = ((((col_rows + 1u)/2u)*256u + wc_rows*256u + 15u) & ~15u) + (kp.quality <= 2u ? 2u : 1u)*slot_bytes;
@@ -382,7 +462,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		sh_den[i] = reinterpret_cast<const uint16_t*>(blob + H->off_den)[i];
 	for (uint32_t i = threadIdx.x; i < ngrids; i += nthreads)
 		reinterpret_cast<uint32_t*>(sh_grid)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_grid)[i];
-	for (uint32_t i = threadIdx.x; i < 2u*17u*64u; i += nthreads)
+	for (uint32_t i = threadIdx.x; i < (hdrf ? 3u : 2u)*17u*64u; i += nthreads)
 		reinterpret_cast<uint32_t*>(sh_ctab)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_ctab)[i];
 	for (uint32_t i = threadIdx.x; i < 304u; i += nthreads)
 		reinterpret_cast<uint32_t*>(sh_wtab)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_wtab)[i];
@@ -400,11 +480,21 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			y = y < kp.height ? y : kp.height - 1u;
 			const uint8_t* rowp = kp.src + (long long)y*kp.pitch;
 			uint32_t px;
-			if (PIX == 0)
+			if (PIX == 0) {
 				px = *reinterpret_cast<const uint32_t*>(rowp + (size_t)x*4u);
-			else {
+				if (hdrf) {
+					const float k = 1.0f/255.0f;
+					const uint32_t a = (hdrf & 2u) ? hdr_code((float)(px >> 24)*k) : px >> 24;
+					px = hdr_code((float)(px & 255u)*k) | (hdr_code((float)((px >> 8) & 255u)*k) << 8) |
+						(hdr_code((float)((px >> 16) & 255u)*k) << 16) | (a << 24);
+				}
+			} else {
 				const float4 f = *reinterpret_cast<const float4*>(rowp + (size_t)x*16u);
-				px = cf_unorm8(f.x) | (cf_unorm8(f.y) << 8) | (cf_unorm8(f.z) << 16) | (cf_unorm8(f.w) << 24);
+				if (hdrf)
+					px = hdr_code(f.x) | (hdr_code(f.y) << 8) | (hdr_code(f.z) << 16) |
+						(((hdrf & 2u) ? hdr_code(f.w) : cf_unorm8(f.w)) << 24);
+				else
+					px = cf_unorm8(f.x) | (cf_unorm8(f.y) << 8) | (cf_unorm8(f.z) << 16) | (cf_unorm8(f.w) << 24);
 			}
 			// swizzle from colour mask / alpha type (AstcConverter.cpp:140-149)
 			tile[blk*n + row*bw + cx] = (px & kp.keep_mask) | kp.set_mask;
@@ -414,7 +504,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 
 	Shared sh;
 	sh.infill = sh_infill; sh.den = sh_den; sh.grid = sh_grid;
-	sh.cunq = sh_ctab; sh.cnear = sh_ctab + 17u*256u;
+	sh.cunq = sh_ctab; sh.cnear = sh_ctab + 17u*256u; sh.cnear_hi = sh_ctab + 2u*17u*256u;
 	sh.wunq = sh_wtab; sh.wnear = sh_wtab + 12u*32u;
 	const int8_t* clevel = reinterpret_cast<const int8_t*>(blob + H->off_clevel);
 	const uint8_t* ise = blob + H->off_ise;
@@ -458,12 +548,14 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 
 		// ---- block statistics (texels strided over the group) ----
 		const uint32_t p0 = tp[0];
+		// the alpha a block without an alpha endpoint decodes to: 1.0 = 255 (UNORM) or LNS code 120
+		const uint32_t opaque_a = (hdrf & 2u) ? 120u : 255u;
 		bool diff = false, alpha = false, colour = false;
 		uint32_t s01 = 0, s23 = 0, m00 = 0, m01 = 0, m02 = 0, m03 = 0, m11 = 0, m12 = 0, m13 = 0, m22 = 0, m23 = 0, m33 = 0;
 		for (uint32_t i = hl; i < n; i += gsz) {
 			const uint32_t p = tp[i];
 			diff = diff || p != p0;
-			alpha = alpha || (p >> 24) != 255u;
+			alpha = alpha || (p >> 24) != opaque_a;
 			const uint32_t c0 = p & 255u, c1 = (p >> 8) & 255u, c2 = (p >> 16) & 255u;
 			colour = colour || c0 != c1 || c0 != c2;
 		}
@@ -473,7 +565,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		const bool grey = (pair ? (uint32_t)(h ? cbal >> 32 : cbal) : (uint32_t)(cbal | (cbal >> 32))) == 0u;
 		if (solid && hl == 0u) {
 			const uint32_t r = p0 & 255u, g = (p0 >> 8) & 255u, bl = (p0 >> 16) & 255u, a = p0 >> 24;
-			outb[b] = make_uint4(0xFFFFFDFCu, 0xFFFFFFFFu, (r*257u) | ((g*257u) << 16), (bl*257u) | ((a*257u) << 16));
+			outb[b] = void_extent(r, g, bl, a, hdrf);
 		}
 		if (__ballot(!solid) == 0ull)
 			continue;
@@ -1052,7 +1144,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 #pragma unroll
 					for (int o = 0; o < 3; ++o) {
 						const uint32_t nv = (has_alpha ? 8u : 6u) - 2u*(uint32_t)o;
-						okk[o] = !(nv*P > 18u || (o == 2 && !grey) || (o > 0 && dual && ccs < 3u));
+						okk[o] = !(nv*P > 18u || (o == 2 && !grey) || (o > 0 && dual && ccs < 3u) || (o > 0 && hdrf));
 						lvs[o] = okk[o] ? (int)clevel[(nv*P/2u)*132u + cfg.cbits] : -1;
 						okk[o] = okk[o] && lvs[o] >= 0;
 					}
@@ -1064,7 +1156,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 #pragma unroll
 						for (int o = 0; o < 3; ++o)
 							if (okk[o])
-								okk[o] = cem_option(sh, o, (uint32_t)lvs[o], has_alpha, r0, r1, cA, cB, cC, cw, est[o], d0p, d1p, vals);
+								okk[o] = cem_option(sh, o, (uint32_t)lvs[o], has_alpha, hdrf, r0, r1, cA, cB, cC, cw, est[o], d0p, d1p, vals);
 					}
 					float best_est = 3.0e38f;
 					int best_opt = -1;
@@ -1082,7 +1174,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							solve(p, r0, r1, cA, cB, cC);
 							float e_ = 0.0f;
 							uint32_t d0p = 0, d1p = 0, vals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-							cem_option(sh, best_opt, best_lv, has_alpha, r0, r1, cA, cB, cC, cw, e_, d0p, d1p, vals);
+							cem_option(sh, best_opt, best_lv, has_alpha, hdrf, r0, r1, cA, cB, cC, cw, e_, d0p, d1p, vals);
 #pragma unroll
 							for (uint32_t k = 0; k < 4u; ++k) {
 								D0[k] = p == k ? d0p : D0[k];
@@ -1127,7 +1219,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 								if (c < nc) {
 									const uint32_t wi = (dual && c == ccs) ? w1 : w0;
 									const uint32_t ea0 = (q0 >> (8u*c)) & 255u, eb0 = (q1 >> (8u*c)) & 255u;
-									const int v = (int)(((ea0*257u*(64u - wi) + eb0*257u*wi + 32u) >> 6) >> 8);
+									// LDR: 8-bit endpoints expand by 257; an HDR channel's endpoint e is the LNS value
+									// e << 8 and the error is taken on the top 8 bits of the interpolated value
+									const uint32_t xw = ea0*(64u - wi) + eb0*wi;
+									const int v = (hdrf && (c < 3u || (hdrf & 2u))) ? (int)((xw + 32u) >> 6) : (int)((257u*xw + 32u) >> 14);
 									const int dd_ = v - (int)((p >> (8u*c)) & 255u);
 									if (c < 3u) ergb += cw[c]*(uint32_t)(dd_*dd_);
 									else ea = cw[3]*(uint32_t)(dd_*dd_);
@@ -1137,7 +1232,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							e64 += (unsigned long long)ergb*wa + (unsigned long long)ea*255ull;
 						}
 						err = e64;
-						r_cem = (has_alpha ? 12u : 8u) - (best_opt == 1 ? 2u : (best_opt == 2 ? 8u : 0u));
+						r_cem = hdrf ? (has_alpha ? ((hdrf & 2u) ? 15u : 14u) : 11u)
+							: (has_alpha ? 12u : 8u) - (best_opt == 1 ? 2u : (best_opt == 2 ? 8u : 0u));
 						r_lv = best_lv;
 						r_ncv = nv*P;
 					}
@@ -1180,8 +1276,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 #pragma unroll
 					for (int c = 0; c < 4; ++c)
 						cavg[c] = (uint32_t)((2*sum[c] + (int)n)/(2*(int)n));
-					if (nc == 3u) cavg[3] = 255u;
-					outb[b] = make_uint4(0xFFFFFDFCu, 0xFFFFFFFFu, (cavg[0]*257u) | ((cavg[1]*257u) << 16), (cavg[2]*257u) | ((cavg[3]*257u) << 16));
+					if (nc == 3u) cavg[3] = opaque_a;
+					outb[b] = void_extent(cavg[0], cavg[1], cavg[2], cavg[3], hdrf);
 				}
 			} else if (!solid) {
 				const uint32_t d = S.best[0], meta = S.best[1];
@@ -1260,7 +1356,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 }
 
 // dynamic LDS of a launch for this footprint (same carve-up as in the kernel)
-static size_t astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality, uint32_t nwaves, bool wcached)
+static size_t astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality, uint32_t nwaves, bool wcached, bool hdr)
 {
 	const uint32_t n = h->n, ngrids = h->ngrids, npad = h->npad;
 	uint32_t off = nwaves*4u*n*4u;
@@ -1268,7 +1364,7 @@ static size_t astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality, 
 	off += ngrids*n*4u; off = (off + 15u) & ~15u;
 	off += ngrids*128u;
 	off += (ngrids*4u + 15u) & ~15u;
-	off += 2u*17u*256u + 1216u;
+	off += (hdr ? 3u : 2u)*17u*256u + 1216u;
 	const uint32_t wc_rows = wcached ? 2u*((n + 3u)/4u) : 0u;
 	const uint32_t slot_bytes = ((10u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
 	const uint32_t wave_bytes = ((((h->col_rows + 1u)/2u)*256u + wc_rows*256u + 15u) & ~15u) + (quality <= 2u ? 2u : 1u)*slot_bytes;
@@ -1279,7 +1375,7 @@ static size_t astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality, 
 // 4 blocks per wave of one block row) and whether the texel-weight cache rows are carved.  The
 // choice maximises the waves resident on a CU (12 = three per SIMD with the 168-register build,
 // else 8), then prefers the cache, then the smaller workgroup (finer scheduling grain).
-extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t quality, uint32_t* nwaves, uint32_t* wcached, size_t* lds_bytes)
+extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t quality, uint32_t hdr, uint32_t* nwaves, uint32_t* wcached, size_t* lds_bytes)
 {
 	const size_t cu_lds = 160u*1024u, wg_max = 160u*1024u - 1024u;
 	const bool can_cache = h->n <= 36u;
@@ -1291,7 +1387,7 @@ extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t qualit
 		for (uint32_t nw = 4; nw <= 12u; nw += 4u) {
 			if (force && (uint32_t)atoi(force) != nw)
 				continue;
-			const size_t b = astc_lds_bytes(h, quality, nw, c != 0u);
+			const size_t b = astc_lds_bytes(h, quality, nw, c != 0u, hdr != 0u);
 			if (b > wg_max)
 				continue;
 			uint32_t w = (uint32_t)(cu_lds/(b + 1024u))*nw;      // 1024: the static outb + allocation granule
@@ -1303,7 +1399,7 @@ extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t qualit
 	}
 	*nwaves = best_nw;
 	*wcached = best_c;
-	*lds_bytes = astc_lds_bytes(h, quality, best_nw, best_c != 0u);
+	*lds_bytes = astc_lds_bytes(h, quality, best_nw, best_c != 0u, hdr != 0u);
 }
 
 extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, uint32_t nwaves, size_t lds_bytes, hipStream_t stream)

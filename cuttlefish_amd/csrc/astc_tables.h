@@ -13,7 +13,8 @@
 //   den     : ngrids x 64 x u16  per-grid-point factor sums
 //   cfg     : [5 classes][2 alpha][64] x AstcCfgRec (16 B), ncfg[10]
 //   part    : for P = 2, 3, 4: seeds u16[npart], masks u64[npart][4][3], ids u8[npart][npad]
-//   ctab    : colour unquant u8[17][256] then nearest-index u8[17][256]
+//   ctab    : colour unquant u8[17][256], nearest-index u8[17][256], then (HDR direct sub-mode) the
+//             nearest index among the values with bit 7 set, by decoded value (u & 0x7F) << 1, u8[17][256]
 //   wtab    : weight unquant u8[12][32] then nearest-index u8[12][68]
 //   clevel  : i8[10][132]   highest colour range for (values / 2, bits)
 //   ise     : trit_enc u8[256], quint_enc u8[128], wq descr u8[12][4], cq descr u8[17][4]
@@ -416,7 +417,7 @@ inline std::vector<uint8_t> build_blob(int bw, int bh)
 		h.off_mask[t] = (uint32_t)off; off = align16(off + masks[t].size()*8);
 		h.off_ids[t] = (uint32_t)off; off = align16(off + ids[t].size());
 	}
-	h.off_ctab = (uint32_t)off; off = align16(off + 2*17*256);
+	h.off_ctab = (uint32_t)off; off = align16(off + 3*17*256);
 	h.off_wtab = (uint32_t)off; off = align16(off + 12*32 + 12*68);
 	h.off_clevel = (uint32_t)off; off = align16(off + 10*132);
 	h.off_ise = (uint32_t)off; off = align16(off + 256 + 128 + 12*4 + 17*4);
@@ -449,6 +450,19 @@ inline std::vector<uint8_t> build_blob(int bw, int bh)
 					if (d < bd || (d == bd && u < bu)) { bd = d; bu = u; best = v; }
 				}
 				near[r*256 + w] = (uint8_t)best;
+			}
+			// HDR direct sub-mode (CEM 11 / 14 / 15): blue and HDR alpha are stored as 0x80 | 7 bits
+			uint8_t* near_hi = near + 17*256;
+			for (int w = 0; w < 256; ++w) {
+				int best = 0, bd = 1000, bu = 1000;
+				for (int v = 0; v < CQ[r].levels; ++v) {
+					const int u = unq[r*256 + v];
+					if (u < 128)
+						continue;
+					const int dec = (u & 0x7F) << 1, d = dec > w ? dec - w : w - dec;
+					if (d < bd || (d == bd && u < bu)) { bd = d; bu = u; best = v; }
+				}
+				near_hi[r*256 + w] = (uint8_t)best;
 			}
 		}
 		uint8_t* wunq = blob.data() + h.off_wtab;

@@ -24,7 +24,7 @@
 extern "C" hipError_t cfhip_launch_bc7(const cf_kparams* kp, int pixel_type, int unit_weights,
 	hipStream_t stream);
 extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, uint32_t nwaves, size_t lds_bytes, hipStream_t stream);
-extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t quality, uint32_t* nwaves, uint32_t* wcached, size_t* lds_bytes);
+extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t quality, uint32_t hdr, uint32_t* nwaves, uint32_t* wcached, size_t* lds_bytes);
 extern "C" hipError_t cfhip_launch_etc(const cf_kparams* kp, int format, int pixel_type, int snorm,
 	hipStream_t stream);
 extern "C" hipError_t cfhip_launch_bc6h(const cf_kparams* kp, int pixel_type, int is_signed,
@@ -223,11 +223,10 @@ bool format_implemented(int format, int type)
 {
 	if (is_std_format(format))
 		return true;
-	// ASTC UFloat (the HDR profile, AstcConverter.cpp:150-162) is a legal pair (cfhip_query
-	// answers it) but is REFUSED here until the HDR endpoint modes exist: encoding it with the
-	// LDR modes would clamp the data to [0, 1] silently.  The adapter falls back to astcenc.
+	// ASTC: UNorm = the LDR profile; UFloat = the HDR profiles (AstcConverter.cpp:150-162), encoded
+	// with the HDR endpoint modes 11 / 14 / 15 in their direct sub-mode (csrc/astc_encode.hip)
 	if (format >= CFHIP_FORMAT_ASTC_4x4 && format <= CFHIP_FORMAT_ASTC_12x12)
-		return type == CFHIP_TYPE_UNORM;
+		return type == CFHIP_TYPE_UNORM || type == CFHIP_TYPE_UFLOAT;
 	switch (format) {
 		case CFHIP_FORMAT_BC1_RGB:
 		case CFHIP_FORMAT_BC1_RGBA:
@@ -367,7 +366,7 @@ int blocks_per_wg(cfhip_ctx* ctx, const cfhip_params& p, uint32_t quality, uint3
 			return rc;
 		uint32_t nwaves, wcached;
 		size_t lds_bytes;
-		cfhip_astc_plan(&ctx->astc_hdr[p.format], quality, &nwaves, &wcached, &lds_bytes);
+		cfhip_astc_plan(&ctx->astc_hdr[p.format], quality, p.type == CFHIP_TYPE_UFLOAT ? 1u : 0u, &nwaves, &wcached, &lds_bytes);
 		*out = nwaves*4u;
 	}
 	return CFHIP_OK;
@@ -399,16 +398,19 @@ int launch(cfhip_ctx* ctx, const cf_kparams& kp, const cfhip_params& p, int pixe
 		case CFHIP_FORMAT_ASTC_10x6: case CFHIP_FORMAT_ASTC_10x8: case CFHIP_FORMAT_ASTC_10x10:
 		case CFHIP_FORMAT_ASTC_12x10: case CFHIP_FORMAT_ASTC_12x12: {
 			if (pixel_type != CFHIP_PIXEL_RGBA8 && pixel_type != CFHIP_PIXEL_RGBA32F)
-				return fail(ctx, CFHIP_E_UNSUPPORTED, "ASTC LDR takes RGBA8 or RGBA32F pixels");
+				return fail(ctx, CFHIP_E_UNSUPPORTED, "ASTC takes RGBA8 or RGBA32F pixels");
 			const int trc = astc_prepare(ctx, p.format);
 			if (trc != CFHIP_OK)
 				return trc;
 			uint32_t nwaves, wcached;
 			size_t lds_bytes;
-			cfhip_astc_plan(&ctx->astc_hdr[p.format], kp.quality, &nwaves, &wcached, &lds_bytes);
+			const uint32_t hdr = p.type == CFHIP_TYPE_UFLOAT ? 1u : 0u;
+			// HDR profile (AstcConverter.cpp:150-162): HDR_RGB_LDR_A for Alpha::None / PreMultiplied, HDR otherwise
+			const uint32_t hdr_alpha = hdr && !(p.alpha == CFHIP_ALPHA_NONE || p.alpha == CFHIP_ALPHA_PREMULTIPLIED) ? 1u : 0u;
+			cfhip_astc_plan(&ctx->astc_hdr[p.format], kp.quality, hdr, &nwaves, &wcached, &lds_bytes);
 			cf_kparams k2 = kp;
 			k2.aux = ctx->astc_tables[p.format];
-			k2.flags |= wcached << 18;
+			k2.flags |= (wcached << 18) | (hdr << 19) | (hdr_alpha << 20);
 			// ASTCENC_FLG_USE_ALPHA_WEIGHT for Alpha::Standard / PreMultiplied, USE_PERCEPTUAL for sRGB
 			// images (AstcConverter.cpp:163-172)
 			k2.flags |= ((p.alpha == CFHIP_ALPHA_STANDARD || p.alpha == CFHIP_ALPHA_PREMULTIPLIED) ? 1u << 16 : 0u) |

@@ -31,6 +31,7 @@ typedef struct {
 	/* colours: unquantised 8-bit value of each ISE value; nearest ISE value for a target 0..255 */
 	uint8_t c_unq[ASTC_NCQ][256];
 	uint8_t c_near[ASTC_NCQ][256];
+	uint8_t c_near_hi[ASTC_NCQ][256];   /* HDR direct sub-mode: nearest index among values with bit 7 set, see astc_tables.c */
 	/* ISE: T byte for 5 trits (index t0+3t1+9t2+27t3+81t4), Q for 3 quints (q0+5q1+25q2), and back */
 	uint8_t trit_enc[243], quint_enc[125];
 	uint8_t trit_dec[256][5], quint_dec[128][3];

@@ -34,6 +34,8 @@
 
 #define ASTC_FLAG_ALPHA_WEIGHT 1
 #define ASTC_FLAG_PERCEPTUAL 2
+#define ASTC_FLAG_HDR 4            /* HDR profile: the colour channels are 8-bit LNS codes (cfo_astc_hdr_code) */
+#define ASTC_FLAG_HDR_ALPHA 8      /* ASTCENC_PRF_HDR: alpha is an LNS code too (else LDR alpha, PRF_HDR_RGB_LDR_A) */
 #define ASTC_MAX_CFG 200       /* array bound; a class lists at most 64 (200 only in the census build) */
 #define ASTC_LIST_CFG 64       /* configs listed per class; K of them are tried per candidate */
 #define ASTC_MAX_GRIDS 128     /* array bound; 24 distinct grids per footprint (all in the census build) */
@@ -249,6 +251,7 @@ typedef struct {
 typedef struct {
 	const astc_fmt* f;
 	int n, nc, has_alpha, grey, flags;
+	int hdr, hdr_alpha;                 /* HDR profile (colour channels are LNS codes), HDR alpha */
 	int px[ASTC_MAX_TEXELS][4];
 	int cw[4];                          /* channel weights of the error metric */
 	int wa[ASTC_MAX_TEXELS];            /* texel weight of the RGB error (alpha or 255) */
@@ -467,6 +470,15 @@ static int quant_c(const astc_tables* T, int lv, float x, int* stored)
 
 /* quadratic estimate of the error an endpoint pair (D0, D1) adds over the least-squares pair
  * (r0, r1) of one channel: (A d0^2 + 2 B d0 d1 + C d1^2) */
+/* HDR direct sub-mode: the blue / HDR alpha endpoint goes through the values with bit 7 set and
+ * decodes to (u & 0x7F) << 1 */
+static int quant_hi(const astc_tables* T, int lv, float x, int* stored)
+{
+	int xi = (int)floorf(clampf255(x) + 0.5f);
+	*stored = T->c_near_hi[lv][xi];
+	return (T->c_unq[lv][*stored] & 0x7F) << 1;
+}
+
 static float quad_est(float fA, float fB, float fC, float d0, float d1)
 {
 	float t = fA*d0;
@@ -559,13 +571,15 @@ static void phase_b(const astc_blk* b, int j, const astc_pc* pc, const astc_cfg*
 	 * decided per partition), 1 = base + scale (6 / 10), 2 = luminance (0 / 4) */
 	int nvo[3] = {b->has_alpha ? 8 : 6, b->has_alpha ? 6 : 4, b->has_alpha ? 4 : 2};
 	int cemo[3] = {b->has_alpha ? 12 : 8, b->has_alpha ? 10 : 6, b->has_alpha ? 4 : 0};
+	if (b->hdr)     /* HDR RGB direct (11), + LDR alpha (14), + HDR alpha (15); no other option */
+		cemo[0] = b->has_alpha ? (b->hdr_alpha ? 15 : 14) : 11;
 	float best_est = 3.0e38f;
 	int best_opt = -1;
 	int D0[3][4][4], D1[3][4][4];
 	uint8_t cv[3][18];
 	for (int o = 0; o < 3; ++o) {
 		int nv = nvo[o];
-		if (nv*P > 18 || (o == 2 && !b->grey) || (o > 0 && pc->dual && pc->ccs < 3))
+		if (nv*P > 18 || (o == 2 && !b->grey) || (o > 0 && pc->dual && pc->ccs < 3) || (o > 0 && b->hdr))
 			continue;
 		int lv = T->c_level[nv*P/2][cfg->cbits];
 		if (lv < 0 || cfg->cbits < (13*nv*P + 4)/5)
@@ -581,7 +595,38 @@ static void phase_b(const astc_blk* b, int j, const astc_pc* pc, const astc_cfg*
 			int cset[4];
 			for (int c = 0; c < 4; ++c)
 				cset[c] = pc->dual ? (c == pc->ccs) : p;
-			if (o == 0) {
+			if (o == 0 && b->hdr) {
+				/* HDR direct sub-mode (major component 3): v0..v3 = the top 8 bits of the red and
+				 * green LNS endpoints, v4, v5 = 0x80 | the top 7 bits of blue; no ordering rule, no
+				 * blue contraction.  Alpha: two LDR values (14) or 0x80 | 7 bits like blue (15) */
+				for (int c = 0; c < 3; ++c) {
+					int s0, s1;
+					if (c < 2) {
+						d0[c] = quant_c(T, lv, r0[p][c], &s0);
+						d1[c] = quant_c(T, lv, r1[p][c], &s1);
+					} else {
+						d0[c] = quant_hi(T, lv, r0[p][c], &s0);
+						d1[c] = quant_hi(T, lv, r1[p][c], &s1);
+					}
+					vals[2*c] = (uint8_t)s0; vals[2*c + 1] = (uint8_t)s1;
+					est = fmaf((float)b->cw[c], quad_est(fA[cset[c]], fB[cset[c]], fC[cset[c]],
+						(float)d0[c] - r0[p][c], (float)d1[c] - r1[p][c]), est);
+				}
+				d0[3] = 255; d1[3] = 255;
+				if (b->has_alpha) {
+					int s6, s7;
+					if (b->hdr_alpha) {
+						d0[3] = quant_hi(T, lv, r0[p][3], &s6);
+						d1[3] = quant_hi(T, lv, r1[p][3], &s7);
+					} else {
+						d0[3] = quant_c(T, lv, r0[p][3], &s6);
+						d1[3] = quant_c(T, lv, r1[p][3], &s7);
+					}
+					vals[6] = (uint8_t)s6; vals[7] = (uint8_t)s7;
+					est = fmaf((float)b->cw[3], quad_est(fA[aset], fB[aset], fC[aset],
+						(float)d0[3] - r0[p][3], (float)d1[3] - r1[p][3]), est);
+				}
+			} else if (o == 0) {
 				/* direct */
 				int dd0[4], dd1[4], sd0 = 0, sd1 = 0;
 				for (int c = 0; c < 3; ++c) {
@@ -698,7 +743,11 @@ static void phase_b(const astc_blk* b, int j, const astc_pc* pc, const astc_cfg*
 		uint32_t ergb = 0, ea = 0;
 		for (int c = 0; c < b->nc; ++c) {
 			int wi = w[(pc->dual && c == pc->ccs) ? 1 : 0][i];
-			int v = ((D0[best_opt][p][c]*257*(64 - wi) + D1[best_opt][p][c]*257*wi + 32) >> 6) >> 8;
+			/* LDR: 8-bit endpoints expand by 257; an HDR channel's endpoint e is the 16-bit LNS value
+			 * e << 8 (blue, HDR alpha: even e), and the error is taken on the top 8 bits of the
+			 * interpolated LNS value, rounded */
+			int x = D0[best_opt][p][c]*(64 - wi) + D1[best_opt][p][c]*wi;
+			int v = (b->hdr && (c < 3 || b->hdr_alpha)) ? (x + 32) >> 6 : (257*x + 32) >> 14;
 			int d = v - b->px[i][c];
 			if (c < 3) ergb += (uint32_t)(b->cw[c]*d*d);
 			else ea = (uint32_t)(b->cw[3]*d*d);
@@ -847,6 +896,55 @@ static void void_extent(const int c[4], uint8_t out[16])
 	}
 }
 
+/* ---- HDR profile: 8-bit LNS codes ----
+ * ASTC interpolates HDR endpoints as 16-bit "LNS" integers (5 exponent + 11 mantissa bits, a
+ * piecewise-linear log2) and converts the result to half (specification; oracle/astc_decode.c
+ * lns_to_half).  This encoder searches HDR blocks in the top 8 bits of that domain: a texel
+ * channel becomes code = round(LNS16(half(x)) / 256), the search is the LDR search on those
+ * bytes, and the endpoints leave through the direct sub-mode of CEM 11 / 14 / 15, which stores
+ * exactly such 8-bit (blue, HDR alpha: 7-bit) values.  Errors are therefore log-domain errors. */
+int cfo_astc_lns16(uint16_t h)
+{
+	int e = h >> 10, m10 = h & 1023, m;
+	if (m10 < 192) m = (8*m10 + 1)/3;              /* inverse of mt = 3 m (m < 512) */
+	else if (m10 < 704) m = 2*m10 + 128;            /* mt = 4 m - 512 */
+	else m = (8*m10 + 2048 + 2)/5;                  /* mt = 5 m - 2048 */
+	if (m > 2047) m = 2047;
+	return (e << 11) | m;
+}
+
+int cfo_astc_hdr_code(float x)
+{
+	if (!(x > 0.0f))                                /* negative, zero, NaN */
+		return 0;
+	uint16_t h = cfo_float_to_half(x > 65504.0f ? 65504.0f : x);
+	if (h > 0x7BFF) h = 0x7BFF;
+	int c = (cfo_astc_lns16(h) + 128) >> 8;
+	return c > 255 ? 255 : c;
+}
+
+static uint16_t lns_code_to_half(int code)
+{
+	int c = code << 8, e = c >> 11, m = c & 0x7FF, mt;
+	if (m < 512) mt = 3*m;
+	else if (m < 1536) mt = 4*m - 512;
+	else mt = 5*m - 2048;
+	int h = (e << 10) + (mt >> 3);
+	return (uint16_t)(h > 0x7BFF ? 0x7BFF : h);
+}
+
+/* HDR void extent: bit 9 of the header set, four halves */
+static void void_extent_hdr(const int c[4], int hdr_alpha, uint8_t out[16])
+{
+	static const uint8_t hdr[8] = {0xFC, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF};
+	memcpy(out, hdr, 8);
+	for (int k = 0; k < 4; ++k) {
+		uint16_t h = (k < 3 || hdr_alpha) ? lns_code_to_half(c[k]) : cfo_float_to_half((float)c[k]*(1.0f/255.0f));
+		out[8 + 2*k] = (uint8_t)(h & 255);
+		out[8 + 2*k + 1] = (uint8_t)(h >> 8);
+	}
+}
+
 /* px: bw*bh texels RGBA u8 (swizzled, edge-replicated) */
 void cfo_encode_astc_block(const int px[][4], int bw, int bh, int quality, int flags, uint8_t out[16])
 {
@@ -855,15 +953,22 @@ void cfo_encode_astc_block(const int px[][4], int bw, int bh, int quality, int f
 	int n = bw*bh, solid = 1;
 	memset(out, 0, 16);
 	b->f = f; b->n = n; b->flags = flags; b->has_alpha = 0; b->grey = 1;
+	b->hdr = (flags & ASTC_FLAG_HDR) != 0;
+	b->hdr_alpha = b->hdr && (flags & ASTC_FLAG_HDR_ALPHA) != 0;
+	/* the alpha a block without an alpha endpoint decodes to: 1.0 = 255 (UNORM) or LNS code 120 */
+	const int opaque = b->hdr_alpha ? 120 : 255;
 	for (int i = 0; i < n; ++i) {
 		memcpy(b->px[i], px[i], sizeof(b->px[i]));
 		if (memcmp(px[i], px[0], 4*sizeof(int)) != 0) solid = 0;
-		if (px[i][3] != 255) b->has_alpha = 1;
+		if (px[i][3] != opaque) b->has_alpha = 1;
 		if (px[i][0] != px[i][1] || px[i][0] != px[i][2]) b->grey = 0;
 		b->wa[i] = (flags & ASTC_FLAG_ALPHA_WEIGHT) ? px[i][3] : 255;
 	}
 	if (solid) {
-		void_extent(px[0], out);
+		if (b->hdr)
+			void_extent_hdr(px[0], b->hdr_alpha, out);
+		else
+			void_extent(px[0], out);
 		free(b);
 		return;
 	}

@@ -171,6 +171,20 @@ static void build_tables(void)
 			}
 			t->c_near[r][w] = (uint8_t)best;
 		}
+		/* HDR endpoint modes 11 / 14 / 15 in their direct sub-mode store the blue (and HDR alpha)
+		 * endpoint as 0x80 | b7, b7 = the top 7 bits of the 16-bit LNS value: an 8-bit target w is
+		 * reached through the stored values u >= 128, which decode to (u & 0x7F) << 1 */
+		for (int w = 0; w < 256; ++w) {
+			int best = 0, bd = 1000, bu = 1000;
+			for (int v = 0; v < L; ++v) {
+				int u = t->c_unq[r][v];
+				if (u < 128)
+					continue;
+				int dec = (u & 0x7F) << 1, d = dec > w ? dec - w : w - dec;
+				if (d < bd || (d == bd && u < bu)) { bd = d; bu = u; best = v; }
+			}
+			t->c_near_hi[r][w] = (uint8_t)best;
+		}
 	}
 	memset(t->trit_enc, 0xFF, sizeof(t->trit_enc));
 	memset(t->quint_enc, 0xFF, sizeof(t->quint_enc));

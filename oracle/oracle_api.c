@@ -25,6 +25,8 @@ int cfo_encode_etc_block(const float rgbaf[64], const uint8_t rgba[64], unsigned
 void cfo_decode_etc_rgb(const uint8_t* blk, int a1, uint8_t* rgba64);
 int cfo_astc_footprint(int format, int* bw, int* bh);
 void cfo_encode_astc_block(const int px[][4], int bw, int bh, int quality, int flags, uint8_t out[16]);
+int cfo_astc_hdr_code(float x);
+int cfo_decode_astc_block_hdr(const uint8_t* blk, int bw, int bh, uint16_t* rgba_half);
 int cfo_decode_astc_block(const uint8_t* blk, int bw, int bh, uint8_t* rgba);
 void cfo_decode_eac(const uint8_t* blk, int kind, int* out16);
 int cfo_decode_bc6h(const uint8_t* blk, int flags, uint16_t* rgb48);
@@ -147,6 +149,9 @@ static void* worker(void* arg)
 			 * swizzle from the colour mask / alpha type (:140-149); LDR path quantises to
 			 * UNORM8 like toColorBlock */
 			int apx[144][4];
+			/* Type::UFloat = the HDR profiles (AstcConverter.cpp:150-162): HDR_RGB_LDR_A for
+			 * Alpha::None / PreMultiplied, HDR otherwise; texels become 8-bit LNS codes */
+			const int hdr = j->p->type == 4, hdr_alpha = hdr && !(j->p->alpha == 0 || j->p->alpha == 2);
 			for (uint32_t r = 0; r < j->bh; ++r) {
 				uint32_t sy = y*j->bh + r;
 				if (sy > j->height - 1) sy = j->height - 1;
@@ -156,12 +161,19 @@ static void* worker(void* arg)
 					if (sx > j->width - 1) sx = j->width - 1;
 					int* o = apx[r*j->bw + c];
 					for (int k = 0; k < 4; ++k) {
-						if (j->pixel_type == CFO_PIX_RGBA8)
+						float fv;
+						if (j->pixel_type == CFO_PIX_RGBA8) {
 							o[k] = row[sx*4 + k];
-						else if (j->pixel_type == CFO_PIX_RGBA32F)
-							o[k] = unorm8(((const float*)(row + (size_t)sx*16))[k]);
-						else
-							o[k] = unorm8(half_to_float(((const uint16_t*)(row + (size_t)sx*8))[k]));
+							fv = (float)o[k]*(1.0f/255.0f);
+						} else if (j->pixel_type == CFO_PIX_RGBA32F) {
+							fv = ((const float*)(row + (size_t)sx*16))[k];
+							o[k] = unorm8(fv);
+						} else {
+							fv = half_to_float(((const uint16_t*)(row + (size_t)sx*8))[k]);
+							o[k] = unorm8(fv);
+						}
+						if (hdr && (k < 3 || hdr_alpha))
+							o[k] = cfo_astc_hdr_code(fv);
 					}
 					for (int k = 0; k < 3; ++k)
 						if (!j->p->mask[k]) o[k] = 0;
@@ -171,7 +183,8 @@ static void* worker(void* arg)
 			}
 			/* ASTCENC_FLG_USE_ALPHA_WEIGHT for Alpha::Standard / PreMultiplied, USE_PERCEPTUAL for
 			 * sRGB images (AstcConverter.cpp:163-172) */
-			int aflags = ((j->p->alpha == 1 || j->p->alpha == 2) ? 1 : 0) | (j->p->color_space == 1 ? 2 : 0);
+			int aflags = ((j->p->alpha == 1 || j->p->alpha == 2) ? 1 : 0) | (j->p->color_space == 1 ? 2 : 0) |
+				(hdr ? 4 : 0) | (hdr_alpha ? 8 : 0);
 			cfo_encode_astc_block((const int (*)[4])apx, (int)j->bw, (int)j->bh, j->p->quality, aflags, dst);
 			continue;
 		}
@@ -341,6 +354,29 @@ int cfo_decode_astc_image(int format, const void* blocks, uint32_t width, uint32
 				for (uint32_t i = 0; i < (uint32_t)bw && x*(uint32_t)bw + i < width; ++i)
 					memcpy(rgba_out + (((size_t)y*(uint32_t)bh + j)*width + x*(uint32_t)bw + i)*4,
 						px + (j*(uint32_t)bw + i)*4, 4);
+		}
+	return bad;
+}
+
+/* Decode an ASTC payload under the HDR profile to RGBA16F (bit patterns); returns the number of
+ * blocks the decoder does not model (HDR sub-modes this backend never emits) or that are illegal. */
+int cfo_decode_astc_image_hdr(int format, const void* blocks, uint32_t width, uint32_t height,
+	uint16_t* rgba_half_out)
+{
+	int bw, bh, bad = 0;
+	if (cfo_astc_footprint(format, &bw, &bh) != 0)
+		return -1;
+	uint32_t bx = (width + (uint32_t)bw - 1)/(uint32_t)bw, by = (height + (uint32_t)bh - 1)/(uint32_t)bh;
+	const uint8_t* src = (const uint8_t*)blocks;
+	for (uint32_t y = 0; y < by; ++y)
+		for (uint32_t x = 0; x < bx; ++x) {
+			uint16_t px[144*4];
+			if (cfo_decode_astc_block_hdr(src + ((size_t)y*bx + x)*16, bw, bh, px) != 0)
+				++bad;
+			for (int j = 0; j < bh && y*(uint32_t)bh + (uint32_t)j < height; ++j)
+				for (int i = 0; i < bw && x*(uint32_t)bw + (uint32_t)i < width; ++i)
+					memcpy(rgba_half_out + (((size_t)y*(size_t)bh + (size_t)j)*width + x*(size_t)bw + (size_t)i)*4,
+						px + (j*bw + i)*4, 8);
 		}
 	return bad;
 }

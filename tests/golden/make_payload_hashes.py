@@ -27,6 +27,7 @@ CASES = [("BC1_RGB", 29, 0, "opaque"), ("BC1_RGBA", 30, 0, "cutout"), ("BC2", 31
          ("BC5_UNorm", 34, 0, "alpha"), ("BC5_SNorm", 34, 1, "float"), ("BC6H_UFloat", 35, 4, "hdr"),
          ("BC6H_Float", 35, 5, "hdr"), ("BC7", 36, 0, "alpha"), ("BC7_opaque", 36, 0, "opaque"),
          ("BC7_sRGB", 36, 0, "alpha"), ("ETC2_R8G8B8_sRGB", 38, 0, "opaque"),
+         ("ASTC_4x4_UFloat", 43, 4, "hdr32"), ("ASTC_6x6_UFloat", 47, 4, "hdr32"), ("ASTC_8x8_UFloat", 50, 4, "hdr32"),
          ("ETC1", 37, 0, "opaque"), ("ETC2_R8G8B8", 38, 0, "opaque"), ("ETC2_R8G8B8A1", 39, 0, "cutout"),
          ("ETC2_R8G8B8A8", 40, 0, "alpha"), ("EAC_R11_UNorm", 41, 0, "alpha"), ("EAC_R11_SNorm", 41, 1, "float"),
          ("EAC_R11G11_UNorm", 42, 0, "alpha"), ("EAC_R11G11_SNorm", 42, 1, "float")] + \
@@ -51,6 +52,8 @@ def image(kind):
         return np.ascontiguousarray(f)
     elif kind == "hdr":
         return synth.hdr_probe(W, H, seed=78)
+    elif kind == "hdr32":
+        return np.ascontiguousarray(synth.hdr_probe(W, H, seed=78).astype(np.float32))
     return np.ascontiguousarray(img)
 
 
@@ -66,6 +69,10 @@ def quality_metric(name, fmt, typ, img, payload):
         dec = O.decode_etc(payload, fmt, W, H)
     elif fmt in (41, 42):
         return None
+    elif fmt >= 43 and typ == 4:
+        dec = O.decode_astc_hdr(payload, fmt, W, H)[0].astype(np.float32)
+        e = np.log2(1 + np.abs(dec[..., :3])) - np.log2(1 + np.abs(img[..., :3].astype(np.float32)))
+        return round(float(10*np.log10(16.0**2/max(np.mean(e**2), 1e-12))), 3)
     elif fmt >= 43:
         dec, _ = O.decode_astc(payload, fmt, W, H)
     else:

@@ -135,6 +135,19 @@ def decode_astc(blocks: np.ndarray, fmt, width: int, height: int):
     return out, bad
 
 
+def decode_astc_hdr(blocks: np.ndarray, fmt, width: int, height: int):
+    """ASTC under the HDR profile -> ((h, w, 4) float16, blocks the decoder does not model)."""
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
+    out = np.zeros((height, width, 4), np.uint16)
+    L = lib()
+    L.cfo_decode_astc_image_hdr.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32,
+                                            ctypes.c_uint32, ctypes.c_void_p]
+    bad = L.cfo_decode_astc_image_hdr(int(fmt), blocks.ctypes.data, width, height, out.ctypes.data)
+    if bad < 0:
+        raise RuntimeError("cfo_decode_astc_image_hdr failed")
+    return out.view(np.float16), bad
+
+
 def decode_eac(blocks: np.ndarray, fmt, width: int, height: int, typ=0) -> np.ndarray:
     """EAC R11 / RG11 (fmt 41/42) -> (h, w, nch) int32 (0..2047 or -1023..1023)."""
     blocks = np.ascontiguousarray(blocks, dtype=np.uint8)

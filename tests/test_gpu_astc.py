@@ -54,7 +54,8 @@ def test_texture_convert_size_contract_and_type_legality(gpu_ctx):
     t = Texture(16, 16)
     t.set_image(img)
     assert not t.convert(Format.ASTC_6x6, Type.SNorm)      # createConverter -> nullptr
-    assert not t.convert(Format.ASTC_6x6, Type.UFloat)     # HDR profile: refused until the HDR endpoint modes exist
+    assert t.convert(Format.ASTC_6x6, Type.UFloat)         # HDR profile (tests/test_gpu_astc_hdr.py)
+    assert t.data_size() == 9 * 16
 
 
 def test_config3_full_size_properties_4096(gpu_ctx):

@@ -1,0 +1,79 @@
+"""ASTC HDR profiles on the GPU (Type::UFloat): byte parity with the oracle for float and 8-bit
+sources, both alpha profiles, every quality level and a spread of footprints; and the range check
+through the from-specification HDR decoder."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from cuttlefish_amd import Alpha, Format, Type, make_params, synth
+
+pytestmark = pytest.mark.gpu
+UF = Type.UFloat
+
+
+def _hdr_img(w, h, seed, alpha="one"):
+    rng = np.random.default_rng(seed)
+    img = synth.hdr_probe(w, h, seed=seed).astype(np.float32)
+    if alpha == "ldr":
+        img[..., 3] = rng.random((h, w)).astype(np.float32)
+    elif alpha == "hdr":
+        img[..., 3] = np.exp2(rng.random((h, w))*10.0 - 5.0).astype(np.float32)
+    # special values: negative, zero, NaN, Inf, beyond half range, denormal-sized
+    sp = rng.random((h, w, 4)) < 0.02
+    vals = rng.choice(np.array([-1.0, 0.0, np.nan, np.inf, 1.0e9, 6.0e-8, 65504.0], np.float32), (h, w, 4))
+    img = np.where(sp, vals, img).astype(np.float32)
+    if alpha == "one":
+        img[..., 3] = 1.0
+    return np.ascontiguousarray(img)
+
+
+@pytest.mark.parametrize("fmt", [Format.ASTC_4x4, Format.ASTC_5x5, Format.ASTC_6x6, Format.ASTC_8x6,
+                                 Format.ASTC_10x10, Format.ASTC_12x12])
+def test_hdr_bit_exact_footprints(gpu_ctx, fmt):
+    img = _hdr_img(70, 50, seed=int(fmt))
+    for q in (0, 2, 3):
+        want = O.encode(img, int(fmt), typ=int(UF), quality=q, threads=8, alpha=int(Alpha.None_))
+        got = gpu_ctx.encode([img], make_params(fmt, UF, q, alpha=Alpha.None_))[0]
+        assert np.array_equal(want, got), (fmt, q)
+
+
+@pytest.mark.parametrize("alpha,kind", [(Alpha.None_, "ldr"), (Alpha.PreMultiplied, "ldr"), (Alpha.Standard, "hdr"),
+                                        (Alpha.Encoded, "hdr"), (Alpha.Standard, "one")])
+def test_hdr_alpha_profiles_all_qualities(gpu_ctx, alpha, kind):
+    img = _hdr_img(66, 42, seed=31, alpha=kind)
+    for q in range(5):
+        want = O.encode(img, int(Format.ASTC_6x6), typ=int(UF), quality=q, threads=8, alpha=int(alpha))
+        got = gpu_ctx.encode([img], make_params(Format.ASTC_6x6, UF, q, alpha=alpha))[0]
+        assert np.array_equal(want, got), (alpha, kind, q)
+
+
+def test_hdr_from_rgba8_source_mask_and_srgb_flag(gpu_ctx):
+    from cuttlefish_amd import ColorSpace
+    img = synth.photo(44, 40, seed=3)
+    for mask in ((1, 1, 1, 1), (1, 0, 1, 1), (1, 1, 1, 0)):
+        for cs in (0, 1):
+            want = O.encode(img, int(Format.ASTC_8x8), typ=int(UF), quality=2, threads=4, alpha=1, mask=mask,
+                            color_space=cs)
+            got = gpu_ctx.encode([img], make_params(Format.ASTC_8x8, UF, 2, alpha=Alpha.Standard,
+                                                    color_mask=tuple(bool(m) for m in mask),
+                                                    color_space=ColorSpace(cs)))[0]
+            assert np.array_equal(want, got), (mask, cs)
+
+
+def test_hdr_range_and_batch(gpu_ctx):
+    base = _hdr_img(128, 96, seed=9)
+    chain = [np.ascontiguousarray(base[::1 << k, ::1 << k]) for k in range(5)]
+    outs = gpu_ctx.encode(chain, make_params(Format.ASTC_6x6, UF, 3, alpha=Alpha.None_))
+    for im, pay in zip(chain, outs):
+        want = O.encode(im, int(Format.ASTC_6x6), typ=int(UF), quality=3, threads=8, alpha=0)
+        assert np.array_equal(want, pay)
+    # quality on the clean probe (the speckles above are outliers no 6x6 block can follow)
+    clean = synth.hdr_probe(128, 96, seed=9).astype(np.float32)
+    pay = gpu_ctx.encode([clean], make_params(Format.ASTC_6x6, UF, 3, alpha=Alpha.None_))[0]
+    dec, bad = O.decode_astc_hdr(pay, int(Format.ASTC_6x6), 128, 96)
+    assert bad == 0
+    ref = clean[..., :3]
+    got = dec[..., :3].astype(np.float32)
+    a, b = np.log2(1 + ref.astype(np.float64)), np.log2(1 + got.astype(np.float64))
+    assert 10*np.log10(np.log2(65505.0)**2/np.mean((a - b)**2)) > 36.0
+    assert got.max() > 3.0e4

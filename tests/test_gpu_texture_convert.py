@@ -2,8 +2,7 @@
 823-985) run through the Texture mirror on the GPU: a 16x16 (0,0,0,1) RGBAF image converts to
 every (format, type) of the reference's instantiation lists and data_size() is
 blocksX*blocksY*blockSize; what createConverter rejects makes convert() return False; the sRGB
-gate of TextureTest.cpp:815-820.  ASTC UFloat (the HDR profile) is a legal pair that the backend
-REFUSES (CFHIP_E_UNSUPPORTED -> the adapter falls back to astcenc) until it has HDR endpoint modes."""
+gate of TextureTest.cpp:815-820.  ASTC UFloat (the HDR profiles) is encoded with HDR endpoint modes."""
 import numpy as np
 import pytest
 
@@ -18,7 +17,7 @@ COMPRESSED = [(Format.BC1_RGB, [U]), (Format.BC1_RGBA, [U]), (Format.BC2, [U]), 
               (Format.BC4, [U, S]), (Format.BC5, [U, S]), (Format.BC6H, [UF, F]), (Format.BC7, [U]),
               (Format.ETC1, [U]), (Format.ETC2_R8G8B8, [U]), (Format.ETC2_R8G8B8A1, [U]),
               (Format.ETC2_R8G8B8A8, [U]), (Format.EAC_R11, [U, S]), (Format.EAC_R11G11, [U, S])] + \
-             [(Format(v), [U]) for v in range(int(Format.ASTC_4x4), int(Format.ASTC_12x12) + 1)]
+             [(Format(v), [U, UF]) for v in range(int(Format.ASTC_4x4), int(Format.ASTC_12x12) + 1)]
 CASES = [(Format(f), Type(t)) for f, t in ALL_PAIRS] + [(f, t) for f, ts in COMPRESSED for t in ts]
 
 
@@ -72,13 +71,22 @@ def test_srgb_images_convert_only_to_formats_with_native_srgb():
         assert t.convert(fmt, U) == ok, fmt
 
 
-def test_astc_hdr_profile_request_is_refused_not_clamped():
+def test_astc_hdr_profile_request_keeps_the_range():
+    """Type::UFloat selects astcenc's HDR profiles (AstcConverter.cpp:150-162): values above 1 must
+    come back (round 1 clamped them, round 2 first refused the pair)."""
     rng = np.random.default_rng(4)
-    img = (rng.random((24, 36, 4)).astype(np.float32)*1.6 - 0.2)          # values below 0 and above 1
+    img = (rng.random((24, 36, 4)).astype(np.float32)*40.0 - 0.2)          # values below 0 and far above 1
     img[..., 3] = 1.0
     t = Texture(36, 24)
-    assert t.set_image(img) and not t.convert(Format.ASTC_6x6, UF)
-    assert not t.converted()
+    assert t.set_image(img) and t.convert(Format.ASTC_6x6, UF)
+    dec, bad = O.decode_astc_hdr(np.asarray(t.data()), int(Format.ASTC_6x6), 36, 24)
+    assert bad == 0
+    ref = np.maximum(img[..., :3], 0.0)
+    got = dec[..., :3].astype(np.float32)
+    assert got.max() > 30.0
+    big = ref > 1.0
+    assert np.median(np.abs(got[big] - ref[big])/ref[big]) < 0.08
+    assert np.all(dec[..., 3].astype(np.float32) == 1.0)
 
 
 def test_half_float_images_convert_to_every_block_format():

@@ -26,6 +26,7 @@ def main():
     ldr = torch.from_numpy(synth.photo(n, n, seed=1)).cuda()
     hdr = torch.from_numpy(synth.hdr_probe(n, n, seed=4).view(np.uint16).astype(np.int32)
                            .astype(np.uint16).view(np.int16)).cuda()
+    hdr32 = torch.from_numpy(synth.hdr_probe(n, n, seed=4).astype(np.float32)).cuda()
     ctx = Context(0)
     stream = torch.cuda.current_stream().cuda_stream
     rows = []
@@ -37,19 +38,22 @@ def main():
              (Format.ETC2_R8G8B8A1, Type.UNorm), (Format.ETC2_R8G8B8A8, Type.UNorm),
              (Format.EAC_R11, Type.UNorm), (Format.EAC_R11G11, Type.SNorm),
              (Format.ASTC_4x4, Type.UNorm), (Format.ASTC_6x6, Type.UNorm),
-             (Format.ASTC_8x8, Type.UNorm), (Format.ASTC_12x12, Type.UNorm)]
+             (Format.ASTC_8x8, Type.UNorm), (Format.ASTC_12x12, Type.UNorm),
+             (Format.ASTC_6x6, Type.UFloat)]
     if args.formats:
         want = set(args.formats.split(","))
         cases = [c for c in cases if c[0].name in want]
     quals = [int(q) for q in args.qualities.split(",")]
     for fmt, typ in cases:
         is_hdr = fmt == Format.BC6H
-        src = hdr if is_hdr else ldr
+        astc_hdr = fmt.name.startswith("ASTC") and typ == Type.UFloat      # HDR profile: RGBA32F source
+        src = hdr if is_hdr else (hdr32 if astc_hdr else ldr)
+        texel = 8 if is_hdr else (16 if astc_hdr else 4)
         nbytes = payload_size(fmt, typ, n, n)
         out = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
         surf = [{"pixels": src.data_ptr(), "pixel_type": PixelType.RGBA16F if is_hdr else
-                 PixelType.RGBA8, "width": n, "height": n,
-                 "row_pitch_bytes": n * (8 if is_hdr else 4), "out": out.data_ptr(),
+                 (PixelType.RGBA32F if astc_hdr else PixelType.RGBA8), "width": n, "height": n,
+                 "row_pitch_bytes": n * texel, "out": out.data_ptr(),
                  "out_capacity": nbytes}]
         for q in quals:
             p = make_params(fmt, typ, q)
@@ -60,7 +64,7 @@ def main():
                 ctx.encode_device(surf, p, stream)
             ms, launches = ctx.profile_end()
             ms /= launches
-            algo = n * n * (8 if is_hdr else 4) + nbytes
+            algo = n * n * texel + nbytes
             rows.append({"format": fmt.name, "type": typ.name, "quality": q,
                          "kernel_ms": round(ms, 3), "mpix_s": round(n * n / ms / 1e3, 1),
                          "algo_gb_s": round(algo / ms / 1e6, 3)})

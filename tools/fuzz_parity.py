@@ -48,7 +48,7 @@ def run(format_name, cases, seed, verbose=True):
     """-> number of mismatching cases"""
     import numpy as np
     import oracle_lib as O
-    from cuttlefish_amd import ColorSpace, Context, Format, Type, make_params
+    from cuttlefish_amd import Alpha, ColorSpace, Context, Format, Type, make_params
     fmt = Format[format_name]
     rng = np.random.default_rng(seed)
     bad = 0
@@ -76,6 +76,25 @@ def run(format_name, cases, seed, verbose=True):
                 k = int(rng.integers(0, 3))
                 img = f.astype(np.float16) if k == 0 else (f.astype(np.float32) if k == 1 else img)
                 cs, mask = 0, (1, 1, 1, 1)
+            elif fmt.name.startswith("ASTC") and rng.integers(0, 3) == 0:
+                # HDR profiles: float content over 18 stops with special values; alpha type picks
+                # ASTCENC_PRF_HDR_RGB_LDR_A (None / PreMultiplied) or ASTCENC_PRF_HDR
+                typ = Type.UFloat
+                f = np.exp2(img.astype(np.float32)/255.0*18.0 - 9.0)
+                sp = rng.random(f.shape) < 0.01
+                f = np.where(sp, rng.choice(np.array([0.0, -2.0, 65504.0, 1e9, 6e-8, np.inf], np.float32), f.shape), f)
+                alpha_t = int(rng.integers(0, 4))
+                if alpha_t in (0, 2):
+                    f[..., 3] = img[..., 3].astype(np.float32)/255.0
+                img = np.ascontiguousarray(f.astype(np.float32)) if rng.integers(0, 4) else img
+                ref = O.encode(img, int(fmt), int(typ), quality=q, threads=16, color_space=cs, mask=mask, alpha=alpha_t)
+                got = ctx.encode([img], make_params(fmt, typ, q, color_space=ColorSpace(cs), alpha=Alpha(alpha_t),
+                                                    color_mask=tuple(bool(m) for m in mask)))[0]
+                if not np.array_equal(ref, got):
+                    bad += 1
+                    if verbose:
+                        print("MISMATCH %s HDR case %d: %dx%d q%d cs%d mask%s alpha%d" % (fmt.name, case, w, h, q, cs, mask, alpha_t))
+                continue
             elif fmt in (Format.BC4, Format.BC5, Format.EAC_R11, Format.EAC_R11G11) and rng.integers(0, 2):
                 typ = Type.SNorm
                 cs = 0
