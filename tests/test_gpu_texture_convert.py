@@ -74,8 +74,9 @@ def test_srgb_images_convert_only_to_formats_with_native_srgb():
 def test_astc_hdr_profile_request_keeps_the_range():
     """Type::UFloat selects astcenc's HDR profiles (AstcConverter.cpp:150-162): values above 1 must
     come back (round 1 clamped them, round 2 first refused the pair)."""
-    rng = np.random.default_rng(4)
-    img = (rng.random((24, 36, 4)).astype(np.float32)*40.0 - 0.2)          # values below 0 and far above 1
+    from cuttlefish_amd import synth
+    img = synth.hdr_probe(36, 24, seed=4).astype(np.float32)*np.float32(4.0)   # up to 2.4e5: beyond half range
+    img[:4, :4, :3] = -0.5                                                      # and below zero
     img[..., 3] = 1.0
     t = Texture(36, 24)
     assert t.set_image(img) and t.convert(Format.ASTC_6x6, UF)
@@ -83,9 +84,9 @@ def test_astc_hdr_profile_request_keeps_the_range():
     assert bad == 0
     ref = np.maximum(img[..., :3], 0.0)
     got = dec[..., :3].astype(np.float32)
-    assert got.max() > 30.0
-    big = ref > 1.0
-    assert np.median(np.abs(got[big] - ref[big])/ref[big]) < 0.08
+    assert got.max() == 65504.0 and got[:4, :4].max() == 0.0
+    big = (ref > 1.0) & (ref < 6.0e4)
+    assert np.median(np.abs(got[big] - ref[big])/ref[big]) < 0.12
     assert np.all(dec[..., 3].astype(np.float32) == 1.0)
 
 
