@@ -56,7 +56,62 @@ __device__ __forceinline__ void bc4_palette(int a0, int a1, bool mode6, int e0, 
 	}
 }
 
-// tp: the block's 16 texel words in LDS; ch: byte holding the value; pre: 256 words of LDS
+// One endpoint pair of the BC4 search: error through the block's prefix table (see bc4_search).
+// mode6: the 6-value order (a0 <= a1, palette vmin, a0 .. a1, 255), else the 8-value order
+// (a0 > a1; dl moves the low endpoint a1, dh the high endpoint a0).  Returns false for an
+// invalid pair.
+__device__ __forceinline__ bool bc4_pair(const uint32_t* pre, uint32_t all, uint32_t sum2, bool mode6, int lo, int hi,
+	int lo6, int hi6, int vmin, int dl, int dh, int& a0, int& a1, uint32_t& err)
+{
+	uint32_t q[8];   // the palette in ascending order
+	bool valid;
+	if (!mode6) {
+		a1 = clampi(lo + dl, vmin, 255);
+		a0 = clampi(hi + dh, vmin, 255);
+		valid = a0 > a1;
+		q[0] = (uint32_t)a1;
+#pragma unroll
+		for (int j = 1; j < 7; ++j)   // pal[8-j] = (j*a0 + (7-j)*a1)/7
+			q[j] = div7((uint32_t)(j*a0 + (7 - j)*a1));
+		q[7] = (uint32_t)a0;
+	} else {
+		a0 = clampi(lo6 + dl, vmin, 255);
+		a1 = clampi(hi6 + dh, vmin, 255);
+		valid = a0 <= a1;
+		q[0] = (uint32_t)vmin;
+		q[1] = (uint32_t)a0;
+#pragma unroll
+		for (int k = 2; k < 6; ++k)
+			q[k] = div5((uint32_t)((6 - k)*a0 + (k - 1)*a1));
+		q[6] = (uint32_t)a1;
+		q[7] = 255u;
+	}
+	int e = (int)sum2;
+	uint32_t below = 0u;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		const uint32_t upto = k < 7 ? pre[(q[k] + q[k < 7 ? k + 1 : 7]) >> 1] : all;
+		const uint32_t seg = upto - below;   // n << 16 | s: both fields are monotone
+		below = upto;
+		const int n = (int)(seg >> 16), sk = (int)(seg & 0xFFFFu), qk = (int)q[k];
+		e += qk*(n*qk - 2*sk);
+	}
+	err = (uint32_t)e;
+	return valid;
+}
+
+// sum over the texels v <= x of (c - v)^2, from the count | sum table and the table of squares
+// (x = -1: no texel)
+__device__ __forceinline__ uint32_t bc4_sq_below(const uint32_t* pre, const uint32_t* pre2, int x, int c)
+{
+	if (x < 0)
+		return 0u;
+	const uint32_t ns = pre[x], s2 = pre2[x];
+	const int n = (int)(ns >> 16), sm = (int)(ns & 0xFFFFu);
+	return (uint32_t)((int)s2 - 2*c*sm + n*c*c);
+}
+
+// tp: the block's 16 texel words in LDS; ch: byte holding the value; pre: 512 words of LDS
 // private to this wavefront.  Returns the 8-byte block (lo, hi words) in every lane.
 //
 // The search is the exhaustive one of the oracle (every endpoint pair within `radius` of the
@@ -69,6 +124,15 @@ __device__ __forceinline__ void bc4_palette(int a0, int a1, bool mode6, int e0, 
 //   error = sum v^2 + sum_k q_k*(n_k*q_k - 2*s_k)                       (exact, integers)
 // -- 7 LDS lookups and ~100 VALU instructions per candidate instead of 16 texels x 8 entries
 // (~340): same errors, same ids, same winner, 3x fewer instructions.
+//
+// From radius 16 (High, Highest: 2 x 33^2 and 2 x 65^2 pairs) the window is cut down first,
+// EXACTLY: a pair's error is at least the squared distance of the texels outside its palette's
+// range to the nearest palette entry -- L(low endpoint) + H(high endpoint), each monotone in
+// its endpoint and a closed form of the prefix tables (count | sum, and sums of squares).  64
+// seed pairs around the extremes give an error e0 that some pair reaches; every low endpoint
+// with L > e0 and every high endpoint with H > e0 is then out (its pairs cannot reach e0, so
+// they neither win nor tie) and only the remaining rectangle of offsets is enumerated -- with
+// the ids of the full window, so the winner is the oracle's.
 __device__ __forceinline__ uint2 bc4_search(const uint32_t* tp, uint32_t* pre, int ch, int vmin,
 	int radius, uint32_t lane)
 {
@@ -83,61 +147,87 @@ __device__ __forceinline__ uint2 bc4_search(const uint32_t* tp, uint32_t* pre, i
 		lo6 = hi6 = vmin;
 	cf_prefix_table_u8(pre, uv, lane < 16u, lane);
 	const uint32_t all = pre[255];   // 16 << 16 | sum
-	const uint32_t span = 2u*(uint32_t)radius + 1u, span2 = span*span, total = 2u*span2;
-	const float inv_span = 1.0f/(float)span;
+	const uint32_t span = 2u*(uint32_t)radius + 1u, span2 = span*span;
+	// offsets kept per mode: low endpoint offsets dl < dl_cut, high endpoint offsets dh > -dh_cut
+	int dl_cut[2] = {radius + 1, radius + 1}, dh_cut[2] = {radius + 1, radius + 1};
+	if (radius >= 16) {
+		uint32_t* pre2 = pre + 256;
+		cf_prefix_table_add(pre2, uv, uv*uv, lane < 16u, lane);
+		const int tot_n = 16, tot_s = (int)(all & 0xFFFFu), tot_s2 = (int)sum2;
+		// seeds: 32 pairs per mode around the extremes
+		uint32_t e0;
+		{
+			const uint32_t sd = lane & 31u;
+			int a0, a1;
+			uint32_t err;
+			const bool ok = bc4_pair(pre, all, sum2, lane >= 32u, lo, hi, lo6, hi6, vmin, (int)(sd & 7u) - 3, (int)(sd >> 3) - 2, a0, a1, err);
+			e0 = cf_wave_min_u32(ok ? err : 0xFFFFFFFFu);
+		}
+		// lane d < 32: low endpoint offset d + 1 (offsets <= 0 leave no texel below); lane d + 32: high
+		// endpoint offset -(d + 1); both modes
+#pragma unroll
+		for (int m = 0; m < 2; ++m) {
+			const int d = (int)(lane & 31u) + 1;
+			uint32_t lb = 0u;
+			if (d <= radius) {
+				if (lane < 32u) {
+					const int c = clampi((m ? lo6 : lo) + d, vmin, 255);
+					if (m == 0)
+						lb = bc4_sq_below(pre, pre2, c - 1, c);
+					else {
+						// texels below c go to the nearer of vmin and c: split at their midpoint
+						const int mid = (vmin + c) >> 1;
+						const int midc = mid < c - 1 ? mid : c - 1;
+						lb = bc4_sq_below(pre, pre2, midc, vmin) + bc4_sq_below(pre, pre2, c - 1, c) - bc4_sq_below(pre, pre2, midc, c);
+					}
+				} else {
+					const int c = clampi((m ? hi6 : hi) - d, vmin, 255);
+					// texels above c: totals minus the part <= c
+					const uint32_t ns = pre[c], s2 = pre2[c];
+					const int n = tot_n - (int)(ns >> 16), sm = tot_s - (int)(ns & 0xFFFFu), q2 = tot_s2 - (int)s2;
+					if (m == 0)
+						lb = (uint32_t)(q2 - 2*c*sm + n*c*c);
+					else {
+						// ... to the nearer of c and 255
+						const int mid = (c + 255) >> 1;
+						const uint32_t nm = pre[mid], s2m = pre2[mid];
+						const int n1 = (int)(nm >> 16) - (int)(ns >> 16), s1 = (int)(nm & 0xFFFFu) - (int)(ns & 0xFFFFu), q1 = (int)s2m - (int)s2;
+						const int n2 = tot_n - (int)(nm >> 16), sm2 = tot_s - (int)(nm & 0xFFFFu), q22 = tot_s2 - (int)s2m;
+						lb = (uint32_t)(q1 - 2*c*s1 + n1*c*c) + (uint32_t)(q22 - 2*255*sm2 + n2*255*255);
+					}
+				}
+			}
+			const unsigned long long out = __ballot(d <= radius && lb > e0);
+			const uint32_t out_lo = (uint32_t)out, out_hi = (uint32_t)(out >> 32);
+			if (out_lo) dl_cut[m] = __builtin_ctz(out_lo) + 1;
+			if (out_hi) dh_cut[m] = __builtin_ctz(out_hi) + 1;
+		}
+	}
 	uint32_t best_err = 0xFFFFFFFFu, best_id = 0xFFFFFFFFu;
 	int best_a0 = 0, best_a1 = 0;
-	for (uint32_t base = 0; base < total; base += 64u) {
-		const uint32_t id = base + lane;
-		if (id < total) {
-			const bool mode6 = id >= span2;
-			const uint32_t t = mode6 ? id - span2 : id;
-			uint32_t il = (uint32_t)(((float)t + 0.5f)*inv_span);
-			il = il*span > t ? il - 1u : il;
-			il = (il + 1u)*span <= t ? il + 1u : il;
-			const uint32_t ih = t - il*span;
-			const int dl = (int)il - radius, dh = (int)ih - radius;
-			int a0, a1;
-			bool valid;
-			uint32_t q[8];   // the palette in ascending order
-			if (!mode6) {
-				a1 = clampi(lo + dl, vmin, 255);
-				a0 = clampi(hi + dh, vmin, 255);
-				valid = a0 > a1;
-				q[0] = (uint32_t)a1;
-#pragma unroll
-				for (int j = 1; j < 7; ++j)   // pal[8-j] = (j*a0 + (7-j)*a1)/7
-					q[j] = div7((uint32_t)(j*a0 + (7 - j)*a1));
-				q[7] = (uint32_t)a0;
-			} else {
-				a0 = clampi(lo6 + dl, vmin, 255);
-				a1 = clampi(hi6 + dh, vmin, 255);
-				valid = a0 <= a1;
-				q[0] = (uint32_t)vmin;
-				q[1] = (uint32_t)a0;
-#pragma unroll
-				for (int k = 2; k < 6; ++k)
-					q[k] = div5((uint32_t)((6 - k)*a0 + (k - 1)*a1));
-				q[6] = (uint32_t)a1;
-				q[7] = 255u;
-			}
-			if (valid) {
-				int e = (int)sum2;
-				uint32_t below = 0u;
-#pragma unroll
-				for (int k = 0; k < 8; ++k) {
-					const uint32_t upto = k < 7 ? pre[(q[k] + q[k < 7 ? k + 1 : 7]) >> 1] : all;
-					const uint32_t seg = upto - below;   // n << 16 | s: both fields are monotone
-					below = upto;
-					const int n = (int)(seg >> 16), sk = (int)(seg & 0xFFFFu), qk = (int)q[k];
-					e += qk*(n*qk - 2*sk);
-				}
-				const uint32_t err = (uint32_t)e;
-				if (err < best_err) {   // ids ascend per lane, so strict < keeps the lowest id
-					best_err = err;
-					best_id = id;
-					best_a0 = a0;
-					best_a1 = a1;
+#pragma unroll 1
+	for (int m = 0; m < 2; ++m) {
+		// the rectangle of offsets: il = dl + radius in [0, H), ih = dh + radius in [ih0, span)
+		const uint32_t H = (uint32_t)(radius + dl_cut[m]), ih0 = (uint32_t)(radius - dh_cut[m] + 1), W = span - ih0;
+		const uint32_t total = W*H;
+		const float inv_w = 1.0f/(float)W;
+		for (uint32_t base = 0; base < total; base += 64u) {
+			const uint32_t t = base + lane;
+			if (t < total) {
+				uint32_t il = (uint32_t)(((float)t + 0.5f)*inv_w);
+				il = il*W > t ? il - 1u : il;
+				il = (il + 1u)*W <= t ? il + 1u : il;
+				const uint32_t ih = ih0 + (t - il*W);
+				const uint32_t id = (m ? span2 : 0u) + il*span + ih;
+				int a0, a1;
+				uint32_t err;
+				if (bc4_pair(pre, all, sum2, m != 0, lo, hi, lo6, hi6, vmin, (int)il - radius, (int)ih - radius, a0, a1, err)) {
+					if (err < best_err) {   // ids ascend per lane, so strict < keeps the lowest id
+						best_err = err;
+						best_id = id;
+						best_a0 = a0;
+						best_a1 = a1;
+					}
 				}
 			}
 		}
@@ -754,7 +844,7 @@ cfhip_bc15_encode_kernel(cf_kparams kp)
 	__shared__ uint32_t outb[CF_BLOCKS_PER_WG*4];
 	// BC3 / BC4 / BC5: one 256-entry prefix table per wavefront (bc4_search)
 	constexpr bool HAS_BC4 = FMT == F_BC3 || FMT == F_BC4 || FMT == F_BC5;
-	__shared__ __attribute__((aligned(16))) uint32_t pre_tab[HAS_BC4 ? (CF_WG_THREADS/64)*256 : 4];
+	__shared__ __attribute__((aligned(16))) uint32_t pre_tab[HAS_BC4 ? (CF_WG_THREADS/64)*512 : 4];   // per wave: count | sum table, table of squares
 	uint32_t gx_, gy_;
 	cf_resolve(kp, gx_, gy_);
 	const uint32_t bx0 = gx_*CF_BLOCKS_PER_WG;
@@ -763,7 +853,7 @@ cfhip_bc15_encode_kernel(cf_kparams kp)
 	__syncthreads();
 
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	uint32_t* pre = pre_tab + (HAS_BC4 ? wave*256u : 0u);
+	uint32_t* pre = pre_tab + (HAS_BC4 ? wave*512u : 0u);
 	for (uint32_t j = 0; j < 4u; ++j) {
 		const uint32_t b = wave*4u + j;
 		if (bx0 + b >= kp.bx)

@@ -174,13 +174,15 @@ __device__ __forceinline__ uint32_t cf_div_small(uint32_t num, uint32_t den)
 // owns four consecutive entries, scans them, and adds the exclusive prefix of the lanes before
 // it (Hillis-Steele inside each DPP row, row totals carried over through v_readlane).  All 64
 // lanes active.  Users: bc4_search (bc15_encode.hip), eac_search (etc_encode.hip).
-__device__ __forceinline__ void cf_prefix_table_u8(uint32_t* pre, uint32_t v, bool mine, uint32_t lane)
+// `add`: what a texel of value v contributes to entry v (count << 16 | v for the count | sum
+// table, v * v for a table of prefix sums of squares).
+__device__ __forceinline__ void cf_prefix_table_add(uint32_t* pre, uint32_t v, uint32_t add, bool mine, uint32_t lane)
 {
 	const uint32_t x0 = lane*4u;
 	*reinterpret_cast<uint4*>(pre + x0) = make_uint4(0u, 0u, 0u, 0u);
 	__builtin_amdgcn_wave_barrier();
 	if (mine)
-		atomicAdd(pre + v, 0x10000u | v);
+		atomicAdd(pre + v, add);
 	__builtin_amdgcn_wave_barrier();
 	uint4 e = *reinterpret_cast<const uint4*>(pre + x0);
 	e.y += e.x; e.z += e.y; e.w += e.z;
@@ -197,6 +199,11 @@ __device__ __forceinline__ void cf_prefix_table_u8(uint32_t* pre, uint32_t v, bo
 	e.x += before; e.y += before; e.z += before; e.w += before;
 	*reinterpret_cast<uint4*>(pre + x0) = e;
 	__builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void cf_prefix_table_u8(uint32_t* pre, uint32_t v, bool mine, uint32_t lane)
+{
+	cf_prefix_table_add(pre, v, 0x10000u | v, mine, lane);
 }
 
 // wave64 minimum of a 32-bit key, uniform result (all 64 lanes must be active)
