@@ -11,10 +11,11 @@ Pure serialisation, host side, mirrors the reference writers field for field:
                                             pixel format :272-470, channel type :107-268)
 All three cover the uncompressed formats of csrc/std_pack.hip too (getDdsFormat,
 SaveDds.cpp:252-440; getFormatInfo, SaveKtx.cpp:200-630, rows padded to 4 bytes :1240-1285).
-Only 2-D textures and 2-D arrays of the formats this backend encodes are covered (cube maps
-and 3-D textures are containers of the same surfaces in a different order: not needed by the
-hot path's tests).  `read_dds` parses what `write_dds` emits (round-trip tests; Pillow is the
-independent reader used by tests/test_containers.py).
+2-D textures, 2-D arrays, cube maps, cube arrays and 3-D textures: `write_dds` / `write_ktx` /
+`write_pvr` take one 2-D texture or array; `write_dds_texture` / `write_ktx_texture` /
+`write_pvr_texture` take the reference's general [level][depth][face] surface lists with a
+dimension ("2d", "cube", "3d").  `read_dds` parses what the DDS writers emit (round-trip tests;
+Pillow is the independent reader used by tests/test_containers.py).
 """
 from __future__ import annotations
 
@@ -383,3 +384,149 @@ def read_pvr(data: bytes):
     return {"flags": flags, "pixel_format": pixfmt, "color_space": cspace, "channel_type": chtype,
             "width": width, "height": height, "depth": depth, "elements": surfaces, "faces": faces,
             "levels": levels, "metadata": data[52:52 + meta], "offset": 52 + meta}
+
+
+# ---- general [level][depth][face] writers: cube maps, cube arrays, 3-D textures -------------
+# (Texture::data(face, level, depth); depth(level) = max(1, depth >> level) for Dim3D, the array
+#  size otherwise, Texture.cpp:1207-1216)
+
+_DIM_TEXTURE3D = 4
+_DDSD_DEPTH = 0x800000
+_DDSCAPS2_CUBE_ALL = 0x200 | 0x400 | 0x800 | 0x1000 | 0x2000 | 0x4000 | 0x8000
+_DDSCAPS2_VOLUME = 0x200000
+_DDS_MISC_CUBEMAP = 0x4
+
+
+class TextureLayout:
+    """Shape of a texture as the reference's writers see it."""
+
+    def __init__(self, fmt, typ, width, height, surfaces, dimension="2d", depth=0, is_array=None):
+        self.fmt, self.typ = Format(fmt), Type(typ)
+        self.width, self.height = int(width), int(height)
+        self.dimension = dimension
+        if dimension not in ("2d", "cube", "3d"):
+            raise ValueError("dimension must be '2d', 'cube' or '3d'")
+        self.faces = 6 if dimension == "cube" else 1
+        self.depth = int(depth)                                  # Texture::depth(): 0 = not an array / not 3-D
+        self.is_array = (dimension != "3d" and self.depth > 0) if is_array is None else bool(is_array)
+        if dimension == "3d" and self.depth < 1:
+            raise ValueError("a 3-D texture needs a depth")
+        self.surfaces = [[[_b(f) for f in d] for d in lvl] for lvl in surfaces]
+        self.levels = len(self.surfaces)
+        for l, lvl in enumerate(self.surfaces):
+            w, h = max(1, self.width >> l), max(1, self.height >> l)
+            if len(lvl) != self.depth_at(l):
+                raise ValueError("level %d: %d depth entries, expected %d" % (l, len(lvl), self.depth_at(l)))
+            for d in lvl:
+                if len(d) != self.faces:
+                    raise ValueError("level %d: %d faces, expected %d" % (l, len(d), self.faces))
+                for f in d:
+                    if len(f) != payload_size(self.fmt, self.typ, w, h):
+                        raise ValueError("level %d: %d bytes, expected %d" % (l, len(f), payload_size(self.fmt, self.typ, w, h)))
+
+    def depth_at(self, level):
+        if self.dimension == "3d":
+            return max(self.depth >> level, 1)
+        return max(self.depth, 1)
+
+
+def write_dds_texture(stream, tex: TextureLayout, color_space=ColorSpace.Linear, alpha=Alpha.Standard) -> int:
+    """saveDds (SaveDds.cpp:565-683) for any dimension: surface order element -> face -> level ->
+    volume slice (:657-680)."""
+    key = (tex.fmt, tex.typ)
+    if key not in _DXGI:
+        raise ValueError("no DDS format for %s/%s (saveDds returns Unsupported)" % (tex.fmt.name, tex.typ.name))
+    lin, srgb = _DXGI[key]
+    dxgi = srgb if (ColorSpace(color_space) == ColorSpace.sRGB and srgb) else lin
+    bw, _bh, bs = query(tex.fmt, tex.typ)
+    pitch = (tex.width + bw - 1) // bw * bs
+    is3d = tex.dimension == "3d"
+    flags = _DDSD_CAPS | _DDSD_HEIGHT | _DDSD_WIDTH | _DDSD_PIXELFORMAT | _DDSD_MIPMAPCOUNT | _DDSD_PITCH
+    if is3d:
+        flags |= _DDSD_DEPTH                                            # :579-580
+    caps = _DDSCAPS_TEXTURE
+    if tex.levels > 1:
+        caps |= _DDSCAPS_MIPMAP
+    if tex.levels > 1 or is3d or tex.is_array:                          # :592-596 (a lone cube map is not "complex" there)
+        caps |= _DDSCAPS_COMPLEX
+    caps2 = _DDSCAPS2_CUBE_ALL if tex.dimension == "cube" else (_DDSCAPS2_VOLUME if is3d else 0)
+    misc2 = _ALPHA_MODE[Alpha(alpha)] if has_alpha(tex.fmt) else 3
+    out = struct.pack("<I", DDS_MAGIC)
+    out += struct.pack("<7I44x", 124, flags, tex.height, tex.width, pitch, tex.depth if is3d else 0, tex.levels)
+    out += struct.pack("<2I4s5I", 32, _DDPF_FOURCC, b"DX10", 0, 0, 0, 0, 0)
+    out += struct.pack("<5I", caps, caps2, 0, 0, 0)
+    out += struct.pack("<5I", dxgi, _DIM_TEXTURE3D if is3d else _DIM_TEXTURE2D,
+                       _DDS_MISC_CUBEMAP if tex.dimension == "cube" else 0,
+                       1 if is3d else max(tex.depth, 1), misc2)           # arraySize :637
+    elements = max(tex.depth, 1) if tex.is_array else 1
+    for element in range(elements):
+        for face in range(tex.faces):
+            for level in range(tex.levels):
+                volumes = tex.depth_at(level) if is3d else 1
+                for volume in range(volumes):
+                    out += tex.surfaces[level][volume + element][face]
+    stream.write(out)
+    return len(out)
+
+
+def write_ktx_texture(stream, tex: TextureLayout, color_space=ColorSpace.Linear) -> int:
+    """saveKtx (SaveKtx.cpp:1189-1290) for any dimension: per level imageSize, then depth -> face;
+    imageSize counts ONE face of a non-array cube map (:1224-1240, the KTX rule)."""
+    key = (tex.fmt, tex.typ)
+    srgb_wanted = ColorSpace(color_space) == ColorSpace.sRGB
+    if key in _GL:
+        lin, srgb, base = _GL[key]
+        gl_type, type_size, gl_format, compressed = 0, 1, 0, True
+    elif key in _GLU:
+        gl_type, type_size, gl_format, (lin, srgb), base = _GLU[key]
+        compressed = False
+    else:
+        raise ValueError("no KTX format for %s/%s (saveKtx returns Unsupported)" % (tex.fmt.name, tex.typ.name))
+    internal = srgb if (srgb_wanted and srgb) else lin
+    out = KTX_IDENTIFIER + struct.pack("<I", KTX_ENDIANNESS)
+    out += struct.pack("<5I", gl_type, type_size, gl_format, internal, base)
+    out += struct.pack("<7I", tex.width, tex.height, tex.depth if tex.dimension == "3d" else 0,
+                       tex.depth if tex.is_array else 0, tex.faces, tex.levels, 0)
+    bpp = query(tex.fmt, tex.typ)[2]
+    for l in range(tex.levels):
+        w, h = max(1, tex.width >> l), max(1, tex.height >> l)
+        row = w*bpp
+        pad = 0 if compressed else (4 - row % 4) % 4
+        one = len(tex.surfaces[l][0][0]) if compressed else (row + pad)*h
+        size = one*tex.depth_at(l)
+        if tex.is_array:
+            size *= tex.faces
+        assert size % 4 == 0
+        out += struct.pack("<I", size)
+        for d in range(tex.depth_at(l)):
+            for f in range(tex.faces):
+                data = tex.surfaces[l][d][f]
+                if pad == 0:
+                    out += data
+                else:
+                    for y in range(h):
+                        out += data[y*row:(y + 1)*row] + b"\0"*pad
+    stream.write(out)
+    return len(out)
+
+
+def write_pvr_texture(stream, tex: TextureLayout, color_space=ColorSpace.Linear, alpha=Alpha.Standard) -> int:
+    """savePvr (SavePvr.cpp:478-600) for any dimension: surface order level -> depth -> face."""
+    out = struct.pack("<II", _fourcc("P", "V", "R", 3), 0x2 if Alpha(alpha) == Alpha.PreMultiplied else 0)
+    out += struct.pack("<Q", pvr_pixel_format(tex.fmt, alpha))
+    out += struct.pack("<II", 1 if ColorSpace(color_space) == ColorSpace.sRGB else 0, pvr_channel_type(tex.fmt, tex.typ))
+    out += struct.pack("<6I", tex.height, tex.width, tex.depth if tex.dimension == "3d" else 1,
+                       tex.depth if tex.is_array else 1, tex.faces, tex.levels)
+    meta = b""
+    if tex.fmt in (Format.BC1_RGB, Format.BC1_RGBA):
+        code = _fourcc("B", "C", "1", "A") if tex.fmt == Format.BC1_RGBA else _fourcc("B", "C", "1", 0)
+        meta += struct.pack("<4I", _fourcc("C", "T", "F", "S"), code, 4, 0)
+    if tex.is_array:
+        meta += struct.pack("<4I", _fourcc("C", "T", "F", "S"), _fourcc("A", "R", "R", "Y"), 4, 0)
+    out += struct.pack("<I", len(meta)) + meta
+    for l in range(tex.levels):
+        for d in range(tex.depth_at(l)):
+            for f in range(tex.faces):
+                out += tex.surfaces[l][d][f]
+    stream.write(out)
+    return len(out)

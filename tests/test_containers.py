@@ -251,3 +251,96 @@ def test_writers_accept_exactly_what_the_reference_save_tests_expect():
                 assert n == header + extra + size, (kind, key, n)
             checked += 1
     assert checked > 250
+
+
+# ---- cube maps, cube arrays, 3-D textures (general [level][depth][face] writers) -------------
+
+def _tagged(fmt, typ, w, h, tag):
+    return bytes([tag % 251])*payload_size(fmt, typ, w, h)
+
+
+def _layout(dimension, depth, levels, w=16, h=16, fmt=None, typ=None, is_array=None):
+    from cuttlefish_amd import Format, Type
+    fmt, typ = fmt or Format.BC1_RGB, typ or Type.UNorm
+    faces = 6 if dimension == "cube" else 1
+    surf, tag = [], 0
+    for l in range(levels):
+        nd = max(depth >> l, 1) if dimension == "3d" else max(depth, 1)
+        lvl = []
+        for d in range(nd):
+            lvl.append([_tagged(fmt, typ, max(1, w >> l), max(1, h >> l), 16*l + 4*d + f + 1) for f in range(faces)])
+        surf.append(lvl)
+    return C.TextureLayout(fmt, typ, w, h, surf, dimension=dimension, depth=depth, is_array=is_array)
+
+
+def _runs(payload):
+    """the distinct tag bytes of a payload, in order"""
+    out = []
+    for b in payload:
+        if not out or out[-1] != b:
+            out.append(b)
+    return out
+
+
+def test_cube_map_orders_follow_the_three_writers():
+    tex = _layout("cube", 0, 2)
+    tag = lambda l, d, f: 16*l + 4*d + f + 1
+    buf = io.BytesIO(); C.write_dds_texture(buf, tex); data = buf.getvalue()
+    hdr = C.read_dds(data)
+    caps, caps2 = struct.unpack_from("<2I", data, 4 + 104)
+    dxgi, dim, misc, array, _ = struct.unpack_from("<5I", data, 4 + 124)
+    assert caps2 == 0xFE00 and misc == 0x4 and dim == 3 and array == 1        # SaveDds.cpp:600-604, :624-627, :637
+    assert caps & 0x8                                                         # mip levels -> complex
+    # DDS: face -> level (SaveDds.cpp:657-680)
+    assert _runs(data[hdr["offset"]:]) == [tag(l, 0, f) for f in range(6) for l in range(2)]
+    buf = io.BytesIO(); C.write_ktx_texture(buf, tex); k = buf.getvalue()
+    w, h, d, arr, faces, levels, kv = struct.unpack_from("<7I", k, 12 + 4 + 20)
+    assert (d, arr, faces, levels) == (0, 0, 6, 2)
+    size0 = struct.unpack_from("<I", k, 64)[0]
+    assert size0 == len(tex.surfaces[0][0][0])                                # ONE face for a non-array cube map
+    # KTX: level -> face
+    body = k[64:]
+    assert _runs(body[4:4 + 6*size0]) == [tag(0, 0, f) for f in range(6)]
+    buf = io.BytesIO(); C.write_pvr_texture(buf, tex); p = buf.getvalue()
+    ph = C.read_pvr(p)
+    assert (ph["depth"], ph["elements"], ph["faces"], ph["levels"]) == (1, 1, 6, 2)
+    assert _runs(p[ph["offset"]:]) == [tag(l, 0, f) for l in range(2) for f in range(6)]
+
+
+def test_3d_texture_headers_and_slice_order():
+    tex = _layout("3d", 4, 3)                          # 16x16x4, levels with 4 / 2 / 1 slices
+    tag = lambda l, d: 16*l + 4*d + 1
+    buf = io.BytesIO(); C.write_dds_texture(buf, tex); data = buf.getvalue()
+    _, size, flags, height, width, pitch, depth, levels = struct.unpack_from("<8I", data, 0)
+    caps, caps2 = struct.unpack_from("<2I", data, 4 + 104)
+    dxgi, dim, misc, array, _ = struct.unpack_from("<5I", data, 4 + 124)
+    assert flags & 0x800000 and depth == 4 and caps2 == 0x200000 and dim == 4 and array == 1 and caps & 0x8
+    assert _runs(data[4 + 124 + 20:]) == [tag(l, d) for l in range(3) for d in range(max(4 >> l, 1))]
+    buf = io.BytesIO(); C.write_ktx_texture(buf, tex); k = buf.getvalue()
+    w, h, d, arr, faces, levels, kv = struct.unpack_from("<7I", k, 12 + 4 + 20)
+    assert (d, arr, faces, levels) == (4, 0, 1, 3)
+    assert struct.unpack_from("<I", k, 64)[0] == 4*len(tex.surfaces[0][0][0])
+    buf = io.BytesIO(); C.write_pvr_texture(buf, tex); p = buf.getvalue()
+    ph = C.read_pvr(p)
+    assert (ph["depth"], ph["elements"], ph["faces"]) == (4, 1, 1)
+    assert _runs(p[ph["offset"]:]) == [tag(l, d) for l in range(3) for d in range(max(4 >> l, 1))]
+
+
+def test_cube_array_and_equivalence_with_the_2d_writers():
+    tex = _layout("cube", 2, 1, is_array=True)         # two cubes
+    tag = lambda d, f: 4*d + f + 1
+    buf = io.BytesIO(); C.write_dds_texture(buf, tex); data = buf.getvalue()
+    dxgi, dim, misc, array, _ = struct.unpack_from("<5I", data, 4 + 124)
+    assert array == 2 and misc == 0x4
+    assert _runs(data[4 + 124 + 20:]) == [tag(d, f) for d in range(2) for f in range(6)]
+    buf = io.BytesIO(); C.write_ktx_texture(buf, tex); k = buf.getvalue()
+    assert struct.unpack_from("<I", k, 64)[0] == 2*6*len(tex.surfaces[0][0][0])    # arrays: every face counted
+    # a plain 2-D array through the general writer = the 2-D writer, byte for byte
+    from cuttlefish_amd import Format, Type, payload_size
+    lv = [[bytes([7 + e + 3*l])*payload_size(Format.BC7, Type.UNorm, 8 >> l, 8 >> l) for l in range(2)] for e in range(3)]
+    gen = C.TextureLayout(Format.BC7, Type.UNorm, 8, 8, [[[lv[e][l]] for e in range(3)] for l in range(2)], "2d", depth=3)
+    for wa, wb in ((C.write_dds, C.write_dds_texture), (C.write_ktx, C.write_ktx_texture), (C.write_pvr, C.write_pvr_texture)):
+        a, b = io.BytesIO(), io.BytesIO()
+        wa(a, Format.BC7, Type.UNorm, 8, 8, lv)
+        wb(b, gen)
+        assert a.getvalue() == b.getvalue(), wa.__name__
