@@ -1,7 +1,8 @@
 /*
  * oracle/astc_encode.c -- TEST INFRASTRUCTURE (see cf_oracle.h header).
  *
- * ASTC 2-D LDR encoder: CPU restatement of the ASTC leg of the reference hot path
+ * ASTC 2-D encoder (LDR profile, and the HDR profiles on 8-bit LNS codes): CPU restatement of the
+ * ASTC leg of the reference hot path
  *   AstcConverter ctor (swizzle / profile / flags / preset)   lib/src/AstcConverter.cpp:134-201
  *   AstcConverter::process (edge-replicated bw x bh tile -> astcenc_compress_image)  :208-230
  * The reference forwards to ARM astc-encoder (absent submodule: "parity unpinned"); this is a
@@ -15,6 +16,9 @@
  * without blue contraction), 6/10 (base + scale), 0/4 (luminance), all at the colour
  * quantisation level the remaining bits allow (ISE).  ASTCENC_FLG_USE_ALPHA_WEIGHT and
  * ASTCENC_FLG_USE_PERCEPTUAL (AstcConverter.cpp:163-172) enter the error metric.
+ * Type::UFloat (ASTCENC_PRF_HDR / HDR_RGB_LDR_A, :150-162): HDR endpoint modes 11 / 14 / 15 in
+ * their direct sub-mode, HDR void extents; see "HDR profile" below.  No independent HDR decoder
+ * exists in this environment: that leg is pinned to oracle/astc_decode.c alone (parity unpinned).
  *
  * Search (lane = (partitioning candidate, weight-grid config), ids fixed = the GPU's):
  *   phase A  lane = (candidate, subset/plane): integer moments -> principal axis -> extremes
