@@ -205,28 +205,55 @@ __device__ __forceinline__ uint2 bc4_search(const uint32_t* tp, uint32_t* pre, i
 	}
 	uint32_t best_err = 0xFFFFFFFFu, best_id = 0xFFFFFFFFu;
 	int best_a0 = 0, best_a1 = 0;
-#pragma unroll 1
-	for (int m = 0; m < 2; ++m) {
-		// the rectangle of offsets: il = dl + radius in [0, H), ih = dh + radius in [ih0, span)
-		const uint32_t H = (uint32_t)(radius + dl_cut[m]), ih0 = (uint32_t)(radius - dh_cut[m] + 1), W = span - ih0;
-		const uint32_t total = W*H;
-		const float inv_w = 1.0f/(float)W;
+	if (radius < 16) {
+		// small windows (Lowest .. Normal: 2 x 1, 2 x 121 pairs): both modes in one id range
+		const uint32_t total = 2u*span2;
+		const float inv_span = 1.0f/(float)span;
 		for (uint32_t base = 0; base < total; base += 64u) {
-			const uint32_t t = base + lane;
-			if (t < total) {
-				uint32_t il = (uint32_t)(((float)t + 0.5f)*inv_w);
-				il = il*W > t ? il - 1u : il;
-				il = (il + 1u)*W <= t ? il + 1u : il;
-				const uint32_t ih = ih0 + (t - il*W);
-				const uint32_t id = (m ? span2 : 0u) + il*span + ih;
+			const uint32_t id = base + lane;
+			if (id < total) {
+				const bool mode6 = id >= span2;
+				const uint32_t t = mode6 ? id - span2 : id;
+				uint32_t il = (uint32_t)(((float)t + 0.5f)*inv_span);
+				il = il*span > t ? il - 1u : il;
+				il = (il + 1u)*span <= t ? il + 1u : il;
+				const uint32_t ih = t - il*span;
 				int a0, a1;
 				uint32_t err;
-				if (bc4_pair(pre, all, sum2, m != 0, lo, hi, lo6, hi6, vmin, (int)il - radius, (int)ih - radius, a0, a1, err)) {
+				if (bc4_pair(pre, all, sum2, mode6, lo, hi, lo6, hi6, vmin, (int)il - radius, (int)ih - radius, a0, a1, err)) {
 					if (err < best_err) {   // ids ascend per lane, so strict < keeps the lowest id
 						best_err = err;
 						best_id = id;
 						best_a0 = a0;
 						best_a1 = a1;
+					}
+				}
+			}
+		}
+	} else {
+#pragma unroll 1
+		for (int m = 0; m < 2; ++m) {
+			// the rectangle of offsets: il = dl + radius in [0, H), ih = dh + radius in [ih0, span)
+			const uint32_t H = (uint32_t)(radius + dl_cut[m]), ih0 = (uint32_t)(radius - dh_cut[m] + 1), W = span - ih0;
+			const uint32_t total = W*H;
+			const float inv_w = 1.0f/(float)W;
+			for (uint32_t base = 0; base < total; base += 64u) {
+				const uint32_t t = base + lane;
+				if (t < total) {
+					uint32_t il = (uint32_t)(((float)t + 0.5f)*inv_w);
+					il = il*W > t ? il - 1u : il;
+					il = (il + 1u)*W <= t ? il + 1u : il;
+					const uint32_t ih = ih0 + (t - il*W);
+					const uint32_t id = (m ? span2 : 0u) + il*span + ih;
+					int a0, a1;
+					uint32_t err;
+					if (bc4_pair(pre, all, sum2, m != 0, lo, hi, lo6, hi6, vmin, (int)il - radius, (int)ih - radius, a0, a1, err)) {
+						if (err < best_err) {   // ids ascend per lane, so strict < keeps the lowest id
+							best_err = err;
+							best_id = id;
+							best_a0 = a0;
+							best_a1 = a1;
+						}
 					}
 				}
 			}
