@@ -1023,7 +1023,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					for (uint32_t r = 0; r < (ng + N + 2u)*planes; ++r)
 						COLR(r) = 0;
 #pragma unroll 1
-					for (uint32_t pl = 0; pl < planes; ++pl) {
+					for (uint32_t pl = 0; pl < ((CF_ASTC_ABLATE & 16) ? 0u : planes); ++pl) {
 						const uint8_t* Trow = S.T + (pl ? 8u + ((j - 1u) & 1u) : j)*npad;
 						// the next texel's record and ideal weight are fetched before this texel's stores: the
 						// compiler cannot move LDS loads above LDS stores it cannot disambiguate, and the
@@ -1065,7 +1065,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					uint32_t wpack0 = 0, wpack1 = 0;
 					uint32_t rec = inf[0], p = tp[0], part = byp ? 0u : prow[0];
 #pragma unroll 1
-					for (uint32_t i = 0; i < n; ++i) {
+					for (uint32_t i = 0; i < ((CF_ASTC_ABLATE & 64) ? 1u : n); ++i) {
 						const uint32_t nx = i + 1u < n ? i + 1u : i;
 						const uint32_t nrec = inf[nx], np = tp[nx], npart = byp ? 0u : prow[nx];   // before the cache stores
 						const uint32_t g0 = rec & 255u, f00 = (rec >> 8) & 31u, f01 = (rec >> 13) & 31u, f10 = (rec >> 18) & 31u, f11 = rec >> 23;
@@ -1152,7 +1152,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						okk[o] = okk[o] && lvs[o] >= 0;
 					}
 #pragma unroll 1
-					for (uint32_t p = 0; p < P; ++p) {
+					for (uint32_t p = 0; p < ((CF_ASTC_ABLATE & 128) ? 0u : P); ++p) {
 						float r0[4], r1[4], cA[4], cB[4], cC[4];
 						solve(p, r0, r1, cA, cB, cC);
 						uint32_t d0p, d1p, vals[8];
@@ -1198,7 +1198,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						// 5. exact error through the decode arithmetic
 						unsigned long long e64 = 0;
 #pragma unroll 1
-						for (uint32_t i = 0; i < n; ++i) {
+						for (uint32_t i = 0; i < ((CF_ASTC_ABLATE & 256) ? 1u : n); ++i) {
 							uint32_t w0, w1;
 							if (wcached) {
 								w0 = (wcache[((i >> 2)*2u)*64u] >> (8u*(i & 3u))) & 255u;
