@@ -352,7 +352,13 @@ int astc_prepare(cfhip_ctx* ctx, int format)
 	const std::vector<uint8_t> host = cfastc::build_blob(fbw, fbh);
 	memcpy(&ctx->astc_hdr[format], host.data(), sizeof(cfastc::AstcBlobHeader));
 	HIP_TRY(ctx, hipMalloc(&tab, host.size()));
-	HIP_TRY(ctx, hipMemcpy(tab, host.data(), host.size(), hipMemcpyHostToDevice));
+	const hipError_t ce = hipMemcpy(tab, host.data(), host.size(), hipMemcpyHostToDevice);
+	if (ce != hipSuccess) {
+		// never leave a half-initialised table behind: the next call builds it again
+		(void)hipFree(tab);
+		tab = nullptr;
+		return fail(ctx, CFHIP_E_DEVICE, "ASTC table upload: %s", hipGetErrorString(ce));
+	}
 	return CFHIP_OK;
 }
 
