@@ -177,9 +177,15 @@ def valu_issue_view(kernel_substr, avg_kernel_s, quality=2):
                 if not cyc:
                     cyc = insts * mix["valu_cycles_per_inst"]
                 ceiling_s = cyc / N_SIMD / GPU_CLOCK_HZ
+                # the same mix at the rates the microbenchmark actually measured for the two classes at
+                # 8 waves / SIMD (2.6 and 4.2 cycles, loop overhead included: profiles/r01_valu_rate.txt)
+                # -- an upper view of the fraction; `frac` below uses the ideal 2 / 4 cycles
+                fast_share = (4.0 - cyc / insts) / 2.0
+                cyc_meas = insts * (2.6 * fast_share + 4.2 * (1.0 - fast_share))
                 view.update({"wave_insts_per_launch": insts,
                              "issue_cycles_per_launch": int(cyc),
                              "cycles_per_inst": round(cyc / insts, 4),
+                             "frac_at_measured_class_rates": round(cyc_meas / N_SIMD / GPU_CLOCK_HZ / avg_kernel_s, 4),
                              "class_source": pj.get("class_source", "static ISA mix"),
                              "ceiling_ms": round(ceiling_s * 1e3, 4),
                              "frac": round(ceiling_s / avg_kernel_s, 4),
