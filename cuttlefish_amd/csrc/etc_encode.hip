@@ -946,11 +946,13 @@ __device__ __forceinline__ uint32_t r11_word(float f, bool snorm)
 
 } // namespace
 
-// register budget: 4 waves/SIMD (128 VGPRs) holds every variant without scratch except
-// ETC2 RGBA8 (RGB search + EAC alpha in one kernel), which gets 3
+// register budget: at least 5 waves/SIMD (96 VGPRs).  The ETC2 variants then spill 44-124 bytes per
+// lane, and still run faster than at 3-4 waves without scratch (A/B on one box, Normal: RGB
+// 1.65 -> 1.56 ms, A1 1.80 -> 1.56 ms, RGBA8 2.05 -> 1.82 ms): the kernel has long dependent chains
+// between its phases and the extra waves cover them; 6 waves bought nothing more
 template <int PIX, int FMT, bool SNORM>
 __global__ void __launch_bounds__(CF_WG_THREADS)
-__attribute__((amdgpu_waves_per_eu((FMT == E_A8 || FMT == E_A1 || FMT == E_RGB) ? 3 : 4, 8)))
+__attribute__((amdgpu_waves_per_eu(5, 8)))
 cfhip_etc_encode_kernel(cf_kparams kp)
 {
 	constexpr bool IS_EAC = FMT == E_R11 || FMT == E_RG11;
