@@ -29,11 +29,28 @@ def _deps():
     return d
 
 
+def _fingerprint() -> str:
+    """SHA-256 over the build flags and the CONTENT of every dependency: modification times are
+    not trusted (git checkout / stash restore files with arbitrary times, and a stale library on
+    the GPU box silently measures old kernels)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for p in sorted(_deps()):
+        if os.path.isfile(p):
+            h.update(os.path.basename(p).encode())
+            with open(p, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+STAMP = LIB + ".srchash"
+
+
 def is_stale() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in _deps())
+    with open(STAMP) as f:
+        return f.read().strip() != _fingerprint()
 
 
 def hipcc_path():
@@ -48,6 +65,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
+    with open(STAMP, "w") as f:
+        f.write(_fingerprint() + "\n")
     return LIB
 
 
