@@ -1229,13 +1229,13 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 } // namespace
 
 // Waves per SIMD the register allocation is held to.  The kernel is VALU-issue-bound
-// (tools/ubench/valu_rate.hip) with LDS / cross-lane latency to hide.  Round 1 ran 3 waves in 168
-// registers without scratch; with the round-2 kernel 4 waves in 128 registers spill 48-68 bytes per
-// lane, and the fourth wave is worth more than those spills cost: A/B on one box, Normal 3.90 ->
-// 3.78 ms, High 5.32 -> 5.08 ms, Highest 11.78 -> 11.32 ms (the scratch stays in cache: PMC
-// WRITE_SIZE in profiles/).
+// (tools/ubench/valu_rate.hip) with LDS / cross-lane latency to hide.  3 waves = 166 registers and
+// no scratch.  4 waves (128 registers, 48 B of scratch per lane) run 3 % faster in A/B, 5 waves
+// (96, 136 B) 3 % faster again -- but the scratch reaches HBM: PMC traffic per launch 108 MB and
+// 5 GB against 84 MB algorithmic (profiles/r02_occupancy_ab.txt).  A search kernel that re-reads
+// nothing is worth more than 3 %: 3 waves.
 #ifndef CF_BC7_WAVES
-#define CF_BC7_WAVES 4
+#define CF_BC7_WAVES 3
 #endif
 template <int PIX, bool UNITW, bool WIDE>
 __global__ void __launch_bounds__(CF_WG_THREADS)

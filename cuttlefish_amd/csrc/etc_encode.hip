@@ -946,13 +946,14 @@ __device__ __forceinline__ uint32_t r11_word(float f, bool snorm)
 
 } // namespace
 
-// register budget: at least 5 waves/SIMD (96 VGPRs).  The ETC2 variants then spill 44-124 bytes per
-// lane, and still run faster than at 3-4 waves without scratch (A/B on one box, Normal: RGB
-// 1.65 -> 1.56 ms, A1 1.80 -> 1.56 ms, RGBA8 2.05 -> 1.82 ms): the kernel has long dependent chains
-// between its phases and the extra waves cover them; 6 waves bought nothing more
+// register budget: at least 4 waves/SIMD (128 VGPRs) for every variant -- ETC2 A1 and RGBA8 ran at 3
+// (132 / 144 registers) and gain 10 % / 9 % from the fourth wave with no scratch (RGBA8: 8 bytes).
+// 5 waves (96 registers) are another 4-6 % faster, but their 44-124 bytes of scratch per lane reach
+// HBM (PMC WRITE_SIZE 27 / 189 / 496 MB per 2048^2 launch against a 2-4 MB payload): not taken
+// (profiles/r02_occupancy_ab.txt)
 template <int PIX, int FMT, bool SNORM>
 __global__ void __launch_bounds__(CF_WG_THREADS)
-__attribute__((amdgpu_waves_per_eu(5, 8)))
+__attribute__((amdgpu_waves_per_eu(4, 8)))
 cfhip_etc_encode_kernel(cf_kparams kp)
 {
 	constexpr bool IS_EAC = FMT == E_R11 || FMT == E_RG11;

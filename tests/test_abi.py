@@ -106,3 +106,12 @@ def test_header_compiles_as_plain_c99(tmp_path):
     src = os.path.join(ROOT, "integration", "check_header.c")
     subprocess.check_call(["gcc", "-std=c99", "-pedantic-errors", "-Wall", "-Wextra", "-Werror", "-c",
                            "-I" + os.path.join(ROOT, "include"), src, "-o", str(tmp_path / "h.o")])
+
+
+def test_graft_entry_module_imports():
+    """the driver imports __graft_entry__ and calls build(): a syntax error there hides every
+    later source change behind a stale library"""
+    import importlib
+    import __graft_entry__
+    importlib.reload(__graft_entry__)
+    assert callable(__graft_entry__.build) and callable(__graft_entry__.smoke)
