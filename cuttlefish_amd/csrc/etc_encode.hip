@@ -36,6 +36,9 @@ __device__ __forceinline__ int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 2
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int ex4(int v) { return (v << 4) | v; }
 __device__ __forceinline__ int ex5(int v) { return (v << 3) | (v >> 2); }
+// either expansion without a branch on the lane's family: ex4(v) = 17 v, ex5(v) = 33 v >> 2 (the
+// select between the two compiled to three exec-mask branches per candidate of the base-colour walk)
+__device__ __forceinline__ int ex45(int v, bool fam4) { return (int)(__umul24((uint32_t)v, fam4 ? 17u : 33u) >> (fam4 ? 0u : 2u)); }
 __device__ __forceinline__ int ex6(int v) { return (v << 2) | (v >> 4); }
 __device__ __forceinline__ int ex7(int v) { return (v << 1) | (v >> 6); }
 __device__ __forceinline__ int sx3(int v) { return v >= 4 ? v - 8 : v; }
@@ -568,8 +571,7 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 				if (o1 > r) { o1 = -r; ++o0; }
 			}
 			const int q[3] = {clampi(q0[0] + d0, 0, maxq), clampi(q0[1] + d1, 0, maxq), clampi(q0[2] + d2, 0, maxq)};
-			const int c[3] = {fam4 ? ex4(q[0]) : ex5(q[0]), fam4 ? ex4(q[1]) : ex5(q[1]),
-				fam4 ? ex4(q[2]) : ex5(q[2])};
+			const int c[3] = {ex45(q[0], fam4), ex45(q[1], fam4), ex45(q[2], fam4)};
 			const uint32_t e = unitw ? half_err_fast<true>(ht8, o, c, tma, tmb)
 				: half_err_fast<false>(ht8, o, c, tma, tmb);
 			if (e < berr) {
@@ -589,8 +591,7 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 					q[0] = clampi(q[0] + (ax == 0 ? dd : 0), 0, maxq);
 					q[1] = clampi(q[1] + (ax == 1 ? dd : 0), 0, maxq);
 					q[2] = clampi(q[2] + (ax == 2 ? dd : 0), 0, maxq);
-					const int c[3] = {fam4 ? ex4(q[0]) : ex5(q[0]), fam4 ? ex4(q[1]) : ex5(q[1]),
-						fam4 ? ex4(q[2]) : ex5(q[2])};
+					const int c[3] = {ex45(q[0], fam4), ex45(q[1], fam4), ex45(q[2], fam4)};
 					const uint32_t e = unitw ? half_err_fast<true>(ht8, o, c, tma, tmb)
 						: half_err_fast<false>(ht8, o, c, tma, tmb);
 					if (e < be) {
