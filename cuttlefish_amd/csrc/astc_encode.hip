@@ -1377,25 +1377,27 @@ static size_t astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality, 
 // Launch shape of a footprint / quality: waves per workgroup (4, 8 or 12; a workgroup covers
 // 4 blocks per wave of one block row) and whether the texel-weight cache rows are carved.  The
 // choice maximises the waves resident on a CU (12 = three per SIMD with the 168-register build,
-// else 8), then prefers the cache, then the smaller workgroup (finer scheduling grain).
+// else 8), then prefers the smaller workgroup (finer scheduling grain), then the cache.
 extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t quality, uint32_t hdr, uint32_t* nwaves, uint32_t* wcached, size_t* lds_bytes)
 {
 	const size_t cu_lds = 160u*1024u, wg_max = 160u*1024u - 1024u;
 	const bool can_cache = h->n <= 36u;
 	uint32_t best_w = 0, best_nw = 4, best_c = 0;
 	static const char* const force = getenv("CFHIP_ASTC_WAVES");     // experiments: pin the workgroup shape
-	for (uint32_t c = 0; c < 2u; ++c) {
-		if (c && !can_cache)
-			break;
-		for (uint32_t nw = 4; nw <= 12u; nw += 4u) {
-			if (force && (uint32_t)atoi(force) != nw)
-				continue;
+	const uint32_t forced = (force && *force) ? (uint32_t)atoi(force) : 0u;
+	// most resident waves first; then the SMALLER workgroup (blocks differ in cost -- early outs --
+	// and a 12-wave workgroup holds its LDS until its slowest wave is done: 4x4 Normal 4.6 ms as one
+	// 12-wave workgroup with the cache, 4.2 ms as three 4-wave workgroups without); then the cache
+	for (uint32_t nw = 4; nw <= 12u; nw += 4u) {
+		if (forced && forced != nw)
+			continue;
+		for (uint32_t c = can_cache ? 2u : 1u; c-- > 0u;) {
 			const size_t b = astc_lds_bytes(h, quality, nw, c != 0u, hdr != 0u);
 			if (b > wg_max)
 				continue;
 			uint32_t w = (uint32_t)(cu_lds/(b + 1024u))*nw;      // 1024: the static outb + allocation granule
 			w = w >= 12u ? 12u : (w >= 8u ? 8u : w);
-			if (w > best_w || (w == best_w && c > best_c)) {
+			if (w > best_w) {
 				best_w = w; best_nw = nw; best_c = c;
 			}
 		}
