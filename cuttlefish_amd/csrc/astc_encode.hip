@@ -9,7 +9,7 @@
 // Emitted: void extent; 1-4 partitions (partition hash, shortlist by k-means cluster matching
 // against the canonical seed list); single / dual plane; every weight grid N x M <= footprint
 // and weight range (bits, trits, quints); endpoint modes 8/12 (with and without blue
-// contraction), 6/10, 0/4 at the colour quantisation level the remaining bits allow.  Type::UFloat
+// contraction), 6/10, 0/4, 9/13 (base + offset, 4x4 and 5x4) at the colour quantisation level the remaining bits allow.  Type::UFloat
 // (the HDR profiles, AstcConverter.cpp:150-162): the loader turns every HDR channel into the top
 // 8 bits of its 16-bit LNS value, the same search runs on those bytes, and the endpoints leave
 // through the direct sub-mode of CEM 11 / 14 / 15 (hdr_code, quant_hi, cem_option).
@@ -318,6 +318,48 @@ __device__ __forceinline__ bool cem_option(const Shared& sh, int o, uint32_t lv,
 			vals[7] = contract ? s6 : s7;
 			est = fmaf((float)cw[3], quad_est(fA[3], fB[3], fC[3], (float)d0[3] - r0[3], (float)d1[3] - r1[3]), est);
 		}
+	} else if (o == 3) {
+		// base + offset (CEM 9 / 13; oracle: base_offset): v_even = the base's low 7 bits (its own LSB is
+		// dropped by the decoder's bit transfer), v_odd = the base's top bit | the 6-bit signed offset << 1;
+		// e0 = base, e1 = base + offset.  Only the form with a non-negative offset sum (a negative one
+		// makes the decoder swap and blue-contract the pair)
+		int offsum = 0;
+		bool ok = true;
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			if (c < 3 || has_alpha) {
+				const int B = (int)floorf(clampf255(r0[c]) + 0.5f), E = (int)floorf(clampf255(r1[c]) + 0.5f);
+				const uint32_t t0 = (uint32_t)(B & 0x7F) << 1;
+				const uint32_t qa = sh.cnear[lv*256u + t0], qb = sh.cnear[lv*256u + (t0 | 1u)];
+				const int ua = (int)sh.cunq[lv*256u + qa], ub_ = (int)sh.cunq[lv*256u + qb];
+				const int da = abs((ua >> 1) - (B & 0x7F)), db = abs((ub_ >> 1) - (B & 0x7F));
+				const uint32_t q0 = db < da ? qb : qa;
+				const int u0 = db < da ? ub_ : ua;
+				const int hb = B & 0x80, base = hb | (u0 >> 1);
+				const int D = E - base;
+				ok = ok && D >= -32 && D <= 31;
+				const uint32_t t1 = (uint32_t)hb | ((uint32_t)(D & 0x3F) << 1);
+				const uint32_t qc = sh.cnear[lv*256u + (t1 & 255u)], qd = sh.cnear[lv*256u + ((t1 | 1u) & 255u)];
+				const int uc = (int)sh.cunq[lv*256u + qc], ud = (int)sh.cunq[lv*256u + qd];
+				int ac = (uc >> 1) & 0x3F, ad = (ud >> 1) & 0x3F;
+				ac = (ac & 0x20) ? ac - 0x40 : ac;
+				ad = (ad & 0x20) ? ad - 0x40 : ad;
+				const bool vc = (uc & 0x80) == hb, vd = (ud & 0x80) == hb;
+				const int ec = vc ? abs(ac - D) : 1000, ed = vd ? abs(ad - D) : 1000;
+				const bool pick_d = ed < ec;
+				ok = ok && (vc || vd);
+				const int a = pick_d ? ad : ac;
+				vals[2*c] = q0;
+				vals[2*c + 1] = pick_d ? qd : qc;
+				d0[c] = base;
+				const int e1v = base + a;
+				d1[c] = e1v < 0 ? 0 : (e1v > 255 ? 255 : e1v);
+				if (c < 3) offsum += a;
+				est = fmaf((float)cw[c], quad_est(fA[c], fB[c], fC[c], (float)d0[c] - r0[c], (float)d1[c] - r1[c]), est);
+			}
+		}
+		if (!ok || offsum < 0)
+			return false;
 	} else if (o == 1) {
 		float num = 0.0f, dn = 0.0f;
 #pragma unroll
@@ -1141,13 +1183,15 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					};
 					// 4. endpoint mode by the quadratic estimate (same mode for every partition):
 					// option o = 0 direct (CEM 8/12), 1 base + scale (6/10), 2 luminance (0/4)
-					float est[3] = {0.0f, 0.0f, 0.0f};
-					bool okk[3];
-					int lvs[3];
+					// option o = 3: base + offset (CEM 9 / 13), the value count of the direct mode
+					float est[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+					bool okk[4];
+					int lvs[4];
 #pragma unroll
-					for (int o = 0; o < 3; ++o) {
-						const uint32_t nv = (has_alpha ? 8u : 6u) - 2u*(uint32_t)o;
-						okk[o] = !(nv*P > 18u || (o == 2 && !grey) || (o > 0 && dual && ccs < 3u) || (o > 0 && hdrf));
+					for (int o = 0; o < 4; ++o) {
+						const uint32_t nv = (has_alpha ? 8u : 6u) - (o == 3 ? 0u : 2u*(uint32_t)o);
+						okk[o] = !(nv*P > 18u || (o == 2 && !grey) || ((o == 1 || o == 2) && dual && ccs < 3u) || (o > 0 && hdrf) ||
+							(o == 3 && n > 20u));   // base + offset: 4x4 and 5x4 only (oracle: same rule)
 						lvs[o] = okk[o] ? (int)clevel[(nv*P/2u)*132u + cfg.cbits] : -1;
 						okk[o] = okk[o] && lvs[o] >= 0;
 					}
@@ -1157,7 +1201,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						solve(p, r0, r1, cA, cB, cC);
 						uint32_t d0p, d1p, vals[8];
 #pragma unroll
-						for (int o = 0; o < 3; ++o)
+						for (int o = 0; o < 4; ++o)
 							if (okk[o])
 								okk[o] = cem_option(sh, o, (uint32_t)lvs[o], has_alpha, hdrf, r0, r1, cA, cB, cC, cw, est[o], d0p, d1p, vals);
 					}
@@ -1165,12 +1209,12 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					int best_opt = -1;
 					uint32_t best_lv = 0;
 #pragma unroll
-					for (int o = 0; o < 3; ++o)
+					for (int o = 0; o < 4; ++o)
 						if (okk[o] && est[o] < best_est) { best_est = est[o]; best_opt = o; best_lv = (uint32_t)lvs[o]; }
 					if (best_opt >= 0) {
 						// materialise the chosen option: decoded endpoints + stored values
 						uint32_t D0[4] = {0, 0, 0, 0}, D1[4] = {0, 0, 0, 0};
-						const uint32_t nv = (has_alpha ? 8u : 6u) - 2u*(uint32_t)best_opt;
+						const uint32_t nv = (has_alpha ? 8u : 6u) - (best_opt == 3 ? 0u : 2u*(uint32_t)best_opt);
 #pragma unroll 1
 						for (uint32_t p = 0; p < P; ++p) {
 							float r0[4], r1[4], cA[4], cB[4], cC[4];
@@ -1236,7 +1280,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						}
 						err = e64;
 						r_cem = hdrf ? (has_alpha ? ((hdrf & 2u) ? 15u : 14u) : 11u)
-							: (has_alpha ? 12u : 8u) - (best_opt == 1 ? 2u : (best_opt == 2 ? 8u : 0u));
+							: (best_opt == 3 ? (has_alpha ? 13u : 9u)
+								: (has_alpha ? 12u : 8u) - (best_opt == 1 ? 2u : (best_opt == 2 ? 8u : 0u)));
 						r_lv = best_lv;
 						r_ncv = nv*P;
 					}

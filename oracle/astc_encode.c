@@ -13,7 +13,8 @@
  * Emitted: void extent; 1-4 partitions (partition hash, canonical de-duplicated seed list,
  * shortlist by k-means cluster matching); single and dual plane; weight grids N x M <= footprint
  * with every weight range (bits / trits / quints); endpoint modes 8/12 (direct, with and
- * without blue contraction), 6/10 (base + scale), 0/4 (luminance), all at the colour
+ * without blue contraction), 6/10 (base + scale), 0/4 (luminance), 9/13 (base + offset; 4x4 and
+ * 5x4 only), all at the colour
  * quantisation level the remaining bits allow (ISE).  ASTCENC_FLG_USE_ALPHA_WEIGHT and
  * ASTCENC_FLG_USE_PERCEPTUAL (AstcConverter.cpp:163-172) enter the error metric.
  * Type::UFloat (ASTCENC_PRF_HDR / HDR_RGB_LDR_A, :150-162): HDR endpoint modes 11 / 14 / 15 in
@@ -494,6 +495,51 @@ static float quad_est(float fA, float fB, float fC, float d0, float d1)
 	return q;
 }
 
+/* One channel of the base + offset modes: stored values for base x0 and second endpoint x1 at
+ * colour level lv, the endpoints they decode to, the decoded offset added to *offsum (colour
+ * channels).  0 when the pair cannot be expressed (offset out of [-32, 31], or no stored value
+ * with the base's top bit). */
+static int base_offset(const astc_tables* T, int lv, float x0, float x1, int* s0, int* s1, int* d0, int* d1,
+	int* offsum, int colour)
+{
+	int B = (int)floorf(clampf255(x0) + 0.5f), E = (int)floorf(clampf255(x1) + 0.5f);
+	int t0 = (B & 0x7F) << 1;
+	int best0 = -1, bd = 1000;
+	for (int k = 0; k < 2; ++k) {                    /* the stored LSB is free: both neighbours */
+		int q = T->c_near[lv][t0 | k], u = T->c_unq[lv][q];
+		int d = abs((u >> 1) - (B & 0x7F));
+		if (d < bd) { bd = d; best0 = q; }
+	}
+	int u0 = T->c_unq[lv][best0];
+	int hb = B & 0x80, base = hb | (u0 >> 1);
+	int D = E - base;
+	if (D < -32 || D > 31)
+		return 0;
+	int t1 = hb | ((D & 0x3F) << 1);
+	int best1 = -1;
+	bd = 1000;
+	for (int k = 0; k < 2; ++k) {
+		int q = T->c_near[lv][t1 | k], u = T->c_unq[lv][q];
+		if ((u & 0x80) != hb)
+			continue;
+		int a = (u >> 1) & 0x3F;
+		if (a & 0x20) a -= 0x40;
+		int d = abs(a - D);
+		if (d < bd) { bd = d; best1 = q; }
+	}
+	if (best1 < 0)
+		return 0;
+	int u1 = T->c_unq[lv][best1];
+	int a = (u1 >> 1) & 0x3F;
+	if (a & 0x20) a -= 0x40;
+	*s0 = best0; *s1 = best1;
+	*d0 = base;
+	*d1 = base + a < 0 ? 0 : (base + a > 255 ? 255 : base + a);
+	if (colour)
+		*offsum += a;
+	return 1;
+}
+
 static void phase_b(const astc_blk* b, int j, const astc_pc* pc, const astc_cfg* cfg, astc_lane* L)
 {
 	const astc_tables* T = astc_get_tables();
@@ -573,17 +619,18 @@ static void phase_b(const astc_blk* b, int j, const astc_pc* pc, const astc_cfg*
 		for (int p = 0; p < P; ++p) { r0[p][3] = 255.0f; r1[p][3] = 255.0f; }
 	/* 4. endpoint mode + quantisation: options 0 = direct RGB(A) (CEM 8 / 12, blue contraction
 	 * decided per partition), 1 = base + scale (6 / 10), 2 = luminance (0 / 4) */
-	int nvo[3] = {b->has_alpha ? 8 : 6, b->has_alpha ? 6 : 4, b->has_alpha ? 4 : 2};
-	int cemo[3] = {b->has_alpha ? 12 : 8, b->has_alpha ? 10 : 6, b->has_alpha ? 4 : 0};
+	int nvo[4] = {b->has_alpha ? 8 : 6, b->has_alpha ? 6 : 4, b->has_alpha ? 4 : 2, b->has_alpha ? 8 : 6};
+	int cemo[4] = {b->has_alpha ? 12 : 8, b->has_alpha ? 10 : 6, b->has_alpha ? 4 : 0, b->has_alpha ? 13 : 9};
 	if (b->hdr)     /* HDR RGB direct (11), + LDR alpha (14), + HDR alpha (15); no other option */
 		cemo[0] = b->has_alpha ? (b->hdr_alpha ? 15 : 14) : 11;
 	float best_est = 3.0e38f;
 	int best_opt = -1;
-	int D0[3][4][4], D1[3][4][4];
-	uint8_t cv[3][18];
-	for (int o = 0; o < 3; ++o) {
+	int D0[4][4][4], D1[4][4][4];
+	uint8_t cv[4][18];
+	for (int o = 0; o < 4; ++o) {
 		int nv = nvo[o];
-		if (nv*P > 18 || (o == 2 && !b->grey) || (o > 0 && pc->dual && pc->ccs < 3) || (o > 0 && b->hdr))
+		if (nv*P > 18 || (o == 2 && !b->grey) || ((o == 1 || o == 2) && pc->dual && pc->ccs < 3) || (o > 0 && b->hdr) ||
+			(o == 3 && n > 20))    /* base + offset pays on 4x4 / 5x4 only: +0.35 / +0.24 dB there, <= 0.06 dB elsewhere */
 			continue;
 		int lv = T->c_level[nv*P/2][cfg->cbits];
 		if (lv < 0 || cfg->cbits < (13*nv*P + 4)/5)
@@ -712,6 +759,24 @@ static void phase_b(const astc_blk* b, int j, const astc_pc* pc, const astc_cfg*
 					est = fmaf((float)b->cw[3], quad_est(fA[aset], fB[aset], fC[aset],
 						(float)d0[3] - r0[p][3], (float)d1[3] - r1[p][3]), est);
 				}
+			} else if (o == 3) {
+				/* base + offset (CEM 9 / 13): per channel v_even = the low 7 bits of the base (its own LSB
+				 * is dropped by the decoder's bit transfer), v_odd = the base's top bit | the 6-bit
+				 * signed offset << 1; e0 = base, e1 = base + offset.  Only the form with a
+				 * non-negative offset sum is used (a negative sum makes the decoder swap and
+				 * blue-contract the pair) */
+				int offsum = 0;
+				for (int c = 0; c < (b->has_alpha ? 4 : 3) && ok; ++c) {
+					int s0, s1;
+					if (!base_offset(T, lv, r0[p][c], r1[p][c], &s0, &s1, &d0[c], &d1[c], &offsum, c < 3)) { ok = 0; break; }
+					vals[2*c] = (uint8_t)s0; vals[2*c + 1] = (uint8_t)s1;
+					int cs = c < 3 ? cset[c] : aset;
+					est = fmaf((float)b->cw[c], quad_est(fA[cs], fB[cs], fC[cs],
+						(float)d0[c] - r0[p][c], (float)d1[c] - r1[p][c]), est);
+				}
+				if (!b->has_alpha) { d0[3] = 255; d1[3] = 255; }
+				if (ok && offsum < 0) ok = 0;
+				if (!ok) break;
 			} else {
 				/* luminance (grey blocks: r = g = b) */
 				int s0, s1;

@@ -40,7 +40,7 @@ def test_solid_blocks_are_void_extent_per_spec():
 
 def test_block_header_fields_and_features_in_use():
     """Non-constant blocks: legal partition counts, the endpoint modes this encoder emits
-    (0/4 luminance, 6/10 base + scale, 8/12 direct), and -- on content with hard edges, an alpha
+    (0/4 luminance, 6/10 base + scale, 8/12 direct, 9/13 base + offset), and -- on content with hard edges, an alpha
     band and smooth areas -- multi-partition blocks, dual-plane blocks and trit / quint weight
     ranges are all actually chosen."""
     img = synth.photo(144, 144, seed=5, alpha=True)
@@ -62,9 +62,16 @@ def test_block_header_fields_and_features_in_use():
             dual += (v >> 10) & 1
         r = ((v >> 4) & 1) | (((v & 3) if v & 3 else (v >> 2) & 3) << 1)
         triq += r in (3, 5, 6)
-    assert cems <= {0, 4, 6, 8, 10, 12} and len(cems) >= 3
+    assert cems <= {0, 4, 6, 8, 10, 12} and len(cems) >= 3          # (base + offset: 4x4 / 5x4 only)
     assert parts[1] > 0 and parts[2] > 0 and parts[4] == 0
     assert dual > 0 and triq > 0
+    # base + offset (CEM 9 / 13) is searched on the two smallest footprints, where it pays
+    cem44 = set()
+    for b in O.encode(img, 43, quality=2, threads=8).reshape(-1, 16):
+        v = int.from_bytes(bytes(b), "little")
+        if (v & 0x1FF) != 0x1FC and ((v >> 11) & 3) == 0:
+            cem44.add((v >> 13) & 15)
+    assert 9 in cem44 and 13 in cem44 and cem44 <= {0, 4, 6, 8, 9, 10, 12, 13}
     # three flat colour regions crossing the blocks: three-partition blocks are chosen too
     rng = np.random.default_rng(3)
     yy, xx = np.mgrid[0:96, 0:96]
