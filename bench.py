@@ -370,6 +370,12 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if local_rank == 0 and not os.environ.get("CFHIP_LIB"):
+        # never measure a library older than its sources (content hash, cuttlefish_amd/build.py):
+        # a no-op after `__graft_entry__.build()`, one hipcc run otherwise
+        from cuttlefish_amd import build as _build
+        if _build.is_stale():
+            _build.build()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
