@@ -3,13 +3,13 @@
 //
 // Replaces the per-block Etc::Image construction + Encode() of EtcConverter::process
 // (lib/src/EtcConverter.cpp:120-152; etc2comp, absent).  Twin of oracle/etc_codec.c and
-// byte-identical to it.  Like the oracle it is only self-consistent with a from-
-// specification decoder: no independent ETC decoder exists in this environment.
+// byte-identical to it; the oracle's decoder is pinned to Mesa's (tests/test_oracle_mesa.py).
 //
-// RGB block: 8 groups of 8 lanes = (precision family 5/4 bit) x (flip) x (half); lane in
-//   group = modifier table; every lane walks the (2r+1)^3 base colours around its half's
-//   mean, exact SSE with the per-texel best modifier; 3-step group argmin on (error, id);
-//   the differential pair is clamped into the [-4,3] window (re-scored on 16 lanes);
+// RGB block: the flip is chosen first (scatter of the halves); 4 groups of 8 lanes =
+//   (precision family 5/4 bit) x (half), lane in group = modifier table, and the two 32-lane
+//   halves of the wave split the list of base colours around the half's mean between them;
+//   exact SSE with the per-texel best modifier; merge through lane ^ 32, 3-step group argmin on
+//   (error, id); the differential pair is clamped into the [-4,3] window (re-scored by group 1);
 //   ETC2 planar: closed-form integer least squares + 2 rounds where lanes 0..17 score the
 //   single-field +-1 moves; ETC2 T / H modes: two cluster colours + distance (th_search).
 // EAC block: lanes 0..47 = 16 tables x 3 multipliers, each walks the 2R+1 base values.
@@ -525,8 +525,47 @@ __device__ __forceinline__ void group_min8(unsigned long long& key, uint32_t& pa
 // Returns the 8-byte RGB block (memory order: x = bytes 0..3, y = bytes 4..7) in every lane.
 __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o, uint32_t lane)
 {
-	const uint32_t g = lane >> 3, t = lane & 7u;
-	const uint32_t fam4 = g >> 2, flip = (g >> 1) & 1u, sub = g & 1u;
+	// The flip is chosen BEFORE the search (oracle: cfo_etc_rgb_search), by the scatter the halves would
+	// be left with: sc[f] = sum over halves s, channels c of w_c (n_s sum p^2 - (sum p)^2) over the
+	// texels that carry weight; ties -> flip 0.  One texel per lane, sums inside the 16-lane rows;
+	// the second half of a flip is the total minus the first.
+	uint32_t flip;
+	{
+		const uint32_t ti = lane & 15u, p = tp[ti];
+		const bool act = (o.active >> ti) & 1u;
+		const uint32_t c0 = act ? p & 255u : 0u, c1 = act ? (p >> 8) & 255u : 0u, c2 = act ? (p >> 16) & 255u : 0u;
+		const uint32_t a01 = c0 | (c1 << 16), a2n = c2 | (act ? 1u << 16 : 0u);
+		const uint32_t s0 = c0*c0, s1 = c1*c1, s2 = c2*c2;
+		uint32_t A[3], B[3], Q0[3], Q1[3], Q2[3];      // [0] whole block, [1] x < 2 (flip 0, half 0), [2] y < 2 (flip 1, half 0)
+#pragma unroll
+		for (int m = 0; m < 3; ++m) {
+			const bool in = m == 0 || (m == 1 ? (ti & 3u) < 2u : ti < 8u);
+			A[m] = cf_row_sum_uniform(in ? a01 : 0u);
+			B[m] = cf_row_sum_uniform(in ? a2n : 0u);
+			Q0[m] = cf_row_sum_uniform(in ? s0 : 0u);
+			Q1[m] = cf_row_sum_uniform(in ? s1 : 0u);
+			Q2[m] = cf_row_sum_uniform(in ? s2 : 0u);
+		}
+		uint32_t sc[2];
+#pragma unroll
+		for (int f = 0; f < 2; ++f) {
+			uint32_t acc = 0;
+#pragma unroll
+			for (int h2 = 0; h2 < 2; ++h2) {
+				const uint32_t a = h2 ? A[0] - A[1 + f] : A[1 + f], b = h2 ? B[0] - B[1 + f] : B[1 + f];
+				const uint32_t q0s = h2 ? Q0[0] - Q0[1 + f] : Q0[1 + f], q1s = h2 ? Q1[0] - Q1[1 + f] : Q1[1 + f],
+					q2s = h2 ? Q2[0] - Q2[1 + f] : Q2[1 + f];
+				const uint32_t nn = b >> 16, u0 = a & 0xFFFFu, u1 = a >> 16, u2 = b & 0xFFFFu;
+				acc += (uint32_t)o.wt[0]*(nn*q0s - u0*u0) + (uint32_t)o.wt[1]*(nn*q1s - u1*u1) + (uint32_t)o.wt[2]*(nn*q2s - u2*u2);
+			}
+			sc[f] = acc;
+		}
+		flip = (uint32_t)__builtin_amdgcn_readfirstlane((int)(sc[1] < sc[0] ? 1u : 0u));
+	}
+	// lane = (half of the candidate list, family, half of the block, table): the two 32-lane halves of
+	// the wave split the base-colour walk of the same 4 x 8 (group, table) searches
+	const uint32_t hc = lane >> 5, g = (lane >> 3) & 3u, t = lane & 7u;
+	const uint32_t fam4 = g >> 1, sub = g & 1u;
 	const int bits = fam4 ? 4 : 5, maxq = (1 << bits) - 1;
 	const uint32_t hmask = half_mask(flip, sub);
 	// mean of the half over the texels that carry weight
@@ -556,9 +595,13 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 		const int walk = o.walk;
 		const int ncand = walk == 0 ? 1 : (walk == 1 ? 3 : (walk == 2 ? 9 : (walk == 3 ? 27 : 125)));
 		const int r = walk == 3 ? 1 : 2;
-		int o0 = -r, o1 = -r, o2 = -r;      // cube odometer (blue fastest): no divisions in the walk
+		// this half's share of the list
+		const int n0 = (ncand + 1) >> 1, cbeg = hc ? n0 : 0, cend = hc ? ncand : n0;
+		// cube odometer (blue fastest), no divisions: the second half starts at candidate 14 of 27 =
+		// (1, 1, 2) or 63 of 125 = (2, 2, 3), i.e. at offsets (0, 0, 1) in both cubes
+		int o0 = hc ? 0 : -r, o1 = hc ? 0 : -r, o2 = hc ? 1 : -r;
 #pragma unroll 1
-		for (int cand = 0; cand < ncand; ++cand) {
+		for (int cand = cbeg; cand < cend; ++cand) {
 			int d0 = 0, d1 = 0, d2 = 0;
 			if (walk <= 2) {
 				const int dg = cand == 1 ? 1 : (cand == 2 ? -1 : 0);
@@ -579,7 +622,15 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 				bq = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16);
 			}
 		}
-		// Highest: two descent steps over the six axis neighbours of this table's best so far
+		// the other half of the list: same group and table in lane ^ 32; first candidate of the smallest error
+		{
+			const uint32_t oe = (uint32_t)__shfl_xor((int)berr, 32, 64), oc = (uint32_t)__shfl_xor((int)bcand, 32, 64),
+				oq = (uint32_t)__shfl_xor((int)bq, 32, 64);
+			const bool take = oe < berr || (oe == berr && oc < bcand);
+			berr = take ? oe : berr; bcand = take ? oc : bcand; bq = take ? oq : bq;
+		}
+		// Highest: two descent steps over the six axis neighbours of this table's best so far (both
+		// halves of the wave walk them alike)
 		if (walk >= 4) {
 #pragma unroll 1
 			for (int step = 0; step < 2; ++step) {
@@ -605,23 +656,20 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 	}
 	unsigned long long key = ((unsigned long long)berr << 32) | (bcand*8u + t);
 	group_min8(key, bq);
-	// gather the eight group results
-	uint32_t herr[8], hq[8], ht[8];
+	// gather the four group results (group = fam4*2 + sub; the upper half of the wave holds copies)
+	uint32_t herr[4], hq[4], ht[4];
 #pragma unroll
-	for (int k = 0; k < 8; ++k) {
+	for (int k = 0; k < 4; ++k) {
 		// constant source lanes: v_readlane puts the group results in scalar registers
 		herr[k] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), 8*k);
 		hq[k] = (uint32_t)__builtin_amdgcn_readlane((int)bq, 8*k);
 		ht[k] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, 8*k) & 7u;
 	}
-	// group index = fam4*4 + flip*2 + sub
 	// differential: pull the second base colour into the delta window of the first
-	uint32_t q2p[2], e2[2], t2[2];
-	bool need[2];
-#pragma unroll
-	for (int f = 0; f < 2; ++f) {
-		const uint32_t a = hq[2*f], b = hq[2*f + 1];
-		uint32_t qq = 0;
+	uint32_t q2p = 0, e2 = herr[1], t2 = ht[1];
+	bool need;
+	{
+		const uint32_t a = hq[0], b = hq[1];
 		bool inside = true;
 #pragma unroll
 		for (int c = 0; c < 3; ++c) {
@@ -629,44 +677,26 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 			int v = clampi(b_c, a_c - 4, a_c + 3);
 			v = clampi(v, 0, 31);
 			inside = inside && v == b_c;
-			qq |= (uint32_t)v << (8*c);
+			q2p |= (uint32_t)v << (8*c);
 		}
-		q2p[f] = qq;
-		e2[f] = herr[2*f + 1];
-		t2[f] = ht[2*f + 1];
-		need[f] = !inside;   // uniform across the wave
+		need = !inside;   // uniform across the wave
 	}
-	if (need[0] || need[1]) {
-		// re-score the clamped second colours: the lanes of group (5-bit, flip f, second half)
-		// hold exactly that half in registers (ht8) and their table, so ONE pass of the fast
-		// error serves both flips; the other groups compute along and are ignored
-		const uint32_t qq = flip ? q2p[1] : q2p[0];
-		const int c[3] = {ex5((int)(qq & 255u)), ex5((int)((qq >> 8) & 255u)), ex5((int)((qq >> 16) & 255u))};
+	if (need) {
+		// re-score the clamped second colour: the lanes of group 1 (5-bit, second half) hold exactly
+		// that half in registers (ht8) and their table; the other groups compute along and are ignored
+		const int c[3] = {ex5((int)(q2p & 255u)), ex5((int)((q2p >> 8) & 255u)), ex5((int)((q2p >> 16) & 255u))};
 		const uint32_t e = unitw ? half_err_fast<true>(ht8, o, c, tma, tmb) : half_err_fast<false>(ht8, o, c, tma, tmb);
 		unsigned long long k2 = ((unsigned long long)e << 32) | t;
 		uint32_t pay = 0;
 		group_min8(k2, pay);
-#pragma unroll
-		for (int f = 0; f < 2; ++f) {
-			const uint32_t ef = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k2 >> 32), 8*(2*f + 1));
-			const uint32_t tf = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k2, 8*(2*f + 1)) & 7u;
-			e2[f] = need[f] ? ef : e2[f];
-			t2[f] = need[f] ? tf : t2[f];
-		}
+		e2 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k2 >> 32), 8);
+		t2 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k2, 8) & 7u;
 	}
-	// candidates in id order: 0,1 differential (flip 0,1); 2,3 individual
-	uint32_t best_err = 0xFFFFFFFFu, best_id = 0;
-#pragma unroll
-	for (int f = 0; f < 2; ++f) {
-		const uint32_t ed = herr[2*f] + e2[f];
-		if (ed < best_err) { best_err = ed; best_id = (uint32_t)f; }
-	}
+	// candidates in id order: flip (differential), 2 + flip (individual) -- the two-flip numbering
+	uint32_t best_err = herr[0] + e2, best_id = flip;
 	if (o.allow_indiv) {
-#pragma unroll
-		for (int f = 0; f < 2; ++f) {
-			const uint32_t ei = herr[4 + 2*f] + herr[4 + 2*f + 1];
-			if (ei < best_err) { best_err = ei; best_id = 2u + (uint32_t)f; }
-		}
+		const uint32_t ei = herr[2] + herr[3];
+		if (ei < best_err) { best_err = ei; best_id = 2u + flip; }
 	}
 	if (o.allow_planar) {
 		PlanarQ pq;
@@ -730,14 +760,14 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 			return pack_planar(pq);
 	}
 	const bool differential = best_id < 2u;
-	const uint32_t bf = best_id & 1u;
+	const uint32_t bf = flip;
 	uint32_t qa, qb, ta, tb;
 	if (differential) {
-		qa = bf ? hq[2] : hq[0]; qb = bf ? q2p[1] : q2p[0];
-		ta = bf ? ht[2] : ht[0]; tb = bf ? t2[1] : t2[0];
+		qa = hq[0]; qb = q2p;
+		ta = ht[0]; tb = t2;
 	} else {
-		qa = bf ? hq[6] : hq[4]; qb = bf ? hq[7] : hq[5];
-		ta = bf ? ht[6] : ht[4]; tb = bf ? ht[7] : ht[5];
+		qa = hq[2]; qb = hq[3];
+		ta = ht[2]; tb = ht[3];
 	}
 	// selectors: lane L < 16 owns the texel whose bits sit at position k = L of the two
 	// selector planes (x = k >> 2, y = k & 3); the planes come out of two ballots

@@ -13,7 +13,7 @@
  * only SELF-consistent with it -- stated in DESIGN.md; the judge's "partial" cap applies.
  *
  * Encoder (all integer, scalar twin of the HIP kernel):
- *   RGB block: for both flips, per half: 27 (radius 1) base colours around the half's
+ *   RGB block: for the flip with the smaller within-half scatter, per half: base colours around the half's
  *   mean in 5-bit (differential) and 4-bit (individual) precision x 8 modifier tables,
  *   exact SSE with per-texel best modifier; differential pairs are clamped into the
  *   [-4,3] delta window; ETC2 adds the planar mode (closed-form integer least squares +
@@ -729,7 +729,31 @@ void cfo_etc_rgb_search(const int px[16][4], const rgb_opts* o, uint8_t out[8])
 	int bq[2][3], bt[2];
 	memset(bq, 0, sizeof(bq));
 	memset(bt, 0, sizeof(bt));
+	/* The flip is chosen BEFORE the search, by the scatter the two halves would be left with:
+	 * sc[f] = sum over halves s and channels c of w_c (n_s sum p^2 - (sum p)^2) over the texels that
+	 * carry weight (an integer; for full halves n_s = 8, so this orders like the within-half
+	 * variance); ties -> flip 0.  Searching both flips costs the kernel half of its lanes and buys
+	 * 0.001 dB on ETC2 and 0.02 dB on ETC1 at Normal (0.1 dB at Lowest): with one flip the lanes
+	 * split the base-colour walk instead.  Candidate ids keep their two-flip numbering. */
+	int only_flip;
+	{
+		long long sc[2] = {0, 0};
+		for (int flip = 0; flip < 2; ++flip)
+			for (int s2 = 0; s2 < 2; ++s2) {
+				int n = 0, su[3] = {0, 0, 0}, sq[3] = {0, 0, 0};
+				for (int i = 0; i < 16; ++i)
+					if (in_half(i, flip, s2) && ((o->active >> i) & 1)) {
+						++n;
+						for (int c = 0; c < 3; ++c) { su[c] += px[i][c]; sq[c] += px[i][c]*px[i][c]; }
+					}
+				for (int c = 0; c < 3; ++c)
+					sc[flip] += (long long)o->wt[c]*(n*sq[c] - su[c]*su[c]);
+			}
+		only_flip = sc[1] < sc[0] ? 1 : 0;
+	}
 	for (int flip = 0; flip < 2; ++flip) {
+		if (flip != only_flip)
+			continue;
 		half_best h5[2], h4[2];
 		for (int s = 0; s < 2; ++s) {
 			search_half(px, o, flip, s, 5, &h5[s]);
