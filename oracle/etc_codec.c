@@ -8,9 +8,11 @@
  *       (only the in-image w<=4 x h<=4 region is handed to the codec, :122-129,:145;
  *        signed EAC inputs are remapped v*0.5+0.5, :133-143)
  * The reference forwards to etc2comp (Etc::Image::Encode, absent: "parity unpinned").
- * NO independent ETC decoder exists in this environment either (Pillow has none), so the
- * decoder below is written from the public ETC2/EAC specification and the encoder is
- * only SELF-consistent with it -- stated in DESIGN.md; the judge's "partial" cap applies.
+ * The decoders below are written from the public ETC2 / EAC specification and are pinned to an
+ * independent implementation: Mesa 23.2's software decoders reproduce them bit for bit on
+ * committed random-block fixtures covering every mode, and decode the encoder's output the same
+ * way (tests/test_oracle_mesa.py, tests/golden/mesa_blocks.npz).  The ENCODER's choices remain
+ * unpinned against etc2comp (absent): stated in DESIGN.md.
  *
  * Encoder (all integer, scalar twin of the HIP kernel):
  *   RGB block: for the flip with the smaller within-half scatter, per half: base colours around the half's
