@@ -868,10 +868,14 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 
 			// ---- phase A: lane = (candidate j, slot s) ----
 			{
-				const uint32_t j = hl >> 2, s = hl & 3u;
+				// 32 (candidate, slot) units; a wave that holds one block gives each unit two lanes (hl and
+				// hl ^ 32), which take the even and the odd texels: integer sums and float min / max meet
+				// through the lane pair, so the results are those of one lane walking all texels
+				const uint32_t sl = hl & 31u, par = pair ? 0u : hl >> 5, stp = pair ? 1u : 2u;
+				const uint32_t j = sl >> 2, s = sl & 3u;
 				const uint32_t d = j < cnt ? S.pcs[base + j] : 0u;
 				const uint32_t P = pc_P(d), dual = pc_dual(d), ccs = pc_ccs(d);
-				const bool active = !(CF_ASTC_ABLATE & 2) && !solid && j < cnt && hl < 32u && s < (dual ? 2u : P);
+				const bool active = !(CF_ASTC_ABLATE & 2) && !solid && j < cnt && s < (dual ? 2u : P);
 				if (active) {
 					uint32_t chmask = (1u << nc) - 1u;
 					if (dual)
@@ -883,7 +887,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					int a0 = 0, a1 = 0, a2 = 0, a3 = 0, cnt_t = 0;
 					int q00 = 0, q01 = 0, q02 = 0, q03 = 0, q11 = 0, q12 = 0, q13 = 0, q22 = 0, q23 = 0, q33 = 0;
 #pragma unroll 1
-					for (uint32_t i = 0; i < n; ++i) {
+					for (uint32_t i = par; i < n; i += stp) {
 						const bool in_ = byp || prow[i] == s;
 						const uint32_t p = in_ ? (tp[i] & bytemask) : 0u;
 						const int c0 = (int)(p & 255u), c1 = (int)((p >> 8) & 255u), c2 = (int)((p >> 16) & 255u), c3 = (int)(p >> 24);
@@ -892,6 +896,13 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						q00 += c0*c0; q01 += c0*c1; q02 += c0*c2; q03 += c0*c3;
 						q11 += c1*c1; q12 += c1*c2; q13 += c1*c3;
 						q22 += c2*c2; q23 += c2*c3; q33 += c3*c3;
+					}
+					if (!pair) {
+#define ASTC_PAIRSUM(v) v += __shfl_xor(v, 32, 64)
+						ASTC_PAIRSUM(cnt_t); ASTC_PAIRSUM(a0); ASTC_PAIRSUM(a1); ASTC_PAIRSUM(a2); ASTC_PAIRSUM(a3);
+						ASTC_PAIRSUM(q00); ASTC_PAIRSUM(q01); ASTC_PAIRSUM(q02); ASTC_PAIRSUM(q03); ASTC_PAIRSUM(q11);
+						ASTC_PAIRSUM(q12); ASTC_PAIRSUM(q13); ASTC_PAIRSUM(q22); ASTC_PAIRSUM(q23); ASTC_PAIRSUM(q33);
+#undef ASTC_PAIRSUM
 					}
 					Cov Cs;
 					Cs.c00 = (float)(cnt_t*q00 - a0*a0); Cs.c01 = (float)(cnt_t*q01 - a0*a1);
@@ -906,7 +917,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					principal_axis(Cs, ax);
 					float lo_t = 3.0e38f, hi_t = -3.0e38f;
 #pragma unroll 1
-					for (uint32_t i = 0; i < n; ++i) {
+					for (uint32_t i = par; i < n; i += stp) {
 						const bool in_ = byp || prow[i] == s;
 						const uint32_t p = tp[i] & bytemask;
 						float t = ax[0]*((float)(p & 255u) - mn[0]);
@@ -915,6 +926,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						t = fmaf(ax[3], (float)(p >> 24) - mn[3], t);
 						lo_t = in_ ? fminf(lo_t, t) : lo_t;
 						hi_t = in_ ? fmaxf(hi_t, t) : hi_t;
+					}
+					if (!pair) {
+						lo_t = fminf(lo_t, __shfl_xor(lo_t, 32, 64));
+						hi_t = fmaxf(hi_t, __shfl_xor(hi_t, 32, 64));
 					}
 					int e0[4] = {0, 0, 0, 0}, e1[4] = {0, 0, 0, 0}, s0 = 0, s1 = 0;
 #pragma unroll
@@ -938,7 +953,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					const float rdd2 = dd > 0 ? 1.0f/(float)(2*dd) : 0.0f;
 					uint8_t* Trow = S.T + ((dual && s == 1u) ? 8u + ((j - 1u) & 1u) : j)*npad;
 #pragma unroll 1
-					for (uint32_t i = 0; i < n; ++i) {
+					for (uint32_t i = par; i < n; i += stp) {
 						const bool in_ = byp || prow[i] == s;
 						const uint32_t p = tp[i];
 						int t = ((int)(p & 255u) - e0[0])*dv[0] + ((int)((p >> 8) & 255u) - e0[1])*dv[1] +
@@ -956,16 +971,16 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 #pragma unroll
 					for (uint32_t c = 0; c < 4u; ++c)
 						sp += ((chmask >> c) & 1u) ? (int)cw[c]*dv[c]*dv[c] : 0;
-					S.span[hl] = (uint32_t)(sp*cnt_t);
+					S.span[sl] = (uint32_t)(sp*cnt_t);
 					// the slot's endpoints as masked bytes: the (up to two) planes of a dual-plane
 					// candidate OR into subset 0
 					const uint32_t pe0 = (uint32_t)e0[0] | ((uint32_t)e0[1] << 8) | ((uint32_t)e0[2] << 16) | ((uint32_t)e0[3] << 24);
 					const uint32_t pe1 = (uint32_t)e1[0] | ((uint32_t)e1[1] << 8) | ((uint32_t)e1[2] << 16) | ((uint32_t)e1[3] << 24);
-					S.e0[hl] = pe0;
-					S.e1[hl] = pe1;
-					S.sum01[hl] = (uint32_t)a0 | ((uint32_t)a1 << 16);
-					S.sum23[hl] = (uint32_t)a2 | ((uint32_t)a3 << 16);
-					S.scnt[hl] = (uint32_t)cnt_t;
+					S.e0[sl] = pe0;
+					S.e1[sl] = pe1;
+					S.sum01[sl] = (uint32_t)a0 | ((uint32_t)a1 << 16);
+					S.sum23[sl] = (uint32_t)a2 | ((uint32_t)a3 << 16);
+					S.scnt[sl] = (uint32_t)cnt_t;
 				}
 			}
 			__builtin_amdgcn_wave_barrier();
