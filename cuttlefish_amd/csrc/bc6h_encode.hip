@@ -464,7 +464,8 @@ cfhip_bc6h_encode_kernel(cf_kparams kp)
 {
 	__shared__ uint32_t tile[CF_BLOCKS_PER_WG*16*3];
 	__shared__ uint4 outb[CF_BLOCKS_PER_WG];
-	__shared__ uint32_t cand_lds[(CF_WG_THREADS/64)*4*20];   // parked candidates, see below
+	__shared__ uint32_t cand_lds[CF_BLOCKS_PER_WG*20];   // one-subset candidate of every block
+	__shared__ uint32_t part_lds[CF_BLOCKS_PER_WG*20];   // best partition candidate of every block
 	uint32_t gx_, gy_;
 	cf_resolve(kp, gx_, gy_);
 	const uint32_t bx0 = gx_*CF_BLOCKS_PER_WG;
@@ -505,29 +506,30 @@ cfhip_bc6h_encode_kernel(cf_kparams kp)
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	const uint32_t quality = kp.quality;
 	const uint32_t iters = quality <= 1u ? 0u : (quality == 2u ? 1u : (quality == 3u ? 2u : 3u));
-	// Schedule of a wavefront's four blocks (33 candidates each would leave 31 lanes idle, and
-	// the one-subset candidate is one fit where a partition is two):
-	//   pass 0: lanes 0..3 fit the one-subset candidate of blocks 0..3 and park it in LDS;
-	//   2 passes: two blocks per pass, lane group h = lane >> 5 owns the block's 32 partitions;
-	//            the group's best replaces the parked candidate if its (error, id) key is smaller;
-	//   then every block is packed by the whole wavefront from its slot.
-	// 1 + 2 x 2 subset fits per wavefront instead of 4 x 2; Lowest is pass 0 alone.
-	uint32_t* slots = cand_lds + wave*80u;
+	// Schedule of a workgroup's 16 blocks (33 candidates each: one one-subset fit, 32 partitions
+	// of two fits):
+	//   wavefront 0, lanes 0..15: the one-subset candidate of all 16 blocks, parked in cand_lds
+	//            (one 16-lane pass per workgroup instead of a 4-lane pass per wavefront -- the
+	//            kernel is bound by issued instructions, not by the slowest wave);
+	//   every wavefront, 2 passes over its four blocks: two blocks per pass, lane group
+	//            h = lane >> 5 owns the block's 32 partitions, the group's best goes to part_lds;
+	//   then every block is packed by a whole wavefront from the slot with the smaller
+	//   (error, id) key.  Lowest is the one-subset pass alone.
 	const uint32_t first = wave*4u;
-	const uint32_t nblk = bx0 + first >= kp.bx ? 0u : (kp.bx - bx0 - first < 4u ? kp.bx - bx0 - first : 4u);
-	{
+	const uint32_t nwg = kp.bx - bx0 < (uint32_t)CF_BLOCKS_PER_WG ? kp.bx - bx0 : (uint32_t)CF_BLOCKS_PER_WG;
+	const uint32_t nblk = first >= nwg ? 0u : (nwg - first < 4u ? nwg - first : 4u);
+	if (wave == 0u) {
 		HCand c;
 		c.err = ~0ull; c.id = 63u; c.mode = 10u; c.part = 0u; c.idx = 0ull;
 #pragma unroll
 		for (int k = 0; k < 4; ++k)
 			for (int ch = 0; ch < 3; ++ch)
 				c.q[k][ch] = 0;
-		if (lane < nblk) {
-			eval_candidate<SIGNED>(tile + (first + lane)*48u, 0u, iters, c);
-			store_cand(slots + lane*20u, c, (c.err << 6) | c.id);   // error < 2^37, id < 64
+		if (lane < nwg) {
+			eval_candidate<SIGNED>(tile + lane*48u, 0u, iters, c);
+			store_cand(cand_lds + lane*20u, c, (c.err << 6) | c.id);   // error < 2^37, id < 64
 		}
 	}
-	__builtin_amdgcn_wave_barrier();
 	if (quality != 0u) {
 		const uint32_t h = lane >> 5;
 #pragma unroll 1
@@ -546,15 +548,21 @@ cfhip_bc6h_encode_kernel(cf_kparams kp)
 				eval_candidate<SIGNED>(tile + (first + bi)*48u, 1u + (lane & 31u), iters, c);
 			const unsigned long long key = exists ? ((c.err << 6) | c.id) : ~0ull;
 			const unsigned long long kmin = cf_group_min_u64(key, true, h);
-			uint32_t* slot = slots + (exists ? bi : 0u)*20u;
-			const unsigned long long parked = ((unsigned long long)slot[1] << 32) | slot[0];
-			if (exists && key == kmin && kmin < parked)   // keys are distinct (id): one lane per group
-				store_cand(slot, c, key);
-			__builtin_amdgcn_wave_barrier();
+			if (exists && key == kmin)   // keys are distinct (id): one lane per group
+				store_cand(part_lds + (first + bi)*20u, c, key);
 		}
 	}
+	__syncthreads();
 	for (uint32_t j = 0; j < nblk; ++j) {
-		const uint4 blk = pack_bc6h_wave(slots + j*20u, lane);
+		const uint32_t* one = cand_lds + (first + j)*20u;
+		const uint32_t* two = part_lds + (first + j)*20u;
+		bool use_two = false;
+		if (quality != 0u) {
+			const unsigned long long k1 = ((unsigned long long)one[1] << 32) | one[0];
+			const unsigned long long k2 = ((unsigned long long)two[1] << 32) | two[0];
+			use_two = k2 < k1;
+		}
+		const uint4 blk = pack_bc6h_wave(use_two ? two : one, lane);
 		if (lane == 0u)
 			outb[first + j] = blk;
 	}
