@@ -29,8 +29,10 @@ __device__ const uint8_t k6_anchor2[32] = {
 	15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,
 	15, 2, 8, 2, 2, 8, 8,15,  2, 8, 2, 2, 8, 8, 2, 2
 };
-__device__ const uint8_t k6_w3[8] = {0, 9, 18, 27, 37, 46, 55, 64};
-__device__ const uint8_t k6_w4[16] = {0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64};
+// interpolation weights {0, 9, 18, 27, 37, 46, 55, 64} and {0, 4, 9, 13, 17, 21, 26, 30, 34, 38,
+// 43, 47, 51, 55, 60, 64} in closed form (a table indexed per lane would be a memory load)
+__device__ __forceinline__ int k6_w3(int k) { return k*9 + (k >> 2); }
+__device__ __forceinline__ int k6_w4(int k) { return k*4 + ((k + 2) >> 2); }
 
 template <bool SIGNED>
 __device__ __forceinline__ int half_to_v(uint32_t h)
@@ -115,6 +117,39 @@ __device__ __forceinline__ Tx load_tx(const uint32_t* tp, uint32_t i)
 	return t;
 }
 
+// principal axis of a 3x3 covariance: three normalised power iterations from the column of the
+// largest diagonal element (zero vector for a zero matrix)
+__device__ __forceinline__ void principal_axis(float C00, float C01, float C02, float C11, float C12,
+	float C22, float (&axis)[3])
+{
+	float bestd = C00, a0 = C00, a1 = C01, a2 = C02;
+	if (C11 > bestd) { bestd = C11; a0 = C01; a1 = C11; a2 = C12; }
+	if (C22 > bestd) { bestd = C22; a0 = C02; a1 = C12; a2 = C22; }
+#pragma unroll
+	for (int it = 0; it < 3; ++it) {
+		const float m = fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fabsf(a2));
+		if (m > 0.0f) {
+			const float im = 1.0f/m;
+			a0 = a0*im; a1 = a1*im; a2 = a2*im;
+		}
+		float r0 = C00*a0; r0 = fmaf(C01, a1, r0); r0 = fmaf(C02, a2, r0);
+		float r1 = C01*a0; r1 = fmaf(C11, a1, r1); r1 = fmaf(C12, a2, r1);
+		float r2 = C02*a0; r2 = fmaf(C12, a1, r2); r2 = fmaf(C22, a2, r2);
+		a0 = r0; a1 = r1; a2 = r2;
+	}
+	const float m = fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fabsf(a2));
+	axis[0] = axis[1] = axis[2] = 0.0f;
+	if (m > 0.0f) {
+		const float im = 1.0f/m;
+		a0 = a0*im; a1 = a1*im; a2 = a2*im;
+		float l2 = a0*a0;
+		l2 = fmaf(a1, a1, l2);
+		l2 = fmaf(a2, a2, l2);
+		const float is = 1.0f/sqrtf(l2);
+		axis[0] = a0*is; axis[1] = a1*is; axis[2] = a2*is;
+	}
+}
+
 // Fit one subset (mirrors fit_subset() of the oracle): float endpoints + selectors
 // (4 bits per texel in idx64, zero outside the subset).
 template <bool SIGNED>
@@ -145,32 +180,8 @@ __device__ __forceinline__ void fit_subset(const uint32_t* tp, uint32_t mask, in
 		C00 = fmaf(d0, d0, C00); C01 = fmaf(d0, d1, C01); C02 = fmaf(d0, d2, C02);
 		C11 = fmaf(d1, d1, C11); C12 = fmaf(d1, d2, C12); C22 = fmaf(d2, d2, C22);
 	}
-	float bestd = C00, a0 = C00, a1 = C01, a2 = C02;
-	if (C11 > bestd) { bestd = C11; a0 = C01; a1 = C11; a2 = C12; }
-	if (C22 > bestd) { bestd = C22; a0 = C02; a1 = C12; a2 = C22; }
-#pragma unroll
-	for (int it = 0; it < 3; ++it) {
-		const float m = fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fabsf(a2));
-		if (m > 0.0f) {
-			const float im = 1.0f/m;
-			a0 = a0*im; a1 = a1*im; a2 = a2*im;
-		}
-		float r0 = C00*a0; r0 = fmaf(C01, a1, r0); r0 = fmaf(C02, a2, r0);
-		float r1 = C01*a0; r1 = fmaf(C11, a1, r1); r1 = fmaf(C12, a2, r1);
-		float r2 = C02*a0; r2 = fmaf(C12, a1, r2); r2 = fmaf(C22, a2, r2);
-		a0 = r0; a1 = r1; a2 = r2;
-	}
-	const float m = fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fabsf(a2));
-	float axis[3] = {0.0f, 0.0f, 0.0f};
-	if (m > 0.0f) {
-		const float im = 1.0f/m;
-		a0 = a0*im; a1 = a1*im; a2 = a2*im;
-		float l2 = a0*a0;
-		l2 = fmaf(a1, a1, l2);
-		l2 = fmaf(a2, a2, l2);
-		const float is = 1.0f/sqrtf(l2);
-		axis[0] = a0*is; axis[1] = a1*is; axis[2] = a2*is;
-	}
+	float axis[3];
+	principal_axis(C00, C01, C02, C11, C12, C22, axis);
 	float tmin = 3.0e38f, tmax = -3.0e38f;
 #pragma unroll 1
 	for (uint32_t i = 0; i < 16u; ++i) {
@@ -208,7 +219,7 @@ __device__ __forceinline__ void fit_subset(const uint32_t* tp, uint32_t mask, in
 			k = k < 0 ? 0 : (k > nidx - 1 ? nidx - 1 : k);
 			idx64 |= (unsigned long long)(uint32_t)k << (4u*i);
 			if (more) {
-				const int w = two ? (int)k6_w3[k] : (int)k6_w4[k], iw = 64 - w;
+				const int w = two ? k6_w3((int)k) : k6_w4((int)k), iw = 64 - w;
 				S += w; A += iw*iw; B += iw*w; C += w*w;
 #pragma unroll
 				for (int c = 0; c < 3; ++c) {
@@ -249,52 +260,169 @@ __device__ __forceinline__ bool fits(int d, int bits)
 	return d >= -(1 << (bits - 1)) && d <= (1 << (bits - 1)) - 1;
 }
 
+// Both subsets of a partition in ONE pass over the texels per stage (fit_subset twice walks the
+// 16 texels twice per stage, every lane skipping the other subset's texels -- and the wavefront
+// executes all 32 iterations, its lanes hold different partitions).  A texel's subset bit selects
+// the mean / axis / endpoints it is measured against; the per-subset accumulators see a zero
+// contribution from the other subset's texels, so every float sum is the same sequence of
+// operations as in fit_subset (fma(0, d, C) == C), and the integer sums of subset 0 are
+// all - subset 1.  m1: texels of subset 1.
 template <bool SIGNED>
-__device__ __forceinline__ void eval_candidate(const uint32_t* tp, uint32_t id, uint32_t iters,
-	HCand& c)
+__device__ __forceinline__ void fit_pair(const uint32_t* tp, uint32_t m1, uint32_t iters,
+	float (&lo)[2][3], float (&hi)[2][3], unsigned long long& idx64)
 {
-	const bool two = id > 0u;
-	const uint32_t part = two ? id - 1u : 0u;
-	const int nidx = two ? 8 : 16;
-	const uint32_t m1 = two ? (uint32_t)k6_part2[part] : 0u;
-	const uint32_t m0 = two ? (~m1 & 0xFFFFu) : 0xFFFFu;
-	int e[4][3];
-	unsigned long long idx = 0ull;
+	const float vmin = SIGNED ? -32767.0f : 0.0f, vmax = SIGNED ? 32767.0f : 65535.0f;
+	const int n1 = __builtin_popcount(m1), n0 = 16 - n1;
+	int sa[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
+#pragma unroll 1
+	for (uint32_t i = 0; i < 16u; ++i) {
+		const Tx t = load_tx<SIGNED>(tp, i);
+		const bool b = (m1 >> i) & 1u;
 #pragma unroll
-	for (int k = 0; k < 4; ++k)
-		for (int ch = 0; ch < 3; ++ch)
-			e[k][ch] = 0;
-	for (uint32_t s = 0; s < (two ? 2u : 1u); ++s) {
-		const uint32_t mask = s ? m1 : m0;
-		float lo[3], hi[3];
-		unsigned long long sidx;
-		fit_subset<SIGNED>(tp, mask, nidx, two, iters, lo, hi, sidx);
-		int elo[3], ehi[3];
-#pragma unroll
-		for (int ch = 0; ch < 3; ++ch) {
-			elo[ch] = (int)floorf(lo[ch] + 0.5f);
-			ehi[ch] = (int)floorf(hi[ch] + 0.5f);
-		}
-		const uint32_t anchor = s ? (uint32_t)k6_anchor2[part] : 0u;
-		const bool swap = (int)((sidx >> (4u*anchor)) & 15ull) >= nidx/2;
-		if (swap) {
-			// idx -> nidx-1-idx on the subset's texels (nibble-wise)
-			unsigned long long nib = 0ull;
-#pragma unroll
-			for (int i = 0; i < 16; ++i)
-				if ((mask >> i) & 1u)
-					nib |= (unsigned long long)(uint32_t)(nidx - 1) << (4*i);
-			sidx = nib - sidx;   // no borrows: every nibble of sidx <= nidx-1
-		}
-		idx |= sidx;
-#pragma unroll
-		for (int ch = 0; ch < 3; ++ch) {
-			const int a = swap ? ehi[ch] : elo[ch], b = swap ? elo[ch] : ehi[ch];
-			if (s == 0u) { e[0][ch] = a; e[1][ch] = b; }
-			else { e[2][ch] = a; e[3][ch] = b; }
+		for (int c = 0; c < 3; ++c) {
+			sa[c] += t.v[c];
+			s1[c] += b ? t.v[c] : 0;
 		}
 	}
-	// highest-precision mode whose deltas fit
+	const float in0 = 1.0f/(float)n0, in1 = 1.0f/(float)n1;
+	float mean[2][3];
+#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		mean[0][c] = (float)(sa[c] - s1[c])*in0;
+		mean[1][c] = (float)s1[c]*in1;
+	}
+	float C[2][6];
+#pragma unroll
+	for (int k = 0; k < 6; ++k)
+		C[0][k] = C[1][k] = 0.0f;
+#pragma unroll 1
+	for (uint32_t i = 0; i < 16u; ++i) {
+		const Tx t = load_tx<SIGNED>(tp, i);
+		const bool b = (m1 >> i) & 1u;
+		float d[3], z0[3], z1[3];
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			d[c] = (float)t.v[c] - (b ? mean[1][c] : mean[0][c]);
+			z0[c] = b ? 0.0f : d[c];
+			z1[c] = b ? d[c] : 0.0f;
+		}
+		C[0][0] = fmaf(z0[0], d[0], C[0][0]); C[0][1] = fmaf(z0[0], d[1], C[0][1]);
+		C[0][2] = fmaf(z0[0], d[2], C[0][2]); C[0][3] = fmaf(z0[1], d[1], C[0][3]);
+		C[0][4] = fmaf(z0[1], d[2], C[0][4]); C[0][5] = fmaf(z0[2], d[2], C[0][5]);
+		C[1][0] = fmaf(z1[0], d[0], C[1][0]); C[1][1] = fmaf(z1[0], d[1], C[1][1]);
+		C[1][2] = fmaf(z1[0], d[2], C[1][2]); C[1][3] = fmaf(z1[1], d[1], C[1][3]);
+		C[1][4] = fmaf(z1[1], d[2], C[1][4]); C[1][5] = fmaf(z1[2], d[2], C[1][5]);
+	}
+	float axis[2][3];
+	principal_axis(C[0][0], C[0][1], C[0][2], C[0][3], C[0][4], C[0][5], axis[0]);
+	principal_axis(C[1][0], C[1][1], C[1][2], C[1][3], C[1][4], C[1][5], axis[1]);
+	float tmin0 = 3.0e38f, tmax0 = -3.0e38f, tmin1 = 3.0e38f, tmax1 = -3.0e38f;
+#pragma unroll 1
+	for (uint32_t i = 0; i < 16u; ++i) {
+		const Tx t = load_tx<SIGNED>(tp, i);
+		const bool b = (m1 >> i) & 1u;
+		float p = (b ? axis[1][0] : axis[0][0])*((float)t.v[0] - (b ? mean[1][0] : mean[0][0]));
+		p = fmaf(b ? axis[1][1] : axis[0][1], (float)t.v[1] - (b ? mean[1][1] : mean[0][1]), p);
+		p = fmaf(b ? axis[1][2] : axis[0][2], (float)t.v[2] - (b ? mean[1][2] : mean[0][2]), p);
+		tmin0 = fminf(tmin0, b ? 3.0e38f : p);
+		tmax0 = fmaxf(tmax0, b ? -3.0e38f : p);
+		tmin1 = fminf(tmin1, b ? p : 3.0e38f);
+		tmax1 = fmaxf(tmax1, b ? p : -3.0e38f);
+	}
+#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		lo[0][c] = clampf(fmaf(axis[0][c], tmin0, mean[0][c]), vmin, vmax);
+		hi[0][c] = clampf(fmaf(axis[0][c], tmax0, mean[0][c]), vmin, vmax);
+		lo[1][c] = clampf(fmaf(axis[1][c], tmin1, mean[1][c]), vmin, vmax);
+		hi[1][c] = clampf(fmaf(axis[1][c], tmax1, mean[1][c]), vmin, vmax);
+	}
+
+	// refit rounds; a subset whose normal equations are singular keeps its endpoints from then
+	// on (fit_subset stops there), and selectors recomputed from unchanged endpoints are the same
+	bool live0 = true, live1 = true;
+	for (uint32_t r = 0; ; ++r) {
+		float dl[2][3], scale[2];
+#pragma unroll
+		for (int s = 0; s < 2; ++s) {
+			dl[s][0] = hi[s][0] - lo[s][0]; dl[s][1] = hi[s][1] - lo[s][1]; dl[s][2] = hi[s][2] - lo[s][2];
+			float dd = dl[s][0]*dl[s][0];
+			dd = fmaf(dl[s][1], dl[s][1], dd);
+			dd = fmaf(dl[s][2], dl[s][2], dd);
+			scale[s] = dd > 0.0f ? (float)(8 - 1)/dd : 0.0f;
+		}
+		idx64 = 0ull;
+		// sums over all texels (a) and over subset 1 (b)
+		int Sa = 0, Aa = 0, Ba = 0, Ca = 0, Ua[3] = {0, 0, 0}, Va[3] = {0, 0, 0};
+		int Sb = 0, Ab = 0, Bb = 0, Cb = 0, Ub[3] = {0, 0, 0}, Vb[3] = {0, 0, 0};
+		const bool more = r < iters && (live0 || live1);
+#pragma unroll 1
+		for (uint32_t i = 0; i < 16u; ++i) {
+			const Tx t = load_tx<SIGNED>(tp, i);
+			const bool b = (m1 >> i) & 1u;
+			float p = ((float)t.v[0] - (b ? lo[1][0] : lo[0][0]))*(b ? dl[1][0] : dl[0][0]);
+			p = fmaf((float)t.v[1] - (b ? lo[1][1] : lo[0][1]), b ? dl[1][1] : dl[0][1], p);
+			p = fmaf((float)t.v[2] - (b ? lo[1][2] : lo[0][2]), b ? dl[1][2] : dl[0][2], p);
+			int k = (int)floorf(p*(b ? scale[1] : scale[0]) + 0.5f);
+			k = k < 0 ? 0 : (k > 7 ? 7 : k);
+			idx64 |= (unsigned long long)(uint32_t)k << (4u*i);
+			if (more) {
+				const int w = k6_w3(k), iw = 64 - w;
+				const int wb = b ? w : 0, iwb = b ? iw : 0;
+				Sa += w; Aa += iw*iw; Ba += iw*w; Ca += w*w;
+				Sb += wb; Ab += iwb*iw; Bb += iwb*w; Cb += wb*w;
+#pragma unroll
+				for (int c = 0; c < 3; ++c) {
+					Ua[c] += iw*t.v[c];
+					Va[c] += w*t.v[c];
+					Ub[c] += iwb*t.v[c];
+					Vb[c] += wb*t.v[c];
+				}
+			}
+		}
+		if (!more)
+			break;
+#pragma unroll
+		for (int s = 0; s < 2; ++s) {
+			const bool live = s ? live1 : live0;
+			const int n = s ? n1 : n0;
+			const int S = s ? Sb : Sa - Sb, A = s ? Ab : Aa - Ab, B = s ? Bb : Ba - Bb, Cq = s ? Cb : Ca - Cb;
+			const int det = n*Cq - S*S;
+			const bool upd = live && det > 0;
+			if (s) live1 = upd; else live0 = upd;
+			const float inv = 1.0f/(64.0f*(float)det);
+			const float fA = (float)A, fB = (float)B, fC = (float)Cq;
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				const float fU = (float)(s ? Ub[c] : Ua[c] - Ub[c]), fV = (float)(s ? Vb[c] : Va[c] - Vb[c]);
+				const float t0 = fB*fV;
+				const float nn0 = fmaf(fC, fU, -t0);
+				const float t1 = fB*fU;
+				const float nn1 = fmaf(fA, fV, -t1);
+				if (upd) {
+					lo[s][c] = clampf(nn0*inv, vmin, vmax);
+					hi[s][c] = clampf(nn1*inv, vmin, vmax);
+				}
+			}
+		}
+	}
+}
+
+// 16 subset bits -> one bit per selector nibble (bit i -> bit 4 i)
+__device__ __forceinline__ unsigned long long spread_nibbles(uint32_t m)
+{
+	uint32_t a = m & 0xFFu, b = (m >> 8) & 0xFFu;
+	a = (a | (a << 12)) & 0x000F000Fu; b = (b | (b << 12)) & 0x000F000Fu;
+	a = (a | (a << 6)) & 0x03030303u;  b = (b | (b << 6)) & 0x03030303u;
+	a = (a | (a << 3)) & 0x11111111u;  b = (b | (b << 3)) & 0x11111111u;
+	return ((unsigned long long)b << 32) | a;
+}
+
+// From a candidate's rounded endpoints (already anchor-ordered) and selectors: the highest-
+// precision mode whose deltas fit, and the exact error of what the decoder will produce.
+template <bool SIGNED>
+__device__ __forceinline__ void finish_candidate(const uint32_t* tp, bool two, uint32_t m1, uint32_t id,
+	uint32_t part, const int (&e)[4][3], unsigned long long idx, HCand& c)
+{
 	const uint32_t norder = two ? 10u : 4u, ne = two ? 4u : 2u;
 	uint32_t mode = two ? 9u : 10u;
 	int q[4][3];
@@ -340,7 +468,7 @@ __device__ __forceinline__ void eval_candidate(const uint32_t* tp, uint32_t id, 
 		const Tx t = load_tx<SIGNED>(tp, i);
 		const uint32_t s = two ? (m1 >> i) & 1u : 0u;
 		const uint32_t k = (uint32_t)((idx >> (4u*i)) & 15ull);
-		const int w = two ? (int)k6_w3[k] : (int)k6_w4[k];
+		const int w = two ? k6_w3((int)k) : k6_w4((int)k);
 #pragma unroll
 		for (int ch = 0; ch < 3; ++ch) {
 			const int ea = s ? u[2][ch] : u[0][ch], eb = s ? u[3][ch] : u[1][ch];
@@ -359,6 +487,52 @@ __device__ __forceinline__ void eval_candidate(const uint32_t* tp, uint32_t id, 
 #pragma unroll
 		for (int ch = 0; ch < 3; ++ch)
 			c.q[k][ch] = q[k][ch];
+}
+
+// candidate 0: one subset, 16 selectors
+template <bool SIGNED>
+__device__ __forceinline__ void eval_one(const uint32_t* tp, uint32_t iters, HCand& c)
+{
+	float lo[3], hi[3];
+	unsigned long long idx;
+	fit_subset<SIGNED>(tp, 0xFFFFu, 16, false, iters, lo, hi, idx);
+	const bool swap = (int)(idx & 15ull) >= 8;   // anchor: texel 0
+	if (swap)
+		idx ^= 0xFFFFFFFFFFFFFFFFull;            // 15 - k on every nibble
+	int e[4][3];
+#pragma unroll
+	for (int ch = 0; ch < 3; ++ch) {
+		const int a = (int)floorf(lo[ch] + 0.5f), b = (int)floorf(hi[ch] + 0.5f);
+		e[0][ch] = swap ? b : a;
+		e[1][ch] = swap ? a : b;
+		e[2][ch] = e[3][ch] = 0;
+	}
+	finish_candidate<SIGNED>(tp, false, 0u, 0u, 0u, e, idx, c);
+}
+
+// candidate 1 + part: two subsets, 8 selectors each
+template <bool SIGNED>
+__device__ __forceinline__ void eval_two(const uint32_t* tp, uint32_t part, uint32_t iters, HCand& c)
+{
+	const uint32_t m1 = (uint32_t)k6_part2[part];
+	float lo[2][3], hi[2][3];
+	unsigned long long idx;
+	fit_pair<SIGNED>(tp, m1, iters, lo, hi, idx);
+	// anchors: texel 0 (always subset 0) and the partition's second anchor; a subset whose anchor
+	// selector has its top bit set swaps its endpoints and takes 7 - k
+	const bool swap0 = (uint32_t)(idx & 15ull) >= 4u;
+	const bool swap1 = (uint32_t)((idx >> (4u*(uint32_t)k6_anchor2[part])) & 15ull) >= 4u;
+	const unsigned long long n1 = spread_nibbles(m1), n0 = n1 ^ 0x1111111111111111ull;
+	idx ^= ((swap0 ? n0 : 0ull) | (swap1 ? n1 : 0ull))*7ull;
+	int e[4][3];
+#pragma unroll
+	for (int ch = 0; ch < 3; ++ch) {
+		const int a0 = (int)floorf(lo[0][ch] + 0.5f), b0 = (int)floorf(hi[0][ch] + 0.5f);
+		const int a1 = (int)floorf(lo[1][ch] + 0.5f), b1 = (int)floorf(hi[1][ch] + 0.5f);
+		e[0][ch] = swap0 ? b0 : a0; e[1][ch] = swap0 ? a0 : b0;
+		e[2][ch] = swap1 ? b1 : a1; e[3][ch] = swap1 ? a1 : b1;
+	}
+	finish_candidate<SIGNED>(tp, true, m1, 1u + part, part, e, idx, c);
 }
 
 struct Bits128 {
@@ -526,7 +700,7 @@ cfhip_bc6h_encode_kernel(cf_kparams kp)
 			for (int ch = 0; ch < 3; ++ch)
 				c.q[k][ch] = 0;
 		if (lane < nwg) {
-			eval_candidate<SIGNED>(tile + lane*48u, 0u, iters, c);
+			eval_one<SIGNED>(tile + lane*48u, iters, c);
 			store_cand(cand_lds + lane*20u, c, (c.err << 6) | c.id);   // error < 2^37, id < 64
 		}
 	}
@@ -545,7 +719,7 @@ cfhip_bc6h_encode_kernel(cf_kparams kp)
 				for (int ch = 0; ch < 3; ++ch)
 					c.q[k][ch] = 0;
 			if (exists)
-				eval_candidate<SIGNED>(tile + (first + bi)*48u, 1u + (lane & 31u), iters, c);
+				eval_two<SIGNED>(tile + (first + bi)*48u, lane & 31u, iters, c);
 			const unsigned long long key = exists ? ((c.err << 6) | c.id) : ~0ull;
 			const unsigned long long kmin = cf_group_min_u64(key, true, h);
 			if (exists && key == kmin)   // keys are distinct (id): one lane per group
