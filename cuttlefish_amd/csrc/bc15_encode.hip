@@ -229,10 +229,14 @@ __device__ __forceinline__ uint2 bc4_search(const uint32_t* tp, uint32_t* pre, i
 					}
 				}
 			}
+			// ids ascend with the chunks: once a pair reproduces the block exactly, no later one wins
+			if (__ballot(best_err == 0u) != 0ull)
+				break;
 		}
 	} else {
+		bool exact = false;
 #pragma unroll 1
-		for (int m = 0; m < 2; ++m) {
+		for (int m = 0; m < 2 && !exact; ++m) {
 			// the rectangle of offsets: il = dl + radius in [0, H), ih = dh + radius in [ih0, span)
 			const uint32_t H = (uint32_t)(radius + dl_cut[m]), ih0 = (uint32_t)(radius - dh_cut[m] + 1), W = span - ih0;
 			const uint32_t total = W*H;
@@ -255,6 +259,13 @@ __device__ __forceinline__ uint2 bc4_search(const uint32_t* tp, uint32_t* pre, i
 							best_a1 = a1;
 						}
 					}
+				}
+				// ids ascend with the chunks and the modes: an exact pair ends the search (flat
+				// blocks -- an opaque BC3 alpha channel -- would otherwise scan the whole window,
+				// their zero seed error cuts nothing)
+				if (__ballot(best_err == 0u) != 0ull) {
+					exact = true;
+					break;
 				}
 			}
 		}
