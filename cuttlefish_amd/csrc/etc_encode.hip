@@ -929,6 +929,10 @@ __device__ __forceinline__ uint2 eac_search(const uint32_t* tp, uint32_t* pre, i
 				err = vv2 - (uint32_t)acc;
 			}
 			if (err < berr) { berr = err; bbase = base; bdb = db + R; }
+			// lane 0 holds the smallest ids: once it reproduces the block exactly (flat blocks, the
+			// opaque alpha of most RGBA8 textures) nothing later can win
+			if (__builtin_amdgcn_readfirstlane((int)berr) == 0)
+				break;
 		}
 		key = ((unsigned long long)berr << 32) | (uint32_t)(((t*3 + dm + 1)*(2*R + 1)) + bdb);
 		pay = (uint32_t)(bbase & 0xFFFF) | ((uint32_t)mult << 16) | ((uint32_t)t << 24);
