@@ -130,7 +130,7 @@ EXPORTS = ["cfhip_abi_version", "cfhip_device_count", "cfhip_create", "cfhip_des
            "cfhip_query", "cfhip_encode", "cfhip_encode_multi", "cfhip_encode_device", "cfhip_shard_rows",
            "cfhip_last_kernel_ms", "cfhip_last_kernel_name", "cfhip_last_error",
            "cfhip_profile_begin", "cfhip_profile_end", "cfhip_generate_mips_device",
-           "cfhip_generate_mips3d_device"]
+           "cfhip_generate_mips3d_device", "cfhip_resize_device"]
 
 
 class Params(ctypes.Structure):
@@ -213,6 +213,10 @@ def load_library(path: Optional[str] = None):
         ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
         ctypes.c_uint32, ctypes.c_void_p]
     L.cfhip_generate_mips3d_device.restype = ctypes.c_int
+    L.cfhip_resize_device.argtypes = [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_size_t,
+        ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    L.cfhip_resize_device.restype = ctypes.c_int
     _lib = L
     return L
 
@@ -370,6 +374,16 @@ class Context:
         self._check(self._lib.cfhip_generate_mips3d_device(
             self._h, ctypes.c_void_p(int(src)), int(pixel_type), width, height, depth, row_pitch_bytes,
             slice_pitch_bytes, int(color_space), int(filter), arr, n,
+            ctypes.c_void_p(stream) if stream else None))
+
+    def resize_device(self, src: int, pixel_type, width: int, height: int, row_pitch_bytes: int,
+                      dst: int, dst_width: int, dst_height: int, color_space=ColorSpace.Linear,
+                      filter=0, stream: int = 0):
+        """Image::resize on the GPU: src (device pointer) -> dst (device pointer, dst_width x
+        dst_height RGBA32F tightly packed), in linear space."""
+        self._check(self._lib.cfhip_resize_device(
+            self._h, ctypes.c_void_p(int(src)), int(pixel_type), width, height, row_pitch_bytes,
+            int(color_space), int(filter), ctypes.c_void_p(int(dst)), dst_width, dst_height,
             ctypes.c_void_p(stream) if stream else None))
 
     def last_kernel_ms(self) -> float:

@@ -391,6 +391,7 @@ def read_pvr(data: bytes):
 #  size otherwise, Texture.cpp:1207-1216)
 
 _DIM_TEXTURE3D = 4
+_DIM_TEXTURE1D = 2
 _DDSD_DEPTH = 0x800000
 _DDSCAPS2_CUBE_ALL = 0x200 | 0x400 | 0x800 | 0x1000 | 0x2000 | 0x4000 | 0x8000
 _DDSCAPS2_VOLUME = 0x200000
@@ -404,8 +405,8 @@ class TextureLayout:
         self.fmt, self.typ = Format(fmt), Type(typ)
         self.width, self.height = int(width), int(height)
         self.dimension = dimension
-        if dimension not in ("2d", "cube", "3d"):
-            raise ValueError("dimension must be '2d', 'cube' or '3d'")
+        if dimension not in ("1d", "2d", "cube", "3d"):
+            raise ValueError("dimension must be '1d', '2d', 'cube' or '3d'")
         self.faces = 6 if dimension == "cube" else 1
         self.depth = int(depth)                                  # Texture::depth(): 0 = not an array / not 3-D
         self.is_array = (dimension != "3d" and self.depth > 0) if is_array is None else bool(is_array)
@@ -455,7 +456,7 @@ def write_dds_texture(stream, tex: TextureLayout, color_space=ColorSpace.Linear,
     out += struct.pack("<7I44x", 124, flags, tex.height, tex.width, pitch, tex.depth if is3d else 0, tex.levels)
     out += struct.pack("<2I4s5I", 32, _DDPF_FOURCC, b"DX10", 0, 0, 0, 0, 0)
     out += struct.pack("<5I", caps, caps2, 0, 0, 0)
-    out += struct.pack("<5I", dxgi, _DIM_TEXTURE3D if is3d else _DIM_TEXTURE2D,
+    out += struct.pack("<5I", dxgi, _DIM_TEXTURE3D if is3d else (_DIM_TEXTURE1D if tex.dimension == "1d" else _DIM_TEXTURE2D),
                        _DDS_MISC_CUBEMAP if tex.dimension == "cube" else 0,
                        1 if is3d else max(tex.depth, 1), misc2)           # arraySize :637
     elements = max(tex.depth, 1) if tex.is_array else 1
@@ -485,7 +486,8 @@ def write_ktx_texture(stream, tex: TextureLayout, color_space=ColorSpace.Linear)
     internal = srgb if (srgb_wanted and srgb) else lin
     out = KTX_IDENTIFIER + struct.pack("<I", KTX_ENDIANNESS)
     out += struct.pack("<5I", gl_type, type_size, gl_format, internal, base)
-    out += struct.pack("<7I", tex.width, tex.height, tex.depth if tex.dimension == "3d" else 0,
+    out += struct.pack("<7I", tex.width, 0 if tex.dimension == "1d" else tex.height,      # :1209
+                       tex.depth if tex.dimension == "3d" else 0,
                        tex.depth if tex.is_array else 0, tex.faces, tex.levels, 0)
     bpp = query(tex.fmt, tex.typ)[2]
     for l in range(tex.levels):
@@ -523,6 +525,8 @@ def write_pvr_texture(stream, tex: TextureLayout, color_space=ColorSpace.Linear,
         meta += struct.pack("<4I", _fourcc("C", "T", "F", "S"), code, 4, 0)
     if tex.is_array:
         meta += struct.pack("<4I", _fourcc("C", "T", "F", "S"), _fourcc("A", "R", "R", "Y"), 4, 0)
+    if tex.dimension == "1d":                                          # SavePvr.cpp:568-575
+        meta += struct.pack("<4I", _fourcc("C", "T", "F", "S"), _fourcc("D", "I", "M", "1"), 4, 0)
     out += struct.pack("<I", len(meta)) + meta
     for l in range(tex.levels):
         for d in range(tex.depth_at(l)):

@@ -776,9 +776,10 @@ __device__ __forceinline__ uint2 bc1_search(const uint32_t* tp, const COpts& o_i
 	cur.b = (uint32_t)__shfl((int)best.b, (int)wl, 64);
 	cur.mode3 = (uint32_t)__shfl((int)best.mode3, (int)wl, 64);
 
-	if (o.cluster)
+	// a start candidate that reproduces the block exactly cannot be beaten (later ids are larger)
+	if (o.cluster && cur.err != 0u)
 		cluster_fit<UNITW>(tp, o, n, s, s00, s01, s02, s11, s12, s22, lane, cur);
-	for (uint32_t r = 1; r <= o.rounds; ++r) {
+	for (uint32_t r = 1; r <= o.rounds && cur.err != 0u; ++r) {
 		uint32_t na, nb;
 		move565(lane, cur.a, cur.b, na, nb);
 		CBest cand = {0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};

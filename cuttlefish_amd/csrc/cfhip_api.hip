@@ -1116,6 +1116,49 @@ int cfhip_generate_mips_device(cfhip_ctx* ctx, const void* src, int src_pixel_ty
 	return CFHIP_OK;
 }
 
+int cfhip_resize_device(cfhip_ctx* ctx, const void* src, int src_pixel_type, uint32_t src_width,
+	uint32_t src_height, size_t src_pitch_bytes, int color_space, int filter, void* dst,
+	uint32_t dst_width, uint32_t dst_height, void* stream_)
+{
+	if (!ctx)
+		return fail(nullptr, CFHIP_E_INVALID, "ctx is NULL");
+	std::lock_guard<std::mutex> guard(ctx->lock);
+	if (!src || !dst || !src_width || !src_height || !dst_width || !dst_height)
+		return fail(ctx, CFHIP_E_INVALID, "resize: NULL or empty argument");
+	if (src_pixel_type < CFHIP_PIXEL_RGBA8 || src_pixel_type > CFHIP_PIXEL_RGBA16F)
+		return fail(ctx, CFHIP_E_INVALID, "resize: pixel type %d", src_pixel_type);
+	if (color_space != CFHIP_COLOR_LINEAR && color_space != CFHIP_COLOR_SRGB)
+		return fail(ctx, CFHIP_E_INVALID, "resize: colour space %d", color_space);
+	if (filter < CFHIP_FILTER_BOX || filter > CFHIP_FILTER_BSPLINE)
+		return fail(ctx, CFHIP_E_INVALID, "resize filter %d", filter);
+	const size_t texel = src_pixel_type == CFHIP_PIXEL_RGBA8 ? 4 : (src_pixel_type == CFHIP_PIXEL_RGBA32F ? 16 : 8);
+	if (src_pitch_bytes < (size_t)src_width*texel)
+		return fail(ctx, CFHIP_E_INVALID, "resize: row pitch smaller than a row");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : ctx->stream;
+	bool used_staging = false;
+	if (src_width == dst_width && src_height == dst_height) {
+		// Image::resize returns the image itself (Image.cpp:1330-1334): the texels as RGBAF, no
+		// colour-space round trip (a 1:1 box footprint is the texel)
+		HIP_TRY(ctx, cfhip_launch_mip_resize(src, src_pixel_type, src_pitch_bytes, src_width, src_height, dst,
+			dst_width, dst_height, CFHIP_FILTER_BOX, 0, stream));
+	} else {
+		const int rc = mip_level_2d(ctx, src, src_pixel_type, src_pitch_bytes, src_width, src_height, dst,
+			dst_width, dst_height, filter, color_space == CFHIP_COLOR_SRGB ? 1 : 0, stream, &used_staging);
+		if (rc != CFHIP_OK)
+			return rc;
+	}
+	if (used_staging) {
+		const int rc = staging_release(ctx, stream);
+		if (rc != CFHIP_OK) return rc;
+	}
+	if (!stream_) {
+		HIP_TRY(ctx, hipStreamSynchronize(stream));
+		ctx->staging_busy = false;
+	}
+	return CFHIP_OK;
+}
+
 int cfhip_generate_mips3d_device(cfhip_ctx* ctx, const void* src, int src_pixel_type,
 	uint32_t width, uint32_t height, uint32_t depth, size_t src_pitch_bytes, size_t src_slice_pitch_bytes,
 	int color_space, int filter, void* const* dst_levels, uint32_t levels, void* stream_)

@@ -248,6 +248,14 @@ int cfhip_generate_mips_device(cfhip_ctx* ctx, const void* src, int src_pixel_ty
 	uint32_t width, uint32_t height, size_t src_pitch_bytes, int color_space, int filter,
 	void* const* dst_levels, uint32_t levels, void* stream);
 
+/* One Image::resize on the GPU (lib/src/Image.cpp:1324-1511) -- what Texture::generateMipmaps calls
+ * per level, and per custom mip image (Texture.cpp:1499-1503, any source size): src (any of the
+ * three pixel types) -> dst, dst_width x dst_height tightly packed RGBA32F, in linear space as
+ * above; equal sizes copy the texels (Image.cpp:1330-1334).  Same filters, same stream rule. */
+int cfhip_resize_device(cfhip_ctx* ctx, const void* src, int src_pixel_type, uint32_t src_width,
+	uint32_t src_height, size_t src_pitch_bytes, int color_space, int filter, void* dst,
+	uint32_t dst_width, uint32_t dst_height, void* stream);
+
 /* The same for a 3-D texture (Texture::generateMipmaps, Dim3D branch, lib/src/Texture.cpp:1345-1440):
  * level k = every slice of level k-1 resized to max(1, w >> k) x max(1, h >> k) by Image::resize, then
  * generateMips3d (Texture.cpp:103-227) along the depth to max(1, depth >> k) slices -- Box counts

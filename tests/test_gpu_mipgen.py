@@ -158,7 +158,7 @@ def test_generate_mipmaps_level_dimensions_as_in_the_reference_test():
     assert t.set_image(np.zeros((10, 15, 4), np.float32))
     assert t.images_complete() and t.generate_mipmaps() and t.images_complete()
     assert t.mip_level_count() == 4
-    assert [t._images[k][0].shape[:2] for k in range(4)] == [(10, 15), (5, 7), (2, 3), (1, 1)]
+    assert [t.get_image(k).shape[:2] for k in range(4)] == [(10, 15), (5, 7), (2, 3), (1, 1)]
 
 
 def _gpu_chain3d(ctx, vol, levels, color_space, filt):
