@@ -201,6 +201,43 @@ __device__ __forceinline__ void cf_prefix_table_add(uint32_t* pre, uint32_t v, u
 	__builtin_amdgcn_wave_barrier();
 }
 
+// The same table over CHUNKS x 256 entries (11-bit values: 8 chunks = 8 KB per wavefront): lane
+// owns entries 4 lane .. 4 lane + 3 of every chunk (a wave-level access is one contiguous 1 KB
+// run), the chunks are scanned in turn and carry their running total.
+template <int CHUNKS>
+__device__ __forceinline__ void cf_prefix_table_chunks(uint32_t* pre, uint32_t v, uint32_t add, bool mine, uint32_t lane)
+{
+	const uint32_t x0 = lane*4u;
+#pragma unroll
+	for (int j = 0; j < CHUNKS; ++j)
+		*reinterpret_cast<uint4*>(pre + 256*j + x0) = make_uint4(0u, 0u, 0u, 0u);
+	__builtin_amdgcn_wave_barrier();
+	if (mine)
+		atomicAdd(pre + v, add);
+	__builtin_amdgcn_wave_barrier();
+	uint32_t carry = 0u;
+	const uint32_t row = lane >> 4;
+#pragma unroll 2
+	for (int j = 0; j < CHUNKS; ++j) {
+		uint4 e = *reinterpret_cast<const uint4*>(pre + 256*j + x0);
+		e.y += e.x; e.z += e.y; e.w += e.z;
+		uint32_t sc = e.w;
+		sc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sc, 0x111, 0xF, 0xF, false);   // row_shr:1
+		sc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sc, 0x112, 0xF, 0xF, false);   // row_shr:2
+		sc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sc, 0x114, 0xF, 0xF, false);   // row_shr:4
+		sc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sc, 0x118, 0xF, 0xF, false);   // row_shr:8
+		const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)sc, 15);
+		const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)sc, 31);
+		const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)sc, 47);
+		const uint32_t t3 = (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+		const uint32_t before = carry + (row == 0u ? 0u : (row == 1u ? t0 : (row == 2u ? t0 + t1 : t0 + t1 + t2))) + sc - e.w;
+		e.x += before; e.y += before; e.z += before; e.w += before;
+		*reinterpret_cast<uint4*>(pre + 256*j + x0) = e;
+		carry += t0 + t1 + t2 + t3;
+	}
+	__builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ void cf_prefix_table_u8(uint32_t* pre, uint32_t v, bool mine, uint32_t lane)
 {
 	cf_prefix_table_add(pre, v, 0x10000u | v, mine, lane);

@@ -842,26 +842,25 @@ __device__ __forceinline__ int eac_decode(int kind, int base, int m, int mult)
 __device__ __forceinline__ uint2 eac_search(const uint32_t* tp, uint32_t* pre, int kind, int ch,
 	uint32_t active, int R, uint32_t lane)
 {
-	uint32_t sum2 = 0, all = 0;
-	if (kind == 0) {
-		const uint32_t ti = lane & 15u, uv = (tp[ti] >> (8*ch)) & 255u;
-		const bool act = (active >> ti) & 1u;
-		sum2 = cf_row_sum_uniform(act ? uv*uv : 0u);
-		cf_prefix_table_u8(pre, uv, lane < 16u && act, lane);
-		all = pre[255];
-	}
-	// range of the active texels and (11-bit kinds) the sum of their squares: one texel per lane
+	// prefix table of the block's values (11-bit kinds: biased to 0..2047, 2048 entries)
+	const int bias = kind == 2 ? 1024 : 0;
+	uint32_t sum2, all;
 	int lo, hi;
-	uint32_t vv2 = 0;
 	{
 		const uint32_t ti = lane & 15u;
 		const int v = eac_value(tp, ti, kind, ch);
+		const uint32_t uv = (uint32_t)(v + bias);
 		const bool act = (active >> ti) & 1u;
+		sum2 = cf_row_sum_uniform(act ? uv*uv : 0u);
+		if (kind == 0)
+			cf_prefix_table_u8(pre, uv, lane < 16u && act, lane);
+		else
+			cf_prefix_table_chunks<8>(pre, uv, 0x10000u | uv, lane < 16u && act, lane);
+		all = pre[kind == 0 ? 255 : 2047];
+		// range of the active texels: one texel per lane
 		const uint32_t bv = (uint32_t)(v + 1024);   // biased: signed R11 is -1023..1023
 		lo = __builtin_amdgcn_readfirstlane((int)cf_row_min_u32(act ? bv : 0xFFFFu)) - 1024;
 		hi = __builtin_amdgcn_readfirstlane((int)cf_row_max_u32(act ? bv : 0u)) - 1024;
-		if (kind != 0)
-			vv2 = cf_row_sum_uniform(act ? (uint32_t)__mul24(v, v) : 0u);
 	}
 	if (lo > hi)
 		lo = hi = 0;
@@ -889,9 +888,12 @@ __device__ __forceinline__ uint2 eac_search(const uint32_t* tp, uint32_t* pre, i
 #pragma unroll
 			for (int k = 0; k < 8; ++k)
 				dec[k] = eac_decode(kind, base, mods[k], mult);
-			uint32_t err = 0;
-			if (kind == 0) {
-				const int q[8] = {dec[3], dec[2], dec[1], dec[0], dec[4], dec[5], dec[6], dec[7]};
+			// error through the prefix table: the entries in ascending order, the midpoints between
+			// neighbours cut the value axis into the texels each entry wins
+			uint32_t err;
+			{
+				const int q[8] = {dec[3] + bias, dec[2] + bias, dec[1] + bias, dec[0] + bias,
+					dec[4] + bias, dec[5] + bias, dec[6] + bias, dec[7] + bias};
 				int e = (int)sum2;
 				uint32_t below = 0u;
 #pragma unroll
@@ -903,30 +905,6 @@ __device__ __forceinline__ uint2 eac_search(const uint32_t* tp, uint32_t* pre, i
 					e += q[k]*(n*q[k] - 2*sk);
 				}
 				err = (uint32_t)e;
-			} else {
-				// (dec - v)^2 = v^2 - (2 dec v - dec^2): one multiply-add per entry and a max, the
-				// sum of v^2 over the active texels (vv2) once per block
-				int d2[8], nd[8];
-#pragma unroll
-				for (int k = 0; k < 8; ++k) {
-					d2[k] = 2*dec[k];
-					nd[k] = -__mul24(dec[k], dec[k]);
-					asm volatile("" : "+v"(nd[k]));   // keep v*d2 + nd ONE v_mad_i32_i24 (not a multiply and a subtract)
-				}
-				int acc = 0;
-#pragma unroll 4
-				for (uint32_t i = 0; i < 16u; ++i) {
-					const int v = eac_value(tp, i, kind, ch);
-					// 24-bit multiplies (|v| <= 2047, 2 dec <= 4094): full rate, unlike v_mul_lo_u32
-					int best = __mul24(v, d2[0]) + nd[0];
-#pragma unroll
-					for (int k = 1; k < 8; ++k) {
-						const int kk = __mul24(v, d2[k]) + nd[k];
-						best = kk > best ? kk : best;
-					}
-					acc += ((active >> i) & 1u) ? best : 0;
-				}
-				err = vv2 - (uint32_t)acc;
 			}
 			if (err < berr) { berr = err; bbase = base; bdb = db + R; }
 			// lane 0 holds the smallest ids: once it reproduces the block exactly (flat blocks, the
@@ -996,7 +974,7 @@ cfhip_etc_encode_kernel(cf_kparams kp)
 	__shared__ uint32_t tile[CF_BLOCKS_PER_WG*16];
 	__shared__ uint32_t outb[CF_BLOCKS_PER_WG*4];
 	// ETC2 RGBA8: one 256-entry prefix table per wavefront for the 8-bit alpha search
-	__shared__ __attribute__((aligned(16))) uint32_t pre_tab[FMT == E_A8 ? (CF_WG_THREADS/64)*256 : 4];
+	__shared__ __attribute__((aligned(16))) uint32_t pre_tab[FMT == E_A8 ? (CF_WG_THREADS/64)*256 : (IS_EAC ? (CF_WG_THREADS/64)*2048 : 4)];
 	uint32_t gx_, gy_;
 	cf_resolve(kp, gx_, gy_);
 	const uint32_t bx0 = gx_*CF_BLOCKS_PER_WG;
@@ -1027,7 +1005,7 @@ cfhip_etc_encode_kernel(cf_kparams kp)
 	__syncthreads();
 
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	uint32_t* pre = pre_tab + (FMT == E_A8 ? wave*256u : 0u);
+	uint32_t* pre = pre_tab + (FMT == E_A8 ? wave*256u : (IS_EAC ? wave*2048u : 0u));
 	const uint32_t q = kp.quality;
 	const int R = q <= 1u ? 1 : (q == 2u ? 2 : 4);
 	for (uint32_t j = 0; j < 4u; ++j) {
