@@ -51,6 +51,14 @@ __global__ void __launch_bounds__(256)
 cfhip_mip_resize_kernel(const uint8_t* __restrict__ src, size_t pitch, uint32_t sw, uint32_t sh,
 	float4* __restrict__ dst, uint32_t dw, uint32_t dh, int filter, int srgb)
 {
+	// an 8-bit source has 256 possible sRGB values: their linear values are computed once per
+	// workgroup (one per thread, the same function on the same input as the per-texel call), not
+	// once per texel read -- 12 of the 15 pow() of a 2x2 box footprint
+	__shared__ float lin_of_u8[SRC_PIX == 0 ? 256 : 1];
+	if (SRC_PIX == 0 && srgb) {
+		lin_of_u8[threadIdx.x] = (float)srgb_to_linear((double)(float)((double)threadIdx.x/255.0));
+		__syncthreads();
+	}
 	const uint32_t x = blockIdx.x*64u + (threadIdx.x & 63u);
 	const uint32_t y = blockIdx.y*4u + (threadIdx.x >> 6);
 	if (x >= dw || y >= dh)
@@ -97,11 +105,18 @@ cfhip_mip_resize_kernel(const uint8_t* __restrict__ src, size_t pitch, uint32_t 
 				if (scaleX == 0.0)
 					continue;
 			}
-			float4 p = load_rgbaf<SRC_PIX>(row, j);
-			if (srgb) {   // the linear copy of the source level is an RGBAF image: float store
-				p.x = (float)srgb_to_linear((double)p.x);
-				p.y = (float)srgb_to_linear((double)p.y);
-				p.z = (float)srgb_to_linear((double)p.z);
+			float4 p;
+			if (SRC_PIX == 0 && srgb) {
+				const uint32_t u = *reinterpret_cast<const uint32_t*>(row + (size_t)j*4u);
+				p = make_float4(lin_of_u8[u & 255u], lin_of_u8[(u >> 8) & 255u], lin_of_u8[(u >> 16) & 255u],
+					(float)((double)(u >> 24)/255.0));
+			} else {
+				p = load_rgbaf<SRC_PIX>(row, j);
+				if (srgb) {   // the linear copy of the source level is an RGBAF image: float store
+					p.x = (float)srgb_to_linear((double)p.x);
+					p.y = (float)srgb_to_linear((double)p.y);
+					p.z = (float)srgb_to_linear((double)p.z);
+				}
 			}
 			if (filter == 0) {
 				c0 += (double)p.x; c1 += (double)p.y; c2 += (double)p.z; c3 += (double)p.w;
@@ -159,6 +174,11 @@ __global__ void __launch_bounds__(256)
 cfhip_mip_pass_kernel(const uint8_t* __restrict__ src, size_t pitch, uint32_t src_n, float4* __restrict__ dst,
 	uint32_t dst_w, uint32_t dst_h, int filter, int to_linear, int to_srgb)
 {
+	__shared__ float lin_of_u8[SRC_PIX == 0 ? 256 : 1];   // see cfhip_mip_resize_kernel
+	if (SRC_PIX == 0 && to_linear) {
+		lin_of_u8[threadIdx.x] = (float)srgb_to_linear((double)(float)((double)threadIdx.x/255.0));
+		__syncthreads();
+	}
 	const uint32_t x = blockIdx.x*64u + (threadIdx.x & 63u);
 	const uint32_t y = blockIdx.y*4u + (threadIdx.x >> 6);
 	if (x >= dst_w || y >= dst_h)
@@ -183,12 +203,20 @@ cfhip_mip_pass_kernel(const uint8_t* __restrict__ src, size_t pitch, uint32_t sr
 		double w = fscale*fi_filter(filter, fscale*((double)i + 0.5 - center));
 		if (total > 0.0 && total != 1.0)
 			w /= total;
-		float4 p = ALONG_X ? load_rgbaf<SRC_PIX>(src + (size_t)y*pitch, (uint32_t)i)
-			: load_rgbaf<SRC_PIX>(src + (size_t)i*pitch, x);
-		if (to_linear) {
-			p.x = (float)srgb_to_linear((double)p.x);
-			p.y = (float)srgb_to_linear((double)p.y);
-			p.z = (float)srgb_to_linear((double)p.z);
+		float4 p;
+		if (SRC_PIX == 0 && to_linear) {
+			const uint8_t* rowp = ALONG_X ? src + (size_t)y*pitch : src + (size_t)i*pitch;
+			const uint32_t v = *reinterpret_cast<const uint32_t*>(rowp + (size_t)(ALONG_X ? (uint32_t)i : x)*4u);
+			p = make_float4(lin_of_u8[v & 255u], lin_of_u8[(v >> 8) & 255u], lin_of_u8[(v >> 16) & 255u],
+				(float)((double)(v >> 24)/255.0));
+		} else {
+			p = ALONG_X ? load_rgbaf<SRC_PIX>(src + (size_t)y*pitch, (uint32_t)i)
+				: load_rgbaf<SRC_PIX>(src + (size_t)i*pitch, x);
+			if (to_linear) {
+				p.x = (float)srgb_to_linear((double)p.x);
+				p.y = (float)srgb_to_linear((double)p.y);
+				p.z = (float)srgb_to_linear((double)p.z);
+			}
 		}
 		c0 += w*(double)p.x; c1 += w*(double)p.y; c2 += w*(double)p.z; c3 += w*(double)p.w;
 	}
