@@ -219,17 +219,21 @@ __device__ __forceinline__ void fit_subset(const uint32_t* tp, uint32_t mask, in
 			k = k < 0 ? 0 : (k > nidx - 1 ? nidx - 1 : k);
 			idx64 |= (unsigned long long)(uint32_t)k << (4u*i);
 			if (more) {
-				const int w = two ? k6_w3((int)k) : k6_w4((int)k), iw = 64 - w;
-				S += w; A += iw*iw; B += iw*w; C += w*w;
+				const int w = two ? k6_w3((int)k) : k6_w4((int)k);
+				S += w; C += w*w;
 #pragma unroll
-				for (int c = 0; c < 3; ++c) {
-					U[c] += iw*t.v[c];
+				for (int c = 0; c < 3; ++c)
 					V[c] += w*t.v[c];
-				}
 			}
 		}
 		if (!more)
 			break;
+		// with iw = 64 - w: sum iw^2, sum iw w and sum iw v follow from S, C, V and the subset's
+		// texel count and value sums (exact integers)
+		A = 4096*n - 128*S + C; B = 64*S - C;
+#pragma unroll
+		for (int c = 0; c < 3; ++c)
+			U[c] = 64*sum[c] - V[c];
 		const int det = n*C - S*S;
 		if (det <= 0)
 			break;
@@ -352,40 +356,52 @@ __device__ __forceinline__ void fit_pair(const uint32_t* tp, uint32_t m1, uint32
 		}
 		idx64 = 0ull;
 		// sums over all texels (a) and over subset 1 (b)
-		int Sa = 0, Aa = 0, Ba = 0, Ca = 0, Ua[3] = {0, 0, 0}, Va[3] = {0, 0, 0};
-		int Sb = 0, Ab = 0, Bb = 0, Cb = 0, Ub[3] = {0, 0, 0}, Vb[3] = {0, 0, 0};
+		int Sa = 0, Ca = 0, Va[3] = {0, 0, 0};
+		int Sb = 0, Cb = 0, Vb[3] = {0, 0, 0};
 		const bool more = r < iters && (live0 || live1);
+		// eight texels per trip, unrolled: the selector's shift and the texel's LDS offset are
+		// constants, the eight loads go out together
+		uint32_t iword[2] = {0u, 0u};
 #pragma unroll 1
-		for (uint32_t i = 0; i < 16u; ++i) {
-			const Tx t = load_tx<SIGNED>(tp, i);
-			const bool b = (m1 >> i) & 1u;
+		for (uint32_t hb = 0; hb < 2u; ++hb) {
+			const uint32_t mh = m1 >> (8u*hb);
+			const uint32_t* tph = tp + 24u*hb;
+			uint32_t word = 0u;
+#pragma unroll
+			for (uint32_t j = 0; j < 8u; ++j) {
+			const Tx t = load_tx<SIGNED>(tph, j);
+			const bool b = (mh >> j) & 1u;
 			float p = ((float)t.v[0] - (b ? lo[1][0] : lo[0][0]))*(b ? dl[1][0] : dl[0][0]);
 			p = fmaf((float)t.v[1] - (b ? lo[1][1] : lo[0][1]), b ? dl[1][1] : dl[0][1], p);
 			p = fmaf((float)t.v[2] - (b ? lo[1][2] : lo[0][2]), b ? dl[1][2] : dl[0][2], p);
 			int k = (int)floorf(p*(b ? scale[1] : scale[0]) + 0.5f);
 			k = k < 0 ? 0 : (k > 7 ? 7 : k);
-			idx64 |= (unsigned long long)(uint32_t)k << (4u*i);
+			word |= (uint32_t)k << (4u*j);
 			if (more) {
-				const int w = k6_w3(k), iw = 64 - w;
-				const int wb = b ? w : 0, iwb = b ? iw : 0;
-				Sa += w; Aa += iw*iw; Ba += iw*w; Ca += w*w;
-				Sb += wb; Ab += iwb*iw; Bb += iwb*w; Cb += wb*w;
+				const int w = k6_w3(k);
+				const int wb = b ? w : 0;
+				Sa += w; Ca += w*w;
+				Sb += wb; Cb += wb*w;
 #pragma unroll
 				for (int c = 0; c < 3; ++c) {
-					Ua[c] += iw*t.v[c];
 					Va[c] += w*t.v[c];
-					Ub[c] += iwb*t.v[c];
 					Vb[c] += wb*t.v[c];
 				}
 			}
+			}
+			if (hb) iword[1] = word; else iword[0] = word;
 		}
+		idx64 = ((unsigned long long)iword[1] << 32) | iword[0];
 		if (!more)
 			break;
 #pragma unroll
 		for (int s = 0; s < 2; ++s) {
 			const bool live = s ? live1 : live0;
 			const int n = s ? n1 : n0;
-			const int S = s ? Sb : Sa - Sb, A = s ? Ab : Aa - Ab, B = s ? Bb : Ba - Bb, Cq = s ? Cb : Ca - Cb;
+			// with iw = 64 - w: sum iw^2 = 4096 n - 128 S + C, sum iw w = 64 S - C and
+			// sum iw v = 64 sum v - V (exact integers; sum v of the subset from the first walk)
+			const int S = s ? Sb : Sa - Sb, Cq = s ? Cb : Ca - Cb;
+			const int A = 4096*n - 128*S + Cq, B = 64*S - Cq;
 			const int det = n*Cq - S*S;
 			const bool upd = live && det > 0;
 			if (s) live1 = upd; else live0 = upd;
@@ -393,7 +409,8 @@ __device__ __forceinline__ void fit_pair(const uint32_t* tp, uint32_t m1, uint32
 			const float fA = (float)A, fB = (float)B, fC = (float)Cq;
 #pragma unroll
 			for (int c = 0; c < 3; ++c) {
-				const float fU = (float)(s ? Ub[c] : Ua[c] - Ub[c]), fV = (float)(s ? Vb[c] : Va[c] - Vb[c]);
+				const int Vq = s ? Vb[c] : Va[c] - Vb[c];
+				const float fU = (float)(64*(s ? s1[c] : sa[c] - s1[c]) - Vq), fV = (float)Vq;
 				const float t0 = fB*fV;
 				const float nn0 = fmaf(fC, fU, -t0);
 				const float t1 = fB*fU;
