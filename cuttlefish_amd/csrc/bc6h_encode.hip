@@ -259,11 +259,6 @@ struct HCand {
 	unsigned long long idx;   // 4 bits per texel
 };
 
-__device__ __forceinline__ bool fits(int d, int bits)
-{
-	return d >= -(1 << (bits - 1)) && d <= (1 << (bits - 1)) - 1;
-}
-
 // Both subsets of a partition in ONE pass over the texels per stage (fit_subset twice walks the
 // 16 texels twice per stage, every lane skipping the other subset's texels -- and the wavefront
 // executes all 32 iterations, its lanes hold different partitions).  A texel's subset bit selects
@@ -440,27 +435,43 @@ template <bool SIGNED>
 __device__ __forceinline__ void finish_candidate(const uint32_t* tp, bool two, uint32_t m1, uint32_t id,
 	uint32_t part, const int (&e)[4][3], unsigned long long idx, HCand& c)
 {
-	const uint32_t norder = two ? 10u : 4u, ne = two ? 4u : 2u;
+	const uint32_t norder = two ? 10u : 4u;
 	uint32_t mode = two ? 9u : 10u;
 	int q[4][3];
 	bool done = false;
+	// modes of one endpoint precision share the quantised endpoints and the ranges of their deltas
+	// (3 + 1 + 1 + 3 + 1 + 1 two-subset modes): both are recomputed only when the precision changes
+	int qq[4][3], dlo[3] = {0, 0, 0}, dhi[3] = {0, 0, 0};
+	int prev_bits = -1;
 	for (uint32_t oi = 0; oi < norder && !done; ++oi) {
 		const uint32_t mi = two ? (uint32_t)k_bc6_order2[oi] : (uint32_t)k_bc6_order1[oi];
 		const Bc6Mode md = k_bc6_modes[mi];
-		bool ok = true;
-		int qq[4][3];
+		if ((int)md.ebits != prev_bits) {
+			prev_bits = (int)md.ebits;
 #pragma unroll
-		for (int k = 0; k < 4; ++k)
-#pragma unroll
-			for (int ch = 0; ch < 3; ++ch)
-				qq[k][ch] = quant<SIGNED>(e[k][ch], (int)md.ebits);
-		if (md.transformed) {
-#pragma unroll
-			for (int k = 1; k < 4; ++k)
+			for (int k = 0; k < 4; ++k)
 #pragma unroll
 				for (int ch = 0; ch < 3; ++ch)
-					if ((uint32_t)k < ne && !fits(qq[k][ch] - qq[0][ch], (int)md.d[ch]))
-						ok = false;
+					qq[k][ch] = quant<SIGNED>(e[k][ch], (int)md.ebits);
+#pragma unroll
+			for (int ch = 0; ch < 3; ++ch) {
+				const int d1 = qq[1][ch] - qq[0][ch];
+				dlo[ch] = dhi[ch] = d1;
+				if (two) {
+					const int d2 = qq[2][ch] - qq[0][ch], d3 = qq[3][ch] - qq[0][ch];
+					dlo[ch] = min(d1, min(d2, d3));
+					dhi[ch] = max(d1, max(d2, d3));
+				}
+			}
+		}
+		bool ok = true;
+		if (md.transformed) {
+#pragma unroll
+			for (int ch = 0; ch < 3; ++ch) {
+				const int lim = 1 << ((int)md.d[ch] - 1);
+				if (dlo[ch] < -lim || dhi[ch] > lim - 1)
+					ok = false;
+			}
 		}
 		if (ok) {
 			done = true;
