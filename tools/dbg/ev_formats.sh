@@ -1,4 +1,4 @@
-R=${GRAFT_REPO_ROOT:-$PWD}; G=$R/gpurun_out; tag=r02k
+R=${GRAFT_REPO_ROOT:-$PWD}; G=$R/gpurun_out; tag=${1:-r02l}
 python $R/tools/bench_formats.py --size 2048 --steps 3 --qualities 0,1,2,3,4 2>/dev/null | grep format > $G/${tag}_formats_2048.jsonl
 bash $R/tools/fuzz_all.sh 300 13 > $G/${tag}_fuzz.txt 2>&1
 python $R/bench.py > $G/${tag}_bench.json 2> $G/${tag}_bench.err
