@@ -20,7 +20,7 @@ Pillow is the independent reader used by tests/test_containers.py).
 from __future__ import annotations
 
 import struct
-from typing import List, Sequence
+from typing import Sequence
 
 from .api import Alpha, ColorSpace, Format, Type, payload_size, query
 

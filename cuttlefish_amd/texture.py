@@ -32,7 +32,7 @@ from __future__ import annotations
 
 import enum
 import io
-from typing import Dict, List, Optional, Sequence, Tuple, Union
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -305,7 +305,7 @@ class Texture:
 
     # ---- images (Texture.cpp:1234-1318) -------------------------------------------------------
     @staticmethod
-    def _face_args(args, names=("mip", "depth")):
+    def _face_args(args):
         """([face,] mip=0, depth=0) -> (face or None, mip, depth)"""
         if args and isinstance(args[0], CubeFace):
             face, rest = args[0], args[1:]

@@ -2,14 +2,13 @@
 539-805 GenerateMipmaps / GenerateMipmapsCustomMips / Generate3DMipmaps / Generate3DMipmapsCustomMips),
 run through the mirror with the GPU doing the resizing and the encoding, plus the new
 cfhip_resize_device against the oracle's Image::resize and whole-texture convert + save."""
-import io
 import struct
 
 import numpy as np
 import pytest
 
 import oracle_lib as O
-from cuttlefish_amd import ColorSpace, Context, Format, Type, api, containers, synth
+from cuttlefish_amd import ColorSpace, Context, Format, Type, api, synth
 from cuttlefish_amd.texture import (CubeFace, CustomMipImage, Dimension, FileType, MipReplacement,
                                     SaveResult, Texture, image_index)
 

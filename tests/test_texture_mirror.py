@@ -5,7 +5,6 @@ import json
 import os
 
 import numpy as np
-import pytest
 
 from cuttlefish_amd import ColorSpace, Format, Type
 from cuttlefish_amd.texture import (CubeFace, Dimension, FileType, SaveResult, Texture, image_index)
