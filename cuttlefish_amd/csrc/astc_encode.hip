@@ -39,6 +39,14 @@ using cfastc::AstcCfgRec;
 #ifndef CF_ASTC_ABLATE
 #define CF_ASTC_ABLATE 0   // timing experiments only (tools/dbg/astc_ablate.sh): phases switched off
 #endif
+#ifndef CF_ASTC_PROF
+#define CF_ASTC_PROF 0   // debug build (tools/dbg/astc_phase_prof.sh): one wave prints the clock ticks it spent per phase
+#endif
+#if CF_ASTC_PROF
+#define PROF_MARK(k) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); prof_acc[k] += t__ - prof_t; prof_t = t__; }
+#else
+#define PROF_MARK(k)
+#endif
 
 namespace {
 
@@ -565,6 +573,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	uint8_t* slot0 = wbase + ((((col_rows + 1u)/2u)*256u + wc_rows*256u + 15u) & ~15u);
 
 	const uint32_t q = kp.quality > 4u ? 4u : kp.quality;
+#if CF_ASTC_PROF
+	unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
+#endif
 	const Ladder lad = ladder(q);
 	const bool can_pair = q <= 2u;
 	uint32_t cw[4] = {1u, 1u, 1u, 1u};
@@ -591,6 +602,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			S.pcs = w32 + 240; S.best = w32 + 280;
 		}
 
+		PROF_MARK(0)
 		// ---- block statistics (texels strided over the group) ----
 		const uint32_t p0 = tp[0];
 		// the alpha a block without an alpha endpoint decodes to: 1.0 = 255 (UNORM) or LNS code 120
@@ -838,6 +850,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		}
 		__builtin_amdgcn_wave_barrier();
 
+		PROF_MARK(1)   // statistics + candidate list + shortlist
 		// ---- passes of (gsz / K) candidates x K configs ----
 		const uint32_t K = lad.K, kshift = K == 2u ? 1u : (K == 4u ? 2u : 3u), per_pass = gsz >> kshift;
 		unsigned long long bestkey = ~0ull;
@@ -866,6 +879,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			}
 			__builtin_amdgcn_wave_barrier();
 
+			PROF_MARK(2)   // partition rows
 			// ---- phase A: lane = (candidate j, slot s) ----
 			{
 				// 32 (candidate, slot) units; a wave that holds one block gives each unit two lanes (hl and
@@ -985,6 +999,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			}
 			__builtin_amdgcn_wave_barrier();
 
+			PROF_MARK(3)   // phase A
 			// ---- lane = weight grid: decimation error of candidate 0's ideal weights (pass 0) ----
 			if (pass == 0u) {
 				const uint32_t g = hl;
@@ -1022,6 +1037,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				__builtin_amdgcn_wave_barrier();
 			}
 
+			PROF_MARK(4)   // grids
 			// ---- ranking: lane = config of the candidate's class, K smallest estimates ----
 			for (uint32_t j = 0; j < (per_pass < 8u ? per_pass : 8u); ++j) {
 				const bool jact = j < cnt;
@@ -1058,6 +1074,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			}
 			__builtin_amdgcn_wave_barrier();
 
+			PROF_MARK(5)   // ranking
 			// ---- phase B: lane = (candidate j, rank ks) ----
 			unsigned long long err = ~0ull;
 			uint32_t r_cem = 0, r_lv = 0, r_ncv = 0, r_cfg = 0;
@@ -1110,6 +1127,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							COLR(g*planes + pl) = (uint16_t)((uint32_t)sh.wunq[wq*32u + qv] | (qv << 8));
 						}
 					}
+					PROF_MARK(6)   // B: decimate + quantise
 					// 2. + 3. texel weights and the least-squares sums per set (subset, or plane)
 					const uint32_t nset = dual ? 2u : P;
 					// per set only S = sum w, C = sum w^2 and V_c = sum w p_c are accumulated: with the
@@ -1196,6 +1214,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							r1[c] = bq;
 						}
 					};
+					PROF_MARK(7)   // B: texel weights + sums
 					// 4. endpoint mode by the quadratic estimate (same mode for every partition):
 					// option o = 0 direct (CEM 8/12), 1 base + scale (6/10), 2 luminance (0/4)
 					// option o = 3: base + offset (CEM 9 / 13), the value count of the direct mode
@@ -1254,6 +1273,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							}
 						}
 #undef SEL4
+						PROF_MARK(8)   // B: endpoint modes
 						// 5. exact error through the decode arithmetic
 						unsigned long long e64 = 0;
 #pragma unroll 1
@@ -1305,6 +1325,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					e1min = cf_group_min_u64(P == 1u ? err : ~0ull, false, 0u);
 					e2min = cf_group_min_u64(P == 2u ? err : ~0ull, false, 0u);
 				}
+				PROF_MARK(9)   // B: exact error (+ idle lanes waiting)
 				// ---- argmin (error, id); the winner parks its result in the block's slot ----
 				const uint32_t id = pass*64u + hl;
 				unsigned long long key = err == ~0ull ? ~0ull : ((err << 10) | id);
@@ -1328,6 +1349,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			}
 		}
 
+		PROF_MARK(10)  // argmin + park
 		// ---- pack the winner, spread over the group ----
 		{
 			unsigned long long lo64 = 0ull, hi64 = 0ull;
@@ -1404,8 +1426,15 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			if (!solid && have && hl == 0u)
 				outb[b] = make_uint4(w0, w1, w2, w3);
 		}
+		PROF_MARK(11)  // pack
 		__builtin_amdgcn_wave_barrier();
 	}
+#if CF_ASTC_PROF
+	if (blockIdx.y*gridDim.x + blockIdx.x == 1000u && threadIdx.x == 0u)
+		printf("astc prof q%u (clock ticks of wave 0, 4 blocks): pre %llu stats+shortlist %llu rows %llu A %llu grids %llu rank %llu "
+			"B.dec %llu B.lsq %llu B.cem %llu B.err %llu park %llu pack %llu\n", q, prof_acc[0], prof_acc[1], prof_acc[2],
+			prof_acc[3], prof_acc[4], prof_acc[5], prof_acc[6], prof_acc[7], prof_acc[8], prof_acc[9], prof_acc[10], prof_acc[11]);
+#endif
 	__syncthreads();
 	const uint32_t t = threadIdx.x;
 	if (t < nblk*4u) {
