@@ -9,10 +9,10 @@ from .api import (Alpha, CfhipError, ColorSpace, Context, Format, PixelType, Qua
                   ResizeFilter, Type,
                   device_count, load_library, make_params, payload_size, query, shard_rows)
 from . import shard  # noqa: F401
-from .texture import (CubeFace, CustomMipImage, Dimension, FileType, MipReplacement, SaveResult,  # noqa: F401
+from .texture import (CubeFace, CustomMipImage, Dimension, FileType, ImageFormat, MipReplacement, SaveResult,  # noqa: F401
                       Texture, image_index)
 
 __all__ = ["Alpha", "CfhipError", "ColorSpace", "Context", "Format", "PixelType", "Quality",
            "ResizeFilter", "Type", "Texture", "Dimension", "CubeFace", "FileType", "SaveResult",
-           "MipReplacement", "CustomMipImage", "image_index", "device_count", "load_library", "make_params", "payload_size",
+           "MipReplacement", "CustomMipImage", "ImageFormat", "image_index", "device_count", "load_library", "make_params", "payload_size",
            "query", "shard", "shard_rows"]

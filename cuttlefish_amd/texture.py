@@ -12,7 +12,8 @@ Mirrors ``cuttlefish::Texture`` as the reference's callers and tests use it
     converted / format / type / alpha_type / color_mask / data / data_size           :1563-1634
     save(file_name | None, file_type) -> SaveResult (or bytes)                       :1636-1685
     statics: is_format_valid, has_native_srgb, has_alpha, max_mipmap_levels, block_width /
-             block_height / block_size, min_width / min_height, file_type            :318-957
+             block_height / block_size, min_width / min_height, file_type,
+             adjust_image_value_range                                              :318-1084
 
 Same argument meaning and error behaviour: ``convert`` returns False when the images are
 incomplete, the (format, type) pair is illegal (isFormatValid / createConverter returning nullptr,
@@ -79,6 +80,27 @@ class SaveResult(enum.IntEnum):     # Texture::SaveResult (Texture.h:204-211)
     UnknownFormat = 2
     Unsupported = 3
     WriteError = 4
+
+
+class ImageFormat(enum.IntEnum):    # Image::Format (Image.h:54-74): only names an image's ORIGINAL storage here
+    Invalid = 0
+    Gray8 = 1
+    Gray16 = 2
+    RGB5 = 3
+    RGB565 = 4
+    RGB8 = 5
+    RGB16 = 6
+    RGBF = 7
+    RGBA8 = 8
+    RGBA16 = 9
+    RGBAF = 10
+    Int16 = 11
+    UInt16 = 12
+    Int32 = 13
+    UInt32 = 14
+    Float = 15
+    Double = 16
+    Complex = 17
 
 
 class CustomMipImage:
@@ -201,6 +223,52 @@ class Texture:
             if low.endswith(ext):
                 return ft
         return FileType.Auto
+
+    @staticmethod
+    def adjust_image_value_range(image, type, orig_image_format=ImageFormat.Invalid) -> Optional[np.ndarray]:
+        """Texture::adjustImageValueRange (Texture.cpp:959-1084): what the reference's front end does
+        to an image that came from an integer file format before a SNorm / UInt / Int conversion --
+        SNorm remaps [0, 1] to [-1, 1] (v*2 - 1 in float), UInt scales to the original integer range
+        (round(v*max)), Int also offsets by the type's minimum.  Images from float formats, and
+        UNorm / UFloat / Float conversions, are returned unchanged.  image: (h, w, C) array; uint8 /
+        uint16 arrays are read as v/255, v/65535 and name their own original format."""
+        if image is None:
+            return None
+        image = np.asarray(image)
+        fmt = ImageFormat(orig_image_format)
+        if fmt == ImageFormat.Invalid:
+            if image.dtype == np.uint8:
+                fmt = {1: ImageFormat.Gray8, 3: ImageFormat.RGB8}.get(image.shape[-1], ImageFormat.RGBA8)
+            elif image.dtype == np.uint16:
+                fmt = {1: ImageFormat.Gray16, 3: ImageFormat.RGB16}.get(image.shape[-1], ImageFormat.RGBA16)
+            else:
+                fmt = ImageFormat.RGBAF
+        if image.dtype == np.uint8:
+            out = (image.astype(np.float64)/255.0).astype(np.float32)
+        elif image.dtype == np.uint16:
+            out = (image.astype(np.float64)/65535.0).astype(np.float32)
+        else:
+            out = image.astype(np.float32)
+        type = Type(type)
+        integer_origin = fmt in (ImageFormat.Gray8, ImageFormat.Gray16, ImageFormat.RGB5, ImageFormat.RGB565,
+                                 ImageFormat.RGB8, ImageFormat.RGB16, ImageFormat.RGBA8, ImageFormat.RGBA16)
+        if type not in (Type.SNorm, Type.UInt, Type.Int) or not integer_origin:
+            return out if out is not image else out.copy()
+        if type == Type.SNorm:
+            return out*np.float32(2.0) - np.float32(1.0)
+        if fmt in (ImageFormat.Gray8, ImageFormat.RGB8, ImageFormat.RGBA8):
+            mul, off = [255.0]*4, [-128.0]*4
+        elif fmt in (ImageFormat.Gray16, ImageFormat.RGB16, ImageFormat.RGBA16):
+            mul, off = [65535.0]*4, [-32768.0]*4
+        elif fmt == ImageFormat.RGB5:
+            mul, off = [31.0, 31.0, 31.0, 0.0], [-16.0, -16.0, -16.0, 0.0]
+        else:                                                    # RGB565
+            mul, off = [31.0, 63.0, 31.0, 0.0], [-16.0, -32.0, -16.0, 0.0]
+        c = out.shape[-1]
+        m = np.array(mul[:c], np.float32)
+        o = np.array(off[:c] if type == Type.Int else [0.0]*c, np.float32)
+        v = out*m + o
+        return (np.sign(v)*np.floor(np.abs(v) + np.float32(0.5))).astype(np.float32)    # std::round
 
     # ---- construction ---------------------------------------------------------------------------
     def __init__(self, *args, depth: int = 0, mip_levels: int = 1,

@@ -114,3 +114,41 @@ def test_is_format_valid_per_file_type_matches_the_reference_save_tables():
             n += 1
     assert n > 250
     assert not Texture.is_format_valid(Format.BC7, Type.UNorm, FileType.Auto)
+
+
+def _test_colour(w, h):
+    """getTestColor of the reference's tests (lib/test/TextureTest.cpp:53-61)"""
+    x, y = np.meshgrid(np.arange(w), np.arange(h))
+    return np.stack([x/(w - 1), y/(h - 1), (w - 1 - x)/(w - 1), (h - 1 - y)/(h - 1)], axis=-1)
+
+
+def test_adjust_image_value_range():
+    """TextureTest.AdjustImageValueRangeUNorm / UInt / Int (lib/test/TextureTest.cpp:63-418) for the
+    RGBA images this path carries: SNorm remaps an integer-origin image to [-1, 1], UInt scales to the
+    original range, Int also offsets; float-origin images and UNorm are untouched."""
+    from cuttlefish_amd.texture import ImageFormat
+
+    def std_round(v):                                            # half away from zero, like std::round
+        return np.sign(v)*np.floor(np.abs(v) + np.float32(0.5))
+    ref = _test_colour(14, 15)
+    img = ref.astype(np.float32)
+    same = Texture.adjust_image_value_range(img, Type.UNorm, ImageFormat.RGBA8)
+    assert np.array_equal(same, img)
+    sn = Texture.adjust_image_value_range(img, Type.SNorm, ImageFormat.RGBA8)
+    assert np.allclose(sn, ref*2.0 - 1.0, atol=1e-6)
+    assert np.array_equal(Texture.adjust_image_value_range(img, Type.SNorm, ImageFormat.RGBAF), img)   # float origin
+    for fmt, maxv, gmax, bits, gbits, ch in ((ImageFormat.RGBA8, 255, 255, 8, 8, 4), (ImageFormat.RGBA16, 65535, 65535, 16, 16, 4),
+                                            (ImageFormat.RGB565, 31, 63, 5, 6, 3), (ImageFormat.RGB5, 31, 31, 5, 5, 3)):
+        src = img[..., :ch]
+        ui = Texture.adjust_image_value_range(src, Type.UInt, fmt)
+        ii = Texture.adjust_image_value_range(src, Type.Int, fmt)
+        for c in range(ch):
+            m = gmax if c == 1 else maxv
+            b = gbits if c == 1 else bits
+            want = std_round(src[..., c].astype(np.float32)*np.float32(m))
+            assert np.array_equal(ui[..., c], want), (fmt, c)
+            assert np.array_equal(ii[..., c], std_round(src[..., c].astype(np.float32)*np.float32(m) + np.float32(-(1 << (b - 1))))), (fmt, c)
+    u8 = (ref*255 + 0.5).astype(np.uint8)
+    a = Texture.adjust_image_value_range(u8, Type.Int)                   # names its own format
+    assert np.array_equal(a, std_round((u8.astype(np.float64)/255.0).astype(np.float32)*np.float32(255.0) - np.float32(128.0)))
+    assert a.min() == -128.0 and a.max() == 127.0
