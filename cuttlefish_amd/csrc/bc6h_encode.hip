@@ -6,7 +6,8 @@
 // nearest-even packing of the block (:113-129, HalfFloat.h:96-136).
 //
 // Candidates: id 0 = one subset (modes 14/13/12/11), ids 1..32 = the 32 two-subset partitions
-// (ten modes); a wavefront's four blocks take three passes (see the kernel body).  Per subset: PCA axis in the decoder's 16-bit
+// (ten modes); wavefront 0 fits the one-subset candidates of the workgroup's 16 blocks on 16 lanes, every
+// wavefront its four blocks' partitions in two passes (see the kernel body).  Per subset: PCA axis in the decoder's 16-bit
 // interpolation space -> extremes -> refit rounds (projection selectors, closed-form
 // least squares) -> anchor fix-up -> highest-precision mode whose deltas fit -> exact
 // integer error in half-bit space (64-bit).  Wave argmin on (error, id), the winning lane
