@@ -832,7 +832,8 @@ __device__ __forceinline__ int eac_decode(int kind, int base, int m, int mult)
 	return clampi(base*8 + m*mult*8, -1023, 1023);
 }
 
-// pre: 256 words of wave-private LDS, used for kind 0 (8-bit values) only: the block's prefix
+// pre: wave-private LDS, 256 words for kind 0 (8-bit values), 2048 for the 11-bit kinds (values
+// biased to 0..2047): the block's prefix
 // table pre[x] = (number of active texels <= x) << 16 | (sum of those texels).  The eight
 // decoded values of a candidate are monotone in the order k = 3,2,1,0,4,5,6,7 (every modifier
 // table is four descending negatives then four ascending non-negatives, and clamping keeps the
