@@ -12,6 +12,14 @@ max-over-ranks of the elapsed time.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Launched plainly with --gpus N > 1 (no WORLD_SIZE in the environment) the script starts its N
+ranks itself (re-exec under torch.distributed.run on 127.0.0.1); under a launcher it is one rank.
+For N > 1 the same JSON line also carries `strong_scaling`: ONE 4096x4096 tile held by rank 0, its
+block rows cut by cfhip_shard_rows (Converter.cpp:540-583 parallelises inside a surface), source
+rows scattered over RCCL, every rank encoding its range, payload ranges gathered to rank 0 as
+device buffers and compared byte for byte with rank 0's own whole-tile encode; the RCCL scatter
+is timed beside per-rank pinned-host uploads of the same byte counts.
+
 `--config c5` runs BASELINE.json configs[4] instead: a texture array of 256 x
 (2048x2048 RGBA8 + its 12-level mip chain), BC7 Normal, the textures LPT-sharded over the N
 ranks (cuttlefish_amd/shard.py), mips generated on the GPU, ONE batched encode per rank, payload
@@ -303,24 +311,29 @@ def run_c5(args, rank, local_rank, world, backend):
     elapsed = max(float(s[0]) for s in allstats)
 
     if rank == 0:
-        # byte-equality of the sharded result against a local re-encode on a sub-sample of the
-        # textures OTHER ranks own (regenerated from their seeds)
+        # byte-equality of the batched / sharded result against a per-texture re-encode on rank 0
+        # (texture regenerated from its seed, mips regenerated, ONE texture per encode call): the
+        # first and last texture of rank 0's own share -- so the check is not vacuous at N = 1 --
+        # and, for N > 1, of rank 1's and the last rank's share as they arrived through the gather
         check = {"textures_checked": [], "equal": True}
+        local_view = out if parts is None else parts[0]
+        todo = [(0, pos, local_view) for pos in sorted({0, len(plan[0]) - 1}) if plan[0]]
         if world > 1 and parts is not None:
             for r in sorted({1, world - 1}):
-                for pos in sorted({0, len(plan[r]) - 1}):
-                    t = plan[r][pos]
-                    b = [gpu_texture(torch, n, t, dev)]
-                    c = [[torch.empty((d, d, 4), dtype=torch.float32, device=dev) for d in dims[1:]]]
-                    o = torch.empty(chain_bytes, dtype=torch.uint8, device=dev)
-                    ctx.generate_mips_device(b[0].data_ptr(), PixelType.RGBA8, n, n, n * 4,
-                                             [x.data_ptr() for x in c[0]], color_space=ColorSpace.Linear,
-                                             filter=0, stream=stream)
-                    ctx.encode_device(surfaces(b, c, o), params, stream)
-                    torch.cuda.synchronize()
-                    same = bool(torch.equal(o, parts[r][pos * chain_bytes:(pos + 1) * chain_bytes]))
-                    check["textures_checked"].append(t)
-                    check["equal"] = check["equal"] and same
+                todo += [(r, pos, parts[r]) for pos in sorted({0, len(plan[r]) - 1}) if plan[r]]
+        for r, pos, buf in todo:
+            t = plan[r][pos]
+            b = [gpu_texture(torch, n, t, dev)]
+            c = [[torch.empty((d, d, 4), dtype=torch.float32, device=dev) for d in dims[1:]]]
+            o = torch.empty(chain_bytes, dtype=torch.uint8, device=dev)
+            ctx.generate_mips_device(b[0].data_ptr(), PixelType.RGBA8, n, n, n * 4,
+                                     [x.data_ptr() for x in c[0]], color_space=ColorSpace.Linear,
+                                     filter=0, stream=stream)
+            ctx.encode_device(surfaces(b, c, o), params, stream)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(o, buf[pos * chain_bytes:(pos + 1) * chain_bytes]))
+            check["textures_checked"].append({"texture": t, "owner_rank": r, "equal": same})
+            check["equal"] = check["equal"] and same
         pixels = float(T) * px_chain
         line = {
             "metric": "Mpixels/s encode, BC7 texture-array batch (256 x 2048x2048 RGBA8 mip chains)",
@@ -345,62 +358,97 @@ def run_c5(args, rank, local_rank, world, backend):
     ctx.close()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--quality", type=int, default=2)
-    ap.add_argument("--size", type=int, default=SIZE)
-    ap.add_argument("--config", default="c2", choices=["c2", "c5"])
-    ap.add_argument("--textures", type=int, default=256, help="c5: textures in the array")
-    ap.add_argument("--tex-size", type=int, default=2048, help="c5: base level size")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-    if args.steps is None:
-        args.steps = 20 if args.config == "c2" else 3
-    if args.warmup is None:
-        args.warmup = 3 if args.config == "c2" else 1
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
+
+def self_launch(n):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks here (one process per GPU,
+    RCCL rendezvous on 127.0.0.1) and pass rank 0's JSON line through."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def strong_c2(args, ctx, torch, dist, rank, world, backend, img, local_out):
+    """Strong-scaling leg of C2: rank 0's tile split by block rows over the ranks."""
+    from cuttlefish_amd import Format, PixelType, Type, make_params, shard
+    size = args.size
+    dev = torch.device("cuda", torch.cuda.current_device())
+    params = make_params(Format.BC7, Type.UNorm, args.quality)
+    full = torch.from_numpy(img).to(dev).reshape(-1) if rank == 0 else None
+    ranges = shard.row_ranges(size, 4, world)
+    y0, y1, _, _ = ranges[rank]
+    my_bytes = (y1 - y0) * size * 4
+
+    def one(timings=None):
+        return shard.encode_rows_sharded_device(ctx, full, size, size, PixelType.RGBA8, params, rank, world,
+                                                src=0, dst=0, timings=timings)
+
+    def barrier():
+        dist.barrier()
+    for _ in range(max(1, args.warmup)):
+        got = one()
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        got = one()
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # phase split of one more step (synchronised between the phases: not part of `elapsed`)
+    tm = {}
+    one(tm)
+    # the alternative input leg: every rank uploads ITS byte count from pinned host memory
+    pinned = torch.from_numpy(img.reshape(-1)[:max(my_bytes, 1)].copy()).pin_memory()
+    dst = torch.empty(max(my_bytes, 1), dtype=torch.uint8, device=dev)
+    dst.copy_(pinned, non_blocking=True)
+    torch.cuda.synchronize(); barrier()
+    t1 = time.perf_counter()
+    dst.copy_(pinned, non_blocking=True)
+    torch.cuda.synchronize()
+    h2d = time.perf_counter() - t1
+    cpu = backend != "nccl"
+    stats = torch.tensor([elapsed, tm.get("scatter_s", 0.0), tm.get("encode_s", 0.0), tm.get("gather_s", 0.0), h2d],
+                         dtype=torch.float64, device="cpu" if cpu else dev)
+    allstats = [stats.clone() for _ in range(world)]
+    dist.all_gather(allstats, stats)
+    if rank != 0:
+        return None
+    elapsed = max(float(a[0]) for a in allstats)
+    equal = bool(torch.equal(got, local_out))
+    return {
+        "workload": "ONE %dx%d RGBA8 tile held by rank 0, block rows split over %d ranks by cfhip_shard_rows; "
+                    "per step: scatter of source rows (%s) -> BC7 encode of the rank's rows -> exact-size "
+                    "device-buffer gather of the payload to rank 0" % (size, size, world, "RCCL" if not cpu else backend),
+        "scaling": "strong", "value": round(size * size * args.steps / elapsed / 1e6, 3), "unit": "Mpixels/s",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "phases_ms_max_over_ranks": {"scatter": round(max(float(a[1]) for a in allstats) * 1e3, 4),
+                                     "encode": round(max(float(a[2]) for a in allstats) * 1e3, 4),
+                                     "gather": round(max(float(a[3]) for a in allstats) * 1e3, 4)},
+        "input_leg_alternative": {"pinned_h2d_ms_max_over_ranks": round(max(float(a[4]) for a in allstats) * 1e3, 4),
+                                  "bytes_per_rank": [(r1 - r0) * size * 4 for (r0, r1, _, _) in ranges],
+                                  "note": "each rank uploads its own row range from pinned host memory instead "
+                                          "of receiving it from rank 0"},
+        "block_rows_per_rank": [b - a for (_, _, a, b) in ranges],
+        "sharded_equals_local": {"equal": equal, "bytes_compared": int(got.numel()),
+                                 "against": "rank 0's whole-tile encode of the same tile"},
+    }
+
+
+def run_c2(args, rank, local_rank, world, backend):
     import numpy as np
     import torch
     import torch.distributed as dist
-
     from cuttlefish_amd import Context, Format, PixelType, Type, make_params, synth
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if local_rank == 0 and not os.environ.get("CFHIP_LIB"):
-        # never measure a library older than its sources (content hash, cuttlefish_amd/build.py):
-        # a no-op after `__graft_entry__.build()`, one hipcc run otherwise
-        from cuttlefish_amd import build as _build
-        if _build.is_stale():
-            _build.build()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
-    # BENCH_DIST_BACKEND=gloo is a TEST HOOK: it lets the N-rank flow (rendezvous, barriers,
-    # max-over-ranks, rank-0 JSON) run on a box with fewer GPUs than ranks, ranks sharing devices.
-    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    if args.config == "c5":
-        run_c5(args, rank, local_rank, world, backend)
-        if world > 1:
-            dist.destroy_process_group()
-        return
 
     size = args.size
     # every rank encodes its own tile (independent surfaces; weak scaling)
@@ -433,10 +481,17 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = ctx.profile_end()
 
+    per_rank = [{"rank": 0, "kernel_ms": round(kernel_ms / max(launches, 1), 4)}]
+    strong = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed, kernel_ms / max(launches, 1)], dtype=torch.float64,
+                         device="cuda" if backend == "nccl" else "cpu")
+        allt = [t.clone() for _ in range(world)]
+        dist.all_gather(allt, t)
+        elapsed = max(float(a[0]) for a in allt)
+        per_rank = [{"rank": r, "kernel_ms": round(float(allt[r][1]), 4)} for r in range(world)]
+        if not args.no_strong:
+            strong = strong_c2(args, ctx, torch, dist, rank, world, backend, img, out)
 
     if rank == 0:
         pixels_per_step = float(size * size) * world
@@ -456,6 +511,7 @@ def main():
                        "format": FORMAT_NAME, "quality": args.quality,
                        "blocks_per_launch": (size // 4) ** 2, "parallelism": "surface-per-gpu x%d"
                        % world},
+            "per_rank": per_rank,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 8),
                          "traffic": None, "kernel": ctx.last_kernel_name(),
@@ -471,16 +527,83 @@ def main():
             if traffic is not None:
                 line["roofline"]["traffic"] = traffic
                 line["roofline"]["traffic_source"] = source
+            # PMC passes cannot run inside the timed region: traffic and the dynamic instruction
+            # counts are REPLAYED from the committed profile of the same code hash, never measured here
+            line["roofline"]["traffic_measured_in_this_run"] = False
+        if strong is not None:
+            line["strong_scaling"] = strong
         if world == 1 and not args.no_cpu_baseline and size == SIZE:
             payload = out.cpu().numpy()
             line["cpu_baseline"] = cpu_baseline(img, payload, size, args.quality)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-
     ctx.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--quality", type=int, default=2)
+    ap.add_argument("--size", type=int, default=SIZE)
+    ap.add_argument("--config", default="c2", choices=["c2", "c5"])
+    ap.add_argument("--textures", type=int, default=256, help="c5: textures in the array")
+    ap.add_argument("--tex-size", type=int, default=2048, help="c5: base level size")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="c2, N > 1: skip the row-split strong-scaling leg")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 20 if args.config == "c2" else 3
+    if args.warmup is None:
+        args.warmup = 3 if args.config == "c2" else 1
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: become one (the ranks re-enter main() with WORLD_SIZE set)
+        if not os.environ.get("CFHIP_LIB"):
+            from cuttlefish_amd import build as _build
+            if _build.is_stale():
+                _build.build()
+        raise SystemExit(self_launch(args.gpus))
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if local_rank == 0 and not os.environ.get("CFHIP_LIB"):
+        # never measure a library older than its sources (content hash, cuttlefish_amd/build.py):
+        # a no-op after `__graft_entry__.build()`, one hipcc run otherwise
+        from cuttlefish_amd import build as _build
+        if _build.is_stale():
+            _build.build()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    # BENCH_DIST_BACKEND=gloo is a TEST HOOK: it lets the N-rank flow (rendezvous, barriers,
+    # max-over-ranks, rank-0 JSON) run on a box with fewer GPUs than ranks, ranks sharing devices.
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.destroy_process_group()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        if args.config == "c5":
+            run_c5(args, rank, local_rank, world, backend)
+        else:
+            run_c2(args, rank, local_rank, world, backend)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -57,12 +57,51 @@ def hipcc_path():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+def _object_key(src: str) -> str:
+    """Content hash of one translation unit: flags, the source, every header of csrc/ and the ABI header."""
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    deps = [src] + sorted(p for p in _deps() if p.endswith(".h"))
+    for p in deps:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    """One object per .hip file (compiled in parallel, reused while its content hash stands:
+    changing one kernel recompiles one file), then one link."""
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc_path()] + HIPCC_FLAGS + ["-o", LIB + ".tmp"] + sources()
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(PKG, "build")
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"]
+
+    def compile_one(src):
+        base = os.path.splitext(os.path.basename(src))[0]
+        obj = os.path.join(objdir, base + ".o")
+        stamp = obj + ".key"
+        key = _object_key(src)
+        if not force and os.path.exists(obj) and os.path.exists(stamp):
+            with open(stamp) as f:
+                if f.read().strip() == key:
+                    return obj
+        cmd = [hipcc_path()] + cflags + ["-c", "-o", obj + ".tmp", src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        os.replace(obj + ".tmp", obj)
+        with open(stamp, "w") as f:
+            f.write(key + "\n")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, sources()))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
     with open(STAMP, "w") as f:

@@ -27,11 +27,13 @@
 // Data: the workgroup (4, 8 or 12 waves, cfhip_astc_plan) stages a strip of 4 blocks per wave, the footprint's infill / factor-sum tables
 // and the colour / weight quantisation tables in LDS; each lane owns an LDS column for its grid
 // accumulators and quantised weights ([row][lane], conflict-free for a fixed row).
+#include <mutex>
 #include "cf_device.h"
 #include "astc_tables.h"
 #include <hip/hip_fp16.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 using cfastc::AstcBlobHeader;
 using cfastc::AstcCfgRec;
@@ -1447,6 +1449,39 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	}
 }
 
+// LDS of a compute unit and the most one workgroup may ask for, from the device the calling thread
+// has selected (gfx950: 160 KB; queried once per device, 160 KB assumed if the runtime cannot say --
+// cfhip_astc_plan also runs without a device when the tests inspect launch shapes)
+static size_t cf_astc_cu_lds()
+{
+	static std::mutex lock;
+	static size_t cached[64] = {};
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+		return 160u*1024u;
+	std::lock_guard<std::mutex> guard(lock);
+	if (!cached[dev]) {
+		int per_cu = 0, per_wg = 0;
+		size_t v = 160u*1024u;
+		if (hipDeviceGetAttribute(&per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) == hipSuccess && per_cu >= 64*1024)
+			v = (size_t)per_cu;
+		// a runtime that reports the per-workgroup limit only still bounds the CU from below
+		if (hipDeviceGetAttribute(&per_wg, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && (size_t)per_wg > v)
+			v = (size_t)per_wg;
+		// gfx950 has 160 KB whatever an older runtime's attribute table says
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties(&prop, dev) == hipSuccess && !strncmp(prop.gcnArchName, "gfx950", 6) && v < 160u*1024u)
+			v = 160u*1024u;
+		cached[dev] = v;
+	}
+	return cached[dev];
+}
+
+static size_t cf_astc_wg_lds_max()
+{
+	return cf_astc_cu_lds() - 1024u;     // the kernel's static LDS (payload rows) + allocation granule
+}
+
 // dynamic LDS of a launch for this footprint (same carve-up as in the kernel)
 static size_t astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality, uint32_t nwaves, bool wcached, bool hdr)
 {
@@ -1469,7 +1504,7 @@ static size_t astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality, 
 // else 8), then prefers the smaller workgroup (finer scheduling grain), then the cache.
 extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t quality, uint32_t hdr, uint32_t* nwaves, uint32_t* wcached, size_t* lds_bytes)
 {
-	const size_t cu_lds = 160u*1024u, wg_max = 160u*1024u - 1024u;
+	const size_t cu_lds = cf_astc_cu_lds(), wg_max = cf_astc_wg_lds_max();
 	const bool can_cache = h->n <= 36u;
 	uint32_t best_w = 0, best_nw = 4, best_c = 0;
 	static const char* const force = getenv("CFHIP_ASTC_WAVES");     // experiments: pin the workgroup shape
@@ -1502,18 +1537,34 @@ extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, ui
 	if (kp->batch)
 		grid = dim3(kp->total_wg, 1, 1);
 	dim3 block(nwaves*64u, 1, 1);
-	static bool attr_set = false;
-	if (!attr_set) {
-		// more than 64 KB of dynamic LDS needs the opt-in (160 KB per CU on gfx950)
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 1024);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 1024);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 1024);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<1, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 1024);
-		attr_set = true;
+	// more than 64 KB of dynamic LDS needs the opt-in, and the attribute is PER DEVICE: one process
+	// may drive every GPU of the node (cfhip_encode_multi, one context and host thread per device),
+	// so the opt-in is tracked per device id, set under a lock, and its result is checked
+	if (lds_bytes > 64u*1024u) {
+		static std::mutex attr_lock;
+		static bool attr_set[64] = {};
+		int dev = 0;
+		hipError_t de = hipGetDevice(&dev);
+		if (de != hipSuccess)
+			return de;
+		std::lock_guard<std::mutex> guard(attr_lock);
+		if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+			const int optin = (int)cf_astc_wg_lds_max();
+			const void* const fns[4] = {
+				reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 8>), reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<1, 8>),
+				reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 12>), reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<1, 12>)};
+			for (const void* fn : fns) {
+				const hipError_t ae = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, optin);
+				if (ae != hipSuccess)
+					return ae;
+			}
+			if (dev >= 0 && dev < 64)
+				attr_set[dev] = true;
+		}
 	}
 	// the 168-register build only where three waves per SIMD actually become resident
 	static const bool no_dense = getenv("CFHIP_ASTC_NO_DENSE") != nullptr, debug = getenv("CFHIP_ASTC_DEBUG") != nullptr;
-	const bool dense = (160u*1024u/(lds_bytes + 1024u))*nwaves >= 12u && !no_dense;
+	const bool dense = (cf_astc_cu_lds()/(lds_bytes + 1024u))*nwaves >= 12u && !no_dense;
 	if (debug) {
 		int nb = -1;
 		const void* fn = dense ? reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 12>) : reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 8>);

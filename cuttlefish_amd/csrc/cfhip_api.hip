@@ -522,6 +522,22 @@ int staging_release(cfhip_ctx* ctx, hipStream_t stream)
 	return CFHIP_OK;
 }
 
+// Error exit of a call that may already have enqueued work on the staging buffers: drain the
+// stream (errors are rare) and record the release, so a later call on another stream neither
+// skips its wait nor overwrites buffers this call's kernels still read.  Returns `rc`.
+int staging_abort(cfhip_ctx* ctx, hipStream_t stream, bool used_staging, int rc)
+{
+	if (used_staging) {
+		const std::string keep = ctx->error;
+		// the acquire made `stream` wait for the buffers' previous user, so once `stream` has
+		// drained nothing is in flight on them
+		if (hipStreamSynchronize(stream) == hipSuccess)
+			ctx->staging_busy = false;
+		ctx->error = keep;
+	}
+	return rc;
+}
+
 // One launch for many surfaces (same format / pixel type): workgroups are numbered across
 // the surfaces, the kernel resolves its surface with a uniform binary search (cf_resolve).
 int batched_launch(cfhip_ctx* ctx, const std::vector<cf_kparams>& kps, const cfhip_params& p,
@@ -968,7 +984,7 @@ int cfhip_encode_multi(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface* s
 {
 	if (!ctxs || n_ctx <= 0 || !ctxs[0])
 		return CFHIP_E_INVALID;
-	if (n_ctx == 1 || n_surfaces <= 1)
+	if (n_ctx == 1 || n_surfaces == 0)
 		return cfhip_encode(ctxs[0], surfaces, n_surfaces, params);
 	if (!surfaces || !params)
 		return fail(ctxs[0], CFHIP_E_INVALID, "null surfaces or params");
@@ -978,15 +994,67 @@ int cfhip_encode_multi(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface* s
 	int bw = 4, bh = 4, bs = 16;
 	if (cfhip_query(params->format, params->type, &bw, &bh, &bs) != CFHIP_OK)
 		return fail(ctxs[0], CFHIP_E_UNSUPPORTED, "format %d with type %d is not supported", params->format, params->type);
-	// longest-processing-time assignment on block counts: surfaces by (blocks desc, index asc),
-	// each to the least loaded context (ties: the lowest index) -- cuttlefish_amd/shard.py's rule
-	std::vector<size_t> order(n_surfaces);
-	std::vector<uint64_t> blocks(n_surfaces);
+	// Work units.  The reference parallelises WITHIN a surface (jobsX*jobsY jobs on an atomic
+	// counter, Converter.cpp:540-583) as well as over nothing else, so one big surface must not pin
+	// the call to one GPU: a surface holding more than 1/n_ctx of the call's blocks is cut into
+	// n_ctx ranges of whole block rows (cfhip_shard_rows).  A range is a
+	// surface of its own -- `pixels` advanced by whole block rows, `out` by the rows' payload --
+	// and only the last range sees the true bottom edge, so edge replication and the ETC border
+	// rule act exactly as in the unsplit surface: same bytes.
+	std::vector<uint64_t> sblocks(n_surfaces);
+	uint64_t total = 0;
 	for (size_t i = 0; i < n_surfaces; ++i) {
-		order[i] = i;
-		blocks[i] = (uint64_t)((surfaces[i].width + (uint32_t)bw - 1u)/(uint32_t)bw)*
+		sblocks[i] = (uint64_t)((surfaces[i].width + (uint32_t)bw - 1u)/(uint32_t)bw)*
 			((surfaces[i].height + (uint32_t)bh - 1u)/(uint32_t)bh);
+		total += sblocks[i];
 	}
+	// rows of a standard format are cut in multiples of 4 so that every range's payload keeps the
+	// 4-byte alignment the packers store with
+	const uint32_t row_quant = is_std_format(params->format) ? 4u : 1u;
+	const uint64_t kMinSplitBlocks = 4096;      // below this a second launch costs more than it saves
+	std::vector<cfhip_surface> units;
+	std::vector<uint64_t> blocks;
+	units.reserve(n_surfaces + (size_t)n_ctx);
+	for (size_t i = 0; i < n_surfaces; ++i) {
+		const cfhip_surface& s = surfaces[i];
+		const uint32_t bx = (s.width + (uint32_t)bw - 1u)/(uint32_t)bw;
+		const uint32_t by = (s.height + (uint32_t)bh - 1u)/(uint32_t)bh;
+		const bool split = sblocks[i]*(uint64_t)n_ctx > total && sblocks[i] >= kMinSplitBlocks &&
+			by/row_quant >= 2u && s.pixels && s.out && s.pixel_type >= CFHIP_PIXEL_RGBA8 &&
+			s.pixel_type <= CFHIP_PIXEL_RGBA16F;
+		if (!split) {
+			units.push_back(s);
+			blocks.push_back(sblocks[i]);
+			continue;
+		}
+		const uint32_t qrows = (by + row_quant - 1u)/row_quant;     // rows in units of row_quant
+		const int parts = (int)std::min<uint32_t>((uint32_t)n_ctx, qrows);
+		for (int r = 0; r < parts; ++r) {
+			uint32_t q0, q1;
+			cfhip_shard_rows(qrows, r, parts, &q0, &q1);
+			const uint32_t br0 = q0*row_quant, br1 = std::min(by, q1*row_quant);
+			if (br1 <= br0)
+				continue;
+			const uint32_t y0 = br0*(uint32_t)bh, y1 = std::min(s.height, br1*(uint32_t)bh);
+			cfhip_surface u = s;
+			u.pixels = static_cast<const uint8_t*>(s.pixels) + (ptrdiff_t)y0*s.row_pitch_bytes;
+			u.height = y1 - y0;
+			const size_t off = (size_t)br0*bx*(size_t)bs;
+			u.out = static_cast<uint8_t*>(s.out) + off;
+			// the capacity check of the whole surface is kept: a range may use what is left of it
+			u.out_capacity = s.out_capacity > off ? s.out_capacity - off : 0;
+			if (r + 1 < parts)
+				u.out_capacity = std::min(u.out_capacity, (size_t)(br1 - br0)*bx*(size_t)bs);
+			units.push_back(u);
+			blocks.push_back((uint64_t)(br1 - br0)*bx);
+		}
+	}
+	const size_t n_units = units.size();
+	// longest-processing-time assignment on block counts: units by (blocks desc, index asc),
+	// each to the least loaded context (ties: the lowest index) -- cuttlefish_amd/shard.py's rule
+	std::vector<size_t> order(n_units);
+	for (size_t i = 0; i < n_units; ++i)
+		order[i] = i;
 	std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return blocks[a] > blocks[b]; });
 	std::vector<std::vector<cfhip_surface>> share((size_t)n_ctx);
 	std::vector<uint64_t> load((size_t)n_ctx, 0);
@@ -995,7 +1063,7 @@ int cfhip_encode_multi(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface* s
 		for (size_t c = 1; c < (size_t)n_ctx; ++c)
 			if (load[c] < load[k])
 				k = c;
-		share[k].push_back(surfaces[i]);
+		share[k].push_back(units[i]);
 		load[k] += blocks[i];
 	}
 	std::vector<int> rc((size_t)n_ctx, CFHIP_OK);
@@ -1094,12 +1162,13 @@ int cfhip_generate_mips_device(cfhip_ctx* ctx, const void* src, int src_pixel_ty
 	uint32_t pw = width, ph = height;
 	for (uint32_t k = 1; k < levels; ++k) {
 		if (!dst_levels[k - 1])
-			return fail(ctx, CFHIP_E_INVALID, "mip generation: dst_levels[%u] is NULL", k - 1);
+			return staging_abort(ctx, stream, used_staging,
+				fail(ctx, CFHIP_E_INVALID, "mip generation: dst_levels[%u] is NULL", k - 1));
 		const uint32_t w = (width >> k) ? (width >> k) : 1u, h = (height >> k) ? (height >> k) : 1u;
 		const int rc2 = mip_level_2d(ctx, prev, prev_type, prev_pitch, pw, ph, dst_levels[k - 1], w, h, filter,
 			color_space == CFHIP_COLOR_SRGB ? 1 : 0, stream, &used_staging);
 		if (rc2 != CFHIP_OK)
-			return rc2;
+			return staging_abort(ctx, stream, used_staging, rc2);
 		prev = dst_levels[k - 1];
 		prev_type = CFHIP_PIXEL_RGBA32F;
 		prev_pitch = (size_t)w*16u;
@@ -1111,7 +1180,10 @@ int cfhip_generate_mips_device(cfhip_ctx* ctx, const void* src, int src_pixel_ty
 	}
 	if (!stream_) {
 		HIP_TRY(ctx, hipStreamSynchronize(stream));
-		ctx->staging_busy = false;
+		// the staging buffers are idle only if THIS stream was their last user (an earlier
+		// asynchronous call on another stream may still have d_src / d_batch / d_mip3d in flight)
+		if (used_staging || ctx->staging_stream == stream)
+			ctx->staging_busy = false;
 	}
 	return CFHIP_OK;
 }
@@ -1146,7 +1218,7 @@ int cfhip_resize_device(cfhip_ctx* ctx, const void* src, int src_pixel_type, uin
 		const int rc = mip_level_2d(ctx, src, src_pixel_type, src_pitch_bytes, src_width, src_height, dst,
 			dst_width, dst_height, filter, color_space == CFHIP_COLOR_SRGB ? 1 : 0, stream, &used_staging);
 		if (rc != CFHIP_OK)
-			return rc;
+			return staging_abort(ctx, stream, used_staging, rc);
 	}
 	if (used_staging) {
 		const int rc = staging_release(ctx, stream);
@@ -1154,7 +1226,10 @@ int cfhip_resize_device(cfhip_ctx* ctx, const void* src, int src_pixel_type, uin
 	}
 	if (!stream_) {
 		HIP_TRY(ctx, hipStreamSynchronize(stream));
-		ctx->staging_busy = false;
+		// the staging buffers are idle only if THIS stream was their last user (an earlier
+		// asynchronous call on another stream may still have d_src / d_batch / d_mip3d in flight)
+		if (used_staging || ctx->staging_stream == stream)
+			ctx->staging_busy = false;
 	}
 	return CFHIP_OK;
 }
@@ -1202,13 +1277,14 @@ int cfhip_generate_mips3d_device(cfhip_ctx* ctx, const void* src, int src_pixel_
 	}
 	for (uint32_t k = 1; k < levels; ++k) {
 		if (!dst_levels[k - 1])
-			return fail(ctx, CFHIP_E_INVALID, "3-D mip generation: dst_levels[%u] is NULL", k - 1);
+			return staging_abort(ctx, stream, used_staging,
+				fail(ctx, CFHIP_E_INVALID, "3-D mip generation: dst_levels[%u] is NULL", k - 1));
 		const uint32_t w = (width >> k) ? (width >> k) : 1u, h = (height >> k) ? (height >> k) : 1u,
 			d = (depth >> k) ? (depth >> k) : 1u;
 		const size_t slice_bytes = (size_t)w*h*16u;
 		int rc = reserve(ctx, &ctx->d_mip3d, &ctx->mip3d_cap, slice_bytes*pd);
 		if (rc != CFHIP_OK)
-			return rc;
+			return staging_abort(ctx, stream, used_staging, rc);
 		for (uint32_t i = 0; i < pd; ++i) {
 			uint8_t* dst = static_cast<uint8_t*>(ctx->d_mip3d) + slice_bytes*i;
 			if (w == pw && h == ph)    // Image::resize returns a copy (Image.cpp:1330-1334): an exact Box identity
@@ -1218,7 +1294,7 @@ int cfhip_generate_mips3d_device(cfhip_ctx* ctx, const void* src, int src_pixel_
 				rc = mip_level_2d(ctx, prev + prev_slice*i, prev_type, prev_pitch, pw, ph, dst, w, h, filter, srgb,
 					stream, &used_staging);
 				if (rc != CFHIP_OK)
-					return rc;
+					return staging_abort(ctx, stream, used_staging, rc);
 			}
 		}
 		HIP_TRY(ctx, cfhip_launch_mip_depth(ctx->d_mip3d, pd, w*h, dst_levels[k - 1], d,
@@ -1235,7 +1311,10 @@ int cfhip_generate_mips3d_device(cfhip_ctx* ctx, const void* src, int src_pixel_
 	}
 	if (!stream_) {
 		HIP_TRY(ctx, hipStreamSynchronize(stream));
-		ctx->staging_busy = false;
+		// the staging buffers are idle only if THIS stream was their last user (an earlier
+		// asynchronous call on another stream may still have d_src / d_batch / d_mip3d in flight)
+		if (used_staging || ctx->staging_stream == stream)
+			ctx->staging_busy = false;
 	}
 	return CFHIP_OK;
 }

@@ -37,3 +37,45 @@ def test_multi_reports_the_failure_of_any_share(gpu_ctx):
             gpu_ctx.encode_multi([other], imgs, params)
     finally:
         other.close()
+
+
+@pytest.mark.parametrize("fmt,quality,w,h", [(Format.ASTC_6x6, 1, 1024, 1000), (Format.BC7, 2, 1024, 770),
+                                              (Format.ETC2_R8G8B8, 1, 515, 1021), (Format.R8G8B8, 2, 333, 1027)])
+def test_one_big_surface_is_row_split_over_the_contexts(gpu_ctx, fmt, quality, w, h):
+    """A surface holding more than 1/n of the call's blocks is cut into block-row ranges, one per
+    context (the reference parallelises INSIDE a surface, Converter.cpp:540-583): byte-identical
+    to the one-context encode -- ragged bottom edge, ASTC block height 6, a 3-byte standard
+    format (ranges in multiples of 4 rows) and a small companion surface that is not split."""
+    params = make_params(fmt, Type.UNorm, quality)
+    tile = synth.photo(256, 256, seed=77)
+    big = np.ascontiguousarray(np.tile(tile, (h // 256 + 1, w // 256 + 1, 1))[:h, :w])
+    big[::7, ::5, :3] ^= 0x15                        # break the tiling period
+    imgs = [big, synth.photo(40, 24, seed=78)]
+    want = gpu_ctx.encode(imgs, params)
+    ndev = api.device_count()
+    others = [Context(d % ndev) for d in range(1, 3)]
+    try:
+        got = gpu_ctx.encode_multi(others, imgs, params)
+        kernel_ms = [c.last_kernel_ms() for c in [gpu_ctx] + others]
+    finally:
+        for c in others:
+            c.close()
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    # all three contexts really encoded something
+    assert all(ms > 0 for ms in kernel_ms), kernel_ms
+
+
+def test_row_split_keeps_the_capacity_check(gpu_ctx):
+    import ctypes
+    params = make_params(Format.BC7, Type.UNorm, 0)
+    img = np.zeros((512, 512, 4), np.uint8)
+    other = Context(0)
+    try:
+        surf, outs, keep = gpu_ctx._host_surfaces([img], params)
+        surf[0].out_capacity = outs[0].nbytes - 16
+        arr = (ctypes.c_void_p * 2)(gpu_ctx._h, other._h)
+        rc = gpu_ctx._lib.cfhip_encode_multi(arr, 2, surf, 1, ctypes.byref(params))
+        assert rc == api.E_CAPACITY
+    finally:
+        other.close()

@@ -76,3 +76,53 @@ def test_world2_equals_world1(gpu_ctx):
     want_rows = gpu_ctx.encode([synth.photo(64, 100, seed=7)], p)[0].tobytes()
     for rank, got, rows in results:
         assert got == want and rows == want_rows, "rank %d" % rank
+
+
+def _dev_worker(rank, world, port, backend, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        from cuttlefish_amd import PixelType
+        with Context(dev) as ctx:
+            p = make_params(Format.ASTC_6x6, Type.UNorm, 1)
+            img = synth.photo(70, 100, seed=7)
+            full = torch.from_numpy(img).cuda().reshape(-1) if rank == 0 else None
+            tm = {}
+            rows = shard.encode_rows_sharded_device(ctx, full, 70, 100, PixelType.RGBA8, p, rank, world,
+                                                    src=0, dst=0, timings=tm)
+            assert rows.is_cuda and set(tm) == {"scatter_s", "encode_s", "gather_s"}
+            p7 = make_params(Format.BC7, Type.UNorm, 2)
+            surfs = [{"width": im.shape[1], "height": im.shape[0], "pixel_type": PixelType.RGBA8,
+                      "pixels": torch.from_numpy(im).cuda()} for im in _chain()]
+            outs = shard.encode_surfaces_sharded_device(ctx, surfs, p7, rank, world, dst=None)
+            assert all(o.is_cuda for o in outs)
+            q.put((rank, rows.cpu().numpy().tobytes(), [o.cpu().numpy().tobytes() for o in outs]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_world2_device_buffer_path_equals_world1(gpu_ctx):
+    """scatter -> encode_device -> gather with device tensors on both ends (RCCL when two devices
+    are visible; on one device the ranks share it and gloo carries the bytes)."""
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    port = _free_port()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_dev_worker, args=(r, 2, port, backend, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    results = dict((r[0], r) for r in [q.get(timeout=480) for _ in range(2)])
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    pa = make_params(Format.ASTC_6x6, Type.UNorm, 1)
+    want_rows = gpu_ctx.encode([synth.photo(70, 100, seed=7)], pa)[0].tobytes()
+    want = [o.tobytes() for o in gpu_ctx.encode(_chain(), make_params(Format.BC7, Type.UNorm, 2))]
+    assert results[0][1] == want_rows                    # rank 0 holds the whole payload
+    assert results[1][1] == want_rows[8*12*16:]          # rank 1 keeps its own range: block rows 8..16 of 17, 12 blocks each
+    for r in (0, 1):
+        assert results[r][2] == want

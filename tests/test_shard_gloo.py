@@ -104,3 +104,51 @@ def test_row_shards_follow_the_format_block_height():
     assert seen == [6, 6, 6, 6]
     assert np.array_equal(np.concatenate(parts), whole)
     assert shard.block_count(12, 24, *api.query(Format.ASTC_6x6, Type.UNorm)[:2]) == 2*4
+
+
+def _scatter_worker(rank, world, port, q):
+    import torch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        params = make_params(Format.ASTC_6x6, Type.UNorm, 0)
+        h, w = 44, 30
+        ranges = shard.row_ranges(h, 6, world)
+        sizes = [(y1 - y0)*w*4 for (y0, y1, _, _) in ranges]
+        parts = None
+        if rank == 1:                    # the surface lives on rank 1: scatter from there
+            flat = torch.from_numpy(synth.photo(w, h, seed=81).reshape(-1).copy())
+            parts = [flat[y0*w*4:y1*w*4] for (y0, y1, _, _) in ranges]
+        mine = shard.scatter(parts, sizes, rank, world, src=1, device=torch.device("cpu"))
+        y0, y1, a, b = ranges[rank]
+        rows = mine.numpy().reshape(y1 - y0, w, 4)
+        local = torch.from_numpy(_oracle_encode([rows], params)[0].reshape(-1).copy())
+        out_sizes = [(rb - ra)*5*16 for (_, _, ra, rb) in ranges]
+        got = shard.exchange(local, out_sizes, rank, world, dst=0)
+        q.put((rank, ranges, None if rank else b"".join(p.numpy().tobytes() for p in got)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world2_scatter_encode_gather_equals_single_rank():
+    """The device-path building blocks on CPU tensors: exact-size scatter of block-row ranges from
+    the rank holding the surface, encode, exact-size gather to rank 0."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_scatter_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict((r[0], r) for r in [q.get(timeout=240) for _ in range(world)])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ap = make_params(Format.ASTC_6x6, Type.UNorm, 0)
+    want = _oracle_encode([synth.photo(30, 44, seed=81)], ap)[0].tobytes()
+    assert results[0][2] == want
+    assert results[1][2] is None
+    # 8 block rows of 6 scanlines (the last one ragged: 44 = 7*6 + 2) split 4 + 4
+    assert results[0][1] == [(0, 24, 0, 4), (24, 44, 4, 8)]
