@@ -205,7 +205,10 @@ def write_dds(stream, fmt, typ, width: int, height: int, levels_or_elements: Seq
     out += struct.pack("<7I44x", 124, flags, height, width, pitch, 0, levels)
     out += struct.pack("<2I4s5I", 32, _DDPF_FOURCC, b"DX10", 0, 0, 0, 0, 0)
     out += struct.pack("<5I", caps, 0, 0, 0, 0)
-    out += struct.pack("<5I", dxgi, _DIM_TEXTURE2D, 0, len(elements), misc2)
+    # arraySize = texture.depth() (SaveDds.cpp:637): 0 for a texture that is not an array
+    first = levels_or_elements[0]
+    is_array = not (isinstance(first, (bytes, bytearray, memoryview)) or hasattr(first, "tobytes"))
+    out += struct.pack("<5I", dxgi, _DIM_TEXTURE2D, 0, len(elements) if is_array else 0, misc2)
     assert len(out) == 4 + 124 + 20
     for e in elements:          # element -> (face) -> mip, SaveDds.cpp:657-680
         for m in e:
@@ -458,7 +461,7 @@ def write_dds_texture(stream, tex: TextureLayout, color_space=ColorSpace.Linear,
     out += struct.pack("<5I", caps, caps2, 0, 0, 0)
     out += struct.pack("<5I", dxgi, _DIM_TEXTURE3D if is3d else (_DIM_TEXTURE1D if tex.dimension == "1d" else _DIM_TEXTURE2D),
                        _DDS_MISC_CUBEMAP if tex.dimension == "cube" else 0,
-                       1 if is3d else max(tex.depth, 1), misc2)           # arraySize :637
+                       1 if is3d else tex.depth, misc2)   # arraySize = texture.depth(), 0 for a non-array (:637)
     elements = max(tex.depth, 1) if tex.is_array else 1
     for element in range(elements):
         for face in range(tex.faces):

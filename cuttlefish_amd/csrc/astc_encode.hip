@@ -1569,8 +1569,8 @@ extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, ui
 		int nb = -1;
 		const void* fn = dense ? reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 12>) : reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 8>);
 		hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, (int)(nwaves*64u), lds_bytes);
-		fprintf(stderr, "[astc] %u waves per workgroup, dynamic LDS %zu B, %s build, workgroups per CU %d (%s), grid %u x %u\n",
-			nwaves, lds_bytes, dense ? "168-VGPR" : "256-VGPR", nb, hipGetErrorString(oe), grid.x, grid.y);
+		fprintf(stderr, "[astc] %u waves per workgroup, dynamic LDS %zu B (CU has %zu), %s build, workgroups per CU %d (%s), grid %u x %u\n",
+			nwaves, lds_bytes, cf_astc_cu_lds(), dense ? "168-VGPR" : "256-VGPR", nb, hipGetErrorString(oe), grid.x, grid.y);
 	}
 	if (dense) {
 		if (pixel_type == 0)

@@ -1089,8 +1089,18 @@ int cfhip_encode_device(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n_
 	return encode_impl(ctx, surfaces, n_surfaces, params, true, static_cast<hipStream_t>(stream));
 }
 
+// Image::ResizeFilter 0..4, Box / Linear optionally with the fallback flag
+static bool filter_valid(int filter)
+{
+	const int base = filter & ~CFHIP_FILTER_FALLBACK;
+	if (base < CFHIP_FILTER_BOX || base > CFHIP_FILTER_BSPLINE)
+		return false;
+	return !(filter & CFHIP_FILTER_FALLBACK) || base <= CFHIP_FILTER_LINEAR;
+}
+
 // One 2-D resize of Image::resize (Image.cpp:1324-1511): prev (any pixel type) -> dst (RGBA32F,
-// tightly packed w x h).  Box / Linear: one kernel; the cubic family: FreeImage_Rescale's two passes.
+// tightly packed w x h): FreeImage_Rescale's two passes for all five filters; one kernel for the
+// in-tree fallback of Box / Linear (CFHIP_FILTER_FALLBACK).
 static int mip_level_2d(cfhip_ctx* ctx, const void* prev, int prev_type, size_t prev_pitch, uint32_t pw,
 	uint32_t ph, void* dst, uint32_t w, uint32_t h, int filter, int srgb, hipStream_t stream, bool* used_staging_)
 {
@@ -1098,9 +1108,10 @@ static int mip_level_2d(cfhip_ctx* ctx, const void* prev, int prev_type, size_t 
 	void* const dst_levels[1] = {dst};
 	const uint32_t k = 1;
 	{
-		if (filter <= CFHIP_FILTER_LINEAR) {
+		if (filter & CFHIP_FILTER_FALLBACK) {
+			// the loops Image::resize runs itself when FreeImage_Rescale fails (Image.cpp:1393-1505)
 			HIP_TRY(ctx, cfhip_launch_mip_resize(prev, prev_type, prev_pitch, pw, ph, dst_levels[k - 1], w, h,
-				filter, srgb, stream));
+				filter & 0xFF, srgb, stream));
 		} else {
 			// FreeImage_Rescale's two passes, horizontal first when dst_w*src_h <= dst_h*src_w, with a
 			// float intermediate image in the context's staging buffer; a pass whose size does
@@ -1140,7 +1151,7 @@ int cfhip_generate_mips_device(cfhip_ctx* ctx, const void* src, int src_pixel_ty
 		return fail(ctx, CFHIP_E_INVALID, "mip generation: pixel type %d", src_pixel_type);
 	if (color_space != CFHIP_COLOR_LINEAR && color_space != CFHIP_COLOR_SRGB)
 		return fail(ctx, CFHIP_E_INVALID, "mip generation: colour space %d", color_space);
-	if (filter < CFHIP_FILTER_BOX || filter > CFHIP_FILTER_BSPLINE)
+	if (!filter_valid(filter))
 		return fail(ctx, CFHIP_E_INVALID, "resize filter %d", filter);
 	// maxMipmapLevels for a 2-D texture: floor(log2(max(w, h))) + 1 (Texture.cpp)
 	uint32_t max_levels = 1;
@@ -1201,7 +1212,7 @@ int cfhip_resize_device(cfhip_ctx* ctx, const void* src, int src_pixel_type, uin
 		return fail(ctx, CFHIP_E_INVALID, "resize: pixel type %d", src_pixel_type);
 	if (color_space != CFHIP_COLOR_LINEAR && color_space != CFHIP_COLOR_SRGB)
 		return fail(ctx, CFHIP_E_INVALID, "resize: colour space %d", color_space);
-	if (filter < CFHIP_FILTER_BOX || filter > CFHIP_FILTER_BSPLINE)
+	if (!filter_valid(filter))
 		return fail(ctx, CFHIP_E_INVALID, "resize filter %d", filter);
 	const size_t texel = src_pixel_type == CFHIP_PIXEL_RGBA8 ? 4 : (src_pixel_type == CFHIP_PIXEL_RGBA32F ? 16 : 8);
 	if (src_pitch_bytes < (size_t)src_width*texel)
@@ -1247,7 +1258,7 @@ int cfhip_generate_mips3d_device(cfhip_ctx* ctx, const void* src, int src_pixel_
 		return fail(ctx, CFHIP_E_INVALID, "3-D mip generation: pixel type %d", src_pixel_type);
 	if (color_space != CFHIP_COLOR_LINEAR && color_space != CFHIP_COLOR_SRGB)
 		return fail(ctx, CFHIP_E_INVALID, "3-D mip generation: colour space %d", color_space);
-	if (filter < CFHIP_FILTER_BOX || filter > CFHIP_FILTER_BSPLINE)
+	if (!filter_valid(filter))
 		return fail(ctx, CFHIP_E_INVALID, "resize filter %d", filter);
 	// maxMipmapLevels for a 3-D texture: floor(log2(max(w, h, d))) + 1
 	uint32_t max_levels = 1, big = width > height ? width : height;
@@ -1298,7 +1309,7 @@ int cfhip_generate_mips3d_device(cfhip_ctx* ctx, const void* src, int src_pixel_
 			}
 		}
 		HIP_TRY(ctx, cfhip_launch_mip_depth(ctx->d_mip3d, pd, w*h, dst_levels[k - 1], d,
-			filter == CFHIP_FILTER_BOX ? 1 : 0, srgb, stream));
+			(filter & 0xFF) == CFHIP_FILTER_BOX ? 1 : 0, srgb, stream));
 		prev = static_cast<const uint8_t*>(dst_levels[k - 1]);
 		prev_type = CFHIP_PIXEL_RGBA32F;
 		prev_pitch = (size_t)w*16u;

@@ -1,9 +1,12 @@
 // mipgen.hip -- mip-level resize on the GPU: one thread per output
-// texel, double arithmetic, float storage -- the arithmetic of the reference's in-tree
-// Image::resize fallback (lib/src/Image.cpp:1393-1505) with its linear-space wrapper (:1337-1346)
-// and Color.h's sRGBToLinear / linearToSRGB (:224-242).  Twin of oracle/mipgen.c; the only
-// difference a GPU can show is the last bit of pow() (ocml vs libm), i.e. <= 1 float ulp after
-// the float store, which tests/test_gpu_mipgen.py bounds.
+// texel, double arithmetic, float storage.  Image::resize (lib/src/Image.cpp:1324-1511) hands all
+// five filters to FreeImage_Rescale in a stock build (:1348-1380): cfhip_mip_pass_kernel is the
+// restated two-pass weights-table resampler (box, tent and the three cubics);
+// cfhip_mip_resize_kernel is the in-tree fallback of Box / Linear (:1393-1505, taken when
+// FreeImage_Rescale fails; CFHIP_FILTER_FALLBACK) and the 1:1 copy.  Linear-space wrapper
+// (:1337-1346) with Color.h's sRGBToLinear / linearToSRGB (:224-242).  Twin of oracle/mipgen.c;
+// the only difference a GPU can show is the last bit of pow() (ocml vs libm), i.e. <= 1 float ulp
+// after the float store, which tests/test_gpu_mipgen.py bounds.
 //
 // HBM-bound by construction (16 B written per texel, 4 x 4..16 B read), the opposite corner
 // of the roofline from the encoders; it exists so that a mip chain can be produced next to
@@ -138,10 +141,16 @@ cfhip_mip_resize_kernel(const uint8_t* __restrict__ src, size_t pitch, uint32_t 
 	dst[(size_t)y*dw + x] = o;
 }
 
-// ---- Cubic / CatmullRom / BSpline: FreeImage_Rescale's algorithm (absent third-party code,
-// restated from its published source -- parity unpinned; oracle/mipgen.c: fi_filter / fi_pass)
+// ---- FreeImage_Rescale's algorithm (absent third-party code, restated from its published
+// source -- parity unpinned; oracle/mipgen.c: fi_filter / fi_width / fi_pass)
 __device__ __forceinline__ double fi_filter(int filter, double v)
 {
+	if (filter == 0)      // FILTER_BOX: width 0.5, boundary included
+		return fabs(v) <= 0.5 ? 1.0 : 0.0;
+	if (filter == 1) {    // FILTER_BILINEAR: the tent of width 1
+		v = fabs(v);
+		return v < 1.0 ? 1.0 - v : 0.0;
+	}
 	if (filter == 3) {
 		if (v < -2.0) return 0.0;
 		if (v < -1.0) return 0.5*(4.0 + v*(8.0 + v*(5.0 + v)));
@@ -185,9 +194,10 @@ cfhip_mip_pass_kernel(const uint8_t* __restrict__ src, size_t pitch, uint32_t sr
 		return;
 	const uint32_t dst_n = ALONG_X ? dst_w : dst_h, u = ALONG_X ? x : y;
 	const double scale = (double)dst_n/(double)src_n;
-	double width = 2.0, fscale = 1.0;
+	const double fwidth = filter == 0 ? 0.5 : (filter == 1 ? 1.0 : 2.0);     // CGenericFilter::GetWidth
+	double width = fwidth, fscale = 1.0;
 	if (scale < 1.0) {
-		width = 2.0/scale;
+		width = fwidth/scale;
 		fscale = scale;
 	}
 	const double center = (double)u/scale + 0.5/scale;
@@ -288,7 +298,7 @@ cfhip_mip_depth_kernel(const float4* __restrict__ prev, uint32_t n_prev, uint32_
 
 } // namespace
 
-// one separable pass (filters 2..4): src (any pixel type, `pitch`) -> dst (RGBA32F, dst_w x dst_h)
+// one separable pass (filters 0..4): src (any pixel type, `pitch`) -> dst (RGBA32F, dst_w x dst_h)
 extern "C" hipError_t cfhip_launch_mip_pass(const void* src, int src_pixel_type, size_t pitch,
 	uint32_t src_n, void* dst, uint32_t dst_w, uint32_t dst_h, int along_x, int filter, int to_linear,
 	int to_srgb, hipStream_t stream)

@@ -462,7 +462,13 @@ class Texture:
         """the next level of a 3-D texture from the slices of one level: every slice resized in
         x, y, then generateMips3d along the depth (Texture.cpp:1384-1400, :103-227)"""
         import torch
-        vol = np.ascontiguousarray(np.stack([np.asarray(s) for s in slices]))
+        arrs = [np.asarray(s) for s in slices]
+        if len({a.dtype for a in arrs}) > 1:
+            # slices of mixed storage: every image becomes RGBAF first, as Image::convert does
+            # (uint8 through v/255.0, Image.cpp:293-296) -- np.stack alone would promote 0..255
+            arrs = [(a.astype(np.float64)/255.0).astype(np.float32) if a.dtype == np.uint8 else a.astype(np.float32)
+                    for a in arrs]
+        vol = np.ascontiguousarray(np.stack(arrs))
         src = torch.from_numpy(vol).to("cuda:%d" % self._device_id)
         d0, h0, w0 = vol.shape[:3]
         w, h, d = max(1, w0 >> 1), max(1, h0 >> 1), max(1, d0 >> 1)

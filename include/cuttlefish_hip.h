@@ -227,11 +227,13 @@ int cfhip_encode_device(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n_
  * max(1, h >> k), filter) (lib/src/Image.cpp:1324-1511), resized in LINEAR space -- an sRGB
  * image is converted with sRGBToLinear, resized and converted back with linearToSRGB
  * (Image.cpp:1337-1346, Color.h:224-242; alpha is not converted) -- on RGBAF images whose
- * float storage rounds every intermediate.  Filters: Box and Linear run the reference's in-tree
- * fallback arithmetic (Image.cpp:1393-1447, :1448-1505).  Cubic, CatmullRom (the reference's
- * default) and BSpline are FreeImage_Rescale in the reference (Image.cpp:1348-1380), a
- * third-party library that is absent: they run a restatement of FreeImage's published
- * two-pass weights-table resampler -- same results class, parity unpinned.
+ * float storage rounds every intermediate.  Filters: in a stock build Image::resize hands all
+ * five to FreeImage_Rescale (Image.cpp:1348-1380: Box -> FILTER_BOX, Linear -> FILTER_BILINEAR,
+ * Cubic -> FILTER_BICUBIC, CatmullRom -- the reference's default -- and BSpline), a third-party
+ * library that is absent: they run a restatement of FreeImage's published two-pass weights-table
+ * resampler -- same results class, parity unpinned.  Box / Linear | CFHIP_FILTER_FALLBACK select
+ * the arithmetic Image::resize runs itself when FreeImage_Rescale returns no image
+ * (Image.cpp:1393-1447, :1448-1505), which IS in the reference tree.
  *   src / src_pixel_type / src_pitch_bytes : level 0 on the device (RGBA8 is read as v/255.0,
  *                                            RGBA16F / RGBA32F as stored)
  *   dst_levels[k-1], k = 1..levels-1       : device buffers that receive level k as tightly
@@ -242,7 +244,8 @@ enum cfhip_resize_filter {     /* Image::ResizeFilter (Image.h), same values */
 	CFHIP_FILTER_LINEAR = 1,
 	CFHIP_FILTER_CUBIC = 2,
 	CFHIP_FILTER_CATMULL_ROM = 3,
-	CFHIP_FILTER_BSPLINE = 4
+	CFHIP_FILTER_BSPLINE = 4,
+	CFHIP_FILTER_FALLBACK = 0x100  /* flag, Box / Linear only: the in-tree loops instead of FreeImage's */
 };
 int cfhip_generate_mips_device(cfhip_ctx* ctx, const void* src, int src_pixel_type,
 	uint32_t width, uint32_t height, size_t src_pitch_bytes, int color_space, int filter,

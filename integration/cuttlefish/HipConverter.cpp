@@ -130,6 +130,10 @@ bool HipConverter::supports(Texture::Format format, Texture::Type type)
 	// resident (mip chains generated on the GPU) through cfhip_encode_device.
 	if (format < Texture::Format::BC1_RGB)
 		return false;
+	// the gate Texture::convert applies (Texture.cpp:1539), compile-time codec switches included:
+	// the backend never widens what this build of Cuttlefish accepts
+	if (!Texture::isFormatValid(format, type))
+		return false;
 	int blockW, blockH, blockBytes;
 	return cfhip_query(static_cast<int>(format), static_cast<int>(type), &blockW, &blockH,
 		&blockBytes) == CFHIP_OK;
@@ -229,6 +233,12 @@ void HipConverter::process(unsigned int, unsigned int, ThreadData*)
 				cpu->process(x, y, threadData.get());
 		}
 		data() = std::move(cpu->data());
+	}
+	else
+	{
+		// neither the backend nor a CPU converter produced anything: an EMPTY payload is how the
+		// patched Converter::convert learns of it and returns false (process has no error channel)
+		data().clear();
 	}
 }
 

@@ -75,8 +75,11 @@ int cfo_decode_bc6h_image(const void* blocks, int type, uint32_t width, uint32_t
 	uint16_t* rgb_out);
 uint16_t cfo_float_to_half(float f);
 
-/* mip-level resize of RGBAF images (mipgen.c): Image::resize's in-tree Box (0) / Linear (1)
- * fallback in linear space, with the sRGB round trip of Image.cpp:1337-1346 */
+/* mip-level resize of RGBAF images (mipgen.c): Image::resize in linear space with the sRGB round
+ * trip of Image.cpp:1337-1346.  filter = Image::ResizeFilter 0..4, all five through the restated
+ * FreeImage_Rescale algorithm (what a stock build runs, Image.cpp:1348-1380);
+ * Box / Linear | CFO_FILTER_FALLBACK = the in-tree loops of Image.cpp:1393-1505 instead */
+#define CFO_FILTER_FALLBACK 0x100
 double cfo_srgb_to_linear(double c);
 double cfo_linear_to_srgb(double c);
 int cfo_resize_rgbaf(const float* src, unsigned sw, unsigned sh, float* dst, unsigned dw,

@@ -12,8 +12,10 @@
  * Pinning: the two colour-space functions are checked bit for bit against the reference's own
  * Color.h compiled into oracle/_ref (tests/test_oracle_mipgen.py); the resize loops cannot be
  * compiled (Image.cpp needs FreeImage, absent) and are restated line by line.  The reference
- * reaches these loops only when FreeImage_Rescale fails.  Cubic / CatmullRom (default) / BSpline
- * exist only inside FreeImage (absent): their restatement further down is "PARITY UNPINNED".
+ * reaches these loops only when FreeImage_Rescale fails (filter | CFO_FILTER_FALLBACK selects
+ * them here).  In a stock build ALL FIVE filters go through FreeImage_Rescale
+ * (Image.cpp:1348-1380: Box -> FILTER_BOX, Linear -> FILTER_BILINEAR, ...), which exists only
+ * inside FreeImage (absent): its restatement further down is "PARITY UNPINNED".
  *
  * All images are RGBAF: float storage, double arithmetic, every stored value rounded to float
  * (setPixelNoGrayscaleImpl's static_cast<float>).
@@ -106,8 +108,8 @@ static void resize_linear_space(const float* src, unsigned sw, unsigned sh, floa
 	}
 }
 
-/* ---- Cubic / CatmullRom / BSpline: the FreeImage_Rescale path -------------------------------
- * Image::resize hands these filters to FreeImage_Rescale (Image.cpp:1348-1380); FreeImage is a
+/* ---- the FreeImage_Rescale path: all five filters of a stock build -----------------------------
+ * Image::resize hands every filter to FreeImage_Rescale (Image.cpp:1348-1380); FreeImage is a
  * third-party library that is ABSENT from /root/reference (3.18.0 is what Cuttlefish's build
  * looks for; version unpinned by the tree) -- "PARITY UNPINNED" for this part.  What follows
  * restates FreeImage's published resampling algorithm (Source/FreeImageToolkit/Resize.cpp,
@@ -118,11 +120,17 @@ static void resize_linear_space(const float* src, unsigned sw, unsigned sh, floa
  *     weights normalised to sum 1
  * applied in two passes (horizontal first when dst_w*src_h <= dst_h*src_w) with a float
  * intermediate image, double accumulation, no clamping for float pixels.  The in-tree fallback
- * above (Image.cpp:1393-1505) is visibly modelled on the same table arithmetic.  Filter kernels
- * (all of support W = 2): Catmull-Rom, Mitchell-Netravali B = C = 1/3 ("bicubic"), cubic
- * B-spline. */
+ * above (Image.cpp:1393-1505) is visibly modelled on the same table arithmetic.  Filter kernels:
+ * box (W = 0.5), tent (W = 1), and of support W = 2 Catmull-Rom, Mitchell-Netravali B = C = 1/3
+ * ("bicubic") and the cubic B-spline. */
 static double fi_filter(int filter, double v)
 {
+	if (filter == 0)     /* FILTER_BOX (CBoxFilter, width 0.5): 1 inside, boundary included */
+		return fabs(v) <= 0.5 ? 1.0 : 0.0;
+	if (filter == 1) {   /* FILTER_BILINEAR (CBilinearFilter, width 1): the tent */
+		v = fabs(v);
+		return v < 1.0 ? 1.0 - v : 0.0;
+	}
 	if (filter == 3) {   /* FILTER_CATMULLROM */
 		if (v < -2.0) return 0.0;
 		if (v < -1.0) return 0.5*(4.0 + v*(8.0 + v*(5.0 + v)));
@@ -148,14 +156,20 @@ static double fi_filter(int filter, double v)
 	return 0.0;
 }
 
+/* CGenericFilter::GetWidth of the five filter classes */
+static double fi_width(int filter)
+{
+	return filter == 0 ? 0.5 : (filter == 1 ? 1.0 : 2.0);
+}
+
 /* one pass along x (stride_px = 1) or y (stride_px = row length), `lines` independent lines */
 static void fi_pass(const float* src, unsigned src_n, unsigned src_line_stride, unsigned src_px_stride,
 	float* dst, unsigned dst_n, unsigned dst_line_stride, unsigned dst_px_stride, unsigned lines, int filter)
 {
 	const double scale = (double)dst_n/(double)src_n;
-	double width = 2.0, fscale = 1.0;
+	double width = fi_width(filter), fscale = 1.0;
 	if (scale < 1.0) {
-		width = 2.0/scale;
+		width = fi_width(filter)/scale;
 		fscale = scale;
 	}
 	const double offset = 0.5/scale;
@@ -210,20 +224,23 @@ static int resize_freeimage(const float* src, unsigned sw, unsigned sh, float* d
 static int resize_any(const float* src, unsigned sw, unsigned sh, float* dst, unsigned dw, unsigned dh,
 	int filter)
 {
-	if (filter <= 1) {
-		resize_linear_space(src, sw, sh, dst, dw, dh, filter);
+	if (filter & CFO_FILTER_FALLBACK) {
+		/* what Image::resize computes itself when FreeImage_Rescale returns no image */
+		resize_linear_space(src, sw, sh, dst, dw, dh, filter & 0xFF);
 		return 0;
 	}
 	return resize_freeimage(src, sw, sh, dst, dw, dh, filter);
 }
 
 /* Image::resize for an RGBAF image in `color_space` (0 linear, 1 sRGB); filter = ResizeFilter
- * (0 Box, 1 Linear: in-tree fallback arithmetic; 2 Cubic, 3 CatmullRom, 4 BSpline: FreeImage's
- * algorithm restated, parity unpinned).  Returns 0 or a negative error. */
+ * (0 Box, 1 Linear, 2 Cubic, 3 CatmullRom, 4 BSpline: FreeImage_Rescale's algorithm restated,
+ * parity unpinned), optionally | CFO_FILTER_FALLBACK for Box / Linear: the in-tree loops the
+ * reference runs when FreeImage_Rescale fails (Image.cpp:1393-1505).  Returns 0 or a negative error. */
 int cfo_resize_rgbaf(const float* src, unsigned sw, unsigned sh, float* dst, unsigned dw, unsigned dh,
 	int filter, int color_space)
 {
-	if (filter < 0 || filter > 4)
+	if ((filter & ~CFO_FILTER_FALLBACK) < 0 || (filter & ~CFO_FILTER_FALLBACK) > 4 ||
+		((filter & CFO_FILTER_FALLBACK) && (filter & 0xFF) > 1))
 		return -2;
 	if (!sw || !sh || !dw || !dh)
 		return -1;
@@ -267,6 +284,7 @@ int cfo_mip_depth_pass(const float* prev, unsigned n_prev, unsigned w, unsigned 
 {
 	if (!prev || !out || !n_prev || !w || !h || !depth)
 		return -1;
+	filter &= 0xFF;      /* the depth pass is in-tree code whichever way Image::resize went */
 	const size_t slice = (size_t)w*h*4;
 	double invScale = (double)n_prev/(double)depth;
 	double offset = invScale > 1.0 ? invScale : 1.0;

@@ -173,6 +173,9 @@ def decode(blocks: np.ndarray, fmt, width: int, height: int, typ=0) -> np.ndarra
 
 # ---- mip-level resize (oracle/mipgen.c) --------------------------------------------------
 
+FILTER_FALLBACK = 0x100      # CFO_FILTER_FALLBACK: Box / Linear through the in-tree loops of Image.cpp:1393-1505
+
+
 def resize_rgbaf(img: np.ndarray, width: int, height: int, filter=0, color_space=0) -> np.ndarray:
     """Image::resize of an RGBAF image (h, w, 4) float32 -> (height, width, 4) float32."""
     img = np.ascontiguousarray(img, np.float32)

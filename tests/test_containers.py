@@ -39,7 +39,8 @@ def test_dds_opens_in_pillow_and_matches_oracle_decode(fmt, typ):
     data = buf.getvalue()
     assert n == len(data) == 148 + sum(l.nbytes for l in levels)
     info = C.read_dds(data)
-    assert (info["width"], info["height"], info["levels"], info["elements"]) == (64, 64, 5, 1)
+    # arraySize = Texture::depth() = 0 for a texture that is not an array (SaveDds.cpp:637); Pillow still opens it
+    assert (info["width"], info["height"], info["levels"], info["elements"]) == (64, 64, 5, 0)
     assert data[info["offset"]:info["offset"] + levels[0].nbytes] == levels[0].tobytes()
     im = PIL.open(io.BytesIO(data))
     im.load()
@@ -70,7 +71,7 @@ def test_dds_header_fields_follow_savedds():
     assert (pf_size, pf_flags, d[4 + 80:4 + 84]) == (32, 0x4, b"DX10")
     assert struct.unpack_from("<I", d, 4 + 104)[0] == 0x1000      # caps: texture only
     dxgi, dim, misc, array, misc2 = struct.unpack_from("<5I", d, 128)
-    assert (dxgi, dim, misc, array, misc2) == (99, 3, 0, 1, 1)    # BC7_UNORM_SRGB, 2-D, straight alpha
+    assert (dxgi, dim, misc, array, misc2) == (99, 3, 0, 0, 1)    # BC7_UNORM_SRGB, 2-D, arraySize = depth() = 0, straight alpha
     assert len(d) == 148 + 256
 
 
@@ -289,7 +290,7 @@ def test_cube_map_orders_follow_the_three_writers():
     hdr = C.read_dds(data)
     caps, caps2 = struct.unpack_from("<2I", data, 4 + 104)
     dxgi, dim, misc, array, _ = struct.unpack_from("<5I", data, 4 + 124)
-    assert caps2 == 0xFE00 and misc == 0x4 and dim == 3 and array == 1        # SaveDds.cpp:600-604, :624-627, :637
+    assert caps2 == 0xFE00 and misc == 0x4 and dim == 3 and array == 0        # SaveDds.cpp:600-604, :624-627, :637
     assert caps & 0x8                                                         # mip levels -> complex
     # DDS: face -> level (SaveDds.cpp:657-680)
     assert _runs(data[hdr["offset"]:]) == [tag(l, 0, f) for f in range(6) for l in range(2)]

@@ -39,8 +39,10 @@ def _ulps(a, b):
     return np.abs(ai - bi)
 
 
-@pytest.mark.parametrize("filt", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("filt", [0, 1, 2, 3, 4, 0 | O.FILTER_FALLBACK, 1 | O.FILTER_FALLBACK])
 def test_linear_space_chain_is_bit_exact(filt):
+    """All five filters through the FreeImage_Rescale passes (what a stock build computes,
+    Image.cpp:1348-1380) and Box / Linear through the in-tree fallback loops (:1393-1505)."""
     rng = np.random.default_rng(1)
     base = rng.random((192, 256, 4)).astype(np.float32)
     with Context(0) as ctx:
@@ -62,7 +64,7 @@ def test_base_level_pixel_types(dtype):
         assert np.array_equal(g, r)
 
 
-@pytest.mark.parametrize("filt", [0, 3])
+@pytest.mark.parametrize("filt", [0, 3, 0 | O.FILTER_FALLBACK])
 def test_srgb_chain_within_pow_rounding(filt):
     img = synth.photo(256, 256, seed=4)
     with Context(0) as ctx:
@@ -90,6 +92,10 @@ def test_unsupported_filter_and_bad_arguments():
         with pytest.raises(CfhipError) as e:
             ctx.generate_mips_device(x.data_ptr(), PixelType.RGBA32F, 8, 8, 128, [d.data_ptr()], filter=9)
         assert e.value.code == -1                                # not a ResizeFilter
+        with pytest.raises(CfhipError) as e:
+            ctx.generate_mips_device(x.data_ptr(), PixelType.RGBA32F, 8, 8, 128, [d.data_ptr()],
+                                     filter=3 | O.FILTER_FALLBACK)
+        assert e.value.code == -1                                # the fallback knows Box and Linear only
         with pytest.raises(CfhipError) as e:
             ctx.generate_mips_device(x.data_ptr(), PixelType.RGBA32F, 8, 8, 64, [d.data_ptr()])
         assert e.value.code == -1                                # pitch smaller than a row

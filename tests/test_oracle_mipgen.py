@@ -70,34 +70,41 @@ def _box_py(src, dw, dh):
 def test_box_resize_matches_the_transcribed_loops(sw, sh, dw, dh):
     rng = np.random.default_rng(sw*100 + sh)
     src = rng.random((sh, sw, 4)).astype(np.float32)
-    got = O.resize_rgbaf(src, dw, dh, filter=0, color_space=0)
+    got = O.resize_rgbaf(src, dw, dh, filter=0 | O.FILTER_FALLBACK, color_space=0)
     assert np.array_equal(got, _box_py(src, dw, dh))
 
 
 def test_box_halving_is_the_2x2_mean_in_double():
     rng = np.random.default_rng(9)
     src = rng.random((32, 48, 4)).astype(np.float32)
-    got = O.resize_rgbaf(src, 24, 16)
+    got = O.resize_rgbaf(src, 24, 16, filter=0 | O.FILTER_FALLBACK)
     s = src.astype(np.float64)
     ref = ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2])/4.0).astype(np.float32)
     assert np.array_equal(got, ref)
+    # the stock path (FreeImage FILTER_BOX): two passes of pair means with a FLOAT image between them
+    got = O.resize_rgbaf(src, 24, 16, filter=0)
+    hor = (0.5*s[:, 0::2] + 0.5*s[:, 1::2]).astype(np.float32).astype(np.float64)
+    ref2 = (0.5*hor[0::2] + 0.5*hor[1::2]).astype(np.float32)
+    assert np.array_equal(got, ref2)
+    assert np.abs(ref2.astype(np.float64) - ref).max() < 1e-7 and not np.array_equal(ref, ref2)
 
 
 def test_linear_filter_properties():
     const = np.full((12, 20, 4), 0.375, np.float32)
-    assert np.array_equal(O.resize_rgbaf(const, 10, 6, filter=1), np.full((6, 10, 4), 0.375, np.float32))
-    # horizontal ramp stays a ramp under the triangle filter (interior texels)
-    ramp = np.tile(np.linspace(0, 1, 32, dtype=np.float32)[None, :, None], (8, 1, 4))
-    out = O.resize_rgbaf(ramp, 16, 4, filter=1)
-    d = np.diff(out[0, 2:-2, 0].astype(np.float64))
-    assert np.allclose(d, d[0], rtol=0, atol=1e-6)
+    for filt in (1, 1 | O.FILTER_FALLBACK):
+        assert np.array_equal(O.resize_rgbaf(const, 10, 6, filter=filt), np.full((6, 10, 4), 0.375, np.float32))
+        # horizontal ramp stays a ramp under the triangle filter (interior texels)
+        ramp = np.tile(np.linspace(0, 1, 32, dtype=np.float32)[None, :, None], (8, 1, 4))
+        out = O.resize_rgbaf(ramp, 16, 4, filter=filt)
+        d = np.diff(out[0, 2:-2, 0].astype(np.float64))
+        assert np.allclose(d, d[0], rtol=0, atol=1e-6)
 
 
 def test_srgb_round_trip_and_alpha_untouched():
     rng = np.random.default_rng(3)
     src = rng.random((16, 16, 4)).astype(np.float32)
-    lin = O.resize_rgbaf(src, 8, 8, color_space=0)
-    srgb = O.resize_rgbaf(src, 8, 8, color_space=1)
+    lin = O.resize_rgbaf(src, 8, 8, filter=O.FILTER_FALLBACK, color_space=0)
+    srgb = O.resize_rgbaf(src, 8, 8, filter=O.FILTER_FALLBACK, color_space=1)
     assert np.array_equal(lin[..., 3], srgb[..., 3])           # alpha is averaged as stored
     assert np.all(srgb[..., :3] >= lin[..., :3] - 1e-6)        # mean in linear light is brighter (convexity)
     # explicit model of Image.cpp:1337-1346 on one texel
@@ -115,11 +122,65 @@ def test_chain_and_errors():
     assert chain[0].dtype == np.float32 and chain[0][0, 0, 1] == np.float32(1/255.0)
     with pytest.raises(RuntimeError):
         O.resize_rgbaf(chain[0], 8, 8, filter=7)               # not a ResizeFilter
+    with pytest.raises(RuntimeError):
+        O.resize_rgbaf(chain[0], 8, 8, filter=3 | O.FILTER_FALLBACK)   # the fallback has Box and Linear only
 
 
-@pytest.mark.parametrize("filt", [2, 3, 4])
+def _fi_py(src, dw, dh, filt):
+    """FreeImage's CWeightsTable + horizontal / vertical filter passes for float images, written
+    independently of oracle/mipgen.c with Python floats (= C doubles); box and tent kernels."""
+    W = {0: 0.5, 1: 1.0}[filt]
+    F = {0: (lambda v: 1.0 if abs(v) <= 0.5 else 0.0), 1: (lambda v: 1.0 - abs(v) if abs(v) < 1.0 else 0.0)}[filt]
+
+    def table(dst_n, src_n):
+        scale = dst_n/src_n
+        width, fscale = (W/scale, scale) if scale < 1.0 else (W, 1.0)
+        rows = []
+        for u in range(dst_n):
+            center = u/scale + 0.5/scale
+            left, right = max(0, int(center - width + 0.5)), min(int(center + width + 0.5), src_n)
+            w = [fscale*F(fscale*(i + 0.5 - center)) for i in range(left, right)]
+            tot = sum(w)
+            if tot > 0 and tot != 1:
+                w = [x/tot for x in w]
+            rows.append((left, w))
+        return rows
+
+    def along_x(img, dst_n):
+        h, n = img.shape[:2]
+        if dst_n == n:
+            return img
+        out = np.zeros((h, dst_n, 4), np.float32)
+        for u, (left, w) in enumerate(table(dst_n, n)):
+            for y in range(h):
+                acc = [0.0]*4
+                for k, wk in enumerate(w):
+                    for c in range(4):
+                        acc[c] += wk*float(img[y, left + k, c])
+                out[y, u] = [np.float32(a) for a in acc]
+        return out
+    sh, sw = src.shape[:2]
+    if dw*sh <= dh*sw:
+        tmp = along_x(src, dw)
+        return along_x(tmp.transpose(1, 0, 2), dh).transpose(1, 0, 2)
+    tmp = along_x(src.transpose(1, 0, 2), dh).transpose(1, 0, 2)
+    return along_x(tmp, dw)
+
+
+@pytest.mark.parametrize("filt", [0, 1])
+@pytest.mark.parametrize("sw,sh,dw,dh", [(16, 16, 8, 8), (10, 6, 5, 3), (7, 5, 3, 2), (9, 1, 4, 1), (1, 8, 1, 4),
+                                         (5, 5, 2, 2), (3, 3, 1, 1), (8, 8, 3, 5), (4, 4, 9, 7), (6, 3, 6, 1)])
+def test_stock_box_and_linear_follow_the_freeimage_weights_table(filt, sw, sh, dw, dh):
+    """Image.cpp:1348-1380: Box -> FILTER_BOX, Linear -> FILTER_BILINEAR of FreeImage_Rescale."""
+    rng = np.random.default_rng(sw*100 + sh + filt)
+    src = rng.random((sh, sw, 4)).astype(np.float32)
+    got = O.resize_rgbaf(src, dw, dh, filter=filt, color_space=0)
+    assert np.array_equal(got, _fi_py(src, dw, dh, filt))
+
+
+@pytest.mark.parametrize("filt", [0, 1, 2, 3, 4])
 def test_freeimage_style_filters_properties(filt):
-    """Cubic / CatmullRom / BSpline (FreeImage_Rescale's algorithm restated, parity unpinned):
+    """All five filters through FreeImage_Rescale's algorithm (restated, parity unpinned):
     normalised weights keep constants, the interior of a ramp stays a ramp, the kernel is
     symmetric (mirrored input -> mirrored output), and the separable passes commute with a
     transpose."""
