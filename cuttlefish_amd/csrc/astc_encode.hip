@@ -145,15 +145,76 @@ __device__ __forceinline__ float quad_est(float fA, float fB, float fC, float d0
 
 // the workgroup's shared tables in LDS
 struct Shared {
-	const uint32_t* infill;   // [grid][n]
-	const uint16_t* den;      // [grid][64]
-	const uint8_t* grid;      // [grid][4]: N, M, ng
+	const uint2* infill;      // [grid][n]: x = the four factors as bytes, y = slot offsets of rows r0 | r1 << 16
+	const uint16_t* den;      // [grid][ASTC_DEN_STRIDE]: factor sums in the padded row order
+	const uint8_t* grid;      // [grid][4]: N, M, ng, Np (even row pitch)
 	const uint8_t* cunq;      // [17][256]
 	const uint8_t* cnear;     // [17][256]
 	const uint8_t* cnear_hi;  // [17][256] HDR launches only: nearest index among values with bit 7 set
 	const uint8_t* wunq;      // [12][32]
 	const uint8_t* wnear;     // [12][68]
+	const uint8_t* wnu;       // [12][68] nearest unquantised weight of an average 0..64
 };
+
+// ---- a lane's weight column ----------------------------------------------------------------
+// Row r of a grid plane (r = gy*Np + gx, Np even) is the (r & 1) half of 32-bit word [r >> 1][lane]:
+// a wave-level access touches 32 consecutive banks per half-wave whatever rows the lanes address.
+// `base` = the byte address of the plane's word 0 for this lane; words are 256 bytes apart.
+//
+// Decimation: texel t adds f*T[t] to the accumulators of its four grid points.  The two points of a
+// row pair are neighbouring rows, i.e. the two halves of one word (even r0) or the high half of a
+// word and the low half of the next (odd r0): TWO no-return LDS atomics per row pair, the second
+// one adding 0 in the even case -- no load, no store, nothing for the next texel to wait on (the
+// read-modify-write form made every texel wait for the previous one's stores).  Sums stay below
+// 2^16 (<= 64 * factor sum), so the halves never carry into each other.
+__device__ __forceinline__ void decim_add(uint8_t* base, uint32_t F, uint32_t offs, uint32_t T)
+{
+	const uint32_t o0 = offs & 0xFFFFu, o1 = offs >> 16;
+	const bool odd = (o0 & 2u) != 0u;          // r0 and r1 have the same parity (even row pitch)
+	const uint32_t ta = T*(F & 255u), tb = T*((F >> 8) & 255u), tc = T*((F >> 16) & 255u), td = T*(F >> 24);
+	const uint32_t A0 = odd ? ta << 16 : (ta | (tb << 16)), B0 = odd ? tb : 0u;
+	const uint32_t A1 = odd ? tc << 16 : (tc | (td << 16)), B1 = odd ? td : 0u;
+	uint32_t* w0 = reinterpret_cast<uint32_t*>(base + (o0 & ~3u));
+	uint32_t* w1 = reinterpret_cast<uint32_t*>(base + (o1 & ~3u));
+	(void)__hip_atomic_fetch_add(w0, A0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+	(void)__hip_atomic_fetch_add(w0 + 64, B0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+	(void)__hip_atomic_fetch_add(w1, A1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+	(void)__hip_atomic_fetch_add(w1 + 64, B1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+// Accumulators -> weights, in place: word k holds the sums of rows 2k | 2k+1; each becomes the
+// rounded average (sum + den/2)/den and (QUANT) the nearest unquantised weight of the lane's range.
+// What is stored is the PAIR form the infill reads: slot r = w[r] | w[r+1] << 8, so that the two
+// horizontally adjacent weights of a texel are one 16-bit load and the four of them one dword.
+template <bool QUANT>
+__device__ __forceinline__ void normalise_rows(uint8_t* base, const uint16_t* den, uint32_t PW, const uint8_t* wnu)
+{
+	uint32_t prev = 0;        // w[2k-2] | w[2k-1] << 8
+#pragma unroll 1
+	for (uint32_t k = 0; k < PW; ++k) {
+		uint32_t* wp = reinterpret_cast<uint32_t*>(base + k*256u);
+		const uint32_t acc = *wp, dd = *reinterpret_cast<const uint32_t*>(den + 2u*k);
+		const uint32_t d0 = dd & 0xFFFFu, d1 = dd >> 16;
+		uint32_t g0 = d0 ? div_small((acc & 0xFFFFu) + d0/2u, d0, 1.0f/(float)d0) : 0u;
+		uint32_t g1 = d1 ? div_small((acc >> 16) + d1/2u, d1, 1.0f/(float)d1) : 0u;
+		if (QUANT) {
+			g0 = wnu[g0];
+			g1 = wnu[g1];
+		}
+		if (k)
+			wp[-64] = prev | (((prev >> 8) | (g0 << 8)) << 16);
+		prev = g0 | (g1 << 8);
+	}
+	reinterpret_cast<uint32_t*>(base + (PW - 1u)*256u)[0] = prev | ((prev >> 8) << 16);
+}
+
+// the weight a texel decodes to: (8 + sum of factor x grid weight) >> 4, the ASTC infill
+__device__ __forceinline__ uint32_t infill_w(const uint8_t* base, uint32_t F, uint32_t offs)
+{
+	const uint32_t a = *reinterpret_cast<const uint16_t*>(base + (offs & 0xFFFFu));
+	const uint32_t b = *reinterpret_cast<const uint16_t*>(base + (offs >> 16));
+	return __builtin_amdgcn_udot4(F, a | (b << 16), 8u, false) >> 4;
+}
 
 // per (wave, block slot) scratch in LDS
 struct Slot {
@@ -491,35 +552,31 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	const uint32_t aflags = (kp.flags >> 16) & 3u;
 	// HDR profile (Type::UFloat, AstcConverter.cpp:150-162): bit 0 = HDR colour, bit 1 = HDR alpha too
 	const uint32_t hdrf = (kp.flags >> 19) & 3u;
-	// texel-weight cache rows: a launch-time choice (cfhip_astc_plan) -- on when they fit without
-	// costing a wave of occupancy; the cache never changes a result
-	const bool wcached = (kp.flags >> 18) & 1u;
-	const uint32_t wc_rows = wcached ? 2u*((n + 3u)/4u) : 0u;
 
 	// ---- LDS carve-up (byte offsets, 16-byte aligned sections) ----
 	uint8_t* lds = reinterpret_cast<uint8_t*>(dyn_lds);
 	uint32_t off = 0;
 	uint32_t* tile = reinterpret_cast<uint32_t*>(lds + off); off += nblk*n*4u;
 	off = (off + 15u) & ~15u;
-	uint32_t* sh_infill = reinterpret_cast<uint32_t*>(lds + off); off += ngrids*n*4u; off = (off + 15u) & ~15u;
-	uint16_t* sh_den = reinterpret_cast<uint16_t*>(lds + off); off += ngrids*128u;
+	uint32_t* sh_infill = reinterpret_cast<uint32_t*>(lds + off); off += ngrids*n*8u; off = (off + 15u) & ~15u;
+	uint16_t* sh_den = reinterpret_cast<uint16_t*>(lds + off); off += ngrids*(uint32_t)cfastc::ASTC_DEN_STRIDE*2u;
 	uint8_t* sh_grid = lds + off; off += (ngrids*4u + 15u) & ~15u;
 	uint8_t* sh_ctab = lds + off; off += (hdrf ? 3u : 2u)*17u*256u;
-	uint8_t* sh_wtab = lds + off; off += 1216u;
+	uint8_t* sh_wtab = lds + off; off += 2016u;
 	const uint32_t slot_bytes = ((10u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
-	const uint32_t wave_bytes = ((((col_rows + 1u)/2u)*256u + wc_rows*256u + 15u) & ~15u) + (kp.quality <= 2u ? 2u : 1u)*slot_bytes;
+	const uint32_t wave_bytes = ((((col_rows + 1u)/2u)*256u + 15u) & ~15u) + (kp.quality <= 2u ? 2u : 1u)*slot_bytes;
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	uint8_t* wbase = lds + off + wave*wave_bytes;
 
-	for (uint32_t i = threadIdx.x; i < ngrids*n; i += nthreads)
+	for (uint32_t i = threadIdx.x; i < ngrids*n*2u; i += nthreads)
 		sh_infill[i] = reinterpret_cast<const uint32_t*>(blob + H->off_infill)[i];
-	for (uint32_t i = threadIdx.x; i < ngrids*64u; i += nthreads)
-		sh_den[i] = reinterpret_cast<const uint16_t*>(blob + H->off_den)[i];
+	for (uint32_t i = threadIdx.x; i < ngrids*(uint32_t)cfastc::ASTC_DEN_STRIDE/2u; i += nthreads)
+		reinterpret_cast<uint32_t*>(sh_den)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_den)[i];
 	for (uint32_t i = threadIdx.x; i < ngrids; i += nthreads)
 		reinterpret_cast<uint32_t*>(sh_grid)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_grid)[i];
 	for (uint32_t i = threadIdx.x; i < (hdrf ? 3u : 2u)*17u*64u; i += nthreads)
 		reinterpret_cast<uint32_t*>(sh_ctab)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_ctab)[i];
-	for (uint32_t i = threadIdx.x; i < 304u; i += nthreads)
+	for (uint32_t i = threadIdx.x; i < 504u; i += nthreads)
 		reinterpret_cast<uint32_t*>(sh_wtab)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_wtab)[i];
 
 	uint32_t gx_, gy_;
@@ -558,21 +615,17 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	__syncthreads();
 
 	Shared sh;
-	sh.infill = sh_infill; sh.den = sh_den; sh.grid = sh_grid;
+	sh.infill = reinterpret_cast<const uint2*>(sh_infill); sh.den = sh_den; sh.grid = sh_grid;
 	sh.cunq = sh_ctab; sh.cnear = sh_ctab + 17u*256u; sh.cnear_hi = sh_ctab + 2u*17u*256u;
-	sh.wunq = sh_wtab; sh.wnear = sh_wtab + 12u*32u;
+	sh.wunq = sh_wtab; sh.wnear = sh_wtab + 12u*32u; sh.wnu = sh_wtab + 12u*32u + 12u*68u;
 	const int8_t* clevel = reinterpret_cast<const int8_t*>(blob + H->off_clevel);
 	const uint8_t* ise = blob + H->off_ise;
 	const AstcCfgRec* cfgs = reinterpret_cast<const AstcCfgRec*>(blob + H->off_cfg);
 	const uint8_t* ncfgs = blob + H->off_ncfg;
 
-	// a lane's grid column: row r is the (r & 1) half of 32-bit word [r >> 1][lane] -- a wave-level
-	// access then touches 32 consecutive banks per half-wave whatever rows the lanes address
-	// (with 16-bit elements [row][lane] two lanes share a bank and conflict when their rows differ)
-	uint16_t* colb = reinterpret_cast<uint16_t*>(wbase) + lane*2u;
-#define COLR(r) colb[((r) >> 1)*128u + ((r) & 1u)]
-	uint32_t* wcache = reinterpret_cast<uint32_t*>(wbase + ((col_rows + 1u)/2u)*256u) + lane;   // row r: wcache[r*64]
-	uint8_t* slot0 = wbase + ((((col_rows + 1u)/2u)*256u + wc_rows*256u + 15u) & ~15u);
+	// a lane's weight column (layout: decim_add / normalise_rows / infill_w above)
+	uint8_t* colbase = wbase + lane*4u;
+	uint8_t* slot0 = wbase + ((((col_rows + 1u)/2u)*256u + 15u) & ~15u);
 
 	const uint32_t q = kp.quality > 4u ? 4u : kp.quality;
 #if CF_ASTC_PROF
@@ -1006,32 +1059,22 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			if (pass == 0u) {
 				const uint32_t g = hl;
 				if (!(CF_ASTC_ABLATE & 4) && !solid && g < ngrids) {
-					const uint32_t N = sh.grid[g*4u], ng = sh.grid[g*4u + 2u];
-					const uint32_t* inf = sh.infill + g*n;
+					const uint32_t Rp = (uint32_t)sh.grid[g*4u + 1u]*(uint32_t)sh.grid[g*4u + 3u], PW = (Rp + 1u) >> 1;
+					const uint2* inf = sh.infill + g*n;
 					const uint8_t* Trow = S.T;
-					for (uint32_t r = 0; r < ng + N + 2u; ++r)
-						COLR(r) = 0;
-#pragma unroll 1
+					for (uint32_t k = 0; k <= PW; ++k)
+						*reinterpret_cast<uint32_t*>(colbase + k*256u) = 0u;
+#pragma unroll 2
 					for (uint32_t i = 0; i < n; ++i) {
-						const uint32_t rec = inf[i], T = Trow[i];
-						const uint32_t g0 = rec & 255u, f00 = (rec >> 8) & 31u, f01 = (rec >> 13) & 31u, f10 = (rec >> 18) & 31u, f11 = rec >> 23;
-						const uint32_t v0 = COLR(g0), v1 = COLR(g0 + 1u), v2 = COLR(g0 + N), v3 = COLR(g0 + N + 1u);
-						COLR(g0) = (uint16_t)(v0 + f00*T);
-						COLR(g0 + 1u) = (uint16_t)(v1 + f01*T);
-						COLR(g0 + N) = (uint16_t)(v2 + f10*T);
-						COLR(g0 + N + 1u) = (uint16_t)(v3 + f11*T);
+						const uint2 rec = inf[i];
+						decim_add(colbase, rec.x, rec.y, Trow[i]);
 					}
-					for (uint32_t r = 0; r < ng; ++r) {
-						const uint32_t den = sh.den[g*64u + r];
-						COLR(r) = (uint16_t)(den ? div_small((uint32_t)COLR(r) + den/2u, den, 1.0f/(float)den) : 0u);
-					}
+					normalise_rows<false>(colbase, sh.den + g*(uint32_t)cfastc::ASTC_DEN_STRIDE, PW, nullptr);
 					uint32_t e = 0;
-#pragma unroll 1
+#pragma unroll 2
 					for (uint32_t i = 0; i < n; ++i) {
-						const uint32_t rec = inf[i];
-						const uint32_t g0 = rec & 255u, f00 = (rec >> 8) & 31u, f01 = (rec >> 13) & 31u, f10 = (rec >> 18) & 31u, f11 = rec >> 23;
-						const uint32_t acc = 8u + f00*COLR(g0) + f01*COLR(g0 + 1u) + f10*COLR(g0 + N) + f11*COLR(g0 + N + 1u);
-						const int dgt = (int)(acc >> 4) - (int)Trow[i];
+						const uint2 rec = inf[i];
+						const int dgt = (int)infill_w(colbase, rec.x, rec.y) - (int)Trow[i];
 						e += (uint32_t)(dgt*dgt);
 					}
 					S.edec[g] = e;
@@ -1089,46 +1132,31 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				const bool active = !(CF_ASTC_ABLATE & 1) && !solid && j < cnt && oi != 255u;
 				const AstcCfgRec cfg = cfgs[(cls*2u + alpha_i)*64u + (active ? oi : 0u)];
 				r_cfg = oi;
-				const uint32_t planes = dual ? 2u : 1u, N = cfg.N, ng = cfg.ng, wq = cfg.wq;
-				const uint32_t* inf = sh.infill + (uint32_t)cfg.grid*n;
-				const uint16_t* den = sh.den + (uint32_t)cfg.grid*64u;
+				const uint32_t planes = dual ? 2u : 1u, wq = cfg.wq;
+				const uint2* inf = sh.infill + (uint32_t)cfg.grid*n;
+				const uint16_t* den = sh.den + (uint32_t)cfg.grid*(uint32_t)cfastc::ASTC_DEN_STRIDE;
+				// words per plane of the lane's column (rows at the grid's even pitch); plane 1 follows plane 0
+				const uint32_t PW = ((uint32_t)cfg.M*(uint32_t)sh.grid[(uint32_t)cfg.grid*4u + 3u] + 1u) >> 1;
+				uint8_t* colp1 = colbase + (dual ? PW*256u : 0u);
 				const uint8_t* prow = S.pid + j*npad;
 				const bool byp = P <= 1u;
 				if (active) {
-					// 1. decimate + quantise (slots: unquantised | quantised << 8)
-					for (uint32_t r = 0; r < (ng + N + 2u)*planes; ++r)
-						COLR(r) = 0;
+					// 1. decimate + quantise
+					for (uint32_t k = 0; k <= PW*planes; ++k)
+						*reinterpret_cast<uint32_t*>(colbase + k*256u) = 0u;
 #pragma unroll 1
 					for (uint32_t pl = 0; pl < ((CF_ASTC_ABLATE & 16) ? 0u : planes); ++pl) {
 						const uint8_t* Trow = S.T + (pl ? 8u + ((j - 1u) & 1u) : j)*npad;
-						// the next texel's record and ideal weight are fetched before this texel's stores: the
-						// compiler cannot move LDS loads above LDS stores it cannot disambiguate, and the
-						// read-modify-write chain below is what the wave waits on
-						uint32_t rec = inf[0], T = Trow[0];
-#pragma unroll 1
+						uint8_t* cb = pl ? colp1 : colbase;
+#pragma unroll 2
 						for (uint32_t i = 0; i < n; ++i) {
-							const uint32_t nx = i + 1u < n ? i + 1u : i;
-							const uint32_t nrec = inf[nx], nT = Trow[nx];
-							const uint32_t g0 = rec & 255u, f00 = (rec >> 8) & 31u, f01 = (rec >> 13) & 31u, f10 = (rec >> 18) & 31u, f11 = rec >> 23;
-							const uint32_t i0 = g0*planes + pl, i1 = i0 + planes, i2 = i0 + N*planes, i3 = i2 + planes;
-							const uint32_t v0 = COLR(i0), v1 = COLR(i1), v2 = COLR(i2), v3 = COLR(i3);
-							COLR(i0) = (uint16_t)(v0 + f00*T);
-							COLR(i1) = (uint16_t)(v1 + f01*T);
-							COLR(i2) = (uint16_t)(v2 + f10*T);
-							COLR(i3) = (uint16_t)(v3 + f11*T);
-							rec = nrec; T = nT;
+							const uint2 rec = inf[i];
+							decim_add(cb, rec.x, rec.y, Trow[i]);
 						}
 					}
-					for (uint32_t g = 0; g < ng; ++g) {
-						const uint32_t dn = den[g];
-						const float rd = 1.0f/(float)dn;
 #pragma unroll 1
-						for (uint32_t pl = 0; pl < planes; ++pl) {
-							const uint32_t gi = dn ? div_small((uint32_t)COLR(g*planes + pl) + dn/2u, dn, rd) : 0u;
-							const uint32_t qv = sh.wnear[wq*68u + gi];
-							COLR(g*planes + pl) = (uint16_t)((uint32_t)sh.wunq[wq*32u + qv] | (qv << 8));
-						}
-					}
+					for (uint32_t pl = 0; pl < planes; ++pl)
+						normalise_rows<true>(pl ? colp1 : colbase, den, PW, sh.wnu + wq*68u);
 					PROF_MARK(6)   // B: decimate + quantise
 					// 2. + 3. texel weights and the least-squares sums per set (subset, or plane)
 					const uint32_t nset = dual ? 2u : P;
@@ -1139,30 +1167,12 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					// index makes the compiler keep the arrays in scratch)
 					struct SetAcc { uint32_t S, C, V0, V1, V2, V3, cn, p01, p23; };
 					SetAcc q0 = {0, 0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;
-					uint32_t wpack0 = 0, wpack1 = 0;
-					uint32_t rec = inf[0], p = tp[0], part = byp ? 0u : prow[0];
 #pragma unroll 1
 					for (uint32_t i = 0; i < ((CF_ASTC_ABLATE & 64) ? 1u : n); ++i) {
-						const uint32_t nx = i + 1u < n ? i + 1u : i;
-						const uint32_t nrec = inf[nx], np = tp[nx], npart = byp ? 0u : prow[nx];   // before the cache stores
-						const uint32_t g0 = rec & 255u, f00 = (rec >> 8) & 31u, f01 = (rec >> 13) & 31u, f10 = (rec >> 18) & 31u, f11 = rec >> 23;
-						uint32_t wA, wB;
-						{
-							const uint32_t i0 = g0*planes, i1 = i0 + planes, i2 = i0 + N*planes, i3 = i2 + planes;
-							wA = (8u + f00*(COLR(i0) & 255u) + f01*(COLR(i1) & 255u) + f10*(COLR(i2) & 255u) + f11*(COLR(i3) & 255u)) >> 4;
-							wB = wA;
-							if (dual)
-								wB = (8u + f00*(COLR(i0 + 1u) & 255u) + f01*(COLR(i1 + 1u) & 255u) + f10*(COLR(i2 + 1u) & 255u) + f11*(COLR(i3 + 1u) & 255u)) >> 4;
-						}
-						if (wcached) {
-							wpack0 |= wA << (8u*(i & 3u));
-							wpack1 |= wB << (8u*(i & 3u));
-							if ((i & 3u) == 3u || i == n - 1u) {
-								wcache[((i >> 2)*2u)*64u] = wpack0;
-								wcache[((i >> 2)*2u + 1u)*64u] = wpack1;
-								wpack0 = 0; wpack1 = 0;
-							}
-						}
+						const uint2 rec = inf[i];
+						const uint32_t p = tp[i], part = byp ? 0u : prow[i];
+						const uint32_t wA = infill_w(colbase, rec.x, rec.y);
+						const uint32_t wB = dual ? infill_w(colp1, rec.x, rec.y) : wA;
 						const uint32_t pc0_ = p & 255u, pc1_ = (p >> 8) & 255u, pc2_ = (p >> 16) & 255u, pc3_ = p >> 24;
 #define ASTC_ACC(Q, ST) if (ST < nset) { \
 							const uint32_t wi = (dual && ST == 1u) ? wB : wA; \
@@ -1171,7 +1181,6 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							Q.V0 += wm*pc0_; Q.V1 += wm*pc1_; Q.V2 += wm*pc2_; Q.V3 += wm*pc3_; }
 						ASTC_ACC(q0, 0u) ASTC_ACC(q1, 1u) ASTC_ACC(q2, 2u) ASTC_ACC(q3, 3u)
 #undef ASTC_ACC
-						rec = nrec; p = np; part = npart;
 					}
 					// texel count and channel sums of every set: the subset's slot, or (dual) the whole
 					// block = the OR of the two planes' masked sums
@@ -1280,19 +1289,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						unsigned long long e64 = 0;
 #pragma unroll 1
 						for (uint32_t i = 0; i < ((CF_ASTC_ABLATE & 256) ? 1u : n); ++i) {
-							uint32_t w0, w1;
-							if (wcached) {
-								w0 = (wcache[((i >> 2)*2u)*64u] >> (8u*(i & 3u))) & 255u;
-								w1 = (wcache[((i >> 2)*2u + 1u)*64u] >> (8u*(i & 3u))) & 255u;
-							} else {
-								const uint32_t rec = inf[i];
-								const uint32_t g0 = rec & 255u, f00 = (rec >> 8) & 31u, f01 = (rec >> 13) & 31u, f10 = (rec >> 18) & 31u, f11 = rec >> 23;
-								const uint32_t i0 = g0*planes, i1 = i0 + planes, i2 = i0 + N*planes, i3 = i2 + planes;
-								w0 = (8u + f00*(COLR(i0) & 255u) + f01*(COLR(i1) & 255u) + f10*(COLR(i2) & 255u) + f11*(COLR(i3) & 255u)) >> 4;
-								w1 = w0;
-								if (dual)
-									w1 = (8u + f00*(COLR(i0 + 1u) & 255u) + f01*(COLR(i1 + 1u) & 255u) + f10*(COLR(i2 + 1u) & 255u) + f11*(COLR(i3 + 1u) & 255u)) >> 4;
-							}
+							const uint2 rec = inf[i];
+							const uint32_t w0 = infill_w(colbase, rec.x, rec.y);
+							const uint32_t w1 = dual ? infill_w(colp1, rec.x, rec.y) : w0;
 							const uint32_t part = byp ? 0u : prow[i];
 							const uint32_t q0 = part == 0u ? D0[0] : (part == 1u ? D0[1] : (part == 2u ? D0[2] : D0[3]));
 							const uint32_t q1 = part == 0u ? D1[0] : (part == 1u ? D1[1] : (part == 2u ? D1[2] : D1[3]));
@@ -1340,11 +1339,20 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 #pragma unroll
 						for (int k = 0; k < 5; ++k)
 							S.best[4 + k] = r_cv[k];
-						// quantised weights in stream order (high byte of the column slots)
-						const uint32_t nw = cfg.nw;
+						// quantised weights in stream order (grid point by grid point, planes interleaved): the
+						// column holds unquantised values at the even row pitch; an exact value is its own
+						// nearest neighbour, so wnear gives the index back
+						const uint32_t Ng = cfg.N, Npg = sh.grid[(uint32_t)cfg.grid*4u + 3u], ngp = cfg.ng;
 						uint8_t* wdst = reinterpret_cast<uint8_t*>(S.best + 12);
-						for (uint32_t g = 0; g < nw; ++g)
-							wdst[g] = (uint8_t)(COLR(g) >> 8);
+						uint32_t gx = 0, rr = 0;
+						for (uint32_t g = 0; g < ngp; ++g) {
+							const uint32_t so = (rr >> 1)*256u + (rr & 1u)*2u;
+							wdst[g*planes] = sh.wnear[wq*68u + colbase[so]];
+							if (dual)
+								wdst[g*planes + 1u] = sh.wnear[wq*68u + colp1[so]];
+							++gx; ++rr;
+							if (gx == Ng) { gx = 0; rr += Npg - Ng; }
+						}
 					}
 				}
 				__builtin_amdgcn_wave_barrier();
@@ -1488,13 +1496,13 @@ static size_t astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality, 
 	const uint32_t n = h->n, ngrids = h->ngrids, npad = h->npad;
 	uint32_t off = nwaves*4u*n*4u;
 	off = (off + 15u) & ~15u;
-	off += ngrids*n*4u; off = (off + 15u) & ~15u;
-	off += ngrids*128u;
+	off += ngrids*n*8u; off = (off + 15u) & ~15u;
+	off += ngrids*(uint32_t)cfastc::ASTC_DEN_STRIDE*2u;
 	off += (ngrids*4u + 15u) & ~15u;
-	off += (hdr ? 3u : 2u)*17u*256u + 1216u;
-	const uint32_t wc_rows = wcached ? 2u*((n + 3u)/4u) : 0u;
+	off += (hdr ? 3u : 2u)*17u*256u + 2016u;
+	(void)wcached;
 	const uint32_t slot_bytes = ((10u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
-	const uint32_t wave_bytes = ((((h->col_rows + 1u)/2u)*256u + wc_rows*256u + 15u) & ~15u) + (quality <= 2u ? 2u : 1u)*slot_bytes;
+	const uint32_t wave_bytes = ((((h->col_rows + 1u)/2u)*256u + 15u) & ~15u) + (quality <= 2u ? 2u : 1u)*slot_bytes;
 	return (size_t)off + nwaves*(size_t)wave_bytes;
 }
 
@@ -1505,7 +1513,7 @@ static size_t astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality, 
 extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t quality, uint32_t hdr, uint32_t* nwaves, uint32_t* wcached, size_t* lds_bytes)
 {
 	const size_t cu_lds = cf_astc_cu_lds(), wg_max = cf_astc_wg_lds_max();
-	const bool can_cache = h->n <= 36u;
+	const bool can_cache = false;       // the texel-weight cache is gone: a texel's weight is two loads and one v_dot4 now
 	uint32_t best_w = 0, best_nw = 4, best_c = 0;
 	static const char* const force = getenv("CFHIP_ASTC_WAVES");     // experiments: pin the workgroup shape
 	const uint32_t forced = (force && *force) ? (uint32_t)atoi(force) : 0u;

@@ -7,15 +7,21 @@
 //
 // Blob layout (offsets in the header, all sections 16-byte aligned):
 //   AstcBlobHeader
-//   grids   : ngrids x {N, M, ng, 0}                       (u8 x 4)
-//   infill  : ngrids x n x u32   g0 | f00<<8 | f01<<13 | f10<<18 | f11<<23
-//             (the four grid points are g0, g0+1, g0+N, g0+N+1; factors sum to 16)
-//   den     : ngrids x 64 x u16  per-grid-point factor sums
+//   grids   : ngrids x {N, M, ng, Np}                      (u8 x 4; Np = N rounded up to even)
+//   infill  : ngrids x n x {u32 F, u32 offs}
+//             F    = f00 | f01<<8 | f10<<16 | f11<<24: the factors of grid points g0, g0+1, g0+N,
+//                    g0+N+1 (they sum to 16), one byte each: an operand of v_dot4_u32_u8
+//             offs = slot(r0) | slot(r1)<<16: byte offsets, inside a lane's LDS weight column, of the
+//                    16-bit slots of rows r0 = gy*Np + gx and r1 = r0 + Np (r1 = r0 where the lower
+//                    pair has no weight: f10 = f11 = 0).  A grid is stored with an even row pitch Np,
+//                    so r0 and r1 have the same parity; slot(r) = (r>>1)*256 + (r&1)*2, i.e. word
+//                    [r>>1][lane] half r&1 -- conflict-free whatever rows the lanes address
+//   den     : ngrids x 80 x u16  per-grid-point factor sums in the padded row order (0 in the pad)
 //   cfg     : [5 classes][2 alpha][64] x AstcCfgRec (16 B), ncfg[10]
 //   part    : for P = 2, 3, 4: seeds u16[npart], masks u64[npart][4][3], ids u8[npart][npad]
 //   ctab    : colour unquant u8[17][256], nearest-index u8[17][256], then (HDR direct sub-mode) the
 //             nearest index among the values with bit 7 set, by decoded value (u & 0x7F) << 1, u8[17][256]
-//   wtab    : weight unquant u8[12][32] then nearest-index u8[12][68]
+//   wtab    : weight unquant u8[12][32], nearest-index u8[12][68], nearest unquantised value u8[12][68]
 //   clevel  : i8[10][132]   highest colour range for (values / 2, bits)
 //   ise     : trit_enc u8[256], quint_enc u8[128], wq descr u8[12][4], cq descr u8[17][4]
 //             (descr = bits, trits, quints, 0)
@@ -228,26 +234,31 @@ inline int select_partition(int seed, int x, int y, int parts, bool small_block)
 inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 struct GridHost { int N, M; std::vector<uint32_t> infill; std::vector<uint16_t> den; };
+enum { ASTC_DEN_STRIDE = 80 };     // u16 entries per grid in the den section (M * Np <= 76)
+
+inline uint32_t slot_off(uint32_t r) { return (r >> 1)*256u + (r & 1u)*2u; }
 
 inline GridHost make_grid(int bw, int bh, int N, int M)
 {
 	GridHost g;
 	g.N = N; g.M = M;
-	g.infill.resize((size_t)bw*bh);
-	g.den.assign(64, 0);
+	g.infill.resize((size_t)bw*bh*2);
+	g.den.assign(ASTC_DEN_STRIDE, 0);
+	const int Np = N + (N & 1);
 	const int Ds = (1024 + bw/2)/(bw - 1), Dt = (1024 + bh/2)/(bh - 1);
 	for (int t = 0; t < bh; ++t)
 		for (int s = 0; s < bw; ++s) {
 			const int gs = (Ds*s*(N - 1) + 32) >> 6, gt = (Dt*t*(M - 1) + 32) >> 6;
 			const int js = gs >> 4, fs = gs & 15, jt = gt >> 4, ft = gt & 15;
 			const int f11 = (fs*ft + 8) >> 4, f10 = ft - f11, f01 = fs - f11, f00 = 16 - fs - ft + f11;
-			const int g0 = js + jt*N;
-			g.infill[(size_t)t*bw + s] = (uint32_t)g0 | ((uint32_t)f00 << 8) | ((uint32_t)f01 << 13) |
-				((uint32_t)f10 << 18) | ((uint32_t)f11 << 23);
-			g.den[g0] = (uint16_t)(g.den[g0] + f00);
-			if (f01) g.den[g0 + 1] = (uint16_t)(g.den[g0 + 1] + f01);
-			if (f10) g.den[g0 + N] = (uint16_t)(g.den[g0 + N] + f10);
-			if (f11) g.den[g0 + N + 1] = (uint16_t)(g.den[g0 + N + 1] + f11);
+			const int r0 = js + jt*Np, r1 = (f10 || f11) ? r0 + Np : r0;
+			g.infill[((size_t)t*bw + s)*2] = (uint32_t)f00 | ((uint32_t)f01 << 8) | ((uint32_t)f10 << 16) |
+				((uint32_t)f11 << 24);
+			g.infill[((size_t)t*bw + s)*2 + 1] = slot_off((uint32_t)r0) | (slot_off((uint32_t)r1) << 16);
+			g.den[r0] = (uint16_t)(g.den[r0] + f00);
+			if (f01) g.den[r0 + 1] = (uint16_t)(g.den[r0 + 1] + f01);
+			if (f10) g.den[r0 + Np] = (uint16_t)(g.den[r0 + Np] + f10);
+			if (f11) g.den[r0 + Np + 1] = (uint16_t)(g.den[r0 + Np + 1] + f11);
 		}
 	return g;
 }
@@ -358,9 +369,13 @@ inline std::vector<uint8_t> build_blob(int bw, int bh)
 				c.wq16 = (uint16_t)((16*64*64)/(12*(Lw - 1)*(Lw - 1)));
 				c.cq16 = (uint16_t)((16*255*255)/(18*(Lc - 1)*(Lc - 1)));
 				c.lv0 = (uint16_t)all[i].lv;
-				// rows a lane's column needs: the grid (interleaved planes) + the rows the unmasked
-				// neighbour reads / writes of the last grid point reach
-				col_rows = std::max<uint32_t>(col_rows, (uint32_t)(nw + (dual ? 2 : 1)*(all[i].N + 2)));
+				// 16-bit rows a lane's column needs: every plane's grid at its even row pitch, planes one
+				// after the other on word boundaries, plus the word the (zero) carry of the last row pair
+				// may touch
+				{
+					const uint32_t Np = (uint32_t)(all[i].N + (all[i].N & 1)), Rp = Np*(uint32_t)all[i].M;
+					col_rows = std::max<uint32_t>(col_rows, (dual ? 2u : 1u)*((Rp + 1u) & ~1u) + 2u);
+				}
 			}
 			ncfg[cls*2 + alpha] = (uint8_t)k;
 		}
@@ -407,8 +422,8 @@ inline std::vector<uint8_t> build_blob(int bw, int bh)
 	h.npad = npad; h.col_rows = col_rows;
 	size_t off = align16(sizeof(h));
 	h.off_grid = (uint32_t)off; off = align16(off + grids.size()*4);
-	h.off_infill = (uint32_t)off; off = align16(off + grids.size()*(size_t)n*4);
-	h.off_den = (uint32_t)off; off = align16(off + grids.size()*128);
+	h.off_infill = (uint32_t)off; off = align16(off + grids.size()*(size_t)n*8);
+	h.off_den = (uint32_t)off; off = align16(off + grids.size()*(size_t)ASTC_DEN_STRIDE*2);
 	h.off_cfg = (uint32_t)off; off = align16(off + cfgs.size()*sizeof(AstcCfgRec));
 	h.off_ncfg = (uint32_t)off; off = align16(off + 16);
 	for (int t = 0; t < 3; ++t) {
@@ -418,7 +433,7 @@ inline std::vector<uint8_t> build_blob(int bw, int bh)
 		h.off_ids[t] = (uint32_t)off; off = align16(off + ids[t].size());
 	}
 	h.off_ctab = (uint32_t)off; off = align16(off + 3*17*256);
-	h.off_wtab = (uint32_t)off; off = align16(off + 12*32 + 12*68);
+	h.off_wtab = (uint32_t)off; off = align16(off + 12*32 + 2*12*68);
 	h.off_clevel = (uint32_t)off; off = align16(off + 10*132);
 	h.off_ise = (uint32_t)off; off = align16(off + 256 + 128 + 12*4 + 17*4);
 	h.total = (uint32_t)off;
@@ -427,8 +442,9 @@ inline std::vector<uint8_t> build_blob(int bw, int bh)
 	for (size_t g = 0; g < grids.size(); ++g) {
 		uint8_t* r = blob.data() + h.off_grid + g*4;
 		r[0] = (uint8_t)grids[g].N; r[1] = (uint8_t)grids[g].M; r[2] = (uint8_t)(grids[g].N*grids[g].M);
-		memcpy(blob.data() + h.off_infill + g*(size_t)n*4, grids[g].infill.data(), (size_t)n*4);
-		memcpy(blob.data() + h.off_den + g*128, grids[g].den.data(), 128);
+		r[3] = (uint8_t)(grids[g].N + (grids[g].N & 1));
+		memcpy(blob.data() + h.off_infill + g*(size_t)n*8, grids[g].infill.data(), (size_t)n*8);
+		memcpy(blob.data() + h.off_den + g*(size_t)ASTC_DEN_STRIDE*2, grids[g].den.data(), (size_t)ASTC_DEN_STRIDE*2);
 	}
 	memcpy(blob.data() + h.off_cfg, cfgs.data(), cfgs.size()*sizeof(AstcCfgRec));
 	memcpy(blob.data() + h.off_ncfg, ncfg, 16);
@@ -479,6 +495,12 @@ inline std::vector<uint8_t> build_blob(int bw, int bh)
 				wnear[r*68 + w] = (uint8_t)best;
 			}
 		}
+		// nearest UNQUANTISED weight of an average 0..64 in one lookup (the search never needs the
+		// index; the winner recovers it as wnear[its unquantised value])
+		uint8_t* wnu = wnear + 12*68;
+		for (int r = 0; r < 12; ++r)
+			for (int w = 0; w <= 64; ++w)
+				wnu[r*68 + w] = wunq[r*32 + wnear[r*68 + w]];
 		memcpy(blob.data() + h.off_clevel, clevel.data(), clevel.size());
 		uint8_t* ise = blob.data() + h.off_ise;
 		memset(ise, 0xFF, 256 + 128);
