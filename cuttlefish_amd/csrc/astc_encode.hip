@@ -146,7 +146,7 @@ __device__ __forceinline__ float quad_est(float fA, float fB, float fC, float d0
 // the workgroup's shared tables in LDS
 struct Shared {
 	const uint2* infill;      // [grid][n]: x = the four factors as bytes, y = slot offsets of rows r0 | r1 << 16
-	const uint16_t* den;      // [grid][ASTC_DEN_STRIDE]: factor sums in the padded row order
+	const uint32_t* den;      // [grid][den_stride]: factor sum | floor(65536 / sum) << 16 per padded row
 	const uint8_t* grid;      // [grid][4]: N, M, ng, Np (even row pitch)
 	const uint8_t* cunq;      // [17][256]
 	const uint8_t* cnear;     // [17][256]
@@ -186,17 +186,26 @@ __device__ __forceinline__ void decim_add(uint8_t* base, uint32_t F, uint32_t of
 // rounded average (sum + den/2)/den and (QUANT) the nearest unquantised weight of the lane's range.
 // What is stored is the PAIR form the infill reads: slot r = w[r] | w[r+1] << 8, so that the two
 // horizontally adjacent weights of a texel are one 16-bit load and the four of them one dword.
+// floor((acc + den/2) / den) for acc <= 64 den, den < 1024, from the table entry e = den | floor(65536/den) << 16:
+// the reciprocal product is the quotient or one less (num < 2^16), one compare fixes it.  Empty rows carry
+// den = 0xFFFF, reciprocal 0 -> 0.
+__device__ __forceinline__ uint32_t avg_round(uint32_t acc, uint32_t e)
+{
+	const uint32_t den = e & 0xFFFFu, num = acc + (den >> 1);
+	const uint32_t q0 = (num*(e >> 16)) >> 16;
+	return q0 + ((num - q0*den) >= den ? 1u : 0u);
+}
+
 template <bool QUANT>
-__device__ __forceinline__ void normalise_rows(uint8_t* base, const uint16_t* den, uint32_t PW, const uint8_t* wnu)
+__device__ __forceinline__ void normalise_rows(uint8_t* base, const uint32_t* den, uint32_t PW, const uint8_t* wnu)
 {
 	uint32_t prev = 0;        // w[2k-2] | w[2k-1] << 8
 #pragma unroll 1
 	for (uint32_t k = 0; k < PW; ++k) {
 		uint32_t* wp = reinterpret_cast<uint32_t*>(base + k*256u);
-		const uint32_t acc = *wp, dd = *reinterpret_cast<const uint32_t*>(den + 2u*k);
-		const uint32_t d0 = dd & 0xFFFFu, d1 = dd >> 16;
-		uint32_t g0 = d0 ? div_small((acc & 0xFFFFu) + d0/2u, d0, 1.0f/(float)d0) : 0u;
-		uint32_t g1 = d1 ? div_small((acc >> 16) + d1/2u, d1, 1.0f/(float)d1) : 0u;
+		const uint32_t acc = *wp;
+		const uint2 dd = *reinterpret_cast<const uint2*>(den + 2u*k);
+		uint32_t g0 = avg_round(acc & 0xFFFFu, dd.x), g1 = avg_round(acc >> 16, dd.y);
 		if (QUANT) {
 			g0 = wnu[g0];
 			g1 = wnu[g1];
@@ -532,6 +541,30 @@ __device__ __forceinline__ unsigned long long ise_group(const uint8_t* ise, cons
 	return out;
 }
 
+typedef unsigned short astc_us2 __attribute__((ext_vector_type(2)));
+typedef short astc_s2 __attribute__((ext_vector_type(2)));
+
+// two channels at once: the 8-bit value (257 (e0 (64 - w) + e1 w) + 32) >> 14 an LDR endpoint pair
+// interpolates to, all three operands as 16-bit pairs
+__device__ __forceinline__ uint32_t pk_interp(uint32_t e0, uint32_t e1, uint32_t w)
+{
+	const astc_us2 a = __builtin_bit_cast(astc_us2, e0), b = __builtin_bit_cast(astc_us2, e1), ww = __builtin_bit_cast(astc_us2, w);
+	const astc_us2 k64 = {64, 64}, k32 = {32, 32}, s8 = {8, 8}, s6 = {6, 6};
+	const astc_us2 x = a*(k64 - ww) + b*ww;
+	const astc_us2 v = (x + ((x + k32) >> s8)) >> s6;
+	return __builtin_bit_cast(uint32_t, v);
+}
+
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b)
+{
+	return __builtin_bit_cast(uint32_t, (astc_s2)(__builtin_bit_cast(astc_s2, a) - __builtin_bit_cast(astc_s2, b)));
+}
+
+__device__ __forceinline__ int sdot2_i16(uint32_t a, uint32_t b, int acc)
+{
+	return __builtin_amdgcn_sdot2(__builtin_bit_cast(astc_s2, a), __builtin_bit_cast(astc_s2, b), acc, false);
+}
+
 } // namespace
 
 // A workgroup is 4, 8 or 12 waves (4 blocks per wave): the launcher picks the shape that puts the
@@ -548,7 +581,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	const uint8_t* blob = reinterpret_cast<const uint8_t*>(kp.aux);
 	const AstcBlobHeader* H = reinterpret_cast<const AstcBlobHeader*>(blob);
 	const uint32_t n = H->n, bw = H->bw, bh = H->bh, ngrids = H->ngrids, npad = H->npad;
-	const uint32_t col_rows = H->col_rows;
+	const uint32_t col_rows = H->col_rows, den_stride = H->den_stride;
 	const uint32_t aflags = (kp.flags >> 16) & 3u;
 	// HDR profile (Type::UFloat, AstcConverter.cpp:150-162): bit 0 = HDR colour, bit 1 = HDR alpha too
 	const uint32_t hdrf = (kp.flags >> 19) & 3u;
@@ -559,7 +592,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	uint32_t* tile = reinterpret_cast<uint32_t*>(lds + off); off += nblk*n*4u;
 	off = (off + 15u) & ~15u;
 	uint32_t* sh_infill = reinterpret_cast<uint32_t*>(lds + off); off += ngrids*n*8u; off = (off + 15u) & ~15u;
-	uint16_t* sh_den = reinterpret_cast<uint16_t*>(lds + off); off += ngrids*(uint32_t)cfastc::ASTC_DEN_STRIDE*2u;
+	uint32_t* sh_den = reinterpret_cast<uint32_t*>(lds + off); off += ngrids*den_stride*4u;
 	uint8_t* sh_grid = lds + off; off += (ngrids*4u + 15u) & ~15u;
 	uint8_t* sh_ctab = lds + off; off += (hdrf ? 3u : 2u)*17u*256u;
 	uint8_t* sh_wtab = lds + off; off += 2016u;
@@ -570,8 +603,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 
 	for (uint32_t i = threadIdx.x; i < ngrids*n*2u; i += nthreads)
 		sh_infill[i] = reinterpret_cast<const uint32_t*>(blob + H->off_infill)[i];
-	for (uint32_t i = threadIdx.x; i < ngrids*(uint32_t)cfastc::ASTC_DEN_STRIDE/2u; i += nthreads)
-		reinterpret_cast<uint32_t*>(sh_den)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_den)[i];
+	for (uint32_t i = threadIdx.x; i < ngrids*den_stride; i += nthreads)
+		sh_den[i] = reinterpret_cast<const uint32_t*>(blob + H->off_den)[i];
 	for (uint32_t i = threadIdx.x; i < ngrids; i += nthreads)
 		reinterpret_cast<uint32_t*>(sh_grid)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_grid)[i];
 	for (uint32_t i = threadIdx.x; i < (hdrf ? 3u : 2u)*17u*64u; i += nthreads)
@@ -1069,7 +1102,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						const uint2 rec = inf[i];
 						decim_add(colbase, rec.x, rec.y, Trow[i]);
 					}
-					normalise_rows<false>(colbase, sh.den + g*(uint32_t)cfastc::ASTC_DEN_STRIDE, PW, nullptr);
+					normalise_rows<false>(colbase, sh.den + g*den_stride, PW, nullptr);
 					uint32_t e = 0;
 #pragma unroll 2
 					for (uint32_t i = 0; i < n; ++i) {
@@ -1134,7 +1167,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				r_cfg = oi;
 				const uint32_t planes = dual ? 2u : 1u, wq = cfg.wq;
 				const uint2* inf = sh.infill + (uint32_t)cfg.grid*n;
-				const uint16_t* den = sh.den + (uint32_t)cfg.grid*(uint32_t)cfastc::ASTC_DEN_STRIDE;
+				const uint32_t* den = sh.den + (uint32_t)cfg.grid*den_stride;
 				// words per plane of the lane's column (rows at the grid's even pitch); plane 1 follows plane 0
 				const uint32_t PW = ((uint32_t)cfg.M*(uint32_t)sh.grid[(uint32_t)cfg.grid*4u + 3u] + 1u) >> 1;
 				uint8_t* colp1 = colbase + (dual ? PW*256u : 0u);
@@ -1167,19 +1200,25 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					// index makes the compiler keep the arrays in scratch)
 					struct SetAcc { uint32_t S, C, V0, V1, V2, V3, cn, p01, p23; };
 					SetAcc q0 = {0, 0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;
+					// a texel's membership mask over the sets (bit ST): its subset, or both planes; sets 2 and 3
+					// are walked only when some lane of the wave has them (a scalar branch, not per-lane
+					// predication -- the wave executes the instructions either way)
+					const bool any3 = __ballot(nset > 2u) != 0ull, any4 = __ballot(nset > 3u) != 0ull;
 #pragma unroll 1
 					for (uint32_t i = 0; i < ((CF_ASTC_ABLATE & 64) ? 1u : n); ++i) {
 						const uint2 rec = inf[i];
 						const uint32_t p = tp[i], part = byp ? 0u : prow[i];
 						const uint32_t wA = infill_w(colbase, rec.x, rec.y);
-						const uint32_t wB = dual ? infill_w(colp1, rec.x, rec.y) : wA;
+						const uint32_t w1s = dual ? infill_w(colp1, rec.x, rec.y) : wA;     // what set 1 fits with
+						const uint32_t mm = dual ? 3u : (1u << part);
 						const uint32_t pc0_ = p & 255u, pc1_ = (p >> 8) & 255u, pc2_ = (p >> 16) & 255u, pc3_ = p >> 24;
-#define ASTC_ACC(Q, ST) if (ST < nset) { \
-							const uint32_t wi = (dual && ST == 1u) ? wB : wA; \
-							const uint32_t wm = dual ? wi : (part == ST ? wi : 0u); \
-							Q.S += wm; Q.C += wm*wi; \
+#define ASTC_ACC(Q, ST, WI) { \
+							const uint32_t wm = (mm & (1u << ST)) ? WI : 0u; \
+							Q.S += wm; Q.C += wm*WI; \
 							Q.V0 += wm*pc0_; Q.V1 += wm*pc1_; Q.V2 += wm*pc2_; Q.V3 += wm*pc3_; }
-						ASTC_ACC(q0, 0u) ASTC_ACC(q1, 1u) ASTC_ACC(q2, 2u) ASTC_ACC(q3, 3u)
+						ASTC_ACC(q0, 0u, wA) ASTC_ACC(q1, 1u, w1s)
+						if (any3) ASTC_ACC(q2, 2u, wA)
+						if (any4) ASTC_ACC(q3, 3u, wA)
 #undef ASTC_ACC
 					}
 					// texel count and channel sums of every set: the subset's slot, or (dual) the whole
@@ -1287,6 +1326,39 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						PROF_MARK(8)   // B: endpoint modes
 						// 5. exact error through the decode arithmetic
 						unsigned long long e64 = 0;
+						if (!hdrf && !(aflags & ASTC_FLAG_PERCEPTUAL)) {
+							// LDR, unit channel weights: two channels per instruction.  Endpoints and texel as
+							// 16-bit pairs (v_perm), x = e0 (64 - w) + e1 w <= 16320 in packed 16-bit arithmetic,
+							// (257 x + 32) >> 14 == (x + ((x + 32) >> 8)) >> 6 (256 x + x + 32 = 256 (x + (x + 32)/256):
+							// dropping the fraction of an integer numerator cannot cross a multiple of 64), squared
+							// differences through v_dot2_i32_i16.  A block without alpha has endpoint and texel
+							// alpha 255: its alpha term is 0 by itself.
+							const uint32_t mlo = dual ? (ccs == 0u ? 0x0000FFFFu : (ccs == 1u ? 0xFFFF0000u : 0u)) : 0u;
+							const uint32_t mhi = dual ? (ccs == 2u ? 0x0000FFFFu : (ccs == 3u ? 0xFFFF0000u : 0u)) : 0u;
+							const bool wide = __ballot(P > 2u) != 0ull;
+#pragma unroll 1
+							for (uint32_t i = 0; i < ((CF_ASTC_ABLATE & 256) ? 1u : n); ++i) {
+								const uint2 rec = inf[i];
+								const uint32_t w0p = infill_w(colbase, rec.x, rec.y)*0x00010001u;
+								const uint32_t w1p = dual ? infill_w(colp1, rec.x, rec.y)*0x00010001u : w0p;
+								const uint32_t wlo = (w0p & ~mlo) | (w1p & mlo), whi = (w0p & ~mhi) | (w1p & mhi);
+								const uint32_t part = byp ? 0u : prow[i];
+								uint32_t q0 = part == 0u ? D0[0] : D0[1], q1 = part == 0u ? D1[0] : D1[1];
+								if (wide) {
+									q0 = part == 2u ? D0[2] : (part == 3u ? D0[3] : q0);
+									q1 = part == 2u ? D1[2] : (part == 3u ? D1[3] : q1);
+								}
+								const uint32_t p = tp[i];
+								const uint32_t vlo = pk_interp(__builtin_amdgcn_perm(0u, q0, 0x0C010C00u), __builtin_amdgcn_perm(0u, q1, 0x0C010C00u), wlo);
+								const uint32_t vhi = pk_interp(__builtin_amdgcn_perm(0u, q0, 0x0C030C02u), __builtin_amdgcn_perm(0u, q1, 0x0C030C02u), whi);
+								const uint32_t dlo = pk_sub_i16(vlo, __builtin_amdgcn_perm(0u, p, 0x0C010C00u));
+								const uint32_t dhi = pk_sub_i16(vhi, __builtin_amdgcn_perm(0u, p, 0x0C030C02u));
+								const uint32_t ergb = (uint32_t)sdot2_i16(dlo, dlo, sdot2_i16(dhi, dhi & 0x0000FFFFu, 0));
+								const uint32_t ea = (uint32_t)sdot2_i16(dhi, dhi & 0xFFFF0000u, 0);
+								const uint32_t wa = (aflags & ASTC_FLAG_ALPHA_WEIGHT) ? (p >> 24) : 255u;
+								e64 += (unsigned long long)(ergb*wa + ea*255u);      // < 2^27 per texel
+							}
+						} else {
 #pragma unroll 1
 						for (uint32_t i = 0; i < ((CF_ASTC_ABLATE & 256) ? 1u : n); ++i) {
 							const uint2 rec = inf[i];
@@ -1313,6 +1385,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							}
 							const uint32_t wa = (aflags & ASTC_FLAG_ALPHA_WEIGHT) ? (p >> 24) : 255u;
 							e64 += (unsigned long long)ergb*wa + (unsigned long long)ea*255ull;
+						}
 						}
 						err = e64;
 						r_cem = hdrf ? (has_alpha ? ((hdrf & 2u) ? 15u : 14u) : 11u)
@@ -1497,7 +1570,7 @@ static size_t astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality, 
 	uint32_t off = nwaves*4u*n*4u;
 	off = (off + 15u) & ~15u;
 	off += ngrids*n*8u; off = (off + 15u) & ~15u;
-	off += ngrids*(uint32_t)cfastc::ASTC_DEN_STRIDE*2u;
+	off += ngrids*h->den_stride*4u;
 	off += (ngrids*4u + 15u) & ~15u;
 	off += (hdr ? 3u : 2u)*17u*256u + 2016u;
 	(void)wcached;

@@ -16,7 +16,9 @@
 //                    pair has no weight: f10 = f11 = 0).  A grid is stored with an even row pitch Np,
 //                    so r0 and r1 have the same parity; slot(r) = (r>>1)*256 + (r&1)*2, i.e. word
 //                    [r>>1][lane] half r&1 -- conflict-free whatever rows the lanes address
-//   den     : ngrids x 80 x u16  per-grid-point factor sums in the padded row order (0 in the pad)
+//   den     : ngrids x den_stride x u32  per row of the padded order: factor sum | floor(65536 / sum) << 16
+//             (the reciprocal makes the rounded average a multiply, a shift and one fix-up); rows no
+//             texel touches hold 0xFFFF | 0 << 16 and so average to 0
 //   cfg     : [5 classes][2 alpha][64] x AstcCfgRec (16 B), ncfg[10]
 //   part    : for P = 2, 3, 4: seeds u16[npart], masks u64[npart][4][3], ids u8[npart][npad]
 //   ctab    : colour unquant u8[17][256], nearest-index u8[17][256], then (HDR direct sub-mode) the
@@ -42,7 +44,8 @@ struct AstcBlobHeader {
 	uint32_t off_ctab, off_wtab, off_clevel, off_ise;
 	uint32_t col_rows;        // rows of a lane's LDS grid column that any listed config needs
 	uint32_t total;
-	uint32_t pad[2];
+	uint32_t den_stride;      // u32 entries per grid in the den section: the largest M * Np, rounded up to even
+	uint32_t pad[1];
 };
 
 struct AstcCfgRec {
@@ -423,7 +426,11 @@ inline std::vector<uint8_t> build_blob(int bw, int bh)
 	size_t off = align16(sizeof(h));
 	h.off_grid = (uint32_t)off; off = align16(off + grids.size()*4);
 	h.off_infill = (uint32_t)off; off = align16(off + grids.size()*(size_t)n*8);
-	h.off_den = (uint32_t)off; off = align16(off + grids.size()*(size_t)ASTC_DEN_STRIDE*2);
+	uint32_t den_stride = 2;
+	for (const GridHost& g : grids)
+		den_stride = std::max<uint32_t>(den_stride, (uint32_t)(g.M*(g.N + (g.N & 1)) + 1) & ~1u);
+	h.den_stride = den_stride;
+	h.off_den = (uint32_t)off; off = align16(off + grids.size()*(size_t)den_stride*4);
 	h.off_cfg = (uint32_t)off; off = align16(off + cfgs.size()*sizeof(AstcCfgRec));
 	h.off_ncfg = (uint32_t)off; off = align16(off + 16);
 	for (int t = 0; t < 3; ++t) {
@@ -444,7 +451,11 @@ inline std::vector<uint8_t> build_blob(int bw, int bh)
 		r[0] = (uint8_t)grids[g].N; r[1] = (uint8_t)grids[g].M; r[2] = (uint8_t)(grids[g].N*grids[g].M);
 		r[3] = (uint8_t)(grids[g].N + (grids[g].N & 1));
 		memcpy(blob.data() + h.off_infill + g*(size_t)n*8, grids[g].infill.data(), (size_t)n*8);
-		memcpy(blob.data() + h.off_den + g*(size_t)ASTC_DEN_STRIDE*2, grids[g].den.data(), (size_t)ASTC_DEN_STRIDE*2);
+		uint32_t* dn = reinterpret_cast<uint32_t*>(blob.data() + h.off_den) + g*(size_t)den_stride;
+		for (uint32_t r = 0; r < den_stride; ++r) {
+			const uint32_t d = grids[g].den[r];
+			dn[r] = d ? (d | (std::min<uint32_t>(65535u, 65536u/d) << 16)) : 0xFFFFu;
+		}
 	}
 	memcpy(blob.data() + h.off_cfg, cfgs.data(), cfgs.size()*sizeof(AstcCfgRec));
 	memcpy(blob.data() + h.off_ncfg, ncfg, 16);
