@@ -78,7 +78,7 @@ __device__ __forceinline__ Ladder ladder(uint32_t q)
 		case 0: return {2, 0, 0, 0, 0, 0};
 		case 1: return {4, 16, 2, 0, 0, 1};
 		case 2: return {4, 32, 3, 2, 0, 2};
-		case 3: return {8, 256, 8, 5, 0, 2};
+		case 3: return {8, 256, 4, 2, 0, 2};
 		default: return {8, 256, 14, 9, 6, 2};
 	}
 }
@@ -795,6 +795,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			++npc;
 		}
 		// k-means clusters along the principal axis + one Lloyd step, then the partition shortlist
+		const uint32_t nb = npc;            // candidates before the partitioned ones
+		uint32_t got2 = 0, got3 = 0;
 		for (uint32_t P = 2; P <= 4u; ++P) {
 			const uint32_t want = (CF_ASTC_ABLATE & 8) ? 0u : (P == 2u ? lad.j2 : (P == 3u ? lad.j3 : lad.j4));
 			if (!want)
@@ -933,10 +935,30 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				if (gmin != 0xFFFFFFFFu) {
 					if (hl == 0u) S.pcs[npc] = pc_make(P, 0, 0, P, gmin & 0xFFFFu);
 					++npc;
+					got2 += P == 2u ? 1u : 0u;
+					got3 += P == 3u ? 1u : 0u;
 				}
 			}
 		}
 		__builtin_amdgcn_wave_barrier();
+		if (q >= 3u) {
+			// High and Highest (one block per wave) share the head of the walk: 4 two-partition seeds, then
+			// 2 three-partition seeds, then the rest in the old order (oracle: ASTC_HEAD2 / ASTC_HEAD3);
+			// High keeps the first pass of 8 candidates only.  Lane t moves entry t.
+			const uint32_t h2 = got2 < 4u ? got2 : 4u, h3 = got3 < 2u ? got3 : 2u;
+			uint32_t src = lane;
+			if (lane >= nb && lane < nb + got2 + got3) {
+				const uint32_t u = lane - nb;
+				src = u < h2 ? lane : (u < h2 + h3 ? nb + got2 + (u - h2) : (u < got2 + h3 ? nb + h2 + (u - h2 - h3) : lane));
+			}
+			const uint32_t moved = lane < npc ? S.pcs[src] : 0u;
+			__builtin_amdgcn_wave_barrier();
+			if (lane < npc)
+				S.pcs[lane] = moved;
+			__builtin_amdgcn_wave_barrier();
+			if (q == 3u && npc > 8u)
+				npc = 8u;
+		}
 
 		PROF_MARK(1)   // statistics + candidate list + shortlist
 		// ---- passes of (gsz / K) candidates x K configs ----
@@ -1356,7 +1378,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 								const uint32_t ergb = (uint32_t)sdot2_i16(dlo, dlo, sdot2_i16(dhi, dhi & 0x0000FFFFu, 0));
 								const uint32_t ea = (uint32_t)sdot2_i16(dhi, dhi & 0xFFFF0000u, 0);
 								const uint32_t wa = (aflags & ASTC_FLAG_ALPHA_WEIGHT) ? (p >> 24) : 255u;
-								e64 += (unsigned long long)(ergb*wa + ea*255u);      // < 2^27 per texel
+								e64 += __umul24(ergb, wa) + __umul24(ea, 255u);      // < 2^27 per texel: one 32-bit value, a 64-bit add
 							}
 						} else {
 #pragma unroll 1
