@@ -34,6 +34,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 using cfastc::AstcBlobHeader;
 using cfastc::AstcCfgRec;
@@ -1138,25 +1139,32 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			}
 
 			PROF_MARK(4)   // grids
-			// ---- ranking: lane = config of the candidate's class, K smallest estimates ----
-			for (uint32_t j = 0; j < (per_pass < 8u ? per_pass : 8u); ++j) {
-				const bool jact = j < cnt;
+			// ---- ranking: all (at most 8) candidates of the pass at once.  Lane = (candidate, one of SUB
+			// sub-lanes), SUB = group size / 8; a sub-lane owns the configs t, t + SUB, ... of the
+			// candidate's class list; the K smallest estimates leave in (estimate, list index) order through
+			// K minima over the candidate's SUB lanes (two or three DPP steps each) -- one walk instead of
+			// one K-step wave reduction per candidate ----
+			auto rank_pass = [&](auto nk_) __attribute__((always_inline)) {
+				constexpr uint32_t NK = decltype(nk_)::value;          // configs per lane: 64 / SUB
+				constexpr uint32_t sub_sh = NK == 16u ? 2u : 3u, SUB = 1u << sub_sh;
+				const uint32_t j = hl >> sub_sh, t = hl & (SUB - 1u);
+				const bool jact = j < cnt && j < 8u;
 				const uint32_t d = jact ? S.pcs[base + j] : 0u;
 				const uint32_t cls = pc_cls(d), slots = pc_dual(d) ? 2u : pc_P(d);
 				uint32_t spn = 0;
 #pragma unroll
 				for (uint32_t s = 0; s < 4u; ++s)
-					spn += (jact && s < slots) ? S.span[j*4u + s] : 0u;
+					spn += (jact && s < slots) ? S.span[(j*4u + s) & 31u] : 0u;
 				const unsigned long long span2 = ((unsigned long long)spn*recip_n) >> 16;
 				const uint32_t ncfg = jact ? ncfgs[cls*2u + alpha_i] : 0u;
 				const AstcCfgRec* list = cfgs + (cls*2u + alpha_i)*64u;
 				// keys: (estimate >> 8, clamped to 26 bits) << 6 | list index
-				uint32_t key[2];
+				uint32_t key[NK];
 #pragma unroll
-				for (uint32_t m = 0; m < 2u; ++m) {
-					const uint32_t k = hl + gsz*m;
+				for (uint32_t m = 0; m < NK; ++m) {
+					const uint32_t k = t + (m << sub_sh);
 					key[m] = 0xFFFFFFFFu;
-					if (k < ncfg && k < 64u) {
+					if (k < ncfg) {
 						const AstcCfgRec c = list[k];
 						const unsigned long long wn = (unsigned long long)S.edec[c.grid]*40ull + (unsigned long long)(n*c.wq16);
 						const unsigned long long est = (((span2*wn) >> 12) + (unsigned long long)(n*nc)*c.cq16) >> 8;
@@ -1164,14 +1172,25 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					}
 				}
 				for (uint32_t it = 0; it < K; ++it) {
-					const uint32_t mk = key[0] < key[1] ? key[0] : key[1];
-					const uint32_t gmin = cf_group_min_u32(mk, pair, h);
-					key[0] = key[0] == gmin ? 0xFFFFFFFFu : key[0];
-					key[1] = key[1] == gmin ? 0xFFFFFFFFu : key[1];
-					if (hl == 0u && jact)
+					uint32_t mk = key[0];
+#pragma unroll
+					for (uint32_t m = 1; m < NK; ++m)
+						mk = key[m] < mk ? key[m] : mk;
+					uint32_t gmin = mk;
+					{ const uint32_t o = cf_xor1(gmin); gmin = o < gmin ? o : gmin; }
+					{ const uint32_t o = cf_xor2(gmin); gmin = o < gmin ? o : gmin; }
+					if (SUB == 8u) { const uint32_t o = cf_dpp<0x141>(gmin); gmin = o < gmin ? o : gmin; }     // row_half_mirror: the other quad of the 8
+#pragma unroll
+					for (uint32_t m = 0; m < NK; ++m)
+						key[m] = key[m] == gmin ? 0xFFFFFFFFu : key[m];
+					if (t == 0u && jact)
 						S.order[j*8u + it] = gmin == 0xFFFFFFFFu ? (uint8_t)255 : (uint8_t)(gmin & 63u);
 				}
-			}
+			};
+			if (pair)
+				rank_pass(std::integral_constant<uint32_t, 16u>{});
+			else
+				rank_pass(std::integral_constant<uint32_t, 8u>{});
 			__builtin_amdgcn_wave_barrier();
 
 			PROF_MARK(5)   // ranking
