@@ -1113,28 +1113,47 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			PROF_MARK(3)   // phase A
 			// ---- lane = weight grid: decimation error of candidate 0's ideal weights (pass 0) ----
 			if (pass == 0u) {
-				const uint32_t g = hl;
-				if (!(CF_ASTC_ABLATE & 4) && !solid && g < ngrids) {
-					const uint32_t Rp = (uint32_t)sh.grid[g*4u + 1u]*(uint32_t)sh.grid[g*4u + 3u], PW = (Rp + 1u) >> 1;
-					const uint2* inf = sh.infill + g*n;
-					const uint8_t* Trow = S.T;
-					for (uint32_t k = 0; k <= PW; ++k)
-						*reinterpret_cast<uint32_t*>(colbase + k*256u) = 0u;
+				// a wave that holds one block has 64 lanes for at most 24 grids: lanes g and g + 32 share
+				// grid g -- each decimates every other texel into lane g's column (the scatter is atomic) and
+				// takes every other texel of the error walk; lane g alone turns the sums into averages
+				const uint32_t g = hl & 31u, half = pair ? 0u : hl >> 5, step = pair ? 1u : 2u;
+				const bool gact = !(CF_ASTC_ABLATE & 4) && !solid && g < ngrids && hl < 32u + (pair ? 0u : 32u);
+				uint8_t* gcol = wbase + (pair ? lane : g)*4u;
+				uint32_t PW = 0;
+				const uint2* inf = sh.infill + g*n;
+				const uint8_t* Trow = S.T;
+				if (gact) {
+					const uint32_t Rp = (uint32_t)sh.grid[g*4u + 1u]*(uint32_t)sh.grid[g*4u + 3u];
+					PW = (Rp + 1u) >> 1;
+					if (half == 0u)
+						for (uint32_t k = 0; k <= PW; ++k)
+							*reinterpret_cast<uint32_t*>(gcol + k*256u) = 0u;
+				}
+				__builtin_amdgcn_wave_barrier();
+				if (gact) {
 #pragma unroll 2
-					for (uint32_t i = 0; i < n; ++i) {
+					for (uint32_t i = half; i < n; i += step) {
 						const uint2 rec = inf[i];
-						decim_add(colbase, rec.x, rec.y, Trow[i]);
+						decim_add(gcol, rec.x, rec.y, Trow[i]);
 					}
-					normalise_rows<false>(colbase, sh.den + g*den_stride, PW, nullptr);
-					uint32_t e = 0;
+				}
+				__builtin_amdgcn_wave_barrier();
+				if (gact && half == 0u)
+					normalise_rows<false>(gcol, sh.den + g*den_stride, PW, nullptr);
+				__builtin_amdgcn_wave_barrier();
+				uint32_t e = 0;
+				if (gact) {
 #pragma unroll 2
-					for (uint32_t i = 0; i < n; ++i) {
+					for (uint32_t i = half; i < n; i += step) {
 						const uint2 rec = inf[i];
-						const int dgt = (int)infill_w(colbase, rec.x, rec.y) - (int)Trow[i];
+						const int dgt = (int)infill_w(gcol, rec.x, rec.y) - (int)Trow[i];
 						e += (uint32_t)(dgt*dgt);
 					}
-					S.edec[g] = e;
 				}
+				if (!pair)
+					e += (uint32_t)__shfl_xor((int)e, 32, 64);
+				if (gact && half == 0u)
+					S.edec[g] = e;
 				__builtin_amdgcn_wave_barrier();
 			}
 
@@ -1453,19 +1472,25 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 #pragma unroll
 						for (int k = 0; k < 5; ++k)
 							S.best[4 + k] = r_cv[k];
-						// quantised weights in stream order (grid point by grid point, planes interleaved): the
-						// column holds unquantised values at the even row pitch; an exact value is its own
-						// nearest neighbour, so wnear gives the index back
-						const uint32_t Ng = cfg.N, Npg = sh.grid[(uint32_t)cfg.grid*4u + 3u], ngp = cfg.ng;
+						// where the group finds this lane's weight column and how to walk it
+						S.best[2] = lane | (wq << 8) | (dual << 16) | (PW << 24);
+						S.best[3] = (uint32_t)cfg.N | ((uint32_t)sh.grid[(uint32_t)cfg.grid*4u + 3u] << 8) | ((uint32_t)cfg.ng << 16);
+					}
+					__builtin_amdgcn_wave_barrier();
+					// quantised weights in stream order (grid point by grid point, planes interleaved), one
+					// weight per lane of the group: the winner's column holds unquantised values at the even
+					// row pitch; an exact value is its own nearest neighbour, so wnear gives the index back
+					{
+						const uint32_t w2 = S.best[2], w3 = S.best[3];
+						const uint32_t wl = w2 & 255u, wqw = (w2 >> 8) & 255u, dualw = (w2 >> 16) & 1u, PWw = w2 >> 24;
+						const uint32_t Ng = w3 & 255u, Npg = (w3 >> 8) & 255u, nww = (w3 >> 16) << dualw;
+						const uint8_t* wcol = wbase + wl*4u;
 						uint8_t* wdst = reinterpret_cast<uint8_t*>(S.best + 12);
-						uint32_t gx = 0, rr = 0;
-						for (uint32_t g = 0; g < ngp; ++g) {
-							const uint32_t so = (rr >> 1)*256u + (rr & 1u)*2u;
-							wdst[g*planes] = sh.wnear[wq*68u + colbase[so]];
-							if (dual)
-								wdst[g*planes + 1u] = sh.wnear[wq*68u + colp1[so]];
-							++gx; ++rr;
-							if (gx == Ng) { gx = 0; rr += Npg - Ng; }
+						const float rN = 1.0f/(float)Ng;
+						for (uint32_t wi = hl; wi < nww; wi += gsz) {
+							const uint32_t g = wi >> dualw, pl = wi & dualw;
+							const uint32_t gy = div_small(g, Ng, rN), rr = gy*Npg + (g - gy*Ng);
+							wdst[wi] = sh.wnear[wqw*68u + wcol[pl*PWw*256u + (rr >> 1)*256u + (rr & 1u)*2u]];
 						}
 					}
 				}
