@@ -250,10 +250,6 @@ __device__ __forceinline__ int quant_c(const Shared& sh, uint32_t lv, float x, u
 	return (int)sh.cunq[lv*256u + stored];
 }
 
-// One endpoint-mode option of one partition: estimate, and (when `emit`) the decoded endpoint
-// bytes and the stored ISE values.  o: 0 direct (CEM 8/12), 1 base+scale (6/10), 2 luminance (0/4).
-// r0 / r1: least-squares endpoints (alpha = 255 for blocks without alpha); A/B/C per channel.
-// Returns false when the option cannot represent the pair (direct with neither order valid).
 // constant-colour block: UNORM16 (LDR) or, with bit 9 of the header set, four halves (HDR profile)
 __device__ __forceinline__ uint4 void_extent(uint32_t r, uint32_t g, uint32_t b, uint32_t a, uint32_t hdrf);
 
@@ -299,105 +295,136 @@ __device__ __forceinline__ uint4 void_extent(uint32_t r, uint32_t g, uint32_t b,
 		lns_code_to_half(b) | (ha << 16));
 }
 
-__device__ __forceinline__ bool cem_option(const Shared& sh, int o, uint32_t lv, bool has_alpha, uint32_t hdr,
-	const float (&r0)[4], const float (&r1)[4], const float (&fA)[4], const float (&fB)[4],
-	const float (&fC)[4], const uint32_t (&cw)[4], float& est, uint32_t& d0p, uint32_t& d1p,
-	uint32_t (&vals)[8])
+// The least-squares system of one partition as cem_option needs it: the pair (r0, r1) per channel and
+// the quadratic form (A, B, C) of the set the channel fits with -- X for every channel, Y for channel
+// `ych` of a dual-plane candidate (ych = 4: no such channel).
+struct CemIn {
+	float r0[4], r1[4];
+	float XA, XB, XC, YA, YB, YC;
+	uint32_t ych;
+};
+
+__device__ __forceinline__ float cem_q(const CemIn& in, uint32_t c, float d0, float d1)
 {
-	int d0[4], d1[4];
-	d0[3] = 255; d1[3] = 255;
-	uint32_t s;
+	const bool y = c == in.ych;
+	return quad_est(y ? in.YA : in.XA, y ? in.YB : in.XB, y ? in.YC : in.XC, d0 - in.r0[c], d1 - in.r1[c]);
+}
+
+// One endpoint-mode option of one partition: adds its quadratic error estimate to `est` and returns
+// the decoded endpoint bytes (d0p, d1p) and the stored ISE values (byte k of vlo | vhi << 32 = value k).
+// o: 0 direct (CEM 8/12; HDR: 11/14/15), 1 base+scale (6/10), 2 luminance (0/4), 3 base+offset (9/13).
+// r0 / r1: least-squares endpoints (alpha = 255 for blocks without alpha).  Returns false when the
+// option cannot represent the pair (direct with neither order valid, offsets out of range).
+// Written channel by channel with packed outputs: the array form of this function (every channel's
+// quantised values, stored indices and contracted alternatives alive at once) was what pushed the
+// kernel past its register budget.  The float operations and their order are those of the oracle.
+__device__ __forceinline__ bool cem_option(const Shared& sh, int o, uint32_t lv, bool has_alpha, uint32_t hdr,
+	const CemIn& in, const uint32_t (&cw)[4], float& est, uint32_t& d0p, uint32_t& d1p, uint32_t& vlo, uint32_t& vhi)
+{
+	uint32_t s0, s1;
+	d0p = 0xFF000000u; d1p = 0xFF000000u; vlo = 0; vhi = 0;
 	if (o == 0 && hdr) {
 		// HDR direct sub-mode (CEM 11 / 14 / 15, major component 3): v0..v3 = the 8-bit red and green
 		// endpoints, v4, v5 = 0x80 | 7 bits of blue; no ordering rule, no blue contraction (uniform
 		// per launch: `hdr` comes from the launch flags)
 #pragma unroll
-		for (int c = 0; c < 3; ++c) {
-			uint32_t s0, s1;
-			if (c < 2) {
-				d0[c] = quant_c(sh, lv, r0[c], s0);
-				d1[c] = quant_c(sh, lv, r1[c], s1);
+		for (uint32_t c = 0; c < 3u; ++c) {
+			int e0, e1;
+			if (c < 2u) {
+				e0 = quant_c(sh, lv, in.r0[c], s0);
+				e1 = quant_c(sh, lv, in.r1[c], s1);
 			} else {
-				d0[c] = quant_hi(sh, lv, r0[c], s0);
-				d1[c] = quant_hi(sh, lv, r1[c], s1);
+				e0 = quant_hi(sh, lv, in.r0[c], s0);
+				e1 = quant_hi(sh, lv, in.r1[c], s1);
 			}
-			vals[2*c] = s0; vals[2*c + 1] = s1;
-			est = fmaf((float)cw[c], quad_est(fA[c], fB[c], fC[c], (float)d0[c] - r0[c], (float)d1[c] - r1[c]), est);
+			d0p |= (uint32_t)e0 << (8u*c); d1p |= (uint32_t)e1 << (8u*c);
+			if (c < 2u) vlo |= (s0 | (s1 << 8)) << (16u*c);
+			else vhi |= s0 | (s1 << 8);
+			est = fmaf((float)cw[c], cem_q(in, c, (float)e0, (float)e1), est);
 		}
 		if (has_alpha) {
-			uint32_t s6, s7;
+			int e0, e1;
 			if (hdr & 2u) {
-				d0[3] = quant_hi(sh, lv, r0[3], s6);
-				d1[3] = quant_hi(sh, lv, r1[3], s7);
+				e0 = quant_hi(sh, lv, in.r0[3], s0);
+				e1 = quant_hi(sh, lv, in.r1[3], s1);
 			} else {
-				d0[3] = quant_c(sh, lv, r0[3], s6);
-				d1[3] = quant_c(sh, lv, r1[3], s7);
+				e0 = quant_c(sh, lv, in.r0[3], s0);
+				e1 = quant_c(sh, lv, in.r1[3], s1);
 			}
-			vals[6] = s6; vals[7] = s7;
-			est = fmaf((float)cw[3], quad_est(fA[3], fB[3], fC[3], (float)d0[3] - r0[3], (float)d1[3] - r1[3]), est);
+			d0p = (d0p & 0x00FFFFFFu) | ((uint32_t)e0 << 24); d1p = (d1p & 0x00FFFFFFu) | ((uint32_t)e1 << 24);
+			vhi |= (s0 | (s1 << 8)) << 16;
+			est = fmaf((float)cw[3], cem_q(in, 3u, (float)e0, (float)e1), est);
 		}
 	} else if (o == 0) {
-		int dd0[3], dd1[3], sd0 = 0, sd1 = 0;
-		uint32_t st[6];
-#pragma unroll
-		for (int c = 0; c < 3; ++c) {
-			dd0[c] = quant_c(sh, lv, r0[c], st[2*c]);
-			dd1[c] = quant_c(sh, lv, r1[c], st[2*c + 1]);
-			sd0 += dd0[c]; sd1 += dd1[c];
+		// plain order
+		uint32_t pd0 = 0, pd1 = 0, vdl = 0, vdh = 0;
+		int sd0 = 0, sd1 = 0;
+		float t0, t1, t2;
+		{
+			const int a0 = quant_c(sh, lv, in.r0[0], s0), a1 = quant_c(sh, lv, in.r1[0], s1);
+			sd0 += a0; sd1 += a1; pd0 |= (uint32_t)a0; pd1 |= (uint32_t)a1; vdl |= s0 | (s1 << 8);
+			t0 = cem_q(in, 0u, (float)a0, (float)a1);
+		}
+		{
+			const int a0 = quant_c(sh, lv, in.r0[1], s0), a1 = quant_c(sh, lv, in.r1[1], s1);
+			sd0 += a0; sd1 += a1; pd0 |= (uint32_t)a0 << 8; pd1 |= (uint32_t)a1 << 8; vdl |= (s0 | (s1 << 8)) << 16;
+			t1 = cem_q(in, 1u, (float)a0, (float)a1);
+		}
+		{
+			const int a0 = quant_c(sh, lv, in.r0[2], s0), a1 = quant_c(sh, lv, in.r1[2], s1);
+			sd0 += a0; sd1 += a1; pd0 |= (uint32_t)a0 << 16; pd1 |= (uint32_t)a1 << 16; vdh |= s0 | (s1 << 8);
+			t2 = cem_q(in, 2u, (float)a0, (float)a1);
 		}
 		float ed = 3.0e38f, ec = 3.0e38f;
 		if (sd1 >= sd0) {
 			ed = 0.0f;
-#pragma unroll
-			for (int c = 0; c < 3; ++c)
-				ed = fmaf((float)cw[c], quad_est(fA[c], fB[c], fC[c], (float)dd0[c] - r0[c], (float)dd1[c] - r1[c]), ed);
+			ed = fmaf((float)cw[0], t0, ed);
+			ed = fmaf((float)cw[1], t1, ed);
+			ed = fmaf((float)cw[2], t2, ed);
 		}
-		const float i0[3] = {fmaf(2.0f, r0[0], -r0[2]), fmaf(2.0f, r0[1], -r0[2]), r0[2]};
-		const float i1[3] = {fmaf(2.0f, r1[0], -r1[2]), fmaf(2.0f, r1[1], -r1[2]), r1[2]};
-		bool cok = true;
-#pragma unroll
-		for (int c = 0; c < 3; ++c)
-			cok = cok && i0[c] >= 0.0f && i0[c] <= 255.0f && i1[c] >= 0.0f && i1[c] <= 255.0f;
-		uint32_t sc[6] = {0, 0, 0, 0, 0, 0};
-		int c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
-		if (cok) {
-			int u0[3], u1[3], sc0 = 0, sc1 = 0;
-#pragma unroll
-			for (int c = 0; c < 3; ++c) {
-				u0[c] = quant_c(sh, lv, i0[c], sc[2*c + 1]);
-				u1[c] = quant_c(sh, lv, i1[c], sc[2*c]);
-				sc1 += u0[c]; sc0 += u1[c];
-			}
-			if (sc1 < sc0) {
-				c0[0] = (u0[0] + u0[2]) >> 1; c0[1] = (u0[1] + u0[2]) >> 1; c0[2] = u0[2];
-				c1[0] = (u1[0] + u1[2]) >> 1; c1[1] = (u1[1] + u1[2]) >> 1; c1[2] = u1[2];
-				ec = 0.0f;
-#pragma unroll
-				for (int c = 0; c < 3; ++c)
-					ec = fmaf((float)cw[c], quad_est(fA[c], fB[c], fC[c], (float)c0[c] - r0[c], (float)c1[c] - r1[c]), ec);
+		// blue contraction: stored = (2r - b, 2g - b, b), endpoints swapped (endpoint 0 sits in the odd values)
+		uint32_t pc0 = 0, pc1 = 0, vcl = 0, vch = 0;
+		{
+			const float i0r = fmaf(2.0f, in.r0[0], -in.r0[2]), i0g = fmaf(2.0f, in.r0[1], -in.r0[2]), i0b = in.r0[2];
+			const float i1r = fmaf(2.0f, in.r1[0], -in.r1[2]), i1g = fmaf(2.0f, in.r1[1], -in.r1[2]), i1b = in.r1[2];
+			const bool cok = i0r >= 0.0f && i0r <= 255.0f && i1r >= 0.0f && i1r <= 255.0f &&
+				i0g >= 0.0f && i0g <= 255.0f && i1g >= 0.0f && i1g <= 255.0f &&
+				i0b >= 0.0f && i0b <= 255.0f && i1b >= 0.0f && i1b <= 255.0f;
+			if (cok) {
+				uint32_t sa, sb;
+				const int u0b = quant_c(sh, lv, i0b, sa), u1b = quant_c(sh, lv, i1b, sb);
+				vch = sb | (sa << 8);
+				int sc1 = u0b, sc0 = u1b;
+				const int u0r = quant_c(sh, lv, i0r, sa), u1r = quant_c(sh, lv, i1r, sb);
+				vcl = sb | (sa << 8);
+				sc1 += u0r; sc0 += u1r;
+				const int u0g = quant_c(sh, lv, i0g, sa), u1g = quant_c(sh, lv, i1g, sb);
+				vcl |= (sb | (sa << 8)) << 16;
+				sc1 += u0g; sc0 += u1g;
+				if (sc1 < sc0) {
+					const int c0r = (u0r + u0b) >> 1, c0g = (u0g + u0b) >> 1, c1r = (u1r + u1b) >> 1, c1g = (u1g + u1b) >> 1;
+					pc0 = (uint32_t)c0r | ((uint32_t)c0g << 8) | ((uint32_t)u0b << 16);
+					pc1 = (uint32_t)c1r | ((uint32_t)c1g << 8) | ((uint32_t)u1b << 16);
+					ec = 0.0f;
+					ec = fmaf((float)cw[0], cem_q(in, 0u, (float)c0r, (float)c1r), ec);
+					ec = fmaf((float)cw[1], cem_q(in, 1u, (float)c0g, (float)c1g), ec);
+					ec = fmaf((float)cw[2], cem_q(in, 2u, (float)u0b, (float)u1b), ec);
+				}
 			}
 		}
 		if (ed >= 3.0e38f && ec >= 3.0e38f)
 			return false;
 		const bool contract = ec < ed;
-		const uint32_t cm = contract ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-		for (int c = 0; c < 3; ++c) {
-			// (mask arithmetic, not selects: a select between elements of two local arrays ends up
-			// as an indexed access in scratch)
-			d0[c] = dd0[c] ^ ((dd0[c] ^ c0[c]) & (int)cm);
-			d1[c] = dd1[c] ^ ((dd1[c] ^ c1[c]) & (int)cm);
-			vals[2*c] = st[2*c] ^ ((st[2*c] ^ sc[2*c]) & cm);
-			vals[2*c + 1] = st[2*c + 1] ^ ((st[2*c + 1] ^ sc[2*c + 1]) & cm);
-		}
+		d0p = contract ? pc0 : pd0; d1p = contract ? pc1 : pd1;
+		vlo = contract ? vcl : vdl; vhi = contract ? vch : vdh;
 		est += contract ? ec : ed;
 		if (has_alpha) {
-			uint32_t s6, s7;
-			d0[3] = quant_c(sh, lv, r0[3], s6);
-			d1[3] = quant_c(sh, lv, r1[3], s7);
-			vals[6] = contract ? s7 : s6;
-			vals[7] = contract ? s6 : s7;
-			est = fmaf((float)cw[3], quad_est(fA[3], fB[3], fC[3], (float)d0[3] - r0[3], (float)d1[3] - r1[3]), est);
+			const int a0 = quant_c(sh, lv, in.r0[3], s0), a1 = quant_c(sh, lv, in.r1[3], s1);
+			d0p |= (uint32_t)a0 << 24; d1p |= (uint32_t)a1 << 24;
+			vhi |= (contract ? (s1 | (s0 << 8)) : (s0 | (s1 << 8))) << 16;
+			est = fmaf((float)cw[3], cem_q(in, 3u, (float)a0, (float)a1), est);
+		} else {
+			d0p |= 0xFF000000u; d1p |= 0xFF000000u;
 		}
 	} else if (o == 3) {
 		// base + offset (CEM 9 / 13; oracle: base_offset): v_even = the base's low 7 bits (its own LSB is
@@ -406,10 +433,11 @@ __device__ __forceinline__ bool cem_option(const Shared& sh, int o, uint32_t lv,
 		// makes the decoder swap and blue-contract the pair)
 		int offsum = 0;
 		bool ok = true;
+		d0p = 0; d1p = 0;
 #pragma unroll
-		for (int c = 0; c < 4; ++c) {
-			if (c < 3 || has_alpha) {
-				const int B = (int)floorf(clampf255(r0[c]) + 0.5f), E = (int)floorf(clampf255(r1[c]) + 0.5f);
+		for (uint32_t c = 0; c < 4u; ++c) {
+			if (c < 3u || has_alpha) {
+				const int B = (int)floorf(clampf255(in.r0[c]) + 0.5f), E = (int)floorf(clampf255(in.r1[c]) + 0.5f);
 				const uint32_t t0 = (uint32_t)(B & 0x7F) << 1;
 				const uint32_t qa = sh.cnear[lv*256u + t0], qb = sh.cnear[lv*256u + (t0 | 1u)];
 				const int ua = (int)sh.cunq[lv*256u + qa], ub_ = (int)sh.cunq[lv*256u + qb];
@@ -430,60 +458,61 @@ __device__ __forceinline__ bool cem_option(const Shared& sh, int o, uint32_t lv,
 				const bool pick_d = ed < ec;
 				ok = ok && (vc || vd);
 				const int a = pick_d ? ad : ac;
-				vals[2*c] = q0;
-				vals[2*c + 1] = pick_d ? qd : qc;
-				d0[c] = base;
+				const uint32_t pairv = q0 | ((pick_d ? qd : qc) << 8);
+				if (c < 2u) vlo |= pairv << (16u*c);
+				else vhi |= pairv << (16u*(c - 2u));
 				const int e1v = base + a;
-				d1[c] = e1v < 0 ? 0 : (e1v > 255 ? 255 : e1v);
-				if (c < 3) offsum += a;
-				est = fmaf((float)cw[c], quad_est(fA[c], fB[c], fC[c], (float)d0[c] - r0[c], (float)d1[c] - r1[c]), est);
+				const int e1c = e1v < 0 ? 0 : (e1v > 255 ? 255 : e1v);
+				d0p |= (uint32_t)base << (8u*c); d1p |= (uint32_t)e1c << (8u*c);
+				if (c < 3u) offsum += a;
+				est = fmaf((float)cw[c], cem_q(in, c, (float)base, (float)e1c), est);
 			}
 		}
+		if (!has_alpha) { d0p |= 0xFF000000u; d1p |= 0xFF000000u; }
 		if (!ok || offsum < 0)
 			return false;
 	} else if (o == 1) {
+		// base + scale: e1 = (v0, v1, v2), e0 = e1 * v3 >> 8
 		float num = 0.0f, dn = 0.0f;
-#pragma unroll
-		for (int c = 0; c < 3; ++c) {
-			d1[c] = quant_c(sh, lv, r1[c], s);
-			vals[c] = s;
-			num = fmaf(r0[c], (float)d1[c], num);
-			dn = fmaf((float)d1[c], (float)d1[c], dn);
-		}
+		const int b0 = quant_c(sh, lv, in.r1[0], s0); vlo |= s0;
+		num = fmaf(in.r0[0], (float)b0, num); dn = fmaf((float)b0, (float)b0, dn);
+		const int b1 = quant_c(sh, lv, in.r1[1], s0); vlo |= s0 << 8;
+		num = fmaf(in.r0[1], (float)b1, num); dn = fmaf((float)b1, (float)b1, dn);
+		const int b2 = quant_c(sh, lv, in.r1[2], s0); vlo |= s0 << 16;
+		num = fmaf(in.r0[2], (float)b2, num); dn = fmaf((float)b2, (float)b2, dn);
 		const float sf = dn > 0.0f ? num*(256.0f/dn) : 0.0f;
-		const int sq = quant_c(sh, lv, sf, s);
-		vals[3] = s;
-#pragma unroll
-		for (int c = 0; c < 3; ++c) {
-			d0[c] = (d1[c]*sq) >> 8;
-			est = fmaf((float)cw[c], quad_est(fA[c], fB[c], fC[c], (float)d0[c] - r0[c], (float)d1[c] - r1[c]), est);
-		}
+		const int sq = quant_c(sh, lv, sf, s0); vlo |= s0 << 24;
+		const int a0 = (b0*sq) >> 8, a1 = (b1*sq) >> 8, a2 = (b2*sq) >> 8;
+		est = fmaf((float)cw[0], cem_q(in, 0u, (float)a0, (float)b0), est);
+		est = fmaf((float)cw[1], cem_q(in, 1u, (float)a1, (float)b1), est);
+		est = fmaf((float)cw[2], cem_q(in, 2u, (float)a2, (float)b2), est);
+		d0p = (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)a2 << 16);
+		d1p = (uint32_t)b0 | ((uint32_t)b1 << 8) | ((uint32_t)b2 << 16);
 		if (has_alpha) {
-			uint32_t s4, s5;
-			d0[3] = quant_c(sh, lv, r0[3], s4);
-			d1[3] = quant_c(sh, lv, r1[3], s5);
-			vals[4] = s4; vals[5] = s5;
-			est = fmaf((float)cw[3], quad_est(fA[3], fB[3], fC[3], (float)d0[3] - r0[3], (float)d1[3] - r1[3]), est);
+			const int e0 = quant_c(sh, lv, in.r0[3], s0), e1 = quant_c(sh, lv, in.r1[3], s1);
+			vhi |= s0 | (s1 << 8);
+			d0p |= (uint32_t)e0 << 24; d1p |= (uint32_t)e1 << 24;
+			est = fmaf((float)cw[3], cem_q(in, 3u, (float)e0, (float)e1), est);
+		} else {
+			d0p |= 0xFF000000u; d1p |= 0xFF000000u;
 		}
 	} else {
-		uint32_t s0, s1;
-		const int l0 = quant_c(sh, lv, r0[0], s0), l1 = quant_c(sh, lv, r1[0], s1);
-		vals[0] = s0; vals[1] = s1;
-#pragma unroll
-		for (int c = 0; c < 3; ++c) {
-			d0[c] = l0; d1[c] = l1;
-			est = fmaf((float)cw[c], quad_est(fA[c], fB[c], fC[c], (float)l0 - r0[c], (float)l1 - r1[c]), est);
-		}
+		// luminance (grey blocks: r = g = b)
+		const int l0 = quant_c(sh, lv, in.r0[0], s0), l1 = quant_c(sh, lv, in.r1[0], s1);
+		vlo |= s0 | (s1 << 8);
+		est = fmaf((float)cw[0], cem_q(in, 0u, (float)l0, (float)l1), est);
+		est = fmaf((float)cw[1], cem_q(in, 1u, (float)l0, (float)l1), est);
+		est = fmaf((float)cw[2], cem_q(in, 2u, (float)l0, (float)l1), est);
+		d0p = (uint32_t)l0*0x010101u; d1p = (uint32_t)l1*0x010101u;
 		if (has_alpha) {
-			uint32_t s2, s3;
-			d0[3] = quant_c(sh, lv, r0[3], s2);
-			d1[3] = quant_c(sh, lv, r1[3], s3);
-			vals[2] = s2; vals[3] = s3;
-			est = fmaf((float)cw[3], quad_est(fA[3], fB[3], fC[3], (float)d0[3] - r0[3], (float)d1[3] - r1[3]), est);
+			const int e0 = quant_c(sh, lv, in.r0[3], s0), e1 = quant_c(sh, lv, in.r1[3], s1);
+			vlo |= (s0 | (s1 << 8)) << 16;
+			d0p |= (uint32_t)e0 << 24; d1p |= (uint32_t)e1 << 24;
+			est = fmaf((float)cw[3], cem_q(in, 3u, (float)e0, (float)e1), est);
+		} else {
+			d0p |= 0xFF000000u; d1p |= 0xFF000000u;
 		}
 	}
-	d0p = (uint32_t)d0[0] | ((uint32_t)d0[1] << 8) | ((uint32_t)d0[2] << 16) | ((uint32_t)d0[3] << 24);
-	d1p = (uint32_t)d1[0] | ((uint32_t)d1[1] << 8) | ((uint32_t)d1[2] << 16) | ((uint32_t)d1[3] << 24);
 	return true;
 }
 
@@ -1258,8 +1287,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					// B = sum (64-w) w = 64 S - C and U_c = sum (64-w) p_c = 64 sum p_c - V_c (exact integers)
 					// (named scalars per set, not arrays: selecting among array elements by a run-time set
 					// index makes the compiler keep the arrays in scratch)
-					struct SetAcc { uint32_t S, C, V0, V1, V2, V3, cn, p01, p23; };
-					SetAcc q0 = {0, 0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;
+					struct SetAcc { uint32_t S, C, V0, V1, V2, V3; };
+					SetAcc q0 = {0, 0, 0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;
 					// a texel's membership mask over the sets (bit ST): its subset, or both planes; sets 2 and 3
 					// are walked only when some lane of the wave has them (a scalar branch, not per-lane
 					// predication -- the wave executes the instructions either way)
@@ -1281,47 +1310,48 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						if (any4) ASTC_ACC(q3, 3u, wA)
 #undef ASTC_ACC
 					}
-					// texel count and channel sums of every set: the subset's slot, or (dual) the whole
-					// block = the OR of the two planes' masked sums
-#define ASTC_SETSUM(Q, ST) { \
-						const uint32_t sl = (j*4u + (dual ? 0u : ST)) & 31u; \
-						Q.cn = ST < nset ? S.scnt[sl] : 0u; \
-						Q.p01 = S.sum01[sl]; Q.p23 = S.sum23[sl]; \
-						if (dual) { Q.p01 |= S.sum01[(sl + 1u) & 31u]; Q.p23 |= S.sum23[(sl + 1u) & 31u]; } }
-					ASTC_SETSUM(q0, 0u) ASTC_SETSUM(q1, 1u) ASTC_SETSUM(q2, 2u) ASTC_SETSUM(q3, 3u)
-#undef ASTC_SETSUM
 #define SEL4(i, a0, a1, a2, a3) ((i) == 0u ? (a0) : ((i) == 1u ? (a1) : ((i) == 2u ? (a2) : (a3))))
 					// least-squares endpoints of partition p, one partition at a time (nothing but the
 					// sums stays live across partitions): channel c fits with set st = p, or its plane
-					auto solve = [&](uint32_t p, float (&r0)[4], float (&r1)[4], float (&cA)[4], float (&cB)[4], float (&cC)[4]) __attribute__((always_inline)) {
+					auto solve = [&](uint32_t p, CemIn& in) __attribute__((always_inline)) {
+						in.ych = dual ? ccs : 4u;
+						in.YA = in.YB = in.YC = 0.0f;
+						// texel count and channel sums of the partition (phase A left them in the block slot): the
+						// subset's slot, or (dual) the whole block = the OR of the two planes' masked sums
+						const uint32_t slx = (j*4u + (dual ? 0u : p)) & 31u;
+						const uint32_t cnt_s = S.scnt[slx];
+						uint32_t p01 = S.sum01[slx], p23 = S.sum23[slx];
+						if (dual) { p01 |= S.sum01[(slx + 1u) & 31u]; p23 |= S.sum23[(slx + 1u) & 31u]; }
 #pragma unroll
 						for (uint32_t c = 0; c < 4u; ++c) {
 							const uint32_t st = dual ? (c == ccs ? 1u : 0u) : p;
 							const uint32_t Ss = SEL4(st, q0.S, q1.S, q2.S, q3.S), Cs = SEL4(st, q0.C, q1.C, q2.C, q3.C);
 							const uint32_t Vc = c == 0u ? SEL4(st, q0.V0, q1.V0, q2.V0, q3.V0) : (c == 1u ? SEL4(st, q0.V1, q1.V1, q2.V1, q3.V1) :
 								(c == 2u ? SEL4(st, q0.V2, q1.V2, q2.V2, q3.V2) : SEL4(st, q0.V3, q1.V3, q2.V3, q3.V3)));
-							const uint32_t cnt_s = SEL4(st, q0.cn, q1.cn, q2.cn, q3.cn);
-							const uint32_t ps = c < 2u ? SEL4(st, q0.p01, q1.p01, q2.p01, q3.p01) : SEL4(st, q0.p23, q1.p23, q2.p23, q3.p23);
+							const uint32_t ps = c < 2u ? p01 : p23;
 							const uint32_t sumP = (c & 1u) ? ps >> 16 : ps & 0xFFFFu;
 							const uint32_t Aq = 4096u*cnt_s - 128u*Ss + Cs, Bq = 64u*Ss - Cs, Uq = 64u*sumP - Vc;
 							const int det = (int)(cnt_s*Cs) - (int)(Ss*Ss);
-							cA[c] = (float)Aq; cB[c] = (float)Bq; cC[c] = (float)Cs;
+							const float fAq = (float)Aq, fBq = (float)Bq, fCq = (float)Cs;
+							// the form is the set's: the same for every channel of X, and Y's for channel ych
+							if (c == in.ych) { in.YA = fAq; in.YB = fBq; in.YC = fCq; }
+							else { in.XA = fAq; in.XB = fBq; in.XC = fCq; }
 							// ideal endpoints of phase A: subset p (dual: planes 0 and 1 of subset 0)
 							const uint32_t slot_i = (j*4u + (dual ? (c == ccs ? 1u : 0u) : p)) & 31u;
 							float a = (float)((S.e0[slot_i] >> (8u*c)) & 255u), bq = (float)((S.e1[slot_i] >> (8u*c)) & 255u);
 							if (det > 0) {
 								const float inv = 1.0f/(64.0f*(float)det);
 								const float fU = (float)Uq, fV = (float)Vc;
-								const float t0 = cB[c]*fV;
-								const float n0 = fmaf(cC[c], fU, -t0);
-								const float t1 = cB[c]*fU;
-								const float n1 = fmaf(cA[c], fV, -t1);
+								const float t0 = fBq*fV;
+								const float n0 = fmaf(fCq, fU, -t0);
+								const float t1 = fBq*fU;
+								const float n1 = fmaf(fAq, fV, -t1);
 								a = clampf255(n0*inv);
 								bq = clampf255(n1*inv);
 							}
 							if (c == 3u && nc == 3u) { a = 255.0f; bq = 255.0f; }
-							r0[c] = a;
-							r1[c] = bq;
+							in.r0[c] = a;
+							in.r1[c] = bq;
 						}
 					};
 					PROF_MARK(7)   // B: texel weights + sums
@@ -1341,13 +1371,13 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					}
 #pragma unroll 1
 					for (uint32_t p = 0; p < ((CF_ASTC_ABLATE & 128) ? 0u : P); ++p) {
-						float r0[4], r1[4], cA[4], cB[4], cC[4];
-						solve(p, r0, r1, cA, cB, cC);
-						uint32_t d0p, d1p, vals[8];
+						CemIn in;
+						solve(p, in);
+						uint32_t d0p, d1p, vlo, vhi;
 #pragma unroll
 						for (int o = 0; o < 4; ++o)
 							if (okk[o])
-								okk[o] = cem_option(sh, o, (uint32_t)lvs[o], has_alpha, hdrf, r0, r1, cA, cB, cC, cw, est[o], d0p, d1p, vals);
+								okk[o] = cem_option(sh, o, (uint32_t)lvs[o], has_alpha, hdrf, in, cw, est[o], d0p, d1p, vlo, vhi);
 					}
 					float best_est = 3.0e38f;
 					int best_opt = -1;
@@ -1361,25 +1391,26 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						const uint32_t nv = (has_alpha ? 8u : 6u) - (best_opt == 3 ? 0u : 2u*(uint32_t)best_opt);
 #pragma unroll 1
 						for (uint32_t p = 0; p < P; ++p) {
-							float r0[4], r1[4], cA[4], cB[4], cC[4];
-							solve(p, r0, r1, cA, cB, cC);
+							CemIn in;
+							solve(p, in);
 							float e_ = 0.0f;
-							uint32_t d0p = 0, d1p = 0, vals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-							cem_option(sh, best_opt, best_lv, has_alpha, hdrf, r0, r1, cA, cB, cC, cw, e_, d0p, d1p, vals);
+							uint32_t d0p = 0, d1p = 0, vlo = 0, vhi = 0;
+							cem_option(sh, best_opt, best_lv, has_alpha, hdrf, in, cw, e_, d0p, d1p, vlo, vhi);
 #pragma unroll
 							for (uint32_t k = 0; k < 4u; ++k) {
 								D0[k] = p == k ? d0p : D0[k];
 								D1[k] = p == k ? d1p : D1[k];
 							}
-							// stored values, partition by partition: byte (p*nv + k) of the list
+							// stored values, partition by partition: the nv bytes of vlo | vhi << 32 go to byte p*nv
+							// of the list -- a 64-bit shift into the (at most three) words they straddle
+							{
+								const unsigned long long vv = ((unsigned long long)vhi << 32 | vlo) & (nv >= 8u ? ~0ull : ((1ull << (8u*nv)) - 1ull));
+								const uint32_t bit = p*nv*8u, wd0 = bit >> 5, sh_ = bit & 31u;
+								const unsigned long long lo = vv << sh_;
+								const uint32_t x0 = (uint32_t)lo, x1 = (uint32_t)(lo >> 32), x2 = sh_ ? (uint32_t)(vv >> (64u - sh_)) : 0u;
 #pragma unroll
-							for (uint32_t k = 0; k < 8u; ++k) {
-								if (k < nv) {
-									const uint32_t pos = p*nv + k;
-#pragma unroll
-									for (uint32_t wd = 0; wd < 5u; ++wd)
-										r_cv[wd] |= (pos >> 2) == wd ? vals[k] << (8u*(pos & 3u)) : 0u;
-								}
+								for (uint32_t wd = 0; wd < 5u; ++wd)
+									r_cv[wd] |= wd == wd0 ? x0 : (wd == wd0 + 1u ? x1 : (wd == wd0 + 2u ? x2 : 0u));
 							}
 						}
 #undef SEL4
