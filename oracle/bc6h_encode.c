@@ -365,3 +365,26 @@ void cfo_encode_bc6h_block(const uint16_t rgba_half[64], uint8_t out[16], const 
 	}
 	pack(&best, out);
 }
+
+
+/* ---- test-only: the WIDE search -- all 33 candidates (one subset; the 32
+ * two-subset partitions) with the refit iterated 12 rounds instead of the ladder's 0..3.  Returns
+ * the block; the caller measures it like any other payload. */
+void cfo_bc6h_wide_search(const uint16_t rgba_half[64], uint8_t out[16], const cfo_params* p)
+{
+	int is_signed = p->type == CFO_TYPE_FLOAT;
+	int v[16][3], h[16][3];
+	for (int i = 0; i < 16; ++i)
+		for (int c = 0; c < 3; ++c) {
+			v[i][c] = half_to_v(rgba_half[4*i + c], is_signed);
+			h[i][c] = half_to_h(rgba_half[4*i + c], is_signed);
+		}
+	hcand best, cur;
+	eval_candidate(v, h, 0, 12, is_signed, &best);
+	for (int k = 0; k < 32; ++k) {
+		eval_candidate(v, h, 1 + k, 12, is_signed, &cur);
+		if (cur.err < best.err)
+			best = cur;
+	}
+	pack(&best, out);
+}

@@ -875,3 +875,53 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 		uber_refine(px, wt, &best, b.uber);
 	pack(&best, out);
 }
+
+
+/* ---- test-only: the WIDE search (tests/test_oracle_bounds.py) -------------------
+ * Every candidate the format has -- mode 6; mode 5 x 4 rotations; mode 4 x 4 rotations x 2 index
+ * selectors; modes 1, 3, 7 on all 64 two-subset partitions; mode 0 on its 16 and mode 2 on all 64
+ * three-subset partitions -- each with the least squares iterated 8 rounds and 8 rounds of endpoint
+ * perturbation applied to EVERY candidate, not only to the winner.  A few hundred times the work of
+ * Texture::Quality::Highest: the bound the quality ladder is measured against ("gap to the wide
+ * search"; it is built from the same fit routines, so it bounds the SEARCH, not the routines).
+ * Returns the smallest error found (the weighted SSE the encoder minimises) and the block. */
+uint32_t cfo_bc7_wide_search(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p)
+{
+	int px[16][4], wt[CFO_BC7_NW];
+	cfo_bc7_weights(p, wt);
+	int has_alpha = 0;
+	for (int i = 0; i < 16; ++i) {
+		for (int c = 0; c < 4; ++c)
+			px[i][c] = wt[c] ? rgba[4*i + c] : (c == 3 ? 255 : 0);
+		if (px[i][3] != 255)
+			has_alpha = 1;
+	}
+	for (int c = 0; c < 4; ++c)
+		if (!wt[c])
+			wt[c] = 1;
+	cand best, cur;
+	memset(&best, 0, sizeof(best));
+	best.err = 0xFFFFFFFFu;
+	best.id = 0x7FFFFFFF;
+	for (int id = 0; id < 384; ++id) {
+		if (id >= 13 && id < 64)
+			continue;
+		if (id >= 192 + 16 && id < 256)
+			continue;                                  /* mode 0 has 16 partitions */
+		if (has_alpha && ((id >= 64 && id < 320)))
+			continue;                                  /* modes 0 - 3 cannot carry alpha */
+		if (!has_alpha && id >= 320)
+			continue;                                  /* mode 7 spends bits on an alpha that is constant */
+		if (wt[4] && ((id >= 2 && id <= 4) || (id >= 5 && id <= 12 && ((id - 5) & 3))))
+			continue;                                  /* perceptual metric: rotation 0 only, as the encoder */
+		eval_candidate(px, wt, id, 8, &cur);
+		if (cur.err != 0)
+			uber_refine(px, wt, &cur, 8);
+		if (cur.err < best.err || (cur.err == best.err && cur.id < best.id))
+			best = cur;
+		if (best.err == 0)
+			break;
+	}
+	pack(&best, out);
+	return best.err;
+}

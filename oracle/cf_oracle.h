@@ -94,6 +94,10 @@ int cfo_std_pack(int format, int type, const float* pixels, uint32_t width, uint
 /* single-block encoders (inputs already quantised as the reference does) */
 void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p);
 
+/* test-only wide searches: the bound the quality ladders are measured against */
+uint32_t cfo_bc7_wide_search(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p);
+void cfo_bc6h_wide_search(const uint16_t rgba_half[64], uint8_t out[16], const cfo_params* p);
+
 /* sum of squared differences over RGBA8 images, per channel (for PSNR) */
 void cfo_sse_rgba8(const uint8_t* a, const uint8_t* b, size_t n_pixels, uint64_t sse[4]);
 

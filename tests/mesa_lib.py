@@ -93,3 +93,27 @@ def decode(fmt: int, payload: np.ndarray, width: int, height: int, typ: int = 0,
     if srgb and int(fmt) >= 43:
         g += 0x20
     return decode_gl(g, payload, width, height, rb_format, rb_type)
+
+
+def encode(fmt: int, img: np.ndarray, typ: int = 0) -> np.ndarray:
+    """Mesa's OWN software encoder (an independent encoder, not ours): (h, w, 4) uint8 RGBA -- or
+    float32 for BC6H -- through glTexImage2D with a compressed internal format, payload back through
+    glGetCompressedTexImage.  S3TC (29..32), RGTC (33, 34), BPTC (35, 36)."""
+    assert available()
+    _lib.mesa_encode.argtypes = [ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_uint,
+                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    _lib.mesa_encode.restype = ctypes.c_int
+    g = GLFMT[int(fmt)]
+    if int(fmt) in (33, 34) and typ == 1:
+        g += 1
+    if int(fmt) == 35 and typ == 5:
+        g = GL_BPTC_SIGNED_FLOAT
+    img = np.ascontiguousarray(img)
+    h, w = img.shape[:2]
+    src_type = GL_FLOAT if img.dtype == np.float32 else GL_UNSIGNED_BYTE
+    cap = ((w + 3)//4)*((h + 3)//4)*16
+    out = np.zeros(cap, np.uint8)
+    rc = _lib.mesa_encode(g, w, h, GL_RGBA, src_type, img.ctypes.data, out.ctypes.data, cap)
+    if rc <= 0:
+        raise RuntimeError("Mesa could not compress format %d (GL error / not compressed: %d)" % (fmt, rc))
+    return out[:rc].copy()

@@ -10,6 +10,8 @@ from the best possible block" is the independent yardstick available):
   optimum of the exact error.
 * BC4: exhaustive 256 x 256 endpoint pairs lives in tests/test_oracle_bc15.py.
 """
+import os
+
 import numpy as np
 import pytest
 from scipy.ndimage import minimum_filter
@@ -111,3 +113,23 @@ def test_bc7_mode6_blocks_are_local_optima_of_the_exact_error():
     gap = 10*np.log10(max(tot_e, 1)/max(tot_b, 1))
     print("mode-6 blocks %d, gap to the best single-coordinate move %.3f dB" % (n6, gap))
     assert gap < 0.3, gap      # measured 0.086 dB: one more endpoint move would gain that little
+
+
+def test_bc7_and_bc6h_ladders_stay_close_to_the_wide_search():
+    """Gap of the quality ladder to a search a few hundred times wider (every mode x partition x
+    rotation x selector, least squares and endpoint perturbation iterated on every candidate:
+    cfo_bc7_wide_search / cfo_bc6h_wide_search).  The full table over 2 048 blocks is
+    profiles/r03_quality_tables.md; here 96 blocks keep the CPU suite fast."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "quality_tables", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "quality_tables.py"))
+    qt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(qt)
+    rng = np.random.default_rng(7)
+    for label, ps in qt.bc7_gap(96, rng):
+        assert ps[5] >= ps[4] - 1e-9, (label, ps)              # the wide search is a bound
+        assert ps[5] - ps[4] <= 0.35, (label, ps)              # Highest within 0.35 dB of it
+        assert ps[5] - ps[2] <= 0.60, (label, ps)              # Normal within 0.6 dB
+        assert all(ps[q + 1] >= ps[q] - 1e-9 for q in range(4)), (label, ps)
+    ps = qt.bc6h_gap(96, rng)
+    assert ps[5] >= ps[4] - 0.02 and ps[5] - ps[2] <= 0.45, ps

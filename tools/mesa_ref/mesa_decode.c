@@ -7,6 +7,11 @@
  * way libGLX's drisw loader does.  A compressed payload goes in through
  * glCompressedTexImage2D and comes back decoded through glGetTexImage.
  *
+ * mesa_encode goes the other way: an INDEPENDENT ENCODER.  Pixels go in through glTexImage2D with a
+ * compressed internal format -- Mesa's software drivers then compress on the CPU with their own
+ * encoders (S3TC: the former libtxc_dxtn in texcompress_s3tc_tmp.h, RGTC: texcompress_rgtc,
+ * BPTC: texcompress_bptc_tmp.h) -- and the payload comes back through glGetCompressedTexImage.
+ *
  * Build:  gcc -O1 -shared -fPIC -o libmesa_decode.so mesa_decode.c -ldl
  * Used by tests/golden/make_mesa_fixtures.py (commits random valid blocks + Mesa's pixels) and,
  * when the driver file is present, by tests/test_mesa_crosscheck.py on live encoder output. */
@@ -43,6 +48,9 @@ static void (*p_TexParameteri)(GLenum, GLenum, GLint);
 static void (*p_PixelStorei)(GLenum, GLint);
 static void (*p_CompressedTexImage2D)(GLenum, GLint, GLenum, GLsizei, GLsizei, GLint, GLsizei, const void *);
 static void (*p_GetTexImage)(GLenum, GLint, GLenum, GLenum, void *);
+static void (*p_TexImage2D)(GLenum, GLint, GLint, GLsizei, GLsizei, GLint, GLenum, GLenum, const void *);
+static void (*p_GetCompressedTexImage)(GLenum, GLint, void *);
+static void (*p_GetTexLevelParameteriv)(GLenum, GLint, GLenum, GLint *);
 static GLenum (*p_GetError)(void);
 static const GLubyte *(*p_GetString)(GLenum);
 static void (*p_Finish)(void);
@@ -83,6 +91,7 @@ int mesa_init(const char *driver_path)
 #define GP(n) do { *(void **)&p_##n = g_gpa("gl" #n); if (!p_##n) return -10; } while (0)
     GP(GenTextures); GP(BindTexture); GP(DeleteTextures); GP(TexParameteri); GP(PixelStorei);
     GP(CompressedTexImage2D); GP(GetTexImage); GP(GetError); GP(GetString); GP(Finish);
+    GP(TexImage2D); GP(GetCompressedTexImage); GP(GetTexLevelParameteriv);
 #undef GP
     g_ready = 1;
     return 0;
@@ -113,4 +122,42 @@ int mesa_decode(unsigned glfmt, int w, int h, const void *data, int size,
     p_BindTexture(GL_TEXTURE_2D, 0);
     p_DeleteTextures(1, &tex);
     return e;
+}
+
+/* pixels (src_format, src_type; tightly packed, top row first) of a w x h texture -> the payload
+ * Mesa's own software encoder produces for GL internal format `glfmt`.  Returns the payload size
+ * (<= cap) or a negative GL error / -1. */
+int mesa_encode(unsigned glfmt, int w, int h, unsigned src_format, unsigned src_type, const void *pixels,
+                void *out, int cap)
+{
+    if (!g_ready) return -1;
+    while (p_GetError() != GL_NO_ERROR) {}
+    GLuint tex = 0;
+    int size = -1;
+    p_GenTextures(1, &tex);
+    p_BindTexture(GL_TEXTURE_2D, tex);
+    p_TexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
+    p_TexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
+    p_TexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAX_LEVEL, 0);
+    p_PixelStorei(GL_PACK_ALIGNMENT, 1);
+    p_PixelStorei(GL_UNPACK_ALIGNMENT, 1);
+    p_TexImage2D(GL_TEXTURE_2D, 0, (GLint)glfmt, w, h, 0, src_format, src_type, pixels);
+    int e = (int)p_GetError();
+    if (!e) {
+        GLint compressed = 0, csize = 0, ifmt = 0;
+        p_GetTexLevelParameteriv(GL_TEXTURE_2D, 0, GL_TEXTURE_COMPRESSED, &compressed);
+        p_GetTexLevelParameteriv(GL_TEXTURE_2D, 0, GL_TEXTURE_COMPRESSED_IMAGE_SIZE, &csize);
+        p_GetTexLevelParameteriv(GL_TEXTURE_2D, 0, GL_TEXTURE_INTERNAL_FORMAT, &ifmt);
+        if (!compressed || (unsigned)ifmt != glfmt || csize <= 0 || csize > cap)
+            e = 1;
+        else {
+            p_GetCompressedTexImage(GL_TEXTURE_2D, 0, out);
+            p_Finish();
+            e = (int)p_GetError();
+            size = csize;
+        }
+    }
+    p_BindTexture(GL_TEXTURE_2D, 0);
+    p_DeleteTextures(1, &tex);
+    return e ? -(e > 0 ? e : 1) : size;
 }
