@@ -201,7 +201,7 @@ template <bool QUANT>
 __device__ __forceinline__ void normalise_rows(uint8_t* base, const uint32_t* den, uint32_t PW, const uint8_t* wnu)
 {
 	uint32_t prev = 0;        // w[2k-2] | w[2k-1] << 8
-#pragma unroll 1
+#pragma unroll 2
 	for (uint32_t k = 0; k < PW; ++k) {
 		uint32_t* wp = reinterpret_cast<uint32_t*>(base + k*256u);
 		const uint32_t acc = *wp;
@@ -1040,7 +1040,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					const bool byp = dual || P == 1u;
 					int a0 = 0, a1 = 0, a2 = 0, a3 = 0, cnt_t = 0;
 					int q00 = 0, q01 = 0, q02 = 0, q03 = 0, q11 = 0, q12 = 0, q13 = 0, q22 = 0, q23 = 0, q33 = 0;
-#pragma unroll 1
+#pragma unroll 2
 					for (uint32_t i = par; i < n; i += stp) {
 						const bool in_ = byp || prow[i] == s;
 						const uint32_t p = in_ ? (tp[i] & bytemask) : 0u;
@@ -1070,7 +1070,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					float ax[4];
 					principal_axis(Cs, ax);
 					float lo_t = 3.0e38f, hi_t = -3.0e38f;
-#pragma unroll 1
+#pragma unroll 2
 					for (uint32_t i = par; i < n; i += stp) {
 						const bool in_ = byp || prow[i] == s;
 						const uint32_t p = tp[i] & bytemask;
@@ -1106,7 +1106,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					}
 					const float rdd2 = dd > 0 ? 1.0f/(float)(2*dd) : 0.0f;
 					uint8_t* Trow = S.T + ((dual && s == 1u) ? 8u + ((j - 1u) & 1u) : j)*npad;
-#pragma unroll 1
+#pragma unroll 2
 					for (uint32_t i = par; i < n; i += stp) {
 						const bool in_ = byp || prow[i] == s;
 						const uint32_t p = tp[i];
@@ -1160,7 +1160,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				}
 				__builtin_amdgcn_wave_barrier();
 				if (gact) {
-#pragma unroll 2
+#pragma unroll 4
 					for (uint32_t i = half; i < n; i += step) {
 						const uint2 rec = inf[i];
 						decim_add(gcol, rec.x, rec.y, Trow[i]);
@@ -1172,7 +1172,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				__builtin_amdgcn_wave_barrier();
 				uint32_t e = 0;
 				if (gact) {
-#pragma unroll 2
+#pragma unroll 4
 					for (uint32_t i = half; i < n; i += step) {
 						const uint2 rec = inf[i];
 						const int dgt = (int)infill_w(gcol, rec.x, rec.y) - (int)Trow[i];
@@ -1270,7 +1270,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					for (uint32_t pl = 0; pl < ((CF_ASTC_ABLATE & 16) ? 0u : planes); ++pl) {
 						const uint8_t* Trow = S.T + (pl ? 8u + ((j - 1u) & 1u) : j)*npad;
 						uint8_t* cb = pl ? colp1 : colbase;
-#pragma unroll 2
+#pragma unroll 4
 						for (uint32_t i = 0; i < n; ++i) {
 							const uint2 rec = inf[i];
 							decim_add(cb, rec.x, rec.y, Trow[i]);
@@ -1293,7 +1293,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					// are walked only when some lane of the wave has them (a scalar branch, not per-lane
 					// predication -- the wave executes the instructions either way)
 					const bool any3 = __ballot(nset > 2u) != 0ull, any4 = __ballot(nset > 3u) != 0ull;
-#pragma unroll 1
+#pragma unroll 2
 					for (uint32_t i = 0; i < ((CF_ASTC_ABLATE & 64) ? 1u : n); ++i) {
 						const uint2 rec = inf[i];
 						const uint32_t p = tp[i], part = byp ? 0u : prow[i];
@@ -1427,7 +1427,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							const uint32_t mlo = dual ? (ccs == 0u ? 0x0000FFFFu : (ccs == 1u ? 0xFFFF0000u : 0u)) : 0u;
 							const uint32_t mhi = dual ? (ccs == 2u ? 0x0000FFFFu : (ccs == 3u ? 0xFFFF0000u : 0u)) : 0u;
 							const bool wide = __ballot(P > 2u) != 0ull;
-#pragma unroll 1
+#pragma unroll 2
 							for (uint32_t i = 0; i < ((CF_ASTC_ABLATE & 256) ? 1u : n); ++i) {
 								const uint2 rec = inf[i];
 								const uint32_t w0p = infill_w(colbase, rec.x, rec.y)*0x00010001u;
