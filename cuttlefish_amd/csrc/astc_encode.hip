@@ -664,7 +664,13 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						(hdr_code((float)((px >> 16) & 255u)*k) << 16) | (a << 24);
 				}
 			} else {
-				const float4 f = *reinterpret_cast<const float4*>(rowp + (size_t)x*16u);
+				float4 f;
+				if (kp.flags & (1u << 21)) {       // RGBA16F source: the same floats, 8 bytes per texel
+					const uint2 hb = *reinterpret_cast<const uint2*>(rowp + (size_t)x*8u);
+					f = make_float4(__half2float(__ushort_as_half((unsigned short)(hb.x & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(hb.x >> 16))),
+						__half2float(__ushort_as_half((unsigned short)(hb.y & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(hb.y >> 16))));
+				} else
+					f = *reinterpret_cast<const float4*>(rowp + (size_t)x*16u);
 				if (hdrf)
 					px = hdr_code(f.x) | (hdr_code(f.y) << 8) | (hdr_code(f.z) << 16) |
 						(((hdrf & 2u) ? hdr_code(f.w) : cf_unorm8(f.w)) << 24);

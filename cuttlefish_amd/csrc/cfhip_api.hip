@@ -403,8 +403,8 @@ int launch(cfhip_ctx* ctx, const cf_kparams& kp, const cfhip_params& p, int pixe
 		case CFHIP_FORMAT_ASTC_8x6: case CFHIP_FORMAT_ASTC_8x8: case CFHIP_FORMAT_ASTC_10x5:
 		case CFHIP_FORMAT_ASTC_10x6: case CFHIP_FORMAT_ASTC_10x8: case CFHIP_FORMAT_ASTC_10x10:
 		case CFHIP_FORMAT_ASTC_12x10: case CFHIP_FORMAT_ASTC_12x12: {
-			if (pixel_type != CFHIP_PIXEL_RGBA8 && pixel_type != CFHIP_PIXEL_RGBA32F)
-				return fail(ctx, CFHIP_E_UNSUPPORTED, "ASTC takes RGBA8 or RGBA32F pixels");
+			if (pixel_type != CFHIP_PIXEL_RGBA8 && pixel_type != CFHIP_PIXEL_RGBA32F && pixel_type != CFHIP_PIXEL_RGBA16F)
+				return fail(ctx, CFHIP_E_UNSUPPORTED, "ASTC takes RGBA8, RGBA16F or RGBA32F pixels");
 			const int trc = astc_prepare(ctx, p.format);
 			if (trc != CFHIP_OK)
 				return trc;
@@ -421,7 +421,9 @@ int launch(cfhip_ctx* ctx, const cf_kparams& kp, const cfhip_params& p, int pixe
 			// images (AstcConverter.cpp:163-172)
 			k2.flags |= ((p.alpha == CFHIP_ALPHA_STANDARD || p.alpha == CFHIP_ALPHA_PREMULTIPLIED) ? 1u << 16 : 0u) |
 				(p.color_space == CFHIP_COLOR_SRGB ? 1u << 17 : 0u);
-			e = cfhip_launch_astc(&k2, pixel_type == CFHIP_PIXEL_RGBA32F ? 1 : 0, nwaves, lds_bytes, stream);
+			// a half-float source runs the float kernel with bit 21 set: its loader reads 8 bytes per texel
+			k2.flags |= pixel_type == CFHIP_PIXEL_RGBA16F ? 1u << 21 : 0u;
+			e = cfhip_launch_astc(&k2, pixel_type == CFHIP_PIXEL_RGBA8 ? 0 : 1, nwaves, lds_bytes, stream);
 			ctx->last_kernel = "cfhip_astc_encode_kernel";
 			break;
 		}

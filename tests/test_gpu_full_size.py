@@ -2,6 +2,8 @@
 cannot finish these in seconds, so the checks are size-independent properties -- payload size,
 determinism, a PSNR floor through the oracle DECODER, and byte parity with the oracle ENCODER on
 a strip of block rows cut out of the big payload (blocks are independent)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -25,7 +27,13 @@ def test_config3_astc_6x6_4096(ctx):
     assert a.nbytes == bx*bx*16
     assert np.array_equal(a, ctx.encode([img], p)[0])               # deterministic
     dec, outside = O.decode_astc(a, int(Format.ASTC_6x6), 4096, 4096)
-    assert outside == 0 and synth.psnr(img, dec) > 40.0
+    psnr = synth.psnr(img, dec)
+    # round 3's High (one pass of 8 candidates x 8 configs): 47.13 dB on this tile with the oracle, same bytes
+    assert outside == 0 and psnr > 47.0, psnr
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "c3_psnr.txt"), "w") as f:
+            f.write("C3 ASTC 6x6 High 4096x4096 RGBA PSNR (GPU payload, oracle decoder): %.4f dB\n" % psnr)
     # block rows 340..343 (texel rows 2040..2063, inside the alpha band) against the oracle encoder
     strip = img[340*6:344*6]
     ref = O.encode(strip, int(Format.ASTC_6x6), 0, quality=3, threads=16)

@@ -29,7 +29,7 @@ def test_multi_context_equals_single_context(gpu_ctx, fmt, quality):
 
 
 def test_multi_reports_the_failure_of_any_share(gpu_ctx):
-    params = make_params(Format.ASTC_6x6, Type.UFloat, 2)      # refused: ASTC takes RGBA8 or RGBA32F pixels
+    params = make_params(Format.BC7, Type.UNorm, 2)            # refused: BC7 takes RGBA8 or RGBA32F pixels
     imgs = [(synth.photo(16, 16, seed=1).astype(np.float32)/255.0).astype(np.float16) for _ in range(3)]
     other = Context(0)
     try:
