@@ -79,7 +79,7 @@ __device__ __forceinline__ Ladder ladder(uint32_t q)
 		case 0: return {2, 0, 0, 0, 0, 0};
 		case 1: return {4, 16, 2, 0, 0, 1};
 		case 2: return {4, 32, 3, 2, 0, 2};
-		case 3: return {8, 256, 4, 2, 0, 2};
+		case 3: return {6, 256, 4, 2, 0, 2};   // K = the deepest list of High's uneven allocation (high_k)
 		default: return {8, 256, 14, 9, 6, 2};
 	}
 }
@@ -627,7 +627,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	uint8_t* sh_ctab = lds + off; off += (hdrf ? 3u : 2u)*17u*256u;
 	uint8_t* sh_wtab = lds + off; off += 2016u;
 	const uint32_t slot_bytes = ((10u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
-	const uint32_t wave_bytes = ((((col_rows + 1u)/2u)*256u + 15u) & ~15u) + (kp.quality <= 2u ? 2u : 1u)*slot_bytes;
+	const uint32_t wave_bytes = ((((col_rows + 1u)/2u)*256u + 15u) & ~15u) + (kp.quality <= 3u ? 2u : 1u)*slot_bytes;
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	uint8_t* wbase = lds + off + wave*wave_bytes;
 
@@ -701,7 +701,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
 #endif
 	const Ladder lad = ladder(q);
-	const bool can_pair = q <= 2u;
+	// up to High a block needs 32 lanes (8 candidates; High: 6,6,6,6,2,2,2,2 configs, the others 4 each):
+	// two blocks share a wavefront
+	const bool can_pair = q <= 3u;
 	uint32_t cw[4] = {1u, 1u, 1u, 1u};
 	if (aflags & ASTC_FLAG_PERCEPTUAL) { cw[0] = 11u; cw[1] = 21u; cw[2] = 4u; cw[3] = 16u; }
 	const uint32_t recip_n = 65536u/n;                                          // x / n as (x * recip_n) >> 16, like the oracle
@@ -917,9 +919,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			// lane = table entry: mismatch = n - best label-permuted overlap
 			const uint32_t np = H->npart[P - 2u] < lad.limit ? H->npart[P - 2u] : lad.limit;
 			const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(blob + H->off_mask[P - 2u]);
-			uint32_t keys[4];
+			// up to 256 entries: 4 per lane of a 64-lane group, 8 per lane when two blocks share the wave
+			uint32_t keys[8];
 #pragma unroll
-			for (uint32_t m = 0; m < 4u; ++m) {
+			for (uint32_t m = 0; m < 8u; ++m) {
 				keys[m] = 0xFFFFFFFFu;
 				const uint32_t e = hl + gsz*m;
 				if (e < np) {
@@ -962,11 +965,11 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			for (uint32_t jj = 0; jj < want; ++jj) {
 				uint32_t mk = keys[0];
 #pragma unroll
-				for (uint32_t m = 1; m < 4u; ++m)
+				for (uint32_t m = 1; m < 8u; ++m)
 					mk = keys[m] < mk ? keys[m] : mk;
 				const uint32_t gmin = cf_group_min_u32(mk, pair, h);
 #pragma unroll
-				for (uint32_t m = 0; m < 4u; ++m)
+				for (uint32_t m = 0; m < 8u; ++m)
 					keys[m] = keys[m] == gmin ? 0xFFFFFFFFu : keys[m];
 				if (gmin != 0xFFFFFFFFu) {
 					if (hl == 0u) S.pcs[npc] = pc_make(P, 0, 0, P, gmin & 0xFFFFu);
@@ -977,10 +980,12 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			}
 		}
 		__builtin_amdgcn_wave_barrier();
-		if (q >= 3u) {
-			// High and Highest (one block per wave) share the head of the walk: 4 two-partition seeds, then
-			// 2 three-partition seeds, then the rest in the old order (oracle: ASTC_HEAD2 / ASTC_HEAD3);
-			// High keeps the first pass of 8 candidates only.  Lane t moves entry t.
+		if (q == 3u && npc > 8u)
+			npc = 8u;          // High: the first pass only (its 4 + 2 seeds already are the head of the walk)
+		if (q >= 4u) {
+			// Highest (one block per wave) walks the same head as High: 4 two-partition seeds, then 2
+			// three-partition seeds, then the rest in the old order (oracle: ASTC_HEAD2 / ASTC_HEAD3).
+			// Lane t moves entry t.
 			const uint32_t h2 = got2 < 4u ? got2 : 4u, h3 = got3 < 2u ? got3 : 2u;
 			uint32_t src = lane;
 			if (lane >= nb && lane < nb + got2 + got3) {
@@ -992,13 +997,13 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			if (lane < npc)
 				S.pcs[lane] = moved;
 			__builtin_amdgcn_wave_barrier();
-			if (q == 3u && npc > 8u)
-				npc = 8u;
 		}
 
 		PROF_MARK(1)   // statistics + candidate list + shortlist
 		// ---- passes of (gsz / K) candidates x K configs ----
-		const uint32_t K = lad.K, kshift = K == 2u ? 1u : (K == 4u ? 2u : 3u), per_pass = gsz >> kshift;
+		// High: candidate j of the pass has high_k(j) = 6 (j < 4) or 2 lanes, side by side: 32 lanes
+		const bool varK = q == 3u;
+		const uint32_t K = lad.K, kshift = K == 2u ? 1u : (K == 4u ? 2u : 3u), per_pass = varK ? 8u : gsz >> kshift;
 		unsigned long long bestkey = ~0ull;
 		const uint32_t alpha_i = has_alpha ? 1u : 0u;
 		uint32_t npc_max = npc;
@@ -1225,6 +1230,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						key[m] = ((est > 0x3FFFFFEull ? 0x3FFFFFEu : (uint32_t)est) << 6) | k;
 					}
 				}
+				const uint32_t Kj = varK ? (j < 4u ? 6u : 2u) : K;
 				for (uint32_t it = 0; it < K; ++it) {
 					uint32_t mk = key[0];
 #pragma unroll
@@ -1237,7 +1243,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 #pragma unroll
 					for (uint32_t m = 0; m < NK; ++m)
 						key[m] = key[m] == gmin ? 0xFFFFFFFFu : key[m];
-					if (t == 0u && jact)
+					if (t == 0u && jact && it < Kj)
 						S.order[j*8u + it] = gmin == 0xFFFFFFFFu ? (uint8_t)255 : (uint8_t)(gmin & 63u);
 				}
 			};
@@ -1253,7 +1259,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			uint32_t r_cem = 0, r_lv = 0, r_ncv = 0, r_cfg = 0;
 			uint32_t r_cv[5] = {0, 0, 0, 0, 0};
 			{
-				const uint32_t j = hl >> kshift, ks = hl & (K - 1u);
+				// High: lanes 0..23 = candidates 0..3 x 6 configs ((hl * 43) >> 8 == hl / 6 there), lanes 24..31 =
+				// candidates 4..7 x 2; a lone block in a 64-lane group leaves lanes 32.. idle
+				const uint32_t jv = hl < 24u ? (hl*43u) >> 8 : (hl < 32u ? 4u + ((hl - 24u) >> 1) : 8u);
+				const uint32_t j = varK ? jv : hl >> kshift, ks = varK ? (hl < 24u ? hl - jv*6u : hl & 1u) : hl & (K - 1u);
 				const uint32_t d = j < cnt ? S.pcs[base + j] : 0u;
 				const uint32_t P = pc_P(d), dual = pc_dual(d), ccs = pc_ccs(d), cls = pc_cls(d);
 				const uint32_t oi = (j < cnt) ? S.order[j*8u + ks] : 255u;
@@ -1678,7 +1687,7 @@ static size_t astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality, 
 	off += (hdr ? 3u : 2u)*17u*256u + 2016u;
 	(void)wcached;
 	const uint32_t slot_bytes = ((10u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
-	const uint32_t wave_bytes = ((((h->col_rows + 1u)/2u)*256u + 15u) & ~15u) + (quality <= 2u ? 2u : 1u)*slot_bytes;
+	const uint32_t wave_bytes = ((((h->col_rows + 1u)/2u)*256u + 15u) & ~15u) + (quality <= 3u ? 2u : 1u)*slot_bytes;
 	return (size_t)off + nwaves*(size_t)wave_bytes;
 }
 
