@@ -76,9 +76,9 @@ __device__ __forceinline__ Ladder ladder(uint32_t q)
 {
 	// twin of k_ladder in oracle/astc_encode.c (stands in for astcenc's presets)
 	switch (q) {
-		case 0: return {2, 0, 0, 0, 0, 0};
-		case 1: return {4, 16, 2, 0, 0, 1};
-		case 2: return {4, 32, 3, 2, 0, 2};
+		case 0: return {8, 0, 0, 0, 0, 0};
+		case 1: return {8, 16, 2, 0, 0, 1};
+		case 2: return {6, 64, 4, 2, 0, 2};
 		case 3: return {6, 256, 4, 2, 0, 2};   // K = the deepest list of High's uneven allocation (high_k)
 		default: return {8, 256, 14, 9, 6, 2};
 	}
@@ -980,8 +980,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			}
 		}
 		__builtin_amdgcn_wave_barrier();
-		if (q == 3u && npc > 8u)
-			npc = 8u;          // High: the first pass only (its 4 + 2 seeds already are the head of the walk)
+		if ((q == 2u || q == 3u) && npc > 8u)
+			npc = 8u;          // Normal, High: the first pass only (their 4 + 2 seeds already are the head of the walk)
 		if (q >= 4u) {
 			// Highest (one block per wave) walks the same head as High: 4 two-partition seeds, then 2
 			// three-partition seeds, then the rest in the old order (oracle: ASTC_HEAD2 / ASTC_HEAD3).
@@ -1001,8 +1001,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 
 		PROF_MARK(1)   // statistics + candidate list + shortlist
 		// ---- passes of (gsz / K) candidates x K configs ----
-		// High: candidate j of the pass has high_k(j) = 6 (j < 4) or 2 lanes, side by side: 32 lanes
-		const bool varK = q == 3u;
+		// Normal, High: candidate j of the pass has 6 (j < 4) or 2 lanes, side by side: 32 lanes; the other
+		// levels give every candidate 8
+		const bool varK = q == 2u || q == 3u;
 		const uint32_t K = lad.K, kshift = K == 2u ? 1u : (K == 4u ? 2u : 3u), per_pass = varK ? 8u : gsz >> kshift;
 		unsigned long long bestkey = ~0ull;
 		const uint32_t alpha_i = has_alpha ? 1u : 0u;

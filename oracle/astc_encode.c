@@ -945,8 +945,12 @@ static int shortlist(const astc_blk* b, int P, int limit, int want, const float 
  * configs per candidate, partitions searched, shortlisted 2/3/4-partition candidates, dual planes */
 typedef struct { int K, limit, j2, j3, j4, nd; } astc_ladder;
 static const astc_ladder k_ladder[5] = {
-	{2, 0, 0, 0, 0, 0}, {4, 16, 2, 0, 0, 1}, {4, 32, 3, 2, 0, 2}, {6, 256, 4, 2, 0, 2},
+	{8, 0, 0, 0, 0, 0}, {8, 16, 2, 0, 0, 1}, {6, 64, 4, 2, 0, 2}, {6, 256, 4, 2, 0, 2},
 	{8, 256, 14, 9, 6, 2}};
+/* Up to High a block has the 32 lanes of half a wavefront, and round 3 spends ALL of them: Lowest
+ * gives its one candidate 8 configs (2 before: +0.27 dB on the bench crops for the same wave time),
+ * Low its (at most) four candidates 8 each (4 before: +0.25 dB), Normal and High spread
+ * 6,6,6,6,2,2,2,2 over eight candidates and differ in how many partition seeds they rank (64 / 256). */
 /* High and Highest walk their candidates in passes of 8 and the FIRST pass is the same for both:
  * one partition, the dual planes, the 4 best two-partition and the 2 best three-partition seeds
  * (measured on the bench tile: this one pass is within 0.011 dB of the 8 + 5 seeds in two passes
@@ -1127,7 +1131,8 @@ void cfo_encode_astc_block(const int px[][4], int bw, int bh, int quality, int f
 			pcs[npc++] = (astc_pc){P, 0, 0, P, sl[k]};
 	}
 	/* passes of (group size / K) candidates x K configs */
-	int gsz = q <= 3 ? 32 : 64, per_pass = q == 3 ? 8 : gsz/lad->K;
+	const int var_k = q == 2 || q == 3;       /* the uneven allocation astc_high_k */
+	int gsz = q <= 3 ? 32 : 64, per_pass = var_k ? 8 : gsz/lad->K;
 	if (q >= 3) {
 		/* the head of the walk: ASTC_HEAD2 two-partition seeds, then ASTC_HEAD3 three-partition seeds,
 		 * then the rest in the old order; High keeps the first pass only */
@@ -1138,9 +1143,9 @@ void cfo_encode_astc_block(const int px[][4], int bw, int bh, int quality, int f
 		for (int k = 0; k < h3; ++k) pcs[t++] = old[nb + got_p[2] + k];
 		for (int k = h2; k < got_p[2]; ++k) pcs[t++] = old[nb + k];
 		for (int k = h3; k < got_p[3]; ++k) pcs[t++] = old[nb + got_p[2] + k];
-		if (q == 3 && npc > per_pass)
-			npc = per_pass;
 	}
+	if (var_k && npc > per_pass)
+		npc = per_pass;             /* Normal and High: one pass */
 
 	astc_lane best, cur;
 	memset(&best, 0, sizeof(best));
@@ -1169,7 +1174,7 @@ void cfo_encode_astc_block(const int px[][4], int bw, int bh, int quality, int f
 			const astc_pc* pc = &pcs[base + j];
 			int order[ASTC_MAX_CFG];
 			/* lane of the pair in its pass = its id: candidates side by side, K (High: astc_high_k) lanes each */
-			int Kj = q == 3 ? astc_high_k(j) : lad->K, lane0 = q == 3 ? (j < 4 ? 6*j : 24 + 2*(j - 4)) : j*lad->K;
+			int Kj = var_k ? astc_high_k(j) : lad->K, lane0 = var_k ? (j < 4 ? 6*j : 24 + 2*(j - 4)) : j*lad->K;
 			int nk = rank_configs(b, j, pc, Kj, order);
 			for (int k = 0; k < nk; ++k) {
 				phase_b(b, j, pc, &f->cfg[pc->cls][b->has_alpha][order[k]], &cur);
