@@ -79,7 +79,7 @@ def test_block_header_fields_and_features_in_use():
     img = (cols[((xx*0.9 + yy*0.5)//7).astype(int) % 3] + rng.integers(-6, 7, (96, 96, 4))).clip(0, 255).astype(np.uint8)
     img[..., 3] = 255
     three = 0
-    for b in O.encode(img, 47, quality=3, threads=8).reshape(-1, 16):
+    for b in O.encode(img, 47, quality=4, threads=8).reshape(-1, 16):
         v = int.from_bytes(bytes(b), "little")
         three += (v & 0x1FF) != 0x1FC and ((v >> 11) & 3) == 2
     assert three > 0
