@@ -31,7 +31,7 @@ CASES = [("BC1_RGB", 29, 0, "opaque"), ("BC1_RGBA", 30, 0, "cutout"), ("BC2", 31
          ("ETC1", 37, 0, "opaque"), ("ETC2_R8G8B8", 38, 0, "opaque"), ("ETC2_R8G8B8A1", 39, 0, "cutout"),
          ("ETC2_R8G8B8A8", 40, 0, "alpha"), ("EAC_R11_UNorm", 41, 0, "alpha"), ("EAC_R11_SNorm", 41, 1, "float"),
          ("EAC_R11G11_UNorm", 42, 0, "alpha"), ("EAC_R11G11_SNorm", 42, 1, "float")] + \
-        [("ASTC_%dx%d" % fp, 43 + i, 0, "alpha") for i, fp in enumerate(
+        [("ASTC_%dx%d" % fp, 43 + i, 0, "alpha_big") for i, fp in enumerate(
             [(4, 4), (5, 4), (5, 5), (6, 5), (6, 6), (8, 5), (8, 6), (8, 8), (10, 5), (10, 6), (10, 8),
              (10, 10), (12, 10), (12, 12)])]
 
@@ -42,6 +42,10 @@ def color_space(name):
 
 
 def image(kind):
+    if kind == "alpha_big":
+        # ASTC's levels rank differently sized seed lists and spread their lanes unevenly: a few hundred
+        # blocks are too few for the PSNR ladder to mean anything (round 3), so these cases get 9x the area
+        return np.ascontiguousarray(synth.photo(3*W, 3*H, seed=77))
     img = synth.photo(W, H, seed=77)
     if kind == "opaque":
         img = img.copy(); img[..., 3] = 255
@@ -74,7 +78,7 @@ def quality_metric(name, fmt, typ, img, payload):
         e = np.log2(1 + np.abs(dec[..., :3])) - np.log2(1 + np.abs(img[..., :3].astype(np.float32)))
         return round(float(10*np.log10(16.0**2/max(np.mean(e**2), 1e-12))), 3)
     elif fmt >= 43:
-        dec, _ = O.decode_astc(payload, fmt, W, H)
+        dec, _ = O.decode_astc(payload, fmt, img.shape[1], img.shape[0])
     else:
         dec = O.decode(payload, fmt, W, H, typ)
     if img.dtype != np.uint8:

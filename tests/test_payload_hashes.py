@@ -35,15 +35,15 @@ def test_oracle_payload_hashes_unchanged(case):
 def test_quality_never_costs_quality():
     """PSNR is non-decreasing in Texture::Quality for every format whose levels search nested
     candidate sets; ASTC's levels up to High shortlist partitions from differently sized lists (not
-    nested) and get 0.5 dB of slack; High -> Highest is nested (same list, more candidates taken
-    from it) and must never lose."""
+    nested) and get 0.1 dB of slack; High -> Highest is nested (same candidates in the same order,
+    every config list a prefix of the deeper one) and must never lose."""
     for name, fmt, typ, kind in G.CASES:
         ps = [HASHES["%s/q%d" % (name, q)]["psnr"] for q in range(5)]
         if ps[0] is None or G.color_space(name):
             continue      # (sRGB cases minimise a perceptual error, not the recorded PSNR)
-        # (on the two 768 x 768 crops of the bench tile every footprint's ladder is monotone; the 64 x 64
-        # fixture has a few hundred blocks and a level may lose to its neighbour by a rank-6/7 config)
-        slack = 0.6 if name.startswith("ASTC") else 0.01
+        # (the ASTC cases use a 192 x 144 image: on 64 x 48 -- a few dozen blocks of the larger
+        # footprints -- one block decided the ladder)
+        slack = 0.1 if name.startswith("ASTC") else 0.01
         if name.startswith("ASTC") and name.endswith("UFloat"):
             # the HDR profiles minimise an error on LNS codes, the recorded figure is a log-domain PSNR of
             # the halves, and the fixture is 64 x 64: the ladder is monotone on a 384 x 384 probe
