@@ -1706,7 +1706,8 @@ extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t qualit
 	// most resident waves first; then the SMALLER workgroup (blocks differ in cost -- early outs --
 	// and a 12-wave workgroup holds its LDS until its slowest wave is done: 4x4 Normal 4.6 ms as one
 	// 12-wave workgroup with the cache, 4.2 ms as three 4-wave workgroups without); then the cache
-	for (uint32_t nw = 4; nw <= 12u; nw += 4u) {
+	static const bool plan_no_dense = getenv("CFHIP_ASTC_NO_DENSE") != nullptr;   // experiments: the 256-register build only
+	for (uint32_t nw = 4; nw <= (plan_no_dense ? 8u : 12u); nw += 4u) {
 		if (forced && forced != nw)
 			continue;
 		for (uint32_t c = can_cache ? 2u : 1u; c-- > 0u;) {
@@ -1714,7 +1715,7 @@ extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t qualit
 			if (b > wg_max)
 				continue;
 			uint32_t w = (uint32_t)(cu_lds/(b + 1024u))*nw;      // 1024: the static outb + allocation granule
-			w = w >= 12u ? 12u : (w >= 8u ? 8u : w);
+			w = w >= 12u ? (plan_no_dense ? 8u : 12u) : (w >= 8u ? 8u : w);
 			if (w > best_w) {
 				best_w = w; best_nw = nw; best_c = c;
 			}
