@@ -17,6 +17,14 @@ for q in 2 3 4; do
   extra=""; [ $q != 2 ] && extra="--no-cpu-baseline"
   python $R/bench.py --quality $q $extra > $G/${tag}${sfx}_bench.json 2> $G/${tag}${sfx}_bench.err
 done
+# ASTC at BASELINE config 3 (6x6 High, 4096x4096): kernel stats + PMC passes incl. FETCH_SIZE / WRITE_SIZE
+PROFILE_CMD="python $R/tools/bench_formats.py --size 4096 --steps 3 --formats ASTC_6x6 --qualities 3" \
+  bash $R/tools/profile.sh ${tag}_astc > $G/${tag}_astc_pmc_summary.txt 2>&1
+for f in $(find $G/prof_${tag}_astc/stats -name "*kernel_stats.csv"); do cp $f $G/${tag}_astc_kernel_stats.csv; done
+bash $R/tools/dbg/astc_dense_ab.sh > $G/${tag}_astc_dense_ab.txt 2>&1
+# the N-rank flow as the driver launches it (plain `python bench.py --gpus 2`); one device: gloo hook
+BENCH_DIST_BACKEND=gloo python $R/bench.py --gpus 2 --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | grep "^{" > $G/${tag}_bench_gpus2_gloo.json
+BENCH_DIST_BACKEND=gloo python $R/bench.py --config c5 --gpus 2 --textures 16 2>/dev/null | grep "^{" > $G/${tag}_c5_16tex_gpus2_gloo.json
 python $R/tools/bench_formats.py --size 2048 --steps 3 --qualities 0,1,2,3,4 2>/dev/null | grep format > $G/${tag}_formats_2048.jsonl
 python $R/tools/bench_configs.py 2>/dev/null | grep "^{" > $G/${tag}_baseline_configs.jsonl
 python $R/bench.py --config c5 --textures 16 2>/dev/null | grep "^{" > $G/${tag}_c5_16tex.json
