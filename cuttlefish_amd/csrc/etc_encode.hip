@@ -49,7 +49,7 @@ struct RgbOpts {
 	uint32_t active, transparent;
 	int wt[3];
 	int radius;    // move rounds of the T / H search
-	int walk;      // base-colour walk of the half search: 1 / 3 / 9 / 27 / 125 + 2 descent steps
+	int walk;      // base-colour walk of the half search: 1 / 3 / 9 / 27 / 27 + 6 descent steps
 	bool refine;   // false: Lowest -- no planar move rounds, no T/H modes
 };
 
@@ -590,15 +590,15 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 	const int tma = o.punch ? 0 : k_etc_mod[t][0], tmb = k_etc_mod[t][1];
 	if (!fam4 || o.allow_indiv) {
 		// candidates in id order (oracle: search_half): the quantised half mean; + its two grey-
-		// diagonal neighbours; + its six axis neighbours; the 3x3x3 cube; the 5x5x5 cube;
+		// diagonal neighbours; + its six axis neighbours; the 3x3x3 cube (Highest: + six descent steps);
 		// out-of-range coordinates clamp
 		const int walk = o.walk;
-		const int ncand = walk == 0 ? 1 : (walk == 1 ? 3 : (walk == 2 ? 9 : (walk == 3 ? 27 : 125)));
-		const int r = walk == 3 ? 1 : 2;
+		const int ncand = walk == 0 ? 1 : (walk == 1 ? 3 : (walk == 2 ? 9 : 27));
+		const int r = 1;
 		// this half's share of the list
 		const int n0 = (ncand + 1) >> 1, cbeg = hc ? n0 : 0, cend = hc ? ncand : n0;
 		// cube odometer (blue fastest), no divisions: the second half starts at candidate 14 of 27 =
-		// (1, 1, 2) or 63 of 125 = (2, 2, 3), i.e. at offsets (0, 0, 1) in both cubes
+		// (1, 1, 2), i.e. at offsets (0, 0, 1)
 		int o0 = hc ? 0 : -r, o1 = hc ? 0 : -r, o2 = hc ? 1 : -r;
 #pragma unroll 1
 		for (int cand = cbeg; cand < cend; ++cand) {
@@ -629,11 +629,11 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 			const bool take = oe < berr || (oe == berr && oc < bcand);
 			berr = take ? oe : berr; bcand = take ? oc : bcand; bq = take ? oq : bq;
 		}
-		// Highest: two descent steps over the six axis neighbours of this table's best so far (both
+		// Highest: six descent steps over the six axis neighbours of this table's best so far (both
 		// halves of the wave walk them alike)
 		if (walk >= 4) {
 #pragma unroll 1
-			for (int step = 0; step < 2; ++step) {
+			for (int step = 0; step < 6; ++step) {
 				uint32_t be = berr, bqn = bq, bc = bcand;
 #pragma unroll 1
 				for (int m = 0; m < 6; ++m) {
@@ -650,7 +650,12 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 						bqn = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16);
 					}
 				}
+				// a step in which no lane of the wave moved leaves every later step with the same six
+				// neighbours and the same answer: stop (the oracle walks them to no effect)
+				const bool moved = be < berr;
 				berr = be; bq = bqn; bcand = bc;
+				if (__ballot(moved) == 0ull)
+					break;
 			}
 		}
 	}

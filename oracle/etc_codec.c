@@ -282,12 +282,13 @@ static void search_half(const int px[16][4], const rgb_opts* o, int flip, int su
 	/* the base-colour walk, per modifier table (lane = table on the GPU): candidates in id order,
 	 * the table's best = first candidate of its smallest error
 	 *   walk 0: the quantised half mean                                   (1 candidate)
-	 *   walk 1: + its six axis neighbours                                 (7)
-	 *   walk 2: the 3x3x3 cube around it                                  (27)
-	 *   walk 3: the 5x5x5 cube                                            (125)
-	 *   walk 4: the 5x5x5 cube, then two descent steps over the six axis neighbours of the
-	 *           table's best so far                                       (125 + 2 x 6)
-	 * out-of-range coordinates clamp (duplicates are harmless) */
+ *   walk 1: + its two neighbours on the grey diagonal                 (3)
+ *   walk 2: + its six axis neighbours                                 (9)
+ *   walk 3: the 3x3x3 cube around it                                  (27)
+ *   walk 4: the 3x3x3 cube, then six descent steps over the six axis neighbours of the table's
+ *           best so far (27 + 6 x 6).  Round 3: the 5x5x5 cube + two steps this replaces cost 137
+ *           evaluations for +0.004 dB on ETC2 and +0.013 dB on ETC1 over this
+ * out-of-range coordinates clamp (duplicates are harmless) */
 	uint32_t terr[8];
 	int tq[8][3], tcand[8];
 	for (int t = 0; t < 8; ++t) {
@@ -295,8 +296,8 @@ static void search_half(const int px[16][4], const rgb_opts* o, int flip, int su
 		tcand[t] = 0;
 		tq[t][0] = tq[t][1] = tq[t][2] = 0;
 	}
-	int ncand = o->walk == 0 ? 1 : (o->walk == 1 ? 3 : (o->walk == 2 ? 9 : (o->walk == 3 ? 27 : 125)));
-	int r = o->walk == 3 ? 1 : 2, side = 2*r + 1;
+	int ncand = o->walk == 0 ? 1 : (o->walk == 1 ? 3 : (o->walk == 2 ? 9 : 27));
+	int r = 1, side = 2*r + 1;
 	for (int cand = 0; cand < ncand; ++cand) {
 		int d[3] = {0, 0, 0};
 		if (o->walk == 1 || o->walk == 2) {
@@ -324,7 +325,7 @@ static void search_half(const int px[16][4], const rgb_opts* o, int flip, int su
 		}
 	}
 	if (o->walk >= 4)
-		for (int step = 0; step < 2; ++step)
+		for (int step = 0; step < 6; ++step)
 			for (int t = 0; t < 8; ++t) {
 				uint32_t be = terr[t];
 				int bq[3] = {tq[t][0], tq[t][1], tq[t][2]}, bc = tcand[t];
