@@ -253,6 +253,7 @@ def run_c5(args, rank, local_rank, world, backend):
     params = make_params(Format.BC7, Type.UNorm, args.quality)
 
     bases = [gpu_texture(torch, n, t, dev) for t in mine]
+    torch.cuda.synchronize()          # the textures exist before any other stream reads them
     chains = [[torch.empty((d, d, 4), dtype=torch.float32, device=dev) for d in dims[1:]] for _ in mine]
     out = torch.empty(len(mine) * chain_bytes, dtype=torch.uint8, device=dev)
 
@@ -326,6 +327,9 @@ def run_c5(args, rank, local_rank, world, backend):
             b = [gpu_texture(torch, n, t, dev)]
             c = [[torch.empty((d, d, 4), dtype=torch.float32, device=dev) for d in dims[1:]]]
             o = torch.empty(chain_bytes, dtype=torch.uint8, device=dev)
+            # torch produced the texture on ITS stream; the library reads it on the stream it is given
+            # (torch's legacy default stream has handle 0 = "the context's own stream"): finish first
+            torch.cuda.synchronize()
             ctx.generate_mips_device(b[0].data_ptr(), PixelType.RGBA8, n, n, n * 4,
                                      [x.data_ptr() for x in c[0]], color_space=ColorSpace.Linear,
                                      filter=0, stream=stream)

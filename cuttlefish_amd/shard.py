@@ -241,8 +241,7 @@ def encode_rows_sharded_device(ctx, image, width: int, height: int, pixel_type, 
     if b > a:
         ctx.encode_device([{"pixels": local_src.data_ptr(), "pixel_type": int(pixel_type), "width": width,
                             "height": y1 - y0, "row_pitch_bytes": row_bytes, "out": local.data_ptr(),
-                            "out_capacity": out_sizes[rank]}], params,
-                          torch.cuda.current_stream().cuda_stream)
+                            "out_capacity": out_sizes[rank]}], params, _producer_stream(torch))
     if timings is not None:
         sync()
         timings["encode_s"] = _time.perf_counter() - t0
@@ -257,6 +256,17 @@ def encode_rows_sharded_device(ctx, image, width: int, height: int, pixel_type, 
     if dst is None or dst == rank:
         return torch.cat([p for p in parts])
     return local
+
+
+def _producer_stream(torch) -> int:
+    """The stream handle to give the library so that it reads what torch (and RCCL, which hands its
+    results to torch's current stream) produced.  A real stream orders the kernels by itself.  The
+    legacy default stream has handle 0, which the C ABI reads as "the context's own stream" -- a
+    non-blocking one that does not wait for the default stream -- so finish the producers first."""
+    h = torch.cuda.current_stream().cuda_stream
+    if not h:
+        torch.cuda.synchronize()
+    return h
 
 
 def encode_surfaces_sharded_device(ctx, surfaces: Sequence[dict], params, rank: int, world: int,
@@ -288,7 +298,7 @@ def encode_surfaces_sharded_device(ctx, surfaces: Sequence[dict], params, rank: 
         off += nbytes[i]
     if desc:
         order = sorted(range(len(desc)), key=lambda k: desc[k]["pixel_type"])     # one launch per source type
-        ctx.encode_device([desc[k] for k in order], params, torch.cuda.current_stream().cuda_stream)
+        ctx.encode_device([desc[k] for k in order], params, _producer_stream(torch))
     torch.cuda.current_stream().synchronize()
     parts = exchange(local, sizes, rank, world, dst, group) if world > 1 else [local]
     result: list = [None] * len(surfaces)

@@ -217,7 +217,10 @@ int cfhip_encode_multi(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface* s
 /* Device-buffer entry point: pixels/out of every surface are device pointers on
  * ctx's GPU (e.g. produced by a GPU mip generator).  Kernels are enqueued on
  * `stream` (a hipStream_t, NULL = the context's own stream) and the call returns
- * without synchronising when stream != NULL. */
+ * without synchronising when stream != NULL.  The context's own stream is NON-BLOCKING: it
+ * does not order itself against the legacy default stream (handle 0, which is what NULL is read
+ * as).  A caller whose producer ran on the default stream -- torch's current stream unless one
+ * was set -- synchronises the device before a stream = NULL call, or passes a real stream. */
 int cfhip_encode_device(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n_surfaces,
 	const cfhip_params* params, void* stream);
 

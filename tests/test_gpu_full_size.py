@@ -28,8 +28,9 @@ def test_config3_astc_6x6_4096(ctx):
     assert np.array_equal(a, ctx.encode([img], p)[0])               # deterministic
     dec, outside = O.decode_astc(a, int(Format.ASTC_6x6), 4096, 4096)
     psnr = synth.psnr(img, dec)
-    # round 3's High (one pass of 8 candidates x 8 configs): 47.13 dB on this tile with the oracle, same bytes
-    assert outside == 0 and psnr > 47.0, psnr
+    # round 3's High (8 candidates on half a wavefront, 6,6,6,6,2,2,2,2 configs): 46.99 dB on this tile with
+    # the oracle, same bytes (uniform 8 x 8 on a whole wavefront: 47.13 dB at 1.5x the time)
+    assert outside == 0 and psnr > 46.9, psnr
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "c3_psnr.txt"), "w") as f:

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from cuttlefish_amd import Context, Format, Type, make_params, shard, synth
+from cuttlefish_amd import Context, Format, PixelType, Type, make_params, shard, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -32,6 +32,26 @@ def test_world1_sharded_equals_direct(gpu_ctx):
         whole = gpu_ctx.encode([big], q)[0]
         parts = [shard.encode_rows_sharded(big, q, gpu_ctx.encode, r, 3, gather=False) for r in range(3)]
         assert np.array_equal(np.concatenate(parts), whole), fmt
+
+
+def test_device_path_waits_for_torch_producers(gpu_ctx):
+    """torch's legacy default stream has handle 0 -- "the context's own stream" to the C ABI, a
+    non-blocking stream that does not order itself behind torch's work.  The device helpers finish
+    the producers first: a surface still being written by queued torch kernels encodes to the same
+    bytes as one copied to the host and back."""
+    dev = torch.device("cuda", 0)
+    p = make_params(Format.BC1_RGB, Type.UNorm, 0)             # a fast kernel: it would overtake the producer
+    n = 2048
+    for seed in range(3):
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        x = torch.rand((n, n, 4), generator=g, device=dev)
+        for _ in range(6):                                      # a queue of dependent elementwise kernels
+            x = (x * 1.7 + 0.1).frac()
+        img = (x * 255.0).round().to(torch.uint8).contiguous()
+        got = shard.encode_rows_sharded_device(gpu_ctx, img, n, n, PixelType.RGBA8, p, 0, 1)
+        ref = gpu_ctx.encode([img.cpu().numpy()], p)[0]
+        assert np.array_equal(got.cpu().numpy(), ref), seed
 
 
 def _free_port():
