@@ -7,9 +7,10 @@
  * UNORM8 output = the top byte of the 16-bit interpolation result, as Mesa returns it.
  *
  * HDR profile (cfo_decode_astc_block_hdr): the interpolation and LNS -> half conversion of the
- * specification, with the HDR endpoint modes this backend emits (11 / 14 / 15 in their
- * direct sub-mode) plus the LDR modes; other HDR sub-modes return -1.  No independent HDR
- * decoder exists in this environment (Mesa is LDR-only): parity unpinned for that part.
+ * specification and every HDR endpoint mode (2, 3, 7, 11, 14, 15 with all their sub-modes) beside
+ * the LDR ones.  No independent HDR decoder exists in this environment (Mesa is LDR-only): the
+ * sub-modes are checked against a second, table-driven statement of the specification's
+ * bit-placement tables (tests/test_oracle_astc_hdr.py) -- parity unpinned for that part.
  */
 #include "astc_common.h"
 #include "cf_oracle.h"
@@ -41,8 +42,132 @@ static void blue_contract(int c[4])
 	c[1] = (c[1] + c[2]) >> 1;
 }
 
+/* ---- HDR endpoint modes (specification: "HDR endpoint mode 7 / 11 / 15"; values are 12-bit
+ * until the final << 4).  Written from the bit-placement tables of the specification;
+ * tests/test_oracle_astc_hdr.py re-derives every sub-mode from those tables in a second,
+ * table-driven formulation and compares. ---- */
+
+/* mode 7: base RGB + scale.  Six sub-modes: (red, green, blue, scale) bits 11 5 5 7 / 11 6 6 5 /
+ * 10 5 5 8 / 9 6 6 7 / 8 7 7 6 / 7 7 7 7; green and blue are differences from red except in
+ * sub-mode 5; the major component swaps into red's place */
+static void hdr_rgb_scale_unpack(const int* v, int e0[4], int e1[4])
+{
+	int v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+	int modeval = ((v0 & 0xC0) >> 6) | (((v1 & 0x80) >> 7) << 2) | (((v2 & 0x80) >> 7) << 3);
+	int majcomp, mode;
+	if ((modeval & 0xC) != 0xC) { majcomp = modeval >> 2; mode = modeval & 3; }
+	else if (modeval != 0xF) { majcomp = modeval & 3; mode = 4; }
+	else { majcomp = 0; mode = 5; }
+	int red = v0 & 0x3F, green = v1 & 0x1F, blue = v2 & 0x1F, scale = v3 & 0x1F;
+	int bit0 = (v1 >> 6) & 1, bit1 = (v1 >> 5) & 1, bit2 = (v2 >> 6) & 1, bit3 = (v2 >> 5) & 1;
+	int bit4 = (v3 >> 7) & 1, bit5 = (v3 >> 6) & 1, bit6 = (v3 >> 5) & 1;
+	int oh = 1 << mode;
+	if (oh & 0x30) green |= bit0 << 6;
+	if (oh & 0x3A) green |= bit1 << 5;
+	if (oh & 0x30) blue |= bit2 << 6;
+	if (oh & 0x3A) blue |= bit3 << 5;
+	if (oh & 0x3D) scale |= bit6 << 5;
+	if (oh & 0x2D) scale |= bit5 << 6;
+	if (oh & 0x04) scale |= bit4 << 7;
+	if (oh & 0x3B) red |= bit4 << 6;
+	if (oh & 0x04) red |= bit3 << 6;
+	if (oh & 0x10) red |= bit5 << 7;
+	if (oh & 0x0F) red |= bit2 << 7;
+	if (oh & 0x05) red |= bit1 << 8;
+	if (oh & 0x0A) red |= bit0 << 8;
+	if (oh & 0x05) red |= bit0 << 9;
+	if (oh & 0x02) red |= bit6 << 9;
+	if (oh & 0x01) red |= bit3 << 10;
+	if (oh & 0x02) red |= bit5 << 10;
+	static const int shamts[6] = {1, 1, 2, 3, 4, 5};
+	int sh = shamts[mode];
+	red <<= sh; green <<= sh; blue <<= sh; scale <<= sh;
+	if (mode != 5) { green = red - green; blue = red - blue; }
+	int t;
+	if (majcomp == 1) { t = red; red = green; green = t; }
+	if (majcomp == 2) { t = red; red = blue; blue = t; }
+	int r0 = red - scale, g0 = green - scale, b0 = blue - scale;
+	if (red < 0) red = 0;
+	if (green < 0) green = 0;
+	if (blue < 0) blue = 0;
+	if (r0 < 0) r0 = 0;
+	if (g0 < 0) g0 = 0;
+	if (b0 < 0) b0 = 0;
+	e0[0] = r0 << 4; e0[1] = g0 << 4; e0[2] = b0 << 4; e0[3] = 0x7800;
+	e1[0] = red << 4; e1[1] = green << 4; e1[2] = blue << 4; e1[3] = 0x7800;
+}
+
+/* mode 11 (and the RGB part of 14 / 15): major component 3 = the direct form; otherwise eight
+ * sub-modes a / b0,b1 / c / d0,d1 of 9 7 6 7, 9 8 6 6, 10 6 7 7, 10 7 7 6, 11 8 6 5, 11 6 8 6,
+ * 12 7 7 5, 12 6 7 6 bits */
+static void hdr_rgb_unpack(const int* v, int e0[4], int e1[4])
+{
+	int v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3], v4 = v[4], v5 = v[5];
+	int majcomp = ((v4 & 0x80) >> 7) | (((v5 & 0x80) >> 7) << 1);
+	if (majcomp == 3) {
+		e0[0] = v0 << 8; e0[1] = v2 << 8; e0[2] = (v4 & 0x7F) << 9;
+		e1[0] = v1 << 8; e1[1] = v3 << 8; e1[2] = (v5 & 0x7F) << 9;
+		return;
+	}
+	int mode = ((v1 & 0x80) >> 7) | (((v2 & 0x80) >> 7) << 1) | (((v3 & 0x80) >> 7) << 2);
+	int a = v0 | ((v1 & 0x40) << 2), b0 = v2 & 0x3F, b1 = v3 & 0x3F, c = v1 & 0x3F;
+	int d0 = v4 & 0x7F, d1 = v5 & 0x7F;
+	static const int dbits_tab[8] = {7, 6, 7, 6, 5, 6, 5, 6};
+	int dbits = dbits_tab[mode];
+	int bit0 = (v2 >> 6) & 1, bit1 = (v3 >> 6) & 1, bit2 = (v4 >> 6) & 1, bit3 = (v5 >> 6) & 1;
+	int bit4 = (v4 >> 5) & 1, bit5 = (v5 >> 5) & 1;
+	int oh = 1 << mode;
+	if (oh & 0xA4) a |= bit0 << 9;
+	if (oh & 0x08) a |= bit2 << 9;
+	if (oh & 0x50) a |= bit4 << 9;
+	if (oh & 0x50) a |= bit5 << 10;
+	if (oh & 0xA0) a |= bit1 << 10;
+	if (oh & 0xC0) a |= bit2 << 11;
+	if (oh & 0x04) c |= bit1 << 6;
+	if (oh & 0xE8) c |= bit3 << 6;
+	if (oh & 0x20) c |= bit2 << 7;
+	if (oh & 0x5B) { b0 |= bit0 << 6; b1 |= bit1 << 6; }
+	if (oh & 0x12) { b0 |= bit2 << 7; b1 |= bit3 << 7; }
+	/* d0, d1: the low dbits bits, sign-extended */
+	d0 &= (1 << dbits) - 1; d1 &= (1 << dbits) - 1;
+	if (d0 & (1 << (dbits - 1))) d0 -= 1 << dbits;
+	if (d1 & (1 << (dbits - 1))) d1 -= 1 << dbits;
+	int sh = (mode >> 1) ^ 3;
+	a <<= sh; b0 <<= sh; b1 <<= sh; c <<= sh; d0 *= 1 << sh; d1 *= 1 << sh;
+	int red1 = a, green1 = a - b0, blue1 = a - b1;
+	int red0 = a - c, green0 = a - b0 - c - d0, blue0 = a - b1 - c - d1;
+	int* q[6] = {&red0, &green0, &blue0, &red1, &green1, &blue1};
+	for (int k = 0; k < 6; ++k)
+		*q[k] = *q[k] < 0 ? 0 : (*q[k] > 4095 ? 4095 : *q[k]);
+	int t;
+	if (majcomp == 1) { t = red0; red0 = green0; green0 = t; t = red1; red1 = green1; green1 = t; }
+	if (majcomp == 2) { t = red0; red0 = blue0; blue0 = t; t = red1; red1 = blue1; blue1 = t; }
+	e0[0] = red0 << 4; e0[1] = green0 << 4; e0[2] = blue0 << 4;
+	e1[0] = red1 << 4; e1[1] = green1 << 4; e1[2] = blue1 << 4;
+}
+
+/* the alpha pair of mode 15: selector 3 = two 7-bit values; 0..2 = base + signed offset */
+static void hdr_alpha_unpack(int v6, int v7, int* a0, int* a1)
+{
+	int selector = ((v6 >> 7) & 1) | ((v7 >> 6) & 2);
+	v6 &= 0x7F; v7 &= 0x7F;
+	if (selector == 3) {
+		*a0 = v6 << 9; *a1 = v7 << 9;
+		return;
+	}
+	v6 |= (v7 << (selector + 1)) & 0x780;
+	v7 &= 0x3F >> selector;
+	v7 ^= 32 >> selector;
+	v7 -= 32 >> selector;
+	v6 <<= 4 - selector;
+	v7 <<= 4 - selector;
+	v7 += v6;
+	v7 = v7 < 0 ? 0 : (v7 > 0xFFF ? 0xFFF : v7);
+	*a0 = v6 << 4; *a1 = v7 << 4;
+}
+
 /* endpoint pair of one partition; returns 0 LDR, 1 HDR rgb + HDR alpha, 2 HDR rgb + LDR alpha,
- * -1 HDR sub-mode not modelled.  LDR values 0..255; HDR values 16-bit LNS. */
+ * -1 reserved.  LDR values 0..255; HDR values 16-bit LNS. */
 static int unpack_endpoints(int cem, const int* v, int e0[4], int e1[4])
 {
 	switch (cem) {
@@ -116,25 +241,45 @@ static int unpack_endpoints(int cem, const int* v, int e0[4], int e1[4])
 			}
 			return 0;
 		}
-		case 11:
-		case 14:
-		case 15: {
-			/* HDR RGB direct: only the sub-mode with major component 3 (both top bits of v4, v5
-			 * set): the six values are the top 8 bits (blue: 7 bits) of the 16-bit LNS endpoints */
-			if (!((v[4] & 0x80) && (v[5] & 0x80)))
-				return -1;
-			e0[0] = v[0] << 8; e0[1] = v[2] << 8; e0[2] = (v[4] & 0x7F) << 9;
-			e1[0] = v[1] << 8; e1[1] = v[3] << 8; e1[2] = (v[5] & 0x7F) << 9;
-			if (cem == 11) { e0[3] = e1[3] = 0x7800; return 1; }
-			if (cem == 14) { e0[3] = v[6]; e1[3] = v[7]; return 2; }
-			if (!((v[6] & 0x80) && (v[7] & 0x80)))
-				return -1;                      /* HDR alpha: only the direct selector (3) */
-			e0[3] = (v[6] & 0x7F) << 9; e1[3] = (v[7] & 0x7F) << 9;
+		case 2: {
+			/* HDR luminance, large range (specification, "HDR endpoint mode 2") */
+			int y0, y1;
+			if (v[1] >= v[0]) { y0 = v[0] << 4; y1 = v[1] << 4; }
+			else { y0 = (v[1] << 4) + 8; y1 = (v[0] << 4) - 8; }
+			e0[0] = e0[1] = e0[2] = y0 << 4; e0[3] = 0x7800;
+			e1[0] = e1[1] = e1[2] = y1 << 4; e1[3] = 0x7800;
 			return 1;
 		}
+		case 3: {
+			/* HDR luminance, small range: 2 or 1 fraction bits, 5- or 4-bit offset */
+			int y0, d;
+			if (v[0] & 0x80) { y0 = ((v[1] & 0xE0) << 4) | ((v[0] & 0x7F) << 2); d = (v[1] & 0x1F) << 2; }
+			else { y0 = ((v[1] & 0xF0) << 4) | ((v[0] & 0x7F) << 1); d = (v[1] & 0x0F) << 1; }
+			int y1 = y0 + d > 0xFFF ? 0xFFF : y0 + d;
+			e0[0] = e0[1] = e0[2] = y0 << 4; e0[3] = 0x7800;
+			e1[0] = e1[1] = e1[2] = y1 << 4; e1[3] = 0x7800;
+			return 1;
+		}
+		case 7:
+			hdr_rgb_scale_unpack(v, e0, e1);
+			return 1;
+		case 11:
+		case 14:
+		case 15:
+			hdr_rgb_unpack(v, e0, e1);
+			if (cem == 11) { e0[3] = e1[3] = 0x7800; return 1; }
+			if (cem == 14) { e0[3] = v[6]; e1[3] = v[7]; return 2; }
+			hdr_alpha_unpack(v[6], v[7], &e0[3], &e1[3]);
+			return 1;
 		default:
 			return -1;
 	}
+}
+
+/* test hook: the endpoint pair a value list decodes to (LDR 0..255, HDR 16-bit LNS) */
+int cfo_astc_unpack_endpoints(int cem, const int* v, int* e0, int* e1)
+{
+	return unpack_endpoints(cem, v, e0, e1);
 }
 
 static uint16_t lns_to_half(int c)

@@ -1,6 +1,5 @@
 """ASTC under the HDR profiles (Type::UFloat, lib/src/AstcConverter.cpp:150-162): the oracle encodes
-HDR blocks with the endpoint modes 11 / 14 / 15 in their direct sub-mode, searching in the top 8
-bits of the LNS domain.  No independent HDR ASTC decoder exists in this environment (Mesa's is
+HDR blocks with the endpoint modes 11 / 14 / 15.  No independent HDR ASTC decoder exists in this environment (Mesa's is
 LDR only), so this leg is pinned only to the oracle's own from-specification decoder -- "parity
 unpinned", stated in DESIGN.md; the tests check range, field use and self-consistency."""
 import ctypes
@@ -105,3 +104,161 @@ def test_ldr_profile_is_untouched_by_the_hdr_flags():
     assert O.decode_astc(a, int(Format.ASTC_6x6), 36, 24)[1] == 0
     cem = _cems(a)
     assert not (set(cem[cem >= 0]) & {11, 14, 15})
+
+
+# ---- every HDR endpoint sub-mode of the decoder against the specification's bit-placement tables ----
+# The C decoder (oracle/astc_decode.c) extracts the fields with one-hot masks; this side PLACES
+# them, straight from the tables: which bit of which field each variable-placement position X_k
+# carries in each sub-mode.  A field is ("a", 9) = bit 9 of a.
+
+_M11_BITS = [(9, 7, 6, 7), (9, 8, 6, 6), (10, 6, 7, 7), (10, 7, 7, 6), (11, 8, 6, 5), (11, 6, 8, 6), (12, 7, 7, 5), (12, 6, 7, 6)]
+# X0 = v2 bit 6, X1 = v3 bit 6, X2 = v4 bit 6, X3 = v5 bit 6, X4 = v4 bit 5, X5 = v5 bit 5
+_M11_X = [
+    [("b0", 6), ("b1", 6), ("d0", 6), ("d1", 6), ("d0", 5), ("d1", 5)],
+    [("b0", 6), ("b1", 6), ("b0", 7), ("b1", 7), ("d0", 5), ("d1", 5)],
+    [("a", 9), ("c", 6), ("d0", 6), ("d1", 6), ("d0", 5), ("d1", 5)],
+    [("b0", 6), ("b1", 6), ("a", 9), ("c", 6), ("d0", 5), ("d1", 5)],
+    [("b0", 6), ("b1", 6), ("b0", 7), ("b1", 7), ("a", 9), ("a", 10)],
+    [("a", 9), ("a", 10), ("c", 7), ("c", 6), ("d0", 5), ("d1", 5)],
+    [("b0", 6), ("b1", 6), ("a", 11), ("c", 6), ("a", 9), ("a", 10)],
+    [("a", 9), ("a", 10), ("a", 11), ("c", 6), ("d0", 5), ("d1", 5)],
+]
+
+
+def _unpack(cem, v):
+    L = O.lib()
+    arr = (ctypes.c_int*8)(*(list(v) + [0]*(8 - len(v))))
+    e0, e1 = (ctypes.c_int*4)(), (ctypes.c_int*4)()
+    L.cfo_astc_unpack_endpoints.restype = ctypes.c_int
+    kind = L.cfo_astc_unpack_endpoints(cem, arr, e0, e1)
+    return kind, list(e0), list(e1)
+
+
+def _place_mode11(mode, maj, f):
+    """fields (two's-complement d0 / d1 in their dbits) -> v0..v5"""
+    bit = lambda name, k: (f[name] >> k) & 1
+    v = [0]*6
+    v[0] = f["a"] & 0xFF
+    v[1] = ((mode & 1) << 7) | (bit("a", 8) << 6) | (f["c"] & 0x3F)
+    v[2] = (((mode >> 1) & 1) << 7) | (f["b0"] & 0x3F)
+    v[3] = (((mode >> 2) & 1) << 7) | (f["b1"] & 0x3F)
+    v[4] = ((maj & 1) << 7) | (f["d0"] & 0x1F)
+    v[5] = (((maj >> 1) & 1) << 7) | (f["d1"] & 0x1F)
+    pos = [(2, 6), (3, 6), (4, 6), (5, 6), (4, 5), (5, 5)]
+    for (vi, bi), (name, k) in zip(pos, _M11_X[mode]):
+        v[vi] |= bit(name, k) << bi
+    return v
+
+
+def test_mode_11_submodes_against_the_placement_table():
+    rng = np.random.default_rng(11)
+    for mode in range(8):
+        ab, bb, cb, db = _M11_BITS[mode]
+        sh = 12 - ab
+        assert sh == (mode >> 1) ^ 3
+        for maj in range(3):
+            for _ in range(200):
+                a, b0, b1, c = (int(rng.integers(0, 1 << n)) for n in (ab, bb, bb, cb))
+                d0, d1 = (int(rng.integers(-(1 << (db - 1)), 1 << (db - 1))) for _ in range(2))
+                f = {"a": a, "b0": b0, "b1": b1, "c": c, "d0": d0 & ((1 << db) - 1), "d1": d1 & ((1 << db) - 1)}
+                v = _place_mode11(mode, maj, f)
+                A, B0, B1, C, D0, D1 = (x << sh for x in (a, b0, b1, c, d0, d1))
+                hi = [A, A - B0, A - B1]
+                lo = [A - C, A - B0 - C - D0, A - B1 - C - D1]
+                cl = lambda x: min(max(x, 0), 4095) << 4
+                hi, lo = [cl(x) for x in hi], [cl(x) for x in lo]
+                if maj:                                    # the major component takes red's place
+                    hi[0], hi[maj] = hi[maj], hi[0]
+                    lo[0], lo[maj] = lo[maj], lo[0]
+                kind, e0, e1 = _unpack(11, v)
+                assert kind == 1 and e0[:3] == lo and e1[:3] == hi and e0[3] == e1[3] == 0x7800, (mode, maj, f)
+
+
+def test_mode_11_known_answers_by_hand():
+    # sub-mode 7 (12-bit a, shift 0), major component 0: a = 0xABC, b0 = 5, b1 = 9, c = 0x21, d0 = -3, d1 = 2
+    #   v0 = 0xBC; v1 = m0 1 | a8 (0xABC >> 8 & 1 = 0) | c[5:0] 0x21            = 0xA1
+    #   v2 = m1 1 | X0 = a9 (1) | b0 = 5                                          = 0xC5
+    #   v3 = m2 1 | X1 = a10 (0) | b1 = 9                                         = 0x89
+    #   v4 = maj0 0 | X2 = a11 (1) | X4 = d0 bit 5 (-3 = 0b111101 -> 1) | 0b11101 = 0x7D
+    #   v5 = maj1 0 | X3 = c6 (0) | X5 = d1 bit 5 (0) | 0b00010                   = 0x02
+    kind, e0, e1 = _unpack(11, [0xBC, 0xA1, 0xC5, 0x89, 0x7D, 0x02])
+    a, b0, b1, c, d0, d1 = 0xABC, 5, 9, 0x21, -3, 2
+    assert e1[:3] == [a << 4, (a - b0) << 4, (a - b1) << 4]
+    assert e0[:3] == [(a - c) << 4, (a - b0 - c - d0) << 4, (a - b1 - c - d1) << 4]
+    assert e1[:3] == [43968, 43888, 43824] and e0[:3] == [43440, 43408, 43264]
+    # the direct form (major component 3): six values, blue on 7 bits
+    kind, e0, e1 = _unpack(11, [0x12, 0x34, 0x56, 0x78, 0x80 | 0x1A, 0x80 | 0x7F])
+    assert kind == 1 and e0 == [0x1200, 0x5600, 0x1A << 9, 0x7800] and e1 == [0x3400, 0x7800, 0x7F << 9, 0x7800]
+    # sub-mode 0, major component 2 (blue leads): a = 0x1FF (9 bits, shift 3), all differences zero
+    #   v0 = 0xFF, v1 = 0 | a8 1 << 6 | 0 = 0x40, v2 = v3 = 0, v4 = 0x00, v5 = 0x80
+    kind, e0, e1 = _unpack(11, [0xFF, 0x40, 0, 0, 0x00, 0x80])
+    assert e0[:3] == e1[:3] == [(0x1FF << 3) << 4]*3
+
+
+_M7_BITS = [(11, 5, 5, 7), (11, 6, 6, 5), (10, 5, 5, 8), (9, 6, 6, 7), (8, 7, 7, 6), (7, 7, 7, 7)]
+# X0 = v1 bit 6, X1 = v1 bit 5, X2 = v2 bit 6, X3 = v2 bit 5, X4 = v3 bit 7, X5 = v3 bit 6, X6 = v3 bit 5
+_M7_X = [
+    [("r", 9), ("r", 8), ("r", 7), ("r", 10), ("r", 6), ("s", 6), ("s", 5)],
+    [("r", 8), ("g", 5), ("r", 7), ("b", 5), ("r", 6), ("r", 10), ("r", 9)],
+    [("r", 9), ("r", 8), ("r", 7), ("r", 6), ("s", 7), ("s", 6), ("s", 5)],
+    [("r", 8), ("g", 5), ("r", 7), ("b", 5), ("r", 6), ("s", 6), ("s", 5)],
+    [("g", 6), ("g", 5), ("b", 6), ("b", 5), ("r", 6), ("r", 7), ("s", 5)],
+    [("g", 6), ("g", 5), ("b", 6), ("b", 5), ("r", 6), ("s", 6), ("s", 5)],
+]
+
+
+def test_mode_7_submodes_against_the_placement_table():
+    rng = np.random.default_rng(7)
+    for mode in range(6):
+        rb, gb_, bb, sb = _M7_BITS[mode]
+        sh = [1, 1, 2, 3, 4, 5][mode]
+        assert rb + sh == 12
+        for maj in range(3 if mode < 5 else 1):
+            # the four mode bits M0..M3: sub-modes 0-3 = major component << 2 | mode; 4 = 0b11xx with xx = major
+            # component; 5 = 0b1111
+            mv = (maj << 2 | mode) if mode < 4 else ((0xC | maj) if mode == 4 else 0xF)
+            for _ in range(200):
+                f = {"r": int(rng.integers(0, 1 << rb)), "g": int(rng.integers(0, 1 << gb_)),
+                     "b": int(rng.integers(0, 1 << bb)), "s": int(rng.integers(0, 1 << sb))}
+                bit = lambda name, k: (f[name] >> k) & 1
+                v = [((mv & 3) << 6) | (f["r"] & 0x3F), (((mv >> 2) & 1) << 7) | (f["g"] & 0x1F),
+                     (((mv >> 3) & 1) << 7) | (f["b"] & 0x1F), f["s"] & 0x1F]
+                pos = [(1, 6), (1, 5), (2, 6), (2, 5), (3, 7), (3, 6), (3, 5)]
+                for (vi, bi), (name, k) in zip(pos, _M7_X[mode]):
+                    v[vi] |= bit(name, k) << bi
+                R, G, B, S = (f[k] << sh for k in "rgbs")
+                if mode != 5:
+                    G, B = R - G, R - B
+                hi = [R, G, B]
+                if maj:
+                    hi[0], hi[maj] = hi[maj], hi[0]
+                lo = [max(x - S, 0) << 4 for x in hi]
+                hi = [max(x, 0) << 4 for x in hi]
+                kind, e0, e1 = _unpack(7, v)
+                assert kind == 1 and e0[:3] == lo and e1[:3] == hi and e0[3] == e1[3] == 0x7800, (mode, maj, f)
+
+
+def test_hdr_luminance_and_alpha_modes_known_answers():
+    # mode 2: v1 >= v0 -> (v0 << 4, v1 << 4) as 12-bit values; else the half-step form
+    assert _unpack(2, [0x10, 0x20])[1:] == ([0x1000]*3 + [0x7800], [0x2000]*3 + [0x7800])
+    assert _unpack(2, [0x20, 0x10])[1:] == ([((0x10 << 4) + 8) << 4]*3 + [0x7800], [((0x20 << 4) - 8) << 4]*3 + [0x7800])
+    # mode 3, v0 bit 7 set: y0 = v1[7:5] << 9 | v0[6:0] << 2, d = v1[4:0] << 2
+    k, e0, e1 = _unpack(3, [0x80 | 0x55, 0xA0 | 0x13])
+    y0 = ((0xA0 | 0x13) & 0xE0) << 4 | 0x55 << 2
+    assert e0[:3] == [y0 << 4]*3 and e1[:3] == [(y0 + (0x13 << 2)) << 4]*3
+    # mode 3, v0 bit 7 clear: y0 = v1[7:4] << 8 | v0 << 1, d = v1[3:0] << 1; y1 saturates at 0xFFF
+    k, e0, e1 = _unpack(3, [0x7F, 0xFF])
+    assert e0[0] == (0xF00 | 0xFE) << 4 and e1[0] == 0xFFF << 4
+    # mode 15 alpha, selector 3 (both top bits set): two 7-bit values << 9
+    k, e0, e1 = _unpack(15, [0, 0, 0, 0, 0x80, 0x80, 0x80 | 0x3C, 0x80 | 0x41])
+    assert (e0[3], e1[3]) == (0x3C << 9, 0x41 << 9)
+    # selector 0 (v6 bit 7 = 0, v7 bit 7 = 0): base = v6[6:0] | v7[6] << 7 (8 bits) << 4, offset = v7[5:0]
+    # signed 6 bits << 4:  v6 = 0x35, v7 = 0x40 | 0x3E (offset -2) -> base 0xB5 << 4 = 0xB50, end 0xB50 - 0x20
+    k, e0, e1 = _unpack(15, [0, 0, 0, 0, 0x80, 0x80, 0x35, 0x40 | 0x3E])
+    assert (e0[3], e1[3]) == (0xB50 << 4, (0xB50 - 0x20) << 4)
+    # selector 1 (v6 bit 7 = 1, v7 bit 7 = 0): base 9 bits (v6[6:0] | v7[6:5] << 7) << 3, offset v7[4:0] signed << 3
+    k, e0, e1 = _unpack(15, [0, 0, 0, 0, 0x80, 0x80, 0x80 | 0x11, 0x60 | 0x05])
+    assert (e0[3], e1[3]) == (((0x11 | 3 << 7) << 3) << 4, (((0x11 | 3 << 7) << 3) + (5 << 3)) << 4)
+    # selector 2 (v6 bit 7 = 0, v7 bit 7 = 1): base 10 bits (v6[6:0] | v7[6:4] << 7) << 2, offset v7[3:0] signed << 2
+    k, e0, e1 = _unpack(15, [0, 0, 0, 0, 0x80, 0x80, 0x7F, 0x80 | 0x70 | 0x9])
+    assert (e0[3], e1[3]) == ((0x3FF << 2) << 4, ((0x3FF << 2) + ((9 - 16) << 2)) << 4)
