@@ -261,9 +261,9 @@ __device__ __forceinline__ int quant_hi(const Shared& sh, uint32_t lv, float x, 
 	return (int)((sh.cunq[lv*256u + stored] & 0x7Fu) << 1);
 }
 
-// HDR profile (oracle: cfo_astc_hdr_code): a channel is searched as the top 8 bits of its 16-bit
-// LNS value, code = round(LNS16(half(x)) / 256); negative / NaN -> 0, beyond 65504 -> 65504
-__device__ __forceinline__ uint32_t hdr_code(float x)
+// HDR profile: the 16-bit LNS value of a channel (oracle: cfo_astc_lns16 of the half; negative / NaN -> 0,
+// beyond 65504 -> 0x7BFF)
+__device__ __forceinline__ uint32_t hdr_lns16(float x)
 {
 	if (!(x > 0.0f))
 		return 0u;
@@ -272,14 +272,13 @@ __device__ __forceinline__ uint32_t hdr_code(float x)
 	const uint32_t e = hb >> 10, m10 = hb & 1023u;
 	uint32_t m = m10 < 192u ? (8u*m10 + 1u)/3u : (m10 < 704u ? 2u*m10 + 128u : (8u*m10 + 2050u)/5u);
 	m = m > 2047u ? 2047u : m;
-	const uint32_t c = (((e << 11) | m) + 128u) >> 8;
-	return c > 255u ? 255u : c;
+	return (e << 11) | m;
 }
 
-// the half an 8-bit LNS code decodes to (specification: LNS -> half; oracle: lns_code_to_half)
-__device__ __forceinline__ uint32_t lns_code_to_half(uint32_t code)
+// the half a 16-bit LNS value decodes to (specification: LNS -> half; oracle: lns16_to_half)
+__device__ __forceinline__ uint32_t lns16_to_half(uint32_t c)
 {
-	const uint32_t c = code << 8, e = c >> 11, m = c & 0x7FFu;
+	const uint32_t e = c >> 11, m = c & 0x7FFu;
 	const uint32_t mt = m < 512u ? 3u*m : (m < 1536u ? 4u*m - 512u : 5u*m - 2048u);
 	const uint32_t hb = (e << 10) + (mt >> 3);
 	return hb > 0x7BFFu ? 0x7BFFu : hb;
@@ -287,12 +286,17 @@ __device__ __forceinline__ uint32_t lns_code_to_half(uint32_t code)
 
 __device__ __forceinline__ uint4 void_extent(uint32_t r, uint32_t g, uint32_t b, uint32_t a, uint32_t hdrf)
 {
-	if (!hdrf)
-		return make_uint4(0xFFFFFDFCu, 0xFFFFFFFFu, (r*257u) | ((g*257u) << 16), (b*257u) | ((a*257u) << 16));
-	const uint32_t ha = (hdrf & 2u) ? lns_code_to_half(a)
-		: (uint32_t)__half_as_ushort(__float2half_rn((float)a*(1.0f/255.0f)));
-	return make_uint4(0xFFFFFFFCu, 0xFFFFFFFFu, lns_code_to_half(r) | (lns_code_to_half(g) << 16),
-		lns_code_to_half(b) | (ha << 16));
+	(void)hdrf;
+	return make_uint4(0xFFFFFDFCu, 0xFFFFFFFFu, (r*257u) | ((g*257u) << 16), (b*257u) | ((a*257u) << 16));
+}
+
+// HDR void extent (header bit 9): four halves from 16-bit LNS values (LDR alpha: 0..255)
+__device__ __forceinline__ uint4 void_extent_lns(uint32_t l0, uint32_t l1, uint32_t l2, uint32_t l3, uint32_t hdrf)
+{
+	const uint32_t ha = (hdrf & 2u) ? lns16_to_half(l3)
+		: (uint32_t)__half_as_ushort(__float2half_rn((float)l3*(1.0f/255.0f)));
+	return make_uint4(0xFFFFFFFCu, 0xFFFFFFFFu, lns16_to_half(l0) | (lns16_to_half(l1) << 16),
+		lns16_to_half(l2) | (ha << 16));
 }
 
 // The least-squares system of one partition as cem_option needs it: the pair (r0, r1) per channel and
@@ -571,6 +575,176 @@ __device__ __forceinline__ unsigned long long ise_group(const uint8_t* ise, cons
 	return out;
 }
 
+// ---- HDR endpoint refinement (oracle: hdr_refine and its helpers, same arithmetic) ----------------
+// nearest stored value to v among those that keep the bits of himask; -1: the level has none
+__device__ __forceinline__ int requant_keep(const Shared& sh, uint32_t lv, int v, int himask)
+{
+	const int lo = v & himask, hi = lo | (~himask & 0xFF);
+	int q = (int)sh.cnear[lv*256u + (uint32_t)v], u = (int)sh.cunq[lv*256u + (uint32_t)q];
+	if (u >= lo && u <= hi)
+		return q;
+	for (int d = 1; d < 128; ++d) {
+		int x = v - d;
+		if (x >= lo) {
+			q = (int)sh.cnear[lv*256u + (uint32_t)x]; u = (int)sh.cunq[lv*256u + (uint32_t)q];
+			if (u >= lo && u <= hi) return q;
+		}
+		x = v + d;
+		if (x <= hi) {
+			q = (int)sh.cnear[lv*256u + (uint32_t)x]; u = (int)sh.cunq[lv*256u + (uint32_t)q];
+			if (u >= lo && u <= hi) return q;
+		}
+	}
+	return -1;
+}
+
+__device__ __forceinline__ int rs_u(int x, int sh) { return x <= 0 ? 0 : (x + ((1 << sh) >> 1)) >> sh; }
+__device__ __forceinline__ int rs_s(int x, int sh) { return (x + ((1 << sh) >> 1)) >> sh; }
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+__device__ __forceinline__ int sel3(int i, int a0, int a1, int a2) { return i == 0 ? a0 : (i == 1 ? a1 : a2); }
+
+// mode 11 value list of the 12-bit pair (E0, E1): k = 0 the direct form (from the 16-bit fit), k = 1 + sub-mode
+__device__ __forceinline__ void hdr_rgb_place(int k, const int (&E0)[4], const int (&E1)[4], const double (&r0)[4], const double (&r1)[4],
+	int (&v)[6], int (&hm)[6])
+{
+	if (k == 0) {
+#pragma unroll
+		for (int c = 0; c < 2; ++c) {
+			v[2*c] = clampi((int)floor(r0[c]*(1.0/256.0) + 0.5), 0, 255);
+			v[2*c + 1] = clampi((int)floor(r1[c]*(1.0/256.0) + 0.5), 0, 255);
+			hm[2*c] = hm[2*c + 1] = 0;
+		}
+		v[4] = 0x80 | clampi((int)floor(r0[2]*(1.0/512.0) + 0.5), 0, 127);
+		v[5] = 0x80 | clampi((int)floor(r1[2]*(1.0/512.0) + 0.5), 0, 127);
+		hm[4] = hm[5] = 0x80;
+		return;
+	}
+	const int m = k - 1;
+	// a / b / c / d bits of sub-mode m: 9 7 6 7, 9 8 6 6, 10 6 7 7, 10 7 7 6, 11 8 6 5, 11 6 8 6, 12 7 7 5, 12 6 7 6 (nibbles)
+	const int ab = 9 + (m >> 1);
+	const int bb = (int)((0x67687687u >> (4*m)) & 15u), cb = (int)((0x77867766u >> (4*m)) & 15u), db = (int)((0x65656767u >> (4*m)) & 15u);
+	const int sh = 12 - ab;
+	int maj = 0;
+	if (E1[1] > E1[maj]) maj = 1;
+	if (E1[2] > sel3(maj, E1[0], E1[1], E1[2])) maj = 2;
+	// channel order: the major component takes red's place
+	const int c0 = maj, c1 = maj == 1 ? 0 : 1, c2 = maj == 2 ? 0 : 2;
+	const int h0 = sel3(c0, E1[0], E1[1], E1[2]), h1 = sel3(c1, E1[0], E1[1], E1[2]), h2 = sel3(c2, E1[0], E1[1], E1[2]);
+	const int l0 = sel3(c0, E0[0], E0[1], E0[2]), l1 = sel3(c1, E0[0], E0[1], E0[2]), l2 = sel3(c2, E0[0], E0[1], E0[2]);
+	const int a = clampi(rs_u(h0, sh), 0, (1 << ab) - 1), aq = a << sh;
+	const int c = clampi(rs_u(aq - l0, sh), 0, (1 << cb) - 1), cq = c << sh;
+	const int b0 = clampi(rs_u(aq - h1, sh), 0, (1 << bb) - 1), b1 = clampi(rs_u(aq - h2, sh), 0, (1 << bb) - 1);
+	const int dl = -(1 << (db - 1)), dh = (1 << (db - 1)) - 1;
+	const int d0 = clampi(rs_s(aq - (b0 << sh) - cq - l1, sh), dl, dh);
+	const int d1 = clampi(rs_s(aq - (b1 << sh) - cq - l2, sh), dl, dh);
+	const int d0u = d0 & ((1 << db) - 1), d1u = d1 & ((1 << db) - 1), oh = 1 << m;
+#define ASTC_BIT(x, n) (((x) >> (n)) & 1)
+	const int X0 = (oh & 0xA4) ? ASTC_BIT(a, 9) : ASTC_BIT(b0, 6);
+	const int X1 = (oh & 0xA0) ? ASTC_BIT(a, 10) : ((oh & 0x04) ? ASTC_BIT(c, 6) : ASTC_BIT(b1, 6));
+	const int X2 = (oh & 0x08) ? ASTC_BIT(a, 9) : ((oh & 0xC0) ? ASTC_BIT(a, 11) : ((oh & 0x20) ? ASTC_BIT(c, 7) : ((oh & 0x12) ? ASTC_BIT(b0, 7) : ASTC_BIT(d0u, 6))));
+	const int X3 = (oh & 0xE8) ? ASTC_BIT(c, 6) : ((oh & 0x12) ? ASTC_BIT(b1, 7) : ASTC_BIT(d1u, 6));
+	const int X4 = (oh & 0x50) ? ASTC_BIT(a, 9) : ASTC_BIT(d0u, 5);
+	const int X5 = (oh & 0x50) ? ASTC_BIT(a, 10) : ASTC_BIT(d1u, 5);
+	v[0] = a & 0xFF;
+	v[1] = ((m & 1) << 7) | (ASTC_BIT(a, 8) << 6) | (c & 0x3F);
+	v[2] = (((m >> 1) & 1) << 7) | (X0 << 6) | (b0 & 0x3F);
+	v[3] = (((m >> 2) & 1) << 7) | (X1 << 6) | (b1 & 0x3F);
+	v[4] = ((maj & 1) << 7) | (X2 << 6) | (X4 << 5) | (d0u & 0x1F);
+	v[5] = (((maj >> 1) & 1) << 7) | (X3 << 6) | (X5 << 5) | (d1u & 0x1F);
+#undef ASTC_BIT
+	// v4 / v5 keep: 0x80, 0xC0, 0x80, 0xC0, 0xE0, 0xC0, 0xE0, 0xC0
+	const int dm = (m == 4 || m == 6) ? 0xE0 : ((m & 1) ? 0xC0 : 0x80);
+	hm[0] = 0; hm[1] = 0xC0; hm[2] = hm[3] = 0xC0; hm[4] = hm[5] = dm;
+}
+
+// what a mode 11 value list decodes to (oracle/astc_decode.c hdr_rgb_unpack; 16-bit LNS endpoints)
+__device__ __forceinline__ void hdr_rgb_unpack(const int (&v)[6], int (&e0)[3], int (&e1)[3])
+{
+	const int majcomp = ((v[4] & 0x80) >> 7) | (((v[5] & 0x80) >> 7) << 1);
+	if (majcomp == 3) {
+		e0[0] = v[0] << 8; e0[1] = v[2] << 8; e0[2] = (v[4] & 0x7F) << 9;
+		e1[0] = v[1] << 8; e1[1] = v[3] << 8; e1[2] = (v[5] & 0x7F) << 9;
+		return;
+	}
+	const int mode = ((v[1] & 0x80) >> 7) | (((v[2] & 0x80) >> 7) << 1) | (((v[3] & 0x80) >> 7) << 2);
+	int a = v[0] | ((v[1] & 0x40) << 2), b0 = v[2] & 0x3F, b1 = v[3] & 0x3F, c = v[1] & 0x3F;
+	int d0 = v[4] & 0x7F, d1 = v[5] & 0x7F;
+	const int dbits = (int)((0x65656767u >> (4*mode)) & 15u);
+	const int bit0 = (v[2] >> 6) & 1, bit1 = (v[3] >> 6) & 1, bit2 = (v[4] >> 6) & 1, bit3 = (v[5] >> 6) & 1;
+	const int bit4 = (v[4] >> 5) & 1, bit5 = (v[5] >> 5) & 1;
+	const int oh = 1 << mode;
+	if (oh & 0xA4) a |= bit0 << 9;
+	if (oh & 0x08) a |= bit2 << 9;
+	if (oh & 0x50) a |= bit4 << 9;
+	if (oh & 0x50) a |= bit5 << 10;
+	if (oh & 0xA0) a |= bit1 << 10;
+	if (oh & 0xC0) a |= bit2 << 11;
+	if (oh & 0x04) c |= bit1 << 6;
+	if (oh & 0xE8) c |= bit3 << 6;
+	if (oh & 0x20) c |= bit2 << 7;
+	if (oh & 0x5B) { b0 |= bit0 << 6; b1 |= bit1 << 6; }
+	if (oh & 0x12) { b0 |= bit2 << 7; b1 |= bit3 << 7; }
+	d0 &= (1 << dbits) - 1; d1 &= (1 << dbits) - 1;
+	if (d0 & (1 << (dbits - 1))) d0 -= 1 << dbits;
+	if (d1 & (1 << (dbits - 1))) d1 -= 1 << dbits;
+	const int sh = (mode >> 1) ^ 3;
+	a <<= sh; b0 <<= sh; b1 <<= sh; c <<= sh; d0 *= 1 << sh; d1 *= 1 << sh;
+	int red1 = clampi(a, 0, 4095), green1 = clampi(a - b0, 0, 4095), blue1 = clampi(a - b1, 0, 4095);
+	int red0 = clampi(a - c, 0, 4095), green0 = clampi(a - b0 - c - d0, 0, 4095), blue0 = clampi(a - b1 - c - d1, 0, 4095);
+	int t;
+	if (majcomp == 1) { t = red0; red0 = green0; green0 = t; t = red1; red1 = green1; green1 = t; }
+	if (majcomp == 2) { t = red0; red0 = blue0; blue0 = t; t = red1; red1 = blue1; blue1 = t; }
+	e0[0] = red0 << 4; e0[1] = green0 << 4; e0[2] = blue0 << 4;
+	e1[0] = red1 << 4; e1[1] = green1 << 4; e1[2] = blue1 << 4;
+}
+
+// mode 15 alpha pair: selector 3 = two 7-bit values, 0..2 = base (8 + s bits) + signed offset (6 - s bits)
+__device__ __forceinline__ void hdr_alpha_place(int sel, int A0, int A1, double r0, double r1, int& v6, int& v7, int& hm6, int& hm7)
+{
+	if (sel == 3) {
+		v6 = 0x80 | clampi((int)floor(r0*(1.0/512.0) + 0.5), 0, 127);
+		v7 = 0x80 | clampi((int)floor(r1*(1.0/512.0) + 0.5), 0, 127);
+		hm6 = hm7 = 0x80;
+		return;
+	}
+	const int sh = 4 - sel, base = clampi(rs_u(A0, sh), 0, (1 << (8 + sel)) - 1);
+	const int off = clampi(rs_s(A1 - (base << sh), sh), -(1 << (5 - sel)), (1 << (5 - sel)) - 1);
+	v6 = ((sel & 1) << 7) | (base & 0x7F);
+	v7 = (((sel >> 1) & 1) << 7) | ((base >> 7) << (6 - sel)) | (off & (0x3F >> sel));
+	hm6 = 0x80;
+	hm7 = 0x80 | (0x7F & ~(0x3F >> sel));
+}
+
+__device__ __forceinline__ void hdr_alpha_unpack(int v6, int v7, int& a0, int& a1)
+{
+	const int selector = ((v6 >> 7) & 1) | ((v7 >> 6) & 2);
+	v6 &= 0x7F; v7 &= 0x7F;
+	if (selector == 3) {
+		a0 = v6 << 9; a1 = v7 << 9;
+		return;
+	}
+	v6 |= (v7 << (selector + 1)) & 0x780;
+	v7 &= 0x3F >> selector;
+	v7 ^= 32 >> selector;
+	v7 -= 32 >> selector;
+	v6 <<= 4 - selector;
+	v7 <<= 4 - selector;
+	v7 += v6;
+	v7 = v7 < 0 ? 0 : (v7 > 0xFFF ? 0xFFF : v7);
+	a0 = v6 << 4; a1 = v7 << 4;
+}
+
+__device__ __forceinline__ double quad_est_d(double fA, double fB, double fC, double d0, double d1)
+{
+	double t = fA*d0;
+	t = t + fB*d1;
+	double u = fB*d0;
+	u = u + fC*d1;
+	double q = t*d0;
+	q = q + u*d1;
+	return q;
+}
+
 typedef unsigned short astc_us2 __attribute__((ext_vector_type(2)));
 typedef short astc_s2 __attribute__((ext_vector_type(2)));
 
@@ -601,7 +775,7 @@ __device__ __forceinline__ int sdot2_i16(uint32_t a, uint32_t b, int acc)
 // most waves on a CU within the 160 KB of LDS -- the kernel is latency bound (dependent LDS
 // gathers, cross-lane reductions), so the third wave per SIMD is worth more than the registers it
 // costs.  MAXW is the launch bound: 12 waves cap the kernel at 168 VGPRs, 8 waves leave it 256.
-template <int PIX, int MAXW>
+template <int PIX, int MAXW, bool HDR>
 __global__ void __launch_bounds__(MAXW*64)
 cfhip_astc_encode_kernel(cf_kparams kp)
 {
@@ -614,12 +788,16 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	const uint32_t col_rows = H->col_rows, den_stride = H->den_stride;
 	const uint32_t aflags = (kp.flags >> 16) & 3u;
 	// HDR profile (Type::UFloat, AstcConverter.cpp:150-162): bit 0 = HDR colour, bit 1 = HDR alpha too
-	const uint32_t hdrf = (kp.flags >> 19) & 3u;
+	// (a template parameter: the LDR builds carry none of the HDR code)
+	const uint32_t hdrf = HDR ? (kp.flags >> 19) & 3u : 0u;
 
 	// ---- LDS carve-up (byte offsets, 16-byte aligned sections) ----
 	uint8_t* lds = reinterpret_cast<uint8_t*>(dyn_lds);
 	uint32_t off = 0;
 	uint32_t* tile = reinterpret_cast<uint32_t*>(lds + off); off += nblk*n*4u;
+	off = (off + 15u) & ~15u;
+	// HDR: the texels' 16-bit LNS values, two words per texel (r | g << 16, b | a << 16; an LDR alpha 0..255)
+	uint32_t* tile16 = reinterpret_cast<uint32_t*>(lds + off); off += HDR ? nblk*n*8u : 0u;
 	off = (off + 15u) & ~15u;
 	uint32_t* sh_infill = reinterpret_cast<uint32_t*>(lds + off); off += ngrids*n*8u; off = (off + 15u) & ~15u;
 	uint32_t* sh_den = reinterpret_cast<uint32_t*>(lds + off); off += ngrids*den_stride*4u;
@@ -654,34 +832,89 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			x = x < kp.width ? x : kp.width - 1u;
 			y = y < kp.height ? y : kp.height - 1u;
 			const uint8_t* rowp = kp.src + (long long)y*kp.pitch;
-			uint32_t px;
-			if (PIX == 0) {
-				px = *reinterpret_cast<const uint32_t*>(rowp + (size_t)x*4u);
-				if (hdrf) {
-					const float k = 1.0f/255.0f;
-					const uint32_t a = (hdrf & 2u) ? hdr_code((float)(px >> 24)*k) : px >> 24;
-					px = hdr_code((float)(px & 255u)*k) | (hdr_code((float)((px >> 8) & 255u)*k) << 8) |
-						(hdr_code((float)((px >> 16) & 255u)*k) << 16) | (a << 24);
-				}
-			} else {
+			uint32_t px = 0;
+			if (HDR) {
 				float4 f;
-				if (kp.flags & (1u << 21)) {       // RGBA16F source: the same floats, 8 bytes per texel
-					const uint2 hb = *reinterpret_cast<const uint2*>(rowp + (size_t)x*8u);
-					f = make_float4(__half2float(__ushort_as_half((unsigned short)(hb.x & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(hb.x >> 16))),
-						__half2float(__ushort_as_half((unsigned short)(hb.y & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(hb.y >> 16))));
-				} else
-					f = *reinterpret_cast<const float4*>(rowp + (size_t)x*16u);
-				if (hdrf)
-					px = hdr_code(f.x) | (hdr_code(f.y) << 8) | (hdr_code(f.z) << 16) |
-						(((hdrf & 2u) ? hdr_code(f.w) : cf_unorm8(f.w)) << 24);
-				else
+				uint32_t a8;
+				if (PIX == 0) {
+					const uint32_t p8 = *reinterpret_cast<const uint32_t*>(rowp + (size_t)x*4u);
+					const float k = 1.0f/255.0f;
+					f = make_float4((float)(p8 & 255u)*k, (float)((p8 >> 8) & 255u)*k, (float)((p8 >> 16) & 255u)*k, (float)(p8 >> 24)*k);
+					a8 = p8 >> 24;
+				} else {
+					if (kp.flags & (1u << 21)) {       // RGBA16F source: the same floats, 8 bytes per texel
+						const uint2 hb = *reinterpret_cast<const uint2*>(rowp + (size_t)x*8u);
+						f = make_float4(__half2float(__ushort_as_half((unsigned short)(hb.x & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(hb.x >> 16))),
+							__half2float(__ushort_as_half((unsigned short)(hb.y & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(hb.y >> 16))));
+					} else
+						f = *reinterpret_cast<const float4*>(rowp + (size_t)x*16u);
+					a8 = cf_unorm8(f.w);
+				}
+				// swizzle (AstcConverter.cpp:140-149): a masked HDR channel is 0.0 = LNS 0, an LDR alpha goes
+				// through the byte masks
+				const uint32_t l0 = (kp.keep_mask & 0xFFu) ? hdr_lns16(f.x) : 0u;
+				const uint32_t l1 = (kp.keep_mask & 0xFF00u) ? hdr_lns16(f.y) : 0u;
+				const uint32_t l2 = (kp.keep_mask & 0xFF0000u) ? hdr_lns16(f.z) : 0u;
+				const uint32_t l3 = (hdrf & 2u) ? ((kp.keep_mask & 0xFF000000u) ? hdr_lns16(f.w) : 0u)
+					: ((((a8 << 24) & kp.keep_mask) | kp.set_mask) >> 24);
+				const uint32_t ti = (blk*n + row*bw + cx)*2u;
+				tile16[ti] = l0 | (l1 << 16);
+				tile16[ti + 1u] = l2 | (l3 << 16);
+			} else {
+				if (PIX == 0) {
+					px = *reinterpret_cast<const uint32_t*>(rowp + (size_t)x*4u);
+				} else {
+					float4 f;
+					if (kp.flags & (1u << 21)) {       // RGBA16F source: the same floats, 8 bytes per texel
+						const uint2 hb = *reinterpret_cast<const uint2*>(rowp + (size_t)x*8u);
+						f = make_float4(__half2float(__ushort_as_half((unsigned short)(hb.x & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(hb.x >> 16))),
+							__half2float(__ushort_as_half((unsigned short)(hb.y & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(hb.y >> 16))));
+					} else
+						f = *reinterpret_cast<const float4*>(rowp + (size_t)x*16u);
 					px = cf_unorm8(f.x) | (cf_unorm8(f.y) << 8) | (cf_unorm8(f.z) << 16) | (cf_unorm8(f.w) << 24);
+				}
+				// swizzle from colour mask / alpha type (AstcConverter.cpp:140-149)
+				tile[blk*n + row*bw + cx] = (px & kp.keep_mask) | kp.set_mask;
 			}
-			// swizzle from colour mask / alpha type (AstcConverter.cpp:140-149)
-			tile[blk*n + row*bw + cx] = (px & kp.keep_mask) | kp.set_mask;
 		}
 	}
 	__syncthreads();
+	if (HDR) {
+		// The search runs on 8-bit codes of each block's own window of the LNS domain (oracle:
+		// cfo_encode_astc_block_hdr): per channel the block minimum comes off, one shift for the block brings
+		// the widest HDR channel range into 0..255.  A wave codes its own four blocks, 16 lanes each.
+		const uint32_t lane_ = threadIdx.x & 63u, bl = lane_ >> 4, tl = lane_ & 15u, bidx = (threadIdx.x >> 6)*4u + bl;
+		const uint32_t* t16 = tile16 + bidx*n*2u;
+		uint32_t mn0 = 65535u, mn1 = 65535u, mn2 = 65535u, mn3 = 65535u, mx0 = 0u, mx1 = 0u, mx2 = 0u, mx3 = 0u;
+		for (uint32_t i = tl; i < n; i += 16u) {
+			const uint32_t a = t16[2u*i], c = t16[2u*i + 1u];
+			const uint32_t l0 = a & 0xFFFFu, l1 = a >> 16, l2 = c & 0xFFFFu, l3 = c >> 16;
+			mn0 = min(mn0, l0); mx0 = max(mx0, l0); mn1 = min(mn1, l1); mx1 = max(mx1, l1);
+			mn2 = min(mn2, l2); mx2 = max(mx2, l2); mn3 = min(mn3, l3); mx3 = max(mx3, l3);
+		}
+#pragma unroll
+		for (int m = 1; m < 16; m <<= 1) {
+			mn0 = min(mn0, (uint32_t)__shfl_xor((int)mn0, m, 64)); mx0 = max(mx0, (uint32_t)__shfl_xor((int)mx0, m, 64));
+			mn1 = min(mn1, (uint32_t)__shfl_xor((int)mn1, m, 64)); mx1 = max(mx1, (uint32_t)__shfl_xor((int)mx1, m, 64));
+			mn2 = min(mn2, (uint32_t)__shfl_xor((int)mn2, m, 64)); mx2 = max(mx2, (uint32_t)__shfl_xor((int)mx2, m, 64));
+			mn3 = min(mn3, (uint32_t)__shfl_xor((int)mn3, m, 64)); mx3 = max(mx3, (uint32_t)__shfl_xor((int)mx3, m, 64));
+		}
+		uint32_t R = max(max(mx0 - mn0, mx1 - mn1), mx2 - mn2);
+		if (hdrf & 2u) R = max(R, mx3 - mn3);
+		uint32_t sft = 0;
+		while (((R + ((1u << sft) >> 1)) >> sft) > 255u)
+			++sft;
+		const uint32_t hf = (1u << sft) >> 1;
+		const bool opaque = mn3 == 0x7800u && mx3 == 0x7800u;
+		for (uint32_t i = tl; i < n; i += 16u) {
+			const uint32_t a = t16[2u*i], c = t16[2u*i + 1u];
+			const uint32_t l0 = a & 0xFFFFu, l1 = a >> 16, l2 = c & 0xFFFFu, l3 = c >> 16;
+			// an HDR alpha that is 1.0 everywhere: the search's "no alpha endpoint" value
+			const uint32_t ca = (hdrf & 2u) ? (opaque ? 120u : (l3 - mn3 + hf) >> sft) : l3;
+			tile[bidx*n + i] = ((l0 - mn0 + hf) >> sft) | (((l1 - mn1 + hf) >> sft) << 8) | (((l2 - mn2 + hf) >> sft) << 16) | (ca << 24);
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
 
 	Shared sh;
 	sh.infill = reinterpret_cast<const uint2*>(sh_infill); sh.den = sh_den; sh.grid = sh_grid;
@@ -748,7 +981,11 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		const bool grey = (pair ? (uint32_t)(h ? cbal >> 32 : cbal) : (uint32_t)(cbal | (cbal >> 32))) == 0u;
 		if (solid && hl == 0u) {
 			const uint32_t r = p0 & 255u, g = (p0 >> 8) & 255u, bl = (p0 >> 16) & 255u, a = p0 >> 24;
-			outb[b] = void_extent(r, g, bl, a, hdrf);
+			if (HDR) {
+				const uint32_t t0 = tile16[b*n*2u], t1 = tile16[b*n*2u + 1u];
+				outb[b] = void_extent_lns(t0 & 0xFFFFu, t0 >> 16, t1 & 0xFFFFu, t1 >> 16, hdrf);
+			} else
+				outb[b] = void_extent(r, g, bl, a, hdrf);
 		}
 		if (__ballot(!solid) == 0ull)
 			continue;
@@ -1296,6 +1533,193 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					for (uint32_t pl = 0; pl < planes; ++pl)
 						normalise_rows<true>(pl ? colp1 : colbase, den, PW, sh.wnu + wq*68u);
 					PROF_MARK(6)   // B: decimate + quantise
+					if (HDR) {
+						// ---- HDR: the pair is fitted and priced on the 16-bit LNS texels through the real
+						// encodings (oracle: hdr_phase_b, same arithmetic) ----
+						const uint32_t nvh = has_alpha ? 8u : 6u;
+						const int lvh = nvh*P <= 18u ? (int)clevel[(nvh*P/2u)*132u + cfg.cbits] : -1;
+						if (lvh >= 0) {
+							const uint32_t lv = (uint32_t)lvh;
+							const uint32_t* t16 = tile16 + b*n*2u;
+							struct SetAccH { uint32_t cnt, S, C, V0, V1, V2, V3, T0, T1, T2, T3; };
+							SetAccH q0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;
+							const bool any3 = __ballot(P > 2u) != 0ull, any4 = __ballot(P > 3u) != 0ull;
+#pragma unroll 1
+							for (uint32_t i = 0; i < n; ++i) {
+								const uint2 rec = inf[i];
+								const uint32_t part = byp ? 0u : prow[i];
+								const uint32_t wA = infill_w(colbase, rec.x, rec.y);
+								const uint32_t w1s = dual ? infill_w(colp1, rec.x, rec.y) : wA;
+								const uint32_t mm = dual ? 3u : (1u << part);
+								const uint32_t x01 = t16[2u*i], x23 = t16[2u*i + 1u];
+								const uint32_t l0 = x01 & 0xFFFFu, l1 = x01 >> 16, l2 = x23 & 0xFFFFu, l3 = x23 >> 16;
+#define ASTC_ACCH(Q, ST, WI) { \
+								const bool mem = (mm & (1u << ST)) != 0u; \
+								const uint32_t wm = mem ? WI : 0u; \
+								Q.cnt += mem ? 1u : 0u; Q.S += wm; Q.C += wm*WI; \
+								Q.V0 += wm*l0; Q.V1 += wm*l1; Q.V2 += wm*l2; Q.V3 += wm*l3; \
+								Q.T0 += mem ? l0 : 0u; Q.T1 += mem ? l1 : 0u; Q.T2 += mem ? l2 : 0u; Q.T3 += mem ? l3 : 0u; }
+								ASTC_ACCH(q0, 0u, wA) ASTC_ACCH(q1, 1u, w1s)
+								if (any3) ASTC_ACCH(q2, 2u, wA)
+								if (any4) ASTC_ACCH(q3, 3u, wA)
+#undef ASTC_ACCH
+							}
+#define HSEL4(i, F) ((i) == 0u ? q0.F : ((i) == 1u ? q1.F : ((i) == 2u ? q2.F : q3.F)))
+							uint32_t D0lo[4] = {0, 0, 0, 0}, D0hi[4] = {0, 0, 0, 0}, D1lo[4] = {0, 0, 0, 0}, D1hi[4] = {0, 0, 0, 0};
+							const bool a_hdr = has_alpha && (hdrf & 2u);
+							bool all_ok = true;
+#pragma unroll 1
+							for (uint32_t p = 0; p < P; ++p) {
+								double r0[4], r1[4], fA[4], fB[4], fC[4];
+								int E0[4], E1[4];
+#pragma unroll
+								for (uint32_t c = 0; c < 4u; ++c) {
+									const uint32_t st = dual ? (c == ccs ? 1u : 0u) : p;
+									const long long cnt_ = HSEL4(st, cnt), S_ = HSEL4(st, S), C_ = HSEL4(st, C);
+									const long long V_ = c == 0u ? HSEL4(st, V0) : (c == 1u ? HSEL4(st, V1) : (c == 2u ? HSEL4(st, V2) : HSEL4(st, V3)));
+									const long long T_ = c == 0u ? HSEL4(st, T0) : (c == 1u ? HSEL4(st, T1) : (c == 2u ? HSEL4(st, T2) : HSEL4(st, T3)));
+									const long long A_ = 4096ll*cnt_ - 128ll*S_ + C_, B_ = 64ll*S_ - C_, U_ = 64ll*T_ - V_;
+									const long long det = cnt_*C_ - S_*S_;
+									fA[c] = (double)A_; fB[c] = (double)B_; fC[c] = (double)C_;
+									double x0, x1;
+									if (det > 0) {
+										const double den_ = (double)(64ll*det);
+										x0 = (double)(C_*U_ - B_*V_)/den_;
+										x1 = (double)(A_*V_ - B_*U_)/den_;
+									} else {
+										x0 = x1 = cnt_ ? (double)T_/(double)cnt_ : 0.0;
+									}
+									x0 = x0 < 0.0 ? 0.0 : (x0 > 65535.0 ? 65535.0 : x0);
+									x1 = x1 < 0.0 ? 0.0 : (x1 > 65535.0 ? 65535.0 : x1);
+									r0[c] = x0; r1[c] = x1;
+									E0[c] = clampi((int)floor(x0*(1.0/16.0) + 0.5), 0, 4095);
+									E1[c] = clampi((int)floor(x1*(1.0/16.0) + 0.5), 0, 4095);
+								}
+								// mode 11: the direct form and the eight sub-modes, cheapest by the quadratic form
+								double best = 1.0e300;
+								uint32_t bq_lo = 0, bq_hi = 0, bd0lo = 0, bd0hi = 0, bd1lo = 0, bd1hi = 0;
+								bool got = false;
+#pragma unroll 1
+								for (int k = 0; k < 9; ++k) {
+									int v[6], hm[6], q6[6];
+									hdr_rgb_place(k, E0, E1, r0, r1, v, hm);
+									bool ok = true;
+#pragma unroll
+									for (int i = 0; i < 6; ++i) {
+										q6[i] = ok ? requant_keep(sh, lv, v[i], hm[i]) : -1;
+										ok = ok && q6[i] >= 0;
+										v[i] = ok ? (int)sh.cunq[lv*256u + (uint32_t)q6[i]] : 0;
+									}
+									if (ok) {
+										int d0[3], d1[3];
+										hdr_rgb_unpack(v, d0, d1);
+										double est = 0.0;
+#pragma unroll
+										for (int c = 0; c < 3; ++c)
+											est = est + (double)cw[c]*quad_est_d(fA[c], fB[c], fC[c], (double)d0[c] - r0[c], (double)d1[c] - r1[c]);
+										est = est > 0.0 ? est : 0.0;
+										if (est < best) {
+											best = est;
+											got = true;
+											bq_lo = (uint32_t)q6[0] | ((uint32_t)q6[1] << 8) | ((uint32_t)q6[2] << 16) | ((uint32_t)q6[3] << 24);
+											bq_hi = (uint32_t)q6[4] | ((uint32_t)q6[5] << 8);
+											bd0lo = (uint32_t)d0[0] | ((uint32_t)d0[1] << 16); bd0hi = (uint32_t)d0[2];
+											bd1lo = (uint32_t)d1[0] | ((uint32_t)d1[1] << 16); bd1hi = (uint32_t)d1[2];
+										}
+									}
+								}
+								all_ok = all_ok && got;
+								uint32_t a0e = 255u, a1e = 255u;
+								if (a_hdr) {
+									best = 1.0e300;
+									got = false;
+#pragma unroll 1
+									for (int sel = 3; sel >= 0; --sel) {
+										int v6, v7, hm6, hm7;
+										hdr_alpha_place(sel, E0[3], E1[3], r0[3], r1[3], v6, v7, hm6, hm7);
+										const int qa = requant_keep(sh, lv, v6, hm6), qb = requant_keep(sh, lv, v7, hm7);
+										if (qa >= 0 && qb >= 0) {
+											int a0, a1;
+											hdr_alpha_unpack((int)sh.cunq[lv*256u + (uint32_t)qa], (int)sh.cunq[lv*256u + (uint32_t)qb], a0, a1);
+											double est = quad_est_d(fA[3], fB[3], fC[3], (double)a0 - r0[3], (double)a1 - r1[3]);
+											est = est > 0.0 ? est : 0.0;
+											if (est < best) {
+												best = est;
+												got = true;
+												bq_hi = (bq_hi & 0xFFFFu) | ((uint32_t)qa << 16) | ((uint32_t)qb << 24);
+												a0e = (uint32_t)a0; a1e = (uint32_t)a1;
+											}
+										}
+									}
+									all_ok = all_ok && got;
+								} else if (has_alpha) {
+									// LDR alpha (mode 14): two UNORM8 values; the fit above ran on the 0..255 values
+									uint32_t s6, s7;
+									a0e = (uint32_t)quant_c(sh, lv, (float)r0[3], s6);
+									a1e = (uint32_t)quant_c(sh, lv, (float)r1[3], s7);
+									bq_hi = (bq_hi & 0xFFFFu) | (s6 << 16) | (s7 << 24);
+								}
+								bd0hi |= a0e << 16; bd1hi |= a1e << 16;
+#pragma unroll
+								for (uint32_t k = 0; k < 4u; ++k) {
+									D0lo[k] = p == k ? bd0lo : D0lo[k]; D0hi[k] = p == k ? bd0hi : D0hi[k];
+									D1lo[k] = p == k ? bd1lo : D1lo[k]; D1hi[k] = p == k ? bd1hi : D1hi[k];
+								}
+								{
+									const unsigned long long vv = ((unsigned long long)bq_hi << 32 | bq_lo) & (nvh >= 8u ? ~0ull : ((1ull << (8u*nvh)) - 1ull));
+									const uint32_t bit = p*nvh*8u, wd0 = bit >> 5, sh_ = bit & 31u;
+									const unsigned long long lo = vv << sh_;
+									const uint32_t x0 = (uint32_t)lo, x1 = (uint32_t)(lo >> 32), x2 = sh_ ? (uint32_t)(vv >> (64u - sh_)) : 0u;
+#pragma unroll
+									for (uint32_t wd = 0; wd < 5u; ++wd)
+										r_cv[wd] |= wd == wd0 ? x0 : (wd == wd0 + 1u ? x1 : (wd == wd0 + 2u ? x2 : 0u));
+								}
+							}
+#undef HSEL4
+							if (all_ok) {
+								// exact error through the decode arithmetic: HDR channels on the 16-bit LNS values; an LDR
+								// alpha on UNORM8 scaled by 257 to the same range
+								unsigned long long e64 = 0;
+#pragma unroll 1
+								for (uint32_t i = 0; i < n; ++i) {
+									const uint2 rec = inf[i];
+									const uint32_t w0 = infill_w(colbase, rec.x, rec.y);
+									const uint32_t w1 = dual ? infill_w(colp1, rec.x, rec.y) : w0;
+									const uint32_t part = byp ? 0u : prow[i];
+									const uint32_t e0lo = part == 0u ? D0lo[0] : (part == 1u ? D0lo[1] : (part == 2u ? D0lo[2] : D0lo[3]));
+									const uint32_t e0hi = part == 0u ? D0hi[0] : (part == 1u ? D0hi[1] : (part == 2u ? D0hi[2] : D0hi[3]));
+									const uint32_t e1lo = part == 0u ? D1lo[0] : (part == 1u ? D1lo[1] : (part == 2u ? D1lo[2] : D1lo[3]));
+									const uint32_t e1hi = part == 0u ? D1hi[0] : (part == 1u ? D1hi[1] : (part == 2u ? D1hi[2] : D1hi[3]));
+									const uint32_t x01 = t16[2u*i], x23 = t16[2u*i + 1u];
+									unsigned long long ergb = 0, ea = 0;
+#pragma unroll
+									for (uint32_t c = 0; c < 4u; ++c) {
+										if (c < nc) {
+											const uint32_t wi = (dual && c == ccs) ? w1 : w0;
+											const uint32_t ea0 = c == 0u ? e0lo & 0xFFFFu : (c == 1u ? e0lo >> 16 : (c == 2u ? e0hi & 0xFFFFu : e0hi >> 16));
+											const uint32_t eb0 = c == 0u ? e1lo & 0xFFFFu : (c == 1u ? e1lo >> 16 : (c == 2u ? e1hi & 0xFFFFu : e1hi >> 16));
+											const uint32_t tx = c == 0u ? x01 & 0xFFFFu : (c == 1u ? x01 >> 16 : (c == 2u ? x23 & 0xFFFFu : x23 >> 16));
+											const uint32_t xw = ea0*(64u - wi) + eb0*wi;
+											int dd_;
+											if (c < 3u || (hdrf & 2u))
+												dd_ = (int)((xw + 32u) >> 6) - (int)tx;
+											else
+												dd_ = ((int)((257u*xw + 32u) >> 14) - (int)tx)*257;
+											const unsigned long long e = (unsigned long long)cw[c]*(unsigned long long)((long long)dd_*(long long)dd_);
+											if (c < 3u) ergb += e;
+											else ea = e;
+										}
+									}
+									const uint32_t wa = ((aflags & ASTC_FLAG_ALPHA_WEIGHT) && !(hdrf & 2u)) ? (x23 >> 16) : 255u;
+									e64 += ergb*wa + ea*255ull;
+								}
+								err = e64;
+								r_cem = has_alpha ? ((hdrf & 2u) ? 15u : 14u) : 11u;
+								r_lv = lv;
+								r_ncv = nvh*P;
+							}
+						}
+					} else {
 					// 2. + 3. texel weights and the least-squares sums per set (subset, or plane)
 					const uint32_t nset = dual ? 2u : P;
 					// per set only S = sum w, C = sum w^2 and V_c = sum w p_c are accumulated: with the
@@ -1490,7 +1914,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 									else ea = cw[3]*(uint32_t)(dd_*dd_);
 								}
 							}
-							const uint32_t wa = (aflags & ASTC_FLAG_ALPHA_WEIGHT) ? (p >> 24) : 255u;
+							// (alpha weighting needs a linear alpha: an HDR alpha code is not one)
+							const uint32_t wa = ((aflags & ASTC_FLAG_ALPHA_WEIGHT) && !(hdrf & 2u)) ? (p >> 24) : 255u;
 							e64 += (unsigned long long)ergb*wa + (unsigned long long)ea*255ull;
 						}
 						}
@@ -1500,6 +1925,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 								: (has_alpha ? 12u : 8u) - (best_opt == 1 ? 2u : (best_opt == 2 ? 8u : 0u)));
 						r_lv = best_lv;
 						r_ncv = nv*P;
+					}
 					}
 				}
 				if (pass == 0u && !pair) {
@@ -1546,6 +1972,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		}
 
 		PROF_MARK(10)  // argmin + park
+
 		// ---- pack the winner, spread over the group ----
 		{
 			unsigned long long lo64 = 0ull, hi64 = 0ull;
@@ -1558,7 +1985,18 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					for (int c = 0; c < 4; ++c)
 						cavg[c] = (uint32_t)((2*sum[c] + (int)n)/(2*(int)n));
 					if (nc == 3u) cavg[3] = opaque_a;
-					outb[b] = void_extent(cavg[0], cavg[1], cavg[2], cavg[3], hdrf);
+					if (HDR) {
+						unsigned long long t[4] = {0ull, 0ull, 0ull, 0ull};
+						for (uint32_t i = 0; i < n; ++i) {
+							const uint32_t a = tile16[(b*n + i)*2u], c = tile16[(b*n + i)*2u + 1u];
+							t[0] += a & 0xFFFFu; t[1] += a >> 16; t[2] += c & 0xFFFFu; t[3] += c >> 16;
+						}
+#pragma unroll
+						for (int c = 0; c < 4; ++c)
+							cavg[c] = (uint32_t)((2ull*t[c] + n)/(2ull*n));
+						outb[b] = void_extent_lns(cavg[0], cavg[1], cavg[2], cavg[3], hdrf);
+					} else
+						outb[b] = void_extent(cavg[0], cavg[1], cavg[2], cavg[3], hdrf);
 				}
 			} else if (!solid) {
 				const uint32_t d = S.best[0], meta = S.best[1];
@@ -1682,6 +2120,8 @@ static size_t astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality, 
 	const uint32_t n = h->n, ngrids = h->ngrids, npad = h->npad;
 	uint32_t off = nwaves*4u*n*4u;
 	off = (off + 15u) & ~15u;
+	off += hdr ? nwaves*4u*n*8u : 0u;        // the 16-bit LNS texels
+	off = (off + 15u) & ~15u;
 	off += ngrids*n*8u; off = (off + 15u) & ~15u;
 	off += ngrids*h->den_stride*4u;
 	off += (ngrids*4u + 15u) & ~15u;
@@ -1707,7 +2147,9 @@ extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t qualit
 	// and a 12-wave workgroup holds its LDS until its slowest wave is done: 4x4 Normal 4.6 ms as one
 	// 12-wave workgroup with the cache, 4.2 ms as three 4-wave workgroups without); then the cache
 	static const bool plan_no_dense = getenv("CFHIP_ASTC_NO_DENSE") != nullptr;   // experiments: the 256-register build only
-	for (uint32_t nw = 4; nw <= (plan_no_dense ? 8u : 12u); nw += 4u) {
+	// (the HDR builds exist for 8 waves only: their phase B holds 16-bit sums and double-precision fits)
+	const bool no12 = plan_no_dense || hdr != 0u;
+	for (uint32_t nw = 4; nw <= (no12 ? 8u : 12u); nw += 4u) {
 		if (forced && forced != nw)
 			continue;
 		for (uint32_t c = can_cache ? 2u : 1u; c-- > 0u;) {
@@ -1715,7 +2157,7 @@ extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t qualit
 			if (b > wg_max)
 				continue;
 			uint32_t w = (uint32_t)(cu_lds/(b + 1024u))*nw;      // 1024: the static outb + allocation granule
-			w = w >= 12u ? (plan_no_dense ? 8u : 12u) : (w >= 8u ? 8u : w);
+			w = w >= 12u ? (no12 ? 8u : 12u) : (w >= 8u ? 8u : w);
 			if (w > best_w) {
 				best_w = w; best_nw = nw; best_c = c;
 			}
@@ -1745,9 +2187,10 @@ extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, ui
 		std::lock_guard<std::mutex> guard(attr_lock);
 		if (dev < 0 || dev >= 64 || !attr_set[dev]) {
 			const int optin = (int)cf_astc_wg_lds_max();
-			const void* const fns[4] = {
-				reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 8>), reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<1, 8>),
-				reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 12>), reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<1, 12>)};
+			const void* const fns[6] = {
+				reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 8, false>), reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<1, 8, false>),
+				reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 12, false>), reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<1, 12, false>),
+				reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 8, true>), reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<1, 8, true>)};
 			for (const void* fn : fns) {
 				const hipError_t ae = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, optin);
 				if (ae != hipSuccess)
@@ -1759,24 +2202,20 @@ extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, ui
 	}
 	// the 168-register build only where three waves per SIMD actually become resident
 	static const bool no_dense = getenv("CFHIP_ASTC_NO_DENSE") != nullptr, debug = getenv("CFHIP_ASTC_DEBUG") != nullptr;
-	const bool dense = (cf_astc_cu_lds()/(lds_bytes + 1024u))*nwaves >= 12u && !no_dense;
+	const bool hdr = ((kp->flags >> 19) & 3u) != 0u;
+	const bool dense = (cf_astc_cu_lds()/(lds_bytes + 1024u))*nwaves >= 12u && !no_dense && !hdr;
+	void (*fn)(cf_kparams) = nullptr;
+	if (dense)
+		fn = pixel_type == 0 ? &cfhip_astc_encode_kernel<0, 12, false> : &cfhip_astc_encode_kernel<1, 12, false>;
+	else
+		fn = hdr ? (pixel_type == 0 ? &cfhip_astc_encode_kernel<0, 8, true> : &cfhip_astc_encode_kernel<1, 8, true>)
+			: (pixel_type == 0 ? &cfhip_astc_encode_kernel<0, 8, false> : &cfhip_astc_encode_kernel<1, 8, false>);
 	if (debug) {
 		int nb = -1;
-		const void* fn = dense ? reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 12>) : reinterpret_cast<const void*>(&cfhip_astc_encode_kernel<0, 8>);
-		hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, (int)(nwaves*64u), lds_bytes);
-		fprintf(stderr, "[astc] %u waves per workgroup, dynamic LDS %zu B (CU has %zu), %s build, workgroups per CU %d (%s), grid %u x %u\n",
-			nwaves, lds_bytes, cf_astc_cu_lds(), dense ? "168-VGPR" : "256-VGPR", nb, hipGetErrorString(oe), grid.x, grid.y);
+		hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(fn), (int)(nwaves*64u), lds_bytes);
+		fprintf(stderr, "[astc] %u waves per workgroup, dynamic LDS %zu B (CU has %zu), %s build%s, workgroups per CU %d (%s), grid %u x %u\n",
+			nwaves, lds_bytes, cf_astc_cu_lds(), dense ? "168-VGPR" : "256-VGPR", hdr ? " (HDR)" : "", nb, hipGetErrorString(oe), grid.x, grid.y);
 	}
-	if (dense) {
-		if (pixel_type == 0)
-			hipLaunchKernelGGL((cfhip_astc_encode_kernel<0, 12>), grid, block, lds_bytes, stream, *kp);
-		else
-			hipLaunchKernelGGL((cfhip_astc_encode_kernel<1, 12>), grid, block, lds_bytes, stream, *kp);
-	} else {
-		if (pixel_type == 0)
-			hipLaunchKernelGGL((cfhip_astc_encode_kernel<0, 8>), grid, block, lds_bytes, stream, *kp);
-		else
-			hipLaunchKernelGGL((cfhip_astc_encode_kernel<1, 8>), grid, block, lds_bytes, stream, *kp);
-	}
+	hipLaunchKernelGGL(fn, grid, block, lds_bytes, stream, *kp);
 	return hipGetLastError();
 }

@@ -258,6 +258,8 @@ typedef struct {
 	int n, nc, has_alpha, grey, flags;
 	int hdr, hdr_alpha;                 /* HDR profile (colour channels are LNS codes), HDR alpha */
 	int px[ASTC_MAX_TEXELS][4];
+	int lns[ASTC_MAX_TEXELS][4];        /* HDR profile: the texels' 16-bit LNS values (LDR alpha: 0..255) */
+	int have_lns;
 	int cw[4];                          /* channel weights of the error metric */
 	int wa[ASTC_MAX_TEXELS];            /* texel weight of the RGB error (alpha or 255) */
 	/* phase A results per (candidate, subset-or-plane) */
@@ -540,6 +542,262 @@ static int base_offset(const astc_tables* T, int lv, float x0, float x1, int* s0
 	return 1;
 }
 
+/* ------------------------------------------------------------------ HDR phase B
+ * Statistics, shortlist, phase A, the grid errors and the config ranking run on 8-bit codes of the
+ * block's own window of the LNS domain (cfo_encode_astc_block_hdr below): they only propose.  What a
+ * (candidate, config) pair really costs is decided here, on the 16-bit LNS texels and through the
+ * real encodings: least squares per set and channel, then every way mode 11 can store the pair
+ * (the direct form and the eight base + difference sub-modes, major component = the largest channel
+ * of the high endpoint), each quantised to the pair's colour level, decoded through the decoder's
+ * own unpack and priced by the quadratic form of the fit; HDR alpha (mode 15) through its four
+ * selectors the same way, LDR alpha (mode 14) as two UNORM8 values; then the exact error of the
+ * decode arithmetic on 16 bits. */
+int cfo_astc_unpack_endpoints(int cem, const int* v, int* e0, int* e1);
+
+/* nearest stored value to v among those that keep the bits of himask; -1: the level has none */
+static int requant_keep(const astc_tables* T, int lv, int v, int himask)
+{
+	int lo = v & himask, hi = lo | (~himask & 0xFF);
+	int q = T->c_near[lv][v], u = T->c_unq[lv][q];
+	if (u >= lo && u <= hi)
+		return q;
+	for (int d = 1; d < 128; ++d) {
+		int x = v - d;
+		if (x >= lo) {
+			q = T->c_near[lv][x]; u = T->c_unq[lv][q];
+			if (u >= lo && u <= hi) return q;
+		}
+		x = v + d;
+		if (x <= hi) {
+			q = T->c_near[lv][x]; u = T->c_unq[lv][q];
+			if (u >= lo && u <= hi) return q;
+		}
+	}
+	return -1;
+}
+
+static int rs_u(int x, int sh) { return x <= 0 ? 0 : (x + ((1 << sh) >> 1)) >> sh; }
+static int rs_s(int x, int sh) { return (x + ((1 << sh) >> 1)) >> sh; }        /* arithmetic shift */
+static int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+/* mode 11 value list for the 12-bit pair (E0, E1): k = 0 the direct form (from the 16-bit fit r),
+ * k = 1 + sub-mode otherwise.  himask[i]: the bits of v[i] a requantisation has to keep. */
+static void hdr_rgb_place(int k, const int E0[3], const int E1[3], const double r0[3], const double r1[3],
+	int v[6], int himask[6])
+{
+	if (k == 0) {
+		for (int c = 0; c < 2; ++c) {
+			v[2*c] = clampi((int)floor(r0[c]*(1.0/256.0) + 0.5), 0, 255);
+			v[2*c + 1] = clampi((int)floor(r1[c]*(1.0/256.0) + 0.5), 0, 255);
+			himask[2*c] = himask[2*c + 1] = 0;
+		}
+		v[4] = 0x80 | clampi((int)floor(r0[2]*(1.0/512.0) + 0.5), 0, 127);
+		v[5] = 0x80 | clampi((int)floor(r1[2]*(1.0/512.0) + 0.5), 0, 127);
+		himask[4] = himask[5] = 0x80;
+		return;
+	}
+	static const uint8_t bits[8][4] = {{9, 7, 6, 7}, {9, 8, 6, 6}, {10, 6, 7, 7}, {10, 7, 7, 6}, {11, 8, 6, 5},
+		{11, 6, 8, 6}, {12, 7, 7, 5}, {12, 6, 7, 6}};
+	int m = k - 1, ab = bits[m][0], bb = bits[m][1], cb = bits[m][2], db = bits[m][3], sh = 12 - ab;
+	int maj = 0;
+	if (E1[1] > E1[maj]) maj = 1;
+	if (E1[2] > E1[maj]) maj = 2;
+	int ch[3] = {0, 1, 2};
+	ch[0] = maj; ch[maj] = 0;
+	int a = clampi(rs_u(E1[ch[0]], sh), 0, (1 << ab) - 1), aq = a << sh;
+	int c = clampi(rs_u(aq - E0[ch[0]], sh), 0, (1 << cb) - 1), cq = c << sh;
+	int b0 = clampi(rs_u(aq - E1[ch[1]], sh), 0, (1 << bb) - 1), b1 = clampi(rs_u(aq - E1[ch[2]], sh), 0, (1 << bb) - 1);
+	int dl = -(1 << (db - 1)), dh = (1 << (db - 1)) - 1;
+	int d0 = clampi(rs_s(aq - (b0 << sh) - cq - E0[ch[1]], sh), dl, dh);
+	int d1 = clampi(rs_s(aq - (b1 << sh) - cq - E0[ch[2]], sh), dl, dh);
+	int d0u = d0 & ((1 << db) - 1), d1u = d1 & ((1 << db) - 1), oh = 1 << m;
+#define BIT(x, n) (((x) >> (n)) & 1)
+	int X0 = (oh & 0xA4) ? BIT(a, 9) : BIT(b0, 6);
+	int X1 = (oh & 0xA0) ? BIT(a, 10) : ((oh & 0x04) ? BIT(c, 6) : BIT(b1, 6));
+	int X2 = (oh & 0x08) ? BIT(a, 9) : ((oh & 0xC0) ? BIT(a, 11) : ((oh & 0x20) ? BIT(c, 7) : ((oh & 0x12) ? BIT(b0, 7) : BIT(d0u, 6))));
+	int X3 = (oh & 0xE8) ? BIT(c, 6) : ((oh & 0x12) ? BIT(b1, 7) : BIT(d1u, 6));
+	int X4 = (oh & 0x50) ? BIT(a, 9) : BIT(d0u, 5);
+	int X5 = (oh & 0x50) ? BIT(a, 10) : BIT(d1u, 5);
+	v[0] = a & 0xFF;
+	v[1] = ((m & 1) << 7) | (BIT(a, 8) << 6) | (c & 0x3F);
+	v[2] = (((m >> 1) & 1) << 7) | (X0 << 6) | (b0 & 0x3F);
+	v[3] = (((m >> 2) & 1) << 7) | (X1 << 6) | (b1 & 0x3F);
+	v[4] = ((maj & 1) << 7) | (X2 << 6) | (X4 << 5) | (d0u & 0x1F);
+	v[5] = (((maj >> 1) & 1) << 7) | (X3 << 6) | (X5 << 5) | (d1u & 0x1F);
+#undef BIT
+	static const uint8_t dmask[8] = {0x80, 0xC0, 0x80, 0xC0, 0xE0, 0xC0, 0xE0, 0xC0};
+	himask[0] = 0; himask[1] = 0xC0; himask[2] = himask[3] = 0xC0; himask[4] = himask[5] = dmask[m];
+}
+
+/* mode 15 alpha pair: selector 3 = two 7-bit values, 0..2 = base (8 + s bits) + signed offset (6 - s bits) */
+static void hdr_alpha_place(int sel, int A0, int A1, double r0, double r1, int v[2], int himask[2])
+{
+	if (sel == 3) {
+		v[0] = 0x80 | clampi((int)floor(r0*(1.0/512.0) + 0.5), 0, 127);
+		v[1] = 0x80 | clampi((int)floor(r1*(1.0/512.0) + 0.5), 0, 127);
+		himask[0] = himask[1] = 0x80;
+		return;
+	}
+	int sh = 4 - sel, base = clampi(rs_u(A0, sh), 0, (1 << (8 + sel)) - 1);
+	int off = clampi(rs_s(A1 - (base << sh), sh), -(1 << (5 - sel)), (1 << (5 - sel)) - 1);
+	v[0] = ((sel & 1) << 7) | (base & 0x7F);
+	v[1] = (((sel >> 1) & 1) << 7) | ((base >> 7) << (6 - sel)) | (off & (0x3F >> sel));
+	himask[0] = 0x80;
+	himask[1] = 0x80 | (0x7F & ~(0x3F >> sel));
+}
+
+static double quad_est_d(double fA, double fB, double fC, double d0, double d1)
+{
+	double t = fA*d0;
+	t = t + fB*d1;
+	double u = fB*d0;
+	u = u + fC*d1;
+	double q = t*d0;
+	q = q + u*d1;
+	return q;
+}
+
+static float clampf255(float x);
+static int quant_c(const astc_tables* T, int lv, float x, int* stored);
+
+static void hdr_phase_b(const astc_blk* b, const astc_pc* pc, const astc_cfg* cfg, uint8_t w[2][ASTC_MAX_TEXELS], astc_lane* L)
+{
+	const astc_tables* T = astc_get_tables();
+	int n = b->n, P = pc->P;
+	int nv = b->has_alpha ? 8 : 6;
+	if (nv*P > 18)
+		return;
+	int lv = T->c_level[nv*P/2][cfg->cbits];
+	if (lv < 0 || cfg->cbits < (13*nv*P + 4)/5)
+		return;
+	int nset = pc->dual ? 2 : P, a_hdr = b->has_alpha && b->hdr_alpha;
+	int64_t S[4] = {0}, A[4] = {0}, B[4] = {0}, C[4] = {0}, cnt[4] = {0}, V[4][4], Ts[4][4];
+	memset(V, 0, sizeof(V));
+	memset(Ts, 0, sizeof(Ts));
+	for (int i = 0; i < n; ++i) {
+		int part = pc_part(b, pc, i);
+		for (int st = 0; st < nset; ++st) {
+			if (!pc->dual && st != part)
+				continue;
+			int wi = w[pc->dual ? st : 0][i], iw = 64 - wi;
+			S[st] += wi; A[st] += iw*iw; B[st] += iw*wi; C[st] += wi*wi; cnt[st]++;
+		}
+		for (int c = 0; c < 4; ++c) {
+			int st = pc->dual ? (c == pc->ccs) : part;
+			int wi = w[pc->dual ? st : 0][i];
+			int sub = pc->dual ? 0 : part;      /* dual plane: one partition, channel c fits with plane st */
+			V[sub][c] += (int64_t)wi*b->lns[i][c];
+			Ts[sub][c] += b->lns[i][c];
+		}
+	}
+	int D0[4][4], D1[4][4];                  /* decoded endpoints: HDR channels 16-bit LNS, LDR alpha 0..255 */
+	for (int p = 0; p < P; ++p) {
+		double r0[4], r1[4], fA[4], fB[4], fC[4];
+		int E0[4], E1[4];
+		for (int c = 0; c < 4; ++c) {
+			int st = pc->dual ? (c == pc->ccs) : p;
+			int64_t det = cnt[st]*C[st] - S[st]*S[st], U = 64*Ts[p][c] - V[p][c];
+			fA[c] = (double)A[st]; fB[c] = (double)B[st]; fC[c] = (double)C[st];
+			if (det > 0) {
+				double den = (double)(64*det);
+				r0[c] = (double)(C[st]*U - B[st]*V[p][c])/den;
+				r1[c] = (double)(A[st]*V[p][c] - B[st]*U)/den;
+			} else {
+				r0[c] = r1[c] = cnt[st] ? (double)Ts[p][c]/(double)cnt[st] : 0.0;
+			}
+			r0[c] = r0[c] < 0.0 ? 0.0 : (r0[c] > 65535.0 ? 65535.0 : r0[c]);
+			r1[c] = r1[c] < 0.0 ? 0.0 : (r1[c] > 65535.0 ? 65535.0 : r1[c]);
+			E0[c] = clampi((int)floor(r0[c]*(1.0/16.0) + 0.5), 0, 4095);
+			E1[c] = clampi((int)floor(r1[c]*(1.0/16.0) + 0.5), 0, 4095);
+		}
+		uint8_t* vals = L->cvals + p*nv;
+		double best = 1.0e300;
+		int got = 0;
+		for (int k = 0; k < 9; ++k) {
+			int v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hm[6], q[6], ok = 1;
+			hdr_rgb_place(k, E0, E1, r0, r1, v, hm);
+			for (int i = 0; i < 6 && ok; ++i) {
+				q[i] = requant_keep(T, lv, v[i], hm[i]);
+				if (q[i] < 0) ok = 0;
+				else v[i] = T->c_unq[lv][q[i]];
+			}
+			if (!ok)
+				continue;
+			int d0[4], d1[4];
+			cfo_astc_unpack_endpoints(11, v, d0, d1);
+			double est = 0.0;
+			for (int c = 0; c < 3; ++c)
+				est = est + (double)b->cw[c]*quad_est_d(fA[c], fB[c], fC[c], (double)d0[c] - r0[c], (double)d1[c] - r1[c]);
+			est = est > 0.0 ? est : 0.0;         /* (the kernel compares bit patterns: no negative zero) */
+			if (est < best) {
+				best = est;
+				got = 1;
+				for (int i = 0; i < 6; ++i)
+					vals[i] = (uint8_t)q[i];
+				for (int c = 0; c < 3; ++c) { D0[p][c] = d0[c]; D1[p][c] = d1[c]; }
+			}
+		}
+		if (!got)
+			return;                              /* no form survives this colour level */
+		D0[p][3] = D1[p][3] = 255;
+		if (a_hdr) {
+			best = 1.0e300;
+			got = 0;
+			for (int sel = 3; sel >= 0; --sel) {
+				int v[8] = {0, 0, 0, 0, 0x80, 0x80, 0, 0}, hm[2], q[2];
+				hdr_alpha_place(sel, E0[3], E1[3], r0[3], r1[3], v + 6, hm);
+				q[0] = requant_keep(T, lv, v[6], hm[0]);
+				q[1] = requant_keep(T, lv, v[7], hm[1]);
+				if (q[0] < 0 || q[1] < 0)
+					continue;
+				v[6] = T->c_unq[lv][q[0]]; v[7] = T->c_unq[lv][q[1]];
+				int d0[4], d1[4];
+				cfo_astc_unpack_endpoints(15, v, d0, d1);
+				double est = quad_est_d(fA[3], fB[3], fC[3], (double)d0[3] - r0[3], (double)d1[3] - r1[3]);
+				est = est > 0.0 ? est : 0.0;
+				if (est < best) {
+					best = est;
+					got = 1;
+					vals[6] = (uint8_t)q[0]; vals[7] = (uint8_t)q[1];
+					D0[p][3] = d0[3]; D1[p][3] = d1[3];
+				}
+			}
+			if (!got)
+				return;
+		} else if (b->has_alpha) {
+			/* LDR alpha (mode 14): two UNORM8 values; the fit above ran on the 0..255 values */
+			int s6, s7;
+			D0[p][3] = quant_c(T, lv, (float)r0[3], &s6);
+			D1[p][3] = quant_c(T, lv, (float)r1[3], &s7);
+			vals[6] = (uint8_t)s6; vals[7] = (uint8_t)s7;
+		}
+	}
+	/* exact error through the decode arithmetic: HDR channels on the 16-bit LNS values; an LDR alpha on
+	 * UNORM8 scaled by 257 to the same range */
+	uint64_t err = 0;
+	for (int i = 0; i < n; ++i) {
+		int p = pc_part(b, pc, i);
+		uint64_t ergb = 0, ea = 0;
+		for (int c = 0; c < b->nc; ++c) {
+			int wi = w[(pc->dual && c == pc->ccs) ? 1 : 0][i];
+			int x = D0[p][c]*(64 - wi) + D1[p][c]*wi, d;
+			if (c < 3 || b->hdr_alpha)
+				d = ((x + 32) >> 6) - b->lns[i][c];
+			else
+				d = (((257*x + 32) >> 14) - b->lns[i][c])*257;
+			uint64_t e = (uint64_t)b->cw[c]*(uint64_t)((int64_t)d*d);
+			if (c < 3) ergb += e;
+			else ea = e;
+		}
+		err += ergb*(uint64_t)b->wa[i] + ea*255u;
+	}
+	L->err = err;
+	L->valid = 1;
+	L->cem = b->has_alpha ? (b->hdr_alpha ? 15 : 14) : 11;
+	L->ncv = nv*P;
+	L->lv = lv;
+}
+
 static void phase_b(const astc_blk* b, int j, const astc_pc* pc, const astc_cfg* cfg, astc_lane* L)
 {
 	const astc_tables* T = astc_get_tables();
@@ -571,6 +829,10 @@ static void phase_b(const astc_blk* b, int j, const astc_pc* pc, const astc_cfg*
 					acc += inf[i].f[k]*unq[inf[i].g[k]];
 			w[pl][i] = (uint8_t)(acc >> 4);
 		}
+	}
+	if (b->hdr && b->have_lns) {
+		hdr_phase_b(b, pc, cfg, w, L);
+		return;
 	}
 	/* 3. least-squares endpoints per set (set = subset, or plane for dual) */
 	int nset = pc->dual ? 2 : P;
@@ -1033,13 +1295,80 @@ static void void_extent_hdr(const int c[4], int hdr_alpha, uint8_t out[16])
 	}
 }
 
+/* 16-bit LNS -> half (the decoder's conversion) */
+static uint16_t lns16_to_half(int c)
+{
+	int e = c >> 11, m = c & 0x7FF, mt;
+	if (m < 512) mt = 3*m;
+	else if (m < 1536) mt = 4*m - 512;
+	else mt = 5*m - 2048;
+	int h = (e << 10) + (mt >> 3);
+	return (uint16_t)(h > 0x7BFF ? 0x7BFF : h);
+}
+
+/* HDR void extent from 16-bit LNS values (LDR alpha: 0..255) */
+static void void_extent_lns(const int c[4], int hdr_alpha, uint8_t out[16])
+{
+	static const uint8_t hdr[8] = {0xFC, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF};
+	memcpy(out, hdr, 8);
+	for (int k = 0; k < 4; ++k) {
+		uint16_t h = (k < 3 || hdr_alpha) ? lns16_to_half(c[k]) : cfo_float_to_half((float)c[k]*(1.0f/255.0f));
+		out[8 + 2*k] = (uint8_t)(h & 255);
+		out[8 + 2*k + 1] = (uint8_t)(h >> 8);
+	}
+}
+
+static void encode_core(const int px[][4], const int lns[][4], int bw, int bh, int quality, int flags, uint8_t out[16]);
+
 /* px: bw*bh texels RGBA u8 (swizzled, edge-replicated) */
 void cfo_encode_astc_block(const int px[][4], int bw, int bh, int quality, int flags, uint8_t out[16])
+{
+	encode_core(px, NULL, bw, bh, quality, flags, out);
+}
+
+/* HDR profiles.  lns: bw*bh texels, the HDR channels (RGB, and alpha under ASTC_FLAG_HDR_ALPHA) as
+ * 16-bit LNS values (cfo_astc_lns16 of the half), an LDR alpha as 0..255; swizzled, edge-replicated.
+ * The search runs on 8-bit codes of the block's own window: per channel the minimum is taken off,
+ * and one shift for the whole block brings the widest channel range into 0..255 -- a smooth block
+ * is searched at full LNS precision, a block that spans many octaves at the coarseness it needs.
+ * All codes equal <=> all values equal (the shift is the smallest that fits), so a solid block is a
+ * void extent holding its exact halves.  Every (candidate, config) pair is then fitted and priced on
+ * the 16-bit values through the real encodings (hdr_phase_b). */
+void cfo_encode_astc_block_hdr(const int lns[][4], int bw, int bh, int quality, int flags, uint8_t out[16])
+{
+	int n = bw*bh, px[ASTC_MAX_TEXELS][4];
+	int hdr_alpha = (flags & ASTC_FLAG_HDR_ALPHA) != 0, nh = hdr_alpha ? 4 : 3;
+	int mn[4] = {65536, 65536, 65536, 65536}, mx[4] = {0, 0, 0, 0}, R = 0, opaque = 1;
+	for (int i = 0; i < n; ++i) {
+		for (int c = 0; c < nh; ++c) {
+			if (lns[i][c] < mn[c]) mn[c] = lns[i][c];
+			if (lns[i][c] > mx[c]) mx[c] = lns[i][c];
+		}
+		if (lns[i][3] != 0x7800) opaque = 0;
+	}
+	for (int c = 0; c < nh; ++c)
+		if (mx[c] - mn[c] > R) R = mx[c] - mn[c];
+	int s = 0;
+	while (((R + ((1 << s) >> 1)) >> s) > 255)
+		++s;
+	for (int i = 0; i < n; ++i) {
+		for (int c = 0; c < nh; ++c)
+			px[i][c] = (lns[i][c] - mn[c] + ((1 << s) >> 1)) >> s;
+		if (!hdr_alpha) px[i][3] = lns[i][3];
+		else if (opaque) px[i][3] = 120;           /* the search's "no alpha endpoint needed" value */
+	}
+	encode_core((const int (*)[4])px, lns, bw, bh, quality, flags | ASTC_FLAG_HDR, out);
+}
+
+static void encode_core(const int px[][4], const int lns[][4], int bw, int bh, int quality, int flags, uint8_t out[16])
 {
 	const astc_fmt* f = get_fmt(bw, bh);
 	astc_blk* b = (astc_blk*)malloc(sizeof(astc_blk));
 	int n = bw*bh, solid = 1;
 	memset(out, 0, 16);
+	b->have_lns = lns != NULL;
+	if (lns)
+		memcpy(b->lns, lns, (size_t)n*sizeof(b->lns[0]));
 	b->f = f; b->n = n; b->flags = flags; b->has_alpha = 0; b->grey = 1;
 	b->hdr = (flags & ASTC_FLAG_HDR) != 0;
 	b->hdr_alpha = b->hdr && (flags & ASTC_FLAG_HDR_ALPHA) != 0;
@@ -1050,10 +1379,13 @@ void cfo_encode_astc_block(const int px[][4], int bw, int bh, int quality, int f
 		if (memcmp(px[i], px[0], 4*sizeof(int)) != 0) solid = 0;
 		if (px[i][3] != opaque) b->has_alpha = 1;
 		if (px[i][0] != px[i][1] || px[i][0] != px[i][2]) b->grey = 0;
-		b->wa[i] = (flags & ASTC_FLAG_ALPHA_WEIGHT) ? px[i][3] : 255;
+		/* alpha weighting needs a linear alpha: an HDR alpha (a code of the block's LNS window) is not one */
+		b->wa[i] = ((flags & ASTC_FLAG_ALPHA_WEIGHT) && !b->hdr_alpha) ? px[i][3] : 255;
 	}
 	if (solid) {
-		if (b->hdr)
+		if (b->hdr && lns)
+			void_extent_lns(lns[0], b->hdr_alpha, out);
+		else if (b->hdr)
 			void_extent_hdr(px[0], b->hdr_alpha, out);
 		else
 			void_extent(px[0], out);
@@ -1195,7 +1527,17 @@ void cfo_encode_astc_block(const int px[][4], int bw, int bh, int quality, int f
 		for (int k = 0; k < 4; ++k)
 			c[k] = (2*sum[k] + n)/(2*n);
 		if (b->nc == 3) c[3] = 255;
-		void_extent(c, out);
+		if (b->hdr && lns) {
+			/* (not reached with the configs in use: some candidate is always valid) the block's mean */
+			int64_t t[4] = {0, 0, 0, 0};
+			for (int i = 0; i < n; ++i)
+				for (int k = 0; k < 4; ++k)
+					t[k] += lns[i][k];
+			for (int k = 0; k < 4; ++k)
+				c[k] = (int)((2*t[k] + n)/(2*n));
+			void_extent_lns(c, b->hdr_alpha, out);
+		} else
+			void_extent(c, out);
 		free(b);
 		return;
 	}

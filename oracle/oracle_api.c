@@ -26,6 +26,8 @@ void cfo_decode_etc_rgb(const uint8_t* blk, int a1, uint8_t* rgba64);
 int cfo_astc_footprint(int format, int* bw, int* bh);
 void cfo_encode_astc_block(const int px[][4], int bw, int bh, int quality, int flags, uint8_t out[16]);
 int cfo_astc_hdr_code(float x);
+int cfo_astc_lns16(uint16_t h);
+void cfo_encode_astc_block_hdr(const int lns[][4], int bw, int bh, int quality, int flags, uint8_t out[16]);
 int cfo_decode_astc_block_hdr(const uint8_t* blk, int bw, int bh, uint16_t* rgba_half);
 int cfo_decode_astc_block(const uint8_t* blk, int bw, int bh, uint8_t* rgba);
 void cfo_decode_eac(const uint8_t* blk, int kind, int* out16);
@@ -150,7 +152,7 @@ static void* worker(void* arg)
 			 * UNORM8 like toColorBlock */
 			int apx[144][4];
 			/* Type::UFloat = the HDR profiles (AstcConverter.cpp:150-162): HDR_RGB_LDR_A for
-			 * Alpha::None / PreMultiplied, HDR otherwise; texels become 8-bit LNS codes */
+			 * Alpha::None / PreMultiplied, HDR otherwise; texels become 16-bit LNS values */
 			const int hdr = j->p->type == 4, hdr_alpha = hdr && !(j->p->alpha == 0 || j->p->alpha == 2);
 			for (uint32_t r = 0; r < j->bh; ++r) {
 				uint32_t sy = y*j->bh + r;
@@ -172,8 +174,12 @@ static void* worker(void* arg)
 							fv = half_to_float(((const uint16_t*)(row + (size_t)sx*8))[k]);
 							o[k] = unorm8(fv);
 						}
-						if (hdr && (k < 3 || hdr_alpha))
-							o[k] = cfo_astc_hdr_code(fv);
+						if (hdr && (k < 3 || hdr_alpha)) {
+							/* the 16-bit LNS value of the half (negative, zero, NaN -> 0; above 65504 -> 0x7BFF) */
+							uint16_t hb = !(fv > 0.0f) ? 0 : cfo_float_to_half(fv > 65504.0f ? 65504.0f : fv);
+							if (hb > 0x7BFF) hb = 0x7BFF;
+							o[k] = cfo_astc_lns16(hb);
+						}
 					}
 					for (int k = 0; k < 3; ++k)
 						if (!j->p->mask[k]) o[k] = 0;
@@ -185,7 +191,10 @@ static void* worker(void* arg)
 			 * sRGB images (AstcConverter.cpp:163-172) */
 			int aflags = ((j->p->alpha == 1 || j->p->alpha == 2) ? 1 : 0) | (j->p->color_space == 1 ? 2 : 0) |
 				(hdr ? 4 : 0) | (hdr_alpha ? 8 : 0);
-			cfo_encode_astc_block((const int (*)[4])apx, (int)j->bw, (int)j->bh, j->p->quality, aflags, dst);
+			if (hdr)
+				cfo_encode_astc_block_hdr((const int (*)[4])apx, (int)j->bw, (int)j->bh, j->p->quality, aflags, dst);
+			else
+				cfo_encode_astc_block((const int (*)[4])apx, (int)j->bw, (int)j->bh, j->p->quality, aflags, dst);
 			continue;
 		}
 		float f[64];
