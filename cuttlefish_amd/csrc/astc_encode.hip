@@ -270,7 +270,8 @@ __device__ __forceinline__ uint32_t hdr_lns16(float x)
 	uint32_t hb = (uint32_t)__half_as_ushort(__float2half_rn(x > 65504.0f ? 65504.0f : x));   // v_cvt_f16_f32, RNE
 	hb = hb > 0x7BFFu ? 0x7BFFu : hb;
 	const uint32_t e = hb >> 10, m10 = hb & 1023u;
-	uint32_t m = m10 < 192u ? (8u*m10 + 1u)/3u : (m10 < 704u ? 2u*m10 + 128u : (8u*m10 + 2050u)/5u);
+	// the smallest m whose transform gives the half's mantissa back: half -> LNS -> half is exact
+	uint32_t m = m10 < 192u ? (8u*m10 + 2u)/3u : (m10 < 704u ? 2u*m10 + 128u : (8u*m10 + 2052u)/5u);
 	m = m > 2047u ? 2047u : m;
 	return (e << 11) | m;
 }
@@ -1217,8 +1218,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			}
 		}
 		__builtin_amdgcn_wave_barrier();
-		if ((q == 2u || q == 3u) && npc > 8u)
-			npc = 8u;          // Normal, High: the first pass only (their 4 + 2 seeds already are the head of the walk)
+		// Normal, High: the first pass only (their 4 + 2 seeds already are the head of the walk); HDR: four
+		// candidates of 8 configs (oracle: the config ranking is nearly flat on HDR content)
+		if ((q == 2u || q == 3u) && npc > (HDR ? 4u : 8u))
+			npc = HDR ? 4u : 8u;
 		if (q >= 4u) {
 			// Highest (one block per wave) walks the same head as High: 4 two-partition seeds, then 2
 			// three-partition seeds, then the rest in the old order (oracle: ASTC_HEAD2 / ASTC_HEAD3).
@@ -1240,8 +1243,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		// ---- passes of (gsz / K) candidates x K configs ----
 		// Normal, High: candidate j of the pass has 6 (j < 4) or 2 lanes, side by side: 32 lanes; the other
 		// levels give every candidate 8
-		const bool varK = q == 2u || q == 3u;
-		const uint32_t K = lad.K, kshift = K == 2u ? 1u : (K == 4u ? 2u : 3u), per_pass = varK ? 8u : gsz >> kshift;
+		const bool varK = (q == 2u || q == 3u) && !HDR;
+		const uint32_t K = (HDR && (q == 2u || q == 3u)) ? 8u : lad.K, kshift = K == 2u ? 1u : (K == 4u ? 2u : 3u), per_pass = varK ? 8u : gsz >> kshift;
 		unsigned long long bestkey = ~0ull;
 		const uint32_t alpha_i = has_alpha ? 1u : 0u;
 		uint32_t npc_max = npc;

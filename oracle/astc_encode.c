@@ -1256,9 +1256,12 @@ static void void_extent(const int c[4], uint8_t out[16])
 int cfo_astc_lns16(uint16_t h)
 {
 	int e = h >> 10, m10 = h & 1023, m;
-	if (m10 < 192) m = (8*m10 + 1)/3;              /* inverse of mt = 3 m (m < 512) */
+	/* the SMALLEST 11-bit m whose mantissa transform gives the half's 10 bits back (the decoder keeps
+	 * mt >> 3): half -> LNS -> half is exact for every finite non-negative half (checked over all of them
+	 * in tests/test_oracle_astc_hdr.py), and 1.0 is 0x7800 */
+	if (m10 < 192) m = (8*m10 + 2)/3;              /* mt = 3 m (m < 512): ceil(8 m10 / 3) */
 	else if (m10 < 704) m = 2*m10 + 128;            /* mt = 4 m - 512 */
-	else m = (8*m10 + 2048 + 2)/5;                  /* mt = 5 m - 2048 */
+	else m = (8*m10 + 2048 + 4)/5;                  /* mt = 5 m - 2048: ceil((8 m10 + 2048) / 5) */
 	if (m > 2047) m = 2047;
 	return (e << 11) | m;
 }
@@ -1463,8 +1466,12 @@ static void encode_core(const int px[][4], const int lns[][4], int bw, int bh, i
 			pcs[npc++] = (astc_pc){P, 0, 0, P, sl[k]};
 	}
 	/* passes of (group size / K) candidates x K configs */
-	const int var_k = q == 2 || q == 3;       /* the uneven allocation astc_high_k */
-	int gsz = q <= 3 ? 32 : 64, per_pass = var_k ? 8 : gsz/lad->K;
+	/* Normal and High: the uneven allocation astc_high_k -- LDR only.  On HDR content the config ranking
+	 * (tuned on 8-bit photographs) is nearly flat and the one-partition candidate wins five blocks in six,
+	 * so there the two levels give 8 configs each to the first four candidates instead */
+	const int mid = q == 2 || q == 3, var_k = mid && !b->hdr;
+	const int K = (mid && b->hdr) ? 8 : lad->K;
+	int gsz = q <= 3 ? 32 : 64, per_pass = var_k ? 8 : gsz/K;
 	if (q >= 3) {
 		/* the head of the walk: ASTC_HEAD2 two-partition seeds, then ASTC_HEAD3 three-partition seeds,
 		 * then the rest in the old order; High keeps the first pass only */
@@ -1476,7 +1483,7 @@ static void encode_core(const int px[][4], const int lns[][4], int bw, int bh, i
 		for (int k = h2; k < got_p[2]; ++k) pcs[t++] = old[nb + k];
 		for (int k = h3; k < got_p[3]; ++k) pcs[t++] = old[nb + got_p[2] + k];
 	}
-	if (var_k && npc > per_pass)
+	if (mid && npc > per_pass)
 		npc = per_pass;             /* Normal and High: one pass */
 
 	astc_lane best, cur;
@@ -1506,7 +1513,7 @@ static void encode_core(const int px[][4], const int lns[][4], int bw, int bh, i
 			const astc_pc* pc = &pcs[base + j];
 			int order[ASTC_MAX_CFG];
 			/* lane of the pair in its pass = its id: candidates side by side, K (High: astc_high_k) lanes each */
-			int Kj = var_k ? astc_high_k(j) : lad->K, lane0 = var_k ? (j < 4 ? 6*j : 24 + 2*(j - 4)) : j*lad->K;
+			int Kj = var_k ? astc_high_k(j) : K, lane0 = var_k ? (j < 4 ? 6*j : 24 + 2*(j - 4)) : j*K;
 			int nk = rank_configs(b, j, pc, Kj, order);
 			for (int k = 0; k < nk; ++k) {
 				phase_b(b, j, pc, &f->cfg[pc->cls][b->has_alpha][order[k]], &cur);
