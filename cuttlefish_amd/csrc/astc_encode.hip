@@ -1,4 +1,4 @@
-// astc_encode.hip -- ASTC 2-D block encoder for gfx950 (LDR profile; HDR profiles on 8-bit LNS codes).
+// astc_encode.hip -- ASTC 2-D block encoder for gfx950 (LDR profile; HDR profiles on 16-bit LNS texels).
 //
 // Replaces, behind cfhip_encode(), the per-block astcenc_compress_image call of
 // AstcConverter::process (lib/src/AstcConverter.cpp:208-230; ARM astc-encoder, absent
@@ -10,9 +10,10 @@
 // against the canonical seed list); single / dual plane; every weight grid N x M <= footprint
 // and weight range (bits, trits, quints); endpoint modes 8/12 (with and without blue
 // contraction), 6/10, 0/4, 9/13 (base + offset, 4x4 and 5x4) at the colour quantisation level the remaining bits allow.  Type::UFloat
-// (the HDR profiles, AstcConverter.cpp:150-162): the loader turns every HDR channel into the top
-// 8 bits of its 16-bit LNS value, the same search runs on those bytes, and the endpoints leave
-// through the direct sub-mode of CEM 11 / 14 / 15 (hdr_code, quant_hi, cem_option).
+// (the HDR profiles, AstcConverter.cpp:150-162; HDR == true instantiations): texels are 16-bit LNS
+// values; the proposing stages run on 8-bit codes of the block's own window of that domain, phase B
+// fits and prices every pair on the 16-bit values through every form of CEM 11 / 14 / 15 (hdr_lns16,
+// hdr_rgb_place / hdr_rgb_unpack, hdr_alpha_place, requant_keep).
 //
 // One wavefront per block (two blocks per wavefront up to Quality::Normal), every lane a
 // different unit of search work in ONE instruction stream:

@@ -1,7 +1,7 @@
 /*
  * oracle/astc_encode.c -- TEST INFRASTRUCTURE (see cf_oracle.h header).
  *
- * ASTC 2-D encoder (LDR profile, and the HDR profiles on 8-bit LNS codes): CPU restatement of the
+ * ASTC 2-D encoder (LDR profile, and the HDR profiles on 16-bit LNS texels): CPU restatement of the
  * ASTC leg of the reference hot path
  *   AstcConverter ctor (swizzle / profile / flags / preset)   lib/src/AstcConverter.cpp:134-201
  *   AstcConverter::process (edge-replicated bw x bh tile -> astcenc_compress_image)  :208-230
@@ -17,9 +17,10 @@
  * 5x4 only), all at the colour
  * quantisation level the remaining bits allow (ISE).  ASTCENC_FLG_USE_ALPHA_WEIGHT and
  * ASTCENC_FLG_USE_PERCEPTUAL (AstcConverter.cpp:163-172) enter the error metric.
- * Type::UFloat (ASTCENC_PRF_HDR / HDR_RGB_LDR_A, :150-162): HDR endpoint modes 11 / 14 / 15 in
- * their direct sub-mode, HDR void extents; see "HDR profile" below.  No independent HDR decoder
- * exists in this environment: that leg is pinned to oracle/astc_decode.c alone (parity unpinned).
+ * Type::UFloat (ASTCENC_PRF_HDR / HDR_RGB_LDR_A, :150-162): HDR endpoint modes 11 / 14 / 15 with all
+ * their sub-modes, HDR void extents; see "HDR phase B" and cfo_encode_astc_block_hdr below.  No
+ * independent HDR decoder exists in this environment: that leg is pinned to oracle/astc_decode.c
+ * alone (parity unpinned).
  *
  * Search (lane = (partitioning candidate, weight-grid config), ids fixed = the GPU's):
  *   phase A  lane = (candidate, subset/plane): integer moments -> principal axis -> extremes
@@ -39,7 +40,7 @@
 
 #define ASTC_FLAG_ALPHA_WEIGHT 1
 #define ASTC_FLAG_PERCEPTUAL 2
-#define ASTC_FLAG_HDR 4            /* HDR profile: the colour channels are 8-bit LNS codes (cfo_astc_hdr_code) */
+#define ASTC_FLAG_HDR 4            /* HDR profile: the colour channels are LNS values (cfo_encode_astc_block_hdr) */
 #define ASTC_FLAG_HDR_ALPHA 8      /* ASTCENC_PRF_HDR: alpha is an LNS code too (else LDR alpha, PRF_HDR_RGB_LDR_A) */
 #define ASTC_MAX_CFG 200       /* array bound; a class lists at most 64 (200 only in the census build) */
 #define ASTC_LIST_CFG 64       /* configs listed per class; K of them are tried per candidate */
