@@ -34,6 +34,17 @@
 
 namespace {
 
+// the lane id, recomputed where a phase starts: a volatile mbcnt pair cannot be hoisted or merged, so no
+// lane-derived value has to stay in a register (or be spilled) across the phases of the search
+#define CF_FRESH_LANE(x) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x))
+
+// value of lane `src` (mod 64): ds_bpermute without the lane-id arithmetic __shfl wraps around it (a
+// hoisted mbcnt pair is one more VGPR alive through the whole search)
+__device__ __forceinline__ int cf_bperm(int v, uint32_t src)
+{
+	return __builtin_amdgcn_ds_bpermute((int)(src << 2), v);
+}
+
 __device__ const uint16_t k_part2[64] = {
 	0xcccc, 0x8888, 0xeeee, 0xecc8, 0xc880, 0xfeec, 0xfec8, 0xec80,
 	0xc800, 0xffec, 0xfe80, 0xe800, 0xffe8, 0xff00, 0xfff0, 0xf000,
@@ -641,10 +652,10 @@ __device__ __forceinline__ uint4 pack_block_group(const uint32_t* wcol, uint32_t
 	uint32_t idxv = w2i(wv, ibc);
 	uint32_t idxs = iba ? w2i(ws, iba) : 0u;
 	// anchors decide the endpoint order of their subset (texel a lives in lane hbase + a)
-	const uint32_t i0 = (uint32_t)__shfl((int)idxv, (int)hbase, 64);
-	const uint32_t i1 = (uint32_t)__shfl((int)idxv, (int)(hbase + a1), 64);
-	const uint32_t i2 = (uint32_t)__shfl((int)idxv, (int)(hbase + a2), 64);
-	const uint32_t is0 = (uint32_t)__shfl((int)idxs, (int)hbase, 64);
+	const uint32_t i0 = (uint32_t)cf_bperm((int)idxv, (uint32_t)((int)hbase));
+	const uint32_t i1 = (uint32_t)cf_bperm((int)idxv, (uint32_t)((int)(hbase + a1)));
+	const uint32_t i2 = (uint32_t)cf_bperm((int)idxv, (uint32_t)((int)(hbase + a2)));
+	const uint32_t is0 = (uint32_t)cf_bperm((int)idxs, (uint32_t)((int)hbase));
 	const uint32_t sw0 = i0 >> (ibc - 1u);
 	const uint32_t sw1 = ns > 1u ? i1 >> (ibc - 1u) : 0u;
 	const uint32_t sw2 = ns > 2u ? i2 >> (ibc - 1u) : 0u;
@@ -820,11 +831,14 @@ __device__ __forceinline__ float subset_residual(const Tex& tx, uint32_t mask)
 // (colour mask already applied), identical for every lane.
 template <bool UNITW, bool WIDE>
 __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint32_t* plan, const uint32_t* yccp, uint32_t b,
-	bool pair, uint32_t* cslot, const cf_kparams& kp, uint32_t lane0)
+	bool pair, uint32_t* cbase, const cf_kparams& kp)
 {
-	uint32_t lane = lane0;
+	uint32_t lane;
+	CF_FRESH_LANE(lane);
+#define cslot (cbase + lane)
 	// pair: blocks b and b + 1 at Low or Normal, one per half wavefront
-	const uint32_t h = lane >> 5, hbase = pair ? (lane & 32u) : 0u;
+#define h (lane >> 5)
+#define hbase (pair ? (lane & 32u) : 0u)
 	const uint32_t* tp = tile + (pair ? b + h : b)*16u;
 	const uint32_t* pl = plan + (pair ? b + h : b)*16u;
 	const uint32_t* yc = UNITW ? yccp : yccp + (pair ? b + h : b)*32u;
@@ -866,15 +880,15 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	// the residual estimator and the best are taken in (score, index) order.
 	// Highest instead refits every partition (below), after a stream 0 without partitions.
 	const bool lay32 = !WIDE;
-	const uint32_t hl = lay32 ? (lane & 31u) : lane;
-	const bool slot_ok = !lay32 || pair || lane < 32u;
+#define hl (lay32 ? (lane & 31u) : lane)
+#define slot_ok (!lay32 || pair || lane < 32u)
 	bool solved = false;
 	{
 		const uint32_t nstreams = (WIDE && !has_alpha) ? 2u : 1u;
 		const Tex txp = make_tex(tp, pl, yc, 0u, has_alpha ? 15u : 7u);   // partition fits: no rotation
 #pragma unroll 1
 		for (uint32_t st = 0; st < nstreams && !solved; ++st) {
-			asm volatile("" : "+v"(lane));   // roles are recomputed per stream, not kept
+			CF_FRESH_LANE(lane);   // roles are recomputed per stream, not kept
 			const uint32_t ns = 2u + st;
 			const bool parts = quality >= 1u;
 			// partition lanes: first lane, slots of the first mode, slots in all
@@ -885,12 +899,14 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			} else if (st == 1u) { pfirst = 0u; nper0 = 5u; nslots = 10u; }
 			else if (has_alpha) { pfirst = 26u; nper0 = 16u; nslots = 16u; }
 			else { pfirst = 26u; nper0 = 8u; nslots = 16u; }
-			const uint32_t rel = hl - pfirst;                            // wraps below pfirst
-			const uint32_t slotidx = st == 1u ? rel/3u : rel >> 1;
-			const uint32_t sub = rel - slotidx*ns;
-			const bool plane = parts && slot_ok && hl >= pfirst && slotidx < nslots;
-			const uint32_t mi = slotidx >= nper0 ? 1u : 0u;
-			const uint32_t rank = slotidx - mi*nper0;
+			// lane roles as expressions of the CURRENT lane id (re-read where a phase starts), so that none of
+			// them is carried in a register through the fit
+#define R_REL (hl - pfirst)                                   /* wraps below pfirst */
+#define R_SLOT (st == 1u ? R_REL/3u : R_REL >> 1)
+#define R_SUB (R_REL - R_SLOT*ns)
+#define R_PLANE (parts && slot_ok && hl >= pfirst && R_SLOT < nslots)
+#define R_MI (R_SLOT >= nper0 ? 1u : 0u)
+#define R_RANK (R_SLOT - R_MI*nper0)
 			uint32_t mypart = 0;
 			// ---- phase 1: partition scores (one partition per lane, two when the group has
 			// only 32 lanes) and selection of the nper0 best by iterated group minimum ----
@@ -924,7 +940,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 					const uint32_t nsel = lay32 ? (quality == 2u ? (any_alpha ? 11u : 6u) : 14u) : nper0;
 					for (uint32_t t = 0; t < nsel; ++t) {
 						const uint32_t kmin = cf_group_min_u32(ka < kb ? ka : kb, pair, h);
-						const bool mine = rank == t && (st == 0u || mi == run);
+						const bool mine = R_RANK == t && (st == 0u || R_MI == run);
 						mypart = mine ? (kmin & 63u) : mypart;
 						ka = ka == kmin ? 0xFFFFFFFFu : ka;
 						kb = kb == kmin ? 0xFFFFFFFFu : kb;
@@ -932,28 +948,17 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 				}
 			}
 			// ---- lane roles ----
-			asm volatile("" : "+v"(lane), "+v"(mypart));   // nothing of phase 1 but mypart lives on
-			const bool m6 = st == 0u && slot_ok && hl < 2u;
-			bool sca, vecp;
-			uint32_t cid;
-			if (lay32) {
-				if (quality == 2u) {
-					vecp = slot_ok && hl >= 2u && hl < 6u;
-					sca = slot_ok && hl >= 6u && hl < 10u;
-					cid = hl - (sca ? 5u : 1u);
-				} else {
-					vecp = slot_ok && hl == 2u;
-					sca = slot_ok && hl == 3u;
-					cid = 1u;
-				}
-			} else {
-				sca = st == 0u && lane >= 14u && lane < 26u;
-				vecp = st == 0u && lane >= 2u && lane < 14u;
-				cid = 1u + (lane - (sca ? 14u : 2u));
-			}
+			CF_FRESH_LANE(lane);
+			asm volatile("" : "+v"(mypart));   // nothing of phase 1 but mypart lives on
+#define R_M6 (st == 0u && slot_ok && hl < 2u)
+#define R_VECP (lay32 ? (quality == 2u ? (slot_ok && hl >= 2u && hl < 6u) : (slot_ok && hl == 2u)) : (st == 0u && lane >= 2u && lane < 14u))
+#define R_SCA (lay32 ? (quality == 2u ? (slot_ok && hl >= 6u && hl < 10u) : (slot_ok && hl == 3u)) : (st == 0u && lane >= 14u && lane < 26u))
+#define R_CID (R_M6 ? 0u : (lay32 ? (quality == 2u ? hl - (R_SCA ? 5u : 1u) : 1u) : 1u + (lane - (R_SCA ? 14u : 2u))))   /* meaningful for vecp / sca */
+#define R_IDBASE (R_PLANE ? (st == 1u ? (R_MI ? 256u : 192u) : (has_alpha ? 320u : (R_MI ? 128u : 64u))) : 0u)
+			const bool m6 = R_M6, sca = R_SCA, vecp = R_VECP, plane = R_PLANE;
+			const uint32_t cid = R_CID, sub = R_SUB, mi = R_MI;
 			const uint32_t s2off = lay32 ? (quality == 2u ? 4u : 1u) : (st == 0u ? 12u : 2u);
-			cid = m6 ? 0u : cid;   // meaningful for vecp / sca
-			uint32_t rot = 0, cb = 7, ab = 7, pbk = 1, ib = 4, idbase = 0, mask = 0xFFFFu;
+			uint32_t rot = 0, cb = 7, ab = 7, pbk = 1, ib = 4, mask = 0xFFFFu;
 			bool active = m6;
 			if (vecp || sca) {
 				if (cid <= 4u) {
@@ -975,11 +980,11 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 				if (st == 1u) mode = mi ? 2u : 0u;
 				else mode = has_alpha ? 7u : (mi ? 3u : 1u);
 				switch (mode) {
-					case 1: cb = 6; ab = 0; pbk = 2; ib = 3; idbase = 64; break;
-					case 3: cb = 7; ab = 0; pbk = 1; ib = 2; idbase = 128; break;
-					case 0: cb = 4; ab = 0; pbk = 1; ib = 3; idbase = 192; break;
-					case 2: cb = 5; ab = 0; pbk = 0; ib = 2; idbase = 256; break;
-					default: cb = 5; ab = 5; pbk = 1; ib = 2; idbase = 320; break;
+					case 1: cb = 6; ab = 0; pbk = 2; ib = 3; break;
+					case 3: cb = 7; ab = 0; pbk = 1; ib = 2; break;
+					case 0: cb = 4; ab = 0; pbk = 1; ib = 3; break;
+					case 2: cb = 5; ab = 0; pbk = 0; ib = 2; break;
+					default: cb = 5; ab = 5; pbk = 1; ib = 2; break;
 				}
 				const uint32_t sp2 = k_part2[mypart], sp3 = k_part3[mypart];
 				if (st == 0u)
@@ -1015,6 +1020,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			if (active)
 				fit_lane<UNITW>(make_tex(tp, pl, yc, rot, chm), mask, m6, lane & 1u, cb, ab, pbk, ib, iters,
 					wv, yw, sca, lf);
+			CF_FRESH_LANE(lane);         // the roles below are computed again from here
 			// ---- assemble candidates in their leader lanes ----
 			//   mode 6: its first lane;  mode 4/5: vector lane (scalar plane s2off lanes up);
 			//   partitions: subset-0 lane (the other subsets in the next lanes)
@@ -1022,45 +1028,45 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			const int s2 = (int)((lane + s2off) & 63u);
 			// error and id first: only a leader whose candidate beats its best so far stores
 			// the payload fields, straight from the shuffles into its LDS column
-			const uint32_t e1 = (uint32_t)__shfl((int)lf.err, s1, 64), e2 = (uint32_t)__shfl((int)lf.err, s2, 64);
-			const bool use1 = plane, use2 = vecp || (plane && st == 1u);
+			const uint32_t e1 = (uint32_t)cf_bperm((int)lf.err, (uint32_t)(s1)), e2 = (uint32_t)cf_bperm((int)lf.err, (uint32_t)(s2));
+			const bool use1 = R_PLANE, use2 = R_VECP || (R_PLANE && st == 1u);
 			const uint32_t cerr = lf.err + (use1 ? e1 : 0u) + (use2 ? e2 : 0u);
-			const uint32_t cidv = m6 ? 0u : (vecp ? cid : idbase + mypart);
-			const bool leader = active && (m6 ? hl == 0u : (vecp || (plane && sub == 0u)));
+			const uint32_t cidv = R_M6 ? 0u : (R_VECP ? R_CID : R_IDBASE + mypart);
+			const bool leader = active && (R_M6 ? hl == 0u : (R_VECP || (R_PLANE && R_SUB == 0u)));
 			const bool take = leader && (cerr < best_err || (cerr == best_err && cidv < best_id));
 			if (take) {
 				best_err = cerr;
 				best_id = cidv;
 			}
 			{
-				const uint32_t a01 = (uint32_t)__shfl((int)lf.q0, s1, 64), a11 = (uint32_t)__shfl((int)lf.q1, s1, 64);
-				const uint32_t a02 = (uint32_t)__shfl((int)lf.q0, s2, 64), a12 = (uint32_t)__shfl((int)lf.q1, s2, 64);
-				const uint32_t pb1 = (uint32_t)__shfl((int)lf.pb, s1, 64), pb2 = (uint32_t)__shfl((int)lf.pb, s2, 64);
+				const uint32_t a01 = (uint32_t)cf_bperm((int)lf.q0, (uint32_t)(s1)), a11 = (uint32_t)cf_bperm((int)lf.q1, (uint32_t)(s1));
+				const uint32_t a02 = (uint32_t)cf_bperm((int)lf.q0, (uint32_t)(s2)), a12 = (uint32_t)cf_bperm((int)lf.q1, (uint32_t)(s2));
+				const uint32_t pb1 = (uint32_t)cf_bperm((int)lf.pb, (uint32_t)(s1)), pb2 = (uint32_t)cf_bperm((int)lf.pb, (uint32_t)(s2));
 				if (take) {
 					cslot[0*CF_WG_THREADS] = lf.q0;
 					cslot[1*CF_WG_THREADS] = lf.q1;
-					cslot[2*CF_WG_THREADS] = plane ? a01 : 0u;
-					cslot[3*CF_WG_THREADS] = plane ? a11 : 0u;
+					cslot[2*CF_WG_THREADS] = R_PLANE ? a01 : 0u;
+					cslot[3*CF_WG_THREADS] = R_PLANE ? a11 : 0u;
 					// modes 4/5: the scalar plane's endpoints are parked in q[4], q[5] (byte 3)
-					cslot[4*CF_WG_THREADS] = vecp ? (a02 & 0xFF000000u) : ((plane && st == 1u) ? a02 : 0u);
-					cslot[5*CF_WG_THREADS] = vecp ? (a12 & 0xFF000000u) : ((plane && st == 1u) ? a12 : 0u);
-					cslot[6*CF_WG_THREADS] = lf.pb | (plane ? (pb1 << 2) : 0u) |
-						((plane && st == 1u) ? (pb2 << 4) : 0u);
+					cslot[4*CF_WG_THREADS] = R_VECP ? (a02 & 0xFF000000u) : ((R_PLANE && st == 1u) ? a02 : 0u);
+					cslot[5*CF_WG_THREADS] = R_VECP ? (a12 & 0xFF000000u) : ((R_PLANE && st == 1u) ? a12 : 0u);
+					cslot[6*CF_WG_THREADS] = lf.pb | (R_PLANE ? (pb1 << 2) : 0u) |
+						((R_PLANE && st == 1u) ? (pb2 << 4) : 0u);
 					// errors of the candidate's fits: subset 0 / vector plane / mode 6, then subset 1 or
 					// the scalar plane, then subset 2
 					cslot[15*CF_WG_THREADS] = lf.err;
-					cslot[16*CF_WG_THREADS] = plane ? e1 : (vecp ? e2 : 0u);
-					cslot[17*CF_WG_THREADS] = (plane && st == 1u) ? e2 : 0u;
+					cslot[16*CF_WG_THREADS] = R_PLANE ? e1 : (R_VECP ? e2 : 0u);
+					cslot[17*CF_WG_THREADS] = (R_PLANE && st == 1u) ? e2 : 0u;
 				}
 			}
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
-				const uint32_t w1 = (uint32_t)__shfl((int)lf.w[k], s1, 64);
-				const uint32_t w2 = (uint32_t)__shfl((int)lf.w[k], s2, 64);
+				const uint32_t w1 = (uint32_t)cf_bperm((int)lf.w[k], (uint32_t)(s1));
+				const uint32_t w2 = (uint32_t)cf_bperm((int)lf.w[k], (uint32_t)(s2));
 				if (take) {
-					cslot[(7 + k)*CF_WG_THREADS] = lf.w[k] | (plane ? w1 : 0u) |
-						((plane && st == 1u) ? w2 : 0u);
-					cslot[(11 + k)*CF_WG_THREADS] = vecp ? w2 : 0u;
+					cslot[(7 + k)*CF_WG_THREADS] = lf.w[k] | (R_PLANE ? w1 : 0u) |
+						((R_PLANE && st == 1u) ? w2 : 0u);
+					cslot[(11 + k)*CF_WG_THREADS] = R_VECP ? w2 : 0u;
 				}
 			}
 			// A zero-error candidate cannot be beaten by a later one (ids grow with the
@@ -1070,17 +1076,29 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			// of at least 48 (oracle: same rule); one block per wave here, so this is uniform
 			if (WIDE && cf_wave_min_u32(best_err) < 48u)
 				solved = true;
+#undef R_REL
+#undef R_SLOT
+#undef R_SUB
+#undef R_PLANE
+#undef R_MI
+#undef R_RANK
+#undef R_M6
+#undef R_VECP
+#undef R_SCA
+#undef R_CID
+#undef R_IDBASE
 		}
 	}
 
 	// ---- group argmin on (error, id); the group packs its winner's candidate ----
+	CF_FRESH_LANE(lane);
 	const unsigned long long key = ((unsigned long long)best_err << 32) | best_id;
 	const unsigned long long kmin = cf_group_min_u64(key, pair, h);
 	const unsigned long long bal = __ballot(key == kmin);
 	const uint32_t gmask = pair ? (h ? (uint32_t)(bal >> 32) : (uint32_t)bal) : 0u;
 	const uint32_t wl = pair ? hbase + (uint32_t)__ffs((int)gmask) - 1u
 		: (uint32_t)__ffsll((long long)bal) - 1u;   // winner lane (unique key in its group)
-	uint32_t* wc = cslot - lane0 + wl;              // the winner's column
+	uint32_t* wc = cbase + wl;                      // the winner's column
 
 	// ---- High / Highest: endpoint perturbation of the winner (oracle: uber_refine) ----
 	// lane = (fit of the winner, move slot): 16 slots per fit -- endpoint m >> 3, channel (m >> 1) & 3,
@@ -1192,7 +1210,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			uint32_t key = valid ? ((f.err << 4) | mv) : 0xFFFFFFFFu;
 			uint32_t fitmin = cf_row_min_u32(key);
 			if (m6) {
-				const uint32_t other = (uint32_t)__shfl_xor((int)fitmin, 16, 64);
+				const uint32_t other = (uint32_t)cf_bperm((int)fitmin, lane ^ 16u);
 				fitmin = other < fitmin ? other : fitmin;
 			}
 			const bool win = valid && key == fitmin && f.err < cur_err && (!m6 || (hl & 1u) == 0u);
@@ -1223,23 +1241,33 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 				break;       // no fit of any block of this wave moved: later rounds would repeat this one
 		}
 	}
-	return pack_block_group(wc, (uint32_t)kmin, lane0, pair);
+	CF_FRESH_LANE(lane);
+	return pack_block_group(wc, (uint32_t)kmin, lane, pair);
+#undef h
+#undef hbase
+#undef hl
+#undef slot_ok
+#undef cslot
 }
 
 } // namespace
 
 // Waves per SIMD the register allocation is held to.  The kernel is VALU-issue-bound
-// (tools/ubench/valu_rate.hip) with LDS / cross-lane latency to hide.  3 waves = 166 registers and
-// no scratch.  4 waves (128 registers, 48 B of scratch per lane) run 3 % faster in A/B, 5 waves
-// (96, 136 B) 3 % faster again -- but the scratch reaches HBM: PMC traffic per launch 108 MB and
-// 5 GB against 84 MB algorithmic (profiles/r02_occupancy_ab.txt).  A search kernel that re-reads
-// nothing is worth more than 3 %: 3 waves.
+// (tools/ubench/valu_rate.hip) with LDS / cross-lane latency to hide, and a fourth wave hides 3 %
+// more of it (profiles/r02_occupancy_ab.txt).  Round 2 stayed at 3 waves (166 registers) because
+// the 128-register build spilled 12 values whose scratch traffic reached HBM (108 MB per launch
+// against 84 MB algorithmic).  Round 3 removed what was spilled -- every one a function of the lane
+// id or of the wave index: the wave index is a scalar now (loop counter, block index and pair flag
+// live in SGPRs), the lane id is re-read with a volatile mbcnt pair where a phase starts, the lane
+// roles are expressions of it instead of variables carried through the fit, and __shfl's hidden
+// lane-id arithmetic is gone (cf_bperm) -- so the linear-metric builds fit 128 registers with
+// private_segment_fixed_size 0.  The perceptual builds (UNITW = false) still need 3 waves.
 #ifndef CF_BC7_WAVES
-#define CF_BC7_WAVES 3
+#define CF_BC7_WAVES(UNITW) ((UNITW) ? 4 : 3)
 #endif
 template <int PIX, bool UNITW, bool WIDE>
 __global__ void __launch_bounds__(CF_WG_THREADS)
-__attribute__((amdgpu_waves_per_eu(CF_BC7_WAVES, CF_BC7_WAVES)))
+__attribute__((amdgpu_waves_per_eu(CF_BC7_WAVES(UNITW), CF_BC7_WAVES(UNITW))))
 cfhip_bc7_encode_kernel(cf_kparams kp)
 {
 	__shared__ uint32_t cands[CF_BC7_CAND_WORDS*CF_WG_THREADS];
@@ -1270,7 +1298,9 @@ cfhip_bc7_encode_kernel(cf_kparams kp)
 	}
 	__syncthreads();
 
-	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	// wave index as a scalar (the loop counter, block index and pair flag then live in SGPRs), lane id
+	// from mbcnt where it is needed: nothing derived from threadIdx stays in a VGPR across the phases
+	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	// the wave's 4 blocks; up to High two neighbouring blocks share one pass
 	for (uint32_t j = 0; j < 4u;) {
 		const uint32_t b = wave*4u + j;
@@ -1280,20 +1310,21 @@ cfhip_bc7_encode_kernel(cf_kparams kp)
 			!(CF_BC7_ABLATE & 4);
 		// opaque copy: keeps the (many) lane-role values of encode_blocks from being hoisted
 		// out of this loop and held in registers across all phases
-		uint32_t ln = lane;
-		asm volatile("" : "+v"(ln));
-		const uint4 blk = encode_blocks<UNITW, WIDE>(tile, plan, yccp, b, pair, cands + threadIdx.x, kp, ln);
+		const uint4 blk = encode_blocks<UNITW, WIDE>(tile, plan, yccp, b, pair, cands + wave*64u, kp);
+		uint32_t lo;
+		asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
 		if (pair) {
-			if ((lane & 31u) == 0u)
-				outb[b + (lane >> 5)] = blk;
-		} else if (lane == 0u)
+			if ((lo & 31u) == 0u)
+				outb[b + (lo >> 5)] = blk;
+		} else if (lo == 0u)
 			outb[b] = blk;
 		j += pair ? 2u : 1u;
 	}
 	__syncthreads();
 	// coalesced payload store: 16 blocks x 16 B = 256 B contiguous
-	const uint32_t t = threadIdx.x;
-	if (t < 64u) {
+	if (wave == 0u) {
+		uint32_t t;
+		asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(t));
 		const uint32_t b = t >> 2;
 		if (bx0 + b < kp.bx) {
 			const uint32_t* o = reinterpret_cast<const uint32_t*>(outb);
