@@ -808,7 +808,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	uint8_t* sh_wtab = lds + off; off += 2016u;
 	const uint32_t slot_bytes = ((10u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
 	const uint32_t wave_bytes = ((((col_rows + 1u)/2u)*256u + 15u) & ~15u) + (kp.quality <= 3u ? 2u : 1u)*slot_bytes;
-	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	// the wave index as a scalar: block indices, the pair flag and the block loop counter live in SGPRs
+	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	uint32_t lane = threadIdx.x & 63u;
 	uint8_t* wbase = lds + off + wave*wave_bytes;
 
 	for (uint32_t i = threadIdx.x; i < ngrids*n*2u; i += nthreads)
@@ -928,7 +930,6 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	const uint8_t* ncfgs = blob + H->off_ncfg;
 
 	// a lane's weight column (layout: decim_add / normalise_rows / infill_w above)
-	uint8_t* colbase = wbase + lane*4u;
 	uint8_t* slot0 = wbase + ((((col_rows + 1u)/2u)*256u + 15u) & ~15u);
 
 	const uint32_t q = kp.quality > 4u ? 4u : kp.quality;
@@ -944,6 +945,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	const uint32_t recip_n = 65536u/n;                                          // x / n as (x * recip_n) >> 16, like the oracle
 
 	for (uint32_t jb = 0; jb < 4u;) {
+		// the lane id is re-read per block (a volatile mbcnt pair): nothing derived from it is hoisted out of
+		// this loop and held -- or spilled -- across the phases
+		asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+		uint8_t* colbase = wbase + lane*4u;
 		const uint32_t b0 = wave*4u + jb;
 		if (bx0 + b0 >= kp.bx)
 			break;
@@ -1018,7 +1023,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			C.c23 = (float)(ni*(int)cf_group_sum_u32(m23, pair, h) - sum[2]*sum[3]);
 			C.c33 = (float)(ni*(int)cf_group_sum_u32(m33, pair, h) - sum[3]*sum[3]);
 		}
-		const float in = 1.0f/(float)n;
+		const float in = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f/(float)n)));
 		float mean[4], axis[4];
 #pragma unroll
 		for (int c = 0; c < 4; ++c)
@@ -1250,7 +1255,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		const uint32_t alpha_i = has_alpha ? 1u : 0u;
 		uint32_t npc_max = npc;
 		if (pair) {
-			const uint32_t o = (uint32_t)__shfl_xor((int)npc, 32, 64);
+			const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ^ 32u) << 2), (int)npc);
 			npc_max = max(npc, o);
 		}
 		// early out (oracle: same rule): no two-partition candidate of pass 0 beat the best
@@ -1260,6 +1265,12 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		for (uint32_t base = 0, pass = 0; base < npc_max; base += per_pass, ++pass) {
 			if (pass >= 1u && !pair && e2min != ~0ull && e2min >= e1min)
 				break;
+			// lane id and what follows from it, re-read per pass (shadowing the block's): the pass's lane roles
+			// and LDS addresses are not computed ahead of the loop and carried -- or spilled -- through it
+			uint32_t lane;
+			asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+			const uint32_t h = pair ? lane >> 5 : 0u, hl = pair ? (lane & 31u) : lane;
+			uint8_t* colbase = wbase + lane*4u;
 			const uint32_t cnt = base >= npc ? 0u : (npc - base < per_pass ? npc - base : per_pass);
 			// partition rows of this pass's candidates
 			for (uint32_t j = 0; j < cnt; ++j) {
@@ -1305,7 +1316,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						q22 += c2*c2; q23 += c2*c3; q33 += c3*c3;
 					}
 					if (!pair) {
-#define ASTC_PAIRSUM(v) v += __shfl_xor(v, 32, 64)
+#define ASTC_PAIRSUM(v) v += __builtin_amdgcn_ds_bpermute((int)((lane ^ 32u) << 2), v)
 						ASTC_PAIRSUM(cnt_t); ASTC_PAIRSUM(a0); ASTC_PAIRSUM(a1); ASTC_PAIRSUM(a2); ASTC_PAIRSUM(a3);
 						ASTC_PAIRSUM(q00); ASTC_PAIRSUM(q01); ASTC_PAIRSUM(q02); ASTC_PAIRSUM(q03); ASTC_PAIRSUM(q11);
 						ASTC_PAIRSUM(q12); ASTC_PAIRSUM(q13); ASTC_PAIRSUM(q22); ASTC_PAIRSUM(q23); ASTC_PAIRSUM(q33);
@@ -1335,8 +1346,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						hi_t = in_ ? fmaxf(hi_t, t) : hi_t;
 					}
 					if (!pair) {
-						lo_t = fminf(lo_t, __shfl_xor(lo_t, 32, 64));
-						hi_t = fmaxf(hi_t, __shfl_xor(hi_t, 32, 64));
+						lo_t = fminf(lo_t, __int_as_float(__builtin_amdgcn_ds_bpermute((int)((lane ^ 32u) << 2), __float_as_int(lo_t))));
+						hi_t = fmaxf(hi_t, __int_as_float(__builtin_amdgcn_ds_bpermute((int)((lane ^ 32u) << 2), __float_as_int(hi_t))));
 					}
 					int e0[4] = {0, 0, 0, 0}, e1[4] = {0, 0, 0, 0}, s0 = 0, s1 = 0;
 #pragma unroll
@@ -1433,7 +1444,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					}
 				}
 				if (!pair)
-					e += (uint32_t)__shfl_xor((int)e, 32, 64);
+					e += (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ^ 32u) << 2), (int)e);
 				if (gact && half == 0u)
 					S.edec[g] = e;
 				__builtin_amdgcn_wave_barrier();
