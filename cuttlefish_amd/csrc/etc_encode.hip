@@ -432,10 +432,10 @@ __device__ __forceinline__ bool th_search(const uint32_t* tp, const RgbOpts& o, 
 		return false;
 	{
 		const int src = (int)(2u*(uint32_t)kmin);   // first lane of the winning candidate
-		best.mode = __shfl(t.mode, src, 64);
-		best.c0 = (uint32_t)__shfl((int)t.c0, src, 64);
-		best.c1 = (uint32_t)__shfl((int)t.c1, src, 64);
-		best.di = __shfl(t.di, src, 64);
+		best.mode = __builtin_amdgcn_ds_bpermute(src << 2, t.mode);
+		best.c0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)t.c0);
+		best.c1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)t.c1);
+		best.di = __builtin_amdgcn_ds_bpermute(src << 2, t.di);
 		best.err = (uint32_t)(kmin >> 32);
 	}
 	for (int r = 0; r < rounds; ++r) {
@@ -465,9 +465,9 @@ __device__ __forceinline__ bool th_search(const uint32_t* tp, const RgbOpts& o, 
 		if ((uint32_t)(kmin >> 32) >= best.err)
 			break;
 		const int src = (int)(4u*(uint32_t)kmin);
-		best.c0 = (uint32_t)__shfl((int)mvc.c0, src, 64);
-		best.c1 = (uint32_t)__shfl((int)mvc.c1, src, 64);
-		best.di = __shfl(mvc.di, src, 64);
+		best.c0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)mvc.c0);
+		best.c1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)mvc.c1);
+		best.di = __builtin_amdgcn_ds_bpermute(src << 2, mvc.di);
 		best.err = (uint32_t)(kmin >> 32);
 	}
 	return true;
@@ -513,10 +513,12 @@ __device__ __forceinline__ uint2 pack_th(const uint32_t* tp, const RgbOpts& o, T
 __device__ __forceinline__ void group_min8(unsigned long long& key, uint32_t& pay)
 {
 #pragma unroll
-	for (int off = 1; off <= 4; off <<= 1) {
-		const uint32_t klo = (uint32_t)__shfl_xor((int)(uint32_t)key, off, 64);
-		const uint32_t khi = (uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), off, 64);
-		const uint32_t op = (uint32_t)__shfl_xor((int)pay, off, 64);
+	for (int step = 0; step < 3; ++step) {
+		// DPP exchanges inside the group of 8: lane ^ 1, lane ^ 2, then the mirror image in the other quad
+		// (keys are unique, so every lane of the group ends with the same pair)
+		const uint32_t klo = step == 0 ? cf_xor1((uint32_t)key) : (step == 1 ? cf_xor2((uint32_t)key) : cf_dpp<0x141>((uint32_t)key));
+		const uint32_t khi = step == 0 ? cf_xor1((uint32_t)(key >> 32)) : (step == 1 ? cf_xor2((uint32_t)(key >> 32)) : cf_dpp<0x141>((uint32_t)(key >> 32)));
+		const uint32_t op = step == 0 ? cf_xor1(pay) : (step == 1 ? cf_xor2(pay) : cf_dpp<0x141>(pay));
 		const unsigned long long ok = ((unsigned long long)khi << 32) | klo;
 		if (ok < key) { key = ok; pay = op; }
 	}
@@ -624,8 +626,9 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 		}
 		// the other half of the list: same group and table in lane ^ 32; first candidate of the smallest error
 		{
-			const uint32_t oe = (uint32_t)__shfl_xor((int)berr, 32, 64), oc = (uint32_t)__shfl_xor((int)bcand, 32, 64),
-				oq = (uint32_t)__shfl_xor((int)bq, 32, 64);
+			const int ol = (int)((lane ^ 32u) << 2);
+			const uint32_t oe = (uint32_t)__builtin_amdgcn_ds_bpermute(ol, (int)berr), oc = (uint32_t)__builtin_amdgcn_ds_bpermute(ol, (int)bcand),
+				oq = (uint32_t)__builtin_amdgcn_ds_bpermute(ol, (int)bq);
 			const bool take = oe < berr || (oe == berr && oc < bcand);
 			berr = take ? oe : berr; bcand = take ? oc : bcand; bq = take ? oq : bq;
 		}
@@ -923,7 +926,7 @@ __device__ __forceinline__ uint2 eac_search(const uint32_t* tp, uint32_t* pre, i
 	}
 	const unsigned long long kmin = cf_wave_min_u64(key);
 	const uint32_t wl = (uint32_t)__builtin_ctzll(__ballot(key == kmin));
-	pay = (uint32_t)__shfl((int)pay, (int)wl, 64);
+	pay = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(wl << 2), (int)pay);
 	const int base = (int)(short)(pay & 0xFFFFu), mult = (int)((pay >> 16) & 255u),
 		table = (int)(pay >> 24);
 	// selectors: lane i < 16 owns texel i, the 48 index bits are the OR of the 16 contributions
@@ -965,14 +968,18 @@ __device__ __forceinline__ uint32_t r11_word(float f, bool snorm)
 
 } // namespace
 
-// register budget: at least 4 waves/SIMD (128 VGPRs) for every variant -- ETC2 A1 and RGBA8 ran at 3
-// (132 / 144 registers) and gain 10 % / 9 % from the fourth wave with no scratch (RGBA8: 8 bytes).
-// 5 waves (96 registers) are another 4-6 % faster, but their 44-124 bytes of scratch per lane reach
-// HBM (PMC WRITE_SIZE 27 / 189 / 496 MB per 2048^2 launch against a 2-4 MB payload): not taken
-// (profiles/r02_occupancy_ab.txt)
+// register budget: at least 5 waves/SIMD (96 VGPRs) for every variant, no scratch.  Round 2 stopped at 4:
+// the 96-register builds spilled 44-124 bytes per lane and the scratch reached HBM
+// (profiles/r02_occupancy_ab.txt).  What was spilled were functions of the lane id and of the wave
+// index; with the wave index a scalar, the lane id re-read per block (a volatile mbcnt pair) and the
+// cross-lane moves as DPP / ds_bpermute without __shfl's lane arithmetic, ETC1 / ETC2 RGB need 91 / 92
+// registers by themselves and A1 / RGBA8 fit 96.
 template <int PIX, int FMT, bool SNORM>
 __global__ void __launch_bounds__(CF_WG_THREADS)
-__attribute__((amdgpu_waves_per_eu(4, 8)))
+#ifndef CF_ETC_MINW
+#define CF_ETC_MINW 5
+#endif
+__attribute__((amdgpu_waves_per_eu(CF_ETC_MINW, 8)))
 cfhip_etc_encode_kernel(cf_kparams kp)
 {
 	constexpr bool IS_EAC = FMT == E_R11 || FMT == E_RG11;
@@ -1010,7 +1017,9 @@ cfhip_etc_encode_kernel(cf_kparams kp)
 	}
 	__syncthreads();
 
-	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	// the wave index as a scalar (block index, tile pointer and edge tests live in SGPRs); the lane id is
+	// re-read per block so that nothing derived from it is carried across the searches
+	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	uint32_t* pre = pre_tab + (FMT == E_A8 ? wave*256u : (IS_EAC ? wave*2048u : 0u));
 	const uint32_t q = kp.quality;
 	const int R = q <= 1u ? 1 : (q == 2u ? 2 : 4);
@@ -1018,6 +1027,8 @@ cfhip_etc_encode_kernel(cf_kparams kp)
 		const uint32_t b = wave*4u + j;
 		if (bx0 + b >= kp.bx)
 			break;
+		uint32_t lane;
+		asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
 		const uint32_t* tp = tile + b*16u;
 		// texels inside the image (EtcConverter.cpp:122-129)
 		uint32_t valid = 0;
