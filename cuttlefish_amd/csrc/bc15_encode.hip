@@ -273,7 +273,7 @@ __device__ __forceinline__ uint2 bc4_search(const uint32_t* tp, uint32_t* pre, i
 	const unsigned long long key = ((unsigned long long)best_err << 32) | best_id;
 	const unsigned long long kmin = cf_wave_min_u64(key);
 	const uint32_t wl = (uint32_t)__builtin_ctzll(__ballot(key == kmin));
-	const int a0 = __shfl(best_a0, (int)wl, 64), a1 = __shfl(best_a1, (int)wl, 64);
+	const int a0 = __builtin_amdgcn_ds_bpermute((int)(wl << 2), best_a0), a1 = __builtin_amdgcn_ds_bpermute((int)(wl << 2), best_a1);
 	int pal[8];
 	bc4_palette(a0, a1, a0 <= a1, vmin, pal);
 	// selectors: lane i < 16 owns texel i (three bits at 3i), OR over the wavefront
@@ -588,7 +588,7 @@ __device__ __forceinline__ void cluster_fit(const uint32_t* tp, const COpts& o, 
 		uint32_t rank = 0;
 #pragma unroll 1
 		for (uint32_t j = 0; j < 16u; ++j) {
-			const float tj = __shfl(t, (int)((lane & 48u) + j), 64);
+			const float tj = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(((lane & 48u) + j) << 2), __float_as_int(t)));
 			const bool before = ((o.active >> j) & 1u) && (tj < t || (tj == t && j < ti));
 			rank += before ? 1u : 0u;
 		}
@@ -596,12 +596,12 @@ __device__ __forceinline__ void cluster_fit(const uint32_t* tp, const COpts& o, 
 		uint32_t P01 = 0, P2 = 0;
 #pragma unroll 1
 		for (uint32_t i = 0; i < 16u; ++i) {
-			const uint32_t ri = (uint32_t)__shfl((int)rank, (int)i, 64), pi = tp[i];
+			const uint32_t ri = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(i << 2), (int)rank), pi = tp[i];
 			const bool in = ((o.active >> i) & 1u) && ri < lane;
 			P01 += in ? (ub(pi, 0) | (ub(pi, 1) << 16)) : 0u;
 			P2 += in ? ub(pi, 2) : 0u;
 		}
-		const uint32_t Pn01 = (uint32_t)__shfl((int)P01, n, 64), Pn2 = (uint32_t)__shfl((int)P2, n, 64);
+		const uint32_t Pn01 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(n << 2), (int)P01), Pn2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(n << 2), (int)P2);
 		unsigned long long bkey = ~0ull;
 		uint32_t bab = 0;
 		const int Pn[3] = {(int)(Pn01 & 0xFFFFu), (int)(Pn01 >> 16), (int)Pn2};
@@ -645,9 +645,9 @@ __device__ __forceinline__ void cluster_fit(const uint32_t* tp, const COpts& o, 
 				const uint32_t ent = sidx < 969u ? k_splits.v[sidx] : 0x7FFFu;
 				const uint32_t i = ent & 31u, j = (ent >> 5) & 31u, k = (ent >> 10) & 31u;
 				const bool want = sidx < 969u && k <= (uint32_t)n;
-				const uint32_t Pi01 = (uint32_t)__shfl((int)P01, (int)i, 64), Pi2 = (uint32_t)__shfl((int)P2, (int)i, 64);
-				const uint32_t Pj01 = (uint32_t)__shfl((int)P01, (int)j, 64), Pj2 = (uint32_t)__shfl((int)P2, (int)j, 64);
-				const uint32_t Pk01 = (uint32_t)__shfl((int)P01, (int)k, 64), Pk2 = (uint32_t)__shfl((int)P2, (int)k, 64);
+				const uint32_t Pi01 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(i << 2), (int)P01), Pi2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(i << 2), (int)P2);
+				const uint32_t Pj01 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)P01), Pj2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)P2);
+				const uint32_t Pk01 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(k << 2), (int)P01), Pk2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(k << 2), (int)P2);
 				const int Pi[3] = {(int)(Pi01 & 0xFFFFu), (int)(Pi01 >> 16), (int)Pi2};
 				const int Pj[3] = {(int)(Pj01 & 0xFFFFu), (int)(Pj01 >> 16), (int)Pj2};
 				const int Pk[3] = {(int)(Pk01 & 0xFFFFu), (int)(Pk01 >> 16), (int)Pk2};
@@ -674,8 +674,8 @@ __device__ __forceinline__ void cluster_fit(const uint32_t* tp, const COpts& o, 
 				const uint32_t j = i + rem;
 				const bool want = t3 < 153u && j <= (uint32_t)n;
 				const uint32_t ii = i & 31u, jj = j & 31u;
-				const uint32_t Pi01 = (uint32_t)__shfl((int)P01, (int)ii, 64), Pi2 = (uint32_t)__shfl((int)P2, (int)ii, 64);
-				const uint32_t Pj01 = (uint32_t)__shfl((int)P01, (int)jj, 64), Pj2 = (uint32_t)__shfl((int)P2, (int)jj, 64);
+				const uint32_t Pi01 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ii << 2), (int)P01), Pi2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ii << 2), (int)P2);
+				const uint32_t Pj01 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jj << 2), (int)P01), Pj2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jj << 2), (int)P2);
 				const int Pi[3] = {(int)(Pi01 & 0xFFFFu), (int)(Pi01 >> 16), (int)Pi2};
 				const int Pj[3] = {(int)(Pj01 & 0xFFFFu), (int)(Pj01 >> 16), (int)Pj2};
 				const int n0 = (int)i, n1 = (int)(j - i), n3 = n - (int)j;
@@ -693,7 +693,7 @@ __device__ __forceinline__ void cluster_fit(const uint32_t* tp, const COpts& o, 
 		if (kmin == ~0ull)
 			break;
 		const uint32_t wl = (uint32_t)__builtin_ctzll(__ballot(bkey == kmin));
-		const uint32_t wab = (uint32_t)__shfl((int)bab, (int)wl, 64);
+		const uint32_t wab = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(wl << 2), (int)bab);
 		const uint32_t ba = wab & 0xFFFFu, bb = wab >> 16;
 		consider<UNITW>(tp, o, ba, bb, 0x10000u + 2u*iter, cur);   // uniform: every lane, same pair
 		const uint32_t xa = expand565(ba), xb = expand565(bb);
@@ -772,9 +772,9 @@ __device__ __forceinline__ uint2 bc1_search(const uint32_t* tp, const COpts& o_i
 	CBest cur;
 	cur.err = (uint32_t)(kmin >> 32);
 	cur.id = (uint32_t)kmin;
-	cur.a = (uint32_t)__shfl((int)best.a, (int)wl, 64);
-	cur.b = (uint32_t)__shfl((int)best.b, (int)wl, 64);
-	cur.mode3 = (uint32_t)__shfl((int)best.mode3, (int)wl, 64);
+	cur.a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(wl << 2), (int)best.a);
+	cur.b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(wl << 2), (int)best.b);
+	cur.mode3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(wl << 2), (int)best.mode3);
 
 	// a start candidate that reproduces the block exactly cannot be beaten (later ids are larger)
 	if (o.cluster && cur.err != 0u)
@@ -791,9 +791,9 @@ __device__ __forceinline__ uint2 bc1_search(const uint32_t* tp, const COpts& o_i
 		wl = (uint32_t)__builtin_ctzll(__ballot(key == kmin));
 		cur.err = (uint32_t)(kmin >> 32);
 		cur.id = (uint32_t)kmin;
-		cur.a = (uint32_t)__shfl((int)cand.a, (int)wl, 64);
-		cur.b = (uint32_t)__shfl((int)cand.b, (int)wl, 64);
-		cur.mode3 = (uint32_t)__shfl((int)cand.mode3, (int)wl, 64);
+		cur.a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(wl << 2), (int)cand.a);
+		cur.b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(wl << 2), (int)cand.b);
+		cur.mode3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(wl << 2), (int)cand.mode3);
 	}
 
 	// selectors of the winner (uniform work, every lane computes the same words)
@@ -891,7 +891,8 @@ cfhip_bc15_encode_kernel(cf_kparams kp)
 	load_tile<PIX, SNORM>(kp, bx0, byy, tile);
 	__syncthreads();
 
-	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	// the wave index as a scalar: block indices, tile pointers and edge tests live in SGPRs
+	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
 	uint32_t* pre = pre_tab + (HAS_BC4 ? wave*512u : 0u);
 	for (uint32_t j = 0; j < 4u; ++j) {
 		const uint32_t b = wave*4u + j;
