@@ -2151,11 +2151,12 @@ static size_t astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality, 
 // 4 blocks per wave of one block row) and whether the texel-weight cache rows are carved.  The
 // choice maximises the waves resident on a CU (12 = three per SIMD with the 168-register build,
 // else 8), then prefers the smaller workgroup (finer scheduling grain), then the cache.
-extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t quality, uint32_t hdr, uint32_t* nwaves, uint32_t* wcached, size_t* lds_bytes)
+extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t quality, uint32_t hdr, uint32_t bx, uint32_t* nwaves, uint32_t* wcached, size_t* lds_bytes)
 {
 	const size_t cu_lds = cf_astc_cu_lds(), wg_max = cf_astc_wg_lds_max();
 	const bool can_cache = false;       // the texel-weight cache is gone: a texel's weight is two loads and one v_dot4 now
-	uint32_t best_w = 0, best_nw = 4, best_c = 0;
+	uint32_t best_nw = 4, best_c = 0;
+	float best_w = 0.0f;
 	static const char* const force = getenv("CFHIP_ASTC_WAVES");     // experiments: pin the workgroup shape
 	const uint32_t forced = (force && *force) ? (uint32_t)atoi(force) : 0u;
 	// most resident waves first; then the SMALLER workgroup (blocks differ in cost -- early outs --
@@ -2164,16 +2165,31 @@ extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t qualit
 	static const bool plan_no_dense = getenv("CFHIP_ASTC_NO_DENSE") != nullptr;   // experiments: the 256-register build only
 	// (the HDR builds exist for 8 waves only: their phase B holds 16-bit sums and double-precision fits)
 	const bool no12 = plan_no_dense || hdr != 0u;
-	for (uint32_t nw = 4; nw <= (no12 ? 8u : 12u); nw += 4u) {
+	// any workgroup of 4 .. 12 waves: what counts is the number of waves resident on the CU (more than 8
+	// = three on some SIMDs = the 168-register build, which no longer spills); e.g. 6x6 up to High fits
+	// one 11-wave workgroup (158 KB) where 12 waves do not and two 4-wave workgroups leave 8
+	for (uint32_t nw = 4; nw <= (no12 ? 8u : 12u); ++nw) {
 		if (forced && forced != nw)
 			continue;
 		for (uint32_t c = can_cache ? 2u : 1u; c-- > 0u;) {
 			const size_t b = astc_lds_bytes(h, quality, nw, c != 0u, hdr != 0u);
 			if (b > wg_max)
 				continue;
-			uint32_t w = (uint32_t)(cu_lds/(b + 1024u))*nw;      // 1024: the static outb + allocation granule
-			w = w >= 12u ? (no12 ? 8u : 12u) : (w >= 8u ? 8u : w);
-			if (w > best_w) {
+			uint32_t wres = (uint32_t)(cu_lds/(b + 1024u))*nw;      // 1024: the static outb + allocation granule
+			wres = wres > 12u ? 12u : wres;
+			if (no12 && wres > 8u) wres = 8u;
+			// a workgroup covers nw*4 blocks of ONE block row: the share of a row's last workgroup that
+			// hangs over the edge is idle (bx = blocks per row of the surface, 0 = unknown)
+			const uint32_t per = nw*4u;
+			// waves of a workgroup go round the four SIMDs: the busiest SIMD sets the pace, and a SIMD with k
+			// waves takes about 0.8 / 1 / 1.19 of the two-wave time for k = 1 / 2 / 3 (measured: 12 against 8
+			// resident waves +26 %, 9 waves -13 %, 6 against 4 +22 %)
+			const uint32_t kmax = (wres + 3u)/4u;
+			const float pace = kmax <= 1u ? 0.8f : (kmax == 2u ? 1.0f : 1.19f);
+			float w = (float)wres/pace;
+			if (bx)
+				w *= (float)bx/(float)(((bx + per - 1u)/per)*per);
+			if (w > best_w*1.0001f) {
 				best_w = w; best_nw = nw; best_c = c;
 			}
 		}
@@ -2218,7 +2234,7 @@ extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, ui
 	// the 168-register build only where three waves per SIMD actually become resident
 	static const bool no_dense = getenv("CFHIP_ASTC_NO_DENSE") != nullptr, debug = getenv("CFHIP_ASTC_DEBUG") != nullptr;
 	const bool hdr = ((kp->flags >> 19) & 3u) != 0u;
-	const bool dense = (cf_astc_cu_lds()/(lds_bytes + 1024u))*nwaves >= 12u && !no_dense && !hdr;
+	const bool dense = (cf_astc_cu_lds()/(lds_bytes + 1024u))*nwaves > 8u && !no_dense && !hdr;
 	void (*fn)(cf_kparams) = nullptr;
 	if (dense)
 		fn = pixel_type == 0 ? &cfhip_astc_encode_kernel<0, 12, false> : &cfhip_astc_encode_kernel<1, 12, false>;

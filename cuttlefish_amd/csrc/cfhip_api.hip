@@ -24,7 +24,7 @@
 extern "C" hipError_t cfhip_launch_bc7(const cf_kparams* kp, int pixel_type, int unit_weights,
 	hipStream_t stream);
 extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, uint32_t nwaves, size_t lds_bytes, hipStream_t stream);
-extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t quality, uint32_t hdr, uint32_t* nwaves, uint32_t* wcached, size_t* lds_bytes);
+extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t quality, uint32_t hdr, uint32_t bx, uint32_t* nwaves, uint32_t* wcached, size_t* lds_bytes);
 extern "C" hipError_t cfhip_launch_etc(const cf_kparams* kp, int format, int pixel_type, int snorm,
 	hipStream_t stream);
 extern "C" hipError_t cfhip_launch_bc6h(const cf_kparams* kp, int pixel_type, int is_signed,
@@ -363,7 +363,7 @@ int astc_prepare(cfhip_ctx* ctx, int format)
 }
 
 // blocks of one block row a workgroup covers (the ASTC launch shape depends on the footprint)
-int blocks_per_wg(cfhip_ctx* ctx, const cfhip_params& p, uint32_t quality, uint32_t* out)
+int blocks_per_wg(cfhip_ctx* ctx, const cfhip_params& p, uint32_t quality, uint32_t bx, uint32_t* out)
 {
 	*out = CF_BLOCKS_PER_WG;
 	if (p.format >= CFHIP_FORMAT_ASTC_4x4 && p.format <= CFHIP_FORMAT_ASTC_12x12) {
@@ -372,7 +372,7 @@ int blocks_per_wg(cfhip_ctx* ctx, const cfhip_params& p, uint32_t quality, uint3
 			return rc;
 		uint32_t nwaves, wcached;
 		size_t lds_bytes;
-		cfhip_astc_plan(&ctx->astc_hdr[p.format], quality, p.type == CFHIP_TYPE_UFLOAT ? 1u : 0u, &nwaves, &wcached, &lds_bytes);
+		cfhip_astc_plan(&ctx->astc_hdr[p.format], quality, p.type == CFHIP_TYPE_UFLOAT ? 1u : 0u, bx, &nwaves, &wcached, &lds_bytes);
 		*out = nwaves*4u;
 	}
 	return CFHIP_OK;
@@ -413,7 +413,7 @@ int launch(cfhip_ctx* ctx, const cf_kparams& kp, const cfhip_params& p, int pixe
 			const uint32_t hdr = p.type == CFHIP_TYPE_UFLOAT ? 1u : 0u;
 			// HDR profile (AstcConverter.cpp:150-162): HDR_RGB_LDR_A for Alpha::None / PreMultiplied, HDR otherwise
 			const uint32_t hdr_alpha = hdr && !(p.alpha == CFHIP_ALPHA_NONE || p.alpha == CFHIP_ALPHA_PREMULTIPLIED) ? 1u : 0u;
-			cfhip_astc_plan(&ctx->astc_hdr[p.format], kp.quality, hdr, &nwaves, &wcached, &lds_bytes);
+			cfhip_astc_plan(&ctx->astc_hdr[p.format], kp.quality, hdr, kp.bx, &nwaves, &wcached, &lds_bytes);
 			cf_kparams k2 = kp;
 			k2.aux = ctx->astc_tables[p.format];
 			k2.flags |= (wcached << 18) | (hdr << 19) | (hdr_alpha << 20);
@@ -558,7 +558,8 @@ int batched_launch(cfhip_ctx* ctx, const std::vector<cf_kparams>& kps, const cfh
 	}
 	std::vector<cf_batch_entry> entries(kps.size());
 	uint32_t wg = 0, per_wg;
-	int rc = blocks_per_wg(ctx, p, kps[0].quality, &per_wg);
+	// (the launch shape is chosen for the first surface's row length; the launch below repeats the choice)
+	int rc = blocks_per_wg(ctx, p, kps[0].quality, kps[0].bx, &per_wg);
 	if (rc != CFHIP_OK)
 		return rc;
 	for (size_t i = 0; i < kps.size(); ++i) {
