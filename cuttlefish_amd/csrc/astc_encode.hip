@@ -825,7 +825,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		reinterpret_cast<uint32_t*>(sh_wtab)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_wtab)[i];
 
 	uint32_t gx_, gy_;
-	cf_resolve(kp, gx_, gy_);
+	cf_resolve<true>(kp, gx_, gy_);
 	const uint32_t bx0 = gx_*nblk, byy = gy_;
 	{
 		const uint32_t sw = nblk*bw, total = sw*bh;

@@ -22,6 +22,9 @@ PROFILE_CMD="python $R/tools/bench_formats.py --size 4096 --steps 3 --formats AS
   bash $R/tools/profile.sh ${tag}_astc > $G/${tag}_astc_pmc_summary.txt 2>&1
 for f in $(find $G/prof_${tag}_astc/stats -name "*kernel_stats.csv"); do cp $f $G/${tag}_astc_kernel_stats.csv; done
 bash $R/tools/dbg/astc_dense_ab.sh > $G/${tag}_astc_dense_ab.txt 2>&1
+# ETC2 RGB at Normal, 2048x2048: SALU / VALU counts and traffic
+PROFILE_CMD="python $R/tools/bench_formats.py --size 2048 --steps 3 --formats ETC2_R8G8B8 --qualities 2" \
+  bash $R/tools/profile.sh ${tag}_misc > $G/${tag}_misc_pmc_summary.txt 2>&1
 # the N-rank flow as the driver launches it (plain `python bench.py --gpus 2`); one device: gloo hook
 BENCH_DIST_BACKEND=gloo python $R/bench.py --gpus 2 --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | grep "^{" > $G/${tag}_bench_gpus2_gloo.json
 BENCH_DIST_BACKEND=gloo python $R/bench.py --config c5 --gpus 2 --textures 16 2>/dev/null | grep "^{" > $G/${tag}_c5_16tex_gpus2_gloo.json
