@@ -1,0 +1,69 @@
+"""What the compiler made of the kernels, read from the code objects inside the built library (no GPU
+needed): every block-encoder kernel runs without scratch (`private_segment_fixed_size 0`) and inside the
+register budget its occupancy is planned for.  DESIGN.md section 4 states these numbers; this keeps them
+true -- round 2's 12-wave ASTC build spilled 192 B per lane and nothing failed."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "cuttlefish_amd", "libcuttlefish_hip.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    if not (os.path.exists(LIB) and os.path.exists(os.path.join(LLVM, "llvm-objdump"))):
+        pytest.skip("library or ROCm LLVM tools not present")
+    d = tmp_path_factory.mktemp("co")
+    lib = shutil.copy(LIB, d)                      # llvm-objdump --offloading extracts next to its input
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", lib], cwd=d, check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out = {}
+    for f in sorted(os.listdir(d)):
+        if "amdgcn" not in f:
+            continue
+        assert f.endswith("gfx950"), f            # one target, no fat binary
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(d, f)],
+                               check=True, capture_output=True, text=True).stdout
+        for m in re.finditer(r"\.name:\s+(\S+)(.*?)(?=\.name:|\Z)", notes, re.S):
+            body = m.group(2)
+            g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, body).group(1)) if re.search(r"\.%s:\s+(\d+)" % k, body) else None
+            if g("vgpr_count") is not None:
+                out[m.group(1)] = {"scratch": g("private_segment_fixed_size"), "vgpr": g("vgpr_count"),
+                                   "lds": g("group_segment_fixed_size")}
+    assert out
+    return out
+
+
+def _of(kernels, stem):
+    return {k: v for k, v in kernels.items() if stem in k}
+
+
+def test_no_block_encoder_kernel_uses_scratch(kernels):
+    stems = ("cfhip_bc7_encode_kernel", "cfhip_bc15_encode_kernel", "cfhip_bc6h_encode_kernel",
+             "cfhip_etc_encode_kernel", "cfhip_astc_encode_kernel")
+    for stem in stems:
+        ks = _of(kernels, stem)
+        assert ks, stem
+        bad = {k: v for k, v in ks.items() if v["scratch"] != 0}
+        assert not bad, bad
+
+
+def test_register_budgets_match_the_planned_occupancy(kernels):
+    # 512 VGPRs per SIMD lane: k waves need <= 512 // k registers each (granule 8)
+    for k, v in _of(kernels, "cfhip_bc7_encode_kernel").items():
+        linear = "ELb1ELb" in k                     # <PIX, UNITW = true, WIDE>
+        assert v["vgpr"] <= (128 if linear else 168), (k, v)        # 4 waves (linear metric) / 3 (perceptual)
+    for k, v in _of(kernels, "cfhip_etc_encode_kernel").items():
+        assert v["vgpr"] <= 96, (k, v)              # 5 waves
+    for k, v in _of(kernels, "cfhip_astc_encode_kernel").items():
+        twelve = "ELi12E" in k
+        assert v["vgpr"] <= (168 if twelve else 256), (k, v)
+    # the ASTC builds that exist: LDR at 8 and 12 waves, HDR at 8, for both source kinds
+    names = "".join(sorted(_of(kernels, "cfhip_astc_encode_kernel")))
+    for inst in ("ILi0ELi8ELb0E", "ILi1ELi8ELb0E", "ILi0ELi12ELb0E", "ILi1ELi12ELb0E", "ILi0ELi8ELb1E", "ILi1ELi8ELb1E"):
+        assert inst in names, inst
