@@ -223,20 +223,26 @@ __device__ __forceinline__ void quantize(const float (&x0)[4], const float (&x1)
 // channel-planar copy (pl: row r -> 4 words R,G,B,A, texel j of the row in byte j),
 // the lane's channel rotation and the set of (rotated) channels this fit codes.
 struct Tex {
-	const uint32_t* tp;
-	const uint32_t* pl;
-	const uint32_t* yc;    // perceptual metric only: the texels as (Y | Cr << 16, Cb | A << 16) word pairs
+	// the workgroup's three LDS arrays (compile-time addresses once inlined) and ONE per-lane value, the
+	// block's word offset: the three per-block pointers are expressions of it, not three live registers
+	const uint32_t* tile_;
+	const uint32_t* plan_;
+	const uint32_t* yccp_; // perceptual metric only: the texels as (Y | Cr << 16, Cb | A << 16) word pairs
+	uint32_t boff;         // block index x 16
+	__device__ __forceinline__ const uint32_t* tp() const { return tile_ + boff; }
+	__device__ __forceinline__ const uint32_t* pl() const { return plan_ + boff; }
+	__device__ __forceinline__ const uint32_t* yc() const { return yccp_ + 2u*boff; }
 	uint32_t sel;      // v_perm_b32 selector of the rotation
 	uint32_t rot;      // 0..3
 	uint32_t chmask;   // bit c: rotated channel c is coded by this fit
 	uint32_t vmask;    // byte mask of chmask
 };
 
-__device__ __forceinline__ Tex make_tex(const uint32_t* tp, const uint32_t* pl, const uint32_t* yc, uint32_t rot,
-	uint32_t chmask)
+__device__ __forceinline__ Tex make_tex(const uint32_t* tile, const uint32_t* plan, const uint32_t* yccp, uint32_t boff,
+	uint32_t rot, uint32_t chmask)
 {
 	Tex t;
-	t.tp = tp; t.pl = pl; t.yc = yc; t.rot = rot; t.chmask = chmask;
+	t.tile_ = tile; t.plan_ = plan; t.yccp_ = yccp; t.boff = boff; t.rot = rot; t.chmask = chmask;
 	t.sel = rot == 0u ? 0x03020100u : (rot == 1u ? 0x00020103u :
 		(rot == 2u ? 0x01020300u : 0x02030100u));
 	t.vmask = ((chmask & 1u) ? 0xFFu : 0u) | ((chmask & 2u) ? 0xFF00u : 0u) |
@@ -315,8 +321,8 @@ __device__ __forceinline__ uint32_t ycc_pp_sum(const Tex& tx, uint32_t mask, con
 	uint32_t pp = 0;
 #pragma unroll 1
 	for (uint32_t r = 0; r < 4u; ++r) {
-		const uint4 ya = *reinterpret_cast<const uint4*>(tx.yc + 8u*r);
-		const uint4 yb = *reinterpret_cast<const uint4*>(tx.yc + 8u*r + 4u);
+		const uint4 ya = *reinterpret_cast<const uint4*>(tx.yc() + 8u*r);
+		const uint4 yb = *reinterpret_cast<const uint4*>(tx.yc() + 8u*r + 4u);
 		const uint32_t pr[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
@@ -383,12 +389,12 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 		// unit weights: the row's packed RGBA texels; perceptual: its (Y | Cr, Cb | A) word pairs
 		uint32_t raw[4], rawh[4];
 		if (UNITW) {
-			const uint4 rw = *reinterpret_cast<const uint4*>(tx.tp + 4u*r);
+			const uint4 rw = *reinterpret_cast<const uint4*>(tx.tp() + 4u*r);
 			raw[0] = rw.x; raw[1] = rw.y; raw[2] = rw.z; raw[3] = rw.w;
 			rawh[0] = rawh[1] = rawh[2] = rawh[3] = 0u;
 		} else {
-			const uint4 ya = *reinterpret_cast<const uint4*>(tx.yc + 8u*r);
-			const uint4 yb = *reinterpret_cast<const uint4*>(tx.yc + 8u*r + 4u);
+			const uint4 ya = *reinterpret_cast<const uint4*>(tx.yc() + 8u*r);
+			const uint4 yb = *reinterpret_cast<const uint4*>(tx.yc() + 8u*r + 4u);
 			raw[0] = ya.x; raw[1] = ya.z; raw[2] = yb.x; raw[3] = yb.z;
 			rawh[0] = ya.y; rawh[1] = ya.w; rawh[2] = yb.y; rawh[3] = yb.w;
 		}
@@ -438,7 +444,7 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 			wp0 = wp1; wp1 = wp2; wp2 = wp3; wp3 = wrow;   // rotates back to the start after 4 trips
 			const uint32_t iwrow = (0x40404040u - wrow) & bytemask4((mask >> (4u*r)) & 15u);
 			uint32_t P[4];
-			planes<true>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
+			planes<true>(tx, *reinterpret_cast<const uint4*>(tx.pl() + 4u*r), P);
 			S = __builtin_amdgcn_udot4(wrow, 0x01010101u, S, false);
 			A = __builtin_amdgcn_udot4(iwrow, iwrow, A, false);
 			B = __builtin_amdgcn_udot4(iwrow, wrow, B, false);
@@ -487,7 +493,7 @@ __device__ __forceinline__ void fit_lane(const Tex& tx, uint32_t mask, bool m6, 
 #pragma unroll 1
 	for (uint32_t r = 0; r < 4u; ++r) {
 		uint32_t P[4];
-		const uint4 pr = *reinterpret_cast<const uint4*>(tx.pl + 4u*r);
+		const uint4 pr = *reinterpret_cast<const uint4*>(tx.pl() + 4u*r);
 		planes<true>(tx, pr, P);
 		const uint32_t a4 = tx.rot == 0u ? pr.w : (tx.rot == 1u ? pr.x : (tx.rot == 2u ? pr.y : pr.z));
 #pragma unroll
@@ -554,7 +560,7 @@ __device__ __forceinline__ void fit_lane(const Tex& tx, uint32_t mask, bool m6, 
 	float tmin = 3.0e38f, tmax = -3.0e38f;
 #pragma unroll 1
 	for (uint32_t r = 0; r < 4u; ++r) {
-		const uint4 rw = *reinterpret_cast<const uint4*>(tx.tp + 4u*r);
+		const uint4 rw = *reinterpret_cast<const uint4*>(tx.tp() + 4u*r);
 		const uint32_t raw[4] = {rw.x, rw.y, rw.z, rw.w};
 		const uint32_t mrow = (mask >> (4u*r)) & 15u;
 #pragma unroll
@@ -756,7 +762,7 @@ __device__ __forceinline__ float subset_residual(const Tex& tx, uint32_t mask)
 #pragma unroll 1
 	for (uint32_t r = 0; r < 4u; ++r) {
 		uint32_t P[4];
-		planes<false>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
+		planes<false>(tx, *reinterpret_cast<const uint4*>(tx.pl() + 4u*r), P);
 		const uint32_t m4 = bytemask4((mask >> (4u*r)) & 15u);
 		const uint32_t M0 = P[0] & m4, M1 = P[1] & m4, M2 = P[2] & m4, M3 = A4 ? P[3] & m4 : 0u;
 		s[0] = __builtin_amdgcn_udot4(M0, 0x01010101u, s[0], false);
@@ -839,14 +845,14 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	// pair: blocks b and b + 1 at Low or Normal, one per half wavefront
 #define h (lane >> 5)
 #define hbase (pair ? (lane & 32u) : 0u)
-	const uint32_t* tp = tile + (pair ? b + h : b)*16u;
-	const uint32_t* pl = plan + (pair ? b + h : b)*16u;
-	const uint32_t* yc = UNITW ? yccp : yccp + (pair ? b + h : b)*32u;
+	// (the block's LDS pointers are expressions of the current lane id too: half h of a pair)
+#define B_TP (tile + (pair ? b + h : b)*16u)
+#define B_OFF ((pair ? b + h : b)*16u)
 	// perceptual axis weights as 16-bit pairs (wY | wCr << 16, wCb | wA << 16); kp.flags holds the bytes
 	const uint32_t ywrg = (kp.flags & 255u) | (((kp.flags >> 8) & 255u) << 16);
 	const uint32_t ywba = ((kp.flags >> 16) & 255u) | (((kp.flags >> 24) & 127u) << 16);
 	// lanes 0..15 of each group test their block's alpha
-	const unsigned long long abal = __ballot((lane & 31u) < 16u && (tp[lane & 15u] >> 24) != 255u);
+	const unsigned long long abal = __ballot((lane & 31u) < 16u && (B_TP[lane & 15u] >> 24) != 255u);
 	const bool has_alpha = pair ? ((uint32_t)(h ? abal >> 32 : abal) & 0xFFFFu) != 0u
 		: ((uint32_t)abal & 0xFFFFu) != 0u;
 	const bool any_alpha = pair ? abal != 0ull : has_alpha;
@@ -885,20 +891,21 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	bool solved = false;
 	{
 		const uint32_t nstreams = (WIDE && !has_alpha) ? 2u : 1u;
-		const Tex txp = make_tex(tp, pl, yc, 0u, has_alpha ? 15u : 7u);   // partition fits: no rotation
 #pragma unroll 1
 		for (uint32_t st = 0; st < nstreams && !solved; ++st) {
 			CF_FRESH_LANE(lane);   // roles are recomputed per stream, not kept
+			const Tex txp = make_tex(tile, plan, yccp, B_OFF, 0u, has_alpha ? 15u : 7u);   // partition fits: no rotation
 			const uint32_t ns = 2u + st;
 			const bool parts = quality >= 1u;
 			// partition lanes: first lane, slots of the first mode, slots in all
-			uint32_t pfirst, nper0, nslots;
+			// (nper0 depends on the half's has_alpha: an expression, like the roles, not a carried value)
+			uint32_t pfirst, nslots;
 			if (lay32) {
-				if (quality == 2u) { pfirst = 10u; nper0 = has_alpha ? 11u : 6u; nslots = 11u; }
-				else { pfirst = 4u; nper0 = 14u; nslots = 14u; }
-			} else if (st == 1u) { pfirst = 0u; nper0 = 5u; nslots = 10u; }
-			else if (has_alpha) { pfirst = 26u; nper0 = 16u; nslots = 16u; }
-			else { pfirst = 26u; nper0 = 8u; nslots = 16u; }
+				if (quality == 2u) { pfirst = 10u; nslots = 11u; }
+				else { pfirst = 4u; nslots = 14u; }
+			} else if (st == 1u) { pfirst = 0u; nslots = 10u; }
+			else { pfirst = 26u; nslots = 16u; }
+#define nper0 (lay32 ? (quality == 2u ? (has_alpha ? 11u : 6u) : 14u) : (st == 1u ? 5u : (has_alpha ? 16u : 8u)))
 			// lane roles as expressions of the CURRENT lane id (re-read where a phase starts), so that none of
 			// them is carried in a register through the fit
 #define R_REL (hl - pfirst)                                   /* wraps below pfirst */
@@ -1018,7 +1025,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			const uint32_t yw[2] = {(chm & 7u) ? ywrg : 0u,
 				((chm & 7u) ? (ywba & 0xFFFFu) : 0u) | ((chm & 8u) ? (ywba & 0xFFFF0000u) : 0u)};
 			if (active)
-				fit_lane<UNITW>(make_tex(tp, pl, yc, rot, chm), mask, m6, lane & 1u, cb, ab, pbk, ib, iters,
+				fit_lane<UNITW>(make_tex(tile, plan, yccp, B_OFF, rot, chm), mask, m6, lane & 1u, cb, ab, pbk, ib, iters,
 					wv, yw, sca, lf);
 			CF_FRESH_LANE(lane);         // the roles below are computed again from here
 			// ---- assemble candidates in their leader lanes ----
@@ -1076,6 +1083,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			// of at least 48 (oracle: same rule); one block per wave here, so this is uniform
 			if (WIDE && cf_wave_min_u32(best_err) < 48u)
 				solved = true;
+#undef nper0
 #undef R_REL
 #undef R_SLOT
 #undef R_SUB
@@ -1151,7 +1159,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 					mask |= (((p3 >> (2*i)) & 3u) == kf ? 1u : 0u) << i;
 			}
 		}
-		const Tex tx = make_tex(tp, pl, yc, rot, chm);
+		const Tex tx = make_tex(tile, plan, yccp, B_OFF, rot, chm);
 		const uint32_t yw[2] = {(chm & 7u) ? ywrg : 0u,
 			((chm & 7u) ? (ywba & 0xFFFFu) : 0u) | ((chm & 8u) ? (ywba & 0xFFFF0000u) : 0u)};
 		// sum over the fit's texels of sum_c p_c^2 (the constant part of its error)
@@ -1160,7 +1168,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 #pragma unroll 1
 			for (uint32_t r = 0; r < 4u; ++r) {
 				uint32_t P[4];
-				planes<true>(tx, *reinterpret_cast<const uint4*>(tx.pl + 4u*r), P);
+				planes<true>(tx, *reinterpret_cast<const uint4*>(tx.pl() + 4u*r), P);
 				const uint32_t m4 = bytemask4((mask >> (4u*r)) & 15u);
 #pragma unroll
 				for (int c = 0; c < 4; ++c)
@@ -1243,6 +1251,8 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	}
 	CF_FRESH_LANE(lane);
 	return pack_block_group(wc, (uint32_t)kmin, lane, pair);
+#undef B_TP
+#undef B_OFF
 #undef h
 #undef hbase
 #undef hl
@@ -1260,14 +1270,15 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 // id or of the wave index: the wave index is a scalar now (loop counter, block index and pair flag
 // live in SGPRs), the lane id is re-read with a volatile mbcnt pair where a phase starts, the lane
 // roles are expressions of it instead of variables carried through the fit, and __shfl's hidden
-// lane-id arithmetic is gone (cf_bperm) -- so the linear-metric builds fit 128 registers with
-// private_segment_fixed_size 0.  The perceptual builds (UNITW = false) still need 3 waves.
+// lane-id arithmetic is gone (cf_bperm), and a block's three LDS pointers are one word offset (Tex) --
+// so every build but the perceptual Highest one fits 128 registers with private_segment_fixed_size 0
+// (that one: 160 registers, 3 waves).
 #ifndef CF_BC7_WAVES
-#define CF_BC7_WAVES(UNITW) ((UNITW) ? 4 : 3)
+#define CF_BC7_WAVES(UNITW, WIDE) (((UNITW) || !(WIDE)) ? 4 : 3)
 #endif
 template <int PIX, bool UNITW, bool WIDE>
 __global__ void __launch_bounds__(CF_WG_THREADS)
-__attribute__((amdgpu_waves_per_eu(CF_BC7_WAVES(UNITW), CF_BC7_WAVES(UNITW))))
+__attribute__((amdgpu_waves_per_eu(CF_BC7_WAVES(UNITW, WIDE), CF_BC7_WAVES(UNITW, WIDE))))
 cfhip_bc7_encode_kernel(cf_kparams kp)
 {
 	__shared__ uint32_t cands[CF_BC7_CAND_WORDS*CF_WG_THREADS];

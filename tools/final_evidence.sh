@@ -17,6 +17,7 @@ for q in 2 3 4; do
   extra=""; [ $q != 2 ] && extra="--no-cpu-baseline"
   python $R/bench.py --quality $q $extra > $G/${tag}${sfx}_bench.json 2> $G/${tag}${sfx}_bench.err
 done
+[ -n "$ONLY_BC7" ] && { tail -c 600 $G/${tag}_bench.json; exit 0; }
 # ASTC at BASELINE config 3 (6x6 High, 4096x4096): kernel stats + PMC passes incl. FETCH_SIZE / WRITE_SIZE
 PROFILE_CMD="python $R/tools/bench_formats.py --size 4096 --steps 3 --formats ASTC_6x6 --qualities 3" \
   bash $R/tools/profile.sh ${tag}_astc > $G/${tag}_astc_pmc_summary.txt 2>&1
