@@ -1304,16 +1304,45 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					const bool byp = dual || P == 1u;
 					int a0 = 0, a1 = 0, a2 = 0, a3 = 0, cnt_t = 0;
 					int q00 = 0, q01 = 0, q02 = 0, q03 = 0, q11 = 0, q12 = 0, q13 = 0, q22 = 0, q23 = 0, q33 = 0;
+					// moments four texels at a time: the four packed texels are transposed into channel planes
+					// (8 v_perm_b32), the slot's members are a byte mask, and every sum / product sum over the
+					// four is ONE v_dot4_u32_u8 (14 per group instead of 14 multiply-adds and the byte
+					// extractions per texel); exact integers either way
+					const uint32_t cm0 = (chmask & 1u) ? ~0u : 0u, cm1 = (chmask & 2u) ? ~0u : 0u, cm2 = (chmask & 4u) ? ~0u : 0u,
+						cm3 = (chmask & 8u) ? ~0u : 0u;
+					const uint32_t srep = s*0x01010101u;
 #pragma unroll 2
-					for (uint32_t i = par; i < n; i += stp) {
-						const bool in_ = byp || prow[i] == s;
-						const uint32_t p = in_ ? (tp[i] & bytemask) : 0u;
-						const int c0 = (int)(p & 255u), c1 = (int)((p >> 8) & 255u), c2 = (int)((p >> 16) & 255u), c3 = (int)(p >> 24);
-						cnt_t += in_ ? 1 : 0;
-						a0 += c0; a1 += c1; a2 += c2; a3 += c3;
-						q00 += c0*c0; q01 += c0*c1; q02 += c0*c2; q03 += c0*c3;
-						q11 += c1*c1; q12 += c1*c2; q13 += c1*c3;
-						q22 += c2*c2; q23 += c2*c3; q33 += c3*c3;
+					for (uint32_t i = par*4u; i < n; i += stp*4u) {
+						const uint32_t w0 = tp[i], w1 = tp[i + 1u], w2 = tp[i + 2u], w3 = tp[i + 3u];
+						uint32_t M = ~0u;
+						if (!byp) {
+							const uint32_t x = *reinterpret_cast<const uint32_t*>(prow + i) ^ srep;     // ids are 0..3: a byte is 0 <=> member
+							const uint32_t m1 = ~(x | (x >> 1)) & 0x01010101u;
+							M = (m1 << 8) - m1;
+						}
+						if (i + 4u > n)
+							M &= (1u << (8u*(n - i))) - 1u;          // the footprint's last, partial group
+						const uint32_t t01 = __builtin_amdgcn_perm(w1, w0, 0x05010400u), t23 = __builtin_amdgcn_perm(w3, w2, 0x05010400u);
+						const uint32_t u01 = __builtin_amdgcn_perm(w1, w0, 0x07030602u), u23 = __builtin_amdgcn_perm(w3, w2, 0x07030602u);
+						const uint32_t P0 = __builtin_amdgcn_perm(t23, t01, 0x05040100u), P1 = __builtin_amdgcn_perm(t23, t01, 0x07060302u);
+						const uint32_t P2 = __builtin_amdgcn_perm(u23, u01, 0x05040100u), P3 = __builtin_amdgcn_perm(u23, u01, 0x07060302u);
+						const uint32_t m0 = P0 & M & cm0, m1_ = P1 & M & cm1, m2 = P2 & M & cm2, m3 = P3 & M & cm3;
+						const uint32_t c1m = P1 & cm1, c2m = P2 & cm2, c3m = P3 & cm3;
+						cnt_t += __popc(M & 0x01010101u);
+						a0 = (int)__builtin_amdgcn_udot4(m0, 0x01010101u, (uint32_t)a0, false);
+						a1 = (int)__builtin_amdgcn_udot4(m1_, 0x01010101u, (uint32_t)a1, false);
+						a2 = (int)__builtin_amdgcn_udot4(m2, 0x01010101u, (uint32_t)a2, false);
+						a3 = (int)__builtin_amdgcn_udot4(m3, 0x01010101u, (uint32_t)a3, false);
+						q00 = (int)__builtin_amdgcn_udot4(m0, P0, (uint32_t)q00, false);
+						q01 = (int)__builtin_amdgcn_udot4(m0, c1m, (uint32_t)q01, false);
+						q02 = (int)__builtin_amdgcn_udot4(m0, c2m, (uint32_t)q02, false);
+						q03 = (int)__builtin_amdgcn_udot4(m0, c3m, (uint32_t)q03, false);
+						q11 = (int)__builtin_amdgcn_udot4(m1_, P1, (uint32_t)q11, false);
+						q12 = (int)__builtin_amdgcn_udot4(m1_, c2m, (uint32_t)q12, false);
+						q13 = (int)__builtin_amdgcn_udot4(m1_, c3m, (uint32_t)q13, false);
+						q22 = (int)__builtin_amdgcn_udot4(m2, P2, (uint32_t)q22, false);
+						q23 = (int)__builtin_amdgcn_udot4(m2, c3m, (uint32_t)q23, false);
+						q33 = (int)__builtin_amdgcn_udot4(m3, P3, (uint32_t)q33, false);
 					}
 					if (!pair) {
 #define ASTC_PAIRSUM(v) v += __builtin_amdgcn_ds_bpermute((int)((lane ^ 32u) << 2), v)
@@ -1369,13 +1398,21 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						dd += dv[c]*dv[c];
 					}
 					const float rdd2 = dd > 0 ? 1.0f/(float)(2*dd) : 0.0f;
+					uint32_t dvp = 0, dvn = 0;
+					int e0dv = 0;
+#pragma unroll
+					for (int c = 0; c < 4; ++c) {
+						dvp |= (uint32_t)(dv[c] > 0 ? dv[c] : 0) << (8*c);
+						dvn |= (uint32_t)(dv[c] < 0 ? -dv[c] : 0) << (8*c);
+						e0dv += e0[c]*dv[c];
+					}
 					uint8_t* Trow = S.T + ((dual && s == 1u) ? 8u + ((j - 1u) & 1u) : j)*npad;
 #pragma unroll 2
 					for (uint32_t i = par; i < n; i += stp) {
 						const bool in_ = byp || prow[i] == s;
 						const uint32_t p = tp[i];
-						int t = ((int)(p & 255u) - e0[0])*dv[0] + ((int)((p >> 8) & 255u) - e0[1])*dv[1] +
-							((int)((p >> 16) & 255u) - e0[2])*dv[2] + ((int)(p >> 24) - e0[3])*dv[3];
+						// sum (c - e0[c]) dv[c] = dot(p, dv+) - dot(p, dv-) - sum e0[c] dv[c]: two v_dot4_u32_u8
+						int t = (int)__builtin_amdgcn_udot4(p, dvp, 0u, false) - (int)__builtin_amdgcn_udot4(p, dvn, 0u, false) - e0dv;
 						int Tw = 0;
 						if (t > 0 && dd > 0) {
 							const int tc = t > dd ? dd : t;
