@@ -1785,21 +1785,37 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					// are walked only when some lane of the wave has them (a scalar branch, not per-lane
 					// predication -- the wave executes the instructions either way)
 					const bool any3 = __ballot(nset > 2u) != 0ull, any4 = __ballot(nset > 3u) != 0ull;
-#pragma unroll 2
-					for (uint32_t i = 0; i < ((CF_ASTC_ABLATE & 64) ? 1u : n); ++i) {
-						const uint2 rec = inf[i];
-						const uint32_t p = tp[i], part = byp ? 0u : prow[i];
-						const uint32_t wA = infill_w(colbase, rec.x, rec.y);
-						const uint32_t w1s = dual ? infill_w(colp1, rec.x, rec.y) : wA;     // what set 1 fits with
-						const uint32_t mm = dual ? 3u : (1u << part);
-						const uint32_t pc0_ = p & 255u, pc1_ = (p >> 8) & 255u, pc2_ = (p >> 16) & 255u, pc3_ = p >> 24;
-#define ASTC_ACC(Q, ST, WI) { \
-							const uint32_t wm = (mm & (1u << ST)) ? WI : 0u; \
-							Q.S += wm; Q.C += wm*WI; \
-							Q.V0 += wm*pc0_; Q.V1 += wm*pc1_; Q.V2 += wm*pc2_; Q.V3 += wm*pc3_; }
-						ASTC_ACC(q0, 0u, wA) ASTC_ACC(q1, 1u, w1s)
-						if (any3) ASTC_ACC(q2, 2u, wA)
-						if (any4) ASTC_ACC(q3, 3u, wA)
+					// four texels per step: their weights as bytes of one word, their channels as planes (8 v_perm),
+					// a set's members as a byte mask -- S, C and the four V_c of a set are six v_dot4_u32_u8 per
+					// step instead of six multiply-adds per texel (texels past the footprint carry weight 0)
+#pragma unroll 1
+					for (uint32_t i = 0; i < ((CF_ASTC_ABLATE & 64) ? 4u : n); i += 4u) {
+						uint32_t WA = 0, W1 = 0;
+#pragma unroll
+						for (uint32_t k = 0; k < 4u; ++k) {
+							if (i + k < n) {
+								const uint2 rec = inf[i + k];
+								WA |= infill_w(colbase, rec.x, rec.y) << (8u*k);
+								W1 |= (dual ? infill_w(colp1, rec.x, rec.y) : 0u) << (8u*k);
+							}
+						}
+						W1 = dual ? W1 : WA;                 // what set 1 fits with
+						const uint32_t w0 = tp[i], w1 = tp[i + 1u], w2 = tp[i + 2u], w3 = tp[i + 3u];
+						const uint32_t t01 = __builtin_amdgcn_perm(w1, w0, 0x05010400u), t23 = __builtin_amdgcn_perm(w3, w2, 0x05010400u);
+						const uint32_t u01 = __builtin_amdgcn_perm(w1, w0, 0x07030602u), u23 = __builtin_amdgcn_perm(w3, w2, 0x07030602u);
+						const uint32_t P0 = __builtin_amdgcn_perm(t23, t01, 0x05040100u), P1 = __builtin_amdgcn_perm(t23, t01, 0x07060302u);
+						const uint32_t P2 = __builtin_amdgcn_perm(u23, u01, 0x05040100u), P3 = __builtin_amdgcn_perm(u23, u01, 0x07060302u);
+						const uint32_t pw = byp ? 0u : *reinterpret_cast<const uint32_t*>(prow + i);      // subset ids 0..3
+#define ASTC_ACC(Q, ST, W) { \
+							const uint32_t x_ = pw ^ (ST*0x01010101u), m_ = ~(x_ | (x_ >> 1)) & 0x01010101u; \
+							const uint32_t wm = W & (dual ? ~0u : (m_ << 8) - m_); \
+							Q.S = __builtin_amdgcn_udot4(wm, 0x01010101u, Q.S, false); \
+							Q.C = __builtin_amdgcn_udot4(wm, W, Q.C, false); \
+							Q.V0 = __builtin_amdgcn_udot4(wm, P0, Q.V0, false); Q.V1 = __builtin_amdgcn_udot4(wm, P1, Q.V1, false); \
+							Q.V2 = __builtin_amdgcn_udot4(wm, P2, Q.V2, false); Q.V3 = __builtin_amdgcn_udot4(wm, P3, Q.V3, false); }
+						ASTC_ACC(q0, 0u, WA) ASTC_ACC(q1, 1u, W1)
+						if (any3) ASTC_ACC(q2, 2u, WA)
+						if (any4) ASTC_ACC(q3, 3u, WA)
 #undef ASTC_ACC
 					}
 #define SEL4(i, a0, a1, a2, a3) ((i) == 0u ? (a0) : ((i) == 1u ? (a1) : ((i) == 2u ? (a2) : (a3))))
