@@ -647,6 +647,20 @@ static void hdr_alpha_place(int sel, int A0, int A1, double r0, double r1, int v
 	himask[1] = 0x80 | (0x7F & ~(0x3F >> sel));
 }
 
+/* test hook: the value list form k (0 direct, 1 + sub-mode) gives the 12-bit pair (E0, E1); r = 16 E for the
+ * direct form */
+void cfo_astc_hdr_place(int k, const int E0[3], const int E1[3], int v[6], int himask[6])
+{
+	double r0[3], r1[3];
+	for (int c = 0; c < 3; ++c) { r0[c] = 16.0*E0[c]; r1[c] = 16.0*E1[c]; }
+	hdr_rgb_place(k, E0, E1, r0, r1, v, himask);
+}
+
+void cfo_astc_hdr_alpha_place(int sel, int A0, int A1, int v[2], int himask[2])
+{
+	hdr_alpha_place(sel, A0, A1, 16.0*A0, 16.0*A1, v, himask);
+}
+
 static double quad_est_d(double fA, double fB, double fC, double d0, double d1)
 {
 	double t = fA*d0;

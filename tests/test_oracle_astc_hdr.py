@@ -304,3 +304,60 @@ def test_half_to_lns_to_half_is_exact_for_every_finite_half():
         assert back(c) == h and c > prev, hex(h)
         prev = c
     assert L.cfo_astc_lns16(0x3C00) == 0x7800
+
+
+def test_encoder_placement_round_trips_through_the_decoder():
+    """What hdr_rgb_place stores is what the decoder reads back: for endpoint pairs a sub-mode can hold
+    (differences inside its b / c / d fields) the decoded pair equals the pair rounded to the mode's step;
+    the direct form keeps the top 8 (blue: 7) bits.  Alpha selectors alike."""
+    L = O.lib()
+    rng = np.random.default_rng(12)
+    bits = [(9, 7, 6, 7), (9, 8, 6, 6), (10, 6, 7, 7), (10, 7, 7, 6), (11, 8, 6, 5), (11, 6, 8, 6), (12, 7, 7, 5), (12, 6, 7, 6)]
+    I3, I6 = ctypes.c_int*3, ctypes.c_int*6
+    for m, (ab, bb, cb, db) in enumerate(bits):
+        sh = 12 - ab
+        hits = 0
+        for _ in range(400):
+            maj = int(rng.integers(0, 3))
+            a = int(rng.integers(1 << (ab - 1), 1 << ab)) << sh
+            c = int(rng.integers(0, 1 << cb)) << sh
+            b = [int(rng.integers(0, 1 << bb)) << sh for _ in range(2)]
+            d = [int(rng.integers(-(1 << (db - 1)), 1 << (db - 1))) << sh for _ in range(2)]
+            hi = [a, a - b[0], a - b[1]]
+            lo = [a - c, a - b[0] - c - d[0], a - b[1] - c - d[1]]
+            if min(hi + lo) < 0 or max(hi + lo) > 4095 or max(hi[1:]) >= hi[0]:
+                continue                               # the major component must be the strict maximum
+            hi[0], hi[maj] = hi[maj], hi[0]
+            lo[0], lo[maj] = lo[maj], lo[0]
+            v, hm = I6(), I6()
+            L.cfo_astc_hdr_place(1 + m, I3(*lo), I3(*hi), v, hm)
+            kind, e0, e1 = _unpack(11, list(v))
+            assert e0[:3] == [x << 4 for x in lo] and e1[:3] == [x << 4 for x in hi], (m, maj, lo, hi, list(v))
+            # the bits a requantisation has to keep cover the mode and major-component bits
+            assert hm[1] & 0x80 and hm[2] & 0x80 and hm[3] & 0x80 and hm[4] & 0x80 and hm[5] & 0x80
+            hits += 1
+        assert hits > 50, m
+    # direct form
+    for _ in range(200):
+        lo = [int(x) for x in rng.integers(0, 4096, 3)]
+        hi = [int(x) for x in rng.integers(0, 4096, 3)]
+        v, hm = I6(), I6()
+        L.cfo_astc_hdr_place(0, I3(*lo), I3(*hi), v, hm)
+        kind, e0, e1 = _unpack(11, list(v))
+        for c in range(3):
+            step = 512 if c == 2 else 256
+            top = 127 if c == 2 else 255
+            assert e0[c] == min((lo[c]*16 + step//2)//step, top)*step and e1[c] == min((hi[c]*16 + step//2)//step, top)*step
+    # alpha selectors 0..2: base on 8 + s bits (step 16 >> s in 12-bit units), offset on 6 - s signed bits
+    I2 = ctypes.c_int*2
+    for sel in range(3):
+        sh = 4 - sel
+        for _ in range(200):
+            base = int(rng.integers(0, 1 << (8 + sel))) << sh
+            off = int(rng.integers(-(1 << (5 - sel)), 1 << (5 - sel))) << sh
+            if not 0 <= base + off <= 4095:
+                continue
+            v, hm = I2(), I2()
+            L.cfo_astc_hdr_alpha_place(sel, base, base + off, v, hm)
+            kind, e0, e1 = _unpack(15, [0, 0, 0, 0, 0x80, 0x80, v[0], v[1]])
+            assert (e0[3], e1[3]) == (base << 4, (base + off) << 4), (sel, base, off)
