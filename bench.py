@@ -494,9 +494,37 @@ def run_c2(args, rank, local_rank, world, backend):
         dist.all_gather(allt, t)
         elapsed = max(float(a[0]) for a in allt)
         per_rank = [{"rank": r, "kernel_ms": round(float(allt[r][1]), 4)} for r in range(world)]
-        if not args.no_strong:
-            strong = strong_c2(args, ctx, torch, dist, rank, world, backend, img, out)
 
+    def guarded_strong(line):
+        """The strong-scaling leg runs AFTER the weak line is complete and can never take it down: an
+        exception is reported in the line, and a watchdog prints the weak line and leaves if the leg
+        does not finish (a collective that hangs on hardware this code has not met would otherwise
+        cost the whole measurement)."""
+        import threading
+        done = threading.Event()
+        limit = float(os.environ.get("BENCH_STRONG_TIMEOUT_S", "240"))
+
+        def watchdog():
+            if not done.wait(limit):
+                if rank == 0:
+                    line["strong_scaling"] = {"error": "the strong-scaling leg did not finish within %.0f s; "
+                                                       "the weak-scaling line stands" % limit}
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            res = strong_c2(args, ctx, torch, dist, rank, world, backend, img, out)
+        except Exception as e:                      # noqa: BLE001 -- reported, not hidden
+            done.set()
+            if rank == 0:
+                line["strong_scaling"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                print(json.dumps(line), flush=True)
+            os._exit(0)                             # the other ranks may sit in a collective: no orderly teardown
+        done.set()
+        return res
+
+    if rank != 0 and world > 1 and not args.no_strong:
+        guarded_strong(None)
     if rank == 0:
         pixels_per_step = float(size * size) * world
         value = pixels_per_step * args.steps / elapsed / 1e6
@@ -534,13 +562,15 @@ def run_c2(args, rank, local_rank, world, backend):
             # PMC passes cannot run inside the timed region: traffic and the dynamic instruction
             # counts are REPLAYED from the committed profile of the same code hash, never measured here
             line["roofline"]["traffic_measured_in_this_run"] = False
-        if strong is not None:
-            line["strong_scaling"] = strong
         if world == 1 and not args.no_cpu_baseline and size == SIZE:
             payload = out.cpu().numpy()
             line["cpu_baseline"] = cpu_baseline(img, payload, size, args.quality)
         else:
             line["cpu_baseline"] = None
+        if world > 1 and not args.no_strong:
+            strong = guarded_strong(line)
+        if strong is not None:
+            line["strong_scaling"] = strong
         print(json.dumps(line), flush=True)
     ctx.close()
 

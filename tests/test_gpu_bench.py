@@ -15,8 +15,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(args, timeout=900):
+def _run(args, timeout=900, extra_env=None):
     env = dict(os.environ)
+    env.update(extra_env or {})
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     if torch.cuda.device_count() < 2:
@@ -53,3 +54,14 @@ def test_bench_c5_checks_textures_at_one_and_two_ranks(hip_lib):
     assert two["n_gpus"] == 2 and chk["equal"] is True
     assert {c["owner_rank"] for c in chk["textures_checked"]} == {0, 1}
     assert all(c["equal"] for c in chk["textures_checked"])
+
+
+@pytest.mark.timeout(600)
+def test_a_stuck_strong_scaling_leg_cannot_take_the_weak_line_down(hip_lib):
+    """The strong-scaling leg is an extra: with its watchdog set to fire at once, the job still prints
+    exactly one line, exit code 0, with the weak-scaling value and an error note in place of the leg."""
+    line = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "1024", "--no-cpu-baseline"],
+                extra_env={"BENCH_STRONG_TIMEOUT_S": "0.01"})
+    assert line["n_gpus"] == 2 and line["value"] > 0 and len(line["per_rank"]) == 2
+    st = line["strong_scaling"]
+    assert "error" in st or st.get("value", 0) > 0
