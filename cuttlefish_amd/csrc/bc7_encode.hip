@@ -841,19 +841,19 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 {
 	uint32_t lane;
 	CF_FRESH_LANE(lane);
-#define cslot (cbase + lane)
+#define L_CSLOT (cbase + lane)
 	// pair: blocks b and b + 1 at Low or Normal, one per half wavefront
-#define h (lane >> 5)
-#define hbase (pair ? (lane & 32u) : 0u)
+#define L_H (lane >> 5)
+#define L_HBASE (pair ? (lane & 32u) : 0u)
 	// (the block's LDS pointers are expressions of the current lane id too: half h of a pair)
-#define B_TP (tile + (pair ? b + h : b)*16u)
-#define B_OFF ((pair ? b + h : b)*16u)
+#define B_TP (tile + (pair ? b + L_H : b)*16u)
+#define B_OFF ((pair ? b + L_H : b)*16u)
 	// perceptual axis weights as 16-bit pairs (wY | wCr << 16, wCb | wA << 16); kp.flags holds the bytes
 	const uint32_t ywrg = (kp.flags & 255u) | (((kp.flags >> 8) & 255u) << 16);
 	const uint32_t ywba = ((kp.flags >> 16) & 255u) | (((kp.flags >> 24) & 127u) << 16);
 	// lanes 0..15 of each group test their block's alpha
 	const unsigned long long abal = __ballot((lane & 31u) < 16u && (B_TP[lane & 15u] >> 24) != 255u);
-	const bool has_alpha = pair ? ((uint32_t)(h ? abal >> 32 : abal) & 0xFFFFu) != 0u
+	const bool has_alpha = pair ? ((uint32_t)(L_H ? abal >> 32 : abal) & 0xFFFFu) != 0u
 		: ((uint32_t)abal & 0xFFFFu) != 0u;
 	const bool any_alpha = pair ? abal != 0ull : has_alpha;
 	// Low runs Normal's candidate set without the refit round (oracle: quality_budget): `quality`
@@ -886,8 +886,8 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	// the residual estimator and the best are taken in (score, index) order.
 	// Highest instead refits every partition (below), after a stream 0 without partitions.
 	const bool lay32 = !WIDE;
-#define hl (lay32 ? (lane & 31u) : lane)
-#define slot_ok (!lay32 || pair || lane < 32u)
+#define L_HL (lay32 ? (lane & 31u) : lane)
+#define L_SLOT_OK (!lay32 || pair || lane < 32u)
 	bool solved = false;
 	{
 		const uint32_t nstreams = (WIDE && !has_alpha) ? 2u : 1u;
@@ -905,15 +905,15 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 				else { pfirst = 4u; nslots = 14u; }
 			} else if (st == 1u) { pfirst = 0u; nslots = 10u; }
 			else { pfirst = 26u; nslots = 16u; }
-#define nper0 (lay32 ? (quality == 2u ? (has_alpha ? 11u : 6u) : 14u) : (st == 1u ? 5u : (has_alpha ? 16u : 8u)))
+#define R_NPER0 (lay32 ? (quality == 2u ? (has_alpha ? 11u : 6u) : 14u) : (st == 1u ? 5u : (has_alpha ? 16u : 8u)))
 			// lane roles as expressions of the CURRENT lane id (re-read where a phase starts), so that none of
 			// them is carried in a register through the fit
-#define R_REL (hl - pfirst)                                   /* wraps below pfirst */
+#define R_REL (L_HL - pfirst)                                   /* wraps below pfirst */
 #define R_SLOT (st == 1u ? R_REL/3u : R_REL >> 1)
 #define R_SUB (R_REL - R_SLOT*ns)
-#define R_PLANE (parts && slot_ok && hl >= pfirst && R_SLOT < nslots)
-#define R_MI (R_SLOT >= nper0 ? 1u : 0u)
-#define R_RANK (R_SLOT - R_MI*nper0)
+#define R_PLANE (parts && L_SLOT_OK && L_HL >= pfirst && R_SLOT < nslots)
+#define R_MI (R_SLOT >= R_NPER0 ? 1u : 0u)
+#define R_RANK (R_SLOT - R_MI*R_NPER0)
 			uint32_t mypart = 0;
 			// ---- phase 1: partition scores (one partition per lane, two when the group has
 			// only 32 lanes) and selection of the nper0 best by iterated group minimum ----
@@ -921,7 +921,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 				uint32_t key0[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
 				const uint32_t npi = pair ? 2u : 1u;
 				for (uint32_t pi = 0; pi < npi; ++pi) {
-					const uint32_t part = pair ? hl + 32u*pi : lane;
+					const uint32_t part = pair ? L_HL + 32u*pi : lane;
 					const uint32_t p2 = k_part2[part], p3 = k_part3[part];
 					float sc = 0.0f;
 					for (uint32_t sb = 0; sb < ns; ++sb) {
@@ -944,9 +944,9 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 					const uint32_t npart = (st == 1u && run == 0u) ? 16u : 64u;
 					uint32_t ka = (key0[0] & 63u) < npart ? key0[0] : 0xFFFFFFFFu, kb = key0[1];
 					// uniform trip count: the larger of the groups' needs
-					const uint32_t nsel = lay32 ? (quality == 2u ? (any_alpha ? 11u : 6u) : 14u) : nper0;
+					const uint32_t nsel = lay32 ? (quality == 2u ? (any_alpha ? 11u : 6u) : 14u) : R_NPER0;
 					for (uint32_t t = 0; t < nsel; ++t) {
-						const uint32_t kmin = cf_group_min_u32(ka < kb ? ka : kb, pair, h);
+						const uint32_t kmin = cf_group_min_u32(ka < kb ? ka : kb, pair, L_H);
 						const bool mine = R_RANK == t && (st == 0u || R_MI == run);
 						mypart = mine ? (kmin & 63u) : mypart;
 						ka = ka == kmin ? 0xFFFFFFFFu : ka;
@@ -957,10 +957,10 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			// ---- lane roles ----
 			CF_FRESH_LANE(lane);
 			asm volatile("" : "+v"(mypart));   // nothing of phase 1 but mypart lives on
-#define R_M6 (st == 0u && slot_ok && hl < 2u)
-#define R_VECP (lay32 ? (quality == 2u ? (slot_ok && hl >= 2u && hl < 6u) : (slot_ok && hl == 2u)) : (st == 0u && lane >= 2u && lane < 14u))
-#define R_SCA (lay32 ? (quality == 2u ? (slot_ok && hl >= 6u && hl < 10u) : (slot_ok && hl == 3u)) : (st == 0u && lane >= 14u && lane < 26u))
-#define R_CID (R_M6 ? 0u : (lay32 ? (quality == 2u ? hl - (R_SCA ? 5u : 1u) : 1u) : 1u + (lane - (R_SCA ? 14u : 2u))))   /* meaningful for vecp / sca */
+#define R_M6 (st == 0u && L_SLOT_OK && L_HL < 2u)
+#define R_VECP (lay32 ? (quality == 2u ? (L_SLOT_OK && L_HL >= 2u && L_HL < 6u) : (L_SLOT_OK && L_HL == 2u)) : (st == 0u && lane >= 2u && lane < 14u))
+#define R_SCA (lay32 ? (quality == 2u ? (L_SLOT_OK && L_HL >= 6u && L_HL < 10u) : (L_SLOT_OK && L_HL == 3u)) : (st == 0u && lane >= 14u && lane < 26u))
+#define R_CID (R_M6 ? 0u : (lay32 ? (quality == 2u ? L_HL - (R_SCA ? 5u : 1u) : 1u) : 1u + (lane - (R_SCA ? 14u : 2u))))   /* meaningful for vecp / sca */
 #define R_IDBASE (R_PLANE ? (st == 1u ? (R_MI ? 256u : 192u) : (has_alpha ? 320u : (R_MI ? 128u : 64u))) : 0u)
 			const bool m6 = R_M6, sca = R_SCA, vecp = R_VECP, plane = R_PLANE;
 			const uint32_t cid = R_CID, sub = R_SUB, mi = R_MI;
@@ -1039,7 +1039,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			const bool use1 = R_PLANE, use2 = R_VECP || (R_PLANE && st == 1u);
 			const uint32_t cerr = lf.err + (use1 ? e1 : 0u) + (use2 ? e2 : 0u);
 			const uint32_t cidv = R_M6 ? 0u : (R_VECP ? R_CID : R_IDBASE + mypart);
-			const bool leader = active && (R_M6 ? hl == 0u : (R_VECP || (R_PLANE && R_SUB == 0u)));
+			const bool leader = active && (R_M6 ? L_HL == 0u : (R_VECP || (R_PLANE && R_SUB == 0u)));
 			const bool take = leader && (cerr < best_err || (cerr == best_err && cidv < best_id));
 			if (take) {
 				best_err = cerr;
@@ -1050,20 +1050,20 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 				const uint32_t a02 = (uint32_t)cf_bperm((int)lf.q0, (uint32_t)(s2)), a12 = (uint32_t)cf_bperm((int)lf.q1, (uint32_t)(s2));
 				const uint32_t pb1 = (uint32_t)cf_bperm((int)lf.pb, (uint32_t)(s1)), pb2 = (uint32_t)cf_bperm((int)lf.pb, (uint32_t)(s2));
 				if (take) {
-					cslot[0*CF_WG_THREADS] = lf.q0;
-					cslot[1*CF_WG_THREADS] = lf.q1;
-					cslot[2*CF_WG_THREADS] = R_PLANE ? a01 : 0u;
-					cslot[3*CF_WG_THREADS] = R_PLANE ? a11 : 0u;
+					L_CSLOT[0*CF_WG_THREADS] = lf.q0;
+					L_CSLOT[1*CF_WG_THREADS] = lf.q1;
+					L_CSLOT[2*CF_WG_THREADS] = R_PLANE ? a01 : 0u;
+					L_CSLOT[3*CF_WG_THREADS] = R_PLANE ? a11 : 0u;
 					// modes 4/5: the scalar plane's endpoints are parked in q[4], q[5] (byte 3)
-					cslot[4*CF_WG_THREADS] = R_VECP ? (a02 & 0xFF000000u) : ((R_PLANE && st == 1u) ? a02 : 0u);
-					cslot[5*CF_WG_THREADS] = R_VECP ? (a12 & 0xFF000000u) : ((R_PLANE && st == 1u) ? a12 : 0u);
-					cslot[6*CF_WG_THREADS] = lf.pb | (R_PLANE ? (pb1 << 2) : 0u) |
+					L_CSLOT[4*CF_WG_THREADS] = R_VECP ? (a02 & 0xFF000000u) : ((R_PLANE && st == 1u) ? a02 : 0u);
+					L_CSLOT[5*CF_WG_THREADS] = R_VECP ? (a12 & 0xFF000000u) : ((R_PLANE && st == 1u) ? a12 : 0u);
+					L_CSLOT[6*CF_WG_THREADS] = lf.pb | (R_PLANE ? (pb1 << 2) : 0u) |
 						((R_PLANE && st == 1u) ? (pb2 << 4) : 0u);
 					// errors of the candidate's fits: subset 0 / vector plane / mode 6, then subset 1 or
 					// the scalar plane, then subset 2
-					cslot[15*CF_WG_THREADS] = lf.err;
-					cslot[16*CF_WG_THREADS] = R_PLANE ? e1 : (R_VECP ? e2 : 0u);
-					cslot[17*CF_WG_THREADS] = (R_PLANE && st == 1u) ? e2 : 0u;
+					L_CSLOT[15*CF_WG_THREADS] = lf.err;
+					L_CSLOT[16*CF_WG_THREADS] = R_PLANE ? e1 : (R_VECP ? e2 : 0u);
+					L_CSLOT[17*CF_WG_THREADS] = (R_PLANE && st == 1u) ? e2 : 0u;
 				}
 			}
 #pragma unroll
@@ -1071,9 +1071,9 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 				const uint32_t w1 = (uint32_t)cf_bperm((int)lf.w[k], (uint32_t)(s1));
 				const uint32_t w2 = (uint32_t)cf_bperm((int)lf.w[k], (uint32_t)(s2));
 				if (take) {
-					cslot[(7 + k)*CF_WG_THREADS] = lf.w[k] | (R_PLANE ? w1 : 0u) |
+					L_CSLOT[(7 + k)*CF_WG_THREADS] = lf.w[k] | (R_PLANE ? w1 : 0u) |
 						((R_PLANE && st == 1u) ? w2 : 0u);
-					cslot[(11 + k)*CF_WG_THREADS] = R_VECP ? w2 : 0u;
+					L_CSLOT[(11 + k)*CF_WG_THREADS] = R_VECP ? w2 : 0u;
 				}
 			}
 			// A zero-error candidate cannot be beaten by a later one (ids grow with the
@@ -1083,7 +1083,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			// of at least 48 (oracle: same rule); one block per wave here, so this is uniform
 			if (WIDE && cf_wave_min_u32(best_err) < 48u)
 				solved = true;
-#undef nper0
+#undef R_NPER0
 #undef R_REL
 #undef R_SLOT
 #undef R_SUB
@@ -1101,10 +1101,10 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	// ---- group argmin on (error, id); the group packs its winner's candidate ----
 	CF_FRESH_LANE(lane);
 	const unsigned long long key = ((unsigned long long)best_err << 32) | best_id;
-	const unsigned long long kmin = cf_group_min_u64(key, pair, h);
+	const unsigned long long kmin = cf_group_min_u64(key, pair, L_H);
 	const unsigned long long bal = __ballot(key == kmin);
-	const uint32_t gmask = pair ? (h ? (uint32_t)(bal >> 32) : (uint32_t)bal) : 0u;
-	const uint32_t wl = pair ? hbase + (uint32_t)__ffs((int)gmask) - 1u
+	const uint32_t gmask = pair ? (L_H ? (uint32_t)(bal >> 32) : (uint32_t)bal) : 0u;
+	const uint32_t wl = pair ? L_HBASE + (uint32_t)__ffs((int)gmask) - 1u
 		: (uint32_t)__ffsll((long long)bal) - 1u;   // winner lane (unique key in its group)
 	uint32_t* wc = cbase + wl;                      // the winner's column
 
@@ -1131,8 +1131,8 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 		const uint32_t ns = (0x21112323u >> (4u*mode)) & 15u;
 		const bool m6 = mode == 6u, planes45 = mode == 4u || mode == 5u;
 		const uint32_t nfits = planes45 ? 2u : ns;
-		const uint32_t kf = m6 ? 0u : (hl >> 4), mv = m6 ? (hl >> 1) & 15u : (hl & 15u);
-		const bool act = slot_ok && hl < 64u && (m6 ? hl < 32u : kf < nfits) && (uint32_t)(kmin >> 32) != 0u;
+		const uint32_t kf = m6 ? 0u : (L_HL >> 4), mv = m6 ? (L_HL >> 1) & 15u : (L_HL & 15u);
+		const bool act = L_SLOT_OK && L_HL < 64u && (m6 ? L_HL < 32u : kf < nfits) && (uint32_t)(kmin >> 32) != 0u;
 		uint32_t cb, ab, pbk, ib, mask = 0xFFFFu, chm;
 		const bool sca = planes45 && kf == 1u;
 		if (planes45) {
@@ -1214,14 +1214,14 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			for (int k = 0; k < 4; ++k) f.w[k] = 0;
 			float x0[4], x1[4];
 			bool okk;
-			assign_lsq_lane<UNITW>(tx, mask, m6, hl & 1u, ib, yw, pp_sum, false, f, x0, x1, okk);
+			assign_lsq_lane<UNITW>(tx, mask, m6, L_HL & 1u, ib, yw, pp_sum, false, f, x0, x1, okk);
 			uint32_t key = valid ? ((f.err << 4) | mv) : 0xFFFFFFFFu;
 			uint32_t fitmin = cf_row_min_u32(key);
 			if (m6) {
 				const uint32_t other = (uint32_t)cf_bperm((int)fitmin, lane ^ 16u);
 				fitmin = other < fitmin ? other : fitmin;
 			}
-			const bool win = valid && key == fitmin && f.err < cur_err && (!m6 || (hl & 1u) == 0u);
+			const bool win = valid && key == fitmin && f.err < cur_err && (!m6 || (L_HL & 1u) == 0u);
 			// one fit at a time: the fits share the p-bit word and the weight words of the column
 #pragma unroll 1
 			for (uint32_t k = 0; k < 3u; ++k) {
@@ -1253,11 +1253,11 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	return pack_block_group(wc, (uint32_t)kmin, lane, pair);
 #undef B_TP
 #undef B_OFF
-#undef h
-#undef hbase
-#undef hl
-#undef slot_ok
-#undef cslot
+#undef L_H
+#undef L_HBASE
+#undef L_HL
+#undef L_SLOT_OK
+#undef L_CSLOT
 }
 
 } // namespace
