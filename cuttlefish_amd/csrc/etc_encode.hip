@@ -16,6 +16,10 @@
 // Texels outside the image carry no error weight (EtcConverter.cpp:122-129).
 #include "cf_device.h"
 
+#ifndef CF_ETC_ABLATE
+#define CF_ETC_ABLATE 0   // timing experiments only (tools/dbg/etc_ablate.sh): 1 = no planar, 2 = no T / H
+#endif
+
 namespace {
 
 enum { E_ETC1 = 37, E_RGB = 38, E_A1 = 39, E_A8 = 40, E_R11 = 41, E_RG11 = 42 };
@@ -711,7 +715,7 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 		bool use_planar = false;
 		// planar has no selectors, so it cannot express transparency: opaque blocks only.
 		// Closed-form least squares on the 4x4 grid (uniform), then 2 rounds of moves.
-		if (!o.punch) {
+		if (!o.punch && !(CF_ETC_ABLATE & 1)) {
 		{
 			// sums over the 16 texels, one texel per lane: S | Sx << 16 in one word (the low field
 			// never borrows, so the signed high field is exact), Sy in another
@@ -759,7 +763,7 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 		// ETC2 T / H modes (ids after planar), also in punch-through blocks
 		ThCand th;
 		bool have_th = false;
-		if (o.refine)
+		if (o.refine && !(CF_ETC_ABLATE & 2))
 			have_th = unitw ? th_search<true>(tp, o, o.radius, lane, th)
 				: th_search<false>(tp, o, o.radius, lane, th);
 		if (have_th && th.err < best_err)
