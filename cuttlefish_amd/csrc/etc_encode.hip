@@ -202,6 +202,47 @@ __device__ __forceinline__ uint32_t planar_err_rows(const uint32_t* tp, const Rg
 	return cf_row_sum_u32(((o.active >> ti) & 1u) ? e : 0u);
 }
 
+// planar_err_rows per channel: e[c] = the channel's share of the error (same integers, three row sums)
+__device__ __forceinline__ void planar_err_rows3(const uint32_t* tp, const RgbOpts& o, const PlanarQ& q,
+	uint32_t lane, uint32_t (&e)[3])
+{
+	const uint32_t ti = lane & 15u;
+	const int x = (int)(ti & 3u), y = (int)(ti >> 2);
+	const uint32_t p = tp[ti];
+	const bool act = ((o.active >> ti) & 1u) != 0u;
+#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		const int O = c == 1 ? ex7(q.O[c]) : ex6(q.O[c]), H = c == 1 ? ex7(q.H[c]) : ex6(q.H[c]),
+			V = c == 1 ? ex7(q.V[c]) : ex6(q.V[c]);
+		const int v = clamp255((x*(H - O) + y*(V - O) + 4*O + 2) >> 2);
+		const int d = v - (int)((p >> (8*c)) & 255u);
+		e[c] = cf_row_sum_u32(act ? (uint32_t)(o.wt[c]*d*d) : 0u);
+	}
+}
+
+// one channel's share of planar_err over texels [i0, i0 + cnt): a single-field move changes the
+// prediction of its own channel only, so a move is scored as (current total - the channel's current
+// share + its new share) -- a third of the arithmetic, the same integers
+__device__ __forceinline__ uint32_t planar_err_ch(const uint32_t* tp, const RgbOpts& o, const PlanarQ& q, int c,
+	int wt, uint32_t i0, uint32_t cnt)
+{
+	const int qO = c == 0 ? q.O[0] : (c == 1 ? q.O[1] : q.O[2]), qH = c == 0 ? q.H[0] : (c == 1 ? q.H[1] : q.H[2]),
+		qV = c == 0 ? q.V[0] : (c == 1 ? q.V[1] : q.V[2]);
+	const int O = c == 1 ? ex7(qO) : ex6(qO), H = c == 1 ? ex7(qH) : ex6(qH), V = c == 1 ? ex7(qV) : ex6(qV);
+	const int dH = H - O, dV = V - O, base = 4*O + 2;
+	uint32_t e = 0;
+#pragma unroll 1
+	for (uint32_t i = i0; i < i0 + cnt; ++i) {
+		if (!((o.active >> i) & 1u))
+			continue;
+		const int x = (int)(i & 3u), y = (int)(i >> 2);
+		const int v = clamp255((x*dH + y*dV + base) >> 2);
+		const int d = v - (int)((tp[i] >> (8*c)) & 255u);
+		e += (uint32_t)(wt*d*d);
+	}
+	return e;
+}
+
 // add d to field f (0..8 = O.rgb, H.rgb, V.rgb) without dynamic register indexing;
 // returns false when the field would leave its range
 __device__ __forceinline__ bool planar_move(PlanarQ& q, int f, int d)
@@ -734,26 +775,44 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 				pq.V[c] = (clampi(5*S - 3*Sx + 5*Sy, 0, 255*80)*mq + 10200)/20400;
 			}
 		}
-		uint32_t ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)planar_err_rows(tp, o, pq, lane));
+		uint32_t ec[3] = {0u, 0u, 0u}, ep;
+		if (o.refine) {
+			planar_err_rows3(tp, o, pq, lane, ec);
+#pragma unroll
+			for (int c = 0; c < 3; ++c)
+				ec[c] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ec[c]);
+			ep = ec[0] + ec[1] + ec[2];
+		} else                               // Lowest: no move rounds, the total alone
+			ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)planar_err_rows(tp, o, pq, lane));
+		// (the channel weights as opaque scalars: a select among o.wt[] by a lane value becomes an indexed
+		// load and puts the whole option block in scratch)
+		int pw0 = o.wt[0], pw1 = o.wt[1], pw2 = o.wt[2];
+		asm volatile("" : "+s"(pw0), "+s"(pw1), "+s"(pw2));
 		for (int round = 0; round < (o.refine ? 2 : 0); ++round) {
-			// 18 single-field moves, two lanes per move (eight texels each)
+			// 18 single-field moves, two lanes per move (eight texels each); a move touches one channel:
+			// its total = the current total - that channel's share + the channel's new share
 			unsigned long long mk = ~0ull;
 			{
 				const uint32_t mv = lane >> 1;
-				const int f = (int)(mv >> 1), d = (mv & 1u) ? 1 : -1;
+				const int f = mv < 18u ? (int)(mv >> 1) : 0, d = (mv & 1u) ? 1 : -1;
+				const int c = f >= 6 ? f - 6 : (f >= 3 ? f - 3 : f);
 				PlanarQ tq = pq;
-				const bool okm = planar_move(tq, mv < 18u ? f : 0, d) && mv < 18u;
-				const uint32_t part = planar_err(tp, o, tq, (lane & 1u)*8u, 8u);
+				const bool okm = planar_move(tq, f, d) && mv < 18u;
+				const uint32_t part = planar_err_ch(tp, o, tq, c, c == 0 ? pw0 : (c == 1 ? pw1 : pw2), (lane & 1u)*8u, 8u);
 				const uint32_t both = part + cf_xor1(part);
+				const uint32_t tot = ep - (c == 0 ? ec[0] : (c == 1 ? ec[1] : ec[2])) + both;
 				if (okm)
-					mk = ((unsigned long long)both << 32) | mv;
+					mk = ((unsigned long long)tot << 32) | mv;
 			}
 			const unsigned long long mm = cf_wave_min_u64(mk);
 			if ((uint32_t)(mm >> 32) >= ep)
 				break;
+			const int id = (int)(uint32_t)mm, fw = id >> 1, cw = fw >= 6 ? fw - 6 : (fw >= 3 ? fw - 3 : fw);
+			// the winner's channel takes its new share
+			const uint32_t nshare = (uint32_t)(mm >> 32) - (ep - (cw == 0 ? ec[0] : (cw == 1 ? ec[1] : ec[2])));
+			ec[0] = cw == 0 ? nshare : ec[0]; ec[1] = cw == 1 ? nshare : ec[1]; ec[2] = cw == 2 ? nshare : ec[2];
 			ep = (uint32_t)(mm >> 32);
-			const int id = (int)(uint32_t)mm;
-			planar_move(pq, id >> 1, (id & 1) ? 1 : -1);
+			planar_move(pq, fw, (id & 1) ? 1 : -1);
 		}
 		if (ep < best_err) {
 			best_err = ep;
