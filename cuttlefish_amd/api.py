@@ -130,7 +130,7 @@ EXPORTS = ["cfhip_abi_version", "cfhip_device_count", "cfhip_create", "cfhip_des
            "cfhip_query", "cfhip_encode", "cfhip_encode_multi", "cfhip_encode_device", "cfhip_shard_rows",
            "cfhip_last_kernel_ms", "cfhip_last_kernel_name", "cfhip_last_error",
            "cfhip_profile_begin", "cfhip_profile_end", "cfhip_generate_mips_device",
-           "cfhip_generate_mips3d_device", "cfhip_resize_device"]
+           "cfhip_generate_mips3d_device", "cfhip_resize_device", "cfhip_generate_mips_array_device"]
 
 
 class Params(ctypes.Structure):
@@ -208,6 +208,11 @@ def load_library(path: Optional[str] = None):
         ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
         ctypes.c_uint32, ctypes.c_void_p]
     L.cfhip_generate_mips_device.restype = ctypes.c_int
+    L.cfhip_generate_mips_array_device.argtypes = [
+        ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32,
+        ctypes.c_uint32, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+        ctypes.c_uint32, ctypes.c_void_p]
+    L.cfhip_generate_mips_array_device.restype = ctypes.c_int
     L.cfhip_generate_mips3d_device.argtypes = [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
         ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
@@ -363,6 +368,23 @@ class Context:
         self._check(self._lib.cfhip_generate_mips_device(
             self._h, ctypes.c_void_p(int(src)), int(pixel_type), width, height, row_pitch_bytes,
             int(color_space), int(filter), arr, n, ctypes.c_void_p(stream) if stream else None))
+
+    def generate_mips_array_device(self, srcs: Sequence[int], pixel_type, width: int, height: int,
+                                   row_pitch_bytes: int, dst_levels: Sequence[Sequence[int]],
+                                   color_space=ColorSpace.Linear, filter=0, stream: int = 0):
+        """generate_mips_device for the layers of an array / cube texture in one call: srcs[l] = level 0
+        of layer l, dst_levels[l][k-1] receives its level k.  One launch per pass and level for all
+        layers; bit-identical to one call per layer."""
+        nl = len(srcs)
+        if nl == 0 or len(dst_levels) != nl or len({len(d) for d in dst_levels}) != 1:
+            raise ValueError("srcs and dst_levels must list the same layers, every layer the same levels")
+        per = len(dst_levels[0])
+        sarr = (ctypes.c_void_p * nl)(*[ctypes.c_void_p(int(p)) for p in srcs])
+        flat = [ctypes.c_void_p(int(p)) for d in dst_levels for p in d]
+        darr = (ctypes.c_void_p * max(len(flat), 1))(*flat)
+        self._check(self._lib.cfhip_generate_mips_array_device(
+            self._h, sarr, nl, int(pixel_type), width, height, row_pitch_bytes, int(color_space), int(filter),
+            darr, per + 1, ctypes.c_void_p(stream) if stream else None))
 
     def generate_mips3d_device(self, src: int, pixel_type, width: int, height: int, depth: int,
                                row_pitch_bytes: int, slice_pitch_bytes: int, dst_levels: Sequence[int],

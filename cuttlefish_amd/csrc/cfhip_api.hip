@@ -32,6 +32,10 @@ extern "C" hipError_t cfhip_launch_bc6h(const cf_kparams* kp, int pixel_type, in
 extern "C" hipError_t cfhip_launch_mip_resize(const void* src, int src_pixel_type, size_t pitch,
 	uint32_t sw, uint32_t sh, void* dst, uint32_t dw, uint32_t dh, int filter, int srgb,
 	hipStream_t stream);
+extern "C" hipError_t cfhip_launch_mip_pass_layers(const void* src, int src_pixel_type, size_t pitch,
+	uint32_t src_n, void* dst, uint32_t dst_w, uint32_t dst_h, int along_x, int filter, int to_linear,
+	int to_srgb, uint32_t layers, const void* const* src_tab, void* const* dst_tab, size_t src_zstride,
+	size_t dst_zstride, hipStream_t stream);
 extern "C" hipError_t cfhip_launch_mip_pass(const void* src, int src_pixel_type, size_t pitch,
 	uint32_t src_n, void* dst, uint32_t dst_w, uint32_t dst_h, int along_x, int filter, int to_linear,
 	int to_srgb, hipStream_t stream);
@@ -1196,6 +1200,119 @@ int cfhip_generate_mips_device(cfhip_ctx* ctx, const void* src, int src_pixel_ty
 		HIP_TRY(ctx, hipStreamSynchronize(stream));
 		// the staging buffers are idle only if THIS stream was their last user (an earlier
 		// asynchronous call on another stream may still have d_src / d_batch / d_mip3d in flight)
+		if (used_staging || ctx->staging_stream == stream)
+			ctx->staging_busy = false;
+	}
+	return CFHIP_OK;
+}
+
+// Array / cube textures: Texture::generateMipmaps resizes every [depth][face] image of a level on its own
+// (Texture.cpp:1480-1511 inside its loops over depth and faces) -- the layers never mix.  Here the layers
+// of a level share ONE launch per pass (blockIdx.z = layer): a 2048^2 chain is 22 launches of which 16
+// are a few microseconds long, and an array of 256 such textures was 5 632 dependent launches on one
+// stream (launch-bound: 28 ms); batched it is 22.  A level whose staging image for all layers would
+// pass the budget below runs layer by layer -- those launches are long enough not to matter.
+int cfhip_generate_mips_array_device(cfhip_ctx* ctx, const void* const* srcs, uint32_t layers,
+	int src_pixel_type, uint32_t width, uint32_t height, size_t src_pitch_bytes, int color_space,
+	int filter, void* const* dst_levels, uint32_t levels, void* stream_)
+{
+	if (!ctx)
+		return fail(nullptr, CFHIP_E_INVALID, "ctx is NULL");
+	std::lock_guard<std::mutex> guard(ctx->lock);
+	if (!srcs || !layers || !width || !height || !levels || (levels > 1 && !dst_levels))
+		return fail(ctx, CFHIP_E_INVALID, "mip generation: NULL or empty argument");
+	if (layers > 65535u)
+		return fail(ctx, CFHIP_E_INVALID, "mip generation: %u layers (at most 65535 per call)", layers);
+	if (src_pixel_type < CFHIP_PIXEL_RGBA8 || src_pixel_type > CFHIP_PIXEL_RGBA16F)
+		return fail(ctx, CFHIP_E_INVALID, "mip generation: pixel type %d", src_pixel_type);
+	if (color_space != CFHIP_COLOR_LINEAR && color_space != CFHIP_COLOR_SRGB)
+		return fail(ctx, CFHIP_E_INVALID, "mip generation: colour space %d", color_space);
+	if (!filter_valid(filter))
+		return fail(ctx, CFHIP_E_INVALID, "resize filter %d", filter);
+	uint32_t max_levels = 1;
+	for (uint32_t d = width > height ? width : height; d > 1; d >>= 1)
+		++max_levels;
+	if (levels > max_levels)
+		return fail(ctx, CFHIP_E_INVALID, "%u mip levels requested, a %ux%u texture has %u", levels,
+			width, height, max_levels);
+	const size_t texel = src_pixel_type == CFHIP_PIXEL_RGBA8 ? 4 : (src_pixel_type == CFHIP_PIXEL_RGBA32F ? 16 : 8);
+	if (src_pitch_bytes < (size_t)width*texel)
+		return fail(ctx, CFHIP_E_INVALID, "mip generation: row pitch smaller than a row");
+	for (uint32_t l = 0; l < layers; ++l) {
+		if (!srcs[l])
+			return fail(ctx, CFHIP_E_INVALID, "mip generation: srcs[%u] is NULL", l);
+		for (uint32_t k = 1; k < levels; ++k)
+			if (!dst_levels[(size_t)l*(levels - 1u) + (k - 1u)])
+				return fail(ctx, CFHIP_E_INVALID, "mip generation: dst_levels[%u][%u] is NULL", l, k - 1u);
+	}
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : ctx->stream;
+	const int srgb = color_space == CFHIP_COLOR_SRGB ? 1 : 0;
+	bool used_staging = false;
+	if (levels > 1) {
+		// device pointer tables, level-major: row 0 = the sources, row k = level k of every layer
+		std::vector<const void*> tab((size_t)levels*layers);
+		for (uint32_t l = 0; l < layers; ++l) {
+			tab[l] = srcs[l];
+			for (uint32_t k = 1; k < levels; ++k)
+				tab[(size_t)k*layers + l] = dst_levels[(size_t)l*(levels - 1u) + (k - 1u)];
+		}
+		int rc = staging_acquire(ctx, stream);
+		if (rc != CFHIP_OK) return rc;
+		used_staging = true;
+		rc = reserve(ctx, &ctx->d_batch, &ctx->batch_cap, tab.size()*sizeof(void*));
+		if (rc != CFHIP_OK) return staging_abort(ctx, stream, used_staging, rc);
+		// pageable source: the runtime stages the copy before returning, so `tab` may die
+		if (hipMemcpyAsync(ctx->d_batch, tab.data(), tab.size()*sizeof(void*), hipMemcpyHostToDevice, stream) != hipSuccess)
+			return staging_abort(ctx, stream, used_staging, fail(ctx, CFHIP_E_DEVICE, "mip generation: table upload failed"));
+		const void* const* d_tab = static_cast<const void* const*>(ctx->d_batch);
+		const size_t kStagingBudget = (size_t)1 << 30;           // the float image between the two passes, all layers
+		uint32_t pw = width, ph = height;
+		int prev_type = src_pixel_type;
+		size_t prev_pitch = src_pitch_bytes;
+		for (uint32_t k = 1; k < levels; ++k) {
+			const uint32_t w = (width >> k) ? (width >> k) : 1u, h = (height >> k) ? (height >> k) : 1u;
+			const void* const* s_tab = d_tab + (size_t)(k - 1u)*layers;
+			void* const* o_tab = const_cast<void* const*>(d_tab + (size_t)k*layers);
+			const bool x_first = (unsigned long long)w*ph <= (unsigned long long)h*pw;
+			const bool need_x = w != pw, need_y = h != ph;
+			const uint32_t tw = x_first ? w : pw, th = x_first ? ph : h;
+			const size_t timg = (size_t)tw*th*16u;
+			const bool batched = !(filter & CFHIP_FILTER_FALLBACK) && (!(need_x && need_y) || timg*layers <= kStagingBudget);
+			if (!batched) {
+				for (uint32_t l = 0; l < layers; ++l) {
+					const int rc2 = mip_level_2d(ctx, tab[(size_t)(k - 1u)*layers + l], prev_type, prev_pitch, pw, ph,
+						const_cast<void*>(tab[(size_t)k*layers + l]), w, h, filter, srgb, stream, &used_staging);
+					if (rc2 != CFHIP_OK)
+						return staging_abort(ctx, stream, used_staging, rc2);
+				}
+			} else if (need_x && need_y) {
+				rc = reserve(ctx, &ctx->d_src, &ctx->src_cap, timg*layers);
+				if (rc != CFHIP_OK) return staging_abort(ctx, stream, used_staging, rc);
+				hipError_t e = cfhip_launch_mip_pass_layers(nullptr, prev_type, prev_pitch, x_first ? pw : ph, ctx->d_src, tw, th,
+					x_first ? 1 : 0, filter, srgb, 0, layers, s_tab, nullptr, 0, timg, stream);
+				if (e == hipSuccess)
+					e = cfhip_launch_mip_pass_layers(ctx->d_src, CFHIP_PIXEL_RGBA32F, (size_t)tw*16u, x_first ? ph : pw, nullptr, w, h,
+						x_first ? 0 : 1, filter, 0, srgb, layers, nullptr, o_tab, timg, 0, stream);
+				if (e != hipSuccess)
+					return staging_abort(ctx, stream, used_staging, fail(ctx, CFHIP_E_DEVICE, "mip pass: %s", hipGetErrorString(e)));
+			} else {
+				const hipError_t e = cfhip_launch_mip_pass_layers(nullptr, prev_type, prev_pitch, need_x ? pw : ph, nullptr, w, h,
+					need_x ? 1 : 0, filter, srgb, srgb, layers, s_tab, o_tab, 0, 0, stream);
+				if (e != hipSuccess)
+					return staging_abort(ctx, stream, used_staging, fail(ctx, CFHIP_E_DEVICE, "mip pass: %s", hipGetErrorString(e)));
+			}
+			prev_type = CFHIP_PIXEL_RGBA32F;
+			prev_pitch = (size_t)w*16u;
+			pw = w; ph = h;
+		}
+	}
+	if (used_staging) {
+		const int rc = staging_release(ctx, stream);
+		if (rc != CFHIP_OK) return rc;
+	}
+	if (!stream_) {
+		HIP_TRY(ctx, hipStreamSynchronize(stream));
 		if (used_staging || ctx->staging_stream == stream)
 			ctx->staging_busy = false;
 	}

@@ -178,11 +178,23 @@ __device__ __forceinline__ double fi_filter(int filter, double v)
 // One separable pass: output (u, l) = sum_i w_i * src(i, l) along x (ALONG_X) or y, weights
 // normalised per output coordinate.  TO_LINEAR converts the source texel (sRGB image, first
 // pass); TO_SRGB converts the result (last pass).  Float store after every step, as RGBAF.
+// Layers (blockIdx.z) of an array texture share one launch: a layer's source / destination is an entry of
+// a device pointer table (surfaces owned by the caller) or base + layer * stride (the staging image).
+struct MipLayers {
+	const void* const* src_tab;
+	void* const* dst_tab;
+	size_t src_zstride, dst_zstride;     // bytes
+};
+
 template <int SRC_PIX, bool ALONG_X>
 __global__ void __launch_bounds__(256)
-cfhip_mip_pass_kernel(const uint8_t* __restrict__ src, size_t pitch, uint32_t src_n, float4* __restrict__ dst,
-	uint32_t dst_w, uint32_t dst_h, int filter, int to_linear, int to_srgb)
+cfhip_mip_pass_kernel(const uint8_t* src_base, size_t pitch, uint32_t src_n, float4* dst_base,
+	uint32_t dst_w, uint32_t dst_h, int filter, int to_linear, int to_srgb, MipLayers L)
 {
+	const uint8_t* __restrict__ src = L.src_tab ? static_cast<const uint8_t*>(L.src_tab[blockIdx.z])
+		: src_base + (size_t)blockIdx.z*L.src_zstride;
+	float4* __restrict__ dst = L.dst_tab ? static_cast<float4*>(L.dst_tab[blockIdx.z])
+		: reinterpret_cast<float4*>(reinterpret_cast<uint8_t*>(dst_base) + (size_t)blockIdx.z*L.dst_zstride);
 	__shared__ float lin_of_u8[SRC_PIX == 0 ? 256 : 1];   // see cfhip_mip_resize_kernel
 	if (SRC_PIX == 0 && to_linear) {
 		lin_of_u8[threadIdx.x] = (float)srgb_to_linear((double)(float)((double)threadIdx.x/255.0));
@@ -299,15 +311,19 @@ cfhip_mip_depth_kernel(const float4* __restrict__ prev, uint32_t n_prev, uint32_
 } // namespace
 
 // one separable pass (filters 0..4): src (any pixel type, `pitch`) -> dst (RGBA32F, dst_w x dst_h)
-extern "C" hipError_t cfhip_launch_mip_pass(const void* src, int src_pixel_type, size_t pitch,
+// `layers` surfaces in one launch: src_tab / dst_tab (device arrays of device pointers) or, where a table is
+// NULL, src / dst + layer * zstride
+extern "C" hipError_t cfhip_launch_mip_pass_layers(const void* src, int src_pixel_type, size_t pitch,
 	uint32_t src_n, void* dst, uint32_t dst_w, uint32_t dst_h, int along_x, int filter, int to_linear,
-	int to_srgb, hipStream_t stream)
+	int to_srgb, uint32_t layers, const void* const* src_tab, void* const* dst_tab, size_t src_zstride,
+	size_t dst_zstride, hipStream_t stream)
 {
-	const dim3 grid((dst_w + 63u)/64u, (dst_h + 3u)/4u, 1), block(256, 1, 1);
+	const dim3 grid((dst_w + 63u)/64u, (dst_h + 3u)/4u, layers), block(256, 1, 1);
 	const uint8_t* s = static_cast<const uint8_t*>(src);
 	float4* d = static_cast<float4*>(dst);
+	const MipLayers L = {src_tab, dst_tab, src_zstride, dst_zstride};
 #define CF_PASS(P, AX) hipLaunchKernelGGL((cfhip_mip_pass_kernel<P, AX>), grid, block, 0, stream, s, pitch, \
-	src_n, d, dst_w, dst_h, filter, to_linear, to_srgb)
+	src_n, d, dst_w, dst_h, filter, to_linear, to_srgb, L)
 	if (along_x) {
 		if (src_pixel_type == 0) CF_PASS(0, true); else if (src_pixel_type == 1) CF_PASS(1, true); else CF_PASS(2, true);
 	} else {
@@ -315,6 +331,14 @@ extern "C" hipError_t cfhip_launch_mip_pass(const void* src, int src_pixel_type,
 	}
 #undef CF_PASS
 	return hipGetLastError();
+}
+
+extern "C" hipError_t cfhip_launch_mip_pass(const void* src, int src_pixel_type, size_t pitch,
+	uint32_t src_n, void* dst, uint32_t dst_w, uint32_t dst_h, int along_x, int filter, int to_linear,
+	int to_srgb, hipStream_t stream)
+{
+	return cfhip_launch_mip_pass_layers(src, src_pixel_type, pitch, src_n, dst, dst_w, dst_h, along_x, filter,
+		to_linear, to_srgb, 1u, nullptr, nullptr, 0, 0, stream);
 }
 
 // one level: src (any pixel type) -> dst (RGBA32F, tightly packed)

@@ -254,6 +254,18 @@ int cfhip_generate_mips_device(cfhip_ctx* ctx, const void* src, int src_pixel_ty
 	uint32_t width, uint32_t height, size_t src_pitch_bytes, int color_space, int filter,
 	void* const* dst_levels, uint32_t levels, void* stream);
 
+/* The same for the layers of an array or cube texture: Texture::generateMipmaps resizes every
+ * [depth][face] image of a level on its own (lib/src/Texture.cpp:1442-1511 inside its loops over depth
+ * and faces), so the `layers` surfaces -- all width x height, `src_pixel_type`, `src_pitch_bytes` -- are
+ * independent chains.  They share one launch per pass and level (the small levels of a chain are a few
+ * microseconds each: 256 chains one after the other are launch-bound, 5 632 launches against 22).
+ *   srcs[l]                                  : level 0 of layer l on the device
+ *   dst_levels[l*(levels-1) + (k-1)]         : receives level k of layer l (RGBA32F, tightly packed)
+ * Results are bit-identical to `layers` calls of cfhip_generate_mips_device. */
+int cfhip_generate_mips_array_device(cfhip_ctx* ctx, const void* const* srcs, uint32_t layers,
+	int src_pixel_type, uint32_t width, uint32_t height, size_t src_pitch_bytes, int color_space,
+	int filter, void* const* dst_levels, uint32_t levels, void* stream);
+
 /* One Image::resize on the GPU (lib/src/Image.cpp:1324-1511) -- what Texture::generateMipmaps calls
  * per level, and per custom mip image (Texture.cpp:1499-1503, any source size): src (any of the
  * three pixel types) -> dst, dst_width x dst_height tightly packed RGBA32F, in linear space as

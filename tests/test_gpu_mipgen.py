@@ -218,3 +218,50 @@ def test_3d_bad_arguments():
             ctx.generate_mips3d_device(t.data_ptr(), PixelType.RGBA8, 4, 4, 4, 16, 64, [o.data_ptr()]*3)   # 4 levels of a 4^3
         with pytest.raises(CfhipError):
             ctx.generate_mips3d_device(t.data_ptr(), PixelType.RGBA8, 4, 4, 4, 16, 32, [o.data_ptr()])     # slice pitch < slice
+
+
+@pytest.mark.parametrize("filt,cs,shape,dtype", [
+    (0, ColorSpace.Linear, (128, 128), np.uint8), (3, ColorSpace.Linear, (37, 20), np.float32),
+    (1, ColorSpace.sRGB, (64, 96), np.uint8), (0 | O.FILTER_FALLBACK, ColorSpace.Linear, (48, 48), np.float16),
+    (4, ColorSpace.sRGB, (33, 1), np.float32)])
+def test_array_layers_in_one_call_equal_one_call_per_layer(filt, cs, shape, dtype):
+    """cfhip_generate_mips_array_device: the layers of an array texture share one launch per pass and
+    level (Texture::generateMipmaps resizes every [depth][face] image on its own); every level of every
+    layer is bit-identical to the per-layer call, on the default stream and on a stream of the caller's."""
+    h, w = shape
+    rng = np.random.default_rng(7)
+    layers = 5
+    levels = max(h, w).bit_length()
+    bases = []
+    for l in range(layers):
+        f = rng.random((h, w, 4)).astype(np.float32)*(l + 1)/layers
+        bases.append((f*255).astype(np.uint8) if dtype == np.uint8 else f.astype(dtype))
+    with Context(0) as ctx:
+        want = [_gpu_chain(ctx, b, levels, cs, filt)[0] for b in bases]
+        for use_stream in (False, True):
+            srcs = [torch.from_numpy(np.ascontiguousarray(b)).cuda() for b in bases]
+            pt = {np.uint8: PixelType.RGBA8, np.float16: PixelType.RGBA16F, np.float32: PixelType.RGBA32F}[dtype]
+            pitch = w*{np.uint8: 4, np.float16: 8, np.float32: 16}[dtype]
+            dsts = [[torch.zeros((max(1, h >> k), max(1, w >> k), 4), dtype=torch.float32, device="cuda")
+                     for k in range(1, levels)] for _ in range(layers)]
+            torch.cuda.synchronize()
+            st = torch.cuda.Stream() if use_stream else None
+            ctx.generate_mips_array_device([s.data_ptr() for s in srcs], pt, w, h, pitch,
+                                           [[d.data_ptr() for d in dl] for dl in dsts], color_space=cs, filter=filt,
+                                           stream=st.cuda_stream if st else 0)
+            torch.cuda.synchronize()
+            for l in range(layers):
+                for k in range(levels - 1):
+                    assert np.array_equal(dsts[l][k].cpu().numpy(), want[l][k]), (use_stream, l, k)
+
+
+def test_array_call_rejects_bad_arguments():
+    with Context(0) as ctx:
+        a = torch.zeros((8, 8, 4), dtype=torch.uint8, device="cuda")
+        d = torch.zeros((4, 4, 4), dtype=torch.float32, device="cuda")
+        with pytest.raises(ValueError):
+            ctx.generate_mips_array_device([a.data_ptr(), a.data_ptr()], PixelType.RGBA8, 8, 8, 32, [[d.data_ptr()]])
+        with pytest.raises(CfhipError):
+            ctx.generate_mips_array_device([a.data_ptr()], PixelType.RGBA8, 8, 8, 32, [[0]])          # NULL level
+        with pytest.raises(CfhipError):
+            ctx.generate_mips_array_device([a.data_ptr()], PixelType.RGBA8, 8, 8, 16, [[d.data_ptr()]])   # pitch < row
