@@ -36,6 +36,9 @@ extern "C" hipError_t cfhip_launch_mip_pass_layers(const void* src, int src_pixe
 	uint32_t src_n, void* dst, uint32_t dst_w, uint32_t dst_h, int along_x, int filter, int to_linear,
 	int to_srgb, uint32_t layers, const void* const* src_tab, void* const* dst_tab, size_t src_zstride,
 	size_t dst_zstride, hipStream_t stream);
+extern "C" hipError_t cfhip_launch_mip_fused_layers(const void* src, int src_pixel_type, size_t pitch, uint32_t sw,
+	uint32_t sh, void* dst, uint32_t dw, uint32_t dh, int x_first, int filter, int srgb, uint32_t layers,
+	const void* const* src_tab, void* const* dst_tab, size_t src_zstride, size_t dst_zstride, hipStream_t stream);
 extern "C" hipError_t cfhip_launch_mip_pass(const void* src, int src_pixel_type, size_t pitch,
 	uint32_t src_n, void* dst, uint32_t dst_w, uint32_t dst_h, int along_x, int filter, int to_linear,
 	int to_srgb, hipStream_t stream);
@@ -1125,7 +1128,11 @@ static int mip_level_2d(cfhip_ctx* ctx, const void* prev, int prev_type, size_t 
 			// not change is skipped (the other one then does both colour conversions)
 			const bool x_first = (unsigned long long)w*ph <= (unsigned long long)h*pw;
 			const bool need_x = w != pw, need_y = h != ph;
-			if (need_x && need_y) {
+			if (need_x && need_y && filter == CFHIP_FILTER_BOX) {
+				// the box filter: both passes in one launch, no float image in between (bit-identical)
+				HIP_TRY(ctx, cfhip_launch_mip_fused_layers(prev, prev_type, prev_pitch, pw, ph, dst_levels[k - 1], w, h,
+					x_first ? 1 : 0, filter, srgb, 1u, nullptr, nullptr, 0, 0, stream));
+			} else if (need_x && need_y) {
 				const uint32_t tw = x_first ? w : pw, th = x_first ? ph : h;
 				int rc = staging_acquire(ctx, stream);
 				if (rc != CFHIP_OK) return rc;
@@ -1278,8 +1285,14 @@ int cfhip_generate_mips_array_device(cfhip_ctx* ctx, const void* const* srcs, ui
 			const bool need_x = w != pw, need_y = h != ph;
 			const uint32_t tw = x_first ? w : pw, th = x_first ? ph : h;
 			const size_t timg = (size_t)tw*th*16u;
-			const bool batched = !(filter & CFHIP_FILTER_FALLBACK) && (!(need_x && need_y) || timg*layers <= kStagingBudget);
-			if (!batched) {
+			const bool fused = filter == CFHIP_FILTER_BOX && need_x && need_y;
+			const bool batched = !(filter & CFHIP_FILTER_FALLBACK) && (fused || !(need_x && need_y) || timg*layers <= kStagingBudget);
+			if (fused) {
+				const hipError_t e = cfhip_launch_mip_fused_layers(nullptr, prev_type, prev_pitch, pw, ph, nullptr, w, h,
+					x_first ? 1 : 0, filter, srgb, layers, s_tab, o_tab, 0, 0, stream);
+				if (e != hipSuccess)
+					return staging_abort(ctx, stream, used_staging, fail(ctx, CFHIP_E_DEVICE, "mip pass: %s", hipGetErrorString(e)));
+			} else if (!batched) {
 				for (uint32_t l = 0; l < layers; ++l) {
 					const int rc2 = mip_level_2d(ctx, tab[(size_t)(k - 1u)*layers + l], prev_type, prev_pitch, pw, ph,
 						const_cast<void*>(tab[(size_t)k*layers + l]), w, h, filter, srgb, stream, &used_staging);

@@ -251,6 +251,104 @@ cfhip_mip_pass_kernel(const uint8_t* src_base, size_t pitch, uint32_t src_n, flo
 	dst[(size_t)y*dst_w + x] = o;
 }
 
+// ---- both passes in one kernel (Box) ------------------------------------------------------------
+// The two-pass route writes a float image between the passes: for a 2:1 level of an RGBA8 source that
+// is 24 bytes of traffic per source texel against 8 when the first pass's values are formed where the
+// second pass needs them.  Same arithmetic, same order, same float rounding of the intermediate value
+// (the taps of the first axis are re-evaluated per output: for the box filter at 2:1 that is 2 x 2
+// source reads, nothing more than the separable passes read) -- bit-identical to the two launches.
+struct AxisTaps { int left, right; double total, fscale, center; };
+
+__device__ __forceinline__ AxisTaps axis_taps(uint32_t u, uint32_t src_n, uint32_t dst_n, int filter)
+{
+	AxisTaps t;
+	const double scale = (double)dst_n/(double)src_n;
+	const double fwidth = filter == 0 ? 0.5 : (filter == 1 ? 1.0 : 2.0);     // CGenericFilter::GetWidth
+	double width = fwidth;
+	t.fscale = 1.0;
+	if (scale < 1.0) {
+		width = fwidth/scale;
+		t.fscale = scale;
+	}
+	t.center = (double)u/scale + 0.5/scale;
+	t.left = (int)(t.center - width + 0.5);
+	t.left = t.left < 0 ? 0 : t.left;
+	t.right = (int)(t.center + width + 0.5);
+	t.right = t.right > (int)src_n ? (int)src_n : t.right;
+	t.total = 0.0;
+	for (int i = t.left; i < t.right; ++i)
+		t.total += t.fscale*fi_filter(filter, t.fscale*((double)i + 0.5 - t.center));
+	return t;
+}
+
+__device__ __forceinline__ double axis_weight(const AxisTaps& t, int i, int filter)
+{
+	double w = t.fscale*fi_filter(filter, t.fscale*((double)i + 0.5 - t.center));
+	if (t.total > 0.0 && t.total != 1.0)
+		w /= t.total;
+	return w;
+}
+
+template <int SRC_PIX, bool X_FIRST>
+__global__ void __launch_bounds__(256)
+cfhip_mip_fused_kernel(const uint8_t* src_base, size_t pitch, uint32_t sw, uint32_t sh, float4* dst_base,
+	uint32_t dw, uint32_t dh, int filter, int srgb, MipLayers L)
+{
+	const uint8_t* __restrict__ src = L.src_tab ? static_cast<const uint8_t*>(L.src_tab[blockIdx.z])
+		: src_base + (size_t)blockIdx.z*L.src_zstride;
+	float4* __restrict__ dst = L.dst_tab ? static_cast<float4*>(L.dst_tab[blockIdx.z])
+		: reinterpret_cast<float4*>(reinterpret_cast<uint8_t*>(dst_base) + (size_t)blockIdx.z*L.dst_zstride);
+	__shared__ float lin_of_u8[SRC_PIX == 0 ? 256 : 1];   // see cfhip_mip_resize_kernel
+	if (SRC_PIX == 0 && srgb) {
+		lin_of_u8[threadIdx.x] = (float)srgb_to_linear((double)(float)((double)threadIdx.x/255.0));
+		__syncthreads();
+	}
+	const uint32_t x = blockIdx.x*64u + (threadIdx.x & 63u);
+	const uint32_t y = blockIdx.y*4u + (threadIdx.x >> 6);
+	if (x >= dw || y >= dh)
+		return;
+	const AxisTaps tx = axis_taps(x, sw, dw, filter), ty = axis_taps(y, sh, dh, filter);
+	auto texel = [&](int sx, int sy) -> float4 {
+		float4 p;
+		const uint8_t* rowp = src + (size_t)sy*pitch;
+		if (SRC_PIX == 0 && srgb) {
+			const uint32_t v = *reinterpret_cast<const uint32_t*>(rowp + (size_t)sx*4u);
+			p = make_float4(lin_of_u8[v & 255u], lin_of_u8[(v >> 8) & 255u], lin_of_u8[(v >> 16) & 255u],
+				(float)((double)(v >> 24)/255.0));
+		} else {
+			p = load_rgbaf<SRC_PIX>(rowp, (uint32_t)sx);
+			if (srgb) {
+				p.x = (float)srgb_to_linear((double)p.x);
+				p.y = (float)srgb_to_linear((double)p.y);
+				p.z = (float)srgb_to_linear((double)p.z);
+			}
+		}
+		return p;
+	};
+	double o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+	// outer = the SECOND pass's axis, inner = the first pass's: the inner sum is the float the first pass stored
+	const AxisTaps& t2 = X_FIRST ? ty : tx;
+	const AxisTaps& t1 = X_FIRST ? tx : ty;
+	for (int a = t2.left; a < t2.right; ++a) {
+		double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+		for (int b = t1.left; b < t1.right; ++b) {
+			const double w = axis_weight(t1, b, filter);
+			const float4 p = X_FIRST ? texel(b, a) : texel(a, b);
+			c0 += w*(double)p.x; c1 += w*(double)p.y; c2 += w*(double)p.z; c3 += w*(double)p.w;
+		}
+		const float4 mid = make_float4((float)c0, (float)c1, (float)c2, (float)c3);
+		const double w2 = axis_weight(t2, a, filter);
+		o0 += w2*(double)mid.x; o1 += w2*(double)mid.y; o2 += w2*(double)mid.z; o3 += w2*(double)mid.w;
+	}
+	float4 o = make_float4((float)o0, (float)o1, (float)o2, (float)o3);
+	if (srgb) {
+		o.x = (float)linear_to_srgb((double)o.x);
+		o.y = (float)linear_to_srgb((double)o.y);
+		o.z = (float)linear_to_srgb((double)o.z);
+	}
+	dst[(size_t)y*dw + x] = o;
+}
+
 // generateMips3d (lib/src/Texture.cpp:103-227): the depth pass of one mip level of a 3-D texture.
 // One thread per output texel; prev = n_prev tightly packed RGBA32F slices of w x h (the previous
 // level's slices resized in x and y), out = depth slices.  Twin of cfo_mip_depth_pass.
@@ -339,6 +437,26 @@ extern "C" hipError_t cfhip_launch_mip_pass(const void* src, int src_pixel_type,
 {
 	return cfhip_launch_mip_pass_layers(src, src_pixel_type, pitch, src_n, dst, dst_w, dst_h, along_x, filter,
 		to_linear, to_srgb, 1u, nullptr, nullptr, 0, 0, stream);
+}
+
+// both passes of one level in one launch (the box filter): x_first as FreeImage_Rescale orders them
+extern "C" hipError_t cfhip_launch_mip_fused_layers(const void* src, int src_pixel_type, size_t pitch, uint32_t sw,
+	uint32_t sh, void* dst, uint32_t dw, uint32_t dh, int x_first, int filter, int srgb, uint32_t layers,
+	const void* const* src_tab, void* const* dst_tab, size_t src_zstride, size_t dst_zstride, hipStream_t stream)
+{
+	const dim3 grid((dw + 63u)/64u, (dh + 3u)/4u, layers), block(256, 1, 1);
+	const uint8_t* s = static_cast<const uint8_t*>(src);
+	float4* d = static_cast<float4*>(dst);
+	const MipLayers L = {src_tab, dst_tab, src_zstride, dst_zstride};
+#define CF_FUSED(P, XF) hipLaunchKernelGGL((cfhip_mip_fused_kernel<P, XF>), grid, block, 0, stream, s, pitch, sw, sh, \
+	d, dw, dh, filter, srgb, L)
+	if (x_first) {
+		if (src_pixel_type == 0) CF_FUSED(0, true); else if (src_pixel_type == 1) CF_FUSED(1, true); else CF_FUSED(2, true);
+	} else {
+		if (src_pixel_type == 0) CF_FUSED(0, false); else if (src_pixel_type == 1) CF_FUSED(1, false); else CF_FUSED(2, false);
+	}
+#undef CF_FUSED
+	return hipGetLastError();
 }
 
 // one level: src (any pixel type) -> dst (RGBA32F, tightly packed)
