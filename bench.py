@@ -232,6 +232,84 @@ def gpu_texture(torch, size, seed, device):
     return (f * 255.0 + grain).round().clamp(0, 255).to(torch.uint8).contiguous()
 
 
+C5_ALGO_BYTES_FULL = 7158285312      # 256 x (5 592 405 px x 4 B read + 349 527 blocks x 16 B written)
+
+
+def c5_geometry(n):
+    """Level sizes, payload bytes per level and block count of ONE n x n texture with its full chain
+    (Texture::generateMipmaps down to 1 x 1, lib/src/Texture.cpp:1320-1514)."""
+    from cuttlefish_amd import Format, Type, payload_size, shard
+    levels = n.bit_length()
+    dims = [max(1, n >> k) for k in range(levels)]
+    nbytes = [payload_size(Format.BC7, Type.UNorm, d, d) for d in dims]
+    return {"levels": levels, "dims": dims, "nbytes": nbytes, "chain_bytes": sum(nbytes),
+            "px_chain": sum(d * d for d in dims), "blocks_chain": sum(shard.block_count(d, d) for d in dims)}
+
+
+def c5_surfaces(geo, base_list, chain_list, out_buf):
+    """The [texture][mip] surfaces of Converter::convert's loop (Converter.cpp:521-527) as one
+    cfhip_encode_device call: texture i's payload at i * chain_bytes, its levels in mip order."""
+    from cuttlefish_amd import PixelType
+    dims, nbytes, chain_bytes = geo["dims"], geo["nbytes"], geo["chain_bytes"]
+    s = []
+    for i in range(len(base_list)):
+        off = i * chain_bytes
+        for k, d in enumerate(dims):
+            src = base_list[i] if k == 0 else chain_list[i][k - 1]
+            s.append({"pixels": src.data_ptr(), "pixel_type": PixelType.RGBA8 if k == 0 else PixelType.RGBA32F,
+                      "width": d, "height": d, "row_pitch_bytes": d * (4 if k == 0 else 16),
+                      "out": out_buf.data_ptr() + off, "out_capacity": nbytes[k]})
+            off += nbytes[k]
+    s.sort(key=lambda e: int(e["pixel_type"]))            # one batched launch per source type
+    return s
+
+
+def c5_cpu_texture(base_np, geo, quality, threads):
+    """ONE texture of C5 on the CPU oracle (test infrastructure): Texture::generateMipmaps (Box, linear
+    space) then the BC7 encode of every level -> (payload bytes of the chain, seconds in the mip
+    generation, seconds in the encode)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as O
+    from cuttlefish_amd import Format
+    t0 = time.perf_counter()
+    chain = O.mip_chain(base_np, geo["levels"], filter=0, color_space=0)
+    t1 = time.perf_counter()
+    parts = [O.encode(base_np, int(Format.BC7), quality=quality, threads=threads)]
+    for lvl in chain[1:]:
+        parts.append(O.encode(lvl, int(Format.BC7), quality=quality, threads=threads))
+    t2 = time.perf_counter()
+    return np.concatenate(parts), t1 - t0, t2 - t1
+
+
+def c5_cpu_baseline(torch, bases, mine, out, geo, quality, budget_s=12.0):
+    """cpu_baseline of the C5 line: whole textures of the same batch through the CPU oracle (mip chain
+    + encode of all 12 levels, the job model of Converter.cpp:521-589 with `cores` threads) until
+    `budget_s` of wall time is spent, each compared byte for byte with the GPU payload of that texture."""
+    import numpy as np
+    cores = usable_cpus()
+    done, t_mip, t_enc, equal = [], 0.0, 0.0, True
+    cb = geo["chain_bytes"]
+    t_start = time.perf_counter()
+    for pos, t in enumerate(mine):
+        ref, a, b = c5_cpu_texture(bases[pos].cpu().numpy(), geo, quality, cores)
+        t_mip += a
+        t_enc += b
+        got = out[pos * cb:(pos + 1) * cb].cpu().numpy()
+        equal = equal and bool(np.array_equal(ref, got))
+        done.append(t)
+        if time.perf_counter() - t_start > budget_s:
+            break
+    mpix = len(done) * geo["px_chain"] / 1e6
+    return {"value": round(mpix / (t_mip + t_enc), 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "encode_only_value": round(mpix / t_enc, 4),
+            "sample": "textures %s of the same batch, whole chains (%d levels, %.2f Mpixel each): mip generation "
+                      "%.1f s on 1 thread + BC7 encode %.1f s on %d threads" %
+                      (done, geo["levels"], geo["px_chain"] / 1e6, t_mip, t_enc, cores),
+            "host_threads_visible": os.cpu_count(),
+            "gpu_payload_equals_cpu": equal, "bytes_compared": len(done) * cb}
+
+
 def run_c5(args, rank, local_rank, world, backend):
     import numpy as np
     import torch
@@ -240,12 +318,9 @@ def run_c5(args, rank, local_rank, world, backend):
 
     dev = torch.device("cuda", local_rank)
     n, T = args.tex_size, args.textures
-    levels = n.bit_length()
-    dims = [max(1, n >> k) for k in range(levels)]
-    px_chain = sum(d * d for d in dims)
-    nbytes = [payload_size(Format.BC7, Type.UNorm, d, d) for d in dims]
-    chain_bytes = sum(nbytes)
-    blocks_chain = sum(shard.block_count(d, d) for d in dims)
+    geo = c5_geometry(n)
+    levels, dims, nbytes = geo["levels"], geo["dims"], geo["nbytes"]
+    px_chain, chain_bytes, blocks_chain = geo["px_chain"], geo["chain_bytes"], geo["blocks_chain"]
     plan = shard.assign_surfaces([blocks_chain] * T, world)      # units = textures (a chain stays on its rank)
     mine = plan[rank]
     ctx = Context(local_rank)
@@ -264,17 +339,7 @@ def run_c5(args, rank, local_rank, world, backend):
     out = torch.empty(len(mine) * chain_bytes, dtype=torch.uint8, device=dev)
 
     def surfaces(base_list, chain_list, out_buf):
-        s = []
-        for i in range(len(base_list)):
-            off = i * chain_bytes
-            for k, d in enumerate(dims):
-                src = base_list[i] if k == 0 else chain_list[i][k - 1]
-                s.append({"pixels": src.data_ptr(), "pixel_type": PixelType.RGBA8 if k == 0 else PixelType.RGBA32F,
-                          "width": d, "height": d, "row_pitch_bytes": d * (4 if k == 0 else 16),
-                          "out": out_buf.data_ptr() + off, "out_capacity": nbytes[k]})
-                off += nbytes[k]
-        s.sort(key=lambda e: int(e["pixel_type"]))            # one batched launch per source type
-        return s
+        return c5_surfaces(geo, base_list, chain_list, out_buf)
     surf = surfaces(bases, chains, out)
     base_ptrs = [b.data_ptr() for b in bases]
     chain_ptrs = [[c.data_ptr() for c in ch] for ch in chains]
@@ -364,8 +429,24 @@ def run_c5(args, rank, local_rank, world, backend):
                           "gather_bytes": sizes[r]} for r in range(world)],
             "kernel_ms_rank0": round(kernel_ms / max(args.steps, 1), 3),
             "sharded_equals_local": check,
-            "roofline": None, "cpu_baseline": None,
         }
+        # the dominant kernel is the BC7 block encoder: two batched launches per step (the RGBA8 level-0
+        # surfaces, the RGBA32F mip surfaces); its hipEvent time on the launch stream, rank 0's share
+        step_kernel_s = kernel_ms / 1e3 / max(args.steps, 1)
+        algo = len(mine) * (px_chain * 4 + chain_bytes)      # 4 B/px read + payload written
+        achieved = algo / step_kernel_s / 1e9 if step_kernel_s > 0 else 0.0
+        line["roofline"] = {
+            "bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 8), "traffic": None, "kernel": ctx.last_kernel_name(),
+            "kernel_ms_per_step": round(step_kernel_s * 1e3, 4), "launches_per_step": launches // max(args.steps, 1),
+            "algorithmic_bytes_per_step": int(algo),
+            "algorithmic_bytes_full_config": C5_ALGO_BYTES_FULL,
+            "note": "rank 0's share; algorithmic bytes = 4 B/px source read + 1 B/px payload write over every "
+                    "level (SURVEY 8d); the mip levels really travel as RGBA32F (16 B/px, the reference's RGBAF), "
+                    "so the bytes the launches move are higher; VALU-issue-bound search (DESIGN.md section 4.1)"}
+        line["cpu_baseline"] = None
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = c5_cpu_baseline(torch, bases, mine, out, geo, args.quality)
         print(json.dumps(line), flush=True)
     ctx.close()
 

@@ -48,6 +48,10 @@ typedef struct {
 	sfit sca;        /* scalar (rotated alpha) fit for modes 4/5 */
 } cand;
 
+/* how hard one fit works: least-squares rounds, and the half-width of the quantised neighbourhood the
+ * refit searches around the closed-form solution (0 = round each end on its own, refit_quantized) */
+typedef struct { int iters; int qwin; } fitopt;
+
 static const uint8_t* weight_table(int ib)
 {
 	return ib == 2 ? cfo_w2 : ib == 3 ? cfo_w3 : cfo_w4;
@@ -242,9 +246,122 @@ static int lsq(const int px[16][4], unsigned mask, const int bits[4], const sfit
 	return 1;
 }
 
+/* Least squares WITH the quantisation inside (qwin > 0).  With the selectors fixed the error of a
+ * channel is a quadratic in its two endpoints whose minimiser x* is the closed-form solution of lsq();
+ * around it  E(e0, e1) - E(x*) = A d0^2 + 2 B d0 d1 + C d1^2  (d = e - x*, up to the 1/4096 scale and the
+ * interpolation rounding).  Rounding each end of x* on its own ignores the cross term B; this routine
+ * takes, per channel and per p-bit choice, the pair of quantised values within +-qwin steps of the
+ * rounded x* that minimises the form, and the p-bit choice with the smallest weighted sum over the
+ * channels.  Same sums as lsq(); float arithmetic in one fixed order. */
+static int refit_quantized(const int px[16][4], unsigned mask, const int bits[4], int pbk,
+	const int wt[CFO_BC7_NW], const sfit* f, int qwin, sfit* out)
+{
+	int n = 0, S = 0, A = 0, B = 0, C = 0;
+	int U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
+	for (int i = 0; i < 16; ++i) {
+		if (!((mask >> i) & 1))
+			continue;
+		int w = f->w[i], iw = 64 - w;
+		++n;
+		S += w;
+		A += iw*iw;
+		B += iw*w;
+		C += w*w;
+		for (int c = 0; c < 4; ++c) {
+			U[c] += iw*px[i][c];
+			V[c] += w*px[i][c];
+		}
+	}
+	int det = n*C - S*S;
+	if (det <= 0)
+		return 0;
+	float inv = 1.0f/(64.0f*(float)det);
+	float fA = (float)A, fB = (float)B, fC = (float)C;
+	float fB2 = fB + fB;
+	const int ncombo = pbk == 1 ? 4 : (pbk == 2 ? 2 : 1);
+	float total[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+	int bq[4][4][2];   /* [combo][channel][endpoint] */
+	for (int c = 0; c < 4; ++c) {
+		if (!bits[c])
+			continue;
+		float fU = (float)U[c], fV = (float)V[c];
+		float t0 = fB*fV;
+		float x0 = fmaf(fC, fU, -t0)*inv;      /* unclamped: the form is centred here */
+		float t1 = fB*fU;
+		float x1 = fmaf(fA, fV, -t1)*inv;
+		float xs[2] = {x0, x1};
+		for (int k = 0; k < ncombo; ++k) {
+			int pe[2];
+			pe[0] = pbk == 1 ? (k & 1) : (pbk == 2 ? k : 0);
+			pe[1] = pbk == 1 ? (k >> 1) : (pbk == 2 ? k : 0);
+			/* candidate quantised values and their deviations, per endpoint */
+			int cq[2][5], ncand[2];
+			float cd[2][5];
+			for (int e = 0; e < 2; ++e) {
+				int t = bits[c] + (pbk ? 1 : 0);
+				float sc = (float)((1 << t) - 1)/255.0f;
+				float y = clamp255(xs[e])*sc;
+				float u = pbk ? (y - (float)pe[e])*0.5f : y;
+				int qc = (int)floorf(u + 0.5f);
+				int qmax = (1 << bits[c]) - 1;
+				qc = qc < 0 ? 0 : (qc > qmax ? qmax : qc);
+				ncand[e] = 0;
+				for (int d = -qwin; d <= qwin; ++d) {
+					int q = qc + d;
+					if (q < 0 || q > qmax)
+						continue;
+					int dd = pbk ? dequant((q << 1) | pe[e], t) : dequant(q, t);
+					cq[e][ncand[e]] = q;
+					cd[e][ncand[e]] = (float)dd - xs[e];
+					++ncand[e];
+				}
+			}
+			float best = 3.0e38f;
+			int b0 = cq[0][0], b1 = cq[1][0];
+			for (int i = 0; i < ncand[0]; ++i) {
+				float d0 = cd[0][i];
+				float a0 = fA*d0;
+				a0 = a0*d0;
+				float cr = fB2*d0;
+				for (int j = 0; j < ncand[1]; ++j) {
+					float d1 = cd[1][j];
+					float v = fC*d1;
+					v = fmaf(v, d1, a0);
+					v = fmaf(cr, d1, v);
+					if (v < best) {
+						best = v;
+						b0 = cq[0][i];
+						b1 = cq[1][j];
+					}
+				}
+			}
+			total[k] = fmaf((float)wt[c], best, total[k]);
+			bq[k][c][0] = b0;
+			bq[k][c][1] = b1;
+		}
+	}
+	int kb = 0;
+	for (int k = 1; k < ncombo; ++k)
+		if (total[k] < total[kb])
+			kb = k;
+	out->pb[0] = pbk == 1 ? (kb & 1) : (pbk == 2 ? kb : 0);
+	out->pb[1] = pbk == 1 ? (kb >> 1) : (pbk == 2 ? kb : 0);
+	for (int e = 0; e < 2; ++e)
+		for (int c = 0; c < 4; ++c) {
+			if (!bits[c]) {
+				out->q[e][c] = out->e[e][c] = 0;
+				continue;
+			}
+			int q = bq[kb][c][e];
+			out->q[e][c] = q;
+			out->e[e][c] = pbk ? dequant((q << 1) | out->pb[e], bits[c] + 1) : dequant(q, bits[c]);
+		}
+	return 1;
+}
+
 /* Vector fit of the pixels selected by mask over the channels with bits[c] > 0. */
 static void fit_subset(const int px[16][4], const int wt[CFO_BC7_NW], unsigned mask, const int bits[4],
-	int pbk, int ib, int iters, sfit* best)
+	int pbk, int ib, const fitopt* fo, sfit* best)
 {
 	/* A: integer statistics */
 	int n = 0, sum[4] = {0, 0, 0, 0}, sq[4][4];
@@ -325,11 +442,16 @@ static void fit_subset(const int px[16][4], const int wt[CFO_BC7_NW], unsigned m
 	/* C/D: quantise + assign; E: LSQ rounds, always restarting from the best */
 	quantize_endpoints(x, bits, pbk, wt, best);
 	assign(px, wt, mask, bits, ib, best);
-	for (int r = 0; r < iters; ++r) {
+	for (int r = 0; r < fo->iters; ++r) {
 		sfit cur;
-		if (!lsq(px, mask, bits, best, x))
-			break;
-		quantize_endpoints(x, bits, pbk, wt, &cur);
+		if (fo->qwin) {
+			if (!refit_quantized(px, mask, bits, pbk, wt, best, fo->qwin, &cur))
+				break;
+		} else {
+			if (!lsq(px, mask, bits, best, x))
+				break;
+			quantize_endpoints(x, bits, pbk, wt, &cur);
+		}
 		assign(px, wt, mask, bits, ib, &cur);
 		if (cur.err < best->err)
 			*best = cur;
@@ -339,7 +461,7 @@ static void fit_subset(const int px[16][4], const int wt[CFO_BC7_NW], unsigned m
 }
 
 /* Scalar fit of channel 3 of px over all 16 pixels (modes 4/5 alpha plane). */
-static void fit_scalar(const int px[16][4], const int wt[CFO_BC7_NW], int abits, int ib, int iters,
+static void fit_scalar(const int px[16][4], const int wt[CFO_BC7_NW], int abits, int ib, const fitopt* fo,
 	sfit* best)
 {
 	const int bits[4] = {0, 0, 0, abits};
@@ -351,11 +473,16 @@ static void fit_scalar(const int px[16][4], const int wt[CFO_BC7_NW], int abits,
 	float x[2][4] = {{0, 0, 0, (float)lo}, {0, 0, 0, (float)hi}};
 	quantize_endpoints(x, bits, 0, wt, best);
 	assign(px, wt, 0xFFFF, bits, ib, best);
-	for (int r = 0; r < iters; ++r) {
+	for (int r = 0; r < fo->iters; ++r) {
 		sfit cur;
-		if (!lsq(px, 0xFFFF, bits, best, x))
-			break;
-		quantize_endpoints(x, bits, 0, wt, &cur);
+		if (fo->qwin) {
+			if (!refit_quantized(px, 0xFFFF, bits, 0, wt, best, fo->qwin, &cur))
+				break;
+		} else {
+			if (!lsq(px, 0xFFFF, bits, best, x))
+				break;
+			quantize_endpoints(x, bits, 0, wt, &cur);
+		}
 		assign(px, wt, 0xFFFF, bits, ib, &cur);
 		if (cur.err < best->err)
 			*best = cur;
@@ -455,7 +582,7 @@ static float partition_score(const int px[16][4], int ns, int part, const int bi
 	return sc;
 }
 
-static void eval_candidate(const int px[16][4], const int wt[CFO_BC7_NW], int id, int iters, cand* c)
+static void eval_candidate(const int px[16][4], const int wt[CFO_BC7_NW], int id, const fitopt* fo, cand* c)
 {
 	memset(c, 0, sizeof(*c));
 	c->id = id;
@@ -464,7 +591,7 @@ static void eval_candidate(const int px[16][4], const int wt[CFO_BC7_NW], int id
 			const int bits[4] = {7, 7, 7, 7};
 			c->mode = 6;
 			c->ns = 1;
-			fit_subset(px, wt, 0xFFFF, bits, 1, 4, iters, &c->vec[0]);
+			fit_subset(px, wt, 0xFFFF, bits, 1, 4, fo, &c->vec[0]);
 			c->err = c->vec[0].err;
 			return;
 		}
@@ -498,8 +625,8 @@ static void eval_candidate(const int px[16][4], const int wt[CFO_BC7_NW], int id
 			rw[rot - 1] = t;
 		}
 		const int bits[4] = {cb, cb, cb, 0};
-		fit_subset(rp, rw, 0xFFFF, bits, 0, ibc, iters, &c->vec[0]);
-		fit_scalar(rp, rw, ab, iba, iters, &c->sca);
+		fit_subset(rp, rw, 0xFFFF, bits, 0, ibc, fo, &c->vec[0]);
+		fit_scalar(rp, rw, ab, iba, fo, &c->sca);
 		c->err = c->vec[0].err + c->sca.err;
 		return;
 	}
@@ -525,7 +652,7 @@ static void eval_candidate(const int px[16][4], const int wt[CFO_BC7_NW], int id
 	}
 	c->err = 0;
 	for (int s = 0; s < m->ns; ++s) {
-		fit_subset(px, wt, masks[s], bits, m->pbits, m->ib, iters, &c->vec[s]);
+		fit_subset(px, wt, masks[s], bits, m->pbits, m->ib, fo, &c->vec[s]);
 		c->err += c->vec[s].err;
 	}
 }
@@ -729,27 +856,38 @@ static void pack(const cand* c, uint8_t out[16])
 /* Search budget per Texture::Quality (S3tcConverter.cpp:170-227 / :600-620).  uber = rounds of
  * endpoint perturbation of the winner (bc7enc's m_uber_level is 0 up to Normal and 4 from High,
  * :200-215). */
-typedef struct { int iters; int m6only; int two; int mode3; int three; int rot; int uber; } budget;
+typedef struct {
+	int iters;      /* least-squares refit rounds per fit */
+	int qwin;       /* refit_quantized neighbourhood half-width (0: plain rounding) */
+	int m6only, two, mode3, three, rot;
+	int uber;       /* rounds of endpoint perturbation */
+	int uber_top;   /* how many of the best candidates are perturbed (1: the winner only) */
+	int n1, n3, n7, n7low; /* partitions refitted per two-subset mode: opaque modes 1 / 3, alpha mode 7; one-mode (Low) count */
+	int n0, n2;     /* three-subset modes (only with `three`) */
+} budget;
 
 static budget quality_budget(int quality)
 {
 	budget b;
+	memset(&b, 0, sizeof(b));
+	b.uber_top = 1;
+	b.n1 = 6; b.n3 = 5; b.n7 = 11; b.n7low = 14; b.n0 = 5; b.n2 = 5;
 	switch (quality) {
 		/* refit rounds: the second round is worth ~0.004 dB on photographic content, so it is
 		 * only spent from High up */
-		case 0: b = (budget){0, 1, 0, 0, 0, 0, 0}; break;
-		case 1: b = (budget){0, 0, 1, 1, 0, 1, 0}; break;   /* Low: Normal's candidate set without the refit round */
-		case 2: b = (budget){1, 0, 1, 1, 0, 1, 0}; break;
+		case 0: b.m6only = 1; break;
+		case 1: b.two = b.mode3 = b.rot = 1; break;   /* Low: Normal's candidate set without the refit round */
+		case 2: b.iters = 1; b.two = b.mode3 = b.rot = 1; break;
 		/* High: Normal's candidate set (half a wavefront per block), then two perturbation rounds
 		 * on the winner: +0.24 dB over Normal on the bench content, where the wider mode set High
 		 * used to walk bought +0.03 dB for four times the work (a second refit round before the
 		 * perturbation is worth 0.000 dB: the perturbation finds what it would have found) */
-		case 3: b = (budget){1, 0, 1, 1, 0, 1, 2}; break;
+		case 3: b.iters = 1; b.two = b.mode3 = b.rot = 1; b.uber = 2; break;
 		/* Highest: the wide set (mode 4, 16 two-subset partitions, the three-subset modes), two
 		 * refit rounds, three perturbation rounds (a third refit round or a fourth perturbation
 		 * round moves PSNR by 0.001 dB).  Refitting EVERY partition (what this level did before)
 		 * was worth 0.015 dB over this and cost five times the time. */
-		default: b = (budget){2, 0, 1, 1, 1, 1, 3}; break;
+		default: b.iters = 2; b.two = b.mode3 = b.three = b.rot = 1; b.uber = 3; b.n1 = b.n3 = 8; b.n7 = 16; break;
 	}
 	return b;
 }
@@ -771,8 +909,12 @@ void cfo_bc7_weights(const cfo_params* p, int wt[CFO_BC7_NW])
 	wt[4] = perceptual;
 }
 
-void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p)
+#define CFO_BC7_MAXTOP 8
+
+static void encode_block(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p, const budget* bp)
 {
+	const budget b = *bp;
+	const fitopt fo = {b.iters, b.qwin};
 	int px[16][4], wt[CFO_BC7_NW];
 	cfo_bc7_weights(p, wt);
 	int has_alpha = 0;
@@ -787,16 +929,23 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 		if (!wt[c])
 			wt[c] = 1;
 
-	budget b = quality_budget(p->quality);
-	cand best, cur;
-	memset(&best, 0, sizeof(best));
-	best.err = 0xFFFFFFFFu;
-	best.id = 0x7FFFFFFF;
+	/* the best `ntop` candidates in (error, id) order; top[0] is the winner */
+	const int ntop = b.uber && b.uber_top > 1 ? (b.uber_top > CFO_BC7_MAXTOP ? CFO_BC7_MAXTOP : b.uber_top) : 1;
+	cand top[CFO_BC7_MAXTOP], cur;
+	int nheld = 0;
 	/* winner = min (error, id): evaluation order must not matter (phase 2 below visits
 	 * partitions in rank order, the kernel visits them lane-parallel) */
 #define BETTER(c, b) ((c).err < (b).err || ((c).err == (b).err && (c).id < (b).id))
-#define TRY(ID) do { eval_candidate(px, wt, (ID), b.iters, &cur); \
-	if (BETTER(cur, best)) best = cur; } while (0)
+#define TRY(ID) do { eval_candidate(px, wt, (ID), &fo, &cur); \
+	int pos_ = nheld; \
+	while (pos_ > 0 && BETTER(cur, top[pos_ - 1])) --pos_; \
+	if (pos_ < ntop) { \
+		int last_ = nheld < ntop ? nheld : ntop - 1; \
+		for (int k_ = last_; k_ > pos_; --k_) top[k_] = top[k_ - 1]; \
+		top[pos_] = cur; \
+		if (nheld < ntop) ++nheld; \
+	} } while (0)
+#define BEST_ERR (nheld ? top[0].err : 0xFFFFFFFFu)
 	TRY(0);
 	if (b.m6only) {
 		if (has_alpha)
@@ -832,7 +981,7 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 			/* the three-subset modes are only tried on blocks the candidates so far leave with an
 			 * error of at least 48 (0.75 per channel-texel): three colour regions in a block that
 			 * already codes this well are rare, and the stream costs a third of Highest's time */
-			for (int g = 0; g < ngroups && best.err != 0 && (g == 0 || best.err >= 48u); ++g) {
+			for (int g = 0; g < ngroups && BEST_ERR != 0 && (g == 0 || BEST_ERR >= 48u); ++g) {
 				uint32_t key0[64];
 				for (int k = 0; k < 64; ++k) {
 					float sc = partition_score(px, 2 + g, k, bits);
@@ -842,15 +991,15 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 				}
 				int bases[2], counts[2], pers[2] = {0, 0}, nm = 0;
 				if (g == 1) {
-					bases[nm] = 192; counts[nm] = 16; pers[nm++] = 5;
-					bases[nm] = 256; counts[nm] = 64; pers[nm++] = 5;
+					bases[nm] = 192; counts[nm] = 16; pers[nm++] = b.n0;
+					bases[nm] = 256; counts[nm] = 64; pers[nm++] = b.n2;
 				} else if (has_alpha) {
-					bases[nm] = 320; counts[nm] = 64; pers[nm++] = b.three ? 16 : (b.mode3 ? 11 : 14);
+					bases[nm] = 320; counts[nm] = 64; pers[nm++] = b.mode3 ? b.n7 : b.n7low;
 				} else if (!b.mode3) {
-					bases[nm] = 64; counts[nm] = 64; pers[nm++] = 14;
+					bases[nm] = 64; counts[nm] = 64; pers[nm++] = b.n7low;
 				} else {
-					bases[nm] = 64; counts[nm] = 64; pers[nm++] = b.three ? 8 : 6;
-					bases[nm] = 128; counts[nm] = 64; pers[nm++] = b.three ? 8 : 5;
+					bases[nm] = 64; counts[nm] = 64; pers[nm++] = b.n1;
+					bases[nm] = 128; counts[nm] = 64; pers[nm++] = b.n3;
 				}
 				for (int mi = 0; mi < nm; ++mi) {
 					uint32_t key[64];
@@ -870,10 +1019,36 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 		}
 	}
 #undef TRY
+	int win = 0;
+	if (b.uber) {
+		for (int k = 0; k < nheld; ++k) {
+			uber_refine(px, wt, &top[k], b.uber);
+			if (BETTER(top[k], top[win]))
+				win = k;
+		}
+	}
 #undef BETTER
-	if (b.uber)
-		uber_refine(px, wt, &best, b.uber);
-	pack(&best, out);
+#undef BEST_ERR
+	pack(&top[win], out);
+}
+
+void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p)
+{
+	const budget b = quality_budget(p->quality);
+	encode_block(rgba, out, p, &b);
+}
+
+/* test-only: the block search with every budget field set by the caller (tools/bc7_lab.py measures what
+ * each step of the search buys before it is given to a Texture::Quality level).  knobs = the budget
+ * fields in declaration order. */
+void cfo_bc7_lab_block(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p, const int knobs[16])
+{
+	budget b;
+	memset(&b, 0, sizeof(b));
+	b.iters = knobs[0]; b.qwin = knobs[1]; b.m6only = knobs[2]; b.two = knobs[3]; b.mode3 = knobs[4];
+	b.three = knobs[5]; b.rot = knobs[6]; b.uber = knobs[7]; b.uber_top = knobs[8];
+	b.n1 = knobs[9]; b.n3 = knobs[10]; b.n7 = knobs[11]; b.n7low = knobs[12]; b.n0 = knobs[13]; b.n2 = knobs[14];
+	encode_block(rgba, out, p, &b);
 }
 
 
@@ -914,7 +1089,8 @@ uint32_t cfo_bc7_wide_search(const uint8_t rgba[64], uint8_t out[16], const cfo_
 			continue;                                  /* mode 7 spends bits on an alpha that is constant */
 		if (wt[4] && ((id >= 2 && id <= 4) || (id >= 5 && id <= 12 && ((id - 5) & 3))))
 			continue;                                  /* perceptual metric: rotation 0 only, as the encoder */
-		eval_candidate(px, wt, id, 8, &cur);
+		const fitopt fo = {8, 0};
+		eval_candidate(px, wt, id, &fo, &cur);
 		if (cur.err != 0)
 			uber_refine(px, wt, &cur, 8);
 		if (cur.err < best.err || (cur.err == best.err && cur.id < best.id))
