@@ -107,9 +107,10 @@ struct Cand {
 };
 
 // A lane's best candidate so far lives in LDS (field-major, one column per thread):
-// only (error, id) stay in registers.  18 words: q[6], pb, w[4], w2[4], the errors of its (up to
-// three) fits -- what the perturbation rounds of High / Highest compare against.
-#define CF_BC7_CAND_WORDS 18
+// only (error, id) stay in registers.  21 words: q[6], pb, w[4], w2[4], the errors of its (up to
+// three) fits -- what the refinement of the best candidates compares against -- and three words where
+// (error, id) and the lanes of the best candidates are parked while the lane runs another fit.
+#define CF_BC7_CAND_WORDS 21
 __device__ __forceinline__ void cand_store(uint32_t* slot, const Cand& c)
 {
 #pragma unroll
@@ -162,6 +163,9 @@ __device__ __forceinline__ float sc_of(uint32_t t)
 // with (T, H, S) = (bits+1, 0.5, 1) for p-bit modes and (bits, 1.0, 0) with P forced to 0
 // otherwise -- for those lanes (y - 0)*1 is exact, both candidates coincide and p = 0 wins.
 // A channel that is not coded has x = 0 and comes out as 0 (its dequantised pattern is masked).
+// UNITW: every coded channel weighs 1 and a channel that is not coded contributes an exact zero, so the
+// weights need no registers (fmaf(1, t2, acc) is the same correctly rounded sum as the oracle's).
+template <bool UNITW>
 __device__ __forceinline__ void quantize(const float (&x0)[4], const float (&x1)[4], uint32_t cb,
 	uint32_t ab, uint32_t pbk, const uint32_t (&wt)[4], SubFit& f)
 {
@@ -195,7 +199,7 @@ __device__ __forceinline__ void quantize(const float (&x0)[4], const float (&x1)
 				const uint32_t dd = dequant(((uint32_t)qq << S) | P, t) & (c < 3 ? cmask : amask);
 				const float dx = (float)dd - xv;
 				const float t2 = dx*dx;
-				acc = fmaf((float)wt[c], t2, acc);
+				acc = UNITW ? acc + t2 : fmaf((float)wt[c], t2, acc);
 				q[e][p] |= (uint32_t)qq << (8*c);
 				d[e][p] |= dd << (8*c);
 			}
@@ -333,19 +337,24 @@ __device__ __forceinline__ uint32_t ycc_pp_sum(const Tex& tx, uint32_t mask, con
 	return pp;
 }
 
+// Timing-ablation switches for tools/ab_bench.sh (never set in the product build).
+#ifndef CF_BC7_ABLATE
+#define CF_BC7_ABLATE 0
+#endif
+
 struct LaneFit {
-	uint32_t e0, e1, q0, q1, pb, err;
+	uint32_t q0, q1, pb, err;   // (the dequantised endpoints are an input of the assignment, not part of a result)
 	uint32_t w[4];          // weights per texel (bytes), 0 outside the subset
 };
 
 template <bool UNITW>
 __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bool m6,
-	uint32_t khalf, uint32_t ib, const uint32_t (&yw)[2], uint32_t pp_sum, bool want_lsq, LaneFit& f,
-	float (&nx0)[4], float (&nx1)[4], bool& ok)
+	uint32_t khalf, uint32_t ib, const uint32_t (&yw)[2], uint32_t pp_sum, bool want_lsq, uint32_t fe0, uint32_t fe1,
+	LaneFit& f, float (&nx0)[4], float (&nx1)[4], float (&hq)[3], bool& ok)
 {
 	const uint32_t nk = m6 ? 8u : (1u << ib), kbase = m6 ? 8u*khalf : 0u;
-	const uint32_t e00 = ub(f.e0, 0), e01 = ub(f.e0, 1), e02 = ub(f.e0, 2), e03 = ub(f.e0, 3);
-	const uint32_t e10 = ub(f.e1, 0), e11 = ub(f.e1, 1), e12 = ub(f.e1, 2), e13 = ub(f.e1, 3);
+	const uint32_t e00 = ub(fe0, 0), e01 = ub(fe0, 1), e02 = ub(fe0, 2), e03 = ub(fe0, 3);
+	const uint32_t e10 = ub(fe1, 0), e11 = ub(fe1, 1), e12 = ub(fe1, 2), e13 = ub(fe1, 3);
 	// straight-line palette: entries past this lane's 2^ib get a key that never wins.
 	// A texel's key is the NEGATED 128 (sum_c w_c c_k^2 - 2 sum_c p_c (w_c c_k)) + weight_k,
 	// maximised over k; sum_c w_c p_c^2 is added once per subset (pp_sum).  Unit weights: the
@@ -444,7 +453,11 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 			wp0 = wp1; wp1 = wp2; wp2 = wp3; wp3 = wrow;   // rotates back to the start after 4 trips
 			const uint32_t iwrow = (0x40404040u - wrow) & bytemask4((mask >> (4u*r)) & 15u);
 			uint32_t P[4];
-			planes<true>(tx, *reinterpret_cast<const uint4*>(tx.pl() + 4u*r), P);
+			// (the block offset made opaque per trip: the row address is then formed here, with the array's base in
+			// the instruction's offset field, instead of being hoisted into a register that lives across the search)
+			uint32_t bo = tx.boff;
+			asm volatile("" : "+v"(bo));
+			planes<true>(tx, *reinterpret_cast<const uint4*>(tx.plan_ + bo + 4u*r), P);
 			S = __builtin_amdgcn_udot4(wrow, 0x01010101u, S, false);
 			A = __builtin_amdgcn_udot4(iwrow, iwrow, A, false);
 			B = __builtin_amdgcn_udot4(iwrow, wrow, B, false);
@@ -468,21 +481,81 @@ __device__ __forceinline__ void assign_lsq_lane(const Tex& tx, uint32_t mask, bo
 			const float n0 = fmaf(fC, fU, -t0);
 			const float t1 = fB*fU;
 			const float n1 = fmaf(fA, fV, -t1);
-			nx0[c] = clamp255(n0*inv);
-			nx1[c] = clamp255(n1*inv);
+			// UNCLAMPED: the quadratic form of refit_window is centred here; fit_lane clamps for the rounding
+			nx0[c] = n0*inv;
+			nx1[c] = n1*inv;
 		} else {
 			nx0[c] = 0.0f;
 			nx1[c] = 0.0f;
 		}
 	}
+	hq[0] = fA; hq[1] = fB; hq[2] = fC;
+}
+
+// Least squares WITH the quantisation inside (oracle: refit_quantized).  With the selectors fixed the
+// error of a channel is a quadratic in its two endpoints, centred at the closed-form solution xu:
+// E(e0, e1) - E(xu) = A d0^2 + 2 B d0 d1 + C d1^2 with d = e - xu.  f holds the plain rounding of the
+// clamped solution (quantize: p-bits and the centre of the search); every channel then takes, among the
+// 3 x 3 pairs of quantised values within one step of that centre, the pair that minimises the form
+// (end 0 outer, end 1 inner, -1, 0, +1; first minimum).  A value outside the field's range gets a
+// deviation of 1e18: its form value is +inf and never the minimum.
+__device__ __forceinline__ void refit_window(const float (&xu0)[4], const float (&xu1)[4], const float (&hq)[3],
+	uint32_t cb, uint32_t ab, uint32_t pbk, SubFit& f)
+{
+	const uint32_t S = pbk ? 1u : 0u;
+	const uint32_t P0 = f.pb & 1u, P1 = (f.pb >> 1) & 1u;
+	const float fA = hq[0], fC = hq[2], fB2 = hq[1] + hq[1];
+	uint32_t nq0 = 0, nq1 = 0, ne0 = 0, ne1 = 0;
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		const uint32_t bits = c < 3 ? cb : ab;
+		const uint32_t sh = bits ? bits + S : 8u, cmask = bits ? 255u : 0u, qmax = (1u << bits) - 1u;
+		const uint32_t qc0 = (f.q0 >> (8*c)) & 255u, qc1 = (f.q1 >> (8*c)) & 255u;
+		float dl0[3], dl1[3];
+#pragma unroll
+		for (int d = 0; d < 3; ++d) {
+			const uint32_t q0 = qc0 + (uint32_t)d - 1u, q1 = qc1 + (uint32_t)d - 1u;   // wraps below zero: > qmax
+			const uint32_t d0 = dequant((q0 << S) | P0, sh) & cmask, d1 = dequant((q1 << S) | P1, sh) & cmask;
+			dl0[d] = q0 <= qmax ? (float)d0 - xu0[c] : 1.0e18f;
+			dl1[d] = q1 <= qmax ? (float)d1 - xu1[c] : 1.0e18f;
+		}
+		float best = 3.0e38f;
+		uint32_t bi = 4u;      // 3 i + j; the centre unless something is better (the centre is always valid)
+#pragma unroll
+		for (int i = 0; i < 3; ++i) {
+			const float d0 = dl0[i];
+			float a0 = fA*d0;
+			a0 = a0*d0;
+			const float cr = fB2*d0;
+#pragma unroll
+			for (int j = 0; j < 3; ++j) {
+				const float d1 = dl1[j];
+				float v = fC*d1;
+				v = fmaf(v, d1, a0);
+				v = fmaf(cr, d1, v);
+				const bool take = v < best;
+				best = take ? v : best;
+				bi = take ? (uint32_t)(3*i + j) : bi;
+			}
+		}
+		const uint32_t b0 = bi/3u, b1 = bi - 3u*b0;
+		const uint32_t q0 = qc0 + b0 - 1u, q1 = qc1 + b1 - 1u;
+		nq0 |= (q0 & 255u) << (8*c);
+		nq1 |= (q1 & 255u) << (8*c);
+		ne0 |= (dequant((q0 << S) | P0, sh) & cmask) << (8*c);
+		ne1 |= (dequant((q1 << S) | P1, sh) & cmask) << (8*c);
+	}
+	f.q0 = nq0; f.q1 = nq1; f.e0 = ne0; f.e1 = ne1;
 }
 
 // scalar: the fit codes only the rotated alpha channel (modes 4/5 second plane); its start
 // endpoints are the exact extremes of that channel (oracle: fit_scalar).
+// frac: where the fit starts -- the extremes along the axis pulled in (positive) or pushed out by this
+// fraction of their distance (oracle: fitopt.start, cfo_start_frac; 0 = the extremes themselves).
 template <bool UNITW>
 __device__ __forceinline__ void fit_lane(const Tex& tx, uint32_t mask, bool m6, uint32_t khalf,
 	uint32_t cb, uint32_t ab, uint32_t pbk, uint32_t ib, uint32_t iters, const uint32_t (&wt)[4],
-	const uint32_t (&yw)[2], bool scalar, LaneFit& best)
+	const uint32_t (&yw)[2], bool scalar, float frac, LaneFit& best)
 {
 	// A: statistics of the subset + extremes of the (rotated) alpha channel
 	const uint32_t n = (uint32_t)__builtin_popcount(mask);
@@ -575,6 +648,11 @@ __device__ __forceinline__ void fit_lane(const Tex& tx, uint32_t mask, bool m6, 
 			tmax = m ? fmaxf(tmax, t) : tmax;
 		}
 	}
+	{
+		const float d = (tmax - tmin)*frac;
+		tmin = tmin + d;
+		tmax = tmax - d;
+	}
 	float x0[4], x1[4];
 #pragma unroll
 	for (int c = 0; c < 4; ++c) {
@@ -582,31 +660,58 @@ __device__ __forceinline__ void fit_lane(const Tex& tx, uint32_t mask, bool m6, 
 		x1[c] = clamp255(fmaf(axis[c], tmax, mean[c]));
 	}
 	if (scalar) {
-		x0[0] = 0.0f; x0[1] = 0.0f; x0[2] = 0.0f; x0[3] = (float)lo;
-		x1[0] = 0.0f; x1[1] = 0.0f; x1[2] = 0.0f; x1[3] = (float)hi;
+		const float flo = (float)lo, fhi = (float)hi;
+		const float d = (fhi - flo)*frac;
+		x0[0] = 0.0f; x0[1] = 0.0f; x0[2] = 0.0f; x0[3] = clamp255(flo + d);
+		x1[0] = 0.0f; x1[1] = 0.0f; x1[2] = 0.0f; x1[3] = clamp255(fhi - d);
 	}
 	// C/D then E rounds.  A round that does not improve ends the lane's search (the same
 	// input would give the same output again): x0/x1 always hold the refit of the newest
 	// selectors and `live` says whether they belong to the best fit so far.
+	// The fit's four small parameters travel through the rounds as ONE word (cb | ab << 4 | pbk << 8 |
+	// ib << 12), unpacked where a step needs them from a copy the compiler cannot see through -- as four
+	// registers held across the selector search they were what pushed the 128-register build into scratch.
+	uint32_t geo = cb | (ab << 4) | (pbk << 8) | (ib << 12);
+	asm volatile("" : "+v"(geo));
+#define G_CB (geo & 15u)
+#define G_AB ((geo >> 4) & 15u)
+#define G_PBK ((geo >> 8) & 15u)
+#define G_IB (geo >> 12)
 	SubFit q;
-	quantize(x0, x1, cb, ab, pbk, wt, q);
-	best.e0 = q.e0; best.e1 = q.e1; best.q0 = q.q0; best.q1 = q.q1; best.pb = q.pb;
+	quantize<UNITW>(x0, x1, G_CB, G_AB, G_PBK, wt, q);
+	best.q0 = q.q0; best.q1 = q.q1; best.pb = q.pb;
 	bool live;
 	// sum over the subset of sum_c p_c^2 (channels that are not coded have p = 0), or of the
 	// weighted squares on the perceptual axes
 	const uint32_t pp_sum = UNITW ? q00 + q11 + q22 + q33 : ycc_pp_sum(tx, mask, yw);
-	assign_lsq_lane<UNITW>(tx, mask, m6, khalf, ib, yw, pp_sum, iters > 0u, best, x0, x1, live);
+	float hq[3];
+	assign_lsq_lane<UNITW>(tx, mask, m6, khalf, G_IB, yw, pp_sum, iters > 0u, q.e0, q.e1, best, x0, x1, hq, live);
 	for (uint32_t r = 0; r < iters; ++r) {
 		LaneFit cur;
 		bool ok;
-		quantize(x0, x1, cb, ab, pbk, wt, q);
-		cur.e0 = q.e0; cur.e1 = q.e1; cur.q0 = q.q0; cur.q1 = q.q1; cur.pb = q.pb;
-		assign_lsq_lane<UNITW>(tx, mask, m6, khalf, ib, yw, pp_sum, r + 1u < iters, cur, x0, x1, ok);
+		asm volatile("" : "+v"(geo));
+		{
+			// x0 / x1: the unclamped least-squares solution; rounded from its clamped copy, then searched
+			float c0[4], c1[4];
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				c0[c] = clamp255(x0[c]);
+				c1[c] = clamp255(x1[c]);
+			}
+			quantize<UNITW>(c0, c1, G_CB, G_AB, G_PBK, wt, q);
+		}
+		if (!(CF_BC7_ABLATE & 8)) refit_window(x0, x1, hq, G_CB, G_AB, G_PBK, q);
+		cur.q0 = q.q0; cur.q1 = q.q1; cur.pb = q.pb;
+		assign_lsq_lane<UNITW>(tx, mask, m6, khalf, G_IB, yw, pp_sum, r + 1u < iters, q.e0, q.e1, cur, x0, x1, hq, ok);
 		const bool better = live && cur.err < best.err;
 		if (better)
 			best = cur;
 		live = better && ok;
 	}
+#undef G_CB
+#undef G_AB
+#undef G_PBK
+#undef G_IB
 }
 
 __device__ __forceinline__ uint32_t w2i(uint32_t w, uint32_t ib)
@@ -828,10 +933,82 @@ __device__ __forceinline__ float subset_residual(const Tex& tx, uint32_t mask)
 	return res;
 }
 
-// Timing-ablation switches for tools/ab_bench.sh (never set in the product build).
-#ifndef CF_BC7_ABLATE
-#define CF_BC7_ABLATE 0
-#endif
+// Geometry of fit kf of candidate id (oracle: fit_geometry): mode, partition / rotation / index selector,
+// the channels and precisions the fit codes, its index width and its texels.
+struct FitGeo {
+	uint32_t mode, part, rot, isel, ns, nfits, cb, ab, pbk, ib, mask, chm;
+	bool m6, planes45, sca;
+};
+
+__device__ __forceinline__ FitGeo fit_geo(uint32_t id, uint32_t kf)
+{
+	FitGeo g;
+	g.part = 0; g.rot = 0; g.isel = 0;
+	if (id == 0u) g.mode = 6;
+	else if (id < 5u) { g.mode = 5; g.rot = id - 1u; }
+	else if (id < 13u) { g.mode = 4; g.rot = (id - 5u) & 3u; g.isel = (id - 5u) >> 2; }
+	else if (id < 128u) { g.mode = 1; g.part = id - 64u; }
+	else if (id < 192u) { g.mode = 3; g.part = id - 128u; }
+	else if (id < 256u) { g.mode = 0; g.part = id - 192u; }
+	else if (id < 320u) { g.mode = 2; g.part = id - 256u; }
+	else { g.mode = 7; g.part = (id - 320u) & 63u; }
+	const uint32_t mode = g.mode;
+	g.ns = (0x21112323u >> (4u*mode)) & 15u;
+	g.m6 = mode == 6u;
+	g.planes45 = mode == 4u || mode == 5u;
+	g.nfits = g.planes45 ? 2u : g.ns;
+	g.sca = g.planes45 && kf == 1u;
+	g.mask = 0xFFFFu;
+	if (g.planes45) {
+		const uint32_t ibc = mode == 5u ? 2u : (g.isel ? 3u : 2u), iba = mode == 5u ? 2u : (g.isel ? 2u : 3u);
+		g.cb = g.sca ? 0u : (mode == 5u ? 7u : 5u);
+		g.ab = g.sca ? (mode == 5u ? 8u : 6u) : 0u;
+		g.ib = g.sca ? iba : ibc;
+		g.pbk = 0;
+		g.chm = g.sca ? 8u : 7u;
+	} else {
+		g.cb = (0x57757564u >> (4u*mode)) & 15u;
+		g.ab = (0x57860000u >> (4u*mode)) & 15u;
+		g.pbk = (0x11001021u >> (4u*mode)) & 15u;
+		g.ib = (0x24222233u >> (4u*mode)) & 15u;
+		g.chm = g.ab ? 15u : 7u;
+		if (g.ns == 2u) {
+			const uint32_t p2 = k_part2[g.part];
+			g.mask = kf ? p2 : (~p2 & 0xFFFFu);
+		} else if (g.ns == 3u) {
+			const uint32_t p3 = k_part3[g.part];
+			g.mask = 0;
+#pragma unroll
+			for (int i = 0; i < 16; ++i)
+				g.mask |= (((p3 >> (2*i)) & 3u) == kf ? 1u : 0u) << i;
+		}
+	}
+	return g;
+}
+
+// Store a fit (quantised fields, p-bits, weights, error) into fit slot kf of a candidate's column.
+__device__ __forceinline__ void column_put_fit(uint32_t* wc, const FitGeo& g, uint32_t kf, uint32_t q0, uint32_t q1,
+	uint32_t pb, const uint32_t (&w)[4], uint32_t err)
+{
+	const uint32_t fq0 = g.planes45 ? (g.sca ? 4u : 0u) : 2u*kf;
+	wc[fq0*CF_WG_THREADS] = q0;
+	wc[(fq0 + 1u)*CF_WG_THREADS] = q1;
+	wc[(15u + kf)*CF_WG_THREADS] = err;
+	if (!g.planes45) {
+		const uint32_t pw = wc[6*CF_WG_THREADS];
+		wc[6*CF_WG_THREADS] = (pw & ~(3u << (2u*kf))) | (pb << (2u*kf));
+	}
+#pragma unroll
+	for (uint32_t rr = 0; rr < 4u; ++rr) {
+		if (g.sca)
+			wc[(11u + rr)*CF_WG_THREADS] = w[rr];
+		else {
+			const uint32_t mb = bytemask4((g.mask >> (4u*rr)) & 15u);
+			wc[(7u + rr)*CF_WG_THREADS] = (wc[(7u + rr)*CF_WG_THREADS] & ~mb) | w[rr];
+		}
+	}
+}
+
 
 // Encode one block with the whole wavefront.  tp: the block's 16 texels in LDS
 // (colour mask already applied), identical for every lane.
@@ -856,6 +1033,9 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	const bool has_alpha = pair ? ((uint32_t)(L_H ? abal >> 32 : abal) & 0xFFFFu) != 0u
 		: ((uint32_t)abal & 0xFFFFu) != 0u;
 	const bool any_alpha = pair ? abal != 0ull : has_alpha;
+	// inside the stream loop the flag is an expression of the CURRENT lane id (a loop-invariant per-lane value, and
+	// everything derived from it, would be hoisted out of the loop and held in registers through every trip)
+#define H_ALPHA (pair ? ((uint32_t)(L_H ? abal >> 32 : abal) & 0xFFFFu) != 0u : ((uint32_t)abal & 0xFFFFu) != 0u)
 	// Low runs Normal's candidate set without the refit round (oracle: quality_budget): `quality`
 	// below selects the LAYOUT, so Low is mapped onto Normal's
 	const uint32_t iters = (0x21100u >> (4u*(kp.quality < 4u ? kp.quality : 4u))) & 15u;   // refit rounds 0,0,1,1,2
@@ -863,8 +1043,13 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	// High walk Normal's candidate set (High adds a refit round and the perturbation rounds below)
 	const uint32_t quality = WIDE ? 3u : ((kp.quality == 1u || kp.quality >= 3u) ? 2u : kp.quality);
 	const uint32_t wt[4] = {kp.wt[0], kp.wt[1], kp.wt[2], kp.wt[3]};
+	// fits with refit rounds start 1/16 inside the extremes (oracle: fitopt.start 1); a scalar, not a hoisted VGPR
+	const float frac_main = __int_as_float(__builtin_amdgcn_readfirstlane(iters ? 0x3d800000 : 0));
 
-	uint32_t best_err = 0xFFFFFFFFu, best_id = 0x7FFFFFFFu;   // payload fields: cslot (LDS)
+	// a lane's best (error, id) so far live in words 18 / 19 of its column, like the payload fields: nothing of
+	// a candidate is carried in registers from one trip of the stream loop to the next
+	L_CSLOT[18*CF_WG_THREADS] = 0xFFFFFFFFu;
+	L_CSLOT[19*CF_WG_THREADS] = 0x7FFFFFFFu;
 
 	// ---- fit streams: one fit per lane (fit_lane) ----
 	// Lowest / Low / Normal use the 32-lane layout (two blocks share a wave):
@@ -888,24 +1073,53 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	const bool lay32 = !WIDE;
 #define L_HL (lay32 ? (lane & 31u) : lane)
 #define L_SLOT_OK (!lay32 || pair || lane < 32u)
+	const uint32_t ntop = kp.quality >= 2u ? 4u : 1u;
+	const uint32_t uber = kp.quality >= 4u ? 2u : (kp.quality == 3u ? 1u : 0u);    // rounds per top candidate
+	const uint32_t uber2 = kp.quality >= 4u ? 2u : (kp.quality >= 2u ? 1u : 0u);   // rounds on the leader
+	const uint32_t msets = kp.quality >= 3u ? 3u : 1u;       // move sets of a round: bit 0 single, bit 1 joint
 	bool solved = false;
 	{
 		const uint32_t nstreams = (WIDE && !has_alpha) ? 2u : 1u;
+		// The last trip of this loop (sst) is not a stream of new candidates: it selects the `ntop` best so
+		// far and refits them from four more starts (oracle: encode_block, "more starts") -- through the SAME
+		// fit_lane call as the streams (one copy of the fit in the code object, one register allocation).
 #pragma unroll 1
-		for (uint32_t st = 0; st < nstreams && !solved; ++st) {
+		for (uint32_t st = 0; st <= nstreams; ++st) {
+			const bool sst = st == nstreams;
+			if (!sst && solved)
+				continue;
 			CF_FRESH_LANE(lane);   // roles are recomputed per stream, not kept
-			const Tex txp = make_tex(tile, plan, yccp, B_OFF, 0u, has_alpha ? 15u : 7u);   // partition fits: no rotation
+			if (sst) {
+				// ---- the `ntop` best candidates of each group in (error, id) order (oracle: top[]) ----
+				{
+					unsigned long long kk = ((unsigned long long)L_CSLOT[18*CF_WG_THREADS] << 32) | L_CSLOT[19*CF_WG_THREADS];
+					uint32_t wls = 0;          // byte k: lane whose column holds the k-th best candidate of this lane's group
+					for (uint32_t k = 0; k < ntop; ++k) {
+						const unsigned long long km = cf_group_min_u64(kk, pair, L_H);
+						const unsigned long long bal = __ballot(kk == km);
+						const uint32_t gmask = pair ? (L_H ? (uint32_t)(bal >> 32) : (uint32_t)bal) : 0u;
+						const uint32_t wl = pair ? L_HBASE + (uint32_t)__ffs((int)gmask) - 1u
+							: (uint32_t)__ffsll((long long)bal) - 1u;
+						wls |= wl << (8u*k);
+						kk = lane == wl ? ~0ull : kk;
+					}
+					L_CSLOT[20*CF_WG_THREADS] = wls;     // every lane keeps its group's list in its own column
+				}
+				if (uber2 == 0u || (CF_BC7_ABLATE & 16))
+					break;
+			}
+			const Tex txp = make_tex(tile, plan, yccp, B_OFF, 0u, H_ALPHA ? 15u : 7u);   // partition fits: no rotation
 			const uint32_t ns = 2u + st;
-			const bool parts = quality >= 1u;
+			const bool parts = quality >= 1u && !sst;
 			// partition lanes: first lane, slots of the first mode, slots in all
-			// (nper0 depends on the half's has_alpha: an expression, like the roles, not a carried value)
+			// (nper0 depends on the half's H_ALPHA: an expression, like the roles, not a carried value)
 			uint32_t pfirst, nslots;
 			if (lay32) {
 				if (quality == 2u) { pfirst = 10u; nslots = 11u; }
 				else { pfirst = 4u; nslots = 14u; }
 			} else if (st == 1u) { pfirst = 0u; nslots = 10u; }
 			else { pfirst = 26u; nslots = 16u; }
-#define R_NPER0 (lay32 ? (quality == 2u ? (has_alpha ? 11u : 6u) : 14u) : (st == 1u ? 5u : (has_alpha ? 16u : 8u)))
+#define R_NPER0 (lay32 ? (quality == 2u ? (H_ALPHA ? 11u : 6u) : 14u) : (st == 1u ? 5u : (H_ALPHA ? 16u : 8u)))
 			// lane roles as expressions of the CURRENT lane id (re-read where a phase starts), so that none of
 			// them is carried in a register through the fit
 #define R_REL (L_HL - pfirst)                                   /* wraps below pfirst */
@@ -961,17 +1175,38 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 #define R_VECP (lay32 ? (quality == 2u ? (L_SLOT_OK && L_HL >= 2u && L_HL < 6u) : (L_SLOT_OK && L_HL == 2u)) : (st == 0u && lane >= 2u && lane < 14u))
 #define R_SCA (lay32 ? (quality == 2u ? (L_SLOT_OK && L_HL >= 6u && L_HL < 10u) : (L_SLOT_OK && L_HL == 3u)) : (st == 0u && lane >= 14u && lane < 26u))
 #define R_CID (R_M6 ? 0u : (lay32 ? (quality == 2u ? L_HL - (R_SCA ? 5u : 1u) : 1u) : 1u + (lane - (R_SCA ? 14u : 2u))))   /* meaningful for vecp / sca */
-#define R_IDBASE (R_PLANE ? (st == 1u ? (R_MI ? 256u : 192u) : (has_alpha ? 320u : (R_MI ? 128u : 64u))) : 0u)
-			const bool m6 = R_M6, sca = R_SCA, vecp = R_VECP, plane = R_PLANE;
+#define R_IDBASE (R_PLANE ? (st == 1u ? (R_MI ? 256u : 192u) : (H_ALPHA ? 320u : (R_MI ? 128u : 64u))) : 0u)
+			bool m6 = R_M6, sca = R_SCA;
+			const bool vecp = R_VECP, plane = R_PLANE;
 			const uint32_t cid = R_CID, sub = R_SUB, mi = R_MI;
 			const uint32_t s2off = lay32 ? (quality == 2u ? 4u : 1u) : (st == 0u ? 12u : 2u);
 			uint32_t rot = 0, cb = 7, ab = 7, pbk = 1, ib = 4, mask = 0xFFFFu;
 			bool active = m6;
-			if (vecp || sca) {
+			float frac = frac_main;
+			uint32_t chm_s = 0;
+			if (sst) {
+				// lane = (top candidate k, start variant v, fit): 8 lanes per candidate in the 32-lane layouts
+				// (k = hl >> 3, v = (hl >> 1) & 3, fit = hl & 1 -- mode 6: its two palette halves), 16 in the wide
+				// one (k = lane >> 4, v = (lane >> 2) & 3, fit = lane & 3).  Each lane runs the whole fit from its
+				// start; the best start of a fit replaces the column's fit when it is better.
+				const uint32_t k = lay32 ? (L_HL >> 3) : (lane >> 4);
+				const uint32_t v = lay32 ? (L_HL >> 1) & 3u : (lane >> 2) & 3u;
+				const uint32_t fi = lay32 ? (L_HL & 1u) : (lane & 3u);
+				const uint32_t wls = L_CSLOT[20*CF_WG_THREADS];
+				const uint32_t wl = (wls >> (8u*(k & 3u))) & 255u;
+				const uint32_t id = cbase[wl + 19*CF_WG_THREADS], cerr = cbase[wl + 18*CF_WG_THREADS];
+				const uint32_t err0 = cbase[(wls & 255u) + 18*CF_WG_THREADS];
+				const FitGeo g = fit_geo(id, fi);
+				m6 = g.m6; sca = g.sca; rot = g.rot; cb = g.cb; ab = g.ab; pbk = g.pbk; ib = g.ib; mask = g.mask;
+				chm_s = g.chm;
+				active = L_SLOT_OK && k < ntop && cerr != 0xFFFFFFFFu && err0 != 0u && (g.m6 ? fi < 2u : fi < g.nfits);
+				// starts 0, 2, 3, 4 of the oracle: the extremes, pushed out by 1/16, pulled in by 1/8, by 3/16
+				frac = v == 0u ? 0.0f : (v == 1u ? -1.0f/16.0f : (v == 2u ? 1.0f/8.0f : 3.0f/16.0f));
+			} else if (vecp || sca) {
 				if (cid <= 4u) {
 					rot = cid - 1u; pbk = 0; ib = 2;
 					cb = sca ? 0u : 7u; ab = sca ? 8u : 0u;
-					active = quality >= 2u || (quality == 1u ? cid == 1u : (cid == 1u && has_alpha));
+					active = quality >= 2u || (quality == 1u ? cid == 1u : (cid == 1u && H_ALPHA));
 					// the perceptual metric couples R, G and B: no plane split that moves a colour
 					// channel into the scalar plane (oracle: nrot)
 					active = active && (UNITW || rot == 0u);
@@ -985,7 +1220,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			} else if (plane) {
 				uint32_t mode;
 				if (st == 1u) mode = mi ? 2u : 0u;
-				else mode = has_alpha ? 7u : (mi ? 3u : 1u);
+				else mode = H_ALPHA ? 7u : (mi ? 3u : 1u);
 				switch (mode) {
 					case 1: cb = 6; ab = 0; pbk = 2; ib = 3; break;
 					case 3: cb = 7; ab = 0; pbk = 1; ib = 2; break;
@@ -1014,11 +1249,11 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 				else { wl[3] = wl[2]; wl[2] = t3; }
 			}
 			// channels this fit codes (after rotation) and their weights
-			const uint32_t chm = m6 ? 15u : (sca ? 8u : (vecp ? 7u : (has_alpha ? 15u : 7u)));
+			const uint32_t chm = sst ? chm_s : (m6 ? 15u : (sca ? 8u : (vecp ? 7u : (H_ALPHA ? 15u : 7u))));
 			const uint32_t wv[4] = {(chm & 1u) ? wl[0] : 0u, (chm & 2u) ? wl[1] : 0u,
 				(chm & 4u) ? wl[2] : 0u, (chm & 8u) ? wl[3] : 0u};
 			LaneFit lf;
-			lf.err = 0; lf.q0 = 0; lf.q1 = 0; lf.pb = 0; lf.e0 = 0; lf.e1 = 0;
+			lf.err = 0; lf.q0 = 0; lf.q1 = 0; lf.pb = 0;
 #pragma unroll
 			for (int k = 0; k < 4; ++k) lf.w[k] = 0;
 			// perceptual weight pairs of this fit: zero on the axes it does not code
@@ -1026,8 +1261,40 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 				((chm & 7u) ? (ywba & 0xFFFFu) : 0u) | ((chm & 8u) ? (ywba & 0xFFFF0000u) : 0u)};
 			if (active)
 				fit_lane<UNITW>(make_tex(tile, plan, yccp, B_OFF, rot, chm), mask, m6, lane & 1u, cb, ab, pbk, ib, iters,
-					wv, yw, sca, lf);
+					wv, yw, sca, frac, lf);
 			CF_FRESH_LANE(lane);         // the roles below are computed again from here
+			if (sst) {
+				// (every role again from the fresh lane id: nothing but the fit's result lived across fit_lane)
+				const uint32_t wls = L_CSLOT[20*CF_WG_THREADS];
+				const uint32_t k2 = lay32 ? (L_HL >> 3) : (lane >> 4);
+				const uint32_t v2 = lay32 ? (L_HL >> 1) & 3u : (lane >> 2) & 3u;
+				const uint32_t fi2 = lay32 ? (L_HL & 1u) : (lane & 3u);
+				const uint32_t wl2 = (wls >> (8u*(k2 & 3u))) & 255u;
+				const uint32_t id2 = cbase[wl2 + 19*CF_WG_THREADS], cerr2 = cbase[wl2 + 18*CF_WG_THREADS];
+				const uint32_t err02 = cbase[(wls & 255u) + 18*CF_WG_THREADS];
+				const FitGeo g2 = fit_geo(id2, fi2);
+				const uint32_t kf2 = g2.m6 ? 0u : fi2;
+				const bool active2 = L_SLOT_OK && k2 < ntop && cerr2 != 0xFFFFFFFFu && err02 != 0u && (g2.m6 ? fi2 < 2u : fi2 < g2.nfits);
+				// best start of the fit: minimum of (error, v) over the four lanes of (k, fit)
+				uint32_t skey = active2 ? ((lf.err << 2) | v2) : 0xFFFFFFFFu;
+				{
+					const uint32_t o1 = (uint32_t)cf_bperm((int)skey, lane ^ (lay32 ? 2u : 4u));
+					skey = o1 < skey ? o1 : skey;
+					const uint32_t o2 = (uint32_t)cf_bperm((int)skey, lane ^ (lay32 ? 4u : 8u));
+					skey = o2 < skey ? o2 : skey;
+				}
+				uint32_t* wc = cbase + wl2;
+				const uint32_t cur_err = wc[(15u + kf2)*CF_WG_THREADS];
+				const bool win = active2 && skey == ((lf.err << 2) | v2) && lf.err < cur_err && (!g2.m6 || fi2 == 0u);
+				// one fit at a time: the fits of a candidate share the p-bit word and the weight words of its column
+#pragma unroll 1
+				for (uint32_t j = 0; j < 3u; ++j) {
+					if (win && kf2 == j)
+						column_put_fit(wc, g2, kf2, lf.q0, lf.q1, lf.pb, lf.w, lf.err);
+					__builtin_amdgcn_wave_barrier();
+				}
+				continue;
+			}
 			// ---- assemble candidates in their leader lanes ----
 			//   mode 6: its first lane;  mode 4/5: vector lane (scalar plane s2off lanes up);
 			//   partitions: subset-0 lane (the other subsets in the next lanes)
@@ -1040,10 +1307,12 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			const uint32_t cerr = lf.err + (use1 ? e1 : 0u) + (use2 ? e2 : 0u);
 			const uint32_t cidv = R_M6 ? 0u : (R_VECP ? R_CID : R_IDBASE + mypart);
 			const bool leader = active && (R_M6 ? L_HL == 0u : (R_VECP || (R_PLANE && R_SUB == 0u)));
-			const bool take = leader && (cerr < best_err || (cerr == best_err && cidv < best_id));
+			const uint32_t old_err = L_CSLOT[18*CF_WG_THREADS], old_id = L_CSLOT[19*CF_WG_THREADS];
+			const bool take = leader && (cerr < old_err || (cerr == old_err && cidv < old_id));
+			const uint32_t best_err = take ? cerr : old_err;
 			if (take) {
-				best_err = cerr;
-				best_id = cidv;
+				L_CSLOT[18*CF_WG_THREADS] = cerr;
+				L_CSLOT[19*CF_WG_THREADS] = cidv;
 			}
 			{
 				const uint32_t a01 = (uint32_t)cf_bperm((int)lf.q0, (uint32_t)(s1)), a11 = (uint32_t)cf_bperm((int)lf.q1, (uint32_t)(s1));
@@ -1098,159 +1367,157 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 		}
 	}
 
-	// ---- group argmin on (error, id); the group packs its winner's candidate ----
+	// ---- the `ntop` best candidates of each group in (error, id) order (oracle: top[]) ----
+	// From Normal up the best candidates are refined before one of them wins: refitted from four more
+	// starts (every fit keeps its best), perturbed for `uber` rounds each, and the best of them then for
+	// `uber2` more rounds.  Lowest / Low: ntop = 1, no refinement, the argmin packs.
 	CF_FRESH_LANE(lane);
-	const unsigned long long key = ((unsigned long long)best_err << 32) | best_id;
-	const unsigned long long kmin = cf_group_min_u64(key, pair, L_H);
-	const unsigned long long bal = __ballot(key == kmin);
-	const uint32_t gmask = pair ? (L_H ? (uint32_t)(bal >> 32) : (uint32_t)bal) : 0u;
-	const uint32_t wl = pair ? L_HBASE + (uint32_t)__ffs((int)gmask) - 1u
-		: (uint32_t)__ffsll((long long)bal) - 1u;   // winner lane (unique key in its group)
-	uint32_t* wc = cbase + wl;                      // the winner's column
+	const uint32_t wls = L_CSLOT[20*CF_WG_THREADS];
+	uint32_t win_lane = wls & 255u;
 
-	// ---- High / Highest: endpoint perturbation of the winner (oracle: uber_refine) ----
-	// lane = (fit of the winner, move slot): 16 slots per fit -- endpoint m >> 3, channel (m >> 1) & 3,
-	// direction m & 1: +-1 on that quantised field, the slots of a channel the fit does not code
-	// flip p-bits -- scored by the exhaustive selector assignment; per fit (= per DPP row of 16
-	// lanes; mode 6 spreads its 16 palette entries over lane pairs and fills two rows) the best
-	// move is applied when it lowers the fit's error.  Fits are independent, so all of them move
-	// in the same round.
-	const uint32_t uber = kp.quality >= 4u ? 3u : (kp.quality == 3u ? 2u : 0u);
-	if (uber) {
-		__builtin_amdgcn_wave_barrier();
-		const uint32_t id = (uint32_t)kmin;
-		uint32_t mode, part = 0, rot = 0, isel = 0;
-		if (id == 0u) mode = 6;
-		else if (id < 5u) { mode = 5; rot = id - 1u; }
-		else if (id < 13u) { mode = 4; rot = (id - 5u) & 3u; isel = (id - 5u) >> 2; }
-		else if (id < 128u) { mode = 1; part = id - 64u; }
-		else if (id < 192u) { mode = 3; part = id - 128u; }
-		else if (id < 256u) { mode = 0; part = id - 192u; }
-		else if (id < 320u) { mode = 2; part = id - 256u; }
-		else { mode = 7; part = id - 320u; }
-		const uint32_t ns = (0x21112323u >> (4u*mode)) & 15u;
-		const bool m6 = mode == 6u, planes45 = mode == 4u || mode == 5u;
-		const uint32_t nfits = planes45 ? 2u : ns;
-		const uint32_t kf = m6 ? 0u : (L_HL >> 4), mv = m6 ? (L_HL >> 1) & 15u : (L_HL & 15u);
-		const bool act = L_SLOT_OK && L_HL < 64u && (m6 ? L_HL < 32u : kf < nfits) && (uint32_t)(kmin >> 32) != 0u;
-		uint32_t cb, ab, pbk, ib, mask = 0xFFFFu, chm;
-		const bool sca = planes45 && kf == 1u;
-		if (planes45) {
-			const uint32_t ibc = mode == 5u ? 2u : (isel ? 3u : 2u), iba = mode == 5u ? 2u : (isel ? 2u : 3u);
-			cb = sca ? 0u : (mode == 5u ? 7u : 5u);
-			ab = sca ? (mode == 5u ? 8u : 6u) : 0u;
-			ib = sca ? iba : ibc;
-			pbk = 0;
-			chm = sca ? 8u : 7u;
-		} else {
-			cb = (0x57757564u >> (4u*mode)) & 15u;
-			ab = (0x57860000u >> (4u*mode)) & 15u;
-			pbk = (0x11001021u >> (4u*mode)) & 15u;
-			ib = (0x24222233u >> (4u*mode)) & 15u;
-			chm = ab ? 15u : 7u;
-			if (ns == 2u) {
-				const uint32_t p2 = k_part2[part];
-				mask = kf ? p2 : (~p2 & 0xFFFFu);
-			} else if (ns == 3u) {
-				const uint32_t p3 = k_part3[part];
-				mask = 0;
-#pragma unroll
-				for (int i = 0; i < 16; ++i)
-					mask |= (((p3 >> (2*i)) & 3u) == kf ? 1u : 0u) << i;
-			}
+	if (uber2) {
+		// the lanes that own a refined column take its new total
+		CF_FRESH_LANE(lane);
+		{
+			bool own = false;
+			for (uint32_t k = 0; k < ntop; ++k)
+				own = own || lane == ((wls >> (8u*k)) & 255u);
+			if (own && L_CSLOT[18*CF_WG_THREADS] != 0xFFFFFFFFu)
+				L_CSLOT[18*CF_WG_THREADS] = L_CSLOT[15*CF_WG_THREADS] + L_CSLOT[16*CF_WG_THREADS] + L_CSLOT[17*CF_WG_THREADS];
+			__builtin_amdgcn_wave_barrier();
 		}
-		const Tex tx = make_tex(tile, plan, yccp, B_OFF, rot, chm);
-		const uint32_t yw[2] = {(chm & 7u) ? ywrg : 0u,
-			((chm & 7u) ? (ywba & 0xFFFFu) : 0u) | ((chm & 8u) ? (ywba & 0xFFFF0000u) : 0u)};
-		// sum over the fit's texels of sum_c p_c^2 (the constant part of its error)
-		uint32_t pp_sum = 0;
-		if (UNITW) {
+
+		// ---- endpoint perturbation (oracle: uber_refine) of every top candidate, then of the leader ----
+		// lane = (fit of the candidate, move slot): 16 slots per fit and move set -- set 0: endpoint m >> 3,
+		// channel (m >> 1) & 3, direction m & 1: +-1 on that quantised field, the slots of a channel the fit
+		// does not code flip p-bits; set 1: channel m >> 2, both ends of it by (+1,+1), (-1,-1), (+1,-1), (-1,+1)
+		// -- scored by the exhaustive selector assignment; per fit (= per DPP row of 16 lanes; mode 6 spreads
+		// its 16 palette entries over lane pairs and fills two rows) the best move of a set is applied when it
+		// lowers the fit's error; a round walks its sets in order.  Fits are independent, so all of them move
+		// in the same pass.
 #pragma unroll 1
-			for (uint32_t r = 0; r < 4u; ++r) {
-				uint32_t P[4];
-				planes<true>(tx, *reinterpret_cast<const uint4*>(tx.pl() + 4u*r), P);
-				const uint32_t m4 = bytemask4((mask >> (4u*r)) & 15u);
-#pragma unroll
-				for (int c = 0; c < 4; ++c)
-					pp_sum += __builtin_amdgcn_udot4(P[c] & m4, P[c], 0u, false);
+		for (uint32_t kk = ((CF_BC7_ABLATE & 32) || !uber) ? ntop : 0u; kk <= ntop; ++kk) {
+			CF_FRESH_LANE(lane);
+			uint32_t wl = (wls >> (8u*(kk & 3u))) & 255u;
+			if (kk == ntop) {
+				// the leader after the candidates' own rounds
+				const unsigned long long key = ((unsigned long long)L_CSLOT[18*CF_WG_THREADS] << 32) | L_CSLOT[19*CF_WG_THREADS];
+				const unsigned long long kmin = cf_group_min_u64(key, pair, L_H);
+				const unsigned long long bal = __ballot(key == kmin);
+				const uint32_t gmask = pair ? (L_H ? (uint32_t)(bal >> 32) : (uint32_t)bal) : 0u;
+				wl = pair ? L_HBASE + (uint32_t)__ffs((int)gmask) - 1u : (uint32_t)__ffsll((long long)bal) - 1u;
+				win_lane = wl;
 			}
-		} else
-			pp_sum = ycc_pp_sum(tx, mask, yw);
-		const uint32_t S = pbk ? 1u : 0u;
-		const uint32_t fq0 = planes45 ? (sca ? 4u : 0u) : 2u*kf, fq1 = fq0 + 1u;   // column words of the fit's fields
+			uint32_t* wc = cbase + wl;
+			const uint32_t id = wc[19*CF_WG_THREADS], cerr = wc[18*CF_WG_THREADS];
+			const uint32_t kf0 = L_HL >> 4;
+			const FitGeo g0 = fit_geo(id, kf0);
+			const uint32_t kf = g0.m6 ? 0u : kf0, mv = g0.m6 ? (L_HL >> 1) & 15u : (L_HL & 15u);
+			const FitGeo g = g0;
+			const bool act = L_SLOT_OK && L_HL < 64u && (g.m6 ? L_HL < 32u : kf < g.nfits) && cerr != 0u && cerr != 0xFFFFFFFFu;
+			const Tex tx = make_tex(tile, plan, yccp, B_OFF, g.rot, g.chm);
+			const uint32_t yw[2] = {(g.chm & 7u) ? ywrg : 0u,
+				((g.chm & 7u) ? (ywba & 0xFFFFu) : 0u) | ((g.chm & 8u) ? (ywba & 0xFFFF0000u) : 0u)};
+			// sum over the fit's texels of sum_c p_c^2 (the constant part of its error)
+			uint32_t pp_sum = 0;
+			if (UNITW) {
 #pragma unroll 1
-		for (uint32_t r = 0; r < uber; ++r) {
-			const uint32_t q0 = wc[fq0*CF_WG_THREADS], q1 = wc[fq1*CF_WG_THREADS];
-			const uint32_t pbv = planes45 ? 0u : (wc[6*CF_WG_THREADS] >> (2u*kf)) & 3u;
-			const uint32_t cur_err = wc[(15u + kf)*CF_WG_THREADS];
-			const uint32_t e = mv >> 3, ch = (mv >> 1) & 3u, up = mv & 1u;
-			const uint32_t bits_c = ch < 3u ? cb : ab;
-			bool valid = act;
-			uint32_t nq0 = q0, nq1 = q1, npb = pbv;
-			if (bits_c) {
-				const uint32_t src = e ? q1 : q0;
-				const int nv = (int)((src >> (8u*ch)) & 255u) + (up ? 1 : -1);
-				valid = valid && nv >= 0 && nv <= (int)((1u << bits_c) - 1u);
-				const uint32_t nw = (src & ~(255u << (8u*ch))) | (((uint32_t)nv & 255u) << (8u*ch));
-				nq0 = e ? q0 : nw;
-				nq1 = e ? nw : q1;
-			} else if (pbk == 1u && e == 0u)
-				npb = pbv ^ (1u << up);
-			else if (pbk == 2u && e == 0u && up == 0u)
-				npb = pbv ^ 3u;
-			else
-				valid = false;
-			LaneFit f;
-			f.q0 = nq0; f.q1 = nq1; f.pb = npb; f.err = 0; f.e0 = 0; f.e1 = 0;
+				for (uint32_t r = 0; r < 4u; ++r) {
+					uint32_t P[4];
+					planes<true>(tx, *reinterpret_cast<const uint4*>(tx.pl() + 4u*r), P);
+					const uint32_t m4 = bytemask4((g.mask >> (4u*r)) & 15u);
 #pragma unroll
-			for (uint32_t c = 0; c < 4u; ++c) {
-				const uint32_t bc = c < 3u ? cb : ab;
-				if (bc) {       // (uniform per lane group of a fit; a select chain otherwise)
-					f.e0 |= dequant((((nq0 >> (8u*c)) & 255u) << S) | (npb & S), bc + S) << (8u*c);
-					f.e1 |= dequant((((nq1 >> (8u*c)) & 255u) << S) | ((npb >> 1) & S), bc + S) << (8u*c);
+					for (int c = 0; c < 4; ++c)
+						pp_sum += __builtin_amdgcn_udot4(P[c] & m4, P[c], 0u, false);
 				}
-			}
-#pragma unroll
-			for (int k = 0; k < 4; ++k) f.w[k] = 0;
-			float x0[4], x1[4];
-			bool okk;
-			assign_lsq_lane<UNITW>(tx, mask, m6, L_HL & 1u, ib, yw, pp_sum, false, f, x0, x1, okk);
-			uint32_t key = valid ? ((f.err << 4) | mv) : 0xFFFFFFFFu;
-			uint32_t fitmin = cf_row_min_u32(key);
-			if (m6) {
-				const uint32_t other = (uint32_t)cf_bperm((int)fitmin, lane ^ 16u);
-				fitmin = other < fitmin ? other : fitmin;
-			}
-			const bool win = valid && key == fitmin && f.err < cur_err && (!m6 || (L_HL & 1u) == 0u);
-			// one fit at a time: the fits share the p-bit word and the weight words of the column
+			} else
+				pp_sum = ycc_pp_sum(tx, g.mask, yw);
+			const uint32_t S = g.pbk ? 1u : 0u;
+			const uint32_t fq0 = g.planes45 ? (g.sca ? 4u : 0u) : 2u*kf, fq1 = fq0 + 1u;   // column words of the fit's fields
 #pragma unroll 1
-			for (uint32_t k = 0; k < 3u; ++k) {
-				if (win && kf == k) {
-					wc[fq0*CF_WG_THREADS] = nq0;
-					wc[fq1*CF_WG_THREADS] = nq1;
-					wc[(15u + kf)*CF_WG_THREADS] = f.err;
-					if (!planes45) {
-						const uint32_t pw = wc[6*CF_WG_THREADS];
-						wc[6*CF_WG_THREADS] = (pw & ~(3u << (2u*kf))) | (npb << (2u*kf));
+			for (uint32_t r = 0; r < ((CF_BC7_ABLATE & 32) ? 0u : (kk == ntop ? uber2 : uber)); ++r) {
+				bool moved = false;
+#pragma unroll 1
+				for (uint32_t set = 0; set < 2u; ++set) {
+					if (!((msets >> set) & 1u))
+						continue;
+					const uint32_t q0 = wc[fq0*CF_WG_THREADS], q1 = wc[fq1*CF_WG_THREADS];
+					const uint32_t pbv = g.planes45 ? 0u : (wc[6*CF_WG_THREADS] >> (2u*kf)) & 3u;
+					const uint32_t cur_err = wc[(15u + kf)*CF_WG_THREADS];
+					bool valid = act;
+					uint32_t nq0 = q0, nq1 = q1, npb = pbv;
+					if (set == 0u) {
+						const uint32_t e = mv >> 3, ch = (mv >> 1) & 3u, up = mv & 1u;
+						const uint32_t bits_c = ch < 3u ? g.cb : g.ab;
+						if (bits_c) {
+							const uint32_t src = e ? q1 : q0;
+							const int nv = (int)((src >> (8u*ch)) & 255u) + (up ? 1 : -1);
+							valid = valid && nv >= 0 && nv <= (int)((1u << bits_c) - 1u);
+							const uint32_t nw = (src & ~(255u << (8u*ch))) | (((uint32_t)nv & 255u) << (8u*ch));
+							nq0 = e ? q0 : nw;
+							nq1 = e ? nw : q1;
+						} else if (g.pbk == 1u && e == 0u)
+							npb = pbv ^ (1u << up);
+						else if (g.pbk == 2u && e == 0u && up == 0u)
+							npb = pbv ^ 3u;
+						else
+							valid = false;
+					} else {
+						const uint32_t ch = mv >> 2, k4 = mv & 3u;
+						const uint32_t bits_c = ch < 3u ? g.cb : g.ab;
+						const int d0 = (k4 == 0u || k4 == 2u) ? 1 : -1, d1 = (k4 == 0u || k4 == 3u) ? 1 : -1;
+						const int v0 = (int)((q0 >> (8u*ch)) & 255u) + d0, v1 = (int)((q1 >> (8u*ch)) & 255u) + d1;
+						const int qm = (int)((1u << bits_c) - 1u);
+						valid = valid && bits_c != 0u && v0 >= 0 && v0 <= qm && v1 >= 0 && v1 <= qm;
+						nq0 = (q0 & ~(255u << (8u*ch))) | (((uint32_t)v0 & 255u) << (8u*ch));
+						nq1 = (q1 & ~(255u << (8u*ch))) | (((uint32_t)v1 & 255u) << (8u*ch));
 					}
+					LaneFit f;
+					f.q0 = nq0; f.q1 = nq1; f.pb = npb; f.err = 0;
+					uint32_t fe0 = 0, fe1 = 0;
 #pragma unroll
-					for (uint32_t rr = 0; rr < 4u; ++rr) {
-						if (sca)
-							wc[(11u + rr)*CF_WG_THREADS] = f.w[rr];
-						else {
-							const uint32_t mb = bytemask4((mask >> (4u*rr)) & 15u);
-							wc[(7u + rr)*CF_WG_THREADS] = (wc[(7u + rr)*CF_WG_THREADS] & ~mb) | f.w[rr];
+					for (uint32_t c = 0; c < 4u; ++c) {
+						const uint32_t bc = c < 3u ? g.cb : g.ab;
+						if (bc) {       // (uniform per lane group of a fit; a select chain otherwise)
+							fe0 |= dequant((((nq0 >> (8u*c)) & 255u) << S) | (npb & S), bc + S) << (8u*c);
+							fe1 |= dequant((((nq1 >> (8u*c)) & 255u) << S) | ((npb >> 1) & S), bc + S) << (8u*c);
 						}
 					}
+#pragma unroll
+					for (int j = 0; j < 4; ++j) f.w[j] = 0;
+					float x0[4], x1[4], hq[3];
+					bool okk;
+					assign_lsq_lane<UNITW>(tx, g.mask, g.m6, L_HL & 1u, g.ib, yw, pp_sum, false, fe0, fe1, f, x0, x1, hq, okk);
+					const uint32_t key = valid ? ((f.err << 4) | mv) : 0xFFFFFFFFu;
+					uint32_t fitmin = cf_row_min_u32(key);
+					if (g.m6) {
+						const uint32_t other = (uint32_t)cf_bperm((int)fitmin, lane ^ 16u);
+						fitmin = other < fitmin ? other : fitmin;
+					}
+					const bool win = valid && key == fitmin && f.err < cur_err && (!g.m6 || (L_HL & 1u) == 0u);
+					// one fit at a time: the fits share the p-bit word and the weight words of the column
+#pragma unroll 1
+					for (uint32_t j = 0; j < 3u; ++j) {
+						if (win && kf == j)
+							column_put_fit(wc, g, kf, nq0, nq1, npb, f.w, f.err);
+						__builtin_amdgcn_wave_barrier();
+					}
+					moved = moved || __ballot(win) != 0ull;
 				}
-				__builtin_amdgcn_wave_barrier();
+				if (!moved)
+					break;       // no fit of any block of this wave moved: later rounds would repeat this one
 			}
-			if (__ballot(win) == 0ull)
-				break;       // no fit of any block of this wave moved: later rounds would repeat this one
+			// the owner of the column takes its new total
+			CF_FRESH_LANE(lane);
+			if (lane == wl && L_CSLOT[18*CF_WG_THREADS] != 0xFFFFFFFFu)
+				L_CSLOT[18*CF_WG_THREADS] = L_CSLOT[15*CF_WG_THREADS] + L_CSLOT[16*CF_WG_THREADS] + L_CSLOT[17*CF_WG_THREADS];
+			__builtin_amdgcn_wave_barrier();
 		}
 	}
 	CF_FRESH_LANE(lane);
-	return pack_block_group(wc, (uint32_t)kmin, lane, pair);
+	const uint32_t win_id = cbase[win_lane + 19*CF_WG_THREADS];
+	return pack_block_group(cbase + win_lane, win_id, lane, pair);
+#undef H_ALPHA
 #undef B_TP
 #undef B_OFF
 #undef L_H

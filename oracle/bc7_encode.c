@@ -48,9 +48,13 @@ typedef struct {
 	sfit sca;        /* scalar (rotated alpha) fit for modes 4/5 */
 } cand;
 
-/* how hard one fit works: least-squares rounds, and the half-width of the quantised neighbourhood the
- * refit searches around the closed-form solution (0 = round each end on its own, refit_quantized) */
-typedef struct { int iters; int qwin; } fitopt;
+/* how one fit works: least-squares rounds; whether a refit round searches the quantised neighbourhood of
+ * the closed-form solution (refit_quantized) or rounds each end on its own; and where it starts: the
+ * extremes of the subset along its principal axis (start 0), or those pulled in (positive) / pushed out
+ * by a fraction of their distance -- the extremes are rarely the best ends of a palette whose outer
+ * entries serve the texels around them, and different starts end in different local minima */
+typedef struct { int iters; int qwin; int start; } fitopt;
+static const float cfo_start_frac[5] = {0.0f, 1.0f/16.0f, -1.0f/16.0f, 1.0f/8.0f, 3.0f/16.0f};
 
 static const uint8_t* weight_table(int ib)
 {
@@ -246,15 +250,16 @@ static int lsq(const int px[16][4], unsigned mask, const int bits[4], const sfit
 	return 1;
 }
 
-/* Least squares WITH the quantisation inside (qwin > 0).  With the selectors fixed the error of a
+/* Least squares WITH the quantisation inside (fitopt.qwin).  With the selectors fixed the error of a
  * channel is a quadratic in its two endpoints whose minimiser x* is the closed-form solution of lsq();
  * around it  E(e0, e1) - E(x*) = A d0^2 + 2 B d0 d1 + C d1^2  (d = e - x*, up to the 1/4096 scale and the
- * interpolation rounding).  Rounding each end of x* on its own ignores the cross term B; this routine
- * takes, per channel and per p-bit choice, the pair of quantised values within +-qwin steps of the
- * rounded x* that minimises the form, and the p-bit choice with the smallest weighted sum over the
- * channels.  Same sums as lsq(); float arithmetic in one fixed order. */
+ * interpolation rounding).  Rounding each end of x* on its own ignores the cross term B.  Here the
+ * p-bits and the centre of the search are still the plain rounding of the clamped x* (quantize_endpoints);
+ * then every channel takes, among the 3 x 3 pairs of quantised values within one step of that centre,
+ * the pair that minimises the form (scan order: end 0 outer, end 1 inner, -1, 0, +1; first minimum).
+ * Same sums as lsq(); float arithmetic in one fixed order (the kernel's refit_lane is its twin). */
 static int refit_quantized(const int px[16][4], unsigned mask, const int bits[4], int pbk,
-	const int wt[CFO_BC7_NW], const sfit* f, int qwin, sfit* out)
+	const int wt[CFO_BC7_NW], const sfit* f, sfit* out)
 {
 	int n = 0, S = 0, A = 0, B = 0, C = 0;
 	int U[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
@@ -278,84 +283,60 @@ static int refit_quantized(const int px[16][4], unsigned mask, const int bits[4]
 	float inv = 1.0f/(64.0f*(float)det);
 	float fA = (float)A, fB = (float)B, fC = (float)C;
 	float fB2 = fB + fB;
-	const int ncombo = pbk == 1 ? 4 : (pbk == 2 ? 2 : 1);
-	float total[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-	int bq[4][4][2];   /* [combo][channel][endpoint] */
+	float xu[2][4], xc[2][4];      /* unclamped (the form is centred there) and clamped solution */
+	for (int c = 0; c < 4; ++c) {
+		if (!bits[c]) {
+			xu[0][c] = xu[1][c] = xc[0][c] = xc[1][c] = 0.0f;
+			continue;
+		}
+		float fU = (float)U[c], fV = (float)V[c];
+		float t0 = fB*fV;
+		float n0 = fmaf(fC, fU, -t0);
+		float t1 = fB*fU;
+		float n1 = fmaf(fA, fV, -t1);
+		xu[0][c] = n0*inv;
+		xu[1][c] = n1*inv;
+		xc[0][c] = clamp255(xu[0][c]);
+		xc[1][c] = clamp255(xu[1][c]);
+	}
+	quantize_endpoints(xc, bits, pbk, wt, out);
 	for (int c = 0; c < 4; ++c) {
 		if (!bits[c])
 			continue;
-		float fU = (float)U[c], fV = (float)V[c];
-		float t0 = fB*fV;
-		float x0 = fmaf(fC, fU, -t0)*inv;      /* unclamped: the form is centred here */
-		float t1 = fB*fU;
-		float x1 = fmaf(fA, fV, -t1)*inv;
-		float xs[2] = {x0, x1};
-		for (int k = 0; k < ncombo; ++k) {
-			int pe[2];
-			pe[0] = pbk == 1 ? (k & 1) : (pbk == 2 ? k : 0);
-			pe[1] = pbk == 1 ? (k >> 1) : (pbk == 2 ? k : 0);
-			/* candidate quantised values and their deviations, per endpoint */
-			int cq[2][5], ncand[2];
-			float cd[2][5];
-			for (int e = 0; e < 2; ++e) {
-				int t = bits[c] + (pbk ? 1 : 0);
-				float sc = (float)((1 << t) - 1)/255.0f;
-				float y = clamp255(xs[e])*sc;
-				float u = pbk ? (y - (float)pe[e])*0.5f : y;
-				int qc = (int)floorf(u + 0.5f);
-				int qmax = (1 << bits[c]) - 1;
-				qc = qc < 0 ? 0 : (qc > qmax ? qmax : qc);
-				ncand[e] = 0;
-				for (int d = -qwin; d <= qwin; ++d) {
-					int q = qc + d;
-					if (q < 0 || q > qmax)
-						continue;
-					int dd = pbk ? dequant((q << 1) | pe[e], t) : dequant(q, t);
-					cq[e][ncand[e]] = q;
-					cd[e][ncand[e]] = (float)dd - xs[e];
-					++ncand[e];
+		const int t = bits[c] + (pbk ? 1 : 0), qmax = (1 << bits[c]) - 1;
+		float dl[2][3];          /* deviation of candidate d = -1, 0, +1 of each end */
+		int ok[2][3];
+		for (int e = 0; e < 2; ++e)
+			for (int d = 0; d < 3; ++d) {
+				int q = out->q[e][c] + d - 1;
+				ok[e][d] = q >= 0 && q <= qmax;
+				int dd = pbk ? dequant(((q < 0 ? 0 : q) << 1) | out->pb[e], t) : dequant(q < 0 ? 0 : q, t);
+				dl[e][d] = (float)dd - xu[e][c];
+			}
+		float best = 3.0e38f;
+		int b0 = 1, b1 = 1;
+		for (int i = 0; i < 3; ++i) {
+			float d0 = dl[0][i];
+			float a0 = fA*d0;
+			a0 = a0*d0;
+			float cr = fB2*d0;
+			for (int j = 0; j < 3; ++j) {
+				float d1 = dl[1][j];
+				float v = fC*d1;
+				v = fmaf(v, d1, a0);
+				v = fmaf(cr, d1, v);
+				if (ok[0][i] && ok[1][j] && v < best) {
+					best = v;
+					b0 = i;
+					b1 = j;
 				}
 			}
-			float best = 3.0e38f;
-			int b0 = cq[0][0], b1 = cq[1][0];
-			for (int i = 0; i < ncand[0]; ++i) {
-				float d0 = cd[0][i];
-				float a0 = fA*d0;
-				a0 = a0*d0;
-				float cr = fB2*d0;
-				for (int j = 0; j < ncand[1]; ++j) {
-					float d1 = cd[1][j];
-					float v = fC*d1;
-					v = fmaf(v, d1, a0);
-					v = fmaf(cr, d1, v);
-					if (v < best) {
-						best = v;
-						b0 = cq[0][i];
-						b1 = cq[1][j];
-					}
-				}
-			}
-			total[k] = fmaf((float)wt[c], best, total[k]);
-			bq[k][c][0] = b0;
-			bq[k][c][1] = b1;
 		}
+		out->q[0][c] += b0 - 1;
+		out->q[1][c] += b1 - 1;
+		out->e[0][c] = pbk ? dequant((out->q[0][c] << 1) | out->pb[0], t) : dequant(out->q[0][c], t);
+		out->e[1][c] = pbk ? dequant((out->q[1][c] << 1) | out->pb[1], t) : dequant(out->q[1][c], t);
 	}
-	int kb = 0;
-	for (int k = 1; k < ncombo; ++k)
-		if (total[k] < total[kb])
-			kb = k;
-	out->pb[0] = pbk == 1 ? (kb & 1) : (pbk == 2 ? kb : 0);
-	out->pb[1] = pbk == 1 ? (kb >> 1) : (pbk == 2 ? kb : 0);
-	for (int e = 0; e < 2; ++e)
-		for (int c = 0; c < 4; ++c) {
-			if (!bits[c]) {
-				out->q[e][c] = out->e[e][c] = 0;
-				continue;
-			}
-			int q = bq[kb][c][e];
-			out->q[e][c] = q;
-			out->e[e][c] = pbk ? dequant((q << 1) | out->pb[e], bits[c] + 1) : dequant(q, bits[c]);
-		}
 	return 1;
 }
 
@@ -433,6 +414,11 @@ static void fit_subset(const int px[16][4], const int wt[CFO_BC7_NW], unsigned m
 		tmin = fminf(tmin, t);
 		tmax = fmaxf(tmax, t);
 	}
+	if (fo->start) {
+		float d = (tmax - tmin)*cfo_start_frac[fo->start];
+		tmin = tmin + d;
+		tmax = tmax - d;
+	}
 	float x[2][4];
 	for (int a = 0; a < 4; ++a) {
 		x[0][a] = clamp255(fmaf(axis[a], tmin, mean[a]));
@@ -445,7 +431,7 @@ static void fit_subset(const int px[16][4], const int wt[CFO_BC7_NW], unsigned m
 	for (int r = 0; r < fo->iters; ++r) {
 		sfit cur;
 		if (fo->qwin) {
-			if (!refit_quantized(px, mask, bits, pbk, wt, best, fo->qwin, &cur))
+			if (!refit_quantized(px, mask, bits, pbk, wt, best, &cur))
 				break;
 		} else {
 			if (!lsq(px, mask, bits, best, x))
@@ -471,12 +457,17 @@ static void fit_scalar(const int px[16][4], const int wt[CFO_BC7_NW], int abits,
 		if (px[i][3] > hi) hi = px[i][3];
 	}
 	float x[2][4] = {{0, 0, 0, (float)lo}, {0, 0, 0, (float)hi}};
+	if (fo->start) {
+		float d = (x[1][3] - x[0][3])*cfo_start_frac[fo->start];
+		x[0][3] = clamp255(x[0][3] + d);
+		x[1][3] = clamp255(x[1][3] - d);
+	}
 	quantize_endpoints(x, bits, 0, wt, best);
 	assign(px, wt, 0xFFFF, bits, ib, best);
 	for (int r = 0; r < fo->iters; ++r) {
 		sfit cur;
 		if (fo->qwin) {
-			if (!refit_quantized(px, 0xFFFF, bits, 0, wt, best, fo->qwin, &cur))
+			if (!refit_quantized(px, 0xFFFF, bits, 0, wt, best, &cur))
 				break;
 		} else {
 			if (!lsq(px, 0xFFFF, bits, best, x))
@@ -658,13 +649,18 @@ static void eval_candidate(const int px[16][4], const int wt[CFO_BC7_NW], int id
 }
 
 
-/* ---- endpoint perturbation of the winner ("uber" levels of bc7enc, S3tcConverter.cpp:200-215) ----
- * Every fit of the winning candidate (subset, or the vector / scalar plane of modes 4 and 5) has 16
- * move slots m: endpoint m >> 3, channel (m >> 1) & 3, direction m & 1 -- +-1 on that quantised
- * field; the slots of a channel the fit does not code flip p-bits instead (endpoint-0 slots:
- * p-bit of endpoint `direction` for per-endpoint p-bits, both for a shared p-bit).  A round
- * scores all 16 moves of every fit with the exhaustive selector assignment and applies, per fit,
- * the best one if it lowers the fit's error (ties: lowest slot).  On the GPU lane = (fit, slot). */
+/* ---- endpoint perturbation ("uber" levels of bc7enc, S3tcConverter.cpp:200-215) ----
+ * Every fit of a candidate (subset, or the vector / scalar plane of modes 4 and 5) is moved on the
+ * quantised endpoint grid.  A move set has 16 slots m per fit:
+ *   set 0 (single):  endpoint m >> 3, channel (m >> 1) & 3, direction m & 1 -- +-1 on that field; the slots
+ *                    of a channel the fit does not code flip p-bits instead (endpoint-0 slots: p-bit of
+ *                    endpoint `direction` for per-endpoint p-bits, both for a shared p-bit);
+ *   set 1 (joint):   channel m >> 2, both ends of it by (+1,+1), (-1,-1), (+1,-1), (-1,+1) for m & 3 = 0..3:
+ *                    the palette of that channel shifted, widened or narrowed.
+ * A round walks the enabled sets in order; a set scores its 16 moves of every fit with the exhaustive
+ * selector assignment and applies, per fit, the best one if it lowers the fit's error (ties: lowest slot) --
+ * so the second set of a round starts from what the first left.  On the GPU lane = (fit, slot) and a set
+ * is one pass. */
 static void fit_geometry(const cand* c, int which, int bits[4], int* pbk, int* ib, unsigned* mask)
 {
 	const cfo_bc7_mode* m = &cfo_bc7_modes[c->mode];
@@ -691,7 +687,7 @@ static void fit_geometry(const cand* c, int which, int bits[4], int* pbk, int* i
 	}
 }
 
-static void uber_refine(const int px_in[16][4], const int wt_in[CFO_BC7_NW], cand* c, int rounds)
+static void uber_refine(const int px_in[16][4], const int wt_in[CFO_BC7_NW], cand* c, int rounds, int sets)
 {
 	int px[16][4], wt[CFO_BC7_NW];
 	memcpy(px, px_in, sizeof(px));
@@ -710,39 +706,55 @@ static void uber_refine(const int px_in[16][4], const int wt_in[CFO_BC7_NW], can
 	int nfits = planes ? 2 : c->ns;
 	for (int r = 0; r < rounds && c->err != 0; ++r) {
 		int any = 0;
-		for (int k = 0; k < nfits; ++k) {
-			sfit* f = planes ? (k ? &c->sca : &c->vec[0]) : &c->vec[k];
-			int bits[4], pbk, ib;
-			unsigned mask;
-			fit_geometry(c, k, bits, &pbk, &ib, &mask);
-			sfit bestf = *f;
-			for (int m = 0; m < 16; ++m) {
-				int e = m >> 3, ch = (m >> 1) & 3, up = m & 1;
-				sfit t = *f;
-				if (bits[ch]) {
-					int q = t.q[e][ch] + (up ? 1 : -1);
-					if (q < 0 || q > (1 << bits[ch]) - 1)
-						continue;
-					t.q[e][ch] = q;
-				} else if (pbk == 1 && e == 0)
-					t.pb[up] ^= 1;
-				else if (pbk == 2 && e == 0 && up == 0) {
-					t.pb[0] ^= 1;
-					t.pb[1] ^= 1;
-				} else
-					continue;
-				for (int ee = 0; ee < 2; ++ee)
-					for (int cc = 0; cc < 4; ++cc)
-						t.e[ee][cc] = !bits[cc] ? 0 : (pbk ? dequant((t.q[ee][cc] << 1) | t.pb[ee], bits[cc] + 1)
-							: dequant(t.q[ee][cc], bits[cc]));
-				assign(px, wt, mask, bits, ib, &t);
-				if (t.err < bestf.err)
-					bestf = t;
-			}
-			if (bestf.err < f->err) {
-				c->err -= f->err - bestf.err;
-				*f = bestf;
-				any = 1;
+		for (int set = 0; set < 2; ++set) {
+			if (!((sets >> set) & 1))
+				continue;
+			for (int k = 0; k < nfits; ++k) {
+				sfit* f = planes ? (k ? &c->sca : &c->vec[0]) : &c->vec[k];
+				int bits[4], pbk, ib;
+				unsigned mask;
+				fit_geometry(c, k, bits, &pbk, &ib, &mask);
+				sfit bestf = *f;
+				for (int m = 0; m < 16; ++m) {
+					sfit t = *f;
+					if (set == 1) {
+						const int ch = (m >> 2) & 3, k4 = m & 3;
+						if (!bits[ch])
+							continue;
+						const int d0 = (k4 == 0 || k4 == 2) ? 1 : -1, d1 = (k4 == 0 || k4 == 3) ? 1 : -1;
+						const int q0 = t.q[0][ch] + d0, q1 = t.q[1][ch] + d1, qm = (1 << bits[ch]) - 1;
+						if (q0 < 0 || q0 > qm || q1 < 0 || q1 > qm)
+							continue;
+						t.q[0][ch] = q0;
+						t.q[1][ch] = q1;
+					} else {
+						const int e = (m >> 3) & 1, ch = (m >> 1) & 3, up = m & 1;
+						if (bits[ch]) {
+							int q = t.q[e][ch] + (up ? 1 : -1);
+							if (q < 0 || q > (1 << bits[ch]) - 1)
+								continue;
+							t.q[e][ch] = q;
+						} else if (pbk == 1 && e == 0)
+							t.pb[up] ^= 1;
+						else if (pbk == 2 && e == 0 && up == 0) {
+							t.pb[0] ^= 1;
+							t.pb[1] ^= 1;
+						} else
+							continue;
+					}
+					for (int ee = 0; ee < 2; ++ee)
+						for (int cc = 0; cc < 4; ++cc)
+							t.e[ee][cc] = !bits[cc] ? 0 : (pbk ? dequant((t.q[ee][cc] << 1) | t.pb[ee], bits[cc] + 1)
+								: dequant(t.q[ee][cc], bits[cc]));
+					assign(px, wt, mask, bits, ib, &t);
+					if (t.err < bestf.err)
+						bestf = t;
+				}
+				if (bestf.err < f->err) {
+					c->err -= f->err - bestf.err;
+					*f = bestf;
+					any = 1;
+				}
 			}
 		}
 		if (!any)
@@ -853,41 +865,44 @@ static void pack(const cand* c, uint8_t out[16])
 			put(&b, (unsigned)sec[i], (unsigned)m->ib2 - (i == 0 ? 1u : 0u));
 }
 
-/* Search budget per Texture::Quality (S3tcConverter.cpp:170-227 / :600-620).  uber = rounds of
- * endpoint perturbation of the winner (bc7enc's m_uber_level is 0 up to Normal and 4 from High,
- * :200-215). */
+/* Search budget per Texture::Quality (S3tcConverter.cpp:170-227 / :600-620). */
 typedef struct {
-	int iters;      /* least-squares refit rounds per fit */
-	int qwin;       /* refit_quantized neighbourhood half-width (0: plain rounding) */
+	int iters;      /* least-squares refit rounds per fit; with any, the refit searches the quantised
+	                 * neighbourhood (refit_quantized) and the fit starts 1/16 inside the extremes */
 	int m6only, two, mode3, three, rot;
-	int uber;       /* rounds of endpoint perturbation */
-	int uber_top;   /* how many of the best candidates are perturbed (1: the winner only) */
-	int n1, n3, n7, n7low; /* partitions refitted per two-subset mode: opaque modes 1 / 3, alpha mode 7; one-mode (Low) count */
+	int n1, n3, n7, n7low;  /* partitions refitted per two-subset mode: opaque modes 1 / 3, alpha mode 7; one-mode (Low) count */
 	int n0, n2;     /* three-subset modes (only with `three`) */
+	/* refinement of the best candidates (bc7enc's m_uber_level is 1 at Normal and 4 from High,
+	 * :192-215): the `top` best in (error, id) order -- */
+	int top;
+	int starts;     /* -- are refitted from four more starts (fitopt.start 0, 2, 3, 4), each fit keeping its best, */
+	int uber;       /* -- are each perturbed for `uber` rounds with the move sets `sets` (uber_refine), */
+	int uber2;      /* -- and the best of them then for `uber2` more rounds */
+	int sets;
 } budget;
 
 static budget quality_budget(int quality)
 {
 	budget b;
 	memset(&b, 0, sizeof(b));
-	b.uber_top = 1;
 	b.n1 = 6; b.n3 = 5; b.n7 = 11; b.n7low = 14; b.n0 = 5; b.n2 = 5;
+	b.top = 1;
 	switch (quality) {
-		/* refit rounds: the second round is worth ~0.004 dB on photographic content, so it is
-		 * only spent from High up */
 		case 0: b.m6only = 1; break;
 		case 1: b.two = b.mode3 = b.rot = 1; break;   /* Low: Normal's candidate set without the refit round */
-		case 2: b.iters = 1; b.two = b.mode3 = b.rot = 1; break;
-		/* High: Normal's candidate set (half a wavefront per block), then two perturbation rounds
-		 * on the winner: +0.24 dB over Normal on the bench content, where the wider mode set High
-		 * used to walk bought +0.03 dB for four times the work (a second refit round before the
-		 * perturbation is worth 0.000 dB: the perturbation finds what it would have found) */
-		case 3: b.iters = 1; b.two = b.mode3 = b.rot = 1; b.uber = 2; break;
-		/* Highest: the wide set (mode 4, 16 two-subset partitions, the three-subset modes), two
-		 * refit rounds, three perturbation rounds (a third refit round or a fourth perturbation
-		 * round moves PSNR by 0.001 dB).  Refitting EVERY partition (what this level did before)
-		 * was worth 0.015 dB over this and cost five times the time. */
-		default: b.iters = 2; b.two = b.mode3 = b.three = b.rot = 1; b.uber = 3; b.n1 = b.n3 = 8; b.n7 = 16; break;
+		/* Normal: measured on the sampled blocks of tools/quality_tables.py against the wide search
+		 * (cfo_bc7_wide_search), opaque / alpha-carrying content: round 3's Normal (plain refit, no
+		 * refinement) was 0.41 / 0.49 dB under it; the quantisation-aware refit and the inset start
+		 * alone 0.30 / 0.25; with the four best candidates refitted from four more starts and one
+		 * perturbation round on the leader 0.09 / 0.05 */
+		case 2: b.iters = 1; b.two = b.mode3 = b.rot = 1; b.top = 4; b.starts = 1; b.uber = 0; b.uber2 = 1; b.sets = 1; break;
+		/* High: a perturbation round on each of the four as well, and the joint moves as a second set
+		 * of every round */
+		case 3: b.iters = 1; b.two = b.mode3 = b.rot = 1; b.top = 4; b.starts = 1; b.uber = 1; b.uber2 = 1; b.sets = 3; break;
+		/* Highest: the wide set (mode 4, 16 two-subset partitions, the three-subset modes), two refit
+		 * rounds, two perturbation rounds per candidate and two more on the leader */
+		default: b.iters = 2; b.two = b.mode3 = b.three = b.rot = 1; b.n1 = b.n3 = 8; b.n7 = 16;
+			b.top = 4; b.starts = 1; b.uber = 2; b.uber2 = 2; b.sets = 3; break;
 	}
 	return b;
 }
@@ -914,7 +929,7 @@ void cfo_bc7_weights(const cfo_params* p, int wt[CFO_BC7_NW])
 static void encode_block(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p, const budget* bp)
 {
 	const budget b = *bp;
-	const fitopt fo = {b.iters, b.qwin};
+	const fitopt fo = {b.iters, b.iters > 0, b.iters > 0 ? 1 : 0};
 	int px[16][4], wt[CFO_BC7_NW];
 	cfo_bc7_weights(p, wt);
 	int has_alpha = 0;
@@ -929,50 +944,47 @@ static void encode_block(const uint8_t rgba[64], uint8_t out[16], const cfo_para
 		if (!wt[c])
 			wt[c] = 1;
 
-	/* the best `ntop` candidates in (error, id) order; top[0] is the winner */
-	const int ntop = b.uber && b.uber_top > 1 ? (b.uber_top > CFO_BC7_MAXTOP ? CFO_BC7_MAXTOP : b.uber_top) : 1;
-	cand top[CFO_BC7_MAXTOP], cur;
-	int nheld = 0;
-	/* winner = min (error, id): evaluation order must not matter (phase 2 below visits
-	 * partitions in rank order, the kernel visits them lane-parallel) */
+	/* Every candidate is held by the lane that leads it in the kernel (a lane keeps the better of the
+	 * candidates it leads: only the wide layout of Highest gives one lane two, one per stream):
+	 *   mode 6: lane 0;  mode 5 / 4 candidate id: lane 1 + id;  partition slot s of the two-subset
+	 *   stream: lane 26 + 2 s (the 32-lane layouts: 10 + 2 s, or 4 + 2 s at Low), of the three-subset
+	 *   stream: lane 3 s.
+	 * The winner is the minimum of (error, id), so evaluation order does not matter. */
+	cand held[64], cur;
+	int used[64];
+	memset(used, 0, sizeof(used));
+	uint32_t best_err = 0xFFFFFFFFu;
 #define BETTER(c, b) ((c).err < (b).err || ((c).err == (b).err && (c).id < (b).id))
-#define TRY(ID) do { eval_candidate(px, wt, (ID), &fo, &cur); \
-	int pos_ = nheld; \
-	while (pos_ > 0 && BETTER(cur, top[pos_ - 1])) --pos_; \
-	if (pos_ < ntop) { \
-		int last_ = nheld < ntop ? nheld : ntop - 1; \
-		for (int k_ = last_; k_ > pos_; --k_) top[k_] = top[k_ - 1]; \
-		top[pos_] = cur; \
-		if (nheld < ntop) ++nheld; \
-	} } while (0)
-#define BEST_ERR (nheld ? top[0].err : 0xFFFFFFFFu)
-	TRY(0);
+#define TRY(ID, LANE) do { eval_candidate(px, wt, (ID), &fo, &cur); \
+	const int l_ = (LANE); \
+	if (!used[l_] || BETTER(cur, held[l_])) { held[l_] = cur; used[l_] = 1; } \
+	if (cur.err < best_err) best_err = cur.err; } while (0)
+	TRY(0, 0);
 	if (b.m6only) {
 		if (has_alpha)
-			TRY(1);
+			TRY(1, 2);
 	} else {
 		/* the perceptual metric couples R, G and B, so a plane split that moves a colour channel
 		 * into the scalar plane has no separable error: rotation 0 only (bc7enc does the same) */
 		int nrot = (b.rot && !wt[4]) ? 4 : 1;
 		for (int r = 0; r < nrot; ++r)
-			TRY(1 + r);
-		/* mode 4 (rotation x index selector): from High up (worth 0.012 dB on opaque and
+			TRY(1 + r, 2 + r);
+		/* mode 4 (rotation x index selector): Highest only (worth 0.012 dB on opaque and
 		 * 0.006 dB on alpha-carrying content; leaving it out lets the kernel fit a block's
 		 * whole candidate set into half a wavefront) */
 		if (b.rot && b.three)
 			for (int k = 0; k < 8; ++k)
 				if (!wt[4] || (k & 3) == 0)
-					TRY(5 + k);
-		/* Partitioned modes.  Highest refits every partition of every mode.  Below that
-		 * the search is two-phase per subset count (group): phase 1 scores every
+					TRY(5 + k, 6 + k);
+		/* Partitioned modes: two-phase per subset count (group).  Phase 1 scores every
 		 * partition with the residual estimator (partition_score; independent of the
 		 * mode), phase 2 runs the full fit with all refit rounds on the best partitions
 		 * of each mode of the group, ranked by (score bits with the low 6 bits cleared,
 		 * partition index):
-		 *   two-subset group:   Low and Normal: modes 1 / 3 with 6 / 5 (alpha: mode 7 with 11) -- a block
-		 *                       then needs 32 lanes: 2 + 8 + 22; High: modes 1 + 3 with 8 each
-		 *                       (alpha: mode 7 with 16)
-		 *   three-subset group: modes 0 (its 16 partitions) + 2 with 5 partitions each (High)
+		 *   two-subset group:   Low: one mode (1, or 7 with alpha) with 14; Normal, High: modes 1 / 3 with
+		 *                       6 / 5 (alpha: mode 7 with 11) -- a block then needs 32 lanes: 2 + 8 + 22;
+		 *                       Highest: modes 1 + 3 with 8 each (alpha: mode 7 with 16)
+		 *   three-subset group: modes 0 (its 16 partitions) + 2 with 5 partitions each (Highest)
 		 * The HIP kernel runs phase 1 with lane = partition and phase 2 of a whole group
 		 * in one pass with lane = (mode, rank, subset, row pair). */
 		if (b.two) {
@@ -981,7 +993,7 @@ static void encode_block(const uint8_t rgba[64], uint8_t out[16], const cfo_para
 			/* the three-subset modes are only tried on blocks the candidates so far leave with an
 			 * error of at least 48 (0.75 per channel-texel): three colour regions in a block that
 			 * already codes this well are rare, and the stream costs a third of Highest's time */
-			for (int g = 0; g < ngroups && BEST_ERR != 0 && (g == 0 || BEST_ERR >= 48u); ++g) {
+			for (int g = 0; g < ngroups && best_err != 0 && (g == 0 || best_err >= 48u); ++g) {
 				uint32_t key0[64];
 				for (int k = 0; k < 64; ++k) {
 					float sc = partition_score(px, 2 + g, k, bits);
@@ -1001,10 +1013,11 @@ static void encode_block(const uint8_t rgba[64], uint8_t out[16], const cfo_para
 					bases[nm] = 64; counts[nm] = 64; pers[nm++] = b.n1;
 					bases[nm] = 128; counts[nm] = 64; pers[nm++] = b.n3;
 				}
+				int slot = 0;
 				for (int mi = 0; mi < nm; ++mi) {
 					uint32_t key[64];
 					memcpy(key, key0, sizeof(key));
-					for (int r = 0; r < pers[mi]; ++r) {
+					for (int r = 0; r < pers[mi]; ++r, ++slot) {
 						int bk = -1;
 						for (int k = 0; k < counts[mi]; ++k)
 							if (key[k] != 0xFFFFFFFFu && (bk < 0 || key[k] < key[bk]))
@@ -1012,23 +1025,55 @@ static void encode_block(const uint8_t rgba[64], uint8_t out[16], const cfo_para
 						if (bk < 0)
 							break;
 						key[bk] = 0xFFFFFFFFu;
-						TRY(bases[mi] + bk);
+						TRY(bases[mi] + bk, g == 1 ? 3*slot : (b.three ? 26 : (b.mode3 ? 10 : 4)) + 2*slot);
 					}
 				}
 			}
 		}
 	}
 #undef TRY
-	int win = 0;
-	if (b.uber) {
-		for (int k = 0; k < nheld; ++k) {
-			uber_refine(px, wt, &top[k], b.uber);
-			if (BETTER(top[k], top[win]))
-				win = k;
-		}
+	/* the `top` best lanes in (error, id) order */
+	cand top[CFO_BC7_MAXTOP];
+	int ntop = 0;
+	for (; ntop < b.top && ntop < CFO_BC7_MAXTOP; ++ntop) {
+		int bl = -1;
+		for (int l = 0; l < 64; ++l)
+			if (used[l] && (bl < 0 || BETTER(held[l], held[bl])))
+				bl = l;
+		if (bl < 0)
+			break;
+		top[ntop] = held[bl];
+		used[bl] = 0;
 	}
+	/* more starts: every fit of every top candidate keeps the best of its starts (ties: the earlier) */
+	if (b.starts && top[0].err != 0) {
+		static const int variants[4] = {0, 2, 3, 4};
+		for (int k = 0; k < ntop; ++k)
+			for (int v = 0; v < 4; ++v) {
+				const fitopt fo2 = {b.iters, fo.qwin, variants[v]};
+				eval_candidate(px, wt, top[k].id, &fo2, &cur);
+				const int planes = top[k].mode == 4 || top[k].mode == 5;
+				for (int f = 0; f < top[k].ns; ++f)
+					if (cur.vec[f].err < top[k].vec[f].err) {
+						top[k].err -= top[k].vec[f].err - cur.vec[f].err;
+						top[k].vec[f] = cur.vec[f];
+					}
+				if (planes && cur.sca.err < top[k].sca.err) {
+					top[k].err -= top[k].sca.err - cur.sca.err;
+					top[k].sca = cur.sca;
+				}
+			}
+	}
+	int win = 0;
+	if (b.uber)
+		for (int k = 0; k < ntop; ++k)
+			uber_refine(px, wt, &top[k], b.uber, b.sets);
+	for (int k = 1; k < ntop; ++k)
+		if (BETTER(top[k], top[win]))
+			win = k;
+	if (b.uber2)
+		uber_refine(px, wt, &top[win], b.uber2, b.sets);
 #undef BETTER
-#undef BEST_ERR
 	pack(&top[win], out);
 }
 
@@ -1041,25 +1086,240 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 /* test-only: the block search with every budget field set by the caller (tools/bc7_lab.py measures what
  * each step of the search buys before it is given to a Texture::Quality level).  knobs = the budget
  * fields in declaration order. */
-void cfo_bc7_lab_block(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p, const int knobs[16])
+void cfo_bc7_lab_block(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p, const int knobs[17])
 {
 	budget b;
-	memset(&b, 0, sizeof(b));
-	b.iters = knobs[0]; b.qwin = knobs[1]; b.m6only = knobs[2]; b.two = knobs[3]; b.mode3 = knobs[4];
-	b.three = knobs[5]; b.rot = knobs[6]; b.uber = knobs[7]; b.uber_top = knobs[8];
-	b.n1 = knobs[9]; b.n3 = knobs[10]; b.n7 = knobs[11]; b.n7low = knobs[12]; b.n0 = knobs[13]; b.n2 = knobs[14];
+	int* f = (int*)&b;
+	for (unsigned i = 0; i < sizeof(b)/sizeof(int); ++i)
+		f[i] = knobs[i];
 	encode_block(rgba, out, p, &b);
 }
 
 
-/* ---- test-only: the WIDE search (tests/test_oracle_bounds.py) -------------------
- * Every candidate the format has -- mode 6; mode 5 x 4 rotations; mode 4 x 4 rotations x 2 index
- * selectors; modes 1, 3, 7 on all 64 two-subset partitions; mode 0 on its 16 and mode 2 on all 64
- * three-subset partitions -- each with the least squares iterated 8 rounds and 8 rounds of endpoint
- * perturbation applied to EVERY candidate, not only to the winner.  A few hundred times the work of
- * Texture::Quality::Highest: the bound the quality ladder is measured against ("gap to the wide
- * search"; it is built from the same fit routines, so it bounds the SEARCH, not the routines).
+/* ---- test-only: the WIDE search (tests/test_oracle_bounds.py, tools/quality_tables.py) ----
+ * The bound the quality ladder is measured against.  Every candidate the format has -- mode 6; mode 5 x
+ * 4 rotations; mode 4 x 4 rotations x 2 index selectors; modes 1, 3, 7 on all 64 two-subset partitions;
+ * mode 0 on its 16 and mode 2 on all 64 three-subset partitions -- and for every fit of every candidate
+ * an endpoint solver that is NOT the encoder's: steepest descent on the quantised endpoint grid under
+ * the exact error (ws_error below: the palette built from the specification's interpolation, every texel
+ * to its nearest entry -- written separately from assign()), from several starts:
+ *   - the encoder's own fit (PCA + 8 least-squares rounds), with plain and with quantisation-aware
+ *     rounding, so that the bound is never below what the encoder's routines reach on that candidate;
+ *   - the subset's bounding box, corner pairing by the sign of each channel's covariance with the
+ *     channel of largest variance, as is and pulled in by 1/16;
+ * moves per step: every endpoint field by -2 .. +2, both ends of a channel together by -1 .. +1 each,
+ * every p-bit flip alone and together with one field step of -1 .. +1; the best move is applied until
+ * none lowers the error.  A few thousand times the work of Texture::Quality::Highest.
  * Returns the smallest error found (the weighted SSE the encoder minimises) and the block. */
+static uint32_t ws_error(const int px[16][4], const int wt[CFO_BC7_NW], unsigned mask, const int bits[4],
+	int ib, const int e[2][4], uint8_t wsel[16])
+{
+	const uint8_t* wtab = weight_table(ib);
+	const int n = 1 << ib, ycc = wt[4] && bits[0];
+	int pal[16][4];
+	for (int k = 0; k < n; ++k) {
+		int c4[4] = {0, 0, 0, 0};
+		for (int c = 0; c < 4; ++c)
+			if (bits[c])
+				c4[c] = ((64 - wtab[k])*e[0][c] + wtab[k]*e[1][c] + 32) >> 6;
+		if (ycc)
+			to_ycc(c4, pal[k]);
+		else
+			memcpy(pal[k], c4, sizeof(c4));
+	}
+	uint32_t total = 0;
+	for (int i = 0; i < 16; ++i) {
+		if (!((mask >> i) & 1))
+			continue;
+		int t[4] = {bits[0] ? px[i][0] : 0, bits[1] ? px[i][1] : 0, bits[2] ? px[i][2] : 0, bits[3] ? px[i][3] : 0};
+		if (ycc) {
+			int u[4];
+			to_ycc(t, u);
+			memcpy(t, u, sizeof(t));
+		}
+		uint32_t best = 0xFFFFFFFFu;
+		int bk = 0;
+		for (int k = 0; k < n; ++k) {
+			uint32_t d = 0;
+			for (int c = 0; c < 4; ++c) {
+				if (!ycc && !bits[c])
+					continue;
+				int dd = t[c] - pal[k][c];
+				d += (uint32_t)((ycc ? wt[5 + c] : wt[c])*dd*dd);
+			}
+			if (d < best) {
+				best = d;
+				bk = k;
+			}
+		}
+		total += best;
+		if (wsel)
+			wsel[i] = wtab[bk];
+	}
+	return total;
+}
+
+static void ws_dequant(const int q[2][4], const int pb[2], const int bits[4], int pbk, int e[2][4])
+{
+	for (int k = 0; k < 2; ++k)
+		for (int c = 0; c < 4; ++c)
+			e[k][c] = !bits[c] ? 0 : (pbk ? dequant((q[k][c] << 1) | pb[k], bits[c] + 1) : dequant(q[k][c], bits[c]));
+}
+
+/* steepest descent from (q, pb); returns the error reached */
+static uint32_t ws_descend(const int px[16][4], const int wt[CFO_BC7_NW], unsigned mask, const int bits[4],
+	int pbk, int ib, int q[2][4], int pb[2])
+{
+	int e[2][4];
+	ws_dequant(q, pb, bits, pbk, e);
+	uint32_t cur = ws_error(px, wt, mask, bits, ib, e, NULL);
+	for (int step = 0; step < 256 && cur != 0; ++step) {
+		uint32_t best = cur;
+		int bq[2][4], bp[2] = {pb[0], pb[1]};
+		memcpy(bq, q, sizeof(bq));
+		/* p-bit patterns: none, flip 0, flip 1 (per-endpoint p-bits) or flip both (shared) */
+		const int nflip = pbk == 1 ? 3 : (pbk == 2 ? 2 : 1);
+		for (int fl = 0; fl < nflip; ++fl) {
+			int tp[2] = {pb[0], pb[1]};
+			if (fl && pbk == 1)
+				tp[fl - 1] ^= 1;
+			if (fl && pbk == 2) {
+				tp[0] ^= 1;
+				tp[1] ^= 1;
+			}
+			const int r = fl ? 1 : 2;      /* field steps that go with a flip: -1 .. +1 */
+			for (int c = 0; c < 4; ++c) {
+				if (!bits[c])
+					continue;
+				const int qmax = (1 << bits[c]) - 1;
+				for (int d0 = -r; d0 <= r; ++d0)
+					for (int d1 = -r; d1 <= r; ++d1) {
+						if (!fl && !d0 && !d1)
+							continue;
+						if (d0 && d1 && (d0 < -1 || d0 > 1 || d1 < -1 || d1 > 1))
+							continue;          /* joint moves of both ends: -1 .. +1 each */
+						int tq[2][4];
+						memcpy(tq, q, sizeof(tq));
+						tq[0][c] += d0;
+						tq[1][c] += d1;
+						if (tq[0][c] < 0 || tq[0][c] > qmax || tq[1][c] < 0 || tq[1][c] > qmax)
+							continue;
+						ws_dequant(tq, tp, bits, pbk, e);
+						uint32_t er = ws_error(px, wt, mask, bits, ib, e, NULL);
+						if (er < best) {
+							best = er;
+							memcpy(bq, tq, sizeof(bq));
+							bp[0] = tp[0];
+							bp[1] = tp[1];
+						}
+					}
+			}
+		}
+		if (best >= cur)
+			break;
+		cur = best;
+		memcpy(q, bq, sizeof(bq));
+		pb[0] = bp[0];
+		pb[1] = bp[1];
+	}
+	return cur;
+}
+
+/* the wide search's solver for one fit: best descent over the starts; fills *out */
+static void ws_solve(const int px[16][4], const int wt[CFO_BC7_NW], unsigned mask, const int bits[4],
+	int pbk, int ib, int scalar, sfit* out)
+{
+	sfit starts[4];
+	int ns = 0;
+	const fitopt plain = {8, 0, 0}, aware = {8, 1, 0};
+	if (scalar) {
+		fit_scalar(px, wt, bits[3], ib, &plain, &starts[ns++]);
+		fit_scalar(px, wt, bits[3], ib, &aware, &starts[ns++]);
+	} else {
+		fit_subset(px, wt, mask, bits, pbk, ib, &plain, &starts[ns++]);
+		fit_subset(px, wt, mask, bits, pbk, ib, &aware, &starts[ns++]);
+	}
+	/* bounding box starts */
+	int lo[4] = {255, 255, 255, 255}, hi[4] = {0, 0, 0, 0}, n = 0, sum[4] = {0, 0, 0, 0};
+	for (int i = 0; i < 16; ++i)
+		if ((mask >> i) & 1) {
+			++n;
+			for (int c = 0; c < 4; ++c) {
+				int v = bits[c] ? px[i][c] : 0;
+				sum[c] += v;
+				if (v < lo[c]) lo[c] = v;
+				if (v > hi[c]) hi[c] = v;
+			}
+		}
+	int amax = 0;
+	for (int c = 1; c < 4; ++c)
+		if (hi[c] - lo[c] > hi[amax] - lo[amax])
+			amax = c;
+	long cov[4] = {0, 0, 0, 0};
+	for (int i = 0; i < 16; ++i)
+		if ((mask >> i) & 1)
+			for (int c = 0; c < 4; ++c)
+				cov[c] += (long)(n*(bits[c] ? px[i][c] : 0) - sum[c])*(long)(n*(bits[amax] ? px[i][amax] : 0) - sum[amax]);
+	for (int inset = 0; inset < 2; ++inset) {
+		float x[2][4];
+		for (int c = 0; c < 4; ++c) {
+			float a = (float)lo[c], b = (float)hi[c];
+			float d = inset ? (b - a)*(1.0f/16.0f) : 0.0f;
+			a += d;
+			b -= d;
+			x[0][c] = cov[c] < 0 ? b : a;
+			x[1][c] = cov[c] < 0 ? a : b;
+		}
+		quantize_endpoints(x, bits, pbk, wt, &starts[ns++]);
+	}
+	uint32_t best = 0xFFFFFFFFu;
+	for (int k = 0; k < ns; ++k) {
+		int q[2][4], pb[2] = {starts[k].pb[0], starts[k].pb[1]};
+		memcpy(q, starts[k].q, sizeof(q));
+		uint32_t er = ws_descend(px, wt, mask, bits, pbk, ib, q, pb);
+		if (er < best) {
+			best = er;
+			memcpy(out->q, q, sizeof(q));
+			out->pb[0] = pb[0];
+			out->pb[1] = pb[1];
+		}
+		if (best == 0)
+			break;
+	}
+	ws_dequant(out->q, out->pb, bits, pbk, out->e);
+	memset(out->w, 0, sizeof(out->w));
+	out->err = ws_error(px, wt, mask, bits, ib, out->e, out->w);
+}
+
+/* solve every fit of a candidate whose geometry is set (mode, partition, rotation, index selector) */
+static void ws_candidate(const int px[16][4], const int wt[CFO_BC7_NW], cand* cur)
+{
+	int rp[16][4], rw[CFO_BC7_NW];
+	memcpy(rp, px, sizeof(rp));
+	memcpy(rw, wt, sizeof(rw));
+	const int planes = cur->mode == 4 || cur->mode == 5;
+	if (planes && cur->rot) {
+		for (int i = 0; i < 16; ++i) {
+			int t = rp[i][3];
+			rp[i][3] = rp[i][cur->rot - 1];
+			rp[i][cur->rot - 1] = t;
+		}
+		int t = rw[3];
+		rw[3] = rw[cur->rot - 1];
+		rw[cur->rot - 1] = t;
+	}
+	const int nfits = planes ? 2 : cur->ns;
+	cur->err = 0;
+	for (int k = 0; k < nfits; ++k) {
+		int bits[4], pbk, ib;
+		unsigned mask;
+		fit_geometry(cur, k, bits, &pbk, &ib, &mask);
+		sfit* f = planes ? (k ? &cur->sca : &cur->vec[0]) : &cur->vec[k];
+		ws_solve(rp, rw, mask, bits, pbk, ib, planes && k, f);
+		cur->err += f->err;
+	}
+}
+
 uint32_t cfo_bc7_wide_search(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p)
 {
 	int px[16][4], wt[CFO_BC7_NW];
@@ -1089,10 +1349,11 @@ uint32_t cfo_bc7_wide_search(const uint8_t rgba[64], uint8_t out[16], const cfo_
 			continue;                                  /* mode 7 spends bits on an alpha that is constant */
 		if (wt[4] && ((id >= 2 && id <= 4) || (id >= 5 && id <= 12 && ((id - 5) & 3))))
 			continue;                                  /* perceptual metric: rotation 0 only, as the encoder */
-		const fitopt fo = {8, 0};
-		eval_candidate(px, wt, id, &fo, &cur);
-		if (cur.err != 0)
-			uber_refine(px, wt, &cur, 8);
+		/* the candidate's geometry (mode, partition, rotation, index selector) from the encoder's table of
+		 * ids; its fits are then solved by ws_solve */
+		const fitopt geo = {0, 0, 0};
+		eval_candidate(px, wt, id, &geo, &cur);
+		ws_candidate(px, wt, &cur);
 		if (cur.err < best.err || (cur.err == best.err && cur.id < best.id))
 			best = cur;
 		if (best.err == 0)

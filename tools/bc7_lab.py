@@ -5,7 +5,7 @@ sampled blocks of tools/quality_tables.py and the gap to the wide search.
 
     python tools/bc7_lab.py [--blocks 2048] [--content opaque|alpha|both] name=knobs ...
 
-knobs: comma list iters,qwin,m6only,two,mode3,three,rot,uber,uber_top,n1,n3,n7,n7low,n0,n2
+knobs: name:value pairs over the budget fields (defaults = Texture::Quality::Normal), e.g. N4=top:4 H=top:4,sets:3
 """
 import argparse
 import ctypes
@@ -22,15 +22,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O          # noqa: E402
 from cuttlefish_amd import synth    # noqa: E402
 
-FIELDS = "iters,qwin,m6only,two,mode3,three,rot,uber,uber_top,n1,n3,n7,n7low,n0,n2".split(",")
-NORMAL = dict(iters=1, qwin=0, m6only=0, two=1, mode3=1, three=0, rot=1, uber=0, uber_top=1, n1=6, n3=5, n7=11,
-              n7low=14, n0=5, n2=5)
+FIELDS = "iters,m6only,two,mode3,three,rot,n1,n3,n7,n7low,n0,n2,top,starts,uber,uber2,sets".split(",")
+NORMAL = dict(iters=1, m6only=0, two=1, mode3=1, three=0, rot=1, n1=6, n3=5, n7=11, n7low=14, n0=5, n2=5,
+              top=3, starts=1, uber=1, uber2=1, sets=1)
 
 
 def knobs(**kw):
     d = dict(NORMAL)
     d.update(kw)
-    return [d[f] for f in FIELDS] + [0]
+    return [d[f] for f in FIELDS]
 
 
 def sample_blocks(img, count, rng):
@@ -124,7 +124,7 @@ def main():
                                                       psnr(wide, n) - psnr(sse, n) if wide else 0, dt))
         for name, kw in cfgs:
             p = O.make_params(36, 0, 2)
-            kn = (ctypes.c_int * 16)(*knobs(**kw))
+            kn = (ctypes.c_int * 17)(*knobs(**kw))
             t0 = time.time()
             sse = run(blocks, lambda b, o: L.cfo_bc7_lab_block(b, o, ctypes.byref(p), kn))
             dt = time.time() - t0

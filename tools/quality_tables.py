@@ -37,12 +37,15 @@ def psnr_from_sse(sse, n_values):
     return 10.0 * np.log10(255.0 ** 2 * n_values / max(sse, 1e-9))
 
 
-def bc7_gap(count, rng):
+def bc7_gap(count, rng, threads=None):
+    """-> [(label, [PSNR at Q0..Q4, PSNR of the wide search])] on `count` sampled blocks per content class."""
+    from concurrent.futures import ThreadPoolExecutor
     L = O.lib()
     L.cfo_bc7_wide_search.restype = ctypes.c_uint32
     L.cfo_bc7_wide_search.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(O.Params)]
     L.cfo_encode_bc7_block.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(O.Params)]
     L.cfo_decode_bc7.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    threads = threads or min(8, os.cpu_count() or 1)
     rows = []
     for label, alpha in (("opaque", False), ("with alpha", True)):
         img = synth.photo(512, 512, seed=21)
@@ -50,21 +53,25 @@ def bc7_gap(count, rng):
             img[..., 3] = synth.photo(512, 512, seed=22)[..., 0]      # alpha that varies in every block
         else:
             img[..., 3] = 255
-        blocks = sample_blocks(img, count, rng).astype(np.uint8)
-        out = np.zeros(16, np.uint8)
-        dec = np.zeros(64, np.uint8)
-        sse = np.zeros(6)
-        for blk in blocks:
-            b = np.ascontiguousarray(blk.reshape(-1))
-            for q in range(5):
-                p = O.make_params(36, 0, q)
-                L.cfo_encode_bc7_block(b.ctypes.data, out.ctypes.data, ctypes.byref(p))
-                L.cfo_decode_bc7(out.ctypes.data, dec.ctypes.data)
-                sse[q] += float(((dec.astype(np.int64) - b.astype(np.int64)) ** 2).sum())
-            p = O.make_params(36, 0, 4)
-            L.cfo_bc7_wide_search(b.ctypes.data, out.ctypes.data, ctypes.byref(p))
-            L.cfo_decode_bc7(out.ctypes.data, dec.ctypes.data)
-            sse[5] += float(((dec.astype(np.int64) - b.astype(np.int64)) ** 2).sum())
+        blocks = np.ascontiguousarray(sample_blocks(img, count, rng).astype(np.uint8).reshape(count, 64))
+
+        def work(lo, hi):
+            out = np.zeros(16, np.uint8)
+            dec = np.zeros(64, np.uint8)
+            sse = np.zeros(6)
+            for b in blocks[lo:hi]:
+                for q in range(6):
+                    p = O.make_params(36, 0, min(q, 4))
+                    if q < 5:
+                        L.cfo_encode_bc7_block(b.ctypes.data, out.ctypes.data, ctypes.byref(p))
+                    else:
+                        L.cfo_bc7_wide_search(b.ctypes.data, out.ctypes.data, ctypes.byref(p))
+                    L.cfo_decode_bc7(out.ctypes.data, dec.ctypes.data)     # the ctypes calls release the GIL
+                    sse[q] += float(((dec.astype(np.int64) - b.astype(np.int64)) ** 2).sum())
+            return sse
+        step = (count + threads - 1) // threads
+        with ThreadPoolExecutor(threads) as ex:
+            sse = sum(ex.map(lambda k: work(k * step, min(count, (k + 1) * step)), range(threads)))
         rows.append((label, [psnr_from_sse(s, count * 64) for s in sse]))
     return rows
 
