@@ -128,6 +128,43 @@ def cpu_baseline(img, gpu_payload, width, quality, budget_s=12.0):
     }
 
 
+PCIE_GBPS = 63.0             # x16 Gen5, one direction (MI355X_MICROARCH.md host link)
+
+
+def end_to_end(ctx, img, params, device_payload, kernel_ms, reps=5):
+    """The REAL boundary: cfhip_encode on host buffers -- upload, kernels, download, sync -- for
+    the two layouts a Converter can hand over: the RGBA32F bottom-up scanlines of an Image (Converter.h:52-56,
+    Image.cpp:340-343: 16 B/px, negative pitch; quantised to UNORM8 by host threads with toColorBlock's
+    arithmetic, S3tcConverter.cpp:97-111, while earlier strips upload and encode) and RGBA8.  Timed after the
+    headline loop, never part of `value`."""
+    import numpy as np
+    n = img.shape[0] * img.shape[1]
+    out = {}
+    imgf = np.ascontiguousarray((img.astype(np.float32) / 255.0)[::-1])[::-1]     # bottom-up storage, top-down view
+    assert imgf.strides[0] < 0
+    for name, src, bpp in (("rgba32f_bottom_up", imgf, 16), ("rgba8", img, 4)):
+        got = ctx.encode([src], params)[0]          # first call: pinned buffers, worker pool
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            got = ctx.encode([src], params)[0]
+            ts.append(time.perf_counter() - t0)
+        dt = min(ts)
+        wire = n * 4 + got.nbytes                  # what crosses PCIe: UNORM8 texels up, payload down
+        floor_pcie = max(n * 4, got.nbytes) / (PCIE_GBPS * 1e9) * 1e3     # full duplex: the larger direction
+        floor = max(floor_pcie, kernel_ms)
+        out[name] = {"ms": round(dt * 1e3, 3), "ms_median": round(sorted(ts)[len(ts) // 2] * 1e3, 3),
+                     "mpix_s": round(n / dt / 1e6, 1), "host_bytes_read": n * bpp, "pcie_bytes": int(wire),
+                     "pcie_floor_ms": round(floor_pcie, 3), "kernel_ms": round(kernel_ms, 3),
+                     "x_floor": round(dt * 1e3 / floor, 3),
+                     "payload_equals_device_path": bool(np.array_equal(got, device_payload))}
+    out["note"] = ("floor = max(PCIe at %.0f GB/s for the larger direction, kernel time): the pipeline overlaps host "
+                   "gather / quantise, upload, encode and download, so the slowest stage bounds it; raw RGBA32F over "
+                   "PCIe would be %d MB = %.2f ms" % (PCIE_GBPS, n * 16 // 1000000, n * 16 / (PCIE_GBPS * 1e9) * 1e3))
+    out["host_threads"] = usable_cpus()
+    return out
+
+
 def _cached_photo(synth, size, seed):
     """synth.photo takes ~40 s for 4096x4096 (single-threaded numpy): keep the deterministic tile
     in a git-ignored cache next to the repo so that back-to-back runs (N = 1, 2, 4, 8) reuse it.
@@ -656,6 +693,9 @@ def run_c2(args, rank, local_rank, world, backend):
             line["cpu_baseline"] = cpu_baseline(img, payload, size, args.quality)
         else:
             line["cpu_baseline"] = None
+        if world == 1 and not args.no_end_to_end:
+            torch.cuda.synchronize()
+            line["end_to_end"] = end_to_end(ctx, img, params, out.cpu().numpy(), avg_kernel_s * 1e3)
         if world > 1 and not args.no_strong:
             strong = guarded_strong(line)
         if strong is not None:
@@ -675,6 +715,7 @@ def main():
     ap.add_argument("--textures", type=int, default=256, help="c5: textures in the array")
     ap.add_argument("--tex-size", type=int, default=2048, help="c5: base level size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="c2, N = 1: skip the host-buffer (PCIe-inclusive) leg")
     ap.add_argument("--no-strong", action="store_true", help="c2, N > 1: skip the row-split strong-scaling leg")
     args = ap.parse_args()
     if args.steps is None:

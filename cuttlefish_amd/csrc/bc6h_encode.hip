@@ -709,7 +709,7 @@ cfhip_bc6h_encode_kernel(cf_kparams kp)
 	// the wave index as a scalar: block indices, tile pointers and edge tests live in SGPRs
 	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
 	const uint32_t quality = kp.quality;
-	const uint32_t iters = quality <= 1u ? 0u : (quality == 2u ? 1u : (quality == 3u ? 2u : 3u));
+	const uint32_t iters = quality <= 1u ? 0u : (quality == 2u ? 2u : (quality == 3u ? 3u : 4u));   // oracle: cfo_encode_bc6h_block
 	// Schedule of a workgroup's 16 blocks (33 candidates each: one one-subset fit, 32 partitions
 	// of two fits):
 	//   wavefront 0, lanes 0..15: the one-subset candidate of all 16 blocks, parked in cand_lds

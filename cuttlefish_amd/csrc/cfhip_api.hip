@@ -20,6 +20,10 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <condition_variable>
+#include <functional>
+#include <sched.h>
+#include <immintrin.h>
 
 extern "C" hipError_t cfhip_launch_bc7(const cf_kparams* kp, int pixel_type, int unit_weights,
 	hipStream_t stream);
@@ -49,6 +53,80 @@ extern "C" hipError_t cfhip_launch_std_pack(const cf_kparams* kp, int pixel_type
 extern "C" hipError_t cfhip_launch_bc15(const cf_kparams* kp, int format, int pixel_type,
 	int snorm, hipStream_t stream);
 
+// Host worker pool of the pipelined host path: the threads live as long as the context (the reference
+// creates and joins its worker threads per surface, Converter.cpp:557-583; per STRIP that would be tens of
+// thread creations per call).  run(parts, fn) calls fn(part) for part = 0 .. parts-1, part 0 on the caller.
+struct cf_host_pool {
+	std::vector<std::thread> threads;
+	std::mutex m;
+	std::condition_variable wake, done;
+	std::function<void(unsigned)> job;
+	unsigned parts = 0, next = 0, pending = 0, generation = 0;
+	bool stop = false;
+
+	void worker()
+	{
+		unsigned seen = 0;
+		std::unique_lock<std::mutex> lk(m);
+		for (;;) {
+			wake.wait(lk, [&] { return stop || generation != seen; });
+			if (stop)
+				return;
+			seen = generation;
+			while (next < parts) {
+				const unsigned part = next++;
+				lk.unlock();
+				job(part);
+				lk.lock();
+				if (--pending == 0)
+					done.notify_all();
+			}
+		}
+	}
+	void start(unsigned n)
+	{
+		for (unsigned i = 0; i < n; ++i)
+			threads.emplace_back(&cf_host_pool::worker, this);
+	}
+	void run(unsigned nparts, const std::function<void(unsigned)>& fn)
+	{
+		if (nparts <= 1 || threads.empty()) {
+			for (unsigned i = 0; i < nparts; ++i)
+				fn(i);
+			return;
+		}
+		std::unique_lock<std::mutex> lk(m);
+		job = fn;
+		parts = nparts;
+		next = 1;                 // part 0 runs here
+		pending = nparts;
+		++generation;
+		wake.notify_all();
+		lk.unlock();
+		fn(0);
+		lk.lock();
+		while (next < parts) {    // help with what is left
+			const unsigned part = next++;
+			lk.unlock();
+			fn(part);
+			lk.lock();
+			--pending;
+		}
+		--pending;                // part 0
+		done.wait(lk, [&] { return pending == 0; });
+	}
+	~cf_host_pool()
+	{
+		{
+			std::lock_guard<std::mutex> lk(m);
+			stop = true;
+		}
+		wake.notify_all();
+		for (std::thread& t : threads)
+			t.join();
+	}
+};
+
 struct cfhip_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
@@ -58,9 +136,18 @@ struct cfhip_ctx {
 	size_t out_cap = 0;
 	void* d_batch = nullptr;          // cf_batch_entry[] of the current batched launch
 	size_t batch_cap = 0;
-	void* h_pin[2] = {nullptr, nullptr};   // pinned strip slots of the pipelined host path
+	// pipelined host path: pinned strip slots, their events, the two copy streams beside `stream`, the pinned
+	// payload buffer and the worker pool
+	static constexpr int kPinSlots = 3;
+	void* h_pin[kPinSlots] = {nullptr, nullptr, nullptr};
 	size_t pin_cap = 0;
-	hipEvent_t pin_free[2] = {nullptr, nullptr};   // slot's upload has left the host buffer
+	hipEvent_t pin_free[kPinSlots] = {nullptr, nullptr, nullptr};   // slot's upload has left the host buffer
+	hipEvent_t up_done[kPinSlots] = {nullptr, nullptr, nullptr};    // ... and arrived: the strip's kernel may start
+	std::vector<hipEvent_t> strip_events;   // per strip: kernel finished / payload landed (grown on demand, reused)
+	hipStream_t up_stream = nullptr, down_stream = nullptr;
+	void* h_out = nullptr;            // pinned landing buffer of the payload (the caller's buffer is pageable)
+	size_t h_out_cap = 0;
+	cf_host_pool* pool = nullptr;
 	// d_src / d_out / d_batch are shared by every entry point, and calls on a caller's stream
 	// return without synchronising: the last asynchronous user records this event and a call on
 	// ANOTHER stream waits for it before touching the buffers (same-stream reuse is ordered anyway)
@@ -626,9 +713,39 @@ inline uint8_t host_unorm8(float f)
 	return (uint8_t)roundf(f*255.0f);
 }
 
+// 8 floats -> 8 UNORM8 bytes with the arithmetic of host_unorm8, exactly: clamp (NaN -> 0: maxps returns its
+// second operand when one is NaN), times 255, round half away from zero as trunc(x) + (x - trunc(x) >= 0.5)
+// (x + 0.5 would round up at x = 0.5 - 2^-25), all exact in float for x in [0, 255].
+__attribute__((target("avx2")))
+void quantise_row_avx2(const float* f, uint8_t* d, size_t nv)
+{
+	const __m256 zero = _mm256_setzero_ps(), one = _mm256_set1_ps(1.0f), k255 = _mm256_set1_ps(255.0f),
+		half = _mm256_set1_ps(0.5f);
+	size_t i = 0;
+	for (; i + 32 <= nv; i += 32) {
+		__m256i r[4];
+		for (int k = 0; k < 4; ++k) {
+			__m256 v = _mm256_loadu_ps(f + i + 8*k);
+			v = _mm256_min_ps(_mm256_max_ps(v, zero), one);
+			v = _mm256_mul_ps(v, k255);
+			const __m256 t = _mm256_round_ps(v, _MM_FROUND_TO_ZERO | _MM_FROUND_NO_EXC);
+			const __m256 up = _mm256_and_ps(_mm256_cmp_ps(_mm256_sub_ps(v, t), half, _CMP_GE_OQ), one);
+			r[k] = _mm256_cvttps_epi32(_mm256_add_ps(t, up));
+		}
+		// 32 x i32 -> 32 x u8 in order: the packs work per 128-bit lane, one permute restores the order
+		const __m256i p01 = _mm256_packus_epi32(r[0], r[1]), p23 = _mm256_packus_epi32(r[2], r[3]);
+		__m256i b = _mm256_packus_epi16(p01, p23);
+		b = _mm256_permutevar8x32_epi32(b, _mm256_setr_epi32(0, 4, 1, 5, 2, 6, 3, 7));
+		_mm256_storeu_si256(reinterpret_cast<__m256i*>(d + i), b);
+	}
+	for (; i < nv; ++i)
+		d[i] = host_unorm8(f[i]);
+}
+
 void stage_rows(const cfhip_surface& s, uint32_t y0, uint32_t y1, size_t row_bytes, bool quantise,
 	uint8_t* dst, size_t dst_pitch)
 {
+	static const bool avx2 = __builtin_cpu_supports("avx2");
 	const uint8_t* base = static_cast<const uint8_t*>(s.pixels);
 	for (uint32_t y = y0; y < y1; ++y) {
 		const uint8_t* src = base + (ptrdiff_t)y*s.row_pitch_bytes;
@@ -638,12 +755,43 @@ void stage_rows(const cfhip_surface& s, uint32_t y0, uint32_t y1, size_t row_byt
 		else {
 			const float* f = reinterpret_cast<const float*>(src);
 			const size_t nv = (size_t)s.width*4u;
-			for (size_t i = 0; i < nv; ++i)
-				d[i] = host_unorm8(f[i]);
+			if (avx2)
+				quantise_row_avx2(f, d, nv);
+			else
+				for (size_t i = 0; i < nv; ++i)
+					d[i] = host_unorm8(f[i]);
 		}
 	}
 }
 
+// host threads this process may really use: the scheduler affinity capped by the cgroup CPU quota
+// (hardware_concurrency() reports the machine, not the container's share)
+unsigned usable_cpus()
+{
+	unsigned n = std::max(1u, std::thread::hardware_concurrency());
+	cpu_set_t set;
+	if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+		const int c = CPU_COUNT(&set);
+		if (c > 0)
+			n = std::min(n, (unsigned)c);
+	}
+	if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+		char a[32] = {0};
+		long long period = 0;
+		if (std::fscanf(f, "%31s %lld", a, &period) == 2 && std::strcmp(a, "max") != 0 && period > 0) {
+			const long long quota = std::atoll(a);
+			if (quota > 0)
+				n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, quota/period));
+		}
+		std::fclose(f);
+	}
+	return std::max(1u, n);
+}
+
+// Strips of whole block rows flow through four overlapped stages: host threads gather (and quantise) strip
+// k+2 into a pinned slot | the upload stream copies strip k+1 | the launch stream encodes strip k | the
+// download stream returns the payload of strip k-1 into a pinned landing buffer.  Three pinned slots; events
+// order slot reuse (pin_free), upload -> kernel (up_done) and kernel -> download (one pair per strip).
 int encode_host_pipelined(cfhip_ctx* ctx, const cfhip_surface& s, const cfhip_params& p,
 	hipStream_t stream)
 {
@@ -656,9 +804,11 @@ int encode_host_pipelined(cfhip_ctx* ctx, const cfhip_surface& s, const cfhip_pa
 	const size_t src_row = (size_t)s.width*pixel_bytes(s.pixel_type);
 	const uint32_t bx = (s.width + (uint32_t)fbw - 1u)/(uint32_t)fbw;
 	const uint32_t by = (s.height + (uint32_t)fbh - 1u)/(uint32_t)fbh;
-	// strips of whole block rows, ~8 MB of device pixels each, at least 4 of them
-	uint32_t strip_brows = (uint32_t)std::max<size_t>(1, ((size_t)8 << 20)/(dev_row*(size_t)fbh));
-	strip_brows = std::min(strip_brows, std::max(1u, by/4u));
+	const size_t out_bytes = (size_t)bx*by*(size_t)bs;
+	// strips of whole block rows, ~4 MB of device pixels each, at least 8 of them: short enough that the
+	// pipeline's fill (first strip staged and uploaded before anything is encoded) and drain stay small
+	uint32_t strip_brows = (uint32_t)std::max<size_t>(1, ((size_t)4 << 20)/(dev_row*(size_t)fbh));
+	strip_brows = std::min(strip_brows, std::max(1u, by/8u));
 	if (is_std_format(p.format))
 		strip_brows = (strip_brows + 3u) & ~3u;   // every strip's output stays 4-byte aligned
 	const size_t strip_bytes = (size_t)strip_brows*(size_t)fbh*dev_row;
@@ -666,56 +816,122 @@ int encode_host_pipelined(cfhip_ctx* ctx, const cfhip_surface& s, const cfhip_pa
 	if (rc != CFHIP_OK) return rc;
 	rc = reserve(ctx, &ctx->d_src, &ctx->src_cap, dev_row*(size_t)s.height);
 	if (rc != CFHIP_OK) return rc;
-	rc = reserve(ctx, &ctx->d_out, &ctx->out_cap, (size_t)bx*by*(size_t)bs);
+	rc = reserve(ctx, &ctx->d_out, &ctx->out_cap, out_bytes);
 	if (rc != CFHIP_OK) return rc;
+	constexpr int NS = cfhip_ctx::kPinSlots;
+	if (!ctx->up_stream) {
+		HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+		HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
+		for (int i = 0; i < NS; ++i) {
+			HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pin_free[i], hipEventDisableTiming));
+			HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->up_done[i], hipEventDisableTiming));
+		}
+	}
 	if (ctx->pin_cap < strip_bytes) {
-		for (int i = 0; i < 2; ++i) {
+		for (int i = 0; i < NS; ++i) {
 			if (ctx->h_pin[i]) { HIP_TRY(ctx, hipHostFree(ctx->h_pin[i])); ctx->h_pin[i] = nullptr; }
 			HIP_TRY(ctx, hipHostMalloc(&ctx->h_pin[i], strip_bytes, hipHostMallocDefault));
-			if (!ctx->pin_free[i])
-				HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pin_free[i], hipEventDisableTiming));
 		}
 		ctx->pin_cap = strip_bytes;
 	}
-	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-	const unsigned nthreads = std::min(16u, hw);
-	uint32_t slot_used[2] = {0, 0};
+	if (ctx->h_out_cap < out_bytes) {
+		if (ctx->h_out) { HIP_TRY(ctx, hipHostFree(ctx->h_out)); ctx->h_out = nullptr; ctx->h_out_cap = 0; }
+		HIP_TRY(ctx, hipHostMalloc(&ctx->h_out, out_bytes, hipHostMallocDefault));
+		ctx->h_out_cap = out_bytes;
+	}
+	if (!ctx->pool) {
+		ctx->pool = new (std::nothrow) cf_host_pool;
+		if (!ctx->pool)
+			return fail(ctx, CFHIP_E_DEVICE, "host worker pool: out of memory");
+		ctx->pool->start(std::min(32u, usable_cpus()) - 1u);      // the calling thread is a worker too
+	}
+	const unsigned nthreads = (unsigned)ctx->pool->threads.size() + 1u;
+	uint32_t slot_used[NS] = {0, 0, 0};
+	uint8_t* hout = static_cast<uint8_t*>(ctx->h_out);
+	uint8_t* user_out = static_cast<uint8_t*>(s.out);
+	// payload that has landed in h_out is copied to the caller's buffer by this thread while it waits for a slot
+	struct Landed { size_t off, bytes; hipEvent_t ev; };
+	std::vector<Landed> landing;
+	size_t landed = 0;
+	size_t ev_used = 0;
+	auto next_event = [&](hipEvent_t* ev) -> int {
+		if (ev_used == ctx->strip_events.size()) {
+			hipEvent_t e;
+			HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+			ctx->strip_events.push_back(e);
+		}
+		*ev = ctx->strip_events[ev_used++];
+		return CFHIP_OK;
+	};
+	{
+		// the copy streams start after whatever the launch stream was asked to wait for (staging_acquire)
+		hipEvent_t order;
+		rc = next_event(&order);
+		if (rc != CFHIP_OK) return rc;
+		HIP_TRY(ctx, hipEventRecord(order, stream));
+		HIP_TRY(ctx, hipStreamWaitEvent(ctx->up_stream, order, 0));
+		HIP_TRY(ctx, hipStreamWaitEvent(ctx->down_stream, order, 0));
+	}
+	auto drain = [&](bool all) -> int {
+		while (landed < landing.size()) {
+			const Landed& l = landing[landed];
+			if (all)
+				HIP_TRY(ctx, hipEventSynchronize(l.ev));
+			else if (hipEventQuery(l.ev) != hipSuccess)
+				break;
+			std::memcpy(user_out + l.off, hout + l.off, l.bytes);
+			++landed;
+		}
+		return CFHIP_OK;
+	};
 	uint32_t k = 0;
 	for (uint32_t br0 = 0; br0 < by; br0 += strip_brows, ++k) {
 		const uint32_t br1 = std::min(by, br0 + strip_brows);
 		const uint32_t y0 = br0*(uint32_t)fbh, y1 = std::min(s.height, br1*(uint32_t)fbh);
-		const int slot = (int)(k & 1u);
+		const int slot = (int)(k % (uint32_t)NS);
 		if (slot_used[slot])
 			HIP_TRY(ctx, hipEventSynchronize(ctx->pin_free[slot]));
 		uint8_t* pin = static_cast<uint8_t*>(ctx->h_pin[slot]);
-		// stage rows [y0, y1) with the host threads
+		// stage rows [y0, y1) with the pool
 		const uint32_t rows = y1 - y0;
 		const unsigned nt = std::min<unsigned>(nthreads, rows);
-		std::vector<std::thread> workers;
-		workers.reserve(nt);
-		for (unsigned t = 1; t < nt; ++t) {
+		ctx->pool->run(nt, [&](unsigned t) {
 			const uint32_t a = y0 + (uint32_t)((unsigned long long)rows*t/nt);
 			const uint32_t b = y0 + (uint32_t)((unsigned long long)rows*(t + 1)/nt);
-			workers.emplace_back(stage_rows, std::cref(s), a, b, src_row, quantise,
-				pin + (size_t)(a - y0)*dev_row, dev_row);
-		}
-		stage_rows(s, y0, y0 + (uint32_t)((unsigned long long)rows/nt), src_row, quantise, pin, dev_row);
-		for (std::thread& w : workers)
-			w.join();
+			stage_rows(s, a, b, src_row, quantise, pin + (size_t)(a - y0)*dev_row, dev_row);
+		});
 		uint8_t* dsrc = static_cast<uint8_t*>(ctx->d_src) + (size_t)y0*dev_row;
-		HIP_TRY(ctx, hipMemcpyAsync(dsrc, pin, (size_t)rows*dev_row, hipMemcpyHostToDevice, stream));
-		HIP_TRY(ctx, hipEventRecord(ctx->pin_free[slot], stream));
+		HIP_TRY(ctx, hipMemcpyAsync(dsrc, pin, (size_t)rows*dev_row, hipMemcpyHostToDevice, ctx->up_stream));
+		HIP_TRY(ctx, hipEventRecord(ctx->pin_free[slot], ctx->up_stream));
+		HIP_TRY(ctx, hipEventRecord(ctx->up_done[slot], ctx->up_stream));
 		slot_used[slot] = 1;
+		HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->up_done[slot], 0));
 		cf_kparams kp;
-		fill_kparams(kp, p, dsrc, static_cast<uint8_t*>(ctx->d_out) + (size_t)br0*bx*(size_t)bs,
-			(long long)dev_row, s.width, rows);
+		const size_t out_off = (size_t)br0*bx*(size_t)bs, out_n = (size_t)(br1 - br0)*bx*(size_t)bs;
+		fill_kparams(kp, p, dsrc, static_cast<uint8_t*>(ctx->d_out) + out_off, (long long)dev_row, s.width, rows);
 		rc = timed_launch(ctx, kp, p, dev_type, stream);
 		if (rc != CFHIP_OK)
 			return rc;
+		// the strip's payload leaves on the download stream as soon as its kernel is done
+		hipEvent_t enc, down;
+		rc = next_event(&enc);
+		if (rc != CFHIP_OK) return rc;
+		rc = next_event(&down);
+		if (rc != CFHIP_OK) return rc;
+		HIP_TRY(ctx, hipEventRecord(enc, stream));
+		HIP_TRY(ctx, hipStreamWaitEvent(ctx->down_stream, enc, 0));
+		HIP_TRY(ctx, hipMemcpyAsync(hout + out_off, static_cast<uint8_t*>(ctx->d_out) + out_off, out_n,
+			hipMemcpyDeviceToHost, ctx->down_stream));
+		HIP_TRY(ctx, hipEventRecord(down, ctx->down_stream));
+		landing.push_back({out_off, out_n, down});
+		rc = drain(false);
+		if (rc != CFHIP_OK)
+			return rc;
 	}
-	HIP_TRY(ctx, hipMemcpyAsync(s.out, ctx->d_out, (size_t)bx*by*(size_t)bs, hipMemcpyDeviceToHost,
-		stream));
+	rc = drain(true);
 	HIP_TRY(ctx, hipStreamSynchronize(stream));
+	if (rc != CFHIP_OK)
+		return rc;
 	ctx->staging_busy = false;
 	return CFHIP_OK;
 }
@@ -779,10 +995,17 @@ void cfhip_destroy(cfhip_ctx* ctx)
 		(void)hipEventDestroy(ev);
 	for (auto& kv : ctx->astc_tables)
 		if (kv.second) (void)hipFree(kv.second);
-	for (int i = 0; i < 2; ++i) {
+	delete ctx->pool;
+	if (ctx->up_stream) { (void)hipStreamSynchronize(ctx->up_stream); (void)hipStreamDestroy(ctx->up_stream); }
+	if (ctx->down_stream) { (void)hipStreamSynchronize(ctx->down_stream); (void)hipStreamDestroy(ctx->down_stream); }
+	for (int i = 0; i < cfhip_ctx::kPinSlots; ++i) {
 		if (ctx->h_pin[i]) (void)hipHostFree(ctx->h_pin[i]);
 		if (ctx->pin_free[i]) (void)hipEventDestroy(ctx->pin_free[i]);
+		if (ctx->up_done[i]) (void)hipEventDestroy(ctx->up_done[i]);
 	}
+	for (hipEvent_t ev : ctx->strip_events)
+		(void)hipEventDestroy(ev);
+	if (ctx->h_out) (void)hipHostFree(ctx->h_out);
 	if (ctx->staging_done) (void)hipEventDestroy(ctx->staging_done);
 	if (ctx->d_batch) (void)hipFree(ctx->d_batch);
 	if (ctx->d_mip3d) (void)hipFree(ctx->d_mip3d);

@@ -992,8 +992,10 @@ static void encode_block(const uint8_t rgba[64], uint8_t out[16], const cfo_para
 			const int ngroups = (!has_alpha && b.three) ? 2 : 1;
 			/* the three-subset modes are only tried on blocks the candidates so far leave with an
 			 * error of at least 48 (0.75 per channel-texel): three colour regions in a block that
-			 * already codes this well are rare, and the stream costs a third of Highest's time */
-			for (int g = 0; g < ngroups && best_err != 0 && (g == 0 || best_err >= 48u); ++g) {
+			 * already codes this well are rare, and the stream costs a third of Highest's time.
+			 * (The two-subset group is tried whatever the error so far -- the kernel fits it in the same
+			 * pass as the one-subset modes -- so that the list of best candidates is the same list.) */
+			for (int g = 0; g < ngroups && (g == 0 || best_err >= 48u); ++g) {
 				uint32_t key0[64];
 				for (int k = 0; k < 64; ++k) {
 					float sc = partition_score(px, 2 + g, k, bits);

@@ -105,6 +105,21 @@ def run(format_name, cases, seed, verbose=True):
                 bad += 1
                 if verbose:
                     print("MISMATCH %s case %d: %dx%d q%d cs%d mask%s" % (fmt.name, case, w, h, q, cs, mask))
+                dump = os.environ.get("FUZZ_DUMP")
+                if dump and img.dtype == np.uint8:
+                    # first differing block: its texels (edge-replicated like the loader), both encodings
+                    bw, bh, bs = O.block_geometry(int(fmt)) if hasattr(O, "block_geometry") else (4, 4, ref.size//(((w + 3)//4)*((h + 3)//4)))
+                    nbx = (w + bw - 1)//bw
+                    r2, g2 = ref.reshape(-1, bs), got.reshape(-1, bs)
+                    b = int(np.nonzero((r2 != g2).any(axis=1))[0][0])
+                    by_, bx_ = divmod(b, nbx)
+                    ys = np.minimum(np.arange(by_*bh, by_*bh + bh), h - 1)
+                    xs = np.minimum(np.arange(bx_*bw, bx_*bw + bw), w - 1)
+                    blk = img[np.ix_(ys, xs)]
+                    with open(dump, "a") as f:
+                        f.write("%s %d q%d cs%d mask%s block %d\n  px %s\n  ref %s\n  got %s\n" % (
+                            fmt.name, case, q, cs, "".join(str(m) for m in mask), b, blk.tobytes().hex(),
+                            r2[b].tobytes().hex(), g2[b].tobytes().hex()))
     return bad
 
 
