@@ -625,28 +625,35 @@ def run_c2(args, rank, local_rank, world, backend):
         """The strong-scaling leg runs AFTER the weak line is complete and can never take it down: an
         exception is reported in the line, and a watchdog prints the weak line and leaves if the leg
         does not finish (a collective that hangs on hardware this code has not met would otherwise
-        cost the whole measurement)."""
+        cost the whole measurement).  Exactly ONE line is ever printed (a lock and a flag decide between
+        the watchdog and the main thread); with BENCH_STRONG_STRICT=1 a leg that failed leaves with exit status 3."""
         import threading
         done = threading.Event()
+        printed = threading.Lock()
         limit = float(os.environ.get("BENCH_STRONG_TIMEOUT_S", "240"))
+
+        def leave(note):
+            if rank == 0 and printed.acquire(blocking=False):      # never released: one line per job
+                line["strong_scaling"] = {"error": note}
+                print(json.dumps(line), flush=True)
+            # the other ranks may sit in a collective: no orderly teardown.  The weak line stands and carries the
+            # error note; the exit status stays 0 unless BENCH_STRONG_STRICT=1 asks for 3 (a harness that
+            # discards the output of a failed command would otherwise lose the headline measurement to a
+            # failure of the extra leg)
+            os._exit(3 if os.environ.get("BENCH_STRONG_STRICT", "0") == "1" else 0)
 
         def watchdog():
             if not done.wait(limit):
-                if rank == 0:
-                    line["strong_scaling"] = {"error": "the strong-scaling leg did not finish within %.0f s; "
-                                                       "the weak-scaling line stands" % limit}
-                    print(json.dumps(line), flush=True)
-                os._exit(0)
+                leave("the strong-scaling leg did not finish within %.0f s; the weak-scaling line stands" % limit)
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             res = strong_c2(args, ctx, torch, dist, rank, world, backend, img, out)
         except Exception as e:                      # noqa: BLE001 -- reported, not hidden
             done.set()
-            if rank == 0:
-                line["strong_scaling"] = {"error": "%s: %s" % (type(e).__name__, e)}
-                print(json.dumps(line), flush=True)
-            os._exit(0)                             # the other ranks may sit in a collective: no orderly teardown
+            leave("%s: %s" % (type(e).__name__, e))
         done.set()
+        if rank == 0 and not printed.acquire(blocking=False):
+            os._exit(3 if os.environ.get("BENCH_STRONG_STRICT", "0") == "1" else 0)   # the watchdog printed while the leg was finishing
         return res
 
     if rank != 0 and world > 1 and not args.no_strong:

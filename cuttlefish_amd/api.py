@@ -126,8 +126,12 @@ class PixelType(enum.IntEnum):
 
 E_INVALID, E_UNSUPPORTED, E_CAPACITY, E_DEVICE, E_NO_DEVICE = -1, -2, -3, -4, -5
 
+# cfhip_consumed_fn: void (*)(void* user, size_t surface_index)
+CONSUMED_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t)
+
 EXPORTS = ["cfhip_abi_version", "cfhip_device_count", "cfhip_create", "cfhip_destroy",
-           "cfhip_query", "cfhip_encode", "cfhip_encode_multi", "cfhip_encode_device", "cfhip_shard_rows",
+           "cfhip_query", "cfhip_encode", "cfhip_encode_multi", "cfhip_encode_multi_ex", "cfhip_encode_device",
+           "cfhip_shard_rows",
            "cfhip_last_kernel_ms", "cfhip_last_kernel_name", "cfhip_last_error",
            "cfhip_profile_begin", "cfhip_profile_end", "cfhip_generate_mips_device",
            "cfhip_generate_mips3d_device", "cfhip_resize_device", "cfhip_generate_mips_array_device"]
@@ -185,6 +189,9 @@ def load_library(path: Optional[str] = None):
     L.cfhip_encode_multi.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.POINTER(Surface),
                                      ctypes.c_size_t, ctypes.POINTER(Params)]
     L.cfhip_encode_multi.restype = ctypes.c_int
+    L.cfhip_encode_multi_ex.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.POINTER(Surface),
+                                        ctypes.c_size_t, ctypes.POINTER(Params), CONSUMED_FN, ctypes.c_void_p]
+    L.cfhip_encode_multi_ex.restype = ctypes.c_int
     L.cfhip_encode_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(Surface), ctypes.c_size_t,
                                       ctypes.POINTER(Params), ctypes.c_void_p]
     L.cfhip_encode_device.restype = ctypes.c_int
@@ -330,13 +337,20 @@ class Context:
             surf[i].out_capacity = out.nbytes
         return surf, outs, keep
 
-    def encode_multi(self, others: Sequence["Context"], images: Iterable[np.ndarray], params: Params):
+    def encode_multi(self, others: Sequence["Context"], images: Iterable[np.ndarray], params: Params,
+                     consumed=None):
         """cfhip_encode_multi: this context plus `others` (one per GPU of this process) share the
-        surfaces of the call by block count; same payloads as encode()."""
+        surfaces of the call by block count; same payloads as encode().  consumed(index): called (possibly
+        from the contexts' worker threads) once the library has finished reading surface `index`
+        (cfhip_encode_multi_ex: the hook through which HipConverter releases each source image)."""
         ctxs = [self] + list(others)
         surf, outs, keep = self._host_surfaces(images, params)
         arr = (ctypes.c_void_p * len(ctxs))(*[c._h for c in ctxs])
-        rc = self._lib.cfhip_encode_multi(arr, len(ctxs), surf, len(outs), ctypes.byref(params))
+        if consumed is not None:
+            cb = CONSUMED_FN(lambda user, i: consumed(int(i)))
+            rc = self._lib.cfhip_encode_multi_ex(arr, len(ctxs), surf, len(outs), ctypes.byref(params), cb, None)
+        else:
+            rc = self._lib.cfhip_encode_multi(arr, len(ctxs), surf, len(outs), ctypes.byref(params))
         if rc != 0:
             for c in ctxs:
                 c._check(rc)

@@ -99,7 +99,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, sources()))
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
+    # the link line comes from the same flag list as the compiles (arch and anything link-relevant stay in step)
+    lflags = [f for f in HIPCC_FLAGS if f.startswith(("--offload-arch", "-fgpu-rdc", "-fsanitize")) or f in ("-shared", "-fPIC")]
+    cmd = [hipcc_path()] + lflags + ["-o", LIB + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -20,6 +20,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <sched.h>
@@ -1056,29 +1057,12 @@ int cfhip_shard_rows(uint32_t block_rows, int rank, int world, uint32_t* row_beg
 	return CFHIP_OK;
 }
 
-static int encode_impl(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n,
-	const cfhip_params* params, bool device_mem, hipStream_t user_stream)
+// sizes of one surface of a call, and the checks every entry point makes before it reads a texel
+struct Item { size_t src_bytes, out_bytes, row_bytes; };
+static int validate_surfaces(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n, const cfhip_params* params,
+	bool device_mem, Item* items)
 {
-	if (!ctx)
-		return fail(nullptr, CFHIP_E_INVALID, "ctx is NULL");
-	std::lock_guard<std::mutex> guard(ctx->lock);
-	ctx->error.clear();
-	int rc = check_params(ctx, params);
-	if (rc != CFHIP_OK)
-		return rc;
-	if (!surfaces && n)
-		return fail(ctx, CFHIP_E_INVALID, "surfaces is NULL");
-	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	hipStream_t stream = user_stream ? user_stream : ctx->stream;
-	if (!ctx->profiling)
-		ctx->events_used = 0;
-	ctx->events_stream = stream;
-	ctx->last_ms = -1.0f;
 	const int bs = unit_bytes(params->format, params->type);
-
-	// validate everything first, compute sizes
-	struct Item { size_t src_bytes, out_bytes, row_bytes; };
-	std::vector<Item> items(n);
 	int fbw, fbh;
 	block_dims(params->format, &fbw, &fbh);
 	for (size_t i = 0; i < n; ++i) {
@@ -1101,8 +1085,42 @@ static int encode_impl(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n,
 			((((uintptr_t)s.out) & 15u) || (((uintptr_t)s.pixels) & (pb - 1)) || (apitch & (pb - 1))))
 			return fail(ctx, CFHIP_E_INVALID, "surface %zu: standard formats need a 16-byte aligned "
 				"device output and pixel-aligned source rows", i);
-		items[i] = {row_bytes*(size_t)s.height, out_bytes, row_bytes};
+		if (items)
+			items[i] = {row_bytes*(size_t)s.height, out_bytes, row_bytes};
 	}
+	return CFHIP_OK;
+}
+
+// `consumed(user, i)`: called once the library has finished READING surfaces[i].pixels (host path only): the
+// caller may release that source then, as Converter::convert frees every source image as soon as its surface
+// is converted (Converter.cpp:586) instead of holding the whole texture until the call returns.
+static int encode_impl(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n,
+	const cfhip_params* params, bool device_mem, hipStream_t user_stream,
+	cfhip_consumed_fn consumed = nullptr, void* user = nullptr)
+{
+	if (!ctx)
+		return fail(nullptr, CFHIP_E_INVALID, "ctx is NULL");
+	std::lock_guard<std::mutex> guard(ctx->lock);
+	ctx->error.clear();
+	int rc = check_params(ctx, params);
+	if (rc != CFHIP_OK)
+		return rc;
+	if (!surfaces && n)
+		return fail(ctx, CFHIP_E_INVALID, "surfaces is NULL");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	hipStream_t stream = user_stream ? user_stream : ctx->stream;
+	if (!ctx->profiling)
+		ctx->events_used = 0;
+	ctx->events_stream = stream;
+	ctx->last_ms = -1.0f;
+
+	// validate everything first, compute sizes
+	std::vector<Item> items(n);
+	rc = validate_surfaces(ctx, surfaces, n, params, device_mem, items.data());
+	if (rc != CFHIP_OK)
+		return rc;
+	int fbw, fbh;
+	block_dims(params->format, &fbw, &fbh);
 
 	if (device_mem) {
 		size_t i0 = 0;
@@ -1144,6 +1162,8 @@ static int encode_impl(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n,
 				rc = encode_host_pipelined(ctx, surfaces[g0], *params, stream);
 				if (rc != CFHIP_OK)
 					return rc;
+				if (consumed)
+					consumed(user, g0);
 				++g0;
 				continue;
 			}
@@ -1198,6 +1218,9 @@ static int encode_impl(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n,
 					hipMemcpyDeviceToHost, stream));
 			HIP_TRY(ctx, hipStreamSynchronize(stream));   // staging buffers are reused
 			ctx->staging_busy = false;
+			if (consumed)
+				for (size_t i = g0; i < g1; ++i)
+					consumed(user, i);             // the group's uploads have left the host buffers
 			g0 = g1;
 		}
 	}
@@ -1215,10 +1238,16 @@ int cfhip_encode(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n_surface
 int cfhip_encode_multi(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface* surfaces,
 	size_t n_surfaces, const cfhip_params* params)
 {
+	return cfhip_encode_multi_ex(ctxs, n_ctx, surfaces, n_surfaces, params, nullptr, nullptr);
+}
+
+int cfhip_encode_multi_ex(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface* surfaces,
+	size_t n_surfaces, const cfhip_params* params, cfhip_consumed_fn consumed, void* user)
+{
 	if (!ctxs || n_ctx <= 0 || !ctxs[0])
 		return CFHIP_E_INVALID;
 	if (n_ctx == 1 || n_surfaces == 0)
-		return cfhip_encode(ctxs[0], surfaces, n_surfaces, params);
+		return encode_impl(ctxs[0], surfaces, n_surfaces, params, false, nullptr, consumed, user);
 	if (!surfaces || !params)
 		return fail(ctxs[0], CFHIP_E_INVALID, "null surfaces or params");
 	for (int i = 0; i < n_ctx; ++i)
@@ -1227,6 +1256,14 @@ int cfhip_encode_multi(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface* s
 	int bw = 4, bh = 4, bs = 16;
 	if (cfhip_query(params->format, params->type, &bw, &bh, &bs) != CFHIP_OK)
 		return fail(ctxs[0], CFHIP_E_UNSUPPORTED, "format %d with type %d is not supported", params->format, params->type);
+	if (consumed) {
+		// with a release hook nothing may be read before everything that can be checked has been
+		int vrc = check_params(ctxs[0], params);
+		if (vrc == CFHIP_OK)
+			vrc = validate_surfaces(ctxs[0], surfaces, n_surfaces, params, false, nullptr);
+		if (vrc != CFHIP_OK)
+			return vrc;
+	}
 	// Work units.  The reference parallelises WITHIN a surface (jobsX*jobsY jobs on an atomic
 	// counter, Converter.cpp:540-583) as well as over nothing else, so one big surface must not pin
 	// the call to one GPU: a surface holding more than 1/n_ctx of the call's blocks is cut into
@@ -1244,9 +1281,12 @@ int cfhip_encode_multi(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface* s
 	// rows of a standard format are cut in multiples of 4 so that every range's payload keeps the
 	// 4-byte alignment the packers store with
 	const uint32_t row_quant = is_std_format(params->format) ? 4u : 1u;
-	const uint64_t kMinSplitBlocks = 4096;      // below this a second launch costs more than it saves
+	// below this a second launch (host thread, upload, launch, synchronisation) costs more than it saves: 4 096
+	// blocks of a block format = 65 536 texels; a standard format's "block" is ONE pixel, so the same area there
+	const uint64_t kMinSplitBlocks = is_std_format(params->format) ? 65536 : 4096;
 	std::vector<cfhip_surface> units;
 	std::vector<uint64_t> blocks;
+	std::vector<size_t> origin;           // the surface a unit was cut from
 	units.reserve(n_surfaces + (size_t)n_ctx);
 	for (size_t i = 0; i < n_surfaces; ++i) {
 		const cfhip_surface& s = surfaces[i];
@@ -1258,6 +1298,7 @@ int cfhip_encode_multi(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface* s
 		if (!split) {
 			units.push_back(s);
 			blocks.push_back(sblocks[i]);
+			origin.push_back(i);
 			continue;
 		}
 		const uint32_t qrows = (by + row_quant - 1u)/row_quant;     // rows in units of row_quant
@@ -1280,6 +1321,7 @@ int cfhip_encode_multi(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface* s
 				u.out_capacity = std::min(u.out_capacity, (size_t)(br1 - br0)*bx*(size_t)bs);
 			units.push_back(u);
 			blocks.push_back((uint64_t)(br1 - br0)*bx);
+			origin.push_back(i);
 		}
 	}
 	const size_t n_units = units.size();
@@ -1290,6 +1332,7 @@ int cfhip_encode_multi(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface* s
 		order[i] = i;
 	std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return blocks[a] > blocks[b]; });
 	std::vector<std::vector<cfhip_surface>> share((size_t)n_ctx);
+	std::vector<std::vector<size_t>> share_origin((size_t)n_ctx);
 	std::vector<uint64_t> load((size_t)n_ctx, 0);
 	for (size_t i : order) {
 		size_t k = 0;
@@ -1297,17 +1340,37 @@ int cfhip_encode_multi(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface* s
 			if (load[c] < load[k])
 				k = c;
 		share[k].push_back(units[i]);
+		share_origin[k].push_back(origin[i]);
 		load[k] += blocks[i];
 	}
+	// a surface is consumed when the last of its units is: one counter per surface, the contexts' threads
+	// report their units through it (the caller's function may therefore run on any of them, for different
+	// surfaces at the same time)
+	std::vector<std::atomic<int>> pending(consumed ? n_surfaces : 0);
+	if (consumed)
+		for (size_t u = 0; u < n_units; ++u)
+			pending[origin[u]].fetch_add(1, std::memory_order_relaxed);
+	struct Relay { cfhip_consumed_fn fn; void* user; const std::vector<size_t>* origin; std::vector<std::atomic<int>>* pending; };
+	std::vector<Relay> relay((size_t)n_ctx);
+	for (int c = 0; c < n_ctx; ++c)
+		relay[(size_t)c] = {consumed, user, &share_origin[(size_t)c], &pending};
+	const cfhip_consumed_fn unit_done = [](void* r_, size_t unit) {
+		Relay* r = static_cast<Relay*>(r_);
+		const size_t surf = (*r->origin)[unit];
+		if ((*r->pending)[surf].fetch_sub(1, std::memory_order_acq_rel) == 1)
+			r->fn(r->user, surf);
+	};
 	std::vector<int> rc((size_t)n_ctx, CFHIP_OK);
 	std::vector<std::thread> workers;
 	for (int c = 1; c < n_ctx; ++c)
 		if (!share[(size_t)c].empty())
 			workers.emplace_back([&, c]() {
-				rc[(size_t)c] = cfhip_encode(ctxs[c], share[(size_t)c].data(), share[(size_t)c].size(), params);
+				rc[(size_t)c] = encode_impl(ctxs[c], share[(size_t)c].data(), share[(size_t)c].size(), params, false, nullptr,
+					consumed ? unit_done : nullptr, &relay[(size_t)c]);
 			});
 	if (!share[0].empty())
-		rc[0] = cfhip_encode(ctxs[0], share[0].data(), share[0].size(), params);
+		rc[0] = encode_impl(ctxs[0], share[0].data(), share[0].size(), params, false, nullptr,
+			consumed ? unit_done : nullptr, &relay[0]);
 	for (std::thread& t : workers)
 		t.join();
 	for (int c = 0; c < n_ctx; ++c)
@@ -1351,7 +1414,12 @@ static int mip_level_2d(cfhip_ctx* ctx, const void* prev, int prev_type, size_t 
 			// not change is skipped (the other one then does both colour conversions)
 			const bool x_first = (unsigned long long)w*ph <= (unsigned long long)h*pw;
 			const bool need_x = w != pw, need_y = h != ph;
-			if (need_x && need_y && filter == CFHIP_FILTER_BOX) {
+			// the fused kernel does taps_x * taps_y work per output texel: it beats the two passes (24 -> 8 bytes per
+			// texel) only while the footprint is small -- a mip step (2:1, at most 3 x 3 taps with an odd size).  A
+			// resize of a custom mip image can have any ratio (1024 x 1024 -> 1 x 1: a million taps in one thread
+			// against 2 x 1024 for the separable passes): those take the two-pass route
+			const bool small_taps = (unsigned long long)pw <= 2ull*w + 1ull && (unsigned long long)ph <= 2ull*h + 1ull;
+			if (need_x && need_y && filter == CFHIP_FILTER_BOX && small_taps) {
 				// the box filter: both passes in one launch, no float image in between (bit-identical)
 				HIP_TRY(ctx, cfhip_launch_mip_fused_layers(prev, prev_type, prev_pitch, pw, ph, dst_levels[k - 1], w, h,
 					x_first ? 1 : 0, filter, srgb, 1u, nullptr, nullptr, 0, 0, stream));

@@ -329,10 +329,17 @@ cfhip_mip_fused_kernel(const uint8_t* src_base, size_t pitch, uint32_t sw, uint3
 	// outer = the SECOND pass's axis, inner = the first pass's: the inner sum is the float the first pass stored
 	const AxisTaps& t2 = X_FIRST ? ty : tx;
 	const AxisTaps& t1 = X_FIRST ? tx : ty;
+	// the first pass's weights do not depend on the outer tap: formed once (a mip step has at most 3 or 4 of
+	// them; axis_weight divides in double) instead of once per outer tap -- same values, same sums
+	const int n1 = t1.right - t1.left;
+	double w1[4] = {0.0, 0.0, 0.0, 0.0};
+	if (n1 <= 4)
+		for (int b = 0; b < n1; ++b)
+			w1[b] = axis_weight(t1, t1.left + b, filter);
 	for (int a = t2.left; a < t2.right; ++a) {
 		double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 		for (int b = t1.left; b < t1.right; ++b) {
-			const double w = axis_weight(t1, b, filter);
+			const double w = n1 <= 4 ? w1[b - t1.left] : axis_weight(t1, b, filter);
 			const float4 p = X_FIRST ? texel(b, a) : texel(a, b);
 			c0 += w*(double)p.x; c1 += w*(double)p.y; c2 += w*(double)p.z; c3 += w*(double)p.w;
 		}

@@ -207,6 +207,20 @@ int cfhip_encode(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n_surface
  * unspecified.  n_ctx == 1 is exactly cfhip_encode. */
 int cfhip_encode_multi(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface* surfaces,
 	size_t n_surfaces, const cfhip_params* params);
+/* The same with a release hook: Converter::convert frees every source image as soon as its surface is
+ * converted (lib/src/Converter.cpp:586), so that a texture array with mip chains never holds all of its
+ * RGBAF images and all of its payloads at once.  consumed(user, i) is called once the library has finished
+ * READING surfaces[i].pixels -- the surface's last strip was gathered / quantised into the pipeline's pinned
+ * memory, or the group of small surfaces it was uploaded with has left the host -- after which the caller may
+ * free that source.  With several contexts the function runs on the contexts' worker threads, possibly for
+ * different surfaces at the same time; it must not call into this library.  If the call FAILS after some
+ * surfaces were reported, those sources are gone: the caller cannot re-run the work on another path for them
+ * (HipConverter then fails the conversion, as a codec failure would).  Everything that can be checked is
+ * checked before the first surface is read (parameters, sizes, capacities), so what is left to fail late are
+ * HIP runtime errors.  consumed == NULL is exactly cfhip_encode_multi. */
+typedef void (*cfhip_consumed_fn)(void* user, size_t surface_index);
+int cfhip_encode_multi_ex(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface* surfaces,
+	size_t n_surfaces, const cfhip_params* params, cfhip_consumed_fn consumed, void* user);
 /* Host pipeline of cfhip_encode: small surfaces of a call are
  * uploaded together and encoded in ONE batched launch with one synchronisation; a large
  * RGBA32F surface of an 8-bit format, or any bottom-up surface, is cut into strips of whole

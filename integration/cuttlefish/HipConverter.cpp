@@ -9,6 +9,8 @@
 
 #include <cuttlefish_hip.h>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -139,17 +141,44 @@ bool HipConverter::supports(Texture::Format format, Texture::Type type)
 		&blockBytes) == CFHIP_OK;
 }
 
-bool HipConverter::convertAll(const Texture& texture, MipImageList& images,
+namespace
+{
+
+// What the release hook of cfhip_encode_multi_ex needs: where surface i's image lives.
+struct ReleaseList
+{
+	std::vector<Image*> images;
+	std::vector<std::vector<std::uint8_t>>* staging;
+	std::atomic<std::size_t> released{0};
+};
+
+// cfhip_consumed_fn: the backend has finished reading surface `index` -- free its source image now, as
+// Converter::convert does after each surface (Converter.cpp:586), instead of holding every RGBAF image
+// of the texture (16 bytes per texel) until the whole call returns.  May run on the backend's worker
+// threads, for different surfaces at a time: each call touches its own image only.
+void releaseSource(void* user, std::size_t index)
+{
+	ReleaseList* list = static_cast<ReleaseList*>(user);
+	list->images[index]->reset();
+	std::vector<std::uint8_t>().swap((*list->staging)[index]);
+	list->released.fetch_add(1, std::memory_order_relaxed);
+}
+
+} // namespace
+
+HipConverter::Result HipConverter::convertAll(const Texture& texture, MipImageList& images,
 	MipTextureList& textureData, Texture::Quality quality)
 {
 	cfhip_ctx* ctx = sharedContext();
 	if (!ctx || images.empty() || !supports(texture.format(), texture.type()))
-		return false;
+		return Result::NotHandled;
 
-	// payloads first (into a local list: nothing of the caller's is touched before success)
+	// payloads first (into a local list: nothing of the caller's is touched before the backend reads)
 	MipTextureList payloads(images.size());
 	std::vector<cfhip_surface> surfaces;
 	std::vector<std::vector<std::uint8_t>> staging;
+	ReleaseList release;
+	release.staging = &staging;
 	ColorSpace colorSpace = ColorSpace::Linear;
 	for (unsigned int mip = 0; mip < images.size(); ++mip)
 	{
@@ -159,9 +188,9 @@ bool HipConverter::convertAll(const Texture& texture, MipImageList& images,
 			payloads[mip][d].resize(images[mip][d].size());
 			for (unsigned int f = 0; f < images[mip][d].size(); ++f)
 			{
-				const Image& image = images[mip][d][f];
+				Image& image = images[mip][d][f];
 				if (!image.isValid() || image.format() != Image::Format::RGBAF)
-					return false;
+					return Result::NotHandled;
 				if (surfaces.empty())
 					colorSpace = image.colorSpace();
 				TextureData& out = payloads[mip][d][f];
@@ -171,38 +200,36 @@ bool HipConverter::convertAll(const Texture& texture, MipImageList& images,
 				describe(image, surfaces.back(), staging.back());
 				surfaces.back().out = out.data();
 				surfaces.back().out_capacity = out.size();
+				release.images.push_back(&image);
 			}
 		}
 	}
 	if (surfaces.empty())
-		return false;
+		return Result::NotHandled;
 
 	const cfhip_params params = makeParams(texture.format(), texture.type(), quality,
 		texture.alphaType(), texture.colorMask(), colorSpace);
-	// every visible GPU takes a share of the surfaces (by block count); one GPU: plain cfhip_encode
+	// every visible GPU takes a share of the surfaces (by block count); one GPU: plain cfhip_encode.
+	// Each source image is released as soon as the backend has read it (releaseSource).
 	const std::vector<cfhip_ctx*>& contexts = sharedContexts();
-	if (cfhip_encode_multi(contexts.data(), static_cast<int>(contexts.size()), surfaces.data(),
-			surfaces.size(), &params) != CFHIP_OK)
-		return false;
-
-	// success: hand the payloads over and release the sources (Converter.cpp:586-587)
-	for (DepthImageList& depth : images)
+	if (cfhip_encode_multi_ex(contexts.data(), static_cast<int>(contexts.size()), surfaces.data(),
+			surfaces.size(), &params, &releaseSource, &release) != CFHIP_OK)
 	{
-		for (FaceImageList& faces : depth)
-		{
-			for (Image& image : faces)
-				image.reset();
-		}
+		// Nothing read yet (parameters, sizes and capacities are checked before the first texel is):
+		// the stock loop can still run.  Otherwise some sources are gone and only failing is honest.
+		return release.released.load() == 0 ? Result::NotHandled : Result::Failed;
 	}
+
 	textureData = std::move(payloads);
-	return true;
+	return Result::Done;
 }
 
 HipConverter::HipConverter(const Texture& texture, const Image& image, Texture::Quality quality,
-	Factory fallback)
+	unsigned int threadCount, Factory fallback)
 	: Converter(image), m_format(texture.format()), m_type(texture.type()), m_quality(quality),
 	m_alphaType(texture.alphaType()), m_colorMask(texture.colorMask()),
-	m_colorSpace(image.colorSpace()), m_fallback(std::move(fallback))
+	m_colorSpace(image.colorSpace()), m_threadCount(std::max(1U, threadCount)),
+	m_fallback(std::move(fallback))
 {
 	data().resize(payloadSize(m_format, image.width(), image.height()));
 }
@@ -221,17 +248,30 @@ void HipConverter::process(unsigned int, unsigned int, ThreadData*)
 	if (ctx && cfhip_encode(ctx, &surface, 1, &params) == CFHIP_OK)
 		return;
 
-	// Backend failure: build the stock converter now, run its job grid serially and take its
-	// payload.
+	// Backend failure: build the stock converter now and run its job grid the way Converter::convert does
+	// (Converter.cpp:540-583): every thread data object created on this thread first, then `threadCount`
+	// threads drawing jobs from one atomic counter, joined before the payload is taken.
 	std::unique_ptr<Converter> cpu = m_fallback ? m_fallback() : nullptr;
 	if (cpu)
 	{
-		std::unique_ptr<ThreadData> threadData = cpu->createThreadData();
-		for (unsigned int y = 0; y < cpu->jobsY(); ++y)
-		{
-			for (unsigned int x = 0; x < cpu->jobsX(); ++x)
-				cpu->process(x, y, threadData.get());
-		}
+		const unsigned int jobsX = cpu->jobsX(), jobsY = cpu->jobsY();
+		const unsigned int jobs = jobsX*jobsY;
+		const unsigned int threads = std::max(1U, std::min(m_threadCount, jobs));
+		std::vector<std::unique_ptr<ThreadData>> threadData(threads);
+		for (std::unique_ptr<ThreadData>& data : threadData)
+			data = cpu->createThreadData();
+		std::atomic<unsigned int> curJob(0);
+		auto run = [&](ThreadData* data)
+			{
+				for (unsigned int job = curJob++; job < jobs; job = curJob++)
+					cpu->process(job % jobsX, job/jobsX, data);
+			};
+		std::vector<std::thread> workers;
+		for (unsigned int t = 1; t < threads; ++t)
+			workers.emplace_back(run, threadData[t].get());
+		run(threadData[0].get());
+		for (std::thread& worker : workers)
+			worker.join();
 		data() = std::move(cpu->data());
 	}
 	else

@@ -42,17 +42,25 @@ public:
 	// fall back to the CPU path through the failure handling below).
 	static bool supports(Texture::Format format, Texture::Type type);
 
-	// Encodes every image of the texture in one backend call.  On success textureData holds
-	// the payloads (same sizes and order as Converter::convert produces), the source images
-	// are released like Converter.cpp:586 does, and true is returned.  On any failure nothing
-	// is modified and false is returned: the caller continues with the stock loop.
-	static bool convertAll(const Texture& texture, MipImageList& images,
+	// Encodes every image of the texture in one backend call.
+	//   Done:       textureData holds the payloads (same sizes and order as Converter::convert
+	//               produces); every source image was released AS SOON AS the backend had read it
+	//               (cfhip_encode_multi_ex's hook), the way Converter.cpp:586 frees each image after
+	//               its surface -- a texture array with mip chains never holds all of its RGBAF
+	//               images to the end of the call.
+	//   NotHandled: nothing was read or modified; the caller continues with the stock loop.
+	//   Failed:     the backend failed after some sources had been released (a HIP runtime error:
+	//               everything checkable is checked before the first texel is read); the stock loop
+	//               cannot run any more and Converter::convert returns false.
+	enum class Result {Done, NotHandled, Failed};
+	static Result convertAll(const Texture& texture, MipImageList& images,
 		MipTextureList& textureData, Texture::Quality quality);
 
-	// fallback: builds the converter the stock createConverter would have returned; invoked
-	// only if the backend fails at process() time.
+	// threadCount: the worker count Converter::convert was given (Converter.cpp:498-499); used only
+	// by the CPU fallback.  fallback: builds the converter the stock createConverter would have
+	// returned; invoked only if the backend fails at process() time.
 	HipConverter(const Texture& texture, const Image& image, Texture::Quality quality,
-		Factory fallback);
+		unsigned int threadCount, Factory fallback);
 
 	unsigned int jobsX() const override {return 1;}
 	unsigned int jobsY() const override {return 1;}
@@ -65,6 +73,7 @@ private:
 	Texture::Alpha m_alphaType;
 	Texture::ColorMask m_colorMask;
 	ColorSpace m_colorSpace;
+	unsigned int m_threadCount;
 	Factory m_fallback;
 };
 

@@ -44,6 +44,33 @@ def test_bench_gpus2_self_launches_and_reports_strong_scaling(hip_lib):
     assert set(st["phases_ms_max_over_ranks"]) == {"scatter", "encode", "gather"}
 
 
+@pytest.mark.timeout(1800)
+def test_bench_gpus8_weak_line_and_row_split_at_the_node_size(hip_lib):
+    """`python bench.py --gpus 8` as the driver runs it on the 8-GPU node (SCALE): here the ranks share the
+    visible devices through the gloo hook, so what is checked is the flow -- rendezvous, barriers, max over
+    ranks, ONE JSON line from rank 0 -- and the 8-way block-row split of the strong-scaling leg (512 x 512:
+    128 block rows, 16 per rank), byte-compared with the local encode."""
+    line = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--size", "512", "--no-cpu-baseline"], timeout=1500)
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["value"] > 0
+    assert [p["rank"] for p in line["per_rank"]] == list(range(8))
+    st = line["strong_scaling"]
+    assert "error" not in st, st
+    assert st["block_rows_per_rank"] == [16]*8
+    assert st["sharded_equals_local"]["equal"] is True
+    assert st["sharded_equals_local"]["bytes_compared"] == 128*128*16
+
+
+@pytest.mark.timeout(1800)
+def test_bench_c5_at_eight_ranks(hip_lib):
+    """C5's texture sharding at the node size: 16 textures of 256 x 256 over 8 ranks (2 each), gathered to
+    rank 0 and compared with local re-encodes of textures owned by ranks 0, 1 and 7."""
+    line = _run(["--config", "c5", "--gpus", "8", "--textures", "16", "--tex-size", "256", "--steps", "1"], timeout=1500)
+    chk = line["sharded_equals_local"]
+    assert line["n_gpus"] == 8 and chk["equal"] is True
+    assert {c["owner_rank"] for c in chk["textures_checked"]} == {0, 1, 7}
+    assert [p["textures"] for p in line["per_rank"]] == [2]*8
+
+
 @pytest.mark.timeout(1200)
 def test_bench_c5_checks_textures_at_one_and_two_ranks(hip_lib):
     one = _run(["--config", "c5", "--gpus", "1", "--textures", "4", "--tex-size", "256", "--steps", "1"])
@@ -65,3 +92,23 @@ def test_a_stuck_strong_scaling_leg_cannot_take_the_weak_line_down(hip_lib):
     assert line["n_gpus"] == 2 and line["value"] > 0 and len(line["per_rank"]) == 2
     st = line["strong_scaling"]
     assert "error" in st or st.get("value", 0) > 0
+
+
+@pytest.mark.timeout(600)
+def test_strict_mode_reports_a_failed_strong_leg_in_the_exit_status(hip_lib):
+    """BENCH_STRONG_STRICT=1: still exactly one line with the weak value, exit status 3 when the leg timed out."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update({"BENCH_STRONG_TIMEOUT_S": "0.001", "BENCH_STRONG_STRICT": "1"})
+    if torch.cuda.device_count() < 2:
+        env["BENCH_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--size", "512", "--no-cpu-baseline"], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=500, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["value"] > 0
+    if "error" in line["strong_scaling"]:
+        assert r.returncode != 0

@@ -1,4 +1,4 @@
-"""N>1 path on CPU: world_size-2 gloo processes shard surfaces / block rows and gather the
+"""N>1 path on CPU: world_size-2 and world_size-8 gloo processes shard surfaces / block rows and gather the
 payload; the result must be byte-identical to the single-rank result.  The encoder injected
 here is the CPU oracle (tests may use it); on GPUs the same code runs with Context.encode."""
 import os
@@ -152,3 +152,57 @@ def test_world2_scatter_encode_gather_equals_single_rank():
     assert results[1][2] is None
     # 8 block rows of 6 scanlines (the last one ragged: 44 = 7*6 + 2) split 4 + 4
     assert results[0][1] == [(0, 24, 0, 4), (24, 44, 4, 8)]
+
+
+def _worker8(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        params = make_params(Format.BC1_RGB, Type.UNorm, 0)
+        # 3 chains of 5 levels (15 surfaces over 8 ranks: some ranks get one tiny surface) ...
+        chain = [synth.photo(32 >> i, 32 >> i, seed=90 + 10*t + i) for t in range(3) for i in range(5)]
+        got = shard.encode_surfaces_sharded(chain, params, _oracle_encode, rank, world)
+        # ... fewer surfaces than ranks: zero-byte shares in the exchange
+        few = shard.encode_surfaces_sharded(chain[:3], params, _oracle_encode, rank, world)
+        # one surface of 13 block rows over 8 ranks, and one of 3 block rows (fewer rows than ranks:
+        # five ranks own nothing and send nothing)
+        tall = synth.photo(24, 52, seed=120)
+        rows = shard.encode_rows_sharded(tall, params, _oracle_encode, rank, world)
+        short = synth.photo(40, 10, seed=121)
+        srows = shard.encode_rows_sharded(short, params, _oracle_encode, rank, world)
+        q.put((rank, [g.tobytes() for g in got], [g.tobytes() for g in few], rows.tobytes(), srows.tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_world8_gloo_matches_single_rank():
+    """The world size the 8-GPU node runs, on CPU: both sharding functions, ranks with empty
+    shares, a surface with fewer block rows than ranks."""
+    world = 8
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=500) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    params = make_params(Format.BC1_RGB, Type.UNorm, 0)
+    chain = [synth.photo(32 >> i, 32 >> i, seed=90 + 10*t + i) for t in range(3) for i in range(5)]
+    want = [o.tobytes() for o in _oracle_encode(chain, params)]
+    want_rows = _oracle_encode([synth.photo(24, 52, seed=120)], params)[0].tobytes()
+    want_short = _oracle_encode([synth.photo(40, 10, seed=121)], params)[0].tobytes()
+    assert sorted(r[0] for r in results) == list(range(world))
+    for rank, got, few, rows, srows in results:
+        assert got == want, "rank %d surfaces differ" % rank
+        assert few == want[:3], "rank %d: fewer surfaces than ranks" % rank
+        assert rows == want_rows, "rank %d row shards differ" % rank
+        assert srows == want_short, "rank %d: fewer block rows than ranks" % rank
+    # the plan itself: 3 block rows over 8 ranks leave five ranks empty, nothing is lost or doubled
+    ranges = shard.row_ranges(10, 4, world)
+    assert sum(b - a for (_, _, a, b) in ranges) == 3 and sum(1 for (_, _, a, b) in ranges if b > a) == 3
+    assert [y1 - y0 for (y0, y1, _, _) in ranges if y1 > y0] == [4, 4, 2]
