@@ -1103,7 +1103,7 @@ cfhip_etc_encode_kernel(cf_kparams kp)
 		o.allow_indiv = false; o.allow_planar = false; o.punch = false; o.a1 = false;
 		o.active = valid; o.transparent = 0;
 		o.wt[0] = (int)kp.wt[0]; o.wt[1] = (int)kp.wt[1]; o.wt[2] = (int)kp.wt[2];
-		o.radius = q >= 4u ? 3 : (q >= 3u ? 1 : 0);                    // T / H move rounds (oracle: effort_radius)
+		o.radius = q >= 4u ? 4 : (q >= 3u ? 3 : (q >= 2u ? 2 : 0));    // T / H move rounds (oracle: effort_radius)
 		o.walk = q > 4u ? 4 : (int)q;                                  // five distinct effort levels
 		o.refine = q >= 1u;
 		uint2 w0 = make_uint2(0, 0), w1 = make_uint2(0, 0);

@@ -97,6 +97,8 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 /* test-only wide searches: the bound the quality ladders are measured against */
 uint32_t cfo_bc7_wide_search(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p);
 void cfo_bc6h_wide_search(const uint16_t rgba_half[64], uint8_t out[16], const cfo_params* p);
+/* test-only: the TRUE optimum of an ETC1 (etc2 = 0) or ETC2 RGB block: exhaustive over every mode (etc_codec.c) */
+uint32_t cfo_etc_true_optimum(const uint8_t rgba[64], int etc2, uint8_t out[8]);
 
 /* sum of squared differences over RGBA8 images, per channel (for PSNR) */
 void cfo_sse_rgba8(const uint8_t* a, const uint8_t* b, size_t n_pixels, uint64_t sse[4]);

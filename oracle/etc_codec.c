@@ -916,11 +916,14 @@ void cfo_eac_search(const int v[16], int kind, unsigned active, int R, uint8_t o
 static int effort_radius(int quality)
 {
 	/* stands in for etc2comp's five effort levels (EtcConverter.cpp:34-54), all distinct: base
-	 * colours walked per half and table 1 / 3 / 9 / 27 / 125 + 12 (search_half's walk = the
-	 * quality), T / H move rounds 0 / 0 / 0 / 1 / 3 (this value); Lowest also drops the planar
+	 * colours walked per half and table 1 / 3 / 9 / 27 / 27 + 36 (search_half's walk = the
+	 * quality), T / H move rounds 0 / 0 / 2 / 3 / 4 (this value); Lowest also drops the planar
 	 * refinement and the T / H modes.  (Round 2 measured 0.06 dB between a 7- and the
-	 * 27-candidate walk for twice the time: Normal takes the 9.) */
-	return quality >= 4 ? 3 : (quality >= 3 ? 1 : 0);
+	 * 27-candidate walk for twice the time: Normal takes the 9.  Round 4 measured the ladder against the
+	 * TRUE optimum of a block, cfo_etc_true_optimum: nine tenths of what ETC2 RGB Normal left on the table
+	 * sat in its T / H blocks, whose base colours were never moved at that level -- 0.26 .. 0.68 dB under
+	 * the optimum depending on how many such blocks a sample holds; two move rounds: 0.13 .. 0.25.) */
+	return quality >= 4 ? 4 : (quality >= 3 ? 3 : (quality >= 2 ? 2 : 0));
 }
 
 /* rgbaf: 16 texels float RGBA row-major (edge-replicated), rgba: the same as u8,
@@ -998,4 +1001,309 @@ int cfo_encode_etc_block(const float rgbaf[64], const uint8_t rgba[64], unsigned
 		default:
 			return -1;
 	}
+}
+
+
+/* ---------------------------------------------------------------- test-only: the TRUE optimum of an RGB block
+ * (tests/test_oracle_bounds.py, tools/quality_tables.py).  Not a wider heuristic: every
+ * block the format can express is covered, either by enumeration or by an argument that the part left out
+ * cannot hold a better one.  Unit weights, all 16 texels.
+ *   individual / differential (ETC1 and ETC2): every RGB444 / RGB555 base colour of every half of both
+ *       flips with every table and the best modifier per texel; differential pairs = every second base
+ *       within the -4 .. +3 window of the first;
+ *   planar (ETC2): the three channels are independent in this mode, so every (O, H, V) triple of a channel
+ *       (64^3 or 128^3) is tried and the minima add up;
+ *   T and H (ETC2): every distance, and every base colour inside the box that must contain an optimum --
+ *       a base component above (largest texel value + d) has all its paints above every texel, so stepping
+ *       it down moves every unclamped paint towards every texel and the error cannot grow (the same below;
+ *       the lone colour A of T mode: d = 0).  Inside the box the search is exhaustive.
+ * etc2 = 0: ETC1 modes only.  Returns the smallest squared error and the block. */
+static uint32_t opt_half_tables(const int tex[8][3], int bits, uint32_t* errs)
+{
+	/* errs[q] (q = r << 2 bits | g << bits | b) = min over tables of sum over texels of min over modifiers */
+	const int n = 1 << bits;
+	static const int modv[8][4] = {{2, 8, -2, -8}, {5, 17, -5, -17}, {9, 29, -9, -29}, {13, 42, -13, -42},
+		{18, 60, -18, -60}, {24, 80, -24, -80}, {33, 106, -33, -106}, {47, 183, -47, -183}};
+	/* sq[c][value index][table][modifier][texel] */
+	static __thread uint16_t* sq = NULL;
+	if (!sq)
+		sq = (uint16_t*)malloc((size_t)3*32*8*4*8*sizeof(uint16_t));
+	for (int c = 0; c < 3; ++c)
+		for (int v = 0; v < n; ++v) {
+			const int base = bits == 5 ? ex5(v) : ex4(v);
+			for (int t = 0; t < 8; ++t)
+				for (int m = 0; m < 4; ++m)
+					for (int i = 0; i < 8; ++i) {
+						int d = clamp255(base + modv[t][m]) - tex[i][c];
+						sq[((((size_t)c*32 + v)*8 + t)*4 + m)*8 + i] = (uint16_t)(d*d);
+					}
+		}
+	uint32_t best = 0xFFFFFFFFu;
+	for (int r = 0; r < n; ++r)
+		for (int g = 0; g < n; ++g)
+			for (int b = 0; b < n; ++b) {
+				uint32_t e = 0xFFFFFFFFu;
+				for (int t = 0; t < 8; ++t) {
+					const uint16_t* pr = sq + ((((size_t)0*32 + r)*8 + t)*4)*8;
+					const uint16_t* pg = sq + ((((size_t)1*32 + g)*8 + t)*4)*8;
+					const uint16_t* pb = sq + ((((size_t)2*32 + b)*8 + t)*4)*8;
+					uint32_t tot = 0;
+					for (int i = 0; i < 8; ++i) {
+						uint32_t bm = 0xFFFFFFFFu;
+						for (int m = 0; m < 4; ++m) {
+							uint32_t v = (uint32_t)pr[m*8 + i] + pg[m*8 + i] + pb[m*8 + i];
+							if (v < bm) bm = v;
+						}
+						tot += bm;
+					}
+					if (tot < e) e = tot;
+				}
+				errs[((r << bits) | g) << bits | b] = e;
+				if (e < best) best = e;
+			}
+	return best;
+}
+
+uint32_t cfo_etc_true_optimum(const uint8_t rgba[64], int etc2, uint8_t out[8])
+{
+	int px[16][4];
+	for (int i = 0; i < 16; ++i)
+		for (int c = 0; c < 4; ++c)
+			px[i][c] = rgba[4*i + c];
+	rgb_opts o;
+	memset(&o, 0, sizeof(o));
+	o.wt[0] = o.wt[1] = o.wt[2] = 1;
+	o.active = 0xFFFF;
+	o.allow_indiv = 1;
+	uint32_t best = 0xFFFFFFFFu;
+	memset(out, 0, 8);
+	uint32_t* e5[2];
+	uint32_t* e4[2];
+	for (int s = 0; s < 2; ++s) {
+		e5[s] = (uint32_t*)malloc(32768*sizeof(uint32_t));
+		e4[s] = (uint32_t*)malloc(4096*sizeof(uint32_t));
+	}
+	for (int flip = 0; flip < 2; ++flip) {
+		int tex[2][8][3], cnt[2] = {0, 0};
+		for (int i = 0; i < 16; ++i) {
+			int s = in_half(i, flip, 1);
+			for (int c = 0; c < 3; ++c)
+				tex[s][cnt[s]][c] = px[i][c];
+			++cnt[s];
+		}
+		for (int s = 0; s < 2; ++s) {
+			opt_half_tables((const int (*)[3])tex[s], 5, e5[s]);
+			opt_half_tables((const int (*)[3])tex[s], 4, e4[s]);
+		}
+		/* individual */
+		int qi[2] = {0, 0};
+		for (int s = 0; s < 2; ++s)
+			for (int q = 1; q < 4096; ++q)
+				if (e4[s][q] < e4[s][qi[s]])
+					qi[s] = q;
+		/* differential */
+		uint32_t bd = 0xFFFFFFFFu;
+		int qd[2] = {0, 0};
+		for (int q1 = 0; q1 < 32768; ++q1) {
+			if (e5[0][q1] >= bd)
+				continue;
+			const int r1 = q1 >> 10, g1 = (q1 >> 5) & 31, b1 = q1 & 31;
+			for (int dr = -4; dr <= 3; ++dr) {
+				const int r2 = r1 + dr;
+				if (r2 < 0 || r2 > 31) continue;
+				for (int dg = -4; dg <= 3; ++dg) {
+					const int g2 = g1 + dg;
+					if (g2 < 0 || g2 > 31) continue;
+					for (int db = -4; db <= 3; ++db) {
+						const int b2 = b1 + db;
+						if (b2 < 0 || b2 > 31) continue;
+						const int q2 = (r2 << 10) | (g2 << 5) | b2;
+						const uint32_t e = e5[0][q1] + e5[1][q2];
+						if (e < bd) {
+							bd = e;
+							qd[0] = q1;
+							qd[1] = q2;
+						}
+					}
+				}
+			}
+		}
+		for (int kind = 0; kind < 2; ++kind) {       /* 0 differential, 1 individual */
+			const uint32_t e = kind ? e4[0][qi[0]] + e4[1][qi[1]] : bd;
+			if (e >= best)
+				continue;
+			best = e;
+			int q[2][3], table[2] = {0, 0};
+			uint8_t sel[16];
+			for (int s = 0; s < 2; ++s) {
+				const int w = kind ? qi[s] : qd[s], bits = kind ? 4 : 5, mk = (1 << bits) - 1;
+				q[s][0] = w >> (2*bits); q[s][1] = (w >> bits) & mk; q[s][2] = w & mk;
+				int c[3];
+				for (int ch = 0; ch < 3; ++ch)
+					c[ch] = kind ? ex4(q[s][ch]) : ex5(q[s][ch]);
+				uint32_t be = 0xFFFFFFFFu;
+				for (int t = 0; t < 8; ++t) {
+					uint32_t e2 = half_err(px, &o, flip, s, c, t, NULL);
+					if (e2 < be) {
+						be = e2;
+						table[s] = t;
+					}
+				}
+				half_err(px, &o, flip, s, c, table[s], sel);
+			}
+			pack_etc(!kind, flip, (const int (*)[3])q, table, !kind, sel, out);
+		}
+	}
+	for (int s = 0; s < 2; ++s) {
+		free(e5[s]);
+		free(e4[s]);
+	}
+	if (!etc2)
+		return best;
+
+	/* planar: channel by channel */
+	{
+		planar_q pq;
+		uint32_t total = 0;
+		for (int c = 0; c < 3; ++c) {
+			const int n = c == 1 ? 128 : 64;
+			uint32_t bc = 0xFFFFFFFFu;
+			for (int O = 0; O < n; ++O) {
+				const int o8 = c == 1 ? ex7(O) : ex6(O);
+				for (int H = 0; H < n; ++H) {
+					const int h8 = c == 1 ? ex7(H) : ex6(H);
+					/* the part of the error that does not depend on V: row y = 0 */
+					uint32_t e0 = 0;
+					for (int x = 0; x < 4; ++x) {
+						int d = clamp255((x*(h8 - o8) + 4*o8 + 2) >> 2) - px[x][c];
+						e0 += (uint32_t)(d*d);
+					}
+					if (e0 >= bc)
+						continue;
+					for (int V = 0; V < n; ++V) {
+						const int v8 = c == 1 ? ex7(V) : ex6(V);
+						uint32_t e = e0;
+						for (int i = 4; i < 16 && e < bc; ++i) {
+							int x = i & 3, y = i >> 2;
+							int d = clamp255((x*(h8 - o8) + y*(v8 - o8) + 4*o8 + 2) >> 2) - px[i][c];
+							e += (uint32_t)(d*d);
+						}
+						if (e < bc) {
+							bc = e;
+							pq.O[c] = O; pq.H[c] = H; pq.V[c] = V;
+						}
+					}
+				}
+			}
+			total += bc;
+		}
+		if (total < best) {
+			best = total;
+			pack_planar(&pq, out);
+		}
+	}
+
+	/* T and H */
+	int lo[3] = {255, 255, 255}, hi[3] = {0, 0, 0};
+	for (int i = 0; i < 16; ++i)
+		for (int c = 0; c < 3; ++c) {
+			if (px[i][c] < lo[c]) lo[c] = px[i][c];
+			if (px[i][c] > hi[c]) hi[c] = px[i][c];
+		}
+	o.allow_planar = 1;
+	o.refine = 1;
+	th_cand bt;
+	int have = 0;
+	for (int di = 0; di < 8; ++di) {
+		const int d = etc_dist[di];
+		int b0[3], b1[3], a0[3], a1[3];
+		for (int c = 0; c < 3; ++c) {
+			b0[c] = clampi((lo[c] - d)/17 - 1, 0, 15);         /* floor for negatives too: one more step down */
+			b1[c] = clampi((hi[c] + d + 16)/17, 0, 15);
+			a0[c] = clampi(lo[c]/17, 0, 15);
+			a1[c] = clampi((hi[c] + 16)/17, 0, 15);
+		}
+		/* per-texel error of the paints a base colour offers, for every base colour of the boxes:
+		 * eb[..][i] = min over (B + d, B, B - d) or (X + d, X - d); ea = |p - A|^2 */
+		const int nb = (b1[0] - b0[0] + 1)*(b1[1] - b0[1] + 1)*(b1[2] - b0[2] + 1);
+		const int na = (a1[0] - a0[0] + 1)*(a1[1] - a0[1] + 1)*(a1[2] - a0[2] + 1);
+		uint32_t* eb3 = (uint32_t*)malloc((size_t)nb*16*sizeof(uint32_t));   /* T: three paints */
+		uint32_t* eb2 = (uint32_t*)malloc((size_t)nb*16*sizeof(uint32_t));   /* H: two paints */
+		uint32_t* ea = (uint32_t*)malloc((size_t)na*16*sizeof(uint32_t));
+		int* cb = (int*)malloc((size_t)nb*3*sizeof(int));
+		int* ca = (int*)malloc((size_t)na*3*sizeof(int));
+		int k = 0;
+		for (int r = b0[0]; r <= b1[0]; ++r)
+			for (int g = b0[1]; g <= b1[1]; ++g)
+				for (int b = b0[2]; b <= b1[2]; ++b, ++k) {
+					cb[3*k] = r; cb[3*k + 1] = g; cb[3*k + 2] = b;
+					const int base[3] = {ex4(r), ex4(g), ex4(b)};
+					for (int i = 0; i < 16; ++i) {
+						uint32_t em = 0, ep = 0, e0 = 0;
+						for (int c = 0; c < 3; ++c) {
+							int dm = clamp255(base[c] - d) - px[i][c], dp = clamp255(base[c] + d) - px[i][c], d0 = base[c] - px[i][c];
+							em += (uint32_t)(dm*dm); ep += (uint32_t)(dp*dp); e0 += (uint32_t)(d0*d0);
+						}
+						const uint32_t m2 = em < ep ? em : ep;
+						eb2[(size_t)k*16 + i] = m2;
+						eb3[(size_t)k*16 + i] = m2 < e0 ? m2 : e0;
+					}
+				}
+		k = 0;
+		for (int r = a0[0]; r <= a1[0]; ++r)
+			for (int g = a0[1]; g <= a1[1]; ++g)
+				for (int b = a0[2]; b <= a1[2]; ++b, ++k) {
+					ca[3*k] = r; ca[3*k + 1] = g; ca[3*k + 2] = b;
+					for (int i = 0; i < 16; ++i) {
+						uint32_t e0 = 0;
+						const int base[3] = {ex4(r), ex4(g), ex4(b)};
+						for (int c = 0; c < 3; ++c) {
+							int d0 = base[c] - px[i][c];
+							e0 += (uint32_t)(d0*d0);
+						}
+						ea[(size_t)k*16 + i] = e0;
+					}
+				}
+		/* T: A from its box, B from its box */
+		for (int ia = 0; ia < na; ++ia)
+			for (int ib = 0; ib < nb; ++ib) {
+				uint32_t e = 0;
+				const uint32_t* pa = ea + (size_t)ia*16;
+				const uint32_t* pb = eb3 + (size_t)ib*16;
+				for (int i = 0; i < 16 && e < best; ++i)
+					e += pa[i] < pb[i] ? pa[i] : pb[i];
+				if (e < best) {
+					best = e;
+					bt.mode = 1; bt.di = di;
+					memcpy(bt.c[0], ca + 3*ia, 3*sizeof(int));
+					memcpy(bt.c[1], cb + 3*ib, 3*sizeof(int));
+					have = 1;
+				}
+			}
+		/* H: both colours from the wide box (unordered pairs) */
+		for (int ia = 0; ia < nb; ++ia)
+			for (int ib = ia; ib < nb; ++ib) {
+				if (ia == ib && !(di & 1))
+					continue;               /* equal colours can only carry an odd distance index */
+				uint32_t e = 0;
+				const uint32_t* pa = eb2 + (size_t)ia*16;
+				const uint32_t* pb = eb2 + (size_t)ib*16;
+				for (int i = 0; i < 16 && e < best; ++i)
+					e += pa[i] < pb[i] ? pa[i] : pb[i];
+				if (e < best) {
+					best = e;
+					bt.mode = 2; bt.di = di;
+					memcpy(bt.c[0], cb + 3*ia, 3*sizeof(int));
+					memcpy(bt.c[1], cb + 3*ib, 3*sizeof(int));
+					have = 1;
+				}
+			}
+		free(eb3); free(eb2); free(ea); free(cb); free(ca);
+	}
+	if (have) {
+		bt.err = best;
+		bt.id = 0;
+		pack_th(&bt, px, &o, out);
+	}
+	return best;
 }

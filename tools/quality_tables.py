@@ -76,6 +76,35 @@ def bc7_gap(count, rng, threads=None):
     return rows
 
 
+def etc_gap(count, rng, fmt=38, img=None, threads=None):
+    """-> ([PSNR at Q0..Q4], PSNR of the TRUE optimum, modes the optimum uses) of ETC1 (fmt 37) / ETC2 RGB (38) on
+    `count` sampled opaque blocks: cfo_etc_true_optimum enumerates every block the format can express."""
+    from concurrent.futures import ThreadPoolExecutor
+    L = O.lib()
+    L.cfo_etc_true_optimum.restype = ctypes.c_uint32
+    L.cfo_etc_true_optimum.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    threads = threads or min(8, os.cpu_count() or 1)
+    if img is None:
+        img = synth.photo(512, 512, seed=21)
+    img = img.copy()
+    img[..., 3] = 255
+    blocks = np.ascontiguousarray(sample_blocks(img, count, rng).astype(np.uint8).reshape(count, 4, 4, 4))
+
+    def work(i):
+        out = np.zeros(8, np.uint8)
+        return L.cfo_etc_true_optimum(blocks[i].ctypes.data, 1 if fmt == 38 else 0, out.ctypes.data)
+    with ThreadPoolExecutor(threads) as ex:
+        opt = np.array(list(ex.map(work, range(count))), np.float64)
+    strip = np.ascontiguousarray(np.concatenate(list(blocks), axis=1))          # 4 x 4*count
+    ps = []
+    for q in range(5):
+        dec = O.decode_etc(O.encode(strip, fmt, quality=q, threads=threads), fmt, 4 * count, 4)
+        e = ((dec[..., :3].astype(np.int64) - strip[..., :3]) ** 2).reshape(4, count, 4, 3).sum(axis=(0, 2, 3))
+        assert (e >= opt).all(), "a block decodes better than the enumerated optimum"
+        ps.append(psnr_from_sse(float(e.sum()), count * 48))
+    return ps, psnr_from_sse(float(opt.sum()), count * 48)
+
+
 def bc6h_gap(count, rng):
     L = O.lib()
     L.cfo_bc6h_wide_search.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(O.Params)]
@@ -158,6 +187,10 @@ def main():
     print("|---|---|---|---|---|---|---|---|---|---|---|")
     for label, ps in bc7_gap(a.blocks, rng):
         print("| BC7 | %s | %s | %.3f | %.3f | %.3f | %.3f |" % (label, " | ".join("%.3f" % v for v in ps[:5]), ps[5], ps[5] - ps[2], ps[5] - ps[3], ps[5] - ps[4]))
+    for fmt, name in ((37, "ETC1"), (38, "ETC2 RGB")):
+        ps, opt = etc_gap(max(256, a.blocks // 2), rng, fmt)
+        print("| %s | opaque; bound = the TRUE optimum (every expressible block, `cfo_etc_true_optimum`) | %s | %.3f | %.3f | %.3f | %.3f |"
+              % (name, " | ".join("%.3f" % v for v in ps), opt, opt - ps[2], opt - ps[3], opt - ps[4]))
     ps = bc6h_gap(max(256, a.blocks // 2), rng)
     print("| BC6H UF16 | HDR probe (log-domain PSNR) | %s | %.3f | %.3f | %.3f | %.3f |" % (" | ".join("%.3f" % v for v in ps[:5]), ps[5], ps[5] - ps[2], ps[5] - ps[3], ps[5] - ps[4]))
 
