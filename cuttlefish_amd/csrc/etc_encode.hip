@@ -471,29 +471,40 @@ __device__ __forceinline__ bool th_search(const uint32_t* tp, const RgbOpts& o, 
 		const uint32_t both = part + cf_xor1(part);
 		t.err = (cand < 24u && part != 0xFFFFFFFFu) ? pp + both : 0xFFFFFFFFu;
 	}
-	unsigned long long key = ((unsigned long long)t.err << 32) | cand;
-	unsigned long long kmin = cf_wave_min_u64(key);
-	if ((uint32_t)(kmin >> 32) == 0xFFFFFFFFu)
-		return false;
+	// Two tracks (oracle: th_search): the best T candidate (cands 0..15) and the best H candidate (16..23) are
+	// refined side by side -- the cluster means serve T's lone colour well and H's paint pairs less, so an H
+	// block rarely leads before its colours have moved.  Track h lives in the 32-lane half h of the wave:
+	// its state (colours, distance, error) is uniform inside the half, its 14 moves take two lanes each
+	// (eight texels per lane), and the round's best move is the minimum of (error, move) over the half.
+	// A track's state is ONE packed word (c0 | c1 << 12 | di << 24 | mode << 28) and its error: two registers
+	// across the rounds, unpacked where a round needs the fields.
+	const uint32_t h = lane >> 5, l = lane & 31u;
+	uint32_t cur_w, cur_err;
+#define TH_PACK(T) ((T).c0 | ((T).c1 << 12) | ((uint32_t)(T).di << 24) | ((uint32_t)(T).mode << 28))
 	{
-		const int src = (int)(2u*(uint32_t)kmin);   // first lane of the winning candidate
-		best.mode = __builtin_amdgcn_ds_bpermute(src << 2, t.mode);
-		best.c0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)t.c0);
-		best.c1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)t.c1);
-		best.di = __builtin_amdgcn_ds_bpermute(src << 2, t.di);
-		best.err = (uint32_t)(kmin >> 32);
+		// (a candidate outside a track enters with error 0xFFFFFFFF -- an inline constant; a 64-bit all-ones
+		// select value was hoisted into a register pair that lived through the whole kernel)
+		const unsigned long long kt = cf_wave_min_u64(((unsigned long long)(cand < 16u ? t.err : 0xFFFFFFFFu) << 32) | cand);
+		const unsigned long long kh = cf_wave_min_u64(((unsigned long long)((cand >= 16u && cand < 24u) ? t.err : 0xFFFFFFFFu) << 32) | cand);
+		if ((uint32_t)(kt >> 32) == 0xFFFFFFFFu && (uint32_t)(kh >> 32) == 0xFFFFFFFFu)
+			return false;
+		const unsigned long long km = h ? kh : kt;
+		const int src = (int)(2u*((uint32_t)km & 63u));   // first lane of the track's winning candidate
+		cur_w = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)TH_PACK(t));
+		cur_err = (uint32_t)(km >> 32);
 	}
 	for (int r = 0; r < rounds; ++r) {
-		// 14 single moves, four lanes per move (four texels each)
-		ThCand mvc = best;
-		const uint32_t mv = lane >> 2;
-		bool ok = mv < 14u;
+		ThCand mvc;
+		mvc.c0 = cur_w & 0xFFFu; mvc.c1 = (cur_w >> 12) & 0xFFFu; mvc.di = (int)((cur_w >> 24) & 7u);
+		mvc.mode = (int)(cur_w >> 28); mvc.err = 0;
+		const uint32_t mv = l >> 1;
+		bool ok = mv < 14u && cur_err != 0xFFFFFFFFu;
 		const int d = (mv & 1u) ? 1 : -1;
 		if (mv < 12u) {
 			const int f = (int)(mv >> 1);
 			const uint32_t cw = f < 3 ? mvc.c0 : mvc.c1;
 			const int sh = 4*(f % 3), nv = (int)((cw >> sh) & 15u) + d;
-			ok = nv >= 0 && nv <= 15;
+			ok = ok && nv >= 0 && nv <= 15;
 			const uint32_t nw = (cw & ~(15u << sh)) | ((uint32_t)(nv & 15) << sh);
 			if (f < 3) mvc.c0 = nw; else mvc.c1 = nw;
 		} else {
@@ -501,19 +512,28 @@ __device__ __forceinline__ bool th_search(const uint32_t* tp, const RgbOpts& o, 
 			ok = ok && nv >= 0 && nv <= 7;
 			mvc.di = nv & 7;
 		}
-		const uint32_t part = th_err<UNITW>(tp, o.active, (lane & 3u)*4u, 4u, o, mvc);
-		uint32_t sum4 = part + cf_xor1(part);
-		sum4 += cf_xor2(sum4);
-		const uint32_t e = (ok && part != 0xFFFFFFFFu) ? pp + sum4 : 0xFFFFFFFFu;
-		key = ((unsigned long long)e << 32) | mv;
-		kmin = cf_wave_min_u64(key);
-		if ((uint32_t)(kmin >> 32) >= best.err)
-			break;
-		const int src = (int)(4u*(uint32_t)kmin);
-		best.c0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)mvc.c0);
-		best.c1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)mvc.c1);
-		best.di = __builtin_amdgcn_ds_bpermute(src << 2, mvc.di);
-		best.err = (uint32_t)(kmin >> 32);
+		const uint32_t part = th_err<UNITW>(tp, o.active, (l & 1u)*8u, 8u, o, mvc);
+		const uint32_t sum2 = part + cf_xor1(part);
+		const uint32_t e = (ok && part != 0xFFFFFFFFu) ? pp + sum2 : 0xFFFFFFFFu;
+		const unsigned long long key = ((unsigned long long)e << 32) | mv;
+		const unsigned long long kmin = cf_group_min_u64(key, true, h);
+		const bool better = (uint32_t)(kmin >> 32) < cur_err;
+		if (__ballot(better) == 0ull)
+			break;                  // neither track moved: later rounds would repeat this one
+		const int src = (int)(32u*h + 2u*((uint32_t)kmin & 15u));
+		const uint32_t nw = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)TH_PACK(mvc));
+		if (better) {
+			cur_w = nw;
+			cur_err = (uint32_t)(kmin >> 32);
+		}
+	}
+#undef TH_PACK
+	// the better track (ties: T, whose candidate ids come first); uniform result
+	{
+		const uint32_t et = (uint32_t)__builtin_amdgcn_readlane((int)cur_err, 0), eh = (uint32_t)__builtin_amdgcn_readlane((int)cur_err, 32);
+		const uint32_t w = eh < et ? (uint32_t)__builtin_amdgcn_readlane((int)cur_w, 32) : (uint32_t)__builtin_amdgcn_readlane((int)cur_w, 0);
+		best.c0 = w & 0xFFFu; best.c1 = (w >> 12) & 0xFFFu; best.di = (int)((w >> 24) & 7u); best.mode = (int)(w >> 28);
+		best.err = eh < et ? eh : et;
 	}
 	return true;
 }
@@ -1120,9 +1140,18 @@ cfhip_etc_encode_kernel(cf_kparams kp)
 			o.allow_planar = true;
 			w0 = rgb_search(tp, o, lane);
 		} else if (FMT == E_A8) {
+			// the alpha block goes to its place in LDS at once: nothing of it is held in registers through
+			// the colour search (uniform result: every lane holds it, lane 0 stores it)
 			w0 = eac_search(tp, pre, 0, 3, valid, R, lane);
+			if (lane == 0u) {
+				outb[b*4u] = w0.x; outb[b*4u + 1u] = w0.y;
+			}
 			o.allow_indiv = true; o.allow_planar = true;
 			w1 = rgb_search(tp, o, lane);
+			if (lane == 0u) {
+				outb[b*4u + 2u] = w1.x; outb[b*4u + 3u] = w1.y;
+			}
+			continue;
 		} else {
 			w0 = eac_search(tp, pre, SNORM ? 2 : 1, 0, valid, R, lane);
 			if (FMT == E_RG11)

@@ -636,8 +636,13 @@ static int th_search(const int px[16][4], const rgb_opts* o, int rounds, th_cand
 		m[0][c] = (a*15 + 127)/255;
 		m[1][c] = (b*15 + 127)/255;
 	}
-	best->err = 0xFFFFFFFFu;
-	best->id = 0x7FFFFFFF;
+	/* two tracks: the best T candidate and the best H candidate are refined side by side (the cluster means
+	 * serve T's lone colour well and H's paint pairs less: an H block rarely leads before its colours move) */
+	th_cand track[2];
+	for (int k = 0; k < 2; ++k) {
+		track[k].err = 0xFFFFFFFFu;
+		track[k].id = 0x7FFFFFFF;
+	}
 	for (int v = 0; v < 3; ++v)
 		for (int di = 0; di < 8; ++di) {
 			th_cand t;
@@ -647,39 +652,46 @@ static int th_search(const int px[16][4], const rgb_opts* o, int rounds, th_cand
 			memcpy(t.c[0], m[v == 1 ? 1 : 0], sizeof(t.c[0]));
 			memcpy(t.c[1], m[v == 1 ? 0 : 1], sizeof(t.c[1]));
 			t.err = th_err(px, o, &t, NULL);
-			if (t.err < best->err || (t.err == best->err && t.id < best->id))
-				*best = t;
+			th_cand* b = &track[t.mode - 1];
+			if (t.err < b->err || (t.err == b->err && t.id < b->id))
+				*b = t;
 		}
-	if (best->err == 0xFFFFFFFFu)
+	if (track[0].err == 0xFFFFFFFFu && track[1].err == 0xFFFFFFFFu)
 		return 0;
 	/* moves 0..11: field f = mv >> 1 (c[0].rgb, c[1].rgb), delta -1 / +1; 12, 13: di -1 / +1 */
-	for (int r = 0; r < rounds; ++r) {
-		th_cand bt = *best;
-		int bmv = -1;
-		for (int mv = 0; mv < 14; ++mv) {
-			th_cand t = *best;
-			int d = (mv & 1) ? 1 : -1;
-			if (mv < 12) {
-				int f = mv >> 1, nv = t.c[f/3][f % 3] + d;
-				if (nv < 0 || nv > 15)
-					continue;
-				t.c[f/3][f % 3] = nv;
-			} else {
-				int nv = t.di + d;
-				if (nv < 0 || nv > 7)
-					continue;
-				t.di = nv;
+	for (int k = 0; k < 2; ++k) {
+		th_cand* cur = &track[k];
+		if (cur->err == 0xFFFFFFFFu)
+			continue;
+		for (int r = 0; r < rounds; ++r) {
+			th_cand bt = *cur;
+			int bmv = -1;
+			for (int mv = 0; mv < 14; ++mv) {
+				th_cand t = *cur;
+				int d = (mv & 1) ? 1 : -1;
+				if (mv < 12) {
+					int f = mv >> 1, nv = t.c[f/3][f % 3] + d;
+					if (nv < 0 || nv > 15)
+						continue;
+					t.c[f/3][f % 3] = nv;
+				} else {
+					int nv = t.di + d;
+					if (nv < 0 || nv > 7)
+						continue;
+					t.di = nv;
+				}
+				t.err = th_err(px, o, &t, NULL);
+				if (t.err < bt.err) {
+					bt = t;
+					bmv = mv;
+				}
 			}
-			t.err = th_err(px, o, &t, NULL);
-			if (t.err < bt.err) {
-				bt = t;
-				bmv = mv;
-			}
+			if (bmv < 0)
+				break;
+			*cur = bt;
 		}
-		if (bmv < 0)
-			break;
-		*best = bt;
 	}
+	*best = (track[1].err < track[0].err || (track[1].err == track[0].err && track[1].id < track[0].id)) ? track[1] : track[0];
 	return 1;
 }
 
