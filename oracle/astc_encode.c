@@ -813,6 +813,10 @@ static void hdr_phase_b(const astc_blk* b, const astc_pc* pc, const astc_cfg* cf
 	L->lv = lv;
 }
 
+/* test-only hooks of the wide search (cfo_astc_wide_search, end of file): force one endpoint option instead of
+ * choosing by the estimate, lift the footprint rule of base + offset, and hand back the decoded endpoints */
+static __thread struct { int force_opt, wide, have; int D0[4][4], D1[4][4]; } tl_wide = {-1, 0, 0, {{0}}, {{0}}};
+
 static void phase_b(const astc_blk* b, int j, const astc_pc* pc, const astc_cfg* cfg, astc_lane* L)
 {
 	const astc_tables* T = astc_get_tables();
@@ -907,7 +911,9 @@ static void phase_b(const astc_blk* b, int j, const astc_pc* pc, const astc_cfg*
 	for (int o = 0; o < 4; ++o) {
 		int nv = nvo[o];
 		if (nv*P > 18 || (o == 2 && !b->grey) || ((o == 1 || o == 2) && pc->dual && pc->ccs < 3) || (o > 0 && b->hdr) ||
-			(o == 3 && n > 20))    /* base + offset pays on 4x4 / 5x4 only: +0.35 / +0.24 dB there, <= 0.06 dB elsewhere */
+			(o == 3 && n > 20 && !tl_wide.wide))    /* base + offset pays on 4x4 / 5x4 only: +0.35 / +0.24 dB there, <= 0.06 dB elsewhere */
+			continue;
+		if (tl_wide.force_opt >= 0 && o != tl_wide.force_opt)
 			continue;
 		int lv = T->c_level[nv*P/2][cfg->cbits];
 		if (lv < 0 || cfg->cbits < (13*nv*P + 4)/5)
@@ -1099,6 +1105,11 @@ static void phase_b(const astc_blk* b, int j, const astc_pc* pc, const astc_cfg*
 			else ea = (uint32_t)(b->cw[3]*d*d);
 		}
 		err += (uint64_t)ergb*(uint64_t)b->wa[i] + (uint64_t)ea*255u;
+	}
+	if (tl_wide.wide) {
+		tl_wide.have = 1;
+		memcpy(tl_wide.D0, D0[best_opt], sizeof(tl_wide.D0));
+		memcpy(tl_wide.D1, D1[best_opt], sizeof(tl_wide.D1));
 	}
 	L->err = err;
 	L->valid = 1;
@@ -1336,6 +1347,33 @@ static void void_extent_lns(const int c[4], int hdr_alpha, uint8_t out[16])
 	}
 }
 
+/* the 128 bits of a (candidate, config, lane result) */
+static void pack_block(const astc_fmt* f, const astc_pc* pc, const astc_cfg* cfg, const astc_lane* best, uint8_t out[16])
+{
+	memset(out, 0, 16);
+	putbits(out, 0, cfg->mode, 11);
+	putbits(out, 11, (unsigned)(pc->P - 1), 2);
+	int cstart;
+	if (pc->P == 1) {
+		putbits(out, 13, (unsigned)best->cem, 4);
+		cstart = 17;
+	} else {
+		putbits(out, 13, f->pseed[pc->P - 2][pc->tab], 10);
+		putbits(out, 23, 0, 2);
+		putbits(out, 25, (unsigned)best->cem, 4);
+		cstart = 29;
+	}
+	astc_ise_encode(&astc_cq[best->lv], best->cvals, best->ncv, out, cstart);
+	if (pc->dual)
+		putbits(out, 128 - cfg->wbits - 2, (unsigned)pc->ccs, 2);
+	uint8_t ws[16];
+	memset(ws, 0, sizeof(ws));
+	astc_ise_encode(&astc_wq[cfg->wq], best->wq, cfg->nw, ws, 0);
+	for (int i = 0; i < cfg->wbits; ++i)
+		if ((ws[i >> 3] >> (i & 7)) & 1)
+			out[(127 - i) >> 3] |= (uint8_t)(1u << ((127 - i) & 7));
+}
+
 static void encode_core(const int px[][4], const int lns[][4], int bw, int bh, int quality, int flags, uint8_t out[16]);
 
 /* px: bw*bh texels RGBA u8 (swizzled, edge-replicated) */
@@ -1563,48 +1601,20 @@ static void encode_core(const int px[][4], const int lns[][4], int bw, int bh, i
 		free(b);
 		return;
 	}
-	/* pack */
-	const astc_pc* pc = &pcs[best_pc];
-	const astc_cfg* cfg = &f->cfg[pc->cls][b->has_alpha][best_k];
-	putbits(out, 0, cfg->mode, 11);
-	putbits(out, 11, (unsigned)(pc->P - 1), 2);
-	int cstart;
-	if (pc->P == 1) {
-		putbits(out, 13, (unsigned)best.cem, 4);
-		cstart = 17;
-	} else {
-		putbits(out, 13, f->pseed[pc->P - 2][pc->tab], 10);
-		putbits(out, 23, 0, 2);
-		putbits(out, 25, (unsigned)best.cem, 4);
-		cstart = 29;
-	}
-	astc_ise_encode(&astc_cq[best.lv], best.cvals, best.ncv, out, cstart);
-	if (pc->dual)
-		putbits(out, 128 - cfg->wbits - 2, (unsigned)pc->ccs, 2);
-	uint8_t ws[16];
-	memset(ws, 0, sizeof(ws));
-	astc_ise_encode(&astc_wq[cfg->wq], best.wq, cfg->nw, ws, 0);
-	for (int i = 0; i < cfg->wbits; ++i)
-		if ((ws[i >> 3] >> (i & 7)) & 1)
-			out[(127 - i) >> 3] |= (uint8_t)(1u << ((127 - i) & 7));
+	pack_block(f, &pcs[best_pc], &f->cfg[pcs[best_pc].cls][b->has_alpha][best_k], &best, out);
 	free(b);
 }
 
 
-/* ------------------------------------------------------------------ census (tools/astc_rank_configs.py)
- * For every non-constant block of an RGBA8 image and every candidate class (one partition, dual
- * plane, 2 / 3 / 4 partitions -- the class's best shortlisted candidate): which of ALL legal
- * configs gives the smallest exact error.  counts[(cls*2 + alpha)*4096 + (N | M << 4 | wq << 8)]. */
-int cfo_astc_census_image(const uint8_t* rgba, int w, int h, int bw, int bh, int flags, uint32_t* counts)
+/* the footprint's tables with EVERY legal config and grid listed (the encoder's own lists hold the 64 best
+ * ranked configs of a class and 24 grids); partition tables shared with the encoder's */
+static const astc_fmt* census_fmt(const astc_fmt* base)
 {
 	static astc_fmt* cf[14];
-	const astc_fmt* base = get_fmt(bw, bh);
-	if (!base)
-		return -1;
 	pthread_mutex_lock(&g_fmt_lock);
 	if (!cf[base->fp]) {
 		astc_fmt* f = (astc_fmt*)calloc(1, sizeof(astc_fmt));
-		f->bw = bw; f->bh = bh; f->n = bw*bh; f->fp = base->fp; f->census = 1;
+		f->bw = base->bw; f->bh = base->bh; f->n = base->n; f->fp = base->fp; f->census = 1;
 		for (int cls = 0; cls < 5; ++cls)
 			for (int a = 0; a < 2; ++a)
 				build_configs(f, cls, a);
@@ -1615,7 +1625,19 @@ int cfo_astc_census_image(const uint8_t* rgba, int w, int h, int bw, int bh, int
 		cf[base->fp] = f;
 	}
 	pthread_mutex_unlock(&g_fmt_lock);
-	const astc_fmt* f = cf[base->fp];
+	return cf[base->fp];
+}
+
+/* ------------------------------------------------------------------ census (tools/astc_rank_configs.py)
+ * For every non-constant block of an RGBA8 image and every candidate class (one partition, dual
+ * plane, 2 / 3 / 4 partitions -- the class's best shortlisted candidate): which of ALL legal
+ * configs gives the smallest exact error.  counts[(cls*2 + alpha)*4096 + (N | M << 4 | wq << 8)]. */
+int cfo_astc_census_image(const uint8_t* rgba, int w, int h, int bw, int bh, int flags, uint32_t* counts)
+{
+	const astc_fmt* base = get_fmt(bw, bh);
+	if (!base)
+		return -1;
+	const astc_fmt* f = census_fmt(base);
 	int n = bw*bh;
 	astc_blk* b = (astc_blk*)malloc(sizeof(astc_blk));
 	for (int by = 0; by + bh <= h; by += bh)
@@ -1686,4 +1708,179 @@ int cfo_astc_census_image(const uint8_t* rgba, int w, int h, int bw, int bh, int
 		}
 	free(b);
 	return 0;
+}
+
+
+/* ------------------------------------------------------------------ test-only: the WIDE search (LDR profile)
+ * The bound the effort ladder is measured against (tools/quality_tables.py, tests/test_oracle_bounds.py).
+ *   candidates: one partition; a second weight plane on EVERY component; every canonical seed of the 2-, 3-
+ *               and 4-partition tables (the encoder shortlists a handful by k-means overlap);
+ *   configs:    every legal block mode of the candidate's class (grid x weight range: up to 200, the
+ *               encoder's lists hold the 64 best ranked and it tries 2..8 of them) -- for the seeds in two
+ *               stages: every seed with the first ASTC_WIDE_STAGE1 configs of the census list, then the
+ *               ASTC_WIDE_KEEP best seeds of each partition count with all of them;
+ *   endpoints:  every endpoint mode family the encoder knows (direct with / without blue contraction, base +
+ *               scale, luminance, base + offset on every footprint), each FORCED and measured by its exact
+ *               error instead of chosen by the quadratic estimate;
+ *   refinement: the ASTC_WIDE_TOP best (candidate, config, mode) triples are iterated -- ideal weights
+ *               re-projected on the DECODED endpoints, decimated, quantised, endpoints refitted -- until a
+ *               round does not improve (at most 6 rounds).
+ * One endpoint mode for all partitions of a block, like the encoder.  Returns the exact error of the block it
+ * writes (the caller measures the block through the decoder like any other payload). */
+#define ASTC_WIDE_STAGE1 24
+#define ASTC_WIDE_KEEP 32
+#define ASTC_WIDE_TOP 12
+
+typedef struct { uint64_t err; astc_pc pc; int k, opt; astc_lane lane; } wide_hit;
+
+static void wide_note(wide_hit* top, int* ntop, const wide_hit* h)
+{
+	int pos = *ntop;
+	while (pos > 0 && h->err < top[pos - 1].err)
+		--pos;
+	if (pos >= ASTC_WIDE_TOP)
+		return;
+	int last = *ntop < ASTC_WIDE_TOP ? *ntop : ASTC_WIDE_TOP - 1;
+	for (int i = last; i > pos; --i)
+		top[i] = top[i - 1];
+	top[pos] = *h;
+	if (*ntop < ASTC_WIDE_TOP)
+		++*ntop;
+}
+
+/* ideal weights of candidate slot 0 re-projected on decoded endpoints (D0 / D1 per partition) */
+static void wide_reproject(astc_blk* b, const astc_pc* pc, const int D0[4][4], const int D1[4][4])
+{
+	for (int pl = 0; pl < (pc->dual ? 2 : 1); ++pl)
+		for (int i = 0; i < b->n; ++i) {
+			const int p = pc_part(b, pc, i);
+			int t = 0, dd = 0;
+			for (int c = 0; c < b->nc; ++c) {
+				if (pc->dual && (c == pc->ccs) != pl)
+					continue;
+				const int dv = D1[p][c] - D0[p][c];
+				t += (b->px[i][c] - D0[p][c])*dv*b->cw[c];
+				dd += dv*dv*b->cw[c];
+			}
+			int Tw = 0;
+			if (t > 0 && dd > 0) {
+				int tc = t > dd ? dd : t;
+				Tw = (int)((128ll*tc + dd)/(2ll*dd));
+				if (Tw > 64) Tw = 64;
+			}
+			b->T[0][pl][i] = (uint8_t)Tw;
+		}
+}
+
+uint64_t cfo_astc_wide_search(const uint8_t* rgba, int bw, int bh, int flags, uint8_t out[16])
+{
+	const astc_fmt* base = get_fmt(bw, bh);
+	if (!base)
+		return ~0ull;
+	const astc_fmt* f = census_fmt(base);
+	const int n = bw*bh;
+	astc_blk* b = (astc_blk*)calloc(1, sizeof(astc_blk));
+	int solid = 1;
+	b->f = f; b->n = n; b->flags = flags; b->grey = 1;
+	for (int i = 0; i < n; ++i) {
+		for (int c = 0; c < 4; ++c) b->px[i][c] = rgba[4*i + c];
+		if (memcmp(b->px[i], b->px[0], 4*sizeof(int)) != 0) solid = 0;
+		if (rgba[4*i + 3] != 255) b->has_alpha = 1;
+		if (rgba[4*i] != rgba[4*i + 1] || rgba[4*i] != rgba[4*i + 2]) b->grey = 0;
+		b->wa[i] = (flags & ASTC_FLAG_ALPHA_WEIGHT) ? rgba[4*i + 3] : 255;
+	}
+	if (solid) {
+		void_extent(b->px[0], out);
+		free(b);
+		return 0;
+	}
+	b->nc = b->has_alpha ? 4 : 3;
+	static const int cw_uniform[4] = {1, 1, 1, 1}, cw_perceptual[4] = {11, 21, 4, 16};
+	memcpy(b->cw, (flags & ASTC_FLAG_PERCEPTUAL) ? cw_perceptual : cw_uniform, sizeof(b->cw));
+	tl_wide.wide = 1;
+	wide_hit top[ASTC_WIDE_TOP];
+	int ntop = 0;
+	astc_lane cur;
+	/* every config x every endpoint option of one candidate (configs [k0, k1) of its class list) */
+#define WIDE_CAND(PC, K0, K1, BESTERR) do { \
+		const astc_pc* pc_ = (PC); \
+		const int slots_ = pc_->dual ? 2 : pc_->P; \
+		for (int s_ = 0; s_ < slots_; ++s_) phase_a(b, 0, pc_, s_); \
+		const int ncfg_ = f->ncfg[pc_->cls][b->has_alpha]; \
+		for (int k_ = (K0); k_ < (K1) && k_ < ncfg_; ++k_) \
+			for (int o_ = 0; o_ < 4; ++o_) { \
+				tl_wide.force_opt = o_; \
+				phase_b(b, 0, pc_, &f->cfg[pc_->cls][b->has_alpha][k_], &cur); \
+				if (!cur.valid) continue; \
+				if (cur.err < (BESTERR)) (BESTERR) = cur.err; \
+				wide_hit h_; h_.err = cur.err; h_.pc = *pc_; h_.k = k_; h_.opt = o_; h_.lane = cur; \
+				wide_note(top, &ntop, &h_); \
+			} \
+	} while (0)
+	uint64_t dummy = ~0ull;
+	astc_pc pc1 = {1, 0, 0, 0, 0};
+	WIDE_CAND(&pc1, 0, ASTC_MAX_CFG, dummy);
+	for (int ccs = 0; ccs < b->nc; ++ccs) {
+		astc_pc pd = {1, 1, ccs, 1, 0};
+		WIDE_CAND(&pd, 0, ASTC_MAX_CFG, dummy);
+	}
+	for (int P = 2; P <= 4; ++P) {
+		const int np = f->npart[P - 2];
+		uint64_t* serr = (uint64_t*)malloc((size_t)np*sizeof(uint64_t));
+		for (int t = 0; t < np; ++t) {
+			astc_pc pp = {P, 0, 0, P, t};
+			serr[t] = ~0ull;
+			WIDE_CAND(&pp, 0, ASTC_WIDE_STAGE1, serr[t]);
+		}
+		for (int r = 0; r < ASTC_WIDE_KEEP && r < np; ++r) {
+			int bt = -1;
+			for (int t = 0; t < np; ++t)
+				if (serr[t] != ~0ull && (bt < 0 || serr[t] < serr[bt]))
+					bt = t;
+			if (bt < 0)
+				break;
+			serr[bt] = ~0ull;
+			astc_pc pp = {P, 0, 0, P, bt};
+			WIDE_CAND(&pp, ASTC_WIDE_STAGE1, ASTC_MAX_CFG, dummy);
+		}
+		free(serr);
+	}
+#undef WIDE_CAND
+	/* iterated refinement of the best triples */
+	wide_hit best = top[0];
+	for (int t = 0; t < ntop; ++t) {
+		wide_hit h = top[t];
+		const astc_cfg* cfg = &f->cfg[h.pc.cls][b->has_alpha][h.k];
+		/* the decoded endpoints of the hit: run it once more from the principal-axis weights */
+		const int slots = h.pc.dual ? 2 : h.pc.P;
+		for (int s = 0; s < slots; ++s) phase_a(b, 0, &h.pc, s);
+		tl_wide.force_opt = h.opt;
+		tl_wide.have = 0;
+		phase_b(b, 0, &h.pc, cfg, &cur);
+		for (int round = 0; round < 6 && tl_wide.have; ++round) {
+			int D0[4][4], D1[4][4];
+			memcpy(D0, tl_wide.D0, sizeof(D0));
+			memcpy(D1, tl_wide.D1, sizeof(D1));
+			wide_reproject(b, &h.pc, D0, D1);
+			tl_wide.have = 0;
+			phase_b(b, 0, &h.pc, cfg, &cur);
+			if (!cur.valid || cur.err >= h.err)
+				break;
+			h.err = cur.err;
+			h.lane = cur;
+		}
+		if (h.err < best.err)
+			best = h;
+	}
+	tl_wide.wide = 0;
+	tl_wide.force_opt = -1;
+	if (!ntop) {
+		void_extent(b->px[0], out);
+		free(b);
+		return ~0ull;
+	}
+	pack_block(f, &best.pc, &f->cfg[best.pc.cls][b->has_alpha][best.k], &best.lane, out);
+	const uint64_t e = best.err;
+	free(b);
+	return e;
 }

@@ -97,6 +97,9 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 /* test-only wide searches: the bound the quality ladders are measured against */
 uint32_t cfo_bc7_wide_search(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p);
 void cfo_bc6h_wide_search(const uint16_t rgba_half[64], uint8_t out[16], const cfo_params* p);
+/* test-only: the wide search of the ASTC LDR profile (astc_encode.c): rgba = bw*bh texels row-major; returns the
+ * exact error (x 255) of the block it writes */
+uint64_t cfo_astc_wide_search(const uint8_t* rgba, int bw, int bh, int flags, uint8_t out[16]);
 /* test-only: the TRUE optimum of an ETC1 (etc2 = 0) or ETC2 RGB block: exhaustive over every mode (etc_codec.c) */
 uint32_t cfo_etc_true_optimum(const uint8_t rgba[64], int etc2, uint8_t out[8]);
 

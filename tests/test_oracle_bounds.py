@@ -171,3 +171,24 @@ def test_etc_ladders_against_the_true_optimum_of_every_mode():
     ps, opt = qt.etc_gap(192, np.random.default_rng(11), 38)          # asserts e >= optimum per block itself
     assert opt - ps[2] <= 0.30 and opt - ps[4] <= 0.20, (ps, opt)
     assert all(ps[q + 1] >= ps[q] - 1e-9 for q in range(4)), ps
+
+
+def test_astc_ladder_against_the_wide_search():
+    """cfo_astc_wide_search (LDR): one partition, a second weight plane on every component, every canonical seed of
+    the 2 / 3 / 4-partition tables, every legal block mode of the class, every endpoint-mode family forced and
+    measured exactly, the best triples iterated (weights re-projected on the decoded endpoints).  The block it
+    writes decodes (through the decoder pinned to Mesa's) to the error it claims, nothing the ladder emits beats
+    it, and the gap of High stays inside what round 4 measured (profiles/r04_quality_tables.md: 6x6 High 0.36 /
+    0.45 dB on 512 opaque / alpha-carrying blocks, 4x4 0.40 / 0.47, 8x8 1.6 / 1.9 -- the deep config lists and the
+    partition seeds of the large footprints are where the ladder leaves most: DESIGN section 7)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "quality_tables", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "quality_tables.py"))
+    qt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(qt)
+    for alpha in (False, True):
+        ps, wide = qt.astc_gap(96, np.random.default_rng(4), 6, 6, alpha)
+        assert wide >= max(ps) - 1e-9, (alpha, ps, wide)
+        assert wide - ps[3] <= 0.60, (alpha, ps, wide)
+    ps, wide = qt.astc_gap(48, np.random.default_rng(5), 4, 4, False)
+    assert wide >= max(ps) - 1e-9 and wide - ps[3] <= 0.60, (ps, wide)

@@ -105,6 +105,45 @@ def etc_gap(count, rng, fmt=38, img=None, threads=None):
     return ps, psnr_from_sse(float(opt.sum()), count * 48)
 
 
+def astc_gap(count, rng, bw, bh, alpha=False, threads=None):
+    """-> ([PSNR at Q0..Q4], PSNR of cfo_astc_wide_search) on `count` sampled bw x bh blocks of the photo content:
+    every candidate class (one partition, a second plane on every component, every canonical 2 / 3 / 4-partition
+    seed), every legal block mode, every endpoint-mode family forced and measured exactly, the best triples
+    iterated.  Measured through the decoder (pinned to Mesa's)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from cuttlefish_amd import Format
+    L = O.lib()
+    L.cfo_astc_wide_search.restype = ctypes.c_uint64
+    L.cfo_astc_wide_search.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    threads = threads or min(8, os.cpu_count() or 1)
+    fmt = int(getattr(Format, "ASTC_%dx%d" % (bw, bh)))
+    side = 528                                                       # a multiple of 4, 6, 8 and 12
+    img = synth.photo(side, side, seed=21)
+    img[..., 3] = synth.photo(side, side, seed=22)[..., 0] if alpha else 255
+    ys = rng.integers(0, side // bh, count) * bh
+    xs = rng.integers(0, side // bw, count) * bw
+    blocks = np.ascontiguousarray(np.stack([img[y:y + bh, x:x + bw] for y, x in zip(ys, xs)]))
+    outs = np.zeros((count, 16), np.uint8)
+
+    def work(i):
+        L.cfo_astc_wide_search(blocks[i].ctypes.data, bw, bh, 0, outs[i].ctypes.data)
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(work, range(count)))
+    strip = np.ascontiguousarray(np.concatenate(list(blocks), axis=1))
+    nval = strip.size if alpha else strip[..., :3].size
+
+    def psnr_of(payload):
+        dec, outside = O.decode_astc(payload, fmt, bw * count, bh)
+        assert outside == 0
+        d = dec.astype(np.int64) - strip
+        if not alpha:
+            d = d[..., :3]
+        return 10.0 * np.log10(255.0 ** 2 * nval / max(float((d * d).sum()), 1e-9))
+    wide = psnr_of(outs.reshape(-1))
+    ps = [psnr_of(O.encode(strip, fmt, quality=q, threads=threads)) for q in range(5)]
+    return ps, wide
+
+
 def bc6h_gap(count, rng):
     L = O.lib()
     L.cfo_bc6h_wide_search.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(O.Params)]
@@ -181,7 +220,7 @@ def main():
           "field step) from four starts (the encoder's own fit with plain and with quantisation-aware rounding, the "
           "subset's bounding box as is and pulled in).  Round 3's bound (the encoder's fit routines iterated) sat 0.08 / "
           "0.11 dB lower; round 3's ladder measured against THIS bound: Normal 0.41 / 0.49 dB, High 0.25 / 0.19, "
-          "Highest 0.24 / 0.19.  BC6H: all 33 candidates with 12 refit rounds (`cfo_bc6h_wide_search`).  RGBA PSNR of "
+          "Highest 0.24 / 0.19.  ETC1 / ETC2 RGB: the TRUE optimum of a block (`cfo_etc_true_optimum`).  ASTC: `cfo_astc_wide_search` (every candidate class incl. a second plane on every component and every canonical partition seed, every legal block mode, every endpoint-mode family forced and measured exactly, the best triples iterated).  BC6H: all 33 candidates with 12 refit rounds (`cfo_bc6h_wide_search`).  RGBA PSNR of "
           "the sampled blocks.\n")
     print("| format | content | Q0 | Q1 | Q2 | Q3 | Q4 | wide search | gap at Normal | gap at High | gap at Highest |")
     print("|---|---|---|---|---|---|---|---|---|---|---|")
@@ -191,6 +230,12 @@ def main():
         ps, opt = etc_gap(max(256, a.blocks // 2), rng, fmt)
         print("| %s | opaque; bound = the TRUE optimum (every expressible block, `cfo_etc_true_optimum`) | %s | %.3f | %.3f | %.3f | %.3f |"
               % (name, " | ".join("%.3f" % v for v in ps), opt, opt - ps[2], opt - ps[3], opt - ps[4]))
+    for bw, bh in ((4, 4), (6, 6), (8, 8)):
+        for alpha in (False, True):
+            ps, wide = astc_gap(max(256, a.blocks // 4), rng, bw, bh, alpha)
+            print("| ASTC %dx%d | %s; bound = `cfo_astc_wide_search` | %s | %.3f | %.3f | %.3f | %.3f |"
+                  % (bw, bh, "with alpha" if alpha else "opaque", " | ".join("%.3f" % v for v in ps), wide,
+                     wide - ps[2], wide - ps[3], wide - ps[4]))
     ps = bc6h_gap(max(256, a.blocks // 2), rng)
     print("| BC6H UF16 | HDR probe (log-domain PSNR) | %s | %.3f | %.3f | %.3f | %.3f |" % (" | ".join("%.3f" % v for v in ps[:5]), ps[5], ps[5] - ps[2], ps[5] - ps[3], ps[5] - ps[4]))
 
