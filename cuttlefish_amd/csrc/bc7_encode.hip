@@ -107,10 +107,10 @@ struct Cand {
 };
 
 // A lane's best candidate so far lives in LDS (field-major, one column per thread):
-// only (error, id) stay in registers.  21 words: q[6], pb, w[4], w2[4], the errors of its (up to
-// three) fits -- what the refinement of the best candidates compares against -- and three words where
-// (error, id) and the lanes of the best candidates are parked while the lane runs another fit.
-#define CF_BC7_CAND_WORDS 21
+// only (error, id) stay in registers.  22 words: q[6], pb, w[4], w2[4], the errors of its (up to
+// three) fits -- what the refinement of the best candidates compares against -- and four words where
+// (error, id) and the lanes of the (up to eight) best candidates are parked while the lane runs another fit.
+#define CF_BC7_CAND_WORDS 22
 __device__ __forceinline__ void cand_store(uint32_t* slot, const Cand& c)
 {
 #pragma unroll
@@ -1019,6 +1019,8 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	uint32_t lane;
 	CF_FRESH_LANE(lane);
 #define L_CSLOT (cbase + lane)
+	// lane whose column holds the k-th best candidate of this lane's group (list words 20 / 21 of the lane's column)
+#define TOP_LANE(k) ((L_CSLOT[(20u + ((k) >> 2))*CF_WG_THREADS] >> (8u*((k) & 3u))) & 255u)
 	// pair: blocks b and b + 1 at Low or Normal, one per half wavefront
 #define L_H (lane >> 5)
 #define L_HBASE (pair ? (lane & 32u) : 0u)
@@ -1073,7 +1075,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	const bool lay32 = !WIDE;
 #define L_HL (lay32 ? (lane & 31u) : lane)
 #define L_SLOT_OK (!lay32 || pair || lane < 32u)
-	const uint32_t ntop = kp.quality >= 2u ? 4u : 1u;
+	const uint32_t ntop = kp.quality >= 3u ? 8u : (kp.quality == 2u ? 4u : 1u);   // oracle: budget.top
 	const uint32_t uber = kp.quality >= 4u ? 2u : (kp.quality == 3u ? 1u : 0u);    // rounds per top candidate
 	const uint32_t uber2 = kp.quality >= 4u ? 2u : (kp.quality >= 2u ? 1u : 0u);   // rounds on the leader
 	const uint32_t msets = kp.quality >= 3u ? 3u : 1u;       // move sets of a round: bit 0 single, bit 1 joint
@@ -1083,27 +1085,30 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 		// The last trip of this loop (sst) is not a stream of new candidates: it selects the `ntop` best so
 		// far and refits them from four more starts (oracle: encode_block, "more starts") -- through the SAME
 		// fit_lane call as the streams (one copy of the fit in the code object, one register allocation).
+		const uint32_t nsst = ntop > 4u ? 2u : 1u;       // four candidates per starts trip
 #pragma unroll 1
-		for (uint32_t st = 0; st <= nstreams; ++st) {
-			const bool sst = st == nstreams;
+		for (uint32_t st = 0; st < nstreams + nsst; ++st) {
+			const bool sst = st >= nstreams;
+			const uint32_t koff = sst ? (st - nstreams)*4u : 0u;
 			if (!sst && solved)
 				continue;
 			CF_FRESH_LANE(lane);   // roles are recomputed per stream, not kept
-			if (sst) {
+			if (sst && koff == 0u) {
 				// ---- the `ntop` best candidates of each group in (error, id) order (oracle: top[]) ----
 				{
 					unsigned long long kk = ((unsigned long long)L_CSLOT[18*CF_WG_THREADS] << 32) | L_CSLOT[19*CF_WG_THREADS];
-					uint32_t wls = 0;          // byte k: lane whose column holds the k-th best candidate of this lane's group
+					uint32_t wls = 0, wls2 = 0;          // byte k & 3 of word k >> 2: lane whose column holds the k-th best candidate
 					for (uint32_t k = 0; k < ntop; ++k) {
 						const unsigned long long km = cf_group_min_u64(kk, pair, L_H);
 						const unsigned long long bal = __ballot(kk == km);
 						const uint32_t gmask = pair ? (L_H ? (uint32_t)(bal >> 32) : (uint32_t)bal) : 0u;
 						const uint32_t wl = pair ? L_HBASE + (uint32_t)__ffs((int)gmask) - 1u
 							: (uint32_t)__ffsll((long long)bal) - 1u;
-						wls |= wl << (8u*k);
+						if (k < 4u) wls |= wl << (8u*k); else wls2 |= wl << (8u*(k - 4u));
 						kk = lane == wl ? ~0ull : kk;
 					}
 					L_CSLOT[20*CF_WG_THREADS] = wls;     // every lane keeps its group's list in its own column
+					L_CSLOT[21*CF_WG_THREADS] = wls2;
 				}
 				if (uber2 == 0u || (CF_BC7_ABLATE & 16))
 					break;
@@ -1189,13 +1194,12 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 				// (k = hl >> 3, v = (hl >> 1) & 3, fit = hl & 1 -- mode 6: its two palette halves), 16 in the wide
 				// one (k = lane >> 4, v = (lane >> 2) & 3, fit = lane & 3).  Each lane runs the whole fit from its
 				// start; the best start of a fit replaces the column's fit when it is better.
-				const uint32_t k = lay32 ? (L_HL >> 3) : (lane >> 4);
+				const uint32_t k = koff + (lay32 ? (L_HL >> 3) : (lane >> 4));
 				const uint32_t v = lay32 ? (L_HL >> 1) & 3u : (lane >> 2) & 3u;
 				const uint32_t fi = lay32 ? (L_HL & 1u) : (lane & 3u);
-				const uint32_t wls = L_CSLOT[20*CF_WG_THREADS];
-				const uint32_t wl = (wls >> (8u*(k & 3u))) & 255u;
+				const uint32_t wl = TOP_LANE(k & 7u);
 				const uint32_t id = cbase[wl + 19*CF_WG_THREADS], cerr = cbase[wl + 18*CF_WG_THREADS];
-				const uint32_t err0 = cbase[(wls & 255u) + 18*CF_WG_THREADS];
+				const uint32_t err0 = cbase[TOP_LANE(0u) + 18*CF_WG_THREADS];
 				const FitGeo g = fit_geo(id, fi);
 				m6 = g.m6; sca = g.sca; rot = g.rot; cb = g.cb; ab = g.ab; pbk = g.pbk; ib = g.ib; mask = g.mask;
 				chm_s = g.chm;
@@ -1265,13 +1269,12 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			CF_FRESH_LANE(lane);         // the roles below are computed again from here
 			if (sst) {
 				// (every role again from the fresh lane id: nothing but the fit's result lived across fit_lane)
-				const uint32_t wls = L_CSLOT[20*CF_WG_THREADS];
-				const uint32_t k2 = lay32 ? (L_HL >> 3) : (lane >> 4);
+				const uint32_t k2 = koff + (lay32 ? (L_HL >> 3) : (lane >> 4));
 				const uint32_t v2 = lay32 ? (L_HL >> 1) & 3u : (lane >> 2) & 3u;
 				const uint32_t fi2 = lay32 ? (L_HL & 1u) : (lane & 3u);
-				const uint32_t wl2 = (wls >> (8u*(k2 & 3u))) & 255u;
+				const uint32_t wl2 = TOP_LANE(k2 & 7u);
 				const uint32_t id2 = cbase[wl2 + 19*CF_WG_THREADS], cerr2 = cbase[wl2 + 18*CF_WG_THREADS];
-				const uint32_t err02 = cbase[(wls & 255u) + 18*CF_WG_THREADS];
+				const uint32_t err02 = cbase[TOP_LANE(0u) + 18*CF_WG_THREADS];
 				const FitGeo g2 = fit_geo(id2, fi2);
 				const uint32_t kf2 = g2.m6 ? 0u : fi2;
 				const bool active2 = L_SLOT_OK && k2 < ntop && cerr2 != 0xFFFFFFFFu && err02 != 0u && (g2.m6 ? fi2 < 2u : fi2 < g2.nfits);
@@ -1372,8 +1375,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	// starts (every fit keeps its best), perturbed for `uber` rounds each, and the best of them then for
 	// `uber2` more rounds.  Lowest / Low: ntop = 1, no refinement, the argmin packs.
 	CF_FRESH_LANE(lane);
-	const uint32_t wls = L_CSLOT[20*CF_WG_THREADS];
-	uint32_t win_lane = wls & 255u;
+	uint32_t win_lane = TOP_LANE(0u);
 
 	if (uber2) {
 		// the lanes that own a refined column take its new total
@@ -1381,7 +1383,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 		{
 			bool own = false;
 			for (uint32_t k = 0; k < ntop; ++k)
-				own = own || lane == ((wls >> (8u*k)) & 255u);
+				own = own || lane == TOP_LANE(k);
 			if (own && L_CSLOT[18*CF_WG_THREADS] != 0xFFFFFFFFu)
 				L_CSLOT[18*CF_WG_THREADS] = L_CSLOT[15*CF_WG_THREADS] + L_CSLOT[16*CF_WG_THREADS] + L_CSLOT[17*CF_WG_THREADS];
 			__builtin_amdgcn_wave_barrier();
@@ -1398,7 +1400,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 #pragma unroll 1
 		for (uint32_t kk = ((CF_BC7_ABLATE & 32) || !uber) ? ntop : 0u; kk <= ntop; ++kk) {
 			CF_FRESH_LANE(lane);
-			uint32_t wl = (wls >> (8u*(kk & 3u))) & 255u;
+			uint32_t wl = TOP_LANE(kk & 7u);
 			if (kk == ntop) {
 				// the leader after the candidates' own rounds
 				const unsigned long long key = ((unsigned long long)L_CSLOT[18*CF_WG_THREADS] << 32) | L_CSLOT[19*CF_WG_THREADS];
@@ -1518,6 +1520,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	const uint32_t win_id = cbase[win_lane + 19*CF_WG_THREADS];
 	return pack_block_group(cbase + win_lane, win_id, lane, pair);
 #undef H_ALPHA
+#undef TOP_LANE
 #undef B_TP
 #undef B_OFF
 #undef L_H

@@ -119,8 +119,8 @@ def test_bc7_and_bc6h_ladders_stay_close_to_the_wide_search():
     """Gap of the quality ladder to the wide search (cfo_bc7_wide_search: every mode x partition x rotation x
     selector, every fit solved by a steepest descent on the quantised endpoint grid under the exact error from
     several starts -- an endpoint solver that is not the encoder's; cfo_bc6h_wide_search: all 33 candidates with
-    12 refit rounds).  The full table over 2 048 blocks is profiles/r04_quality_tables.md (Normal 0.09 / 0.05 dB,
-    High 0.06 / 0.02, Highest 0.05 / 0.02 on opaque / alpha-carrying content; round 3's ladder measured against
+    12 refit rounds).  The full table over 2 048 blocks is profiles/r04_quality_tables.md (Normal 0.10 / 0.05 dB,
+    High 0.05 / 0.02, Highest 0.04 / 0.01 on opaque / alpha-carrying content; round 3's ladder measured against
     the same bound: 0.41 / 0.49, 0.25 / 0.19, 0.24 / 0.19); here 192 blocks keep the CPU suite fast, and the
     thresholds leave room for what a sample of that size moves (+- 0.02 dB)."""
     import importlib.util
@@ -132,8 +132,8 @@ def test_bc7_and_bc6h_ladders_stay_close_to_the_wide_search():
     for label, ps in qt.bc7_gap(192, rng):
         assert ps[5] >= max(ps[:5]) - 1e-9, (label, ps)        # the wide search is a bound
         assert ps[5] - ps[2] <= 0.10, (label, ps)              # Normal within 0.10 dB of it (north_star's tolerance)
-        assert ps[5] - ps[3] <= 0.07, (label, ps)              # High
-        assert ps[5] - ps[4] <= 0.07, (label, ps)              # Highest
+        assert ps[5] - ps[3] <= 0.06, (label, ps)              # High: 0.047 / 0.015 on 2 048 blocks
+        assert ps[5] - ps[4] <= 0.06, (label, ps)              # Highest: 0.038 / 0.010
         # the ladder rises; Highest walks another candidate set than High and may land 0.01 dB beside it
         assert all(ps[q + 1] >= ps[q] - 1e-9 for q in range(3)) and ps[4] >= ps[3] - 0.01, (label, ps)
     ps = qt.bc6h_gap(96, rng)
