@@ -700,6 +700,81 @@ __device__ __forceinline__ void hdr_rgb_unpack(const int (&v)[6], int (&e0)[3], 
 	e1[0] = red1 << 4; e1[1] = green1 << 4; e1[2] = blue1 << 4;
 }
 
+// mode 7 (HDR RGB base + scale) value list of the 12-bit high endpoint E1 and the 12-bit scale S (low endpoint =
+// E1 - (S, S, S)); sub-mode m = 0..5 spends (red, green = blue, scale) = 11 5 7 / 11 6 5 / 10 5 8 / 9 6 7 / 8 7 6 /
+// 7 7 7 bits at shifts 1 1 2 3 4 5 (oracle: hdr_scale_place)
+__device__ __forceinline__ void hdr_scale_place(int m, const int (&E1)[4], int S12, int (&v)[6], int (&hm)[6])
+{
+	const int rb = (int)((0x789ABBu >> (4*m)) & 15u), gb = (int)((0x776565u >> (4*m)) & 15u), sb = (int)((0x767857u >> (4*m)) & 15u);
+	const int sh = (int)((0x543211u >> (4*m)) & 15u);
+	int maj = 0;
+	if (m < 5) {
+		if (E1[1] > E1[maj]) maj = 1;
+		if (E1[2] > sel3(maj, E1[0], E1[1], E1[2])) maj = 2;
+	}
+	const int c1 = maj == 1 ? 0 : 1, c2 = maj == 2 ? 0 : 2;
+	const int h0 = sel3(maj, E1[0], E1[1], E1[2]), h1 = sel3(c1, E1[0], E1[1], E1[2]), h2 = sel3(c2, E1[0], E1[1], E1[2]);
+	const int red = clampi(rs_u(h0, sh), 0, (1 << rb) - 1), rq = red << sh;
+	const int green = clampi(rs_u(m < 5 ? rq - h1 : E1[1], sh), 0, (1 << gb) - 1);
+	const int blue = clampi(rs_u(m < 5 ? rq - h2 : E1[2], sh), 0, (1 << gb) - 1);
+	const int scale = clampi(rs_u(S12, sh), 0, (1 << sb) - 1);
+	const int modeval = m < 4 ? ((maj << 2) | m) : (m == 4 ? (0xC | maj) : 0xF);
+	const int oh = 1 << m;
+#define ASTC_BIT(x, n) (((x) >> (n)) & 1)
+	const int b0 = (oh & 0x30) ? ASTC_BIT(green, 6) : ((oh & 0x0A) ? ASTC_BIT(red, 8) : ASTC_BIT(red, 9));
+	const int b1 = (oh & 0x3A) ? ASTC_BIT(green, 5) : ASTC_BIT(red, 8);
+	const int b2 = (oh & 0x30) ? ASTC_BIT(blue, 6) : ASTC_BIT(red, 7);
+	const int b3 = (oh & 0x3A) ? ASTC_BIT(blue, 5) : ((oh & 0x04) ? ASTC_BIT(red, 6) : ASTC_BIT(red, 10));
+	const int b4 = (oh & 0x3B) ? ASTC_BIT(red, 6) : ASTC_BIT(scale, 7);
+	const int b5 = (oh & 0x2D) ? ASTC_BIT(scale, 6) : ((oh & 0x10) ? ASTC_BIT(red, 7) : ASTC_BIT(red, 10));
+	const int b6 = (oh & 0x3D) ? ASTC_BIT(scale, 5) : ASTC_BIT(red, 9);
+#undef ASTC_BIT
+	v[0] = ((modeval & 3) << 6) | (red & 0x3F);
+	v[1] = (((modeval >> 2) & 1) << 7) | (b0 << 6) | (b1 << 5) | (green & 0x1F);
+	v[2] = (((modeval >> 3) & 1) << 7) | (b2 << 6) | (b3 << 5) | (blue & 0x1F);
+	v[3] = (b4 << 7) | (b5 << 6) | (b6 << 5) | (scale & 0x1F);
+	v[4] = v[5] = 0;
+	hm[0] = 0xC0; hm[1] = hm[2] = hm[3] = 0xE0; hm[4] = hm[5] = 0;
+}
+
+// what a mode 7 value list decodes to (oracle/astc_decode.c hdr_rgb_scale_unpack; 16-bit LNS endpoints)
+__device__ __forceinline__ void hdr_scale_unpack(const int (&v)[6], int (&e0)[3], int (&e1)[3])
+{
+	const int modeval = ((v[0] & 0xC0) >> 6) | (((v[1] & 0x80) >> 7) << 2) | (((v[2] & 0x80) >> 7) << 3);
+	const int mode = (modeval & 0xC) != 0xC ? (modeval & 3) : (modeval != 0xF ? 4 : 5);
+	const int majcomp = (modeval & 0xC) != 0xC ? (modeval >> 2) : (modeval != 0xF ? (modeval & 3) : 0);
+	int red = v[0] & 0x3F, green = v[1] & 0x1F, blue = v[2] & 0x1F, scale = v[3] & 0x1F;
+	const int bit0 = (v[1] >> 6) & 1, bit1 = (v[1] >> 5) & 1, bit2 = (v[2] >> 6) & 1, bit3 = (v[2] >> 5) & 1;
+	const int bit4 = (v[3] >> 7) & 1, bit5 = (v[3] >> 6) & 1, bit6 = (v[3] >> 5) & 1;
+	const int oh = 1 << mode;
+	if (oh & 0x30) green |= bit0 << 6;
+	if (oh & 0x3A) green |= bit1 << 5;
+	if (oh & 0x30) blue |= bit2 << 6;
+	if (oh & 0x3A) blue |= bit3 << 5;
+	if (oh & 0x3D) scale |= bit6 << 5;
+	if (oh & 0x2D) scale |= bit5 << 6;
+	if (oh & 0x04) scale |= bit4 << 7;
+	if (oh & 0x3B) red |= bit4 << 6;
+	if (oh & 0x04) red |= bit3 << 6;
+	if (oh & 0x10) red |= bit5 << 7;
+	if (oh & 0x0F) red |= bit2 << 7;
+	if (oh & 0x05) red |= bit1 << 8;
+	if (oh & 0x0A) red |= bit0 << 8;
+	if (oh & 0x05) red |= bit0 << 9;
+	if (oh & 0x02) red |= bit6 << 9;
+	if (oh & 0x01) red |= bit3 << 10;
+	if (oh & 0x02) red |= bit5 << 10;
+	const int sh = (int)((0x543211u >> (4*mode)) & 15u);
+	red <<= sh; green <<= sh; blue <<= sh; scale <<= sh;
+	if (mode != 5) { green = red - green; blue = red - blue; }
+	int t;
+	if (majcomp == 1) { t = red; red = green; green = t; }
+	if (majcomp == 2) { t = red; red = blue; blue = t; }
+	const int r0 = red - scale, g0 = green - scale, bl0 = blue - scale;
+	e0[0] = (r0 < 0 ? 0 : r0) << 4; e0[1] = (g0 < 0 ? 0 : g0) << 4; e0[2] = (bl0 < 0 ? 0 : bl0) << 4;
+	e1[0] = (red < 0 ? 0 : red) << 4; e1[1] = (green < 0 ? 0 : green) << 4; e1[2] = (blue < 0 ? 0 : blue) << 4;
+}
+
 // mode 15 alpha pair: selector 3 = two 7-bit values, 0..2 = base (8 + s bits) + signed offset (6 - s bits)
 __device__ __forceinline__ void hdr_alpha_place(int sel, int A0, int A1, double r0, double r1, int& v6, int& v7, int& hm6, int& hm7)
 {
@@ -1588,10 +1663,14 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					if (HDR) {
 						// ---- HDR: the pair is fitted and priced on the 16-bit LNS texels through the real
 						// encodings (oracle: hdr_phase_b, same arithmetic) ----
-						const uint32_t nvh = has_alpha ? 8u : 6u;
-						const int lvh = nvh*P <= 18u ? (int)clevel[(nvh*P/2u)*132u + cfg.cbits] : -1;
-						if (lvh >= 0) {
-							const uint32_t lv = (uint32_t)lvh;
+						// Two ways to store an opaque block's endpoints: option 0 = mode 11 (six values per
+						// partition, nine forms; with alpha 14 / 15, eight values), option 1 = mode 7 (four values:
+						// the high endpoint and one scale, six sub-modes).  Each is fitted, requantised at ITS colour
+						// level, decoded and priced by the quadratic form of the unconstrained fit; the cheaper one
+						// (summed over the partitions) keeps its value list and goes on to the exact error.
+						const bool opt1_any = __ballot(!has_alpha && 4u*P <= 18u) != 0ull;
+						const bool opt0_any = __ballot((has_alpha ? 8u : 6u)*P <= 18u) != 0ull;
+						if (opt0_any || opt1_any) {
 							const uint32_t* t16 = tile16 + b*n*2u;
 							struct SetAccH { uint32_t cnt, S, C, V0, V1, V2, V3, T0, T1, T2, T3; };
 							SetAccH q0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;
@@ -1617,118 +1696,195 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 #undef ASTC_ACCH
 							}
 #define HSEL4(i, F) ((i) == 0u ? q0.F : ((i) == 1u ? q1.F : ((i) == 2u ? q2.F : q3.F)))
-							uint32_t D0lo[4] = {0, 0, 0, 0}, D0hi[4] = {0, 0, 0, 0}, D1lo[4] = {0, 0, 0, 0}, D1hi[4] = {0, 0, 0, 0};
 							const bool a_hdr = has_alpha && (hdrf & 2u);
-							bool all_ok = true;
+							double tot_best = 1.0e300;
+							uint32_t sel_nv = 0u, sel_lv = 0u;
 #pragma unroll 1
-							for (uint32_t p = 0; p < P; ++p) {
-								double r0[4], r1[4], fA[4], fB[4], fC[4];
-								int E0[4], E1[4];
-#pragma unroll
-								for (uint32_t c = 0; c < 4u; ++c) {
-									const uint32_t st = dual ? (c == ccs ? 1u : 0u) : p;
-									const long long cnt_ = HSEL4(st, cnt), S_ = HSEL4(st, S), C_ = HSEL4(st, C);
-									const long long V_ = c == 0u ? HSEL4(st, V0) : (c == 1u ? HSEL4(st, V1) : (c == 2u ? HSEL4(st, V2) : HSEL4(st, V3)));
-									const long long T_ = c == 0u ? HSEL4(st, T0) : (c == 1u ? HSEL4(st, T1) : (c == 2u ? HSEL4(st, T2) : HSEL4(st, T3)));
-									const long long A_ = 4096ll*cnt_ - 128ll*S_ + C_, B_ = 64ll*S_ - C_, U_ = 64ll*T_ - V_;
-									const long long det = cnt_*C_ - S_*S_;
-									fA[c] = (double)A_; fB[c] = (double)B_; fC[c] = (double)C_;
-									double x0, x1;
-									if (det > 0) {
-										const double den_ = (double)(64ll*det);
-										x0 = (double)(C_*U_ - B_*V_)/den_;
-										x1 = (double)(A_*V_ - B_*U_)/den_;
-									} else {
-										x0 = x1 = cnt_ ? (double)T_/(double)cnt_ : 0.0;
-									}
-									x0 = x0 < 0.0 ? 0.0 : (x0 > 65535.0 ? 65535.0 : x0);
-									x1 = x1 < 0.0 ? 0.0 : (x1 > 65535.0 ? 65535.0 : x1);
-									r0[c] = x0; r1[c] = x1;
-									E0[c] = clampi((int)floor(x0*(1.0/16.0) + 0.5), 0, 4095);
-									E1[c] = clampi((int)floor(x1*(1.0/16.0) + 0.5), 0, 4095);
-								}
-								// mode 11: the direct form and the eight sub-modes, cheapest by the quadratic form
-								double best = 1.0e300;
-								uint32_t bq_lo = 0, bq_hi = 0, bd0lo = 0, bd0hi = 0, bd1lo = 0, bd1hi = 0;
-								bool got = false;
+							for (uint32_t opt = 0; opt < 2u; ++opt) {
+								if (opt ? !opt1_any : !opt0_any)
+									continue;
+								const uint32_t nvh = opt ? 4u : (has_alpha ? 8u : 6u);
+								const int lvh = (nvh*P <= 18u && !(opt && has_alpha)) ? (int)clevel[(nvh*P/2u)*132u + cfg.cbits] : -1;
+								bool all_ok = lvh >= 0;
+								const uint32_t lv = all_ok ? (uint32_t)lvh : 0u;
+								uint32_t cvt[5] = {0, 0, 0, 0, 0};
+								double tot = 0.0;
 #pragma unroll 1
-								for (int k = 0; k < 9; ++k) {
-									int v[6], hm[6], q6[6];
-									hdr_rgb_place(k, E0, E1, r0, r1, v, hm);
-									bool ok = true;
+								for (uint32_t p = 0; p < P; ++p) {
+									double r0[4], r1[4], fA[4], fB[4], fC[4];
+									int E0[4], E1[4];
+									double Nn = 0.0, Dd = 0.0;
 #pragma unroll
-									for (int i = 0; i < 6; ++i) {
-										q6[i] = ok ? requant_keep(sh, lv, v[i], hm[i]) : -1;
-										ok = ok && q6[i] >= 0;
-										v[i] = ok ? (int)sh.cunq[lv*256u + (uint32_t)q6[i]] : 0;
-									}
-									if (ok) {
-										int d0[3], d1[3];
-										hdr_rgb_unpack(v, d0, d1);
-										double est = 0.0;
-#pragma unroll
-										for (int c = 0; c < 3; ++c)
-											est = est + (double)cw[c]*quad_est_d(fA[c], fB[c], fC[c], (double)d0[c] - r0[c], (double)d1[c] - r1[c]);
-										est = est > 0.0 ? est : 0.0;
-										if (est < best) {
-											best = est;
-											got = true;
-											bq_lo = (uint32_t)q6[0] | ((uint32_t)q6[1] << 8) | ((uint32_t)q6[2] << 16) | ((uint32_t)q6[3] << 24);
-											bq_hi = (uint32_t)q6[4] | ((uint32_t)q6[5] << 8);
-											bd0lo = (uint32_t)d0[0] | ((uint32_t)d0[1] << 16); bd0hi = (uint32_t)d0[2];
-											bd1lo = (uint32_t)d1[0] | ((uint32_t)d1[1] << 16); bd1hi = (uint32_t)d1[2];
+									for (uint32_t c = 0; c < 4u; ++c) {
+										const uint32_t st = dual ? (c == ccs ? 1u : 0u) : p;
+										const long long cnt_ = HSEL4(st, cnt), S_ = HSEL4(st, S), C_ = HSEL4(st, C);
+										const long long V_ = c == 0u ? HSEL4(st, V0) : (c == 1u ? HSEL4(st, V1) : (c == 2u ? HSEL4(st, V2) : HSEL4(st, V3)));
+										const long long T_ = c == 0u ? HSEL4(st, T0) : (c == 1u ? HSEL4(st, T1) : (c == 2u ? HSEL4(st, T2) : HSEL4(st, T3)));
+										const long long A_ = 4096ll*cnt_ - 128ll*S_ + C_, B_ = 64ll*S_ - C_, U_ = 64ll*T_ - V_;
+										const long long det = cnt_*C_ - S_*S_;
+										fA[c] = (double)A_; fB[c] = (double)B_; fC[c] = (double)C_;
+										double x0, x1;
+										if (det > 0) {
+											const double den_ = (double)(64ll*det);
+											x0 = (double)(C_*U_ - B_*V_)/den_;
+											x1 = (double)(A_*V_ - B_*U_)/den_;
+										} else {
+											x0 = x1 = cnt_ ? (double)T_/(double)cnt_ : 0.0;
+										}
+										x0 = x0 < 0.0 ? 0.0 : (x0 > 65535.0 ? 65535.0 : x0);
+										x1 = x1 < 0.0 ? 0.0 : (x1 > 65535.0 ? 65535.0 : x1);
+										r0[c] = x0; r1[c] = x1;
+										E0[c] = clampi((int)floor(x0*(1.0/16.0) + 0.5), 0, 4095);
+										E1[c] = clampi((int)floor(x1*(1.0/16.0) + 0.5), 0, 4095);
+										if (c < 3u) {
+											Nn = Nn + (double)(cnt_*V_ - T_*S_);
+											Dd = Dd + (double)det;
 										}
 									}
-								}
-								all_ok = all_ok && got;
-								uint32_t a0e = 255u, a1e = 255u;
-								if (a_hdr) {
-									best = 1.0e300;
-									got = false;
+									int S12 = 0;
+									if (opt) {
+										// the constrained fit (low = high - s on every channel): s = 64 N / D, then
+										// e1_c = (T_c + s (64 cnt - S)/64) / cnt
+										double s16 = Dd > 0.0 ? (64.0*Nn)/Dd : 0.0;
+										s16 = s16 < 0.0 ? 0.0 : (s16 > 65535.0 ? 65535.0 : s16);
+#pragma unroll
+										for (uint32_t c = 0; c < 3u; ++c) {
+											const uint32_t st = dual ? (c == ccs ? 1u : 0u) : p;
+											const long long cnt_ = HSEL4(st, cnt), S_ = HSEL4(st, S);
+											const long long T_ = c == 0u ? HSEL4(st, T0) : (c == 1u ? HSEL4(st, T1) : HSEL4(st, T2));
+											const double sa = (double)(64ll*cnt_ - S_)*(1.0/64.0);
+											double x = cnt_ ? ((double)T_ + s16*sa)/(double)cnt_ : 0.0;
+											x = x < 0.0 ? 0.0 : (x > 65535.0 ? 65535.0 : x);
+											E1[c] = clampi((int)floor(x*(1.0/16.0) + 0.5), 0, 4095);
+										}
+										S12 = clampi((int)floor(s16*(1.0/16.0) + 0.5), 0, 4095);
+									}
+									// mode 11: the direct form and the eight sub-modes; mode 7: the six sub-modes --
+									// cheapest by the quadratic form
+									double best = 1.0e300;
+									uint32_t bq_lo = 0, bq_hi = 0;
+									bool got = false;
+									const int nk = opt ? 6 : 9, nq = opt ? 4 : 6;
 #pragma unroll 1
-									for (int sel = 3; sel >= 0; --sel) {
-										int v6, v7, hm6, hm7;
-										hdr_alpha_place(sel, E0[3], E1[3], r0[3], r1[3], v6, v7, hm6, hm7);
-										const int qa = requant_keep(sh, lv, v6, hm6), qb = requant_keep(sh, lv, v7, hm7);
-										if (qa >= 0 && qb >= 0) {
-											int a0, a1;
-											hdr_alpha_unpack((int)sh.cunq[lv*256u + (uint32_t)qa], (int)sh.cunq[lv*256u + (uint32_t)qb], a0, a1);
-											double est = quad_est_d(fA[3], fB[3], fC[3], (double)a0 - r0[3], (double)a1 - r1[3]);
+									for (int k = 0; k < nk; ++k) {
+										int v[6], hm[6], q6[6];
+										if (opt)
+											hdr_scale_place(k, E1, S12, v, hm);
+										else
+											hdr_rgb_place(k, E0, E1, r0, r1, v, hm);
+										bool ok = true;
+#pragma unroll
+										for (int i = 0; i < 6; ++i) {
+											q6[i] = (ok && i < nq) ? requant_keep(sh, lv, v[i], hm[i]) : (i < nq ? -1 : 0);
+											ok = ok && q6[i] >= 0;
+											v[i] = (ok && i < nq) ? (int)sh.cunq[lv*256u + (uint32_t)q6[i]] : 0;
+										}
+										if (ok) {
+											int d0[3], d1[3];
+											if (opt)
+												hdr_scale_unpack(v, d0, d1);
+											else
+												hdr_rgb_unpack(v, d0, d1);
+											double est = 0.0;
+#pragma unroll
+											for (int c = 0; c < 3; ++c)
+												est = est + (double)cw[c]*quad_est_d(fA[c], fB[c], fC[c], (double)d0[c] - r0[c], (double)d1[c] - r1[c]);
 											est = est > 0.0 ? est : 0.0;
 											if (est < best) {
 												best = est;
 												got = true;
-												bq_hi = (bq_hi & 0xFFFFu) | ((uint32_t)qa << 16) | ((uint32_t)qb << 24);
-												a0e = (uint32_t)a0; a1e = (uint32_t)a1;
+												bq_lo = (uint32_t)q6[0] | ((uint32_t)q6[1] << 8) | ((uint32_t)q6[2] << 16) | ((uint32_t)q6[3] << 24);
+												bq_hi = (uint32_t)q6[4] | ((uint32_t)q6[5] << 8);
 											}
 										}
 									}
 									all_ok = all_ok && got;
-								} else if (has_alpha) {
-									// LDR alpha (mode 14): two UNORM8 values; the fit above ran on the 0..255 values
-									uint32_t s6, s7;
-									a0e = (uint32_t)quant_c(sh, lv, (float)r0[3], s6);
-									a1e = (uint32_t)quant_c(sh, lv, (float)r1[3], s7);
-									bq_hi = (bq_hi & 0xFFFFu) | (s6 << 16) | (s7 << 24);
-								}
-								bd0hi |= a0e << 16; bd1hi |= a1e << 16;
+									tot = tot + (got ? best : 0.0);
+									if (a_hdr) {
+										best = 1.0e300;
+										got = false;
+#pragma unroll 1
+										for (int sel = 3; sel >= 0; --sel) {
+											int v6, v7, hm6, hm7;
+											hdr_alpha_place(sel, E0[3], E1[3], r0[3], r1[3], v6, v7, hm6, hm7);
+											const int qa = requant_keep(sh, lv, v6, hm6), qb = requant_keep(sh, lv, v7, hm7);
+											if (qa >= 0 && qb >= 0) {
+												int a0, a1;
+												hdr_alpha_unpack((int)sh.cunq[lv*256u + (uint32_t)qa], (int)sh.cunq[lv*256u + (uint32_t)qb], a0, a1);
+												double est = quad_est_d(fA[3], fB[3], fC[3], (double)a0 - r0[3], (double)a1 - r1[3]);
+												est = est > 0.0 ? est : 0.0;
+												if (est < best) {
+													best = est;
+													got = true;
+													bq_hi = (bq_hi & 0xFFFFu) | ((uint32_t)qa << 16) | ((uint32_t)qb << 24);
+												}
+											}
+										}
+										all_ok = all_ok && got;
+									} else if (has_alpha) {
+										// LDR alpha (mode 14): two UNORM8 values; the fit above ran on the 0..255 values
+										uint32_t s6, s7;
+										quant_c(sh, lv, (float)r0[3], s6);
+										quant_c(sh, lv, (float)r1[3], s7);
+										bq_hi = (bq_hi & 0xFFFFu) | (s6 << 16) | (s7 << 24);
+									}
+									{
+										const unsigned long long vv = ((unsigned long long)bq_hi << 32 | bq_lo) & (nvh >= 8u ? ~0ull : ((1ull << (8u*nvh)) - 1ull));
+										const uint32_t bit = p*nvh*8u, wd0 = bit >> 5, sh_ = bit & 31u;
+										const unsigned long long lo = vv << sh_;
+										const uint32_t x0 = (uint32_t)lo, x1 = (uint32_t)(lo >> 32), x2 = sh_ ? (uint32_t)(vv >> (64u - sh_)) : 0u;
 #pragma unroll
-								for (uint32_t k = 0; k < 4u; ++k) {
-									D0lo[k] = p == k ? bd0lo : D0lo[k]; D0hi[k] = p == k ? bd0hi : D0hi[k];
-									D1lo[k] = p == k ? bd1lo : D1lo[k]; D1hi[k] = p == k ? bd1hi : D1hi[k];
+										for (uint32_t wd = 0; wd < 5u; ++wd)
+											cvt[wd] |= wd == wd0 ? x0 : (wd == wd0 + 1u ? x1 : (wd == wd0 + 2u ? x2 : 0u));
+									}
 								}
-								{
-									const unsigned long long vv = ((unsigned long long)bq_hi << 32 | bq_lo) & (nvh >= 8u ? ~0ull : ((1ull << (8u*nvh)) - 1ull));
-									const uint32_t bit = p*nvh*8u, wd0 = bit >> 5, sh_ = bit & 31u;
-									const unsigned long long lo = vv << sh_;
-									const uint32_t x0 = (uint32_t)lo, x1 = (uint32_t)(lo >> 32), x2 = sh_ ? (uint32_t)(vv >> (64u - sh_)) : 0u;
+								if (all_ok && tot < tot_best) {
+									tot_best = tot;
+									sel_nv = nvh; sel_lv = lv;
 #pragma unroll
 									for (uint32_t wd = 0; wd < 5u; ++wd)
-										r_cv[wd] |= wd == wd0 ? x0 : (wd == wd0 + 1u ? x1 : (wd == wd0 + 2u ? x2 : 0u));
+										r_cv[wd] = cvt[wd];
 								}
 							}
 #undef HSEL4
-							if (all_ok) {
+							if (sel_nv) {
+								// the endpoints the chosen value list decodes to
+								uint32_t D0lo[4] = {0, 0, 0, 0}, D0hi[4] = {0, 0, 0, 0}, D1lo[4] = {0, 0, 0, 0}, D1hi[4] = {0, 0, 0, 0};
+#pragma unroll 1
+								for (uint32_t p = 0; p < P; ++p) {
+									const uint32_t bit = p*sel_nv*8u, wd0 = bit >> 5, sh_ = bit & 31u;
+									uint32_t y0 = 0, y1 = 0, y2 = 0;
+#pragma unroll
+									for (uint32_t wd = 0; wd < 5u; ++wd) {
+										y0 = wd == wd0 ? r_cv[wd] : y0; y1 = wd == wd0 + 1u ? r_cv[wd] : y1; y2 = wd == wd0 + 2u ? r_cv[wd] : y2;
+									}
+									const unsigned long long lo64 = ((unsigned long long)y1 << 32 | y0) >> sh_;
+									const unsigned long long vv = lo64 | (sh_ ? (unsigned long long)y2 << (64u - sh_) : 0ull);
+									int v[6], d0[3], d1[3];
+#pragma unroll
+									for (int i = 0; i < 6; ++i)
+										v[i] = (int)sh.cunq[sel_lv*256u + (uint32_t)((vv >> (8*i)) & 0xFFull)];
+									if (sel_nv == 4u)
+										hdr_scale_unpack(v, d0, d1);
+									else
+										hdr_rgb_unpack(v, d0, d1);
+									uint32_t a0e = 255u, a1e = 255u;
+									if (has_alpha) {
+										const int u6 = (int)sh.cunq[sel_lv*256u + (uint32_t)((vv >> 48) & 0xFFull)];
+										const int u7 = (int)sh.cunq[sel_lv*256u + (uint32_t)((vv >> 56) & 0xFFull)];
+										int a0 = u6, a1 = u7;
+										if (a_hdr)
+											hdr_alpha_unpack(u6, u7, a0, a1);
+										a0e = (uint32_t)a0; a1e = (uint32_t)a1;
+									}
+									const uint32_t bd0lo = (uint32_t)d0[0] | ((uint32_t)d0[1] << 16), bd0hi = (uint32_t)d0[2] | (a0e << 16);
+									const uint32_t bd1lo = (uint32_t)d1[0] | ((uint32_t)d1[1] << 16), bd1hi = (uint32_t)d1[2] | (a1e << 16);
+#pragma unroll
+									for (uint32_t k = 0; k < 4u; ++k) {
+										D0lo[k] = p == k ? bd0lo : D0lo[k]; D0hi[k] = p == k ? bd0hi : D0hi[k];
+										D1lo[k] = p == k ? bd1lo : D1lo[k]; D1hi[k] = p == k ? bd1hi : D1hi[k];
+									}
+								}
 								// exact error through the decode arithmetic: HDR channels on the 16-bit LNS values; an LDR
 								// alpha on UNORM8 scaled by 257 to the same range
 								unsigned long long e64 = 0;
@@ -1766,9 +1922,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 									e64 += ergb*wa + ea*255ull;
 								}
 								err = e64;
-								r_cem = has_alpha ? ((hdrf & 2u) ? 15u : 14u) : 11u;
-								r_lv = lv;
-								r_ncv = nvh*P;
+								r_cem = sel_nv == 4u ? 7u : (has_alpha ? ((hdrf & 2u) ? 15u : 14u) : 11u);
+								r_lv = sel_lv;
+								r_ncv = sel_nv*P;
 							}
 						}
 					} else {

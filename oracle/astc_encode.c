@@ -630,6 +630,58 @@ static void hdr_rgb_place(int k, const int E0[3], const int E1[3], const double 
 	himask[0] = 0; himask[1] = 0xC0; himask[2] = himask[3] = 0xC0; himask[4] = himask[5] = dmask[m];
 }
 
+/* mode 7 (HDR RGB, base + scale): four values for the 12-bit high endpoint E1 and the 12-bit scale S; the low
+ * endpoint is E1 - (S, S, S).  Sub-mode m = 0..5 spends (red, green, blue, scale) = 11 5 5 7 / 11 6 6 5 / 10 5 5 8 /
+ * 9 6 6 7 / 8 7 7 6 / 7 7 7 7 bits at shifts 1 1 2 3 4 5; up to m = 4 the largest channel of E1 goes into red's
+ * place and green / blue are stored as differences from it.  himask[i]: the bits of v[i] a requantisation has to
+ * keep (mode and major-component bits, and the high field bits scattered over bits 7..5).  The inverse of
+ * astc_decode.c's hdr_rgb_scale_unpack. */
+static void hdr_scale_place(int m, const int E1[3], int S12, int v[4], int himask[4])
+{
+	static const uint8_t bits[6][3] = {{11, 5, 7}, {11, 6, 5}, {10, 5, 8}, {9, 6, 7}, {8, 7, 6}, {7, 7, 7}};
+	static const uint8_t shamt[6] = {1, 1, 2, 3, 4, 5};
+	const int rb = bits[m][0], gb = bits[m][1], sb = bits[m][2], sh = shamt[m];
+	int maj = 0;
+	if (m < 5) {
+		if (E1[1] > E1[maj]) maj = 1;
+		if (E1[2] > E1[maj]) maj = 2;
+	}
+	int ch[3] = {0, 1, 2};
+	ch[0] = maj; ch[maj] = 0;
+	const int red = clampi(rs_u(E1[ch[0]], sh), 0, (1 << rb) - 1), rq = red << sh;
+	int green, blue;
+	if (m < 5) {
+		green = clampi(rs_u(rq - E1[ch[1]], sh), 0, (1 << gb) - 1);
+		blue = clampi(rs_u(rq - E1[ch[2]], sh), 0, (1 << gb) - 1);
+	} else {
+		green = clampi(rs_u(E1[1], sh), 0, (1 << gb) - 1);
+		blue = clampi(rs_u(E1[2], sh), 0, (1 << gb) - 1);
+	}
+	const int scale = clampi(rs_u(S12, sh), 0, (1 << sb) - 1);
+	const int modeval = m < 4 ? ((maj << 2) | m) : (m == 4 ? (0xC | maj) : 0xF);
+#define BIT(x, n) (((x) >> (n)) & 1)
+	const int oh = 1 << m;
+	const int b0 = (oh & 0x30) ? BIT(green, 6) : ((oh & 0x0A) ? BIT(red, 8) : BIT(red, 9));
+	const int b1 = (oh & 0x3A) ? BIT(green, 5) : BIT(red, 8);
+	const int b2 = (oh & 0x30) ? BIT(blue, 6) : BIT(red, 7);
+	const int b3 = (oh & 0x3A) ? BIT(blue, 5) : ((oh & 0x04) ? BIT(red, 6) : BIT(red, 10));
+	const int b4 = (oh & 0x3B) ? BIT(red, 6) : BIT(scale, 7);
+	const int b5 = (oh & 0x2D) ? BIT(scale, 6) : ((oh & 0x10) ? BIT(red, 7) : BIT(red, 10));
+	const int b6 = (oh & 0x3D) ? BIT(scale, 5) : BIT(red, 9);
+#undef BIT
+	v[0] = ((modeval & 3) << 6) | (red & 0x3F);
+	v[1] = (((modeval >> 2) & 1) << 7) | (b0 << 6) | (b1 << 5) | (green & 0x1F);
+	v[2] = (((modeval >> 3) & 1) << 7) | (b2 << 6) | (b3 << 5) | (blue & 0x1F);
+	v[3] = (b4 << 7) | (b5 << 6) | (b6 << 5) | (scale & 0x1F);
+	himask[0] = 0xC0; himask[1] = himask[2] = himask[3] = 0xE0;
+}
+
+/* test hook */
+void cfo_astc_hdr_scale_place(int m, const int E1[3], int S12, int v[4], int himask[4])
+{
+	hdr_scale_place(m, E1, S12, v, himask);
+}
+
 /* mode 15 alpha pair: selector 3 = two 7-bit values, 0..2 = base (8 + s bits) + signed offset (6 - s bits) */
 static void hdr_alpha_place(int sel, int A0, int A1, double r0, double r1, int v[2], int himask[2])
 {
@@ -679,12 +731,6 @@ static void hdr_phase_b(const astc_blk* b, const astc_pc* pc, const astc_cfg* cf
 {
 	const astc_tables* T = astc_get_tables();
 	int n = b->n, P = pc->P;
-	int nv = b->has_alpha ? 8 : 6;
-	if (nv*P > 18)
-		return;
-	int lv = T->c_level[nv*P/2][cfg->cbits];
-	if (lv < 0 || cfg->cbits < (13*nv*P + 4)/5)
-		return;
 	int nset = pc->dual ? 2 : P, a_hdr = b->has_alpha && b->hdr_alpha;
 	int64_t S[4] = {0}, A[4] = {0}, B[4] = {0}, C[4] = {0}, cnt[4] = {0}, V[4][4], Ts[4][4];
 	memset(V, 0, sizeof(V));
@@ -705,88 +751,169 @@ static void hdr_phase_b(const astc_blk* b, const astc_pc* pc, const astc_cfg* cf
 			Ts[sub][c] += b->lns[i][c];
 		}
 	}
+	/* Two ways to store an opaque block's endpoints (round 4): option 0 = mode 11 (six values per partition: both
+	 * endpoints, nine forms), option 1 = mode 7 (four values: the high endpoint and ONE scale, low = high -
+	 * (s, s, s) -- a change of exposure in the log domain; six sub-modes).  Mode 7 leaves a third of the colour
+	 * values to the weights or to a finer colour level, and makes four partitions storable at all (4 x 4 = 16
+	 * values).  Each option is fitted, placed, requantised at ITS colour level, decoded through the decoder's
+	 * unpack and priced by the quadratic form of the unconstrained fit; the cheaper option (sum over the
+	 * partitions) goes on to the exact error.  Blocks with alpha: option 0 only (modes 14 / 15). */
 	int D0[4][4], D1[4][4];                  /* decoded endpoints: HDR channels 16-bit LNS, LDR alpha 0..255 */
-	for (int p = 0; p < P; ++p) {
-		double r0[4], r1[4], fA[4], fB[4], fC[4];
-		int E0[4], E1[4];
-		for (int c = 0; c < 4; ++c) {
-			int st = pc->dual ? (c == pc->ccs) : p;
-			int64_t det = cnt[st]*C[st] - S[st]*S[st], U = 64*Ts[p][c] - V[p][c];
-			fA[c] = (double)A[st]; fB[c] = (double)B[st]; fC[c] = (double)C[st];
-			if (det > 0) {
-				double den = (double)(64*det);
-				r0[c] = (double)(C[st]*U - B[st]*V[p][c])/den;
-				r1[c] = (double)(A[st]*V[p][c] - B[st]*U)/den;
+	double best_total = 1.0e300;
+	int best_opt = -1, best_lv = 0, best_nv = 0;
+	for (int opt = 0; opt < (b->has_alpha ? 1 : 2); ++opt) {
+		const int nv = opt ? 4 : (b->has_alpha ? 8 : 6);
+		if (nv*P > 18)
+			continue;
+		const int lv = T->c_level[nv*P/2][cfg->cbits];
+		if (lv < 0 || cfg->cbits < (13*nv*P + 4)/5)
+			continue;
+		int tD0[4][4], tD1[4][4], all_ok = 1;
+		uint8_t tvals[18];
+		double total = 0.0;
+		for (int p = 0; p < P && all_ok; ++p) {
+			double r0[4], r1[4], fA[4], fB[4], fC[4];
+			int E0[4], E1[4];
+			for (int c = 0; c < 4; ++c) {
+				int st = pc->dual ? (c == pc->ccs) : p;
+				int64_t det = cnt[st]*C[st] - S[st]*S[st], U = 64*Ts[p][c] - V[p][c];
+				fA[c] = (double)A[st]; fB[c] = (double)B[st]; fC[c] = (double)C[st];
+				if (det > 0) {
+					double den = (double)(64*det);
+					r0[c] = (double)(C[st]*U - B[st]*V[p][c])/den;
+					r1[c] = (double)(A[st]*V[p][c] - B[st]*U)/den;
+				} else {
+					r0[c] = r1[c] = cnt[st] ? (double)Ts[p][c]/(double)cnt[st] : 0.0;
+				}
+				r0[c] = r0[c] < 0.0 ? 0.0 : (r0[c] > 65535.0 ? 65535.0 : r0[c]);
+				r1[c] = r1[c] < 0.0 ? 0.0 : (r1[c] > 65535.0 ? 65535.0 : r1[c]);
+				E0[c] = clampi((int)floor(r0[c]*(1.0/16.0) + 0.5), 0, 4095);
+				E1[c] = clampi((int)floor(r1[c]*(1.0/16.0) + 0.5), 0, 4095);
+			}
+			uint8_t* vals = tvals + p*nv;
+			double best = 1.0e300;
+			int got = 0;
+			if (opt == 0) {
+				for (int k = 0; k < 9; ++k) {
+					int v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hm[6], q[6], ok = 1;
+					hdr_rgb_place(k, E0, E1, r0, r1, v, hm);
+					for (int i = 0; i < 6 && ok; ++i) {
+						q[i] = requant_keep(T, lv, v[i], hm[i]);
+						if (q[i] < 0) ok = 0;
+						else v[i] = T->c_unq[lv][q[i]];
+					}
+					if (!ok)
+						continue;
+					int d0[4], d1[4];
+					cfo_astc_unpack_endpoints(11, v, d0, d1);
+					double est = 0.0;
+					for (int c = 0; c < 3; ++c)
+						est = est + (double)b->cw[c]*quad_est_d(fA[c], fB[c], fC[c], (double)d0[c] - r0[c], (double)d1[c] - r1[c]);
+					est = est > 0.0 ? est : 0.0;         /* (the kernel compares bit patterns: no negative zero) */
+					if (est < best) {
+						best = est;
+						got = 1;
+						for (int i = 0; i < 6; ++i)
+							vals[i] = (uint8_t)q[i];
+						for (int c = 0; c < 3; ++c) { tD0[p][c] = d0[c]; tD1[p][c] = d1[c]; }
+					}
+				}
 			} else {
-				r0[c] = r1[c] = cnt[st] ? (double)Ts[p][c]/(double)cnt[st] : 0.0;
-			}
-			r0[c] = r0[c] < 0.0 ? 0.0 : (r0[c] > 65535.0 ? 65535.0 : r0[c]);
-			r1[c] = r1[c] < 0.0 ? 0.0 : (r1[c] > 65535.0 ? 65535.0 : r1[c]);
-			E0[c] = clampi((int)floor(r0[c]*(1.0/16.0) + 0.5), 0, 4095);
-			E1[c] = clampi((int)floor(r1[c]*(1.0/16.0) + 0.5), 0, 4095);
-		}
-		uint8_t* vals = L->cvals + p*nv;
-		double best = 1.0e300;
-		int got = 0;
-		for (int k = 0; k < 9; ++k) {
-			int v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hm[6], q[6], ok = 1;
-			hdr_rgb_place(k, E0, E1, r0, r1, v, hm);
-			for (int i = 0; i < 6 && ok; ++i) {
-				q[i] = requant_keep(T, lv, v[i], hm[i]);
-				if (q[i] < 0) ok = 0;
-				else v[i] = T->c_unq[lv][q[i]];
-			}
-			if (!ok)
-				continue;
-			int d0[4], d1[4];
-			cfo_astc_unpack_endpoints(11, v, d0, d1);
-			double est = 0.0;
-			for (int c = 0; c < 3; ++c)
-				est = est + (double)b->cw[c]*quad_est_d(fA[c], fB[c], fC[c], (double)d0[c] - r0[c], (double)d1[c] - r1[c]);
-			est = est > 0.0 ? est : 0.0;         /* (the kernel compares bit patterns: no negative zero) */
-			if (est < best) {
-				best = est;
-				got = 1;
-				for (int i = 0; i < 6; ++i)
-					vals[i] = (uint8_t)q[i];
-				for (int c = 0; c < 3; ++c) { D0[p][c] = d0[c]; D1[p][c] = d1[c]; }
-			}
-		}
-		if (!got)
-			return;                              /* no form survives this colour level */
-		D0[p][3] = D1[p][3] = 255;
-		if (a_hdr) {
-			best = 1.0e300;
-			got = 0;
-			for (int sel = 3; sel >= 0; --sel) {
-				int v[8] = {0, 0, 0, 0, 0x80, 0x80, 0, 0}, hm[2], q[2];
-				hdr_alpha_place(sel, E0[3], E1[3], r0[3], r1[3], v + 6, hm);
-				q[0] = requant_keep(T, lv, v[6], hm[0]);
-				q[1] = requant_keep(T, lv, v[7], hm[1]);
-				if (q[0] < 0 || q[1] < 0)
-					continue;
-				v[6] = T->c_unq[lv][q[0]]; v[7] = T->c_unq[lv][q[1]];
-				int d0[4], d1[4];
-				cfo_astc_unpack_endpoints(15, v, d0, d1);
-				double est = quad_est_d(fA[3], fB[3], fC[3], (double)d0[3] - r0[3], (double)d1[3] - r1[3]);
-				est = est > 0.0 ? est : 0.0;
-				if (est < best) {
-					best = est;
-					got = 1;
-					vals[6] = (uint8_t)q[0]; vals[7] = (uint8_t)q[1];
-					D0[p][3] = d0[3]; D1[p][3] = d1[3];
+				/* the constrained fit: value = e1_c - s (64 - w)/64.  With N = sum_c (cnt V_c - T_c S) and
+				 * D = sum_c det (the sums of the set each channel fits with): s = 64 N / D, then
+				 * e1_c = (T_c + s (64 cnt - S)/64) / cnt */
+				double Nn = 0.0, Dd = 0.0;
+				for (int c = 0; c < 3; ++c) {
+					int st = pc->dual ? (c == pc->ccs) : p;
+					Nn = Nn + (double)(cnt[st]*V[p][c] - Ts[p][c]*S[st]);
+					Dd = Dd + (double)(cnt[st]*C[st] - S[st]*S[st]);
+				}
+				double s16 = Dd > 0.0 ? (64.0*Nn)/Dd : 0.0;
+				s16 = s16 < 0.0 ? 0.0 : (s16 > 65535.0 ? 65535.0 : s16);
+				int E1c[3];
+				for (int c = 0; c < 3; ++c) {
+					int st = pc->dual ? (c == pc->ccs) : p;
+					double sa = (double)(64*cnt[st] - S[st])*(1.0/64.0);
+					double x = cnt[st] ? ((double)Ts[p][c] + s16*sa)/(double)cnt[st] : 0.0;
+					x = x < 0.0 ? 0.0 : (x > 65535.0 ? 65535.0 : x);
+					E1c[c] = clampi((int)floor(x*(1.0/16.0) + 0.5), 0, 4095);
+				}
+				const int S12 = clampi((int)floor(s16*(1.0/16.0) + 0.5), 0, 4095);
+				for (int m = 0; m < 6; ++m) {
+					int v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hm[4], q[4], ok = 1;
+					hdr_scale_place(m, E1c, S12, v, hm);
+					for (int i = 0; i < 4 && ok; ++i) {
+						q[i] = requant_keep(T, lv, v[i], hm[i]);
+						if (q[i] < 0) ok = 0;
+						else v[i] = T->c_unq[lv][q[i]];
+					}
+					if (!ok)
+						continue;
+					int d0[4], d1[4];
+					cfo_astc_unpack_endpoints(7, v, d0, d1);
+					double est = 0.0;
+					for (int c = 0; c < 3; ++c)
+						est = est + (double)b->cw[c]*quad_est_d(fA[c], fB[c], fC[c], (double)d0[c] - r0[c], (double)d1[c] - r1[c]);
+					est = est > 0.0 ? est : 0.0;
+					if (est < best) {
+						best = est;
+						got = 1;
+						for (int i = 0; i < 4; ++i)
+							vals[i] = (uint8_t)q[i];
+						for (int c = 0; c < 3; ++c) { tD0[p][c] = d0[c]; tD1[p][c] = d1[c]; }
+					}
 				}
 			}
-			if (!got)
-				return;
-		} else if (b->has_alpha) {
-			/* LDR alpha (mode 14): two UNORM8 values; the fit above ran on the 0..255 values */
-			int s6, s7;
-			D0[p][3] = quant_c(T, lv, (float)r0[3], &s6);
-			D1[p][3] = quant_c(T, lv, (float)r1[3], &s7);
-			vals[6] = (uint8_t)s6; vals[7] = (uint8_t)s7;
+			if (!got) {
+				all_ok = 0;                          /* no form survives this colour level */
+				break;
+			}
+			total = total + best;
+			tD0[p][3] = tD1[p][3] = 255;
+			if (a_hdr) {
+				best = 1.0e300;
+				got = 0;
+				for (int sel = 3; sel >= 0; --sel) {
+					int v[8] = {0, 0, 0, 0, 0x80, 0x80, 0, 0}, hm[2], q[2];
+					hdr_alpha_place(sel, E0[3], E1[3], r0[3], r1[3], v + 6, hm);
+					q[0] = requant_keep(T, lv, v[6], hm[0]);
+					q[1] = requant_keep(T, lv, v[7], hm[1]);
+					if (q[0] < 0 || q[1] < 0)
+						continue;
+					v[6] = T->c_unq[lv][q[0]]; v[7] = T->c_unq[lv][q[1]];
+					int d0[4], d1[4];
+					cfo_astc_unpack_endpoints(15, v, d0, d1);
+					double est = quad_est_d(fA[3], fB[3], fC[3], (double)d0[3] - r0[3], (double)d1[3] - r1[3]);
+					est = est > 0.0 ? est : 0.0;
+					if (est < best) {
+						best = est;
+						got = 1;
+						vals[6] = (uint8_t)q[0]; vals[7] = (uint8_t)q[1];
+						tD0[p][3] = d0[3]; tD1[p][3] = d1[3];
+					}
+				}
+				if (!got) {
+					all_ok = 0;
+					break;
+				}
+			} else if (b->has_alpha) {
+				/* LDR alpha (mode 14): two UNORM8 values; the fit above ran on the 0..255 values */
+				int s6, s7;
+				tD0[p][3] = quant_c(T, lv, (float)r0[3], &s6);
+				tD1[p][3] = quant_c(T, lv, (float)r1[3], &s7);
+				vals[6] = (uint8_t)s6; vals[7] = (uint8_t)s7;
+			}
+		}
+		if (all_ok && total < best_total) {
+			best_total = total;
+			best_opt = opt; best_lv = lv; best_nv = nv;
+			memcpy(D0, tD0, sizeof(D0));
+			memcpy(D1, tD1, sizeof(D1));
+			memcpy(L->cvals, tvals, (size_t)(nv*P));
 		}
 	}
+	if (best_opt < 0)
+		return;
 	/* exact error through the decode arithmetic: HDR channels on the 16-bit LNS values; an LDR alpha on
 	 * UNORM8 scaled by 257 to the same range */
 	uint64_t err = 0;
@@ -808,9 +935,9 @@ static void hdr_phase_b(const astc_blk* b, const astc_pc* pc, const astc_cfg* cf
 	}
 	L->err = err;
 	L->valid = 1;
-	L->cem = b->has_alpha ? (b->hdr_alpha ? 15 : 14) : 11;
-	L->ncv = nv*P;
-	L->lv = lv;
+	L->cem = best_opt ? 7 : (b->has_alpha ? (b->hdr_alpha ? 15 : 14) : 11);
+	L->ncv = best_nv*P;
+	L->lv = best_lv;
 }
 
 /* test-only hooks of the wide search (cfo_astc_wide_search, end of file): force one endpoint option instead of

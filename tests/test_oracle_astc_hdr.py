@@ -48,10 +48,10 @@ def test_lns_code_known_answers():
     assert codes == sorted(codes)
 
 
-@pytest.mark.parametrize("fmt,floor", [(Format.ASTC_4x4, 50.5), (Format.ASTC_6x6, 44.0), (Format.ASTC_10x8, 37.7)])
+@pytest.mark.parametrize("fmt,floor", [(Format.ASTC_4x4, 54.0), (Format.ASTC_6x6, 44.5), (Format.ASTC_10x8, 39.3)])
 def test_hdr_probe_round_trip(fmt, floor):
     img = synth.hdr_probe(96, 72, seed=4).astype(np.float32)
-    ps = []
+    ps, seen = [], set()
     for q in (0, 2, 3):
         pay = O.encode(img, int(fmt), typ=int(Type.UFloat), quality=q, threads=8, alpha=int(Alpha.None_))
         dec, bad = O.decode_astc_hdr(pay, int(fmt), 96, 72)
@@ -59,10 +59,12 @@ def test_hdr_probe_round_trip(fmt, floor):
         assert np.all(dec[..., 3].astype(np.float32) == 1.0)
         ps.append(_plog(img, dec.astype(np.float32)))
         cem = _cems(pay)
-        assert set(cem[cem >= 0]) <= {11}            # opaque HDR blocks: mode 11
+        assert set(cem[cem >= 0]) <= {7, 11}         # opaque HDR blocks: mode 11, or mode 7 (base + scale)
+        seen |= set(cem[cem >= 0])
     # (Lowest already ranks 8 configs of its one candidate; on a 96 x 72 probe the log-domain PSNR of the
     # levels is within noise of each other)
     assert ps[0] >= floor and ps[2] >= ps[0] - 0.1
+    assert seen == {7, 11}                           # both ways of storing the endpoints are in use
     # the range survives: the probe's suns are tens of thousands
     assert float(dec[..., :3].astype(np.float32).max()) > 0.5*float(img[..., :3].max())
 
@@ -361,3 +363,55 @@ def test_encoder_placement_round_trips_through_the_decoder():
             L.cfo_astc_hdr_alpha_place(sel, base, base + off, v, hm)
             kind, e0, e1 = _unpack(15, [0, 0, 0, 0, 0x80, 0x80, v[0], v[1]])
             assert (e0[3], e1[3]) == (base << 4, (base + off) << 4), (sel, base, off)
+
+
+def test_mode_7_placement_round_trips_through_the_decoder():
+    """hdr_scale_place against the decoder: a (high endpoint, scale) pair a sub-mode can hold (the differences
+    from the major component inside its green / blue fields) decodes to the pair rounded to the sub-mode's
+    step; any pair decodes to within half a step per field where no field clamps."""
+    L = O.lib()
+    rng = np.random.default_rng(13)
+    bits = [(11, 5, 7), (11, 6, 5), (10, 5, 8), (9, 6, 7), (8, 7, 6), (7, 7, 7)]
+    shamt = [1, 1, 2, 3, 4, 5]
+    I3, I4 = ctypes.c_int*3, ctypes.c_int*4
+    for m, (rb, gb, sb) in enumerate(bits):
+        sh = shamt[m]
+        hits = 0
+        for _ in range(600):
+            maj = int(rng.integers(0, 3)) if m < 5 else 0
+            red = int(rng.integers(1 << (rb - 2), 1 << rb)) << sh
+            if m < 5:
+                g = red - (int(rng.integers(1, 1 << gb)) << sh)
+                b = red - (int(rng.integers(1, 1 << gb)) << sh)
+            else:
+                g = int(rng.integers(0, 1 << gb)) << sh
+                b = int(rng.integers(0, 1 << gb)) << sh
+            scale = int(rng.integers(0, 1 << sb)) << sh
+            hi = [red, g, b]
+            if min(hi) < 0 or max(hi) > 4095:
+                continue
+            hi[0], hi[maj] = hi[maj], hi[0]
+            v, hm = I4(), I4()
+            L.cfo_astc_hdr_scale_place(m, I3(*hi), scale, v, hm)
+            kind, e0, e1 = _unpack(7, list(v))
+            assert e1[:3] == [x << 4 for x in hi], (m, maj, hi, scale, list(v))
+            assert e0[:3] == [max(x - scale, 0) << 4 for x in hi], (m, maj, hi, scale, list(v))
+            assert hm[0] == 0xC0 and hm[1] & 0x80 and hm[2] & 0x80      # mode and major-component bits are kept
+            hits += 1
+        assert hits > 100, m
+        # arbitrary pairs: half a step per field where nothing clamps
+        for _ in range(300):
+            hi = sorted((int(x) for x in rng.integers(0, min(4095, ((1 << rb) - 1) << sh), 3)), reverse=True)
+            lim = (1 << gb) << sh
+            if m < 5 and (hi[0] - hi[2] >= lim - (1 << sh)):
+                continue
+            if m == 5 and max(hi) > ((1 << gb) - 1) << sh:
+                continue
+            scale = int(rng.integers(0, ((1 << sb) - 1) << sh))
+            v, hm = I4(), I4()
+            L.cfo_astc_hdr_scale_place(m, I3(*hi), scale, v, hm)
+            kind, e0, e1 = _unpack(7, list(v))
+            half = 1 << (sh - 1)
+            assert abs((e1[0] >> 4) - hi[0]) <= half
+            for c in (1, 2):
+                assert abs((e1[c] >> 4) - hi[c]) <= 2*half, (m, hi, list(v), e1)
