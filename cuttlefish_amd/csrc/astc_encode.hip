@@ -152,7 +152,7 @@ struct Shared {
 	const uint8_t* grid;      // [grid][4]: N, M, ng, Np (even row pitch)
 	const uint8_t* cunq;      // [17][256]
 	const uint8_t* cnear;     // [17][256]
-	const uint8_t* cnear_hi;  // [17][256] HDR launches only: nearest index among values with bit 7 set
+	const uint8_t* cfloor;    // [17][256] HDR launches only: index of the largest stored value <= v
 	const uint8_t* wunq;      // [12][32]
 	const uint8_t* wnear;     // [12][68]
 	const uint8_t* wnu;       // [12][68] nearest unquantised weight of an average 0..64
@@ -254,14 +254,6 @@ __device__ __forceinline__ int quant_c(const Shared& sh, uint32_t lv, float x, u
 // constant-colour block: UNORM16 (LDR) or, with bit 9 of the header set, four halves (HDR profile)
 __device__ __forceinline__ uint4 void_extent(uint32_t r, uint32_t g, uint32_t b, uint32_t a, uint32_t hdrf);
 
-// HDR direct sub-mode: blue / HDR alpha go through the values with bit 7 set, decode (u & 0x7F) << 1
-__device__ __forceinline__ int quant_hi(const Shared& sh, uint32_t lv, float x, uint32_t& stored)
-{
-	const uint32_t xi = (uint32_t)(int)floorf(clampf255(x) + 0.5f);
-	stored = sh.cnear_hi[lv*256u + xi];
-	return (int)((sh.cunq[lv*256u + stored] & 0x7Fu) << 1);
-}
-
 // HDR profile: the 16-bit LNS value of a channel (oracle: cfo_astc_lns16 of the half; negative / NaN -> 0,
 // beyond 65504 -> 0x7BFF)
 __device__ __forceinline__ uint32_t hdr_lns16(float x)
@@ -318,7 +310,7 @@ __device__ __forceinline__ float cem_q(const CemIn& in, uint32_t c, float d0, fl
 
 // One endpoint-mode option of one partition: adds its quadratic error estimate to `est` and returns
 // the decoded endpoint bytes (d0p, d1p) and the stored ISE values (byte k of vlo | vhi << 32 = value k).
-// o: 0 direct (CEM 8/12; HDR: 11/14/15), 1 base+scale (6/10), 2 luminance (0/4), 3 base+offset (9/13).
+// o: 0 direct (CEM 8/12), 1 base+scale (6/10), 2 luminance (0/4), 3 base+offset (9/13).
 // r0 / r1: least-squares endpoints (alpha = 255 for blocks without alpha).  Returns false when the
 // option cannot represent the pair (direct with neither order valid, offsets out of range).
 // Written channel by channel with packed outputs: the array form of this function (every channel's
@@ -329,39 +321,8 @@ __device__ __forceinline__ bool cem_option(const Shared& sh, int o, uint32_t lv,
 {
 	uint32_t s0, s1;
 	d0p = 0xFF000000u; d1p = 0xFF000000u; vlo = 0; vhi = 0;
-	if (o == 0 && hdr) {
-		// HDR direct sub-mode (CEM 11 / 14 / 15, major component 3): v0..v3 = the 8-bit red and green
-		// endpoints, v4, v5 = 0x80 | 7 bits of blue; no ordering rule, no blue contraction (uniform
-		// per launch: `hdr` comes from the launch flags)
-#pragma unroll
-		for (uint32_t c = 0; c < 3u; ++c) {
-			int e0, e1;
-			if (c < 2u) {
-				e0 = quant_c(sh, lv, in.r0[c], s0);
-				e1 = quant_c(sh, lv, in.r1[c], s1);
-			} else {
-				e0 = quant_hi(sh, lv, in.r0[c], s0);
-				e1 = quant_hi(sh, lv, in.r1[c], s1);
-			}
-			d0p |= (uint32_t)e0 << (8u*c); d1p |= (uint32_t)e1 << (8u*c);
-			if (c < 2u) vlo |= (s0 | (s1 << 8)) << (16u*c);
-			else vhi |= s0 | (s1 << 8);
-			est = fmaf((float)cw[c], cem_q(in, c, (float)e0, (float)e1), est);
-		}
-		if (has_alpha) {
-			int e0, e1;
-			if (hdr & 2u) {
-				e0 = quant_hi(sh, lv, in.r0[3], s0);
-				e1 = quant_hi(sh, lv, in.r1[3], s1);
-			} else {
-				e0 = quant_c(sh, lv, in.r0[3], s0);
-				e1 = quant_c(sh, lv, in.r1[3], s1);
-			}
-			d0p = (d0p & 0x00FFFFFFu) | ((uint32_t)e0 << 24); d1p = (d1p & 0x00FFFFFFu) | ((uint32_t)e1 << 24);
-			vhi |= (s0 | (s1 << 8)) << 16;
-			est = fmaf((float)cw[3], cem_q(in, 3u, (float)e0, (float)e1), est);
-		}
-	} else if (o == 0) {
+	(void)hdr;
+	if (o == 0) {
 		// plain order
 		uint32_t pd0 = 0, pd1 = 0, vdl = 0, vdh = 0;
 		int sd0 = 0, sd1 = 0;
@@ -578,26 +539,21 @@ __device__ __forceinline__ unsigned long long ise_group(const uint8_t* ise, cons
 }
 
 // ---- HDR endpoint refinement (oracle: hdr_refine and its helpers, same arithmetic) ----------------
-// nearest stored value to v among those that keep the bits of himask; -1: the level has none
+// nearest stored value to v among those that keep the bits of himask; -1: the level has none.  The oracle scans
+// outwards from v; in closed form: the nearest value if it keeps the bits, else the first stored value on the
+// other side of v -- the largest <= v (floor table), or the smallest >= v = the mirror image of the largest
+// <= 255 - v (every colour level is symmetric; oracle: cfo_astc_requant_closed_form_mismatches = 0)
 __device__ __forceinline__ int requant_keep(const Shared& sh, uint32_t lv, int v, int himask)
 {
 	const int lo = v & himask, hi = lo | (~himask & 0xFF);
-	int q = (int)sh.cnear[lv*256u + (uint32_t)v], u = (int)sh.cunq[lv*256u + (uint32_t)q];
+	const uint8_t* unq = sh.cunq + lv*256u;
+	const int q = (int)sh.cnear[lv*256u + (uint32_t)v], u = (int)unq[q];
 	if (u >= lo && u <= hi)
 		return q;
-	for (int d = 1; d < 128; ++d) {
-		int x = v - d;
-		if (x >= lo) {
-			q = (int)sh.cnear[lv*256u + (uint32_t)x]; u = (int)sh.cunq[lv*256u + (uint32_t)q];
-			if (u >= lo && u <= hi) return q;
-		}
-		x = v + d;
-		if (x <= hi) {
-			q = (int)sh.cnear[lv*256u + (uint32_t)x]; u = (int)sh.cunq[lv*256u + (uint32_t)q];
-			if (u >= lo && u <= hi) return q;
-		}
-	}
-	return -1;
+	const int f = (int)sh.cfloor[lv*256u + (uint32_t)(u > hi ? v : 255 - v)];
+	const int q2 = u > hi ? f : (int)sh.cnear[lv*256u + 255u - (uint32_t)unq[f]];
+	const int u2 = (int)unq[q2];
+	return (u2 >= lo && u2 <= hi) ? q2 : -1;
 }
 
 __device__ __forceinline__ int rs_u(int x, int sh) { return x <= 0 ? 0 : (x + ((1 << sh) >> 1)) >> sh; }
@@ -698,6 +654,61 @@ __device__ __forceinline__ void hdr_rgb_unpack(const int (&v)[6], int (&e0)[3], 
 	if (majcomp == 2) { t = red0; red0 = blue0; blue0 = t; t = red1; red1 = blue1; blue1 = t; }
 	e0[0] = red0 << 4; e0[1] = green0 << 4; e0[2] = blue0 << 4;
 	e1[0] = red1 << 4; e1[1] = green1 << 4; e1[2] = blue1 << 4;
+}
+
+// Which forms a partition tries (oracle: hdr_form_list): mode 11 the direct form and the two finest sub-modes
+// whose fields hold the pair without clamping, mode 7 the two finest of sub-modes 0..4 that hold (high, scale)
+// and sub-mode 5.  h0 = the major component's high value, h1 / h2 the others in stored order; l0..l2 the lows.
+__device__ __forceinline__ bool hdr_rgb_holds(int m, int h0, int h1, int h2, int l0, int l1, int l2)
+{
+	const int ab = 9 + (m >> 1);
+	const int bb = (int)((0x67687687u >> (4*m)) & 15u), cb = (int)((0x77867766u >> (4*m)) & 15u), db = (int)((0x65656767u >> (4*m)) & 15u);
+	const int sh = 12 - ab;
+	const int aq = clampi(rs_u(h0, sh), 0, (1 << ab) - 1) << sh;
+	const int cf = rs_u(aq - l0, sh), bf0 = rs_u(aq - h1, sh), bf1 = rs_u(aq - h2, sh);
+	const int dl = -(1 << (db - 1)), dh = (1 << (db - 1)) - 1;
+	const int d0 = rs_s(aq - (bf0 << sh) - (cf << sh) - l1, sh), d1 = rs_s(aq - (bf1 << sh) - (cf << sh) - l2, sh);
+	return aq >= l0 && cf <= (1 << cb) - 1 && bf0 <= (1 << bb) - 1 && bf1 <= (1 << bb) - 1 && d0 >= dl && d0 <= dh && d1 >= dl && d1 <= dh;
+}
+
+__device__ __forceinline__ bool hdr_scale_holds(int m, int h0, int h1, int h2, int S12)
+{
+	const int rb = (int)((0x89ABBu >> (4*m)) & 15u), gb = (int)((0x76565u >> (4*m)) & 15u), sb = (int)((0x67857u >> (4*m)) & 15u);
+	const int sh = (int)((0x43211u >> (4*m)) & 15u);
+	const int rq = clampi(rs_u(h0, sh), 0, (1 << rb) - 1) << sh;
+	return rs_u(S12, sh) <= (1 << sb) - 1 && rs_u(rq - h1, sh) <= (1 << gb) - 1 && rs_u(rq - h2, sh) <= (1 << gb) - 1;
+}
+
+// the list as nibbles (k of hdr_rgb_place, or m of hdr_scale_place), nl = how many
+__device__ __forceinline__ uint32_t hdr_form_list(uint32_t opt, const int (&E0)[4], const int (&E1)[4], int S12, uint32_t& nl)
+{
+	int maj = 0;
+	if (E1[1] > E1[maj]) maj = 1;
+	if (E1[2] > sel3(maj, E1[0], E1[1], E1[2])) maj = 2;
+	const int c1 = maj == 1 ? 0 : 1, c2 = maj == 2 ? 0 : 2;
+	const int h0 = sel3(maj, E1[0], E1[1], E1[2]), h1 = sel3(c1, E1[0], E1[1], E1[2]), h2 = sel3(c2, E1[0], E1[1], E1[2]);
+	uint32_t list = 0u, held = 0u;
+	if (!opt) {
+		const int l0 = sel3(maj, E0[0], E0[1], E0[2]), l1 = sel3(c1, E0[0], E0[1], E0[2]), l2 = sel3(c2, E0[0], E0[1], E0[2]);
+		nl = 1u;
+#pragma unroll
+		for (int m = 7; m >= 0; --m) {
+			const bool take = held < 2u && hdr_rgb_holds(m, h0, h1, h2, l0, l1, l2);
+			list |= take ? (uint32_t)(1 + m) << (4u*nl) : 0u;
+			nl += take ? 1u : 0u; held += take ? 1u : 0u;
+		}
+	} else {
+		nl = 0u;
+#pragma unroll
+		for (int m = 0; m < 5; ++m) {
+			const bool take = held < 2u && hdr_scale_holds(m, h0, h1, h2, S12);
+			list |= take ? (uint32_t)m << (4u*nl) : 0u;
+			nl += take ? 1u : 0u; held += take ? 1u : 0u;
+		}
+		list |= 5u << (4u*nl);
+		nl += 1u;
+	}
+	return list;
 }
 
 // mode 7 (HDR RGB base + scale) value list of the 12-bit high endpoint E1 and the 12-bit scale S (low endpoint =
@@ -997,7 +1008,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 
 	Shared sh;
 	sh.infill = reinterpret_cast<const uint2*>(sh_infill); sh.den = sh_den; sh.grid = sh_grid;
-	sh.cunq = sh_ctab; sh.cnear = sh_ctab + 17u*256u; sh.cnear_hi = sh_ctab + 2u*17u*256u;
+	sh.cunq = sh_ctab; sh.cnear = sh_ctab + 17u*256u; sh.cfloor = sh_ctab + 2u*17u*256u;
 	sh.wunq = sh_wtab; sh.wnear = sh_wtab + 12u*32u; sh.wnu = sh_wtab + 12u*32u + 12u*68u;
 	const int8_t* clevel = reinterpret_cast<const int8_t*>(blob + H->off_clevel);
 	const uint8_t* ise = blob + H->off_ise;
@@ -1696,6 +1707,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 #undef ASTC_ACCH
 							}
 #define HSEL4(i, F) ((i) == 0u ? q0.F : ((i) == 1u ? q1.F : ((i) == 2u ? q2.F : q3.F)))
+							PROF_MARK(7)   // B (HDR): texel weights + sums
 							const bool a_hdr = has_alpha && (hdrf & 2u);
 							double tot_best = 1.0e300;
 							uint32_t sel_nv = 0u, sel_lv = 0u;
@@ -1759,20 +1771,23 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 										}
 										S12 = clampi((int)floor(s16*(1.0/16.0) + 0.5), 0, 4095);
 									}
-									// mode 11: the direct form and the eight sub-modes; mode 7: the six sub-modes --
-									// cheapest by the quadratic form
+									// mode 11: the direct form and the two finest sub-modes that hold the pair; mode 7: the two
+									// finest sub-modes that hold (high, scale) and sub-mode 5 -- cheapest by the quadratic form
 									double best = 1.0e300;
 									uint32_t bq_lo = 0, bq_hi = 0;
 									bool got = false;
-									const int nk = opt ? 6 : 9, nq = opt ? 4 : 6;
+									uint32_t nl;
+									const uint32_t list = hdr_form_list(opt, E0, E1, S12, nl);
+									const int nq = opt ? 4 : 6;
 #pragma unroll 1
-									for (int k = 0; k < nk; ++k) {
+									for (uint32_t t = 0; t < 3u; ++t) {
+										const int k = (int)((list >> (4u*t)) & 15u);
 										int v[6], hm[6], q6[6];
 										if (opt)
 											hdr_scale_place(k, E1, S12, v, hm);
 										else
 											hdr_rgb_place(k, E0, E1, r0, r1, v, hm);
-										bool ok = true;
+										bool ok = t < nl;
 #pragma unroll
 										for (int i = 0; i < 6; ++i) {
 											q6[i] = (ok && i < nq) ? requant_keep(sh, lv, v[i], hm[i]) : (i < nq ? -1 : 0);
@@ -1847,6 +1862,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 								}
 							}
 #undef HSEL4
+							PROF_MARK(8)   // B (HDR): endpoint modes
 							if (sel_nv) {
 								// the endpoints the chosen value list decodes to
 								uint32_t D0lo[4] = {0, 0, 0, 0}, D0hi[4] = {0, 0, 0, 0}, D1lo[4] = {0, 0, 0, 0}, D1hi[4] = {0, 0, 0, 0};

@@ -478,18 +478,15 @@ inline std::vector<uint8_t> build_blob(int bw, int bh)
 				}
 				near[r*256 + w] = (uint8_t)best;
 			}
-			// HDR direct sub-mode (CEM 11 / 14 / 15): blue and HDR alpha are stored as 0x80 | 7 bits
-			uint8_t* near_hi = near + 17*256;
+			// HDR endpoint modes (requant_keep): index of the largest stored value <= w
+			uint8_t* floor_ = near + 17*256;
 			for (int w = 0; w < 256; ++w) {
-				int best = 0, bd = 1000, bu = 1000;
+				int best = 0, bu = -1;
 				for (int v = 0; v < CQ[r].levels; ++v) {
 					const int u = unq[r*256 + v];
-					if (u < 128)
-						continue;
-					const int dec = (u & 0x7F) << 1, d = dec > w ? dec - w : w - dec;
-					if (d < bd || (d == bd && u < bu)) { bd = d; bu = u; best = v; }
+					if (u <= w && u > bu) { bu = u; best = v; }
 				}
-				near_hi[r*256 + w] = (uint8_t)best;
+				floor_[r*256 + w] = (uint8_t)best;
 			}
 		}
 		uint8_t* wunq = blob.data() + h.off_wtab;

@@ -8,5 +8,5 @@ mkdir -p $R/tools/ab
 ( cd $R/cuttlefish_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-function \
     -DCF_ASTC_PROF=1 -o $R/tools/ab/astc_prof.so astc_encode.hip bc15_encode.hip bc6h_encode.hip bc7_encode.hip cfhip_api.hip etc_encode.hip mipgen.hip std_pack.hip )
 for q in $qs; do
-  CFHIP_LIB=$R/tools/ab/astc_prof.so python $R/tools/bench_formats.py --size 2048 --steps 1 --formats $fmt --qualities $q 2>&1 | grep "astc prof" | head -1
+  CFHIP_LIB=$R/tools/ab/astc_prof.so python $R/tools/bench_formats.py --size 2048 --steps 1 --formats $fmt --qualities $q 2>&1 | grep "astc prof\|\"format\"" | cut -c1-400
 done
