@@ -152,7 +152,7 @@ struct Shared {
 	const uint8_t* grid;      // [grid][4]: N, M, ng, Np (even row pitch)
 	const uint8_t* cunq;      // [17][256]
 	const uint8_t* cnear;     // [17][256]
-	const uint8_t* cfloor;    // [17][256] HDR launches only: index of the largest stored value <= v
+	const uint32_t* creq;     // [17][256] HDR launches only: nearest index | its value << 8 | the first stored value on the other side of v: index << 16 | value << 24
 	const uint8_t* wunq;      // [12][32]
 	const uint8_t* wnear;     // [12][68]
 	const uint8_t* wnu;       // [12][68] nearest unquantised weight of an average 0..64
@@ -541,19 +541,15 @@ __device__ __forceinline__ unsigned long long ise_group(const uint8_t* ise, cons
 // ---- HDR endpoint refinement (oracle: hdr_refine and its helpers, same arithmetic) ----------------
 // nearest stored value to v among those that keep the bits of himask; -1: the level has none.  The oracle scans
 // outwards from v; in closed form: the nearest value if it keeps the bits, else the first stored value on the
-// other side of v -- the largest <= v (floor table), or the smallest >= v = the mirror image of the largest
-// <= 255 - v (every colour level is symmetric; oracle: cfo_astc_requant_closed_form_mismatches = 0)
-__device__ __forceinline__ int requant_keep(const Shared& sh, uint32_t lv, int v, int himask)
+// other side of v (oracle: cfo_astc_requant_closed_form_mismatches = 0) -- both in one table word.  u = the value.
+__device__ __forceinline__ int requant_keep(const Shared& sh, uint32_t lv, int v, int himask, int& u)
 {
 	const int lo = v & himask, hi = lo | (~himask & 0xFF);
-	const uint8_t* unq = sh.cunq + lv*256u;
-	const int q = (int)sh.cnear[lv*256u + (uint32_t)v], u = (int)unq[q];
-	if (u >= lo && u <= hi)
-		return q;
-	const int f = (int)sh.cfloor[lv*256u + (uint32_t)(u > hi ? v : 255 - v)];
-	const int q2 = u > hi ? f : (int)sh.cnear[lv*256u + 255u - (uint32_t)unq[f]];
-	const int u2 = (int)unq[q2];
-	return (u2 >= lo && u2 <= hi) ? q2 : -1;
+	const uint32_t e = sh.creq[lv*256u + (uint32_t)v];
+	const int un = (int)((e >> 8) & 255u), uo = (int)(e >> 24);
+	const bool in = un >= lo && un <= hi, ino = uo >= lo && uo <= hi;
+	u = in ? un : uo;
+	return in ? (int)(e & 255u) : (ino ? (int)((e >> 16) & 255u) : -1);
 }
 
 __device__ __forceinline__ int rs_u(int x, int sh) { return x <= 0 ? 0 : (x + ((1 << sh) >> 1)) >> sh; }
@@ -890,7 +886,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	uint32_t* sh_infill = reinterpret_cast<uint32_t*>(lds + off); off += ngrids*n*8u; off = (off + 15u) & ~15u;
 	uint32_t* sh_den = reinterpret_cast<uint32_t*>(lds + off); off += ngrids*den_stride*4u;
 	uint8_t* sh_grid = lds + off; off += (ngrids*4u + 15u) & ~15u;
-	uint8_t* sh_ctab = lds + off; off += (hdrf ? 3u : 2u)*17u*256u;
+	uint8_t* sh_ctab = lds + off; off += (hdrf ? 6u : 2u)*17u*256u;
 	uint8_t* sh_wtab = lds + off; off += 2016u;
 	const uint32_t slot_bytes = ((10u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
 	const uint32_t wave_bytes = ((((col_rows + 1u)/2u)*256u + 15u) & ~15u) + (kp.quality <= 3u ? 2u : 1u)*slot_bytes;
@@ -905,7 +901,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		sh_den[i] = reinterpret_cast<const uint32_t*>(blob + H->off_den)[i];
 	for (uint32_t i = threadIdx.x; i < ngrids; i += nthreads)
 		reinterpret_cast<uint32_t*>(sh_grid)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_grid)[i];
-	for (uint32_t i = threadIdx.x; i < (hdrf ? 3u : 2u)*17u*64u; i += nthreads)
+	for (uint32_t i = threadIdx.x; i < (hdrf ? 6u : 2u)*17u*64u; i += nthreads)
 		reinterpret_cast<uint32_t*>(sh_ctab)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_ctab)[i];
 	for (uint32_t i = threadIdx.x; i < 504u; i += nthreads)
 		reinterpret_cast<uint32_t*>(sh_wtab)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_wtab)[i];
@@ -1008,7 +1004,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 
 	Shared sh;
 	sh.infill = reinterpret_cast<const uint2*>(sh_infill); sh.den = sh_den; sh.grid = sh_grid;
-	sh.cunq = sh_ctab; sh.cnear = sh_ctab + 17u*256u; sh.cfloor = sh_ctab + 2u*17u*256u;
+	sh.cunq = sh_ctab; sh.cnear = sh_ctab + 17u*256u; sh.creq = reinterpret_cast<const uint32_t*>(sh_ctab + 2u*17u*256u);
 	sh.wunq = sh_wtab; sh.wnear = sh_wtab + 12u*32u; sh.wnu = sh_wtab + 12u*32u + 12u*68u;
 	const int8_t* clevel = reinterpret_cast<const int8_t*>(blob + H->off_clevel);
 	const uint8_t* ise = blob + H->off_ise;
@@ -1679,97 +1675,147 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						// the high endpoint and one scale, six sub-modes).  Each is fitted, requantised at ITS colour
 						// level, decoded and priced by the quadratic form of the unconstrained fit; the cheaper one
 						// (summed over the partitions) keeps its value list and goes on to the exact error.
-						const bool opt1_any = __ballot(!has_alpha && 4u*P <= 18u) != 0ull;
+						const bool opt1_any = !(CF_ASTC_ABLATE & 1024) && __ballot(!has_alpha && 4u*P <= 18u) != 0ull;
 						const bool opt0_any = __ballot((has_alpha ? 8u : 6u)*P <= 18u) != 0ull;
 						if (opt0_any || opt1_any) {
 							const uint32_t* t16 = tile16 + b*n*2u;
 							struct SetAccH { uint32_t cnt, S, C, V0, V1, V2, V3, T0, T1, T2, T3; };
 							SetAccH q0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;
 							const bool any3 = __ballot(P > 2u) != 0ull, any4 = __ballot(P > 3u) != 0ull;
+							// four texels per step (as the LDR sums below): weights as bytes of one word, the 16-bit texels
+							// as eight byte planes (low and high byte of each channel), a set's members as a byte mask --
+							// S, C, V_c = sum w l_c and T_c = sum l_c by v_dot4_u32_u8, the high plane shifted in
 #pragma unroll 1
-							for (uint32_t i = 0; i < n; ++i) {
-								const uint2 rec = inf[i];
-								const uint32_t part = byp ? 0u : prow[i];
-								const uint32_t wA = infill_w(colbase, rec.x, rec.y);
-								const uint32_t w1s = dual ? infill_w(colp1, rec.x, rec.y) : wA;
-								const uint32_t mm = dual ? 3u : (1u << part);
-								const uint32_t x01 = t16[2u*i], x23 = t16[2u*i + 1u];
-								const uint32_t l0 = x01 & 0xFFFFu, l1 = x01 >> 16, l2 = x23 & 0xFFFFu, l3 = x23 >> 16;
-#define ASTC_ACCH(Q, ST, WI) { \
-								const bool mem = (mm & (1u << ST)) != 0u; \
-								const uint32_t wm = mem ? WI : 0u; \
-								Q.cnt += mem ? 1u : 0u; Q.S += wm; Q.C += wm*WI; \
-								Q.V0 += wm*l0; Q.V1 += wm*l1; Q.V2 += wm*l2; Q.V3 += wm*l3; \
-								Q.T0 += mem ? l0 : 0u; Q.T1 += mem ? l1 : 0u; Q.T2 += mem ? l2 : 0u; Q.T3 += mem ? l3 : 0u; }
-								ASTC_ACCH(q0, 0u, wA) ASTC_ACCH(q1, 1u, w1s)
-								if (any3) ASTC_ACCH(q2, 2u, wA)
-								if (any4) ASTC_ACCH(q3, 3u, wA)
+							for (uint32_t i = 0; i < n; i += 4u) {
+								uint32_t WA = 0, W1 = 0, valid = 0;
+#pragma unroll
+								for (uint32_t k = 0; k < 4u; ++k) {
+									if (i + k < n) {
+										const uint2 rec = inf[i + k];
+										WA |= infill_w(colbase, rec.x, rec.y) << (8u*k);
+										W1 |= (dual ? infill_w(colp1, rec.x, rec.y) : 0u) << (8u*k);
+										valid |= 1u << (8u*k);
+									}
+								}
+								W1 = dual ? W1 : WA;
+								const uint32_t i1 = min(i + 1u, n - 1u), i2 = min(i + 2u, n - 1u), i3 = min(i + 3u, n - 1u);
+								const uint32_t a0 = t16[2u*i], a1 = t16[2u*i1], a2 = t16[2u*i2], a3 = t16[2u*i3];
+								const uint32_t b0 = t16[2u*i + 1u], b1 = t16[2u*i1 + 1u], b2 = t16[2u*i2 + 1u], b3 = t16[2u*i3 + 1u];
+								const uint32_t s01 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), s23 = __builtin_amdgcn_perm(a3, a2, 0x05010400u);
+								const uint32_t u01 = __builtin_amdgcn_perm(a1, a0, 0x07030602u), u23 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
+								const uint32_t RL = __builtin_amdgcn_perm(s23, s01, 0x05040100u), RH = __builtin_amdgcn_perm(s23, s01, 0x07060302u);
+								const uint32_t GL = __builtin_amdgcn_perm(u23, u01, 0x05040100u), GH = __builtin_amdgcn_perm(u23, u01, 0x07060302u);
+								const uint32_t y01 = __builtin_amdgcn_perm(b1, b0, 0x05010400u), y23 = __builtin_amdgcn_perm(b3, b2, 0x05010400u);
+								const uint32_t z01 = __builtin_amdgcn_perm(b1, b0, 0x07030602u), z23 = __builtin_amdgcn_perm(b3, b2, 0x07030602u);
+								const uint32_t BL = __builtin_amdgcn_perm(y23, y01, 0x05040100u), BH = __builtin_amdgcn_perm(y23, y01, 0x07060302u);
+								const uint32_t AL = __builtin_amdgcn_perm(z23, z01, 0x05040100u), AH = __builtin_amdgcn_perm(z23, z01, 0x07060302u);
+								const uint32_t pw = byp ? 0u : *reinterpret_cast<const uint32_t*>(prow + i);      // subset ids 0..3
+#define ASTC_ACCH(Q, ST, W) { \
+								const uint32_t x_ = pw ^ (ST*0x01010101u); \
+								const uint32_t m_ = dual ? (ST < 2u ? valid : 0u) : (~(x_ | (x_ >> 1)) & valid); \
+								const uint32_t wm = W & ((m_ << 8) - m_); \
+								Q.cnt += (uint32_t)__builtin_popcount(m_); \
+								Q.S = __builtin_amdgcn_udot4(wm, 0x01010101u, Q.S, false); \
+								Q.C = __builtin_amdgcn_udot4(wm, W, Q.C, false); \
+								Q.V0 = __builtin_amdgcn_udot4(wm, RL, Q.V0, false) + (__builtin_amdgcn_udot4(wm, RH, 0u, false) << 8); \
+								Q.V1 = __builtin_amdgcn_udot4(wm, GL, Q.V1, false) + (__builtin_amdgcn_udot4(wm, GH, 0u, false) << 8); \
+								Q.V2 = __builtin_amdgcn_udot4(wm, BL, Q.V2, false) + (__builtin_amdgcn_udot4(wm, BH, 0u, false) << 8); \
+								Q.V3 = __builtin_amdgcn_udot4(wm, AL, Q.V3, false) + (__builtin_amdgcn_udot4(wm, AH, 0u, false) << 8); \
+								Q.T0 = __builtin_amdgcn_udot4(m_, RL, Q.T0, false) + (__builtin_amdgcn_udot4(m_, RH, 0u, false) << 8); \
+								Q.T1 = __builtin_amdgcn_udot4(m_, GL, Q.T1, false) + (__builtin_amdgcn_udot4(m_, GH, 0u, false) << 8); \
+								Q.T2 = __builtin_amdgcn_udot4(m_, BL, Q.T2, false) + (__builtin_amdgcn_udot4(m_, BH, 0u, false) << 8); \
+								Q.T3 = __builtin_amdgcn_udot4(m_, AL, Q.T3, false) + (__builtin_amdgcn_udot4(m_, AH, 0u, false) << 8); }
+								ASTC_ACCH(q0, 0u, WA) ASTC_ACCH(q1, 1u, W1)
+								if (any3) ASTC_ACCH(q2, 2u, WA)
+								if (any4) ASTC_ACCH(q3, 3u, WA)
 #undef ASTC_ACCH
 							}
 #define HSEL4(i, F) ((i) == 0u ? q0.F : ((i) == 1u ? q1.F : ((i) == 2u ? q2.F : q3.F)))
 							PROF_MARK(7)   // B (HDR): texel weights + sums
 							const bool a_hdr = has_alpha && (hdrf & 2u);
-							double tot_best = 1.0e300;
-							uint32_t sel_nv = 0u, sel_lv = 0u;
+							// colour level and state of each option (a lane without the option: level -1, never chosen)
+							const uint32_t nv0 = has_alpha ? 8u : 6u;
+							const int lv0 = nv0*P <= 18u ? (int)clevel[(nv0*P/2u)*132u + cfg.cbits] : -1;
+							const int lv1 = (!has_alpha && 4u*P <= 18u) ? (int)clevel[(4u*P/2u)*132u + cfg.cbits] : -1;
+							bool ok0 = lv0 >= 0, ok1 = lv1 >= 0;
+							double tot0 = 0.0, tot1 = 0.0;
+							uint32_t cv0[5] = {0, 0, 0, 0, 0}, cv1[4] = {0, 0, 0, 0};       // option 1: four values = one word per partition
 #pragma unroll 1
-							for (uint32_t opt = 0; opt < 2u; ++opt) {
-								if (opt ? !opt1_any : !opt0_any)
-									continue;
-								const uint32_t nvh = opt ? 4u : (has_alpha ? 8u : 6u);
-								const int lvh = (nvh*P <= 18u && !(opt && has_alpha)) ? (int)clevel[(nvh*P/2u)*132u + cfg.cbits] : -1;
-								bool all_ok = lvh >= 0;
-								const uint32_t lv = all_ok ? (uint32_t)lvh : 0u;
-								uint32_t cvt[5] = {0, 0, 0, 0, 0};
-								double tot = 0.0;
-#pragma unroll 1
-								for (uint32_t p = 0; p < P; ++p) {
-									double r0[4], r1[4], fA[4], fB[4], fC[4];
-									int E0[4], E1[4];
-									double Nn = 0.0, Dd = 0.0;
+							for (uint32_t p = 0; p < ((CF_ASTC_ABLATE & 8192) ? 1u : P); ++p) {
+								// least squares once per partition.  Every product below is an integer under 2^53: the
+								// double arithmetic is exact and equals the oracle's 64-bit integers.  X = the form of
+								// the partition's set (dual plane: plane 0), Y = plane 1's (the channel ccs of a dual lane)
+								double r0[4], r1[4];
+								int E0[4], E1[4];
+								const uint32_t sx = dual ? 0u : p;
+								const uint32_t cntX = HSEL4(sx, cnt), SX = HSEL4(sx, S), CX = HSEL4(sx, C);
+								const uint32_t cntY = q1.cnt, SY = q1.S, CY = q1.C;
+								// (the forms stay 32-bit integers, converted where they are used: half the registers)
+								const uint32_t XAu = 4096u*cntX - 128u*SX + CX, XBu = 64u*SX - CX;
+								const uint32_t YAu = 4096u*cntY - 128u*SY + CY, YBu = 64u*SY - CY;
+#define XA ((double)XAu)
+#define XB ((double)XBu)
+#define XC ((double)CX)
+#define YA ((double)YAu)
+#define YB ((double)YBu)
+#define YC ((double)CY)
+								const int detX = (int)(cntX*CX) - (int)(SX*SX), detY = (int)(cntY*CY) - (int)(SY*SY);
+								const double invX = detX > 0 ? 1.0/(64.0*(double)detX) : 0.0, invY = detY > 0 ? 1.0/(64.0*(double)detY) : 0.0;
+								double Nn = 0.0, Dd = 0.0;
 #pragma unroll
-									for (uint32_t c = 0; c < 4u; ++c) {
-										const uint32_t st = dual ? (c == ccs ? 1u : 0u) : p;
-										const long long cnt_ = HSEL4(st, cnt), S_ = HSEL4(st, S), C_ = HSEL4(st, C);
-										const long long V_ = c == 0u ? HSEL4(st, V0) : (c == 1u ? HSEL4(st, V1) : (c == 2u ? HSEL4(st, V2) : HSEL4(st, V3)));
-										const long long T_ = c == 0u ? HSEL4(st, T0) : (c == 1u ? HSEL4(st, T1) : (c == 2u ? HSEL4(st, T2) : HSEL4(st, T3)));
-										const long long A_ = 4096ll*cnt_ - 128ll*S_ + C_, B_ = 64ll*S_ - C_, U_ = 64ll*T_ - V_;
-										const long long det = cnt_*C_ - S_*S_;
-										fA[c] = (double)A_; fB[c] = (double)B_; fC[c] = (double)C_;
-										double x0, x1;
-										if (det > 0) {
-											const double den_ = (double)(64ll*det);
-											x0 = (double)(C_*U_ - B_*V_)/den_;
-											x1 = (double)(A_*V_ - B_*U_)/den_;
-										} else {
-											x0 = x1 = cnt_ ? (double)T_/(double)cnt_ : 0.0;
-										}
-										x0 = x0 < 0.0 ? 0.0 : (x0 > 65535.0 ? 65535.0 : x0);
-										x1 = x1 < 0.0 ? 0.0 : (x1 > 65535.0 ? 65535.0 : x1);
-										r0[c] = x0; r1[c] = x1;
-										E0[c] = clampi((int)floor(x0*(1.0/16.0) + 0.5), 0, 4095);
-										E1[c] = clampi((int)floor(x1*(1.0/16.0) + 0.5), 0, 4095);
-										if (c < 3u) {
-											Nn = Nn + (double)(cnt_*V_ - T_*S_);
-											Dd = Dd + (double)det;
-										}
+								for (uint32_t c = 0; c < 4u; ++c) {
+									const bool y = dual && c == ccs;
+									const uint32_t st = y ? 1u : sx;
+									const uint32_t Vu = c == 0u ? HSEL4(st, V0) : (c == 1u ? HSEL4(st, V1) : (c == 2u ? HSEL4(st, V2) : HSEL4(st, V3)));
+									const uint32_t Tu = c == 0u ? HSEL4(st, T0) : (c == 1u ? HSEL4(st, T1) : (c == 2u ? HSEL4(st, T2) : HSEL4(st, T3)));
+									const double fA_ = y ? YA : XA, fB_ = y ? YB : XB, fC_ = y ? YC : XC, inv = y ? invY : invX;
+									const double dcnt = (double)(y ? cntY : cntX), dS = (double)(y ? SY : SX);
+									const int det = y ? detY : detX;
+									const double dV = (double)Vu, dT = (double)Tu, dU = (double)(64u*Tu - Vu);
+									double x0, x1;
+									if (det > 0) {
+										x0 = (fC_*dU - fB_*dV)*inv;
+										x1 = (fA_*dV - fB_*dU)*inv;
+									} else {
+										x0 = x1 = dcnt > 0.0 ? dT/dcnt : 0.0;
 									}
-									int S12 = 0;
-									if (opt) {
-										// the constrained fit (low = high - s on every channel): s = 64 N / D, then
-										// e1_c = (T_c + s (64 cnt - S)/64) / cnt
-										double s16 = Dd > 0.0 ? (64.0*Nn)/Dd : 0.0;
-										s16 = s16 < 0.0 ? 0.0 : (s16 > 65535.0 ? 65535.0 : s16);
+									x0 = x0 < 0.0 ? 0.0 : (x0 > 65535.0 ? 65535.0 : x0);
+									x1 = x1 < 0.0 ? 0.0 : (x1 > 65535.0 ? 65535.0 : x1);
+									r0[c] = x0; r1[c] = x1;
+									E0[c] = clampi((int)floor(x0*(1.0/16.0) + 0.5), 0, 4095);
+									E1[c] = clampi((int)floor(x1*(1.0/16.0) + 0.5), 0, 4095);
+									if (c < 3u) {
+										Nn = Nn + (dcnt*dV - dT*dS);
+										Dd = Dd + (double)det;
+									}
+								}
+								// mode 7's constrained fit (low = high - s on every channel): s = 64 N / D, then
+								// e1_c = (T_c + s (64 cnt - S)/64) / cnt; 12-bit high endpoint and scale, packed
+								unsigned long long m7 = 0ull;
+								if (opt1_any) {
+									double s16 = Dd > 0.0 ? (64.0*Nn)/Dd : 0.0;
+									s16 = s16 < 0.0 ? 0.0 : (s16 > 65535.0 ? 65535.0 : s16);
 #pragma unroll
-										for (uint32_t c = 0; c < 3u; ++c) {
-											const uint32_t st = dual ? (c == ccs ? 1u : 0u) : p;
-											const long long cnt_ = HSEL4(st, cnt), S_ = HSEL4(st, S);
-											const long long T_ = c == 0u ? HSEL4(st, T0) : (c == 1u ? HSEL4(st, T1) : HSEL4(st, T2));
-											const double sa = (double)(64ll*cnt_ - S_)*(1.0/64.0);
-											double x = cnt_ ? ((double)T_ + s16*sa)/(double)cnt_ : 0.0;
-											x = x < 0.0 ? 0.0 : (x > 65535.0 ? 65535.0 : x);
-											E1[c] = clampi((int)floor(x*(1.0/16.0) + 0.5), 0, 4095);
-										}
-										S12 = clampi((int)floor(s16*(1.0/16.0) + 0.5), 0, 4095);
+									for (uint32_t c = 0; c < 3u; ++c) {
+										const bool y = dual && c == ccs;
+										const uint32_t st = y ? 1u : sx;
+										const uint32_t cn = y ? cntY : cntX, Su = y ? SY : SX;
+										const uint32_t Tu = c == 0u ? HSEL4(st, T0) : (c == 1u ? HSEL4(st, T1) : HSEL4(st, T2));
+										const double sa = (double)(64u*cn - Su)*(1.0/64.0);
+										double x = cn ? ((double)Tu + s16*sa)/(double)cn : 0.0;
+										x = x < 0.0 ? 0.0 : (x > 65535.0 ? 65535.0 : x);
+										m7 |= (unsigned long long)clampi((int)floor(x*(1.0/16.0) + 0.5), 0, 4095) << (12u*c);
+									}
+									m7 |= (unsigned long long)clampi((int)floor(s16*(1.0/16.0) + 0.5), 0, 4095) << 36;
+								}
+#pragma unroll 1
+								for (uint32_t opt = 0; opt < 2u; ++opt) {
+									if (opt ? !opt1_any : !opt0_any)
+										continue;
+									const uint32_t lv = opt ? (lv1 >= 0 ? (uint32_t)lv1 : 0u) : (lv0 >= 0 ? (uint32_t)lv0 : 0u);
+									const int S12 = (int)(m7 >> 36);
+									if (opt) {
+										E1[0] = (int)(m7 & 0xFFFull); E1[1] = (int)((m7 >> 12) & 0xFFFull); E1[2] = (int)((m7 >> 24) & 0xFFFull);
 									}
 									// mode 11: the direct form and the two finest sub-modes that hold the pair; mode 7: the two
 									// finest sub-modes that hold (high, scale) and sub-mode 5 -- cheapest by the quadratic form
@@ -1777,10 +1823,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 									uint32_t bq_lo = 0, bq_hi = 0;
 									bool got = false;
 									uint32_t nl;
-									const uint32_t list = hdr_form_list(opt, E0, E1, S12, nl);
+									const uint32_t list = (CF_ASTC_ABLATE & 2048) ? (nl = 3u, opt ? 0x531u : 0x780u) : hdr_form_list(opt, E0, E1, S12, nl);
 									const int nq = opt ? 4 : 6;
 #pragma unroll 1
-									for (uint32_t t = 0; t < 3u; ++t) {
+									for (uint32_t t = 0; t < ((CF_ASTC_ABLATE & 512) ? 1u : 3u); ++t) {
 										const int k = (int)((list >> (4u*t)) & 15u);
 										int v[6], hm[6], q6[6];
 										if (opt)
@@ -1790,9 +1836,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 										bool ok = t < nl;
 #pragma unroll
 										for (int i = 0; i < 6; ++i) {
-											q6[i] = (ok && i < nq) ? requant_keep(sh, lv, v[i], hm[i]) : (i < nq ? -1 : 0);
+											int u = 0;
+											q6[i] = i < nq ? requant_keep(sh, lv, v[i], hm[i], u) : 0;     // (independent lookups: they overlap)
 											ok = ok && q6[i] >= 0;
-											v[i] = (ok && i < nq) ? (int)sh.cunq[lv*256u + (uint32_t)q6[i]] : 0;
+											v[i] = u;
 										}
 										if (ok) {
 											int d0[3], d1[3];
@@ -1802,9 +1849,12 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 												hdr_rgb_unpack(v, d0, d1);
 											double est = 0.0;
 #pragma unroll
-											for (int c = 0; c < 3; ++c)
-												est = est + (double)cw[c]*quad_est_d(fA[c], fB[c], fC[c], (double)d0[c] - r0[c], (double)d1[c] - r1[c]);
+											for (uint32_t c = 0; c < 3u; ++c) {
+												const bool y = dual && c == ccs;
+												est = est + (double)cw[c]*quad_est_d(y ? YA : XA, y ? YB : XB, y ? YC : XC, (double)d0[c] - r0[c], (double)d1[c] - r1[c]);
+											}
 											est = est > 0.0 ? est : 0.0;
+											if (CF_ASTC_ABLATE & 4096) est = (double)(d0[0] + d1[1] + d0[2]);
 											if (est < best) {
 												best = est;
 												got = true;
@@ -1813,8 +1863,16 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 											}
 										}
 									}
-									all_ok = all_ok && got;
-									tot = tot + (got ? best : 0.0);
+									if (opt) {
+										ok1 = ok1 && got;
+										tot1 = tot1 + (got ? best : 0.0);
+#pragma unroll
+										for (uint32_t k = 0; k < 4u; ++k)
+											cv1[k] |= p == k ? bq_lo : 0u;
+										continue;
+									}
+									ok0 = ok0 && got;
+									tot0 = tot0 + (got ? best : 0.0);
 									if (a_hdr) {
 										best = 1.0e300;
 										got = false;
@@ -1822,11 +1880,13 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 										for (int sel = 3; sel >= 0; --sel) {
 											int v6, v7, hm6, hm7;
 											hdr_alpha_place(sel, E0[3], E1[3], r0[3], r1[3], v6, v7, hm6, hm7);
-											const int qa = requant_keep(sh, lv, v6, hm6), qb = requant_keep(sh, lv, v7, hm7);
+											int ua, ub;
+											const int qa = requant_keep(sh, lv, v6, hm6, ua), qb = requant_keep(sh, lv, v7, hm7, ub);
 											if (qa >= 0 && qb >= 0) {
 												int a0, a1;
-												hdr_alpha_unpack((int)sh.cunq[lv*256u + (uint32_t)qa], (int)sh.cunq[lv*256u + (uint32_t)qb], a0, a1);
-												double est = quad_est_d(fA[3], fB[3], fC[3], (double)a0 - r0[3], (double)a1 - r1[3]);
+												hdr_alpha_unpack(ua, ub, a0, a1);
+												const bool y = dual && ccs == 3u;
+												double est = quad_est_d(y ? YA : XA, y ? YB : XB, y ? YC : XC, (double)a0 - r0[3], (double)a1 - r1[3]);
 												est = est > 0.0 ? est : 0.0;
 												if (est < best) {
 													best = est;
@@ -1835,7 +1895,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 												}
 											}
 										}
-										all_ok = all_ok && got;
+										ok0 = ok0 && got;
 									} else if (has_alpha) {
 										// LDR alpha (mode 14): two UNORM8 values; the fit above ran on the 0..255 values
 										uint32_t s6, s7;
@@ -1844,21 +1904,32 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 										bq_hi = (bq_hi & 0xFFFFu) | (s6 << 16) | (s7 << 24);
 									}
 									{
-										const unsigned long long vv = ((unsigned long long)bq_hi << 32 | bq_lo) & (nvh >= 8u ? ~0ull : ((1ull << (8u*nvh)) - 1ull));
-										const uint32_t bit = p*nvh*8u, wd0 = bit >> 5, sh_ = bit & 31u;
+										const unsigned long long vv = ((unsigned long long)bq_hi << 32 | bq_lo) & (nv0 >= 8u ? ~0ull : ((1ull << (8u*nv0)) - 1ull));
+										const uint32_t bit = p*nv0*8u, wd0 = bit >> 5, sh_ = bit & 31u;
 										const unsigned long long lo = vv << sh_;
 										const uint32_t x0 = (uint32_t)lo, x1 = (uint32_t)(lo >> 32), x2 = sh_ ? (uint32_t)(vv >> (64u - sh_)) : 0u;
 #pragma unroll
 										for (uint32_t wd = 0; wd < 5u; ++wd)
-											cvt[wd] |= wd == wd0 ? x0 : (wd == wd0 + 1u ? x1 : (wd == wd0 + 2u ? x2 : 0u));
+											cv0[wd] |= wd == wd0 ? x0 : (wd == wd0 + 1u ? x1 : (wd == wd0 + 2u ? x2 : 0u));
 									}
 								}
-								if (all_ok && tot < tot_best) {
-									tot_best = tot;
-									sel_nv = nvh; sel_lv = lv;
+							}
+#undef XA
+#undef XB
+#undef XC
+#undef YA
+#undef YB
+#undef YC
+							uint32_t sel_nv = 0u, sel_lv = 0u;
+							{
+								const bool take1 = ok1 && (!ok0 || tot1 < tot0);
+								if (ok0 || ok1) {
+									sel_nv = take1 ? 4u : nv0;
+									sel_lv = (uint32_t)(take1 ? lv1 : lv0);
 #pragma unroll
-									for (uint32_t wd = 0; wd < 5u; ++wd)
-										r_cv[wd] = cvt[wd];
+									for (uint32_t wd = 0; wd < 4u; ++wd)
+										r_cv[wd] = take1 ? cv1[wd] : cv0[wd];
+									r_cv[4] = take1 ? 0u : cv0[4];
 								}
 							}
 #undef HSEL4
@@ -1902,8 +1973,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 									}
 								}
 								// exact error through the decode arithmetic: HDR channels on the 16-bit LNS values; an LDR
-								// alpha on UNORM8 scaled by 257 to the same range
-								unsigned long long e64 = 0;
+								// alpha on UNORM8 scaled by 257 to the same range.  Integer sums regrouped (exact): per channel
+								// sum_i d^2 wa_i, the channel weight once at the end; d^2 < 2^32
+								unsigned long long ec0 = 0, ec1 = 0, ec2 = 0, ec3 = 0;
+								const bool wa_on = (aflags & ASTC_FLAG_ALPHA_WEIGHT) && !(hdrf & 2u);
 #pragma unroll 1
 								for (uint32_t i = 0; i < n; ++i) {
 									const uint2 rec = inf[i];
@@ -1915,7 +1988,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 									const uint32_t e1lo = part == 0u ? D1lo[0] : (part == 1u ? D1lo[1] : (part == 2u ? D1lo[2] : D1lo[3]));
 									const uint32_t e1hi = part == 0u ? D1hi[0] : (part == 1u ? D1hi[1] : (part == 2u ? D1hi[2] : D1hi[3]));
 									const uint32_t x01 = t16[2u*i], x23 = t16[2u*i + 1u];
-									unsigned long long ergb = 0, ea = 0;
+									const uint32_t wa = wa_on ? (x23 >> 16) : 255u;
 #pragma unroll
 									for (uint32_t c = 0; c < 4u; ++c) {
 										if (c < nc) {
@@ -1929,14 +2002,16 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 												dd_ = (int)((xw + 32u) >> 6) - (int)tx;
 											else
 												dd_ = ((int)((257u*xw + 32u) >> 14) - (int)tx)*257;
-											const unsigned long long e = (unsigned long long)cw[c]*(unsigned long long)((long long)dd_*(long long)dd_);
-											if (c < 3u) ergb += e;
-											else ea = e;
+											const uint32_t ad = (uint32_t)(dd_ < 0 ? -dd_ : dd_), sq = ad*ad;       // |d| <= 65535
+											if (c == 0u) ec0 += (unsigned long long)sq*wa;
+											else if (c == 1u) ec1 += (unsigned long long)sq*wa;
+											else if (c == 2u) ec2 += (unsigned long long)sq*wa;
+											else ec3 += (unsigned long long)sq;
 										}
 									}
-									const uint32_t wa = ((aflags & ASTC_FLAG_ALPHA_WEIGHT) && !(hdrf & 2u)) ? (x23 >> 16) : 255u;
-									e64 += ergb*wa + ea*255ull;
 								}
+								const unsigned long long e64 = ec0*(unsigned long long)cw[0] + ec1*(unsigned long long)cw[1] + ec2*(unsigned long long)cw[2]
+									+ ec3*(unsigned long long)cw[3]*255ull;
 								err = e64;
 								r_cem = sel_nv == 4u ? 7u : (has_alpha ? ((hdrf & 2u) ? 15u : 14u) : 11u);
 								r_lv = sel_lv;
@@ -2365,7 +2440,7 @@ static size_t astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality, 
 	off += ngrids*n*8u; off = (off + 15u) & ~15u;
 	off += ngrids*h->den_stride*4u;
 	off += (ngrids*4u + 15u) & ~15u;
-	off += (hdr ? 3u : 2u)*17u*256u + 2016u;
+	off += (hdr ? 6u : 2u)*17u*256u + 2016u;
 	(void)wcached;
 	const uint32_t slot_bytes = ((10u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
 	const uint32_t wave_bytes = ((((h->col_rows + 1u)/2u)*256u + 15u) & ~15u) + (quality <= 3u ? 2u : 1u)*slot_bytes;

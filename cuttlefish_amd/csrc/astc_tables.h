@@ -439,7 +439,7 @@ inline std::vector<uint8_t> build_blob(int bw, int bh)
 		h.off_mask[t] = (uint32_t)off; off = align16(off + masks[t].size()*8);
 		h.off_ids[t] = (uint32_t)off; off = align16(off + ids[t].size());
 	}
-	h.off_ctab = (uint32_t)off; off = align16(off + 3*17*256);
+	h.off_ctab = (uint32_t)off; off = align16(off + 6*17*256);
 	h.off_wtab = (uint32_t)off; off = align16(off + 12*32 + 2*12*68);
 	h.off_clevel = (uint32_t)off; off = align16(off + 10*132);
 	h.off_ise = (uint32_t)off; off = align16(off + 256 + 128 + 12*4 + 17*4);
@@ -478,15 +478,22 @@ inline std::vector<uint8_t> build_blob(int bw, int bh)
 				}
 				near[r*256 + w] = (uint8_t)best;
 			}
-			// HDR endpoint modes (requant_keep): index of the largest stored value <= w
-			uint8_t* floor_ = near + 17*256;
+			// HDR endpoint modes (requant_keep): per value w one word = the nearest stored value (index, value) and
+			// the first stored value on the other side of w (index << 16, value << 24): the smallest >= w when the
+			// nearest lies below w, the largest <= w when it lies above, the nearest itself when it is w
+			uint32_t* req = reinterpret_cast<uint32_t*>(near + 17*256);
 			for (int w = 0; w < 256; ++w) {
-				int best = 0, bu = -1;
-				for (int v = 0; v < CQ[r].levels; ++v) {
-					const int u = unq[r*256 + v];
-					if (u <= w && u > bu) { bu = u; best = v; }
+				const int qn = near[r*256 + w], un = unq[r*256 + qn];
+				int qo = qn, uo = un;
+				if (un != w) {
+					int bu = un < w ? 1000 : -1;
+					for (int v = 0; v < CQ[r].levels; ++v) {
+						const int u = unq[r*256 + v];
+						if (un < w ? (u >= w && u < bu) : (u <= w && u > bu)) { bu = u; qo = v; }
+					}
+					uo = bu;
 				}
-				floor_[r*256 + w] = (uint8_t)best;
+				req[r*256 + w] = (uint32_t)qn | ((uint32_t)un << 8) | ((uint32_t)qo << 16) | ((uint32_t)uo << 24);
 			}
 		}
 		uint8_t* wunq = blob.data() + h.off_wtab;

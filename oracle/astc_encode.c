@@ -875,9 +875,9 @@ static void hdr_phase_b(const astc_blk* b, const astc_pc* pc, const astc_cfg* cf
 				int64_t det = cnt[st]*C[st] - S[st]*S[st], U = 64*Ts[p][c] - V[p][c];
 				fA[c] = (double)A[st]; fB[c] = (double)B[st]; fC[c] = (double)C[st];
 				if (det > 0) {
-					double den = (double)(64*det);
-					r0[c] = (double)(C[st]*U - B[st]*V[p][c])/den;
-					r1[c] = (double)(A[st]*V[p][c] - B[st]*U)/den;
+					const double inv = 1.0/(double)(64*det);     /* one reciprocal per set (kernel: hoisted) */
+					r0[c] = (double)(C[st]*U - B[st]*V[p][c])*inv;
+					r1[c] = (double)(A[st]*V[p][c] - B[st]*U)*inv;
 				} else {
 					r0[c] = r1[c] = cnt[st] ? (double)Ts[p][c]/(double)cnt[st] : 0.0;
 				}

@@ -415,3 +415,9 @@ def test_mode_7_placement_round_trips_through_the_decoder():
             assert abs((e1[0] >> 4) - hi[0]) <= half
             for c in (1, 2):
                 assert abs((e1[c] >> 4) - hi[c]) <= 2*half, (m, hi, list(v), e1)
+
+
+def test_requant_keep_closed_form_equals_the_scan():
+    """The kernel's requant_keep (nearest value if it keeps the bits, else the first stored value on the other
+    side: floor table / its mirror image) against the oracle's outward scan: every level, value and mask."""
+    assert O.lib().cfo_astc_requant_closed_form_mismatches() == 0
