@@ -1597,7 +1597,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					key[m] = 0xFFFFFFFFu;
 					if (k < ncfg) {
 						const AstcCfgRec c = list[k];
-						const unsigned long long wn = (unsigned long long)S.edec[c.grid]*40ull + (unsigned long long)(n*c.wq16);
+						const unsigned long long wn = (unsigned long long)S.edec[c.grid]*(HDR ? 40ull : 160ull) + (unsigned long long)(n*c.wq16);
 						const unsigned long long est = (((span2*wn) >> 12) + (unsigned long long)(n*nc)*c.cq16) >> 8;
 						key[m] = ((est > 0x3FFFFFEull ? 0x3FFFFFEu : (uint32_t)est) << 6) | k;
 					}

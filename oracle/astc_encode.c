@@ -431,7 +431,11 @@ static int grid_decimation_error(const astc_blk* b, int g)
 }
 
 /* the K configs of a candidate's class with the smallest estimated error
- *   span^2 (2.5 decimation + weight quantisation noise) / 4096 + colour quantisation noise,
+ *   span^2 (10 decimation + weight quantisation noise) / 4096 + colour quantisation noise
+ * (round 4: the decimation term weighs four times what it did -- the measured decimation error is that of
+ * candidate 0's ideal weights, and a grid that loses there loses more once the weights are quantised as well:
+ * 8x8 / 10x10 / 12x12 Normal +0.37 / +0.20 / +0.18 dB on the photo image, smooth content +0.44 / +0.30 / +0.43,
+ * 4x4 .. 6x6 within +-0.1; the HDR profiles keep 2.5: there the colour values decide, 6x6 loses 2.4 dB with 10),
  * in (estimate, list index) order (lane = config, K group-min steps) */
 static int rank_configs(const astc_blk* b, int j, const astc_pc* pc, int K, int* order)
 {
@@ -443,7 +447,7 @@ static int rank_configs(const astc_blk* b, int j, const astc_pc* pc, int K, int*
 	uint32_t key[ASTC_MAX_CFG];
 	for (int k = 0; k < ncfg; ++k) {
 		const astc_cfg* c = &f->cfg[pc->cls][b->has_alpha][k];
-		uint64_t wn = (uint64_t)b->edec[c->grid]*40u + (uint64_t)b->n*c->wq16;
+		uint64_t wn = (uint64_t)b->edec[c->grid]*(b->hdr ? 40u : 160u) + (uint64_t)b->n*c->wq16;
 		uint64_t est = (((span2*wn) >> 12) + (uint64_t)(b->n*b->nc)*c->cq16) >> 8;
 		key[k] = ((est > 0x3FFFFFEull ? 0x3FFFFFEu : (uint32_t)est) << 6) | (uint32_t)k;
 	}
