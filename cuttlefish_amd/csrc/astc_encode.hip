@@ -1243,7 +1243,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				}
 			}
 			// lane = table entry: mismatch = n - best label-permuted overlap
-			const uint32_t np = H->npart[P - 2u] < lad.limit ? H->npart[P - 2u] : lad.limit;
+			// (Normal on footprints of 64 texels and more ranks 256 seeds: oracle encode_core)
+			const uint32_t limit = (lad.limit == 64u && n >= 64u) ? 256u : lad.limit;
+			const uint32_t np = H->npart[P - 2u] < limit ? H->npart[P - 2u] : limit;
 			const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(blob + H->off_mask[P - 2u]);
 			// up to 256 entries: 4 per lane of a 64-lane group, 8 per lane when two blocks share the wave
 			uint32_t keys[8];

@@ -1746,7 +1746,10 @@ static void encode_core(const int px[][4], const int lns[][4], int bw, int bh, i
 		int want = P == 2 ? lad->j2 : (P == 3 ? lad->j3 : lad->j4);
 		if (!want)
 			continue;
-		int got = shortlist(b, P, lad->limit, want, axis, mean, tmin, tmax, sl);
+		/* Normal on the footprints of 64 texels and more ranks 256 seeds, not 64: +0.2 dB there (8x8 .. 12x12 on
+		 * the photo images), nothing on the smaller ones */
+		const int limit = (lad->limit == 64 && n >= 64) ? 256 : lad->limit;
+		int got = shortlist(b, P, limit, want, axis, mean, tmin, tmax, sl);
 		got_p[P] = got;
 		for (int k = 0; k < got; ++k)
 			pcs[npc++] = (astc_pc){P, 0, 0, P, sl[k]};
