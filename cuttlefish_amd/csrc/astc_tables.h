@@ -318,8 +318,8 @@ inline std::vector<uint8_t> build_blob(int bw, int bh)
 					for (int wq = 0; wq < 12; ++wq) {
 						const int nw = N*M*(dual ? 2 : 1);
 						// a lane's LDS column holds the grid (planes interleaved) plus the rows the unmasked
-						// neighbour accesses of the last grid point reach: 64 rows
-						if (nw > 64 || nw + (dual ? 2 : 1)*(N + 2) > 64)
+						// neighbour accesses of the last grid point reach: 76 rows (round 4; 64 before: no 8x8 grid)
+						if (nw > 64 || nw + (dual ? 2 : 1)*(N + 2) > 76)
 							continue;
 						const int wbits = ise_bits(nw, WQ[wq]);
 						if (wbits < 24 || wbits > 96 || block_mode(N, M, wq, dual) < 0)
@@ -353,6 +353,16 @@ inline std::vector<uint8_t> build_blob(int bw, int bh)
 							std::rotate(all.begin() + (long)placed, all.begin() + (long)i, all.begin() + (long)i + 1);
 							++placed;
 							break;
+						}
+				}
+				// a footprint in the fixed order (no census list): its finest grids (56 weights and more) are
+				// listed from place 48 on, at most 8 of them (oracle: build_configs, ASTC_FINE_AT / ASTC_FINE_MAX)
+				if (!rk[0] && !dual) {
+					size_t at = 48;
+					for (size_t i = 48; i < all.size() && at < 48 + 8; ++i)
+						if (all[i].N*all[i].M >= 56) {
+							std::rotate(all.begin() + (long)at, all.begin() + (long)i, all.begin() + (long)i + 1);
+							++at;
 						}
 				}
 			}

@@ -69,6 +69,13 @@ def main():
                     help="footprints that keep the fixed noise-model order (empty lists): on held-out content\n"
                          "(bench tile crops, not in the census) their census lists scored 0.4-1.2 dB lower --\n"
                          "24 grids cover only 55-75 %% of the winning configs of the large footprints")
+    ap.add_argument("--keep", default="6x6,12x12",
+                    help="footprints whose rows are taken over from the existing oracle/astc_cfg_rank.h (round 3's census,\n"
+                         "which saw the 200 best-scored configs per class).  12x12: on held-out images round 3's list beats\n"
+                         "both the full census of round 4 (photo -0.1, alpha-carrying -0.7 dB) and the fixed order\n"
+                         "(gradients -0.9 dB).  6x6: the full census adds the two-plane 6x5 / 5x6 grids (+0.2 dB on the\n"
+                         "photo image) and a wave then waits for the lane with the 60-weight column: 6x6 Normal 2.49 ->\n"
+                         "2.73 ms -- BASELINE config 3 is quoted on 6x6, its list stays")
     args = ap.parse_args()
     L = O.lib()
     L.cfo_astc_census_image.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -110,6 +117,16 @@ def main():
     for name in [x for x in args.static_for.split(",") if x]:
         bw, bh = [int(v) for v in name.split("x")]
         table[FP.index((bw, bh))] = 0
+    keep = [x for x in args.keep.split(",") if x]
+    if keep:
+        import re
+        rows = re.findall(r"\{([0-9, ]+)\},", open(os.path.join(ROOT, "oracle", "astc_cfg_rank.h")).read())
+        assert len(rows) == 140
+        for name in keep:
+            bw, bh = [int(v) for v in name.split("x")]
+            fi = FP.index((bw, bh))
+            for k in range(10):
+                table[fi, k] = [int(v) for v in rows[fi*10 + k].split(",")]
     lines = ["/* astc_cfg_rank.h -- GENERATED by tools/astc_rank_configs.py (do not edit): per footprint and",
              " * candidate class x alpha, the weight-grid configs (N | M << 4 | weight range << 8) ranked by how",
              " * often each was the best of ALL legal configs in a census of synthetic content; 0 ends a list",
