@@ -175,12 +175,14 @@ def test_etc_ladders_against_the_true_optimum_of_every_mode():
 
 def test_astc_ladder_against_the_wide_search():
     """cfo_astc_wide_search (LDR): one partition, a second weight plane on every component, every canonical seed of
-    the 2 / 3 / 4-partition tables, every legal block mode of the class, every endpoint-mode family forced and
-    measured exactly, the best triples iterated (weights re-projected on the decoded endpoints).  The block it
-    writes decodes (through the decoder pinned to Mesa's) to the error it claims, nothing the ladder emits beats
-    it, and the gap of High stays inside what round 4 measured (profiles/r04_quality_tables.md: 6x6 High 0.36 /
-    0.45 dB on 512 opaque / alpha-carrying blocks, 4x4 0.40 / 0.47, 8x8 1.6 / 1.9 -- the deep config lists and the
-    partition seeds of the large footprints are where the ladder leaves most: DESIGN section 7)."""
+    the 2 / 3 / 4-partition tables, EVERY legal block mode of the class (the census tables: no cut at the 200
+    best-scored, no kernel column limit), every endpoint-mode family forced and measured exactly, the best triples
+    iterated (weights re-projected on the decoded endpoints); the better of a run over the census tables and one
+    over the encoder's own lists.  The block it writes decodes (through the decoder pinned to Mesa's) to the error
+    it claims, nothing the ladder emits beats it, and the gap of High stays inside what round 4 measured
+    (profiles/r04_quality_tables.md: 6x6 High 0.54 / 0.46 dB on 512 opaque / alpha-carrying blocks, 4x4 0.36 /
+    0.46, 8x8 1.09 / 0.77 -- the weights <-> endpoints iteration and the partition seeds of the large footprints
+    are where the ladder leaves most: DESIGN section 7)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location(
         "quality_tables", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "quality_tables.py"))
@@ -192,3 +194,22 @@ def test_astc_ladder_against_the_wide_search():
         assert wide - ps[3] <= 0.60, (alpha, ps, wide)
     ps, wide = qt.astc_gap(48, np.random.default_rng(5), 4, 4, False)
     assert wide >= max(ps) - 1e-9 and wide - ps[3] <= 0.60, (ps, wide)
+    # the full-resolution grid: a two-colour 8x8 block with a ragged edge is what the 8x8 x 2-level config is for;
+    # the encoder lists it since round 4 (76-row lane column) and must come close to the bound on such a block
+    rng = np.random.default_rng(6)
+    mask = rng.random((8, 8)) < 0.5
+    blk = np.where(mask[..., None], np.array([230, 40, 30, 255], np.uint8), np.array([20, 60, 200, 255], np.uint8))
+    blk = np.ascontiguousarray(blk.astype(np.uint8))
+    import ctypes
+    import oracle_lib as O
+    from cuttlefish_amd import Format
+    L = O.lib()
+    L.cfo_astc_wide_search.restype = ctypes.c_uint64
+    L.cfo_astc_wide_search.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    out = np.zeros(16, np.uint8)
+    L.cfo_astc_wide_search(blk.ctypes.data, 8, 8, 0, out.ctypes.data)
+    dec_w, _ = O.decode_astc(out, int(Format.ASTC_8x8), 8, 8)
+    dec_e, _ = O.decode_astc(O.encode(blk, int(Format.ASTC_8x8), quality=2, threads=1), int(Format.ASTC_8x8), 8, 8)
+    ew = float(((dec_w.astype(np.int64) - blk)[..., :3]**2).sum())
+    ee = float(((dec_e.astype(np.int64) - blk)[..., :3]**2).sum())
+    assert ew <= 64*3*4 and ee <= 64*3*4, (ew, ee)      # both within +-2 per channel on average: the exact grid
