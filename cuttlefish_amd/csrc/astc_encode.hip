@@ -782,6 +782,44 @@ __device__ __forceinline__ void hdr_scale_unpack(const int (&v)[6], int (&e0)[3]
 	e1[0] = (red < 0 ? 0 : red) << 4; e1[1] = (green < 0 ? 0 : green) << 4; e1[2] = (blue < 0 ? 0 : blue) << 4;
 }
 
+// HDR luminance (modes 2 and 3): two values for a grey 12-bit pair E0 <= E1; form 0 / 1 = mode 2 (stored order /
+// swapped with the half-step shift), form 2 / 3 = mode 3 (11- or 10-bit low end + 4- or 5-bit offset).  false: the
+// form cannot hold the pair (oracle: hdr_lum_place)
+__device__ __forceinline__ bool hdr_lum_place(int form, int E0, int E1, int (&v)[6], int (&hm)[6])
+{
+	v[2] = v[3] = v[4] = v[5] = 0; hm[2] = hm[3] = hm[4] = hm[5] = 0;
+	if (form < 2) {
+		const int a = clampi(rs_u(form ? E0 - 8 : E0, 4), 0, 255), b = clampi(rs_u(form ? E1 + 8 : E1, 4), 0, 255);
+		v[0] = form ? b : a; v[1] = form ? a : b;
+		hm[0] = hm[1] = 0;
+		return form ? v[1] < v[0] : v[1] >= v[0];
+	}
+	const bool fine = form == 2;
+	const int sh = fine ? 1 : 2, db = fine ? 4 : 5;
+	const int yq = clampi(rs_u(E0, sh), 0, (1 << (12 - sh)) - 1), du = rs_u(E1 - (yq << sh), sh);
+	const int d = clampi(du, 0, (1 << db) - 1);
+	v[0] = (fine ? 0 : 0x80) | (yq & 0x7F);
+	v[1] = ((yq >> 7) << db) | d;
+	hm[0] = 0x80; hm[1] = 0xFF & ~((1 << db) - 1);
+	return E1 >= (yq << sh) && du <= (1 << db) - 1;
+}
+
+// what a mode 2 / mode 3 value pair decodes to (oracle/astc_decode.c cases 2 and 3; 16-bit LNS, all channels alike)
+__device__ __forceinline__ void hdr_lum_unpack(bool mode3, int v0, int v1, int& y0o, int& y1o)
+{
+	int y0, y1;
+	if (!mode3) {
+		if (v1 >= v0) { y0 = v0 << 4; y1 = v1 << 4; }
+		else { y0 = (v1 << 4) + 8; y1 = (v0 << 4) - 8; }
+	} else {
+		int d;
+		if (v0 & 0x80) { y0 = ((v1 & 0xE0) << 4) | ((v0 & 0x7F) << 2); d = (v1 & 0x1F) << 2; }
+		else { y0 = ((v1 & 0xF0) << 4) | ((v0 & 0x7F) << 1); d = (v1 & 0x0F) << 1; }
+		y1 = y0 + d > 0xFFF ? 0xFFF : y0 + d;
+	}
+	y0o = y0 << 4; y1o = y1 << 4;
+}
+
 // mode 15 alpha pair: selector 3 = two 7-bit values, 0..2 = base (8 + s bits) + signed offset (6 - s bits)
 __device__ __forceinline__ void hdr_alpha_place(int sel, int A0, int A1, double r0, double r1, int& v6, int& v7, int& hm6, int& hm7)
 {
@@ -1684,6 +1722,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							struct SetAccH { uint32_t cnt, S, C, V0, V1, V2, V3, T0, T1, T2, T3; };
 							SetAccH q0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;
 							const bool any3 = __ballot(P > 2u) != 0ull, any4 = __ballot(P > 3u) != 0ull;
+							uint32_t not_grey = 0u;      // R == G == B on every texel's 16-bit values: the luminance modes can hold the block
 							// four texels per step (as the LDR sums below): weights as bytes of one word, the 16-bit texels
 							// as eight byte planes (low and high byte of each channel), a set's members as a byte mask --
 							// S, C, V_c = sum w l_c and T_c = sum l_c by v_dot4_u32_u8, the high plane shifted in
@@ -1711,6 +1750,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 								const uint32_t z01 = __builtin_amdgcn_perm(b1, b0, 0x07030602u), z23 = __builtin_amdgcn_perm(b3, b2, 0x07030602u);
 								const uint32_t BL = __builtin_amdgcn_perm(y23, y01, 0x05040100u), BH = __builtin_amdgcn_perm(y23, y01, 0x07060302u);
 								const uint32_t AL = __builtin_amdgcn_perm(z23, z01, 0x05040100u), AH = __builtin_amdgcn_perm(z23, z01, 0x07060302u);
+								not_grey |= (RL ^ GL) | (RH ^ GH) | (RL ^ BL) | (RH ^ BH);      // (texels past the footprint repeat the last one)
 								const uint32_t pw = byp ? 0u : *reinterpret_cast<const uint32_t*>(prow + i);      // subset ids 0..3
 #define ASTC_ACCH(Q, ST, W) { \
 								const uint32_t x_ = pw ^ (ST*0x01010101u); \
@@ -1739,8 +1779,13 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							const uint32_t nv0 = has_alpha ? 8u : 6u;
 							const int lv0 = nv0*P <= 18u ? (int)clevel[(nv0*P/2u)*132u + cfg.cbits] : -1;
 							const int lv1 = (!has_alpha && 4u*P <= 18u) ? (int)clevel[(4u*P/2u)*132u + cfg.cbits] : -1;
-							bool ok0 = lv0 >= 0, ok1 = lv1 >= 0;
-							double tot0 = 0.0, tot1 = 0.0;
+							// option 2: the HDR luminance modes 2 / 3 (two values) for an opaque grey block, one partition, one plane
+							const bool lum = !has_alpha && P == 1u && !dual && not_grey == 0u;
+							const bool opt2_any = __ballot(lum) != 0ull;
+							const int lv2 = lum ? (int)clevel[1u*132u + cfg.cbits] : -1;
+							bool ok0 = lv0 >= 0, ok1 = lv1 >= 0, ok2 = lv2 >= 0;
+							double tot0 = 0.0, tot1 = 0.0, tot2 = 0.0;
+							uint32_t cv2 = 0u;                 // option 2: v0 | v1 << 8 | (mode 3) << 16
 							uint32_t cv0[5] = {0, 0, 0, 0, 0}, cv1[4] = {0, 0, 0, 0};       // option 1: four values = one word per partition
 #pragma unroll 1
 							for (uint32_t p = 0; p < ((CF_ASTC_ABLATE & 8192) ? 1u : P); ++p) {
@@ -1791,6 +1836,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 										Dd = Dd + (double)det;
 									}
 								}
+								const int E1lum = E1[0];      // (option 1 overwrites E1 with its constrained fit)
 								// mode 7's constrained fit (low = high - s on every channel): s = 64 N / D, then
 								// e1_c = (T_c + s (64 cnt - S)/64) / cnt; 12-bit high endpoint and scale, packed
 								unsigned long long m7 = 0ull;
@@ -1811,12 +1857,13 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 									m7 |= (unsigned long long)clampi((int)floor(s16*(1.0/16.0) + 0.5), 0, 4095) << 36;
 								}
 #pragma unroll 1
-								for (uint32_t opt = 0; opt < 2u; ++opt) {
-									if (opt ? !opt1_any : !opt0_any)
+								for (uint32_t opt = 0; opt < 3u; ++opt) {
+									if (opt == 0u ? !opt0_any : (opt == 1u ? !opt1_any : !opt2_any))
 										continue;
-									const uint32_t lv = opt ? (lv1 >= 0 ? (uint32_t)lv1 : 0u) : (lv0 >= 0 ? (uint32_t)lv0 : 0u);
+									const int lvs = opt == 0u ? lv0 : (opt == 1u ? lv1 : lv2);
+									const uint32_t lv = lvs >= 0 ? (uint32_t)lvs : 0u;
 									const int S12 = (int)(m7 >> 36);
-									if (opt) {
+									if (opt == 1u) {
 										E1[0] = (int)(m7 & 0xFFFull); E1[1] = (int)((m7 >> 12) & 0xFFFull); E1[2] = (int)((m7 >> 24) & 0xFFFull);
 									}
 									// mode 11: the direct form and the two finest sub-modes that hold the pair; mode 7: the two
@@ -1824,18 +1871,22 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 									double best = 1.0e300;
 									uint32_t bq_lo = 0, bq_hi = 0;
 									bool got = false;
-									uint32_t nl;
-									const uint32_t list = (CF_ASTC_ABLATE & 2048) ? (nl = 3u, opt ? 0x531u : 0x780u) : hdr_form_list(opt, E0, E1, S12, nl);
-									const int nq = opt ? 4 : 6;
+									uint32_t nl = 4u;
+									const uint32_t list = opt == 2u ? 0x3210u : ((CF_ASTC_ABLATE & 2048) ? (nl = 3u, opt ? 0x531u : 0x780u) : hdr_form_list(opt, E0, E1, S12, nl));
+									const int nq = opt == 2u ? 2 : (opt ? 4 : 6);
+									uint32_t bform = 0u;
 #pragma unroll 1
-									for (uint32_t t = 0; t < ((CF_ASTC_ABLATE & 512) ? 1u : 3u); ++t) {
+									for (uint32_t t = 0; t < ((CF_ASTC_ABLATE & 512) ? 1u : (opt == 2u ? 4u : 3u)); ++t) {
 										const int k = (int)((list >> (4u*t)) & 15u);
 										int v[6], hm[6], q6[6];
-										if (opt)
+										bool holds = true;
+										if (opt == 2u)
+											holds = hdr_lum_place(k, E0[0], E1lum, v, hm);
+										else if (opt)
 											hdr_scale_place(k, E1, S12, v, hm);
 										else
 											hdr_rgb_place(k, E0, E1, r0, r1, v, hm);
-										bool ok = t < nl;
+										bool ok = t < nl && holds;
 #pragma unroll
 										for (int i = 0; i < 6; ++i) {
 											int u = 0;
@@ -1845,7 +1896,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 										}
 										if (ok) {
 											int d0[3], d1[3];
-											if (opt)
+											if (opt == 2u) {
+												hdr_lum_unpack(k >= 2, v[0], v[1], d0[0], d1[0]);
+												d0[1] = d0[2] = d0[0]; d1[1] = d1[2] = d1[0];
+											} else if (opt)
 												hdr_scale_unpack(v, d0, d1);
 											else
 												hdr_rgb_unpack(v, d0, d1);
@@ -1862,8 +1916,15 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 												got = true;
 												bq_lo = (uint32_t)q6[0] | ((uint32_t)q6[1] << 8) | ((uint32_t)q6[2] << 16) | ((uint32_t)q6[3] << 24);
 												bq_hi = (uint32_t)q6[4] | ((uint32_t)q6[5] << 8);
+												bform = (uint32_t)k;
 											}
 										}
+									}
+									if (opt == 2u) {
+										ok2 = ok2 && got;
+										tot2 = tot2 + (got ? best : 0.0);
+										cv2 = (bq_lo & 0xFFFFu) | (bform >= 2u ? 0x10000u : 0u);
+										continue;
 									}
 									if (opt) {
 										ok1 = ok1 && got;
@@ -1923,15 +1984,20 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 #undef YB
 #undef YC
 							uint32_t sel_nv = 0u, sel_lv = 0u;
+							bool sel_mode3 = false;
 							{
+								// (the oracle's walk: an option replaces the best so far when it is strictly cheaper)
 								const bool take1 = ok1 && (!ok0 || tot1 < tot0);
-								if (ok0 || ok1) {
-									sel_nv = take1 ? 4u : nv0;
-									sel_lv = (uint32_t)(take1 ? lv1 : lv0);
+								const double tot01 = take1 ? tot1 : tot0;
+								const bool take2 = ok2 && (!(ok0 || ok1) || tot2 < tot01);
+								if (ok0 || ok1 || ok2) {
+									sel_nv = take2 ? 2u : (take1 ? 4u : nv0);
+									sel_lv = (uint32_t)(take2 ? lv2 : (take1 ? lv1 : lv0));
+									sel_mode3 = take2 && (cv2 & 0x10000u) != 0u;
 #pragma unroll
 									for (uint32_t wd = 0; wd < 4u; ++wd)
-										r_cv[wd] = take1 ? cv1[wd] : cv0[wd];
-									r_cv[4] = take1 ? 0u : cv0[4];
+										r_cv[wd] = take2 ? (wd == 0u ? (cv2 & 0xFFFFu) : 0u) : (take1 ? cv1[wd] : cv0[wd]);
+									r_cv[4] = (take1 || take2) ? 0u : cv0[4];
 								}
 							}
 #undef HSEL4
@@ -1953,7 +2019,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 #pragma unroll
 									for (int i = 0; i < 6; ++i)
 										v[i] = (int)sh.cunq[sel_lv*256u + (uint32_t)((vv >> (8*i)) & 0xFFull)];
-									if (sel_nv == 4u)
+									if (sel_nv == 2u) {
+										hdr_lum_unpack(sel_mode3, v[0], v[1], d0[0], d1[0]);
+										d0[1] = d0[2] = d0[0]; d1[1] = d1[2] = d1[0];
+									} else if (sel_nv == 4u)
 										hdr_scale_unpack(v, d0, d1);
 									else
 										hdr_rgb_unpack(v, d0, d1);
@@ -2015,7 +2084,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 								const unsigned long long e64 = ec0*(unsigned long long)cw[0] + ec1*(unsigned long long)cw[1] + ec2*(unsigned long long)cw[2]
 									+ ec3*(unsigned long long)cw[3]*255ull;
 								err = e64;
-								r_cem = sel_nv == 4u ? 7u : (has_alpha ? ((hdrf & 2u) ? 15u : 14u) : 11u);
+								r_cem = sel_nv == 2u ? (sel_mode3 ? 3u : 2u) : (sel_nv == 4u ? 7u : (has_alpha ? ((hdrf & 2u) ? 15u : 14u) : 11u));
 								r_lv = sel_lv;
 								r_ncv = sel_nv*P;
 							}

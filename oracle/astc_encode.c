@@ -279,6 +279,7 @@ typedef struct {
 	int px[ASTC_MAX_TEXELS][4];
 	int lns[ASTC_MAX_TEXELS][4];        /* HDR profile: the texels' 16-bit LNS values (LDR alpha: 0..255) */
 	int have_lns;
+	int lns_grey;                       /* HDR: R == G == B on every texel's 16-bit values (modes 2 / 3 can hold it) */
 	int cw[4];                          /* channel weights of the error metric */
 	int wa[ASTC_MAX_TEXELS];            /* texel weight of the RGB error (alpha or 255) */
 	/* phase A results per (candidate, subset-or-plane) */
@@ -801,6 +802,37 @@ void cfo_astc_hdr_scale_place(int m, const int E1[3], int S12, int v[4], int him
 }
 
 /* mode 15 alpha pair: selector 3 = two 7-bit values, 0..2 = base (8 + s bits) + signed offset (6 - s bits) */
+/* HDR luminance (modes 2 and 3): two values for a grey pair E0 <= E1 (12 bits).  Form 0 / 1 = mode 2 (8 bits per
+ * end: y = v << 4 in stored order, or shifted by half a step when the values are stored swapped), form 2 / 3 =
+ * mode 3 (an 11- or 10-bit low end and a 4- or 5-bit offset).  Returns 0 when the form cannot hold the pair.
+ * The inverse of astc_decode.c's cases 2 and 3. */
+static int hdr_lum_place(int form, int E0, int E1, int v[2], int himask[2])
+{
+	if (form == 0) {
+		v[0] = clampi(rs_u(E0, 4), 0, 255); v[1] = clampi(rs_u(E1, 4), 0, 255);
+		himask[0] = himask[1] = 0;
+		return v[1] >= v[0];
+	}
+	if (form == 1) {
+		v[1] = clampi(rs_u(E0 - 8, 4), 0, 255); v[0] = clampi(rs_u(E1 + 8, 4), 0, 255);
+		himask[0] = himask[1] = 0;
+		return v[1] < v[0];
+	}
+	const int fine = form == 2, sh = fine ? 1 : 2, db = fine ? 4 : 5;
+	const int yq = clampi(rs_u(E0, sh), 0, (1 << (12 - sh)) - 1), du = rs_u(E1 - (yq << sh), sh);
+	const int d = clampi(du, 0, (1 << db) - 1);
+	v[0] = (fine ? 0 : 0x80) | (yq & 0x7F);
+	v[1] = ((yq >> 7) << db) | d;
+	himask[0] = 0x80; himask[1] = 0xFF & ~((1 << db) - 1);
+	return E1 >= (yq << sh) && du <= (1 << db) - 1;
+}
+
+/* test hook */
+int cfo_astc_hdr_lum_place(int form, int E0, int E1, int v[2], int himask[2])
+{
+	return hdr_lum_place(form, E0, E1, v, himask);
+}
+
 static void hdr_alpha_place(int sel, int A0, int A1, double r0, double r1, int v[2], int himask[2])
 {
 	if (sel == 3) {
@@ -879,8 +911,12 @@ static void hdr_phase_b(const astc_blk* b, const astc_pc* pc, const astc_cfg* cf
 	int D0[4][4], D1[4][4];                  /* decoded endpoints: HDR channels 16-bit LNS, LDR alpha 0..255 */
 	double best_total = 1.0e300;
 	int best_opt = -1, best_lv = 0, best_nv = 0;
-	for (int opt = 0; opt < (b->has_alpha ? 1 : 2); ++opt) {
-		const int nv = opt ? 4 : (b->has_alpha ? 8 : 6);
+	/* option 2 (round 4): the HDR luminance modes 2 / 3 -- two values -- for an opaque block whose texels are grey
+	 * on the 16-bit values, one partition, one plane */
+	const int nopt = b->has_alpha ? 1 : ((b->lns_grey && P == 1 && !pc->dual) ? 3 : 2);
+	int best_cem2 = 2;
+	for (int opt = 0; opt < nopt; ++opt) {
+		const int nv = opt == 2 ? 2 : (opt ? 4 : (b->has_alpha ? 8 : 6));
 		if (nv*P > 18)
 			continue;
 		const int lv = T->c_level[nv*P/2][cfg->cbits];
@@ -937,6 +973,32 @@ static void hdr_phase_b(const astc_blk* b, const astc_pc* pc, const astc_cfg* cf
 						for (int i = 0; i < 6; ++i)
 							vals[i] = (uint8_t)q[i];
 						for (int c = 0; c < 3; ++c) { tD0[p][c] = d0[c]; tD1[p][c] = d1[c]; }
+					}
+				}
+			} else if (opt == 2) {
+				for (int form = 0; form < 4; ++form) {
+					int v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hm[2], q[2], ok = 1;
+					if (!hdr_lum_place(form, E0[0], E1[0], v, hm))
+						continue;
+					for (int i = 0; i < 2 && ok; ++i) {
+						q[i] = requant_keep(T, lv, v[i], hm[i]);
+						if (q[i] < 0) ok = 0;
+						else v[i] = T->c_unq[lv][q[i]];
+					}
+					if (!ok)
+						continue;
+					int d0[4], d1[4];
+					cfo_astc_unpack_endpoints(form < 2 ? 2 : 3, v, d0, d1);
+					double est = 0.0;
+					for (int c = 0; c < 3; ++c)
+						est = est + (double)b->cw[c]*quad_est_d(fA[c], fB[c], fC[c], (double)d0[c] - r0[c], (double)d1[c] - r1[c]);
+					est = est > 0.0 ? est : 0.0;
+					if (est < best) {
+						best = est;
+						got = 1;
+						vals[0] = (uint8_t)q[0]; vals[1] = (uint8_t)q[1];
+						for (int c = 0; c < 3; ++c) { tD0[p][c] = d0[c]; tD1[p][c] = d1[c]; }
+						best_cem2 = form < 2 ? 2 : 3;
 					}
 				}
 			} else {
@@ -1059,7 +1121,7 @@ static void hdr_phase_b(const astc_blk* b, const astc_pc* pc, const astc_cfg* cf
 	}
 	L->err = err;
 	L->valid = 1;
-	L->cem = best_opt ? 7 : (b->has_alpha ? (b->hdr_alpha ? 15 : 14) : 11);
+	L->cem = best_opt == 2 ? best_cem2 : (best_opt ? 7 : (b->has_alpha ? (b->hdr_alpha ? 15 : 14) : 11));
 	L->ncv = best_nv*P;
 	L->lv = best_lv;
 }
@@ -1674,8 +1736,14 @@ static void encode_core(const int px[][4], const int lns[][4], int bw, int bh, i
 	int n = bw*bh, solid = 1;
 	memset(out, 0, 16);
 	b->have_lns = lns != NULL;
-	if (lns)
+	b->lns_grey = 0;
+	if (lns) {
 		memcpy(b->lns, lns, (size_t)n*sizeof(b->lns[0]));
+		b->lns_grey = 1;
+		for (int i = 0; i < n; ++i)
+			if (lns[i][0] != lns[i][1] || lns[i][0] != lns[i][2])
+				b->lns_grey = 0;
+	}
 	b->f = f; b->n = n; b->flags = flags; b->has_alpha = 0; b->grey = 1;
 	b->hdr = (flags & ASTC_FLAG_HDR) != 0;
 	b->hdr_alpha = b->hdr && (flags & ASTC_FLAG_HDR_ALPHA) != 0;

@@ -94,3 +94,27 @@ def test_half_float_sources_are_taken_for_astc(gpu_ctx, typ):
             want = O.encode(np.ascontiguousarray(img16), int(fmt), typ=int(typ), quality=q, threads=8, alpha=1)
             assert np.array_equal(got, want), (fmt, q)
             assert np.array_equal(got, gpu_ctx.encode([img32], p)[0]), (fmt, q)
+
+
+@pytest.mark.parametrize("fmt", [Format.ASTC_4x4, Format.ASTC_6x6, Format.ASTC_8x8, Format.ASTC_12x10])
+def test_hdr_grey_blocks_take_the_luminance_modes(gpu_ctx, fmt):
+    """Opaque grey HDR content: the luminance modes 2 / 3 (two values per block) are in the payload beside 7 and
+    11, byte-identical to the oracle at every level, from float and from half sources."""
+    img = synth.hdr_probe(72, 60, seed=9).astype(np.float32)
+    g = img[..., :3].mean(-1).astype(np.float16).astype(np.float32)
+    img[..., 0] = img[..., 1] = img[..., 2] = g
+    img[..., 3] = 1.0
+    img = np.ascontiguousarray(img)
+    seen = set()
+    for q in range(5):
+        want = O.encode(img, int(fmt), typ=int(UF), quality=q, threads=8, alpha=int(Alpha.None_))
+        got = gpu_ctx.encode([img], make_params(fmt, UF, q, alpha=Alpha.None_))[0]
+        assert np.array_equal(want, got), (fmt, q)
+        blocks = np.asarray(got).reshape(-1, 16)
+        mode = blocks[:, 0].astype(np.uint32) | (blocks[:, 1].astype(np.uint32) << 8)
+        single = ((mode >> 11) & 3) == 0
+        notvoid = (mode & 0x1FF) != 0x1FC
+        seen |= set(int(c) for c in ((mode >> 13) & 15)[single & notvoid])
+    assert {2, 3} & seen, seen
+    half = gpu_ctx.encode([img.astype(np.float16)], make_params(fmt, UF, 2, alpha=Alpha.None_))[0]
+    assert np.array_equal(half, gpu_ctx.encode([img], make_params(fmt, UF, 2, alpha=Alpha.None_))[0])

@@ -421,3 +421,51 @@ def test_requant_keep_closed_form_equals_the_scan():
     """The kernel's requant_keep (nearest value if it keeps the bits, else the first stored value on the other
     side: floor table / its mirror image) against the oracle's outward scan: every level, value and mask."""
     assert O.lib().cfo_astc_requant_closed_form_mismatches() == 0
+
+
+def test_luminance_placement_round_trips_and_grey_blocks_use_modes_2_and_3():
+    """hdr_lum_place against the decoder: a grey pair a form can hold decodes to the pair rounded to the form's
+    step (mode 2: 16, or 16 shifted by 8 when stored swapped; mode 3: 2 with a 4-bit offset, 4 with a 5-bit one).
+    A grey opaque HDR image then carries modes 2 and 3 beside 7 and 11, and decodes without an illegal block."""
+    L = O.lib()
+    L.cfo_astc_hdr_lum_place.restype = ctypes.c_int
+    rng = np.random.default_rng(14)
+    I2 = ctypes.c_int*2
+    seen = [0, 0, 0, 0]
+    for _ in range(4000):
+        form = int(rng.integers(0, 4))
+        if form == 0:
+            lo, hi = sorted(int(x) << 4 for x in rng.integers(0, 256, 2))
+        elif form == 1:
+            a, b = sorted(int(x) for x in rng.integers(0, 256, 2))
+            if a == b:
+                continue
+            lo, hi = (a << 4) + 8, (b << 4) - 8
+        elif form == 2:
+            lo = int(rng.integers(0, 2048)) << 1
+            hi = lo + (int(rng.integers(0, 16)) << 1)
+        else:
+            lo = int(rng.integers(0, 1024)) << 2
+            hi = lo + (int(rng.integers(0, 32)) << 2)
+        if hi > 4095:
+            continue
+        v, hm = I2(), I2()
+        ok = L.cfo_astc_hdr_lum_place(form, lo, hi, v, hm)
+        assert ok == 1, (form, lo, hi)
+        kind, e0, e1 = _unpack(2 if form < 2 else 3, list(v))
+        assert e0[:3] == [lo << 4]*3 and e1[:3] == [hi << 4]*3, (form, lo, hi, list(v), e0, e1)
+        seen[form] += 1
+    assert min(seen) > 300
+    # a pair the small-range forms cannot hold is refused, not clamped silently
+    v, hm = I2(), I2()
+    assert L.cfo_astc_hdr_lum_place(2, 100, 200, v, hm) == 0 and L.cfo_astc_hdr_lum_place(3, 100, 400, v, hm) == 0
+    assert L.cfo_astc_hdr_lum_place(0, 300, 100, v, hm) == 0
+    img = synth.hdr_probe(96, 96, seed=4).astype(np.float32)
+    g = img[..., :3].mean(-1).astype(np.float16).astype(np.float32)
+    img[..., 0] = img[..., 1] = img[..., 2] = g
+    img[..., 3] = 1.0
+    for fmt in (Format.ASTC_4x4, Format.ASTC_8x8):
+        pay = O.encode(img, int(fmt), typ=int(Type.UFloat), quality=2, threads=8, alpha=int(Alpha.None_))
+        dec, bad = O.decode_astc_hdr(pay, int(fmt), 96, 96)
+        cem = _cems(pay)
+        assert bad == 0 and {2, 3} <= set(cem[cem >= 0]) <= {2, 3, 7, 11}

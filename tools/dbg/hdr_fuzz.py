@@ -36,6 +36,8 @@ with Context(0) as ctx:
         img = np.where(sp, rng.choice(np.array([-1.0, 0.0, np.nan, np.inf, 1e9, 6e-8, 65504.0, 1.0], np.float32), (h, w, 4)), img)
         if rng.random() < 0.3:
             img[..., 3] = 1.0
+        if rng.random() < 0.2:             # grey: the luminance modes 2 / 3
+            img[..., 1] = img[..., 0]; img[..., 2] = img[..., 0]
         src = img.astype(np.float16) if rng.random() < 0.3 else img
         mask = tuple(bool(rng.random() > 0.15) for _ in range(4))
         src = np.ascontiguousarray(src)
