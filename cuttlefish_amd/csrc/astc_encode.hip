@@ -1161,7 +1161,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		}
 		tmin = cf_group_min_f32(tmin, pair, h);
 		tmax = cf_group_max_f32(tmax, pair, h);
-		uint32_t lowc = 0;
+		uint32_t lowc = 0, lowc2 = 1;
 		{
 			const float Cd[3] = {C.c00, C.c11, C.c22}, Co[3] = {C.c12, C.c02, C.c01};
 			float score[3];
@@ -1176,6 +1176,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			float sbest = score[0];
 			if (score[1] < sbest) { sbest = score[1]; lowc = 1; }
 			if (score[2] < sbest) lowc = 2;
+			// the runner-up (first of the other two on a tie)
+			const uint32_t ca = lowc == 0u ? 1u : 0u, cb2 = lowc == 2u ? 1u : 2u;
+			const float sa = ca == 0u ? score[0] : score[1], sb = cb2 == 1u ? score[1] : score[2];
+			lowc2 = sb < sa ? cb2 : ca;
 		}
 
 		// ---- candidate list (ids as in the oracle) ----
@@ -1190,6 +1194,11 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			} else if (lad.nd >= 2u && !grey) {
 				if (hl == 0u) S.pcs[npc] = pc_make(1, 1, lowc, 1, 0);
 				++npc;
+				// small footprints: a second plane on the runner-up component as well (oracle: encode_core)
+				if (n <= 25u && !HDR) {
+					if (hl == 0u) S.pcs[npc] = pc_make(1, 1, lowc2, 1, 0);
+					++npc;
+				}
 			}
 		}
 		if (lad.nd >= 2u && has_alpha && !grey) {

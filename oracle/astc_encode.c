@@ -1801,7 +1801,7 @@ static void encode_core(const int px[][4], const int lns[][4], int bw, int bh, i
 	}
 	/* channel c's squared correlation with the other two, summed: Co[k] is the covariance of the
 	 * pair that EXCLUDES channel k */
-	int lowc = 0;
+	int lowc = 0, lowc2 = 1;
 	{
 		float score[3];
 		for (int c = 0; c < 3; ++c) {
@@ -1813,6 +1813,10 @@ static void encode_core(const int px[][4], const int lns[][4], int bw, int bh, i
 		}
 		for (int c = 1; c < 3; ++c)
 			if (score[c] < score[lowc]) lowc = c;
+		/* the runner-up (first of the other two on a tie) */
+		lowc2 = lowc == 0 ? 1 : 0;
+		for (int c = lowc2 + 1; c < 3; ++c)
+			if (c != lowc && score[c] < score[lowc2]) lowc2 = c;
 	}
 
 	/* the candidate list, in id order */
@@ -1825,6 +1829,13 @@ static void encode_core(const int px[][4], const int lns[][4], int bw, int bh, i
 	}
 	if (lad->nd >= 2 && b->has_alpha && !b->grey)
 		pcs[npc++] = (astc_pc){1, 1, lowc, 1, 0};
+	/* round 4: on the small footprints (up to 25 texels) an opaque colour block gets a second plane on the
+	 * runner-up component as well: 4x4 photo +0.15 dB, normal-map-like content +1.35, two-colour edges +0.55; 5x5
+	 * +0.09 / +0.35 / +0.4.  Up to High the candidate takes the place of the last three-partition seed.  (6x6 and
+	 * larger: +-0.05 on photo content, not taken; blocks with alpha already carry two such candidates and the
+	 * kernel keeps two second-plane weight rows per pass.) */
+	if (lad->nd >= 2 && !b->has_alpha && !b->grey && n <= 25 && !b->hdr)      /* (HDR walks four candidates: it would lose a seed) */
+		pcs[npc++] = (astc_pc){1, 1, lowc2, 1, 0};
 	int sl[16];
 	const int nb = npc;                     /* candidates before the partitioned ones */
 	int got_p[5] = {0, 0, 0, 0, 0};
