@@ -180,7 +180,7 @@ def test_astc_ladder_against_the_wide_search():
     iterated (weights re-projected on the decoded endpoints); the better of a run over the census tables and one
     over the encoder's own lists.  The block it writes decodes (through the decoder pinned to Mesa's) to the error
     it claims, nothing the ladder emits beats it, and the gap of High stays inside what round 4 measured
-    (profiles/r04_quality_tables.md: 6x6 High 0.54 / 0.46 dB on 512 opaque / alpha-carrying blocks, 4x4 0.36 /
+    (profiles/r04_quality_tables.md: 6x6 High 0.54 / 0.46 dB on 512 opaque / alpha-carrying blocks, 4x4 0.20 /
     0.46, 8x8 1.09 / 0.77 -- the weights <-> endpoints iteration and the partition seeds of the large footprints
     are where the ladder leaves most: DESIGN section 7)."""
     import importlib.util
@@ -193,7 +193,7 @@ def test_astc_ladder_against_the_wide_search():
         assert wide >= max(ps) - 1e-9, (alpha, ps, wide)
         assert wide - ps[3] <= 0.60, (alpha, ps, wide)
     ps, wide = qt.astc_gap(48, np.random.default_rng(5), 4, 4, False)
-    assert wide >= max(ps) - 1e-9 and wide - ps[3] <= 0.60, (ps, wide)
+    assert wide >= max(ps) - 1e-9 and wide - ps[3] <= 0.40, (ps, wide)
     # the full-resolution grid: a two-colour 8x8 block with a ragged edge is what the 8x8 x 2-level config is for;
     # the encoder lists it since round 4 (76-row lane column) and must come close to the bound on such a block
     rng = np.random.default_rng(6)
