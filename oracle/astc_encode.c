@@ -470,9 +470,13 @@ static int rank_configs(const astc_blk* b, int j, const astc_pc* pc, int K, int*
 		 * alpha), where the endpoint values decide more than the grid (round 4, measured on probes of three sizes
 		 * at every footprint: 5x5 .. 8x6 +0.4 .. +1.8 dB at Normal on each of them, 8x8 0 .. +0.5; 4x4 / 5x4 and
 		 * the footprints above 64 texels lose with it on one probe or another and keep 2.5) */
-		const uint32_t ka = b->hdr ? ((b->n >= (b->has_alpha ? 40 : 25) && b->n <= 64) ? 10u : 40u) : 160u;
+		const uint32_t ka = b->hdr ? ((b->n >= (b->has_alpha ? 40 : 25) && b->n <= 64) ? 10u : 40u) : (b->n >= 60 ? 640u : 160u);
+		/* LDR footprints of 60 texels and more: decimation x 4 once more AND the colour noise x 4 (six kinds of
+		 * content, whole images, Normal: 8x8 +0.24 photo / +0.44 smooth / two-colour edges +6 dB, 10x6 +0.3 / +0.3 /
+		 * +5.5, 10x10 and 12x12 +0.15 .. 0.5; the footprints below lose on gradients with it) */
+		const uint32_t kc = (!b->hdr && b->n >= 60) ? 4u : 1u;
 		uint64_t wn = (uint64_t)b->edec[c->grid]*ka + (uint64_t)b->n*c->wq16;
-		uint64_t est = (((span2*wn) >> 12) + (uint64_t)(b->n*b->nc)*c->cq16) >> 8;
+		uint64_t est = (((span2*wn) >> 12) + (uint64_t)(b->n*b->nc)*c->cq16*kc) >> 8;
 		key[k] = ((est > 0x3FFFFFEull ? 0x3FFFFFEu : (uint32_t)est) << 6) | (uint32_t)k;
 	}
 	int got = 0;
