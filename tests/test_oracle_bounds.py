@@ -181,7 +181,7 @@ def test_astc_ladder_against_the_wide_search():
     over the encoder's own lists.  The block it writes decodes (through the decoder pinned to Mesa's) to the error
     it claims, nothing the ladder emits beats it, and the gap of High stays inside what round 4 measured
     (profiles/r04_quality_tables.md: 6x6 High 0.54 / 0.46 dB on 512 opaque / alpha-carrying blocks, 4x4 0.20 /
-    0.46, 8x8 1.09 / 0.77 -- the weights <-> endpoints iteration and the partition seeds of the large footprints
+    0.46, 8x8 0.51 / 0.57 -- the weights <-> endpoints iteration and the partition seeds of the large footprints
     are where the ladder leaves most: DESIGN section 7)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location(
