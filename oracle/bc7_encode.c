@@ -487,8 +487,9 @@ static void fit_scalar(const int px[16][4], const int wt[CFO_BC7_NW], int abits,
  * with a = the power-iterated principal axis (same statistics and axis arithmetic as
  * fit_subset).  Cheap (no quantisation, no selector assignment) and shared by every
  * mode with the same subset count. */
-static float subset_residual(const int px[16][4], unsigned mask, const int bits[4])
+static float subset_residual(const int px[16][4], unsigned mask, const int bits[4], float* along)
 {
+	*along = 0.0f;
 	int n = 0, sum[4] = {0, 0, 0, 0}, sq[4][4];
 	memset(sq, 0, sizeof(sq));
 	for (int i = 0; i < 16; ++i) {
@@ -553,10 +554,12 @@ static float subset_residual(const int px[16][4], unsigned mask, const int bits[
 	den = fmaf(v[3], v[3], den);
 	float lam = num*(1.0f/den);
 	float res = (tr - lam)*(1.0f/(float)n);
+	float al = lam*(1.0f/(float)n);
+	*along = al > 0.0f ? al : 0.0f;
 	return res > 0.0f ? res : 0.0f;
 }
 
-static float partition_score(const int px[16][4], int ns, int part, const int bits[4])
+static float partition_score(const int px[16][4], int ns, int part, const int bits[4], float* along)
 {
 	unsigned masks[3];
 	if (ns == 2) {
@@ -567,9 +570,13 @@ static float partition_score(const int px[16][4], int ns, int part, const int bi
 		for (int i = 0; i < 16; ++i)
 			masks[(cfo_part3[part] >> (2*i)) & 3] |= 1u << i;
 	}
-	float sc = 0.0f;
-	for (int s = 0; s < ns; ++s)
-		sc = sc + subset_residual(px, masks[s], bits);
+	float sc = 0.0f, sl = 0.0f;
+	for (int s = 0; s < ns; ++s) {
+		float al;
+		sc = sc + subset_residual(px, masks[s], bits, &al);
+		sl = sl + al;
+	}
+	*along = sl;
 	return sc;
 }
 
@@ -879,6 +886,13 @@ typedef struct {
 	int uber;       /* -- are each perturbed for `uber` rounds with the move sets `sets` (uber_refine), */
 	int uber2;      /* -- and the best of them then for `uber2` more rounds */
 	int sets;
+	int starts3;    /* variants (bit v) the three-subset candidates are refitted from: the pulled-in starts buy them
+	                 * nothing (real blocks: 0.177 dB with variants 0 and 1 only, 0.176 with all four), and two
+	                 * starts of three fits fit the 8 lanes a candidate has in the 32-lane layout */
+	int estq;       /* partition ranking: eighths of the index-quantisation term (0 = residual only) */
+	int wide;       /* the 64-lane layout (High, Highest) */
+	int m4;         /* mode 4 candidates: bit k enables rotation k & 3, index selector k >> 2 */
+	int own_lanes;  /* lab only: every candidate its own slot (lane = id), so partition counts are not bound by a lane layout */
 } budget;
 
 static budget quality_budget(int quality)
@@ -887,22 +901,29 @@ static budget quality_budget(int quality)
 	memset(&b, 0, sizeof(b));
 	b.n1 = 6; b.n3 = 5; b.n7 = 11; b.n7low = 14; b.n0 = 5; b.n2 = 5;
 	b.top = 1;
+	b.estq = 4;
+	/* The ladder is measured on blocks of REAL photographs (tests/golden/real_blocks.npz, 4096 opaque + 1024
+	 * alpha-carrying blocks; tools/bc7_lab.py --kind real) against the wide search (cfo_bc7_wide_search).  Round 4
+	 * tuned it on the synthetic tile, whose blocks never want a three-subset mode or mode 4; on the photographs
+	 * that ladder sat 0.60 / 1.00 dB (Normal), 0.55 / 0.97 (High) and 0.11 / 0.02 (Highest) under the wide search. */
 	switch (quality) {
 		case 0: b.m6only = 1; break;
-		case 1: b.two = b.mode3 = b.rot = 1; break;   /* Low: Normal's candidate set without the refit round */
-		/* Normal: measured on the sampled blocks of tools/quality_tables.py against the wide search
-		 * (cfo_bc7_wide_search), opaque / alpha-carrying content: round 3's Normal (plain refit, no
-		 * refinement) was 0.41 / 0.49 dB under it; the quantisation-aware refit and the inset start
-		 * alone 0.30 / 0.25; with the four best candidates refitted from four more starts and one
-		 * perturbation round on the leader 0.09 / 0.05 */
-		case 2: b.iters = 1; b.two = b.mode3 = b.rot = 1; b.top = 4; b.starts = 1; b.uber = 0; b.uber2 = 1; b.sets = 1; break;
-		/* High: eight candidates (four saturate at 0.054 dB under the wide search, eight reach 0.047 / 0.015), a
-		 * perturbation round on each of them as well, and the joint moves as a second set of every round */
-		case 3: b.iters = 1; b.two = b.mode3 = b.rot = 1; b.top = 8; b.starts = 1; b.uber = 1; b.uber2 = 1; b.sets = 3; break;
-		/* Highest: the wide set (mode 4, 16 two-subset partitions, the three-subset modes), two refit
-		 * rounds, two perturbation rounds per candidate and two more on the leader */
-		default: b.iters = 2; b.two = b.mode3 = b.three = b.rot = 1; b.n1 = b.n3 = 8; b.n7 = 16;
-			b.top = 8; b.starts = 1; b.uber = 2; b.uber2 = 2; b.sets = 3; break;
+		case 1: b.two = b.mode3 = b.rot = 1; break;   /* Low: Normal's first pass without the refit round */
+		/* Normal: what the photographs lacked was not refinement but candidates: the three-subset modes
+		 * (opaque: 0.60 -> 0.23 dB) and mode 4 (alpha: 1.00 -> 0.08) -- a second pass of the 32-lane layout,
+		 * walked by the blocks the first leaves with an error of 48 or more; the ranking term of the
+		 * partition scores takes opaque to 0.18.  The four best candidates are refitted from four more starts
+		 * (three-subset ones from two) and the leader perturbed for one round, as in round 4. */
+		case 2: b.iters = 1; b.two = b.mode3 = b.rot = b.three = 1; b.m4 = 255; b.top = 4; b.starts = 15; b.starts3 = 3;
+			b.uber = 0; b.uber2 = 1; b.sets = 1; break;
+		/* High (bc7enc: m_uber_level 4 against Normal's 1, S3tcConverter.cpp:193,204): the wide layout -- mode 4 for
+		 * every block, 16 two-subset partitions -- eight candidates refined, a perturbation round with both
+		 * move sets on each and one more on the leader: 0.08 / 0.03 dB */
+		case 3: b.wide = 1; b.iters = 1; b.two = b.mode3 = b.three = b.rot = 1; b.m4 = 255; b.n1 = 12; b.n3 = 4; b.n7 = 16;
+			b.top = 8; b.starts = 15; b.starts3 = 15; b.uber = 1; b.uber2 = 1; b.sets = 3; break;
+		/* Highest: two refit rounds, two perturbation rounds per candidate and two more on the leader: 0.06 / 0.02 */
+		default: b.wide = 1; b.iters = 2; b.two = b.mode3 = b.three = b.rot = 1; b.m4 = 255; b.n1 = 12; b.n3 = 4; b.n7 = 16;
+			b.top = 8; b.starts = 15; b.starts3 = 15; b.uber = 2; b.uber2 = 2; b.sets = 3; break;
 	}
 	return b;
 }
@@ -925,6 +946,7 @@ void cfo_bc7_weights(const cfo_params* p, int wt[CFO_BC7_NW])
 }
 
 #define CFO_BC7_MAXTOP 8
+#define CFO_BC7_LANES 384   /* 64 in the product layouts; the lab's own_lanes mode indexes by candidate id */
 
 static void encode_block(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p, const budget* bp)
 {
@@ -950,13 +972,13 @@ static void encode_block(const uint8_t rgba[64], uint8_t out[16], const cfo_para
 	 *   stream: lane 26 + 2 s (the 32-lane layouts: 10 + 2 s, or 4 + 2 s at Low), of the three-subset
 	 *   stream: lane 3 s.
 	 * The winner is the minimum of (error, id), so evaluation order does not matter. */
-	cand held[64], cur;
-	int used[64];
+	cand held[CFO_BC7_LANES], cur;
+	int used[CFO_BC7_LANES];
 	memset(used, 0, sizeof(used));
 	uint32_t best_err = 0xFFFFFFFFu;
 #define BETTER(c, b) ((c).err < (b).err || ((c).err == (b).err && (c).id < (b).id))
 #define TRY(ID, LANE) do { eval_candidate(px, wt, (ID), &fo, &cur); \
-	const int l_ = (LANE); \
+	const int l_ = b.own_lanes ? (ID) : (LANE); \
 	if (!used[l_] || BETTER(cur, held[l_])) { held[l_] = cur; used[l_] = 1; } \
 	if (cur.err < best_err) best_err = cur.err; } while (0)
 	TRY(0, 0);
@@ -969,40 +991,38 @@ static void encode_block(const uint8_t rgba[64], uint8_t out[16], const cfo_para
 		int nrot = (b.rot && !wt[4]) ? 4 : 1;
 		for (int r = 0; r < nrot; ++r)
 			TRY(1 + r, 2 + r);
-		/* mode 4 (rotation x index selector): Highest only (worth 0.012 dB on opaque and
-		 * 0.006 dB on alpha-carrying content; leaving it out lets the kernel fit a block's
-		 * whole candidate set into half a wavefront) */
-		if (b.rot && b.three)
+		/* mode 4 (rotation x index selector).  The wide layout fits it in the first pass; the 32-lane layout
+		 * (Normal) gives it to the blocks that carry alpha, in the second pass (below) */
+		if (b.rot && b.m4 && b.wide)
 			for (int k = 0; k < 8; ++k)
-				if (!wt[4] || (k & 3) == 0)
+				if (((b.m4 >> k) & 1) && (!wt[4] || (k & 3) == 0))
 					TRY(5 + k, 6 + k);
-		/* Partitioned modes: two-phase per subset count (group).  Phase 1 scores every
-		 * partition with the residual estimator (partition_score; independent of the
-		 * mode), phase 2 runs the full fit with all refit rounds on the best partitions
-		 * of each mode of the group, ranked by (score bits with the low 6 bits cleared,
-		 * partition index):
-		 *   two-subset group:   Low: one mode (1, or 7 with alpha) with 14; Normal, High: modes 1 / 3 with
-		 *                       6 / 5 (alpha: mode 7 with 11) -- a block then needs 32 lanes: 2 + 8 + 22;
-		 *                       Highest: modes 1 + 3 with 8 each (alpha: mode 7 with 16)
-		 *   three-subset group: modes 0 (its 16 partitions) + 2 with 5 partitions each (Highest)
+		/* Partitioned modes: two-phase per subset count (group).  Phase 1 scores every partition ONCE per
+		 * subset count (partition_score: the scatter no line through the subset means can capture, and the
+		 * scatter ALONG those lines), phase 2 runs the full fit with all refit rounds on the best partitions
+		 * of each mode of the group, ranked by (bits of  residual + along / (4 (2^ib)^2)  with the low 6 bits
+		 * cleared, partition index) -- the second term is half the error a uniform palette of 2^ib entries
+		 * leaves on a uniform spread along the line, so a mode with coarse indices prefers partitions with
+		 * short subsets (measured on the real-photograph blocks of tests/golden/real_blocks.npz: Normal
+		 * 0.232 -> 0.176 dB under the wide search, Highest 0.091 -> 0.063; with it, refitting MORE partitions
+		 * than below buys nothing: all 64 + 64 + 16 + 64 at Highest = 0.061):
+		 *   two-subset group:   32-lane layouts (Low, Normal): modes 1 / 3 with 6 / 5 (alpha: mode 7 with 11)
+		 *                       -- a block then needs 32 lanes: 2 + 8 + 22;
+		 *                       wide layout (High, Highest): modes 1 / 3 with 12 / 4 (alpha: mode 7 with 16)
+		 *   three-subset group: modes 0 (its 16 partitions) + 2 with 5 partitions each (from Normal up)
+		 * The second pass -- the three-subset group of an opaque block, mode 4 of an alpha-carrying block in
+		 * the 32-lane layout -- is only walked by blocks the candidates so far leave with an error of at
+		 * least 48 (0.75 per channel-texel).  (The two-subset group is tried whatever the error so far -- the
+		 * kernel fits it in the same pass as the one-subset modes.)
 		 * The HIP kernel runs phase 1 with lane = partition and phase 2 of a whole group
 		 * in one pass with lane = (mode, rank, subset, row pair). */
 		if (b.two) {
 			const int bits[4] = {1, 1, 1, has_alpha};
 			const int ngroups = (!has_alpha && b.three) ? 2 : 1;
-			/* the three-subset modes are only tried on blocks the candidates so far leave with an
-			 * error of at least 48 (0.75 per channel-texel): three colour regions in a block that
-			 * already codes this well are rare, and the stream costs a third of Highest's time.
-			 * (The two-subset group is tried whatever the error so far -- the kernel fits it in the same
-			 * pass as the one-subset modes -- so that the list of best candidates is the same list.) */
 			for (int g = 0; g < ngroups && (g == 0 || best_err >= 48u); ++g) {
-				uint32_t key0[64];
-				for (int k = 0; k < 64; ++k) {
-					float sc = partition_score(px, 2 + g, k, bits);
-					uint32_t u;
-					memcpy(&u, &sc, 4);
-					key0[k] = (u & ~63u) | (uint32_t)k;
-				}
+				float sc0[64], sl0[64];
+				for (int k = 0; k < 64; ++k)
+					sc0[k] = partition_score(px, 2 + g, k, bits, &sl0[k]);
 				int bases[2], counts[2], pers[2] = {0, 0}, nm = 0;
 				if (g == 1) {
 					bases[nm] = 192; counts[nm] = 16; pers[nm++] = b.n0;
@@ -1018,7 +1038,17 @@ static void encode_block(const uint8_t rgba[64], uint8_t out[16], const cfo_para
 				int slot = 0;
 				for (int mi = 0; mi < nm; ++mi) {
 					uint32_t key[64];
-					memcpy(key, key0, sizeof(key));
+					{
+						const int mode_ = bases[mi] == 64 ? 1 : bases[mi] == 128 ? 3 : bases[mi] == 192 ? 0 : bases[mi] == 256 ? 2 : 7;
+						const int ib_ = cfo_bc7_modes[mode_].ib;
+						const float qf = (float)b.estq*0.125f*(ib_ == 3 ? 1.0f/64.0f : 1.0f/16.0f);
+						for (int k = 0; k < 64; ++k) {
+							float sc = fmaf(qf, sl0[k], sc0[k]);
+							uint32_t u;
+							memcpy(&u, &sc, 4);
+							key[k] = (u & ~63u) | (uint32_t)k;
+						}
+					}
 					for (int r = 0; r < pers[mi]; ++r, ++slot) {
 						int bk = -1;
 						for (int k = 0; k < counts[mi]; ++k)
@@ -1027,11 +1057,18 @@ static void encode_block(const uint8_t rgba[64], uint8_t out[16], const cfo_para
 						if (bk < 0)
 							break;
 						key[bk] = 0xFFFFFFFFu;
-						TRY(bases[mi] + bk, g == 1 ? 3*slot : (b.three ? 26 : (b.mode3 ? 10 : 4)) + 2*slot);
+						/* columns: the second pass of the 32-lane layout leads its candidates from the odd
+						 * lanes 11, 13, ... -- no candidate of the first pass lives there, so none is dropped */
+						TRY(bases[mi] + bk, g == 1 ? (b.wide ? 3*slot : 11 + 2*slot)
+							: (b.wide ? 26 : (b.mode3 ? 10 : 4)) + 2*slot);
 					}
 				}
 			}
 		}
+		if (b.rot && b.m4 && !b.wide && has_alpha && best_err >= 48u)
+			for (int k = 0; k < 8; ++k)
+				if (((b.m4 >> k) & 1) && (!wt[4] || (k & 3) == 0))
+					TRY(5 + k, 11 + 2*k);
 	}
 #undef TRY
 	/* the `top` best lanes in (error, id) order */
@@ -1039,7 +1076,7 @@ static void encode_block(const uint8_t rgba[64], uint8_t out[16], const cfo_para
 	int ntop = 0;
 	for (; ntop < b.top && ntop < CFO_BC7_MAXTOP; ++ntop) {
 		int bl = -1;
-		for (int l = 0; l < 64; ++l)
+		for (int l = 0; l < CFO_BC7_LANES; ++l)
 			if (used[l] && (bl < 0 || BETTER(held[l], held[bl])))
 				bl = l;
 		if (bl < 0)
@@ -1052,6 +1089,8 @@ static void encode_block(const uint8_t rgba[64], uint8_t out[16], const cfo_para
 		static const int variants[4] = {0, 2, 3, 4};
 		for (int k = 0; k < ntop; ++k)
 			for (int v = 0; v < 4; ++v) {
+				if (!(((top[k].ns == 3 ? b.starts3 : b.starts) >> v) & 1))
+					continue;
 				const fitopt fo2 = {b.iters, fo.qwin, variants[v]};
 				eval_candidate(px, wt, top[k].id, &fo2, &cur);
 				const int planes = top[k].mode == 4 || top[k].mode == 5;
@@ -1088,7 +1127,7 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 /* test-only: the block search with every budget field set by the caller (tools/bc7_lab.py measures what
  * each step of the search buys before it is given to a Texture::Quality level).  knobs = the budget
  * fields in declaration order. */
-void cfo_bc7_lab_block(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p, const int knobs[17])
+void cfo_bc7_lab_block(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p, const int knobs[22])
 {
 	budget b;
 	int* f = (int*)&b;

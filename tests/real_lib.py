@@ -1,0 +1,66 @@
+"""Loader of tests/golden/real_blocks.npz -- blocks sampled from real photographs by
+tests/golden/make_real_blocks.py (the photographs stay in the build container; the blocks are data).
+
+Every quality claim of the codecs is measured on these blocks (tools/quality_tables.py, tools/bc7_lab.py,
+tests/test_oracle_bounds.py); TEST INFRASTRUCTURE, nothing under cuttlefish_amd/ reads it.
+"""
+import os
+
+import numpy as np
+
+PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real_blocks.npz")
+_cache = None
+
+
+def _load():
+    global _cache
+    if _cache is None:
+        d = np.load(PATH)
+        _cache = {k: d[k] for k in d.files}
+    return _cache
+
+
+def image_names():
+    return [str(s) for s in _load()["images"]]
+
+
+def blocks4(count=None, alpha=False, image=None):
+    """-> (n, 4, 4, 4) uint8 RGBA blocks.  alpha=False: opaque photograph blocks (interleaved over the
+    images so any prefix is a fair sample); alpha=True: the alpha-carrying set."""
+    d = _load()
+    if alpha:
+        b = d["rgba4"]
+    else:
+        rgb, src = d["rgb4"], d["rgb4_img"]
+        if image is not None:
+            rgb = rgb[src == image_names().index(image)]
+        else:
+            nimg = len(d["images"])
+            per = len(rgb) // nimg
+            rgb = rgb.reshape(nimg, per, 4, 4, 3).transpose(1, 0, 2, 3, 4).reshape(-1, 4, 4, 3)
+        b = np.concatenate([rgb, np.full(rgb.shape[:3] + (1,), 255, np.uint8)], axis=-1)
+    if count is not None:
+        b = b[:count]
+    return np.ascontiguousarray(b)
+
+
+def blocks(bw, bh, count=None, image=None):
+    """-> (n, bh, bw, 4) uint8 opaque blocks of an ASTC footprint up to 12x12 (top-left crop of the patches)."""
+    d = _load()
+    rgb, src = d["rgb12"], d["rgb12_img"]
+    if image is not None:
+        rgb = rgb[src == image_names().index(image)]
+    else:
+        nimg = len(d["images"])
+        per = len(rgb) // nimg
+        rgb = rgb.reshape(nimg, per, 12, 12, 3).transpose(1, 0, 2, 3, 4).reshape(-1, 12, 12, 3)
+    rgb = rgb[:, :bh, :bw]
+    b = np.concatenate([rgb, np.full(rgb.shape[:3] + (1,), 255, np.uint8)], axis=-1)
+    if count is not None:
+        b = b[:count]
+    return np.ascontiguousarray(b)
+
+
+def strip(blks):
+    """(n, bh, bw, 4) blocks -> the (bh, n*bw, 4) image whose block row they are."""
+    return np.ascontiguousarray(np.concatenate(list(blks), axis=1))

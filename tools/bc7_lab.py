@@ -22,9 +22,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O          # noqa: E402
 from cuttlefish_amd import synth    # noqa: E402
 
-FIELDS = "iters,m6only,two,mode3,three,rot,n1,n3,n7,n7low,n0,n2,top,starts,uber,uber2,sets".split(",")
-NORMAL = dict(iters=1, m6only=0, two=1, mode3=1, three=0, rot=1, n1=6, n3=5, n7=11, n7low=14, n0=5, n2=5,
-              top=3, starts=1, uber=1, uber2=1, sets=1)
+FIELDS = "iters,m6only,two,mode3,three,rot,n1,n3,n7,n7low,n0,n2,top,starts,uber,uber2,sets,starts3,estq,wide,m4,own".split(",")
+NORMAL = dict(iters=1, m6only=0, two=1, mode3=1, three=1, rot=1, n1=6, n3=5, n7=11, n7low=14, n0=5, n2=5,
+              top=4, starts=15, uber=0, uber2=1, sets=1, starts3=3, estq=4, wide=0, m4=255, own=0)
 
 
 def knobs(**kw):
@@ -45,6 +45,11 @@ def contents(count, which, kind="photo"):
     out = []
     for label, alpha in (("opaque", False), ("alpha", True)):
         if which not in ("both", label):
+            continue
+        if kind == "real":
+            import real_lib as R
+            blocks = R.blocks4(count, alpha=alpha)
+            out.append(("real " + label, np.ascontiguousarray(blocks.reshape(len(blocks), 64))))
             continue
         img = synth.photo(512, 512, seed=21)
         if alpha:
@@ -83,6 +88,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=2048)
     ap.add_argument("--content", default="both")
     ap.add_argument("--no-wide", action="store_true")
+    ap.add_argument("--kind", default="photo", help="photo = the synthetic generator, real = tests/golden/real_blocks.npz")
     ap.add_argument("cfg", nargs="*")
     a = ap.parse_args()
     L = O.lib()
@@ -100,10 +106,10 @@ def main():
                 k, _, v = item.partition(":")
                 kw[k] = int(v)
         cfgs.append((name, kw))
-    for label, blocks in contents(a.blocks, a.content):
+    for label, blocks in contents(a.blocks, a.content, a.kind):
         n = len(blocks)
         print("== %s, %d blocks" % (label, n))
-        cache = "/tmp/bc7_wide_%s_%d.npy" % (label, n)
+        cache = "/tmp/bc7_wide_%s_%d.npy" % (label.replace(" ", "_"), n)
         wide = None
         if not a.no_wide:
             if os.path.exists(cache):
@@ -124,7 +130,7 @@ def main():
                                                       psnr(wide, n) - psnr(sse, n) if wide else 0, dt))
         for name, kw in cfgs:
             p = O.make_params(36, 0, 2)
-            kn = (ctypes.c_int * 17)(*knobs(**kw))
+            kn = (ctypes.c_int * 22)(*knobs(**kw))
             t0 = time.time()
             sse = run(blocks, lambda b, o: L.cfo_bc7_lab_block(b, o, ctypes.byref(p), kn))
             dt = time.time() - t0
