@@ -858,7 +858,7 @@ __device__ __forceinline__ uint4 pack_block_group(const uint32_t* wcol, uint32_t
 // A4 = false: the block is opaque (the alpha plane is masked to zero), so every term that
 // carries the fourth channel is an exact zero and is left out -- same result, bit for bit.
 template <bool A4>
-__device__ __forceinline__ float subset_residual(const Tex& tx, uint32_t mask)
+__device__ __forceinline__ float subset_residual(const Tex& tx, uint32_t mask, float& along)
 {
 	const uint32_t n = (uint32_t)__builtin_popcount(mask);
 	uint32_t s[4] = {0, 0, 0, 0};
@@ -913,6 +913,7 @@ __device__ __forceinline__ float subset_residual(const Tex& tx, uint32_t mask)
 	tr = tr + C22;
 	if (A4) tr = tr + C33;
 	float res = 0.0f;
+	along = 0.0f;
 	if (mx > 0.0f) {
 		const float im = 1.0f/mx;
 		v0 = v0*im; v1 = v1*im; v2 = v2*im; v3 = A4 ? v3*im : 0.0f;
@@ -928,6 +929,8 @@ __device__ __forceinline__ float subset_residual(const Tex& tx, uint32_t mask)
 		const float lam = num*(1.0f/den);
 		res = (tr - lam)*(1.0f/(float)n);
 		res = res > 0.0f ? res : 0.0f;
+		const float al = lam*(1.0f/(float)n);
+		along = al > 0.0f ? al : 0.0f;
 	}
 #undef CF_MATVEC
 	return res;
@@ -1080,8 +1083,15 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	const uint32_t uber2 = kp.quality >= 4u ? 2u : (kp.quality >= 2u ? 1u : 0u);   // rounds on the leader
 	const uint32_t msets = kp.quality >= 3u ? 3u : 1u;       // move sets of a round: bit 0 single, bit 1 joint
 	bool solved = false;
+	// which halves walk the second pass: bit 0 / bit 32 = the best candidate of the first pass leaves the block
+	// of half 0 / 1 with an error of at least 48 (oracle: best_err >= 48u); a scalar pair
+	unsigned long long gb = 0ull;
+#define H_GATE (((uint32_t)((pair && L_H) ? gb >> 32 : gb) & 1u) != 0u)
+	// some half is opaque (the two-mode rankings are only walked then)
+	const bool any_opaque = pair ? (((uint32_t)abal & 0xFFFFu) == 0u || ((uint32_t)(abal >> 32) & 0xFFFFu) == 0u) : !has_alpha;
 	{
-		const uint32_t nstreams = (WIDE && !has_alpha) ? 2u : 1u;
+		// second pass: the three-subset modes of an opaque block (Normal: mode 4 of an alpha-carrying one)
+		const uint32_t nstreams = WIDE ? (has_alpha ? 1u : 2u) : (kp.quality == 2u ? 2u : 1u);
 		// The last trip of this loop (sst) is not a stream of new candidates: it selects the `ntop` best so
 		// far and refits them from four more starts (oracle: encode_block, "more starts") -- through the SAME
 		// fit_lane call as the streams (one copy of the fit in the code object, one register allocation).
@@ -1115,7 +1125,14 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			}
 			const Tex txp = make_tex(tile, plan, yccp, B_OFF, 0u, H_ALPHA ? 15u : 7u);   // partition fits: no rotation
 			const uint32_t ns = 2u + st;
-			const bool parts = quality >= 1u && !sst;
+			// the second pass of the 32-lane layout (s1l): slot s of an opaque half that walks it has its subsets
+			// in lanes 11 + 2 s, 12 + 2 s and s; candidate 5 + k (mode 4) of an alpha-carrying half its vector /
+			// scalar plane in lanes 11 + 2 k, 12 + 2 k -- the leaders are odd lanes from 11 up, whose columns no
+			// candidate of the first pass uses (oracle: encode_block, "columns")
+			const bool s1l = lay32 && st == 1u;
+			// phase 1 is walked when some group ranks partitions in this trip
+			const bool parts = quality >= 1u && !sst &&
+				(!s1l || __ballot(L_SLOT_OK && !(H_ALPHA) && H_GATE) != 0ull);
 			// partition lanes: first lane, slots of the first mode, slots in all
 			// (nper0 depends on the half's H_ALPHA: an expression, like the roles, not a carried value)
 			uint32_t pfirst, nslots;
@@ -1124,25 +1141,27 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 				else { pfirst = 4u; nslots = 14u; }
 			} else if (st == 1u) { pfirst = 0u; nslots = 10u; }
 			else { pfirst = 26u; nslots = 16u; }
-#define R_NPER0 (lay32 ? (quality == 2u ? (H_ALPHA ? 11u : 6u) : 14u) : (st == 1u ? 5u : (H_ALPHA ? 16u : 8u)))
+#define R_NPER0 (st == 1u ? 5u : (lay32 ? (quality == 2u ? (H_ALPHA ? 11u : 6u) : 14u) : (H_ALPHA ? 16u : 12u)))
 			// lane roles as expressions of the CURRENT lane id (re-read where a phase starts), so that none of
 			// them is carried in a register through the fit
 #define R_REL (L_HL - pfirst)                                   /* wraps below pfirst */
-#define R_SLOT (st == 1u ? R_REL/3u : R_REL >> 1)
-#define R_SUB (R_REL - R_SLOT*ns)
-#define R_PLANE (parts && L_SLOT_OK && L_HL >= pfirst && R_SLOT < nslots)
+#define R_SLOT (s1l ? (L_HL < 10u ? L_HL : (L_HL - 11u) >> 1) : (st == 1u ? R_REL/3u : R_REL >> 1))
+#define R_SUB (s1l ? (L_HL < 10u ? 2u : (L_HL - 11u) & 1u) : R_REL - R_SLOT*ns)
+#define R_PLANE (parts && L_SLOT_OK && (s1l ? (!(H_ALPHA) && H_GATE && L_HL != 10u && L_HL != 31u) : (L_HL >= pfirst && R_SLOT < nslots)))
+#define R_S1M4 (s1l && L_SLOT_OK && (H_ALPHA) && H_GATE && L_HL >= 11u && L_HL < 27u)
 #define R_MI (R_SLOT >= R_NPER0 ? 1u : 0u)
 #define R_RANK (R_SLOT - R_MI*R_NPER0)
 			uint32_t mypart = 0;
 			// ---- phase 1: partition scores (one partition per lane, two when the group has
 			// only 32 lanes) and selection of the nper0 best by iterated group minimum ----
 			if (parts) {
-				uint32_t key0[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+				// residual and scatter along the lines (oracle: partition_score) of the lane's partitions
+				float sc0 = 0.0f, sl0 = 0.0f, sc1 = 0.0f, sl1 = 0.0f;
 				const uint32_t npi = pair ? 2u : 1u;
 				for (uint32_t pi = 0; pi < npi; ++pi) {
 					const uint32_t part = pair ? L_HL + 32u*pi : lane;
 					const uint32_t p2 = k_part2[part], p3 = k_part3[part];
-					float sc = 0.0f;
+					float sc = 0.0f, sl = 0.0f;
 					for (uint32_t sb = 0; sb < ns; ++sb) {
 						uint32_t mask;
 						if (st == 0u)
@@ -1153,20 +1172,28 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 							for (int i = 0; i < 16; ++i)
 								mask |= (((p3 >> (2*i)) & 3u) == sb ? 1u : 0u) << i;
 						}
-						sc = sc + (any_alpha ? subset_residual<true>(txp, mask) : subset_residual<false>(txp, mask));
+						float al;
+						sc = sc + (any_alpha ? subset_residual<true>(txp, mask, al) : subset_residual<false>(txp, mask, al));
+						sl = sl + al;
 					}
-					const uint32_t kk = (__float_as_uint(sc) & ~63u) | part;
-					if (pi == 0u) key0[0] = kk; else key0[1] = kk;
+					if (pi == 0u) { sc0 = sc; sl0 = sl; } else { sc1 = sc; sl1 = sl; }
 				}
-				const uint32_t nruns = st == 1u ? 2u : 1u;   // mode 0 ranks its own 16 partitions
+				// one ranking per mode of the group: modes 1 / 3 (alpha: mode 7 alone), modes 0 / 2; key = bits of
+				// residual + along / (4 (2^ib)^2), low 6 bits = the partition (oracle: encode_block, "qf")
+				const uint32_t nruns = (st == 1u || any_opaque) ? 2u : 1u;
 				for (uint32_t run = 0; run < nruns; ++run) {
-					const uint32_t npart = (st == 1u && run == 0u) ? 16u : 64u;
-					uint32_t ka = (key0[0] & 63u) < npart ? key0[0] : 0xFFFFFFFFu, kb = key0[1];
+					CF_FRESH_LANE(lane);
+					const float qf = (run == 0u && !(st == 0u && (H_ALPHA))) ? 1.0f/128.0f : 1.0f/32.0f;
+					const uint32_t part0 = pair ? L_HL : lane;
+					const uint32_t npart = (st == 1u && run == 0u) ? 16u : 64u;   // mode 0 ranks its own 16 partitions
+					uint32_t ka = part0 < npart ? ((__float_as_uint(fmaf(qf, sl0, sc0)) & ~63u) | part0) : 0xFFFFFFFFu;
+					uint32_t kb = (pair && npart == 64u) ? ((__float_as_uint(fmaf(qf, sl1, sc1)) & ~63u) | (part0 + 32u)) : 0xFFFFFFFFu;
 					// uniform trip count: the larger of the groups' needs
-					const uint32_t nsel = lay32 ? (quality == 2u ? (any_alpha ? 11u : 6u) : 14u) : R_NPER0;
+					const uint32_t nsel = st == 1u ? 5u : (run == 0u ? (lay32 ? (quality == 2u ? (any_alpha ? 11u : 6u) : 14u) : (has_alpha ? 16u : 12u))
+						: (lay32 ? 5u : 4u));
 					for (uint32_t t = 0; t < nsel; ++t) {
 						const uint32_t kmin = cf_group_min_u32(ka < kb ? ka : kb, pair, L_H);
-						const bool mine = R_RANK == t && (st == 0u || R_MI == run);
+						const bool mine = R_RANK == t && R_MI == run;
 						mypart = mine ? (kmin & 63u) : mypart;
 						ka = ka == kmin ? 0xFFFFFFFFu : ka;
 						kb = kb == kmin ? 0xFFFFFFFFu : kb;
@@ -1177,14 +1204,14 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			CF_FRESH_LANE(lane);
 			asm volatile("" : "+v"(mypart));   // nothing of phase 1 but mypart lives on
 #define R_M6 (st == 0u && L_SLOT_OK && L_HL < 2u)
-#define R_VECP (lay32 ? (quality == 2u ? (L_SLOT_OK && L_HL >= 2u && L_HL < 6u) : (L_SLOT_OK && L_HL == 2u)) : (st == 0u && lane >= 2u && lane < 14u))
-#define R_SCA (lay32 ? (quality == 2u ? (L_SLOT_OK && L_HL >= 6u && L_HL < 10u) : (L_SLOT_OK && L_HL == 3u)) : (st == 0u && lane >= 14u && lane < 26u))
-#define R_CID (R_M6 ? 0u : (lay32 ? (quality == 2u ? L_HL - (R_SCA ? 5u : 1u) : 1u) : 1u + (lane - (R_SCA ? 14u : 2u))))   /* meaningful for vecp / sca */
+#define R_VECP (lay32 ? (st == 1u ? (R_S1M4 && ((L_HL - 11u) & 1u) == 0u) : (quality == 2u ? (L_SLOT_OK && L_HL >= 2u && L_HL < 6u) : (L_SLOT_OK && L_HL == 2u))) : (st == 0u && lane >= 2u && lane < 14u))
+#define R_SCA (lay32 ? (st == 1u ? (R_S1M4 && ((L_HL - 11u) & 1u) != 0u) : (quality == 2u ? (L_SLOT_OK && L_HL >= 6u && L_HL < 10u) : (L_SLOT_OK && L_HL == 3u))) : (st == 0u && lane >= 14u && lane < 26u))
+#define R_CID (R_M6 ? 0u : (lay32 ? (st == 1u ? 5u + ((L_HL - 11u) >> 1) : (quality == 2u ? L_HL - (R_SCA ? 5u : 1u) : 1u)) : 1u + (lane - (R_SCA ? 14u : 2u))))   /* meaningful for vecp / sca */
 #define R_IDBASE (R_PLANE ? (st == 1u ? (R_MI ? 256u : 192u) : (H_ALPHA ? 320u : (R_MI ? 128u : 64u))) : 0u)
 			bool m6 = R_M6, sca = R_SCA;
 			const bool vecp = R_VECP, plane = R_PLANE;
 			const uint32_t cid = R_CID, sub = R_SUB, mi = R_MI;
-			const uint32_t s2off = lay32 ? (quality == 2u ? 4u : 1u) : (st == 0u ? 12u : 2u);
+			const uint32_t s2off = lay32 ? ((quality == 2u && st == 0u) ? 4u : 1u) : (st == 0u ? 12u : 2u);
 			uint32_t rot = 0, cb = 7, ab = 7, pbk = 1, ib = 4, mask = 0xFFFFu;
 			bool active = m6;
 			float frac = frac_main;
@@ -1194,11 +1221,15 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 				// (k = hl >> 3, v = (hl >> 1) & 3, fit = hl & 1 -- mode 6: its two palette halves), 16 in the wide
 				// one (k = lane >> 4, v = (lane >> 2) & 3, fit = lane & 3).  Each lane runs the whole fit from its
 				// start; the best start of a fit replaces the column's fit when it is better.
+				// A three-subset candidate has 8 lanes in the 32-lane layout as well: two starts (v = 0, 1: the extremes,
+				// pushed out) of its three fits in j = hl & 7 = 3 v + fit, j < 6 (oracle: budget.starts3)
 				const uint32_t k = koff + (lay32 ? (L_HL >> 3) : (lane >> 4));
-				const uint32_t v = lay32 ? (L_HL >> 1) & 3u : (lane >> 2) & 3u;
-				const uint32_t fi = lay32 ? (L_HL & 1u) : (lane & 3u);
 				const uint32_t wl = TOP_LANE(k & 7u);
 				const uint32_t id = cbase[wl + 19*CF_WG_THREADS], cerr = cbase[wl + 18*CF_WG_THREADS];
+				const bool n3 = lay32 && id >= 192u && id < 320u;
+				const uint32_t j8 = L_HL & 7u;
+				const uint32_t v = lay32 ? (n3 ? (j8 >= 3u ? 1u : 0u) : (L_HL >> 1) & 3u) : (lane >> 2) & 3u;
+				const uint32_t fi = lay32 ? (n3 ? (j8 >= 6u ? 3u : j8 - 3u*v) : (L_HL & 1u)) : (lane & 3u);
 				const uint32_t err0 = cbase[TOP_LANE(0u) + 18*CF_WG_THREADS];
 				const FitGeo g = fit_geo(id, fi);
 				m6 = g.m6; sca = g.sca; rot = g.rot; cb = g.cb; ab = g.ab; pbk = g.pbk; ib = g.ib; mask = g.mask;
@@ -1270,10 +1301,12 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			if (sst) {
 				// (every role again from the fresh lane id: nothing but the fit's result lived across fit_lane)
 				const uint32_t k2 = koff + (lay32 ? (L_HL >> 3) : (lane >> 4));
-				const uint32_t v2 = lay32 ? (L_HL >> 1) & 3u : (lane >> 2) & 3u;
-				const uint32_t fi2 = lay32 ? (L_HL & 1u) : (lane & 3u);
 				const uint32_t wl2 = TOP_LANE(k2 & 7u);
 				const uint32_t id2 = cbase[wl2 + 19*CF_WG_THREADS], cerr2 = cbase[wl2 + 18*CF_WG_THREADS];
+				const bool n32 = lay32 && id2 >= 192u && id2 < 320u;
+				const uint32_t j82 = L_HL & 7u;
+				const uint32_t v2 = lay32 ? (n32 ? (j82 >= 3u ? 1u : 0u) : (L_HL >> 1) & 3u) : (lane >> 2) & 3u;
+				const uint32_t fi2 = lay32 ? (n32 ? (j82 >= 6u ? 3u : j82 - 3u*v2) : (L_HL & 1u)) : (lane & 3u);
 				const uint32_t err02 = cbase[TOP_LANE(0u) + 18*CF_WG_THREADS];
 				const FitGeo g2 = fit_geo(id2, fi2);
 				const uint32_t kf2 = g2.m6 ? 0u : fi2;
@@ -1281,9 +1314,10 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 				// best start of the fit: minimum of (error, v) over the four lanes of (k, fit)
 				uint32_t skey = active2 ? ((lf.err << 2) | v2) : 0xFFFFFFFFu;
 				{
-					const uint32_t o1 = (uint32_t)cf_bperm((int)skey, lane ^ (lay32 ? 2u : 4u));
+					// (three fits in 8 lanes: the other start of the fit is 3 lanes away; lanes 6, 7 idle)
+					const uint32_t o1 = (uint32_t)cf_bperm((int)skey, n32 ? (j82 < 3u ? lane + 3u : (j82 < 6u ? lane - 3u : lane)) : lane ^ (lay32 ? 2u : 4u));
 					skey = o1 < skey ? o1 : skey;
-					const uint32_t o2 = (uint32_t)cf_bperm((int)skey, lane ^ (lay32 ? 4u : 8u));
+					const uint32_t o2 = (uint32_t)cf_bperm((int)skey, n32 ? lane : lane ^ (lay32 ? 4u : 8u));
 					skey = o2 < skey ? o2 : skey;
 				}
 				uint32_t* wc = cbase + wl2;
@@ -1302,7 +1336,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			//   mode 6: its first lane;  mode 4/5: vector lane (scalar plane s2off lanes up);
 			//   partitions: subset-0 lane (the other subsets in the next lanes)
 			const int s1 = (int)((lane + 1u) & 63u);
-			const int s2 = (int)((lane + s2off) & 63u);
+			const int s2 = (s1l && R_PLANE) ? (int)(L_HBASE + ((L_HL - 11u) >> 1)) : (int)((lane + s2off) & 63u);
 			// error and id first: only a leader whose candidate beats its best so far stores
 			// the payload fields, straight from the shuffles into its LDS column
 			const uint32_t e1 = (uint32_t)cf_bperm((int)lf.err, (uint32_t)(s1)), e2 = (uint32_t)cf_bperm((int)lf.err, (uint32_t)(s2));
@@ -1350,11 +1384,13 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			}
 			// A zero-error candidate cannot be beaten by a later one (ids grow with the
 			// streams), so the remaining work may be skipped without changing the payload.
-			solved = __ballot(best_err == 0u) != 0ull;
-			// the three-subset stream only for blocks whose best candidate so far leaves an error
-			// of at least 48 (oracle: same rule); one block per wave here, so this is uniform
-			if (WIDE && cf_wave_min_u32(best_err) < 48u)
-				solved = true;
+			// The second pass only for blocks whose best candidate so far leaves an error of at least 48 (oracle:
+			// same rule; a zero-error block ends its search here): per half, and skipped when no half walks it
+			if (st == 0u) {
+				const uint32_t gmin = cf_group_min_u32(best_err, pair, L_H);
+				gb = __ballot(gmin >= 48u);
+				solved = gb == 0ull;
+			}
 #undef R_NPER0
 #undef R_REL
 #undef R_SLOT
@@ -1367,6 +1403,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 #undef R_SCA
 #undef R_CID
 #undef R_IDBASE
+#undef R_S1M4
 		}
 	}
 
@@ -1397,11 +1434,21 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 		// its 16 palette entries over lane pairs and fills two rows) the best move of a set is applied when it
 		// lowers the fit's error; a round walks its sets in order.  Fits are independent, so all of them move
 		// in the same pass.
+		// In the 32-lane layout a block has two rows of move slots, so the third fit of a three-subset candidate
+		// gets a pass of its own (fp = 1: fits 2 and 3) -- fits are independent, and one that did not move in a round
+		// never moves again, so fit 2 walking its rounds after fits 0 and 1 ends where the oracle's round-major order does.
 #pragma unroll 1
-		for (uint32_t kk = ((CF_BC7_ABLATE & 32) || !uber) ? ntop : 0u; kk <= ntop; ++kk) {
+		for (uint32_t kf2p = ((CF_BC7_ABLATE & 32) || !uber) ? 2u*ntop : 0u; kf2p <= 2u*ntop + 1u; ++kf2p) {
+			const uint32_t kk = kf2p >> 1, fp = kf2p & 1u;
 			CF_FRESH_LANE(lane);
-			uint32_t wl = TOP_LANE(kk & 7u);
-			if (kk == ntop) {
+			uint32_t wl = (fp && kk == ntop) ? win_lane : TOP_LANE(kk & 7u);
+			if (fp) {
+				// a second pass only when a candidate of this wave has a third fit (ids 192 .. 319: modes 0 and 2)
+				const uint32_t idf = cbase[wl + 19*CF_WG_THREADS];
+				if (!lay32 || __ballot(L_SLOT_OK && idf >= 192u && idf < 320u) == 0ull)
+					continue;
+			}
+			if (kk == ntop && !fp) {
 				// the leader after the candidates' own rounds
 				const unsigned long long key = ((unsigned long long)L_CSLOT[18*CF_WG_THREADS] << 32) | L_CSLOT[19*CF_WG_THREADS];
 				const unsigned long long kmin = cf_group_min_u64(key, pair, L_H);
@@ -1412,11 +1459,11 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			}
 			uint32_t* wc = cbase + wl;
 			const uint32_t id = wc[19*CF_WG_THREADS], cerr = wc[18*CF_WG_THREADS];
-			const uint32_t kf0 = L_HL >> 4;
+			const uint32_t kf0 = (L_HL >> 4) + 2u*fp;
 			const FitGeo g0 = fit_geo(id, kf0);
 			const uint32_t kf = g0.m6 ? 0u : kf0, mv = g0.m6 ? (L_HL >> 1) & 15u : (L_HL & 15u);
 			const FitGeo g = g0;
-			const bool act = L_SLOT_OK && L_HL < 64u && (g.m6 ? L_HL < 32u : kf < g.nfits) && cerr != 0u && cerr != 0xFFFFFFFFu;
+			const bool act = L_SLOT_OK && L_HL < 64u && (g.m6 ? (L_HL < 32u && !fp) : kf < g.nfits) && cerr != 0u && cerr != 0xFFFFFFFFu;
 			const Tex tx = make_tex(tile, plan, yccp, B_OFF, g.rot, g.chm);
 			const uint32_t yw[2] = {(g.chm & 7u) ? ywrg : 0u,
 				((g.chm & 7u) ? (ywba & 0xFFFFu) : 0u) | ((g.chm & 8u) ? (ywba & 0xFFFF0000u) : 0u)};
@@ -1520,6 +1567,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	const uint32_t win_id = cbase[win_lane + 19*CF_WG_THREADS];
 	return pack_block_group(cbase + win_lane, win_id, lane, pair);
 #undef H_ALPHA
+#undef H_GATE
 #undef TOP_LANE
 #undef B_TP
 #undef B_OFF
@@ -1623,7 +1671,7 @@ extern "C" hipError_t cfhip_launch_bc7(const cf_kparams* kp, int pixel_type, int
 	if (kp->batch)
 		grid = dim3(kp->total_wg, 1, 1);
 	dim3 block(CF_WG_THREADS, 1, 1);
-	const bool exh = kp->quality >= 4u;   // Highest: the wide (64-lane, two-stream) candidate set
+	const bool exh = kp->quality >= 3u;   // High, Highest: the wide (64-lane, two-stream) candidate set
 #define CF_BC7_LAUNCH(P, U, E) \
 	hipLaunchKernelGGL((cfhip_bc7_encode_kernel<P, U, E>), grid, block, 0, stream, *kp)
 	if (pixel_type == 0) {
