@@ -1088,7 +1088,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	unsigned long long gb = 0ull;
 #define H_GATE (((uint32_t)((pair && L_H) ? gb >> 32 : gb) & 1u) != 0u)
 	// some half is opaque (the two-mode rankings are only walked then)
-	const bool any_opaque = pair ? (((uint32_t)abal & 0xFFFFu) == 0u || ((uint32_t)(abal >> 32) & 0xFFFFu) == 0u) : !has_alpha;
+#define ANY_OPAQUE (pair ? (((uint32_t)abal & 0xFFFFu) == 0u || ((uint32_t)(abal >> 32) & 0xFFFFu) == 0u) : ((uint32_t)abal & 0xFFFFu) == 0u)
 	{
 		// second pass: the three-subset modes of an opaque block (Normal: mode 4 of an alpha-carrying one)
 		const uint32_t nstreams = WIDE ? (has_alpha ? 1u : 2u) : (kp.quality == 2u ? 2u : 1u);
@@ -1180,7 +1180,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 				}
 				// one ranking per mode of the group: modes 1 / 3 (alpha: mode 7 alone), modes 0 / 2; key = bits of
 				// residual + along / (4 (2^ib)^2), low 6 bits = the partition (oracle: encode_block, "qf")
-				const uint32_t nruns = (st == 1u || any_opaque) ? 2u : 1u;
+				const uint32_t nruns = (st == 1u || ANY_OPAQUE) ? 2u : 1u;
 				for (uint32_t run = 0; run < nruns; ++run) {
 					CF_FRESH_LANE(lane);
 					const float qf = (run == 0u && !(st == 0u && (H_ALPHA))) ? 1.0f/128.0f : 1.0f/32.0f;
@@ -1568,6 +1568,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	return pack_block_group(cbase + win_lane, win_id, lane, pair);
 #undef H_ALPHA
 #undef H_GATE
+#undef ANY_OPAQUE
 #undef TOP_LANE
 #undef B_TP
 #undef B_OFF
@@ -1589,10 +1590,11 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 // live in SGPRs), the lane id is re-read with a volatile mbcnt pair where a phase starts, the lane
 // roles are expressions of it instead of variables carried through the fit, and __shfl's hidden
 // lane-id arithmetic is gone (cf_bperm), and a block's three LDS pointers are one word offset (Tex) --
-// so every build but the perceptual Highest one fits 128 registers with private_segment_fixed_size 0
-// (that one: 160 registers, 3 waves).
+// so every linear-metric build fits 128 registers with private_segment_fixed_size 0.  Round 5 (second pass of the
+// 32-lane layout, gate and ranking state): the perceptual builds take 142 / 146 registers and run at 3 waves
+// (held to 128 the 32-lane one spilled one value, 8 B of scratch per lane).
 #ifndef CF_BC7_WAVES
-#define CF_BC7_WAVES(UNITW, WIDE) (((UNITW) || !(WIDE)) ? 4 : 3)
+#define CF_BC7_WAVES(UNITW, WIDE) ((UNITW) ? 4 : 3)
 #endif
 template <int PIX, bool UNITW, bool WIDE>
 __global__ void __launch_bounds__(CF_WG_THREADS)

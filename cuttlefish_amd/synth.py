@@ -157,3 +157,52 @@ def psnr_y(a: np.ndarray, b: np.ndarray) -> float:
     if mse == 0.0:
         return 99.0
     return float(10.0 * np.log10(255.0 * 255.0 / mse))
+
+
+def photo2(width: int, height: int, seed: int = 1) -> np.ndarray:
+    """A second opaque RGBA8 tile built the way a camera picture is: DETAILED luma (fine fractal texture,
+    many small soft-edged objects, luma-only sensor grain) over SMOOTHER chroma (fields with nothing finer
+    than a few texels, as chroma subsampling leaves them), converted Y Cb Cr -> R G B.  ``photo`` adds
+    independent +-2 LSB grain to each channel, which makes the three channels of a block uncorrelated at
+    the LSB level -- its BC7 blocks go to mode 5 (78 %) and never to modes 1 / 6; blocks of real
+    photographs (tests/golden/real_blocks.npz) split 37 / 22 / 18 / 17 % over modes 1 / 3 / 6 / 5, and
+    this tile is tuned to that split (tests/test_synth.py holds the histogram)."""
+    rng = np.random.default_rng(SEED_BASE + 7000 + seed)
+    # luma: large-scale light + fine texture whose strength itself varies over the picture
+    base = _fbm(rng, width, height, base_cell=192, octaves=5, persistence=0.5)
+    fine = _fbm(rng, width, height, base_cell=8, octaves=4, persistence=0.9) - 0.5
+    strength = np.clip(_fbm(rng, width, height, base_cell=96, octaves=3) * 2.6 - 1.0, 0.0, 1.0) ** 2
+    y = 0.08 + 0.84 * base + 1.3 * strength * fine
+    cb = 0.30 * (_fbm(rng, width, height, base_cell=160, octaves=3) - 0.5) + \
+        0.9 * strength * (_fbm(rng, width, height, base_cell=8, octaves=2) - 0.5)
+    cr = 0.30 * (_fbm(rng, width, height, base_cell=160, octaves=3) - 0.5) + \
+        0.9 * strength * (_fbm(rng, width, height, base_cell=8, octaves=2) - 0.5)
+    # soft-edged objects: their own luma offset and chroma, one-texel transition
+    nshapes = max(8, (width * height * 500) // (1 << 20))
+    yy, xx = np.mgrid[0:height, 0:width]
+    for i in range(nshapes):
+        cx, cy = int(rng.integers(0, width)), int(rng.integers(0, height))
+        rx = int(rng.integers(3, 48))
+        ry = int(rng.integers(3, 48))
+        x0, x1 = max(cx - rx - 2, 0), min(cx + rx + 2, width)
+        y0, y1 = max(cy - ry - 2, 0), min(cy + ry + 2, height)
+        if i & 1:
+            d = np.maximum(np.abs(xx[y0:y1, x0:x1] - cx) - rx, np.abs(yy[y0:y1, x0:x1] - cy) - ry)
+        else:
+            r = np.sqrt(((xx[y0:y1, x0:x1] - cx) / rx) ** 2 + ((yy[y0:y1, x0:x1] - cy) / ry) ** 2)
+            d = (r - 1.0) * min(rx, ry)
+        cov = np.clip(0.5 - d, 0.0, 1.0)              # coverage: 1 inside, 0 outside, a ramp one texel wide
+        dy, dcb, dcr = rng.random() * 0.5 - 0.25, rng.random() * 0.4 - 0.2, rng.random() * 0.4 - 0.2
+        y[y0:y1, x0:x1] += cov * dy
+        cb[y0:y1, x0:x1] = cb[y0:y1, x0:x1] * (1 - cov) + cov * dcb
+        cr[y0:y1, x0:x1] = cr[y0:y1, x0:x1] * (1 - cov) + cov * dcr
+    y += rng.normal(0.0, 1.5 / 255.0, size=(height, width))     # luma grain
+    # chroma noise a few texels wide (what a decoded JPEG carries): decorrelates the channels of flat blocks
+    cb += (4.0 / 255.0) * (_value_noise(rng, width, height, 3) - 0.5)
+    cr += (4.0 / 255.0) * (_value_noise(rng, width, height, 3) - 0.5)
+    img = np.empty((height, width, 4), np.float64)
+    img[..., 0] = y + 1.402 * cr
+    img[..., 1] = y - 0.344136 * cb - 0.714136 * cr
+    img[..., 2] = y + 1.772 * cb
+    img[..., 3] = 1.0
+    return np.clip(np.floor(np.clip(img, 0, 1) * 255.0 + 0.5), 0, 255).astype(np.uint8)

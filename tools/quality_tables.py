@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O          # noqa: E402
+import real_lib as R            # noqa: E402
 from cuttlefish_amd import synth    # noqa: E402
 
 NAMES = {29: "BC1", 31: "BC2", 32: "BC3", 33: "BC4", 34: "BC5", 35: "BC6H", 36: "BC7"}
@@ -37,8 +38,9 @@ def psnr_from_sse(sse, n_values):
     return 10.0 * np.log10(255.0 ** 2 * n_values / max(sse, 1e-9))
 
 
-def bc7_gap(count, rng, threads=None):
-    """-> [(label, [PSNR at Q0..Q4, PSNR of the wide search])] on `count` sampled blocks per content class."""
+def bc7_gap(count, rng, threads=None, kind="synth"):
+    """-> [(label, [PSNR at Q0..Q4, PSNR of the wide search])] on `count` blocks per content class: sampled from the
+    synthetic tile (kind "synth") or the first `count` of the real-photograph blocks (kind "real")."""
     from concurrent.futures import ThreadPoolExecutor
     L = O.lib()
     L.cfo_bc7_wide_search.restype = ctypes.c_uint32
@@ -48,12 +50,17 @@ def bc7_gap(count, rng, threads=None):
     threads = threads or min(8, os.cpu_count() or 1)
     rows = []
     for label, alpha in (("opaque", False), ("with alpha", True)):
-        img = synth.photo(512, 512, seed=21)
-        if alpha:
-            img[..., 3] = synth.photo(512, 512, seed=22)[..., 0]      # alpha that varies in every block
+        if kind == "real":
+            blocks = R.blocks4(count, alpha=alpha)
+            blocks = np.ascontiguousarray(blocks.reshape(len(blocks), 64))
         else:
-            img[..., 3] = 255
-        blocks = np.ascontiguousarray(sample_blocks(img, count, rng).astype(np.uint8).reshape(count, 64))
+            img = synth.photo(512, 512, seed=21)
+            if alpha:
+                img[..., 3] = synth.photo(512, 512, seed=22)[..., 0]      # alpha that varies in every block
+            else:
+                img[..., 3] = 255
+            blocks = np.ascontiguousarray(sample_blocks(img, count, rng).astype(np.uint8).reshape(count, 64))
+        count_ = len(blocks)
 
         def work(lo, hi):
             out = np.zeros(16, np.uint8)
@@ -69,14 +76,14 @@ def bc7_gap(count, rng, threads=None):
                     L.cfo_decode_bc7(out.ctypes.data, dec.ctypes.data)     # the ctypes calls release the GIL
                     sse[q] += float(((dec.astype(np.int64) - b.astype(np.int64)) ** 2).sum())
             return sse
-        step = (count + threads - 1) // threads
+        step = (count_ + threads - 1) // threads
         with ThreadPoolExecutor(threads) as ex:
-            sse = sum(ex.map(lambda k: work(k * step, min(count, (k + 1) * step)), range(threads)))
-        rows.append((label, [psnr_from_sse(s, count * 64) for s in sse]))
+            sse = sum(ex.map(lambda k: work(k * step, min(count_, (k + 1) * step)), range(threads)))
+        rows.append((label, [psnr_from_sse(s, count_ * 64) for s in sse]))
     return rows
 
 
-def etc_gap(count, rng, fmt=38, img=None, threads=None):
+def etc_gap(count, rng, fmt=38, img=None, threads=None, kind="synth"):
     """-> ([PSNR at Q0..Q4], PSNR of the TRUE optimum, modes the optimum uses) of ETC1 (fmt 37) / ETC2 RGB (38) on
     `count` sampled opaque blocks: cfo_etc_true_optimum enumerates every block the format can express."""
     from concurrent.futures import ThreadPoolExecutor
@@ -84,11 +91,15 @@ def etc_gap(count, rng, fmt=38, img=None, threads=None):
     L.cfo_etc_true_optimum.restype = ctypes.c_uint32
     L.cfo_etc_true_optimum.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     threads = threads or min(8, os.cpu_count() or 1)
-    if img is None:
-        img = synth.photo(512, 512, seed=21)
-    img = img.copy()
-    img[..., 3] = 255
-    blocks = np.ascontiguousarray(sample_blocks(img, count, rng).astype(np.uint8).reshape(count, 4, 4, 4))
+    if kind == "real":
+        blocks = R.blocks4(count)
+        count = len(blocks)
+    else:
+        if img is None:
+            img = synth.photo(512, 512, seed=21)
+        img = img.copy()
+        img[..., 3] = 255
+        blocks = np.ascontiguousarray(sample_blocks(img, count, rng).astype(np.uint8).reshape(count, 4, 4, 4))
 
     def work(i):
         out = np.zeros(8, np.uint8)
@@ -105,7 +116,7 @@ def etc_gap(count, rng, fmt=38, img=None, threads=None):
     return ps, psnr_from_sse(float(opt.sum()), count * 48)
 
 
-def astc_gap(count, rng, bw, bh, alpha=False, threads=None):
+def astc_gap(count, rng, bw, bh, alpha=False, threads=None, kind="synth"):
     """-> ([PSNR at Q0..Q4], PSNR of cfo_astc_wide_search) on `count` sampled bw x bh blocks of the photo content:
     every candidate class (one partition, a second plane on every component, every canonical 2 / 3 / 4-partition
     seed), every legal block mode, every endpoint-mode family forced and measured exactly, the best triples
@@ -117,12 +128,17 @@ def astc_gap(count, rng, bw, bh, alpha=False, threads=None):
     L.cfo_astc_wide_search.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     threads = threads or min(8, os.cpu_count() or 1)
     fmt = int(getattr(Format, "ASTC_%dx%d" % (bw, bh)))
-    side = 528                                                       # a multiple of 4, 6, 8 and 12
-    img = synth.photo(side, side, seed=21)
-    img[..., 3] = synth.photo(side, side, seed=22)[..., 0] if alpha else 255
-    ys = rng.integers(0, side // bh, count) * bh
-    xs = rng.integers(0, side // bw, count) * bw
-    blocks = np.ascontiguousarray(np.stack([img[y:y + bh, x:x + bw] for y, x in zip(ys, xs)]))
+    if kind == "real":
+        assert not alpha
+        blocks = R.blocks(bw, bh, count)
+        count = len(blocks)
+    else:
+        side = 528                                                       # a multiple of 4, 6, 8 and 12
+        img = synth.photo(side, side, seed=21)
+        img[..., 3] = synth.photo(side, side, seed=22)[..., 0] if alpha else 255
+        ys = rng.integers(0, side // bh, count) * bh
+        xs = rng.integers(0, side // bw, count) * bw
+        blocks = np.ascontiguousarray(np.stack([img[y:y + bh, x:x + bw] for y, x in zip(ys, xs)]))
     outs = np.zeros((count, 16), np.uint8)
 
     def work(i):
