@@ -79,6 +79,17 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
+def _oracle_flags():
+    """the compiler flags the timed oracle was built with (oracle/Makefile)"""
+    try:
+        for ln in open(os.path.join(ROOT, "oracle", "Makefile")):
+            if ln.startswith("CFLAGS"):
+                return "gcc " + ln.split("=", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(img, gpu_payload, width, quality, budget_s=12.0):
     """Time the CPU oracle on a strip of the tile (>= 10 s of host work on all usable cores) and
     check the GPU payload of the same strip against it.  This is the only place bench.py touches
@@ -116,6 +127,7 @@ def cpu_baseline(img, gpu_payload, width, quality, budget_s=12.0):
     dec_gpu = O.decode(got, fmt, width, rows * 4)
     return {
         "value": round(mpix / dt, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+        "flags": _oracle_flags(),
         "value_1_thread": round(rate1, 4),
         "scaling": {str(t): round(v, 3) for t, v in ladder.items()},
         "host_threads_visible": os.cpu_count(),
@@ -126,6 +138,51 @@ def cpu_baseline(img, gpu_payload, width, quality, budget_s=12.0):
         "psnr_rgba_gpu": round(synth.psnr(strip, dec_gpu), 3),
         "gpu_payload_equals_cpu": bool(np.array_equal(ref, got)),
     }
+
+
+def second_tile(ctx, torch, size, params, steps, stream, check):
+    """The same launch on a tile built like a camera picture (synth.photo2: detailed luma over smooth chroma; its
+    BC7 blocks split over the modes the way blocks of real photographs do, tests/test_synth.py) -- the headline
+    tile of SURVEY 8(d) sends 3 of 4 blocks to mode 5 and hardly any through the second pass of the search.
+    A 1024x1024 tile repeated 4 x 4 (the numpy generator takes seconds per Mpixel; a block's cost does not depend
+    on its neighbours).  check = True: PSNR and the payload of the first 64 rows against the CPU oracle."""
+    import numpy as np
+    from cuttlefish_amd import PixelType, synth
+    base = synth.photo2(1024, 1024, seed=1)
+    rep_ = max(1, size // 1024)
+    img = np.ascontiguousarray(np.tile(base, (rep_, rep_, 1)))
+    n = img.shape[0]
+    src = torch.from_numpy(img).cuda()
+    out = torch.empty((n // 4) * (n // 4) * 16, dtype=torch.uint8, device="cuda")
+    surf = [{"pixels": src.data_ptr(), "pixel_type": PixelType.RGBA8, "width": n, "height": n,
+             "row_pitch_bytes": n * 4, "out": out.data_ptr(), "out_capacity": out.numel()}]
+    for _ in range(2):
+        ctx.encode_device(surf, params, stream)
+    torch.cuda.synchronize()
+    ctx.profile_begin()
+    for _ in range(steps):
+        ctx.encode_device(surf, params, stream)
+    torch.cuda.synchronize()
+    kernel_ms, launches = ctx.profile_end()
+    k = kernel_ms / max(launches, 1)
+    res = {"tile": "synth.photo2 1024x1024 (seed 1) repeated %d x %d" % (rep_, rep_), "kernel_ms": round(k, 4),
+           "mpixels_per_s_kernel": round(n * n / 1e3 / k, 1), "launches": launches}
+    payload = out.cpu().numpy()
+    first = payload.reshape(-1, 16)[:, 0]
+    lowbit = first & (~first + 1)
+    res["bc7_mode_percent"] = {str(m): round(float((lowbit == (1 << m)).mean()) * 100.0, 1) for m in range(8)}
+    if check:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        from cuttlefish_amd import Format
+        rows = 64
+        strip = img[:rows * 4, :1024]
+        got = np.ascontiguousarray(payload.reshape(n // 4, n // 4, 16)[:rows, :256]).reshape(-1)
+        ref = O.encode(strip, int(Format.BC7), quality=int(params.quality), threads=usable_cpus())
+        dec = O.decode(got, int(Format.BC7), 1024, rows * 4)
+        res["psnr_rgb_gpu"] = round(synth.psnr(strip, dec, slice(0, 3)), 3)
+        res["gpu_payload_equals_cpu"] = bool(np.array_equal(ref, got))
+    return res
 
 
 PCIE_GBPS = 63.0             # x16 Gen5, one direction (MI355X_MICROARCH.md host link)
@@ -686,7 +743,7 @@ def run_c2(args, rank, local_rank, world, backend):
                                  "tiny by construction (DESIGN.md roofline section)"},
         }
         if size == SIZE:
-            ksub = "cfhip_bc7_encode_kernelILi0ELb1ELb%dE" % (1 if args.quality == 4 else 0)
+            ksub = "cfhip_bc7_encode_kernelILi0ELb1ELb%dE" % (1 if args.quality >= 3 else 0)
             view, traffic, source = valu_issue_view(ksub, avg_kernel_s, args.quality)
             line["roofline"]["valu_issue"] = view
             if traffic is not None:
@@ -700,6 +757,9 @@ def run_c2(args, rank, local_rank, world, backend):
             line["cpu_baseline"] = cpu_baseline(img, payload, size, args.quality)
         else:
             line["cpu_baseline"] = None
+        if world == 1 and size == SIZE:
+            line["second_tile"] = second_tile(ctx, torch, size, params, max(3, args.steps // 2), stream, not args.no_cpu_baseline)
+            line["second_tile"]["vs_headline_tile"] = round(line["second_tile"]["kernel_ms"] / (avg_kernel_s * 1e3), 3)
         if world == 1 and not args.no_end_to_end:
             torch.cuda.synchronize()
             line["end_to_end"] = end_to_end(ctx, img, params, out.cpu().numpy(), avg_kernel_s * 1e3)

@@ -198,8 +198,8 @@ def photo2(width: int, height: int, seed: int = 1) -> np.ndarray:
         cr[y0:y1, x0:x1] = cr[y0:y1, x0:x1] * (1 - cov) + cov * dcr
     y += rng.normal(0.0, 1.5 / 255.0, size=(height, width))     # luma grain
     # chroma noise a few texels wide (what a decoded JPEG carries): decorrelates the channels of flat blocks
-    cb += (4.0 / 255.0) * (_value_noise(rng, width, height, 3) - 0.5)
-    cr += (4.0 / 255.0) * (_value_noise(rng, width, height, 3) - 0.5)
+    cb += (5.0 / 255.0) * (_value_noise(rng, width, height, 3) - 0.5)
+    cr += (5.0 / 255.0) * (_value_noise(rng, width, height, 3) - 0.5)
     img = np.empty((height, width, 4), np.float64)
     img[..., 0] = y + 1.402 * cr
     img[..., 1] = y - 0.344136 * cb - 0.714136 * cr
