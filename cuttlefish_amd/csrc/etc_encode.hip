@@ -55,6 +55,11 @@ struct RgbOpts {
 	int radius;    // move rounds of the T / H search
 	int walk;      // base-colour walk of the half search: 1 / 3 / 9 / 27 / 27 + 6 descent steps
 	bool refine;   // false: Lowest -- no planar move rounds, no T/H modes
+	// round 5, from Normal up (oracle: search_half_lists / flip_candidates): both flips, the walk cut into lists
+	// {mean}, {8 neighbours of the best so far}, {the 18 other cube points}, each moved by least squares
+	int nlists;    // 0: the walk above on one flip
+	int lsq;       // least-squares steps per list
+	uint32_t gate; // blocks the first list leaves below this error stop there (0: none)
 };
 
 __device__ __forceinline__ uint32_t half_mask(uint32_t flip, uint32_t sub)
@@ -589,10 +594,293 @@ __device__ __forceinline__ void group_min8(unsigned long long& key, uint32_t& pa
 	}
 }
 
+// ---- the base-colour search from Normal up (twin of search_half_lists / flip_candidates in oracle/etc_codec.c) ----
+// One least-squares step of the lane's (half, table): the selectors base colour c gives, then the mean over the
+// counted texels of (texel - modifier of its selector) per channel: S[ch]; returns the count.
+template <bool UNITW>
+__device__ __forceinline__ void half_lsq_sums(const HalfTex& h, const RgbOpts& o, const int (&c)[3], int ma, int mb,
+	int (&S)[3])
+{
+	uint32_t ql[4], qh[4];
+	int nb[4];
+#pragma unroll
+	for (int v = 0; v < 4; ++v) {
+		const int m = v == 0 ? ma : (v == 1 ? mb : (v == 2 ? -ma : -mb));
+		const uint32_t q0 = (uint32_t)clamp255(c[0] + m), q1 = (uint32_t)clamp255(c[1] + m),
+			q2 = (uint32_t)clamp255(c[2] + m);
+		if (UNITW) {
+			ql[v] = q0 | (q1 << 8) | (q2 << 16);
+			qh[v] = 0;
+			nb[v] = -(int)__builtin_amdgcn_udot4(ql[v], ql[v], 0u, false);
+		} else {
+			const uint32_t w0 = (uint32_t)o.wt[0]*q0, w1 = (uint32_t)o.wt[1]*q1, w2 = (uint32_t)o.wt[2]*q2;
+			ql[v] = (2u*w0) | ((2u*w1) << 16);
+			qh[v] = 2u*w2;
+			nb[v] = -(int)(w0*q0 + w1*q1 + w2*q2);
+		}
+		if (v == 2 && o.punch)
+			nb[v] = -0x3FFFFFFF;
+		asm volatile("" : "+v"(nb[v]));
+	}
+	S[0] = S[1] = S[2] = 0;
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		int best = -0x7FFFFFFF, bm = 0;
+		const uint32_t prg = UNITW ? 0u : __builtin_amdgcn_perm(0u, h.px[j], 0x0C010C00u);
+		const uint32_t pb = UNITW ? 0u : h.px[j] >> 16;
+#pragma unroll
+		for (int v = 0; v < 4; ++v) {
+			const int m = v == 0 ? ma : (v == 1 ? mb : (v == 2 ? -ma : -mb));
+			const int k = UNITW ? (int)(__builtin_amdgcn_udot4(h.px[j], ql[v], 0u, false) << 1) + nb[v]
+				: wkey(prg, pb, ql[v], qh[v], nb[v]);
+			const bool better = k > best;       // first of the smallest error, like the oracle's e < best
+			best = better ? k : best;
+			bm = better ? m : bm;
+		}
+		if ((h.counted >> j) & 1u) {
+			S[0] += (int)(h.px[j] & 255u) - bm;
+			S[1] += (int)((h.px[j] >> 8) & 255u) - bm;
+			S[2] += (int)(h.px[j] >> 16) - bm;
+		}
+	}
+}
+
+// offsets of candidates 9 .. 26: the cube points that are neither the centre, an axis nor a grey-diagonal
+// neighbour, in (r, g, b) order; two bits per coordinate (offset + 1)
+__device__ const uint8_t k_etc_cube18[18] = {
+	// (-1,-1,0) (-1,-1,1) (-1,0,-1) (-1,0,1) (-1,1,-1) (-1,1,0) (-1,1,1) (0,-1,-1) (0,-1,1) (0,1,-1) (0,1,1)
+	// (1,-1,-1) (1,-1,0) (1,-1,1) (1,0,-1) (1,0,1) (1,1,-1) (1,1,0)
+	0x01 | (0 << 2) | (0 << 4), 0x02 | (0 << 2) | (0 << 4), 0x00 | (1 << 2) | (0 << 4), 0x02 | (1 << 2) | (0 << 4),
+	0x00 | (2 << 2) | (0 << 4), 0x01 | (2 << 2) | (0 << 4), 0x02 | (2 << 2) | (0 << 4), 0x00 | (0 << 2) | (1 << 4),
+	0x02 | (0 << 2) | (1 << 4), 0x00 | (2 << 2) | (1 << 4), 0x02 | (2 << 2) | (1 << 4), 0x00 | (0 << 2) | (2 << 4),
+	0x01 | (0 << 2) | (2 << 4), 0x02 | (0 << 2) | (2 << 4), 0x00 | (1 << 2) | (2 << 4), 0x02 | (1 << 2) | (2 << 4),
+	0x00 | (2 << 2) | (2 << 4), 0x01 | (2 << 2) | (2 << 4)
+};
+
+// The base-colour candidates of BOTH flips from the lanes' per-table bests (oracle: flip_candidates):
+// lane = (flip, family, half, table) holds (te, tq, tid); returns, uniform: the best candidate's error, id
+// (flip: differential, 2 + flip: individual), colours and tables.
+struct BaseBest { uint32_t err, id, qa, qb, ta, tb; };
+template <bool UNITW>
+__device__ __forceinline__ BaseBest base_combine(const HalfTex& ht8, const RgbOpts& o, uint32_t lane, uint32_t te,
+	uint32_t tq, uint32_t tid, int tma, int tmb)
+{
+	const uint32_t t = lane & 7u;
+	unsigned long long key = ((unsigned long long)te << 32) | (tid*8u + t);
+	uint32_t gq = tq;
+	group_min8(key, gq);
+	// group results as scalars: group = flip*4 + family*2 + half
+	uint32_t herr[8], hq[8], htb[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		herr[k] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), 8*k);
+		hq[k] = (uint32_t)__builtin_amdgcn_readlane((int)gq, 8*k);
+		htb[k] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, 8*k) & 7u;
+	}
+	// differential, both directions: the second colour pulled into the window of the first (q2p) and the
+	// first into the window around the second (q1p)
+	uint32_t q2p[2] = {0, 0}, q1p[2] = {0, 0};
+	bool inside[2];
+#pragma unroll
+	for (int f = 0; f < 2; ++f) {
+		const uint32_t a = hq[4*f], b = hq[4*f + 1];
+		bool in = true;
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			const int a_c = (int)((a >> (8*c)) & 255u), b_c = (int)((b >> (8*c)) & 255u);
+			int v = clampi(b_c, a_c - 4, a_c + 3);
+			v = clampi(v, 0, 31);
+			in = in && v == b_c;
+			q2p[f] |= (uint32_t)v << (8*c);
+			int u = clampi(a_c, b_c - 3, b_c + 4);
+			u = clampi(u, 0, 31);
+			q1p[f] |= (uint32_t)u << (8*c);
+		}
+		inside[f] = in;
+	}
+	uint32_t e2[2] = {herr[1], herr[5]}, t2[2] = {htb[1], htb[5]}, e1[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, t1[2] = {0, 0};
+	if (!inside[0] || !inside[1]) {
+		// one pass re-scores both clamped colours of both flips: the lanes of (flip, 5-bit, half 1) take q2p, those
+		// of (flip, 5-bit, half 0) q1p, each over its own table; the 4-bit lanes compute along and are ignored
+		const uint32_t f = lane >> 5, sub = (lane >> 3) & 1u;
+		const uint32_t qq = sub ? (f ? q2p[1] : q2p[0]) : (f ? q1p[1] : q1p[0]);
+		const int c[3] = {ex5((int)(qq & 255u)), ex5((int)((qq >> 8) & 255u)), ex5((int)((qq >> 16) & 255u))};
+		const uint32_t e = half_err_fast<UNITW>(ht8, o, c, tma, tmb);
+		unsigned long long k2 = ((unsigned long long)e << 32) | t;
+		uint32_t pay = 0;
+		group_min8(k2, pay);
+#pragma unroll
+		for (int f2 = 0; f2 < 2; ++f2) {
+			if (!inside[f2]) {
+				e1[f2] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k2 >> 32), 32*f2);
+				t1[f2] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k2, 32*f2) & 7u;
+				e2[f2] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k2 >> 32), 32*f2 + 8);
+				t2[f2] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k2, 32*f2 + 8) & 7u;
+			}
+		}
+	}
+	// the 8 x 8 pairs of the tables' own best colours inside the window: two pairs per lane of the flip's half
+	unsigned long long pk = ~0ull;
+	{
+		const uint32_t fbase = lane & 32u, hl = lane & 31u;
+#pragma unroll
+		for (uint32_t r = 0; r < 2u; ++r) {
+			const uint32_t pr = hl + 32u*r, i = pr >> 3, j = pr & 7u;
+			const int la = (int)((fbase + i) << 2), lb = (int)((fbase + 8u + j) << 2);
+			const uint32_t ea = (uint32_t)__builtin_amdgcn_ds_bpermute(la, (int)te), qa = (uint32_t)__builtin_amdgcn_ds_bpermute(la, (int)tq);
+			const uint32_t eb = (uint32_t)__builtin_amdgcn_ds_bpermute(lb, (int)te), qb = (uint32_t)__builtin_amdgcn_ds_bpermute(lb, (int)tq);
+			bool ok = ea != 0xFFFFFFFFu && eb != 0xFFFFFFFFu;
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				const int d = (int)((qb >> (8*c)) & 255u) - (int)((qa >> (8*c)) & 255u);
+				ok = ok && d >= -4 && d <= 3;
+			}
+			const unsigned long long k = ok ? (((unsigned long long)(ea + eb) << 32) | pr) : ~0ull;
+			pk = k < pk ? k : pk;
+		}
+		pk = cf_group_min_u64(pk, true, lane >> 5);
+	}
+	BaseBest bb;
+	bb.err = 0xFFFFFFFFu; bb.id = 0xFFFFFFFFu; bb.qa = bb.qb = bb.ta = bb.tb = 0;
+#pragma unroll
+	for (int f = 0; f < 2; ++f) {
+		uint32_t ed = herr[4*f] + e2[f], qa = hq[4*f], qb = q2p[f], ta = htb[4*f], tb = t2[f];
+		if (!inside[f] && e1[f] + herr[4*f + 1] < ed) {
+			ed = e1[f] + herr[4*f + 1]; qa = q1p[f]; qb = hq[4*f + 1]; ta = t1[f]; tb = htb[4*f + 1];
+		}
+		// the flip's best pair: wave-uniform per half -> scalars
+		const uint32_t pe = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pk >> 32), 32*f);
+		const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pk, 32*f);
+		if (pe != 0xFFFFFFFFu && pe < ed) {
+			const uint32_t i = (pp >> 3) & 7u, j = pp & 7u;
+			ed = pe; ta = i; tb = j;
+			qa = (uint32_t)__builtin_amdgcn_readlane((int)tq, 0);     // placeholders, replaced below
+			qb = qa;
+			// the colours of tables i / j of this flip (uniform i, j: a readlane with a scalar index)
+			qa = (uint32_t)__builtin_amdgcn_readlane((int)tq, (int)(32u*(uint32_t)f + i));
+			qb = (uint32_t)__builtin_amdgcn_readlane((int)tq, (int)(32u*(uint32_t)f + 8u + j));
+		}
+		if (ed < bb.err || (ed == bb.err && (uint32_t)f < bb.id)) {
+			bb.err = ed; bb.id = (uint32_t)f; bb.qa = qa; bb.qb = qb; bb.ta = ta; bb.tb = tb;
+		}
+	}
+	if (o.allow_indiv) {
+#pragma unroll
+		for (int f = 0; f < 2; ++f) {
+			const uint32_t ei = herr[4*f + 2] + herr[4*f + 3];
+			if (ei < bb.err || (ei == bb.err && 2u + (uint32_t)f < bb.id)) {
+				bb.err = ei; bb.id = 2u + (uint32_t)f;
+				bb.qa = hq[4*f + 2]; bb.qb = hq[4*f + 3]; bb.ta = htb[4*f + 2]; bb.tb = htb[4*f + 3];
+			}
+		}
+	}
+	return bb;
+}
+
+template <bool UNITW>
+__device__ __forceinline__ BaseBest base_search_lists(const uint32_t* tp, const RgbOpts& o, uint32_t lane)
+{
+	const uint32_t flip = lane >> 5, g = (lane >> 3) & 3u, t = lane & 7u;
+	const uint32_t fam4 = g >> 1, sub = g & 1u;
+	const int maxq = fam4 ? 15 : 31;
+	const uint32_t hmask = half_mask(flip, sub);
+	int n = 0, sum[3] = {0, 0, 0};
+#pragma unroll 1
+	for (uint32_t i = 0; i < 16u; ++i) {
+		if (((hmask & o.active) >> i) & 1u) {
+			const uint32_t p = tp[i];
+			++n;
+			sum[0] += (int)(p & 255u); sum[1] += (int)((p >> 8) & 255u); sum[2] += (int)((p >> 16) & 255u);
+		}
+	}
+	uint32_t q0p = 0;
+#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		const int mean = n ? (int)cf_div_small((uint32_t)(2*sum[c] + n), (uint32_t)(2*n)) : 0;
+		q0p |= (uint32_t)((mean*maxq + 127)/255) << (8*c);
+	}
+	const HalfTex ht8 = load_half(tp, o, flip, sub);
+	const int tma = o.punch ? 0 : k_etc_mod[t][0], tmb = k_etc_mod[t][1];
+	const bool live = !fam4 || o.allow_indiv;
+	uint32_t te = 0xFFFFFFFFu, tq = 0, tid = 0;
+	BaseBest bb;
+	bb.err = 0xFFFFFFFFu; bb.id = 0; bb.qa = bb.qb = bb.ta = bb.tb = 0;
+#pragma unroll 1
+	for (int l = 0; l < o.nlists; ++l) {
+		const int lo = l == 0 ? 0 : (l == 1 ? 1 : 9), hi = l == 0 ? 1 : (l == 1 ? 9 : 27);
+		const uint32_t centre = l == 0 ? q0p : tq;        // later lists walk around the table's best so far
+		uint32_t le = 0xFFFFFFFFu, lq = 0, lid = 0;
+#pragma unroll 1
+		for (int cand = lo; cand < hi; ++cand) {
+			int d0 = 0, d1 = 0, d2 = 0;
+			if (cand == 1 || cand == 2)
+				d0 = d1 = d2 = cand == 1 ? 1 : -1;
+			else if (cand > 2 && cand < 9) {
+				const int ax = (cand - 3) >> 1, dd = ((cand - 3) & 1) ? 1 : -1;
+				d0 = ax == 0 ? dd : 0; d1 = ax == 1 ? dd : 0; d2 = ax == 2 ? dd : 0;
+			} else if (cand >= 9) {
+				const uint32_t pk = k_etc_cube18[cand - 9];
+				d2 = (int)(pk & 3u) - 1; d1 = (int)((pk >> 2) & 3u) - 1; d0 = (int)((pk >> 4) & 3u) - 1;
+			}
+			const int q[3] = {clampi((int)(centre & 255u) + d0, 0, maxq), clampi((int)((centre >> 8) & 255u) + d1, 0, maxq),
+				clampi((int)((centre >> 16) & 255u) + d2, 0, maxq)};
+			const int c[3] = {ex45(q[0], fam4), ex45(q[1], fam4), ex45(q[2], fam4)};
+			const uint32_t e = half_err_fast<UNITW>(ht8, o, c, tma, tmb);
+			if (e < le) {
+				le = e; lid = (uint32_t)cand;
+				lq = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16);
+			}
+		}
+		// least-squares steps; a lane whose step did not improve stops (the same selectors again)
+		bool going = n != 0;
+#pragma unroll 1
+		for (int step = 0; step < o.lsq; ++step) {
+			if (__ballot(going && live) == 0ull)
+				break;
+			const int c0[3] = {ex45((int)(lq & 255u), fam4), ex45((int)((lq >> 8) & 255u), fam4), ex45((int)((lq >> 16) & 255u), fam4)};
+			int S[3];
+			half_lsq_sums<UNITW>(ht8, o, c0, tma, tmb, S);
+			int q[3], c[3];
+			const uint32_t den = 510u*(uint32_t)(n ? n : 1);
+#pragma unroll
+			for (int ch = 0; ch < 3; ++ch) {
+				int num = 2*S[ch]*maxq + 255*n;
+				num = num < 0 ? 0 : num;
+				q[ch] = (int)cf_div_small((uint32_t)num, den);
+				q[ch] = q[ch] > maxq ? maxq : q[ch];
+				c[ch] = ex45(q[ch], fam4);
+			}
+			const uint32_t e = half_err_fast<UNITW>(ht8, o, c, tma, tmb);
+			const bool better = going && e < le;
+			le = better ? e : le;
+			lid = better ? 100u + 4u*(uint32_t)l + (uint32_t)step : lid;
+			lq = better ? ((uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16)) : lq;
+			going = better;
+		}
+		if (live && (le < te || (le == te && lid < tid))) {
+			te = le; tid = lid; tq = lq;
+		}
+		// after the first list: blocks it already codes below the gate stop here (oracle: rgb_opts.gate)
+		if (l == 0 && o.nlists > 1 && o.gate) {
+			bb = base_combine<UNITW>(ht8, o, lane, te, tq, tid, tma, tmb);
+			if (bb.err < o.gate)
+				return bb;
+		}
+	}
+	return base_combine<UNITW>(ht8, o, lane, te, tq, tid, tma, tmb);
+}
+
 // Returns the 8-byte RGB block (memory order: x = bytes 0..3, y = bytes 4..7) in every lane.
 __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o, uint32_t lane)
 {
-	// The flip is chosen BEFORE the search (oracle: cfo_etc_rgb_search), by the scatter the halves would
+	const bool unitw = o.wt[0] == 1 && o.wt[1] == 1 && o.wt[2] == 1;   // uniform
+	// the best base-colour candidate: error, id (flip: differential, 2 + flip: individual), colours, tables
+	uint32_t best_err, best_id, qa, qb, ta, tb;
+	if (o.nlists) {
+		const BaseBest bb = unitw ? base_search_lists<true>(tp, o, lane) : base_search_lists<false>(tp, o, lane);
+		best_err = bb.err; best_id = bb.id; qa = bb.qa; qb = bb.qb; ta = bb.ta; tb = bb.tb;
+	} else {
+	// Lowest, Low: the flip is chosen BEFORE the search (oracle: cfo_etc_rgb_search), by the scatter the halves would
 	// be left with: sc[f] = sum over halves s, channels c of w_c (n_s sum p^2 - (sum p)^2) over the
 	// texels that carry weight; ties -> flip 0.  One texel per lane, sums inside the 16-lane rows;
 	// the second half of a flip is the total minus the first.
@@ -653,7 +941,6 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 	}
 	uint32_t berr = 0xFFFFFFFFu, bcand = 0, bq = 0;
 	const HalfTex ht8 = load_half(tp, o, flip, sub);
-	const bool unitw = o.wt[0] == 1 && o.wt[1] == 1 && o.wt[2] == 1;   // uniform
 	const int tma = o.punch ? 0 : k_etc_mod[t][0], tmb = k_etc_mod[t][1];
 	if (!fam4 || o.allow_indiv) {
 		// candidates in id order (oracle: search_half): the quantised half mean; + its two grey-
@@ -766,10 +1053,15 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 		t2 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k2, 8) & 7u;
 	}
 	// candidates in id order: flip (differential), 2 + flip (individual) -- the two-flip numbering
-	uint32_t best_err = herr[0] + e2, best_id = flip;
+	best_err = herr[0] + e2; best_id = flip;
+	qa = hq[0]; qb = q2p; ta = ht[0]; tb = t2;
 	if (o.allow_indiv) {
 		const uint32_t ei = herr[2] + herr[3];
-		if (ei < best_err) { best_err = ei; best_id = 2u + flip; }
+		if (ei < best_err) {
+			best_err = ei; best_id = 2u + flip;
+			qa = hq[2]; qb = hq[3]; ta = ht[2]; tb = ht[3];
+		}
+	}
 	}
 	if (o.allow_planar) {
 		PlanarQ pq;
@@ -851,15 +1143,7 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 			return pack_planar(pq);
 	}
 	const bool differential = best_id < 2u;
-	const uint32_t bf = flip;
-	uint32_t qa, qb, ta, tb;
-	if (differential) {
-		qa = hq[0]; qb = q2p;
-		ta = ht[0]; tb = t2;
-	} else {
-		qa = hq[2]; qb = hq[3];
-		ta = ht[2]; tb = ht[3];
-	}
+	const uint32_t bf = best_id & 1u;
 	// selectors: lane L < 16 owns the texel whose bits sit at position k = L of the two
 	// selector planes (x = k >> 2, y = k & 3); the planes come out of two ballots
 	uint32_t lo;
@@ -1060,7 +1344,7 @@ __device__ __forceinline__ uint32_t r11_word(float f, bool snorm)
 template <int PIX, int FMT, bool SNORM>
 __global__ void __launch_bounds__(CF_WG_THREADS)
 #ifndef CF_ETC_MINW
-#define CF_ETC_MINW 5
+#define CF_ETC_MINW 4
 #endif
 __attribute__((amdgpu_waves_per_eu(CF_ETC_MINW, 8)))
 cfhip_etc_encode_kernel(cf_kparams kp)
@@ -1126,6 +1410,10 @@ cfhip_etc_encode_kernel(cf_kparams kp)
 		o.radius = q >= 4u ? 4 : (q >= 3u ? 3 : (q >= 2u ? 2 : 0));    // T / H move rounds (oracle: effort_radius)
 		o.walk = q > 4u ? 4 : (int)q;                                  // five distinct effort levels
 		o.refine = q >= 1u;
+		// oracle: cfo_encode_etc_block, "Round 5"
+		o.nlists = q >= 3u ? 3 : (q == 2u ? 2 : 0);
+		o.lsq = q >= 4u ? 2 : 1;
+		o.gate = q == 2u ? 256u : (q == 3u ? 128u : 0u);
 		uint2 w0 = make_uint2(0, 0), w1 = make_uint2(0, 0);
 		if (FMT == E_ETC1) {
 			o.allow_indiv = true;

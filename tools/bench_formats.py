@@ -17,13 +17,20 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--formats", default="", help="comma list of Format names (default: all)")
     ap.add_argument("--qualities", default="0,2,4")
+    ap.add_argument("--tile", default="photo", choices=["photo", "photo2"],
+                    help="LDR tile: synth.photo (SURVEY 8d) or the camera-like synth.photo2 (1024x1024 repeated)")
     args = ap.parse_args()
     import numpy as np
     import torch
     from cuttlefish_amd import Context, Format, PixelType, Type, make_params, payload_size, synth
 
     n = args.size
-    ldr = torch.from_numpy(synth.photo(n, n, seed=1)).cuda()
+    if args.tile == "photo2":
+        base = synth.photo2(min(n, 1024), min(n, 1024), seed=1)
+        rep = max(1, n // 1024)
+        ldr = torch.from_numpy(np.ascontiguousarray(np.tile(base, (rep, rep, 1)))).cuda()
+    else:
+        ldr = torch.from_numpy(synth.photo(n, n, seed=1)).cuda()
     hdr = torch.from_numpy(synth.hdr_probe(n, n, seed=4).view(np.uint16).astype(np.int32)
                            .astype(np.uint16).view(np.int16)).cuda()
     hdr32 = torch.from_numpy(synth.hdr_probe(n, n, seed=4).astype(np.float32)).cuda()
@@ -65,7 +72,7 @@ def main():
             ms, launches = ctx.profile_end()
             ms /= launches
             algo = n * n * texel + nbytes
-            rows.append({"format": fmt.name, "type": typ.name, "quality": q,
+            rows.append({"format": fmt.name, "type": typ.name, "quality": q, "tile": args.tile,
                          "kernel_ms": round(ms, 3), "mpix_s": round(n * n / ms / 1e3, 1),
                          "algo_gb_s": round(algo / ms / 1e6, 3)})
             print(json.dumps(rows[-1]), flush=True)
