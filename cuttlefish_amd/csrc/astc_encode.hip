@@ -80,7 +80,7 @@ __device__ __forceinline__ Ladder ladder(uint32_t q)
 		case 0: return {8, 0, 0, 0, 0, 0};
 		case 1: return {8, 16, 2, 0, 0, 1};
 		case 2: return {6, 64, 4, 2, 0, 2};
-		case 3: return {6, 256, 4, 2, 0, 2};   // K = the deepest list of High's uneven allocation (high_k)
+		case 3: return {8, 256, 4, 2, 0, 2};   // round 5: the whole wavefront, Highest's first pass (8 candidates x 8 configs)
 		default: return {8, 256, 14, 9, 6, 2};
 	}
 }
@@ -927,7 +927,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	uint8_t* sh_ctab = lds + off; off += (hdrf ? 6u : 2u)*17u*256u;
 	uint8_t* sh_wtab = lds + off; off += 2016u;
 	const uint32_t slot_bytes = ((10u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
-	const uint32_t wave_bytes = ((((col_rows + 1u)/2u)*256u + 15u) & ~15u) + (kp.quality <= 3u ? 2u : 1u)*slot_bytes;
+	const uint32_t wave_bytes = ((((col_rows + 1u)/2u)*256u + 15u) & ~15u) + (kp.quality <= 2u ? 2u : 1u)*slot_bytes;
 	// the wave index as a scalar: block indices, the pair flag and the block loop counter live in SGPRs
 	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	uint32_t lane = threadIdx.x & 63u;
@@ -1059,7 +1059,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	const Ladder lad = ladder(q);
 	// up to High a block needs 32 lanes (8 candidates; High: 6,6,6,6,2,2,2,2 configs, the others 4 each):
 	// two blocks share a wavefront
-	const bool can_pair = q <= 3u;
+	const bool can_pair = q <= 2u;      // High takes the whole wavefront since round 5 (oracle: encode_core, gsz)
 	uint32_t cw[4] = {1u, 1u, 1u, 1u};
 	if (aflags & ASTC_FLAG_PERCEPTUAL) { cw[0] = 11u; cw[1] = 21u; cw[2] = 4u; cw[3] = 16u; }
 	const uint32_t recip_n = 65536u/n;                                          // x / n as (x * recip_n) >> 16, like the oracle
@@ -1357,8 +1357,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		__builtin_amdgcn_wave_barrier();
 		// Normal, High: the first pass only (their 4 + 2 seeds already are the head of the walk); HDR: four
 		// candidates of 8 configs (oracle: the config ranking is nearly flat on HDR content)
-		if ((q == 2u || q == 3u) && npc > (HDR ? 4u : 8u))
+		if (q == 2u && npc > (HDR ? 4u : 8u))
 			npc = HDR ? 4u : 8u;
+		if (q == 3u && npc > 8u)
+			npc = 8u;
 		if (q >= 4u) {
 			// Highest (one block per wave) walks the same head as High: 4 two-partition seeds, then 2
 			// three-partition seeds, then the rest in the old order (oracle: ASTC_HEAD2 / ASTC_HEAD3).
@@ -1380,8 +1382,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		// ---- passes of (gsz / K) candidates x K configs ----
 		// Normal, High: candidate j of the pass has 6 (j < 4) or 2 lanes, side by side: 32 lanes; the other
 		// levels give every candidate 8
-		const bool varK = (q == 2u || q == 3u) && !HDR;
-		const uint32_t K = (HDR && (q == 2u || q == 3u)) ? 8u : lad.K, kshift = K == 2u ? 1u : (K == 4u ? 2u : 3u), per_pass = varK ? 8u : gsz >> kshift;
+		const bool varK = q == 2u && !HDR;
+		const uint32_t K = (HDR && q == 2u) ? 8u : lad.K, kshift = K == 2u ? 1u : (K == 4u ? 2u : 3u), per_pass = varK ? 8u : gsz >> kshift;
 		unsigned long long bestkey = ~0ull;
 		const uint32_t alpha_i = has_alpha ? 1u : 0u;
 		uint32_t npc_max = npc;
@@ -1702,6 +1704,13 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				uint8_t* colp1 = colbase + (dual ? PW*256u : 0u);
 				const uint8_t* prow = S.pid + j*npad;
 				const bool byp = P <= 1u;
+				// Refinement rounds (oracle: encode_core, "rounds"): after a lane's result its ideal weights are
+				// re-projected on ITS decoded endpoints, decimated, quantised and the endpoints refitted; a round
+				// that does not lower the lane's exact error ends the lane's refinement.  Every round ends with the
+				// group argmin, so a lane's earlier (better) result stays parked when a later round loses.
+				const uint32_t nrounds = HDR ? 0u : (q == 2u ? 1u : (q == 3u ? 2u : (q >= 4u ? 3u : 0u)));
+				bool going = active;
+				unsigned long long prev_err = ~0ull;
 				if (active) {
 					// 1. decimate + quantise
 					for (uint32_t k = 0; k <= PW*planes; ++k)
@@ -1720,6 +1729,15 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					for (uint32_t pl = 0; pl < planes; ++pl)
 						normalise_rows<true>(pl ? colp1 : colbase, den, PW, sh.wnu + wq*68u);
 					PROF_MARK(6)   // B: decimate + quantise
+				}
+#pragma unroll 1
+				for (uint32_t rnd = 0;; ++rnd) {
+				err = ~0ull; r_cem = 0; r_lv = 0; r_ncv = 0;
+#pragma unroll
+				for (int k = 0; k < 5; ++k) r_cv[k] = 0;
+				// the lane's decoded endpoints (bytes r, g, b, a of partition k): what the next round projects on
+				uint32_t D0[4] = {0, 0, 0, 0}, D1[4] = {0, 0, 0, 0};
+				if (going) {
 					if (HDR) {
 						// ---- HDR: the pair is fitted and priced on the 16-bit LNS texels through the real
 						// encodings (oracle: hdr_phase_b, same arithmetic) ----
@@ -2226,7 +2244,6 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						if (okk[o] && est[o] < best_est) { best_est = est[o]; best_opt = o; best_lv = (uint32_t)lvs[o]; }
 					if (best_opt >= 0) {
 						// materialise the chosen option: decoded endpoints + stored values
-						uint32_t D0[4] = {0, 0, 0, 0}, D1[4] = {0, 0, 0, 0};
 						const uint32_t nv = (has_alpha ? 8u : 6u) - (best_opt == 3 ? 0u : 2u*(uint32_t)best_opt);
 #pragma unroll 1
 						for (uint32_t p = 0; p < P; ++p) {
@@ -2327,10 +2344,15 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					}
 					}
 				}
-				if (pass == 0u && !pair) {
+				if (pass == 0u && !pair && rnd == 0u) {
 					e1min = cf_group_min_u64(P == 1u ? err : ~0ull, false, 0u);
 					e2min = cf_group_min_u64(P == 2u ? err : ~0ull, false, 0u);
 				}
+				// a refined result counts only when it lowers the lane's own error
+				if (rnd > 0u && !(err < prev_err))
+					err = ~0ull;
+				going = going && err != ~0ull;
+				prev_err = going ? err : prev_err;
 				PROF_MARK(9)   // B: exact error (+ idle lanes waiting)
 				// ---- argmin (error, id); the winner parks its result in the block's slot ----
 				const uint32_t id = pass*64u + hl;
@@ -2367,6 +2389,52 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					}
 				}
 				__builtin_amdgcn_wave_barrier();
+				if (rnd >= nrounds || __ballot(going) == 0ull)
+					break;
+				// the next round's weights (oracle: wide_reproject): texel i projects on the line D0 -> D1 of its
+				// partition, T = round(64 t / dd) clamped to 0 .. 64, straight into the decimation
+				if (going) {
+					for (uint32_t k = 0; k <= PW*planes; ++k)
+						*reinterpret_cast<uint32_t*>(colbase + k*256u) = 0u;
+#pragma unroll 1
+					for (uint32_t pl = 0; pl < planes; ++pl) {
+						uint8_t* cb = pl ? colp1 : colbase;
+#pragma unroll 2
+						for (uint32_t i = 0; i < n; ++i) {
+							const uint2 rec = inf[i];
+							const uint32_t part = byp ? 0u : prow[i];
+							const uint32_t q0 = part == 0u ? D0[0] : (part == 1u ? D0[1] : (part == 2u ? D0[2] : D0[3]));
+							const uint32_t q1 = part == 0u ? D1[0] : (part == 1u ? D1[1] : (part == 2u ? D1[2] : D1[3]));
+							const uint32_t p = tp[i];
+							int t = 0;
+							uint32_t dd = 0;
+#pragma unroll
+							for (uint32_t c = 0; c < 4u; ++c) {
+								const bool use = c < nc && (!dual || ((c == ccs) == (pl == 1u)));
+								const int e0c = (int)((q0 >> (8u*c)) & 255u), dv = (int)((q1 >> (8u*c)) & 255u) - e0c;
+								const int pc = (int)((p >> (8u*c)) & 255u);
+								t += use ? (pc - e0c)*dv*(int)cw[c] : 0;
+								dd += use ? (uint32_t)(dv*dv)*cw[c] : 0u;
+							}
+							uint32_t Tw = 0;
+							if (t > 0 && dd > 0u) {
+								const uint32_t tc = (uint32_t)t > dd ? dd : (uint32_t)t;
+								const uint32_t num = 128u*tc + dd, dn = 2u*dd;
+								uint32_t qq = (uint32_t)((float)num*__builtin_amdgcn_rcpf((float)dn));
+								int r = (int)num - (int)(qq*dn);
+								qq = r < 0 ? qq - 1u : qq;
+								r = r < 0 ? r + (int)dn : r;
+								qq = r >= (int)dn ? qq + 1u : qq;
+								Tw = qq > 64u ? 64u : qq;
+							}
+							decim_add(cb, rec.x, rec.y, Tw);
+						}
+					}
+#pragma unroll 1
+					for (uint32_t pl = 0; pl < planes; ++pl)
+						normalise_rows<true>(pl ? colp1 : colbase, den, PW, sh.wnu + wq*68u);
+				}
+				}
 			}
 		}
 
@@ -2527,7 +2595,7 @@ static size_t astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality, 
 	off += (hdr ? 6u : 2u)*17u*256u + 2016u;
 	(void)wcached;
 	const uint32_t slot_bytes = ((10u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
-	const uint32_t wave_bytes = ((((h->col_rows + 1u)/2u)*256u + 15u) & ~15u) + (quality <= 3u ? 2u : 1u)*slot_bytes;
+	const uint32_t wave_bytes = ((((h->col_rows + 1u)/2u)*256u + 15u) & ~15u) + (quality <= 2u ? 2u : 1u)*slot_bytes;
 	return (size_t)off + nwaves*(size_t)wave_bytes;
 }
 

@@ -58,6 +58,32 @@ def content(size):
     return [np.ascontiguousarray(i) for i in out]
 
 
+# Real photographs for the census (round 5): pictures that sit in the build container and are NOT the ones the
+# quality fixture (tests/golden/real_blocks.npz) samples its blocks from, so the fixture stays held out.
+SK = "/opt/conda/lib/python3.9/site-packages/skimage/data/"
+REAL_CENSUS = [SK + "motorcycle_right.png", SK + "ihc.png", SK + "retina.jpg", SK + "hubble_deep_field.jpg",
+               SK + "color.png", "/opt/conda/lib/python3.9/site-packages/imageio/resources/images/chelsea.png"]
+
+
+def real_content(size):
+    """centre crops (size x size, opaque) of the census photographs; retina / hubble halved first (they are large)"""
+    from PIL import Image
+    out = []
+    for path in REAL_CENSUS:
+        if not os.path.exists(path):
+            continue
+        im = Image.open(path).convert("RGB")
+        if min(im.size) > 4*size:
+            im = im.resize((im.size[0]//2, im.size[1]//2), Image.BOX)
+        a = np.asarray(im)
+        if a.shape[0] < size or a.shape[1] < size:
+            continue
+        y0, x0 = (a.shape[0] - size)//2, (a.shape[1] - size)//2
+        crop = a[y0:y0 + size, x0:x0 + size]
+        out.append(np.ascontiguousarray(np.dstack([crop, np.full((size, size), 255, np.uint8)])))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=240)
@@ -76,11 +102,16 @@ def main():
                          "(gradients -0.9 dB).  6x6: the full census adds the two-plane 6x5 / 5x6 grids (+0.2 dB on the\n"
                          "photo image) and a wave then waits for the lane with the 60-weight column: 6x6 Normal 2.49 ->\n"
                          "2.73 ms -- BASELINE config 3 is quoted on 6x6, its list stays")
+    ap.add_argument("--real", action="store_true", help="add the census photographs (REAL_CENSUS) and synth.photo2 to the content")
+    ap.add_argument("--only", default="", help="footprints to run the census for (others keep their rows), e.g. 6x6,4x4")
     args = ap.parse_args()
     L = O.lib()
     L.cfo_astc_census_image.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     imgs = content(args.size)
+    if args.real:
+        imgs += real_content(args.size) + [synth.photo2(args.size, args.size, seed=s) for s in (301, 302)]
+    only = [FP.index(tuple(int(v) for v in x.split("x"))) for x in args.only.split(",") if x]
     table = np.zeros((14, 10, 64), np.uint16)
 
     def census(fi):
@@ -91,7 +122,7 @@ def main():
         return fi, counts.reshape(10, 4096)
 
     with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
-        for fi, counts in ex.map(census, range(14)):
+        for fi, counts in ex.map(census, only if only else range(14)):
             # the library keeps 24 weight grids' infill tables in LDS per footprint: pick them by
             # their share of the wins (each class normalised, classes weighted by how often their
             # candidates win a block: one partition 3, two partitions 2, dual plane 1, three 1, four 0.5)
@@ -118,6 +149,9 @@ def main():
         bw, bh = [int(v) for v in name.split("x")]
         table[FP.index((bw, bh))] = 0
     keep = [x for x in args.keep.split(",") if x]
+    if only:
+        keep = ["%dx%d" % FP[fi] for fi in range(14) if fi not in only]
+        args.static_for = ",".join(x for x in args.static_for.split(",") if x and FP.index(tuple(int(v) for v in x.split("x"))) in only)
     if keep:
         import re
         rows = re.findall(r"\{([0-9, ]+)\},", open(os.path.join(ROOT, "oracle", "astc_cfg_rank.h")).read())
