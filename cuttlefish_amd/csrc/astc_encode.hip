@@ -1686,6 +1686,21 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			uint32_t r_cem = 0, r_lv = 0, r_ncv = 0, r_cfg = 0;
 			uint32_t r_cv[5] = {0, 0, 0, 0, 0};
 			{
+				// Refinement rounds (oracle: encode_core, "rounds"): after a lane's result its ideal weights are
+				// re-projected on ITS decoded endpoints, decimated, quantised and the endpoints refitted; a round
+				// that does not lower the lane's exact error ends the lane's refinement.  Every round ends with the
+				// group argmin, so a lane's earlier (better) result stays parked when a later round loses.
+				const uint32_t nrounds = HDR ? 0u : (q == 2u ? 1u : (q == 3u ? 2u : (q >= 4u ? 3u : 0u)));
+				bool going = false;
+				unsigned long long prev_err = ~0ull;
+#pragma unroll 1
+				for (uint32_t rnd = 0;; ++rnd) {
+				// the lane id and every role that follows from it are formed again per round (a volatile mbcnt pair):
+				// held across the rounds they were 25 spilled registers in the 168-register build
+				uint32_t lane;
+				asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+				const uint32_t h = pair ? lane >> 5 : 0u, hl = pair ? (lane & 31u) : lane;
+				uint8_t* colbase = wbase + lane*4u;
 				// High: lanes 0..23 = candidates 0..3 x 6 configs ((hl * 43) >> 8 == hl / 6 there), lanes 24..31 =
 				// candidates 4..7 x 2; a lone block in a 64-lane group leaves lanes 32.. idle
 				const uint32_t jv = hl < 24u ? (hl*43u) >> 8 : (hl < 32u ? 4u + ((hl - 24u) >> 1) : 8u);
@@ -1704,13 +1719,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				uint8_t* colp1 = colbase + (dual ? PW*256u : 0u);
 				const uint8_t* prow = S.pid + j*npad;
 				const bool byp = P <= 1u;
-				// Refinement rounds (oracle: encode_core, "rounds"): after a lane's result its ideal weights are
-				// re-projected on ITS decoded endpoints, decimated, quantised and the endpoints refitted; a round
-				// that does not lower the lane's exact error ends the lane's refinement.  Every round ends with the
-				// group argmin, so a lane's earlier (better) result stays parked when a later round loses.
-				const uint32_t nrounds = HDR ? 0u : (q == 2u ? 1u : (q == 3u ? 2u : (q >= 4u ? 3u : 0u)));
-				bool going = active;
-				unsigned long long prev_err = ~0ull;
+				r_cfg = oi;
+				if (rnd == 0u)
+					going = active;
+				if (rnd == 0u)
 				if (active) {
 					// 1. decimate + quantise
 					for (uint32_t k = 0; k <= PW*planes; ++k)
@@ -1730,8 +1742,6 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						normalise_rows<true>(pl ? colp1 : colbase, den, PW, sh.wnu + wq*68u);
 					PROF_MARK(6)   // B: decimate + quantise
 				}
-#pragma unroll 1
-				for (uint32_t rnd = 0;; ++rnd) {
 				err = ~0ull; r_cem = 0; r_lv = 0; r_ncv = 0;
 #pragma unroll
 				for (int k = 0; k < 5; ++k) r_cv[k] = 0;
