@@ -251,3 +251,35 @@ def test_astc_ladder_against_the_wide_search():
     ew = float(((dec_w.astype(np.int64) - blk)[..., :3]**2).sum())
     ee = float(((dec_e.astype(np.int64) - blk)[..., :3]**2).sum())
     assert ew <= 64*3*4 and ee <= 64*3*4, (ew, ee)      # both within +-2 per channel on average: the exact grid
+
+
+def test_bc1_and_bc3_colour_blocks_against_the_true_optimum():
+    """tests/golden/bc1_optimum.npz: per block the smallest error ANY BC1 colour block can reach -- all 2^32 RGB565
+    endpoint pairs walked on the GPU by tools/bounds/bc1_optimum.hip (tools/bc1_bound.py, round 5; 8 s per 512
+    blocks on an MI355X): E4 over the four-colour palettes (BC2 / BC3 colour, BC1 in c0 > c1 order), E3 over the
+    three-colour + black ones.  First 512 opaque blocks of the real-photograph fixture and 512 sampled blocks of the
+    synthetic tile.  Nothing the encoder emits beats it (encoder and decoder agree), and the ladder: real BC1 0.054 /
+    0.019 / 0.011 dB at Normal / High / Highest, BC3 colour 0.098 / 0.019 / 0.011; synthetic 0.23 / 0.09 / 0.09."""
+    import real_lib as R
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bc1_optimum.npz"))
+    n = int(fx["blocks"])
+    qt = _quality_tables()
+    img = synth.photo(512, 512, seed=21)
+    img[..., 3] = 255
+    rng = np.random.default_rng(20260929)
+    ys = rng.integers(0, 128, n) * 4
+    xs = rng.integers(0, 128, n) * 4
+    sets = {"real": R.blocks4(n), "synth": np.stack([img[y:y + 4, x:x + 4] for y, x in zip(ys, xs)])}
+    for name, blocks in sets.items():
+        strip = R.strip(np.ascontiguousarray(blocks))
+        e4, e3 = fx[name + "_e4"].astype(np.float64), fx[name + "_e3"].astype(np.float64)
+        for fmt, bound in ((29, np.minimum(e4, e3)), (32, e4)):
+            gaps = []
+            for q in range(5):
+                dec = O.decode(O.encode(strip, fmt, quality=q, threads=8), fmt, 4 * n, 4)
+                e = ((dec[..., :3].astype(np.int64) - strip[..., :3]) ** 2).reshape(4, n, 4, 3).sum(axis=(0, 2, 3))
+                assert (e >= bound).all(), (name, fmt, q)
+                gaps.append(10 * np.log10(e.sum() / bound.sum()))
+            assert gaps[2] <= 0.30 and gaps[3] <= 0.15 and gaps[4] <= 0.15, (name, fmt, gaps)
+            assert all(gaps[q + 1] <= gaps[q] + 1e-9 for q in range(4)), (name, fmt, gaps)
+    assert qt is not None
