@@ -17,7 +17,7 @@
 #include "cf_device.h"
 
 #ifndef CF_ETC_ABLATE
-#define CF_ETC_ABLATE 0   // timing experiments only (tools/dbg/etc_ablate.sh): 1 = no planar, 2 = no T / H
+#define CF_ETC_ABLATE 0   // timing experiments only (tools/dbg/etc_ablate.sh): 1 = no planar, 2 = no T / H, 16 .. 128 parts of the list search
 #endif
 
 namespace {
@@ -699,7 +699,7 @@ __device__ __forceinline__ BaseBest base_combine(const HalfTex& ht8, const RgbOp
 		inside[f] = in;
 	}
 	uint32_t e2[2] = {herr[1], herr[5]}, t2[2] = {htb[1], htb[5]}, e1[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, t1[2] = {0, 0};
-	if (!inside[0] || !inside[1]) {
+	if ((!inside[0] || !inside[1]) && !(CF_ETC_ABLATE & 32)) {
 		// one pass re-scores both clamped colours of both flips: the lanes of (flip, 5-bit, half 1) take q2p, those
 		// of (flip, 5-bit, half 0) q1p, each over its own table; the 4-bit lanes compute along and are ignored
 		const uint32_t f = lane >> 5, sub = (lane >> 3) & 1u;
@@ -721,7 +721,7 @@ __device__ __forceinline__ BaseBest base_combine(const HalfTex& ht8, const RgbOp
 	}
 	// the 8 x 8 pairs of the tables' own best colours inside the window: two pairs per lane of the flip's half
 	unsigned long long pk = ~0ull;
-	{
+	if (!(CF_ETC_ABLATE & 64)) {
 		const uint32_t fbase = lane & 32u, hl = lane & 31u;
 #pragma unroll
 		for (uint32_t r = 0; r < 2u; ++r) {
@@ -778,20 +778,21 @@ __device__ __forceinline__ BaseBest base_combine(const HalfTex& ht8, const RgbOp
 }
 
 template <bool UNITW>
-__device__ __forceinline__ BaseBest base_search_lists(const uint32_t* tp, const RgbOpts& o, uint32_t lane)
+__device__ __forceinline__ BaseBest base_search_lists(const uint32_t* tp, const RgbOpts& o, uint32_t lane, uint32_t other_err)
 {
 	const uint32_t flip = lane >> 5, g = (lane >> 3) & 3u, t = lane & 7u;
 	const uint32_t fam4 = g >> 1, sub = g & 1u;
 	const int maxq = fam4 ? 15 : 31;
-	const uint32_t hmask = half_mask(flip, sub);
-	int n = 0, sum[3] = {0, 0, 0};
-#pragma unroll 1
-	for (uint32_t i = 0; i < 16u; ++i) {
-		if (((hmask & o.active) >> i) & 1u) {
-			const uint32_t p = tp[i];
-			++n;
-			sum[0] += (int)(p & 255u); sum[1] += (int)((p >> 8) & 255u); sum[2] += (int)((p >> 16) & 255u);
-		}
+	const HalfTex ht8 = load_half(tp, o, flip, sub);
+	// mean of the half over the texels that carry weight (oracle: in_half && active -- the transparent texels of a
+	// punch-through block are not in `active`), from the registers of load_half
+	const uint32_t cm = (half_mask(flip, sub) & o.active) ? ht8.counted : 0u;
+	const int n = (int)__builtin_popcount(cm);
+	int sum[3] = {0, 0, 0};
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		const uint32_t p = ((cm >> j) & 1u) ? ht8.px[j] : 0u;
+		sum[0] += (int)(p & 255u); sum[1] += (int)((p >> 8) & 255u); sum[2] += (int)(p >> 16);
 	}
 	uint32_t q0p = 0;
 #pragma unroll
@@ -799,7 +800,6 @@ __device__ __forceinline__ BaseBest base_search_lists(const uint32_t* tp, const 
 		const int mean = n ? (int)cf_div_small((uint32_t)(2*sum[c] + n), (uint32_t)(2*n)) : 0;
 		q0p |= (uint32_t)((mean*maxq + 127)/255) << (8*c);
 	}
-	const HalfTex ht8 = load_half(tp, o, flip, sub);
 	const int tma = o.punch ? 0 : k_etc_mod[t][0], tmb = k_etc_mod[t][1];
 	const bool live = !fam4 || o.allow_indiv;
 	uint32_t te = 0xFFFFFFFFu, tq = 0, tid = 0;
@@ -834,7 +834,7 @@ __device__ __forceinline__ BaseBest base_search_lists(const uint32_t* tp, const 
 		// least-squares steps; a lane whose step did not improve stops (the same selectors again)
 		bool going = n != 0;
 #pragma unroll 1
-		for (int step = 0; step < o.lsq; ++step) {
+		for (int step = 0; step < ((CF_ETC_ABLATE & 16) ? 0 : o.lsq); ++step) {
 			if (__ballot(going && live) == 0ull)
 				break;
 			const int c0[3] = {ex45((int)(lq & 255u), fam4), ex45((int)((lq >> 8) & 255u), fam4), ex45((int)((lq >> 16) & 255u), fam4)};
@@ -860,24 +860,93 @@ __device__ __forceinline__ BaseBest base_search_lists(const uint32_t* tp, const 
 		if (live && (le < te || (le == te && lid < tid))) {
 			te = le; tid = lid; tq = lq;
 		}
-		// after the first list: blocks it already codes below the gate stop here (oracle: rgb_opts.gate)
-		if (l == 0 && o.nlists > 1 && o.gate) {
+		// the candidates of the block from the lanes' results: after the last list, and after the first one -- blocks
+		// it (or planar: other_err) already codes below the gate stop there (oracle: rgb_opts.gate).  ONE call site:
+		// the combine step inlines an evaluation of its own
+		const bool lastl = l + 1 >= o.nlists;
+		if (lastl || (l == 0 && o.gate)) {
 			bb = base_combine<UNITW>(ht8, o, lane, te, tq, tid, tma, tmb);
-			if (bb.err < o.gate)
-				return bb;
+			if (lastl || bb.err < o.gate || other_err < o.gate || (CF_ETC_ABLATE & 128))
+				break;
 		}
 	}
-	return base_combine<UNITW>(ht8, o, lane, te, tq, tid, tma, tmb);
+	return bb;
 }
 
 // Returns the 8-byte RGB block (memory order: x = bytes 0..3, y = bytes 4..7) in every lane.
 __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o, uint32_t lane)
 {
 	const bool unitw = o.wt[0] == 1 && o.wt[1] == 1 && o.wt[2] == 1;   // uniform
+	// ETC2: the planar fit comes FIRST (oracle: cfo_etc_rgb_search) -- its error is part of the easy-block gate of the
+	// base-colour search.  Planar has no selectors, so it cannot express transparency: opaque blocks only.
+	// Closed-form least squares on the 4x4 grid (uniform), then 2 rounds of moves.
+	PlanarQ pq = {};
+	uint32_t ep = 0xFFFFFFFFu;
+	if (o.allow_planar) {
+		if (!o.punch && !(CF_ETC_ABLATE & 1)) {
+		{
+			// sums over the 16 texels, one texel per lane: S | Sx << 16 in one word (the low field
+			// never borrows, so the signed high field is exact), Sy in another
+			const uint32_t ti = lane & 15u;
+			const int x = (int)(ti & 3u), y = (int)(ti >> 2);
+			const uint32_t p = tp[ti];
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				const int v = (int)((p >> (8*c)) & 255u);
+				const int ssx = (int)cf_row_sum_uniform((uint32_t)(v + (((2*x - 3)*v) << 16)));
+				const int S = ssx & 0xFFFF, Sx = ssx >> 16;
+				const int Sy = (int)cf_row_sum_uniform((uint32_t)((2*y - 3)*v));
+				const int mq = c == 1 ? 127 : 63;
+				pq.O[c] = (clampi(5*S - 3*Sx - 3*Sy, 0, 255*80)*mq + 10200)/20400;
+				pq.H[c] = (clampi(5*S + 5*Sx - 3*Sy, 0, 255*80)*mq + 10200)/20400;
+				pq.V[c] = (clampi(5*S - 3*Sx + 5*Sy, 0, 255*80)*mq + 10200)/20400;
+			}
+		}
+		uint32_t ec[3] = {0u, 0u, 0u};
+		if (o.refine) {
+			planar_err_rows3(tp, o, pq, lane, ec);
+#pragma unroll
+			for (int c = 0; c < 3; ++c)
+				ec[c] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ec[c]);
+			ep = ec[0] + ec[1] + ec[2];
+		} else                               // Lowest: no move rounds, the total alone
+			ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)planar_err_rows(tp, o, pq, lane));
+		// (the channel weights as opaque scalars: a select among o.wt[] by a lane value becomes an indexed
+		// load and puts the whole option block in scratch)
+		int pw0 = o.wt[0], pw1 = o.wt[1], pw2 = o.wt[2];
+		asm volatile("" : "+s"(pw0), "+s"(pw1), "+s"(pw2));
+		for (int round = 0; round < (o.refine ? 2 : 0); ++round) {
+			// 18 single-field moves, two lanes per move (eight texels each); a move touches one channel:
+			// its total = the current total - that channel's share + the channel's new share
+			unsigned long long mk = ~0ull;
+			{
+				const uint32_t mv = lane >> 1;
+				const int f = mv < 18u ? (int)(mv >> 1) : 0, d = (mv & 1u) ? 1 : -1;
+				const int c = f >= 6 ? f - 6 : (f >= 3 ? f - 3 : f);
+				PlanarQ tq = pq;
+				const bool okm = planar_move(tq, f, d) && mv < 18u;
+				const uint32_t part = planar_err_ch(tp, o, tq, c, c == 0 ? pw0 : (c == 1 ? pw1 : pw2), (lane & 1u)*8u, 8u);
+				const uint32_t both = part + cf_xor1(part);
+				const uint32_t tot = ep - (c == 0 ? ec[0] : (c == 1 ? ec[1] : ec[2])) + both;
+				if (okm)
+					mk = ((unsigned long long)tot << 32) | mv;
+			}
+			const unsigned long long mm = cf_wave_min_u64(mk);
+			if ((uint32_t)(mm >> 32) >= ep)
+				break;
+			const int id = (int)(uint32_t)mm, fw = id >> 1, cw = fw >= 6 ? fw - 6 : (fw >= 3 ? fw - 3 : fw);
+			// the winner's channel takes its new share
+			const uint32_t nshare = (uint32_t)(mm >> 32) - (ep - (cw == 0 ? ec[0] : (cw == 1 ? ec[1] : ec[2])));
+			ec[0] = cw == 0 ? nshare : ec[0]; ec[1] = cw == 1 ? nshare : ec[1]; ec[2] = cw == 2 ? nshare : ec[2];
+			ep = (uint32_t)(mm >> 32);
+			planar_move(pq, fw, (id & 1) ? 1 : -1);
+		}
+		}
+	}
 	// the best base-colour candidate: error, id (flip: differential, 2 + flip: individual), colours, tables
 	uint32_t best_err, best_id, qa, qb, ta, tb;
 	if (o.nlists) {
-		const BaseBest bb = unitw ? base_search_lists<true>(tp, o, lane) : base_search_lists<false>(tp, o, lane);
+		const BaseBest bb = unitw ? base_search_lists<true>(tp, o, lane, ep) : base_search_lists<false>(tp, o, lane, ep);
 		best_err = bb.err; best_id = bb.id; qa = bb.qa; qb = bb.qb; ta = bb.ta; tb = bb.tb;
 	} else {
 	// Lowest, Low: the flip is chosen BEFORE the search (oracle: cfo_etc_rgb_search), by the scatter the halves would
@@ -1064,72 +1133,10 @@ __device__ __forceinline__ uint2 rgb_search(const uint32_t* tp, const RgbOpts& o
 	}
 	}
 	if (o.allow_planar) {
-		PlanarQ pq;
 		bool use_planar = false;
-		// planar has no selectors, so it cannot express transparency: opaque blocks only.
-		// Closed-form least squares on the 4x4 grid (uniform), then 2 rounds of moves.
-		if (!o.punch && !(CF_ETC_ABLATE & 1)) {
-		{
-			// sums over the 16 texels, one texel per lane: S | Sx << 16 in one word (the low field
-			// never borrows, so the signed high field is exact), Sy in another
-			const uint32_t ti = lane & 15u;
-			const int x = (int)(ti & 3u), y = (int)(ti >> 2);
-			const uint32_t p = tp[ti];
-#pragma unroll
-			for (int c = 0; c < 3; ++c) {
-				const int v = (int)((p >> (8*c)) & 255u);
-				const int ssx = (int)cf_row_sum_uniform((uint32_t)(v + (((2*x - 3)*v) << 16)));
-				const int S = ssx & 0xFFFF, Sx = ssx >> 16;
-				const int Sy = (int)cf_row_sum_uniform((uint32_t)((2*y - 3)*v));
-				const int mq = c == 1 ? 127 : 63;
-				pq.O[c] = (clampi(5*S - 3*Sx - 3*Sy, 0, 255*80)*mq + 10200)/20400;
-				pq.H[c] = (clampi(5*S + 5*Sx - 3*Sy, 0, 255*80)*mq + 10200)/20400;
-				pq.V[c] = (clampi(5*S - 3*Sx + 5*Sy, 0, 255*80)*mq + 10200)/20400;
-			}
-		}
-		uint32_t ec[3] = {0u, 0u, 0u}, ep;
-		if (o.refine) {
-			planar_err_rows3(tp, o, pq, lane, ec);
-#pragma unroll
-			for (int c = 0; c < 3; ++c)
-				ec[c] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ec[c]);
-			ep = ec[0] + ec[1] + ec[2];
-		} else                               // Lowest: no move rounds, the total alone
-			ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)planar_err_rows(tp, o, pq, lane));
-		// (the channel weights as opaque scalars: a select among o.wt[] by a lane value becomes an indexed
-		// load and puts the whole option block in scratch)
-		int pw0 = o.wt[0], pw1 = o.wt[1], pw2 = o.wt[2];
-		asm volatile("" : "+s"(pw0), "+s"(pw1), "+s"(pw2));
-		for (int round = 0; round < (o.refine ? 2 : 0); ++round) {
-			// 18 single-field moves, two lanes per move (eight texels each); a move touches one channel:
-			// its total = the current total - that channel's share + the channel's new share
-			unsigned long long mk = ~0ull;
-			{
-				const uint32_t mv = lane >> 1;
-				const int f = mv < 18u ? (int)(mv >> 1) : 0, d = (mv & 1u) ? 1 : -1;
-				const int c = f >= 6 ? f - 6 : (f >= 3 ? f - 3 : f);
-				PlanarQ tq = pq;
-				const bool okm = planar_move(tq, f, d) && mv < 18u;
-				const uint32_t part = planar_err_ch(tp, o, tq, c, c == 0 ? pw0 : (c == 1 ? pw1 : pw2), (lane & 1u)*8u, 8u);
-				const uint32_t both = part + cf_xor1(part);
-				const uint32_t tot = ep - (c == 0 ? ec[0] : (c == 1 ? ec[1] : ec[2])) + both;
-				if (okm)
-					mk = ((unsigned long long)tot << 32) | mv;
-			}
-			const unsigned long long mm = cf_wave_min_u64(mk);
-			if ((uint32_t)(mm >> 32) >= ep)
-				break;
-			const int id = (int)(uint32_t)mm, fw = id >> 1, cw = fw >= 6 ? fw - 6 : (fw >= 3 ? fw - 3 : fw);
-			// the winner's channel takes its new share
-			const uint32_t nshare = (uint32_t)(mm >> 32) - (ep - (cw == 0 ? ec[0] : (cw == 1 ? ec[1] : ec[2])));
-			ec[0] = cw == 0 ? nshare : ec[0]; ec[1] = cw == 1 ? nshare : ec[1]; ec[2] = cw == 2 ? nshare : ec[2];
-			ep = (uint32_t)(mm >> 32);
-			planar_move(pq, fw, (id & 1) ? 1 : -1);
-		}
 		if (ep < best_err) {
 			best_err = ep;
 			use_planar = true;
-		}
 		}
 		// ETC2 T / H modes (ids after planar), also in punch-through blocks
 		ThCand th;
@@ -1344,7 +1351,7 @@ __device__ __forceinline__ uint32_t r11_word(float f, bool snorm)
 template <int PIX, int FMT, bool SNORM>
 __global__ void __launch_bounds__(CF_WG_THREADS)
 #ifndef CF_ETC_MINW
-#define CF_ETC_MINW 4
+#define CF_ETC_MINW 5
 #endif
 __attribute__((amdgpu_waves_per_eu(CF_ETC_MINW, 8)))
 cfhip_etc_encode_kernel(cf_kparams kp)
@@ -1412,6 +1419,9 @@ cfhip_etc_encode_kernel(cf_kparams kp)
 		o.refine = q >= 1u;
 		// oracle: cfo_encode_etc_block, "Round 5"
 		o.nlists = q >= 3u ? 3 : (q == 2u ? 2 : 0);
+#ifdef CF_ETC_AB_OLD_WALK
+		o.nlists = 0;       // A/B only: the round-4 walk
+#endif
 		o.lsq = q >= 4u ? 2 : 1;
 		o.gate = q == 2u ? 256u : (q == 3u ? 128u : 0u);
 		uint2 w0 = make_uint2(0, 0), w1 = make_uint2(0, 0);

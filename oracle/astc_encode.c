@@ -1966,8 +1966,12 @@ static void encode_core(const int px[][4], const int lns[][4], int bw, int bh, i
 						memcpy(D1, tl_wide.D1, sizeof(D1));
 						wide_reproject(b, pc, D0, D1, 8);
 						tl_wide.capture = 1; tl_wide.have = 0; tl_wide.tslot = 8;
+						if (tl_lab.active && tl_lab.exact_opts == 2) {      /* lab: the rounds keep round 0's endpoint option */
+							const int cem = cur.cem;
+							tl_wide.force_opt = (cem == 8 || cem == 12) ? 0 : ((cem == 6 || cem == 10) ? 1 : ((cem == 0 || cem == 4) ? 2 : 3));
+						}
 						phase_b(b, j, pc, &f->cfg[pc->cls][b->has_alpha][order[k]], &cur2);
-						tl_wide.capture = 0; tl_wide.tslot = -1;
+						tl_wide.capture = 0; tl_wide.tslot = -1; tl_wide.force_opt = -1;
 						if (!cur2.valid || cur2.err >= prev)
 							break;
 						prev = cur2.err;
