@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <mutex>
 #include <new>
 #include <algorithm>
@@ -793,7 +794,36 @@ unsigned usable_cpus()
 // k+2 into a pinned slot | the upload stream copies strip k+1 | the launch stream encodes strip k | the
 // download stream returns the payload of strip k-1 into a pinned landing buffer.  Three pinned slots; events
 // order slot reuse (pin_free), upload -> kernel (up_done) and kernel -> download (one pair per strip).
+int encode_host_pipelined_impl(cfhip_ctx* ctx, const cfhip_surface& s, const cfhip_params& p,
+	hipStream_t stream);
+
+// The pipeline proper is encode_host_pipelined_impl; this wrapper owns its failure modes (round-4 ADVICE):
+//  * an error return from the middle of the pipeline leaves copies queued on the upload / download streams that still
+//    read and write the pinned slots, and staging_busy set: all three streams are drained and the staging marked free
+//    before the error goes to the caller, so the next call can never stage into a slot an old upload is reading;
+//  * std::bad_alloc / std::system_error (vector growth, thread creation under a pids limit) must not cross the
+//    extern "C" boundary: they become CFHIP_E_DEVICE with the text in cfhip_last_error.
 int encode_host_pipelined(cfhip_ctx* ctx, const cfhip_surface& s, const cfhip_params& p,
+	hipStream_t stream)
+{
+	int rc;
+	try {
+		rc = encode_host_pipelined_impl(ctx, s, p, stream);
+	} catch (const std::exception& e) {
+		rc = fail(ctx, CFHIP_E_DEVICE, "host pipeline: %s", e.what());
+	} catch (...) {
+		rc = fail(ctx, CFHIP_E_DEVICE, "host pipeline: unknown exception");
+	}
+	if (rc != CFHIP_OK) {
+		(void)hipStreamSynchronize(stream);
+		if (ctx->up_stream) (void)hipStreamSynchronize(ctx->up_stream);
+		if (ctx->down_stream) (void)hipStreamSynchronize(ctx->down_stream);
+		ctx->staging_busy = false;
+	}
+	return rc;
+}
+
+int encode_host_pipelined_impl(cfhip_ctx* ctx, const cfhip_surface& s, const cfhip_params& p,
 	hipStream_t stream)
 {
 	int fbw, fbh;

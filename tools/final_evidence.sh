@@ -9,7 +9,8 @@ mkdir -p $G
 for q in 2 3 4; do
   sfx=""; [ $q != 2 ] && sfx="_q$q"
   kern="cfhip_bc7_encode_kernel<0, true, false>"; mang="cfhip_bc7_encode_kernelILi0ELb1ELb0E"
-  [ $q = 4 ] && kern="cfhip_bc7_encode_kernel<0, true, true>" && mang="cfhip_bc7_encode_kernelILi0ELb1ELb1E"
+  # (round 5: High runs the wide kernel too)
+  [ $q -ge 3 ] && kern="cfhip_bc7_encode_kernel<0, true, true>" && mang="cfhip_bc7_encode_kernelILi0ELb1ELb1E"
   bash $R/tools/profile.sh ${tag}$sfx --quality $q > $G/${tag}${sfx}_bc7_pmc_summary.txt 2>&1
   python $R/tools/pmc_to_json.py $G/prof_${tag}$sfx --tag ${tag}$sfx --quality $q --kernel "$kern" --mangled "$mang" --out $G/bc7_pmc$sfx.json > /dev/null \
     && cp $G/bc7_pmc$sfx.json $R/profiles/bc7_pmc$sfx.json
@@ -17,6 +18,10 @@ for q in 2 3 4; do
   extra=""; [ $q != 2 ] && extra="--no-cpu-baseline"
   python $R/bench.py --quality $q $extra > $G/${tag}${sfx}_bench.json 2> $G/${tag}${sfx}_bench.err
 done
+# the second tile (synth.photo2: the BC7 mode split of real photographs): kernel stats + PMC passes of BC7 Normal on it
+PROFILE_CMD="python $R/tools/bench_formats.py --size 4096 --steps 3 --formats BC7 --qualities 2 --tile photo2" \
+  bash $R/tools/profile.sh ${tag}_photo2 > $G/${tag}_bc7_photo2_pmc_summary.txt 2>&1
+for f in $(find $G/prof_${tag}_photo2/stats -name "*kernel_stats.csv"); do cp $f $G/${tag}_bc7_photo2_kernel_stats.csv; done
 [ -n "$ONLY_BC7" ] && { tail -c 600 $G/${tag}_bench.json; exit 0; }
 # ASTC at BASELINE config 3 (6x6 High, 4096x4096): kernel stats + PMC passes incl. FETCH_SIZE / WRITE_SIZE
 PROFILE_CMD="python $R/tools/bench_formats.py --size 4096 --steps 3 --formats ASTC_6x6 --qualities 3" \
@@ -30,7 +35,9 @@ PROFILE_CMD="python $R/tools/bench_formats.py --size 2048 --steps 3 --formats ET
 BENCH_DIST_BACKEND=gloo python $R/bench.py --gpus 2 --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | grep "^{" > $G/${tag}_bench_gpus2_gloo.json
 BENCH_DIST_BACKEND=gloo python $R/bench.py --config c5 --gpus 2 --textures 16 2>/dev/null | grep "^{" > $G/${tag}_c5_16tex_gpus2_gloo.json
 python $R/tools/bench_formats.py --size 2048 --steps 3 --qualities 0,1,2,3,4 2>/dev/null | grep format > $G/${tag}_formats_2048.jsonl
+python $R/tools/bench_formats.py --size 2048 --steps 3 --qualities 0,1,2,3,4 --tile photo2 2>/dev/null | grep format > $G/${tag}_formats_2048_photo2.jsonl
 python $R/tools/bench_configs.py 2>/dev/null | grep "^{" > $G/${tag}_baseline_configs.jsonl
+python $R/tools/bc1_bound.py --blocks 512 > $G/${tag}_bc1_bound.md 2>/dev/null
 python $R/bench.py --config c5 --textures 16 2>/dev/null | grep "^{" > $G/${tag}_c5_16tex.json
 python $R/tools/bench_srgb.py 2>/dev/null | grep "^{" > $G/${tag}_srgb_vs_linear.jsonl
 bash $R/tools/fuzz_all.sh 300 7 > $G/${tag}_fuzz.txt 2>&1

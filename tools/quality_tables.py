@@ -214,13 +214,39 @@ def independent_table():
     return gold, lines
 
 
+def bc1_rows():
+    """BC1 / BC3 colour against the TRUE optimum of tests/golden/bc1_optimum.npz (tools/bc1_bound.py, GPU brute force)"""
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "bc1_optimum.npz"))
+    n = int(fx["blocks"])
+    img = synth.photo(512, 512, seed=21)
+    img[..., 3] = 255
+    rng = np.random.default_rng(20260929)
+    ys = rng.integers(0, 128, n) * 4
+    xs = rng.integers(0, 128, n) * 4
+    sets = (("real photographs", "real", R.blocks4(n)), ("synthetic tile", "synth", np.stack([img[y:y + 4, x:x + 4] for y, x in zip(ys, xs)])))
+    rows = []
+    for label, key, blocks in sets:
+        strip = R.strip(np.ascontiguousarray(blocks))
+        e4, e3 = fx[key + "_e4"].astype(np.float64), fx[key + "_e3"].astype(np.float64)
+        for fmt, name, bound in ((29, "BC1", np.minimum(e4, e3)), (32, "BC3 colour", e4)):
+            ps = []
+            for q in range(5):
+                dec = O.decode(O.encode(strip, fmt, quality=q, threads=8), fmt, 4 * n, 4)
+                e = ((dec[..., :3].astype(np.int64) - strip[..., :3]) ** 2).reshape(4, n, 4, 3).sum(axis=(0, 2, 3))
+                ps.append(psnr_from_sse(float(e.sum()), n * 48))
+            rows.append((name, "%s, %d blocks; bound = the TRUE optimum (all 2^32 endpoint pairs, tools/bounds/bc1_optimum.hip)" % (label, n),
+                         ps, psnr_from_sse(float(bound.sum()), n * 48)))
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--blocks", type=int, default=2048)
+    ap.add_argument("--real-blocks", type=int, default=4096, help="blocks of tests/golden/real_blocks.npz per BC7 / ETC row (ASTC: a quarter, at most 768)")
     a = ap.parse_args()
     rng = np.random.default_rng(20260929)
     gold, lines = independent_table()
-    print("# Quality against independent encoders and against a wide search (round 4)\n")
+    print("# Quality against independent encoders, against a wide search / the true optimum (round 5)\n")
     print("Generated by `tools/quality_tables.py` on the CPU oracle (the kernels emit the same bytes).\n")
     print("## Ours (Lowest / Low / Normal / High / Highest) vs Pillow %s and Mesa (%s)\n" % (gold["pillow"], gold["mesa"]))
     print("PSNR in dB over the channels the format stores (BC6H: log-domain PSNR of the halves); last column = ours at "
@@ -229,31 +255,45 @@ def main():
     print("|---|---|---|---|---|---|")
     for l in lines:
         print(l)
-    print("\n## Gap to the wide search, %d sampled blocks per row\n" % a.blocks)
-    print("BC7 wide search (`cfo_bc7_wide_search`, round 4) = every mode x partition x rotation x index selector, every fit "
-          "solved by an endpoint solver that is NOT the encoder's: steepest descent on the quantised endpoint grid under "
-          "the exact error (moves: every field by -2..+2, both ends of a channel together, p-bit flips alone and with a "
-          "field step) from four starts (the encoder's own fit with plain and with quantisation-aware rounding, the "
-          "subset's bounding box as is and pulled in).  Round 3's bound (the encoder's fit routines iterated) sat 0.08 / "
-          "0.11 dB lower; round 3's ladder measured against THIS bound: Normal 0.41 / 0.49 dB, High 0.25 / 0.19, "
-          "Highest 0.24 / 0.19.  ETC1 / ETC2 RGB: the TRUE optimum of a block (`cfo_etc_true_optimum`).  ASTC: `cfo_astc_wide_search` (every candidate class incl. a second plane on every component and every canonical partition seed, every legal block mode, every endpoint-mode family forced and measured exactly, the best triples iterated).  BC6H: all 33 candidates with 12 refit rounds (`cfo_bc6h_wide_search`).  RGBA PSNR of "
-          "the sampled blocks.\n")
-    print("| format | content | Q0 | Q1 | Q2 | Q3 | Q4 | wide search | gap at Normal | gap at High | gap at Highest |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|")
+    hdr = "| format | content | Q0 | Q1 | Q2 | Q3 | Q4 | bound | gap at Normal | gap at High | gap at Highest |\n|---|---|---|---|---|---|---|---|---|---|---|"
+
+    def row(fmt, content, ps, bound):
+        print("| %s | %s | %s | %.3f | %.3f | %.3f | %.3f |" % (fmt, content, " | ".join("%.3f" % v for v in ps[:5]), bound,
+                                                              bound - ps[2], bound - ps[3], bound - ps[4]))
+    print("\n## Gap to the bound on blocks of REAL photographs (tests/golden/real_blocks.npz: 8 photographs, see make_real_blocks.py)\n")
+    print("Bounds: BC7 `cfo_bc7_wide_search` (every mode x partition x rotation x index selector, every fit by a steepest descent on "
+          "the quantised endpoint grid from four starts -- a solver that is not the encoder's); ETC1 / ETC2 RGB the TRUE optimum of a "
+          "block (`cfo_etc_true_optimum`: every expressible block); ASTC `cfo_astc_wide_search` (every candidate class, every canonical "
+          "partition seed, every legal block mode, every endpoint-mode family forced and measured exactly, the best triples iterated); "
+          "BC1 / BC3 colour the TRUE optimum by GPU brute force.  RGB(A) PSNR of the blocks.\n")
+    print(hdr)
+    for label, ps in bc7_gap(a.real_blocks, rng, kind="real"):
+        row("BC7", "%s, %d blocks" % (label, a.real_blocks if label == "opaque" else min(a.real_blocks, 1024)), ps, ps[5])
+    for fmt, name in ((37, "ETC1"), (38, "ETC2 RGB")):
+        ps, opt = etc_gap(a.real_blocks, rng, fmt, kind="real")
+        row(name, "opaque, %d blocks" % a.real_blocks, ps, opt)
+    for bw, bh in ((4, 4), (5, 5), (6, 6), (8, 8), (10, 10), (12, 12)):
+        ps, wide = astc_gap(min(768, max(256, a.real_blocks // 4)), rng, bw, bh, kind="real")
+        row("ASTC %dx%d" % (bw, bh), "opaque, %d blocks" % min(768, max(256, a.real_blocks // 4)), ps, wide)
+    for name, content, ps, bound in bc1_rows():
+        if "real" in content:
+            row(name, content, ps, bound)
+    print("\n## Gap to the bound on the synthetic tile (synth.photo), %d sampled blocks per row\n" % a.blocks)
+    print(hdr)
     for label, ps in bc7_gap(a.blocks, rng):
-        print("| BC7 | %s | %s | %.3f | %.3f | %.3f | %.3f |" % (label, " | ".join("%.3f" % v for v in ps[:5]), ps[5], ps[5] - ps[2], ps[5] - ps[3], ps[5] - ps[4]))
+        row("BC7", label, ps, ps[5])
     for fmt, name in ((37, "ETC1"), (38, "ETC2 RGB")):
         ps, opt = etc_gap(max(256, a.blocks // 2), rng, fmt)
-        print("| %s | opaque; bound = the TRUE optimum (every expressible block, `cfo_etc_true_optimum`) | %s | %.3f | %.3f | %.3f | %.3f |"
-              % (name, " | ".join("%.3f" % v for v in ps), opt, opt - ps[2], opt - ps[3], opt - ps[4]))
+        row(name, "opaque", ps, opt)
     for bw, bh in ((4, 4), (6, 6), (8, 8)):
         for alpha in (False, True):
             ps, wide = astc_gap(max(256, a.blocks // 4), rng, bw, bh, alpha)
-            print("| ASTC %dx%d | %s; bound = `cfo_astc_wide_search` | %s | %.3f | %.3f | %.3f | %.3f |"
-                  % (bw, bh, "with alpha" if alpha else "opaque", " | ".join("%.3f" % v for v in ps), wide,
-                     wide - ps[2], wide - ps[3], wide - ps[4]))
+            row("ASTC %dx%d" % (bw, bh), "with alpha" if alpha else "opaque", ps, wide)
     ps = bc6h_gap(max(256, a.blocks // 2), rng)
-    print("| BC6H UF16 | HDR probe (log-domain PSNR) | %s | %.3f | %.3f | %.3f | %.3f |" % (" | ".join("%.3f" % v for v in ps[:5]), ps[5], ps[5] - ps[2], ps[5] - ps[3], ps[5] - ps[4]))
+    row("BC6H UF16", "HDR probe (log-domain PSNR; bound = `cfo_bc6h_wide_search`)", ps, ps[5])
+    for name, content, ps, bound in bc1_rows():
+        if "synthetic" in content:
+            row(name, content, ps, bound)
 
 
 if __name__ == "__main__":
