@@ -1388,7 +1388,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 			// same rule; a zero-error block ends its search here): per half, and skipped when no half walks it
 			if (st == 0u) {
 				const uint32_t gmin = cf_group_min_u32(best_err, pair, L_H);
-				gb = __ballot(gmin >= 48u);
+				gb = __ballot(gmin >= (UNITW ? 48u : 256u));     // oracle: gate2
 				solved = gb == 0ull;
 			}
 #undef R_NPER0

@@ -1351,7 +1351,7 @@ __device__ __forceinline__ uint32_t r11_word(float f, bool snorm)
 template <int PIX, int FMT, bool SNORM>
 __global__ void __launch_bounds__(CF_WG_THREADS)
 #ifndef CF_ETC_MINW
-#define CF_ETC_MINW 5
+#define CF_ETC_MINW 4
 #endif
 __attribute__((amdgpu_waves_per_eu(CF_ETC_MINW, 8)))
 cfhip_etc_encode_kernel(cf_kparams kp)
@@ -1423,7 +1423,7 @@ cfhip_etc_encode_kernel(cf_kparams kp)
 		o.nlists = 0;       // A/B only: the round-4 walk
 #endif
 		o.lsq = q >= 4u ? 2 : 1;
-		o.gate = q == 2u ? 256u : (q == 3u ? 128u : 0u);
+		o.gate = (q == 2u ? 256u : (q == 3u ? 128u : 0u))*(uint32_t)(o.wt[0] + o.wt[1] + o.wt[2])/3u;   // stated for unit weights
 		uint2 w0 = make_uint2(0, 0), w1 = make_uint2(0, 0);
 		if (FMT == E_ETC1) {
 			o.allow_indiv = true;

@@ -981,6 +981,9 @@ static void encode_block(const uint8_t rgba[64], uint8_t out[16], const cfo_para
 	const int l_ = b.own_lanes ? (ID) : (LANE); \
 	if (!used[l_] || BETTER(cur, held[l_])) { held[l_] = cur; used[l_] = 1; } \
 	if (cur.err < best_err) best_err = cur.err; } while (0)
+	/* the second pass's gate, 48 = 0.75 per channel-texel under unit weights; the perceptual metric weighs a grey
+	 * error 16 : 3 against the linear one, so its gate is 256 (with 48 nearly every sRGB block walked the second pass) */
+	const uint32_t gate2 = wt[4] ? 256u : 48u;
 	TRY(0, 0);
 	if (b.m6only) {
 		if (has_alpha)
@@ -1019,7 +1022,7 @@ static void encode_block(const uint8_t rgba[64], uint8_t out[16], const cfo_para
 		if (b.two) {
 			const int bits[4] = {1, 1, 1, has_alpha};
 			const int ngroups = (!has_alpha && b.three) ? 2 : 1;
-			for (int g = 0; g < ngroups && (g == 0 || best_err >= 48u); ++g) {
+			for (int g = 0; g < ngroups && (g == 0 || best_err >= gate2); ++g) {
 				float sc0[64], sl0[64];
 				for (int k = 0; k < 64; ++k)
 					sc0[k] = partition_score(px, 2 + g, k, bits, &sl0[k]);
@@ -1065,7 +1068,7 @@ static void encode_block(const uint8_t rgba[64], uint8_t out[16], const cfo_para
 				}
 			}
 		}
-		if (b.rot && b.m4 && !b.wide && has_alpha && best_err >= 48u)
+		if (b.rot && b.m4 && !b.wide && has_alpha && best_err >= gate2)
 			for (int k = 0; k < 8; ++k)
 				if (((b.m4 >> k) & 1) && (!wt[4] || (k & 3) == 0))
 					TRY(5 + k, 11 + 2*k);

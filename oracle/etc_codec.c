@@ -1015,7 +1015,8 @@ void cfo_etc_rgb_search(const int px[16][4], const rgb_opts* o, uint8_t out[8])
 			int id1 = -1, fl1 = 0, q1[2][3], t1[2];
 			flip_candidates(px, &o1, flip, &fe, &id1, &fl1, q1, t1);
 		}
-		if (fe < (uint32_t)o->gate) {
+		/* (the gate is stated for unit weights: REC709-weighted errors are (3 + 10 + 1) / 3 times as large) */
+		if (fe < (uint32_t)o->gate*(uint32_t)(o->wt[0] + o->wt[1] + o->wt[2])/3u) {
 			og = o1;
 			o = &og;
 		}

@@ -52,11 +52,13 @@ def test_no_block_encoder_kernel_uses_scratch(kernels):
         # round 5: the 12-wave (168-register) ASTC build keeps 44 B per lane in scratch since the refinement rounds
         # loop over phase B (18 values live across the rounds; the 8-wave builds hold them in registers) -- it is
         # still the faster build where three waves per SIMD become resident (4x4 Normal 5.15 against 6.74 ms)
-        # ... and the ETC builds 64 .. 148 B at 5 waves per SIMD since the list search and the planar-first order
-        # (same-box A/B: 5 waves with that scratch 3 % faster than 4 waves with 0 .. 32 B: ETC2 RGB Normal 0.406
-        # against 0.420 ms on 1024x1024)
+        # ... and the ETC2 builds 16 .. 32 B at 4 waves per SIMD (128 registers) since the list search and the
+        # planar-first order.  The 5-wave builds (64 .. 148 B of scratch, 15 .. 38 spilled registers) were 4 % faster and
+        # are NOT used: their RGB8A1 instance returned wrong blocks for partial blocks of sRGB images (3 of 300 fuzz
+        # cases; tests/test_gpu_etc.py::test_a1_srgb_partial_blocks holds the cases) while every build without that
+        # spill pressure -- 4 waves, 3 waves, 5 waves with one stage ablated -- is byte-identical to the oracle.
         bad = {k: v for k, v in ks.items()
-               if v["scratch"] > (48 if ("astc" in k and "ELi12E" in k) else (160 if "cfhip_etc" in k else 0))}
+               if v["scratch"] > (48 if ("astc" in k and "ELi12E" in k) else (32 if "cfhip_etc" in k else 0))}
         assert not bad, bad
 
 
@@ -66,7 +68,7 @@ def test_register_budgets_match_the_planned_occupancy(kernels):
         four = "ELb1ELb" in k                       # <PIX, UNITW, WIDE>: the linear-metric builds; the perceptual ones run at 3 waves
         assert v["vgpr"] <= (128 if four else 168), (k, v)          # 4 waves / 3 waves
     for k, v in _of(kernels, "cfhip_etc_encode_kernel").items():
-        assert v["vgpr"] <= 96, (k, v)              # 5 waves
+        assert v["vgpr"] <= 128, (k, v)             # 4 waves since round 5
     for k, v in _of(kernels, "cfhip_astc_encode_kernel").items():
         twelve = "ELi12E" in k
         assert v["vgpr"] <= (168 if twelve else 256), (k, v)
