@@ -1690,7 +1690,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				// re-projected on ITS decoded endpoints, decimated, quantised and the endpoints refitted; a round
 				// that does not lower the lane's exact error ends the lane's refinement.  Every round ends with the
 				// group argmin, so a lane's earlier (better) result stays parked when a later round loses.
-				const uint32_t nrounds = HDR ? 0u : (q == 2u ? 1u : (q == 3u ? 2u : (q >= 4u ? 3u : 0u)));
+				// (the 12-wave / 168-register build serves Lowest and Low only, which have no rounds: with the rounds
+				// compiled in it kept 18 values in scratch, and a kernel that talks across lanes must not spill vector
+				// registers -- a spill inside divergent control flow saves the active lanes only; see etc_encode.hip)
+				const uint32_t nrounds = (HDR || MAXW == 12) ? 0u : (q == 2u ? 1u : (q == 3u ? 2u : (q >= 4u ? 3u : 0u)));
 				bool going = false;
 				unsigned long long prev_err = ~0ull;
 #pragma unroll 1
@@ -2626,7 +2629,8 @@ extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t qualit
 	// 12-wave workgroup with the cache, 4.2 ms as three 4-wave workgroups without); then the cache
 	static const bool plan_no_dense = getenv("CFHIP_ASTC_NO_DENSE") != nullptr;   // experiments: the 256-register build only
 	// (the HDR builds exist for 8 waves only: their phase B holds 16-bit sums and double-precision fits)
-	const bool no12 = plan_no_dense || hdr != 0u;
+	// (nor for the levels with refinement rounds, Normal and up: the 12-wave build carries none, see the kernel)
+	const bool no12 = plan_no_dense || hdr != 0u || quality >= 2u;
 	// any workgroup of 4 .. 12 waves: what counts is the number of waves resident on the CU (more than 8
 	// = three on some SIMDs = the 168-register build, which no longer spills); e.g. 6x6 up to High fits
 	// one 11-wave workgroup (158 KB) where 12 waves do not and two 4-wave workgroups leave 8
@@ -2696,7 +2700,7 @@ extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, ui
 	// the 168-register build only where three waves per SIMD actually become resident
 	static const bool no_dense = getenv("CFHIP_ASTC_NO_DENSE") != nullptr, debug = getenv("CFHIP_ASTC_DEBUG") != nullptr;
 	const bool hdr = ((kp->flags >> 19) & 3u) != 0u;
-	const bool dense = (cf_astc_cu_lds()/(lds_bytes + 1024u))*nwaves > 8u && !no_dense && !hdr;
+	const bool dense = (cf_astc_cu_lds()/(lds_bytes + 1024u))*nwaves > 8u && !no_dense && !hdr && kp->quality <= 1u;
 	void (*fn)(cf_kparams) = nullptr;
 	if (dense)
 		fn = pixel_type == 0 ? &cfhip_astc_encode_kernel<0, 12, false> : &cfhip_astc_encode_kernel<1, 12, false>;

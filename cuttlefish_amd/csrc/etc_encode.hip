@@ -1351,7 +1351,7 @@ __device__ __forceinline__ uint32_t r11_word(float f, bool snorm)
 template <int PIX, int FMT, bool SNORM>
 __global__ void __launch_bounds__(CF_WG_THREADS)
 #ifndef CF_ETC_MINW
-#define CF_ETC_MINW 4
+#define CF_ETC_MINW 3
 #endif
 __attribute__((amdgpu_waves_per_eu(CF_ETC_MINW, 8)))
 cfhip_etc_encode_kernel(cf_kparams kp)

@@ -49,16 +49,14 @@ def test_no_block_encoder_kernel_uses_scratch(kernels):
     for stem in stems:
         ks = _of(kernels, stem)
         assert ks, stem
-        # round 5: the 12-wave (168-register) ASTC build keeps 44 B per lane in scratch since the refinement rounds
-        # loop over phase B (18 values live across the rounds; the 8-wave builds hold them in registers) -- it is
-        # still the faster build where three waves per SIMD become resident (4x4 Normal 5.15 against 6.74 ms)
-        # ... and the ETC2 builds 16 .. 32 B at 4 waves per SIMD (128 registers) since the list search and the
-        # planar-first order.  The 5-wave builds (64 .. 148 B of scratch, 15 .. 38 spilled registers) were 4 % faster and
-        # are NOT used: their RGB8A1 instance returned wrong blocks for partial blocks of sRGB images (3 of 300 fuzz
-        # cases; tests/test_gpu_etc.py::test_a1_srgb_partial_blocks holds the cases) while every build without that
-        # spill pressure -- 4 waves, 3 waves, 5 waves with one stage ablated -- is byte-identical to the oracle.
-        bad = {k: v for k, v in ks.items()
-               if v["scratch"] > (48 if ("astc" in k and "ELi12E" in k) else (32 if "cfhip_etc" in k else 0))}
+        # No vector-register spill in any block kernel.  Round 5 learned why this is a correctness rule for kernels that
+        # talk across lanes (DPP, ds_bpermute, v_readlane): a spill inside divergent control flow saves the ACTIVE lanes
+        # only, and a later cross-lane read of a lane that was inactive then sees a stale value -- the 5- and 4-wave builds
+        # of the ETC2 RGB8A1 kernel (32 / 7 spilled registers) returned wrong blocks in 3 .. 5 of 300 fuzz cases where
+        # every build without spills is byte-identical to the oracle (tests/test_gpu_etc.py::test_a1_srgb_partial_blocks).
+        # So: ETC2 at 3 waves (135 .. 144 registers), ETC1 at 4; the 168-register ASTC build serves the levels without
+        # refinement rounds only.
+        bad = {k: v for k, v in ks.items() if v["scratch"] != 0}
         assert not bad, bad
 
 
@@ -68,7 +66,7 @@ def test_register_budgets_match_the_planned_occupancy(kernels):
         four = "ELb1ELb" in k                       # <PIX, UNITW, WIDE>: the linear-metric builds; the perceptual ones run at 3 waves
         assert v["vgpr"] <= (128 if four else 168), (k, v)          # 4 waves / 3 waves
     for k, v in _of(kernels, "cfhip_etc_encode_kernel").items():
-        assert v["vgpr"] <= 128, (k, v)             # 4 waves since round 5
+        assert v["vgpr"] <= 168, (k, v)             # 3 waves since round 5 (ETC1: 125 registers, 4 waves)
     for k, v in _of(kernels, "cfhip_astc_encode_kernel").items():
         twelve = "ELi12E" in k
         assert v["vgpr"] <= (168 if twelve else 256), (k, v)
