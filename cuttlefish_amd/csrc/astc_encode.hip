@@ -134,6 +134,46 @@ __device__ __forceinline__ void principal_axis(const Cov& C, float (&axis)[4])
 	}
 }
 
+// What the best line through a subset's mean leaves of its scatter (oracle: linefit_energy, the same operations
+// in the same order -- trace - lambda cancels, so the two sides must agree to the bit): C = count * scatter
+// matrix, v = one power iteration from the column of the largest diagonal, rescaled by exact powers of two
+// (frexpf / ldexpf); (trace C - v' C v / v' v) / count with one rounded division.
+__device__ __forceinline__ float linefit_energy(const Cov& C, int cnt)
+{
+	float bestd = C.c00, v0 = C.c00, v1 = C.c01, v2 = C.c02, v3 = C.c03;
+	if (C.c11 > bestd) { bestd = C.c11; v0 = C.c01; v1 = C.c11; v2 = C.c12; v3 = C.c13; }
+	asm volatile("" : "+v"(bestd));
+	if (C.c22 > bestd) { bestd = C.c22; v0 = C.c02; v1 = C.c12; v2 = C.c22; v3 = C.c23; }
+	asm volatile("" : "+v"(bestd));
+	if (C.c33 > bestd) { bestd = C.c33; v0 = C.c03; v1 = C.c13; v2 = C.c23; v3 = C.c33; }
+#pragma unroll
+	for (int it = 0; it <= 1; ++it) {
+		const float m = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
+		if (m > 0.0f) {
+			int ex;
+			(void)frexpf(m, &ex);
+			v0 = ldexpf(v0, -ex); v1 = ldexpf(v1, -ex); v2 = ldexpf(v2, -ex); v3 = ldexpf(v3, -ex);
+		}
+		if (it == 1)
+			break;
+		float r0 = C.c00*v0; r0 = fmaf(C.c01, v1, r0); r0 = fmaf(C.c02, v2, r0); r0 = fmaf(C.c03, v3, r0);
+		float r1 = C.c01*v0; r1 = fmaf(C.c11, v1, r1); r1 = fmaf(C.c12, v2, r1); r1 = fmaf(C.c13, v3, r1);
+		float r2 = C.c02*v0; r2 = fmaf(C.c12, v1, r2); r2 = fmaf(C.c22, v2, r2); r2 = fmaf(C.c23, v3, r2);
+		float r3 = C.c03*v0; r3 = fmaf(C.c13, v1, r3); r3 = fmaf(C.c23, v2, r3); r3 = fmaf(C.c33, v3, r3);
+		v0 = r0; v1 = r1; v2 = r2; v3 = r3;
+	}
+	float w0 = C.c00*v0; w0 = fmaf(C.c01, v1, w0); w0 = fmaf(C.c02, v2, w0); w0 = fmaf(C.c03, v3, w0);
+	float w1 = C.c01*v0; w1 = fmaf(C.c11, v1, w1); w1 = fmaf(C.c12, v2, w1); w1 = fmaf(C.c13, v3, w1);
+	float w2 = C.c02*v0; w2 = fmaf(C.c12, v1, w2); w2 = fmaf(C.c22, v2, w2); w2 = fmaf(C.c23, v3, w2);
+	float w3 = C.c03*v0; w3 = fmaf(C.c13, v1, w3); w3 = fmaf(C.c23, v2, w3); w3 = fmaf(C.c33, v3, w3);
+	float num = v0*w0; num = fmaf(v1, w1, num); num = fmaf(v2, w2, num); num = fmaf(v3, w3, num);
+	float den = v0*v0; den = fmaf(v1, v1, den); den = fmaf(v2, v2, den); den = fmaf(v3, v3, den);
+	const float tr = ((C.c00 + C.c11) + C.c22) + C.c33;
+	if (!(den > 0.0f))
+		return 0.0f;
+	return fmaf(tr, den, -num)/(den*(float)cnt);
+}
+
 __device__ __forceinline__ float quad_est(float fA, float fB, float fC, float d0, float d1)
 {
 	float t = fA*d0;
@@ -184,6 +224,38 @@ __device__ __forceinline__ void decim_add(uint8_t* base, uint32_t F, uint32_t of
 	(void)__hip_atomic_fetch_add(w1 + 64, B1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
+// One plane's decimation walk, four texels per step: the four infill records and the four ideal weights (one
+// word of the T row; rows are 16-byte aligned) are read first, then the 16 no-return atomics go out -- the
+// one-texel form made every texel's two reads wait behind the previous texel's atomics (LDS operations of a
+// lane complete in order).
+template <uint32_t STEP>
+__device__ __forceinline__ void decim_walk(uint8_t* cb, const uint2* inf, const uint8_t* Trow, uint32_t first, uint32_t n)
+{
+#pragma unroll 1
+	for (uint32_t i = 0; i < n; i += 4u*STEP) {
+		uint2 rec[4];
+		uint32_t ix[4];
+#pragma unroll
+		for (uint32_t k = 0; k < 4u; ++k) {
+			ix[k] = i + first + k*STEP;
+			rec[k] = inf[min(ix[k], n - 1u)];
+		}
+		uint32_t T4[4];
+		if (STEP == 1u) {
+			const uint32_t w = *reinterpret_cast<const uint32_t*>(Trow + i);
+			T4[0] = w & 255u; T4[1] = (w >> 8) & 255u; T4[2] = (w >> 16) & 255u; T4[3] = w >> 24;
+		} else {
+#pragma unroll
+			for (uint32_t k = 0; k < 4u; ++k)
+				T4[k] = Trow[min(ix[k], n - 1u)];
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < 4u; ++k)
+			if (ix[k] < n)
+				decim_add(cb, rec[k].x, rec[k].y, T4[k]);
+	}
+}
+
 // Accumulators -> weights, in place: word k holds the sums of rows 2k | 2k+1; each becomes the
 // rounded average (sum + den/2)/den and (QUANT) the nearest unquantised weight of the lane's range.
 // What is stored is the PAIR form the infill reads: slot r = w[r] | w[r+1] << 8, so that the two
@@ -202,19 +274,37 @@ template <bool QUANT>
 __device__ __forceinline__ void normalise_rows(uint8_t* base, const uint32_t* den, uint32_t PW, const uint8_t* wnu)
 {
 	uint32_t prev = 0;        // w[2k-2] | w[2k-1] << 8
-#pragma unroll 2
-	for (uint32_t k = 0; k < PW; ++k) {
-		uint32_t* wp = reinterpret_cast<uint32_t*>(base + k*256u);
-		const uint32_t acc = *wp;
-		const uint2 dd = *reinterpret_cast<const uint2*>(den + 2u*k);
-		uint32_t g0 = avg_round(acc & 0xFFFFu, dd.x), g1 = avg_round(acc >> 16, dd.y);
-		if (QUANT) {
-			g0 = wnu[g0];
-			g1 = wnu[g1];
+	// four words (eight rows) per step, loads first: the accumulators and the divisors are independent reads,
+	// the eight table lookups depend on the averages only -- two LDS round trips per step (the one-word form
+	// waited for two per word); words past the plane repeat its last one and are not written
+#pragma unroll 1
+	for (uint32_t k = 0; k < PW; k += 4u) {
+		uint32_t acc[4], g[8];
+		uint2 dd[4];
+#pragma unroll
+		for (uint32_t m = 0; m < 4u; ++m) {
+			const uint32_t km = min(k + m, PW - 1u);
+			acc[m] = *reinterpret_cast<const uint32_t*>(base + km*256u);
+			dd[m] = *reinterpret_cast<const uint2*>(den + 2u*km);
 		}
-		if (k)
-			wp[-64] = prev | (((prev >> 8) | (g0 << 8)) << 16);
-		prev = g0 | (g1 << 8);
+#pragma unroll
+		for (uint32_t m = 0; m < 4u; ++m) {
+			g[2u*m] = avg_round(acc[m] & 0xFFFFu, dd[m].x);
+			g[2u*m + 1u] = avg_round(acc[m] >> 16, dd[m].y);
+		}
+		if (QUANT) {
+#pragma unroll
+			for (uint32_t m = 0; m < 8u; ++m)
+				g[m] = wnu[g[m]];
+		}
+#pragma unroll
+		for (uint32_t m = 0; m < 4u; ++m) {
+			if (k + m < PW) {
+				if (k + m)
+					*reinterpret_cast<uint32_t*>(base + (k + m - 1u)*256u) = prev | (((prev >> 8) | (g[2u*m] << 8)) << 16);
+				prev = g[2u*m] | (g[2u*m + 1u] << 8);
+			}
+		}
 	}
 	reinterpret_cast<uint32_t*>(base + (PW - 1u)*256u)[0] = prev | ((prev >> 8) << 16);
 }
@@ -1132,16 +1222,21 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			sum[0] = (int)(s01 & 0xFFFFu); sum[1] = (int)(s01 >> 16);
 			sum[2] = (int)(s23 & 0xFFFFu); sum[3] = (int)(s23 >> 16);
 			const int ni = (int)n;
-			C.c00 = (float)(ni*(int)cf_group_sum_u32(m00, pair, h) - sum[0]*sum[0]);
-			C.c01 = (float)(ni*(int)cf_group_sum_u32(m01, pair, h) - sum[0]*sum[1]);
-			C.c02 = (float)(ni*(int)cf_group_sum_u32(m02, pair, h) - sum[0]*sum[2]);
-			C.c03 = (float)(ni*(int)cf_group_sum_u32(m03, pair, h) - sum[0]*sum[3]);
-			C.c11 = (float)(ni*(int)cf_group_sum_u32(m11, pair, h) - sum[1]*sum[1]);
-			C.c12 = (float)(ni*(int)cf_group_sum_u32(m12, pair, h) - sum[1]*sum[2]);
-			C.c13 = (float)(ni*(int)cf_group_sum_u32(m13, pair, h) - sum[1]*sum[3]);
-			C.c22 = (float)(ni*(int)cf_group_sum_u32(m22, pair, h) - sum[2]*sum[2]);
-			C.c23 = (float)(ni*(int)cf_group_sum_u32(m23, pair, h) - sum[2]*sum[3]);
-			C.c33 = (float)(ni*(int)cf_group_sum_u32(m33, pair, h) - sum[3]*sum[3]);
+			// (the block's product sums stay: the line-fit seed ranking takes a partition's last subset as the block minus the others)
+			m00 = cf_group_sum_u32(m00, pair, h); m01 = cf_group_sum_u32(m01, pair, h); m02 = cf_group_sum_u32(m02, pair, h);
+			m03 = cf_group_sum_u32(m03, pair, h); m11 = cf_group_sum_u32(m11, pair, h); m12 = cf_group_sum_u32(m12, pair, h);
+			m13 = cf_group_sum_u32(m13, pair, h); m22 = cf_group_sum_u32(m22, pair, h); m23 = cf_group_sum_u32(m23, pair, h);
+			m33 = cf_group_sum_u32(m33, pair, h);
+			C.c00 = (float)(ni*(int)m00 - sum[0]*sum[0]);
+			C.c01 = (float)(ni*(int)m01 - sum[0]*sum[1]);
+			C.c02 = (float)(ni*(int)m02 - sum[0]*sum[2]);
+			C.c03 = (float)(ni*(int)m03 - sum[0]*sum[3]);
+			C.c11 = (float)(ni*(int)m11 - sum[1]*sum[1]);
+			C.c12 = (float)(ni*(int)m12 - sum[1]*sum[2]);
+			C.c13 = (float)(ni*(int)m13 - sum[1]*sum[3]);
+			C.c22 = (float)(ni*(int)m22 - sum[2]*sum[2]);
+			C.c23 = (float)(ni*(int)m23 - sum[2]*sum[3]);
+			C.c33 = (float)(ni*(int)m33 - sum[3]*sum[3]);
 		}
 		const float in = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f/(float)n)));
 		float mean[4], axis[4];
@@ -1208,133 +1303,253 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		// k-means clusters along the principal axis + one Lloyd step, then the partition shortlist
 		const uint32_t nb = npc;            // candidates before the partitioned ones
 		uint32_t got2 = 0, got3 = 0;
+#ifdef CF_ASTC_NO_LINEFIT
+		const bool linefit = false;       // (debugging: the oracle's CFO_ASTC_NO_LINEFIT)
+#else
+		const bool linefit = !HDR && n < 64u;      // (the HDR profiles keep the overlap ranking: oracle shortlist)
+#endif
+		// line-fit seed ranking (below): the block's texels as channel planes, four texels per 16-byte record, staged
+		// once per block in the wave's column region (idle until the grids stage; 256 B per block)
+		uint4* lf_planes = reinterpret_cast<uint4*>(wbase + h*256u);
+		if (linefit && lad.j2 && !(CF_ASTC_ABLATE & 8)) {
+			if (hl*4u < n) {
+				const uint32_t i = hl*4u;
+				const uint32_t w0 = tp[i], w1 = tp[min(i + 1u, n - 1u)], w2 = tp[min(i + 2u, n - 1u)], w3 = tp[min(i + 3u, n - 1u)];
+				const uint32_t t01 = __builtin_amdgcn_perm(w1, w0, 0x05010400u), t23 = __builtin_amdgcn_perm(w3, w2, 0x05010400u);
+				const uint32_t u01 = __builtin_amdgcn_perm(w1, w0, 0x07030602u), u23 = __builtin_amdgcn_perm(w3, w2, 0x07030602u);
+				lf_planes[hl] = make_uint4(__builtin_amdgcn_perm(t23, t01, 0x05040100u), __builtin_amdgcn_perm(t23, t01, 0x07060302u),
+					__builtin_amdgcn_perm(u23, u01, 0x05040100u), nc == 4u ? __builtin_amdgcn_perm(u23, u01, 0x07060302u) : 0u);
+			}
+			__builtin_amdgcn_wave_barrier();
+		}
 		for (uint32_t P = 2; P <= 4u; ++P) {
 			const uint32_t want = (CF_ASTC_ABLATE & 8) ? 0u : (P == 2u ? lad.j2 : (P == 3u ? lad.j3 : lad.j4));
 			if (!want)
 				continue;
-			const float step = (tmax - tmin)*(1.0f/(float)P);
-			uint32_t ks01[4] = {0, 0, 0, 0}, ks23[4] = {0, 0, 0, 0}, kcnt[4] = {0, 0, 0, 0};
-			for (uint32_t i = hl; i < n; i += gsz) {
-				const uint32_t p = tp[i];
-				const uint32_t c0 = p & 255u, c1 = (p >> 8) & 255u, c2 = (p >> 16) & 255u, c3 = nc == 4u ? p >> 24 : 0u;
-				float t = axis[0]*((float)c0 - mean[0]);
-				t = fmaf(axis[1], (float)c1 - mean[1], t);
-				t = fmaf(axis[2], (float)c2 - mean[2], t);
-				t = fmaf(axis[3], (float)c3 - mean[3], t);
-				uint32_t k = 0;
-#pragma unroll
-				for (uint32_t m = 1; m < 4u; ++m)
-					if (m < P && t > fmaf(step, (float)m, tmin)) k = m;
-#pragma unroll
-				for (uint32_t a = 0; a < 4u; ++a) {
-					const bool mine = k == a;
-					ks01[a] += mine ? (c0 | (c1 << 16)) : 0u;
-					ks23[a] += mine ? (c2 | (c3 << 16)) : 0u;
-					kcnt[a] += mine ? 1u : 0u;
-				}
-			}
-			float cen[4][4];
-			bool live[4];
-#pragma unroll
-			for (uint32_t a = 0; a < 4u; ++a) {
-				if (a < P) {
-					const uint32_t t01 = cf_group_sum_u32(ks01[a], pair, h), t23 = cf_group_sum_u32(ks23[a], pair, h);
-					const uint32_t cn = cf_group_sum_u32(kcnt[a], pair, h);
-					const float ic = cn ? 1.0f/(float)cn : 0.0f;
-					cen[a][0] = (float)(t01 & 0xFFFFu)*ic; cen[a][1] = (float)(t01 >> 16)*ic;
-					cen[a][2] = (float)(t23 & 0xFFFFu)*ic; cen[a][3] = (float)(t23 >> 16)*ic;
-					live[a] = cn != 0u;
-				} else {
-					cen[a][0] = cen[a][1] = cen[a][2] = cen[a][3] = 0.0f;
-					live[a] = false;
-				}
-			}
-			unsigned long long km[4][3];
-#pragma unroll
-			for (int a = 0; a < 4; ++a)
-				km[a][0] = km[a][1] = km[a][2] = 0ull;
-			const uint32_t rounds = (n + gsz - 1u)/gsz;
-#pragma unroll
-			for (uint32_t r = 0; r < 5u; ++r) {
-				if (r < rounds) {
-					const uint32_t i = r*gsz + hl;
-					uint32_t bk = 0;
-					if (i < n) {
-						const uint32_t p = tp[i];
-						const float f0 = (float)(p & 255u), f1 = (float)((p >> 8) & 255u), f2 = (float)((p >> 16) & 255u);
-						const float f3 = nc == 4u ? (float)(p >> 24) : 0.0f;
-						float bd = 3.0e38f;
-#pragma unroll
-						for (uint32_t a = 0; a < 4u; ++a) {
-							if (a < P) {
-								const float e0 = f0 - cen[a][0], e1 = f1 - cen[a][1], e2 = f2 - cen[a][2], e3 = f3 - cen[a][3];
-								float d = e0*e0;
-								d = fmaf(e1, e1, d);
-								d = fmaf(e2, e2, d);
-								d = fmaf(e3, e3, d);
-								if (live[a] && d < bd) { bd = d; bk = a; }
-							}
-						}
-					}
-#pragma unroll
-					for (uint32_t a = 0; a < 4u; ++a) {
-						if (a < P) {
-							const unsigned long long bal = __ballot(i < n && bk == a);
-							if (pair) {
-								const unsigned long long g32 = h ? bal >> 32 : (bal & 0xFFFFFFFFull);
-								km[a][r >> 1] |= g32 << (32u*(r & 1u));
-							} else if (r < 3u)
-								km[a][r] |= bal;
-						}
-					}
-				}
-			}
-			// lane = table entry: mismatch = n - best label-permuted overlap
 			// (Normal on footprints of 64 texels and more ranks 256 seeds: oracle encode_core)
 			const uint32_t limit = (lad.limit == 64u && n >= 64u) ? 256u : lad.limit;
 			const uint32_t np = H->npart[P - 2u] < limit ? H->npart[P - 2u] : limit;
-			const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(blob + H->off_mask[P - 2u]);
-			// up to 256 entries: 4 per lane of a 64-lane group, 8 per lane when two blocks share the wave
 			uint32_t keys[8];
+			// Footprints below 64 texels rank the seeds by LINE-FIT error (oracle: linefit_key -- the same integers,
+			// the same float operations in the same order): lane = table entry; per subset the moments of its member
+			// texels (four texels per step through v_dot4_u32_u8, the members as a byte mask from the entry's id row;
+			// the last subset = the block minus the others), C = count * sum p p' - (sum p)(sum p)', the principal
+			// axis, and what the best line through the subset's mean leaves: (trace C - axis' C axis) / count.
+			// Key = the sum's float bits without the low 10, then the entry's index.  On blocks of real photographs
+			// the cluster-overlap ranking below missed the seed the wide search takes (4x4 High 0.55 -> 0.16 dB under
+			// the bound, 6x6 0.50 -> 0.32); footprints of 64 texels and more gain nothing and keep it.
+			if (linefit) {
+				// members of subset c of entry e: bit i of word 0 of the entry's 64-bit texel masks (n < 64)
+				const unsigned long long* lmasks = reinterpret_cast<const unsigned long long*>(blob + H->off_mask[P - 2u]);
 #pragma unroll
-			for (uint32_t m = 0; m < 8u; ++m) {
-				keys[m] = 0xFFFFFFFFu;
-				const uint32_t e = hl + gsz*m;
-				if (e < np) {
-					uint32_t O[4][4];
+				for (uint32_t m = 0; m < 8u; ++m)
+					keys[m] = 0xFFFFFFFFu;
+#pragma unroll 1
+				for (uint32_t m = 0; m < 8u && gsz*m < np; ++m) {
+					const uint32_t e = hl + gsz*m;
+					uint32_t key = 0xFFFFFFFFu;
+					if (e < np) {
+						// (the 12-wave build serves Lowest / Low: two-partition seeds only -- one computed subset)
+						constexpr uint32_t NS = MAXW == 12 ? 1u : 3u;
+						int ac[NS][15];
+						unsigned long long mk[NS];
 #pragma unroll
-					for (uint32_t a = 0; a < 4u; ++a)
+						for (uint32_t s_ = 0; s_ < NS; ++s_) {
+							mk[s_] = s_ + 1u < P ? lmasks[((size_t)e*4u + s_)*3u] : 0ull;
 #pragma unroll
-						for (uint32_t c = 0; c < 4u; ++c) {
-							O[a][c] = 0;
-							if (a < P && c < P) {
-								const unsigned long long* pm = masks + ((size_t)e*4u + c)*3u;
-								uint32_t o = (uint32_t)__popcll(km[a][0] & pm[0]);
-								if (n > 64u)
-									o += (uint32_t)__popcll(km[a][1] & pm[1]) + (uint32_t)__popcll(km[a][2] & pm[2]);
-								O[a][c] = o;
+							for (int k = 0; k < 15; ++k)
+								ac[s_][k] = 0;
+						}
+#pragma unroll 1
+						for (uint32_t i = 0; i < n; i += 4u) {
+							const uint4 pl = lf_planes[i >> 2];
+							const uint32_t P0 = pl.x, P1 = pl.y, P2 = pl.z, P3 = pl.w;
+#pragma unroll
+							for (uint32_t s_ = 0; s_ < NS; ++s_) {
+								if (s_ + 1u < P) {
+									// four membership bits -> a byte mask (bit k of the nibble lands on bit 8 k: no two
+									// shifted copies overlap)
+									const uint32_t nib = (uint32_t)(mk[s_] >> i) & 15u;
+									const uint32_t m1 = (nib*0x00204081u) & 0x01010101u;
+									const uint32_t M = (m1 << 8) - m1;
+									const uint32_t q0 = P0 & M, q1 = P1 & M, q2 = P2 & M, q3 = P3 & M;
+									int* A = ac[s_];
+									A[0] += __popc(nib);
+									A[1] = (int)__builtin_amdgcn_udot4(q0, 0x01010101u, (uint32_t)A[1], false);
+									A[2] = (int)__builtin_amdgcn_udot4(q1, 0x01010101u, (uint32_t)A[2], false);
+									A[3] = (int)__builtin_amdgcn_udot4(q2, 0x01010101u, (uint32_t)A[3], false);
+									A[4] = (int)__builtin_amdgcn_udot4(q3, 0x01010101u, (uint32_t)A[4], false);
+									A[5] = (int)__builtin_amdgcn_udot4(q0, P0, (uint32_t)A[5], false);
+									A[6] = (int)__builtin_amdgcn_udot4(q0, P1, (uint32_t)A[6], false);
+									A[7] = (int)__builtin_amdgcn_udot4(q0, P2, (uint32_t)A[7], false);
+									A[8] = (int)__builtin_amdgcn_udot4(q0, P3, (uint32_t)A[8], false);
+									A[9] = (int)__builtin_amdgcn_udot4(q1, P1, (uint32_t)A[9], false);
+									A[10] = (int)__builtin_amdgcn_udot4(q1, P2, (uint32_t)A[10], false);
+									A[11] = (int)__builtin_amdgcn_udot4(q1, P3, (uint32_t)A[11], false);
+									A[12] = (int)__builtin_amdgcn_udot4(q2, P2, (uint32_t)A[12], false);
+									A[13] = (int)__builtin_amdgcn_udot4(q2, P3, (uint32_t)A[13], false);
+									A[14] = (int)__builtin_amdgcn_udot4(q3, P3, (uint32_t)A[14], false);
+								}
 							}
 						}
-					uint32_t best = 0;
-					if (P == 2u)
-						best = max(O[0][0] + O[1][1], O[0][1] + O[1][0]);
-					else if (P == 3u) {
-						best = max(max(O[0][0] + O[1][1] + O[2][2], O[0][0] + O[1][2] + O[2][1]),
-							max(max(O[0][1] + O[1][0] + O[2][2], O[0][1] + O[1][2] + O[2][0]),
-								max(O[0][2] + O[1][0] + O[2][1], O[0][2] + O[1][1] + O[2][0])));
+						// the last subset: the block minus the others
+						int rest[15] = {(int)n, sum[0], sum[1], sum[2], sum[3], (int)m00, (int)m01, (int)m02, (int)m03, (int)m11, (int)m12,
+							(int)m13, (int)m22, (int)m23, (int)m33};
+#pragma unroll
+						for (uint32_t s_ = 0; s_ < NS; ++s_)
+							if (s_ + 1u < P)
+#pragma unroll
+								for (int k = 0; k < 15; ++k)
+									rest[k] -= ac[s_][k];
+						float tot = 0.0f;
+#pragma unroll
+						for (uint32_t s_ = 0; s_ <= NS; ++s_) {
+							if (s_ < P) {
+								int A[15];
+#pragma unroll
+								for (int k = 0; k < 15; ++k)
+									A[k] = (s_ + 1u == P || s_ == NS) ? rest[k] : ac[s_ < NS ? s_ : 0u][k];
+								const int cn = A[0];
+								if (cn) {
+									Cov Cs;
+									Cs.c00 = (float)(cn*A[5] - A[1]*A[1]); Cs.c01 = (float)(cn*A[6] - A[1]*A[2]);
+									Cs.c02 = (float)(cn*A[7] - A[1]*A[3]); Cs.c03 = (float)(cn*A[8] - A[1]*A[4]);
+									Cs.c11 = (float)(cn*A[9] - A[2]*A[2]); Cs.c12 = (float)(cn*A[10] - A[2]*A[3]);
+									Cs.c13 = (float)(cn*A[11] - A[2]*A[4]); Cs.c22 = (float)(cn*A[12] - A[3]*A[3]);
+									Cs.c23 = (float)(cn*A[13] - A[3]*A[4]); Cs.c33 = (float)(cn*A[14] - A[4]*A[4]);
+									tot = tot + linefit_energy(Cs, cn);
+								}
+							}
+						}
+						if (!(tot > 0.0f))
+							tot = 0.0f;
+						key = (__float_as_uint(tot) & ~1023u) | e;
+					}
+#pragma unroll
+					for (uint32_t k = 0; k < 8u; ++k)
+						keys[k] = k == m ? key : keys[k];
+				}
+			} else {
+				const float step = (tmax - tmin)*(1.0f/(float)P);
+				uint32_t ks01[4] = {0, 0, 0, 0}, ks23[4] = {0, 0, 0, 0}, kcnt[4] = {0, 0, 0, 0};
+				for (uint32_t i = hl; i < n; i += gsz) {
+					const uint32_t p = tp[i];
+					const uint32_t c0 = p & 255u, c1 = (p >> 8) & 255u, c2 = (p >> 16) & 255u, c3 = nc == 4u ? p >> 24 : 0u;
+					float t = axis[0]*((float)c0 - mean[0]);
+					t = fmaf(axis[1], (float)c1 - mean[1], t);
+					t = fmaf(axis[2], (float)c2 - mean[2], t);
+					t = fmaf(axis[3], (float)c3 - mean[3], t);
+					uint32_t k = 0;
+#pragma unroll
+					for (uint32_t m = 1; m < 4u; ++m)
+						if (m < P && t > fmaf(step, (float)m, tmin)) k = m;
+#pragma unroll
+					for (uint32_t a = 0; a < 4u; ++a) {
+						const bool mine = k == a;
+						ks01[a] += mine ? (c0 | (c1 << 16)) : 0u;
+						ks23[a] += mine ? (c2 | (c3 << 16)) : 0u;
+						kcnt[a] += mine ? 1u : 0u;
+					}
+				}
+				float cen[4][4];
+				bool live[4];
+#pragma unroll
+				for (uint32_t a = 0; a < 4u; ++a) {
+					if (a < P) {
+						const uint32_t t01 = cf_group_sum_u32(ks01[a], pair, h), t23 = cf_group_sum_u32(ks23[a], pair, h);
+						const uint32_t cn = cf_group_sum_u32(kcnt[a], pair, h);
+						const float ic = cn ? 1.0f/(float)cn : 0.0f;
+						cen[a][0] = (float)(t01 & 0xFFFFu)*ic; cen[a][1] = (float)(t01 >> 16)*ic;
+						cen[a][2] = (float)(t23 & 0xFFFFu)*ic; cen[a][3] = (float)(t23 >> 16)*ic;
+						live[a] = cn != 0u;
 					} else {
+						cen[a][0] = cen[a][1] = cen[a][2] = cen[a][3] = 0.0f;
+						live[a] = false;
+					}
+				}
+				unsigned long long km[4][3];
+#pragma unroll
+				for (int a = 0; a < 4; ++a)
+					km[a][0] = km[a][1] = km[a][2] = 0ull;
+				const uint32_t rounds = (n + gsz - 1u)/gsz;
+#pragma unroll
+				for (uint32_t r = 0; r < 5u; ++r) {
+					if (r < rounds) {
+						const uint32_t i = r*gsz + hl;
+						uint32_t bk = 0;
+						if (i < n) {
+							const uint32_t p = tp[i];
+							const float f0 = (float)(p & 255u), f1 = (float)((p >> 8) & 255u), f2 = (float)((p >> 16) & 255u);
+							const float f3 = nc == 4u ? (float)(p >> 24) : 0.0f;
+							float bd = 3.0e38f;
+#pragma unroll
+							for (uint32_t a = 0; a < 4u; ++a) {
+								if (a < P) {
+									const float e0 = f0 - cen[a][0], e1 = f1 - cen[a][1], e2 = f2 - cen[a][2], e3 = f3 - cen[a][3];
+									float d = e0*e0;
+									d = fmaf(e1, e1, d);
+									d = fmaf(e2, e2, d);
+									d = fmaf(e3, e3, d);
+									if (live[a] && d < bd) { bd = d; bk = a; }
+								}
+							}
+						}
+#pragma unroll
+						for (uint32_t a = 0; a < 4u; ++a) {
+							if (a < P) {
+								const unsigned long long bal = __ballot(i < n && bk == a);
+								if (pair) {
+									const unsigned long long g32 = h ? bal >> 32 : (bal & 0xFFFFFFFFull);
+									km[a][r >> 1] |= g32 << (32u*(r & 1u));
+								} else if (r < 3u)
+									km[a][r] |= bal;
+							}
+						}
+					}
+				}
+				// lane = table entry: mismatch = n - best label-permuted overlap
+				const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(blob + H->off_mask[P - 2u]);
+				// up to 256 entries: 4 per lane of a 64-lane group, 8 per lane when two blocks share the wave
+#pragma unroll
+				for (uint32_t m = 0; m < 8u; ++m) {
+					keys[m] = 0xFFFFFFFFu;
+					const uint32_t e = hl + gsz*m;
+					if (e < np) {
+						uint32_t O[4][4];
 #pragma unroll
 						for (uint32_t a = 0; a < 4u; ++a)
 #pragma unroll
-							for (uint32_t c = 0; c < 4u; ++c)
-#pragma unroll
-								for (uint32_t d = 0; d < 4u; ++d) {
-									const uint32_t e4 = 6u - a - c - d;
-									if (a != c && a != d && c != d)
-										best = max(best, O[0][a] + O[1][c] + O[2][d] + O[3][e4]);
+							for (uint32_t c = 0; c < 4u; ++c) {
+								O[a][c] = 0;
+								if (a < P && c < P) {
+									const unsigned long long* pm = masks + ((size_t)e*4u + c)*3u;
+									uint32_t o = (uint32_t)__popcll(km[a][0] & pm[0]);
+									if (n > 64u)
+										o += (uint32_t)__popcll(km[a][1] & pm[1]) + (uint32_t)__popcll(km[a][2] & pm[2]);
+									O[a][c] = o;
 								}
+							}
+						uint32_t best = 0;
+						if (P == 2u)
+							best = max(O[0][0] + O[1][1], O[0][1] + O[1][0]);
+						else if (P == 3u) {
+							best = max(max(O[0][0] + O[1][1] + O[2][2], O[0][0] + O[1][2] + O[2][1]),
+								max(max(O[0][1] + O[1][0] + O[2][2], O[0][1] + O[1][2] + O[2][0]),
+									max(O[0][2] + O[1][0] + O[2][1], O[0][2] + O[1][1] + O[2][0])));
+						} else {
+#pragma unroll
+							for (uint32_t a = 0; a < 4u; ++a)
+#pragma unroll
+								for (uint32_t c = 0; c < 4u; ++c)
+#pragma unroll
+									for (uint32_t d = 0; d < 4u; ++d) {
+										const uint32_t e4 = 6u - a - c - d;
+										if (a != c && a != d && c != d)
+											best = max(best, O[0][a] + O[1][c] + O[2][d] + O[3][e4]);
+									}
+						}
+						keys[m] = ((n - best) << 16) | e;
 					}
-					keys[m] = ((n - best) << 16) | e;
 				}
 			}
 			for (uint32_t jj = 0; jj < want; ++jj) {
@@ -1347,7 +1562,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				for (uint32_t m = 0; m < 8u; ++m)
 					keys[m] = keys[m] == gmin ? 0xFFFFFFFFu : keys[m];
 				if (gmin != 0xFFFFFFFFu) {
-					if (hl == 0u) S.pcs[npc] = pc_make(P, 0, 0, P, gmin & 0xFFFFu);
+					if (hl == 0u) S.pcs[npc] = pc_make(P, 0, 0, P, gmin & (linefit ? 1023u : 0xFFFFu));
 					++npc;
 					got2 += P == 2u ? 1u : 0u;
 					got3 += P == 3u ? 1u : 0u;
@@ -1594,11 +1809,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				}
 				__builtin_amdgcn_wave_barrier();
 				if (gact) {
-#pragma unroll 4
-					for (uint32_t i = half; i < n; i += step) {
-						const uint2 rec = inf[i];
-						decim_add(gcol, rec.x, rec.y, Trow[i]);
-					}
+					if (pair)
+						decim_walk<1u>(gcol, inf, Trow, 0u, n);
+					else
+						decim_walk<2u>(gcol, inf, Trow, half, n);
 				}
 				__builtin_amdgcn_wave_barrier();
 				if (gact && half == 0u)
@@ -1734,11 +1948,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					for (uint32_t pl = 0; pl < ((CF_ASTC_ABLATE & 16) ? 0u : planes); ++pl) {
 						const uint8_t* Trow = S.T + (pl ? 8u + ((j - 1u) & 1u) : j)*npad;
 						uint8_t* cb = pl ? colp1 : colbase;
-#pragma unroll 4
-						for (uint32_t i = 0; i < n; ++i) {
-							const uint2 rec = inf[i];
-							decim_add(cb, rec.x, rec.y, Trow[i]);
-						}
+						decim_walk<1u>(cb, inf, Trow, 0u, n);
 					}
 #pragma unroll 1
 					for (uint32_t pl = 0; pl < planes; ++pl)
@@ -2296,27 +2506,56 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							const uint32_t mlo = dual ? (ccs == 0u ? 0x0000FFFFu : (ccs == 1u ? 0xFFFF0000u : 0u)) : 0u;
 							const uint32_t mhi = dual ? (ccs == 2u ? 0x0000FFFFu : (ccs == 3u ? 0xFFFF0000u : 0u)) : 0u;
 							const bool wide = __ballot(P > 2u) != 0ull;
-#pragma unroll 2
-							for (uint32_t i = 0; i < ((CF_ASTC_ABLATE & 256) ? 1u : n); ++i) {
-								const uint2 rec = inf[i];
-								const uint32_t w0p = infill_w(colbase, rec.x, rec.y)*0x00010001u;
-								const uint32_t w1p = dual ? infill_w(colp1, rec.x, rec.y)*0x00010001u : w0p;
-								const uint32_t wlo = (w0p & ~mlo) | (w1p & mlo), whi = (w0p & ~mhi) | (w1p & mhi);
-								const uint32_t part = byp ? 0u : prow[i];
-								uint32_t q0 = part == 0u ? D0[0] : D0[1], q1 = part == 0u ? D1[0] : D1[1];
-								if (wide) {
-									q0 = part == 2u ? D0[2] : (part == 3u ? D0[3] : q0);
-									q1 = part == 2u ? D1[2] : (part == 3u ? D1[3] : q1);
+							// Four texels per step, loads first: the four infill records, the texels and the partition
+							// ids are independent LDS reads, the (8 or 16) weight halves depend on the records only --
+							// two LDS round trips per FOUR texels (the one-texel form waited for three per texel:
+							// record, weight halves, partition id).  Texels past the footprint repeat the last one and
+							// count zero.
+#pragma unroll 1
+							for (uint32_t i = 0; i < ((CF_ASTC_ABLATE & 256) ? 1u : n); i += 4u) {
+								uint2 rec[4];
+								uint32_t px[4];
+#pragma unroll
+								for (uint32_t k = 0; k < 4u; ++k) {
+									const uint32_t ik = min(i + k, n - 1u);
+									rec[k] = inf[ik];
+									px[k] = tp[ik];
 								}
-								const uint32_t p = tp[i];
-								const uint32_t vlo = pk_interp(__builtin_amdgcn_perm(0u, q0, 0x0C010C00u), __builtin_amdgcn_perm(0u, q1, 0x0C010C00u), wlo);
-								const uint32_t vhi = pk_interp(__builtin_amdgcn_perm(0u, q0, 0x0C030C02u), __builtin_amdgcn_perm(0u, q1, 0x0C030C02u), whi);
-								const uint32_t dlo = pk_sub_i16(vlo, __builtin_amdgcn_perm(0u, p, 0x0C010C00u));
-								const uint32_t dhi = pk_sub_i16(vhi, __builtin_amdgcn_perm(0u, p, 0x0C030C02u));
-								const uint32_t ergb = (uint32_t)sdot2_i16(dlo, dlo, sdot2_i16(dhi, dhi & 0x0000FFFFu, 0));
-								const uint32_t ea = (uint32_t)sdot2_i16(dhi, dhi & 0xFFFF0000u, 0);
-								const uint32_t wa = (aflags & ASTC_FLAG_ALPHA_WEIGHT) ? (p >> 24) : 255u;
-								e64 += __umul24(ergb, wa) + __umul24(ea, 255u);      // < 2^27 per texel: one 32-bit value, a 64-bit add
+								const uint32_t pw = byp ? 0u : *reinterpret_cast<const uint32_t*>(prow + i);
+								uint32_t w0p[4], w1p[4];
+#pragma unroll
+								for (uint32_t k = 0; k < 4u; ++k)
+									w0p[k] = infill_w(colbase, rec[k].x, rec[k].y)*0x00010001u;
+#pragma unroll
+								for (uint32_t k = 0; k < 4u; ++k)
+									w1p[k] = w0p[k];
+								if (dual) {
+#pragma unroll
+									for (uint32_t k = 0; k < 4u; ++k)
+										w1p[k] = infill_w(colp1, rec[k].x, rec[k].y)*0x00010001u;
+								}
+								uint32_t acc = 0;         // four texels: < 2^29
+#pragma unroll
+								for (uint32_t k = 0; k < 4u; ++k) {
+									const uint32_t wlo = (w0p[k] & ~mlo) | (w1p[k] & mlo), whi = (w0p[k] & ~mhi) | (w1p[k] & mhi);
+									const uint32_t part = (pw >> (8u*k)) & 255u;
+									uint32_t q0 = part == 0u ? D0[0] : D0[1], q1 = part == 0u ? D1[0] : D1[1];
+									if (wide) {
+										q0 = part == 2u ? D0[2] : (part == 3u ? D0[3] : q0);
+										q1 = part == 2u ? D1[2] : (part == 3u ? D1[3] : q1);
+									}
+									const uint32_t p = px[k];
+									const uint32_t vlo = pk_interp(__builtin_amdgcn_perm(0u, q0, 0x0C010C00u), __builtin_amdgcn_perm(0u, q1, 0x0C010C00u), wlo);
+									const uint32_t vhi = pk_interp(__builtin_amdgcn_perm(0u, q0, 0x0C030C02u), __builtin_amdgcn_perm(0u, q1, 0x0C030C02u), whi);
+									const uint32_t dlo = pk_sub_i16(vlo, __builtin_amdgcn_perm(0u, p, 0x0C010C00u));
+									const uint32_t dhi = pk_sub_i16(vhi, __builtin_amdgcn_perm(0u, p, 0x0C030C02u));
+									const uint32_t ergb = (uint32_t)sdot2_i16(dlo, dlo, sdot2_i16(dhi, dhi & 0x0000FFFFu, 0));
+									const uint32_t ea = (uint32_t)sdot2_i16(dhi, dhi & 0xFFFF0000u, 0);
+									const uint32_t wa = (aflags & ASTC_FLAG_ALPHA_WEIGHT) ? (p >> 24) : 255u;
+									const uint32_t e_t = __umul24(ergb, wa) + __umul24(ea, 255u);      // < 2^27 per texel
+									acc += (i + k < n) ? e_t : 0u;
+								}
+								e64 += acc;
 							}
 						} else {
 #pragma unroll 1
@@ -2409,6 +2648,83 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				if (going) {
 					for (uint32_t k = 0; k <= PW*planes; ++k)
 						*reinterpret_cast<uint32_t*>(colbase + k*256u) = 0u;
+					if (!(aflags & ASTC_FLAG_PERCEPTUAL)) {
+						// unit channel weights: the line of a partition as byte words -- dv+ and dv- (the positive
+						// and the negative parts of D1 - D0 on the channels this plane fits), sum e0 dv, |dv|^2 and
+						// 1 / (2 |dv|^2) once per partition; a texel is then two v_dot4_u32_u8, one select per value
+						// and the rounded division (the same integers as the channel loop below).  Four texels per
+						// step, loads first.
+#pragma unroll 1
+						for (uint32_t pl = 0; pl < planes; ++pl) {
+							uint8_t* cb = pl ? colp1 : colbase;
+							uint32_t chm = nc == 4u ? 0xFFFFFFFFu : 0x00FFFFFFu;
+							if (dual)
+								chm = pl == 1u ? (0xFFu << (8u*ccs)) : (chm & ~(0xFFu << (8u*ccs)));
+							uint32_t Lp[4], Ln[4], Ldd[4];
+							int Le[4];
+							float Lr[4];
+#pragma unroll
+							for (uint32_t k = 0; k < 4u; ++k) {
+								uint32_t vp = 0, vn = 0;
+#pragma unroll
+								for (uint32_t c = 0; c < 4u; ++c) {
+									const int dv = (int)((D1[k] >> (8u*c)) & 255u) - (int)((D0[k] >> (8u*c)) & 255u);
+									vp |= (uint32_t)(dv > 0 ? dv : 0) << (8u*c);
+									vn |= (uint32_t)(dv < 0 ? -dv : 0) << (8u*c);
+								}
+								vp &= chm; vn &= chm;
+								Lp[k] = vp; Ln[k] = vn;
+								Le[k] = (int)__builtin_amdgcn_udot4(D0[k], vp, 0u, false) - (int)__builtin_amdgcn_udot4(D0[k], vn, 0u, false);
+								Ldd[k] = __builtin_amdgcn_udot4(vp, vp, __builtin_amdgcn_udot4(vn, vn, 0u, false), false);
+								Lr[k] = __builtin_amdgcn_rcpf((float)(2u*Ldd[k]));
+							}
+							const bool wide = __ballot(P > 2u) != 0ull;
+#pragma unroll 1
+							for (uint32_t i = 0; i < n; i += 4u) {
+								uint2 rec[4];
+								uint32_t px[4];
+#pragma unroll
+								for (uint32_t k = 0; k < 4u; ++k) {
+									const uint32_t ik = min(i + k, n - 1u);
+									rec[k] = inf[ik];
+									px[k] = tp[ik];
+								}
+								const uint32_t pw = byp ? 0u : *reinterpret_cast<const uint32_t*>(prow + i);
+								uint32_t Tw4[4];
+#pragma unroll
+								for (uint32_t k = 0; k < 4u; ++k) {
+									const uint32_t part = (pw >> (8u*k)) & 255u;
+									uint32_t vp = part == 0u ? Lp[0] : Lp[1], vn = part == 0u ? Ln[0] : Ln[1], dd = part == 0u ? Ldd[0] : Ldd[1];
+									int ed = part == 0u ? Le[0] : Le[1];
+									float rr = part == 0u ? Lr[0] : Lr[1];
+									if (wide) {
+										vp = part == 2u ? Lp[2] : (part == 3u ? Lp[3] : vp);
+										vn = part == 2u ? Ln[2] : (part == 3u ? Ln[3] : vn);
+										dd = part == 2u ? Ldd[2] : (part == 3u ? Ldd[3] : dd);
+										ed = part == 2u ? Le[2] : (part == 3u ? Le[3] : ed);
+										rr = part == 2u ? Lr[2] : (part == 3u ? Lr[3] : rr);
+									}
+									const int t = (int)__builtin_amdgcn_udot4(px[k], vp, 0u, false) - (int)__builtin_amdgcn_udot4(px[k], vn, 0u, false) - ed;
+									uint32_t Tw = 0;
+									if (t > 0 && dd > 0u) {
+										const uint32_t tc = (uint32_t)t > dd ? dd : (uint32_t)t;
+										const uint32_t num = 128u*tc + dd, dn = 2u*dd;
+										uint32_t qq = (uint32_t)((float)num*rr);
+										int r = (int)num - (int)(qq*dn);
+										qq = r < 0 ? qq - 1u : qq;
+										r = r < 0 ? r + (int)dn : r;
+										qq = r >= (int)dn ? qq + 1u : qq;
+										Tw = qq > 64u ? 64u : qq;
+									}
+									Tw4[k] = Tw;
+								}
+#pragma unroll
+								for (uint32_t k = 0; k < 4u; ++k)
+									if (i + k < n)
+										decim_add(cb, rec[k].x, rec[k].y, Tw4[k]);
+							}
+						}
+					} else
 #pragma unroll 1
 					for (uint32_t pl = 0; pl < planes; ++pl) {
 						uint8_t* cb = pl ? colp1 : colbase;
