@@ -1910,6 +1910,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				const uint32_t nrounds = (HDR || MAXW == 12) ? 0u : (q == 2u ? 1u : (q == 3u ? 2u : (q >= 4u ? 3u : 0u)));
 				bool going = false;
 				unsigned long long prev_err = ~0ull;
+				// the lane's decoded endpoints (bytes r, g, b, a of partition k): what the next round projects on
+				uint32_t D0[4] = {0, 0, 0, 0}, D1[4] = {0, 0, 0, 0};
 #pragma unroll 1
 				for (uint32_t rnd = 0;; ++rnd) {
 				// the lane id and every role that follows from it are formed again per round (a volatile mbcnt pair):
@@ -1917,14 +1919,29 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				uint32_t lane;
 				asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
 				const uint32_t h = pair ? lane >> 5 : 0u, hl = pair ? (lane & 31u) : lane;
-				uint8_t* colbase = wbase + lane*4u;
-				// High: lanes 0..23 = candidates 0..3 x 6 configs ((hl * 43) >> 8 == hl / 6 there), lanes 24..31 =
+				// Round 0: lane = (candidate, config).  The refinement rounds run on the group's gsz / 4 best results
+				// of round 0 only (oracle: encode_core, ASTC_REFINE_DIV), FOUR lanes per result: the quad takes the
+				// role of the result's lane (its candidate, config and weight column; the owner table sits in
+				// S.span, idle after the ranking), splits the texel walks four ways (reprojection with the atomic
+				// scatter, least-squares sums, exact error: integer partial sums met by two DPP steps) and repeats
+				// the endpoint stage, which is the same arithmetic on the same sums in all four lanes.
+				constexpr bool ROUNDS = !(HDR || MAXW == 12);       // (builds without rounds carry none of this)
+				const bool quad = ROUNDS && rnd != 0u;
+				const uint32_t qr = quad ? hl & 3u : 0u;
+				uint32_t rl = hl;
+				if (quad)
+					rl = S.span[hl >> 2];
+				const bool has_role = !quad || rl != 255u;
+				rl = has_role ? rl : 0u;
+				const uint32_t wfirst = quad ? qr*4u : 0u, wstep = quad ? 16u : 4u;      // a lane's texel groups in the walks
+				uint8_t* colbase = wbase + ((pair ? h << 5 : 0u) + rl)*4u;
+				// High: lanes 0..23 = candidates 0..3 x 6 configs ((rl * 43) >> 8 == rl / 6 there), lanes 24..31 =
 				// candidates 4..7 x 2; a lone block in a 64-lane group leaves lanes 32.. idle
-				const uint32_t jv = hl < 24u ? (hl*43u) >> 8 : (hl < 32u ? 4u + ((hl - 24u) >> 1) : 8u);
-				const uint32_t j = varK ? jv : hl >> kshift, ks = varK ? (hl < 24u ? hl - jv*6u : hl & 1u) : hl & (K - 1u);
-				const uint32_t d = j < cnt ? S.pcs[base + j] : 0u;
+				const uint32_t jv = rl < 24u ? (rl*43u) >> 8 : (rl < 32u ? 4u + ((rl - 24u) >> 1) : 8u);
+				const uint32_t j = varK ? jv : rl >> kshift, ks = varK ? (rl < 24u ? rl - jv*6u : rl & 1u) : rl & (K - 1u);
+				const uint32_t d = (j < cnt && has_role) ? S.pcs[base + j] : 0u;
 				const uint32_t P = pc_P(d), dual = pc_dual(d), ccs = pc_ccs(d), cls = pc_cls(d);
-				const uint32_t oi = (j < cnt) ? S.order[j*8u + ks] : 255u;
+				const uint32_t oi = (j < cnt && has_role) ? S.order[j*8u + ks] : 255u;
 				const bool active = !(CF_ASTC_ABLATE & 1) && !solid && j < cnt && oi != 255u;
 				const AstcCfgRec cfg = cfgs[(cls*2u + alpha_i)*64u + (active ? oi : 0u)];
 				r_cfg = oi;
@@ -1955,11 +1972,133 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						normalise_rows<true>(pl ? colp1 : colbase, den, PW, sh.wnu + wq*68u);
 					PROF_MARK(6)   // B: decimate + quantise
 				}
+				// this round's weights (oracle: wide_reproject): texel i projects on the line D0 -> D1 of its partition
+				// (the previous round's decoded endpoints), T = round(64 t / dd) clamped to 0 .. 64, straight into the
+				// decimation.  The quad shares the result's column: rows are cleared, texel groups scattered and planes
+				// normalised by different lanes, in program order (LDS operations of a wave complete in order)
+				if (quad && going) {
+					for (uint32_t k = qr; k <= PW*planes; k += 4u)
+						*reinterpret_cast<uint32_t*>(colbase + k*256u) = 0u;
+					__builtin_amdgcn_wave_barrier();
+					if (!(aflags & ASTC_FLAG_PERCEPTUAL)) {
+						// unit channel weights: the line of a partition as byte words -- dv+ and dv- (the positive
+						// and the negative parts of D1 - D0 on the channels this plane fits), sum e0 dv, |dv|^2 and
+						// 1 / (2 |dv|^2) once per partition; a texel is then two v_dot4_u32_u8, one select per value
+						// and the rounded division (the same integers as the channel loop below).  Four texels per
+						// step, loads first.
+#pragma unroll 1
+						for (uint32_t pl = 0; pl < planes; ++pl) {
+							uint8_t* cb = pl ? colp1 : colbase;
+							uint32_t chm = nc == 4u ? 0xFFFFFFFFu : 0x00FFFFFFu;
+							if (dual)
+								chm = pl == 1u ? (0xFFu << (8u*ccs)) : (chm & ~(0xFFu << (8u*ccs)));
+							uint32_t Lp[4], Ln[4], Ldd[4];
+							int Le[4];
+							float Lr[4];
+#pragma unroll
+							for (uint32_t k = 0; k < 4u; ++k) {
+								uint32_t vp = 0, vn = 0;
+#pragma unroll
+								for (uint32_t c = 0; c < 4u; ++c) {
+									const int dv = (int)((D1[k] >> (8u*c)) & 255u) - (int)((D0[k] >> (8u*c)) & 255u);
+									vp |= (uint32_t)(dv > 0 ? dv : 0) << (8u*c);
+									vn |= (uint32_t)(dv < 0 ? -dv : 0) << (8u*c);
+								}
+								vp &= chm; vn &= chm;
+								Lp[k] = vp; Ln[k] = vn;
+								Le[k] = (int)__builtin_amdgcn_udot4(D0[k], vp, 0u, false) - (int)__builtin_amdgcn_udot4(D0[k], vn, 0u, false);
+								Ldd[k] = __builtin_amdgcn_udot4(vp, vp, __builtin_amdgcn_udot4(vn, vn, 0u, false), false);
+								Lr[k] = __builtin_amdgcn_rcpf((float)(2u*Ldd[k]));
+							}
+							const bool wide = __ballot(P > 2u) != 0ull;
+#pragma unroll 1
+							for (uint32_t i = wfirst; i < n; i += wstep) {
+								uint2 rec[4];
+								uint32_t px[4];
+#pragma unroll
+								for (uint32_t k = 0; k < 4u; ++k) {
+									const uint32_t ik = min(i + k, n - 1u);
+									rec[k] = inf[ik];
+									px[k] = tp[ik];
+								}
+								const uint32_t pw = byp ? 0u : *reinterpret_cast<const uint32_t*>(prow + i);
+								uint32_t Tw4[4];
+#pragma unroll
+								for (uint32_t k = 0; k < 4u; ++k) {
+									const uint32_t part = (pw >> (8u*k)) & 255u;
+									uint32_t vp = part == 0u ? Lp[0] : Lp[1], vn = part == 0u ? Ln[0] : Ln[1], dd = part == 0u ? Ldd[0] : Ldd[1];
+									int ed = part == 0u ? Le[0] : Le[1];
+									float rr = part == 0u ? Lr[0] : Lr[1];
+									if (wide) {
+										vp = part == 2u ? Lp[2] : (part == 3u ? Lp[3] : vp);
+										vn = part == 2u ? Ln[2] : (part == 3u ? Ln[3] : vn);
+										dd = part == 2u ? Ldd[2] : (part == 3u ? Ldd[3] : dd);
+										ed = part == 2u ? Le[2] : (part == 3u ? Le[3] : ed);
+										rr = part == 2u ? Lr[2] : (part == 3u ? Lr[3] : rr);
+									}
+									const int t = (int)__builtin_amdgcn_udot4(px[k], vp, 0u, false) - (int)__builtin_amdgcn_udot4(px[k], vn, 0u, false) - ed;
+									uint32_t Tw = 0;
+									if (t > 0 && dd > 0u) {
+										const uint32_t tc = (uint32_t)t > dd ? dd : (uint32_t)t;
+										const uint32_t num = 128u*tc + dd, dn = 2u*dd;
+										uint32_t qq = (uint32_t)((float)num*rr);
+										int r = (int)num - (int)(qq*dn);
+										qq = r < 0 ? qq - 1u : qq;
+										r = r < 0 ? r + (int)dn : r;
+										qq = r >= (int)dn ? qq + 1u : qq;
+										Tw = qq > 64u ? 64u : qq;
+									}
+									Tw4[k] = Tw;
+								}
+#pragma unroll
+								for (uint32_t k = 0; k < 4u; ++k)
+									if (i + k < n)
+										decim_add(cb, rec[k].x, rec[k].y, Tw4[k]);
+							}
+						}
+					} else
+#pragma unroll 1
+					for (uint32_t pl = 0; pl < planes; ++pl) {
+						uint8_t* cb = pl ? colp1 : colbase;
+#pragma unroll 2
+						for (uint32_t i = qr; i < n; i += 4u) {
+							const uint2 rec = inf[i];
+							const uint32_t part = byp ? 0u : prow[i];
+							const uint32_t q0 = part == 0u ? D0[0] : (part == 1u ? D0[1] : (part == 2u ? D0[2] : D0[3]));
+							const uint32_t q1 = part == 0u ? D1[0] : (part == 1u ? D1[1] : (part == 2u ? D1[2] : D1[3]));
+							const uint32_t p = tp[i];
+							int t = 0;
+							uint32_t dd = 0;
+#pragma unroll
+							for (uint32_t c = 0; c < 4u; ++c) {
+								const bool use = c < nc && (!dual || ((c == ccs) == (pl == 1u)));
+								const int e0c = (int)((q0 >> (8u*c)) & 255u), dv = (int)((q1 >> (8u*c)) & 255u) - e0c;
+								const int pc = (int)((p >> (8u*c)) & 255u);
+								t += use ? (pc - e0c)*dv*(int)cw[c] : 0;
+								dd += use ? (uint32_t)(dv*dv)*cw[c] : 0u;
+							}
+							uint32_t Tw = 0;
+							if (t > 0 && dd > 0u) {
+								const uint32_t tc = (uint32_t)t > dd ? dd : (uint32_t)t;
+								const uint32_t num = 128u*tc + dd, dn = 2u*dd;
+								uint32_t qq = (uint32_t)((float)num*__builtin_amdgcn_rcpf((float)dn));
+								int r = (int)num - (int)(qq*dn);
+								qq = r < 0 ? qq - 1u : qq;
+								r = r < 0 ? r + (int)dn : r;
+								qq = r >= (int)dn ? qq + 1u : qq;
+								Tw = qq > 64u ? 64u : qq;
+							}
+							decim_add(cb, rec.x, rec.y, Tw);
+						}
+					}
+					__builtin_amdgcn_wave_barrier();
+					if (qr < planes)
+						normalise_rows<true>(qr ? colp1 : colbase, den, PW, sh.wnu + wq*68u);
+				}
+				__builtin_amdgcn_wave_barrier();
 				err = ~0ull; r_cem = 0; r_lv = 0; r_ncv = 0;
 #pragma unroll
 				for (int k = 0; k < 5; ++k) r_cv[k] = 0;
-				// the lane's decoded endpoints (bytes r, g, b, a of partition k): what the next round projects on
-				uint32_t D0[4] = {0, 0, 0, 0}, D1[4] = {0, 0, 0, 0};
 				if (going) {
 					if (HDR) {
 						// ---- HDR: the pair is fitted and priced on the 16-bit LNS texels through the real
@@ -2361,7 +2500,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					// a set's members as a byte mask -- S, C and the four V_c of a set are six v_dot4_u32_u8 per
 					// step instead of six multiply-adds per texel (texels past the footprint carry weight 0)
 #pragma unroll 1
-					for (uint32_t i = 0; i < ((CF_ASTC_ABLATE & 64) ? 4u : n); i += 4u) {
+					for (uint32_t i = wfirst; i < ((CF_ASTC_ABLATE & 64) ? 4u : n); i += wstep) {
 						uint32_t WA = 0, W1 = 0;
 #pragma unroll
 						for (uint32_t k = 0; k < 4u; ++k) {
@@ -2389,6 +2528,15 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						if (any3) ASTC_ACC(q2, 2u, WA)
 						if (any4) ASTC_ACC(q3, 3u, WA)
 #undef ASTC_ACC
+					}
+					if (quad) {
+						// the quad's partial sums meet (exact integers: the order of the additions does not matter)
+#define ASTC_QSUM(v) { v += cf_xor1(v); v += cf_xor2(v); }
+#define ASTC_QSET(Q) ASTC_QSUM(Q.S) ASTC_QSUM(Q.C) ASTC_QSUM(Q.V0) ASTC_QSUM(Q.V1) ASTC_QSUM(Q.V2) ASTC_QSUM(Q.V3)
+						ASTC_QSET(q0) ASTC_QSET(q1)
+						if (any3) ASTC_QSET(q2)
+						if (any4) ASTC_QSET(q3)
+#undef ASTC_QSET
 					}
 #define SEL4(i, a0, a1, a2, a3) ((i) == 0u ? (a0) : ((i) == 1u ? (a1) : ((i) == 2u ? (a2) : (a3))))
 					// least-squares endpoints of partition p, one partition at a time (nothing but the
@@ -2512,7 +2660,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							// record, weight halves, partition id).  Texels past the footprint repeat the last one and
 							// count zero.
 #pragma unroll 1
-							for (uint32_t i = 0; i < ((CF_ASTC_ABLATE & 256) ? 1u : n); i += 4u) {
+							for (uint32_t i = wfirst; i < ((CF_ASTC_ABLATE & 256) ? 1u : n); i += wstep) {
 								uint2 rec[4];
 								uint32_t px[4];
 #pragma unroll
@@ -2559,7 +2707,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							}
 						} else {
 #pragma unroll 1
-						for (uint32_t i = 0; i < ((CF_ASTC_ABLATE & 256) ? 1u : n); ++i) {
+						for (uint32_t i = qr; i < ((CF_ASTC_ABLATE & 256) ? 1u : n); i += (quad ? 4u : 1u)) {
 							const uint2 rec = inf[i];
 							const uint32_t w0 = infill_w(colbase, rec.x, rec.y);
 							const uint32_t w1 = dual ? infill_w(colp1, rec.x, rec.y) : w0;
@@ -2587,6 +2735,13 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							e64 += (unsigned long long)ergb*wa + (unsigned long long)ea*255ull;
 						}
 						}
+						if (quad) {
+							// the quad's partial errors meet
+							uint32_t lo_ = (uint32_t)e64, hi_ = (uint32_t)(e64 >> 32);
+							e64 += (unsigned long long)cf_xor1(lo_) | ((unsigned long long)cf_xor1(hi_) << 32);
+							lo_ = (uint32_t)e64; hi_ = (uint32_t)(e64 >> 32);
+							e64 += (unsigned long long)cf_xor2(lo_) | ((unsigned long long)cf_xor2(hi_) << 32);
+						}
 						err = e64;
 						r_cem = hdrf ? (has_alpha ? ((hdrf & 2u) ? 15u : 14u) : 11u)
 							: (best_opt == 3 ? (has_alpha ? 13u : 9u)
@@ -2607,8 +2762,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				prev_err = going ? err : prev_err;
 				PROF_MARK(9)   // B: exact error (+ idle lanes waiting)
 				// ---- argmin (error, id); the winner parks its result in the block's slot ----
-				const uint32_t id = pass*64u + hl;
-				unsigned long long key = err == ~0ull ? ~0ull : ((err << 10) | id);
+				const uint32_t id = pass*64u + rl;
+				unsigned long long key = (err == ~0ull || qr != 0u) ? ~0ull : ((err << 10) | id);
 				const unsigned long long kmin = cf_group_min_u64(key, pair, h);
 				if (kmin != ~0ull && kmin < bestkey) {
 					bestkey = kmin;
@@ -2619,7 +2774,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						for (int k = 0; k < 5; ++k)
 							S.best[4 + k] = r_cv[k];
 						// where the group finds this lane's weight column and how to walk it
-						S.best[2] = lane | (wq << 8) | (dual << 16) | (PW << 24);
+						S.best[2] = ((pair ? h << 5 : 0u) + rl) | (wq << 8) | (dual << 16) | (PW << 24);
 						S.best[3] = (uint32_t)cfg.N | ((uint32_t)sh.grid[(uint32_t)cfg.grid*4u + 3u] << 8) | ((uint32_t)cfg.ng << 16);
 					}
 					__builtin_amdgcn_wave_barrier();
@@ -2643,125 +2798,38 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				__builtin_amdgcn_wave_barrier();
 				if (rnd >= nrounds || __ballot(going) == 0ull)
 					break;
-				// the next round's weights (oracle: wide_reproject): texel i projects on the line D0 -> D1 of its
-				// partition, T = round(64 t / dd) clamped to 0 .. 64, straight into the decimation
-				if (going) {
-					for (uint32_t k = 0; k <= PW*planes; ++k)
-						*reinterpret_cast<uint32_t*>(colbase + k*256u) = 0u;
-					if (!(aflags & ASTC_FLAG_PERCEPTUAL)) {
-						// unit channel weights: the line of a partition as byte words -- dv+ and dv- (the positive
-						// and the negative parts of D1 - D0 on the channels this plane fits), sum e0 dv, |dv|^2 and
-						// 1 / (2 |dv|^2) once per partition; a texel is then two v_dot4_u32_u8, one select per value
-						// and the rounded division (the same integers as the channel loop below).  Four texels per
-						// step, loads first.
+				if (ROUNDS && rnd == 0u) {
+					// The group's gsz / 4 best results of round 0 go on (oracle: encode_core, ASTC_REFINE_DIV): a lane's
+					// rank = the results ahead of it by (error, lane); result of rank u -> quad u.  Then every quad
+					// lane takes over its result's state: decoded endpoints and the error to beat.
+					const unsigned long long mykey = going ? ((err << 10) | hl) : ~0ull;
+					const uint32_t mylo = (uint32_t)mykey, myhi = (uint32_t)(mykey >> 32);
+					uint32_t rank = 0;
 #pragma unroll 1
-						for (uint32_t pl = 0; pl < planes; ++pl) {
-							uint8_t* cb = pl ? colp1 : colbase;
-							uint32_t chm = nc == 4u ? 0xFFFFFFFFu : 0x00FFFFFFu;
-							if (dual)
-								chm = pl == 1u ? (0xFFu << (8u*ccs)) : (chm & ~(0xFFu << (8u*ccs)));
-							uint32_t Lp[4], Ln[4], Ldd[4];
-							int Le[4];
-							float Lr[4];
-#pragma unroll
-							for (uint32_t k = 0; k < 4u; ++k) {
-								uint32_t vp = 0, vn = 0;
-#pragma unroll
-								for (uint32_t c = 0; c < 4u; ++c) {
-									const int dv = (int)((D1[k] >> (8u*c)) & 255u) - (int)((D0[k] >> (8u*c)) & 255u);
-									vp |= (uint32_t)(dv > 0 ? dv : 0) << (8u*c);
-									vn |= (uint32_t)(dv < 0 ? -dv : 0) << (8u*c);
-								}
-								vp &= chm; vn &= chm;
-								Lp[k] = vp; Ln[k] = vn;
-								Le[k] = (int)__builtin_amdgcn_udot4(D0[k], vp, 0u, false) - (int)__builtin_amdgcn_udot4(D0[k], vn, 0u, false);
-								Ldd[k] = __builtin_amdgcn_udot4(vp, vp, __builtin_amdgcn_udot4(vn, vn, 0u, false), false);
-								Lr[k] = __builtin_amdgcn_rcpf((float)(2u*Ldd[k]));
-							}
-							const bool wide = __ballot(P > 2u) != 0ull;
-#pragma unroll 1
-							for (uint32_t i = 0; i < n; i += 4u) {
-								uint2 rec[4];
-								uint32_t px[4];
-#pragma unroll
-								for (uint32_t k = 0; k < 4u; ++k) {
-									const uint32_t ik = min(i + k, n - 1u);
-									rec[k] = inf[ik];
-									px[k] = tp[ik];
-								}
-								const uint32_t pw = byp ? 0u : *reinterpret_cast<const uint32_t*>(prow + i);
-								uint32_t Tw4[4];
-#pragma unroll
-								for (uint32_t k = 0; k < 4u; ++k) {
-									const uint32_t part = (pw >> (8u*k)) & 255u;
-									uint32_t vp = part == 0u ? Lp[0] : Lp[1], vn = part == 0u ? Ln[0] : Ln[1], dd = part == 0u ? Ldd[0] : Ldd[1];
-									int ed = part == 0u ? Le[0] : Le[1];
-									float rr = part == 0u ? Lr[0] : Lr[1];
-									if (wide) {
-										vp = part == 2u ? Lp[2] : (part == 3u ? Lp[3] : vp);
-										vn = part == 2u ? Ln[2] : (part == 3u ? Ln[3] : vn);
-										dd = part == 2u ? Ldd[2] : (part == 3u ? Ldd[3] : dd);
-										ed = part == 2u ? Le[2] : (part == 3u ? Le[3] : ed);
-										rr = part == 2u ? Lr[2] : (part == 3u ? Lr[3] : rr);
-									}
-									const int t = (int)__builtin_amdgcn_udot4(px[k], vp, 0u, false) - (int)__builtin_amdgcn_udot4(px[k], vn, 0u, false) - ed;
-									uint32_t Tw = 0;
-									if (t > 0 && dd > 0u) {
-										const uint32_t tc = (uint32_t)t > dd ? dd : (uint32_t)t;
-										const uint32_t num = 128u*tc + dd, dn = 2u*dd;
-										uint32_t qq = (uint32_t)((float)num*rr);
-										int r = (int)num - (int)(qq*dn);
-										qq = r < 0 ? qq - 1u : qq;
-										r = r < 0 ? r + (int)dn : r;
-										qq = r >= (int)dn ? qq + 1u : qq;
-										Tw = qq > 64u ? 64u : qq;
-									}
-									Tw4[k] = Tw;
-								}
-#pragma unroll
-								for (uint32_t k = 0; k < 4u; ++k)
-									if (i + k < n)
-										decim_add(cb, rec[k].x, rec[k].y, Tw4[k]);
-							}
-						}
-					} else
-#pragma unroll 1
-					for (uint32_t pl = 0; pl < planes; ++pl) {
-						uint8_t* cb = pl ? colp1 : colbase;
-#pragma unroll 2
-						for (uint32_t i = 0; i < n; ++i) {
-							const uint2 rec = inf[i];
-							const uint32_t part = byp ? 0u : prow[i];
-							const uint32_t q0 = part == 0u ? D0[0] : (part == 1u ? D0[1] : (part == 2u ? D0[2] : D0[3]));
-							const uint32_t q1 = part == 0u ? D1[0] : (part == 1u ? D1[1] : (part == 2u ? D1[2] : D1[3]));
-							const uint32_t p = tp[i];
-							int t = 0;
-							uint32_t dd = 0;
-#pragma unroll
-							for (uint32_t c = 0; c < 4u; ++c) {
-								const bool use = c < nc && (!dual || ((c == ccs) == (pl == 1u)));
-								const int e0c = (int)((q0 >> (8u*c)) & 255u), dv = (int)((q1 >> (8u*c)) & 255u) - e0c;
-								const int pc = (int)((p >> (8u*c)) & 255u);
-								t += use ? (pc - e0c)*dv*(int)cw[c] : 0;
-								dd += use ? (uint32_t)(dv*dv)*cw[c] : 0u;
-							}
-							uint32_t Tw = 0;
-							if (t > 0 && dd > 0u) {
-								const uint32_t tc = (uint32_t)t > dd ? dd : (uint32_t)t;
-								const uint32_t num = 128u*tc + dd, dn = 2u*dd;
-								uint32_t qq = (uint32_t)((float)num*__builtin_amdgcn_rcpf((float)dn));
-								int r = (int)num - (int)(qq*dn);
-								qq = r < 0 ? qq - 1u : qq;
-								r = r < 0 ? r + (int)dn : r;
-								qq = r >= (int)dn ? qq + 1u : qq;
-								Tw = qq > 64u ? 64u : qq;
-							}
-							decim_add(cb, rec.x, rec.y, Tw);
-						}
+					for (uint32_t t = 0; t < 64u; ++t) {
+						const unsigned long long kt = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mylo, (int)t) |
+							((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)myhi, (int)t) << 32);
+						rank += ((!pair || (t >> 5) == h) && kt < mykey) ? 1u : 0u;
 					}
-#pragma unroll 1
-					for (uint32_t pl = 0; pl < planes; ++pl)
-						normalise_rows<true>(pl ? colp1 : colbase, den, PW, sh.wnu + wq*68u);
+					// (a lone block of a level that pairs blocks uses 32 lanes of its 64: the count is the level's)
+					const uint32_t ntop = can_pair ? 8u : 16u;
+					if (hl < 16u)
+						S.span[hl] = 255u;
+					__builtin_amdgcn_wave_barrier();
+					if (going && rank < ntop)
+						S.span[rank] = hl;
+					__builtin_amdgcn_wave_barrier();
+					const uint32_t ow = S.span[hl >> 2];
+					const int src = (int)(((pair ? h << 5 : 0u) + (ow == 255u ? hl : ow)) << 2);
+#pragma unroll
+					for (int k = 0; k < 4; ++k) {
+						D0[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)D0[k]);
+						D1[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)D1[k]);
+					}
+					const uint32_t plo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)prev_err);
+					const uint32_t phi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(prev_err >> 32));
+					prev_err = (unsigned long long)plo | ((unsigned long long)phi << 32);
+					going = ow != 255u;
 				}
 				}
 			}
