@@ -138,14 +138,17 @@ __device__ __forceinline__ void principal_axis(const Cov& C, float (&axis)[4])
 // in the same order -- trace - lambda cancels, so the two sides must agree to the bit): C = count * scatter
 // matrix, v = one power iteration from the column of the largest diagonal, rescaled by exact powers of two
 // (frexpf / ldexpf); (trace C - v' C v / v' v) / count with one rounded division.
-__device__ __forceinline__ float linefit_energy(const Cov& C, int cnt)
+// `four` (wave-uniform): some block of the wave has alpha.  Without it every term of channel 3 is 0 * 0 added to
+// a sum -- leaving those out changes at most the sign of a zero, which no later operation here turns into a
+// different number.
+__device__ __forceinline__ float linefit_energy(const Cov& C, int cnt, bool four)
 {
 	float bestd = C.c00, v0 = C.c00, v1 = C.c01, v2 = C.c02, v3 = C.c03;
 	if (C.c11 > bestd) { bestd = C.c11; v0 = C.c01; v1 = C.c11; v2 = C.c12; v3 = C.c13; }
 	asm volatile("" : "+v"(bestd));
 	if (C.c22 > bestd) { bestd = C.c22; v0 = C.c02; v1 = C.c12; v2 = C.c22; v3 = C.c23; }
 	asm volatile("" : "+v"(bestd));
-	if (C.c33 > bestd) { bestd = C.c33; v0 = C.c03; v1 = C.c13; v2 = C.c23; v3 = C.c33; }
+	if (four && C.c33 > bestd) { bestd = C.c33; v0 = C.c03; v1 = C.c13; v2 = C.c23; v3 = C.c33; }
 #pragma unroll
 	for (int it = 0; it <= 1; ++it) {
 		const float m = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
@@ -156,19 +159,30 @@ __device__ __forceinline__ float linefit_energy(const Cov& C, int cnt)
 		}
 		if (it == 1)
 			break;
-		float r0 = C.c00*v0; r0 = fmaf(C.c01, v1, r0); r0 = fmaf(C.c02, v2, r0); r0 = fmaf(C.c03, v3, r0);
-		float r1 = C.c01*v0; r1 = fmaf(C.c11, v1, r1); r1 = fmaf(C.c12, v2, r1); r1 = fmaf(C.c13, v3, r1);
-		float r2 = C.c02*v0; r2 = fmaf(C.c12, v1, r2); r2 = fmaf(C.c22, v2, r2); r2 = fmaf(C.c23, v3, r2);
-		float r3 = C.c03*v0; r3 = fmaf(C.c13, v1, r3); r3 = fmaf(C.c23, v2, r3); r3 = fmaf(C.c33, v3, r3);
+		float r0 = C.c00*v0; r0 = fmaf(C.c01, v1, r0); r0 = fmaf(C.c02, v2, r0);
+		float r1 = C.c01*v0; r1 = fmaf(C.c11, v1, r1); r1 = fmaf(C.c12, v2, r1);
+		float r2 = C.c02*v0; r2 = fmaf(C.c12, v1, r2); r2 = fmaf(C.c22, v2, r2);
+		float r3 = 0.0f;
+		if (four) {
+			r0 = fmaf(C.c03, v3, r0); r1 = fmaf(C.c13, v3, r1); r2 = fmaf(C.c23, v3, r2);
+			r3 = C.c03*v0; r3 = fmaf(C.c13, v1, r3); r3 = fmaf(C.c23, v2, r3); r3 = fmaf(C.c33, v3, r3);
+		}
 		v0 = r0; v1 = r1; v2 = r2; v3 = r3;
 	}
-	float w0 = C.c00*v0; w0 = fmaf(C.c01, v1, w0); w0 = fmaf(C.c02, v2, w0); w0 = fmaf(C.c03, v3, w0);
-	float w1 = C.c01*v0; w1 = fmaf(C.c11, v1, w1); w1 = fmaf(C.c12, v2, w1); w1 = fmaf(C.c13, v3, w1);
-	float w2 = C.c02*v0; w2 = fmaf(C.c12, v1, w2); w2 = fmaf(C.c22, v2, w2); w2 = fmaf(C.c23, v3, w2);
-	float w3 = C.c03*v0; w3 = fmaf(C.c13, v1, w3); w3 = fmaf(C.c23, v2, w3); w3 = fmaf(C.c33, v3, w3);
-	float num = v0*w0; num = fmaf(v1, w1, num); num = fmaf(v2, w2, num); num = fmaf(v3, w3, num);
-	float den = v0*v0; den = fmaf(v1, v1, den); den = fmaf(v2, v2, den); den = fmaf(v3, v3, den);
-	const float tr = ((C.c00 + C.c11) + C.c22) + C.c33;
+	float w0 = C.c00*v0; w0 = fmaf(C.c01, v1, w0); w0 = fmaf(C.c02, v2, w0);
+	float w1 = C.c01*v0; w1 = fmaf(C.c11, v1, w1); w1 = fmaf(C.c12, v2, w1);
+	float w2 = C.c02*v0; w2 = fmaf(C.c12, v1, w2); w2 = fmaf(C.c22, v2, w2);
+	float num, den, tr = (C.c00 + C.c11) + C.c22;
+	if (four) {
+		w0 = fmaf(C.c03, v3, w0); w1 = fmaf(C.c13, v3, w1); w2 = fmaf(C.c23, v3, w2);
+		float w3 = C.c03*v0; w3 = fmaf(C.c13, v1, w3); w3 = fmaf(C.c23, v2, w3); w3 = fmaf(C.c33, v3, w3);
+		num = v0*w0; num = fmaf(v1, w1, num); num = fmaf(v2, w2, num); num = fmaf(v3, w3, num);
+		den = v0*v0; den = fmaf(v1, v1, den); den = fmaf(v2, v2, den); den = fmaf(v3, v3, den);
+		tr = tr + C.c33;
+	} else {
+		num = v0*w0; num = fmaf(v1, w1, num); num = fmaf(v2, w2, num);
+		den = v0*v0; den = fmaf(v1, v1, den); den = fmaf(v2, v2, den);
+	}
 	if (!(den > 0.0f))
 		return 0.0f;
 	return fmaf(tr, den, -num)/(den*(float)cnt);
@@ -307,6 +321,45 @@ __device__ __forceinline__ void normalise_rows(uint8_t* base, const uint32_t* de
 		}
 	}
 	reinterpret_cast<uint32_t*>(base + (PW - 1u)*256u)[0] = prev | ((prev >> 8) << 16);
+}
+
+// The same, by the four lanes of a refinement quad (they share the result's column): lane qr takes the words
+// 4 qr + 16 m .. + 3.  A step is self-contained -- it also reads the word after its four (that word's first
+// weight completes the pair form of its last one) -- and every lane's reads of a step come before any lane's
+// writes of it (the scheduling barriers; the quad runs the steps in lockstep), so no lane reads a word that a
+// neighbour has already rewritten in place.
+__device__ __forceinline__ void normalise_rows_quad(uint8_t* base, const uint32_t* den, uint32_t PW, const uint8_t* wnu, uint32_t qr)
+{
+#pragma unroll 1
+	for (uint32_t k = 4u*qr; k < PW; k += 16u) {
+		uint32_t acc[5], g[9];
+		uint2 dd[5];
+#pragma unroll
+		for (uint32_t m = 0; m < 5u; ++m) {
+			const uint32_t km = min(k + m, PW - 1u);
+			acc[m] = *reinterpret_cast<const uint32_t*>(base + km*256u);
+			dd[m] = *reinterpret_cast<const uint2*>(den + 2u*km);
+		}
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (uint32_t m = 0; m < 4u; ++m) {
+			g[2u*m] = avg_round(acc[m] & 0xFFFFu, dd[m].x);
+			g[2u*m + 1u] = avg_round(acc[m] >> 16, dd[m].y);
+		}
+		g[8] = avg_round(acc[4] & 0xFFFFu, dd[4].x);
+#pragma unroll
+		for (uint32_t m = 0; m < 9u; ++m)
+			g[m] = wnu[g[m]];
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (uint32_t m = 0; m < 4u; ++m) {
+			if (k + m < PW) {
+				const uint32_t cur = g[2u*m] | (g[2u*m + 1u] << 8);
+				const uint32_t nxt = k + m + 1u < PW ? g[2u*m + 2u] : 0u;
+				*reinterpret_cast<uint32_t*>(base + (k + m)*256u) = cur | (((cur >> 8) | (nxt << 8)) << 16);
+			}
+		}
+	}
 }
 
 // the weight a texel decodes to: (8 + sum of factor x grid weight) >> 4, the ASTC infill
@@ -1341,6 +1394,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			if (linefit) {
 				// members of subset c of entry e: bit i of word 0 of the entry's 64-bit texel masks (n < 64)
 				const unsigned long long* lmasks = reinterpret_cast<const unsigned long long*>(blob + H->off_mask[P - 2u]);
+				const bool four = __ballot(nc == 4u) != 0ull;       // (wave-uniform: the channel-3 terms are all zero without it)
 #pragma unroll
 				for (uint32_t m = 0; m < 8u; ++m)
 					keys[m] = 0xFFFFFFFFu;
@@ -1378,17 +1432,19 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 									A[1] = (int)__builtin_amdgcn_udot4(q0, 0x01010101u, (uint32_t)A[1], false);
 									A[2] = (int)__builtin_amdgcn_udot4(q1, 0x01010101u, (uint32_t)A[2], false);
 									A[3] = (int)__builtin_amdgcn_udot4(q2, 0x01010101u, (uint32_t)A[3], false);
-									A[4] = (int)__builtin_amdgcn_udot4(q3, 0x01010101u, (uint32_t)A[4], false);
 									A[5] = (int)__builtin_amdgcn_udot4(q0, P0, (uint32_t)A[5], false);
 									A[6] = (int)__builtin_amdgcn_udot4(q0, P1, (uint32_t)A[6], false);
 									A[7] = (int)__builtin_amdgcn_udot4(q0, P2, (uint32_t)A[7], false);
-									A[8] = (int)__builtin_amdgcn_udot4(q0, P3, (uint32_t)A[8], false);
 									A[9] = (int)__builtin_amdgcn_udot4(q1, P1, (uint32_t)A[9], false);
 									A[10] = (int)__builtin_amdgcn_udot4(q1, P2, (uint32_t)A[10], false);
-									A[11] = (int)__builtin_amdgcn_udot4(q1, P3, (uint32_t)A[11], false);
 									A[12] = (int)__builtin_amdgcn_udot4(q2, P2, (uint32_t)A[12], false);
-									A[13] = (int)__builtin_amdgcn_udot4(q2, P3, (uint32_t)A[13], false);
-									A[14] = (int)__builtin_amdgcn_udot4(q3, P3, (uint32_t)A[14], false);
+									if (four) {
+										A[4] = (int)__builtin_amdgcn_udot4(q3, 0x01010101u, (uint32_t)A[4], false);
+										A[8] = (int)__builtin_amdgcn_udot4(q0, P3, (uint32_t)A[8], false);
+										A[11] = (int)__builtin_amdgcn_udot4(q1, P3, (uint32_t)A[11], false);
+										A[13] = (int)__builtin_amdgcn_udot4(q2, P3, (uint32_t)A[13], false);
+										A[14] = (int)__builtin_amdgcn_udot4(q3, P3, (uint32_t)A[14], false);
+									}
 								}
 							}
 						}
@@ -1417,7 +1473,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 									Cs.c11 = (float)(cn*A[9] - A[2]*A[2]); Cs.c12 = (float)(cn*A[10] - A[2]*A[3]);
 									Cs.c13 = (float)(cn*A[11] - A[2]*A[4]); Cs.c22 = (float)(cn*A[12] - A[3]*A[3]);
 									Cs.c23 = (float)(cn*A[13] - A[3]*A[4]); Cs.c33 = (float)(cn*A[14] - A[4]*A[4]);
-									tot = tot + linefit_energy(Cs, cn);
+									tot = tot + linefit_energy(Cs, cn, four);
 								}
 							}
 						}
@@ -1907,11 +1963,12 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				// (the 12-wave / 168-register build serves Lowest and Low only, which have no rounds: with the rounds
 				// compiled in it kept 18 values in scratch, and a kernel that talks across lanes must not spill vector
 				// registers -- a spill inside divergent control flow saves the active lanes only; see etc_encode.hip)
-				const uint32_t nrounds = (HDR || MAXW == 12) ? 0u : (q == 2u ? 1u : (q == 3u ? 2u : (q >= 4u ? 3u : 0u)));
+				const uint32_t nrounds = (HDR || MAXW == 12) ? 0u : (q == 2u ? 2u : (q == 3u ? 2u : (q >= 4u ? 3u : 0u)));
 				bool going = false;
 				unsigned long long prev_err = ~0ull;
 				// the lane's decoded endpoints (bytes r, g, b, a of partition k): what the next round projects on
 				uint32_t D0[4] = {0, 0, 0, 0}, D1[4] = {0, 0, 0, 0};
+				int keep_opt = -1;       // refinement rounds: the endpoint option round 0 chose
 #pragma unroll 1
 				for (uint32_t rnd = 0;; ++rnd) {
 				// the lane id and every role that follows from it are formed again per round (a volatile mbcnt pair):
@@ -2092,8 +2149,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						}
 					}
 					__builtin_amdgcn_wave_barrier();
-					if (qr < planes)
-						normalise_rows<true>(qr ? colp1 : colbase, den, PW, sh.wnu + wq*68u);
+#pragma unroll 1
+					for (uint32_t pl = 0; pl < planes; ++pl)
+						normalise_rows_quad(pl ? colp1 : colbase, den, PW, sh.wnu + wq*68u, qr);
 				}
 				__builtin_amdgcn_wave_barrier();
 				err = ~0ull; r_cem = 0; r_lv = 0; r_ncv = 0;
@@ -2598,7 +2656,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						okk[o] = okk[o] && lvs[o] >= 0;
 					}
 #pragma unroll 1
-					for (uint32_t p = 0; p < ((CF_ASTC_ABLATE & 128) ? 0u : P); ++p) {
+					// (a refinement round keeps the option round 0 chose -- oracle: the rounds' force_opt; re-deciding it
+					// bought +-0.002 dB on the real-photograph blocks -- so the quad skips the estimates)
+					for (uint32_t p = 0; p < (((CF_ASTC_ABLATE & 128) || quad) ? 0u : P); ++p) {
 						CemIn in;
 						solve(p, in);
 						uint32_t d0p, d1p, vlo, vhi;
@@ -2612,17 +2672,20 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					uint32_t best_lv = 0;
 #pragma unroll
 					for (int o = 0; o < 4; ++o)
-						if (okk[o] && est[o] < best_est) { best_est = est[o]; best_opt = o; best_lv = (uint32_t)lvs[o]; }
+						if (okk[o] && (quad ? o == keep_opt : est[o] < best_est)) { best_est = est[o]; best_opt = o; best_lv = (uint32_t)lvs[o]; }
 					if (best_opt >= 0) {
-						// materialise the chosen option: decoded endpoints + stored values
+						// materialise the chosen option: decoded endpoints + stored values.  Round 0: the lane walks its
+						// partitions.  Refinement rounds: lane p of the quad takes partition p (the option may still turn
+						// out unable to hold a pair: then the result is dropped), the quad then exchanges endpoints and values
 						const uint32_t nv = (has_alpha ? 8u : 6u) - (best_opt == 3 ? 0u : 2u*(uint32_t)best_opt);
+						bool okm = true;
 #pragma unroll 1
-						for (uint32_t p = 0; p < P; ++p) {
+						for (uint32_t p = quad ? qr : 0u; p < (quad ? (qr < P ? qr + 1u : 0u) : P); ++p) {
 							CemIn in;
 							solve(p, in);
 							float e_ = 0.0f;
 							uint32_t d0p = 0, d1p = 0, vlo = 0, vhi = 0;
-							cem_option(sh, best_opt, best_lv, has_alpha, hdrf, in, cw, e_, d0p, d1p, vlo, vhi);
+							okm = cem_option(sh, best_opt, best_lv, has_alpha, hdrf, in, cw, e_, d0p, d1p, vlo, vhi) && okm;
 #pragma unroll
 							for (uint32_t k = 0; k < 4u; ++k) {
 								D0[k] = p == k ? d0p : D0[k];
@@ -2638,6 +2701,20 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 #pragma unroll
 								for (uint32_t wd = 0; wd < 5u; ++wd)
 									r_cv[wd] |= wd == wd0 ? x0 : (wd == wd0 + 1u ? x1 : (wd == wd0 + 2u ? x2 : 0u));
+							}
+						}
+						if (quad) {
+							uint32_t o_ = okm ? 1u : 0u;
+							o_ &= cf_xor1(o_); o_ &= cf_xor2(o_);
+							okm = o_ != 0u;
+							D0[0] = cf_dpp<0x00>(D0[0]); D1[0] = cf_dpp<0x00>(D1[0]);      // quad_perm broadcasts: lane k holds partition k
+							D0[1] = cf_dpp<0x55>(D0[1]); D1[1] = cf_dpp<0x55>(D1[1]);
+							D0[2] = cf_dpp<0xAA>(D0[2]); D1[2] = cf_dpp<0xAA>(D1[2]);
+							D0[3] = cf_dpp<0xFF>(D0[3]); D1[3] = cf_dpp<0xFF>(D1[3]);
+#pragma unroll
+							for (uint32_t wd = 0; wd < 5u; ++wd) {
+								r_cv[wd] |= cf_xor1(r_cv[wd]);
+								r_cv[wd] |= cf_xor2(r_cv[wd]);
 							}
 						}
 #undef SEL4
@@ -2742,7 +2819,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							lo_ = (uint32_t)e64; hi_ = (uint32_t)(e64 >> 32);
 							e64 += (unsigned long long)cf_xor2(lo_) | ((unsigned long long)cf_xor2(hi_) << 32);
 						}
-						err = e64;
+						err = okm ? e64 : ~0ull;
 						r_cem = hdrf ? (has_alpha ? ((hdrf & 2u) ? 15u : 14u) : 11u)
 							: (best_opt == 3 ? (has_alpha ? 13u : 9u)
 								: (has_alpha ? 12u : 8u) - (best_opt == 1 ? 2u : (best_opt == 2 ? 8u : 0u)));
@@ -2829,6 +2906,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					const uint32_t plo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)prev_err);
 					const uint32_t phi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(prev_err >> 32));
 					prev_err = (unsigned long long)plo | ((unsigned long long)phi << 32);
+					const uint32_t ocem = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)r_cem);
+					keep_opt = (ocem == 8u || ocem == 12u) ? 0 : ((ocem == 6u || ocem == 10u) ? 1 : ((ocem == 0u || ocem == 4u) ? 2 : 3));
 					going = ow != 255u;
 				}
 				}

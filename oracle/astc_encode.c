@@ -1840,7 +1840,7 @@ static __thread struct { int active, q, K; astc_ladder lad; int iter_top, iter_r
 static void wide_reproject(astc_blk* b, const astc_pc* pc, const int D0[4][4], const int D1[4][4], int slot);
 typedef struct { uint64_t err; uint32_t id; int pc, k; astc_lane lane; } core_hit;
 /* a lane's round-0 result, as the ranking for the refinement rounds sees it */
-typedef struct { uint64_t err; uint32_t id; int j, k, have; int D0[4][4], D1[4][4]; } ref_rec;
+typedef struct { uint64_t err; uint32_t id; int j, k, have, cem; int D0[4][4], D1[4][4]; } ref_rec;
 #define ASTC_REFINE_DIV 4
 static __thread int tl_ref_top;          /* lab: results refined per pass (0 = gsz / ASTC_REFINE_DIV) */
 void cfo_astc_lab_set_reftop(int v) { tl_ref_top = v; }
@@ -1987,7 +1987,7 @@ static void encode_core(const int px[][4], const int lns[][4], int bw, int bh, i
 	const int mid = q == 2 || q == 3, var_k = q == 2 && !b->hdr && !(tl_lab.active && tl_lab.K);
 	const int K = (tl_lab.active && tl_lab.K) ? tl_lab.K : ((q == 2 && b->hdr) ? 8 : lad->K);
 	int gsz = q <= 2 ? 32 : 64, per_pass = var_k ? 8 : gsz/K;
-	const int rounds = b->hdr ? 0 : (tl_lab.active ? tl_lab.rounds_all : (q == 2 ? 1 : (q == 3 ? 2 : (q >= 4 ? 3 : 0))));
+	const int rounds = b->hdr ? 0 : (tl_lab.active ? tl_lab.rounds_all : (q == 2 ? 2 : (q == 3 ? 2 : (q >= 4 ? 3 : 0))));
 	if (q >= 3) {
 		/* the head of the walk: ASTC_HEAD2 two-partition seeds, then ASTC_HEAD3 three-partition seeds,
 		 * then the rest in the old order; High keeps the first pass only */
@@ -2062,7 +2062,7 @@ static void encode_core(const int px[][4], const int lns[][4], int bw, int bh, i
 				/* the lane's round-0 result enters the ranking for the refinement rounds (below, after the pass's lanes) */
 				if (cur.valid && rounds && nrec < 64) {
 					recs[nrec].err = cur.err; recs[nrec].id = id; recs[nrec].j = j; recs[nrec].k = order[k];
-					recs[nrec].have = tl_wide.have;
+					recs[nrec].have = tl_wide.have; recs[nrec].cem = cur.cem;
 					memcpy(recs[nrec].D0, tl_wide.D0, sizeof(recs[nrec].D0));
 					memcpy(recs[nrec].D1, tl_wide.D1, sizeof(recs[nrec].D1));
 					++nrec;
@@ -2116,6 +2116,12 @@ static void encode_core(const int px[][4], const int lns[][4], int bw, int bh, i
 					memcpy(D1, tl_wide.D1, sizeof(D1));
 					wide_reproject(b, pc, D0, D1, 8);
 					tl_wide.capture = 1; tl_wide.have = 0; tl_wide.tslot = 8;
+					/* the rounds keep round 0's endpoint option (re-deciding it: +-0.002 dB on the real-photograph blocks;
+					 * the kernel's quad then needs no estimates and takes one partition per lane) */
+					if (!(tl_lab.active && tl_lab.exact_opts == 3)) {
+						const int cem = rc->cem;
+						tl_wide.force_opt = (cem == 8 || cem == 12) ? 0 : ((cem == 6 || cem == 10) ? 1 : ((cem == 0 || cem == 4) ? 2 : 3));
+					}
 					phase_b(b, j, pc, &f->cfg[pc->cls][b->has_alpha][rc->k], &cur2);
 					tl_wide.capture = 0; tl_wide.tslot = -1; tl_wide.force_opt = -1;
 					if (!cur2.valid || cur2.err >= prev)
