@@ -776,7 +776,7 @@ def run_c2(args, rank, local_rank, world, backend):
             line["cpu_baseline"] = None
         if size == SIZE:
             line["vs_previous_round"] = _previous_round(line["metric"], world, value)
-        if world == 1 and size == SIZE:
+        if world == 1 and size == SIZE and not args.no_second_tile:
             line["second_tile"] = second_tile(ctx, torch, size, params, max(3, args.steps // 2), stream, not args.no_cpu_baseline)
             line["second_tile"]["vs_headline_tile"] = round(line["second_tile"]["kernel_ms"] / (avg_kernel_s * 1e3), 3)
         if world == 1 and not args.no_end_to_end:
@@ -803,6 +803,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="c2, N = 1: skip the host-buffer (PCIe-inclusive) leg")
     ap.add_argument("--no-strong", action="store_true", help="c2, N > 1: skip the row-split strong-scaling leg")
+    ap.add_argument("--no-second-tile", action="store_true",
+                    help="c2, N = 1: skip the camera-like second tile (profile passes: the kernel statistics and PMC "
+                         "averages of the run must be the headline tile's alone)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 20 if args.config == "c2" else 3

@@ -198,7 +198,7 @@ def test_etc_and_astc_ladders_on_real_photograph_blocks():
     """Round 5: the ETC and ASTC ladders are held to blocks of REAL photographs (tests/golden/real_blocks.npz) like
     BC7's.  ETC2 RGB against the TRUE optimum: round 4's ladder sat 0.51 / 0.42 / 0.34 dB under it on the 4 096 blocks,
     this round's 0.24 / 0.18 / 0.17 (tools/etc_lab.py; here the first 384).  ASTC 6x6 against cfo_astc_wide_search:
-    round 4 1.03 / 0.95 / 0.79 on 256 blocks, now 0.85 / 0.59 / 0.55 -- and High is a deeper search than Normal
+    round 4 1.03 / 0.95 / 0.79 on 256 blocks, mid-round 0.85 / 0.59 / 0.55, now 0.58 / 0.34 / 0.29 -- and High is a deeper search than Normal
     (AstcConverter.cpp:184,187: MEDIUM against THOROUGH), not the same one with more seeds ranked."""
     qt = _quality_tables()
     ps, opt = qt.etc_gap(384, np.random.default_rng(1), 38, kind="real")
@@ -206,8 +206,16 @@ def test_etc_and_astc_ladders_on_real_photograph_blocks():
     assert all(ps[q + 1] >= ps[q] - 1e-9 for q in range(4)), ps
     ps, wide = qt.astc_gap(256, np.random.default_rng(1), 6, 6, kind="real")
     assert wide >= max(ps) - 1e-9, (ps, wide)
-    assert wide - ps[3] <= 0.65 and wide - ps[2] <= 0.95, (ps, wide)
+    # (late round 5: partition seeds ranked by line-fit error, refinement rounds on the 16 best results:
+    #  0.58 / 0.34 / 0.29 on these 256 blocks, 0.54 / 0.33 / 0.28 on the 768 of profiles/r05_quality_tables.md)
+    assert wide - ps[3] <= 0.40 and wide - ps[2] <= 0.65, (ps, wide)
     assert ps[3] - ps[2] >= 0.20, ps                       # High above Normal by a measurable step
+    assert all(ps[q + 1] >= ps[q] - 1e-9 for q in range(4)), ps
+    # 4x4: the wide search takes two partitions in a third of these blocks, and the seed it takes is seldom the one
+    # a clustering of the texels points at (0.55 dB at High with the cluster-overlap ranking; 0.24 here, 0.18 on 768)
+    ps, wide = qt.astc_gap(256, np.random.default_rng(1), 4, 4, kind="real")
+    assert wide >= max(ps) - 1e-9, (ps, wide)
+    assert wide - ps[3] <= 0.30 and wide - ps[2] <= 0.45, (ps, wide)
     assert all(ps[q + 1] >= ps[q] - 1e-9 for q in range(4)), ps
 
 
