@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from cuttlefish_amd import Alpha, Format, Texture, Type, make_params, synth
+from cuttlefish_amd import Alpha, ColorSpace, Format, Texture, Type, make_params, synth
 
 pytestmark = pytest.mark.gpu
 FORMATS = [Format(v) for v in range(43, 57)]
@@ -27,6 +27,36 @@ def test_bit_exact_quality_ladder_6x6(gpu_ctx, quality):
     img = synth.photo(66, 42, seed=90 + quality)
     ref = O.encode(img, 47, quality=quality, threads=8)
     assert np.array_equal(ref, _gpu(gpu_ctx, img, Format.ASTC_6x6, quality))
+
+
+@pytest.mark.parametrize("fmt", [Format.ASTC_4x4, Format.ASTC_5x5, Format.ASTC_6x5, Format.ASTC_6x6, Format.ASTC_10x5,
+                                 Format.ASTC_8x8, Format.ASTC_12x10])
+@pytest.mark.parametrize("quality", [2, 3, 4])
+def test_refinement_quads_every_metric_and_ragged_rows(gpu_ctx, fmt, quality):
+    """Round 5: the refinement rounds run on the group's best results, four lanes per result.  Footprints whose texel
+    count is not a multiple of four (5x5, 6x5, 10x5), block rows with an odd number of blocks (the lone block of a
+    level that pairs blocks), images with and without alpha, the perceptual metric of sRGB images and the three
+    alpha types (AstcConverter.cpp:163-172: the quad then walks the channel-weighted forms of reprojection and exact
+    error) -- byte for byte against the oracle."""
+    import ctypes
+    cbw, cbh = ctypes.c_int(), ctypes.c_int()
+    O.lib().cfo_astc_footprint(int(fmt), ctypes.byref(cbw), ctypes.byref(cbh))
+    bw, bh = cbw.value, cbh.value
+    w, h = 9*bw - 2, 3*bh + 1                   # nine blocks per row (the wave's ninth is alone), ragged edges
+    img = synth.photo(w, h, seed=300 + int(fmt) + quality)
+    opaque = img.copy()
+    opaque[..., 3] = 255
+    cases = [(img, dict(color_space=1)), (opaque, dict(color_space=1, alpha=0)), (img, dict(alpha=2)), (opaque, dict())]
+    for im, kw in cases:
+        ref = O.encode(im, int(fmt), quality=quality, threads=8, **kw)
+        gkw = dict(kw)
+        if "alpha" in gkw:
+            gkw["alpha"] = Alpha(gkw["alpha"])
+        if "color_space" in gkw:
+            gkw["color_space"] = ColorSpace(gkw["color_space"])
+        got = _gpu(gpu_ctx, im, fmt, quality, **gkw)
+        bad = np.flatnonzero((ref.reshape(-1, 16) != got.reshape(-1, 16)).any(axis=1))
+        assert bad.size == 0, (kw, "blocks differ: %s" % bad[:10])
 
 
 def test_float_source_noise_swizzle_and_solid(gpu_ctx):
