@@ -154,6 +154,7 @@ struct cfhip_ctx {
 	// return without synchronising: the last asynchronous user records this event and a call on
 	// ANOTHER stream waits for it before touching the buffers (same-stream reuse is ordered anyway)
 	hipEvent_t staging_done = nullptr;
+	hipEvent_t group_up = nullptr;    // grouped host path: the group's uploads have left the caller's buffers (release hook)
 	hipStream_t staging_stream = nullptr;
 	bool staging_busy = false;
 	void* d_mip3d = nullptr;          // 3-D mip generation: the previous level's slices resized in x, y
@@ -1038,6 +1039,7 @@ void cfhip_destroy(cfhip_ctx* ctx)
 		(void)hipEventDestroy(ev);
 	if (ctx->h_out) (void)hipHostFree(ctx->h_out);
 	if (ctx->staging_done) (void)hipEventDestroy(ctx->staging_done);
+	if (ctx->group_up) (void)hipEventDestroy(ctx->group_up);
 	if (ctx->d_batch) (void)hipFree(ctx->d_batch);
 	if (ctx->d_mip3d) (void)hipFree(ctx->d_mip3d);
 	if (ctx->d_src) (void)hipFree(ctx->d_src);
@@ -1239,6 +1241,13 @@ static int encode_impl(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n,
 				so += (items[i].src_bytes + 255) & ~(size_t)255;
 				oo += (items[i].out_bytes + 255) & ~(size_t)255;
 			}
+			// release hook: the sources are free once the group's uploads have left them -- an event behind the
+			// last upload, waited for while the kernels run, not the end of the group's encode and download
+			if (consumed) {
+				if (!ctx->group_up)
+					HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->group_up, hipEventDisableTiming));
+				HIP_TRY(ctx, hipEventRecord(ctx->group_up, stream));
+			}
 			rc = batched_launch(ctx, kps, *params, run_type, stream);
 			if (rc != CFHIP_OK)
 				return rc;
@@ -1246,11 +1255,13 @@ static int encode_impl(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n,
 				HIP_TRY(ctx, hipMemcpyAsync(surfaces[i].out,
 					static_cast<uint8_t*>(ctx->d_out) + out_off[i - g0], items[i].out_bytes,
 					hipMemcpyDeviceToHost, stream));
-			HIP_TRY(ctx, hipStreamSynchronize(stream));   // staging buffers are reused
-			ctx->staging_busy = false;
-			if (consumed)
+			if (consumed) {
+				HIP_TRY(ctx, hipEventSynchronize(ctx->group_up));
 				for (size_t i = g0; i < g1; ++i)
 					consumed(user, i);             // the group's uploads have left the host buffers
+			}
+			HIP_TRY(ctx, hipStreamSynchronize(stream));   // staging buffers are reused
+			ctx->staging_busy = false;
 			g0 = g1;
 		}
 	}
