@@ -1633,9 +1633,6 @@ static int shortlist(const astc_blk* b, int P, int limit, int want, const float 
 	if (linefit)
 		for (int t = 0; t < np; ++t)
 			key[t] = linefit_key(b, P, t);
-	if (linefit && getenv("CFO_ASTC_LFDBG"))
-		for (int t = 0; t < np; ++t)
-			printf("LF cpu P%d e%d key %08x\n", P, t, key[t]);
 	int got = 0;
 	for (; got < want && got < np; ++got) {
 		int bi = -1;
