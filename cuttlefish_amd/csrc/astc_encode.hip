@@ -1361,16 +1361,23 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 #else
 		const bool linefit = !HDR && n < 64u;      // (the HDR profiles keep the overlap ranking: oracle shortlist)
 #endif
+		// footprints of 64 texels and more (LDR): half of the seeds by cluster overlap, the rest by line-fit error
+		// among the seeds not yet taken (oracle: shortlist, "mixed")
+#ifdef CF_ASTC_NO_LINEFIT
+		const bool mixed = false;
+#else
+		const bool mixed = !HDR && n >= 64u;
+#endif
 		// line-fit seed ranking (below): the block's texels as channel planes, four texels per 16-byte record, staged
-		// once per block in the wave's column region (idle until the grids stage; 256 B per block)
-		uint4* lf_planes = reinterpret_cast<uint4*>(wbase + h*256u);
-		if (linefit && lad.j2 && !(CF_ASTC_ABLATE & 8)) {
-			if (hl*4u < n) {
-				const uint32_t i = hl*4u;
+		// once per block in the wave's column region (idle until the grids stage; at most 36 records per block)
+		uint4* lf_planes = reinterpret_cast<uint4*>(wbase + h*640u);
+		if ((linefit || mixed) && lad.j2 && !(CF_ASTC_ABLATE & 8)) {
+			for (uint32_t g = hl; g*4u < n; g += gsz) {
+				const uint32_t i = g*4u;
 				const uint32_t w0 = tp[i], w1 = tp[min(i + 1u, n - 1u)], w2 = tp[min(i + 2u, n - 1u)], w3 = tp[min(i + 3u, n - 1u)];
 				const uint32_t t01 = __builtin_amdgcn_perm(w1, w0, 0x05010400u), t23 = __builtin_amdgcn_perm(w3, w2, 0x05010400u);
 				const uint32_t u01 = __builtin_amdgcn_perm(w1, w0, 0x07030602u), u23 = __builtin_amdgcn_perm(w3, w2, 0x07030602u);
-				lf_planes[hl] = make_uint4(__builtin_amdgcn_perm(t23, t01, 0x05040100u), __builtin_amdgcn_perm(t23, t01, 0x07060302u),
+				lf_planes[g] = make_uint4(__builtin_amdgcn_perm(t23, t01, 0x05040100u), __builtin_amdgcn_perm(t23, t01, 0x07060302u),
 					__builtin_amdgcn_perm(u23, u01, 0x05040100u), nc == 4u ? __builtin_amdgcn_perm(u23, u01, 0x07060302u) : 0u);
 			}
 			__builtin_amdgcn_wave_barrier();
@@ -1382,7 +1389,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			// (Normal on footprints of 64 texels and more ranks 256 seeds: oracle encode_core)
 			const uint32_t limit = (lad.limit == 64u && n >= 64u) ? 256u : lad.limit;
 			const uint32_t np = H->npart[P - 2u] < limit ? H->npart[P - 2u] : limit;
-			uint32_t keys[8];
+			uint32_t keys[8], kl[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
 			// Footprints below 64 texels rank the seeds by LINE-FIT error (oracle: linefit_key -- the same integers,
 			// the same float operations in the same order): lane = table entry; per subset the moments of its member
 			// texels (four texels per step through v_dot4_u32_u8, the members as a byte mask from the entry's id row;
@@ -1391,13 +1398,15 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			// Key = the sum's float bits without the low 10, then the entry's index.  On blocks of real photographs
 			// the cluster-overlap ranking below missed the seed the wide search takes (4x4 High 0.55 -> 0.16 dB under
 			// the bound, 6x6 0.50 -> 0.32); footprints of 64 texels and more gain nothing and keep it.
-			if (linefit) {
-				// members of subset c of entry e: bit i of word 0 of the entry's 64-bit texel masks (n < 64)
+			// (mixed: the two-partition seeds only -- the three-partition ones add 0.01 .. 0.03 dB for more than half the time)
+			const bool mixedP = mixed && P == 2u;
+			if (linefit || mixedP) {
+				// members of subset c of entry e: bit i of the entry's 64-bit texel masks (three words per subset)
 				const unsigned long long* lmasks = reinterpret_cast<const unsigned long long*>(blob + H->off_mask[P - 2u]);
 				const bool four = __ballot(nc == 4u) != 0ull;       // (wave-uniform: the channel-3 terms are all zero without it)
 #pragma unroll
 				for (uint32_t m = 0; m < 8u; ++m)
-					keys[m] = 0xFFFFFFFFu;
+					kl[m] = 0xFFFFFFFFu;
 #pragma unroll 1
 				for (uint32_t m = 0; m < 8u && gsz*m < np; ++m) {
 					const uint32_t e = hl + gsz*m;
@@ -1406,10 +1415,13 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						// (the 12-wave build serves Lowest / Low: two-partition seeds only -- one computed subset)
 						constexpr uint32_t NS = MAXW == 12 ? 1u : 3u;
 						int ac[NS][15];
-						unsigned long long mk[NS];
+						unsigned long long mk[NS], mk1[NS], mk2[NS];
 #pragma unroll
 						for (uint32_t s_ = 0; s_ < NS; ++s_) {
-							mk[s_] = s_ + 1u < P ? lmasks[((size_t)e*4u + s_)*3u] : 0ull;
+							const unsigned long long* pm = lmasks + ((size_t)e*4u + s_)*3u;
+							mk[s_] = s_ + 1u < P ? pm[0] : 0ull;
+							mk1[s_] = (s_ + 1u < P && n > 64u) ? pm[1] : 0ull;
+							mk2[s_] = (s_ + 1u < P && n > 128u) ? pm[2] : 0ull;
 #pragma unroll
 							for (int k = 0; k < 15; ++k)
 								ac[s_][k] = 0;
@@ -1423,7 +1435,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 								if (s_ + 1u < P) {
 									// four membership bits -> a byte mask (bit k of the nibble lands on bit 8 k: no two
 									// shifted copies overlap)
-									const uint32_t nib = (uint32_t)(mk[s_] >> i) & 15u;
+									const unsigned long long mw = i < 64u ? mk[s_] : (i < 128u ? mk1[s_] : mk2[s_]);
+									const uint32_t nib = (uint32_t)(mw >> (i & 63u)) & 15u;
 									const uint32_t m1 = (nib*0x00204081u) & 0x01010101u;
 									const uint32_t M = (m1 << 8) - m1;
 									const uint32_t q0 = P0 & M, q1 = P1 & M, q2 = P2 & M, q3 = P3 & M;
@@ -1483,8 +1496,13 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					}
 #pragma unroll
 					for (uint32_t k = 0; k < 8u; ++k)
-						keys[k] = k == m ? key : keys[k];
+						kl[k] = k == m ? key : kl[k];
 				}
+			}
+			if (linefit) {
+#pragma unroll
+				for (uint32_t m = 0; m < 8u; ++m)
+					keys[m] = kl[m];
 			} else {
 				const float step = (tmax - tmin)*(1.0f/(float)P);
 				uint32_t ks01[4] = {0, 0, 0, 0}, ks23[4] = {0, 0, 0, 0}, kcnt[4] = {0, 0, 0, 0};
@@ -1608,20 +1626,42 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					}
 				}
 			}
-			for (uint32_t jj = 0; jj < want; ++jj) {
+			const uint32_t first = mixedP ? (want + 1u) >> 1 : want;
+			for (uint32_t jj = 0; jj < first; ++jj) {
 				uint32_t mk = keys[0];
 #pragma unroll
 				for (uint32_t m = 1; m < 8u; ++m)
 					mk = keys[m] < mk ? keys[m] : mk;
 				const uint32_t gmin = cf_group_min_u32(mk, pair, h);
 #pragma unroll
-				for (uint32_t m = 0; m < 8u; ++m)
-					keys[m] = keys[m] == gmin ? 0xFFFFFFFFu : keys[m];
+				for (uint32_t m = 0; m < 8u; ++m) {
+					const bool won = keys[m] == gmin;
+					keys[m] = won ? 0xFFFFFFFFu : keys[m];
+					kl[m] = won ? 0xFFFFFFFFu : kl[m];        // (mixed: a seed taken by overlap leaves the line-fit ranking)
+				}
 				if (gmin != 0xFFFFFFFFu) {
 					if (hl == 0u) S.pcs[npc] = pc_make(P, 0, 0, P, gmin & (linefit ? 1023u : 0xFFFFu));
 					++npc;
 					got2 += P == 2u ? 1u : 0u;
 					got3 += P == 3u ? 1u : 0u;
+				}
+			}
+			if (mixedP) {
+				for (uint32_t jj = first; jj < want; ++jj) {
+					uint32_t mk = kl[0];
+#pragma unroll
+					for (uint32_t m = 1; m < 8u; ++m)
+						mk = kl[m] < mk ? kl[m] : mk;
+					const uint32_t gmin = cf_group_min_u32(mk, pair, h);
+#pragma unroll
+					for (uint32_t m = 0; m < 8u; ++m)
+						kl[m] = kl[m] == gmin ? 0xFFFFFFFFu : kl[m];
+					if (gmin != 0xFFFFFFFFu) {
+						if (hl == 0u) S.pcs[npc] = pc_make(P, 0, 0, P, gmin & 1023u);
+						++npc;
+						got2 += P == 2u ? 1u : 0u;
+						got3 += P == 3u ? 1u : 0u;
+					}
 				}
 			}
 		}
