@@ -1361,8 +1361,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 #else
 		const bool linefit = !HDR && n < 64u;      // (the HDR profiles keep the overlap ranking: oracle shortlist)
 #endif
-		// footprints of 64 texels and more (LDR): half of the seeds by cluster overlap, the rest by line-fit error
-		// among the seeds not yet taken (oracle: shortlist, "mixed")
+		// footprints of 64 texels and more (LDR): the two-partition seeds come from the cluster-overlap ranking and the
+		// line-fit ranking in turn (oracle: shortlist, "mixed")
 #ifdef CF_ASTC_NO_LINEFIT
 		const bool mixed = false;
 #else
@@ -1626,42 +1626,28 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					}
 				}
 			}
-			const uint32_t first = mixedP ? (want + 1u) >> 1 : want;
-			for (uint32_t jj = 0; jj < first; ++jj) {
-				uint32_t mk = keys[0];
+			// (mixed: the picks alternate -- overlap, line fit, overlap, ... each among the seeds not yet taken, so a
+			// shorter list is a prefix of a longer one: oracle shortlist)
+			for (uint32_t jj = 0; jj < want; ++jj) {
+				const bool use_l = mixedP && (jj & 1u) != 0u;
+				uint32_t mk = use_l ? kl[0] : keys[0];
 #pragma unroll
-				for (uint32_t m = 1; m < 8u; ++m)
-					mk = keys[m] < mk ? keys[m] : mk;
+				for (uint32_t m = 1; m < 8u; ++m) {
+					const uint32_t km = use_l ? kl[m] : keys[m];
+					mk = km < mk ? km : mk;
+				}
 				const uint32_t gmin = cf_group_min_u32(mk, pair, h);
 #pragma unroll
 				for (uint32_t m = 0; m < 8u; ++m) {
-					const bool won = keys[m] == gmin;
+					const bool won = (use_l ? kl[m] : keys[m]) == gmin;
 					keys[m] = won ? 0xFFFFFFFFu : keys[m];
-					kl[m] = won ? 0xFFFFFFFFu : kl[m];        // (mixed: a seed taken by overlap leaves the line-fit ranking)
+					kl[m] = won ? 0xFFFFFFFFu : kl[m];
 				}
 				if (gmin != 0xFFFFFFFFu) {
-					if (hl == 0u) S.pcs[npc] = pc_make(P, 0, 0, P, gmin & (linefit ? 1023u : 0xFFFFu));
+					if (hl == 0u) S.pcs[npc] = pc_make(P, 0, 0, P, gmin & ((linefit || use_l) ? 1023u : 0xFFFFu));
 					++npc;
 					got2 += P == 2u ? 1u : 0u;
 					got3 += P == 3u ? 1u : 0u;
-				}
-			}
-			if (mixedP) {
-				for (uint32_t jj = first; jj < want; ++jj) {
-					uint32_t mk = kl[0];
-#pragma unroll
-					for (uint32_t m = 1; m < 8u; ++m)
-						mk = kl[m] < mk ? kl[m] : mk;
-					const uint32_t gmin = cf_group_min_u32(mk, pair, h);
-#pragma unroll
-					for (uint32_t m = 0; m < 8u; ++m)
-						kl[m] = kl[m] == gmin ? 0xFFFFFFFFu : kl[m];
-					if (gmin != 0xFFFFFFFFu) {
-						if (hl == 0u) S.pcs[npc] = pc_make(P, 0, 0, P, gmin & 1023u);
-						++npc;
-						got2 += P == 2u ? 1u : 0u;
-						got3 += P == 3u ? 1u : 0u;
-					}
 				}
 			}
 		}

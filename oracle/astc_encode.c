@@ -1633,8 +1633,7 @@ static int shortlist(const astc_blk* b, int P, int limit, int want, const float 
 	if (linefit)
 		for (int t = 0; t < np; ++t)
 			key[t] = linefit_key(b, P, t);
-	/* Footprints of 64 texels and more (LDR): HALF of the seeds by each ranking -- the first (want + 1) / 2 by
-	 * cluster overlap, the rest by line-fit error among the seeds not yet taken.  Either ranking alone leaves the
+	/* Footprints of 64 texels and more (LDR): the seeds come from BOTH rankings in turn (below).  Either ranking alone leaves the
 	 * bound's seed out too often there (the line fit alone loses 0.04 .. 0.09 dB at 8x8 and gains 0.07 at 10x10);
 	 * together, on 768 real-photograph blocks: 8x8 0.77 / 0.70 / 0.58 -> 0.71 / 0.60 / 0.55 dB under the wide search
 	 * at Normal / High / Highest, 10x10 0.92 / 0.85 / 0.72 -> 0.83 / 0.69 / 0.64, 12x12 0.93 / 0.84 / 0.68 ->
@@ -1642,28 +1641,24 @@ static int shortlist(const astc_blk* b, int P, int limit, int want, const float 
 	 * Two-partition seeds only: the three-partition seeds add 0.01 .. 0.03 dB of that for more than half of its time
 	 * (8x8 0.73 / 0.61 / 0.55, 10x10 0.84 / 0.72 / 0.67, 12x12 0.87 / 0.76 / 0.65 as built). */
 	const int mixed = b->n >= 64 && P == 2 && !b->hdr && !getenv("CFO_ASTC_NO_LINEFIT");
-	const int first = mixed ? (want + 1)/2 : want;
+	/* mixed: the picks ALTERNATE -- overlap, line fit, overlap, ... each among the seeds not yet taken -- so that a
+	 * shorter list is a prefix of a longer one (High's four seeds are the head of Highest's fourteen) */
+	uint32_t k2[ASTC_MAX_PARTS];
+	if (mixed)
+		for (int t = 0; t < np; ++t)
+			k2[t] = linefit_key(b, P, t);
 	int got = 0;
-	for (; got < first && got < np; ++got) {
+	for (; got < want && got < np; ++got) {
+		const int use_l = mixed && (got & 1);
+		uint32_t* kk = use_l ? k2 : key;
 		int bi = -1;
 		for (int t = 0; t < np; ++t)
-			if (key[t] != 0xFFFFFFFFu && (bi < 0 || key[t] < key[bi]))
+			if (kk[t] != 0xFFFFFFFFu && (bi < 0 || kk[t] < kk[bi]))
 				bi = t;
-		out[got] = (int)(key[bi] & (linefit ? 1023u : 0xFFFFu));
+		out[got] = (int)(kk[bi] & ((linefit || use_l) ? 1023u : 0xFFFFu));
 		key[bi] = 0xFFFFFFFFu;
-	}
-	if (mixed && got < want && got < np) {
-		uint32_t k2[ASTC_MAX_PARTS];
-		for (int t = 0; t < np; ++t)
-			k2[t] = key[t] == 0xFFFFFFFFu ? 0xFFFFFFFFu : linefit_key(b, P, t);
-		for (; got < want && got < np; ++got) {
-			int bi = -1;
-			for (int t = 0; t < np; ++t)
-				if (k2[t] != 0xFFFFFFFFu && (bi < 0 || k2[t] < k2[bi]))
-					bi = t;
-			out[got] = (int)(k2[bi] & 1023u);
+		if (mixed)
 			k2[bi] = 0xFFFFFFFFu;
-		}
 	}
 	return got;
 }
