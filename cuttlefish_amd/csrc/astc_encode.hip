@@ -1426,8 +1426,16 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							for (int k = 0; k < 15; ++k)
 								ac[s_][k] = 0;
 						}
+						// (one mask word = 64 texels at a time: the word is chosen once per 16 steps, not per step)
 #pragma unroll 1
-						for (uint32_t i = 0; i < n; i += 4u) {
+						for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+						unsigned long long mw[NS];
+#pragma unroll
+						for (uint32_t s_ = 0; s_ < NS; ++s_)
+							mw[s_] = i0 == 0u ? mk[s_] : (i0 == 64u ? mk1[s_] : mk2[s_]);
+						const uint32_t iend = min(n, i0 + 64u);
+#pragma unroll 1
+						for (uint32_t i = i0; i < iend; i += 4u) {
 							const uint4 pl = lf_planes[i >> 2];
 							const uint32_t P0 = pl.x, P1 = pl.y, P2 = pl.z, P3 = pl.w;
 #pragma unroll
@@ -1435,8 +1443,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 								if (s_ + 1u < P) {
 									// four membership bits -> a byte mask (bit k of the nibble lands on bit 8 k: no two
 									// shifted copies overlap)
-									const unsigned long long mw = i < 64u ? mk[s_] : (i < 128u ? mk1[s_] : mk2[s_]);
-									const uint32_t nib = (uint32_t)(mw >> (i & 63u)) & 15u;
+									const uint32_t nib = (uint32_t)(mw[s_] >> (i - i0)) & 15u;
 									const uint32_t m1 = (nib*0x00204081u) & 0x01010101u;
 									const uint32_t M = (m1 << 8) - m1;
 									const uint32_t q0 = P0 & M, q1 = P1 & M, q2 = P2 & M, q3 = P3 & M;
@@ -1460,6 +1467,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 									}
 								}
 							}
+						}
 						}
 						// the last subset: the block minus the others
 						int rest[15] = {(int)n, sum[0], sum[1], sum[2], sum[3], (int)m00, (int)m01, (int)m02, (int)m03, (int)m11, (int)m12,
