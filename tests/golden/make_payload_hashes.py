@@ -91,6 +91,28 @@ def quality_metric(name, fmt, typ, img, payload):
     return round(float(synth.psnr(img, dec, ch)), 3)
 
 
+_LNS = None
+
+
+def lns_psnr(fmt, img, payload):
+    """ASTC HDR profiles: PSNR on the 16-bit LNS values of the halves -- the domain the encoder minimises its error
+    in (cfo_astc_lns16; peak 65535).  The log2(1 + x) figure above weighs dark texels differently and is not
+    monotone in the level on this fixture; this one is what the ladder is held to."""
+    global _LNS
+    import ctypes
+    if _LNS is None:
+        L = O.lib()
+        L.cfo_astc_lns16.argtypes = [ctypes.c_uint16]
+        L.cfo_astc_lns16.restype = ctypes.c_int
+        _LNS = np.array([L.cfo_astc_lns16(h) for h in range(65536)], np.int64)
+
+    def lns(x):
+        return _LNS[np.asarray(x, np.float32).clip(0, 65504).astype(np.float16).view(np.uint16)]
+    dec = O.decode_astc_hdr(payload, fmt, W, H)[0].astype(np.float32)
+    e = (lns(dec[..., :3]) - lns(img[..., :3])).astype(np.float64)
+    return round(float(10*np.log10(65535.0**2/max(np.mean(e**2), 1e-12))), 3)
+
+
 def build():
     out = {}
     for name, fmt, typ, kind in CASES:
@@ -99,6 +121,8 @@ def build():
             payload = O.encode(img, fmt, typ=typ, quality=q, threads=8, color_space=color_space(name))
             out["%s/q%d" % (name, q)] = {"sha256": hashlib.sha256(payload.tobytes()).hexdigest(),
                                           "psnr": quality_metric(name, fmt, typ, img, payload)}
+            if fmt >= 43 and typ == 4:
+                out["%s/q%d" % (name, q)]["psnr_lns"] = lns_psnr(fmt, img, payload)
     return out
 
 

@@ -45,15 +45,15 @@ def test_quality_never_costs_quality():
         # footprints -- one block decided the ladder)
         slack = 0.1 if name.startswith("ASTC") else 0.01
         if name.startswith("ASTC") and name.endswith("UFloat"):
-            # the HDR profiles minimise an error on LNS codes, the recorded figure is a log-domain PSNR of
-            # the halves, and the fixture is 64 x 64: the ladder is monotone on a 384 x 384 probe
-            # (53.84 / 53.84 / 54.31 / 54.31 / 54.54 dB for 6x6), not block by block on this one
-            slack = 1.0
+            # The HDR profiles minimise their error on 16-bit LNS values; the log2(1 + x) PSNR recorded beside the
+            # hash weighs dark texels differently and is not monotone in the level on this fixture (round-4 review:
+            # 1 dB of slack).  The ladder is held to the domain it optimises: psnr_lns, with the slack of the LDR
+            # cases (4x4 54.10 / 54.46 / 54.90 / 55.50 / 55.71, 6x6 45.61 .. 45.77, 8x8 41.64 .. 41.88).
+            ps = [HASHES["%s/q%d" % (name, q)]["psnr_lns"] for q in range(5)]
         for a, b in zip(ps, ps[1:]):
             assert b >= a - slack, (name, ps)
-        assert ps[4] >= ps[3] - (0.05 if name.endswith("UFloat") else 0.01), (name, ps)
-        # (HDR: 64 blocks of 8x8 and a metric that is not the one minimised -- Lowest may sit 0.03 dB above Highest)
-        assert ps[4] >= ps[0] - (0.05 if name.endswith("UFloat") else 0.0), (name, ps)
+        assert ps[4] >= ps[3] - 0.01, (name, ps)
+        assert ps[4] >= ps[0], (name, ps)
 
 
 @pytest.mark.gpu
