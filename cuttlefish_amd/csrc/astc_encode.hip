@@ -206,6 +206,7 @@ struct Shared {
 	const uint8_t* grid;      // [grid][4]: N, M, ng, Np (even row pitch)
 	const uint8_t* cunq;      // [17][256]
 	const uint8_t* cnear;     // [17][256]
+	const uint16_t* cq16;     // [17][256] LDR builds (in the place of cunq + cnear): nearest stored index | its value << 8 of a value 0..255 -- one lookup per quantisation
 	const uint32_t* creq;     // [17][256] HDR launches only: nearest index | its value << 8 | the first stored value on the other side of v: index << 16 | value << 24
 	const uint8_t* wunq;      // [12][32]
 	const uint8_t* wnear;     // [12][68]
@@ -390,8 +391,9 @@ struct Slot {
 __device__ __forceinline__ int quant_c(const Shared& sh, uint32_t lv, float x, uint32_t& stored)
 {
 	const uint32_t xi = (uint32_t)(int)floorf(clampf255(x) + 0.5f);
-	stored = sh.cnear[lv*256u + xi];
-	return (int)sh.cunq[lv*256u + stored];
+	const uint32_t e = sh.cq16[lv*256u + xi];
+	stored = e & 255u;
+	return (int)(e >> 8);
 }
 
 // constant-colour block: UNORM16 (LDR) or, with bit 9 of the header set, four halves (HDR profile)
@@ -549,8 +551,9 @@ __device__ __forceinline__ bool cem_option(const Shared& sh, int o, uint32_t lv,
 			if (c < 3u || has_alpha) {
 				const int B = (int)floorf(clampf255(in.r0[c]) + 0.5f), E = (int)floorf(clampf255(in.r1[c]) + 0.5f);
 				const uint32_t t0 = (uint32_t)(B & 0x7F) << 1;
-				const uint32_t qa = sh.cnear[lv*256u + t0], qb = sh.cnear[lv*256u + (t0 | 1u)];
-				const int ua = (int)sh.cunq[lv*256u + qa], ub_ = (int)sh.cunq[lv*256u + qb];
+				const uint32_t ea = sh.cq16[lv*256u + t0], eb = sh.cq16[lv*256u + (t0 | 1u)];
+				const uint32_t qa = ea & 255u, qb = eb & 255u;
+				const int ua = (int)(ea >> 8), ub_ = (int)(eb >> 8);
 				const int da = abs((ua >> 1) - (B & 0x7F)), db = abs((ub_ >> 1) - (B & 0x7F));
 				const uint32_t q0 = db < da ? qb : qa;
 				const int u0 = db < da ? ub_ : ua;
@@ -558,8 +561,9 @@ __device__ __forceinline__ bool cem_option(const Shared& sh, int o, uint32_t lv,
 				const int D = E - base;
 				ok = ok && D >= -32 && D <= 31;
 				const uint32_t t1 = (uint32_t)hb | ((uint32_t)(D & 0x3F) << 1);
-				const uint32_t qc = sh.cnear[lv*256u + (t1 & 255u)], qd = sh.cnear[lv*256u + ((t1 | 1u) & 255u)];
-				const int uc = (int)sh.cunq[lv*256u + qc], ud = (int)sh.cunq[lv*256u + qd];
+				const uint32_t ec_ = sh.cq16[lv*256u + (t1 & 255u)], ed_ = sh.cq16[lv*256u + ((t1 | 1u) & 255u)];
+				const uint32_t qc = ec_ & 255u, qd = ed_ & 255u;
+				const int uc = (int)(ec_ >> 8), ud = (int)(ed_ >> 8);
 				int ac = (uc >> 1) & 0x3F, ad = (ud >> 1) & 0x3F;
 				ac = (ac & 0x20) ? ac - 0x40 : ac;
 				ad = (ad & 0x20) ? ad - 0x40 : ad;
@@ -1082,8 +1086,15 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		sh_den[i] = reinterpret_cast<const uint32_t*>(blob + H->off_den)[i];
 	for (uint32_t i = threadIdx.x; i < ngrids; i += nthreads)
 		reinterpret_cast<uint32_t*>(sh_grid)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_grid)[i];
-	for (uint32_t i = threadIdx.x; i < (hdrf ? 6u : 2u)*17u*64u; i += nthreads)
-		reinterpret_cast<uint32_t*>(sh_ctab)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_ctab)[i];
+	if (HDR) {
+		for (uint32_t i = threadIdx.x; i < (hdrf ? 6u : 2u)*17u*64u; i += nthreads)
+			reinterpret_cast<uint32_t*>(sh_ctab)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_ctab)[i];
+	} else {
+		// LDR: the low halves of the blob's requantisation words (nearest stored index | its value << 8), two per word
+		const uint32_t* req = reinterpret_cast<const uint32_t*>(blob + H->off_ctab + 2u*17u*256u);
+		for (uint32_t i = threadIdx.x; i < 17u*128u; i += nthreads)
+			reinterpret_cast<uint32_t*>(sh_ctab)[i] = (req[2u*i] & 0xFFFFu) | (req[2u*i + 1u] << 16);
+	}
 	for (uint32_t i = threadIdx.x; i < 504u; i += nthreads)
 		reinterpret_cast<uint32_t*>(sh_wtab)[i] = reinterpret_cast<const uint32_t*>(blob + H->off_wtab)[i];
 
@@ -1185,6 +1196,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 
 	Shared sh;
 	sh.infill = reinterpret_cast<const uint2*>(sh_infill); sh.den = sh_den; sh.grid = sh_grid;
+	sh.cq16 = reinterpret_cast<const uint16_t*>(sh_ctab);
 	sh.cunq = sh_ctab; sh.cnear = sh_ctab + 17u*256u; sh.creq = reinterpret_cast<const uint32_t*>(sh_ctab + 2u*17u*256u);
 	sh.wunq = sh_wtab; sh.wnear = sh_wtab + 12u*32u; sh.wnu = sh_wtab + 12u*32u + 12u*68u;
 	const int8_t* clevel = reinterpret_cast<const int8_t*>(blob + H->off_clevel);
@@ -2447,8 +2459,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 									} else if (has_alpha) {
 										// LDR alpha (mode 14): two UNORM8 values; the fit above ran on the 0..255 values
 										uint32_t s6, s7;
-										quant_c(sh, lv, (float)r0[3], s6);
-										quant_c(sh, lv, (float)r1[3], s7);
+										// (HDR launches hold cunq / cnear / creq, not the LDR builds' 16-bit table)
+										s6 = sh.cnear[lv*256u + (uint32_t)(int)floorf(clampf255((float)r0[3]) + 0.5f)];
+										s7 = sh.cnear[lv*256u + (uint32_t)(int)floorf(clampf255((float)r1[3]) + 0.5f)];
 										bq_hi = (bq_hi & 0xFFFFu) | (s6 << 16) | (s7 << 24);
 									}
 									{
