@@ -1412,7 +1412,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			// the bound, 6x6 0.50 -> 0.32); footprints of 64 texels and more gain nothing and keep it.
 			// (mixed: the two-partition seeds only -- the three-partition ones add 0.01 .. 0.03 dB for more than half the time)
 			const bool mixedP = mixed && P == 2u;
-			if (linefit || mixedP) {
+			// (four-partition seeds -- Highest only -- keep the overlap ranking: oracle shortlist)
+			const bool lfP = linefit && P <= 3u;
+			if (lfP || mixedP) {
 				// members of subset c of entry e: bit i of the entry's 64-bit texel masks (three words per subset)
 				const unsigned long long* lmasks = reinterpret_cast<const unsigned long long*>(blob + H->off_mask[P - 2u]);
 				const bool four = __ballot(nc == 4u) != 0ull;       // (wave-uniform: the channel-3 terms are all zero without it)
@@ -1425,7 +1427,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					uint32_t key = 0xFFFFFFFFu;
 					if (e < np) {
 						// (the 12-wave build serves Lowest / Low: two-partition seeds only -- one computed subset)
-						constexpr uint32_t NS = MAXW == 12 ? 1u : 3u;
+						constexpr uint32_t NS = MAXW == 12 ? 1u : 2u;       // (at most three subsets: two computed)
 						int ac[NS][15];
 						unsigned long long mk[NS], mk1[NS], mk2[NS];
 #pragma unroll
@@ -1519,7 +1521,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						kl[k] = k == m ? key : kl[k];
 				}
 			}
-			if (linefit) {
+			if (lfP) {
 #pragma unroll
 				for (uint32_t m = 0; m < 8u; ++m)
 					keys[m] = kl[m];
@@ -1664,7 +1666,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					kl[m] = won ? 0xFFFFFFFFu : kl[m];
 				}
 				if (gmin != 0xFFFFFFFFu) {
-					if (hl == 0u) S.pcs[npc] = pc_make(P, 0, 0, P, gmin & ((linefit || use_l) ? 1023u : 0xFFFFu));
+					if (hl == 0u) S.pcs[npc] = pc_make(P, 0, 0, P, gmin & ((lfP || use_l) ? 1023u : 0xFFFFu));
 					++npc;
 					got2 += P == 2u ? 1u : 0u;
 					got3 += P == 3u ? 1u : 0u;

@@ -1629,7 +1629,9 @@ static int shortlist(const astc_blk* b, int P, int limit, int want, const float 
 	 * bound, 5x5 0.53 -> 0.26, 6x6 0.50 -> 0.32; 8x8 and 12x12 +-0.02 (they keep the overlap ranking, which costs
 	 * less there), tools/astc_lab.py.  The HDR profiles keep the overlap ranking too (the 4x4 HDR fixture loses
 	 * 0.5 .. 1 dB with the line fit on its 8-bit window codes; there is no real HDR content here to tune on).  Key = the float's bits without the low 10, then the index. */
-	const int linefit = b->n < 64 && !b->hdr && !getenv("CFO_ASTC_NO_LINEFIT");      /* (the switch: lab / debugging only) */
+	/* (four-partition seeds -- Highest only -- keep the overlap ranking: the line fit buys them 0.000 dB at 4x4 and
+	 * 0.007 dB at 6x6 for a tenth of the level's time) */
+	const int linefit = b->n < 64 && P <= 3 && !b->hdr && !getenv("CFO_ASTC_NO_LINEFIT");      /* (the switch: lab / debugging only) */
 	if (linefit)
 		for (int t = 0; t < np; ++t)
 			key[t] = linefit_key(b, P, t);
