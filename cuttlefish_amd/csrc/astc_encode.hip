@@ -1223,7 +1223,6 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		// the lane id is re-read per block (a volatile mbcnt pair): nothing derived from it is hoisted out of
 		// this loop and held -- or spilled -- across the phases
 		asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-		uint8_t* colbase = wbase + lane*4u;
 		const uint32_t b0 = wave*4u + jb;
 		if (bx0 + b0 >= kp.bx)
 			break;
@@ -1721,8 +1720,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			// and LDS addresses are not computed ahead of the loop and carried -- or spilled -- through it
 			uint32_t lane;
 			asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-			const uint32_t h = pair ? lane >> 5 : 0u, hl = pair ? (lane & 31u) : lane;
-			uint8_t* colbase = wbase + lane*4u;
+			const uint32_t hl = pair ? (lane & 31u) : lane;
 			const uint32_t cnt = base >= npc ? 0u : (npc - base < per_pass ? npc - base : per_pass);
 			// partition rows of this pass's candidates
 			for (uint32_t j = 0; j < cnt; ++j) {
