@@ -43,6 +43,10 @@ using cfastc::AstcCfgRec;
 #ifndef CF_ASTC_ABLATE
 #define CF_ASTC_ABLATE 0   // timing experiments only (tools/dbg/astc_ablate.sh): phases switched off
 #endif
+#ifndef CF_ASTC_R4_HIGH
+#define CF_ASTC_R4_HIGH 0   // timing experiments only (tools/dbg/astc_r4_high.sh): Quality::High runs round 4's search -- half a wavefront,
+                           // 6,6,6,6,2,2,2,2 configs, no refinement rounds (build with -DCF_ASTC_NO_LINEFIT too); payloads differ from the oracle's
+#endif
 #ifndef CF_ASTC_PROF
 #define CF_ASTC_PROF 0   // debug build (tools/dbg/astc_phase_prof.sh): one wave prints the clock ticks it spent per phase
 #endif
@@ -80,7 +84,7 @@ __device__ __forceinline__ Ladder ladder(uint32_t q)
 		case 0: return {8, 0, 0, 0, 0, 0};
 		case 1: return {8, 16, 2, 0, 0, 1};
 		case 2: return {6, 64, 4, 2, 0, 2};
-		case 3: return {8, 256, 4, 2, 0, 2};   // round 5: the whole wavefront, Highest's first pass (8 candidates x 8 configs)
+		case 3: return {CF_ASTC_R4_HIGH ? 6u : 8u, 256, 4, 2, 0, 2};   // round 5: the whole wavefront, Highest's first pass (8 candidates x 8 configs)
 		default: return {8, 256, 14, 9, 6, 2};
 	}
 }
@@ -1074,7 +1078,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	uint8_t* sh_ctab = lds + off; off += (hdrf ? 6u : 2u)*17u*256u;
 	uint8_t* sh_wtab = lds + off; off += 2016u;
 	const uint32_t slot_bytes = ((10u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
-	const uint32_t wave_bytes = ((((col_rows + 1u)/2u)*256u + 15u) & ~15u) + (kp.quality <= 2u ? 2u : 1u)*slot_bytes;
+	const uint32_t wave_bytes = ((((col_rows + 1u)/2u)*256u + 15u) & ~15u) + (kp.quality <= (CF_ASTC_R4_HIGH ? 3u : 2u) ? 2u : 1u)*slot_bytes;
 	// the wave index as a scalar: block indices, the pair flag and the block loop counter live in SGPRs
 	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	uint32_t lane = threadIdx.x & 63u;
@@ -1214,7 +1218,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	const Ladder lad = ladder(q);
 	// up to High a block needs 32 lanes (8 candidates; High: 6,6,6,6,2,2,2,2 configs, the others 4 each):
 	// two blocks share a wavefront
-	const bool can_pair = q <= 2u;      // High takes the whole wavefront since round 5 (oracle: encode_core, gsz)
+	const bool can_pair = q <= (CF_ASTC_R4_HIGH ? 3u : 2u);      // High takes the whole wavefront since round 5 (oracle: encode_core, gsz)
 	uint32_t cw[4] = {1u, 1u, 1u, 1u};
 	if (aflags & ASTC_FLAG_PERCEPTUAL) { cw[0] = 11u; cw[1] = 21u; cw[2] = 4u; cw[3] = 16u; }
 	const uint32_t recip_n = 65536u/n;                                          // x / n as (x * recip_n) >> 16, like the oracle
@@ -1675,7 +1679,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		__builtin_amdgcn_wave_barrier();
 		// Normal, High: the first pass only (their 4 + 2 seeds already are the head of the walk); HDR: four
 		// candidates of 8 configs (oracle: the config ranking is nearly flat on HDR content)
-		if (q == 2u && npc > (HDR ? 4u : 8u))
+		if ((q == 2u || (CF_ASTC_R4_HIGH && q == 3u)) && npc > (HDR ? 4u : 8u))
 			npc = HDR ? 4u : 8u;
 		if (q == 3u && npc > 8u)
 			npc = 8u;
@@ -1700,8 +1704,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		// ---- passes of (gsz / K) candidates x K configs ----
 		// Normal, High: candidate j of the pass has 6 (j < 4) or 2 lanes, side by side: 32 lanes; the other
 		// levels give every candidate 8
-		const bool varK = q == 2u && !HDR;
-		const uint32_t K = (HDR && q == 2u) ? 8u : lad.K, kshift = K == 2u ? 1u : (K == 4u ? 2u : 3u), per_pass = varK ? 8u : gsz >> kshift;
+		const bool varK = (q == 2u || (CF_ASTC_R4_HIGH && q == 3u)) && !HDR;
+		const uint32_t K = (HDR && (q == 2u || (CF_ASTC_R4_HIGH && q == 3u))) ? 8u : lad.K, kshift = K == 2u ? 1u : (K == 4u ? 2u : 3u), per_pass = varK ? 8u : gsz >> kshift;
 		unsigned long long bestkey = ~0ull;
 		const uint32_t alpha_i = has_alpha ? 1u : 0u;
 		uint32_t npc_max = npc;
@@ -2009,7 +2013,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				// (the 12-wave / 168-register build serves Lowest and Low only, which have no rounds: with the rounds
 				// compiled in it kept 18 values in scratch, and a kernel that talks across lanes must not spill vector
 				// registers -- a spill inside divergent control flow saves the active lanes only; see etc_encode.hip)
-				const uint32_t nrounds = (HDR || MAXW == 12) ? 0u : (q == 2u ? 2u : (q == 3u ? 2u : (q >= 4u ? 3u : 0u)));
+				const uint32_t nrounds = (HDR || MAXW == 12 || CF_ASTC_R4_HIGH) ? 0u : (q == 2u ? 2u : (q == 3u ? 2u : (q >= 4u ? 3u : 0u)));
 				bool going = false;
 				unsigned long long prev_err = ~0ull;
 				// the lane's decoded endpoints (bytes r, g, b, a of partition k): what the next round projects on
@@ -3118,7 +3122,7 @@ static size_t astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality, 
 	off += (hdr ? 6u : 2u)*17u*256u + 2016u;
 	(void)wcached;
 	const uint32_t slot_bytes = ((10u*npad + 8u*npad + 15u) & ~15u) + (32u*4u)*7u + 64u + 40u*4u + 28u*4u;
-	const uint32_t wave_bytes = ((((h->col_rows + 1u)/2u)*256u + 15u) & ~15u) + (quality <= 2u ? 2u : 1u)*slot_bytes;
+	const uint32_t wave_bytes = ((((h->col_rows + 1u)/2u)*256u + 15u) & ~15u) + (quality <= (CF_ASTC_R4_HIGH ? 3u : 2u) ? 2u : 1u)*slot_bytes;
 	return (size_t)off + nwaves*(size_t)wave_bytes;
 }
 
