@@ -49,7 +49,8 @@ def test_4x4_formats_real_blocks(gpu_ctx, fmt, quality):
     _cmp(gpu_ctx, R.strip(R.blocks4(512)), fmt, quality, bs)
 
 
-@pytest.mark.parametrize("bw,bh,quality", [(4, 4, 2), (6, 6, 3), (6, 6, 2), (8, 8, 2), (5, 4, 2), (10, 10, 2), (12, 12, 2)])
+@pytest.mark.parametrize("bw,bh,quality", [(4, 4, 2), (6, 6, 3), (6, 6, 2), (8, 8, 2), (5, 4, 2), (10, 10, 2), (12, 12, 2),
+                                          (4, 4, 4), (5, 5, 3), (6, 6, 4), (8, 8, 3), (10, 10, 4), (12, 12, 3), (10, 6, 3), (8, 5, 1)])
 def test_astc_real_blocks(gpu_ctx, bw, bh, quality):
     fmt = getattr(Format, "ASTC_%dx%d" % (bw, bh))
     _cmp(gpu_ctx, R.strip(R.blocks(bw, bh, 256)), fmt, quality, 16)
