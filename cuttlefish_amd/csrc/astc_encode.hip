@@ -2019,8 +2019,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				// the lane's decoded endpoints (bytes r, g, b, a of partition k): what the next round projects on
 				uint32_t D0[4] = {0, 0, 0, 0}, D1[4] = {0, 0, 0, 0};
 				int keep_opt = -1;       // refinement rounds: the endpoint option round 0 chose
-#pragma unroll 1
-				for (uint32_t rnd = 0;; ++rnd) {
+				// The body of a round exists twice in the code object: round 0 (lane = (candidate, config)) and the
+				// refinement rounds (quad = result).  As one loop body its register demand was the union of the two
+				// forms; as two instances of one generic lambda each keeps its own.
+				auto round_body = [&](auto QC_, const uint32_t rnd) __attribute__((always_inline)) -> bool {
 				// the lane id and every role that follows from it are formed again per round (a volatile mbcnt pair):
 				// held across the rounds they were 25 spilled registers in the 168-register build
 				uint32_t lane;
@@ -2033,7 +2035,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				// scatter, least-squares sums, exact error: integer partial sums met by two DPP steps) and repeats
 				// the endpoint stage, which is the same arithmetic on the same sums in all four lanes.
 				constexpr bool ROUNDS = !(HDR || MAXW == 12);       // (builds without rounds carry none of this)
-				const bool quad = ROUNDS && rnd != 0u;
+				constexpr bool quad = decltype(QC_)::value;        // round 0: false; the refinement rounds: true (two instances of this body)
 				const uint32_t qr = quad ? hl & 3u : 0u;
 				uint32_t rl = hl;
 				if (quad)
@@ -2061,9 +2063,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				const uint8_t* prow = S.pid + j*npad;
 				const bool byp = P <= 1u;
 				r_cfg = oi;
-				if (rnd == 0u)
+				if (!quad)
 					going = active;
-				if (rnd == 0u)
+				if (!quad)
 				if (active) {
 					// 1. decimate + quantise
 					for (uint32_t k = 0; k <= PW*planes; ++k)
@@ -2879,12 +2881,12 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					}
 					}
 				}
-				if (pass == 0u && !pair && rnd == 0u) {
+				if (pass == 0u && !pair && !quad) {
 					e1min = cf_group_min_u64(P == 1u ? err : ~0ull, false, 0u);
 					e2min = cf_group_min_u64(P == 2u ? err : ~0ull, false, 0u);
 				}
 				// a refined result counts only when it lowers the lane's own error
-				if (rnd > 0u && !(err < prev_err))
+				if (quad && !(err < prev_err))
 					err = ~0ull;
 				going = going && err != ~0ull;
 				prev_err = going ? err : prev_err;
@@ -2925,8 +2927,8 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				}
 				__builtin_amdgcn_wave_barrier();
 				if (rnd >= nrounds || __ballot(going) == 0ull)
-					break;
-				if (ROUNDS && rnd == 0u) {
+					return false;
+				if (ROUNDS && !quad) {
 					// The group's gsz / 4 best results of round 0 go on (oracle: encode_core, ASTC_REFINE_DIV): a lane's
 					// rank = the results ahead of it by (error, lane); result of rank u -> quad u.  Then every quad
 					// lane takes over its result's state: decoded endpoints and the error to beat.
@@ -2961,6 +2963,13 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					keep_opt = (ocem == 8u || ocem == 12u) ? 0 : ((ocem == 6u || ocem == 10u) ? 1 : ((ocem == 0u || ocem == 4u) ? 2 : 3));
 					going = ow != 255u;
 				}
+				return true;
+				};
+				if (round_body(std::false_type{}, 0u)) {
+#pragma unroll 1
+					for (uint32_t rnd = 1u;; ++rnd)
+						if (!round_body(std::true_type{}, rnd))
+							break;
 				}
 			}
 		}
