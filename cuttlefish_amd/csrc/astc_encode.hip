@@ -1048,6 +1048,8 @@ __device__ __forceinline__ int sdot2_i16(uint32_t a, uint32_t b, int acc)
 // most waves on a CU within the 160 KB of LDS -- the kernel is latency bound (dependent LDS
 // gathers, cross-lane reductions), so the third wave per SIMD is worth more than the registers it
 // costs.  MAXW is the launch bound: 12 waves cap the kernel at 168 VGPRs, 8 waves leave it 256.
+__device__ __forceinline__ uint32_t astc_opq(uint32_t x) { asm volatile("" : "+v"(x)); return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+
 template <int PIX, int MAXW, bool HDR>
 __global__ void __launch_bounds__(MAXW*64)
 cfhip_astc_encode_kernel(cf_kparams kp)
@@ -1203,10 +1205,12 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	sh.cq16 = reinterpret_cast<const uint16_t*>(sh_ctab);
 	sh.cunq = sh_ctab; sh.cnear = sh_ctab + 17u*256u; sh.creq = reinterpret_cast<const uint32_t*>(sh_ctab + 2u*17u*256u);
 	sh.wunq = sh_wtab; sh.wnear = sh_wtab + 12u*32u; sh.wnu = sh_wtab + 12u*32u + 12u*68u;
-	const int8_t* clevel = reinterpret_cast<const int8_t*>(blob + H->off_clevel);
-	const uint8_t* ise = blob + H->off_ise;
-	const AstcCfgRec* cfgs = reinterpret_cast<const AstcCfgRec*>(blob + H->off_cfg);
-	const uint8_t* ncfgs = blob + H->off_ncfg;
+	// Table pointers are formed where they are used, from an offset the compiler cannot hoist (astc_opq): held for the
+	// whole kernel they were eight more scalars than the scalar file has, parked in vector registers
+#define ASTC_CLEVEL (reinterpret_cast<const int8_t*>(blob + astc_opq(H->off_clevel)))
+#define ASTC_ISE (blob + astc_opq(H->off_ise))
+#define ASTC_CFGS (reinterpret_cast<const AstcCfgRec*>(blob + astc_opq(H->off_cfg)))
+#define ASTC_NCFGS (blob + astc_opq(H->off_ncfg))
 
 	// a lane's weight column (layout: decim_add / normalise_rows / infill_w above)
 	uint8_t* slot0 = wbase + ((((col_rows + 1u)/2u)*256u + 15u) & ~15u);
@@ -1219,9 +1223,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	// up to High a block needs 32 lanes (8 candidates; High: 6,6,6,6,2,2,2,2 configs, the others 4 each):
 	// two blocks share a wavefront
 	const bool can_pair = q <= (CF_ASTC_R4_HIGH ? 3u : 2u);      // High takes the whole wavefront since round 5 (oracle: encode_core, gsz)
-	uint32_t cw[4] = {1u, 1u, 1u, 1u};
-	if (aflags & ASTC_FLAG_PERCEPTUAL) { cw[0] = 11u; cw[1] = 21u; cw[2] = 4u; cw[3] = 16u; }
-	const uint32_t recip_n = 65536u/n;                                          // x / n as (x * recip_n) >> 16, like the oracle
+	// channel weights 1,1,1,1 or (perceptual) 11,21,4,16: formed from the flag where a stage needs them
+#define ASTC_CW_LOCAL const uint32_t cwp_ = (astc_opq(aflags) & ASTC_FLAG_PERCEPTUAL) ? 0x1004150Bu : 0x01010101u; \
+	const uint32_t cw[4] = {cwp_ & 255u, (cwp_ >> 8) & 255u, (cwp_ >> 16) & 255u, cwp_ >> 24}
 
 	for (uint32_t jb = 0; jb < 4u;) {
 		// the lane id is re-read per block (a volatile mbcnt pair): nothing derived from it is hoisted out of
@@ -1429,8 +1433,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					const uint32_t e = hl + gsz*m;
 					uint32_t key = 0xFFFFFFFFu;
 					if (e < np) {
-						// (the 12-wave build serves Lowest / Low: two-partition seeds only -- one computed subset)
-						constexpr uint32_t NS = MAXW == 12 ? 1u : 2u;       // (at most three subsets: two computed)
+						constexpr uint32_t NS = 2u;       // (at most three subsets: two computed)
 						int ac[NS][15];
 						unsigned long long mk[NS], mk1[NS], mk2[NS];
 #pragma unroll
@@ -1706,7 +1709,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		// levels give every candidate 8
 		const bool varK = (q == 2u || (CF_ASTC_R4_HIGH && q == 3u)) && !HDR;
 		const uint32_t K = (HDR && (q == 2u || (CF_ASTC_R4_HIGH && q == 3u))) ? 8u : lad.K, kshift = K == 2u ? 1u : (K == 4u ? 2u : 3u), per_pass = varK ? 8u : gsz >> kshift;
-		unsigned long long bestkey = ~0ull;
+		// (the block's best key and the early-out minima live in its LDS slot, not in registers carried through the passes)
+		if (hl == 0u) { S.best[9] = ~0u; S.best[10] = ~0u; S.pcs[36] = ~0u; S.pcs[37] = ~0u; S.pcs[38] = ~0u; S.pcs[39] = ~0u; }
+		__builtin_amdgcn_wave_barrier();
 		const uint32_t alpha_i = has_alpha ? 1u : 0u;
 		uint32_t npc_max = npc;
 		if (pair) {
@@ -1716,10 +1721,12 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		// early out (oracle: same rule): no two-partition candidate of pass 0 beat the best
 		// one-partition candidate -> the later passes are skipped.  More than one pass only exists
 		// above Normal, where a wave holds one block, so the branch is uniform.
-		unsigned long long e1min = ~0ull, e2min = ~0ull;
 		for (uint32_t base = 0, pass = 0; base < npc_max; base += per_pass, ++pass) {
-			if (pass >= 1u && !pair && e2min != ~0ull && e2min >= e1min)
-				break;
+			if (pass >= 1u && !pair) {
+				const unsigned long long e1min = (unsigned long long)S.pcs[36] | ((unsigned long long)S.pcs[37] << 32), e2min = (unsigned long long)S.pcs[38] | ((unsigned long long)S.pcs[39] << 32);
+				if (e2min != ~0ull && e2min >= e1min)
+					break;
+			}
 			// lane id and what follows from it, re-read per pass (shadowing the block's): the pass's lane roles
 			// and LDS addresses are not computed ahead of the loop and carried -- or spilled -- through it
 			uint32_t lane;
@@ -1877,6 +1884,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							Trow[i] = (uint8_t)Tw;
 					}
 					int sp = 0;
+					ASTC_CW_LOCAL;
 #pragma unroll
 					for (uint32_t c = 0; c < 4u; ++c)
 						sp += ((chmask >> c) & 1u) ? (int)cw[c]*dv[c]*dv[c] : 0;
@@ -1922,7 +1930,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				}
 				__builtin_amdgcn_wave_barrier();
 				if (gact && half == 0u)
-					normalise_rows<false>(gcol, sh.den + g*den_stride, PW, nullptr);
+					normalise_rows<false>(gcol, sh.den + g*astc_opq(H->den_stride), PW, nullptr);
 				__builtin_amdgcn_wave_barrier();
 				uint32_t e = 0;
 				if (gact) {
@@ -1957,9 +1965,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 #pragma unroll
 				for (uint32_t s = 0; s < 4u; ++s)
 					spn += (jact && s < slots) ? S.span[(j*4u + s) & 31u] : 0u;
+				const uint32_t recip_n = 65536u/astc_opq(n);          // x / n as (x * recip_n) >> 16, like the oracle (formed here: not held through the block)
 				const unsigned long long span2 = ((unsigned long long)spn*recip_n) >> 16;
-				const uint32_t ncfg = jact ? ncfgs[cls*2u + alpha_i] : 0u;
-				const AstcCfgRec* list = cfgs + (cls*2u + alpha_i)*64u;
+				const uint32_t ncfg = jact ? ASTC_NCFGS[cls*2u + alpha_i] : 0u;
+				const AstcCfgRec* list = ASTC_CFGS + (cls*2u + alpha_i)*64u;
 				// keys: (estimate >> 8, clamped to 26 bits) << 6 | list index
 				uint32_t key[NK];
 #pragma unroll
@@ -2010,10 +2019,11 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				// re-projected on ITS decoded endpoints, decimated, quantised and the endpoints refitted; a round
 				// that does not lower the lane's exact error ends the lane's refinement.  Every round ends with the
 				// group argmin, so a lane's earlier (better) result stays parked when a later round loses.
-				// (the 12-wave / 168-register build serves Lowest and Low only, which have no rounds: with the rounds
-				// compiled in it kept 18 values in scratch, and a kernel that talks across lanes must not spill vector
-				// registers -- a spill inside divergent control flow saves the active lanes only; see etc_encode.hip)
-				const uint32_t nrounds = (HDR || MAXW == 12 || CF_ASTC_R4_HIGH) ? 0u : (q == 2u ? 2u : (q == 3u ? 2u : (q >= 4u ? 3u : 0u)));
+				// (both LDR builds carry the rounds.  The 12-wave / 168-register build kept 27 values in scratch with them
+				// until the round body became two instances, the block's keys moved to its LDS slot and the table pointers
+				// and channel weights were formed at their uses -- a kernel that talks across lanes must not spill vector
+				// registers: a spill inside divergent control flow saves the active lanes only; see etc_encode.hip)
+				const uint32_t nrounds = (HDR || CF_ASTC_R4_HIGH) ? 0u : (q == 2u ? 2u : (q == 3u ? 2u : (q >= 4u ? 3u : 0u)));
 				bool going = false;
 				unsigned long long prev_err = ~0ull;
 				// the lane's decoded endpoints (bytes r, g, b, a of partition k): what the next round projects on
@@ -2023,6 +2033,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				// refinement rounds (quad = result).  As one loop body its register demand was the union of the two
 				// forms; as two instances of one generic lambda each keeps its own.
 				auto round_body = [&](auto QC_, const uint32_t rnd) __attribute__((always_inline)) -> bool {
+				ASTC_CW_LOCAL;
 				// the lane id and every role that follows from it are formed again per round (a volatile mbcnt pair):
 				// held across the rounds they were 25 spilled registers in the 168-register build
 				uint32_t lane;
@@ -2034,7 +2045,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				// S.span, idle after the ranking), splits the texel walks four ways (reprojection with the atomic
 				// scatter, least-squares sums, exact error: integer partial sums met by two DPP steps) and repeats
 				// the endpoint stage, which is the same arithmetic on the same sums in all four lanes.
-				constexpr bool ROUNDS = !(HDR || MAXW == 12);       // (builds without rounds carry none of this)
+				constexpr bool ROUNDS = !HDR;       // (the HDR builds carry none of this)
 				constexpr bool quad = decltype(QC_)::value;        // round 0: false; the refinement rounds: true (two instances of this body)
 				const uint32_t qr = quad ? hl & 3u : 0u;
 				uint32_t rl = hl;
@@ -2052,11 +2063,11 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				const uint32_t P = pc_P(d), dual = pc_dual(d), ccs = pc_ccs(d), cls = pc_cls(d);
 				const uint32_t oi = (j < cnt && has_role) ? S.order[j*8u + ks] : 255u;
 				const bool active = !(CF_ASTC_ABLATE & 1) && !solid && j < cnt && oi != 255u;
-				const AstcCfgRec cfg = cfgs[(cls*2u + alpha_i)*64u + (active ? oi : 0u)];
+				const AstcCfgRec cfg = ASTC_CFGS[(cls*2u + alpha_i)*64u + (active ? oi : 0u)];
 				r_cfg = oi;
 				const uint32_t planes = dual ? 2u : 1u, wq = cfg.wq;
 				const uint2* inf = sh.infill + (uint32_t)cfg.grid*n;
-				const uint32_t* den = sh.den + (uint32_t)cfg.grid*den_stride;
+				const uint32_t* den = sh.den + (uint32_t)cfg.grid*astc_opq(H->den_stride);
 				// words per plane of the lane's column (rows at the grid's even pitch); plane 1 follows plane 0
 				const uint32_t PW = ((uint32_t)cfg.M*(uint32_t)sh.grid[(uint32_t)cfg.grid*4u + 3u] + 1u) >> 1;
 				uint8_t* colp1 = colbase + (dual ? PW*256u : 0u);
@@ -2280,12 +2291,12 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							const bool a_hdr = has_alpha && (hdrf & 2u);
 							// colour level and state of each option (a lane without the option: level -1, never chosen)
 							const uint32_t nv0 = has_alpha ? 8u : 6u;
-							const int lv0 = nv0*P <= 18u ? (int)clevel[(nv0*P/2u)*132u + cfg.cbits] : -1;
-							const int lv1 = (!has_alpha && 4u*P <= 18u) ? (int)clevel[(4u*P/2u)*132u + cfg.cbits] : -1;
+							const int lv0 = nv0*P <= 18u ? (int)ASTC_CLEVEL[(nv0*P/2u)*132u + cfg.cbits] : -1;
+							const int lv1 = (!has_alpha && 4u*P <= 18u) ? (int)ASTC_CLEVEL[(4u*P/2u)*132u + cfg.cbits] : -1;
 							// option 2: the HDR luminance modes 2 / 3 (two values) for an opaque grey block, one partition, one plane
 							const bool lum = !has_alpha && P == 1u && !dual && not_grey == 0u;
 							const bool opt2_any = __ballot(lum) != 0ull;
-							const int lv2 = lum ? (int)clevel[1u*132u + cfg.cbits] : -1;
+							const int lv2 = lum ? (int)ASTC_CLEVEL[1u*132u + cfg.cbits] : -1;
 							bool ok0 = lv0 >= 0, ok1 = lv1 >= 0, ok2 = lv2 >= 0;
 							double tot0 = 0.0, tot1 = 0.0, tot2 = 0.0;
 							uint32_t cv2 = 0u;                 // option 2: v0 | v1 << 8 | (mode 3) << 16
@@ -2705,7 +2716,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						const uint32_t nv = (has_alpha ? 8u : 6u) - (o == 3 ? 0u : 2u*(uint32_t)o);
 						okk[o] = !(nv*P > 18u || (o == 2 && !grey) || ((o == 1 || o == 2) && dual && ccs < 3u) || (o > 0 && hdrf) ||
 							(o == 3 && n > 20u));   // base + offset: 4x4 and 5x4 only (oracle: same rule)
-						lvs[o] = okk[o] ? (int)clevel[(nv*P/2u)*132u + cfg.cbits] : -1;
+						lvs[o] = okk[o] ? (int)ASTC_CLEVEL[(nv*P/2u)*132u + cfg.cbits] : -1;
 						okk[o] = okk[o] && lvs[o] >= 0;
 					}
 #pragma unroll 1
@@ -2882,8 +2893,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					}
 				}
 				if (pass == 0u && !pair && !quad) {
-					e1min = cf_group_min_u64(P == 1u ? err : ~0ull, false, 0u);
-					e2min = cf_group_min_u64(P == 2u ? err : ~0ull, false, 0u);
+					const unsigned long long e1min = cf_group_min_u64(P == 1u ? err : ~0ull, false, 0u);
+					const unsigned long long e2min = cf_group_min_u64(P == 2u ? err : ~0ull, false, 0u);
+					if (hl == 0u) { S.pcs[36] = (uint32_t)e1min; S.pcs[37] = (uint32_t)(e1min >> 32); S.pcs[38] = (uint32_t)e2min; S.pcs[39] = (uint32_t)(e2min >> 32); }
 				}
 				// a refined result counts only when it lowers the lane's own error
 				if (quad && !(err < prev_err))
@@ -2895,8 +2907,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				const uint32_t id = pass*64u + rl;
 				unsigned long long key = (err == ~0ull || qr != 0u) ? ~0ull : ((err << 10) | id);
 				const unsigned long long kmin = cf_group_min_u64(key, pair, h);
+				const unsigned long long bestkey = (unsigned long long)S.best[9] | ((unsigned long long)S.best[10] << 32);
+				__builtin_amdgcn_wave_barrier();
 				if (kmin != ~0ull && kmin < bestkey) {
-					bestkey = kmin;
+					if (hl == 0u) { S.best[9] = (uint32_t)kmin; S.best[10] = (uint32_t)(kmin >> 32); }
 					if (key == kmin) {
 						S.best[0] = d;
 						S.best[1] = r_cfg | (r_cem << 8) | (r_lv << 16) | (r_ncv << 24);
@@ -2979,14 +2993,21 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 		// ---- pack the winner, spread over the group ----
 		{
 			unsigned long long lo64 = 0ull, hi64 = 0ull;
-			const bool have = bestkey != ~0ull;
+			const bool have = (S.best[9] & S.best[10]) != ~0u;
 			if (!solid && !have) {
 				// no valid candidate (cannot happen for legal tables): mean colour as a void extent
 				if (hl == 0u) {
 					uint32_t cavg[4];
 #pragma unroll
 					for (int c = 0; c < 4; ++c)
-						cavg[c] = (uint32_t)((2*sum[c] + (int)n)/(2*(int)n));
+						cavg[c] = 0u;
+					for (uint32_t i = 0; i < n; ++i) {
+						const uint32_t p = tp[i];
+						cavg[0] += p & 255u; cavg[1] += (p >> 8) & 255u; cavg[2] += (p >> 16) & 255u; cavg[3] += p >> 24;
+					}
+#pragma unroll
+					for (int c = 0; c < 4; ++c)
+						cavg[c] = (2u*cavg[c] + n)/(2u*n);
 					if (nc == 3u) cavg[3] = opaque_a;
 					if (HDR) {
 						unsigned long long t[4] = {0ull, 0ull, 0ull, 0ull};
@@ -3004,12 +3025,12 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			} else if (!solid) {
 				const uint32_t d = S.best[0], meta = S.best[1];
 				const uint32_t P = pc_P(d), dual = pc_dual(d), ccs = pc_ccs(d), cls = pc_cls(d);
-				const AstcCfgRec cfg = cfgs[(cls*2u + alpha_i)*64u + (meta & 255u)];
+				const AstcCfgRec cfg = ASTC_CFGS[(cls*2u + alpha_i)*64u + (meta & 255u)];
 				const uint32_t cem = (meta >> 8) & 255u, lv = (meta >> 16) & 255u, ncv = meta >> 24;
 				const uint8_t* cvals = reinterpret_cast<const uint8_t*>(S.best + 4);
 				const uint8_t* wvals = reinterpret_cast<const uint8_t*>(S.best + 12);
-				const uint8_t* wd = ise + 384u + (uint32_t)cfg.wq*4u;
-				const uint8_t* cd = ise + 384u + 48u + lv*4u;
+				const uint8_t* wd = ASTC_ISE + 384u + (uint32_t)cfg.wq*4u;
+				const uint8_t* cd = ASTC_ISE + 384u + 48u + lv*4u;
 				const uint32_t cstart = P == 1u ? 17u : 29u;
 				if (hl == 0u) {
 					lo64 = (unsigned long long)cfg.mode | ((unsigned long long)(P - 1u) << 11);
@@ -3034,7 +3055,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						for (uint32_t k = 0; k < 5u; ++k)
 							if (k < cntv) v[k] = cvals[first + k];
 						uint32_t len;
-						const unsigned long long bits = ise_group(ise, v, cntv, cb, ct, cq, len);
+						const unsigned long long bits = ise_group(ASTC_ISE, v, cntv, cb, ct, cq, len);
 						put128(lo64, hi64, cstart + ise_size(first, cb, ct, cq), bits, len);
 					}
 				}
@@ -3051,7 +3072,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						for (uint32_t k = 0; k < 5u; ++k)
 							if (k < cntv) v[k] = wvals[first + k];
 						uint32_t len;
-						const uint32_t bits = (uint32_t)ise_group(ise, v, cntv, wb, wt, wqn, len);   // <= 23 bits
+						const uint32_t bits = (uint32_t)ise_group(ASTC_ISE, v, cntv, wb, wt, wqn, len);   // <= 23 bits
 						const uint32_t spos = ise_size(first, wb, wt, wqn);     // stream position
 						const uint32_t rev = __brev(bits) >> (32u - len);
 						put128(lo64, hi64, 128u - spos - len, rev, len);
@@ -3152,8 +3173,7 @@ extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t qualit
 	// 12-wave workgroup with the cache, 4.2 ms as three 4-wave workgroups without); then the cache
 	static const bool plan_no_dense = getenv("CFHIP_ASTC_NO_DENSE") != nullptr;   // experiments: the 256-register build only
 	// (the HDR builds exist for 8 waves only: their phase B holds 16-bit sums and double-precision fits)
-	// (nor for the levels with refinement rounds, Normal and up: the 12-wave build carries none, see the kernel)
-	const bool no12 = plan_no_dense || hdr != 0u || quality >= 2u;
+	const bool no12 = plan_no_dense || hdr != 0u;
 	// any workgroup of 4 .. 12 waves: what counts is the number of waves resident on the CU (more than 8
 	// = three on some SIMDs = the 168-register build, which no longer spills); e.g. 6x6 up to High fits
 	// one 11-wave workgroup (158 KB) where 12 waves do not and two 4-wave workgroups leave 8
@@ -3223,7 +3243,7 @@ extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, ui
 	// the 168-register build only where three waves per SIMD actually become resident
 	static const bool no_dense = getenv("CFHIP_ASTC_NO_DENSE") != nullptr, debug = getenv("CFHIP_ASTC_DEBUG") != nullptr;
 	const bool hdr = ((kp->flags >> 19) & 3u) != 0u;
-	const bool dense = (cf_astc_cu_lds()/(lds_bytes + 1024u))*nwaves > 8u && !no_dense && !hdr && kp->quality <= 1u;
+	const bool dense = (cf_astc_cu_lds()/(lds_bytes + 1024u))*nwaves > 8u && !no_dense && !hdr;
 	void (*fn)(cf_kparams) = nullptr;
 	if (dense)
 		fn = pixel_type == 0 ? &cfhip_astc_encode_kernel<0, 12, false> : &cfhip_astc_encode_kernel<1, 12, false>;
