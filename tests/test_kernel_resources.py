@@ -54,8 +54,8 @@ def test_no_block_encoder_kernel_uses_scratch(kernels):
         # only, and a later cross-lane read of a lane that was inactive then sees a stale value -- the 5- and 4-wave builds
         # of the ETC2 RGB8A1 kernel (32 / 7 spilled registers) returned wrong blocks in 3 .. 5 of 300 fuzz cases where
         # every build without spills is byte-identical to the oracle (tests/test_gpu_etc.py::test_a1_srgb_partial_blocks).
-        # So: ETC2 at 3 waves (135 .. 144 registers), ETC1 at 4; the 168-register ASTC build serves the levels without
-        # refinement rounds only.
+        # So: ETC2 at 3 waves (135 .. 144 registers), ETC1 at 4; the 168-register ASTC build carries the refinement rounds
+        # since late round 5 without a spill (Data and occupancy) and serves every LDR level.
         bad = {k: v for k, v in ks.items() if v["scratch"] != 0}
         assert not bad, bad
 
