@@ -328,11 +328,16 @@ __device__ __forceinline__ void normalise_rows(uint8_t* base, const uint32_t* de
 	reinterpret_cast<uint32_t*>(base + (PW - 1u)*256u)[0] = prev | ((prev >> 8) << 16);
 }
 
-// The same, by the four lanes of a refinement quad (they share the result's column): lane qr takes the words
-// 4 qr + 16 m .. + 3.  A step is self-contained -- it also reads the word after its four (that word's first
-// weight completes the pair form of its last one) -- and every lane's reads of a step come before any lane's
-// writes of it (the scheduling barriers; the quad runs the steps in lockstep), so no lane reads a word that a
-// neighbour has already rewritten in place.
+// The same, by the four lanes of a refinement quad.  Round 6: every lane of the quad scatters ITS texels into
+// ITS OWN column (the quad's four columns are the four words of one 16-byte group of every row: `base` = the
+// first of them), so the scatter, the least-squares walk and the error walk touch one bank per lane like round 0
+// (sharing the result's column, the four lanes met in one bank: 35 % of the LDS-active cycles of the 6x6 High
+// kernel were bank conflicts).  Here the partial sums meet -- one 16-byte read per row word, the halves cannot
+// carry (the total is at most 64 x the factor sum) -- and the pair-form weights go back as four copies, one per
+// lane.  Lane qr takes the words 4 qr + 16 m .. + 3.  A step is self-contained -- it also reads the word after its
+// four (that word's first weight completes the pair form of its last one) -- and every lane's reads of a step come
+// before any lane's writes of it (the scheduling barriers; the quad runs the steps in lockstep), so no lane reads
+// a word that a neighbour has already rewritten in place.
 __device__ __forceinline__ void normalise_rows_quad(uint8_t* base, const uint32_t* den, uint32_t PW, const uint8_t* wnu, uint32_t qr)
 {
 #pragma unroll 1
@@ -342,7 +347,8 @@ __device__ __forceinline__ void normalise_rows_quad(uint8_t* base, const uint32_
 #pragma unroll
 		for (uint32_t m = 0; m < 5u; ++m) {
 			const uint32_t km = min(k + m, PW - 1u);
-			acc[m] = *reinterpret_cast<const uint32_t*>(base + km*256u);
+			const uint4 part = *reinterpret_cast<const uint4*>(base + km*256u);
+			acc[m] = (part.x + part.y) + (part.z + part.w);
 			dd[m] = *reinterpret_cast<const uint2*>(den + 2u*km);
 		}
 		__builtin_amdgcn_wave_barrier();
@@ -361,7 +367,8 @@ __device__ __forceinline__ void normalise_rows_quad(uint8_t* base, const uint32_
 			if (k + m < PW) {
 				const uint32_t cur = g[2u*m] | (g[2u*m + 1u] << 8);
 				const uint32_t nxt = k + m + 1u < PW ? g[2u*m + 2u] : 0u;
-				*reinterpret_cast<uint32_t*>(base + (k + m)*256u) = cur | (((cur >> 8) | (nxt << 8)) << 16);
+				const uint32_t wv = cur | (((cur >> 8) | (nxt << 8)) << 16);
+				*reinterpret_cast<uint4*>(base + (k + m)*256u) = make_uint4(wv, wv, wv, wv);
 			}
 		}
 	}
@@ -1217,7 +1224,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 
 	const uint32_t q = kp.quality > 4u ? 4u : kp.quality;
 #if CF_ASTC_PROF
-	unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
+	unsigned long long prof_acc[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
 #endif
 	const Ladder lad = ladder(q);
 	// up to High a block needs 32 lanes (8 candidates; High: 6,6,6,6,2,2,2,2 configs, the others 4 each):
@@ -1419,8 +1426,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 			// the bound, 6x6 0.50 -> 0.32); footprints of 64 texels and more gain nothing and keep it.
 			// (mixed: the two-partition seeds only -- the three-partition ones add 0.01 .. 0.03 dB for more than half the time)
 			const bool mixedP = mixed && P == 2u;
-			// (four-partition seeds -- Highest only -- keep the overlap ranking: oracle shortlist)
-			const bool lfP = linefit && P <= 3u;
+			// (three- and four-partition seeds keep the overlap ranking: oracle shortlist -- round 6: the line fit of the
+			// 256 three-partition seeds was 9 % of High's vector instructions for 0.011 .. 0.015 dB)
+			const bool lfP = linefit && P == 2u;
 			if (lfP || mixedP) {
 				// members of subset c of entry e: bit i of the entry's 64-bit texel masks (three words per subset)
 				const unsigned long long* lmasks = reinterpret_cast<const unsigned long long*>(blob + H->off_mask[P - 2u]);
@@ -1433,7 +1441,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					const uint32_t e = hl + gsz*m;
 					uint32_t key = 0xFFFFFFFFu;
 					if (e < np) {
-						constexpr uint32_t NS = 2u;       // (at most three subsets: two computed)
+						constexpr uint32_t NS = 1u;       // (two subsets -- P == 2 here --: one computed, the other the block minus it)
 						int ac[NS][15];
 						unsigned long long mk[NS], mk1[NS], mk2[NS];
 #pragma unroll
@@ -1750,6 +1758,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				// 32 (candidate, slot) units; a wave that holds one block gives each unit two lanes (hl and
 				// hl ^ 32), which take the even and the odd texels: integer sums and float min / max meet
 				// through the lane pair, so the results are those of one lane walking all texels
+				// (fresh lane id: the pass's is not held -- or spilled -- across this phase)
+				uint32_t lane;
+				asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+				const uint32_t hl = pair ? (lane & 31u) : lane;
 				const uint32_t sl = hl & 31u, par = pair ? 0u : hl >> 5, stp = pair ? 1u : 2u;
 				const uint32_t j = sl >> 2, s = sl & 3u;
 				const uint32_t d = j < cnt ? S.pcs[base + j] : 0u;
@@ -1908,6 +1920,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				// a wave that holds one block has 64 lanes for at most 24 grids: lanes g and g + 32 share
 				// grid g -- each decimates every other texel into lane g's column (the scatter is atomic) and
 				// takes every other texel of the error walk; lane g alone turns the sums into averages
+				uint32_t lane;
+				asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+				const uint32_t hl = pair ? (lane & 31u) : lane;
 				const uint32_t g = hl & 31u, half = pair ? 0u : hl >> 5, step = pair ? 1u : 2u;
 				const bool gact = !(CF_ASTC_ABLATE & 4) && !solid && g < ngrids && hl < 32u + (pair ? 0u : 32u);
 				uint8_t* gcol = wbase + (pair ? lane : g)*4u;
@@ -2041,9 +2056,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				const uint32_t h = pair ? lane >> 5 : 0u, hl = pair ? (lane & 31u) : lane;
 				// Round 0: lane = (candidate, config).  The refinement rounds run on the group's gsz / 4 best results
 				// of round 0 only (oracle: encode_core, ASTC_REFINE_DIV), FOUR lanes per result: the quad takes the
-				// role of the result's lane (its candidate, config and weight column; the owner table sits in
-				// S.span, idle after the ranking), splits the texel walks four ways (reprojection with the atomic
-				// scatter, least-squares sums, exact error: integer partial sums met by two DPP steps) and repeats
+				// role of the result's lane (its candidate and config; the owner table sits in S.span, idle after the
+				// ranking; the weights live in the quad's OWN four columns, one copy per lane), splits the texel walks four
+				// ways (reprojection with the atomic scatter, least-squares sums, exact error: integer partial sums met by two DPP steps) and repeats
 				// the endpoint stage, which is the same arithmetic on the same sums in all four lanes.
 				constexpr bool ROUNDS = !HDR;       // (the HDR builds carry none of this)
 				constexpr bool quad = decltype(QC_)::value;        // round 0: false; the refinement rounds: true (two instances of this body)
@@ -2054,7 +2069,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				const bool has_role = !quad || rl != 255u;
 				rl = has_role ? rl : 0u;
 				const uint32_t wfirst = quad ? qr*4u : 0u, wstep = quad ? 16u : 4u;      // a lane's texel groups in the walks
-				uint8_t* colbase = wbase + ((pair ? h << 5 : 0u) + rl)*4u;
+				// the lane's column: round 0 its own; a refinement quad works in its own four columns (normalise_rows_quad)
+				const uint32_t coll = (pair ? h << 5 : 0u) + (quad ? hl : rl);
+				uint8_t* colbase = wbase + coll*4u;
+#define ASTC_QUADBASE (colbase - qr*4u)      /* the quad's first column (formed at its uses: one register less across the round) */
 				// High: lanes 0..23 = candidates 0..3 x 6 configs ((rl * 43) >> 8 == rl / 6 there), lanes 24..31 =
 				// candidates 4..7 x 2; a lone block in a 64-lane group leaves lanes 32.. idle
 				const uint32_t jv = rl < 24u ? (rl*43u) >> 8 : (rl < 32u ? 4u + ((rl - 24u) >> 1) : 8u);
@@ -2094,11 +2112,12 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				}
 				// this round's weights (oracle: wide_reproject): texel i projects on the line D0 -> D1 of its partition
 				// (the previous round's decoded endpoints), T = round(64 t / dd) clamped to 0 .. 64, straight into the
-				// decimation.  The quad shares the result's column: rows are cleared, texel groups scattered and planes
-				// normalised by different lanes, in program order (LDS operations of a wave complete in order)
+				// decimation.  Every lane of the quad scatters its texel groups into its own column (round 6); the rows of
+				// the quad's four columns are cleared and, in normalise_rows_quad, summed and normalised by different
+				// lanes, in program order (LDS operations of a wave complete in order)
 				if (quad && going) {
 					for (uint32_t k = qr; k <= PW*planes; k += 4u)
-						*reinterpret_cast<uint32_t*>(colbase + k*256u) = 0u;
+						*reinterpret_cast<uint4*>(ASTC_QUADBASE + k*256u) = make_uint4(0u, 0u, 0u, 0u);
 					__builtin_amdgcn_wave_barrier();
 					if (!(aflags & ASTC_FLAG_PERCEPTUAL)) {
 						// unit channel weights: the line of a partition as byte words -- dv+ and dv- (the positive
@@ -2214,9 +2233,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					__builtin_amdgcn_wave_barrier();
 #pragma unroll 1
 					for (uint32_t pl = 0; pl < planes; ++pl)
-						normalise_rows_quad(pl ? colp1 : colbase, den, PW, sh.wnu + wq*68u, qr);
+						normalise_rows_quad(ASTC_QUADBASE + (pl ? PW*256u : 0u), den, PW, sh.wnu + wq*68u, qr);
 				}
 				__builtin_amdgcn_wave_barrier();
+				PROF_MARK(quad ? 12 : 6)   // refinement rounds: reprojection + decimate + quantise
 				err = ~0ull; r_cem = 0; r_lv = 0; r_ncv = 0;
 #pragma unroll
 				for (int k = 0; k < 5; ++k) r_cv[k] = 0;
@@ -2704,7 +2724,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							in.r1[c] = bq;
 						}
 					};
-					PROF_MARK(7)   // B: texel weights + sums
+					PROF_MARK(quad ? 13 : 7)   // B: texel weights + sums
 					// 4. endpoint mode by the quadratic estimate (same mode for every partition):
 					// option o = 0 direct (CEM 8/12), 1 base + scale (6/10), 2 luminance (0/4)
 					// option o = 3: base + offset (CEM 9 / 13), the value count of the direct mode
@@ -2782,7 +2802,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 							}
 						}
 #undef SEL4
-						PROF_MARK(8)   // B: endpoint modes
+						PROF_MARK(quad ? 14 : 8)   // B: endpoint modes
 						// 5. exact error through the decode arithmetic
 						unsigned long long e64 = 0;
 						if (!hdrf && !(aflags & ASTC_FLAG_PERCEPTUAL)) {
@@ -2902,7 +2922,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					err = ~0ull;
 				going = going && err != ~0ull;
 				prev_err = going ? err : prev_err;
-				PROF_MARK(9)   // B: exact error (+ idle lanes waiting)
+				PROF_MARK(quad ? 15 : 9)   // B: exact error (+ idle lanes waiting)
 				// ---- argmin (error, id); the winner parks its result in the block's slot ----
 				const uint32_t id = pass*64u + rl;
 				unsigned long long key = (err == ~0ull || qr != 0u) ? ~0ull : ((err << 10) | id);
@@ -2918,7 +2938,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						for (int k = 0; k < 5; ++k)
 							S.best[4 + k] = r_cv[k];
 						// where the group finds this lane's weight column and how to walk it
-						S.best[2] = ((pair ? h << 5 : 0u) + rl) | (wq << 8) | (dual << 16) | (PW << 24);
+						S.best[2] = coll | (wq << 8) | (dual << 16) | (PW << 24);
 						S.best[3] = (uint32_t)cfg.N | ((uint32_t)sh.grid[(uint32_t)cfg.grid*4u + 3u] << 8) | ((uint32_t)cfg.ng << 16);
 					}
 					__builtin_amdgcn_wave_barrier();
@@ -2940,6 +2960,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					}
 				}
 				__builtin_amdgcn_wave_barrier();
+				PROF_MARK(quad ? 16 : 10)   // argmin + park
 				if (rnd >= nrounds || __ballot(going) == 0ull)
 					return false;
 				if (ROUNDS && !quad) {
@@ -2976,6 +2997,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					const uint32_t ocem = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)r_cem);
 					keep_opt = (ocem == 8u || ocem == 12u) ? 0 : ((ocem == 6u || ocem == 10u) ? 1 : ((ocem == 0u || ocem == 4u) ? 2 : 3));
 					going = ow != 255u;
+					PROF_MARK(17)   // the best results' ranks + hand-over to the quads
 				}
 				return true;
 				};
@@ -2992,6 +3014,14 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 
 		// ---- pack the winner, spread over the group ----
 		{
+			// (fresh lane roles: the block's own are not held -- or spilled -- across the passes for this)
+			uint32_t lane;
+			asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+			const uint32_t h = pair ? lane >> 5 : 0u, hl = pair ? (lane & 31u) : lane;
+			const uint32_t b = b0 + h;
+			const uint32_t* tp = tile + b*n;
+			struct { uint32_t* best; } S;
+			S.best = reinterpret_cast<uint32_t*>(slot0 + h*slot_bytes + ((18u*npad + 15u) & ~15u)) + 280;
 			unsigned long long lo64 = 0ull, hi64 = 0ull;
 			const bool have = (S.best[9] & S.best[10]) != ~0u;
 			if (!solid && !have) {
@@ -3090,11 +3120,16 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 #if CF_ASTC_PROF
 	if (blockIdx.y*gridDim.x + blockIdx.x == 1000u && threadIdx.x == 0u)
 		printf("astc prof q%u (clock ticks of wave 0, 4 blocks): pre %llu stats+shortlist %llu rows %llu A %llu grids %llu rank %llu "
-			"B.dec %llu B.lsq %llu B.cem %llu B.err %llu park %llu pack %llu\n", q, prof_acc[0], prof_acc[1], prof_acc[2],
-			prof_acc[3], prof_acc[4], prof_acc[5], prof_acc[6], prof_acc[7], prof_acc[8], prof_acc[9], prof_acc[10], prof_acc[11]);
+			"B.dec %llu B.lsq %llu B.cem %llu B.err %llu park %llu pack %llu | rounds: reproject+dec %llu lsq %llu cem %llu err %llu park %llu | select %llu\n", q, prof_acc[0], prof_acc[1], prof_acc[2],
+			prof_acc[3], prof_acc[4], prof_acc[5], prof_acc[6], prof_acc[7], prof_acc[8], prof_acc[9], prof_acc[10], prof_acc[11],
+			prof_acc[12], prof_acc[13], prof_acc[14], prof_acc[15], prof_acc[16], prof_acc[17]);
 #endif
 	__syncthreads();
-	const uint32_t t = threadIdx.x;
+	// (the thread index formed again from the scalar wave index and a fresh lane id: threadIdx.x read here stays live
+	// -- or is spilled -- through the whole search)
+	uint32_t t;
+	asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(t));
+	t += wave*64u;
 	if (t < nblk*4u) {
 		const uint32_t b = t >> 2;
 		if (bx0 + b < kp.bx) {

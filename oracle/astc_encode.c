@@ -1631,7 +1631,14 @@ static int shortlist(const astc_blk* b, int P, int limit, int want, const float 
 	 * 0.5 .. 1 dB with the line fit on its 8-bit window codes; there is no real HDR content here to tune on).  Key = the float's bits without the low 10, then the index. */
 	/* (four-partition seeds -- Highest only -- keep the overlap ranking: the line fit buys them 0.000 dB at 4x4 and
 	 * 0.007 dB at 6x6 for a tenth of the level's time) */
-	const int linefit = b->n < 64 && P <= 3 && !b->hdr && !getenv("CFO_ASTC_NO_LINEFIT");      /* (the switch: lab / debugging only) */
+	/* Round 6: two-partition seeds only.  The kernel is bound by the vector instructions it issues, and ranking the 256
+	 * three-partition seeds this way (two subset walks + three energies each) was 9 % of them at High for 0.011 / 0.015 /
+	 * 0.014 dB at 4x4 / 5x5 / 6x6 on the real-photograph blocks (tools/astc_lab.py; the three-partition candidates are worth
+	 * 0.05 dB in all): they go back to the cluster-overlap ranking, like the four-partition seeds. */
+	static int no_linefit = -1;               /* (read once: this sits inside the timed CPU baseline) */
+	if (no_linefit < 0)
+		no_linefit = getenv("CFO_ASTC_NO_LINEFIT") != NULL;      /* (the switch: lab / debugging only) */
+	const int linefit = b->n < 64 && P == 2 && !b->hdr && !no_linefit;
 	if (linefit)
 		for (int t = 0; t < np; ++t)
 			key[t] = linefit_key(b, P, t);
@@ -1642,7 +1649,7 @@ static int shortlist(const astc_blk* b, int P, int limit, int want, const float 
 	 * 0.85 / 0.76 / 0.64.  (Line-fit keys for the first 128 or 64 seeds only: a third / two thirds of the gain lost.)
 	 * Two-partition seeds only: the three-partition seeds add 0.01 .. 0.03 dB of that for more than half of its time
 	 * (8x8 0.73 / 0.61 / 0.55, 10x10 0.84 / 0.72 / 0.67, 12x12 0.87 / 0.76 / 0.65 as built). */
-	const int mixed = b->n >= 64 && P == 2 && !b->hdr && !getenv("CFO_ASTC_NO_LINEFIT");
+	const int mixed = b->n >= 64 && P == 2 && !b->hdr && !no_linefit;
 	/* mixed: the picks ALTERNATE -- overlap, line fit, overlap, ... each among the seeds not yet taken -- so that a
 	 * shorter list is a prefix of a longer one (High's four seeds are the head of Highest's fourteen) */
 	uint32_t k2[ASTC_MAX_PARTS];

@@ -102,6 +102,8 @@ void cfo_bc6h_wide_search(const uint16_t rgba_half[64], uint8_t out[16], const c
 uint64_t cfo_astc_wide_search(const uint8_t* rgba, int bw, int bh, int flags, uint8_t out[16]);
 /* test-only: the TRUE optimum of an ETC1 (etc2 = 0) or ETC2 RGB block: exhaustive over every mode (etc_codec.c) */
 uint32_t cfo_etc_true_optimum(const uint8_t rgba[64], int etc2, uint8_t out[8]);
+/* test-only: the TRUE optimum of one EAC block (kind 0 alpha8, 1 R11, 2 signed R11): every base x multiplier x table */
+uint32_t cfo_eac_true_optimum(const int v[16], int kind, uint8_t out[8]);
 
 /* sum of squared differences over RGBA8 images, per channel (for PSNR) */
 void cfo_sse_rgba8(const uint8_t* a, const uint8_t* b, size_t n_pixels, uint64_t sse[4]);

@@ -1145,6 +1145,58 @@ void cfo_eac_search(const int v[16], int kind, unsigned active, int R, uint8_t o
 		out[2 + i] = (uint8_t)(bits >> (40 - 8*i));
 }
 
+/* test-only: the TRUE optimum of one EAC block (kind as above): every base x multiplier x table, the best
+ * modifier per texel -- everything the format can express (the bound tools/quality_tables.py measures the EAC
+ * ladders against; a multiplier of 0 included, which the search above never emits).  Returns the squared error and
+ * writes the block. */
+uint32_t cfo_eac_true_optimum(const int v[16], int kind, uint8_t out[8])
+{
+	uint32_t best_err = 0xFFFFFFFFu;
+	int best_base = 0, best_mult = 0, best_table = 0;
+	const int bmin = kind == 2 ? -127 : 0, bmax = kind == 2 ? 127 : 255;
+	for (int t = 0; t < 16; ++t)
+		for (int mult = 0; mult < 16; ++mult)
+			for (int base = bmin; base <= bmax; ++base) {
+				int d[8];
+				for (int k = 0; k < 8; ++k) {
+					const int m = eac_mod[t][k];
+					if (kind == 0) d[k] = clamp255(base + m*mult);
+					else if (kind == 1) d[k] = clampi(base*8 + 4 + (mult ? m*mult*8 : m), 0, 2047);
+					else d[k] = clampi(base*8 + (mult ? m*mult*8 : m), -1023, 1023);
+				}
+				uint32_t err = 0;
+				for (int i = 0; i < 16 && err < best_err; ++i) {
+					uint32_t be = 0xFFFFFFFFu;
+					for (int k = 0; k < 8; ++k) {
+						const int e = d[k] - v[i];
+						if ((uint32_t)(e*e) < be) be = (uint32_t)(e*e);
+					}
+					err += be;
+				}
+				if (err < best_err) { best_err = err; best_base = base; best_mult = mult; best_table = t; }
+			}
+	uint64_t bits = 0;
+	for (int i = 0; i < 16; ++i) {
+		int x = i & 3, y = i >> 2, k = x*4 + y, bk = 0;
+		uint32_t be = 0xFFFFFFFFu;
+		for (int j = 0; j < 8; ++j) {
+			const int m = eac_mod[best_table][j];
+			int d;
+			if (kind == 0) d = clamp255(best_base + m*best_mult);
+			else if (kind == 1) d = clampi(best_base*8 + 4 + (best_mult ? m*best_mult*8 : m), 0, 2047);
+			else d = clampi(best_base*8 + (best_mult ? m*best_mult*8 : m), -1023, 1023);
+			d -= v[i];
+			if ((uint32_t)(d*d) < be) { be = (uint32_t)(d*d); bk = j; }
+		}
+		bits |= (uint64_t)bk << (45 - 3*k);
+	}
+	out[0] = (uint8_t)best_base;
+	out[1] = (uint8_t)((best_mult << 4) | best_table);
+	for (int i = 0; i < 6; ++i)
+		out[2 + i] = (uint8_t)(bits >> (40 - 8*i));
+	return best_err;
+}
+
 /* ---------------------------------------------------------------- dispatch */
 
 static int effort_radius(int quality)

@@ -18,6 +18,15 @@ Content of the archive (all uint8):
                                   half take the luma of ANOTHER photograph as alpha (smooth + textured alpha)
     rgb12      (N12, 12, 12, 3)   12x12 patches; every ASTC footprint crops its block from the top-left corner
     rgb12_img  (N12,)
+Round 6 -- a SECOND group of photographs, held out from every ladder (no tuning tool reads it; it exists to show that
+the gaps measured on the first group generalise), arrays with the suffix _b:
+    images_b   hubble_deep_field, ihc, retina, motorcycle_right, color (skimage sample data)
+    rgb4_b / rgb4_b_img, rgb12_b / rgb12_b_img    as above, 256 / 64 per image
+    The ASTC config census (tools/astc_rank_configs.py --real, the 5x5 / 6x6 lists) read the 240 x 240 CENTRE crop
+    of these five pictures (retina and hubble halved first); the blocks here are sampled OUTSIDE that crop, so no
+    texel of this group was seen by any tool.  BC7 and ETC never had a census.
+    rgba12     (NA12, 12, 12, 4)  12x12 patches of a first-group photograph with another first-group photograph's
+                                  luma as alpha (smooth + textured alpha), for the alpha-carrying ASTC rows
 """
 import os
 
@@ -37,6 +46,17 @@ PHOTOS = [
     ("motorcycle", SK + "motorcycle_left.png"),
 ]
 ALPHA_PICS = [("logo", SK + "logo.png"), ("horse", SK + "horse.png")]
+PHOTOS_B = [
+    ("hubble_deep_field", SK + "hubble_deep_field.jpg", 2),      # (name, path, the census's reduction factor)
+    ("ihc", SK + "ihc.png", 1),
+    ("retina", SK + "retina.jpg", 2),
+    ("motorcycle_right", SK + "motorcycle_right.png", 1),
+    ("color", SK + "color.png", 1),
+]
+CENSUS_CROP = 240                   # tools/astc_rank_configs.py --size
+N4_PER_IMAGE_B = 256
+N12_PER_IMAGE_B = 64
+NA12 = 256
 N4_PER_IMAGE = 512
 NA = 1024
 N12_PER_IMAGE = 96
@@ -82,12 +102,44 @@ def main():
         y, x = int(rng.integers(0, h // 4)) * 4, int(rng.integers(0, w // 4)) * 4
         lum = (ib[y:y + 4, x:x + 4].astype(np.uint32) @ np.array([54, 183, 19], np.uint32) >> 8).astype(np.uint8)
         rgba4.append(np.dstack([ia[y:y + 4, x:x + 4], lum]))
+    # ---- the second, held-out group (its own generator: the first group's arrays stay what they were) ----
+    rngb = np.random.default_rng(0xB10C5)
+    rgb4_b, rgb4_b_img, rgb12_b, rgb12_b_img = [], [], [], []
+    for k, (_, path, red) in enumerate(PHOTOS_B):
+        img = load(path, "RGB")
+        h, w = img.shape[:2]
+        c = CENSUS_CROP * red
+        cy0, cx0 = (h - c) // 2, (w - c) // 2
+
+        def outside(y, x, s):       # the s x s patch at (y, x) shares no texel with the census's centre crop
+            return y + s <= cy0 or y >= cy0 + c or x + s <= cx0 or x >= cx0 + c
+        for size, count, dst, dsti in ((4, N4_PER_IMAGE_B, rgb4_b, rgb4_b_img), (12, N12_PER_IMAGE_B, rgb12_b, rgb12_b_img)):
+            got = 0
+            while got < count:
+                y, x = int(rngb.integers(0, h // size)) * size, int(rngb.integers(0, w // size)) * size
+                if not outside(y, x, size):
+                    continue
+                dst.append(img[y:y + size, x:x + size])
+                dsti.append(k)
+                got += 1
+    rgba12 = []
+    while len(rgba12) < NA12:
+        a, b = rngb.choice(len(photos), 2, replace=False)
+        ia, ib = photos[a], photos[b]
+        h, w = min(ia.shape[0], ib.shape[0]), min(ia.shape[1], ib.shape[1])
+        y, x = int(rngb.integers(0, h // 12)) * 12, int(rngb.integers(0, w // 12)) * 12
+        lum = (ib[y:y + 12, x:x + 12].astype(np.uint32) @ np.array([54, 183, 19], np.uint32) >> 8).astype(np.uint8)
+        rgba12.append(np.dstack([ia[y:y + 12, x:x + 12], lum]))
     out = os.path.join(HERE, "real_blocks.npz")
     np.savez_compressed(
         out, images=np.array([n for n, _ in PHOTOS]),
         rgb4=np.stack(rgb4).astype(np.uint8), rgb4_img=np.array(rgb4_img, np.uint8),
         rgba4=np.stack(rgba4).astype(np.uint8),
-        rgb12=np.stack(rgb12).astype(np.uint8), rgb12_img=np.array(rgb12_img, np.uint8))
+        rgb12=np.stack(rgb12).astype(np.uint8), rgb12_img=np.array(rgb12_img, np.uint8),
+        images_b=np.array([n for n, _, _ in PHOTOS_B]),
+        rgb4_b=np.stack(rgb4_b).astype(np.uint8), rgb4_b_img=np.array(rgb4_b_img, np.uint8),
+        rgb12_b=np.stack(rgb12_b).astype(np.uint8), rgb12_b_img=np.array(rgb12_b_img, np.uint8),
+        rgba12=np.stack(rgba12).astype(np.uint8))
     print(out, os.path.getsize(out), "bytes")
 
 

@@ -20,22 +20,30 @@ def _load():
     return _cache
 
 
-def image_names():
-    return [str(s) for s in _load()["images"]]
+def image_names(group="a"):
+    """the photographs of a group: "a" = the eight the ladders were balanced on (round 5); "b" = the five held-out
+    ones of round 6 (no tuning tool reads them; make_real_blocks.py)"""
+    return [str(s) for s in _load()["images" + _sfx(group)]]
 
 
-def blocks4(count=None, alpha=False, image=None):
+def _sfx(group):
+    assert group in ("a", "b")
+    return "_b" if group == "b" else ""
+
+
+def blocks4(count=None, alpha=False, image=None, group="a"):
     """-> (n, 4, 4, 4) uint8 RGBA blocks.  alpha=False: opaque photograph blocks (interleaved over the
-    images so any prefix is a fair sample); alpha=True: the alpha-carrying set."""
+    images so any prefix is a fair sample); alpha=True: the alpha-carrying set (group "a" only)."""
     d = _load()
     if alpha:
+        assert group == "a"
         b = d["rgba4"]
     else:
-        rgb, src = d["rgb4"], d["rgb4_img"]
+        rgb, src = d["rgb4" + _sfx(group)], d["rgb4" + _sfx(group) + "_img"]
         if image is not None:
-            rgb = rgb[src == image_names().index(image)]
+            rgb = rgb[src == image_names(group).index(image)]
         else:
-            nimg = len(d["images"])
+            nimg = len(d["images" + _sfx(group)])
             per = len(rgb) // nimg
             rgb = rgb.reshape(nimg, per, 4, 4, 3).transpose(1, 0, 2, 3, 4).reshape(-1, 4, 4, 3)
         b = np.concatenate([rgb, np.full(rgb.shape[:3] + (1,), 255, np.uint8)], axis=-1)
@@ -44,14 +52,23 @@ def blocks4(count=None, alpha=False, image=None):
     return np.ascontiguousarray(b)
 
 
-def blocks(bw, bh, count=None, image=None):
+def blocks_alpha(bw, bh, count=None):
+    """-> (n, bh, bw, 4) uint8 blocks WITH a varying alpha channel of an ASTC footprint up to 12x12 (a photograph's
+    colour, another photograph's luma as alpha; top-left crop of the rgba12 patches)."""
+    b = _load()["rgba12"][:, :bh, :bw]
+    if count is not None:
+        b = b[:count]
+    return np.ascontiguousarray(b)
+
+
+def blocks(bw, bh, count=None, image=None, group="a"):
     """-> (n, bh, bw, 4) uint8 opaque blocks of an ASTC footprint up to 12x12 (top-left crop of the patches)."""
     d = _load()
-    rgb, src = d["rgb12"], d["rgb12_img"]
+    rgb, src = d["rgb12" + _sfx(group)], d["rgb12" + _sfx(group) + "_img"]
     if image is not None:
-        rgb = rgb[src == image_names().index(image)]
+        rgb = rgb[src == image_names(group).index(image)]
     else:
-        nimg = len(d["images"])
+        nimg = len(d["images" + _sfx(group)])
         per = len(rgb) // nimg
         rgb = rgb.reshape(nimg, per, 12, 12, 3).transpose(1, 0, 2, 3, 4).reshape(-1, 12, 12, 3)
     rgb = rgb[:, :bh, :bw]
