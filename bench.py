@@ -54,6 +54,10 @@ GPU_CLOCK_HZ = 2.4e9          # MI355X peak engine clock (MI355X_MICROARCH.md)
 N_SIMD = 1024                 # 256 CUs x 4 SIMDs
 ALGO_BYTES_PER_PIXEL = 5.0   # 4 B RGBA8 read + 16 B / 16 px payload write
 QNAMES = ["Lowest", "Low", "Normal", "High", "Highest"]
+ROUND = 6                     # this build's round: vs_previous_round reads the driver's records BELOW it (a re-run inside
+                              # the round, once BENCH_r06.json exists, must not compare the build with itself)
+MIN_VS_PREVIOUS = 0.90        # regression gate: a headline below this share of the previous round's is flagged in the
+                              # line (`regression_gate.ok`), fails tests/test_gpu_bench.py and, with BENCH_STRICT=1, the run
 
 
 def usable_cpus() -> int:
@@ -80,12 +84,15 @@ def usable_cpus() -> int:
 
 
 def _previous_round(metric, n_gpus, value):
-    """The driver's record of the previous round's run of this metric (BENCH_rNN.json at the repo root), so that a
-    change of the search budget of a quality level shows in the line itself (round-4 ADVICE: Normal went 4 459 ->
+    """The driver's record of the previous round's run of this metric (BENCH_rNN.json at the repo root, NN < ROUND), so
+    that a change of the search budget of a quality level shows in the line itself (round-4 ADVICE: Normal went 4 459 ->
     2 018 Mpixel/s for 0.3 dB and nothing in the line said so).  None when no record of the same metric is there."""
     import glob
+    import re
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "BENCH_r[0-9][0-9].json"))):
+        if int(re.search(r"BENCH_r(\d\d)\.json$", path).group(1)) >= ROUND:
+            continue
         try:
             rec = json.load(open(path)).get("parsed") or {}
             if rec.get("metric") == metric and rec.get("n_gpus", 1) == n_gpus and rec.get("value"):
@@ -200,6 +207,49 @@ def second_tile(ctx, torch, size, params, steps, stream, check):
         res["psnr_rgb_gpu"] = round(synth.psnr(strip, dec, slice(0, 3)), 3)
         res["gpu_payload_equals_cpu"] = bool(np.array_equal(ref, got))
     return res
+
+
+def tolerance_view(ctx, torch, surf, size, stream, normal_value, steps=3):
+    """north_star: ">= 50 Mpixel/s BC7 'quality' encode at <= 0.1 dB PSNR delta".  The reference's encoders are absent, so
+    the delta is measured against a bound (cfo_bc7_wide_search) on blocks of real photographs, two photograph groups
+    (profiles/quality_real.json, written by tools/quality_real.py --json on the oracle whose bytes the kernels emit).  The
+    headline level (Normal) is OUTSIDE 0.1 dB there; this key names the lowest level that is inside on both groups and
+    times it on the same tile in the same run (a few launches after the headline loop; never part of `value`)."""
+    from cuttlefish_amd import Format, Type, make_params
+    gaps = None
+    try:
+        js = json.load(open(os.path.join(ROOT, "profiles", "quality_real.json")))
+        gaps = {g: js["BC7 opaque/%s" % g]["pooled_gap_nhh"] for g in ("a", "b")}
+    except (OSError, KeyError, ValueError):
+        pass
+    out = {"target_db": 0.1, "bound": "cfo_bc7_wide_search on blocks of real photographs (tests/golden/real_blocks.npz, groups a / b)",
+           "gap_db_normal_high_highest": gaps, "source": "profiles/quality_real.json (tools/quality_real.py)"}
+    level = None
+    if gaps:
+        for k, q in enumerate((2, 3, 4)):
+            if all(gaps[g][k] <= 0.1 for g in gaps):
+                level = q
+                break
+    out["headline_level_within_target"] = bool(level == 2)
+    out["lowest_level_within_target"] = QNAMES[level] if level is not None else None
+    if level is not None and level != 2:
+        params = make_params(Format.BC7, Type.UNorm, level)
+        ctx.encode_device(surf, params, stream)
+        torch.cuda.synchronize()
+        ctx.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.encode_device(surf, params, stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kernel_ms, launches = ctx.profile_end()
+        out["mpixels_per_s"] = round(size * size * steps / dt / 1e6, 1)
+        out["kernel_ms"] = round(kernel_ms / max(launches, 1), 4)
+        out["x_north_star_50"] = round(out["mpixels_per_s"] / 50.0, 2)
+    elif level == 2:
+        out["mpixels_per_s"] = round(normal_value, 1)
+        out["x_north_star_50"] = round(normal_value / 50.0, 2)
+    return out
 
 
 PCIE_GBPS = 63.0             # x16 Gen5, one direction (MI355X_MICROARCH.md host link)
@@ -776,6 +826,10 @@ def run_c2(args, rank, local_rank, world, backend):
             line["cpu_baseline"] = None
         if size == SIZE:
             line["vs_previous_round"] = _previous_round(line["metric"], world, value)
+            if line["vs_previous_round"] and args.quality == 2:
+                line["regression_gate"] = {"min_ratio": MIN_VS_PREVIOUS, "ok": line["vs_previous_round"]["ratio"] >= MIN_VS_PREVIOUS}
+        if world == 1 and size == SIZE and args.quality == 2 and not args.no_tolerance:
+            line["tolerance"] = tolerance_view(ctx, torch, surf, size, stream, value)
         if world == 1 and size == SIZE and not args.no_second_tile:
             line["second_tile"] = second_tile(ctx, torch, size, params, max(3, args.steps // 2), stream, not args.no_cpu_baseline)
             line["second_tile"]["vs_headline_tile"] = round(line["second_tile"]["kernel_ms"] / (avg_kernel_s * 1e3), 3)
@@ -787,6 +841,13 @@ def run_c2(args, rank, local_rank, world, backend):
         if strong is not None:
             line["strong_scaling"] = strong
         print(json.dumps(line), flush=True)
+        gate = line.get("regression_gate")
+        if gate and not gate["ok"]:
+            print("bench.py: headline %.1f is below %.2f x the previous round's record (%s)" %
+                  (value, MIN_VS_PREVIOUS, line["vs_previous_round"]), file=sys.stderr, flush=True)
+            if os.environ.get("BENCH_STRICT", "0") == "1":
+                ctx.close()
+                raise SystemExit(4)
     ctx.close()
 
 
@@ -803,6 +864,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="c2, N = 1: skip the host-buffer (PCIe-inclusive) leg")
     ap.add_argument("--no-strong", action="store_true", help="c2, N > 1: skip the row-split strong-scaling leg")
+    ap.add_argument("--no-tolerance", action="store_true", help="c2, N = 1: skip the `tolerance` leg (the lowest level within 0.1 dB, timed)")
     ap.add_argument("--no-second-tile", action="store_true",
                     help="c2, N = 1: skip the camera-like second tile (profile passes: the kernel statistics and PMC "
                          "averages of the run must be the headline tile's alone)")

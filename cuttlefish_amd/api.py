@@ -132,7 +132,7 @@ CONSUMED_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t)
 EXPORTS = ["cfhip_abi_version", "cfhip_device_count", "cfhip_create", "cfhip_destroy",
            "cfhip_query", "cfhip_encode", "cfhip_encode_multi", "cfhip_encode_multi_ex", "cfhip_encode_device",
            "cfhip_shard_rows",
-           "cfhip_last_kernel_ms", "cfhip_last_kernel_name", "cfhip_last_error",
+           "cfhip_last_kernel_ms", "cfhip_last_kernel_name", "cfhip_last_error", "cfhip_pinned_bytes",
            "cfhip_profile_begin", "cfhip_profile_end", "cfhip_generate_mips_device",
            "cfhip_generate_mips3d_device", "cfhip_resize_device", "cfhip_generate_mips_array_device"]
 
@@ -201,6 +201,8 @@ def load_library(path: Optional[str] = None):
     L.cfhip_shard_rows.restype = ctypes.c_int
     L.cfhip_last_kernel_ms.argtypes = [ctypes.c_void_p]
     L.cfhip_last_kernel_ms.restype = ctypes.c_float
+    L.cfhip_pinned_bytes.argtypes = [ctypes.c_void_p]
+    L.cfhip_pinned_bytes.restype = ctypes.c_size_t
     L.cfhip_last_kernel_name.argtypes = [ctypes.c_void_p]
     L.cfhip_last_kernel_name.restype = ctypes.c_char_p
     L.cfhip_profile_begin.argtypes = [ctypes.c_void_p]
@@ -433,6 +435,10 @@ class Context:
         ms, n = ctypes.c_float(), ctypes.c_uint32()
         self._check(self._lib.cfhip_profile_end(self._h, ctypes.byref(ms), ctypes.byref(n)))
         return float(ms.value), int(n.value)
+
+    def pinned_bytes(self) -> int:
+        """page-locked host memory the context holds for its host path (source strip slots + payload landing ring)"""
+        return int(self._lib.cfhip_pinned_bytes(self._h))
 
     def last_kernel_name(self) -> str:
         return self._lib.cfhip_last_kernel_name(self._h).decode()

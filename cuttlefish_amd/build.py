@@ -105,10 +105,63 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    check_no_vector_spills(LIB + ".tmp")          # a spilling build never becomes the library
     os.replace(LIB + ".tmp", LIB)
     with open(STAMP, "w") as f:
         f.write(_fingerprint() + "\n")
     return LIB
+
+
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+BLOCK_KERNELS = ("cfhip_bc7_encode_kernel", "cfhip_bc15_encode_kernel", "cfhip_bc6h_encode_kernel",
+                 "cfhip_etc_encode_kernel", "cfhip_astc_encode_kernel")
+
+
+def kernel_metadata(lib: str = LIB):
+    """{kernel name: {scratch, vgpr, agpr, vgpr_spill, sgpr_spill, lds}} read from the gfx950 code objects inside the
+    built library (llvm-objdump --offloading + llvm-readelf --notes); None when the ROCm LLVM tools are absent."""
+    import re
+    import tempfile
+    objdump, readelf = os.path.join(LLVM_BIN, "llvm-objdump"), os.path.join(LLVM_BIN, "llvm-readelf")
+    if not (os.path.exists(lib) and os.path.exists(objdump) and os.path.exists(readelf)):
+        return None
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        cp = shutil.copy(lib, d)                       # llvm-objdump --offloading extracts next to its input
+        subprocess.run([objdump, "--offloading", cp], cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for f in sorted(os.listdir(d)):
+            if "amdgcn" not in f:
+                continue
+            assert f.endswith("gfx950"), f             # one target, no fat binary
+            notes = subprocess.run([readelf, "--notes", os.path.join(d, f)], check=True, capture_output=True, text=True).stdout
+            # one YAML list item per kernel ("  - .agpr_count: ..." opens it: the keys are sorted, .name comes later)
+            for item in re.split(r"\n\s+- (?=\.agpr_count:|\.args:)", notes):
+                name = re.search(r"\.name:\s+(\S+)", item)
+                if not name or ".vgpr_count" not in item:
+                    continue
+
+                def g(k):
+                    m = re.search(r"\.%s:\s+(\d+)" % k, item)
+                    return int(m.group(1)) if m else None
+                out[name.group(1)] = {"scratch": g("private_segment_fixed_size"), "vgpr": g("vgpr_count"), "agpr": g("agpr_count"),
+                                      "vgpr_spill": g("vgpr_spill_count"), "sgpr_spill": g("sgpr_spill_count"),
+                                      "lds": g("group_segment_fixed_size")}
+    return out
+
+
+def check_no_vector_spills(lib: str = LIB):
+    """A correctness rule, not a performance one (round 5): these kernels read each other's lanes (DPP, ds_bpermute,
+    v_readlane), and a vector register spilled inside divergent control flow saves the active lanes only -- a spilling
+    ETC2 build returned wrong blocks.  On gfx950 the compiler can also park VGPRs in AGPRs without touching scratch, so
+    scratch == 0 alone does not prove it: every block kernel must show vgpr_spill_count 0, agpr_count 0 and no scratch.
+    Raises RuntimeError naming the offenders; silently passes where the LLVM tools are missing."""
+    meta = kernel_metadata(lib)
+    if meta is None:
+        return
+    bad = {k: v for k, v in meta.items() if any(s in k for s in BLOCK_KERNELS) and
+           (v["scratch"] != 0 or (v["vgpr_spill"] or 0) != 0 or (v["agpr"] or 0) != 0)}
+    if bad:
+        raise RuntimeError("block kernels with spilled vector registers (wrong blocks under divergence): %r" % (bad,))
 
 
 if __name__ == "__main__":

@@ -147,8 +147,9 @@ struct cfhip_ctx {
 	hipEvent_t up_done[kPinSlots] = {nullptr, nullptr, nullptr};    // ... and arrived: the strip's kernel may start
 	std::vector<hipEvent_t> strip_events;   // per strip: kernel finished / payload landed (grown on demand, reused)
 	hipStream_t up_stream = nullptr, down_stream = nullptr;
-	void* h_out = nullptr;            // pinned landing buffer of the payload (the caller's buffer is pageable)
+	void* h_out = nullptr;            // pinned landing RING of the payload: kOutSlots strips (the caller's buffer is pageable)
 	size_t h_out_cap = 0;
+	static constexpr int kOutSlots = 4;
 	cf_host_pool* pool = nullptr;
 	// d_src / d_out / d_batch are shared by every entry point, and calls on a caller's stream
 	// return without synchronising: the last asynchronous user records this event and a call on
@@ -866,10 +867,23 @@ int encode_host_pipelined_impl(cfhip_ctx* ctx, const cfhip_surface& s, const cfh
 		}
 		ctx->pin_cap = strip_bytes;
 	}
-	if (ctx->h_out_cap < out_bytes) {
+	// The payload lands in a RING of kOutSlots pinned strips (round 6; it used to be one pinned buffer as large as the
+	// largest payload the context had ever produced, never shrunk: 256 MB of locked memory after one 16k x 16k BC7
+	// surface).  A strip's slot is reused once this thread has copied it on to the caller's buffer.  When the pinned
+	// allocation fails the downloads go straight into the caller's pageable buffer -- slower (the runtime stages them),
+	// never an error.
+	constexpr int NO = cfhip_ctx::kOutSlots;
+	const size_t strip_out = (((size_t)strip_brows*bx*(size_t)bs) + 255u) & ~(size_t)255u;
+	if (ctx->h_out_cap < strip_out*(size_t)NO) {
 		if (ctx->h_out) { HIP_TRY(ctx, hipHostFree(ctx->h_out)); ctx->h_out = nullptr; ctx->h_out_cap = 0; }
-		HIP_TRY(ctx, hipHostMalloc(&ctx->h_out, out_bytes, hipHostMallocDefault));
-		ctx->h_out_cap = out_bytes;
+		// (CFHIP_NO_PINNED_OUT: test hook -- behave as if the allocation had failed)
+		if (!std::getenv("CFHIP_NO_PINNED_OUT") &&
+			hipHostMalloc(&ctx->h_out, strip_out*(size_t)NO, hipHostMallocDefault) == hipSuccess)
+			ctx->h_out_cap = strip_out*(size_t)NO;
+		else {
+			(void)hipGetLastError();
+			ctx->h_out = nullptr;
+		}
 	}
 	if (!ctx->pool) {
 		ctx->pool = new (std::nothrow) cf_host_pool;
@@ -882,7 +896,7 @@ int encode_host_pipelined_impl(cfhip_ctx* ctx, const cfhip_surface& s, const cfh
 	uint8_t* hout = static_cast<uint8_t*>(ctx->h_out);
 	uint8_t* user_out = static_cast<uint8_t*>(s.out);
 	// payload that has landed in h_out is copied to the caller's buffer by this thread while it waits for a slot
-	struct Landed { size_t off, bytes; hipEvent_t ev; };
+	struct Landed { size_t off, bytes, ring; hipEvent_t ev; };
 	std::vector<Landed> landing;
 	size_t landed = 0;
 	size_t ev_used = 0;
@@ -911,7 +925,8 @@ int encode_host_pipelined_impl(cfhip_ctx* ctx, const cfhip_surface& s, const cfh
 				HIP_TRY(ctx, hipEventSynchronize(l.ev));
 			else if (hipEventQuery(l.ev) != hipSuccess)
 				break;
-			std::memcpy(user_out + l.off, hout + l.off, l.bytes);
+			if (hout)
+				std::memcpy(user_out + l.off, hout + l.ring, l.bytes);
 			++landed;
 		}
 		return CFHIP_OK;
@@ -952,10 +967,18 @@ int encode_host_pipelined_impl(cfhip_ctx* ctx, const cfhip_surface& s, const cfh
 		if (rc != CFHIP_OK) return rc;
 		HIP_TRY(ctx, hipEventRecord(enc, stream));
 		HIP_TRY(ctx, hipStreamWaitEvent(ctx->down_stream, enc, 0));
-		HIP_TRY(ctx, hipMemcpyAsync(hout + out_off, static_cast<uint8_t*>(ctx->d_out) + out_off, out_n,
+		// the ring slot of strip k held strip k - NO: that one must have gone on to the caller's buffer
+		while (hout && landed + (size_t)NO <= (size_t)k) {
+			const Landed& l = landing[landed];
+			HIP_TRY(ctx, hipEventSynchronize(l.ev));
+			std::memcpy(user_out + l.off, hout + l.ring, l.bytes);
+			++landed;
+		}
+		const size_t ring = (size_t)(k % (uint32_t)NO)*strip_out;
+		HIP_TRY(ctx, hipMemcpyAsync(hout ? hout + ring : user_out + out_off, static_cast<uint8_t*>(ctx->d_out) + out_off, out_n,
 			hipMemcpyDeviceToHost, ctx->down_stream));
 		HIP_TRY(ctx, hipEventRecord(down, ctx->down_stream));
-		landing.push_back({out_off, out_n, down});
+		landing.push_back({out_off, out_n, ring, down});
 		rc = drain(false);
 		if (rc != CFHIP_OK)
 			return rc;
@@ -1126,6 +1149,15 @@ static int validate_surfaces(cfhip_ctx* ctx, const cfhip_surface* surfaces, size
 // `consumed(user, i)`: called once the library has finished READING surfaces[i].pixels (host path only): the
 // caller may release that source then, as Converter::convert frees every source image as soon as its surface
 // is converted (Converter.cpp:586) instead of holding the whole texture until the call returns.
+static int encode_body(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n,
+	const cfhip_params* params, bool device_mem, hipStream_t user_stream,
+	cfhip_consumed_fn consumed, void* user);
+
+// Every encode entry point of the C ABI comes through here (round-5 ADVICE: the guard used to cover the strip pipeline
+// only).  No exception crosses the extern "C" boundary -- std::bad_alloc / std::system_error from the vectors and
+// threads of the body become CFHIP_E_DEVICE with the text in cfhip_last_error -- and an error return from the host
+// path never leaves uploads or downloads queued on the staging buffers with staging_busy set: the context's streams are
+// drained and the staging marked free before the error goes to the caller.
 static int encode_impl(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n,
 	const cfhip_params* params, bool device_mem, hipStream_t user_stream,
 	cfhip_consumed_fn consumed = nullptr, void* user = nullptr)
@@ -1133,6 +1165,28 @@ static int encode_impl(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n,
 	if (!ctx)
 		return fail(nullptr, CFHIP_E_INVALID, "ctx is NULL");
 	std::lock_guard<std::mutex> guard(ctx->lock);
+	int rc;
+	try {
+		rc = encode_body(ctx, surfaces, n, params, device_mem, user_stream, consumed, user);
+	} catch (const std::exception& e) {
+		rc = fail(ctx, CFHIP_E_DEVICE, "encode: %s", e.what());
+	} catch (...) {
+		rc = fail(ctx, CFHIP_E_DEVICE, "encode: unknown exception");
+	}
+	if (rc != CFHIP_OK && !device_mem) {
+		(void)hipStreamSynchronize(ctx->stream);
+		if (ctx->up_stream) (void)hipStreamSynchronize(ctx->up_stream);
+		if (ctx->down_stream) (void)hipStreamSynchronize(ctx->down_stream);
+		(void)hipGetLastError();
+		ctx->staging_busy = false;
+	}
+	return rc;
+}
+
+static int encode_body(cfhip_ctx* ctx, const cfhip_surface* surfaces, size_t n,
+	const cfhip_params* params, bool device_mem, hipStream_t user_stream,
+	cfhip_consumed_fn consumed, void* user)
+{
 	ctx->error.clear();
 	int rc = check_params(ctx, params);
 	if (rc != CFHIP_OK)
@@ -1282,11 +1336,28 @@ int cfhip_encode_multi(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface* s
 	return cfhip_encode_multi_ex(ctxs, n_ctx, surfaces, n_surfaces, params, nullptr, nullptr);
 }
 
+static int encode_multi_body(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface* surfaces,
+	size_t n_surfaces, const cfhip_params* params, cfhip_consumed_fn consumed, void* user);
+
 int cfhip_encode_multi_ex(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface* surfaces,
 	size_t n_surfaces, const cfhip_params* params, cfhip_consumed_fn consumed, void* user)
 {
 	if (!ctxs || n_ctx <= 0 || !ctxs[0])
 		return CFHIP_E_INVALID;
+	// (the planning below builds vectors: an allocation failure there is an error code, not an exception across the C
+	// ABI; the per-context encodes are guarded by encode_impl, and a thread that cannot be started runs its share here)
+	try {
+		return encode_multi_body(ctxs, n_ctx, surfaces, n_surfaces, params, consumed, user);
+	} catch (const std::exception& e) {
+		return fail(ctxs[0], CFHIP_E_DEVICE, "encode_multi: %s", e.what());
+	} catch (...) {
+		return fail(ctxs[0], CFHIP_E_DEVICE, "encode_multi: unknown exception");
+	}
+}
+
+static int encode_multi_body(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface* surfaces,
+	size_t n_surfaces, const cfhip_params* params, cfhip_consumed_fn consumed, void* user)
+{
 	if (n_ctx == 1 || n_surfaces == 0)
 		return encode_impl(ctxs[0], surfaces, n_surfaces, params, false, nullptr, consumed, user);
 	if (!surfaces || !params)
@@ -1403,15 +1474,24 @@ int cfhip_encode_multi_ex(cfhip_ctx* const* ctxs, int n_ctx, const cfhip_surface
 	};
 	std::vector<int> rc((size_t)n_ctx, CFHIP_OK);
 	std::vector<std::thread> workers;
+	std::vector<char> started((size_t)n_ctx, 0);
+	workers.reserve((size_t)n_ctx);
 	for (int c = 1; c < n_ctx; ++c)
-		if (!share[(size_t)c].empty())
-			workers.emplace_back([&, c]() {
-				rc[(size_t)c] = encode_impl(ctxs[c], share[(size_t)c].data(), share[(size_t)c].size(), params, false, nullptr,
-					consumed ? unit_done : nullptr, &relay[(size_t)c]);
-			});
-	if (!share[0].empty())
-		rc[0] = encode_impl(ctxs[0], share[0].data(), share[0].size(), params, false, nullptr,
-			consumed ? unit_done : nullptr, &relay[0]);
+		if (!share[(size_t)c].empty()) {
+			try {
+				workers.emplace_back([&, c]() {
+					rc[(size_t)c] = encode_impl(ctxs[c], share[(size_t)c].data(), share[(size_t)c].size(), params, false, nullptr,
+						consumed ? unit_done : nullptr, &relay[(size_t)c]);
+				});
+				started[(size_t)c] = 1;
+			} catch (...) {
+				// no thread to be had (pids limit): this context's share runs on the calling thread, below
+			}
+		}
+	for (int c = 0; c < n_ctx; ++c)
+		if (!share[(size_t)c].empty() && !started[(size_t)c])
+			rc[(size_t)c] = encode_impl(ctxs[c], share[(size_t)c].data(), share[(size_t)c].size(), params, false, nullptr,
+				consumed ? unit_done : nullptr, &relay[(size_t)c]);
 	for (std::thread& t : workers)
 		t.join();
 	for (int c = 0; c < n_ctx; ++c)
@@ -1837,6 +1917,16 @@ int cfhip_profile_end(cfhip_ctx* ctx, float* total_ms, uint32_t* launches)
 	if (launches) *launches = (uint32_t)(ctx->events_used/2);
 	ctx->events_used = 0;
 	return ms < 0.0f ? CFHIP_E_DEVICE : CFHIP_OK;
+}
+
+size_t cfhip_pinned_bytes(const cfhip_ctx* ctx)
+{
+	if (!ctx)
+		return 0;
+	size_t n = ctx->h_out ? ctx->h_out_cap : 0;
+	for (int i = 0; i < cfhip_ctx::kPinSlots; ++i)
+		n += ctx->h_pin[i] ? ctx->pin_cap : 0;
+	return n;
 }
 
 const char* cfhip_last_kernel_name(const cfhip_ctx* ctx)

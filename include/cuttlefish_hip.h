@@ -316,6 +316,10 @@ float cfhip_last_kernel_ms(cfhip_ctx* ctx);
 int cfhip_profile_begin(cfhip_ctx* ctx);
 int cfhip_profile_end(cfhip_ctx* ctx, float* total_ms, uint32_t* launches);
 
+/* Page-locked host memory this context holds for its host path right now (bytes): the three source strip slots and
+ * the landing ring of the payload (four strips) -- independent of the size of the surfaces it has converted. */
+size_t cfhip_pinned_bytes(const cfhip_ctx* ctx);
+
 /* Name of the kernel that dominated the last call (for rocprof cross-reference). */
 const char* cfhip_last_kernel_name(const cfhip_ctx* ctx);
 

@@ -112,3 +112,22 @@ def test_strict_mode_reports_a_failed_strong_leg_in_the_exit_status(hip_lib):
     assert line["value"] > 0
     if "error" in line["strong_scaling"]:
         assert r.returncode != 0
+
+
+@pytest.mark.timeout(1200)
+def test_headline_line_carries_the_regression_gate_and_the_tolerance_level(hip_lib):
+    """Round-5 ADVICE: nothing gated a drop of the headline against the previous round's record -- the line now says
+    whether it holds 0.90 x that record (`regression_gate`), and this test fails when it does not.  `tolerance` names
+    the lowest level whose gap to the bound is within north_star's 0.1 dB on both photograph groups and its measured
+    throughput on the same tile (round-5 VERDICT item 3)."""
+    line = _run(["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-end-to-end", "--no-second-tile"])
+    prev = line["vs_previous_round"]
+    if prev is not None:
+        assert int(prev["record"][7:9]) < 6, prev          # never this round's own record
+        assert line["regression_gate"]["ok"], (line["value"], prev)
+    tol = line["tolerance"]
+    assert tol["target_db"] == 0.1 and tol["gap_db_normal_high_highest"] is not None
+    assert tol["lowest_level_within_target"] in ("Normal", "High", "Highest")
+    assert tol["mpixels_per_s"] >= 50.0                   # north_star's throughput at the compliant level
+    k = ["Normal", "High", "Highest"].index(tol["lowest_level_within_target"])
+    assert all(g[k] <= 0.1 for g in tol["gap_db_normal_high_highest"].values())

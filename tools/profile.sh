@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_$tag
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH=${PROFILE_CMD:-"python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end --no-second-tile $@"}   # PROFILE_CMD: another driver (run from /tmp)
+BENCH=${PROFILE_CMD:-"python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end --no-second-tile --no-tolerance $@"}   # PROFILE_CMD: another driver (run from /tmp)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o trace -- $BENCH > $OUT/stats.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM --kernel-trace --output-format csv -d $OUT/pmc_sq -o pmc -- $BENCH > $OUT/pmc_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1
