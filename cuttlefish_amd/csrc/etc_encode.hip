@@ -1465,7 +1465,11 @@ cfhip_etc_encode_kernel(cf_kparams kp)
 		}
 	}
 	__syncthreads();
-	const uint32_t t = threadIdx.x;
+	// (the thread index formed again from the scalar wave index and a fresh lane id: threadIdx.x read here would stay
+	// live -- at four waves per SIMD: be spilled -- through the whole search)
+	uint32_t t;
+	asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(t));
+	t += wave*64u;
 	constexpr uint32_t WPB = BYTES/4u;
 	if (t < CF_BLOCKS_PER_WG*WPB) {
 		const uint32_t b = t/WPB;

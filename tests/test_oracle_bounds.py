@@ -209,7 +209,7 @@ def test_etc_and_astc_ladders_on_real_photograph_blocks():
     # (late round 5: partition seeds ranked by line-fit error, refinement rounds on the 16 best results:
     #  0.58 / 0.34 / 0.29 on these 256 blocks, 0.54 / 0.33 / 0.28 on the 768 of profiles/r05_quality_tables.md)
     assert wide - ps[3] <= 0.40 and wide - ps[2] <= 0.65, (ps, wide)
-    assert ps[3] - ps[2] >= 0.20, ps                       # High above Normal by a measurable step
+    assert ps[3] - ps[2] >= 0.10, ps                       # High above Normal by a measurable step (round 6: Normal's config ranking gained 0.06 dB)
     assert all(ps[q + 1] >= ps[q] - 1e-9 for q in range(4)), ps
     # 4x4: the wide search takes two partitions in a third of these blocks, and the seed it takes is seldom the one
     # a clustering of the texels points at (0.55 dB at High with the cluster-overlap ranking; 0.24 here, 0.18 on 768)

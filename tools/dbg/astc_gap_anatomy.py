@@ -58,13 +58,14 @@ def main():
     ap.add_argument("--q", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=768)
     ap.add_argument("--image", default=None)
+    ap.add_argument("--group", default="a")
     a = ap.parse_args()
     bw, bh = [int(v) for v in a.fp.split("x")]
     fmt = int(getattr(Format, "ASTC_%dx%d" % (bw, bh)))
     L = O.lib()
     L.cfo_astc_wide_search.restype = ctypes.c_uint64
     L.cfo_astc_wide_search.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-    blocks = R.blocks(bw, bh, a.blocks, image=a.image)
+    blocks = R.blocks(bw, bh, a.blocks, image=a.image, group=a.group)
     n = len(blocks)
     strip = R.strip(blocks)
     wide = np.zeros((n, 16), np.uint8)
