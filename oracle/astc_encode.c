@@ -475,8 +475,9 @@ static int rank_configs(const astc_blk* b, int j, const astc_pc* pc, int K, int*
 		 * 5x5 +0.03 / +0.02 -- and no worse at High (+0.01 / +0.03), most on smooth pictures, whose best configs are small grids
 		 * with many weight levels (held-out "color": 2.09 -> 1.58 dB under the wide search at 6x6 High, retina 0.85 -> 0.66);
 		 * 4x4 / 5x4 are indifferent (+-0.005) and keep 10; 8x5 .. 10x5 lose 0.02 .. 0.14 dB with 5 and keep 10; the footprints
-		 * of 60 texels and more lose with anything below their 40.  (The synthetic fixture images pay 0.01 .. 0.05 dB.) */
-		const uint32_t ka = b->hdr ? ((b->n >= (b->has_alpha ? 40 : 25) && b->n <= 64) ? 10u : 40u) : (b->n >= 60 ? 640u : ((b->n >= 25 && b->n <= 36) ? 80u : 160u));
+		 * of 60 texels and more lose with anything below their 40.  (The synthetic fixture images pay 0.01 .. 0.05 dB.)  Opaque
+		 * blocks only: on the alpha-carrying 6x6 blocks (rgba12 of the fixture) 5 loses 0.17 / 0.12 / 0.11 dB. */
+		const uint32_t ka = b->hdr ? ((b->n >= (b->has_alpha ? 40 : 25) && b->n <= 64) ? 10u : 40u) : (b->n >= 60 ? 640u : ((b->n >= 25 && b->n <= 36 && !b->has_alpha) ? 80u : 160u));
 		/* LDR footprints of 60 texels and more: decimation x 4 once more AND the colour noise x 4 (six kinds of
 		 * content, whole images, Normal: 8x8 +0.24 photo / +0.44 smooth / two-colour edges +6 dB, 10x6 +0.3 / +0.3 /
 		 * +5.5, 10x10 and 12x12 +0.15 .. 0.5; the footprints below lose on gradients with it) */
@@ -788,10 +789,24 @@ static int hdr_scale_holds(int m, const int E1[3], int S12)
 	return rs_u(S12, sh) <= (1 << sb) - 1 && rs_u(rq - E1[ch[1]], sh) <= (1 << gb) - 1 && rs_u(rq - E1[ch[2]], sh) <= (1 << gb) - 1;
 }
 
+/* test-only (cfo_astc_wide_search_hdr, the bound of the HDR ladder): opt >= 0 forces ONE way of storing the endpoints
+ * (0: mode 11 / 14 / 15, 1: mode 7, 2: the luminance modes) instead of the cheaper one by estimate, and every
+ * partition prices EVERY form of it -- the direct form and all eight base + difference sub-modes of mode 11, all six
+ * sub-modes of mode 7 -- not the two finest that hold the pair */
+static __thread struct { int active, opt; } tl_hwide = {0, -1};
+#define HDR_MAX_FORMS 9
+
 /* the forms a partition tries, as a list of k (mode 11: 0 = direct, 1 + m) or m (mode 7); returns the count */
-static int hdr_form_list(int opt, const int E0[3], const int E1[3], int S12, int list[3])
+static int hdr_form_list(int opt, const int E0[3], const int E1[3], int S12, int list[HDR_MAX_FORMS])
 {
 	int nl = 0, held = 0;
+	if (tl_hwide.active) {
+		if (!opt)
+			for (int k = 0; k <= 8; ++k) list[nl++] = k;
+		else
+			for (int m = 0; m <= 5; ++m) list[nl++] = m;
+		return nl;
+	}
 	if (!opt) {
 		list[nl++] = 0;
 		for (int m = 7; m >= 0 && held < 2; --m)
@@ -932,7 +947,7 @@ static void hdr_phase_b(const astc_blk* b, const astc_pc* pc, const astc_cfg* cf
 	int best_cem2 = 2;
 	for (int opt = 0; opt < nopt; ++opt) {
 		const int nv = opt == 2 ? 2 : (opt ? 4 : (b->has_alpha ? 8 : 6));
-		if (nv*P > 18)
+		if (nv*P > 18 || (tl_hwide.active && tl_hwide.opt >= 0 && opt != tl_hwide.opt))
 			continue;
 		const int lv = T->c_level[nv*P/2][cfg->cbits];
 		if (lv < 0 || cfg->cbits < (13*nv*P + 4)/5)
@@ -963,7 +978,7 @@ static void hdr_phase_b(const astc_blk* b, const astc_pc* pc, const astc_cfg* cf
 			double best = 1.0e300;
 			int got = 0;
 			if (opt == 0) {
-				int list[3];
+				int list[HDR_MAX_FORMS];
 				const int nl = hdr_form_list(0, E0, E1, 0, list);
 				for (int t = 0; t < nl; ++t) {
 					const int k = list[t];
@@ -1037,7 +1052,7 @@ static void hdr_phase_b(const astc_blk* b, const astc_pc* pc, const astc_cfg* cf
 					E1c[c] = clampi((int)floor(x*(1.0/16.0) + 0.5), 0, 4095);
 				}
 				const int S12 = clampi((int)floor(s16*(1.0/16.0) + 0.5), 0, 4095);
-				int list[3];
+				int list[HDR_MAX_FORMS];
 				const int nl = hdr_form_list(1, E1c, E1c, S12, list);
 				for (int t = 0; t < nl; ++t) {
 					const int m = list[t];
@@ -2515,6 +2530,137 @@ static uint64_t wide_search_fmt(const astc_fmt* f, const uint8_t* rgba, int bw, 
 	const uint64_t e = best.err;
 	free(b);
 	return e;
+}
+
+/* test-only: the wide search of the HDR profiles (round 6; the bound the HDR ladder is measured against --
+ * tools/quality_real.py / tests/test_oracle_astc_hdr.py).  lns / flags as cfo_encode_astc_block_hdr.  The proposing
+ * stages run on the block's window codes like the encoder's; what is widened is everything it decides: one
+ * partition, a second plane on every component, EVERY canonical seed of the 2 / 3 / 4-partition tables (screened on
+ * the first ASTC_WIDE_STAGE1 configs, the ASTC_WIDE_KEEP best walked through all), EVERY config of the class (census
+ * tables and the encoder's own lists, the better run kept), every way of storing the endpoints FORCED and measured
+ * exactly on the 16-bit LNS values (mode 11 / 14 / 15, mode 7, the luminance modes), every partition pricing every
+ * sub-mode of it (tl_hwide).  No weights <-> endpoints iteration (the HDR ladder has none either).  Returns the exact
+ * error of the block it writes, in the encoder's own units. */
+static uint64_t wide_search_hdr_fmt(const astc_fmt* f, const int px[][4], const int lns[][4], int bw, int bh, int flags, uint8_t out[16])
+{
+	const int n = bw*bh;
+	astc_blk* b = (astc_blk*)calloc(1, sizeof(astc_blk));
+	b->f = f; b->n = n; b->flags = flags; b->grey = 1; b->hdr = 1; b->have_lns = 1; b->lns_grey = 1;
+	b->hdr_alpha = (flags & ASTC_FLAG_HDR_ALPHA) != 0;
+	const int opaque = b->hdr_alpha ? 120 : 255;
+	int solid = 1;
+	for (int i = 0; i < n; ++i) {
+		memcpy(b->px[i], px[i], sizeof(b->px[i]));
+		memcpy(b->lns[i], lns[i], sizeof(b->lns[i]));
+		if (lns[i][0] != lns[i][1] || lns[i][0] != lns[i][2]) b->lns_grey = 0;
+		if (memcmp(px[i], px[0], 4*sizeof(int)) != 0) solid = 0;
+		if (px[i][3] != opaque) b->has_alpha = 1;
+		if (px[i][0] != px[i][1] || px[i][0] != px[i][2]) b->grey = 0;
+		b->wa[i] = ((flags & ASTC_FLAG_ALPHA_WEIGHT) && !b->hdr_alpha) ? px[i][3] : 255;
+	}
+	if (solid) {
+		void_extent_lns(lns[0], b->hdr_alpha, out);
+		free(b);
+		return 0;
+	}
+	b->nc = b->has_alpha ? 4 : 3;
+	static const int cw_uniform[4] = {1, 1, 1, 1}, cw_perceptual[4] = {11, 21, 4, 16};
+	memcpy(b->cw, (flags & ASTC_FLAG_PERCEPTUAL) ? cw_perceptual : cw_uniform, sizeof(b->cw));
+	tl_hwide.active = 1;
+	astc_lane cur;
+	wide_hit best;
+	memset(&best, 0, sizeof(best));
+	best.err = ~0ull;
+#define HWIDE_CAND(PC, K0, K1, BESTERR) do { \
+		const astc_pc* pc_ = (PC); \
+		const int slots_ = pc_->dual ? 2 : pc_->P; \
+		for (int s_ = 0; s_ < slots_; ++s_) phase_a(b, 0, pc_, s_); \
+		const int ncfg_ = f->ncfg[pc_->cls][b->has_alpha]; \
+		for (int k_ = (K0); k_ < (K1) && k_ < ncfg_; ++k_) \
+			for (int o_ = 0; o_ < 3; ++o_) { \
+				tl_hwide.opt = o_; \
+				phase_b(b, 0, pc_, &f->cfg[pc_->cls][b->has_alpha][k_], &cur); \
+				if (!cur.valid) continue; \
+				if (cur.err < (BESTERR)) (BESTERR) = cur.err; \
+				if (cur.err < best.err) { best.err = cur.err; best.pc = *pc_; best.k = k_; best.opt = o_; best.lane = cur; } \
+			} \
+	} while (0)
+	uint64_t dummy = ~0ull;
+	astc_pc pc1 = {1, 0, 0, 0, 0};
+	HWIDE_CAND(&pc1, 0, ASTC_MAX_CFG, dummy);
+	for (int ccs = 0; ccs < b->nc; ++ccs) {
+		astc_pc pd = {1, 1, ccs, 1, 0};
+		HWIDE_CAND(&pd, 0, ASTC_MAX_CFG, dummy);
+	}
+	for (int P = 2; P <= 4; ++P) {
+		const int np = f->npart[P - 2];
+		uint64_t* serr = (uint64_t*)malloc((size_t)np*sizeof(uint64_t));
+		for (int t = 0; t < np; ++t) {
+			astc_pc pp = {P, 0, 0, P, t};
+			serr[t] = ~0ull;
+			HWIDE_CAND(&pp, 0, ASTC_WIDE_STAGE1, serr[t]);
+		}
+		for (int r = 0; r < ASTC_WIDE_KEEP && r < np; ++r) {
+			int bt = -1;
+			for (int t = 0; t < np; ++t)
+				if (serr[t] != ~0ull && (bt < 0 || serr[t] < serr[bt]))
+					bt = t;
+			if (bt < 0)
+				break;
+			serr[bt] = ~0ull;
+			astc_pc pp = {P, 0, 0, P, bt};
+			HWIDE_CAND(&pp, ASTC_WIDE_STAGE1, ASTC_MAX_CFG, dummy);
+		}
+		free(serr);
+	}
+#undef HWIDE_CAND
+	tl_hwide.active = 0;
+	tl_hwide.opt = -1;
+	if (best.err == ~0ull) {
+		void_extent_lns(lns[0], b->hdr_alpha, out);
+		free(b);
+		return ~0ull;
+	}
+	pack_block(f, &best.pc, &f->cfg[best.pc.cls][b->has_alpha][best.k], &best.lane, out);
+	const uint64_t e = best.err;
+	free(b);
+	return e;
+}
+
+uint64_t cfo_astc_wide_search_hdr(const int lns[][4], int bw, int bh, int flags, uint8_t out[16])
+{
+	const astc_fmt* base = get_fmt(bw, bh);
+	if (!base)
+		return ~0ull;
+	/* the window codes of the block (cfo_encode_astc_block_hdr) */
+	int n = bw*bh, px[ASTC_MAX_TEXELS][4];
+	int hdr_alpha = (flags & ASTC_FLAG_HDR_ALPHA) != 0, nh = hdr_alpha ? 4 : 3;
+	int mn[4] = {65536, 65536, 65536, 65536}, mx[4] = {0, 0, 0, 0}, R = 0, opaque = 1;
+	for (int i = 0; i < n; ++i) {
+		for (int c = 0; c < nh; ++c) {
+			if (lns[i][c] < mn[c]) mn[c] = lns[i][c];
+			if (lns[i][c] > mx[c]) mx[c] = lns[i][c];
+		}
+		if (lns[i][3] != 0x7800) opaque = 0;
+	}
+	for (int c = 0; c < nh; ++c)
+		if (mx[c] - mn[c] > R) R = mx[c] - mn[c];
+	int s = 0;
+	while (((R + ((1 << s) >> 1)) >> s) > 255)
+		++s;
+	for (int i = 0; i < n; ++i) {
+		for (int c = 0; c < nh; ++c)
+			px[i][c] = (lns[i][c] - mn[c] + ((1 << s) >> 1)) >> s;
+		px[i][3] = !hdr_alpha ? lns[i][3] : (opaque ? 120 : px[i][3]);
+	}
+	uint8_t o2[16];
+	const uint64_t e1 = wide_search_hdr_fmt(census_fmt(base), (const int (*)[4])px, lns, bw, bh, flags | ASTC_FLAG_HDR, out);
+	const uint64_t e2 = wide_search_hdr_fmt(base, (const int (*)[4])px, lns, bw, bh, flags | ASTC_FLAG_HDR, o2);
+	if (e2 < e1) {
+		memcpy(out, o2, 16);
+		return e2;
+	}
+	return e1;
 }
 
 /* test-only: an LDR block with the ladder fields and the refinement budget set by the caller.

@@ -100,6 +100,9 @@ void cfo_bc6h_wide_search(const uint16_t rgba_half[64], uint8_t out[16], const c
 /* test-only: the wide search of the ASTC LDR profile (astc_encode.c): rgba = bw*bh texels row-major; returns the
  * exact error (x 255) of the block it writes */
 uint64_t cfo_astc_wide_search(const uint8_t* rgba, int bw, int bh, int flags, uint8_t out[16]);
+/* test-only: the wide search of the ASTC HDR profiles: lns = bw*bh texels as 16-bit LNS values (cfo_astc_lns16 of the
+ * halves; an LDR alpha 0..255), flags bit 3 = HDR alpha; returns the exact error on the LNS values */
+uint64_t cfo_astc_wide_search_hdr(const int lns[][4], int bw, int bh, int flags, uint8_t out[16]);
 /* test-only: the TRUE optimum of an ETC1 (etc2 = 0) or ETC2 RGB block: exhaustive over every mode (etc_codec.c) */
 uint32_t cfo_etc_true_optimum(const uint8_t rgba[64], int etc2, uint8_t out[8]);
 /* test-only: the TRUE optimum of one EAC block (kind 0 alpha8, 1 R11, 2 signed R11): every base x multiplier x table */

@@ -57,12 +57,15 @@ def test_16k_surface_lands_through_a_small_pinned_ring():
     a 16384 x 16384 RGBA8 surface (1 GB of texels, 256 MB of BC7) goes through cfhip_encode with < 32 MB of page-locked
     memory in the context, and the bytes are those of the tile it is made of."""
     tile = synth.photo(1024, 1024, seed=9)
-    big = np.ascontiguousarray(np.tile(tile, (16, 16, 1)))
+    # bottom-up storage, top-down view (an Image's scanlines, Image.cpp:340-343): the layout that takes the strip pipeline
+    # for RGBA8 too (a plain top-down RGBA8 surface is one pageable upload and never touches pinned memory)
+    big = np.ascontiguousarray(np.tile(tile[::-1], (16, 16, 1)))[::-1]
+    assert big.strides[0] < 0 and np.array_equal(big[:1024, :1024], tile)
     p = make_params(Format.BC7, Type.UNorm, 0)
     with Context(0) as c:
         small = c.encode([tile], p)[0].reshape(256, 256, 16)
         got = c.encode([big], p)[0]
-        assert c.pinned_bytes() <= 32 << 20, c.pinned_bytes()
+        assert 0 < c.pinned_bytes() <= 32 << 20, c.pinned_bytes()
         assert np.array_equal(got.reshape(4096, 4096, 16), np.tile(small, (16, 16, 1)))
         # a second, small pipelined surface on the same context: the ring is reused, nothing grows
         before = c.pinned_bytes()

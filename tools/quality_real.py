@@ -7,8 +7,9 @@ held-out pictures, sampled outside whatever crop a tool ever read -- make_real_b
 
 Every row: PSNR of Lowest .. Highest and of the bound, the gaps at Normal / High / Highest; per image the same, and
 the WORST image per family (a pooled figure hides a several-fold spread between pictures: round-5 review).
-Bounds: BC7 cfo_bc7_wide_search; ETC1 / ETC2 RGB cfo_etc_true_optimum; EAC (ETC2 RGBA8's alpha block, R11)
-cfo_eac_true_optimum; ASTC cfo_astc_wide_search.
+Bounds: BC7 cfo_bc7_wide_search; ETC1 / ETC2 RGB cfo_etc_true_optimum; EAC (ETC2 RGBA8's alpha block)
+cfo_eac_true_optimum; ASTC cfo_astc_wide_search; ASTC HDR profiles cfo_astc_wide_search_hdr on real structure under
+synthetic radiometry (hdr_blocks), measured on the 16-bit LNS values.
 """
 import argparse
 import ctypes
@@ -111,22 +112,6 @@ def etc2_rgba8_sse(blocks):
     return sse, 64
 
 
-def eac_r11_sse(blocks):
-    """EAC R11 (41) of the red channel read as UNORM8 -> the 11-bit value the decoder compares in (v * 2047 / 255
-    rounded, as the encoder's loader forms it is not assumed: both sides are measured on the DECODED 8-bit image)"""
-    n = len(blocks)
-    strip = R.strip(blocks)
-    sse = np.zeros((6, n))
-    for q in range(5):
-        dec = O.decode_eac(O.encode(strip, 41, quality=q, threads=THREADS), 41, 4 * n, 4)
-        d = (np.asarray(dec, np.float64)[..., 0] - strip[..., 0].astype(np.float64) / 255.0) if dec.dtype != np.uint8 else None
-        if d is None:
-            d = (dec[..., 0].astype(np.float64) - strip[..., 0]) / 255.0
-        sse[q] = (d * d).reshape(4, n, 4).sum(axis=(0, 2)) * 255.0 ** 2
-    sse[5] = np.nan
-    return sse, 16
-
-
 def astc_sse(blocks, bw, bh, alpha=False):
     L = _lib()
     fmt = int(getattr(Format, "ASTC_%dx%d" % (bw, bh)))
@@ -148,18 +133,78 @@ def astc_sse(blocks, bw, bh, alpha=False):
     return sse, bw * bh * nch
 
 
+_LNS = None
+
+
+def _lns_table():
+    global _LNS
+    if _LNS is None:
+        L = O.lib()
+        L.cfo_astc_lns16.argtypes = [ctypes.c_uint16]
+        L.cfo_astc_lns16.restype = ctypes.c_int
+        _LNS = np.array([L.cfo_astc_lns16(h) for h in range(65536)], np.int64)
+    return _LNS
+
+
+def hdr_blocks(blocks, seed=5):
+    """Real structure, synthetic radiometry (there is no HDR photograph in this image): the 8-bit texels of the
+    photograph blocks through an inverse display curve (v / 255) ^ 2.2 and an exposure of 2 ^ e, e drawn per block from
+    -6 .. +8 stops -> RGBA16F blocks, alpha 1.0.  What the HDR profiles see is then real edges, textures and gradients
+    at radiances from 1e-7 to 256."""
+    rng = np.random.default_rng(seed)
+    lin = (blocks[..., :3].astype(np.float64) / 255.0) ** 2.2
+    e = rng.uniform(-6.0, 8.0, len(blocks))[:, None, None, None]
+    out = np.ones(blocks.shape, np.float16)
+    out[..., :3] = (lin * np.exp2(e)).astype(np.float16)
+    return out
+
+
+def astc_hdr_sse(hblocks, bw, bh):
+    """ASTC HDR profile (Type::UFloat, Alpha::None -> HDR_RGB_LDR_A): squared error on the 16-bit LNS values of the RGB
+    halves (the domain the encoder minimises in); bound = cfo_astc_wide_search_hdr"""
+    L = _lib()
+    L.cfo_astc_wide_search_hdr.restype = ctypes.c_uint64
+    L.cfo_astc_wide_search_hdr.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    fmt = int(getattr(Format, "ASTC_%dx%d" % (bw, bh)))
+    n = len(hblocks)
+    tab = _lns_table()
+    lns = tab[hblocks.view(np.uint16)].astype(np.int32)            # (n, bh, bw, 4)
+    lns[..., 3] = 255                                              # Alpha::None: an LDR alpha forced to 1.0
+    lns = np.ascontiguousarray(lns.reshape(n, bh * bw, 4))
+    outs = np.zeros((n, 16), np.uint8)
+    _pmap(lambda i: L.cfo_astc_wide_search_hdr(lns[i].ctypes.data, bw, bh, 0, outs[i].ctypes.data), n)
+    strip = R.strip(hblocks)
+    ref = tab[strip[..., :3].view(np.uint16)]
+
+    def sse_of(payload):
+        dec, outside = O.decode_astc_hdr(payload, fmt, bw * n, bh)
+        assert outside == 0
+        d = tab[np.ascontiguousarray(dec[..., :3]).view(np.uint16)] - ref
+        return (d * d).reshape(bh, n, bw, 3).sum(axis=(0, 2, 3)).astype(np.float64)
+    sse = np.zeros((6, n))
+    for q in range(5):
+        sse[q] = sse_of(O.encode(strip, fmt, typ=4, quality=q, threads=THREADS, alpha=0))
+    sse[5] = sse_of(outs.reshape(-1))
+    return sse, bw * bh * 3
+
+
+def psnr_lns(s, nvals):
+    return 10.0 * np.log10(65535.0 ** 2 * nvals / max(float(s), 1e-9))
+
+
 def psnr(s, nvals):
     return 10.0 * np.log10(255.0 ** 2 * nvals / max(float(s), 1e-9))
 
 
-def rows_of(sse, vals, img, names):
-    """-> [(label, n, [psnr Q0..Q4, bound])]: pooled first, then per image"""
-    out = [("pooled", sse.shape[1], [psnr(sse[q].sum(), vals * sse.shape[1]) for q in range(6)])]
+def rows_of(sse, vals, img, names, lns=False):
+    """-> [(label, n, [psnr Q0..Q4, bound])]: pooled first, then per image (lns: PSNR on 16-bit LNS values, peak 65535)"""
+    ps = psnr_lns if lns else psnr
+    out = [("pooled", sse.shape[1], [ps(sse[q].sum(), vals * sse.shape[1]) for q in range(6)])]
     if img is not None:
         for k, name in enumerate(names):
             m = img == k
             if m.any():
-                out.append((name, int(m.sum()), [psnr(sse[q][m].sum(), vals * int(m.sum())) for q in range(6)]))
+                out.append((name, int(m.sum()), [ps(sse[q][m].sum(), vals * int(m.sum())) for q in range(6)]))
     return out
 
 
@@ -183,6 +228,11 @@ def family_rows(n4, n12):
     res.append(("ETC2 RGBA8", "a", rows_of(*etc2_rgba8_sse(ba), None, None)))
     for bw, bh in ((4, 4), (6, 6), (8, 8)):
         res.append(("ASTC %dx%d with alpha" % (bw, bh), "a", rows_of(*astc_sse(R.blocks_alpha(bw, bh, n12), bw, bh, True), None, None)))
+    # the HDR profiles: real structure under synthetic radiometry (hdr_blocks), PSNR on the LNS values
+    names = R.image_names("a")
+    for bw, bh in ((4, 4), (6, 6), (8, 8)):
+        b12 = R.blocks(bw, bh, n12)
+        res.append(("ASTC %dx%d HDR (LNS PSNR)" % (bw, bh), "a", rows_of(*astc_hdr_sse(hdr_blocks(b12), bw, bh), np.arange(len(b12)) % len(names), names, lns=True)))
     return res
 
 
