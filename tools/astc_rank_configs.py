@@ -84,6 +84,22 @@ def real_content(size):
     return out
 
 
+def real_alpha_content(size):
+    """alpha-carrying census content with a TEXTURED alpha (round 6): the colour of one census photograph's centre crop,
+    the luma of another's as alpha.  The synthetic content above only ever had smooth alpha (a ramp band, a slow sine), and
+    the dual-plane lists it produced for blocks with alpha are all 2 x 2 / 2 x 3 grids -- the alpha-carrying real blocks
+    of the quality fixture (another set of photographs) want 4 x 4 x 4 .. 5 levels there and sat 1 dB under the wide
+    search at every level."""
+    crops = real_content(size)
+    out = []
+    for i in range(len(crops)):
+        j = (i + 1) % len(crops)
+        im = crops[i].copy()
+        im[..., 3] = (crops[j][..., :3].astype(np.uint32) @ np.array([54, 183, 19], np.uint32) >> 8).astype(np.uint8)
+        out.append(np.ascontiguousarray(im))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=240)
@@ -103,6 +119,8 @@ def main():
                          "photo image) and a wave then waits for the lane with the 60-weight column: 6x6 Normal 2.49 ->\n"
                          "2.73 ms -- BASELINE config 3 is quoted on 6x6, its list stays")
     ap.add_argument("--real", action="store_true", help="add the census photographs (REAL_CENSUS) and synth.photo2 to the content")
+    ap.add_argument("--alpha-real", action="store_true", help="add real_alpha_content (photograph colour, another photograph's luma as alpha)")
+    ap.add_argument("--alpha-rows-only", action="store_true", help="write only the rows of the alpha-carrying classes; the opaque rows keep what the file holds")
     ap.add_argument("--only", default="", help="footprints to run the census for (others keep their rows), e.g. 6x6,4x4")
     args = ap.parse_args()
     L = O.lib()
@@ -111,6 +129,8 @@ def main():
     imgs = content(args.size)
     if args.real:
         imgs += real_content(args.size) + [synth.photo2(args.size, args.size, seed=s) for s in (301, 302)]
+    if args.alpha_real:
+        imgs += real_alpha_content(args.size)
     only = [FP.index(tuple(int(v) for v in x.split("x"))) for x in args.only.split(",") if x]
     table = np.zeros((14, 10, 64), np.uint16)
 
@@ -152,7 +172,7 @@ def main():
     if only:
         keep = ["%dx%d" % FP[fi] for fi in range(14) if fi not in only]
         args.static_for = ",".join(x for x in args.static_for.split(",") if x and FP.index(tuple(int(v) for v in x.split("x"))) in only)
-    if keep:
+    if keep or args.alpha_rows_only:
         import re
         rows = re.findall(r"\{([0-9, ]+)\},", open(os.path.join(ROOT, "oracle", "astc_cfg_rank.h")).read())
         assert len(rows) == 140
@@ -161,6 +181,10 @@ def main():
             fi = FP.index((bw, bh))
             for k in range(10):
                 table[fi, k] = [int(v) for v in rows[fi*10 + k].split(",")]
+        if args.alpha_rows_only:
+            for fi in range(14):
+                for k in range(0, 10, 2):
+                    table[fi, k] = [int(v) for v in rows[fi*10 + k].split(",")]
     lines = ["/* astc_cfg_rank.h -- GENERATED by tools/astc_rank_configs.py (do not edit): per footprint and",
              " * candidate class x alpha, the weight-grid configs (N | M << 4 | weight range << 8) ranked by how",
              " * often each was the best of ALL legal configs in a census of synthetic content; 0 ends a list",

@@ -25,9 +25,9 @@ FIELDS = "walk,radius,refine,nlists,e0,e1,e2,cube,lsq,flips,joint,rec,fst,gate".
 BASE = dict(walk=2, radius=2, refine=1, nlists=0, e0=0, e1=0, e2=0, cube=0, lsq=0, flips=0, joint=0, rec=0, fst=0, gate=0)
 
 
-def blocks_of(kind, count):
+def blocks_of(kind, count, group="a", image=None):
     if kind == "real":
-        return R.blocks4(count)
+        return R.blocks4(count, group=group, image=image)
     img = synth.photo(512, 512, seed=21)
     img[..., 3] = 255
     rng = np.random.default_rng(20260929)
@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=4096)
     ap.add_argument("--kind", default="real")
     ap.add_argument("--etc1", action="store_true")
+    ap.add_argument("--group", default="a", help="photograph group of tests/golden/real_blocks.npz (b = the held-out one)")
+    ap.add_argument("--image", default=None)
     ap.add_argument("--attr", action="store_true", help="attribute the excess error to (mode of the optimum, mode chosen)")
     ap.add_argument("cfg", nargs="*")
     a = ap.parse_args()
@@ -48,11 +50,11 @@ def main():
     L.cfo_etc_true_optimum.restype = ctypes.c_uint32
     L.cfo_etc_true_optimum.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     L.cfo_etc_lab_block.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
-    blocks = blocks_of(a.kind, a.blocks)
+    blocks = blocks_of(a.kind, a.blocks, a.group, a.image)
     n = len(blocks)
     etc2 = 0 if a.etc1 else 1
     fmt = 37 if a.etc1 else 38
-    cache = "/tmp/etc_opt_%s_%d_%d.npy" % (a.kind, n, etc2)
+    cache = "/tmp/etc_opt_%s%s%s_%d_%d.npy" % (a.kind, a.group, a.image or "", n, etc2)
     if os.path.exists(cache):
         opt = np.load(cache)
     else:
@@ -78,7 +80,7 @@ def main():
         return "diff"
     optblk = None
     if a.attr:
-        cb = "/tmp/etc_optblk_%s_%d_%d.npy" % (a.kind, n, etc2)
+        cb = "/tmp/etc_optblk_%s%s%s_%d_%d.npy" % (a.kind, a.group, a.image or "", n, etc2)
         if os.path.exists(cb):
             optblk = np.load(cb)
         else:
