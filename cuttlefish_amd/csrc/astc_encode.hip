@@ -1081,7 +1081,12 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	// HDR: the texels' 16-bit LNS values, two words per texel (r | g << 16, b | a << 16; an LDR alpha 0..255)
 	uint32_t* tile16 = reinterpret_cast<uint32_t*>(lds + off); off += HDR ? nblk*n*8u : 0u;
 	off = (off + 15u) & ~15u;
-	uint32_t* sh_infill = reinterpret_cast<uint32_t*>(lds + off); off += ngrids*n*8u; off = (off + 15u) & ~15u;
+	// (a grid's infill records are n | 1 records apart: in every walk the lanes read record i of THEIR grid at the same
+	// time, and with 36 records = 72 dwords between grids the 24 grids met in 8 bank pairs -- three-way conflicts on every
+	// record read, a quarter of the LDS-active cycles of the 6x6 High kernel; an odd record count spreads 32 grids over all
+	// 64 banks.  The divisor table's stride is made 2 mod 4 dwords by the table builder for the same reason.)
+	const uint32_t nst = n | 1u;
+	uint32_t* sh_infill = reinterpret_cast<uint32_t*>(lds + off); off += ngrids*nst*8u; off = (off + 15u) & ~15u;
 	uint32_t* sh_den = reinterpret_cast<uint32_t*>(lds + off); off += ngrids*den_stride*4u;
 	uint8_t* sh_grid = lds + off; off += (ngrids*4u + 15u) & ~15u;
 	uint8_t* sh_ctab = lds + off; off += (hdrf ? 6u : 2u)*17u*256u;
@@ -1093,8 +1098,10 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 	uint32_t lane = threadIdx.x & 63u;
 	uint8_t* wbase = lds + off + wave*wave_bytes;
 
-	for (uint32_t i = threadIdx.x; i < ngrids*n*2u; i += nthreads)
-		sh_infill[i] = reinterpret_cast<const uint32_t*>(blob + H->off_infill)[i];
+	for (uint32_t i = threadIdx.x; i < ngrids*n*2u; i += nthreads) {
+		const uint32_t g = i/(2u*n);
+		sh_infill[i + g*2u*(nst - n)] = reinterpret_cast<const uint32_t*>(blob + H->off_infill)[i];
+	}
 	for (uint32_t i = threadIdx.x; i < ngrids*den_stride; i += nthreads)
 		sh_den[i] = reinterpret_cast<const uint32_t*>(blob + H->off_den)[i];
 	for (uint32_t i = threadIdx.x; i < ngrids; i += nthreads)
@@ -1927,7 +1934,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				const bool gact = !(CF_ASTC_ABLATE & 4) && !solid && g < ngrids && hl < 32u + (pair ? 0u : 32u);
 				uint8_t* gcol = wbase + (pair ? lane : g)*4u;
 				uint32_t PW = 0;
-				const uint2* inf = sh.infill + g*n;
+				const uint2* inf = sh.infill + g*(astc_opq(n) | 1u);
 				const uint8_t* Trow = S.T;
 				if (gact) {
 					const uint32_t Rp = (uint32_t)sh.grid[g*4u + 1u]*(uint32_t)sh.grid[g*4u + 3u];
@@ -2084,7 +2091,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				const AstcCfgRec cfg = ASTC_CFGS[(cls*2u + alpha_i)*64u + (active ? oi : 0u)];
 				r_cfg = oi;
 				const uint32_t planes = dual ? 2u : 1u, wq = cfg.wq;
-				const uint2* inf = sh.infill + (uint32_t)cfg.grid*n;
+				const uint2* inf = sh.infill + (uint32_t)cfg.grid*(astc_opq(n) | 1u);
 				const uint32_t* den = sh.den + (uint32_t)cfg.grid*astc_opq(H->den_stride);
 				// words per plane of the lane's column (rows at the grid's even pitch); plane 1 follows plane 0
 				const uint32_t PW = ((uint32_t)cfg.M*(uint32_t)sh.grid[(uint32_t)cfg.grid*4u + 3u] + 1u) >> 1;
@@ -3171,6 +3178,28 @@ static size_t cf_astc_cu_lds()
 	return cached[dev];
 }
 
+// what a workgroup takes of the CU's LDS besides its dynamic bytes: the static payload rows (outb: 768 B in the 12-wave
+// builds, 512 B in the 8-wave ones) + 256 B.  Round 6: the 8-wave builds were priced at 1 024 B like the 12-wave ones,
+// and the 384 B of the padded table strides pushed 8x8 High from two 4-wave workgroups per CU to one 8-wave workgroup
+// (+5 % time); with 768 the two fit again, and hipOccupancyMaxActiveBlocksPerMultiprocessor agrees (CFHIP_ASTC_DEBUG).
+static size_t cf_astc_wg_slack(bool dense)
+{
+	return dense ? 1024u : 768u;
+}
+
+// waves resident on a CU for workgroups of nw waves and b dynamic bytes: more than 8 only with the 12-wave (168-register)
+// build, whose workgroups carry the larger static block
+static uint32_t cf_astc_resident(size_t cu_lds, size_t b, uint32_t nw, bool no12)
+{
+	const uint32_t w12 = (uint32_t)(cu_lds/(b + cf_astc_wg_slack(true)))*nw;
+	if (!no12 && w12 > 8u)
+		return w12 > 12u ? 12u : w12;
+	if (nw > 8u)
+		return 0u;               // (a workgroup of more than 8 waves exists in the 12-wave build only)
+	const uint32_t w8 = (uint32_t)(cu_lds/(b + cf_astc_wg_slack(false)))*nw;
+	return w8 > 8u ? 8u : w8;
+}
+
 static size_t cf_astc_wg_lds_max()
 {
 	return cf_astc_cu_lds() - 1024u;     // the kernel's static LDS (payload rows) + allocation granule
@@ -3184,7 +3213,7 @@ static size_t astc_lds_bytes(const cfastc::AstcBlobHeader* h, uint32_t quality, 
 	off = (off + 15u) & ~15u;
 	off += hdr ? nwaves*4u*n*8u : 0u;        // the 16-bit LNS texels
 	off = (off + 15u) & ~15u;
-	off += ngrids*n*8u; off = (off + 15u) & ~15u;
+	off += ngrids*(n | 1u)*8u; off = (off + 15u) & ~15u;      // (records of a grid n | 1 apart: the kernel's carve-up)
 	off += ngrids*h->den_stride*4u;
 	off += (ngrids*4u + 15u) & ~15u;
 	off += (hdr ? 6u : 2u)*17u*256u + 2016u;
@@ -3222,9 +3251,7 @@ extern "C" void cfhip_astc_plan(const cfastc::AstcBlobHeader* h, uint32_t qualit
 			const size_t b = astc_lds_bytes(h, quality, nw, c != 0u, hdr != 0u);
 			if (b > wg_max)
 				continue;
-			uint32_t wres = (uint32_t)(cu_lds/(b + 1024u))*nw;      // 1024: the static outb + allocation granule
-			wres = wres > 12u ? 12u : wres;
-			if (no12 && wres > 8u) wres = 8u;
+			const uint32_t wres = cf_astc_resident(cu_lds, b, nw, no12);
 			// a workgroup covers nw*4 blocks of ONE block row: the share of a row's last workgroup that
 			// hangs over the edge is idle (bx = blocks per row of the surface, 0 = unknown)
 			const uint32_t per = nw*4u;
@@ -3281,7 +3308,7 @@ extern "C" hipError_t cfhip_launch_astc(const cf_kparams* kp, int pixel_type, ui
 	// the 168-register build only where three waves per SIMD actually become resident
 	static const bool no_dense = getenv("CFHIP_ASTC_NO_DENSE") != nullptr, debug = getenv("CFHIP_ASTC_DEBUG") != nullptr;
 	const bool hdr = ((kp->flags >> 19) & 3u) != 0u;
-	const bool dense = (cf_astc_cu_lds()/(lds_bytes + 1024u))*nwaves > 8u && !no_dense && !hdr;
+	const bool dense = (cf_astc_cu_lds()/(lds_bytes + cf_astc_wg_slack(true)))*nwaves > 8u && !no_dense && !hdr;
 	void (*fn)(cf_kparams) = nullptr;
 	if (dense)
 		fn = pixel_type == 0 ? &cfhip_astc_encode_kernel<0, 12, false> : &cfhip_astc_encode_kernel<1, 12, false>;

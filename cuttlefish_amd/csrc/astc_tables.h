@@ -439,6 +439,10 @@ inline std::vector<uint8_t> build_blob(int bw, int bh)
 	uint32_t den_stride = 2;
 	for (const GridHost& g : grids)
 		den_stride = std::max<uint32_t>(den_stride, (uint32_t)(g.M*(g.N + (g.N & 1)) + 1) & ~1u);
+	// (2 mod 4 dwords between grids: the lanes of a walk read the divisor pair of the same row of THEIR grid with one
+	// 8-byte load, and a stride that is a multiple of 4 dwords folds 32 grids onto 16 bank pairs)
+	if ((den_stride & 3u) == 0u)
+		den_stride += 2u;
 	h.den_stride = den_stride;
 	h.off_den = (uint32_t)off; off = align16(off + grids.size()*(size_t)den_stride*4);
 	h.off_cfg = (uint32_t)off; off = align16(off + cfgs.size()*sizeof(AstcCfgRec));

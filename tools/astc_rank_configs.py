@@ -134,6 +134,18 @@ def main():
     only = [FP.index(tuple(int(v) for v in x.split("x"))) for x in args.only.split(",") if x]
     table = np.zeros((14, 10, 64), np.uint16)
 
+    def col_rows(v, dual):          # rows of a lane's LDS column a config needs (csrc/astc_tables.h: col_rows)
+        N, M = v & 15, (v >> 4) & 15
+        return (2 if dual else 1)*(((M*(N + (N & 1))) + 1) & ~1) + 2
+    # --alpha-rows-only: the new alpha rows may not ask for a taller lane column than the footprint's lists did -- the
+    # column sizes the workgroup for EVERY block of the footprint (12x12: 66 -> 74 rows cost its launches a wave)
+    old_max = [0]*14
+    if args.alpha_rows_only:
+        import re
+        rows0 = re.findall(r"\{([0-9, ]+)\},", open(os.path.join(ROOT, "oracle", "astc_cfg_rank.h")).read())
+        for fi in range(14):
+            old_max[fi] = max([col_rows(int(v), k//2 == 1) for k in range(10) for v in rows0[fi*10 + k].split(",") if int(v)] or [0])
+
     def census(fi):
         bw, bh = FP[fi]
         counts = np.zeros(10*4096, np.uint32)
@@ -157,7 +169,13 @@ def main():
             grids = set(int(g) for g in np.argsort(-gscore, kind="stable")[:24] if gscore[g] > 0)
             for k in range(10):
                 order = np.argsort(-counts[k].astype(np.int64), kind="stable")
-                order = [int(c) for c in order if counts[k][c] > 0 and (args.grids == "class" or (c & 255) in grids)][:64]
+                order = [int(c) for c in order if counts[k][c] > 0 and (args.grids == "class" or (c & 255) in grids) and
+                         not (old_max[fi] and (k & 1) and col_rows(int(c), k//2 == 1) > old_max[fi])][:64]
+                if args.alpha_rows_only and (k & 1) and len(order) < 64:
+                    # a short census row is completed from the row the file held (the table builders would fill it from
+                    # the noise-model order, which may bring grids taller than the footprint's column)
+                    prev = [int(v) for v in rows0[fi*10 + k].split(",") if int(v)]
+                    order = (order + [v for v in prev if v not in order])[:64]
                 table[fi, k, :len(order)] = order
                 tot = int(counts[k].sum())
                 cov = int(counts[k][order].sum()) if order else 0
@@ -182,6 +200,9 @@ def main():
             for k in range(10):
                 table[fi, k] = [int(v) for v in rows[fi*10 + k].split(",")]
         if args.alpha_rows_only:
+            def col_rows(v, dual):          # rows of a lane's LDS column this config needs (csrc/astc_tables.h: col_rows)
+                N, M = v & 15, (v >> 4) & 15
+                return (2 if dual else 1)*(((M*(N + (N & 1))) + 1) & ~1) + 2
             for fi in range(14):
                 for k in range(0, 10, 2):
                     table[fi, k] = [int(v) for v in rows[fi*10 + k].split(",")]
