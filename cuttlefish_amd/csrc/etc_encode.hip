@@ -454,13 +454,36 @@ __device__ __forceinline__ bool th_search(const uint32_t* tp, const RgbOpts& o, 
 	const int n0 = n - n1;
 	if (!n0 || !n1)
 		return false;
+	int mu0[3], mu1[3];
+#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		mu0[c] = (int)cf_div_small((uint32_t)(2*s0[c] + n0), (uint32_t)(2*n0));
+		mu1[c] = (int)cf_div_small((uint32_t)(2*s1[c] + n1), (uint32_t)(2*n1));
+	}
+	// two Lloyd steps on the split (oracle: th_search, round 6): one texel per lane, the cluster sums are row sums --
+	// uniform, so the step that would empty a cluster ends them in every lane alike
+#pragma unroll 1
+	for (int it = 0; it < 2; ++it) {
+		const int e00 = p0 - mu0[0], e01 = p1 - mu0[1], e02 = p2 - mu0[2], e10 = p0 - mu1[0], e11 = p1 - mu1[1], e12 = p2 - mu1[2];
+		const int dd0 = o.wt[0]*e00*e00 + o.wt[1]*e01*e01 + o.wt[2]*e02*e02, dd1 = o.wt[0]*e10*e10 + o.wt[1]*e11*e11 + o.wt[2]*e12*e12;
+		const bool to1 = act && dd1 < dd0;
+		const uint32_t g01 = cf_row_sum_uniform(to1 ? (uint32_t)p0 | ((uint32_t)p1 << 16) : 0u);
+		const uint32_t g2n = cf_row_sum_uniform(to1 ? (uint32_t)p2 | (1u << 16) : 0u);
+		const int c1n = (int)(g2n >> 16), c0n = n - c1n;
+		if (!c0n || !c1n)
+			break;
+		const int t1[3] = {(int)(g01 & 0xFFFFu), (int)(g01 >> 16), (int)(g2n & 0xFFFFu)};
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			mu0[c] = (int)cf_div_small((uint32_t)(2*(sum[c] - t1[c]) + c0n), (uint32_t)(2*c0n));
+			mu1[c] = (int)cf_div_small((uint32_t)(2*t1[c] + c1n), (uint32_t)(2*c1n));
+		}
+	}
 	uint32_t m0 = 0, m1 = 0;
 #pragma unroll
 	for (int c = 0; c < 3; ++c) {
-		const int a = (int)cf_div_small((uint32_t)(2*s0[c] + n0), (uint32_t)(2*n0)),
-			b = (int)cf_div_small((uint32_t)(2*s1[c] + n1), (uint32_t)(2*n1));
-		m0 |= (uint32_t)((a*15 + 127)/255) << (4*c);
-		m1 |= (uint32_t)((b*15 + 127)/255) << (4*c);
+		m0 |= (uint32_t)((mu0[c]*15 + 127)/255) << (4*c);
+		m1 |= (uint32_t)((mu1[c]*15 + 127)/255) << (4*c);
 	}
 	// candidates: id = 5 + cand, cand = variant*8 + distance; two lanes per candidate, eight
 	// texels each (lanes 2c and 2c + 1, shares added through DPP)

@@ -300,10 +300,11 @@ def test_ladders_on_both_photograph_groups_pooled_and_worst_image():
     tools/quality_real.py measures every family per image.  Here: a sample of both groups, pooled AND worst image, and
     the alpha-carrying rows (ETC2 RGBA8 against the true optimum of its two halves, ASTC 6x6 with alpha).  The whole
     table is profiles/r06_quality_real.md.  What the numbers say plainly: BC7 generalises (High 0.06 .. 0.09 dB pooled on
-    either group); ETC2 RGB does not hold its group-a figure on group b (0.37 against 0.22 dB at Normal on 1 024 blocks,
-    hubble_deep_field 0.50); ASTC 6x6 High is 0.33 / 0.39 dB pooled and 0.6 .. 0.9 (a: motorcycle; 32 .. 96 blocks of it) / 1.6 dB (b: "color", a near-flat
+    either group); ETC2 RGB held its group-a figure less well on group b (0.37 against 0.22 dB at Normal on 1 024 blocks,
+    hubble_deep_field 0.50) until the T / H seed got two Lloyd steps (now 0.30 against 0.20; this sample of 256: 0.36 / 0.11); ASTC 6x6 High is 0.33 / 0.39 dB pooled and 0.6 .. 0.9 (a: motorcycle; 32 .. 96 blocks of it) / 1.6 dB (b: "color", a near-flat
     graphic at 53 dB) on the worst picture -- smooth pictures want small weight grids with many levels, which the
-    config ranking seldom puts among its eight; ASTC with alpha is about 1 dB out at every level."""
+    config ranking seldom puts among its eight; ASTC with alpha was 1.0 .. 1.4 dB out at every level with round 5's lists and
+    is 0.5 .. 0.7 with lists ranked on textured alpha."""
     import importlib.util
     import real_lib as R
     spec = importlib.util.spec_from_file_location(
@@ -318,7 +319,7 @@ def test_ladders_on_both_photograph_groups_pooled_and_worst_image():
         return g(pooled), (worst[0], g(worst[2])) if worst else None
     lim = {   # (pooled Normal, pooled High, pooled Highest, worst-image High)
         ("bc7", "a"): (0.25, 0.12, 0.10, 0.30), ("bc7", "b"): (0.25, 0.12, 0.10, 0.35),
-        ("etc2", "a"): (0.25, 0.20, 0.20, 0.35), ("etc2", "b"): (0.55, 0.50, 0.48, 0.80),
+        ("etc2", "a"): (0.25, 0.20, 0.20, 0.35), ("etc2", "b"): (0.42, 0.38, 0.33, 0.50),
         ("astc6", "a"): (0.60, 0.40, 0.36, 1.00), ("astc6", "b"): (0.60, 0.47, 0.44, 1.75)}
     for group in ("a", "b"):
         names = R.image_names(group)
@@ -338,7 +339,7 @@ def test_ladders_on_both_photograph_groups_pooled_and_worst_image():
     pooled, _ = gaps(Q.rows_of(*Q.etc2_rgba8_sse(ba), None, None))          # asserts e >= optimum per block itself
     assert pooled[0] <= 0.25 and pooled[2] <= 0.15, pooled
     pooled, _ = gaps(Q.rows_of(*Q.astc_sse(R.blocks_alpha(6, 6, 128), 6, 6, True), None, None))
-    assert pooled[1] <= 1.15 and pooled[1] <= pooled[0] + 1e-9, pooled
+    assert pooled[1] <= 0.65 and pooled[1] <= pooled[0] + 1e-9, pooled
 
 
 def test_eac_true_optimum_is_a_bound_and_decodes_to_what_it_claims():
