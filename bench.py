@@ -26,6 +26,9 @@ ranks (cuttlefish_amd/shard.py), mips generated on the GPU, ONE batched encode p
 gathered to rank 0 as exact-size device buffers over RCCL, and a sub-sample of the gathered
 payload checked byte-for-byte against a local re-encode ("strong" scaling: the batch is fixed).
 
+`--config c3` runs BASELINE.json configs[2]: ASTC 6x6 LDR at Texture::Quality::High on the same kind of tile, one
+JSON line of the same shape (roofline of `cfhip_astc_encode_kernel`, cpu_baseline = the oracle on a strip, payload compared).
+
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM
 (8 TB/s, /opt/skills/guides/MI355X_MICROARCH.md): algorithmic bytes = 5 B/px
 (read RGBA8 once + write 1 B/px payload once) x 16 777 216 px per launch, divided by
@@ -698,6 +701,107 @@ def strong_c2(args, ctx, torch, dist, rank, world, backend, img, local_out):
     }
 
 
+def run_c3(args, rank, local_rank, world, backend):
+    """BASELINE.json configs[2] (SURVEY 8d "C3"): ASTC 6x6 LDR, Texture::Quality::High ("thorough"), one 4096x4096 RGBA8
+    tile per GPU resident in HBM, weak scaling like the headline.  One JSON line: `roofline` prices the kernel against HBM
+    (algorithmic bytes = the source read once + 16 B per 6x6 block written once) and carries `valu_busy`, the measure
+    that actually bounds this kernel, replayed from the committed PMC pass (profiles/r06_astc_lds_pmc.txt: PMC passes
+    cannot run inside a timed benchmark); `cpu_baseline` = the oracle on a strip of the same tile, payload compared."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from cuttlefish_amd import Context, Format, PixelType, Type, make_params, synth
+
+    size = args.size
+    q = 3 if args.quality == 2 else args.quality          # (--quality defaults to the headline's Normal; C3 is High)
+    img = _cached_photo(synth, size, 1 + rank)
+    src = torch.from_numpy(img).cuda()
+    bx, by = (size + 5) // 6, (size + 5) // 6
+    out = torch.empty(bx * by * 16, dtype=torch.uint8, device="cuda")
+    params = make_params(Format.ASTC_6x6, Type.UNorm, q)
+    surf = [{"pixels": src.data_ptr(), "pixel_type": PixelType.RGBA8, "width": size, "height": size,
+             "row_pitch_bytes": size * 4, "out": out.data_ptr(), "out_capacity": out.numel()}]
+    ctx = Context(local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    for _ in range(args.warmup):
+        ctx.encode_device(surf, params, stream)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ctx.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.encode_device(surf, params, stream)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = ctx.profile_end()
+    per_rank = [{"rank": 0, "kernel_ms": round(kernel_ms / max(launches, 1), 4)}]
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms / max(launches, 1)], dtype=torch.float64,
+                         device="cuda" if backend == "nccl" else "cpu")
+        allt = [t.clone() for _ in range(world)]
+        dist.all_gather(allt, t)
+        elapsed = max(float(a[0]) for a in allt)
+        per_rank = [{"rank": r, "kernel_ms": round(float(allt[r][1]), 4)} for r in range(world)]
+    if rank == 0:
+        value = float(size * size) * world * args.steps / elapsed / 1e6
+        avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
+        algo_bytes = size * size * 4 + bx * by * 16
+        achieved = algo_bytes / avg_kernel_s / 1e9
+        line = {"metric": "Mpixels/s encode, ASTC 6x6 4096x4096 RGBA8", "value": round(value, 3), "unit": "Mpixels/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                "config": {"workload": "ASTC 6x6 LDR Texture::Quality::%s, one %dx%d RGBA8 synthetic photo tile per GPU, "
+                                       "resident in HBM (BASELINE config 3)" % (QNAMES[q], size, size),
+                           "format": "ASTC_6x6", "quality": q, "blocks_per_launch": bx * by,
+                           "parallelism": "surface-per-gpu x%d" % world},
+                "per_rank": per_rank,
+                "roofline": {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": round(achieved / HBM_PEAK_GBPS, 8), "traffic": None,
+                             "kernel": ctx.last_kernel_name(), "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
+                             "launches": launches, "algorithmic_bytes_per_launch": int(algo_bytes),
+                             "note": "a VALU-issue-bound search: the HBM fraction is tiny by construction; what bounds the kernel "
+                                     "is valu_busy (DESIGN.md 4.5)"}}
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "astc_c3_pmc.json")))
+            line["roofline"]["traffic"] = pj.get("traffic_bytes_per_launch")
+            line["roofline"]["valu_busy"] = pj.get("valu_busy")
+            line["roofline"]["lds_bank_conflict_share"] = pj.get("lds_bank_conflict_share")
+            line["roofline"]["pmc_source"] = pj.get("source")
+            line["roofline"]["traffic_measured_in_this_run"] = False
+        except (OSError, ValueError):
+            pass
+        if world == 1 and not args.no_cpu_baseline and size == SIZE:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            cores = usable_cpus()
+            fmt = int(Format.ASTC_6x6)
+            t0 = time.perf_counter()
+            O.encode(img[:48], fmt, quality=q, threads=cores)
+            rate = 48 * size / 1e6 / max(time.perf_counter() - t0, 1e-3)
+            rows = int(min(by, max(8, 10.0 * rate * 1e6 / (6 * size))))
+            strip = img[:rows * 6]
+            t0 = time.perf_counter()
+            ref = O.encode(strip, fmt, quality=q, threads=cores)
+            dt = time.perf_counter() - t0
+            got = out.cpu().numpy()[:rows * bx * 16]
+            line["cpu_baseline"] = {"value": round(rows * 6 * size / 1e6 / dt, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+                                    "flags": _oracle_flags(),
+                                    "sample": "rows 0..%d of the same tile (%d blocks): %.1f s wall on %d threads" % (rows * 6, rows * bx, dt, cores),
+                                    "gpu_payload_equals_cpu": bool(np.array_equal(ref, got))}
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    ctx.close()
+
+
 def run_c2(args, rank, local_rank, world, backend):
     import numpy as np
     import torch
@@ -828,6 +932,8 @@ def run_c2(args, rank, local_rank, world, backend):
             line["vs_previous_round"] = _previous_round(line["metric"], world, value)
             if line["vs_previous_round"] and args.quality == 2:
                 line["regression_gate"] = {"min_ratio": MIN_VS_PREVIOUS, "ok": line["vs_previous_round"]["ratio"] >= MIN_VS_PREVIOUS}
+        # (the headline level's payload, taken before the tolerance leg encodes another level into the same buffer)
+        device_payload = out.cpu().numpy() if (world == 1 and not args.no_end_to_end) else None
         if world == 1 and size == SIZE and args.quality == 2 and not args.no_tolerance:
             line["tolerance"] = tolerance_view(ctx, torch, surf, size, stream, value)
         if world == 1 and size == SIZE and not args.no_second_tile:
@@ -835,7 +941,7 @@ def run_c2(args, rank, local_rank, world, backend):
             line["second_tile"]["vs_headline_tile"] = round(line["second_tile"]["kernel_ms"] / (avg_kernel_s * 1e3), 3)
         if world == 1 and not args.no_end_to_end:
             torch.cuda.synchronize()
-            line["end_to_end"] = end_to_end(ctx, img, params, out.cpu().numpy(), avg_kernel_s * 1e3)
+            line["end_to_end"] = end_to_end(ctx, img, params, device_payload, avg_kernel_s * 1e3)
         if world > 1 and not args.no_strong:
             strong = guarded_strong(line)
         if strong is not None:
@@ -858,7 +964,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--quality", type=int, default=2)
     ap.add_argument("--size", type=int, default=SIZE)
-    ap.add_argument("--config", default="c2", choices=["c2", "c5"])
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"])
     ap.add_argument("--textures", type=int, default=256, help="c5: textures in the array")
     ap.add_argument("--tex-size", type=int, default=2048, help="c5: base level size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -870,7 +976,7 @@ def main():
                          "averages of the run must be the headline tile's alone)")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 20 if args.config == "c2" else 3
+        args.steps = 20 if args.config == "c2" else (8 if args.config == "c3" else 3)
     if args.warmup is None:
         args.warmup = 3 if args.config == "c2" else 1
 
@@ -914,6 +1020,8 @@ def main():
     try:
         if args.config == "c5":
             run_c5(args, rank, local_rank, world, backend)
+        elif args.config == "c3":
+            run_c3(args, rank, local_rank, world, backend)
         else:
             run_c2(args, rank, local_rank, world, backend)
     finally:

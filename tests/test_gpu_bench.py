@@ -120,7 +120,11 @@ def test_headline_line_carries_the_regression_gate_and_the_tolerance_level(hip_l
     whether it holds 0.90 x that record (`regression_gate`), and this test fails when it does not.  `tolerance` names
     the lowest level whose gap to the bound is within north_star's 0.1 dB on both photograph groups and its measured
     throughput on the same tile (round-5 VERDICT item 3)."""
-    line = _run(["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-end-to-end", "--no-second-tile"])
+    line = _run(["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-second-tile"])
+    # (the tolerance leg encodes another level into the benchmark's payload buffer: the end-to-end leg that follows must
+    # still be compared with the HEADLINE level's payload)
+    assert line["end_to_end"]["rgba8"]["payload_equals_device_path"] is True
+    assert line["end_to_end"]["rgba32f_bottom_up"]["payload_equals_device_path"] is True
     prev = line["vs_previous_round"]
     if prev is not None:
         assert int(prev["record"][7:9]) < 6, prev          # never this round's own record
@@ -131,3 +135,14 @@ def test_headline_line_carries_the_regression_gate_and_the_tolerance_level(hip_l
     assert tol["mpixels_per_s"] >= 50.0                   # north_star's throughput at the compliant level
     k = ["Normal", "High", "Highest"].index(tol["lowest_level_within_target"])
     assert all(g[k] <= 0.1 for g in tol["gap_db_normal_high_highest"].values())
+
+
+@pytest.mark.timeout(900)
+def test_bench_config3_line(hip_lib):
+    """BASELINE config 3 through bench.py (round-5 VERDICT item 1: the roofline line of --config c3 names the kernel)"""
+    line = _run(["--config", "c3", "--size", "1536", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert line["config"]["format"] == "ASTC_6x6" and line["config"]["quality"] == 3
+    assert line["unit"] == "Mpixels/s" and line["value"] > 50.0 and line["dtype"] == "u8"
+    r = line["roofline"]
+    assert r["kernel"] == "cfhip_astc_encode_kernel" and r["bound"] == "hbm" and 0 < r["frac"] < 1
+    assert r["algorithmic_bytes_per_launch"] == 1536*1536*4 + 256*256*16

@@ -28,6 +28,10 @@ PROFILE_CMD="python $R/tools/bench_formats.py --size 4096 --steps 3 --formats AS
   bash $R/tools/profile.sh ${tag}_astc > $G/${tag}_astc_pmc_summary.txt 2>&1
 for f in $(find $G/prof_${tag}_astc/stats -name "*kernel_stats.csv"); do cp $f $G/${tag}_astc_kernel_stats.csv; done
 bash $R/tools/dbg/astc_dense_ab.sh > $G/${tag}_astc_dense_ab.txt 2>&1
+# what bounds that kernel (VALU busy share, LDS bank-conflict share) -> profiles/astc_c3_pmc.json, replayed by `bench.py --config c3`
+bash $R/tools/dbg/astc_lds_pmc.sh > $G/${tag}_astc_lds_pmc.txt 2>&1
+( cd $R && python tools/astc_pmc_to_json.py $G/${tag}_astc_pmc_summary.txt $G/${tag}_astc_lds_pmc.txt $tag > /dev/null && cp profiles/astc_c3_pmc.json $G/astc_c3_pmc.json )
+python $R/bench.py --config c3 > $G/${tag}_c3_bench.json 2> $G/${tag}_c3_bench.err
 # ETC2 RGB at Normal, 2048x2048: SALU / VALU counts and traffic
 PROFILE_CMD="python $R/tools/bench_formats.py --size 2048 --steps 3 --formats ETC2_R8G8B8 --qualities 2" \
   bash $R/tools/profile.sh ${tag}_misc > $G/${tag}_misc_pmc_summary.txt 2>&1
