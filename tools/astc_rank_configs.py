@@ -65,12 +65,12 @@ REAL_CENSUS = [SK + "motorcycle_right.png", SK + "ihc.png", SK + "retina.jpg", S
                SK + "color.png", "/opt/conda/lib/python3.9/site-packages/imageio/resources/images/chelsea.png"]
 
 
-def real_content(size):
+def real_content(size, exclude=()):
     """centre crops (size x size, opaque) of the census photographs; retina / hubble halved first (they are large)"""
     from PIL import Image
     out = []
     for path in REAL_CENSUS:
-        if not os.path.exists(path):
+        if not os.path.exists(path) or any(x in path for x in exclude):
             continue
         im = Image.open(path).convert("RGB")
         if min(im.size) > 4*size:
@@ -90,7 +90,9 @@ def real_alpha_content(size):
     the dual-plane lists it produced for blocks with alpha are all 2 x 2 / 2 x 3 grids -- the alpha-carrying real blocks
     of the quality fixture (another set of photographs) want 4 x 4 x 4 .. 5 levels there and sat 1 dB under the wide
     search at every level."""
-    crops = real_content(size)
+    # (the chelsea crop is left out here: that picture is also one of the quality fixture's group-a photographs, and the
+    # alpha-carrying fixture blocks are cut from group a -- the five others are sampled for the fixture OUTSIDE this crop)
+    crops = real_content(size, exclude=("chelsea",))
     out = []
     for i in range(len(crops)):
         j = (i + 1) % len(crops)
