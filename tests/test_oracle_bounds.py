@@ -278,6 +278,8 @@ def test_bc1_and_bc3_colour_blocks_against_the_true_optimum():
     ys = rng.integers(0, 128, n) * 4
     xs = rng.integers(0, 128, n) * 4
     sets = {"real": R.blocks4(n), "synth": np.stack([img[y:y + 4, x:x + 4] for y, x in zip(ys, xs)])}
+    if "real_b_e4" in fx.files:          # round 6: the held-out photograph group (BC1 0.04 / 0.01 / 0.01 dB, BC3 0.06 / 0.01 / 0.01)
+        sets["real_b"] = R.blocks4(n, group="b")
     for name, blocks in sets.items():
         strip = R.strip(np.ascontiguousarray(blocks))
         e4, e3 = fx[name + "_e4"].astype(np.float64), fx[name + "_e3"].astype(np.float64)

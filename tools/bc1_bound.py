@@ -44,7 +44,8 @@ def main():
     exe = "/tmp/bc1_optimum"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-w", "-o", exe,
                            os.path.join(ROOT, "tools", "bounds", "bc1_optimum.hip")])
-    sets = {"real": R.blocks4(a.blocks), "synth": synth_blocks(a.blocks)}
+    # (real_b: the held-out photograph group of round 6)
+    sets = {"real": R.blocks4(a.blocks), "real_b": R.blocks4(a.blocks, group="b"), "synth": synth_blocks(a.blocks)}
     fixture = {}
     print("| blocks | format | Q0 | Q1 | Q2 | Q3 | Q4 | TRUE optimum | gap at Normal | gap at High | gap at Highest |")
     print("|---|---|---|---|---|---|---|---|---|---|---|")
