@@ -87,3 +87,42 @@ def test_payload_goes_straight_to_the_callers_buffer_when_no_pinned_ring_can_be_
         got = c.encode([f], p)[0]
         assert c.pinned_bytes() <= 3*(5 << 20)          # the source strip slots only
     assert np.array_equal(got, want)
+
+
+def test_landing_ring_under_concurrent_contexts():
+    """three host threads, each with its own context, push pipelined surfaces of different sizes and layouts through their
+    landing rings at the same time and repeatedly (ring reuse across calls, slots larger and smaller than the last call's):
+    every payload equals the plain top-down RGBA8 path's"""
+    import threading
+    rng = np.random.default_rng(5)
+    cases = []
+    for (w, h, fmt) in ((1280, 1030, Format.BC7), (2048, 516, Format.BC3), (777, 333, Format.ETC2_R8G8B8), (4096, 2052, Format.BC1_RGB)):
+        img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        cases.append((img, fmt))
+    with Context(0) as c:
+        want = [c.encode([img], make_params(fmt, Type.UNorm, 0))[0] for img, fmt in cases]
+    errors = []
+
+    def worker(k):
+        try:
+            with Context(0) as c:
+                for it in range(3):
+                    for j in range(len(cases)):
+                        img, fmt = cases[(j + k) % len(cases)]
+                        p = make_params(fmt, Type.UNorm, 0)
+                        if (it + j + k) & 1:
+                            src = (img.astype(np.float32)/np.float32(255.0))            # float source: host quantiser + strips
+                        else:
+                            src = np.ascontiguousarray(img[::-1])[::-1]                  # bottom-up storage: strips
+                        got = c.encode([src], p)[0]
+                        if not np.array_equal(got, want[(j + k) % len(cases)]):
+                            errors.append((k, it, j))
+                assert c.pinned_bytes() <= 32 << 20
+        except Exception as e:              # noqa: BLE001
+            errors.append((k, repr(e)))
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors

@@ -188,6 +188,37 @@ def astc_hdr_sse(hblocks, bw, bh):
     return sse, bw * bh * 3
 
 
+def bc6h_sse(hblocks):
+    """BC6H UF16 on the same real-structure / synthetic-radiometry blocks (4x4): squared error of log2(1 + x) of the RGB
+    halves (SURVEY 8d's HDR metric, peak log2(1 + 65504)); bound = cfo_bc6h_wide_search"""
+    L = _lib()
+    L.cfo_bc6h_wide_search.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(O.Params)]
+    L.cfo_encode_bc6h_block.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(O.Params)]
+    n = len(hblocks)
+    raw = np.ascontiguousarray(hblocks.view(np.uint16).reshape(n, 64))
+    payloads = np.zeros((6, n, 16), np.uint8)
+
+    def work(i):
+        for q in range(5):
+            p = O.make_params(35, 4, q)
+            L.cfo_encode_bc6h_block(raw[i].ctypes.data, payloads[q, i].ctypes.data, ctypes.byref(p))
+        p = O.make_params(35, 4, 4)
+        L.cfo_bc6h_wide_search(raw[i].ctypes.data, payloads[5, i].ctypes.data, ctypes.byref(p))
+    _pmap(work, n)
+    strip = R.strip(hblocks)
+    ref = np.log2(1.0 + strip[..., :3].astype(np.float64))
+    sse = np.zeros((6, n))
+    for q in range(6):
+        dec = O.decode_bc6h(payloads[q].reshape(-1), 4 * n, 4, 4)
+        d = np.log2(1.0 + np.abs(dec[..., :3].astype(np.float64))) - ref
+        sse[q] = (d * d).reshape(4, n, 4, 3).sum(axis=(0, 2, 3))
+    return sse, 48
+
+
+def psnr_log(s, nvals):
+    return 10.0 * np.log10(np.log2(1.0 + 65504.0) ** 2 * nvals / max(float(s), 1e-12))
+
+
 def psnr_lns(s, nvals):
     return 10.0 * np.log10(65535.0 ** 2 * nvals / max(float(s), 1e-9))
 
@@ -197,8 +228,9 @@ def psnr(s, nvals):
 
 
 def rows_of(sse, vals, img, names, lns=False):
-    """-> [(label, n, [psnr Q0..Q4, bound])]: pooled first, then per image (lns: PSNR on 16-bit LNS values, peak 65535)"""
-    ps = psnr_lns if lns else psnr
+    """-> [(label, n, [psnr Q0..Q4, bound])]: pooled first, then per image (lns: PSNR on 16-bit LNS values, peak 65535;
+    lns = "log": PSNR of log2(1 + x), peak log2(1 + 65504))"""
+    ps = psnr_log if lns == "log" else (psnr_lns if lns else psnr)
     out = [("pooled", sse.shape[1], [ps(sse[q].sum(), vals * sse.shape[1]) for q in range(6)])]
     if img is not None:
         for k, name in enumerate(names):
@@ -230,6 +262,8 @@ def family_rows(n4, n12):
         res.append(("ASTC %dx%d with alpha" % (bw, bh), "a", rows_of(*astc_sse(R.blocks_alpha(bw, bh, n12), bw, bh, True), None, None)))
     # the HDR profiles: real structure under synthetic radiometry (hdr_blocks), PSNR on the LNS values
     names = R.image_names("a")
+    b4 = R.blocks4(min(n4, 1024))
+    res.append(("BC6H UF16 (log2 PSNR)", "a", rows_of(*bc6h_sse(hdr_blocks(b4)), np.arange(len(b4)) % len(names), names, lns="log")))
     for bw, bh in ((4, 4), (6, 6), (8, 8)):
         b12 = R.blocks(bw, bh, n12)
         res.append(("ASTC %dx%d HDR (LNS PSNR)" % (bw, bh), "a", rows_of(*astc_hdr_sse(hdr_blocks(b12), bw, bh), np.arange(len(b12)) % len(names), names, lns=True)))
