@@ -778,6 +778,18 @@ def run_c3(args, rank, local_rank, world, backend):
             line["roofline"]["traffic_measured_in_this_run"] = False
         except (OSError, ValueError):
             pass
+        # north_star's 0.1 dB at C3's level: the same view as the headline's `tolerance` key, read from the same table
+        try:
+            js = json.load(open(os.path.join(ROOT, "profiles", "quality_real.json")))
+            gaps = {g: js["ASTC 6x6/%s" % g]["pooled_gap_nhh"] for g in ("a", "b")}
+            inside = [QNAMES[lv] for k, lv in enumerate((2, 3, 4)) if all(gaps[g][k] <= 0.1 for g in gaps)]
+            line["tolerance"] = {"target_db": 0.1, "bound": "cfo_astc_wide_search on blocks of real photographs "
+                                                             "(tests/golden/real_blocks.npz, groups a / b)",
+                                 "gap_db_normal_high_highest": gaps, "this_level_within_target": bool(QNAMES[q] in inside),
+                                 "lowest_level_within_target": inside[0] if inside else None,
+                                 "source": "profiles/quality_real.json (tools/quality_real.py)"}
+        except (OSError, KeyError, ValueError):
+            line["tolerance"] = None
         if world == 1 and not args.no_cpu_baseline and size == SIZE:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O

@@ -1081,7 +1081,7 @@ __device__ __forceinline__ uint4 encode_blocks(const uint32_t* tile, const uint3
 	const uint32_t ntop = kp.quality >= 3u ? 8u : (kp.quality == 2u ? 4u : 1u);   // oracle: budget.top
 	const uint32_t uber = kp.quality >= 4u ? 2u : (kp.quality == 3u ? 1u : 0u);    // rounds per top candidate
 	const uint32_t uber2 = kp.quality >= 4u ? 2u : (kp.quality >= 2u ? 1u : 0u);   // rounds on the leader
-	const uint32_t msets = kp.quality >= 3u ? 3u : 1u;       // move sets of a round: bit 0 single, bit 1 joint
+	const uint32_t msets = kp.quality >= 4u ? 3u : 1u;       // move sets of a round: bit 0 single, bit 1 joint (Highest only since round 6: oracle quality_budget)
 	bool solved = false;
 	// which halves walk the second pass: bit 0 / bit 32 = the best candidate of the first pass leaves the block
 	// of half 0 / 1 with an error of at least 48 (oracle: best_err >= 48u); a scalar pair

@@ -893,6 +893,7 @@ typedef struct {
 	int wide;       /* the 64-lane layout (High, Highest) */
 	int m4;         /* mode 4 candidates: bit k enables rotation k & 3, index selector k >> 2 */
 	int own_lanes;  /* lab only: every candidate its own slot (lane = id), so partition counts are not bound by a lane layout */
+	int utop;       /* how many of the `top` candidates get the perturbation rounds (0 = all of them) */
 } budget;
 
 static budget quality_budget(int quality)
@@ -917,10 +918,13 @@ static budget quality_budget(int quality)
 		case 2: b.iters = 1; b.two = b.mode3 = b.rot = b.three = 1; b.m4 = 255; b.top = 4; b.starts = 15; b.starts3 = 3;
 			b.uber = 0; b.uber2 = 1; b.sets = 1; break;
 		/* High (bc7enc: m_uber_level 4 against Normal's 1, S3tcConverter.cpp:193,204): the wide layout -- mode 4 for
-		 * every block, 16 two-subset partitions -- eight candidates refined, a perturbation round with both
-		 * move sets on each and one more on the leader: 0.08 / 0.03 dB */
+		 * every block, 16 two-subset partitions -- eight candidates refined, a perturbation round on each and one more on
+		 * the leader: 0.08 / 0.03 dB.  Round 6: the rounds of High use the single-field moves only (the joint moves of
+		 * both ends of a channel stay with Highest): High is the lowest level inside north_star's 0.1 dB on both photograph
+		 * groups, and the joint moves were 11 of its 47 ms for 0.007 dB (0.074 / 0.084 -> 0.081 / 0.091 dB on groups a / b,
+		 * tools/bc7_lab.py; perturbing only four of the eight: 0.085 / 0.096 -- too close to the line) */
 		case 3: b.wide = 1; b.iters = 1; b.two = b.mode3 = b.three = b.rot = 1; b.m4 = 255; b.n1 = 12; b.n3 = 4; b.n7 = 16;
-			b.top = 8; b.starts = 15; b.starts3 = 15; b.uber = 1; b.uber2 = 1; b.sets = 3; break;
+			b.top = 8; b.starts = 15; b.starts3 = 15; b.uber = 1; b.uber2 = 1; b.sets = 1; break;
 		/* Highest: two refit rounds, two perturbation rounds per candidate and two more on the leader: 0.06 / 0.02 */
 		default: b.wide = 1; b.iters = 2; b.two = b.mode3 = b.three = b.rot = 1; b.m4 = 255; b.n1 = 12; b.n3 = 4; b.n7 = 16;
 			b.top = 8; b.starts = 15; b.starts3 = 15; b.uber = 2; b.uber2 = 2; b.sets = 3; break;
@@ -1110,7 +1114,7 @@ static void encode_block(const uint8_t rgba[64], uint8_t out[16], const cfo_para
 	}
 	int win = 0;
 	if (b.uber)
-		for (int k = 0; k < ntop; ++k)
+		for (int k = 0; k < ntop && (!b.utop || k < b.utop); ++k)
 			uber_refine(px, wt, &top[k], b.uber, b.sets);
 	for (int k = 1; k < ntop; ++k)
 		if (BETTER(top[k], top[win]))
@@ -1130,7 +1134,7 @@ void cfo_encode_bc7_block(const uint8_t rgba[64], uint8_t out[16], const cfo_par
 /* test-only: the block search with every budget field set by the caller (tools/bc7_lab.py measures what
  * each step of the search buys before it is given to a Texture::Quality level).  knobs = the budget
  * fields in declaration order. */
-void cfo_bc7_lab_block(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p, const int knobs[22])
+void cfo_bc7_lab_block(const uint8_t rgba[64], uint8_t out[16], const cfo_params* p, const int knobs[23])
 {
 	budget b;
 	int* f = (int*)&b;

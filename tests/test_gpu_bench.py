@@ -146,3 +146,8 @@ def test_bench_config3_line(hip_lib):
     r = line["roofline"]
     assert r["kernel"] == "cfhip_astc_encode_kernel" and r["bound"] == "hbm" and 0 < r["frac"] < 1
     assert r["algorithmic_bytes_per_launch"] == 1536*1536*4 + 256*256*16
+    # the 0.1 dB view at C3's level: stated in the line, from the committed quality table (no level of 6x6 is inside)
+    t = line["tolerance"]
+    assert t["target_db"] == 0.1 and set(t["gap_db_normal_high_highest"]) == {"a", "b"}
+    within = all(t["gap_db_normal_high_highest"][g][1] <= 0.1 for g in ("a", "b"))
+    assert t["this_level_within_target"] == within

@@ -22,9 +22,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O          # noqa: E402
 from cuttlefish_amd import synth    # noqa: E402
 
-FIELDS = "iters,m6only,two,mode3,three,rot,n1,n3,n7,n7low,n0,n2,top,starts,uber,uber2,sets,starts3,estq,wide,m4,own".split(",")
+FIELDS = "iters,m6only,two,mode3,three,rot,n1,n3,n7,n7low,n0,n2,top,starts,uber,uber2,sets,starts3,estq,wide,m4,own,utop".split(",")
 NORMAL = dict(iters=1, m6only=0, two=1, mode3=1, three=1, rot=1, n1=6, n3=5, n7=11, n7low=14, n0=5, n2=5,
-              top=4, starts=15, uber=0, uber2=1, sets=1, starts3=3, estq=4, wide=0, m4=255, own=0)
+              top=4, starts=15, uber=0, uber2=1, sets=1, starts3=3, estq=4, wide=0, m4=255, own=0, utop=0)
 
 
 def knobs(**kw):
@@ -40,7 +40,7 @@ def sample_blocks(img, count, rng):
     return np.stack([img[y:y + 4, x:x + 4].reshape(16, -1) for y, x in zip(ys, xs)])
 
 
-def contents(count, which, kind="photo"):
+def contents(count, which, kind="photo", group="a"):
     rng = np.random.default_rng(20260929)
     out = []
     for label, alpha in (("opaque", False), ("alpha", True)):
@@ -48,8 +48,10 @@ def contents(count, which, kind="photo"):
             continue
         if kind == "real":
             import real_lib as R
-            blocks = R.blocks4(count, alpha=alpha)
-            out.append(("real " + label, np.ascontiguousarray(blocks.reshape(len(blocks), 64))))
+            if alpha and group != "a":
+                continue
+            blocks = R.blocks4(count, alpha=alpha, group=group)
+            out.append(("real %s %s" % (group, label), np.ascontiguousarray(blocks.reshape(len(blocks), 64))))
             continue
         img = synth.photo(512, 512, seed=21)
         if alpha:
@@ -89,6 +91,7 @@ def main():
     ap.add_argument("--content", default="both")
     ap.add_argument("--no-wide", action="store_true")
     ap.add_argument("--kind", default="photo", help="photo = the synthetic generator, real = tests/golden/real_blocks.npz")
+    ap.add_argument("--group", default="a", help="photograph group of the real blocks (b = held out)")
     ap.add_argument("cfg", nargs="*")
     a = ap.parse_args()
     L = O.lib()
@@ -106,7 +109,7 @@ def main():
                 k, _, v = item.partition(":")
                 kw[k] = int(v)
         cfgs.append((name, kw))
-    for label, blocks in contents(a.blocks, a.content, a.kind):
+    for label, blocks in contents(a.blocks, a.content, a.kind, a.group):
         n = len(blocks)
         print("== %s, %d blocks" % (label, n))
         cache = "/tmp/bc7_wide_%s_%d.npy" % (label.replace(" ", "_"), n)
@@ -130,7 +133,7 @@ def main():
                                                       psnr(wide, n) - psnr(sse, n) if wide else 0, dt))
         for name, kw in cfgs:
             p = O.make_params(36, 0, 2)
-            kn = (ctypes.c_int * 22)(*knobs(**kw))
+            kn = (ctypes.c_int * 23)(*knobs(**kw))
             t0 = time.time()
             sse = run(blocks, lambda b, o: L.cfo_bc7_lab_block(b, o, ctypes.byref(p), kn))
             dt = time.time() - t0
