@@ -328,17 +328,26 @@ __device__ __forceinline__ void normalise_rows(uint8_t* base, const uint32_t* de
 	reinterpret_cast<uint32_t*>(base + (PW - 1u)*256u)[0] = prev | ((prev >> 8) << 16);
 }
 
-// The same, by the four lanes of a refinement quad.  Round 6: every lane of the quad scatters ITS texels into
-// ITS OWN column (the quad's four columns are the four words of one 16-byte group of every row: `base` = the
-// first of them), so the scatter, the least-squares walk and the error walk touch one bank per lane like round 0
-// (sharing the result's column, the four lanes met in one bank: 35 % of the LDS-active cycles of the 6x6 High
-// kernel were bank conflicts).  Here the partial sums meet -- one 16-byte read per row word, the halves cannot
-// carry (the total is at most 64 x the factor sum) -- and the pair-form weights go back as four copies, one per
-// lane.  Lane qr takes the words 4 qr + 16 m .. + 3.  A step is self-contained -- it also reads the word after its
-// four (that word's first weight completes the pair form of its last one) -- and every lane's reads of a step come
-// before any lane's writes of it (the scheduling barriers; the quad runs the steps in lockstep), so no lane reads
-// a word that a neighbour has already rewritten in place.
-__device__ __forceinline__ void normalise_rows_quad(uint8_t* base, const uint32_t* den, uint32_t PW, const uint8_t* wnu, uint32_t qr)
+// The weights of a refinement quad.  Every lane of the quad scatters ITS texels into ITS OWN column (the quad's four
+// columns are the four words of one 16-byte group of every row: `base` = the first of them), so the scatter, the
+// least-squares walk and the error walk touch one bank per lane like round 0 (sharing the result's column, the four
+// lanes met in one bank: 35 % of the LDS-active cycles of the 6x6 High kernel were bank conflicts).  In the passes
+// below the partial sums meet -- one 16-byte read per row word, the halves cannot carry (the total is at most 64 x
+// the factor sum) -- and the pair-form weights go back as four copies, one per lane.  Lane qr takes the words
+// 4 qr + 16 m .. + 3.  A step is self-contained -- it also reads the word after its four (that word's first weight
+// completes the pair form of its last one) -- and every lane's reads of a step come before any lane's writes of it
+// (the scheduling barriers; the quad runs the steps in lockstep), so no lane reads a word that a neighbour has
+// already rewritten in place.
+//
+// The rounds take one step towards the least-squares grid (oracle: phase_b, "one step towards the least-squares
+// grid"): g1 = g0 + 2 (num(T) - num(F g0)) / den.  Three passes over the quad's four columns, which hold the four
+// lanes' partial sums of num(T) when the scatter is done:
+//   quad_rows_average   word k of column 0 <- the plain averages g0 in pair form (what infill_w reads), column 1 <-
+//                       the summed num(T), columns 2 and 3 <- 0
+//   (the caller)        every lane infills ITS texels from column 0 and scatters them into column 2 (lanes 0, 1 of
+//                       the quad) or 3 (lanes 2, 3): num(F g0)
+//   quad_rows_step      g1 from the three, clamped to 0 .. 64, quantised; pair form back as four copies
+__device__ __forceinline__ void quad_rows_average(uint8_t* base, const uint32_t* den, uint32_t PW, uint32_t qr)
 {
 #pragma unroll 1
 	for (uint32_t k = 4u*qr; k < PW; k += 16u) {
@@ -358,6 +367,50 @@ __device__ __forceinline__ void normalise_rows_quad(uint8_t* base, const uint32_
 			g[2u*m + 1u] = avg_round(acc[m] >> 16, dd[m].y);
 		}
 		g[8] = avg_round(acc[4] & 0xFFFFu, dd[4].x);
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (uint32_t m = 0; m < 4u; ++m) {
+			if (k + m < PW) {
+				const uint32_t cur = g[2u*m] | (g[2u*m + 1u] << 8);
+				const uint32_t nxt = k + m + 1u < PW ? g[2u*m + 2u] : 0u;
+				const uint32_t wv = cur | (((cur >> 8) | (nxt << 8)) << 16);
+				*reinterpret_cast<uint4*>(base + (k + m)*256u) = make_uint4(wv, acc[m], 0u, 0u);
+			}
+		}
+	}
+}
+
+// one weight of the step: g0 + 2 (round((num0 - num1 + 32 den) / den, clamped to a mean residual of -32 .. 32) - 32)
+__device__ __forceinline__ uint32_t ls_step(uint32_t g0, uint32_t num0, uint32_t num1, uint32_t e)
+{
+	const uint32_t dn = e & 0xFFFFu;
+	const int s = (int)num0 - (int)num1 + (int)(32u*dn);
+	const uint32_t sc = (uint32_t)min(max(s, 0), (int)(64u*dn));
+	const int v = (int)g0 + 2*((int)avg_round(sc, e) - 32);
+	return (uint32_t)min(max(v, 0), 64);
+}
+
+__device__ __forceinline__ void quad_rows_step(uint8_t* base, const uint32_t* den, uint32_t PW, const uint8_t* wnu, uint32_t qr)
+{
+#pragma unroll 1
+	for (uint32_t k = 4u*qr; k < PW; k += 16u) {
+		uint32_t g[9];
+		uint4 part[5];
+		uint2 dd[5];
+#pragma unroll
+		for (uint32_t m = 0; m < 5u; ++m) {
+			const uint32_t km = min(k + m, PW - 1u);
+			part[m] = *reinterpret_cast<const uint4*>(base + km*256u);
+			dd[m] = *reinterpret_cast<const uint2*>(den + 2u*km);
+		}
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (uint32_t m = 0; m < 5u; ++m) {
+			const uint32_t a1 = part[m].z + part[m].w;
+			g[2u*m] = ls_step(part[m].x & 255u, part[m].y & 0xFFFFu, a1 & 0xFFFFu, dd[m].x);
+			if (m < 4u)
+				g[2u*m + 1u] = ls_step((part[m].x >> 8) & 255u, part[m].y >> 16, a1 >> 16, dd[m].y);
+		}
 #pragma unroll
 		for (uint32_t m = 0; m < 9u; ++m)
 			g[m] = wnu[g[m]];
@@ -2045,7 +2098,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				// until the round body became two instances, the block's keys moved to its LDS slot and the table pointers
 				// and channel weights were formed at their uses -- a kernel that talks across lanes must not spill vector
 				// registers: a spill inside divergent control flow saves the active lanes only; see etc_encode.hip)
-				const uint32_t nrounds = (HDR || CF_ASTC_R4_HIGH) ? 0u : (q == 2u ? 2u : (q == 3u ? 2u : (q >= 4u ? 3u : 0u)));
+				const uint32_t nrounds = (HDR || CF_ASTC_R4_HIGH) ? 0u : (q == 2u ? 1u : (q == 3u ? 1u : (q >= 4u ? 3u : 0u)));      // (round 6: one round with the least-squares step at Normal / High)
 				bool going = false;
 				unsigned long long prev_err = ~0ull;
 				// the lane's decoded endpoints (bytes r, g, b, a of partition k): what the next round projects on
@@ -2076,7 +2129,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				const bool has_role = !quad || rl != 255u;
 				rl = has_role ? rl : 0u;
 				const uint32_t wfirst = quad ? qr*4u : 0u, wstep = quad ? 16u : 4u;      // a lane's texel groups in the walks
-				// the lane's column: round 0 its own; a refinement quad works in its own four columns (normalise_rows_quad)
+				// the lane's column: round 0 its own; a refinement quad works in its own four columns (quad_rows_average)
 				const uint32_t coll = (pair ? h << 5 : 0u) + (quad ? hl : rl);
 				uint8_t* colbase = wbase + coll*4u;
 #define ASTC_QUADBASE (colbase - qr*4u)      /* the quad's first column (formed at its uses: one register less across the round) */
@@ -2120,7 +2173,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				// this round's weights (oracle: wide_reproject): texel i projects on the line D0 -> D1 of its partition
 				// (the previous round's decoded endpoints), T = round(64 t / dd) clamped to 0 .. 64, straight into the
 				// decimation.  Every lane of the quad scatters its texel groups into its own column (round 6); the rows of
-				// the quad's four columns are cleared and, in normalise_rows_quad, summed and normalised by different
+				// the quad's four columns are cleared and, in quad_rows_average, summed and normalised by different
 				// lanes, in program order (LDS operations of a wave complete in order)
 				if (quad && going) {
 					for (uint32_t k = qr; k <= PW*planes; k += 4u)
@@ -2239,8 +2292,30 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					}
 					__builtin_amdgcn_wave_barrier();
 #pragma unroll 1
-					for (uint32_t pl = 0; pl < planes; ++pl)
-						normalise_rows_quad(ASTC_QUADBASE + (pl ? PW*256u : 0u), den, PW, sh.wnu + wq*68u, qr);
+					for (uint32_t pl = 0; pl < planes; ++pl) {
+						// the plain averages, then one step towards the least-squares grid (quad_rows_average above)
+						uint8_t* qb = ASTC_QUADBASE + (pl ? PW*256u : 0u);
+						quad_rows_average(qb, den, PW, qr);
+						__builtin_amdgcn_wave_barrier();
+						uint8_t* acc1 = qb + 8u + (qr >> 1)*4u;
+#pragma unroll 1
+						for (uint32_t i = wfirst; i < n; i += wstep) {
+							uint2 rec[4];
+#pragma unroll
+							for (uint32_t k = 0; k < 4u; ++k)
+								rec[k] = inf[min(i + k, n - 1u)];
+							uint32_t w4[4];
+#pragma unroll
+							for (uint32_t k = 0; k < 4u; ++k)
+								w4[k] = infill_w(qb, rec[k].x, rec[k].y);
+#pragma unroll
+							for (uint32_t k = 0; k < 4u; ++k)
+								if (i + k < n)
+									decim_add(acc1, rec[k].x, rec[k].y, w4[k]);
+						}
+						__builtin_amdgcn_wave_barrier();
+						quad_rows_step(qb, den, PW, sh.wnu + wq*68u, qr);
+					}
 				}
 				__builtin_amdgcn_wave_barrier();
 				PROF_MARK(quad ? 12 : 6)   // refinement rounds: reprojection + decimate + quantise

@@ -208,14 +208,18 @@ def test_etc_and_astc_ladders_on_real_photograph_blocks():
     assert wide >= max(ps) - 1e-9, (ps, wide)
     # (late round 5: partition seeds ranked by line-fit error, refinement rounds on the 16 best results:
     #  0.58 / 0.34 / 0.29 on these 256 blocks, 0.54 / 0.33 / 0.28 on the 768 of profiles/r05_quality_tables.md)
-    assert wide - ps[3] <= 0.40 and wide - ps[2] <= 0.65, (ps, wide)
+    # (round 6: a refinement round takes a step towards the least-squares grid (oracle phase_b), and so does every evaluation
+    #  of the wide search: the BOUND rose from 36.24 to 36.92 dB on these blocks, Normal / High from 35.84 / 35.90 to
+    #  36.25 / 36.48 with ONE round where they had two -- both above round 5's bound -- 0.67 / 0.45 / 0.29 under the new one)
+    assert wide - ps[3] <= 0.50 and wide - ps[2] <= 0.72 and wide - ps[4] <= 0.33, (ps, wide)
+    assert ps[2] >= 36.20 and ps[3] >= 36.40 and wide >= 36.85, (ps, wide)
     assert ps[3] - ps[2] >= 0.10, ps                       # High above Normal by a measurable step (round 6: Normal's config ranking gained 0.06 dB)
     assert all(ps[q + 1] >= ps[q] - 1e-9 for q in range(4)), ps
     # 4x4: the wide search takes two partitions in a third of these blocks, and the seed it takes is seldom the one
     # a clustering of the texels points at (0.55 dB at High with the cluster-overlap ranking; 0.24 here, 0.18 on 768)
     ps, wide = qt.astc_gap(256, np.random.default_rng(1), 4, 4, kind="real")
     assert wide >= max(ps) - 1e-9, (ps, wide)
-    assert wide - ps[3] <= 0.30 and wide - ps[2] <= 0.45, (ps, wide)
+    assert wide - ps[3] <= 0.35 and wide - ps[2] <= 0.60, (ps, wide)      # (round 6: against the tighter bound, one round)
     assert all(ps[q + 1] >= ps[q] - 1e-9 for q in range(4)), ps
 
 
@@ -322,7 +326,7 @@ def test_ladders_on_both_photograph_groups_pooled_and_worst_image():
     lim = {   # (pooled Normal, pooled High, pooled Highest, worst-image High)
         ("bc7", "a"): (0.25, 0.12, 0.10, 0.30), ("bc7", "b"): (0.25, 0.12, 0.10, 0.35),
         ("etc2", "a"): (0.25, 0.20, 0.20, 0.35), ("etc2", "b"): (0.42, 0.38, 0.33, 0.50),
-        ("astc6", "a"): (0.60, 0.40, 0.36, 1.00), ("astc6", "b"): (0.60, 0.47, 0.44, 1.75)}
+        ("astc6", "a"): (0.72, 0.50, 0.36, 1.10), ("astc6", "b"): (0.85, 0.70, 0.58, 1.75)}      # (astc6: against the round-6 bound, which rose 0.65 dB with the least-squares step)
     for group in ("a", "b"):
         names = R.image_names(group)
         b4 = R.blocks4(256, group=group)
@@ -341,7 +345,7 @@ def test_ladders_on_both_photograph_groups_pooled_and_worst_image():
     pooled, _ = gaps(Q.rows_of(*Q.etc2_rgba8_sse(ba), None, None))          # asserts e >= optimum per block itself
     assert pooled[0] <= 0.25 and pooled[2] <= 0.15, pooled
     pooled, _ = gaps(Q.rows_of(*Q.astc_sse(R.blocks_alpha(6, 6, 128), 6, 6, True), None, None))
-    assert pooled[1] <= 0.65 and pooled[1] <= pooled[0] + 1e-9, pooled
+    assert pooled[1] <= 0.80 and pooled[1] <= pooled[0] + 1e-9, pooled      # (0.50 against round 5's bound; 0.70 against round 6's, which takes the least-squares step in every evaluation)
 
 
 def test_eac_true_optimum_is_a_bound_and_decodes_to_what_it_claims():
