@@ -328,6 +328,42 @@ __device__ __forceinline__ void normalise_rows(uint8_t* base, const uint32_t* de
 	reinterpret_cast<uint32_t*>(base + (PW - 1u)*256u)[0] = prev | ((prev >> 8) << 16);
 }
 
+// The grids stage of High / Highest (oracle: grid_decimation_error, ls): the averages g0 of `base` (pair form) become
+// g1 = 3 g0 - 2 A F g0, clamped to 0 .. 64, in place; `acc` holds num(F g0) in the accumulator layout.  Word k of
+// `base` is read before word k - 1 is rewritten (normalise_rows's order).
+__device__ __forceinline__ void ls_rows(uint8_t* base, const uint8_t* acc, const uint32_t* den, uint32_t PW)
+{
+	uint32_t prev = 0;
+#pragma unroll 1
+	for (uint32_t k = 0; k < PW; k += 4u) {
+		uint32_t a1[4], g0[4], g[8];
+		uint2 dd[4];
+#pragma unroll
+		for (uint32_t m = 0; m < 4u; ++m) {
+			const uint32_t km = min(k + m, PW - 1u);
+			a1[m] = *reinterpret_cast<const uint32_t*>(acc + km*256u);
+			g0[m] = *reinterpret_cast<const uint32_t*>(base + km*256u);
+			dd[m] = *reinterpret_cast<const uint2*>(den + 2u*km);
+		}
+#pragma unroll
+		for (uint32_t m = 0; m < 4u; ++m) {
+			const int v0 = 3*(int)(g0[m] & 255u) - 2*(int)avg_round(a1[m] & 0xFFFFu, dd[m].x);
+			const int v1 = 3*(int)((g0[m] >> 8) & 255u) - 2*(int)avg_round(a1[m] >> 16, dd[m].y);
+			g[2u*m] = (uint32_t)min(max(v0, 0), 64);
+			g[2u*m + 1u] = (uint32_t)min(max(v1, 0), 64);
+		}
+#pragma unroll
+		for (uint32_t m = 0; m < 4u; ++m) {
+			if (k + m < PW) {
+				if (k + m)
+					*reinterpret_cast<uint32_t*>(base + (k + m - 1u)*256u) = prev | (((prev >> 8) | (g[2u*m] << 8)) << 16);
+				prev = g[2u*m] | (g[2u*m + 1u] << 8);
+			}
+		}
+	}
+	reinterpret_cast<uint32_t*>(base + (PW - 1u)*256u)[0] = prev | ((prev >> 8) << 16);
+}
+
 // The weights of a refinement quad.  Every lane of the quad scatters ITS texels into ITS OWN column (the quad's four
 // columns are the four words of one 16-byte group of every row: `base` = the first of them), so the scatter, the
 // least-squares walk and the error walk touch one bank per lane like round 0 (sharing the result's column, the four
@@ -1985,6 +2021,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				const uint32_t hl = pair ? (lane & 31u) : lane;
 				const uint32_t g = hl & 31u, half = pair ? 0u : hl >> 5, step = pair ? 1u : 2u;
 				const bool gact = !(CF_ASTC_ABLATE & 4) && !solid && g < ngrids && hl < 32u + (pair ? 0u : 32u);
+				const bool ls_edec = !HDR && q >= 3u;        // (never a paired wave: can_pair)
 				uint8_t* gcol = wbase + (pair ? lane : g)*4u;
 				uint32_t PW = 0;
 				const uint2* inf = sh.infill + g*(astc_opq(n) | 1u);
@@ -1995,6 +2032,9 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 					if (half == 0u)
 						for (uint32_t k = 0; k <= PW; ++k)
 							*reinterpret_cast<uint32_t*>(gcol + k*256u) = 0u;
+					if (ls_edec && half == 1u)        // lane g + 32's own column: the second sum of the step below
+						for (uint32_t k = 0; k <= PW; ++k)
+							*reinterpret_cast<uint32_t*>(gcol + 128u + k*256u) = 0u;
 				}
 				__builtin_amdgcn_wave_barrier();
 				if (gact) {
@@ -2007,6 +2047,23 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				if (gact && half == 0u)
 					normalise_rows<false>(gcol, sh.den + g*astc_opq(H->den_stride), PW, nullptr);
 				__builtin_amdgcn_wave_barrier();
+				if (ls_edec) {
+					// High / Highest (one block per wave: lanes g and g + 32 share grid g, and lane g + 32's column is
+					// idle): the error ranked is that of the grid after one step towards least squares -- what the
+					// refinement rounds make of it -- g1 = 3 g0 - 2 A F g0 (oracle: grid_decimation_error, ls).  Both
+					// lanes infill every other texel from g0 and scatter it into the idle column; lane g forms g1.
+					if (gact) {
+#pragma unroll 2
+						for (uint32_t i = half; i < n; i += 2u) {
+							const uint2 rec = inf[i];
+							decim_add(gcol + 128u, rec.x, rec.y, infill_w(gcol, rec.x, rec.y));
+						}
+					}
+					__builtin_amdgcn_wave_barrier();
+					if (gact && half == 0u)
+						ls_rows(gcol, gcol + 128u, sh.den + g*astc_opq(H->den_stride), PW);
+					__builtin_amdgcn_wave_barrier();
+				}
 				uint32_t e = 0;
 				if (gact) {
 #pragma unroll 4
