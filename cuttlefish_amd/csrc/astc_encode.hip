@@ -2016,16 +2016,33 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				// a wave that holds one block has 64 lanes for at most 24 grids: lanes g and g + 32 share
 				// grid g -- each decimates every other texel into lane g's column (the scatter is atomic) and
 				// takes every other texel of the error walk; lane g alone turns the sums into averages
+				// From Normal up (LDR) the error ranked is that of the grid after one step towards least squares, which
+				// needs a second column per grid.  A PAIRED wave (Normal: two blocks, 32 lanes each) therefore walks its two
+				// blocks one after the other in the one-block form -- all 64 lanes on block hb, two lanes per grid, lane
+				// g + 32's column for the second sum: the texel walks halve per lane, so the two turns cost one more
+				// normalisation pass than the paired form did.
 				uint32_t lane;
 				asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-				const uint32_t hl = pair ? (lane & 31u) : lane;
-				const uint32_t g = hl & 31u, half = pair ? 0u : hl >> 5, step = pair ? 1u : 2u;
-				const bool gact = !(CF_ASTC_ABLATE & 4) && !solid && g < ngrids && hl < 32u + (pair ? 0u : 32u);
-				const bool ls_edec = !HDR && q >= 3u;        // (never a paired wave: can_pair)
-				uint8_t* gcol = wbase + (pair ? lane : g)*4u;
+				const bool ls_edec = !HDR && q >= 2u;
+				const bool split = pair && ls_edec, pm = pair && !split;        // pm: the paired form (Lowest / Low, HDR)
+				const unsigned long long sbal = __ballot(solid);
+#pragma unroll 1
+				for (uint32_t hb = 0; hb < (split ? 2u : 1u); ++hb) {
+				const uint32_t hl = pm ? (lane & 31u) : lane;
+				const uint32_t g = hl & 31u, half = pm ? 0u : hl >> 5, step = pm ? 1u : 2u;
+				const bool solid_b = split ? ((sbal >> (hb*32u)) & 1ull) != 0ull : solid;
+				const bool gact = !(CF_ASTC_ABLATE & 4) && !solid_b && g < ngrids && hl < 32u + (pm ? 0u : 32u);
+				uint8_t* gcol = wbase + (pm ? lane : g)*4u;
 				uint32_t PW = 0;
 				const uint2* inf = sh.infill + g*(astc_opq(n) | 1u);
-				const uint8_t* Trow = S.T;
+				// block hb's slot seen from any lane: the lane's own slot moved by (hb - h) slots -- formed at its uses
+				// from a fresh lane id (held across the stage it was four spilled registers in the 168-register build)
+				auto slot_shift = [&]() __attribute__((always_inline)) -> int {
+					uint32_t l2;
+					asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l2));
+					return split ? ((int)hb - (int)(l2 >> 5))*(int)slot_bytes : 0;
+				};
+#define ASTC_TROW (S.T + slot_shift())
 				if (gact) {
 					const uint32_t Rp = (uint32_t)sh.grid[g*4u + 1u]*(uint32_t)sh.grid[g*4u + 3u];
 					PW = (Rp + 1u) >> 1;
@@ -2038,17 +2055,17 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				}
 				__builtin_amdgcn_wave_barrier();
 				if (gact) {
-					if (pair)
-						decim_walk<1u>(gcol, inf, Trow, 0u, n);
+					if (pm)
+						decim_walk<1u>(gcol, inf, ASTC_TROW, 0u, n);
 					else
-						decim_walk<2u>(gcol, inf, Trow, half, n);
+						decim_walk<2u>(gcol, inf, ASTC_TROW, half, n);
 				}
 				__builtin_amdgcn_wave_barrier();
 				if (gact && half == 0u)
 					normalise_rows<false>(gcol, sh.den + g*astc_opq(H->den_stride), PW, nullptr);
 				__builtin_amdgcn_wave_barrier();
 				if (ls_edec) {
-					// High / Highest (one block per wave: lanes g and g + 32 share grid g, and lane g + 32's column is
+					// Normal and up (one block at a time: lanes g and g + 32 share grid g, and lane g + 32's column is
 					// idle): the error ranked is that of the grid after one step towards least squares -- what the
 					// refinement rounds make of it -- g1 = 3 g0 - 2 A F g0 (oracle: grid_decimation_error, ls).  Both
 					// lanes infill every other texel from g0 and scatter it into the idle column; lane g forms g1.
@@ -2066,18 +2083,21 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 				}
 				uint32_t e = 0;
 				if (gact) {
+					const uint8_t* Tr = ASTC_TROW;
 #pragma unroll 4
 					for (uint32_t i = half; i < n; i += step) {
 						const uint2 rec = inf[i];
-						const int dgt = (int)infill_w(gcol, rec.x, rec.y) - (int)Trow[i];
+						const int dgt = (int)infill_w(gcol, rec.x, rec.y) - (int)Tr[i];
 						e += (uint32_t)(dgt*dgt);
 					}
 				}
-				if (!pair)
+				if (!pm)
 					e += (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ^ 32u) << 2), (int)e);
 				if (gact && half == 0u)
-					S.edec[g] = e;
+					(S.edec + slot_shift()/4)[g] = e;
 				__builtin_amdgcn_wave_barrier();
+				}
+#undef ASTC_TROW
 			}
 
 			PROF_MARK(4)   // grids

@@ -426,12 +426,12 @@ static void phase_a(astc_blk* b, int j, const astc_pc* pc, int s)
 
 /* decimation error of candidate 0's ideal weights under grid g (lane = grid): unquantised grid
  * averages, infilled back, squared difference to the ideal weights.
- * ls (High and Highest, LDR; round 6): the error of the grid AFTER one step towards least squares -- what the
+ * ls (Normal and up, LDR; round 6): the error of the grid AFTER one step towards least squares -- what the
  * refinement rounds will make of it (phase_b) -- in the form that needs the averages and num(F g0) only,
  * g1 = 3 g0 - 2 A F g0 (within 0.02 dB of phase_b's form there; this one ranks, it does not encode).  The plain
  * error overrates what a coarse grid loses: ranked by this one, 6x6 High gains 0.05 / 0.16 dB on the two photograph
- * groups, 8x8 0.08 / 0.23 (a per-grid constant factor in its place: 0.01).  Normal and below keep the plain error:
- * two blocks share their wavefront there and the 24 grid lanes of a block have no idle column for the second sum. */
+ * groups, 8x8 0.08 / 0.23; Normal 0.12 / 0.23 and 0.16 / 0.25 (a per-grid constant factor in its place: 0.01).
+ * Lowest and Low keep the plain error: they have no refinement rounds, the plain means are what they encode. */
 static int grid_decimation_error(const astc_blk* b, int g, int ls)
 {
 	const astc_fmt* f = b->f;
@@ -2131,7 +2131,7 @@ static void encode_core(const int px[][4], const int lns[][4], int bw, int bh, i
 		}
 		if (pass == 0)
 			for (int g = 0; g < f->ngrids; ++g)
-				b->edec[g] = grid_decimation_error(b, g, q >= 3 && !b->hdr);
+				b->edec[g] = grid_decimation_error(b, g, q >= 2 && !b->hdr);
 		for (int j = 0; j < cnt; ++j) {
 			const astc_pc* pc = &pcs[base + j];
 			int order[ASTC_MAX_CFG];
