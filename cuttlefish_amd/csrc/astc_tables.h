@@ -304,8 +304,27 @@ inline std::vector<uint8_t> build_blob(int bw, int bh)
 	memset(cfgs.data(), 0, cfgs.size()*sizeof(AstcCfgRec));
 	uint8_t ncfg[16] = {0};
 	uint32_t col_rows = 0;
-	for (int cls = 0; cls < 5; ++cls)
-		for (int alpha = 0; alpha < 2; ++alpha) {
+	// The footprints of 60 texels and more (oracle: get_fmt, round 6) register first the finest grids -- the ones the
+	// first list takes in from place 48 on: a TRIAL build of that list (turn 0) says which made it -- then 4x4, 3x3 and
+	// 2x2 (a gradient block wants a coarse grid with many levels); turn 1 builds the lists for good.
+	for (int turn = n >= 60 ? 0 : 1; turn < 2; ++turn) {
+	if (turn == 1 && n >= 60) {
+		std::vector<std::pair<int, int>> fine;
+		for (int k = 48; k < (int)ncfg[0]; ++k)
+			if (cfgs[(size_t)k].ng >= 56)
+				fine.push_back({cfgs[(size_t)k].N, cfgs[(size_t)k].M});
+		grids.clear();
+		memset(cfgs.data(), 0, cfgs.size()*sizeof(AstcCfgRec));
+		memset(ncfg, 0, sizeof(ncfg));
+		col_rows = 0;
+		for (const auto& fg : fine)
+			grid_index(fg.first, fg.second);
+		grid_index(4, 4);
+		grid_index(3, 3);
+		grid_index(2, 2);
+	}
+	for (int cls = 0; cls < (turn == 0 ? 1 : 5); ++cls)
+		for (int alpha = 0; alpha < (turn == 0 ? 1 : 2); ++alpha) {
 			const int P = cls <= 1 ? 1 : cls;
 			const bool dual = cls == 1;
 			int nv0 = alpha ? 8 : 6;
@@ -392,6 +411,7 @@ inline std::vector<uint8_t> build_blob(int bw, int bh)
 			}
 			ncfg[cls*2 + alpha] = (uint8_t)k;
 		}
+	}
 
 	// partition tables
 	const uint32_t npad = (uint32_t)align16((size_t)n);

@@ -238,6 +238,27 @@ static const astc_fmt* get_fmt(int bw, int bh)
 	if (!g_fmt[idx]) {
 		astc_fmt* f = (astc_fmt*)calloc(1, sizeof(astc_fmt));
 		f->bw = bw; f->bh = bh; f->n = bw*bh; f->fp = idx;
+		/* Round 6: the footprints of 60 texels and more list 4x4, 3x3 and 2x2 whatever the config order asks for first.
+		 * Their 24 grids used to stop at 15 weights; a block that is a smooth gradient in two channels wants a coarse
+		 * grid with many weight levels and a second plane, and since the refinement rounds take the least-squares step
+		 * (phase_b) such a grid keeps its range: the held-out colour graphic +2.1 .. 2.9 dB at 8x8 .. 12x12 High, the
+		 * photographs -0.02 .. +0.03 (three grids of the middle of the list lose their places: at 8x8 4x5, 7x6 and 6x7).
+		 * (Before the step the same three grids were worth +0.6 dB on that picture and cost the photographs 0.12.) */
+		if (f->n >= 60) {
+			/* the finest grids first -- the ones the first list takes in from place ASTC_FINE_AT on (a trial build of
+			 * that list on a scratch table says which made it): a block of fine detail cannot do without them, and they
+			 * were the LAST grids registered (8x8: 8x8 and 8x7 were numbers 23 and 24) */
+			astc_fmt* t = (astc_fmt*)calloc(1, sizeof(astc_fmt));
+			t->bw = bw; t->bh = bh; t->n = bw*bh; t->fp = idx;
+			build_configs(t, 0, 0);
+			for (int k = ASTC_FINE_AT; k < t->ncfg[0][0]; ++k)
+				if (t->cfg[0][0][k].ng >= 56)
+					grid_index(f, t->cfg[0][0][k].N, t->cfg[0][0][k].M);
+			free(t);
+			grid_index(f, 4, 4);
+			grid_index(f, 3, 3);
+			grid_index(f, 2, 2);
+		}
 		for (int cls = 0; cls < 5; ++cls)
 			for (int a = 0; a < 2; ++a)
 				build_configs(f, cls, a);
