@@ -20,10 +20,13 @@
 //   stats     texels strided over the lanes: moments -> principal axis, k-means clusters
 //   shortlist lane = partition-table entry: popcount overlap with the clusters
 //   phase A   lane = (candidate, subset / plane): moments -> axis -> ideal endpoints, weights
-//   grids     lane = weight grid: decimation error of the ideal weights
+//   grids     lane = weight grid: decimation error of the ideal weights (from Normal up: after one
+//             step towards the least-squares grid, ls_rows)
 //   ranking   lane = config of the candidate's class: estimated error, K smallest
 //   phase B   lane = (candidate, config): decimate, quantise, least squares, endpoint mode and
-//             quantisation, EXACT error through the decode arithmetic
+//             quantisation, EXACT error through the decode arithmetic; then refinement rounds on the
+//             best results, a quad of lanes each: weights re-projected on the decoded endpoints and
+//             decimated with the least-squares step (quad_rows_average / quad_rows_step)
 //   argmin (error, id) over the lanes and the passes; the group packs the winner (ISE).
 // Data: the workgroup (4, 8 or 12 waves, cfhip_astc_plan) stages a strip of 4 blocks per wave, the footprint's infill / factor-sum tables
 // and the colour / weight quantisation tables in LDS; each lane owns an LDS column for its grid
