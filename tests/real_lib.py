@@ -81,3 +81,20 @@ def blocks(bw, bh, count=None, image=None, group="a"):
 def strip(blks):
     """(n, bh, bw, 4) blocks -> the (bh, n*bw, 4) image whose block row they are."""
     return np.ascontiguousarray(np.concatenate(list(blks), axis=1))
+
+
+def two_channel_gradients(bw, bh, nbx=6):
+    """one block row of bw x bh blocks, each a bilinear gradient whose red / blue run along x and whose green runs along
+    y (two independent weight fields: what a second weight plane on a coarse grid with many levels is for) -- the
+    content class the held-out colour graphic of group b consists of (round 6)"""
+    img = np.zeros((bh, bw*nbx, 4), np.uint8)
+    img[..., 3] = 255
+    yy, xx = np.mgrid[0:bh, 0:bw*nbx]
+    for k in range(nbx):
+        sl = slice(k*bw, (k + 1)*bw)
+        x = (xx[:, sl] - k*bw)/(bw - 1)
+        y = yy[:, sl]/(bh - 1)
+        img[:, sl, 0] = np.round(40 + 20*k + (30 + 5*k)*x)
+        img[:, sl, 1] = np.round(200 - 15*k - (25 + 3*k)*y)
+        img[:, sl, 2] = np.round(60 + (10 + 2*k)*x)
+    return img

@@ -22,6 +22,19 @@ def test_bit_exact_all_footprints(gpu_ctx, fmt):
     assert bad.size == 0, "blocks differ: %s" % bad[:10]
 
 
+@pytest.mark.parametrize("fmt", [Format.ASTC_6x6, Format.ASTC_8x8, Format.ASTC_10x6, Format.ASTC_10x10, Format.ASTC_12x12])
+@pytest.mark.parametrize("quality", [2, 3, 4])
+def test_bit_exact_two_channel_gradients(gpu_ctx, fmt, quality):
+    """round 6: the content the coarse grids and the least-squares step are for (tests/test_oracle_astc.py:
+    test_two_channel_gradients_take_a_coarse_dual_plane_grid) -- the kernel emits the oracle's bytes on it"""
+    import real_lib as R
+    bw, bh = {Format.ASTC_6x6: (6, 6), Format.ASTC_8x8: (8, 8), Format.ASTC_10x6: (10, 6), Format.ASTC_10x10: (10, 10),
+              Format.ASTC_12x12: (12, 12)}[fmt]
+    img = np.ascontiguousarray(np.tile(R.two_channel_gradients(bw, bh), (3, 1, 1)))
+    ref = O.encode(img, int(fmt), quality=quality, threads=8)
+    assert np.array_equal(ref, _gpu(gpu_ctx, img, fmt, quality))
+
+
 @pytest.mark.parametrize("quality", [0, 1, 3, 4])
 def test_bit_exact_quality_ladder_6x6(gpu_ctx, quality):
     img = synth.photo(66, 42, seed=90 + quality)
