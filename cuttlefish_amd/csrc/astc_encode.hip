@@ -2134,7 +2134,7 @@ cfhip_astc_encode_kernel(cf_kparams kp)
 						const AstcCfgRec c = list[k];
 						// (HDR: the decimation term counts 10, not 40, on the footprints of 25 .. 64 texels -- 40 .. 64 for
 						// blocks with alpha: oracle rank_configs)
-						const unsigned long long ka = HDR ? ((n >= (has_alpha ? 40u : 25u) && n <= 64u) ? 10ull : 40ull) : (n >= 60u ? 640ull : ((n >= 25u && n <= 36u && alpha_i == 0u) ? 80ull : 160ull));      // (oracle rank_configs: round 6, opaque 5x5 .. 6x6 blocks)
+						const unsigned long long ka = HDR ? ((n >= (has_alpha ? 40u : 25u) && n <= 64u) ? 10ull : 40ull) : (n >= 60u ? 320ull : ((n >= 25u && n <= 36u && alpha_i == 0u) ? 80ull : 160ull));      // (oracle rank_configs: round 6, opaque 5x5 .. 6x6 blocks)
 						const uint32_t kc = (!HDR && n >= 60u) ? 4u : 1u;      // (LDR footprints of 60 texels and more: oracle rank_configs)
 						const unsigned long long wn = (unsigned long long)S.edec[c.grid]*ka + (unsigned long long)(n*c.wq16);
 						const unsigned long long est = (((span2*wn) >> 12) + (unsigned long long)(n*nc)*c.cq16*kc) >> 8;

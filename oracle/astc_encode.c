@@ -522,7 +522,10 @@ static int rank_configs(const astc_blk* b, int j, const astc_pc* pc, int K, int*
 		 * 4x4 / 5x4 are indifferent (+-0.005) and keep 10; 8x5 .. 10x5 lose 0.02 .. 0.14 dB with 5 and keep 10; the footprints
 		 * of 60 texels and more lose with anything below their 40.  (The synthetic fixture images pay 0.01 .. 0.05 dB.)  Opaque
 		 * blocks only: on the alpha-carrying 6x6 blocks (rgba12 of the fixture) 5 loses 0.17 / 0.12 / 0.11 dB. */
-		const uint32_t ka = b->hdr ? ((b->n >= (b->has_alpha ? 40 : 25) && b->n <= 64) ? 10u : 40u) : (b->n >= 60 ? 640u : ((b->n >= 25 && b->n <= 36 && !b->has_alpha) ? 80u : 160u));
+		const uint32_t ka = b->hdr ? ((b->n >= (b->has_alpha ? 40 : 25) && b->n <= 64) ? 10u : 40u) : (b->n >= 60 ? 320u : ((b->n >= 25 && b->n <= 36 && !b->has_alpha) ? 80u : 160u));
+		/* (Round 6, footprints of 60 texels and more: 320, not 640, now that the error ranked is the one after the least-squares
+		 * step and the tables hold coarse grids: 8x8 +0.06 / +0.09 dB at Normal and +0.05 at High on the two photograph groups,
+		 * 10x6 / 10x8 / 10x10 / 12x10 +0.02 .. 0.10, 12x12 +-0.01; 160: no better; the smaller footprints are indifferent to theirs.) */
 		/* LDR footprints of 60 texels and more: decimation x 4 once more AND the colour noise x 4 (six kinds of
 		 * content, whole images, Normal: 8x8 +0.24 photo / +0.44 smooth / two-colour edges +6 dB, 10x6 +0.3 / +0.3 /
 		 * +5.5, 10x10 and 12x12 +0.15 .. 0.5; the footprints below lose on gradients with it) */
